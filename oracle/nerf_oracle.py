@@ -1,0 +1,223 @@
+"""CPU oracle for the NeRF volume-rendering hot path  --  TEST INFRASTRUCTURE ONLY.
+
+This file is a plain-PyTorch (CPU, fp32) *restatement* of the reference algorithm
+(zubair-irshad/articulated-object-nerf).  It is the checker, never the product: only ``tests/``,
+``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of ``bench.py`` may import it.  The product
+path (``articulated-object-nerf_amd``) never imports anything from ``oracle/`` and fails loudly when the
+HIP library is missing.
+
+Parity status: PINNED.  Every function below is checked against golden vectors produced by importing
+the real reference in the build container (``tests/golden/make_golden.py`` -> ``tests/golden/*.npz``;
+``tests/test_oracle_golden.py`` runs the comparison on CPU).  The reference ships no tests or golden
+vectors of its own, and one third-party function on the path
+(``kornia.create_meshgrid``, kornia==0.6.1, reference ``requirements.txt:3``) is absent from the image;
+its published semantics ((1,H,W,2), [...,0]=x=column index, [...,1]=y=row index, un-normalised) are
+restated in ``get_ray_directions`` and in the stub used to generate the goldens.
+
+Each function cites the reference file:line it follows (paths relative to the reference root).
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn.functional as F
+
+HALF_PI_F32 = torch.tensor(0.5 * math.pi, dtype=torch.float32)
+
+
+# --------------------------------------------------------------------------------------------------
+# R1 / R2  ray generation                                   datasets/ray_utils.py:71-90, 118-159
+# --------------------------------------------------------------------------------------------------
+def get_ray_directions(H: int, W: int, focal: float) -> torch.Tensor:
+    """datasets/ray_utils.py:71-90.  Camera-space direction per pixel, no +0.5 pixel centre:
+    ((i - W/2)/focal, -(j - H/2)/focal, -1), i = column, j = row.  (H,W,3) fp32."""
+    j = torch.arange(H, dtype=torch.float32)[:, None].expand(H, W)
+    i = torch.arange(W, dtype=torch.float32)[None, :].expand(H, W)
+    return torch.stack([(i - W / 2) / focal, -(j - H / 2) / focal, -torch.ones(H, W)], -1)
+
+
+def get_rays(directions: torch.Tensor, c2w: torch.Tensor):
+    """datasets/ray_utils.py:118-159 with output_view_dirs=True.  Returns (rays_o, viewdirs, rays_d),
+    each (H*W,3); the reference normalises ``rays_d`` in place through its ``viewdirs`` alias
+    (:146-147), so rays_d == viewdirs (unit norm).  ``radii`` (:138-143) is unused downstream and not
+    produced."""
+    rays_d = directions @ c2w[:, :3].T
+    rays_d = rays_d / torch.norm(rays_d, dim=-1, keepdim=True)
+    rays_o = c2w[:, 3].expand(rays_d.shape)
+    rays_d = rays_d.reshape(-1, 3)
+    return rays_o.reshape(-1, 3), rays_d, rays_d
+
+
+# --------------------------------------------------------------------------------------------------
+# R3  stratified sampling                                   models/vanilla_nerf/helper.py:25-26,106-133
+# --------------------------------------------------------------------------------------------------
+def cast_rays(t_vals, origins, directions):
+    """helper.py:25-26 (multiply then add, no fused multiply-add)."""
+    return origins[..., None, :] + t_vals[..., None] * directions[..., None, :]
+
+
+def sample_along_rays(rays_o, rays_d, num_samples, near, far, randomized, t_rand=None):
+    """helper.py:106-133 (lindisp=False branch).  ``t_rand`` (N, num_samples+1) replaces the
+    reference's ``torch.rand`` draw (:126) so randomized runs are reproducible."""
+    n = rays_o.shape[0]
+    s = torch.linspace(0.0, 1.0, num_samples + 1)
+    t_vals = near * (1.0 - s) + far * s
+    if randomized:
+        mids = 0.5 * (t_vals[1:] + t_vals[:-1])
+        upper = torch.cat([mids, t_vals[-1:]])
+        lower = torch.cat([t_vals[:1], mids])
+        t_vals = lower + (upper - lower) * t_rand
+    else:
+        t_vals = t_vals.expand(n, num_samples + 1)
+    return t_vals, cast_rays(t_vals, rays_o, rays_d)
+
+
+# --------------------------------------------------------------------------------------------------
+# R4  positional encoding                                   models/vanilla_nerf/helper.py:136-140
+# --------------------------------------------------------------------------------------------------
+def pos_enc(x, min_deg, max_deg):
+    """helper.py:136-140.  [x ; sin(2^l x) (scale-major, xyz-minor) ; sin(2^l x + fp32(pi/2))]."""
+    scales = torch.tensor([2.0 ** l for l in range(min_deg, max_deg)], dtype=x.dtype)
+    xb = (x[..., None, :] * scales[:, None]).reshape(*x.shape[:-1], -1)
+    return torch.cat([x, torch.sin(torch.cat([xb, xb + HALF_PI_F32], dim=-1))], dim=-1)
+
+
+# --------------------------------------------------------------------------------------------------
+# R5  vanilla NeRFMLP                                       models/vanilla_nerf/model.py:95-120
+# --------------------------------------------------------------------------------------------------
+def nerf_mlp(sd: dict, prefix: str, x_enc, view_enc, netdepth: int = 8, skip_layer: int = 4):
+    """model.py:95-120.  ``sd`` maps '<prefix>pts_linears.0.weight' ... to tensors in nn.Linear (out,in)
+    layout.  x_enc (N,S,63), view_enc (N,27) -> raw_rgb (N,S,3), raw_density (N,S,1)."""
+    n, s, feat = x_enc.shape
+    x = x_enc.reshape(-1, feat)
+    inputs = x
+    for idx in range(netdepth):
+        x = F.relu(F.linear(x, sd[f"{prefix}pts_linears.{idx}.weight"], sd[f"{prefix}pts_linears.{idx}.bias"]))
+        if idx % skip_layer == 0 and idx > 0:
+            x = torch.cat([x, inputs], dim=-1)
+    raw_density = F.linear(x, sd[f"{prefix}density_layer.weight"], sd[f"{prefix}density_layer.bias"]).reshape(n, s, 1)
+    bott = F.linear(x, sd[f"{prefix}bottleneck_layer.weight"], sd[f"{prefix}bottleneck_layer.bias"])
+    cond = view_enc[:, None, :].expand(n, s, view_enc.shape[-1]).reshape(-1, view_enc.shape[-1])
+    x = torch.cat([bott, cond], dim=-1)
+    x = F.relu(F.linear(x, sd[f"{prefix}views_linear.0.weight"], sd[f"{prefix}views_linear.0.bias"]))
+    raw_rgb = F.linear(x, sd[f"{prefix}rgb_layer.weight"], sd[f"{prefix}rgb_layer.bias"]).reshape(n, s, 3)
+    return raw_rgb, raw_density
+
+
+# --------------------------------------------------------------------------------------------------
+# R8  alpha compositing                                     models/vanilla_nerf/helper.py:157-195
+# --------------------------------------------------------------------------------------------------
+def volumetric_rendering(rgb, density, t_vals, dirs, white_bkgd):
+    """helper.py:157-195.  rgb (N,S,3), density (N,S,1) (already activated), t_vals (N,S), dirs (N,3)
+    -> comp_rgb (N,3), acc (N,), weights (N,S), depth (N,)."""
+    eps = 1e-10
+    dists = torch.cat([t_vals[..., 1:] - t_vals[..., :-1], torch.full_like(t_vals[..., :1], 1e10)], dim=-1)
+    dists = dists * torch.norm(dirs[..., None, :], dim=-1)
+    alpha = 1.0 - torch.exp(-density[..., 0] * dists)
+    trans = torch.cat([torch.ones_like(alpha[..., :1]), torch.cumprod(1.0 - alpha[..., :-1] + eps, dim=-1)], dim=-1)
+    weights = alpha * trans
+    comp_rgb = (weights[..., None] * rgb).sum(dim=-2)
+    depth = (weights * t_vals).sum(dim=-1)
+    depth = torch.nan_to_num(depth, float("inf"))          # helper.py:182 (NaN -> +inf)
+    depth = torch.clamp(depth, torch.min(depth), torch.max(depth))  # helper.py:183 (identity)
+    acc = weights.sum(dim=-1)
+    if white_bkgd:
+        comp_rgb = comp_rgb + (1.0 - acc[..., None])
+    return comp_rgb, acc, weights, depth
+
+
+# --------------------------------------------------------------------------------------------------
+# R6 / R7  hierarchical inverse-CDF sampling                models/vanilla_nerf/helper.py:203-252
+# --------------------------------------------------------------------------------------------------
+def deterministic_u(num_samples: int) -> torch.Tensor:
+    """helper.py:229: linspace(0, 1 - 2^-32, num_samples) in fp32 (the last element rounds to 1.0)."""
+    return torch.linspace(0.0, 1.0 - 2.0 ** -32, num_samples)
+
+
+def sorted_piecewise_constant_pdf(bins, weights, num_samples, randomized, u=None):
+    """helper.py:203-243 restated with a searchsorted instead of the (N,64,128) mask/max/min
+    broadcast: for every u the reference picks (bin0,cdf0) = entry at the last index with cdf <= u
+    and (bin1,cdf1) = entry at the first index with cdf > u (else the last entry).  ``u`` (N,num_samples)
+    replaces ``torch.rand`` (:227) when randomized."""
+    eps = 1e-5
+    weight_sum = weights.sum(dim=-1, keepdim=True)
+    padding = torch.fmax(torch.zeros_like(weight_sum), eps - weight_sum)
+    weights = weights + padding / weights.shape[-1]
+    weight_sum = weight_sum + padding
+    pdf = weights / weight_sum
+    cdf = torch.fmin(torch.ones_like(pdf[..., :-1]), torch.cumsum(pdf[..., :-1], dim=-1))
+    cdf = torch.cat([torch.zeros_like(cdf[..., :1]), cdf, torch.ones_like(cdf[..., :1])], dim=-1)
+    if not randomized:
+        u = deterministic_u(num_samples).expand(*cdf.shape[:-1], num_samples)
+    u = u.contiguous()
+    last = cdf.shape[-1] - 1
+    idx = torch.searchsorted(cdf.contiguous(), u, right=True)
+    i0 = (idx - 1).clamp(0, last)
+    i1 = idx.clamp(0, last)
+    cdf0, cdf1 = torch.gather(cdf, -1, i0), torch.gather(cdf, -1, i1)
+    bin0, bin1 = torch.gather(bins, -1, i0), torch.gather(bins, -1, i1)
+    t = torch.clip(torch.nan_to_num((u - cdf0) / (cdf1 - cdf0), 0), 0, 1)
+    return bin0 + t * (bin1 - bin0)
+
+
+def sample_pdf(bins, weights, origins, directions, t_vals, num_samples, randomized, u=None):
+    """helper.py:246-252: inverse-CDF draw, sort-merge with the coarse t's, cast."""
+    t_samples = sorted_piecewise_constant_pdf(bins, weights, num_samples, randomized, u)
+    t_vals = torch.sort(torch.cat([t_vals, t_samples], dim=-1), dim=-1).values
+    return t_vals, cast_rays(t_vals, origins, directions)
+
+
+# --------------------------------------------------------------------------------------------------
+# R9  NeRF.forward                                          models/vanilla_nerf/model.py:147-199
+# --------------------------------------------------------------------------------------------------
+def nerf_forward(sd, rays, randomized, white_bkgd, near, far, num_levels=2, min_deg_point=0,
+                 max_deg_point=10, deg_view=4, num_coarse_samples=64, num_fine_samples=128,
+                 t_rand=None, u=None, return_aux=False):
+    """model.py:147-199.  ``sd`` uses the reference's key names ('coarse_mlp.pts_linears.0.weight', ...).
+    Returns [(comp_rgb, acc, depth)_coarse, (comp_rgb, acc, depth)_fine]; with ``return_aux`` also a
+    dict of intermediates per level (t_vals, raw_rgb, raw_sigma, weights)."""
+    ret, aux = [], []
+    t_vals = weights = None
+    for i_level in range(num_levels):
+        if i_level == 0:
+            t_vals, samples = sample_along_rays(rays["rays_o"], rays["rays_d"], num_coarse_samples, near, far,
+                                                randomized, t_rand)
+            prefix = "coarse_mlp."
+        else:
+            t_mids = 0.5 * (t_vals[..., 1:] + t_vals[..., :-1])
+            t_vals, samples = sample_pdf(t_mids, weights[..., 1:-1], rays["rays_o"], rays["rays_d"], t_vals,
+                                         num_fine_samples, randomized, u)
+            prefix = "fine_mlp."
+        samples_enc = pos_enc(samples, min_deg_point, max_deg_point)
+        viewdirs_enc = pos_enc(rays["viewdirs"], 0, deg_view)
+        raw_rgb, raw_sigma = nerf_mlp(sd, prefix, samples_enc, viewdirs_enc)
+        rgb = torch.sigmoid(raw_rgb)
+        sigma = F.relu(raw_sigma)
+        comp_rgb, acc, weights, depth = volumetric_rendering(rgb, sigma, t_vals, rays["rays_d"], white_bkgd)
+        ret.append((comp_rgb, acc, depth))
+        aux.append({"t_vals": t_vals, "raw_rgb": raw_rgb, "raw_sigma": raw_sigma, "weights": weights})
+    return (ret, aux) if return_aux else ret
+
+
+# --------------------------------------------------------------------------------------------------
+# R13  losses / metrics                   helper.py:17-22, models/interface.py:54-74
+# --------------------------------------------------------------------------------------------------
+def img2mse(x, y):
+    return torch.mean((x - y) ** 2)
+
+
+def mse2psnr(x):
+    return -10.0 * torch.log(x) / math.log(10.0)
+
+
+def psnr_legacy(pred, gt):
+    return -10.0 * torch.log10(torch.mean((pred - gt) ** 2))
+
+
+def psnr_each(preds, gts):
+    out = []
+    for p, g in zip(preds, gts):
+        mse = torch.mean((torch.clip(p, 0, 1) - torch.clip(g, 0, 1)) ** 2)
+        out.append(-10.0 * torch.log(mse) / math.log(10.0))
+    return torch.stack(out)

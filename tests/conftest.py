@@ -1,0 +1,37 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_golden(name):
+    z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+    out = {}
+    for k in z.files:
+        a = z[k]
+        out[k] = torch.from_numpy(a) if a.ndim > 0 else a.item()
+    return out
+
+
+@pytest.fixture(scope="session")
+def golden():
+    return load_golden
+
+
+@pytest.fixture(scope="session")
+def nerf_sd():
+    import aon_amd.synthetic as syn
+
+    return syn.make_nerf_state_dict(seed=0, density_scale=30.0)

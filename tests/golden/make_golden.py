@@ -1,0 +1,262 @@
+"""Generate the golden fixtures under tests/golden/ by importing the REAL reference.
+
+Runs only in the build container (needs /root/reference, which does not exist on the GPU box):
+
+    python tests/golden/make_golden.py
+
+The reference is imported from where it lies (nothing is copied); the third-party packages it imports
+but that are absent from this image and never touch the arithmetic (pytorch_lightning, wandb, cv2,
+torchvision, imageio, piqa, torch_optimizer, numba, kornia) are replaced by inert stub modules.  The one
+stub that carries arithmetic is ``kornia.create_meshgrid`` (kornia==0.6.1): its published semantics are
+restated below (un-normalised pixel grid, (1,H,W,2), [...,0] = x = column, [...,1] = y = row).
+
+Only DATA is written: inputs and the reference's outputs, as .npz.  Network weights are not stored;
+they are rebuilt from ``aon_amd.synthetic.make_nerf_state_dict(seed)`` (numpy PCG64, platform-stable).
+"""
+import contextlib
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+
+
+def _install_stubs():
+    class _Anything:
+        def __init__(self, *a, **k):
+            pass
+
+        def __call__(self, *a, **k):
+            return self
+
+        def __getattr__(self, k):
+            return _Anything()
+
+    class _StubModule(types.ModuleType):
+        def __getattr__(self, k):  # any other attribute the reference imports by name
+            if k.startswith("__"):
+                raise AttributeError(k)
+            return _Anything()
+
+    def mod(name, **attrs):
+        m = _StubModule(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    mod("pytorch_lightning", LightningModule=torch.nn.Module, Trainer=_Anything, seed_everything=lambda *a, **k: None)
+    mod("wandb", Image=_Anything, log=lambda *a, **k: None)
+    mod("cv2")
+    mod("imageio")
+    mod("torch_optimizer")
+    mod("numba", jit=lambda *a, **k: (lambda f: f))
+    tv = mod("torchvision")
+    tv.transforms = mod("torchvision.transforms", ToTensor=_Anything, Compose=_Anything, Resize=_Anything,
+                        Normalize=_Anything)
+    tv.utils = mod("torchvision.utils", make_grid=_Anything, save_image=_Anything)
+    tv.ops = mod("torchvision.ops")
+    tv.models = mod("torchvision.models")
+    pq = mod("piqa")
+    pq.lpips = mod("piqa.lpips", LPIPS=_Anything)
+    pq.ssim = mod("piqa.ssim", SSIM=_Anything)
+
+    def create_meshgrid(height, width, normalized_coordinates=True, device=None, dtype=torch.float32):
+        # kornia==0.6.1 kornia/utils/grid.py: xs = linspace(0, W-1, W), ys = linspace(0, H-1, H);
+        # grid = stack(meshgrid([xs, ys]) ).transpose -> (1, H, W, 2) with [...,0]=x, [...,1]=y.
+        assert not normalized_coordinates
+        xs = torch.linspace(0, width - 1, width, device=device, dtype=dtype)
+        ys = torch.linspace(0, height - 1, height, device=device, dtype=dtype)
+        gx, gy = torch.meshgrid(xs, ys, indexing="ij")  # (W,H)
+        return torch.stack([gx, gy], dim=-1).permute(1, 0, 2).unsqueeze(0)
+
+    mod("kornia", create_meshgrid=create_meshgrid)
+
+
+@contextlib.contextmanager
+def patched_rand(values):
+    """Make ``torch.rand`` return the supplied tensors in order (the reference draws t_rand at
+    helper.py:126 and u at helper.py:227)."""
+    queue = list(values)
+    orig = torch.rand
+
+    def fake(*size, **kw):
+        v = queue.pop(0)
+        want = tuple(size[0]) if len(size) == 1 and not isinstance(size[0], int) else tuple(size)
+        assert tuple(v.shape) == want, (v.shape, want)
+        return v.clone()
+
+    torch.rand = fake
+    try:
+        yield
+    finally:
+        torch.rand = orig
+
+
+def save(name, **arrays):
+    out = {}
+    for k, v in arrays.items():
+        out[k] = v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"{name}.npz  {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+def main():
+    _install_stubs()
+    sys.path.insert(0, REF)
+    os.chdir(REF)  # code_library does sys.path.append('./') + `from opt import get_opts`
+    import models.vanilla_nerf.helper as helper
+    from models.vanilla_nerf.model import NeRF
+    from datasets.ray_utils import get_ray_directions, get_rays
+    from models.interface import LitModel
+
+    import aon_amd.synthetic as syn
+
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    g = torch.Generator().manual_seed(1234)
+
+    # ---------------- G1 raygen ----------------
+    poses = [syn.look_at_pose(4.0, az, el) for az, el in [(30, 30), (200, -30), (91, 5)]]
+    H, W = 8, 12
+    focal_small = syn.focal_from_fovy(H)
+    o_all, v_all, d_all = [], [], []
+    for c2w in poses:
+        dirs = get_ray_directions(H, W, focal_small)
+        ro, vd, rd, _rad = get_rays(dirs, c2w, output_view_dirs=True, output_radii=True)
+        o_all.append(ro.clone()); v_all.append(vd.clone()); d_all.append(rd.clone())
+    Hf, Wf = 480, 640
+    focal_full = syn.focal_from_fovy(Hf)
+    dirs_f = get_ray_directions(Hf, Wf, focal_full)
+    ro, vd, rd, _ = get_rays(dirs_f, poses[0], True, True)
+    pick = torch.tensor([0, 1, 639, 640, 153_600, 307_199, 12_345, 200_001])
+    save("g1_raygen", H=H, W=W, focal=focal_small, c2w=torch.stack(poses), directions=get_ray_directions(H, W, focal_small),
+         rays_o=torch.stack(o_all), viewdirs=torch.stack(v_all), rays_d=torch.stack(d_all),
+         full_H=Hf, full_W=Wf, full_focal=focal_full, full_pick=pick, full_viewdirs_pick=vd[pick],
+         full_rays_o_pick=ro[pick], full_viewdirs_sum=vd.double().sum(0), full_viewdirs_abs_sum=vd.double().abs().sum(0))
+
+    # ---------------- G2 sample_along_rays ----------------
+    rays = syn.random_rays(64, seed=2)
+    t_det, c_det = helper.sample_along_rays(rays["rays_o"], rays["rays_d"], 64, 2.0, 6.0, False, False)
+    t_rand = torch.rand((64, 65), generator=g)
+    with patched_rand([t_rand]):
+        t_rnd, c_rnd = helper.sample_along_rays(rays["rays_o"], rays["rays_d"], 64, 2.0, 6.0, True, False)
+    save("g2_sample_along_rays", rays_o=rays["rays_o"], rays_d=rays["rays_d"], near=2.0, far=6.0,
+         t_det=t_det.contiguous(), coords_det=c_det, t_rand=t_rand, t_rnd=t_rnd, coords_rnd=c_rnd)
+
+    # ---------------- G3 pos_enc ----------------
+    x = (torch.rand((256, 3), generator=g) * 12.0 - 6.0)
+    x[:8] = torch.tensor([[5.9, -5.9, 0.0], [1e-3, -1e-3, 6.0], [-6.0, 6.0, -6.0], [3.14159, 1.5708, -0.7854],
+                          [5.859375, -2.9296875, 4.0], [0.1, 0.2, 0.3], [-0.0, 0.0, 1.0], [2.0, -4.0, 5.5]])
+    v = torch.nn.functional.normalize(torch.randn((64, 3), generator=g), dim=-1)
+    save("g3_pos_enc", x=x, enc10=helper.pos_enc(x, 0, 10), v=v, enc4=helper.pos_enc(v, 0, 4))
+
+    # ---------------- reference model with synthetic weights ----------------
+    sd = syn.make_nerf_state_dict(seed=0, density_scale=30.0)
+    model = NeRF()
+    missing = model.load_state_dict(sd, strict=True)
+    model.eval()
+
+    # ---------------- G4 NeRFMLP ----------------
+    rays4 = syn.random_rays(8, seed=4)
+    with torch.no_grad():
+        t4, c4 = helper.sample_along_rays(rays4["rays_o"], rays4["rays_d"], 64, 2.0, 6.0, False, False)
+        enc4 = helper.pos_enc(c4, 0, 10)
+        venc4 = helper.pos_enc(rays4["viewdirs"], 0, 4)
+        rgb_c, sig_c = model.coarse_mlp(enc4, venc4)
+        rgb_f, sig_f = model.fine_mlp(enc4, venc4)
+    save("g4_mlp", seed=0, density_scale=30.0, rays_o=rays4["rays_o"], rays_d=rays4["rays_d"], t_vals=t4.contiguous(),
+         samples_enc=enc4, viewdirs_enc=venc4, raw_rgb_coarse=rgb_c, raw_sigma_coarse=sig_c,
+         raw_rgb_fine=rgb_f, raw_sigma_fine=sig_f)
+
+    # ---------------- G5 volumetric_rendering ----------------
+    n5, s5 = 48, 65
+    rgb5 = torch.rand((n5, s5, 3), generator=g)
+    sig5 = torch.relu(torch.randn((n5, s5, 1), generator=g) * 8.0)
+    sig5[0] = 0.0                      # fully empty ray
+    sig5[1] = 1e4                      # opaque from the first sample
+    sig5[2] = 0.0; sig5[2, 20] = 50.0  # single spike
+    sig5[3] = 0.0; sig5[3, -1] = 1e-3  # only the far (1e10-long) interval is occupied
+    sig5[4] = 1e-12                    # denormal-ish density
+    t5 = torch.sort(torch.rand((n5, s5), generator=g) * 4.0 + 2.0, dim=-1).values
+    t5[5] = t5[5, :1]                  # all-equal t (zero-length intervals)
+    d5 = torch.nn.functional.normalize(torch.randn((n5, 3), generator=g), dim=-1)
+    d5[6] *= 1.7                       # non-unit direction exercises the norm factor
+    outs = {}
+    for wb in (False, True):
+        cr, acc, w, dep = helper.volumetric_rendering(rgb5, sig5, t5, d5, white_bkgd=wb)
+        outs[f"comp_rgb_wb{int(wb)}"] = cr; outs[f"acc_wb{int(wb)}"] = acc
+        outs[f"weights_wb{int(wb)}"] = w; outs[f"depth_wb{int(wb)}"] = dep
+    save("g5_volumetric_rendering", rgb=rgb5, density=sig5, t_vals=t5, dirs=d5, **outs)
+    # 193-sample variant (fine level)
+    s5f = 193
+    rgb5f = torch.rand((16, s5f, 3), generator=g)
+    sig5f = torch.relu(torch.randn((16, s5f, 1), generator=g) * 20.0)
+    t5f = torch.sort(torch.rand((16, s5f), generator=g) * 4.0 + 2.0, dim=-1).values
+    d5f = torch.nn.functional.normalize(torch.randn((16, 3), generator=g), dim=-1)
+    cr, acc, w, dep = helper.volumetric_rendering(rgb5f, sig5f, t5f, d5f, white_bkgd=True)
+    save("g5b_volumetric_rendering_193", rgb=rgb5f, density=sig5f, t_vals=t5f, dirs=d5f, comp_rgb=cr, acc=acc,
+         weights=w, depth=dep)
+
+    # ---------------- G6 sorted_piecewise_constant_pdf ----------------
+    n6 = 64
+    bins6 = torch.sort(torch.rand((n6, 64), generator=g) * 4.0 + 2.0, dim=-1).values
+    w6 = torch.rand((n6, 63), generator=g) ** 8
+    w6[0] = 0.0                       # all-zero weights -> uniform pdf through the padding branch
+    w6[1] = 0.0; w6[1, 30] = 1.0      # single bin
+    w6[2, 10:40] = 0.0                # flat CDF zone
+    w6[3] = 1e-9                      # sum below eps
+    w6[4] = 0.0; w6[4, 0] = 0.5; w6[4, -1] = 0.5
+    s_det = helper.sorted_piecewise_constant_pdf(bins6, w6, 128, False)
+    u6 = torch.rand((n6, 128), generator=g)
+    u6[5, :4] = torch.tensor([0.0, 1.0 - 2.0 ** -24, 0.5, 1e-8])
+    with patched_rand([u6]):
+        s_rnd = helper.sorted_piecewise_constant_pdf(bins6, w6, 128, True)
+    save("g6_pdf", bins=bins6, weights=w6, u=u6, samples_det=s_det, samples_rnd=s_rnd)
+
+    # ---------------- G7 sample_pdf (merge + cast) ----------------
+    rays7 = syn.random_rays(n6, seed=7)
+    t7 = torch.sort(torch.rand((n6, 65), generator=g) * 4.0 + 2.0, dim=-1).values
+    mids7 = 0.5 * (t7[..., 1:] + t7[..., :-1])
+    tf_det, cf_det = helper.sample_pdf(mids7, w6, rays7["rays_o"], rays7["rays_d"], t7, 128, False)
+    with patched_rand([u6]):
+        tf_rnd, cf_rnd = helper.sample_pdf(mids7, w6, rays7["rays_o"], rays7["rays_d"], t7, 128, True)
+    save("g7_sample_pdf", rays_o=rays7["rays_o"], rays_d=rays7["rays_d"], t_vals=t7, weights=w6, u=u6,
+         t_fine_det=tf_det, coords_det=cf_det, t_fine_rnd=tf_rnd, coords_rnd=cf_rnd)
+
+    # ---------------- G8 end-to-end NeRF.forward ----------------
+    n8 = 192
+    frame = syn.make_rays(24, 32, syn.look_at_pose(4.0, 30, 30), syn.focal_from_fovy(24))
+    sel = torch.arange(0, 24 * 32, 4)[:n8]
+    rays8 = {k: v[sel].contiguous() for k, v in frame.items()}
+    with torch.no_grad():
+        out_det = model(rays8, False, True, 2.0, 6.0)
+        out_det_nowb = model(rays8, False, False, 2.0, 6.0)
+        t_rand8 = torch.rand((n8, 65), generator=g)
+        u8 = torch.rand((n8, 128), generator=g)
+        with patched_rand([t_rand8, u8]):
+            out_rnd = model(rays8, True, True, 2.0, 6.0)
+    arrs = dict(seed=0, density_scale=30.0, near=2.0, far=6.0, t_rand=t_rand8, u=u8, **rays8)
+    for tag, out in (("det", out_det), ("det_nowb", out_det_nowb), ("rnd", out_rnd)):
+        for lvl, name in ((0, "coarse"), (1, "fine")):
+            arrs[f"{tag}_{name}_rgb"] = out[lvl][0]
+            arrs[f"{tag}_{name}_acc"] = out[lvl][1]
+            arrs[f"{tag}_{name}_depth"] = out[lvl][2]
+    save("g8_nerf_forward", **arrs)
+
+    # ---------------- G13 metrics ----------------
+    a = torch.rand((5, 16, 16, 3), generator=g) * 1.2 - 0.1
+    b = torch.rand((5, 16, 16, 3), generator=g)
+    lm = LitModel()
+    save("g13_metrics", a=a, b=b, mse=helper.img2mse(a, b), mse2psnr=helper.mse2psnr(helper.img2mse(a, b)),
+         psnr_legacy=lm.psnr_legacy(a, b), psnr_each=lm.psnr_each(list(a), list(b)))
+
+
+if __name__ == "__main__":
+    main()

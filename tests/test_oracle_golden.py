@@ -1,0 +1,98 @@
+"""CPU: the oracle (oracle/nerf_oracle.py) against the golden vectors generated from the imported
+reference (tests/golden/make_golden.py).  This is what pins the oracle."""
+import torch
+
+from oracle import nerf_oracle as orc
+
+
+def test_g1_raygen(golden):
+    g = golden("g1_raygen")
+    dirs = orc.get_ray_directions(g["H"], g["W"], g["focal"])
+    assert torch.equal(dirs, g["directions"])
+    for p in range(g["c2w"].shape[0]):
+        ro, vd, rd = orc.get_rays(dirs, g["c2w"][p])
+        assert torch.equal(ro, g["rays_o"][p])
+        torch.testing.assert_close(vd, g["viewdirs"][p], rtol=0, atol=1e-7)
+        torch.testing.assert_close(rd, g["rays_d"][p], rtol=0, atol=1e-7)
+    # full 480x640 frame: picked pixels + checksums
+    dirs = orc.get_ray_directions(g["full_H"], g["full_W"], g["full_focal"])
+    ro, vd, _ = orc.get_rays(dirs, g["c2w"][0])
+    torch.testing.assert_close(vd[g["full_pick"]], g["full_viewdirs_pick"], rtol=0, atol=1e-7)
+    assert torch.equal(ro[g["full_pick"]], g["full_rays_o_pick"])
+    torch.testing.assert_close(vd.double().sum(0), g["full_viewdirs_sum"], rtol=0, atol=1e-3)
+    torch.testing.assert_close(vd.double().abs().sum(0), g["full_viewdirs_abs_sum"], rtol=0, atol=1e-3)
+
+
+def test_g2_sample_along_rays(golden):
+    g = golden("g2_sample_along_rays")
+    t, c = orc.sample_along_rays(g["rays_o"], g["rays_d"], 64, g["near"], g["far"], False)
+    assert torch.equal(t, g["t_det"]) and torch.equal(c, g["coords_det"])
+    t, c = orc.sample_along_rays(g["rays_o"], g["rays_d"], 64, g["near"], g["far"], True, g["t_rand"])
+    assert torch.equal(t, g["t_rnd"]) and torch.equal(c, g["coords_rnd"])
+
+
+def test_g3_pos_enc(golden):
+    g = golden("g3_pos_enc")
+    assert torch.equal(orc.pos_enc(g["x"], 0, 10), g["enc10"])
+    assert torch.equal(orc.pos_enc(g["v"], 0, 4), g["enc4"])
+
+
+def test_g4_mlp(golden, nerf_sd):
+    g = golden("g4_mlp")
+    for lvl in ("coarse", "fine"):
+        rgb, sig = orc.nerf_mlp(nerf_sd, f"{lvl}_mlp.", g["samples_enc"], g["viewdirs_enc"])
+        torch.testing.assert_close(rgb, g[f"raw_rgb_{lvl}"], rtol=1e-5, atol=1e-5)
+        torch.testing.assert_close(sig, g[f"raw_sigma_{lvl}"], rtol=1e-5, atol=1e-4)
+
+
+def test_g5_volumetric_rendering(golden):
+    g = golden("g5_volumetric_rendering")
+    for wb in (0, 1):
+        cr, acc, w, dep = orc.volumetric_rendering(g["rgb"], g["density"], g["t_vals"], g["dirs"], bool(wb))
+        assert torch.equal(cr, g[f"comp_rgb_wb{wb}"])
+        assert torch.equal(acc, g[f"acc_wb{wb}"])
+        assert torch.equal(w, g[f"weights_wb{wb}"])
+        assert torch.equal(dep, g[f"depth_wb{wb}"])
+    g = golden("g5b_volumetric_rendering_193")
+    cr, acc, w, dep = orc.volumetric_rendering(g["rgb"], g["density"], g["t_vals"], g["dirs"], True)
+    assert torch.equal(cr, g["comp_rgb"]) and torch.equal(acc, g["acc"])
+    assert torch.equal(w, g["weights"]) and torch.equal(dep, g["depth"])
+
+
+def test_g6_pdf(golden):
+    g = golden("g6_pdf")
+    s = orc.sorted_piecewise_constant_pdf(g["bins"], g["weights"], 128, False)
+    assert torch.equal(s, g["samples_det"])
+    s = orc.sorted_piecewise_constant_pdf(g["bins"], g["weights"], 128, True, g["u"])
+    assert torch.equal(s, g["samples_rnd"])
+
+
+def test_g7_sample_pdf(golden):
+    g = golden("g7_sample_pdf")
+    mids = 0.5 * (g["t_vals"][..., 1:] + g["t_vals"][..., :-1])
+    t, c = orc.sample_pdf(mids, g["weights"], g["rays_o"], g["rays_d"], g["t_vals"], 128, False)
+    assert torch.equal(t, g["t_fine_det"]) and torch.equal(c, g["coords_det"])
+    t, c = orc.sample_pdf(mids, g["weights"], g["rays_o"], g["rays_d"], g["t_vals"], 128, True, g["u"])
+    assert torch.equal(t, g["t_fine_rnd"]) and torch.equal(c, g["coords_rnd"])
+
+
+def test_g8_nerf_forward(golden, nerf_sd):
+    g = golden("g8_nerf_forward")
+    rays = {k: g[k] for k in ("rays_o", "rays_d", "viewdirs")}
+    for tag, kw in (("det", dict(randomized=False, white_bkgd=True)),
+                    ("det_nowb", dict(randomized=False, white_bkgd=False)),
+                    ("rnd", dict(randomized=True, white_bkgd=True, t_rand=g["t_rand"], u=g["u"]))):
+        out = orc.nerf_forward(nerf_sd, rays, near=g["near"], far=g["far"], **kw)
+        for lvl, name in ((0, "coarse"), (1, "fine")):
+            # same op sequence on the same CPU kernels: expect (near) bit equality
+            torch.testing.assert_close(out[lvl][0], g[f"{tag}_{name}_rgb"], rtol=0, atol=2e-6)
+            torch.testing.assert_close(out[lvl][1], g[f"{tag}_{name}_acc"], rtol=0, atol=2e-6)
+            torch.testing.assert_close(out[lvl][2], g[f"{tag}_{name}_depth"], rtol=0, atol=2e-5)
+
+
+def test_g13_metrics(golden):
+    g = golden("g13_metrics")
+    torch.testing.assert_close(orc.img2mse(g["a"], g["b"]), torch.as_tensor(g["mse"]))
+    torch.testing.assert_close(orc.mse2psnr(orc.img2mse(g["a"], g["b"])), torch.as_tensor(g["mse2psnr"]))
+    torch.testing.assert_close(orc.psnr_legacy(g["a"], g["b"]), torch.as_tensor(g["psnr_legacy"]))
+    torch.testing.assert_close(orc.psnr_each(list(g["a"]), list(g["b"])), g["psnr_each"])
