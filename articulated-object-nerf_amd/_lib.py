@@ -1,0 +1,64 @@
+"""ctypes binding of libaon_hip.so (C ABI declared in include/aon_hip.h).
+
+There is NO fallback: if the shared library is missing or fails to load, importing this module raises, and so
+does every op built on it.  Build it with ``python articulated-object-nerf_amd/build.py`` (hipcc, gfx950).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libaon_hip.so")
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} not found: the HIP kernels are the product path and there is no CPU/eager fallback. "
+        "Build them with `python articulated-object-nerf_amd/build.py` (needs /opt/rocm/bin/hipcc)."
+    )
+
+lib = C.CDLL(LIB_PATH)
+
+_p, _i, _l, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
+_SIGS = {
+    "aon_abi_version": (_i, []),
+    "aon_last_error": (C.c_char_p, []),
+    "aon_raygen": (_i, [_p, _i, _i, _f, _l, _l, _p, _p, _p, _p]),
+    "aon_ray_directions": (_i, [_i, _i, _f, _p, _p]),
+    "aon_get_rays": (_i, [_p, _p, _l, _p, _p, _p, _p]),
+    "aon_cast_rays": (_i, [_p, _p, _p, _l, _i, _p, _p]),
+    "aon_sample_along_rays": (_i, [_p, _p, _l, _i, _f, _f, _p, _p, _p, _p]),
+    "aon_pos_enc": (_i, [_p, _l, _i, _i, _p, _p]),
+    "aon_mlp_packed_bytes": (_l, []),
+    "aon_pack_vanilla_mlp": (_i, [_p, _p, _p]),
+    "aon_mlp_fwd": (_i, [_p, _p, _p, _p, _p, _l, _i, _p, _p]),
+    "aon_mlp_fwd_enc": (_i, [_p, _p, _p, _l, _i, _p, _p]),
+    "aon_composite": (_i, [_p, _i, _p, _i, _p, _p, _l, _i, _i, _i, _p, _p, _p, _p, _p]),
+    "aon_sample_pdf": (_i, [_p, _p, _l, _p, _p, _l, _l, _p, _p, _p]),
+    "aon_profile_begin": (_i, []),
+    "aon_profile_end": (_i, [C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "aon_render_workspace_bytes": (_l, [_l]),
+    "aon_render_fwd": (_i, [_p, _p, _p, _p, _p, _l, _f, _f, _i, _i, _p, _p, _l, _p, _p, _p, _p, _p, _p, _p, _l, _p]),
+}
+for _name, (_res, _args) in _SIGS.items():
+    _fn = getattr(lib, _name)  # AttributeError here = the .so does not export what the header declares
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+ABI_VERSION = 1
+if lib.aon_abi_version() != ABI_VERSION:
+    raise ImportError(f"libaon_hip.so ABI {lib.aon_abi_version()} != binding ABI {ABI_VERSION}; rebuild")
+
+
+class AonError(RuntimeError):
+    pass
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = lib.aon_last_error().decode("utf-8", "replace")
+        raise AonError(f"{what or 'libaon_hip'} failed (code {rc}): {msg}")
+
+
+def exported_symbols():
+    return sorted(_SIGS)

@@ -1,0 +1,296 @@
+// extern "C" surface of libaon_hip.so (declared in include/aon_hip.h) and the whole-path orchestration.
+#include "../../include/aon_hip.h"
+#include "aon_common.h"
+
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+namespace aon {
+hipError_t launch_pack_vanilla(const float* const* params, float* packed, hipStream_t stream);
+hipError_t launch_mlp_fwd(const char* packed, const float* rays_o, const float* rays_d, const float* viewdirs,
+                          const float* t_vals, int64_t n_rays, int S, float* raw, hipStream_t stream);
+hipError_t launch_mlp_fwd_enc(const char* packed, const float* samples_enc, const float* viewdirs_enc, int64_t n_rays,
+                              int S, float* raw, hipStream_t stream);
+hipError_t launch_raygen(const float* c2w, int H, int W, float focal, const float* directions, int64_t pix_begin,
+                         int64_t pix_end, float* rays_o, float* viewdirs, float* rays_d, hipStream_t stream);
+hipError_t launch_ray_directions(int H, int W, float focal, float* out, hipStream_t stream);
+hipError_t launch_cast_rays(const float* t_vals, const float* o, const float* d, int64_t n_rays, int S, float* coords,
+                            hipStream_t stream);
+hipError_t launch_sample_along_rays(const float* rays_o, const float* rays_d, int64_t n_rays, int S, float near, float far,
+                                    const float* t_rand, float* t_vals, float* coords, hipStream_t stream);
+hipError_t launch_pos_enc(const float* x, int64_t n, int min_deg, int max_deg, float* out, hipStream_t stream);
+hipError_t launch_composite(const float* rgb, int rgb_stride, const float* sigma, int sigma_stride, const float* t_vals,
+                            const float* dirs, int64_t n_rays, int S, int white_bkgd, int act, float* comp_rgb, float* acc,
+                            float* depth, float* weights, hipStream_t stream);
+hipError_t launch_sample_pdf(const float* bins, const float* weights, int64_t w_stride, const float* t_coarse,
+                             const float* u, int64_t u_stride, int64_t n_rays, float* samples, float* t_fine,
+                             hipStream_t stream);
+}  // namespace aon
+
+namespace {
+
+thread_local char g_err[256] = "";
+
+int fail(int code, const char* msg) {
+  std::snprintf(g_err, sizeof(g_err), "%s", msg);
+  return code;
+}
+
+int check(hipError_t e, const char* where) {
+  if (e == hipSuccess) return AON_OK;
+  std::snprintf(g_err, sizeof(g_err), "%s: %s", where, hipGetErrorString(e));
+  return AON_E_HIP_BASE - (int)e;
+}
+
+constexpr int kSc = 65, kSf = 193;
+
+// Optional live timing of the dominant kernel (the fused MLP) with HIP events on the launch stream.
+struct Profiler {
+  std::mutex mu;
+  bool on = false;
+  std::vector<hipEvent_t> pool;  // pairs (start, stop)
+  size_t used = 0;
+  int64_t samples = 0;
+} g_prof;
+
+struct MlpTimer {
+  hipEvent_t stop = nullptr;
+  hipStream_t stream;
+  MlpTimer(hipStream_t s, int64_t samples) : stream(s) {
+    std::lock_guard<std::mutex> lk(g_prof.mu);
+    if (!g_prof.on) return;
+    if (g_prof.used + 2 > g_prof.pool.size()) {
+      hipEvent_t a, b;
+      if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+      g_prof.pool.push_back(a); g_prof.pool.push_back(b);
+    }
+    hipEvent_t start = g_prof.pool[g_prof.used];
+    stop = g_prof.pool[g_prof.used + 1];
+    g_prof.used += 2;
+    g_prof.samples += samples;
+    (void)hipEventRecord(start, stream);
+  }
+  ~MlpTimer() { if (stop) (void)hipEventRecord(stop, stream); }
+};
+
+int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
+
+// workspace layout for a chunk of n rays
+struct Ws {
+  float* t_c;   // n*65
+  float* w_c;   // n*65
+  float* t_f;   // n*193
+  float* raw;   // n*193*4 (coarse raw uses the first n*65*4)
+  int64_t bytes;
+};
+
+Ws carve(char* base, int64_t n) {
+  Ws w;
+  int64_t off = 0;
+  w.t_c = reinterpret_cast<float*>(base + off); off += align_up(n * kSc * 4, 256);
+  w.w_c = reinterpret_cast<float*>(base + off); off += align_up(n * kSc * 4, 256);
+  w.t_f = reinterpret_cast<float*>(base + off); off += align_up(n * kSf * 4, 256);
+  w.raw = reinterpret_cast<float*>(base + off); off += align_up(n * kSf * 16, 256);
+  w.bytes = off;
+  return w;
+}
+
+}  // namespace
+
+extern "C" {
+
+int aon_abi_version(void) { return AON_ABI_VERSION; }
+
+const char* aon_last_error(void) { return g_err; }
+
+int aon_raygen(const float* c2w_host, int H, int W, float focal, int64_t pix_begin, int64_t pix_end, float* rays_o,
+               float* viewdirs, float* rays_d, void* stream) {
+  if (!c2w_host || !rays_o || !viewdirs) return fail(AON_E_INVALID, "aon_raygen: null pointer");
+  if (H <= 0 || W <= 0 || !(focal > 0.f) || pix_begin < 0 || pix_end < pix_begin || pix_end > (int64_t)H * W)
+    return fail(AON_E_INVALID, "aon_raygen: bad geometry");
+  return check(aon::launch_raygen(c2w_host, H, W, focal, nullptr, pix_begin, pix_end, rays_o, viewdirs, rays_d,
+                                  (hipStream_t)stream), "aon_raygen");
+}
+
+int aon_ray_directions(int H, int W, float focal, float* directions, void* stream) {
+  if (H <= 0 || W <= 0 || !(focal > 0.f) || !directions) return fail(AON_E_INVALID, "aon_ray_directions: bad argument");
+  return check(aon::launch_ray_directions(H, W, focal, directions, (hipStream_t)stream), "aon_ray_directions");
+}
+
+int aon_get_rays(const float* directions, const float* c2w_host, int64_t n, float* rays_o, float* viewdirs, float* rays_d,
+                 void* stream) {
+  if (n < 0) return fail(AON_E_INVALID, "aon_get_rays: bad size");
+  if (n == 0) return AON_OK;
+  if (!directions || !c2w_host || !rays_o || !viewdirs) return fail(AON_E_INVALID, "aon_get_rays: null pointer");
+  // geometry arguments are unused when directions are supplied; W = n keeps the pixel index math in range
+  return check(aon::launch_raygen(c2w_host, 1, (int)(n > INT32_MAX ? INT32_MAX : n), 1.0f, directions, 0, n, rays_o, viewdirs,
+                                  rays_d, (hipStream_t)stream), "aon_get_rays");
+}
+
+int aon_cast_rays(const float* t_vals, const float* origins, const float* directions, int64_t n_rays, int S, float* coords,
+                  void* stream) {
+  if (n_rays < 0 || S < 1) return fail(AON_E_INVALID, "aon_cast_rays: bad size");
+  if (n_rays == 0) return AON_OK;
+  if (!t_vals || !origins || !directions || !coords) return fail(AON_E_INVALID, "aon_cast_rays: null pointer");
+  return check(aon::launch_cast_rays(t_vals, origins, directions, n_rays, S, coords, (hipStream_t)stream), "aon_cast_rays");
+}
+
+int aon_sample_along_rays(const float* rays_o, const float* rays_d, int64_t n_rays, int S, float near_, float far_,
+                          const float* t_rand, float* t_vals, float* coords, void* stream) {
+  if (n_rays < 0 || S < 2) return fail(AON_E_INVALID, "aon_sample_along_rays: bad size");
+  if (n_rays == 0) return AON_OK;
+  if (!t_vals || (coords && (!rays_o || !rays_d))) return fail(AON_E_INVALID, "aon_sample_along_rays: null pointer");
+  return check(aon::launch_sample_along_rays(rays_o, rays_d, n_rays, S, near_, far_, t_rand, t_vals, coords, (hipStream_t)stream),
+               "aon_sample_along_rays");
+}
+
+int aon_pos_enc(const float* x, int64_t n, int min_deg, int max_deg, float* out, void* stream) {
+  if (n < 0 || max_deg < min_deg) return fail(AON_E_INVALID, "aon_pos_enc: bad size");
+  if (n == 0) return AON_OK;
+  if (!x || !out) return fail(AON_E_INVALID, "aon_pos_enc: null pointer");
+  return check(aon::launch_pos_enc(x, n, min_deg, max_deg, out, (hipStream_t)stream), "aon_pos_enc");
+}
+
+int64_t aon_mlp_packed_bytes(void) { return aon::kPackedBytes; }
+
+int aon_pack_vanilla_mlp(const float* const* params_host, void* packed, void* stream) {
+  if (!params_host || !packed) return fail(AON_E_INVALID, "aon_pack_vanilla_mlp: null pointer");
+  for (int i = 0; i < aon::kNumVanillaParams; ++i)
+    if (!params_host[i]) return fail(AON_E_INVALID, "aon_pack_vanilla_mlp: null parameter pointer");
+  if (reinterpret_cast<uintptr_t>(packed) & 15) return fail(AON_E_INVALID, "aon_pack_vanilla_mlp: packed must be 16-byte aligned");
+  return check(aon::launch_pack_vanilla(params_host, static_cast<float*>(packed), (hipStream_t)stream), "aon_pack_vanilla_mlp");
+}
+
+int aon_mlp_fwd(const void* packed, const float* rays_o, const float* rays_d, const float* viewdirs, const float* t_vals,
+                int64_t n_rays, int S, float* raw, void* stream) {
+  if (n_rays < 0 || S < 1) return fail(AON_E_INVALID, "aon_mlp_fwd: bad size");
+  if (n_rays == 0) return AON_OK;
+  if (!packed || !rays_o || !rays_d || !viewdirs || !t_vals || !raw) return fail(AON_E_INVALID, "aon_mlp_fwd: null pointer");
+  if (n_rays * (int64_t)S > (int64_t)INT32_MAX * 64) return fail(AON_E_INVALID, "aon_mlp_fwd: too many samples for one call");
+  MlpTimer timer((hipStream_t)stream, n_rays * S);
+  return check(aon::launch_mlp_fwd(static_cast<const char*>(packed), rays_o, rays_d, viewdirs, t_vals, n_rays, S, raw,
+                                   (hipStream_t)stream), "aon_mlp_fwd");
+}
+
+int aon_mlp_fwd_enc(const void* packed, const float* samples_enc, const float* viewdirs_enc, int64_t n_rays, int S,
+                    float* raw, void* stream) {
+  if (n_rays < 0 || S < 1) return fail(AON_E_INVALID, "aon_mlp_fwd_enc: bad size");
+  if (n_rays == 0) return AON_OK;
+  if (!packed || !samples_enc || !viewdirs_enc || !raw) return fail(AON_E_INVALID, "aon_mlp_fwd_enc: null pointer");
+  return check(aon::launch_mlp_fwd_enc(static_cast<const char*>(packed), samples_enc, viewdirs_enc, n_rays, S, raw,
+                                       (hipStream_t)stream), "aon_mlp_fwd_enc");
+}
+
+int aon_composite(const float* rgb, int rgb_stride, const float* sigma, int sigma_stride, const float* t_vals,
+                  const float* dirs, int64_t n_rays, int S, int white_bkgd, int act, float* comp_rgb, float* acc,
+                  float* depth, float* weights, void* stream) {
+  if (n_rays < 0 || S < 1 || rgb_stride < 3 || sigma_stride < 1 || act < 0 || act > 2)
+    return fail(AON_E_INVALID, "aon_composite: bad size / stride / act");
+  if (n_rays == 0) return AON_OK;
+  if (!rgb || !sigma || !t_vals || !dirs || !comp_rgb || !acc || !depth) return fail(AON_E_INVALID, "aon_composite: null pointer");
+  return check(aon::launch_composite(rgb, rgb_stride, sigma, sigma_stride, t_vals, dirs, n_rays, S, white_bkgd, act, comp_rgb,
+                                     acc, depth, weights, (hipStream_t)stream), "aon_composite");
+}
+
+int aon_sample_pdf(const float* bins, const float* weights, int64_t w_stride, const float* t_coarse, const float* u,
+                   int64_t u_stride, int64_t n_rays, float* samples, float* t_fine, void* stream) {
+  if (n_rays < 0 || w_stride < 63 || (u_stride != 0 && u_stride < 128)) return fail(AON_E_INVALID, "aon_sample_pdf: bad size / stride");
+  if (n_rays == 0) return AON_OK;
+  if (!weights || !u || (!bins && !t_coarse) || (t_fine && !t_coarse) || (!samples && !t_fine))
+    return fail(AON_E_INVALID, "aon_sample_pdf: null pointer");
+  return check(aon::launch_sample_pdf(bins, weights, w_stride, t_coarse, u, u_stride, n_rays, samples, t_fine,
+                                      (hipStream_t)stream), "aon_sample_pdf");
+}
+
+int aon_profile_begin(void) {
+  std::lock_guard<std::mutex> lk(g_prof.mu);
+  g_prof.on = true; g_prof.used = 0; g_prof.samples = 0;
+  return AON_OK;
+}
+
+int aon_profile_end(double* mlp_ms, int64_t* mlp_launches, int64_t* mlp_samples) {
+  std::lock_guard<std::mutex> lk(g_prof.mu);
+  g_prof.on = false;
+  double total = 0.0;
+  for (size_t i = 0; i + 1 < g_prof.used; i += 2) {
+    hipError_t e = hipEventSynchronize(g_prof.pool[i + 1]);
+    if (e != hipSuccess) return check(e, "aon_profile_end");
+    float ms = 0.f;
+    e = hipEventElapsedTime(&ms, g_prof.pool[i], g_prof.pool[i + 1]);
+    if (e != hipSuccess) return check(e, "aon_profile_end");
+    total += ms;
+  }
+  if (mlp_ms) *mlp_ms = total;
+  if (mlp_launches) *mlp_launches = (int64_t)(g_prof.used / 2);
+  if (mlp_samples) *mlp_samples = g_prof.samples;
+  g_prof.used = 0; g_prof.samples = 0;
+  return AON_OK;
+}
+
+int64_t aon_render_workspace_bytes(int64_t n_rays) {
+  if (n_rays < 1) n_rays = 1;
+  return carve(nullptr, n_rays).bytes;
+}
+
+int aon_render_fwd(const void* packed_coarse, const void* packed_fine, const float* rays_o, const float* rays_d,
+                   const float* viewdirs, int64_t n_rays, float near_, float far_, int white_bkgd, int num_levels,
+                   const float* t_rand, const float* u, int64_t u_stride, float* rgb_c, float* acc_c, float* depth_c,
+                   float* rgb_f, float* acc_f, float* depth_f, void* workspace, int64_t workspace_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (n_rays < 0 || (num_levels != 1 && num_levels != 2)) return fail(AON_E_INVALID, "aon_render_fwd: bad size / num_levels");
+  if (n_rays == 0) return AON_OK;
+  if (!packed_coarse || !rays_o || !rays_d || !viewdirs || !rgb_c || !acc_c || !depth_c || !workspace)
+    return fail(AON_E_INVALID, "aon_render_fwd: null pointer");
+  if (num_levels == 2 && (!packed_fine || !rgb_f || !acc_f || !depth_f || !u))
+    return fail(AON_E_INVALID, "aon_render_fwd: null fine-level pointer");
+  if (num_levels == 2 && u_stride != 0 && u_stride < 128) return fail(AON_E_INVALID, "aon_render_fwd: bad u_stride");
+  if (reinterpret_cast<uintptr_t>(workspace) & 255) return fail(AON_E_INVALID, "aon_render_fwd: workspace must be 256-byte aligned");
+
+  // largest chunk the workspace admits
+  int64_t chunk = n_rays;
+  if (carve(nullptr, chunk).bytes > workspace_bytes) {
+    const int64_t per_ray = (kSc + kSc + kSf + 4 * kSf) * 4;
+    chunk = (workspace_bytes - 4 * 256) / per_ray;
+    while (chunk > 0 && carve(nullptr, chunk).bytes > workspace_bytes) --chunk;
+    if (chunk < 1) return fail(AON_E_WORKSPACE, "aon_render_fwd: workspace smaller than aon_render_workspace_bytes(1)");
+  }
+  const Ws w = carve(static_cast<char*>(workspace), chunk);
+
+  for (int64_t r0 = 0; r0 < n_rays; r0 += chunk) {
+    const int64_t n = n_rays - r0 < chunk ? n_rays - r0 : chunk;
+    const float* o = rays_o + r0 * 3;
+    const float* d = rays_d + r0 * 3;
+    const float* v = viewdirs + r0 * 3;
+    int rc;
+    // level 0 (model.py:150-160, :175-197)
+    rc = check(aon::launch_sample_along_rays(o, d, n, kSc, near_, far_, t_rand ? t_rand + r0 * kSc : nullptr, w.t_c, nullptr, stream),
+               "sample_along_rays");
+    if (rc) return rc;
+    {
+      MlpTimer timer(stream, n * kSc);
+      rc = check(aon::launch_mlp_fwd(static_cast<const char*>(packed_coarse), o, d, v, w.t_c, n, kSc, w.raw, stream), "mlp_fwd(coarse)");
+    }
+    if (rc) return rc;
+    rc = check(aon::launch_composite(w.raw, 4, w.raw + 3, 4, w.t_c, d, n, kSc, white_bkgd, AON_ACT_VANILLA, rgb_c + r0 * 3,
+                                     acc_c + r0, depth_c + r0, num_levels == 2 ? w.w_c : nullptr, stream), "composite(coarse)");
+    if (rc) return rc;
+    if (num_levels == 1) continue;
+    // level 1 (model.py:162-173, :175-197)
+    rc = check(aon::launch_sample_pdf(nullptr, w.w_c + 1, kSc, w.t_c, u_stride ? u + r0 * u_stride : u, u_stride, n, nullptr, w.t_f,
+                                      stream), "sample_pdf");
+    if (rc) return rc;
+    {
+      MlpTimer timer(stream, n * kSf);
+      rc = check(aon::launch_mlp_fwd(static_cast<const char*>(packed_fine), o, d, v, w.t_f, n, kSf, w.raw, stream), "mlp_fwd(fine)");
+    }
+    if (rc) return rc;
+    rc = check(aon::launch_composite(w.raw, 4, w.raw + 3, 4, w.t_f, d, n, kSf, white_bkgd, AON_ACT_VANILLA, rgb_f + r0 * 3,
+                                     acc_f + r0, depth_f + r0, nullptr, stream), "composite(fine)");
+    if (rc) return rc;
+  }
+  return AON_OK;
+}
+
+}  // extern "C"

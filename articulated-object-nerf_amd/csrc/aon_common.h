@@ -1,0 +1,94 @@
+// Shared constants and small device helpers for the gfx950 (MI355X / CDNA4) NeRF render kernels.
+// Wave size is 64 on CDNA; every wave-width constant below is hard-coded to 64.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace aon {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// fp32(0.5*pi): the reference computes cos(x) as sin(x + 0.5*np.pi) with the add done in fp32
+// (models/vanilla_nerf/helper.py:139).
+#define AON_HALF_PI_F32 1.57079637050628662109375f
+
+// sin(x) for |x| < ~1e5, max abs error 9.3e-8 against fp64 (|x| <= 3200): three-term Cody-Waite reduction by
+// multiples of pi/2 with FMA, then degree-7/8 minimax polynomials on [-pi/4, pi/4].  Branch-free (the library
+// sinf carries a Payne-Hanek slow path that costs registers and divergence and is never taken here: the
+// largest argument on this path is 2^9 * 6 + pi/2).
+__device__ __forceinline__ float sin_f32(float x) {
+  const float ax = __builtin_fabsf(x);
+  const float k = __builtin_rintf(ax * 0.636619747f);
+  const int q = (int)k;
+  float r = __builtin_fmaf(k, -0x1.921fb4p+0f, ax);   // pi/2 = 0x3fc90fda + 0x33a22168 + 0x27c234c4
+  r = __builtin_fmaf(k, -0x1.4442d0p-24f, r);
+  r = __builtin_fmaf(k, -0x1.846988p-48f, r);
+  const float z = r * r;
+  float ps = __builtin_fmaf(z, -1.9515295891e-4f, 8.3321608736e-3f);
+  ps = __builtin_fmaf(z, ps, -1.6666654611e-1f);
+  const float s = __builtin_fmaf(r * z, ps, r);
+  float pc = __builtin_fmaf(z, 2.443315711809948e-5f, -1.388731625493765e-3f);
+  pc = __builtin_fmaf(z, pc, 4.166664568298827e-2f);
+  const float c = __builtin_fmaf(z * z, pc, __builtin_fmaf(z, -0.5f, 1.0f));
+  float res = (q & 1) ? c : s;
+  res = (q & 2) ? -res : res;
+  return x < 0.f ? -res : res;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Packed-weight stream of one vanilla NeRFMLP (models/vanilla_nerf/model.py:39-120).
+//
+// A *chunk* is the slice of one layer's weight matrix that multiplies one 32-feature input tile:
+//   chunk[q][Tp][lane][c]  (q=0..3, Tp=0..NT_OUT-1, lane=0..63, c=0..3)  fp32, i.e. NT_OUT*4 KiB
+//     = W[32*Tp + (lane&31)][ col(tile, 8q + 4*(lane>>5) + c) ]
+// which is exactly the A operand of v_mfma_f32_32x32x2_f32 for output tile Tp when the B operand is
+// accumulator register r = 4q+c of the producing layer's tile (rows (r&3)+8*(r>>2)+4*(lane>>5)).
+// ------------------------------------------------------------------------------------------------
+constexpr int kNetWidth = 256;
+constexpr int kCondWidth = 128;
+constexpr int kPosEnc = 63;    // 3 + 2*10*3
+constexpr int kViewEnc = 27;   // 3 + 2*4*3
+
+constexpr int kChL0 = 0;       // 2 chunks  (pos-enc tiles)            -> 256
+constexpr int kChL1 = 2;       // 8 chunks each for L1..L4
+constexpr int kChL5 = 34;      // 8 hidden + 2 pos-enc (skip concat)
+constexpr int kChL6 = 44;
+constexpr int kChL7 = 52;
+constexpr int kChBott = 60;    // bottleneck 256 -> 256 (no activation)
+constexpr int kChView = 68;    // 8 hidden + 1 view-enc               -> 128
+constexpr int kNumChunks = 77;
+constexpr int kNumBigChunks = 68;            // chunks with 8 output tiles (32 KiB)
+constexpr int kBigChunkBytes = 8 * 4096;
+constexpr int kSmallChunkBytes = 4 * 4096;   // view layer: 4 output tiles (16 KiB)
+
+__host__ __device__ constexpr int chunk_bytes(int c) { return c < kNumBigChunks ? kBigChunkBytes : kSmallChunkBytes; }
+__host__ __device__ constexpr int64_t chunk_offset(int c) {
+  return c < kNumBigChunks ? (int64_t)c * kBigChunkBytes
+                           : (int64_t)kNumBigChunks * kBigChunkBytes + (int64_t)(c - kNumBigChunks) * kSmallChunkBytes;
+}
+constexpr int64_t kStreamBytes = chunk_offset(kNumChunks);  // 2,375,680 B
+
+// Small per-layer vectors, kept resident in LDS for the whole kernel (floats):
+constexpr int kSmBias = 0;                    // 8 x 256  trunk biases
+constexpr int kSmBiasBott = 8 * 256;          // 256
+constexpr int kSmBiasView = kSmBiasBott + 256;  // 128
+constexpr int kSmWSigma = kSmBiasView + 128;  // 256
+constexpr int kSmWRgb = kSmWSigma + 256;      // 3 x 128
+constexpr int kSmBSigma = kSmWRgb + 384;      // 1
+constexpr int kSmBRgb = kSmBSigma + 1;        // 3
+constexpr int kSmallFloats = 3076;            // padded to a multiple of 4
+constexpr int64_t kSmallBytes = kSmallFloats * 4;
+
+constexpr int64_t kPackedBytes = kStreamBytes + kSmallBytes;  // one packed MLP
+
+// Parameter order of the `params` pointer array handed to aon_pack_vanilla_mlp (device pointers to the
+// unmodified torch nn.Linear storages, (out,in) row-major fp32):
+//   0..15  pts_linears.{0..7}.{weight,bias}
+//   16,17  views_linear.0.{weight,bias}
+//   18,19  bottleneck_layer.{weight,bias}
+//   20,21  density_layer.{weight,bias}
+//   22,23  rgb_layer.{weight,bias}
+constexpr int kNumVanillaParams = 24;
+
+}  // namespace aon

@@ -1,0 +1,441 @@
+// Non-GEMM stages of the NeRF render path for gfx950: ray generation, stratified sampling, positional
+// encoding (stage-level entry point), alpha compositing and hierarchical inverse-CDF sampling.
+//
+// All of them are HBM-bound streaming kernels.  Rays are the parallel axis: compositing and the inverse CDF
+// give one 64-lane wavefront to each ray, lanes stride over the ray's samples so every load/store of a
+// per-ray sample buffer is a contiguous burst, and the transmittance product / CDF sum / merge-sort are
+// wavefront scans and shuffles (no LDS round trip except the 64-entry CDF table the binary search gathers from).
+#include "aon_common.h"
+
+namespace aon {
+
+// ---------------------------------------------------------------------------------------------
+// wave64 helpers
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+
+// inclusive scan over the 64 lanes (Hillis-Steele); OP is + or *
+template <bool MUL>
+__device__ __forceinline__ float wave_inclusive_scan(float v, int lane) {
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const float o = __shfl_up(v, off);
+    if (lane >= off) v = MUL ? v * o : v + o;
+  }
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// R1 + R2  ray generation   (datasets/ray_utils.py:71-90, 118-159)
+// ---------------------------------------------------------------------------------------------
+struct RaygenArgs {
+  float c2w[12];  // row-major (3,4)
+  int H, W;
+  float focal;
+  int64_t pix_begin, pix_end;  // row-major pixel range [begin, end) to generate
+  float* rays_o;   // (n,3)
+  float* viewdirs; // (n,3) unit directions
+  float* rays_d;   // (n,3) or null; the reference's rays_d aliases viewdirs (ray_utils.py:146-147)
+  const float* directions;  // (H*W,3) precomputed camera-space directions, or null -> pinhole model below
+};
+
+__global__ void raygen_kernel(RaygenArgs a) {
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t pix = a.pix_begin + k;
+  if (pix >= a.pix_end) return;
+  const int j = (int)(pix / a.W), i = (int)(pix % a.W);
+  // ((i - W/2)/focal, -(j - H/2)/focal, -1), no +0.5 pixel centre (ray_utils.py:86-88)
+  float dx = __fdiv_rn(__fsub_rn((float)i, (float)a.W * 0.5f), a.focal);
+  float dy = -__fdiv_rn(__fsub_rn((float)j, (float)a.H * 0.5f), a.focal);
+  float dz = -1.0f;
+  if (a.directions) { dx = a.directions[pix * 3]; dy = a.directions[pix * 3 + 1]; dz = a.directions[pix * 3 + 2]; }
+  float d[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r)  // directions @ c2w[:, :3].T
+    d[r] = __builtin_fmaf(dz, a.c2w[4 * r + 2], __builtin_fmaf(dy, a.c2w[4 * r + 1], __fmul_rn(dx, a.c2w[4 * r + 0])));
+  const float nrm = __fsqrt_rn(__builtin_fmaf(d[2], d[2], __builtin_fmaf(d[1], d[1], __fmul_rn(d[0], d[0]))));
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    const float v = __fdiv_rn(d[r], nrm);
+    a.viewdirs[k * 3 + r] = v;
+    if (a.rays_d) a.rays_d[k * 3 + r] = v;
+    a.rays_o[k * 3 + r] = a.c2w[4 * r + 3];
+  }
+}
+
+__global__ void ray_directions_kernel(int H, int W, float focal, float* __restrict__ out) {
+  const int64_t pix = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (pix >= (int64_t)H * W) return;
+  const int j = (int)(pix / W), i = (int)(pix % W);
+  out[pix * 3 + 0] = __fdiv_rn(__fsub_rn((float)i, (float)W * 0.5f), focal);
+  out[pix * 3 + 1] = -__fdiv_rn(__fsub_rn((float)j, (float)H * 0.5f), focal);
+  out[pix * 3 + 2] = -1.0f;
+}
+
+hipError_t launch_ray_directions(int H, int W, float focal, float* out, hipStream_t stream) {
+  const int64_t n = (int64_t)H * W;
+  ray_directions_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream>>>(H, W, focal, out);
+  return hipGetLastError();
+}
+
+hipError_t launch_raygen(const float* c2w, int H, int W, float focal, const float* directions, int64_t pix_begin,
+                         int64_t pix_end, float* rays_o, float* viewdirs, float* rays_d, hipStream_t stream) {
+  RaygenArgs a;
+  a.directions = directions;
+  for (int i = 0; i < 12; ++i) a.c2w[i] = c2w[i];
+  a.H = H; a.W = W; a.focal = focal; a.pix_begin = pix_begin; a.pix_end = pix_end;
+  a.rays_o = rays_o; a.viewdirs = viewdirs; a.rays_d = rays_d;
+  const int64_t n = pix_end - pix_begin;
+  if (n <= 0) return hipSuccess;
+  raygen_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream>>>(a);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// R3  stratified sampling   (models/vanilla_nerf/helper.py:106-133, lindisp=False)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float linspace01(int idx, int steps) {
+  // torch.linspace(0, 1, steps) (CPU kernel): step = 1/(steps-1); first half counts up from start,
+  // second half counts down from end.
+  const float step = __fdiv_rn(1.0f, (float)(steps - 1));
+  return idx < steps / 2 ? __fmul_rn(step, (float)idx) : __fsub_rn(1.0f, __fmul_rn(step, (float)(steps - idx - 1)));
+}
+
+__device__ __forceinline__ float coarse_t(int idx, int steps, float near, float far) {
+  const float s = linspace01(idx, steps);
+  return __fadd_rn(__fmul_rn(near, __fsub_rn(1.0f, s)), __fmul_rn(far, s));  // near*(1-s) + far*s
+}
+
+__global__ void sample_along_rays_kernel(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                         int64_t n_rays, int S, float near, float far,
+                                         const float* __restrict__ t_rand, float* __restrict__ t_vals,
+                                         float* __restrict__ coords) {
+  const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= n_rays * S) return;
+  const int64_t ray = g / S;
+  const int s = (int)(g - ray * S);
+  float t = coarse_t(s, S, near, far);
+  if (t_rand) {  // stratified jitter between interval mid-points (helper.py:122-127)
+    const float lo = s == 0 ? t : __fmul_rn(0.5f, __fadd_rn(t, coarse_t(s - 1, S, near, far)));
+    const float hi = s == S - 1 ? t : __fmul_rn(0.5f, __fadd_rn(coarse_t(s + 1, S, near, far), t));
+    t = __fadd_rn(lo, __fmul_rn(__fsub_rn(hi, lo), t_rand[g]));
+  }
+  t_vals[g] = t;
+  if (coords) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) coords[g * 3 + a] = __fadd_rn(rays_o[ray * 3 + a], __fmul_rn(t, rays_d[ray * 3 + a]));
+  }
+}
+
+__global__ void cast_rays_kernel(const float* __restrict__ t_vals, const float* __restrict__ o, const float* __restrict__ d,
+                                 int64_t n_rays, int S, float* __restrict__ coords) {
+  const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= n_rays * S) return;
+  const int64_t ray = g / S;
+  const float t = t_vals[g];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) coords[g * 3 + a] = __fadd_rn(o[ray * 3 + a], __fmul_rn(t, d[ray * 3 + a]));
+}
+
+hipError_t launch_cast_rays(const float* t_vals, const float* o, const float* d, int64_t n_rays, int S, float* coords,
+                            hipStream_t stream) {
+  const int64_t n = n_rays * S;
+  if (n <= 0) return hipSuccess;
+  cast_rays_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream>>>(t_vals, o, d, n_rays, S, coords);
+  return hipGetLastError();
+}
+
+hipError_t launch_sample_along_rays(const float* rays_o, const float* rays_d, int64_t n_rays, int S, float near,
+                                    float far, const float* t_rand, float* t_vals, float* coords, hipStream_t stream) {
+  const int64_t n = n_rays * S;
+  if (n <= 0) return hipSuccess;
+  sample_along_rays_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream>>>(rays_o, rays_d, n_rays, S, near, far,
+                                                                                       t_rand, t_vals, coords);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// R4  positional encoding, stage-level entry point   (helper.py:136-140)
+// (the render path never materialises this tensor: the fused MLP kernel encodes in registers)
+// ---------------------------------------------------------------------------------------------
+__global__ void pos_enc_kernel(const float* __restrict__ x, int64_t n, int min_deg, int max_deg, float* __restrict__ out) {
+  const int L = max_deg - min_deg;
+  const int F = 3 + 6 * L;
+  const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= n * F) return;
+  const int64_t row = g / F;
+  const int f = (int)(g - row * F);
+  float v;
+  if (f < 3) {
+    v = x[row * 3 + f];
+  } else {
+    const int e = (f - 3) % (3 * L);
+    const bool shifted = (f - 3) >= 3 * L;
+    const float xb = __fmul_rn(x[row * 3 + e % 3], __builtin_ldexpf(1.0f, min_deg + e / 3));
+    v = sin_f32(shifted ? __fadd_rn(xb, AON_HALF_PI_F32) : xb);
+  }
+  out[g] = v;
+}
+
+hipError_t launch_pos_enc(const float* x, int64_t n, int min_deg, int max_deg, float* out, hipStream_t stream) {
+  const int64_t tot = n * (3 + 6 * (max_deg - min_deg));
+  if (tot <= 0) return hipSuccess;
+  pos_enc_kernel<<<dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream>>>(x, n, min_deg, max_deg, out);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// R8  alpha compositing   (helper.py:157-195), one wavefront per ray
+// ---------------------------------------------------------------------------------------------
+// act: 0 = inputs already activated (stage-level parity with volumetric_rendering)
+//      1 = vanilla NeRF: rgb = sigmoid(raw), sigma = relu(raw)                     (model.py:186-187)
+//      2 = articulated:  rgb = sigmoid(raw)*(1+2*0.001)-0.001, sigma = softplus(raw-1)  (model_autodecoder.py:321-323)
+struct CompositeArgs {
+  const float* rgb;    int rgb_stride;    // floats between consecutive samples (3 or 4)
+  const float* sigma;  int sigma_stride;  // 1 or 4
+  const float* t_vals;  // (n,S)
+  const float* dirs;    // (n,3)
+  int64_t n_rays; int S; int white_bkgd; int act;
+  float* comp_rgb;  // (n,3)
+  float* acc;       // (n,)
+  float* depth;     // (n,)
+  float* weights;   // (n,S) or null
+};
+
+__device__ __forceinline__ float sigmoid_f32(float x) { return __fdiv_rn(1.0f, __fadd_rn(1.0f, expf(-x))); }
+
+__device__ __forceinline__ float softplus_f32(float x) {  // torch Softplus(beta=1, threshold=20)
+  return x > 20.0f ? x : log1pf(expf(x));
+}
+
+__global__ void __launch_bounds__(256) composite_kernel(CompositeArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int64_t ray = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (ray >= a.n_rays) return;  // wave-uniform
+  const int S = a.S;
+  const float* tv = a.t_vals + ray * S;
+  const float dn = __fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(a.dirs[ray * 3], a.dirs[ray * 3]),
+                                                  __fmul_rn(a.dirs[ray * 3 + 1], a.dirs[ray * 3 + 1])),
+                                        __fmul_rn(a.dirs[ray * 3 + 2], a.dirs[ray * 3 + 2])));
+  float carry = 1.0f;  // transmittance entering this 64-sample block
+  float s_r = 0.f, s_g = 0.f, s_b = 0.f, s_w = 0.f, s_d = 0.f;
+  for (int base = 0; base < S; base += 64) {
+    const int s = base + lane;
+    const bool in = s < S;
+    float alpha = 0.f, c0 = 0.f, c1 = 0.f, c2 = 0.f, t = 0.f;
+    if (in) {
+      const int64_t g = ray * S + s;
+      t = tv[s];
+      const float dist = __fmul_rn(s == S - 1 ? 1e10f : __fsub_rn(tv[s + 1], t), dn);
+      float sg = a.sigma[g * a.sigma_stride];
+      c0 = a.rgb[g * a.rgb_stride + 0]; c1 = a.rgb[g * a.rgb_stride + 1]; c2 = a.rgb[g * a.rgb_stride + 2];
+      if (a.act == 1) {
+        sg = __builtin_fmaxf(sg, 0.f);
+        c0 = sigmoid_f32(c0); c1 = sigmoid_f32(c1); c2 = sigmoid_f32(c2);
+      } else if (a.act == 2) {
+        sg = softplus_f32(__fadd_rn(sg, -1.0f));
+        c0 = __fsub_rn(__fmul_rn(sigmoid_f32(c0), 1.002f), 0.001f);
+        c1 = __fsub_rn(__fmul_rn(sigmoid_f32(c1), 1.002f), 0.001f);
+        c2 = __fsub_rn(__fmul_rn(sigmoid_f32(c2), 1.002f), 0.001f);
+      }
+      alpha = __fsub_rn(1.0f, expf(-__fmul_rn(sg, dist)));
+    }
+    // T_i = prod_{j<i} (1 - alpha_j + 1e-10)   (helper.py:169-176)
+    const float f = in ? __fadd_rn(__fsub_rn(1.0f, alpha), 1e-10f) : 1.0f;
+    const float incl = wave_inclusive_scan<true>(f, lane);
+    float excl = __shfl_up(incl, 1);
+    if (lane == 0) excl = 1.0f;
+    const float T = __fmul_rn(carry, excl);
+    carry = __fmul_rn(carry, __shfl(incl, 63));
+    const float w = __fmul_rn(alpha, T);
+    if (in) {
+      s_r = __fadd_rn(s_r, __fmul_rn(w, c0));
+      s_g = __fadd_rn(s_g, __fmul_rn(w, c1));
+      s_b = __fadd_rn(s_b, __fmul_rn(w, c2));
+      s_w = __fadd_rn(s_w, w);
+      s_d = __fadd_rn(s_d, __fmul_rn(w, t));
+      if (a.weights) a.weights[ray * S + s] = w;
+    }
+  }
+  s_r = wave_sum(s_r); s_g = wave_sum(s_g); s_b = wave_sum(s_b); s_w = wave_sum(s_w); s_d = wave_sum(s_d);
+  if (lane == 0) {
+    if (a.white_bkgd) {  // comp_rgb + (1 - acc)
+      const float bg = __fsub_rn(1.0f, s_w);
+      s_r = __fadd_rn(s_r, bg); s_g = __fadd_rn(s_g, bg); s_b = __fadd_rn(s_b, bg);
+    }
+    a.comp_rgb[ray * 3 + 0] = s_r; a.comp_rgb[ray * 3 + 1] = s_g; a.comp_rgb[ray * 3 + 2] = s_b;
+    a.acc[ray] = s_w;
+    // helper.py:182-183: nan_to_num(depth, nan=inf); the clamp to the batch's own [min,max] is the identity
+    a.depth[ray] = (s_d != s_d) ? __builtin_inff() : s_d;
+  }
+}
+
+hipError_t launch_composite(const float* rgb, int rgb_stride, const float* sigma, int sigma_stride, const float* t_vals,
+                            const float* dirs, int64_t n_rays, int S, int white_bkgd, int act, float* comp_rgb,
+                            float* acc, float* depth, float* weights, hipStream_t stream) {
+  if (n_rays <= 0) return hipSuccess;
+  CompositeArgs a{rgb, rgb_stride, sigma, sigma_stride, t_vals, dirs, n_rays, S, white_bkgd, act, comp_rgb, acc, depth, weights};
+  composite_kernel<<<dim3((unsigned)((n_rays + 3) / 4)), dim3(256), 0, stream>>>(a);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// R6 + R7  inverse-CDF sampling and sort-merge   (helper.py:203-252), one wavefront per ray
+// ---------------------------------------------------------------------------------------------
+// Fixed to the reference's default geometry: 64 bins (mids of 65 coarse t's), 63 weights, 128 new samples.
+struct PdfArgs {
+  const float* bins;     // (n,64) or null -> mids of t_coarse
+  const float* weights;  // pointer to the first of the 63 pdf weights of ray 0
+  int64_t w_stride;      // floats between rays (63 for a dense (n,63) tensor, 65 for coarse weights[...,1:-1])
+  const float* t_coarse; // (n,65) or null (samples-only call)
+  const float* u;        // (128,) if u_stride == 0 else (n,128)
+  int64_t u_stride;
+  int64_t n_rays;
+  float* samples;        // (n,128) or null
+  float* t_fine;         // (n,193) or null
+};
+
+template <int K, int J>
+__device__ __forceinline__ void bitonic_step(float (&v)[4], int lane) {
+  if constexpr (J >= 4) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float o = __shfl_xor(v[r], J >> 2);
+      const int e = lane * 4 + r;
+      const bool up = (e & K) == 0, lower = (e & J) == 0;
+      v[r] = (up == lower) ? __builtin_fminf(v[r], o) : __builtin_fmaxf(v[r], o);
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if ((r & J) == 0) {
+        const int e = lane * 4 + r;
+        const bool up = (e & K) == 0;
+        const float lo = __builtin_fminf(v[r], v[r ^ J]), hi = __builtin_fmaxf(v[r], v[r ^ J]);
+        v[r] = up ? lo : hi;
+        v[r ^ J] = up ? hi : lo;
+      }
+    }
+  }
+}
+
+template <int K>
+__device__ __forceinline__ void bitonic_merge(float (&v)[4], int lane) {
+  if constexpr (K >= 256) bitonic_step<K, 128>(v, lane);
+  if constexpr (K >= 128) bitonic_step<K, 64>(v, lane);
+  if constexpr (K >= 64) bitonic_step<K, 32>(v, lane);
+  if constexpr (K >= 32) bitonic_step<K, 16>(v, lane);
+  if constexpr (K >= 16) bitonic_step<K, 8>(v, lane);
+  if constexpr (K >= 8) bitonic_step<K, 4>(v, lane);
+  if constexpr (K >= 4) bitonic_step<K, 2>(v, lane);
+  bitonic_step<K, 1>(v, lane);
+}
+
+__device__ __forceinline__ void wave_lds_sync() {
+  // LDS traffic of one wave is serviced in order; this only pins the compiler's ordering and drains lgkmcnt.
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+__global__ void __launch_bounds__(256) sample_pdf_kernel(PdfArgs a) {
+  __shared__ float lds[4][256];  // per wave: cdf[64] | bins[64], later reused as the 193-entry merge stage
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t ray = (int64_t)blockIdx.x * 4 + wv;
+  if (ray >= a.n_rays) return;  // wave-uniform; no block-level barrier below
+  float* cdf = lds[wv];
+  float* bin = lds[wv] + 64;
+
+  // bins: 0.5*(t[i+1]+t[i])  (model.py:163)
+  float tc = 0.f;
+  if (a.t_coarse) tc = a.t_coarse[ray * 65 + lane];
+  float b;
+  if (a.bins) {
+    b = a.bins[ray * 64 + lane];
+  } else {
+    const float tn = a.t_coarse[ray * 65 + lane + 1];
+    b = __fmul_rn(0.5f, __fadd_rn(tn, tc));
+  }
+  bin[lane] = b;
+
+  // pdf / cdf  (helper.py:206-222)
+  float w = lane < 63 ? a.weights[ray * a.w_stride + lane] : 0.f;
+  float wsum = wave_sum(w);
+  const float padding = __builtin_fmaxf(0.f, __fsub_rn(1e-5f, wsum));
+  w = __fadd_rn(w, __fdiv_rn(padding, 63.0f));
+  wsum = __fadd_rn(wsum, padding);
+  const float pdf = __fdiv_rn(w, wsum);
+  // cdf64 = [0, min(1, cumsum(pdf[:-1])) (62 entries), 1].  The running sum is taken in index order (a
+  // wave-uniform scalar fed by v_readlane), exactly like torch.cumsum: a tree scan would break the exact
+  // flatness of zero-weight zones and the monotonicity the binary search below relies on.
+  float run = 0.f, mine = 0.f;
+#pragma unroll
+  for (int j = 0; j < 62; ++j) {
+    run = __fadd_rn(run, __shfl(pdf, j));
+    if (lane == j + 1) mine = __builtin_fminf(1.f, run);
+  }
+  cdf[lane] = lane == 63 ? 1.f : mine;  // lane 0 keeps 0
+  wave_lds_sync();
+
+  float smp[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int j = lane + 64 * k;
+    const float u = a.u[ray * a.u_stride + j];
+    // idx = #(cdf <= u)  == searchsorted(cdf, u, right=True); cdf is non-decreasing
+    int idx = 0;
+#pragma unroll
+    for (int step = 32; step > 0; step >>= 1) {
+      if (cdf[idx + step - 1] <= u) idx += step;
+    }
+    if (idx == 63 && cdf[63] <= u) idx = 64;
+    const int i0 = idx - 1 < 0 ? 0 : idx - 1;
+    const int i1 = idx > 63 ? 63 : idx;
+    const float c0 = cdf[i0], c1 = cdf[i1], b0 = bin[i0], b1 = bin[i1];
+    float t = __fdiv_rn(__fsub_rn(u, c0), __fsub_rn(c1, c0));
+    if (t != t) t = 0.f;                                   // nan_to_num(., 0)
+    t = __builtin_fminf(__builtin_fmaxf(t, 0.f), 1.f);     // clip (+-inf land on the same ends as nan_to_num + clip)
+    smp[k] = __fadd_rn(b0, __fmul_rn(t, __fsub_rn(b1, b0)));
+    if (a.samples) a.samples[ray * 128 + j] = smp[k];
+  }
+  if (!a.t_fine) return;
+
+  // sort(cat[t_coarse(65), samples(128)]) -> 193   (helper.py:250): bitonic sort of 256 (+inf padded) keys held
+  // 4 per lane (element e = lane*4 + r), exchanges by v_permute/shuffle; cdf[]/bin[] are dead -> reuse as stage.
+  wave_lds_sync();
+  float* stage = lds[wv];
+  stage[lane] = tc;
+  if (lane == 0) stage[64] = a.t_coarse[ray * 65 + 64];
+  stage[65 + lane] = smp[0];
+  stage[129 + lane] = smp[1];
+  wave_lds_sync();
+  float v[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int e = lane * 4 + r;
+    v[r] = e < 193 ? stage[e] : __builtin_inff();
+  }
+  bitonic_merge<2>(v, lane); bitonic_merge<4>(v, lane); bitonic_merge<8>(v, lane); bitonic_merge<16>(v, lane);
+  bitonic_merge<32>(v, lane); bitonic_merge<64>(v, lane); bitonic_merge<128>(v, lane); bitonic_merge<256>(v, lane);
+  float* out = a.t_fine + ray * 193;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int e = lane * 4 + r;
+    if (e < 193) out[e] = v[r];
+  }
+}
+
+hipError_t launch_sample_pdf(const float* bins, const float* weights, int64_t w_stride, const float* t_coarse,
+                             const float* u, int64_t u_stride, int64_t n_rays, float* samples, float* t_fine,
+                             hipStream_t stream) {
+  if (n_rays <= 0) return hipSuccess;
+  PdfArgs a{bins, weights, w_stride, t_coarse, u, u_stride, n_rays, samples, t_fine};
+  sample_pdf_kernel<<<dim3((unsigned)((n_rays + 3) / 4)), dim3(256), 0, stream>>>(a);
+  return hipGetLastError();
+}
+
+}  // namespace aon

@@ -1,0 +1,110 @@
+"""Drop-in ``NeRFMLP`` / ``NeRF`` modules: same constructor defaults, attribute and parameter names (so the
+reference's Lightning checkpoints load unchanged) and the same ``forward`` signatures and return structure as
+``models/vanilla_nerf/model.py:39-199`` -- with ``forward`` running on the fused HIP kernels.
+
+Only the reference's default geometry has kernels (8x256 trunk with a skip at layer 4, 1x128 view branch,
+10/4 encoding degrees, 64+128 samples): that is the only geometry the reference can instantiate from its CLI
+(``LitNeRF`` builds ``NeRF()`` with all defaults, model.py:218).  Anything else raises at construction.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+import torch.nn.init as init
+
+from ... import ops
+
+
+class NeRFMLP(nn.Module):
+    """model.py:39-120.  ``forward(x, condition)``: x (N,S,63) encoded samples, condition (N,27) encoded view
+    directions -> (raw_rgb (N,S,3), raw_density (N,S,1))."""
+
+    def __init__(self, min_deg_point, max_deg_point, deg_view, netdepth: int = 8, netwidth: int = 256,
+                 netdepth_condition: int = 1, netwidth_condition: int = 128, skip_layer: int = 4, input_ch: int = 3,
+                 input_ch_view: int = 3, num_rgb_channels: int = 3, num_density_channels: int = 1):
+        super().__init__()
+        geometry = (min_deg_point, max_deg_point, deg_view, netdepth, netwidth, netdepth_condition, netwidth_condition,
+                    skip_layer, input_ch, input_ch_view, num_rgb_channels, num_density_channels)
+        if geometry != (0, 10, 4, 8, 256, 1, 128, 4, 3, 3, 3, 1):
+            raise NotImplementedError(f"NeRFMLP geometry {geometry} has no HIP kernel (only the reference defaults do)")
+        self.min_deg_point, self.max_deg_point, self.deg_view = min_deg_point, max_deg_point, deg_view
+        self.netdepth, self.netwidth, self.skip_layer = netdepth, netwidth, skip_layer
+        self.netdepth_condition, self.netwidth_condition = netdepth_condition, netwidth_condition
+        self.num_rgb_channels, self.num_density_channels = num_rgb_channels, num_density_channels
+        self.net_activation = nn.ReLU()
+        pos_size = ((max_deg_point - min_deg_point) * 2 + 1) * input_ch
+        view_pos_size = (deg_view * 2 + 1) * input_ch_view
+        layers = [nn.Linear(pos_size, netwidth)]
+        for idx in range(netdepth - 1):
+            layers.append(nn.Linear(netwidth + pos_size if (idx % skip_layer == 0 and idx > 0) else netwidth, netwidth))
+        for layer in layers:
+            init.xavier_uniform_(layer.weight)
+        self.pts_linears = nn.ModuleList(layers)
+        self.views_linear = nn.ModuleList([nn.Linear(netwidth + view_pos_size, netwidth_condition)])
+        self.bottleneck_layer = nn.Linear(netwidth, netwidth)
+        self.density_layer = nn.Linear(netwidth, num_density_channels)
+        self.rgb_layer = nn.Linear(netwidth_condition, num_rgb_channels)
+        init.xavier_uniform_(self.bottleneck_layer.weight)
+        init.xavier_uniform_(self.density_layer.weight)
+        init.xavier_uniform_(self.rgb_layer.weight)
+        self._packed = None
+        self._packed_key = None
+
+    def packed(self) -> torch.Tensor:
+        """The kernel-side weight stream; re-packed (one small HIP kernel) whenever a parameter was modified
+        in place, replaced, or moved."""
+        params = dict(self.named_parameters())
+        key = tuple((p.data_ptr(), p._version, str(p.device)) for p in params.values())
+        if self._packed is None or key != self._packed_key:
+            out = self._packed if (self._packed is not None and self._packed.device == next(iter(params.values())).device) else None
+            self._packed = ops.pack_vanilla_mlp(params, out=out)
+            self._packed_key = key
+        return self._packed
+
+    def forward(self, x, condition):
+        raw = ops.mlp_fwd_enc(self.packed(), x, condition)
+        return raw[..., :3], raw[..., 3:4]
+
+
+class NeRF(nn.Module):
+    """model.py:123-199.  ``forward(rays, randomized, white_bkgd, near, far)`` with ``rays`` a dict holding
+    ``rays_o``, ``rays_d``, ``viewdirs`` (extra keys are ignored, as in the reference) returns
+    ``[(comp_rgb, acc, depth)_coarse, (comp_rgb, acc, depth)_fine]``.
+
+    ``t_rand`` (N,65) / ``u`` (N,128) optionally replace the reference's in-function ``torch.rand`` draws."""
+
+    def __init__(self, num_levels: int = 2, min_deg_point: int = 0, max_deg_point: int = 10, deg_view: int = 4,
+                 num_coarse_samples: int = 64, num_fine_samples: int = 128, use_viewdirs: bool = True,
+                 noise_std: float = 0.0, lindisp: bool = False):
+        super().__init__()
+        if (num_coarse_samples, num_fine_samples, use_viewdirs, lindisp) != (64, 128, True, False) or num_levels not in (1, 2):
+            raise NotImplementedError("only the reference's default sampling geometry (64 coarse + 128 fine, viewdirs, "
+                                      "no lindisp) has HIP kernels")
+        if noise_std != 0.0:
+            raise NotImplementedError("noise_std > 0 is dead code on the reference path (model.py:183-184, default 0)")
+        self.num_levels, self.min_deg_point, self.max_deg_point, self.deg_view = num_levels, min_deg_point, max_deg_point, deg_view
+        self.num_coarse_samples, self.num_fine_samples = num_coarse_samples, num_fine_samples
+        self.use_viewdirs, self.noise_std, self.lindisp = use_viewdirs, noise_std, lindisp
+        self.rgb_activation = nn.Sigmoid()
+        self.sigma_activation = nn.ReLU()
+        self.coarse_mlp = NeRFMLP(min_deg_point, max_deg_point, deg_view)
+        self.fine_mlp = NeRFMLP(min_deg_point, max_deg_point, deg_view)
+
+    def forward(self, rays, randomized, white_bkgd, near, far, t_rand=None, u=None):
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError(
+                "the HIP backward of the render path is not implemented yet: call under torch.no_grad() "
+                "(validation / test rendering); there is deliberately no eager-PyTorch fallback")
+        rays_o = rays["rays_o"]
+        n = rays_o.shape[0]
+        if randomized:
+            if t_rand is None:
+                t_rand = torch.rand((n, self.num_coarse_samples + 1), device=rays_o.device)
+            if u is None and self.num_levels == 2:
+                u = torch.rand((n, self.num_fine_samples), device=rays_o.device)
+        else:
+            t_rand, u = None, None
+        fine = self.fine_mlp.packed() if self.num_levels == 2 else None
+        outs = ops.render_fwd(self.coarse_mlp.packed(), fine, rays_o, rays["rays_d"], rays["viewdirs"], near, far,
+                              white_bkgd, self.num_levels, t_rand, u)
+        return [tuple(o) for o in outs]

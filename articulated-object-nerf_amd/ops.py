@@ -1,0 +1,305 @@
+"""Tensor-level wrappers over the C ABI: torch is used for device memory and streams only.
+
+Every function takes/returns CUDA(HIP) fp32 tensors, allocates its outputs, and enqueues on torch's current
+stream.  CPU tensors are rejected: there is no host fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import check, lib
+
+ACT_NONE, ACT_VANILLA, ACT_ARTICULATED = 0, 1, 2
+
+
+def _stream() -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _f32(t: torch.Tensor, name: str) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name}: expected a torch.Tensor, got {type(t)}")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: tensor is on {t.device}; the HIP path needs a cuda (ROCm) tensor and has no CPU fallback")
+    if t.dtype != torch.float32:
+        raise TypeError(f"{name}: expected float32, got {t.dtype}")
+    return t.contiguous()
+
+
+def _ptr(t: torch.Tensor | None) -> C.c_void_p:
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _c2w_host(c2w) -> "C.Array":
+    c = torch.as_tensor(c2w, dtype=torch.float32).detach().cpu().reshape(-1)
+    if c.numel() < 12:
+        raise ValueError("c2w must hold at least (3,4) values")
+    return (C.c_float * 12)(*c[:12].tolist())
+
+
+# ------------------------------------------------------------------ R1/R2 ray generation
+def raygen(c2w, H: int, W: int, focal: float, pix_begin: int = 0, pix_end: int | None = None, device=None):
+    """Fused get_ray_directions + get_rays for row-major pixels [pix_begin, pix_end).
+    Returns (rays_o, viewdirs) with shapes (n,3); the reference's rays_d is the same tensor as viewdirs."""
+    pix_end = H * W if pix_end is None else pix_end
+    n = pix_end - pix_begin
+    dev = torch.device("cuda") if device is None else torch.device(device)
+    rays_o = torch.empty((n, 3), dtype=torch.float32, device=dev)
+    viewdirs = torch.empty((n, 3), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        check(lib.aon_raygen(_c2w_host(c2w), H, W, float(focal), pix_begin, pix_end, _ptr(rays_o), _ptr(viewdirs), None,
+                             _stream()), "aon_raygen")
+    return rays_o, viewdirs
+
+
+def ray_directions(H: int, W: int, focal: float, device=None):
+    dev = torch.device("cuda") if device is None else torch.device(device)
+    out = torch.empty((H, W, 3), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        check(lib.aon_ray_directions(H, W, float(focal), _ptr(out), _stream()), "aon_ray_directions")
+    return out
+
+
+def get_rays(directions: torch.Tensor, c2w):
+    d = _f32(directions, "directions")
+    n = d.numel() // 3
+    rays_o = torch.empty((n, 3), dtype=torch.float32, device=d.device)
+    viewdirs = torch.empty((n, 3), dtype=torch.float32, device=d.device)
+    with torch.cuda.device(d.device):
+        check(lib.aon_get_rays(_ptr(d), _c2w_host(c2w), n, _ptr(rays_o), _ptr(viewdirs), None, _stream()), "aon_get_rays")
+    return rays_o, viewdirs
+
+
+# ------------------------------------------------------------------ R3 sampling
+def cast_rays(t_vals, origins, directions):
+    t, o, d = _f32(t_vals, "t_vals"), _f32(origins, "origins"), _f32(directions, "directions")
+    n, S = t.shape
+    coords = torch.empty((n, S, 3), dtype=torch.float32, device=t.device)
+    with torch.cuda.device(t.device):
+        check(lib.aon_cast_rays(_ptr(t), _ptr(o), _ptr(d), n, S, _ptr(coords), _stream()), "aon_cast_rays")
+    return coords
+
+
+def sample_along_rays(rays_o, rays_d, num_samples: int, near: float, far: float, t_rand=None, want_coords=True):
+    o, d = _f32(rays_o, "rays_o"), _f32(rays_d, "rays_d")
+    n, S = o.shape[0], num_samples + 1
+    tr = None if t_rand is None else _f32(t_rand, "t_rand")
+    if tr is not None and tuple(tr.shape) != (n, S):
+        raise ValueError(f"t_rand must be ({n},{S}), got {tuple(tr.shape)}")
+    t_vals = torch.empty((n, S), dtype=torch.float32, device=o.device)
+    coords = torch.empty((n, S, 3), dtype=torch.float32, device=o.device) if want_coords else None
+    with torch.cuda.device(o.device):
+        check(lib.aon_sample_along_rays(_ptr(o), _ptr(d), n, S, float(near), float(far), _ptr(tr), _ptr(t_vals), _ptr(coords),
+                                        _stream()), "aon_sample_along_rays")
+    return t_vals, coords
+
+
+# ------------------------------------------------------------------ R4 positional encoding (stage-level)
+def pos_enc(x, min_deg: int, max_deg: int):
+    xc = _f32(x, "x")
+    if xc.shape[-1] != 3:
+        raise ValueError("pos_enc expects (...,3)")
+    n = xc.numel() // 3
+    F = 3 + 6 * (max_deg - min_deg)
+    out = torch.empty((*xc.shape[:-1], F), dtype=torch.float32, device=xc.device)
+    with torch.cuda.device(xc.device):
+        check(lib.aon_pos_enc(_ptr(xc), n, min_deg, max_deg, _ptr(out), _stream()), "aon_pos_enc")
+    return out
+
+
+# ------------------------------------------------------------------ R5 MLP
+VANILLA_PARAM_ORDER = (
+    [f"pts_linears.{i}.{k}" for i in range(8) for k in ("weight", "bias")]
+    + [f"{m}.{k}" for m in ("views_linear.0", "bottleneck_layer", "density_layer", "rgb_layer") for k in ("weight", "bias")]
+)
+VANILLA_PARAM_SHAPES = {
+    "pts_linears.0.weight": (256, 63), "pts_linears.5.weight": (256, 319), "views_linear.0.weight": (128, 283),
+    "bottleneck_layer.weight": (256, 256), "density_layer.weight": (1, 256), "rgb_layer.weight": (3, 128),
+    "views_linear.0.bias": (128,), "bottleneck_layer.bias": (256,), "density_layer.bias": (1,), "rgb_layer.bias": (3,),
+}
+for _i in (1, 2, 3, 4, 6, 7):
+    VANILLA_PARAM_SHAPES[f"pts_linears.{_i}.weight"] = (256, 256)
+for _i in range(8):
+    VANILLA_PARAM_SHAPES[f"pts_linears.{_i}.bias"] = (256,)
+
+
+def packed_bytes() -> int:
+    return int(lib.aon_mlp_packed_bytes())
+
+
+def pack_vanilla_mlp(params: dict, out: torch.Tensor | None = None) -> torch.Tensor:
+    """params: name -> tensor with the reference's NeRFMLP parameter names (no prefix).  Returns the packed
+    uint8 weight stream consumed by mlp_fwd / render_fwd (re-pack whenever the parameters change)."""
+    tensors = []
+    for name in VANILLA_PARAM_ORDER:
+        t = _f32(params[name].detach(), name)
+        if tuple(t.shape) != VANILLA_PARAM_SHAPES[name]:
+            raise ValueError(f"{name}: shape {tuple(t.shape)} != {VANILLA_PARAM_SHAPES[name]} (only the reference's default "
+                             "NeRFMLP geometry has a HIP kernel)")
+        tensors.append(t)
+    dev = tensors[0].device
+    if out is None:
+        out = torch.empty(packed_bytes(), dtype=torch.uint8, device=dev)
+    arr = (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+    with torch.cuda.device(dev):
+        check(lib.aon_pack_vanilla_mlp(arr, _ptr(out), _stream()), "aon_pack_vanilla_mlp")
+    return out
+
+
+def mlp_fwd(packed, rays_o, rays_d, viewdirs, t_vals):
+    """cast_rays + pos_enc + NeRFMLP.forward fused.  Returns raw (n,S,4) = (raw_rgb, raw_density)."""
+    o, d, v, t = _f32(rays_o, "rays_o"), _f32(rays_d, "rays_d"), _f32(viewdirs, "viewdirs"), _f32(t_vals, "t_vals")
+    n, S = t.shape
+    raw = torch.empty((n, S, 4), dtype=torch.float32, device=t.device)
+    with torch.cuda.device(t.device):
+        check(lib.aon_mlp_fwd(_ptr(packed), _ptr(o), _ptr(d), _ptr(v), _ptr(t), n, S, _ptr(raw), _stream()), "aon_mlp_fwd")
+    return raw
+
+
+def mlp_fwd_enc(packed, samples_enc, viewdirs_enc):
+    x, c = _f32(samples_enc, "samples_enc"), _f32(viewdirs_enc, "viewdirs_enc")
+    n, S, F = x.shape
+    if F != 63 or tuple(c.shape) != (n, 27):
+        raise ValueError("mlp_fwd_enc expects samples_enc (n,S,63) and viewdirs_enc (n,27)")
+    raw = torch.empty((n, S, 4), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        check(lib.aon_mlp_fwd_enc(_ptr(packed), _ptr(x), _ptr(c), n, S, _ptr(raw), _stream()), "aon_mlp_fwd_enc")
+    return raw
+
+
+# ------------------------------------------------------------------ R8 compositing
+def _composite(rgb_t, rgb_stride, sig_t, sig_off, sig_stride, t_vals, dirs, white_bkgd, act, want_weights):
+    t, d = _f32(t_vals, "t_vals"), _f32(dirs, "dirs")
+    n, S = t.shape
+    dev = t.device
+    comp = torch.empty((n, 3), dtype=torch.float32, device=dev)
+    acc = torch.empty((n,), dtype=torch.float32, device=dev)
+    depth = torch.empty((n,), dtype=torch.float32, device=dev)
+    weights = torch.empty((n, S), dtype=torch.float32, device=dev) if want_weights else None
+    sig_ptr = C.c_void_p(sig_t.data_ptr() + 4 * sig_off)
+    with torch.cuda.device(dev):
+        check(lib.aon_composite(_ptr(rgb_t), rgb_stride, sig_ptr, sig_stride, _ptr(t), _ptr(d), n, S, int(bool(white_bkgd)), act,
+                                _ptr(comp), _ptr(acc), _ptr(depth), _ptr(weights), _stream()), "aon_composite")
+    return comp, acc, weights, depth
+
+
+def volumetric_rendering(rgb, density, t_vals, dirs, white_bkgd):
+    """helper.volumetric_rendering on activated rgb (n,S,3) / density (n,S,1)."""
+    r, s = _f32(rgb, "rgb"), _f32(density, "density")
+    return _composite(r, 3, s, 0, 1, t_vals, dirs, white_bkgd, ACT_NONE, True)
+
+
+def composite_raw(raw, t_vals, dirs, white_bkgd, act=ACT_VANILLA, want_weights=True):
+    """Activation + compositing of the fused kernel's packed raw (n,S,4)."""
+    r = _f32(raw, "raw")
+    return _composite(r, 4, r, 3, 4, t_vals, dirs, white_bkgd, act, want_weights)
+
+
+# ------------------------------------------------------------------ R6/R7 inverse CDF
+_U_CACHE: dict = {}
+
+
+def deterministic_u(device) -> torch.Tensor:
+    """helper.py:229: torch.linspace(0, 1 - 2**-32, 128) (fp32; the last element rounds to exactly 1.0).
+    Computed once on the host and copied, so it is the same vector the reference builds."""
+    key = str(device)
+    if key not in _U_CACHE:
+        _U_CACHE[key] = torch.linspace(0.0, 1.0 - 2.0 ** -32, 128).to(device)
+    return _U_CACHE[key]
+
+
+def _u_args(u, n, device):
+    if u is None:
+        return deterministic_u(device), 0
+    uu = _f32(u, "u")
+    if tuple(uu.shape) == (128,):
+        return uu, 0
+    if tuple(uu.shape) != (n, 128):
+        raise ValueError(f"u must be (128,) or ({n},128), got {tuple(uu.shape)}")
+    return uu, 128
+
+
+def sorted_piecewise_constant_pdf(bins, weights, u=None):
+    b, w = _f32(bins, "bins"), _f32(weights, "weights")
+    n = b.shape[0]
+    if tuple(b.shape) != (n, 64) or tuple(w.shape) != (n, 63):
+        raise ValueError("HIP inverse-CDF is fixed to the reference geometry: bins (n,64), weights (n,63)")
+    uu, us = _u_args(u, n, b.device)
+    samples = torch.empty((n, 128), dtype=torch.float32, device=b.device)
+    with torch.cuda.device(b.device):
+        check(lib.aon_sample_pdf(_ptr(b), _ptr(w), 63, None, _ptr(uu), us, n, _ptr(samples), None, _stream()), "aon_sample_pdf")
+    return samples
+
+
+def sample_pdf_t(t_coarse, coarse_weights, u=None, bins=None):
+    """t_fine (n,193) = sort(cat[t_coarse, inverse-CDF samples]) from the full coarse weights (n,65)
+    (the pdf uses weights[...,1:-1]) -- or from explicit (bins (n,64), weights (n,63))."""
+    t = _f32(t_coarse, "t_coarse")
+    w = _f32(coarse_weights, "weights")
+    n = t.shape[0]
+    if tuple(t.shape) != (n, 65):
+        raise ValueError("t_coarse must be (n,65)")
+    if tuple(w.shape) == (n, 65):
+        w_ptr, w_stride = C.c_void_p(w.data_ptr() + 4), 65
+    elif tuple(w.shape) == (n, 63):
+        w_ptr, w_stride = _ptr(w), 63
+    else:
+        raise ValueError("weights must be (n,65) or (n,63)")
+    b = None if bins is None else _f32(bins, "bins")
+    uu, us = _u_args(u, n, t.device)
+    t_fine = torch.empty((n, 193), dtype=torch.float32, device=t.device)
+    with torch.cuda.device(t.device):
+        check(lib.aon_sample_pdf(_ptr(b), w_ptr, w_stride, _ptr(t), _ptr(uu), us, n, None, _ptr(t_fine), _stream()), "aon_sample_pdf")
+    return t_fine
+
+
+# ------------------------------------------------------------------ R9 whole path
+_WS_CACHE: dict = {}
+MAX_CHUNK_RAYS = 65536  # rays rendered per internal chunk (bounds the workspace to ~290 MB)
+
+
+def _workspace(device, n_rays: int) -> torch.Tensor:
+    need = int(lib.aon_render_workspace_bytes(min(n_rays, MAX_CHUNK_RAYS)))
+    key = str(device)
+    ws = _WS_CACHE.get(key)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, dtype=torch.uint8, device=device)
+        _WS_CACHE[key] = ws
+    return ws
+
+
+def render_fwd(packed_coarse, packed_fine, rays_o, rays_d, viewdirs, near, far, white_bkgd, num_levels=2, t_rand=None, u=None):
+    """NeRF.forward: returns [(rgb, acc, depth)_coarse, (rgb, acc, depth)_fine] (fine omitted if num_levels == 1)."""
+    o, d, v = _f32(rays_o, "rays_o"), _f32(rays_d, "rays_d"), _f32(viewdirs, "viewdirs")
+    n, dev = o.shape[0], o.device
+    tr = None if t_rand is None else _f32(t_rand, "t_rand")
+    if tr is not None and tuple(tr.shape) != (n, 65):
+        raise ValueError(f"t_rand must be ({n},65)")
+    uu, us = _u_args(u, n, dev) if num_levels == 2 else (None, 0)
+    outs = []
+    for _ in range(num_levels):
+        outs.append((torch.empty((n, 3), dtype=torch.float32, device=dev), torch.empty((n,), dtype=torch.float32, device=dev),
+                     torch.empty((n,), dtype=torch.float32, device=dev)))
+    fine = outs[1] if num_levels == 2 else (None, None, None)
+    ws = _workspace(dev, n)
+    with torch.cuda.device(dev):
+        check(lib.aon_render_fwd(_ptr(packed_coarse), _ptr(packed_fine), _ptr(o), _ptr(d), _ptr(v), n, float(near), float(far),
+                                 int(bool(white_bkgd)), num_levels, _ptr(tr), _ptr(uu), us,
+                                 _ptr(outs[0][0]), _ptr(outs[0][1]), _ptr(outs[0][2]), _ptr(fine[0]), _ptr(fine[1]), _ptr(fine[2]),
+                                 _ptr(ws), ws.numel(), _stream()), "aon_render_fwd")
+    return outs
+
+
+# ------------------------------------------------------------------ measurement aid
+def profile_begin() -> None:
+    check(lib.aon_profile_begin(), "aon_profile_begin")
+
+
+def profile_end():
+    """-> (mlp_kernel_ms_total, launches, samples) for the fused-MLP launches since profile_begin()."""
+    ms, launches, samples = C.c_double(0), C.c_int64(0), C.c_int64(0)
+    check(lib.aon_profile_end(C.byref(ms), C.byref(launches), C.byref(samples)), "aon_profile_end")
+    return ms.value, launches.value, samples.value

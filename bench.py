@@ -1,0 +1,157 @@
+"""Benchmark of the hot path: full-frame NeRF render throughput in rays/s (65 coarse + 193 fine network
+evaluations per ray), BASELINE.json's metric on its config 2 (Sapien single-scene 640x480, 1x MI355X), and the
+weak-scaled multi-GPU form of it (config 3: every rank renders a 640x480 frame of ray batches, rendered pixels
+are exchanged with one RCCL all-gather).
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One step = one pass of NeRF.forward over one synthetic 307,200-ray frame per GPU, inputs already resident in HBM.
+Prints ONE JSON line (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FLOP_PER_SAMPLE = 1_186_816          # reference-literal MACs x 2 of one NeRFMLP evaluation
+EVALS_PER_RAY = 65 + 193
+PEAK_FP32_MATRIX_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense fp32 matrix peak
+
+
+def cpu_baseline(sd, rays_cpu, budget_s=20.0):
+    """The oracle (plain-PyTorch restatement of the reference path) timed on the host cores on a bounded sample:
+    reference-sized chunks of 3840 rays (opt.py:103) of the same frame, one small warm-up, then chunks until
+    ~budget_s seconds have been spent (at least one, at most five)."""
+    from oracle import nerf_oracle as orc
+
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    n = rays_cpu["rays_o"].shape[0]
+    chunk = 3840
+    with torch.no_grad():
+        warm = {k: v[:256] for k, v in rays_cpu.items()}
+        orc.nerf_forward(sd, warm, False, True, 2.0, 6.0)
+        done, t0, outs, starts = 0, time.perf_counter(), [], []
+        start = n // 2 - chunk  # middle of the frame: rays that actually hit the scene volume
+        while done < 5:
+            s = start + done * chunk
+            sl = {k: v[s:s + chunk] for k, v in rays_cpu.items()}
+            outs.append(orc.nerf_forward(sd, sl, False, True, 2.0, 6.0)[1][0])
+            starts.append(s)
+            done += 1
+            if time.perf_counter() - t0 > budget_s:
+                break
+        dt = time.perf_counter() - t0
+    return {"value": done * chunk / dt, "unit": "rays/s", "cores": threads, "kind": "port",
+            "sample": f"{done} x 3840-ray chunks of the same 640x480 frame, fp32, torch {torch.__version__} CPU, {dt:.1f} s"}, \
+        torch.cat(outs), (starts[0], starts[0] + done * chunk)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--height", type=int, default=480)
+    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    import aon_amd.synthetic as syn
+    from aon_amd import ops
+    from aon_amd.datasets.ray_utils import get_frame_rays
+    from aon_amd.models.vanilla_nerf.model import NeRF
+    from aon_amd.parallel import all_gather_pixels
+
+    H, W = args.height, args.width
+    n_rays = H * W
+    sd = syn.make_nerf_state_dict(seed=0, density_scale=30.0)
+    model = NeRF().to(dev)
+    model.load_state_dict(sd)
+    # weak scaling: rank r renders its own frame (pose r of a ring around the object)
+    c2w = syn.look_at_pose(4.0, 30.0 + 45.0 * rank, 30.0)
+    rays_o, viewdirs = get_frame_rays(H, W, syn.focal_from_fovy(H), c2w, device=dev)
+    rays = {"rays_o": rays_o, "rays_d": viewdirs, "viewdirs": viewdirs}
+
+    def step():
+        out = model(rays, False, True, syn.NEAR, syn.FAR)
+        if world > 1:
+            return all_gather_pixels(out[1])
+        return out[1]
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            step()
+        fence()
+        ops.profile_begin()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            fine = step()
+        fence()
+        dt = time.perf_counter() - t0
+        mlp_ms, mlp_launches, mlp_samples = ops.profile_end()
+
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = t.item()
+
+    if rank == 0:
+        rays_per_s = world * n_rays * args.steps / dt
+        mlp_tflops = mlp_samples * FLOP_PER_SAMPLE / (mlp_ms * 1e-3) / 1e12 if mlp_ms > 0 else 0.0
+        res = {
+            "metric": "rays/sec (64c+128f samples)", "value": rays_per_s, "unit": "rays/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"sapien-single-scene vanilla NeRF full-frame render {W}x{H}, 65 coarse + 193 fine evals/ray, "
+                                   f"{n_rays} rays per GPU per step, randomized=False, white_bkgd=True",
+                       "rays_per_gpu": n_rays, "evals_per_ray": EVALS_PER_RAY,
+                       "exchange": "RCCL all_gather of (rgb,acc,depth)=20 B/ray" if world > 1 else "none"},
+            "roofline": {"bound": "mfma", "kernel": "aon::mlp_fwd_kernel<true> (fused encode+MLP, fp32 MFMA)",
+                         "achieved": mlp_tflops, "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
+                         "frac": mlp_tflops / PEAK_FP32_MATRIX_TFLOPS, "traffic": None,
+                         "launches": mlp_launches, "avg_launch_ms": mlp_ms / max(mlp_launches, 1),
+                         "flop_per_sample": FLOP_PER_SAMPLE,
+                         "whole_path_frac": rays_per_s / world * EVALS_PER_RAY * FLOP_PER_SAMPLE / (PEAK_FP32_MATRIX_TFLOPS * 1e12)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            rays_cpu = {k: v.cpu() for k, v in rays.items()}
+            base, ref_rgb, (a, b) = cpu_baseline(sd, rays_cpu)
+            res["cpu_baseline"] = base
+            mse = torch.mean((fine[0][a:b].cpu() - ref_rgb) ** 2).item()
+            res["psnr_vs_oracle_db"] = float(-10.0 * torch.log10(torch.tensor(max(mse, 1e-20))))
+            res["speedup_vs_cpu"] = rays_per_s / base["value"]
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

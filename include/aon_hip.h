@@ -1,0 +1,131 @@
+/* aon_hip.h -- C ABI of libaon_hip.so, the MI355X (gfx950) NeRF volume-rendering hot path.
+ *
+ * The reference (zubair-irshad/articulated-object-nerf) is 100 % Python and has no FFI of its own: the boundary
+ * it offers is `NeRF.forward(rays, randomized, white_bkgd, near, far)` (models/vanilla_nerf/model.py:147-199)
+ * and the free functions of models/vanilla_nerf/helper.py.  Each entry point below replaces one of those
+ * functions (cited per declaration); the Python host side in articulated-object-nerf_amd/ binds them with ctypes and
+ * re-exposes the reference's names and signatures (INTEGRATION.md shows the binding a maintainer would add).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to contiguous row-major fp32 unless the parameter is marked `host`;
+ *   - nothing is allocated, freed or synchronised inside: outputs and workspace are caller-owned, launches are
+ *     enqueued on `stream` (a hipStream_t passed as void*; NULL = the default stream) and return immediately;
+ *   - inputs are never written;
+ *   - return value: 0 = success, negative = failure (AON_E_* below, or -(hipError_t) - 1000 for a HIP error);
+ *     aon_last_error() returns a thread-local human-readable message for the last failure.
+ */
+#ifndef AON_HIP_H
+#define AON_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AON_ABI_VERSION 1
+
+#define AON_OK 0
+#define AON_E_INVALID (-1)    /* null pointer, negative size, unsupported geometry */
+#define AON_E_WORKSPACE (-2)  /* workspace too small */
+#define AON_E_HIP_BASE (-1000) /* HIP error e is reported as AON_E_HIP_BASE - e */
+
+/* activation applied to the raw network outputs inside aon_composite */
+#define AON_ACT_NONE 0     /* inputs already activated: helper.volumetric_rendering as is */
+#define AON_ACT_VANILLA 1  /* rgb = sigmoid(raw), sigma = relu(raw)                 model.py:186-187 */
+#define AON_ACT_ARTICULATED 2 /* rgb = sigmoid(raw)*1.002-0.001, sigma = softplus(raw-1)  model_autodecoder.py:321-323 */
+
+int aon_abi_version(void);
+const char* aon_last_error(void);
+
+/* ---- R1+R2  datasets/ray_utils.py:71-90 (get_ray_directions) + :118-159 (get_rays, output_view_dirs=True) ----
+ * Generates the rays of row-major pixels [pix_begin, pix_end) of an HxW pinhole frame: no +0.5 pixel centre,
+ * OpenGL camera (looks down -z).  c2w: HOST pointer to 12 floats, row-major (3,4).  Writes rays_o (n,3) and the
+ * unit-norm viewdirs (n,3); rays_d (n,3) may be NULL (the reference's rays_d is the same storage as viewdirs). */
+int aon_raygen(const float* c2w_host, int H, int W, float focal, int64_t pix_begin, int64_t pix_end,
+               float* rays_o, float* viewdirs, float* rays_d, void* stream);
+
+/* get_ray_directions alone (ray_utils.py:71-90): directions (H*W,3), un-normalised camera-space. */
+int aon_ray_directions(int H, int W, float focal, float* directions, void* stream);
+
+/* get_rays on caller-supplied camera-space directions (ray_utils.py:118-159): directions (n,3) -> rays_o,
+ * viewdirs (unit), rays_d (may be NULL). */
+int aon_get_rays(const float* directions, const float* c2w_host, int64_t n, float* rays_o, float* viewdirs,
+                 float* rays_d, void* stream);
+
+/* helper.cast_rays (helper.py:25-26): coords (n,S,3) = origins[:,None,:] + t_vals[...,None] * directions[:,None,:] */
+int aon_cast_rays(const float* t_vals, const float* origins, const float* directions, int64_t n_rays, int S,
+                  float* coords, void* stream);
+
+/* ---- R3  helper.sample_along_rays (helper.py:106-133, lindisp=False) + helper.cast_rays (:25-26) ----
+ * S = num_samples + 1 t-values per ray.  t_rand (n,S) replaces the reference's torch.rand draw when the
+ * caller wants randomized=True; NULL = deterministic.  coords (n,S,3) may be NULL. */
+int aon_sample_along_rays(const float* rays_o, const float* rays_d, int64_t n_rays, int S, float near_, float far_,
+                          const float* t_rand, float* t_vals, float* coords, void* stream);
+
+/* ---- R4  helper.pos_enc (helper.py:136-140), stage-level ----  x (n,3) -> out (n, 3 + 6*(max_deg-min_deg)) */
+int aon_pos_enc(const float* x, int64_t n, int min_deg, int max_deg, float* out, void* stream);
+
+/* ---- R5  NeRFMLP weights (models/vanilla_nerf/model.py:39-93) ----
+ * params: HOST array of 24 DEVICE pointers to the unmodified nn.Linear storages ((out,in) row-major), order:
+ *   pts_linears.{0..7}.{weight,bias}, views_linear.0.{weight,bias}, bottleneck_layer.{weight,bias},
+ *   density_layer.{weight,bias}, rgb_layer.{weight,bias}.
+ * Re-run whenever the parameters change; `packed` needs aon_mlp_packed_bytes() bytes, 16-byte aligned. */
+int64_t aon_mlp_packed_bytes(void);
+int aon_pack_vanilla_mlp(const float* const* params_host, void* packed, void* stream);
+
+/* ---- R3(cast)+R4+R5  cast_rays + pos_enc + NeRFMLP.forward fused (model.py:175-181 -> :95-120) ----
+ * raw (n*S,4) = (raw_rgb[3], raw_density) per sample, before the sigmoid/relu of model.py:186-187. */
+int aon_mlp_fwd(const void* packed, const float* rays_o, const float* rays_d, const float* viewdirs,
+                const float* t_vals, int64_t n_rays, int S, float* raw, void* stream);
+
+/* ---- R5  NeRFMLP.forward(x, condition) on caller-encoded inputs (model.py:95-120), stage-level ----
+ * samples_enc (n,S,63), viewdirs_enc (n,27). */
+int aon_mlp_fwd_enc(const void* packed, const float* samples_enc, const float* viewdirs_enc, int64_t n_rays, int S,
+                    float* raw, void* stream);
+
+/* ---- R8  helper.volumetric_rendering (helper.py:157-195) ----
+ * rgb / sigma are addressed as rgb[g*rgb_stride + c], sigma[g*sigma_stride] for sample g = ray*S + s, so both
+ * the reference's separate (n,S,3)/(n,S,1) tensors (strides 3,1) and the fused kernel's packed raw (n*S,4)
+ * (rgb = raw, sigma = raw+3, strides 4,4) can be composited.  weights (n,S) may be NULL.
+ * depth: NaN -> +inf (helper.py:182); the clamp to the batch's own [min,max] (:183) is an identity. */
+int aon_composite(const float* rgb, int rgb_stride, const float* sigma, int sigma_stride, const float* t_vals,
+                  const float* dirs, int64_t n_rays, int S, int white_bkgd, int act, float* comp_rgb, float* acc,
+                  float* depth, float* weights, void* stream);
+
+/* ---- R6+R7  helper.sorted_piecewise_constant_pdf (helper.py:203-243) and helper.sample_pdf (:246-252) ----
+ * Fixed to the reference geometry: 64 bins, 63 weights, 128 new samples, 65 coarse t's -> 193 sorted t's.
+ *   bins     (n,64) or NULL (then bins = mid-points of t_coarse, model.py:163)
+ *   weights  pointer to the first of ray 0's 63 weights; w_stride floats between rays (63 dense, or 65 with
+ *            weights = coarse_weights + 1 for the reference's weights[..., 1:-1], model.py:166)
+ *   t_coarse (n,65); may be NULL when only `samples` is requested
+ *   u        the uniform draws: (128,) shared by all rays when u_stride == 0 (randomized=False: pass
+ *            torch.linspace(0, 1-2^-32, 128), helper.py:229), else (n,128) with u_stride = 128
+ *   samples  (n,128) unsorted draws, or NULL;   t_fine (n,193) sorted union with t_coarse, or NULL */
+int aon_sample_pdf(const float* bins, const float* weights, int64_t w_stride, const float* t_coarse, const float* u,
+                   int64_t u_stride, int64_t n_rays, float* samples, float* t_fine, void* stream);
+
+/* ---- R9  NeRF.forward (model.py:147-199): the whole path in one call ----
+ * num_levels 1 (coarse only) or 2.  t_rand (n,65) / u as above, NULL t_rand = randomized False (then u must be
+ * the deterministic (128,) vector with u_stride 0).  Outputs: per level comp_rgb (n,3), acc (n,), depth (n,);
+ * the *_f pointers may be NULL when num_levels == 1.  The call is chunked internally so that any workspace of
+ * at least aon_render_workspace_bytes(1) works; aon_render_workspace_bytes(n) avoids chunking. */
+int64_t aon_render_workspace_bytes(int64_t n_rays);
+int aon_render_fwd(const void* packed_coarse, const void* packed_fine, const float* rays_o, const float* rays_d,
+                   const float* viewdirs, int64_t n_rays, float near_, float far_, int white_bkgd, int num_levels,
+                   const float* t_rand, const float* u, int64_t u_stride, float* rgb_c, float* acc_c,
+                   float* depth_c, float* rgb_f, float* acc_f, float* depth_f, void* workspace,
+                   int64_t workspace_bytes, void* stream);
+
+/* ---- measurement aid (no reference counterpart) ----
+ * Between aon_profile_begin() and aon_profile_end() every launch of the fused MLP kernel (the dominant kernel of
+ * the path) made through aon_mlp_fwd / aon_render_fwd is bracketed by HIP events recorded on the launch stream.
+ * aon_profile_end() waits for those events and returns the summed kernel time (ms), the number of launches and
+ * the number of samples (network evaluations) they covered. */
+int aon_profile_begin(void);
+int aon_profile_end(double* mlp_ms, int64_t* mlp_launches, int64_t* mlp_samples);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AON_HIP_H */

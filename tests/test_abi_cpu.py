@@ -1,0 +1,80 @@
+"""CPU: the C-ABI library loads and exports every symbol include/aon_hip.h declares; argument validation
+that needs no GPU; the package fails loudly when the library is absent."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "aon_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(aon_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from aon_amd import _lib
+
+    names = declared_symbols()
+    assert len(names) >= 18
+    for n in names:
+        assert hasattr(_lib.lib, n), f"{n} declared in aon_hip.h but not exported"
+    assert sorted(_lib.exported_symbols()) == names, "ctypes binding and header disagree"
+    assert _lib.lib.aon_abi_version() == 1
+
+
+def test_argument_validation_without_gpu():
+    from aon_amd import _lib
+
+    lib = _lib.lib
+    # null pointers / bad sizes are rejected before any HIP call
+    assert lib.aon_pos_enc(None, 4, 0, 10, None, None) == -1
+    assert b"null pointer" in lib.aon_last_error()
+    assert lib.aon_mlp_fwd(None, None, None, None, None, -1, 65, None, None) == -1
+    assert lib.aon_composite(None, 2, None, 1, None, None, 1, 65, 1, 0, None, None, None, None, None) == -1
+    assert lib.aon_sample_pdf(None, None, 10, None, None, 0, 1, None, None, None) == -1
+    assert lib.aon_render_fwd(None, None, None, None, None, 5, 2.0, 6.0, 1, 3, None, None, 0, None, None, None, None, None,
+                              None, None, 0, None) == -1
+    # empty problems are a successful no-op
+    assert lib.aon_pos_enc(None, 0, 0, 10, None, None) == 0
+    assert lib.aon_mlp_fwd(None, None, None, None, None, 0, 65, None, None) == 0
+    assert lib.aon_mlp_packed_bytes() == 2_375_680 + 3076 * 4
+    per_ray = (65 + 65 + 193 + 4 * 193) * 4
+    assert lib.aon_render_workspace_bytes(1000) >= 1000 * per_ray
+    assert lib.aon_render_workspace_bytes(1000) < 1000 * per_ray + 4 * 256 + 1
+
+
+def test_ops_reject_cpu_tensors():
+    import pytest
+    import torch
+
+    from aon_amd import ops
+
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.pos_enc(torch.zeros(2, 3), 0, 10)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.volumetric_rendering(torch.zeros(1, 65, 3), torch.zeros(1, 65, 1), torch.zeros(1, 65), torch.zeros(1, 3), True)
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    """A copy of the package without libaon_hip.so must refuse to import its binding (no silent fallback)."""
+    import shutil
+
+    pkg = tmp_path / "pkgcopy"
+    shutil.copytree(os.path.join(ROOT, "articulated-object-nerf_amd"), pkg,
+                    ignore=shutil.ignore_patterns("*.so", "build", "__pycache__"))
+    code = (
+        "import importlib.util, sys\n"
+        f"spec = importlib.util.spec_from_file_location('pk', r'{pkg}/__init__.py', submodule_search_locations=[r'{pkg}'])\n"
+        "m = importlib.util.module_from_spec(spec); sys.modules['pk'] = m; spec.loader.exec_module(m)\n"
+        "try:\n"
+        "    import pk.ops\n"
+        "except ImportError as e:\n"
+        "    print('LOUD:', e); sys.exit(0)\n"
+        "sys.exit(1)\n"
+    )
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "LOUD:" in r.stdout and "no CPU/eager fallback" in r.stdout, r.stdout + r.stderr
