@@ -35,6 +35,13 @@ _SIGS = {
     "aon_mlp_fwd_enc": (_i, [_p, _p, _p, _l, _i, _p, _p]),
     "aon_composite": (_i, [_p, _i, _p, _i, _p, _p, _l, _i, _i, _i, _p, _p, _p, _p, _p]),
     "aon_sample_pdf": (_i, [_p, _p, _l, _p, _p, _l, _l, _p, _p, _p]),
+    "aon_art_packed_bytes": (_l, []),
+    "aon_art_small_bytes": (_l, []),
+    "aon_pack_art_mlp": (_i, [_p, _p, _p]),
+    "aon_art_prepare": (_i, [_p, _p, _p, _p, _p, _p]),
+    "aon_art_mlp_fwd": (_i, [_p, _p, _p, _p, _p, _p, _l, _i, _p, _p]),
+    "aon_art_mlp_fwd_pos": (_i, [_p, _p, _p, _p, _l, _i, _p, _p]),
+    "aon_art_render_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _l, _f, _f, _i, _i, _p, _p, _l, _p, _p, _p, _p, _p, _p, _p, _l, _p]),
     "aon_profile_begin": (_i, []),
     "aon_profile_end": (_i, [C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "aon_render_workspace_bytes": (_l, [_l]),

@@ -13,6 +13,16 @@ hipError_t launch_mlp_fwd(const char* packed, const float* rays_o, const float* 
                           const float* t_vals, int64_t n_rays, int S, float* raw, hipStream_t stream);
 hipError_t launch_mlp_fwd_enc(const char* packed, const float* samples_enc, const float* viewdirs_enc, int64_t n_rays,
                               int S, float* raw, hipStream_t stream);
+hipError_t launch_pack_art(const float* const* params, float* packed, hipStream_t stream);
+hipError_t launch_prepare_art(const float* const* params, const float* shape, const float* app, const float* art,
+                              float* small, hipStream_t stream);
+hipError_t launch_art_mlp_fwd(const char* packed, const float* small, const float* rays_o, const float* rays_d,
+                              const float* viewdirs, const float* t_vals, int64_t n_rays, int S, float* raw,
+                              hipStream_t stream);
+hipError_t launch_art_mlp_fwd_pos(const char* packed, const float* small, const float* pos, const float* viewdirs_enc,
+                                  int64_t n_rays, int S, float* raw, hipStream_t stream);
+int64_t art_stream_bytes();
+int64_t art_small_bytes();
 hipError_t launch_raygen(const float* c2w, int H, int W, float focal, const float* directions, int64_t pix_begin,
                          int64_t pix_end, float* rays_o, float* viewdirs, float* rays_d, hipStream_t stream);
 hipError_t launch_ray_directions(int H, int W, float focal, float* out, hipStream_t stream);
@@ -234,19 +244,36 @@ int64_t aon_render_workspace_bytes(int64_t n_rays) {
   return carve(nullptr, n_rays).bytes;
 }
 
-int aon_render_fwd(const void* packed_coarse, const void* packed_fine, const float* rays_o, const float* rays_d,
-                   const float* viewdirs, int64_t n_rays, float near_, float far_, int white_bkgd, int num_levels,
-                   const float* t_rand, const float* u, int64_t u_stride, float* rgb_c, float* acc_c, float* depth_c,
-                   float* rgb_f, float* acc_f, float* depth_f, void* workspace, int64_t workspace_bytes, void* stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
-  if (n_rays < 0 || (num_levels != 1 && num_levels != 2)) return fail(AON_E_INVALID, "aon_render_fwd: bad size / num_levels");
+// Whole-path orchestration shared by the vanilla and the articulated network (NeRF.forward, model.py:147-199;
+// NeRF_AE_Art.forward, model_autodecoder.py:278-337): only the MLP launch and the output activation differ.
+struct NetRef {
+  bool articulated;
+  const void* packed;
+  const float* small;  // articulated only
+};
+
+static hipError_t launch_net(const NetRef& net, const float* o, const float* d, const float* v, const float* t, int64_t n, int S,
+                             float* raw, hipStream_t stream) {
+  MlpTimer timer(stream, n * S);
+  if (net.articulated)
+    return aon::launch_art_mlp_fwd(static_cast<const char*>(net.packed), net.small, o, d, v, t, n, S, raw, stream);
+  return aon::launch_mlp_fwd(static_cast<const char*>(net.packed), o, d, v, t, n, S, raw, stream);
+}
+
+static int render_impl(const char* who, const NetRef& coarse, const NetRef& fine, const float* rays_o, const float* rays_d,
+                       const float* viewdirs, int64_t n_rays, float near_, float far_, int white_bkgd, int num_levels,
+                       const float* t_rand, const float* u, int64_t u_stride, float* rgb_c, float* acc_c, float* depth_c,
+                       float* rgb_f, float* acc_f, float* depth_f, void* workspace, int64_t workspace_bytes, hipStream_t stream) {
+  if (n_rays < 0 || (num_levels != 1 && num_levels != 2)) return fail(AON_E_INVALID, "render: bad size / num_levels");
   if (n_rays == 0) return AON_OK;
-  if (!packed_coarse || !rays_o || !rays_d || !viewdirs || !rgb_c || !acc_c || !depth_c || !workspace)
-    return fail(AON_E_INVALID, "aon_render_fwd: null pointer");
-  if (num_levels == 2 && (!packed_fine || !rgb_f || !acc_f || !depth_f || !u))
-    return fail(AON_E_INVALID, "aon_render_fwd: null fine-level pointer");
-  if (num_levels == 2 && u_stride != 0 && u_stride < 128) return fail(AON_E_INVALID, "aon_render_fwd: bad u_stride");
-  if (reinterpret_cast<uintptr_t>(workspace) & 255) return fail(AON_E_INVALID, "aon_render_fwd: workspace must be 256-byte aligned");
+  if (!coarse.packed || !rays_o || !rays_d || !viewdirs || !rgb_c || !acc_c || !depth_c || !workspace)
+    return fail(AON_E_INVALID, "render: null pointer");
+  if (num_levels == 2 && (!fine.packed || !rgb_f || !acc_f || !depth_f || !u))
+    return fail(AON_E_INVALID, "render: null fine-level pointer");
+  if (coarse.articulated && (!coarse.small || (num_levels == 2 && !fine.small))) return fail(AON_E_INVALID, "render: null latent block");
+  if (num_levels == 2 && u_stride != 0 && u_stride < 128) return fail(AON_E_INVALID, "render: bad u_stride");
+  if (reinterpret_cast<uintptr_t>(workspace) & 255) return fail(AON_E_INVALID, "render: workspace must be 256-byte aligned");
+  const int act = coarse.articulated ? AON_ACT_ARTICULATED : AON_ACT_VANILLA;
 
   // largest chunk the workspace admits
   int64_t chunk = n_rays;
@@ -254,7 +281,7 @@ int aon_render_fwd(const void* packed_coarse, const void* packed_fine, const flo
     const int64_t per_ray = (kSc + kSc + kSf + 4 * kSf) * 4;
     chunk = (workspace_bytes - 4 * 256) / per_ray;
     while (chunk > 0 && carve(nullptr, chunk).bytes > workspace_bytes) --chunk;
-    if (chunk < 1) return fail(AON_E_WORKSPACE, "aon_render_fwd: workspace smaller than aon_render_workspace_bytes(1)");
+    if (chunk < 1) return fail(AON_E_WORKSPACE, "render: workspace smaller than aon_render_workspace_bytes(1)");
   }
   const Ws w = carve(static_cast<char*>(workspace), chunk);
 
@@ -265,32 +292,85 @@ int aon_render_fwd(const void* packed_coarse, const void* packed_fine, const flo
     const float* v = viewdirs + r0 * 3;
     int rc;
     // level 0 (model.py:150-160, :175-197)
-    rc = check(aon::launch_sample_along_rays(o, d, n, kSc, near_, far_, t_rand ? t_rand + r0 * kSc : nullptr, w.t_c, nullptr, stream),
-               "sample_along_rays");
+    rc = check(aon::launch_sample_along_rays(o, d, n, kSc, near_, far_, t_rand ? t_rand + r0 * kSc : nullptr, w.t_c, nullptr, stream), who);
     if (rc) return rc;
-    {
-      MlpTimer timer(stream, n * kSc);
-      rc = check(aon::launch_mlp_fwd(static_cast<const char*>(packed_coarse), o, d, v, w.t_c, n, kSc, w.raw, stream), "mlp_fwd(coarse)");
-    }
+    rc = check(launch_net(coarse, o, d, v, w.t_c, n, kSc, w.raw, stream), who);
     if (rc) return rc;
-    rc = check(aon::launch_composite(w.raw, 4, w.raw + 3, 4, w.t_c, d, n, kSc, white_bkgd, AON_ACT_VANILLA, rgb_c + r0 * 3,
-                                     acc_c + r0, depth_c + r0, num_levels == 2 ? w.w_c : nullptr, stream), "composite(coarse)");
+    rc = check(aon::launch_composite(w.raw, 4, w.raw + 3, 4, w.t_c, d, n, kSc, white_bkgd, act, rgb_c + r0 * 3, acc_c + r0,
+                                     depth_c + r0, num_levels == 2 ? w.w_c : nullptr, stream), who);
     if (rc) return rc;
     if (num_levels == 1) continue;
     // level 1 (model.py:162-173, :175-197)
     rc = check(aon::launch_sample_pdf(nullptr, w.w_c + 1, kSc, w.t_c, u_stride ? u + r0 * u_stride : u, u_stride, n, nullptr, w.t_f,
-                                      stream), "sample_pdf");
+                                      stream), who);
     if (rc) return rc;
-    {
-      MlpTimer timer(stream, n * kSf);
-      rc = check(aon::launch_mlp_fwd(static_cast<const char*>(packed_fine), o, d, v, w.t_f, n, kSf, w.raw, stream), "mlp_fwd(fine)");
-    }
+    rc = check(launch_net(fine, o, d, v, w.t_f, n, kSf, w.raw, stream), who);
     if (rc) return rc;
-    rc = check(aon::launch_composite(w.raw, 4, w.raw + 3, 4, w.t_f, d, n, kSf, white_bkgd, AON_ACT_VANILLA, rgb_f + r0 * 3,
-                                     acc_f + r0, depth_f + r0, nullptr, stream), "composite(fine)");
+    rc = check(aon::launch_composite(w.raw, 4, w.raw + 3, 4, w.t_f, d, n, kSf, white_bkgd, act, rgb_f + r0 * 3, acc_f + r0,
+                                     depth_f + r0, nullptr, stream), who);
     if (rc) return rc;
   }
   return AON_OK;
+}
+
+int aon_render_fwd(const void* packed_coarse, const void* packed_fine, const float* rays_o, const float* rays_d,
+                   const float* viewdirs, int64_t n_rays, float near_, float far_, int white_bkgd, int num_levels,
+                   const float* t_rand, const float* u, int64_t u_stride, float* rgb_c, float* acc_c, float* depth_c,
+                   float* rgb_f, float* acc_f, float* depth_f, void* workspace, int64_t workspace_bytes, void* stream) {
+  const NetRef c{false, packed_coarse, nullptr}, f{false, packed_fine, nullptr};
+  return render_impl("aon_render_fwd", c, f, rays_o, rays_d, viewdirs, n_rays, near_, far_, white_bkgd, num_levels, t_rand, u,
+                     u_stride, rgb_c, acc_c, depth_c, rgb_f, acc_f, depth_f, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+// ---- articulated network (model_autodecoder.py) ----
+int64_t aon_art_packed_bytes(void) { return aon::art_stream_bytes(); }
+int64_t aon_art_small_bytes(void) { return aon::art_small_bytes(); }
+
+int aon_pack_art_mlp(const float* const* params_host, void* packed, void* stream) {
+  if (!params_host || !packed) return fail(AON_E_INVALID, "aon_pack_art_mlp: null pointer");
+  for (int i = 0; i < 40; ++i)
+    if (!params_host[i]) return fail(AON_E_INVALID, "aon_pack_art_mlp: null parameter pointer");
+  if (reinterpret_cast<uintptr_t>(packed) & 15) return fail(AON_E_INVALID, "aon_pack_art_mlp: packed must be 16-byte aligned");
+  return check(aon::launch_pack_art(params_host, static_cast<float*>(packed), (hipStream_t)stream), "aon_pack_art_mlp");
+}
+
+int aon_art_prepare(const float* const* params_host, const float* shape, const float* appearance, const float* articulation,
+                    void* small, void* stream) {
+  if (!params_host || !shape || !appearance || !articulation || !small) return fail(AON_E_INVALID, "aon_art_prepare: null pointer");
+  for (int i = 0; i < 40; ++i)
+    if (!params_host[i]) return fail(AON_E_INVALID, "aon_art_prepare: null parameter pointer");
+  if (reinterpret_cast<uintptr_t>(small) & 15) return fail(AON_E_INVALID, "aon_art_prepare: small must be 16-byte aligned");
+  return check(aon::launch_prepare_art(params_host, shape, appearance, articulation, static_cast<float*>(small), (hipStream_t)stream),
+               "aon_art_prepare");
+}
+
+int aon_art_mlp_fwd(const void* packed, const void* small, const float* rays_o, const float* rays_d, const float* viewdirs,
+                    const float* t_vals, int64_t n_rays, int S, float* raw, void* stream) {
+  if (n_rays < 0 || S < 1) return fail(AON_E_INVALID, "aon_art_mlp_fwd: bad size");
+  if (n_rays == 0) return AON_OK;
+  if (!packed || !small || !rays_o || !rays_d || !viewdirs || !t_vals || !raw) return fail(AON_E_INVALID, "aon_art_mlp_fwd: null pointer");
+  MlpTimer timer((hipStream_t)stream, n_rays * S);
+  return check(aon::launch_art_mlp_fwd(static_cast<const char*>(packed), static_cast<const float*>(small), rays_o, rays_d, viewdirs,
+                                       t_vals, n_rays, S, raw, (hipStream_t)stream), "aon_art_mlp_fwd");
+}
+
+int aon_art_mlp_fwd_pos(const void* packed, const void* small, const float* pos, const float* viewdirs_enc, int64_t n_rays, int S,
+                        float* raw, void* stream) {
+  if (n_rays < 0 || S < 1) return fail(AON_E_INVALID, "aon_art_mlp_fwd_pos: bad size");
+  if (n_rays == 0) return AON_OK;
+  if (!packed || !small || !pos || !viewdirs_enc || !raw) return fail(AON_E_INVALID, "aon_art_mlp_fwd_pos: null pointer");
+  return check(aon::launch_art_mlp_fwd_pos(static_cast<const char*>(packed), static_cast<const float*>(small), pos, viewdirs_enc,
+                                           n_rays, S, raw, (hipStream_t)stream), "aon_art_mlp_fwd_pos");
+}
+
+int aon_art_render_fwd(const void* packed_coarse, const void* small_coarse, const void* packed_fine, const void* small_fine,
+                       const float* rays_o, const float* rays_d, const float* viewdirs, int64_t n_rays, float near_, float far_,
+                       int white_bkgd, int num_levels, const float* t_rand, const float* u, int64_t u_stride, float* rgb_c,
+                       float* acc_c, float* depth_c, float* rgb_f, float* acc_f, float* depth_f, void* workspace,
+                       int64_t workspace_bytes, void* stream) {
+  const NetRef c{true, packed_coarse, static_cast<const float*>(small_coarse)}, f{true, packed_fine, static_cast<const float*>(small_fine)};
+  return render_impl("aon_art_render_fwd", c, f, rays_o, rays_d, viewdirs, n_rays, near_, far_, white_bkgd, num_levels, t_rand, u,
+                     u_stride, rgb_c, acc_c, depth_c, rgb_f, acc_f, depth_f, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 }  // extern "C"

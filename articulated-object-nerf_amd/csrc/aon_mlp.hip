@@ -19,9 +19,14 @@
 //     read their A operands with conflict-free ds_read_b128 (4 MFMA steps per read).
 //   * per 128-sample pass a wave issues ~9.3k MFMAs (64 cycles each) against ~2.4k ds_read_b128 and a few
 //     hundred VALU ops (bias init, ReLU, heads), so the kernel is bound by the fp32 matrix pipe.
-#include "aon_common.h"
+#include "aon_mlp_core.h"
 
 namespace aon {
+
+struct VanillaNet {
+  static constexpr int kNumChunks = aon::kNumChunks;
+  static constexpr int chunk_bytes(int c) { return aon::chunk_bytes(c); }
+};
 
 // ---------------------------------------------------------------------------------------------
 // weight packing
@@ -29,23 +34,6 @@ namespace aon {
 struct PackArgs {
   const float* p[kNumVanillaParams];
 };
-
-__device__ __forceinline__ int posenc_col(int tile, int q, int cc, int h) {
-  // position of packed input (tile, reg r=4q+cc, half h) in the reference's 63-wide encoding
-  // [x(3) ; sin(2^l x) l-major (30) ; sin(2^l x + pi/2) (30)]   (helper.py:136-140)
-  const int rho = 16 * tile + 4 * q + cc;
-  if (rho < 30) return 3 + rho + 30 * h;
-  if (rho == 30) return h ? 2 : 0;
-  return h ? -1 : 1;
-}
-
-__device__ __forceinline__ int viewenc_col(int q, int cc, int h) {
-  const int rho = 4 * q + cc;  // 27-wide: [v(3) ; sin (12) ; sin(+pi/2) (12)]
-  if (rho < 12) return 3 + rho + 12 * h;
-  if (rho == 12) return h ? 2 : 0;
-  if (rho == 13) return h ? -1 : 1;
-  return -1;
-}
 
 __global__ void pack_vanilla_kernel(PackArgs a, float* __restrict__ packed) {
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -105,125 +93,7 @@ struct MlpArgs {
   int npass;                 // ceil(total/128)
 };
 
-constexpr int kRingBytes = 2 * kBigChunkBytes;
 constexpr int kLdsBytes = kRingBytes + (int)kSmallBytes;
-
-struct Pipe {
-  const char* stream;  // packed stream base (wave-uniform -> SGPR pair)
-  char* ring;          // LDS ring base
-  unsigned voff;       // this lane's byte offset inside a 4 KiB round: wave*1024 + lane*16
-  int wave_off;        // wave*1024
-  int lane_off;        // lane*16
-  int slot;            // slot holding the chunk being consumed
-  unsigned issue_off;  // byte offset (in the stream) of the next chunk to issue
-};
-
-typedef __attribute__((address_space(3))) void lds_void;
-typedef const __attribute__((address_space(1))) char gbl_char;
-
-// LDS-DMA one chunk: global (SGPR base + per-lane VGPR offset) -> LDS (M0 base + lane*16), 1 KiB per wave per
-// instruction.  The stream offset is kept as an opaque loop-carried scalar so that the several hundred
-// distinct chunk addresses are recomputed with one s_add instead of being hoisted out of the pass loop.
-template <int C>
-__device__ __forceinline__ void issue_chunk(Pipe& p, int slot) {
-  constexpr int rounds = chunk_bytes(C) / 4096;
-  unsigned off = p.issue_off;
-  asm volatile("" : "+s"(off));
-  gbl_char* src = (gbl_char*)(p.stream + off);
-  char* dst = p.ring + slot * kBigChunkBytes + p.wave_off;  // wave-uniform; hardware adds lane*16
-#pragma unroll
-  for (int r = 0; r < rounds; ++r) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + r * 4096 + p.voff),
-                                     (lds_void*)(dst + r * 4096), 16, 0, 0);
-  }
-  p.issue_off = (C == kNumChunks - 1) ? 0u : off + (unsigned)chunk_bytes(C);
-}
-
-// Wait for chunk C (DMA issued one chunk earlier), release the other slot, start streaming chunk C+1.
-template <int C>
-__device__ __forceinline__ void acquire(Pipe& p) {
-  __syncthreads();  // drains this wave's LDS-DMA (vmcnt(0)) + workgroup barrier
-  p.slot ^= 1;
-  issue_chunk<(C + 1) % kNumChunks>(p, p.slot ^ 1);
-}
-
-// out[Tp] += W_chunk[Tp] * in   for one 32-feature input tile held in accumulator layout.
-// The A-operand reads are software-pipelined one ds_read_b128 (= 4 MFMA steps, 256 matrix-pipe cycles) ahead.
-template <int C, int NT_OUT, int NREG>
-__device__ __forceinline__ void chunk_mma(Pipe& p, const f32x16& in, f32x16 (&out)[NT_OUT]) {
-  static_assert(chunk_bytes(C) == NT_OUT * 4096, "chunk/out-tile mismatch");
-  static_assert(NREG % 2 == 0 && NREG > 12, "register count");
-  acquire<C>(p);
-  const char* buf = p.ring + p.slot * kBigChunkBytes + p.lane_off;
-  constexpr int NQ = (NREG + 3) / 4;
-  constexpr int NSTEP = NQ * NT_OUT;
-  f32x4 a_cur = *reinterpret_cast<const f32x4*>(buf);
-#pragma unroll
-  for (int i = 0; i < NSTEP; ++i) {
-    const int q = i / NT_OUT, tp = i % NT_OUT;
-    f32x4 a_nxt = a_cur;
-    if (i + 1 < NSTEP) a_nxt = *reinterpret_cast<const f32x4*>(buf + (i + 1) * 1024);
-#pragma unroll
-    for (int cc = 0; cc < 4; ++cc) {
-      if (4 * q + cc < NREG) out[tp] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[cc], in[4 * q + cc], out[tp], 0, 0, 0);
-    }
-    a_cur = a_nxt;
-  }
-}
-
-template <int NT_OUT>
-__device__ __forceinline__ void init_bias(f32x16 (&acc)[NT_OUT], const float* sm_bias, int h) {
-#pragma unroll
-  for (int tp = 0; tp < NT_OUT; ++tp) {
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const f32x4 b = *reinterpret_cast<const f32x4*>(sm_bias + 32 * tp + 8 * g + 4 * h);
-      acc[tp][4 * g + 0] = b[0]; acc[tp][4 * g + 1] = b[1]; acc[tp][4 * g + 2] = b[2]; acc[tp][4 * g + 3] = b[3];
-    }
-  }
-}
-
-template <int NT>
-__device__ __forceinline__ void relu_tiles(f32x16 (&x)[NT]) {
-#pragma unroll
-  for (int t = 0; t < NT; ++t) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      float y;  // plain v_max_f32: fmaxf() would add a canonicalising v_max in front of the real one
-      asm("v_max_f32 %0, 0, %1" : "=v"(y) : "v"(x[t][r]));
-      x[t][r] = y;
-    }
-  }
-}
-
-// 256 -> 256 trunk layer, input/output both in accumulator layout.
-template <int CBASE>
-__device__ __forceinline__ void hidden_layer(Pipe& p, const f32x16 (&in)[8], f32x16 (&out)[8]) {
-  chunk_mma<CBASE + 0, 8, 16>(p, in[0], out);
-  chunk_mma<CBASE + 1, 8, 16>(p, in[1], out);
-  chunk_mma<CBASE + 2, 8, 16>(p, in[2], out);
-  chunk_mma<CBASE + 3, 8, 16>(p, in[3], out);
-  chunk_mma<CBASE + 4, 8, 16>(p, in[4], out);
-  chunk_mma<CBASE + 5, 8, 16>(p, in[5], out);
-  chunk_mma<CBASE + 6, 8, 16>(p, in[6], out);
-  chunk_mma<CBASE + 7, 8, 16>(p, in[7], out);
-}
-
-// per-lane partial of  w . x  over the features this lane holds (NT tiles of 32 features)
-template <int NT>
-__device__ __forceinline__ float head_partial(const f32x16 (&x)[NT], const float* sm_w, int h) {
-  float acc = 0.f;
-#pragma unroll
-  for (int t = 0; t < NT; ++t) {
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const f32x4 w = *reinterpret_cast<const f32x4*>(sm_w + 32 * t + 8 * g + 4 * h);
-#pragma unroll
-      for (int cc = 0; cc < 4; ++cc) acc = __builtin_fmaf(w[cc], x[t][4 * g + cc], acc);
-    }
-  }
-  return acc;
-}
 
 template <bool ENC_IN_KERNEL>
 __global__ void __launch_bounds__(256) mlp_fwd_kernel(MlpArgs args) {
@@ -248,7 +118,7 @@ __global__ void __launch_bounds__(256) mlp_fwd_kernel(MlpArgs args) {
   p.wave_off = wave * 1024;
   p.lane_off = lane * 16;
   p.slot = 1;  // acquire<0> flips to 0
-  issue_chunk<0>(p, 0);
+  issue_chunk<VanillaNet, 0>(p, 0);
 
   for (int pass = blockIdx.x; pass < args.npass; pass += gridDim.x) {
     const int64_t g = (int64_t)pass * 128 + wave * 32 + m;
@@ -267,73 +137,54 @@ __global__ void __launch_bounds__(256) mlp_fwd_kernel(MlpArgs args) {
         x[a] = __fadd_rn(args.rays_o[ray * 3 + a], __fmul_rn(t, args.rays_d[ray * 3 + a]));
         vd[a] = args.viewdirs[ray * 3 + a];
       }
-      const float phase = h ? AON_HALF_PI_F32 : 0.f;
-#pragma unroll
-      for (int rho = 0; rho < 30; ++rho) {
-        const float xb = __fmul_rn(x[rho % 3], (float)(1 << (rho / 3)));
-        E[rho >> 4][rho & 15] = sin_f32(__fadd_rn(xb, phase));
-      }
-      E[1][14] = h ? x[2] : x[0];
-      E[1][15] = h ? 0.f : x[1];
-#pragma unroll
-      for (int rho = 0; rho < 12; ++rho) {
-        const float xb = __fmul_rn(vd[rho % 3], (float)(1 << (rho / 3)));
-        V[rho] = sin_f32(__fadd_rn(xb, phase));
-      }
-      V[12] = h ? vd[2] : vd[0];
-      V[13] = h ? 0.f : vd[1];
-      V[14] = 0.f; V[15] = 0.f;
+      encode_pos(x, h, E);
+      encode_view(vd, h, V);
     } else {
       const float* se = args.samples_enc + gc * kPosEnc;
 #pragma unroll
       for (int rho = 0; rho < 30; ++rho) E[rho >> 4][rho & 15] = se[3 + rho + 30 * h];
       E[1][14] = h ? se[2] : se[0];
       E[1][15] = h ? 0.f : se[1];
-      const float* ve = args.viewdirs_enc + ray * kViewEnc;
-#pragma unroll
-      for (int rho = 0; rho < 12; ++rho) V[rho] = ve[3 + rho + 12 * h];
-      V[12] = h ? ve[2] : ve[0];
-      V[13] = h ? 0.f : ve[1];
-      V[14] = 0.f; V[15] = 0.f;
+      load_view_enc(args.viewdirs_enc + ray * kViewEnc, h, V);
     }
 
     f32x16 X[8], Y[8];
     // L0: enc(63) -> 256
     init_bias(X, sm + kSmBias + 0 * 256, h);
-    chunk_mma<kChL0 + 0, 8, 16>(p, E[0], X);
-    chunk_mma<kChL0 + 1, 8, 16>(p, E[1], X);
+    chunk_mma<VanillaNet, kChL0 + 0, 8, 16>(p, E[0], X);
+    chunk_mma<VanillaNet, kChL0 + 1, 8, 16>(p, E[1], X);
     relu_tiles(X);
     // L1..L4
-    init_bias(Y, sm + kSmBias + 1 * 256, h); hidden_layer<kChL1 + 0>(p, X, Y); relu_tiles(Y);
-    init_bias(X, sm + kSmBias + 2 * 256, h); hidden_layer<kChL1 + 8>(p, Y, X); relu_tiles(X);
-    init_bias(Y, sm + kSmBias + 3 * 256, h); hidden_layer<kChL1 + 16>(p, X, Y); relu_tiles(Y);
-    init_bias(X, sm + kSmBias + 4 * 256, h); hidden_layer<kChL1 + 24>(p, Y, X); relu_tiles(X);
+    init_bias(Y, sm + kSmBias + 1 * 256, h); dense_layer<VanillaNet, kChL1 + 0, 8, 8>(p, X, Y); relu_tiles(Y);
+    init_bias(X, sm + kSmBias + 2 * 256, h); dense_layer<VanillaNet, kChL1 + 8, 8, 8>(p, Y, X); relu_tiles(X);
+    init_bias(Y, sm + kSmBias + 3 * 256, h); dense_layer<VanillaNet, kChL1 + 16, 8, 8>(p, X, Y); relu_tiles(Y);
+    init_bias(X, sm + kSmBias + 4 * 256, h); dense_layer<VanillaNet, kChL1 + 24, 8, 8>(p, Y, X); relu_tiles(X);
     // L5: cat[h(256), enc(63)] -> 256     (model.py:102-103: concat after layer 4's ReLU)
     init_bias(Y, sm + kSmBias + 5 * 256, h);
-    hidden_layer<kChL5>(p, X, Y);
-    chunk_mma<kChL5 + 8, 8, 16>(p, E[0], Y);
-    chunk_mma<kChL5 + 9, 8, 16>(p, E[1], Y);
+    dense_layer<VanillaNet, kChL5, 8, 8>(p, X, Y);
+    chunk_mma<VanillaNet, kChL5 + 8, 8, 16>(p, E[0], Y);
+    chunk_mma<VanillaNet, kChL5 + 9, 8, 16>(p, E[1], Y);
     relu_tiles(Y);
     // L6, L7
-    init_bias(X, sm + kSmBias + 6 * 256, h); hidden_layer<kChL6>(p, Y, X); relu_tiles(X);
-    init_bias(Y, sm + kSmBias + 7 * 256, h); hidden_layer<kChL7>(p, X, Y); relu_tiles(Y);
+    init_bias(X, sm + kSmBias + 6 * 256, h); dense_layer<VanillaNet, kChL6, 8, 8>(p, Y, X); relu_tiles(X);
+    init_bias(Y, sm + kSmBias + 7 * 256, h); dense_layer<VanillaNet, kChL7, 8, 8>(p, X, Y); relu_tiles(Y);
     // density head (model.py:105) on the post-ReLU layer-7 output
     float sigma = head_partial<8>(Y, sm + kSmWSigma, h);
     sigma = sigma + __shfl_xor(sigma, 32) + sm[kSmBSigma];
     // bottleneck, no activation (model.py:109)
-    init_bias(X, sm + kSmBiasBott, h); hidden_layer<kChBott>(p, Y, X);
+    init_bias(X, sm + kSmBiasBott, h); dense_layer<VanillaNet, kChBott, 8, 8>(p, Y, X);
     // view branch: cat[bottleneck(256), viewenc(27)] -> 128, ReLU (model.py:110-116)
     f32x16 Z[4];
     init_bias(Z, sm + kSmBiasView, h);
-    chunk_mma<kChView + 0, 4, 16>(p, X[0], Z);
-    chunk_mma<kChView + 1, 4, 16>(p, X[1], Z);
-    chunk_mma<kChView + 2, 4, 16>(p, X[2], Z);
-    chunk_mma<kChView + 3, 4, 16>(p, X[3], Z);
-    chunk_mma<kChView + 4, 4, 16>(p, X[4], Z);
-    chunk_mma<kChView + 5, 4, 16>(p, X[5], Z);
-    chunk_mma<kChView + 6, 4, 16>(p, X[6], Z);
-    chunk_mma<kChView + 7, 4, 16>(p, X[7], Z);
-    chunk_mma<kChView + 8, 4, 14>(p, V, Z);
+    chunk_mma<VanillaNet, kChView + 0, 4, 16>(p, X[0], Z);
+    chunk_mma<VanillaNet, kChView + 1, 4, 16>(p, X[1], Z);
+    chunk_mma<VanillaNet, kChView + 2, 4, 16>(p, X[2], Z);
+    chunk_mma<VanillaNet, kChView + 3, 4, 16>(p, X[3], Z);
+    chunk_mma<VanillaNet, kChView + 4, 4, 16>(p, X[4], Z);
+    chunk_mma<VanillaNet, kChView + 5, 4, 16>(p, X[5], Z);
+    chunk_mma<VanillaNet, kChView + 6, 4, 16>(p, X[6], Z);
+    chunk_mma<VanillaNet, kChView + 7, 4, 16>(p, X[7], Z);
+    chunk_mma<VanillaNet, kChView + 8, 4, 14>(p, V, Z);
     relu_tiles(Z);
     // rgb head (model.py:118)
     float rgb[3];
@@ -361,8 +212,18 @@ hipError_t launch_pack_vanilla(const float* const* params, float* packed, hipStr
   return hipGetLastError();
 }
 
-static int g_num_cus = 0;
 static bool g_attr_set[2] = {false, false};
+
+int num_cus() {  // CUs of the current device (one process drives one GPU)
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return -1;
+    cus = prop.multiProcessorCount;
+  }
+  return cus;
+}
 
 template <bool ENC>
 static hipError_t launch_mlp_t(const MlpArgs& args, hipStream_t stream) {
@@ -372,15 +233,8 @@ static hipError_t launch_mlp_t(const MlpArgs& args, hipStream_t stream) {
     if (e != hipSuccess) return e;
     g_attr_set[ENC] = true;
   }
-  if (g_num_cus == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    hipError_t e = hipGetDevice(&dev);
-    if (e != hipSuccess) return e;
-    e = hipGetDeviceProperties(&prop, dev);
-    if (e != hipSuccess) return e;
-    g_num_cus = prop.multiProcessorCount;
-  }
+  const int g_num_cus = num_cus();
+  if (g_num_cus <= 0) return hipErrorInvalidDevice;
   const int grid = args.npass < g_num_cus ? args.npass : g_num_cus;
   if (grid <= 0) return hipSuccess;
   mlp_fwd_kernel<ENC><<<dim3(grid), dim3(256), kLdsBytes, stream>>>(args);

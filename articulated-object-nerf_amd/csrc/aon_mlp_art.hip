@@ -1,0 +1,341 @@
+// Fused articulated NeRFMLP forward for gfx950: deformation MLP -> positional encoding of the deformed point ->
+// latent-conditioned 8x256 trunk (+skip) -> sigma head, bottleneck -> 4x128 view branch -> rgb head.
+//
+// Replaces the reference's  models/vanilla_nerf/model_autodecoder.py:172-239 (NeRFMLP.forward with
+// deformation_mlp=True, enc_after=True) preceded by helper.cast_rays (helper.py:25-26).
+//
+// Same register-resident transposed-MFMA scheme as aon_mlp.hip (see its header).  What is specific here:
+//   * the three latents (shape 128, appearance 128, articulation 32) are broadcast to every sample by the
+//     reference (einops.repeat, :186-194), i.e. every weight column that multiplies a latent contributes a
+//     per-call constant.  aon_art_prepare folds those columns into effective bias vectors once per call
+//     (163->3, 191->63, 447->319, 411->283 effective K), so the kernel never touches them.
+//   * the 3->128 first deformation layer and the 128->3 deformation head are VALU work on register tiles;
+//     the deformed point is encoded in registers exactly like the vanilla path.
+#include "aon_mlp_core.h"
+
+namespace aon {
+
+// ---- chunk stream of one articulated MLP (execution order) ----
+constexpr int kAChD1 = 0;     // deformations_linear.1..3 : 4 chunks each, 4 output tiles (16 KiB)
+constexpr int kAChT0 = 12;    // pts_linears.0 : 2 pos-enc chunks (32 KiB)
+constexpr int kAChT1 = 14;    // pts_linears.1..4 : 8 chunks each
+constexpr int kAChT5 = 46;    // pts_linears.5 : 8 hidden + 2 pos-enc
+constexpr int kAChT6 = 56;
+constexpr int kAChT7 = 64;
+constexpr int kAChBott = 72;
+constexpr int kAChV0 = 80;    // views_linear.0 : 8 hidden + 1 view-enc, 4 output tiles (16 KiB)
+constexpr int kAChV1 = 89;    // views_linear.1..3 : 4 chunks each
+constexpr int kANumChunks = 101;
+
+struct ArtNet {
+  static constexpr int kNumChunks = kANumChunks;
+  static constexpr int chunk_bytes(int c) { return (c < kAChT0 || c >= kAChV0) ? kSmallChunkBytes : kBigChunkBytes; }
+  static constexpr int64_t chunk_offset(int c) {
+    return c < kAChT0 ? (int64_t)c * kSmallChunkBytes
+         : c < kAChV0 ? (int64_t)kAChT0 * kSmallChunkBytes + (int64_t)(c - kAChT0) * kBigChunkBytes
+                      : (int64_t)kAChT0 * kSmallChunkBytes + (int64_t)(kAChV0 - kAChT0) * kBigChunkBytes +
+                        (int64_t)(c - kAChV0) * kSmallChunkBytes;
+  }
+};
+constexpr int64_t kAStreamBytes = ArtNet::chunk_offset(kANumChunks);  // 2,768,896 B
+
+// ---- per-call small block (floats), rebuilt by aon_art_prepare because it depends on the latents ----
+constexpr int kA_BD0 = 0;       // 128   effective bias of deformations_linear.0 (shape + articulation folded in)
+constexpr int kA_WD0 = 128;     // 3x128 deformations_linear.0 weight, [xyz][feature]
+constexpr int kA_BD = 512;      // 3x128 biases of deformations_linear.1..3
+constexpr int kA_WDL = 896;     // 3x128 deformation_layer weight rows
+constexpr int kA_BDL = 1280;    // 3 (+1 pad)
+constexpr int kA_BT = 1284;     // 8x256 trunk biases (layers 0 and 5 effective: shape latent folded in)
+constexpr int kA_BBOT = 3332;   // 256
+constexpr int kA_BV = 3588;     // 4x128 view-branch biases (layer 0 effective: appearance latent folded in)
+constexpr int kA_WSIG = 4100;   // 256
+constexpr int kA_WRGB = 4356;   // 3x128
+constexpr int kA_BSIG = 4740;   // 1
+constexpr int kA_BRGB = 4741;   // 3
+constexpr int kASmallFloats = 4744;
+constexpr int kALdsBytes = kRingBytes + kASmallFloats * 4;
+
+// parameter order of the articulated NeRFMLP (model_autodecoder.py:60-170):
+//   0..7   deformations_linear.{0..3}.{weight,bias}      8,9  deformation_layer.{weight,bias}
+//   10..25 pts_linears.{0..7}.{weight,bias}              26..33 views_linear.{0..3}.{weight,bias}
+//   34,35  bottleneck_layer   36,37 density_layer   38,39 rgb_layer
+constexpr int kNumArtParams = 40;
+struct ArtPackArgs {
+  const float* p[kNumArtParams];
+};
+
+__global__ void pack_art_kernel(ArtPackArgs a, float* __restrict__ packed) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= kAStreamBytes / 4) return;
+  // locate the chunk
+  int c, r, nt;
+  const int64_t s0 = (int64_t)kAChT0 * (kSmallChunkBytes / 4);
+  const int64_t s1 = s0 + (int64_t)(kAChV0 - kAChT0) * (kBigChunkBytes / 4);
+  if (idx < s0) { c = (int)(idx / (kSmallChunkBytes / 4)); r = (int)(idx % (kSmallChunkBytes / 4)); nt = 4; }
+  else if (idx < s1) { c = kAChT0 + (int)((idx - s0) / (kBigChunkBytes / 4)); r = (int)((idx - s0) % (kBigChunkBytes / 4)); nt = 8; }
+  else { c = kAChV0 + (int)((idx - s1) / (kSmallChunkBytes / 4)); r = (int)((idx - s1) % (kSmallChunkBytes / 4)); nt = 4; }
+  const int cc = r & 3, lane = (r >> 2) & 63, rest = r >> 8;
+  const int tp = rest % nt, q = rest / nt;
+  const int h = lane >> 5, row = 32 * tp + (lane & 31);
+  const int hid = 8 * q + 4 * h + cc;
+  const float* W; int ld, col;
+  if (c < kAChT0) { const int l = 1 + c / 4; W = a.p[2 * l]; ld = 128; col = 32 * (c % 4) + hid; }
+  else if (c < kAChT1) { W = a.p[10]; ld = 191; col = posenc_col(c - kAChT0, q, cc, h); }                    // cols 0..62
+  else if (c < kAChT5) { const int l = 1 + (c - kAChT1) / 8; W = a.p[10 + 2 * l]; ld = 256; col = 32 * ((c - kAChT1) % 8) + hid; }
+  else if (c < kAChT5 + 8) { W = a.p[20]; ld = 447; col = 32 * (c - kAChT5) + hid; }
+  else if (c < kAChT6) { W = a.p[20]; ld = 447; col = posenc_col(c - kAChT5 - 8, q, cc, h); if (col >= 0) col += 256; }
+  else if (c < kAChT7) { W = a.p[22]; ld = 256; col = 32 * (c - kAChT6) + hid; }
+  else if (c < kAChBott) { W = a.p[24]; ld = 256; col = 32 * (c - kAChT7) + hid; }
+  else if (c < kAChV0) { W = a.p[34]; ld = 256; col = 32 * (c - kAChBott) + hid; }
+  else if (c < kAChV0 + 8) { W = a.p[26]; ld = 411; col = 32 * (c - kAChV0) + hid; }
+  else if (c < kAChV1) { W = a.p[26]; ld = 411; col = viewenc_col(q, cc, h); if (col >= 0) col += 256; }
+  else { const int l = 1 + (c - kAChV1) / 4; W = a.p[26 + 2 * l]; ld = 128; col = 32 * ((c - kAChV1) % 4) + hid; }
+  packed[idx] = col >= 0 ? W[(int64_t)row * ld + col] : 0.f;  // every layer here has a multiple of 32 outputs
+}
+
+struct ArtPrepArgs {
+  const float* p[kNumArtParams];
+  const float* shape;  // (128) latents["density"]
+  const float* app;    // (128) latents["color"]
+  const float* art;    // (32)  latents["articulation"]
+};
+
+// small[] = plain copies of the small vectors + the latent-folded effective biases
+__global__ void prepare_art_kernel(ArtPrepArgs a, float* __restrict__ small) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= kASmallFloats) return;
+  float v = 0.f;
+  if (s < kA_WD0) {  // b + W[:,3:131].shape + W[:,131:163].art   (input = cat[pos, shape, articulation], :196-198)
+    const float* w = a.p[0] + (int64_t)s * 163;
+    float acc = a.p[1][s];
+    for (int k = 0; k < 128; ++k) acc = __builtin_fmaf(w[3 + k], a.shape[k], acc);
+    for (int k = 0; k < 32; ++k) acc = __builtin_fmaf(w[131 + k], a.art[k], acc);
+    v = acc;
+  } else if (s < kA_BD) { const int i = s - kA_WD0; v = a.p[0][(int64_t)(i & 127) * 163 + (i >> 7)]; }
+  else if (s < kA_WDL) { const int i = s - kA_BD; v = a.p[2 * (1 + (i >> 7)) + 1][i & 127]; }
+  else if (s < kA_BDL) { v = a.p[8][s - kA_WDL]; }
+  else if (s < kA_BT) { const int i = s - kA_BDL; v = i < 3 ? a.p[9][i] : 0.f; }
+  else if (s < kA_BBOT) {
+    const int i = s - kA_BT, l = i >> 8, f = i & 255;
+    float acc = a.p[10 + 2 * l + 1][f];
+    if (l == 0) {        // cat[enc(63), shape(128)]  (:210)
+      const float* w = a.p[10] + (int64_t)f * 191 + 63;
+      for (int k = 0; k < 128; ++k) acc = __builtin_fmaf(w[k], a.shape[k], acc);
+    } else if (l == 5) { // cat[h(256), enc(63), shape(128)]  (:216-217)
+      const float* w = a.p[20] + (int64_t)f * 447 + 319;
+      for (int k = 0; k < 128; ++k) acc = __builtin_fmaf(w[k], a.shape[k], acc);
+    }
+    v = acc;
+  } else if (s < kA_BV) { v = a.p[35][s - kA_BBOT]; }
+  else if (s < kA_WSIG) {
+    const int i = s - kA_BV, l = i >> 7, f = i & 127;
+    float acc = a.p[26 + 2 * l + 1][f];
+    if (l == 0) {        // cat[bottleneck(256), viewenc(27), appearance(128)]  (:228-230)
+      const float* w = a.p[26] + (int64_t)f * 411 + 283;
+      for (int k = 0; k < 128; ++k) acc = __builtin_fmaf(w[k], a.app[k], acc);
+    }
+    v = acc;
+  } else if (s < kA_WRGB) { v = a.p[36][s - kA_WSIG]; }
+  else if (s < kA_BSIG) { v = a.p[38][s - kA_WRGB]; }
+  else if (s < kA_BRGB) { v = a.p[37][0]; }
+  else if (s < kA_BRGB + 3) { v = a.p[39][s - kA_BRGB]; }
+  small[s] = v;
+}
+
+struct ArtMlpArgs {
+  const char* packed;     // kAStreamBytes
+  const float* small;     // kASmallFloats (from prepare_art_kernel)
+  const float* rays_o;    // [POS_IN_KERNEL]
+  const float* rays_d;
+  const float* viewdirs;
+  const float* t_vals;
+  const float* pos;          // (n*S,3)   [!POS_IN_KERNEL]
+  const float* viewdirs_enc; // (n,27)
+  float* raw;             // (n*S,4)
+  int64_t total;
+  int S;
+  int npass;
+};
+
+template <bool POS_IN_KERNEL>
+__global__ void __launch_bounds__(256) art_mlp_fwd_kernel(ArtMlpArgs args) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* sm = reinterpret_cast<float*>(smem + kRingBytes);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int m = lane & 31, h = lane >> 5;
+  {
+    const f32x4* src = reinterpret_cast<const f32x4*>(args.small);
+    f32x4* dst = reinterpret_cast<f32x4*>(sm);
+    for (int i = tid; i < kASmallFloats / 4; i += 256) dst[i] = src[i];
+  }
+  Pipe p;
+  p.stream = args.packed; p.ring = smem;
+  p.voff = (unsigned)(wave * 1024 + lane * 16);
+  p.wave_off = wave * 1024; p.lane_off = lane * 16;
+  p.slot = 1; p.issue_off = 0;
+  issue_chunk<ArtNet, 0>(p, 0);
+  __syncthreads();  // small block visible before the VALU first layer reads it
+
+  for (int pass = blockIdx.x; pass < args.npass; pass += gridDim.x) {
+    const int64_t g = (int64_t)pass * 128 + wave * 32 + m;
+    const bool valid = g < args.total;
+    const int64_t gc = valid ? g : args.total - 1;
+    const int64_t ray = gc / args.S;
+    float x[3];
+    f32x16 V;
+    if constexpr (POS_IN_KERNEL) {
+      const float t = args.t_vals[gc];
+      float vd[3];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        x[a] = __fadd_rn(args.rays_o[ray * 3 + a], __fmul_rn(t, args.rays_d[ray * 3 + a]));
+        vd[a] = args.viewdirs[ray * 3 + a];
+      }
+      encode_view(vd, h, V);
+    } else {
+#pragma unroll
+      for (int a = 0; a < 3; ++a) x[a] = args.pos[gc * 3 + a];
+      load_view_enc(args.viewdirs_enc + ray * kViewEnc, h, V);
+    }
+
+    // ---- deformation MLP (:196-205) ----
+    f32x16 H0[4], H1[4];
+    init_bias(H0, sm + kA_BD0, h);  // effective bias, then the three xyz columns on the VALU
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+          const f32x4 w = *reinterpret_cast<const f32x4*>(sm + kA_WD0 + a * 128 + 32 * t + 8 * gq + 4 * h);
+#pragma unroll
+          for (int cc = 0; cc < 4; ++cc) H0[t][4 * gq + cc] = __builtin_fmaf(w[cc], x[a], H0[t][4 * gq + cc]);
+        }
+      }
+    }
+    relu_tiles(H0);
+    init_bias(H1, sm + kA_BD + 0 * 128, h); dense_layer<ArtNet, kAChD1 + 0, 4, 4>(p, H0, H1); relu_tiles(H1);
+    init_bias(H0, sm + kA_BD + 1 * 128, h); dense_layer<ArtNet, kAChD1 + 4, 4, 4>(p, H1, H0); relu_tiles(H0);
+    init_bias(H1, sm + kA_BD + 2 * 128, h); dense_layer<ArtNet, kAChD1 + 8, 4, 4>(p, H0, H1); relu_tiles(H1);
+    float xd[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {  // x' = deformation_layer(h) + pos   (:205)
+      float v = head_partial<4>(H1, sm + kA_WDL + a * 128, h);
+      v = v + __shfl_xor(v, 32) + sm[kA_BDL + a];
+      xd[a] = __fadd_rn(v, x[a]);
+    }
+    f32x16 E[2];
+    encode_pos(xd, h, E);  // pos_enc after the deformation (enc_after=True, :207-208)
+
+    // ---- trunk (:212-217), shape latent folded into the biases of layers 0 and 5 ----
+    f32x16 X[8], Y[8];
+    init_bias(X, sm + kA_BT + 0 * 256, h);
+    chunk_mma<ArtNet, kAChT0 + 0, 8, 16>(p, E[0], X);
+    chunk_mma<ArtNet, kAChT0 + 1, 8, 16>(p, E[1], X);
+    relu_tiles(X);
+    init_bias(Y, sm + kA_BT + 1 * 256, h); dense_layer<ArtNet, kAChT1 + 0, 8, 8>(p, X, Y); relu_tiles(Y);
+    init_bias(X, sm + kA_BT + 2 * 256, h); dense_layer<ArtNet, kAChT1 + 8, 8, 8>(p, Y, X); relu_tiles(X);
+    init_bias(Y, sm + kA_BT + 3 * 256, h); dense_layer<ArtNet, kAChT1 + 16, 8, 8>(p, X, Y); relu_tiles(Y);
+    init_bias(X, sm + kA_BT + 4 * 256, h); dense_layer<ArtNet, kAChT1 + 24, 8, 8>(p, Y, X); relu_tiles(X);
+    init_bias(Y, sm + kA_BT + 5 * 256, h);
+    dense_layer<ArtNet, kAChT5, 8, 8>(p, X, Y);
+    chunk_mma<ArtNet, kAChT5 + 8, 8, 16>(p, E[0], Y);
+    chunk_mma<ArtNet, kAChT5 + 9, 8, 16>(p, E[1], Y);
+    relu_tiles(Y);
+    init_bias(X, sm + kA_BT + 6 * 256, h); dense_layer<ArtNet, kAChT6, 8, 8>(p, Y, X); relu_tiles(X);
+    init_bias(Y, sm + kA_BT + 7 * 256, h); dense_layer<ArtNet, kAChT7, 8, 8>(p, X, Y); relu_tiles(Y);
+    float sigma = head_partial<8>(Y, sm + kA_WSIG, h);  // density_layer (:219)
+    sigma = sigma + __shfl_xor(sigma, 32) + sm[kA_BSIG];
+    init_bias(X, sm + kA_BBOT, h); dense_layer<ArtNet, kAChBott, 8, 8>(p, Y, X);  // bottleneck (:223)
+
+    // ---- view branch (:227-234): cat[bottleneck, viewenc, appearance] -> 4 x (128, ReLU) ----
+    f32x16 Z0[4], Z1[4];
+    init_bias(Z0, sm + kA_BV + 0 * 128, h);
+    chunk_mma<ArtNet, kAChV0 + 0, 4, 16>(p, X[0], Z0);
+    chunk_mma<ArtNet, kAChV0 + 1, 4, 16>(p, X[1], Z0);
+    chunk_mma<ArtNet, kAChV0 + 2, 4, 16>(p, X[2], Z0);
+    chunk_mma<ArtNet, kAChV0 + 3, 4, 16>(p, X[3], Z0);
+    chunk_mma<ArtNet, kAChV0 + 4, 4, 16>(p, X[4], Z0);
+    chunk_mma<ArtNet, kAChV0 + 5, 4, 16>(p, X[5], Z0);
+    chunk_mma<ArtNet, kAChV0 + 6, 4, 16>(p, X[6], Z0);
+    chunk_mma<ArtNet, kAChV0 + 7, 4, 16>(p, X[7], Z0);
+    chunk_mma<ArtNet, kAChV0 + 8, 4, 14>(p, V, Z0);
+    relu_tiles(Z0);
+    init_bias(Z1, sm + kA_BV + 1 * 128, h); dense_layer<ArtNet, kAChV1 + 0, 4, 4>(p, Z0, Z1); relu_tiles(Z1);
+    init_bias(Z0, sm + kA_BV + 2 * 128, h); dense_layer<ArtNet, kAChV1 + 4, 4, 4>(p, Z1, Z0); relu_tiles(Z0);
+    init_bias(Z1, sm + kA_BV + 3 * 128, h); dense_layer<ArtNet, kAChV1 + 8, 4, 4>(p, Z0, Z1); relu_tiles(Z1);
+    float rgb[3];
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {  // rgb_layer (:236)
+      float v = head_partial<4>(Z1, sm + kA_WRGB + ch * kCondWidth, h);
+      rgb[ch] = v + __shfl_xor(v, 32) + sm[kA_BRGB + ch];
+    }
+    if (valid && h == 0) {
+      f32x4 o; o[0] = rgb[0]; o[1] = rgb[1]; o[2] = rgb[2]; o[3] = sigma;
+      reinterpret_cast<f32x4*>(args.raw)[g] = o;
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// ---------------------------------------------------------------------------------------------
+// host launchers
+// ---------------------------------------------------------------------------------------------
+hipError_t launch_pack_art(const float* const* params, float* packed, hipStream_t stream) {
+  ArtPackArgs a;
+  for (int i = 0; i < kNumArtParams; ++i) a.p[i] = params[i];
+  const int64_t n = kAStreamBytes / 4;
+  pack_art_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream>>>(a, packed);
+  return hipGetLastError();
+}
+
+hipError_t launch_prepare_art(const float* const* params, const float* shape, const float* app, const float* art,
+                              float* small, hipStream_t stream) {
+  ArtPrepArgs a;
+  for (int i = 0; i < kNumArtParams; ++i) a.p[i] = params[i];
+  a.shape = shape; a.app = app; a.art = art;
+  prepare_art_kernel<<<dim3((kASmallFloats + 255) / 256), dim3(256), 0, stream>>>(a, small);
+  return hipGetLastError();
+}
+
+int num_cus();  // aon_mlp.hip
+
+template <bool POS>
+static hipError_t launch_art_t(const ArtMlpArgs& args, hipStream_t stream) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&art_mlp_fwd_kernel<POS>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, kALdsBytes);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  const int cus = num_cus();
+  if (cus <= 0) return hipErrorInvalidDevice;
+  const int grid = args.npass < cus ? args.npass : cus;
+  if (grid <= 0) return hipSuccess;
+  art_mlp_fwd_kernel<POS><<<dim3(grid), dim3(256), kALdsBytes, stream>>>(args);
+  return hipGetLastError();
+}
+
+hipError_t launch_art_mlp_fwd(const char* packed, const float* small, const float* rays_o, const float* rays_d,
+                              const float* viewdirs, const float* t_vals, int64_t n_rays, int S, float* raw,
+                              hipStream_t stream) {
+  ArtMlpArgs a{};
+  a.packed = packed; a.small = small; a.rays_o = rays_o; a.rays_d = rays_d; a.viewdirs = viewdirs; a.t_vals = t_vals;
+  a.raw = raw; a.total = n_rays * S; a.S = S; a.npass = (int)((a.total + 127) / 128);
+  return launch_art_t<true>(a, stream);
+}
+
+hipError_t launch_art_mlp_fwd_pos(const char* packed, const float* small, const float* pos, const float* viewdirs_enc,
+                                  int64_t n_rays, int S, float* raw, hipStream_t stream) {
+  ArtMlpArgs a{};
+  a.packed = packed; a.small = small; a.pos = pos; a.viewdirs_enc = viewdirs_enc;
+  a.raw = raw; a.total = n_rays * S; a.S = S; a.npass = (int)((a.total + 127) / 128);
+  return launch_art_t<false>(a, stream);
+}
+
+int64_t art_stream_bytes() { return kAStreamBytes; }
+int64_t art_small_bytes() { return (int64_t)kASmallFloats * 4; }
+
+}  // namespace aon

@@ -1,0 +1,181 @@
+// Shared machinery of the fused, register-resident MLP kernels (vanilla: aon_mlp.hip, articulated: aon_mlp_art.hip).
+// See the header comment of aon_mlp.hip for the mapping onto CDNA4.
+#pragma once
+#include "aon_common.h"
+
+namespace aon {
+
+constexpr int kRingBytes = 2 * kBigChunkBytes;  // two 32 KiB LDS slots for the weight stream
+
+struct Pipe {
+  const char* stream;  // packed stream base (wave-uniform -> SGPR pair)
+  char* ring;          // LDS ring base
+  unsigned voff;       // this lane's byte offset inside a 4 KiB round: wave*1024 + lane*16
+  int wave_off;        // wave*1024
+  int lane_off;        // lane*16
+  int slot;            // slot holding the chunk being consumed
+  unsigned issue_off;  // byte offset (in the stream) of the next chunk to issue
+};
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) char gbl_char;
+
+// LDS-DMA one chunk: global (SGPR base + per-lane VGPR offset) -> LDS (M0 base + lane*16), 1 KiB per wave per
+// instruction.  The stream offset is kept as an opaque loop-carried scalar so that the several hundred
+// distinct chunk addresses are recomputed with one s_add instead of being hoisted out of the pass loop.
+template <class Net, int C>
+__device__ __forceinline__ void issue_chunk(Pipe& p, int slot) {
+  constexpr int rounds = Net::chunk_bytes(C) / 4096;
+  unsigned off = p.issue_off;
+  asm volatile("" : "+s"(off));
+  gbl_char* src = (gbl_char*)(p.stream + off);
+  char* dst = p.ring + slot * kBigChunkBytes + p.wave_off;  // wave-uniform; hardware adds lane*16
+#pragma unroll
+  for (int r = 0; r < rounds; ++r) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + r * 4096 + p.voff),
+                                     (lds_void*)(dst + r * 4096), 16, 0, 0);
+  }
+  p.issue_off = (C == Net::kNumChunks - 1) ? 0u : off + (unsigned)Net::chunk_bytes(C);
+}
+
+// Wait for chunk C (DMA issued one chunk earlier), release the other slot, start streaming chunk C+1.
+template <class Net, int C>
+__device__ __forceinline__ void acquire(Pipe& p) {
+  __syncthreads();  // drains this wave's LDS-DMA (vmcnt(0)) + workgroup barrier
+  p.slot ^= 1;
+  issue_chunk<Net, (C + 1) % Net::kNumChunks>(p, p.slot ^ 1);
+}
+
+// out[Tp] += W_chunk[Tp] * in   for one 32-feature input tile held in accumulator layout.
+// The A-operand reads are software-pipelined one ds_read_b128 (= 4 MFMA steps, 256 matrix-pipe cycles) ahead.
+template <class Net, int C, int NT_OUT, int NREG>
+__device__ __forceinline__ void chunk_mma(Pipe& p, const f32x16& in, f32x16 (&out)[NT_OUT]) {
+  static_assert(Net::chunk_bytes(C) == NT_OUT * 4096, "chunk/out-tile mismatch");
+  static_assert(NREG % 2 == 0 && NREG > 12, "register count");
+  acquire<Net, C>(p);
+  const char* buf = p.ring + p.slot * kBigChunkBytes + p.lane_off;
+  constexpr int NQ = (NREG + 3) / 4;
+  constexpr int NSTEP = NQ * NT_OUT;
+  f32x4 a_cur = *reinterpret_cast<const f32x4*>(buf);
+#pragma unroll
+  for (int i = 0; i < NSTEP; ++i) {
+    const int q = i / NT_OUT, tp = i % NT_OUT;
+    f32x4 a_nxt = a_cur;
+    if (i + 1 < NSTEP) a_nxt = *reinterpret_cast<const f32x4*>(buf + (i + 1) * 1024);
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc) {
+      if (4 * q + cc < NREG) out[tp] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[cc], in[4 * q + cc], out[tp], 0, 0, 0);
+    }
+    a_cur = a_nxt;
+  }
+}
+
+template <int NT_OUT>
+__device__ __forceinline__ void init_bias(f32x16 (&acc)[NT_OUT], const float* sm_bias, int h) {
+#pragma unroll
+  for (int tp = 0; tp < NT_OUT; ++tp) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 b = *reinterpret_cast<const f32x4*>(sm_bias + 32 * tp + 8 * g + 4 * h);
+      acc[tp][4 * g + 0] = b[0]; acc[tp][4 * g + 1] = b[1]; acc[tp][4 * g + 2] = b[2]; acc[tp][4 * g + 3] = b[3];
+    }
+  }
+}
+
+template <int NT>
+__device__ __forceinline__ void relu_tiles(f32x16 (&x)[NT]) {
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float y;  // plain v_max_f32: fmaxf() would add a canonicalising v_max in front of the real one
+      asm("v_max_f32 %0, 0, %1" : "=v"(y) : "v"(x[t][r]));
+      x[t][r] = y;
+    }
+  }
+}
+
+// NT_IN*32 -> NT_OUT*32 layer, input/output both in accumulator layout; chunks CBASE .. CBASE+NT_IN-1.
+template <class Net, int CBASE, int NT_IN, int NT_OUT>
+__device__ __forceinline__ void dense_layer(Pipe& p, const f32x16 (&in)[NT_IN], f32x16 (&out)[NT_OUT]) {
+  chunk_mma<Net, CBASE + 0, NT_OUT, 16>(p, in[0], out);
+  chunk_mma<Net, CBASE + 1, NT_OUT, 16>(p, in[1], out);
+  chunk_mma<Net, CBASE + 2, NT_OUT, 16>(p, in[2], out);
+  chunk_mma<Net, CBASE + 3, NT_OUT, 16>(p, in[3], out);
+  if constexpr (NT_IN == 8) {
+    chunk_mma<Net, CBASE + 4, NT_OUT, 16>(p, in[4], out);
+    chunk_mma<Net, CBASE + 5, NT_OUT, 16>(p, in[5], out);
+    chunk_mma<Net, CBASE + 6, NT_OUT, 16>(p, in[6], out);
+    chunk_mma<Net, CBASE + 7, NT_OUT, 16>(p, in[7], out);
+  }
+}
+
+// per-lane partial of  w . x  over the features this lane holds (NT tiles of 32 features)
+template <int NT>
+__device__ __forceinline__ float head_partial(const f32x16 (&x)[NT], const float* sm_w, int h) {
+  float acc = 0.f;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 w = *reinterpret_cast<const f32x4*>(sm_w + 32 * t + 8 * g + 4 * h);
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) acc = __builtin_fmaf(w[cc], x[t][4 * g + cc], acc);
+    }
+  }
+  return acc;
+}
+
+
+// Positional / view encodings directly in accumulator (= next layer's B operand) layout: lanes 0-31 hold the sin
+// features, lanes 32-63 the sin(. + fp32(pi/2)) features of the same sample; the identity features ride in the
+// last registers (pack kernels: posenc_col / viewenc_col).  helper.py:136-140.
+__device__ __forceinline__ void encode_pos(const float (&x)[3], int h, f32x16 (&E)[2]) {
+  const float phase = h ? AON_HALF_PI_F32 : 0.f;
+#pragma unroll
+  for (int rho = 0; rho < 30; ++rho) {
+    const float xb = __fmul_rn(x[rho % 3], (float)(1 << (rho / 3)));
+    E[rho >> 4][rho & 15] = sin_f32(__fadd_rn(xb, phase));
+  }
+  E[1][14] = h ? x[2] : x[0];
+  E[1][15] = h ? 0.f : x[1];
+}
+
+__device__ __forceinline__ void encode_view(const float (&vd)[3], int h, f32x16& V) {
+  const float phase = h ? AON_HALF_PI_F32 : 0.f;
+#pragma unroll
+  for (int rho = 0; rho < 12; ++rho) {
+    const float xb = __fmul_rn(vd[rho % 3], (float)(1 << (rho / 3)));
+    V[rho] = sin_f32(__fadd_rn(xb, phase));
+  }
+  V[12] = h ? vd[2] : vd[0];
+  V[13] = h ? 0.f : vd[1];
+  V[14] = 0.f; V[15] = 0.f;
+}
+
+__device__ __forceinline__ void load_view_enc(const float* ve, int h, f32x16& V) {  // caller-encoded (n,27)
+#pragma unroll
+  for (int rho = 0; rho < 12; ++rho) V[rho] = ve[3 + rho + 12 * h];
+  V[12] = h ? ve[2] : ve[0];
+  V[13] = h ? 0.f : ve[1];
+  V[14] = 0.f; V[15] = 0.f;
+}
+
+__device__ __forceinline__ int posenc_col(int tile, int q, int cc, int h) {
+  // position of packed input (tile, reg r=4q+cc, half h) in the reference's 63-wide encoding
+  // [x(3) ; sin(2^l x) l-major (30) ; sin(2^l x + pi/2) (30)]   (helper.py:136-140)
+  const int rho = 16 * tile + 4 * q + cc;
+  if (rho < 30) return 3 + rho + 30 * h;
+  if (rho == 30) return h ? 2 : 0;
+  return h ? -1 : 1;
+}
+
+__device__ __forceinline__ int viewenc_col(int q, int cc, int h) {
+  const int rho = 4 * q + cc;  // 27-wide: [v(3) ; sin (12) ; sin(+pi/2) (12)]
+  if (rho < 12) return 3 + rho + 12 * h;
+  if (rho == 12) return h ? 2 : 0;
+  if (rho == 13) return h ? -1 : 1;
+  return -1;
+}
+
+}  // namespace aon

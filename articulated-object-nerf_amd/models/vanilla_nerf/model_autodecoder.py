@@ -1,0 +1,122 @@
+"""Drop-in articulated ``NeRFMLP`` / ``NeRF_AE_Art`` (reference ``models/vanilla_nerf/model_autodecoder.py:60-337``):
+same constructor defaults, parameter names (``deformations_linear.*``, ``deformation_layer``, ``pts_linears.*``,
+``views_linear.*``, ``bottleneck_layer``, ``density_layer``, ``rgb_layer`` under ``coarse_mlp`` / ``fine_mlp``) and
+``forward`` signatures, running on the fused HIP kernels.  Only the reference's default geometry
+(deformation_mlp=True, enc_after=True, embed_deg=False, 4x128 deformation and view branches) has kernels."""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+import torch.nn.init as init
+
+from ... import ops
+
+
+class NeRFMLP(nn.Module):
+    """model_autodecoder.py:60-239.  ``forward(pos, condition, latents)``: pos (N,S,3) un-encoded sample positions,
+    condition (N,27) encoded view dirs, latents {"density": (1,128), "color": (1,128), "articulation": (1,32)}
+    -> (raw_rgb (N,S,3), raw_density (N,S,1))."""
+
+    def __init__(self, min_deg_point, max_deg_point, deg_view, netdepth: int = 8, netwidth: int = 256,
+                 netdepth_deformation=4, netwidth_deformation: int = 128, netdepth_condition: int = 4,
+                 netwidth_condition: int = 128, shape_latent_dim=128, appearance_latent_dim=128,
+                 articulation_latent_dim=32, skip_layer: int = 4, input_ch: int = 3, input_ch_view: int = 3,
+                 num_rgb_channels: int = 3, num_density_channels: int = 1, deformation_mlp: bool = True,
+                 enc_after: bool = True, embed_deg: bool = False):
+        super().__init__()
+        geometry = (min_deg_point, max_deg_point, deg_view, netdepth, netwidth, netdepth_deformation, netwidth_deformation,
+                    netdepth_condition, netwidth_condition, shape_latent_dim, appearance_latent_dim, articulation_latent_dim,
+                    skip_layer, input_ch, input_ch_view, num_rgb_channels, num_density_channels, deformation_mlp, enc_after,
+                    embed_deg)
+        if geometry != (0, 10, 4, 8, 256, 4, 128, 4, 128, 128, 128, 32, 4, 3, 3, 3, 1, True, True, False):
+            raise NotImplementedError(f"articulated NeRFMLP geometry {geometry} has no HIP kernel (only the reference defaults do)")
+        self.net_activation = nn.ReLU()
+        self.enc_after, self.embed_deg, self.deformation_mlp = enc_after, embed_deg, deformation_mlp
+        self.netdepth, self.netdepth_deformation, self.netdepth_condition, self.skip_layer = netdepth, 4, 4, skip_layer
+        self.min_deg_point, self.max_deg_point = min_deg_point, max_deg_point
+        self.num_rgb_channels, self.num_density_channels = num_rgb_channels, num_density_channels
+        deform = [nn.Linear(3 + 128 + 32, 128)] + [nn.Linear(128, 128) for _ in range(3)]
+        self.deformations_linear = nn.ModuleList(deform)
+        self.deformation_layer = nn.Linear(128, 3)
+        pos_size = 63 + 128
+        pts = [nn.Linear(pos_size, 256)]
+        for idx in range(7):
+            pts.append(nn.Linear(256 + pos_size if (idx % skip_layer == 0 and idx > 0) else 256, 256))
+        self.pts_linears = nn.ModuleList(pts)
+        self.views_linear = nn.ModuleList([nn.Linear(256 + 27 + 128, 128)] + [nn.Linear(128, 128) for _ in range(3)])
+        self.bottleneck_layer = nn.Linear(256, 256)
+        self.density_layer = nn.Linear(256, 1)
+        self.rgb_layer = nn.Linear(128, 3)
+        for m in list(self.deformations_linear) + [self.deformation_layer] + list(self.pts_linears) + \
+                list(self.views_linear)[1:] + [self.bottleneck_layer, self.density_layer, self.rgb_layer]:
+            init.xavier_uniform_(m.weight)  # views_linear[0] keeps the default init, like the reference (:147-151)
+        self._packed = None
+        self._packed_key = None
+        self._small = None
+
+    def packed(self) -> torch.Tensor:
+        params = dict(self.named_parameters())
+        key = tuple((p.data_ptr(), p._version, str(p.device)) for p in params.values())
+        if self._packed is None or key != self._packed_key:
+            dev = next(iter(params.values())).device
+            out = self._packed if (self._packed is not None and self._packed.device == dev) else None
+            self._packed = ops.pack_art_mlp(params, out=out)
+            self._packed_key = key
+        return self._packed
+
+    def prepared(self, latents: dict) -> torch.Tensor:
+        """Per-call latent-folded block (cheap: ~0.1 MFLOP); always rebuilt because latents are call arguments."""
+        params = dict(self.named_parameters())
+        dev = next(iter(params.values())).device
+        out = self._small if (self._small is not None and self._small.device == dev) else None
+        self._small = ops.art_prepare(params, latents, out=out)
+        return self._small
+
+    def forward(self, pos, condition, latents):
+        if self.embed_deg:
+            raise NotImplementedError
+        raw = ops.art_mlp_fwd_pos(self.packed(), self.prepared(latents), pos, condition)
+        return raw[..., :3], raw[..., 3:4]
+
+
+class NeRF_AE_Art(nn.Module):
+    """model_autodecoder.py:242-337.  ``forward(rays, randomized, white_bkgd, near, far, latents, train=True)`` ->
+    ``[(comp_rgb, acc, depth)_coarse, (comp_rgb, acc, depth)_fine]`` with rgb = sigmoid(raw)*(1+2*0.001)-0.001 and
+    sigma = softplus(raw - 1)."""
+
+    def __init__(self, num_levels: int = 2, min_deg_point: int = 0, max_deg_point: int = 10, deg_view: int = 4,
+                 num_coarse_samples: int = 64, num_fine_samples: int = 128, use_viewdirs: bool = True,
+                 noise_std: float = 0.0, lindisp: bool = False, rgb_padding: float = 0.001, density_bias: float = -1.0,
+                 enc_after=True, embed_deg=False):
+        super().__init__()
+        if (num_coarse_samples, num_fine_samples, use_viewdirs, lindisp, rgb_padding, density_bias, enc_after, embed_deg) != \
+                (64, 128, True, False, 0.001, -1.0, True, False) or num_levels not in (1, 2) or noise_std != 0.0:
+            raise NotImplementedError("only the reference's default NeRF_AE_Art configuration has HIP kernels")
+        self.num_levels, self.min_deg_point, self.max_deg_point, self.deg_view = num_levels, min_deg_point, max_deg_point, deg_view
+        self.num_coarse_samples, self.num_fine_samples = num_coarse_samples, num_fine_samples
+        self.rgb_padding, self.density_bias, self.enc_after, self.embed_deg = rgb_padding, density_bias, enc_after, embed_deg
+        self.rgb_activation = nn.Sigmoid()
+        self.sigma_activation = nn.Softplus()
+        self.coarse_mlp = NeRFMLP(min_deg_point, max_deg_point, deg_view)
+        self.fine_mlp = NeRFMLP(min_deg_point, max_deg_point, deg_view)
+
+    def forward(self, rays, randomized, white_bkgd, near, far, latents, train=True, t_rand=None, u=None):
+        if torch.is_grad_enabled() and (any(p.requires_grad for p in self.parameters())
+                                        or any(getattr(v, "requires_grad", False) for v in latents.values())):
+            raise NotImplementedError(
+                "the HIP backward of the render path is not implemented yet: call under torch.no_grad(); there is "
+                "deliberately no eager-PyTorch fallback")
+        rays_o = rays["rays_o"]
+        n = rays_o.shape[0]
+        if randomized:
+            if t_rand is None:
+                t_rand = torch.rand((n, self.num_coarse_samples + 1), device=rays_o.device)
+            if u is None and self.num_levels == 2:
+                u = torch.rand((n, self.num_fine_samples), device=rays_o.device)
+        else:
+            t_rand, u = None, None
+        two = self.num_levels == 2
+        outs = ops.art_render_fwd(self.coarse_mlp.packed(), self.coarse_mlp.prepared(latents),
+                                  self.fine_mlp.packed() if two else None, self.fine_mlp.prepared(latents) if two else None,
+                                  rays_o, rays["rays_d"], rays["viewdirs"], near, far, white_bkgd, self.num_levels, t_rand, u)
+        return [tuple(o) for o in outs]

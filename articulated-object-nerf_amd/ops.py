@@ -293,6 +293,119 @@ def render_fwd(packed_coarse, packed_fine, rays_o, rays_d, viewdirs, near, far, 
     return outs
 
 
+# ------------------------------------------------------------------ R10/R11 articulated network
+ART_PARAM_ORDER = (
+    [f"deformations_linear.{i}.{k}" for i in range(4) for k in ("weight", "bias")]
+    + [f"deformation_layer.{k}" for k in ("weight", "bias")]
+    + [f"pts_linears.{i}.{k}" for i in range(8) for k in ("weight", "bias")]
+    + [f"views_linear.{i}.{k}" for i in range(4) for k in ("weight", "bias")]
+    + [f"{m}.{k}" for m in ("bottleneck_layer", "density_layer", "rgb_layer") for k in ("weight", "bias")]
+)
+ART_PARAM_SHAPES = {
+    "deformations_linear.0.weight": (128, 163), "deformation_layer.weight": (3, 128), "deformation_layer.bias": (3,),
+    "pts_linears.0.weight": (256, 191), "pts_linears.5.weight": (256, 447), "views_linear.0.weight": (128, 411),
+    "bottleneck_layer.weight": (256, 256), "bottleneck_layer.bias": (256,), "density_layer.weight": (1, 256),
+    "density_layer.bias": (1,), "rgb_layer.weight": (3, 128), "rgb_layer.bias": (3,),
+}
+for _i in (1, 2, 3):
+    ART_PARAM_SHAPES[f"deformations_linear.{_i}.weight"] = (128, 128)
+    ART_PARAM_SHAPES[f"views_linear.{_i}.weight"] = (128, 128)
+for _i in range(4):
+    ART_PARAM_SHAPES[f"deformations_linear.{_i}.bias"] = (128,)
+    ART_PARAM_SHAPES[f"views_linear.{_i}.bias"] = (128,)
+for _i in (1, 2, 3, 4, 6, 7):
+    ART_PARAM_SHAPES[f"pts_linears.{_i}.weight"] = (256, 256)
+for _i in range(8):
+    ART_PARAM_SHAPES[f"pts_linears.{_i}.bias"] = (256,)
+
+
+def _art_param_array(params: dict):
+    tensors = []
+    for name in ART_PARAM_ORDER:
+        t = _f32(params[name].detach(), name)
+        if tuple(t.shape) != ART_PARAM_SHAPES[name]:
+            raise ValueError(f"{name}: shape {tuple(t.shape)} != {ART_PARAM_SHAPES[name]} (only the reference's default "
+                             "articulated NeRFMLP geometry has a HIP kernel)")
+        tensors.append(t)
+    return tensors, (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+
+def pack_art_mlp(params: dict, out: torch.Tensor | None = None) -> torch.Tensor:
+    """Packed weight stream of one articulated NeRFMLP (re-pack whenever the parameters change)."""
+    tensors, arr = _art_param_array(params)
+    dev = tensors[0].device
+    if out is None:
+        out = torch.empty(int(lib.aon_art_packed_bytes()), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        check(lib.aon_pack_art_mlp(arr, _ptr(out), _stream()), "aon_pack_art_mlp")
+    return out
+
+
+def _latent(latents: dict, key: str, width: int) -> torch.Tensor:
+    t = _f32(latents[key].detach(), f"latents[{key!r}]").reshape(-1)
+    if t.numel() != width:
+        raise ValueError(f"latents[{key!r}] must hold {width} values (one instance per call, like the reference's "
+                         f"'n1 c -> (n1 n2) c' broadcast), got {tuple(latents[key].shape)}")
+    return t
+
+
+def art_prepare(params: dict, latents: dict, out: torch.Tensor | None = None) -> torch.Tensor:
+    """Per-call block: small vectors + biases with the three latents folded in (latents keys as the reference:
+    'density' (1,128), 'color' (1,128), 'articulation' (1,32))."""
+    tensors, arr = _art_param_array(params)
+    dev = tensors[0].device
+    shape, app, art = _latent(latents, "density", 128), _latent(latents, "color", 128), _latent(latents, "articulation", 32)
+    if out is None:
+        out = torch.empty(int(lib.aon_art_small_bytes()), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        check(lib.aon_art_prepare(arr, _ptr(shape), _ptr(app), _ptr(art), _ptr(out), _stream()), "aon_art_prepare")
+    return out
+
+
+def art_mlp_fwd(packed, small, rays_o, rays_d, viewdirs, t_vals):
+    o, d, v, t = _f32(rays_o, "rays_o"), _f32(rays_d, "rays_d"), _f32(viewdirs, "viewdirs"), _f32(t_vals, "t_vals")
+    n, S = t.shape
+    raw = torch.empty((n, S, 4), dtype=torch.float32, device=t.device)
+    with torch.cuda.device(t.device):
+        check(lib.aon_art_mlp_fwd(_ptr(packed), _ptr(small), _ptr(o), _ptr(d), _ptr(v), _ptr(t), n, S, _ptr(raw), _stream()),
+              "aon_art_mlp_fwd")
+    return raw
+
+
+def art_mlp_fwd_pos(packed, small, pos, viewdirs_enc):
+    x, c = _f32(pos, "pos"), _f32(viewdirs_enc, "viewdirs_enc")
+    n, S, F = x.shape
+    if F != 3 or tuple(c.shape) != (n, 27):
+        raise ValueError("art_mlp_fwd_pos expects pos (n,S,3) and viewdirs_enc (n,27)")
+    raw = torch.empty((n, S, 4), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        check(lib.aon_art_mlp_fwd_pos(_ptr(packed), _ptr(small), _ptr(x), _ptr(c), n, S, _ptr(raw), _stream()), "aon_art_mlp_fwd_pos")
+    return raw
+
+
+def art_render_fwd(packed_c, small_c, packed_f, small_f, rays_o, rays_d, viewdirs, near, far, white_bkgd, num_levels=2,
+                   t_rand=None, u=None):
+    """NeRF_AE_Art.forward: [(rgb, acc, depth)_coarse, (rgb, acc, depth)_fine]."""
+    o, d, v = _f32(rays_o, "rays_o"), _f32(rays_d, "rays_d"), _f32(viewdirs, "viewdirs")
+    n, dev = o.shape[0], o.device
+    tr = None if t_rand is None else _f32(t_rand, "t_rand")
+    if tr is not None and tuple(tr.shape) != (n, 65):
+        raise ValueError(f"t_rand must be ({n},65)")
+    uu, us = _u_args(u, n, dev) if num_levels == 2 else (None, 0)
+    outs = []
+    for _ in range(num_levels):
+        outs.append((torch.empty((n, 3), dtype=torch.float32, device=dev), torch.empty((n,), dtype=torch.float32, device=dev),
+                     torch.empty((n,), dtype=torch.float32, device=dev)))
+    fine = outs[1] if num_levels == 2 else (None, None, None)
+    ws = _workspace(dev, n)
+    with torch.cuda.device(dev):
+        check(lib.aon_art_render_fwd(_ptr(packed_c), _ptr(small_c), _ptr(packed_f), _ptr(small_f), _ptr(o), _ptr(d), _ptr(v), n,
+                                     float(near), float(far), int(bool(white_bkgd)), num_levels, _ptr(tr), _ptr(uu), us,
+                                     _ptr(outs[0][0]), _ptr(outs[0][1]), _ptr(outs[0][2]), _ptr(fine[0]), _ptr(fine[1]), _ptr(fine[2]),
+                                     _ptr(ws), ws.numel(), _stream()), "aon_art_render_fwd")
+    return outs
+
+
 # ------------------------------------------------------------------ measurement aid
 def profile_begin() -> None:
     check(lib.aon_profile_begin(), "aon_profile_begin")

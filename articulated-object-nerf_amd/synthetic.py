@@ -90,6 +90,43 @@ def make_nerf_state_dict(seed: int = 0, density_scale: float = 30.0, **layout_kw
     return sd
 
 
+# articulated NeRFMLP (models/vanilla_nerf/model_autodecoder.py:60-170, default geometry)
+def art_mlp_layout():
+    layout = [("deformations_linear.0", 128, 163, "xavier")]
+    layout += [(f"deformations_linear.{i}", 128, 128, "xavier") for i in (1, 2, 3)]
+    layout.append(("deformation_layer", 3, 128, "xavier"))
+    layout.append(("pts_linears.0", 256, 191, "xavier"))
+    for idx in range(7):
+        layout.append((f"pts_linears.{idx + 1}", 256, 447 if idx == 4 else 256, "xavier"))
+    layout.append(("views_linear.0", 128, 411, "kaiming"))
+    layout += [(f"views_linear.{i}", 128, 128, "xavier") for i in (1, 2, 3)]
+    layout.append(("bottleneck_layer", 256, 256, "xavier"))
+    layout.append(("density_layer", 1, 256, "xavier"))
+    layout.append(("rgb_layer", 3, 128, "xavier"))
+    return layout
+
+
+def make_art_state_dict(seed: int = 0, density_scale: float = 30.0) -> "OrderedDict[str, torch.Tensor]":
+    """State dict with the reference's key names for ``NeRF_AE_Art`` (coarse_mlp.* / fine_mlp.*)."""
+    rng = np.random.Generator(np.random.PCG64(seed + 1000))
+    sd = OrderedDict()
+    for prefix in ("coarse_mlp", "fine_mlp"):
+        for k, v in make_mlp_state(rng, art_mlp_layout(), density_scale).items():
+            sd[f"{prefix}.{k}"] = v
+    return sd
+
+
+def make_code_library_state(seed: int = 0, n_max_objs: int = 2, code_len: int = 128):
+    """CodeLibraryArticulated weights (models/code_library.py:20-34): xavier-uniform embeddings."""
+    rng = np.random.Generator(np.random.PCG64(seed + 2000))
+    sd = OrderedDict()
+    for name, rows, cols in (("embedding_instance_shape", n_max_objs, code_len),
+                             ("embedding_instance_appearance", n_max_objs, code_len),
+                             ("embedding_instance_articulation", 10, 32)):
+        sd[name + ".weight"] = _uniform(rng, (rows, cols), math.sqrt(6.0 / (rows + cols)))
+    return sd
+
+
 def make_rays(H: int, W: int, c2w: torch.Tensor | None = None, focal: float | None = None):
     """CPU/torch construction of the per-ray record of one frame (row-major pixel order) following
     datasets/ray_utils.py:71-90,118-159 semantics; returns dict(rays_o, rays_d, viewdirs) fp32 (H*W,3)."""

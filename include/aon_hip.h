@@ -117,6 +117,33 @@ int aon_render_fwd(const void* packed_coarse, const void* packed_fine, const flo
                    float* depth_c, float* rgb_f, float* acc_f, float* depth_f, void* workspace,
                    int64_t workspace_bytes, void* stream);
 
+/* ---- R10/R11  articulated network: NeRFMLP.forward(pos, condition, latents) (models/vanilla_nerf/
+ * model_autodecoder.py:172-239, deformation_mlp=True, enc_after=True) and NeRF_AE_Art.forward (:278-337) ----
+ * params: HOST array of 40 DEVICE pointers, order: deformations_linear.{0..3}.{weight,bias}, deformation_layer.{w,b},
+ *   pts_linears.{0..7}.{w,b}, views_linear.{0..3}.{w,b}, bottleneck_layer.{w,b}, density_layer.{w,b}, rgb_layer.{w,b}.
+ * aon_pack_art_mlp: once per parameter update -> `packed` (aon_art_packed_bytes()).
+ * aon_art_prepare : once per (parameters, latents) -> `small` (aon_art_small_bytes()): the three latents
+ *   (latents["density"] (128), ["color"] (128), ["articulation"] (32); model_autodecoder.py:172-178) are broadcast to
+ *   every sample by the reference, so their weight columns are folded into effective bias vectors here.
+ * aon_art_mlp_fwd    : cast_rays + deformation MLP + pos_enc + trunk + view branch, raw (n*S,4) as aon_mlp_fwd.
+ * aon_art_mlp_fwd_pos: the same on caller-supplied sample positions pos (n,S,3) and encoded view dirs (n,27),
+ *   i.e. exactly NeRFMLP.forward(pos, condition, latents).
+ * aon_art_render_fwd : NeRF_AE_Art.forward; as aon_render_fwd with rgb = sigmoid*1.002-0.001, sigma = softplus(raw-1). */
+int64_t aon_art_packed_bytes(void);
+int64_t aon_art_small_bytes(void);
+int aon_pack_art_mlp(const float* const* params_host, void* packed, void* stream);
+int aon_art_prepare(const float* const* params_host, const float* shape, const float* appearance,
+                    const float* articulation, void* small, void* stream);
+int aon_art_mlp_fwd(const void* packed, const void* small, const float* rays_o, const float* rays_d,
+                    const float* viewdirs, const float* t_vals, int64_t n_rays, int S, float* raw, void* stream);
+int aon_art_mlp_fwd_pos(const void* packed, const void* small, const float* pos, const float* viewdirs_enc,
+                        int64_t n_rays, int S, float* raw, void* stream);
+int aon_art_render_fwd(const void* packed_coarse, const void* small_coarse, const void* packed_fine,
+                       const void* small_fine, const float* rays_o, const float* rays_d, const float* viewdirs,
+                       int64_t n_rays, float near_, float far_, int white_bkgd, int num_levels, const float* t_rand,
+                       const float* u, int64_t u_stride, float* rgb_c, float* acc_c, float* depth_c, float* rgb_f,
+                       float* acc_f, float* depth_f, void* workspace, int64_t workspace_bytes, void* stream);
+
 /* ---- measurement aid (no reference counterpart) ----
  * Between aon_profile_begin() and aon_profile_end() every launch of the fused MLP kernel (the dominant kernel of
  * the path) made through aon_mlp_fwd / aon_render_fwd is bracketed by HIP events recorded on the launch stream.

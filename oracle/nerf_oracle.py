@@ -201,6 +201,85 @@ def nerf_forward(sd, rays, randomized, white_bkgd, near, far, num_levels=2, min_
 
 
 # --------------------------------------------------------------------------------------------------
+# R10  articulated NeRFMLP              models/vanilla_nerf/model_autodecoder.py:172-239
+# --------------------------------------------------------------------------------------------------
+def art_mlp(sd: dict, prefix: str, pos, view_enc, latents: dict):
+    """model_autodecoder.py:172-239 (deformation_mlp=True, enc_after=True, embed_deg=False).
+    pos (N,S,3) raw sample positions, view_enc (N,27), latents = {"density": (1,128), "color": (1,128),
+    "articulation": (1,32)} broadcast to every sample (einops.repeat, :186-194)."""
+    n, s, _ = pos.shape
+    p = pos.reshape(-1, 3)
+    bn = p.shape[0]
+    shape = latents["density"].expand(bn, -1)
+    app = latents["color"].expand(bn, -1)
+    art = latents["articulation"].expand(bn, -1)
+    lin = lambda name, x: F.linear(x, sd[f"{prefix}{name}.weight"], sd[f"{prefix}{name}.bias"])  # noqa: E731
+    x = torch.cat([p, shape, art], -1)
+    for i in range(4):
+        x = F.relu(lin(f"deformations_linear.{i}", x))
+    x = lin("deformation_layer", x) + p
+    x = pos_enc(x, 0, 10)
+    x = torch.cat([x, shape], -1)
+    inputs = x
+    for idx in range(8):
+        x = F.relu(lin(f"pts_linears.{idx}", x))
+        if idx % 4 == 0 and idx > 0:
+            x = torch.cat([x, inputs], dim=-1)
+    raw_density = lin("density_layer", x).reshape(n, s, 1)
+    bott = lin("bottleneck_layer", x)
+    cond = view_enc[:, None, :].expand(n, s, view_enc.shape[-1]).reshape(-1, view_enc.shape[-1])
+    x = torch.cat([bott, cond, app], dim=-1)
+    for i in range(4):
+        x = F.relu(lin(f"views_linear.{i}", x))
+    raw_rgb = lin("rgb_layer", x).reshape(n, s, 3)
+    return raw_rgb, raw_density
+
+
+# --------------------------------------------------------------------------------------------------
+# R11  NeRF_AE_Art.forward              models/vanilla_nerf/model_autodecoder.py:278-337
+# --------------------------------------------------------------------------------------------------
+def nerf_ae_art_forward(sd, rays, randomized, white_bkgd, near, far, latents, num_levels=2, t_rand=None, u=None,
+                        return_aux=False):
+    ret, aux = [], []
+    t_vals = weights = None
+    for i_level in range(num_levels):
+        if i_level == 0:
+            t_vals, samples = sample_along_rays(rays["rays_o"], rays["rays_d"], 64, near, far, randomized, t_rand)
+            prefix = "coarse_mlp."
+        else:
+            t_mids = 0.5 * (t_vals[..., 1:] + t_vals[..., :-1])
+            t_vals, samples = sample_pdf(t_mids, weights[..., 1:-1], rays["rays_o"], rays["rays_d"], t_vals, 128, randomized, u)
+            prefix = "fine_mlp."
+        viewdirs_enc = pos_enc(rays["viewdirs"], 0, 4)
+        raw_rgb, raw_sigma = art_mlp(sd, prefix, samples, viewdirs_enc, latents)  # samples un-encoded (:306-307)
+        rgb = torch.sigmoid(raw_rgb) * (1 + 2 * 0.001) - 0.001                    # :321-322
+        sigma = F.softplus(raw_sigma + (-1.0))                                     # :323 (density_bias = -1)
+        comp_rgb, acc, weights, depth = volumetric_rendering(rgb, sigma, t_vals, rays["rays_d"], white_bkgd)
+        ret.append((comp_rgb, acc, depth))
+        aux.append({"t_vals": t_vals, "raw_rgb": raw_rgb, "raw_sigma": raw_sigma, "weights": weights})
+    return (ret, aux) if return_aux else ret
+
+
+# --------------------------------------------------------------------------------------------------
+# R12  CodeLibraryArticulated           models/code_library.py:36-71
+# --------------------------------------------------------------------------------------------------
+def code_library(sd, instance_id, articulation_id, is_test=False):
+    """Embedding lookups; at test time the 10 learned articulation codes are expanded to 19 = 10 + 9 mid-points
+    (code_library.py:55-71) and indexed by articulation_id."""
+    out = {"density": sd["embedding_instance_shape.weight"][instance_id],
+           "color": sd["embedding_instance_appearance.weight"][instance_id]}
+    art = sd["embedding_instance_articulation.weight"]
+    if is_test:
+        table = torch.zeros(19, art.shape[1])
+        table[0::2] = art
+        table[1::2] = (art[:-1] + art[1:]) / 2
+        out["articulation"] = table[articulation_id]
+    else:
+        out["articulation"] = art[articulation_id]
+    return out
+
+
+# --------------------------------------------------------------------------------------------------
 # R13  losses / metrics                   helper.py:17-22, models/interface.py:54-74
 # --------------------------------------------------------------------------------------------------
 def img2mse(x, y):

@@ -250,6 +250,41 @@ def main():
             arrs[f"{tag}_{name}_depth"] = out[lvl][2]
     save("g8_nerf_forward", **arrs)
 
+    # ---------------- G10/G11/G12 articulated model ----------------
+    from models.vanilla_nerf.model_autodecoder import NeRF_AE_Art
+    from models.code_library import CodeLibraryArticulated
+
+    hp = types.SimpleNamespace(N_max_objs=2, N_obj_code_length=128)
+    lib = CodeLibraryArticulated(hp)
+    lib.load_state_dict(syn.make_code_library_state(seed=0, n_max_objs=2))
+    batch = {"instance_id": torch.tensor([1]), "articulation_id": torch.tensor([3])}
+    lat_train = lib(batch)
+    lat_test = lib({"instance_id": torch.tensor([0]), "articulation_id": torch.tensor([7])}, is_test=True)
+    art_sd = syn.make_art_state_dict(seed=0, density_scale=30.0)
+    amodel = NeRF_AE_Art()
+    amodel.load_state_dict(art_sd, strict=True)
+    amodel.eval()
+    n9 = 96
+    rays9 = {k: v[:n9].contiguous() for k, v in rays8.items()}
+    with torch.no_grad():
+        t9, c9 = helper.sample_along_rays(rays9["rays_o"][:6], rays9["rays_d"][:6], 64, 2.0, 6.0, False, False)
+        venc9 = helper.pos_enc(rays9["viewdirs"][:6], 0, 4)
+        a_rgb, a_sig = amodel.fine_mlp(c9, venc9, lat_train)
+        aout_det = amodel(rays9, False, True, 2.0, 6.0, lat_train)
+        aout_tst = amodel(rays9, False, False, 2.0, 6.0, lat_test)
+        with patched_rand([t_rand8[:n9], u8[:n9]]):
+            aout_rnd = amodel(rays9, True, True, 2.0, 6.0, lat_train)
+    arrs = dict(seed=0, density_scale=30.0, near=2.0, far=6.0, t_rand=t_rand8[:n9], u=u8[:n9], **rays9,
+                lat_train_density=lat_train["density"], lat_train_color=lat_train["color"], lat_train_articulation=lat_train["articulation"],
+                lat_test_density=lat_test["density"], lat_test_color=lat_test["color"], lat_test_articulation=lat_test["articulation"],
+                mlp_pos=c9, mlp_viewdirs_enc=venc9, mlp_raw_rgb=a_rgb, mlp_raw_sigma=a_sig)
+    for tag, out in (("det", aout_det), ("tst_nowb", aout_tst), ("rnd", aout_rnd)):
+        for lvl, name in ((0, "coarse"), (1, "fine")):
+            arrs[f"{tag}_{name}_rgb"] = out[lvl][0]
+            arrs[f"{tag}_{name}_acc"] = out[lvl][1]
+            arrs[f"{tag}_{name}_depth"] = out[lvl][2]
+    save("g11_nerf_ae_art", **arrs)
+
     # ---------------- G13 metrics ----------------
     a = torch.rand((5, 16, 16, 3), generator=g) * 1.2 - 0.1
     b = torch.rand((5, 16, 16, 3), generator=g)
