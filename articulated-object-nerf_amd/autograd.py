@@ -1,0 +1,52 @@
+"""torch.autograd glue for the HIP render path (SURVEY 8(a) R14, 8(b) "Ownership"): ``NeRF.forward`` under
+``torch.is_grad_enabled()`` returns tensors whose graph reaches the module's parameters, so the reference's
+``training_step`` (``loss.backward()``, model.py:264-282) works unchanged.  Forward and backward are both HIP kernels
+(no eager-PyTorch math): fused forward with activation planes -> composite backward -> fused data-gradient chain ->
+split-N weight-gradient GEMMs.  Gradients reach only the MLP parameters: the inverse-CDF draws are detached
+(helper.py:249) and rays are data."""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+
+
+class RenderVanilla(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, rays_o, rays_d, viewdirs, near, far, white_bkgd, num_levels, t_rand, u, packs, *params):
+        # packs: [(packed_fwd, packed_bwd)] per level; params: 24 tensors per level in ops.VANILLA_PARAM_ORDER
+        saved, outs = [], []
+        t_vals = weights = None
+        for lvl in range(num_levels):
+            packed_fwd, packed_bwd = packs[lvl]
+            if lvl == 0:
+                t_vals, _ = ops.sample_along_rays(rays_o, rays_d, 64, near, far, t_rand, want_coords=False)
+            else:
+                t_vals = ops.sample_pdf_t(t_vals, weights, u)
+            raw, planes = ops.mlp_fwd_train(packed_fwd, rays_o, rays_d, viewdirs, t_vals)
+            rgb, acc, weights, depth = ops.composite_raw(raw, t_vals, rays_d, white_bkgd, ops.ACT_VANILLA, want_weights=True)
+            outs += [rgb, acc, depth]
+            saved.append((raw, t_vals, planes, packed_fwd, packed_bwd))
+        ctx.saved = saved
+        ctx.rays_d = rays_d
+        ctx.white_bkgd = white_bkgd
+        ctx.num_levels = num_levels
+        ctx.mark_non_differentiable(*[o for i, o in enumerate(outs) if False])
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        grads = []
+        for lvl in range(ctx.num_levels):
+            raw, t_vals, planes, packed_fwd, packed_bwd = ctx.saved[lvl]
+            g_rgb, g_acc, g_depth = gouts[3 * lvl: 3 * lvl + 3]
+            if g_rgb is None:
+                g_rgb = torch.zeros((t_vals.shape[0], 3), dtype=torch.float32, device=t_vals.device)
+            d_raw = ops.composite_bwd(raw, t_vals, ctx.rays_d, g_rgb.contiguous(), g_acc, g_depth, ctx.white_bkgd, ops.ACT_VANILLA,
+                                      planes.shape[1])
+            dplanes = ops.mlp_bwd_chain(packed_bwd, packed_fwd, d_raw, planes)
+            g = ops.vanilla_wgrad(planes, dplanes, d_raw)
+            grads += [g[name] for name in ops.VANILLA_PARAM_ORDER]
+            del dplanes
+        ctx.saved = None
+        return (None,) * 10 + tuple(grads)

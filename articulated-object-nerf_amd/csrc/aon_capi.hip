@@ -23,6 +23,18 @@ hipError_t launch_art_mlp_fwd_pos(const char* packed, const float* small, const 
                                   int64_t n_rays, int S, float* raw, hipStream_t stream);
 int64_t art_stream_bytes();
 int64_t art_small_bytes();
+hipError_t launch_mlp_fwd_train(const char* packed, const float* rays_o, const float* rays_d, const float* viewdirs,
+                                const float* t_vals, int64_t n_rays, int S, float* raw, float* planes, hipStream_t stream);
+hipError_t launch_composite_bwd(const float* raw, const float* t_vals, const float* dirs, const float* g_rgb, const float* g_acc,
+                                const float* g_depth, int64_t n_rays, int S, int white_bkgd, int act, float* d_raw,
+                                hipStream_t stream);
+hipError_t launch_pack_vanilla_bwd(const float* const* params, float* packed, hipStream_t stream);
+int64_t bwd_stream_bytes();
+hipError_t launch_mlp_bwd_chain(const char* packed_bwd, const char* packed_fwd, const float* d_raw, const float* planes,
+                                float* dplanes, int64_t Np, hipStream_t stream);
+int64_t wgrad_workspace_bytes();
+hipError_t launch_vanilla_wgrad(const float* planes, const float* dplanes, const float* d_raw, int64_t Np, float* const* grads,
+                                float* ws, hipStream_t stream);
 hipError_t launch_raygen(const float* c2w, int H, int W, float focal, const float* directions, int64_t pix_begin,
                          int64_t pix_end, float* rays_o, float* viewdirs, float* rays_d, hipStream_t stream);
 hipError_t launch_ray_directions(int H, int W, float focal, float* out, hipStream_t stream);
@@ -212,6 +224,58 @@ int aon_sample_pdf(const float* bins, const float* weights, int64_t w_stride, co
     return fail(AON_E_INVALID, "aon_sample_pdf: null pointer");
   return check(aon::launch_sample_pdf(bins, weights, w_stride, t_coarse, u, u_stride, n_rays, samples, t_fine,
                                       (hipStream_t)stream), "aon_sample_pdf");
+}
+
+// ---- training (R14) ----
+int64_t aon_train_plane_rows(void) { return aon::kPlRows; }
+int64_t aon_bwd_packed_bytes(void) { return aon::bwd_stream_bytes(); }
+int64_t aon_wgrad_workspace_bytes(void) { return aon::wgrad_workspace_bytes(); }
+
+int aon_pack_vanilla_mlp_bwd(const float* const* params_host, void* packed_bwd, void* stream) {
+  if (!params_host || !packed_bwd) return fail(AON_E_INVALID, "aon_pack_vanilla_mlp_bwd: null pointer");
+  for (int i = 0; i < aon::kNumVanillaParams; ++i)
+    if (!params_host[i]) return fail(AON_E_INVALID, "aon_pack_vanilla_mlp_bwd: null parameter pointer");
+  if (reinterpret_cast<uintptr_t>(packed_bwd) & 15) return fail(AON_E_INVALID, "aon_pack_vanilla_mlp_bwd: buffer must be 16-byte aligned");
+  return check(aon::launch_pack_vanilla_bwd(params_host, static_cast<float*>(packed_bwd), (hipStream_t)stream), "aon_pack_vanilla_mlp_bwd");
+}
+
+int aon_mlp_fwd_train(const void* packed, const float* rays_o, const float* rays_d, const float* viewdirs, const float* t_vals,
+                      int64_t n_rays, int S, float* raw, float* planes, void* stream) {
+  if (n_rays < 0 || S < 1) return fail(AON_E_INVALID, "aon_mlp_fwd_train: bad size");
+  if (n_rays == 0) return AON_OK;
+  if (!packed || !rays_o || !rays_d || !viewdirs || !t_vals || !raw || !planes) return fail(AON_E_INVALID, "aon_mlp_fwd_train: null pointer");
+  MlpTimer timer((hipStream_t)stream, n_rays * S);
+  return check(aon::launch_mlp_fwd_train(static_cast<const char*>(packed), rays_o, rays_d, viewdirs, t_vals, n_rays, S, raw, planes,
+                                         (hipStream_t)stream), "aon_mlp_fwd_train");
+}
+
+int aon_composite_bwd(const float* raw, const float* t_vals, const float* dirs, const float* g_rgb, const float* g_acc,
+                      const float* g_depth, int64_t n_rays, int S, int white_bkgd, int act, float* d_raw, void* stream) {
+  if (n_rays < 0 || S < 1 || S > 256 || act < 0 || act > 2) return fail(AON_E_INVALID, "aon_composite_bwd: bad size / act (S <= 256)");
+  if (n_rays == 0) return AON_OK;
+  if (!raw || !t_vals || !dirs || !g_rgb || !d_raw) return fail(AON_E_INVALID, "aon_composite_bwd: null pointer");
+  return check(aon::launch_composite_bwd(raw, t_vals, dirs, g_rgb, g_acc, g_depth, n_rays, S, white_bkgd, act, d_raw,
+                                         (hipStream_t)stream), "aon_composite_bwd");
+}
+
+int aon_mlp_bwd_chain(const void* packed_bwd, const void* packed_fwd, const float* d_raw, const float* planes, float* dplanes,
+                      int64_t Np, void* stream) {
+  if (Np < 0 || (Np & 127)) return fail(AON_E_INVALID, "aon_mlp_bwd_chain: Np must be a multiple of 128");
+  if (Np == 0) return AON_OK;
+  if (!packed_bwd || !packed_fwd || !d_raw || !planes || !dplanes) return fail(AON_E_INVALID, "aon_mlp_bwd_chain: null pointer");
+  return check(aon::launch_mlp_bwd_chain(static_cast<const char*>(packed_bwd), static_cast<const char*>(packed_fwd), d_raw, planes,
+                                         dplanes, Np, (hipStream_t)stream), "aon_mlp_bwd_chain");
+}
+
+int aon_vanilla_wgrad(const float* planes, const float* dplanes, const float* d_raw, int64_t Np, float* const* grads_host,
+                      void* workspace, int64_t workspace_bytes, void* stream) {
+  if (Np <= 0 || (Np & 127)) return fail(AON_E_INVALID, "aon_vanilla_wgrad: Np must be a positive multiple of 128");
+  if (!planes || !dplanes || !d_raw || !grads_host || !workspace) return fail(AON_E_INVALID, "aon_vanilla_wgrad: null pointer");
+  for (int i = 0; i < aon::kNumVanillaParams; ++i)
+    if (!grads_host[i]) return fail(AON_E_INVALID, "aon_vanilla_wgrad: null gradient pointer");
+  if (workspace_bytes < aon::wgrad_workspace_bytes()) return fail(AON_E_WORKSPACE, "aon_vanilla_wgrad: workspace too small");
+  return check(aon::launch_vanilla_wgrad(planes, dplanes, d_raw, Np, grads_host, static_cast<float*>(workspace), (hipStream_t)stream),
+               "aon_vanilla_wgrad");
 }
 
 int aon_profile_begin(void) {

@@ -82,6 +82,17 @@ constexpr int64_t kSmallBytes = kSmallFloats * 4;
 
 constexpr int64_t kPackedBytes = kStreamBytes + kSmallBytes;  // one packed MLP
 
+// Training: feature-major activation planes of one vanilla NeRFMLP level, plane[row * Np + sample] (Np = samples padded
+// to a multiple of 128).  Rows are TRUE feature indices (encodings: the reference's column order), so weight
+// gradients come out in nn.Linear's (out,in) order without un-permuting.  The same row map is used for the
+// pre-activation gradient planes written by the backward chain.
+constexpr int kPlE = 0;                        // 64 rows: pos-enc (63 + zero pad)            input of L0 / L5 skip
+__host__ __device__ constexpr int plane_h(int l) { return 64 + 256 * l; }  // 8 x 256 rows: trunk outputs (post-ReLU)
+constexpr int kPlBot = 64 + 8 * 256;           // 256 rows: bottleneck output (no activation)
+constexpr int kPlVE = kPlBot + 256;            // 32 rows: view-enc (27 + zero pad)
+constexpr int kPlHV = kPlVE + 32;              // 128 rows: view-layer output (post-ReLU)
+constexpr int kPlRows = kPlHV + 128;           // 2528 rows = 10,112 B per sample
+
 // Parameter order of the `params` pointer array handed to aon_pack_vanilla_mlp (device pointers to the
 // unmodified torch nn.Linear storages, (out,in) row-major fp32):
 //   0..15  pts_linears.{0..7}.{weight,bias}

@@ -91,11 +91,14 @@ struct MlpArgs {
   int64_t total;             // n_rays*S
   int S;
   int npass;                 // ceil(total/128)
+  float* planes;             // [TRAIN] kPlRows x Np feature-major activation planes
+  int64_t Np;                // npass * 128
 };
 
 constexpr int kLdsBytes = kRingBytes + (int)kSmallBytes;
 
-template <bool ENC_IN_KERNEL>
+// TRAIN additionally stores every layer's input/output activations as feature-major planes for the backward pass.
+template <bool ENC_IN_KERNEL, bool TRAIN>
 __global__ void __launch_bounds__(256) mlp_fwd_kernel(MlpArgs args) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* sm = reinterpret_cast<float*>(smem + kRingBytes);
@@ -148,31 +151,41 @@ __global__ void __launch_bounds__(256) mlp_fwd_kernel(MlpArgs args) {
       load_view_enc(args.viewdirs_enc + ray * kViewEnc, h, V);
     }
 
+    const int64_t col = (int64_t)pass * 128 + wave * 32 + m;  // plane column of this lane's sample
+    PlaneIO io{};
+    if constexpr (TRAIN) io = make_plane_io(args.Np, col, h);
+    auto save = [&](auto& tiles, int row) {
+      if constexpr (TRAIN) store_plane(tiles, reinterpret_cast<float*>(reinterpret_cast<char*>(args.planes) + (int64_t)row * io.row_bytes), io);
+    };
+    if constexpr (TRAIN) {
+      store_pos_enc_plane(E, reinterpret_cast<float*>(reinterpret_cast<char*>(args.planes) + (int64_t)kPlE * io.row_bytes), io, col, h);
+      store_view_enc_plane(V, reinterpret_cast<float*>(reinterpret_cast<char*>(args.planes) + (int64_t)kPlVE * io.row_bytes), io, col, h);
+    }
     f32x16 X[8], Y[8];
     // L0: enc(63) -> 256
     init_bias(X, sm + kSmBias + 0 * 256, h);
     chunk_mma<VanillaNet, kChL0 + 0, 8, 16>(p, E[0], X);
     chunk_mma<VanillaNet, kChL0 + 1, 8, 16>(p, E[1], X);
-    relu_tiles(X);
+    relu_tiles(X); save(X, plane_h(0));
     // L1..L4
-    init_bias(Y, sm + kSmBias + 1 * 256, h); dense_layer<VanillaNet, kChL1 + 0, 8, 8>(p, X, Y); relu_tiles(Y);
-    init_bias(X, sm + kSmBias + 2 * 256, h); dense_layer<VanillaNet, kChL1 + 8, 8, 8>(p, Y, X); relu_tiles(X);
-    init_bias(Y, sm + kSmBias + 3 * 256, h); dense_layer<VanillaNet, kChL1 + 16, 8, 8>(p, X, Y); relu_tiles(Y);
-    init_bias(X, sm + kSmBias + 4 * 256, h); dense_layer<VanillaNet, kChL1 + 24, 8, 8>(p, Y, X); relu_tiles(X);
+    init_bias(Y, sm + kSmBias + 1 * 256, h); dense_layer<VanillaNet, kChL1 + 0, 8, 8>(p, X, Y); relu_tiles(Y); save(Y, plane_h(1));
+    init_bias(X, sm + kSmBias + 2 * 256, h); dense_layer<VanillaNet, kChL1 + 8, 8, 8>(p, Y, X); relu_tiles(X); save(X, plane_h(2));
+    init_bias(Y, sm + kSmBias + 3 * 256, h); dense_layer<VanillaNet, kChL1 + 16, 8, 8>(p, X, Y); relu_tiles(Y); save(Y, plane_h(3));
+    init_bias(X, sm + kSmBias + 4 * 256, h); dense_layer<VanillaNet, kChL1 + 24, 8, 8>(p, Y, X); relu_tiles(X); save(X, plane_h(4));
     // L5: cat[h(256), enc(63)] -> 256     (model.py:102-103: concat after layer 4's ReLU)
     init_bias(Y, sm + kSmBias + 5 * 256, h);
     dense_layer<VanillaNet, kChL5, 8, 8>(p, X, Y);
     chunk_mma<VanillaNet, kChL5 + 8, 8, 16>(p, E[0], Y);
     chunk_mma<VanillaNet, kChL5 + 9, 8, 16>(p, E[1], Y);
-    relu_tiles(Y);
+    relu_tiles(Y); save(Y, plane_h(5));
     // L6, L7
-    init_bias(X, sm + kSmBias + 6 * 256, h); dense_layer<VanillaNet, kChL6, 8, 8>(p, Y, X); relu_tiles(X);
-    init_bias(Y, sm + kSmBias + 7 * 256, h); dense_layer<VanillaNet, kChL7, 8, 8>(p, X, Y); relu_tiles(Y);
+    init_bias(X, sm + kSmBias + 6 * 256, h); dense_layer<VanillaNet, kChL6, 8, 8>(p, Y, X); relu_tiles(X); save(X, plane_h(6));
+    init_bias(Y, sm + kSmBias + 7 * 256, h); dense_layer<VanillaNet, kChL7, 8, 8>(p, X, Y); relu_tiles(Y); save(Y, plane_h(7));
     // density head (model.py:105) on the post-ReLU layer-7 output
     float sigma = head_partial<8>(Y, sm + kSmWSigma, h);
     sigma = sigma + __shfl_xor(sigma, 32) + sm[kSmBSigma];
     // bottleneck, no activation (model.py:109)
-    init_bias(X, sm + kSmBiasBott, h); dense_layer<VanillaNet, kChBott, 8, 8>(p, Y, X);
+    init_bias(X, sm + kSmBiasBott, h); dense_layer<VanillaNet, kChBott, 8, 8>(p, Y, X); save(X, kPlBot);
     // view branch: cat[bottleneck(256), viewenc(27)] -> 128, ReLU (model.py:110-116)
     f32x16 Z[4];
     init_bias(Z, sm + kSmBiasView, h);
@@ -185,7 +198,7 @@ __global__ void __launch_bounds__(256) mlp_fwd_kernel(MlpArgs args) {
     chunk_mma<VanillaNet, kChView + 6, 4, 16>(p, X[6], Z);
     chunk_mma<VanillaNet, kChView + 7, 4, 16>(p, X[7], Z);
     chunk_mma<VanillaNet, kChView + 8, 4, 14>(p, V, Z);
-    relu_tiles(Z);
+    relu_tiles(Z); save(Z, kPlHV);
     // rgb head (model.py:118)
     float rgb[3];
 #pragma unroll
@@ -212,7 +225,7 @@ hipError_t launch_pack_vanilla(const float* const* params, float* packed, hipStr
   return hipGetLastError();
 }
 
-static bool g_attr_set[2] = {false, false};
+static bool g_attr_set[3] = {false, false, false};
 
 int num_cus() {  // CUs of the current device (one process drives one GPU)
   static int cus = 0;
@@ -225,19 +238,20 @@ int num_cus() {  // CUs of the current device (one process drives one GPU)
   return cus;
 }
 
-template <bool ENC>
+template <bool ENC, bool TRAIN>
 static hipError_t launch_mlp_t(const MlpArgs& args, hipStream_t stream) {
-  if (!g_attr_set[ENC]) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fwd_kernel<ENC>),
+  constexpr int slot = TRAIN ? 2 : (ENC ? 1 : 0);
+  if (!g_attr_set[slot]) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fwd_kernel<ENC, TRAIN>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
     if (e != hipSuccess) return e;
-    g_attr_set[ENC] = true;
+    g_attr_set[slot] = true;
   }
   const int g_num_cus = num_cus();
   if (g_num_cus <= 0) return hipErrorInvalidDevice;
   const int grid = args.npass < g_num_cus ? args.npass : g_num_cus;
   if (grid <= 0) return hipSuccess;
-  mlp_fwd_kernel<ENC><<<dim3(grid), dim3(256), kLdsBytes, stream>>>(args);
+  mlp_fwd_kernel<ENC, TRAIN><<<dim3(grid), dim3(256), kLdsBytes, stream>>>(args);
   return hipGetLastError();
 }
 
@@ -246,7 +260,17 @@ hipError_t launch_mlp_fwd(const char* packed, const float* rays_o, const float* 
   MlpArgs a{};
   a.packed = packed; a.rays_o = rays_o; a.rays_d = rays_d; a.viewdirs = viewdirs; a.t_vals = t_vals;
   a.raw = raw; a.total = n_rays * S; a.S = S; a.npass = (int)((a.total + 127) / 128);
-  return launch_mlp_t<true>(a, stream);
+  return launch_mlp_t<true, false>(a, stream);
+}
+
+// Training forward: as launch_mlp_fwd, plus the activation planes (kPlRows x Np floats, Np = 128*ceil(n*S/128)).
+hipError_t launch_mlp_fwd_train(const char* packed, const float* rays_o, const float* rays_d, const float* viewdirs,
+                                const float* t_vals, int64_t n_rays, int S, float* raw, float* planes, hipStream_t stream) {
+  MlpArgs a{};
+  a.packed = packed; a.rays_o = rays_o; a.rays_d = rays_d; a.viewdirs = viewdirs; a.t_vals = t_vals;
+  a.raw = raw; a.total = n_rays * S; a.S = S; a.npass = (int)((a.total + 127) / 128);
+  a.planes = planes; a.Np = (int64_t)a.npass * 128;
+  return launch_mlp_t<true, true>(a, stream);
 }
 
 hipError_t launch_mlp_fwd_enc(const char* packed, const float* samples_enc, const float* viewdirs_enc,
@@ -254,7 +278,7 @@ hipError_t launch_mlp_fwd_enc(const char* packed, const float* samples_enc, cons
   MlpArgs a{};
   a.packed = packed; a.samples_enc = samples_enc; a.viewdirs_enc = viewdirs_enc;
   a.raw = raw; a.total = n_rays * S; a.S = S; a.npass = (int)((a.total + 127) / 128);
-  return launch_mlp_t<false>(a, stream);
+  return launch_mlp_t<false, false>(a, stream);
 }
 
 }  // namespace aon

@@ -127,6 +127,59 @@ __device__ __forceinline__ float head_partial(const f32x16 (&x)[NT], const float
 }
 
 
+// Training: register tiles <-> feature-major planes (row = true feature, column = sample).  Per memory
+// instruction the two half-waves touch two 128-byte row segments (32 consecutive samples of features f and f+4).
+// Addressing is  [uniform 64-bit row base in SGPRs]  +  [one 32-bit per-lane byte offset]: `row_bytes` is re-made
+// opaque every pass so that the hundreds of distinct row bases are recomputed on the scalar unit instead of being
+// hoisted out of the pass loop into (spilled) vector registers.
+struct PlaneIO {
+  int64_t row_bytes;  // Np * 4
+  unsigned voff;      // (col + 4*h*Np) * 4 : this lane's offset from the base of row (32t + (r&3) + 8(r>>2))
+};
+
+__device__ __forceinline__ PlaneIO make_plane_io(int64_t Np, int64_t col, int h) {
+  PlaneIO io;
+  int64_t rb = Np * 4;
+  asm volatile("" : "+s"(rb));
+  io.row_bytes = rb;
+  io.voff = (unsigned)((col + (int64_t)(4 * h) * Np) * 4);
+  return io;
+}
+
+__device__ __forceinline__ float* plane_addr(float* plane, const PlaneIO& io, int row) {
+  return reinterpret_cast<float*>(reinterpret_cast<char*>(plane) + (int64_t)row * io.row_bytes + io.voff);
+}
+__device__ __forceinline__ const float* plane_addr(const float* plane, const PlaneIO& io, int row) {
+  return reinterpret_cast<const float*>(reinterpret_cast<const char*>(plane) + (int64_t)row * io.row_bytes + io.voff);
+}
+
+template <int NT>
+__device__ __forceinline__ void store_plane(const f32x16 (&x)[NT], float* plane, const PlaneIO& io) {
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) *plane_addr(plane, io, 32 * t + (r & 3) + 8 * (r >> 2)) = x[t][r];
+  }
+}
+
+// encodings are held in a permuted register order (posenc_col / viewenc_col); planes use the reference's columns.
+// `col_off` = byte offset of the lane's sample inside a row (col*4), rows are addressed individually here.
+__device__ __forceinline__ void store_pos_enc_plane(const f32x16 (&E)[2], float* plane, const PlaneIO& io, int64_t col, int h) {
+  char* base = reinterpret_cast<char*>(plane) + col * 4;
+#pragma unroll
+  for (int rho = 0; rho < 30; ++rho) *reinterpret_cast<float*>(base + (int64_t)(3 + rho + 30 * h) * io.row_bytes) = E[rho >> 4][rho & 15];
+  *reinterpret_cast<float*>(base + (int64_t)(h ? 2 : 0) * io.row_bytes) = E[1][14];
+  if (!h) *reinterpret_cast<float*>(base + io.row_bytes) = E[1][15];
+}
+
+__device__ __forceinline__ void store_view_enc_plane(const f32x16& V, float* plane, const PlaneIO& io, int64_t col, int h) {
+  char* base = reinterpret_cast<char*>(plane) + col * 4;
+#pragma unroll
+  for (int rho = 0; rho < 12; ++rho) *reinterpret_cast<float*>(base + (int64_t)(3 + rho + 12 * h) * io.row_bytes) = V[rho];
+  *reinterpret_cast<float*>(base + (int64_t)(h ? 2 : 0) * io.row_bytes) = V[12];
+  if (!h) *reinterpret_cast<float*>(base + io.row_bytes) = V[13];
+}
+
 // Positional / view encodings directly in accumulator (= next layer's B operand) layout: lanes 0-31 hold the sin
 // features, lanes 32-63 the sin(. + fp32(pi/2)) features of the same sample; the identity features ride in the
 // last registers (pack kernels: posenc_col / viewenc_col).  helper.py:136-140.

@@ -1,0 +1,571 @@
+// Backward pass of the vanilla render path for gfx950 (what autograd does implicitly for
+// models/vanilla_nerf/model.py:264-273 loss.backward()).  Gradients reach only the MLP parameters: t_samples is
+// detached (helper.py:249) and rays / t are data.
+//
+// Four kernels, all in the feature-major ("transposed") register/plane layout of the fused forward:
+//   composite_bwd_kernel   d(comp_rgb, acc, depth) -> d(raw rgb, raw sigma) per sample, one wavefront per ray.
+//   mlp_bwd_chain_kernel   the data-gradient chain rgb head -> view layer -> bottleneck (+sigma head) -> trunk 7..1,
+//                          register-resident exactly like the forward: dH_{l-1}^T = W_l^T . dZ_l^T with the
+//                          TRANSPOSED weights streamed as MFMA A operands and the gradient tiles as B operands;
+//                          writes every layer's pre-activation gradient dZ_l as a feature-major plane.
+//   wgrad_kernel           dW_l = dZ_l^T[M x N] . H_{l-1}^T[K x N]^T : both operands are planes whose contiguous axis
+//                          is the contraction axis (samples), so fragments are plain ds_read_b128; the sample range is
+//                          split across workgroups, each holding a full M x K accumulator block in registers, and a
+//                          deterministic second stage sums the per-workgroup partials (no atomics).
+//   head_wgrad_kernel      the 1- and 3-row head weights and all bias sums (row reductions of planes).
+#include "aon_mlp_core.h"
+
+namespace aon {
+
+__device__ __forceinline__ float wsum64(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// composite backward   (helper.volumetric_rendering, helper.py:157-195, + the activations of model.py:186-187 /
+// model_autodecoder.py:321-323)
+// ---------------------------------------------------------------------------------------------
+struct CompositeBwdArgs {
+  const float* raw;     // (n*S,4) raw rgb, raw sigma (as written by the forward)
+  const float* t_vals;  // (n,S)
+  const float* dirs;    // (n,3)
+  const float* g_rgb;   // (n,3) dL/d comp_rgb
+  const float* g_acc;   // (n,) or null
+  const float* g_depth; // (n,) or null
+  int64_t n_rays; int S; int white_bkgd; int act;
+  float* d_raw;         // (n*S,4) dL/d raw
+};
+
+__device__ __forceinline__ float sigmoidf_(float x) { return __fdiv_rn(1.0f, __fadd_rn(1.0f, expf(-x))); }
+
+__global__ void __launch_bounds__(256) composite_bwd_kernel(CompositeBwdArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int64_t ray = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (ray >= a.n_rays) return;
+  const int S = a.S;
+  const int nblk = (S + 63) >> 6;  // <= 4 (S <= 256)
+  const float* tv = a.t_vals + ray * S;
+  const float dn = __fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(a.dirs[ray * 3], a.dirs[ray * 3]),
+                                                  __fmul_rn(a.dirs[ray * 3 + 1], a.dirs[ray * 3 + 1])),
+                                        __fmul_rn(a.dirs[ray * 3 + 2], a.dirs[ray * 3 + 2])));
+  const float gC0 = a.g_rgb[ray * 3], gC1 = a.g_rgb[ray * 3 + 1], gC2 = a.g_rgb[ray * 3 + 2];
+  const float gA = a.g_acc ? a.g_acc[ray] : 0.f, gD = a.g_depth ? a.g_depth[ray] : 0.f;
+  // dL/dw_i = gC.c_i - [white] sum(gC) + g_acc + t_i g_depth     (comp_rgb += 1 - acc, helper.py:187-188)
+  const float gw_const = gA - (a.white_bkgd ? (gC0 + gC1 + gC2) : 0.f);
+
+  float alpha[4], T[4], f[4], dist[4], wgw[4], gw[4], dsig_draw[4], w_[4];
+  float dc0[4], dc1[4], dc2[4];  // d c / d raw  (activation derivative), later reused as gC.c' products
+  float carry = 1.0f;
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    alpha[b] = 0.f; T[b] = 0.f; f[b] = 1.f; dist[b] = 0.f; wgw[b] = 0.f; gw[b] = 0.f; dsig_draw[b] = 0.f; w_[b] = 0.f;
+    dc0[b] = dc1[b] = dc2[b] = 0.f;
+    if (b < nblk) {
+      const int s = b * 64 + lane;
+      const bool in = s < S;
+      float c0 = 0.f, c1 = 0.f, c2 = 0.f, t = 0.f;
+      if (in) {
+        const int64_t g = ray * S + s;
+        t = tv[s];
+        dist[b] = __fmul_rn(s == S - 1 ? 1e10f : __fsub_rn(tv[s + 1], t), dn);
+        const float4 r = reinterpret_cast<const float4*>(a.raw)[g];
+        float sg;
+        if (a.act == 1) {
+          sg = __builtin_fmaxf(r.w, 0.f); dsig_draw[b] = r.w > 0.f ? 1.f : 0.f;
+          c0 = sigmoidf_(r.x); c1 = sigmoidf_(r.y); c2 = sigmoidf_(r.z);
+          dc0[b] = c0 * (1.f - c0); dc1[b] = c1 * (1.f - c1); dc2[b] = c2 * (1.f - c2);
+        } else if (a.act == 2) {
+          const float xs = r.w - 1.0f;
+          sg = xs > 20.0f ? xs : log1pf(expf(xs)); dsig_draw[b] = xs > 20.0f ? 1.f : sigmoidf_(xs);
+          const float s0 = sigmoidf_(r.x), s1 = sigmoidf_(r.y), s2 = sigmoidf_(r.z);
+          c0 = s0 * 1.002f - 0.001f; c1 = s1 * 1.002f - 0.001f; c2 = s2 * 1.002f - 0.001f;
+          dc0[b] = 1.002f * s0 * (1.f - s0); dc1[b] = 1.002f * s1 * (1.f - s1); dc2[b] = 1.002f * s2 * (1.f - s2);
+        } else {
+          sg = r.w; dsig_draw[b] = 1.f; c0 = r.x; c1 = r.y; c2 = r.z; dc0[b] = dc1[b] = dc2[b] = 1.f;
+        }
+        alpha[b] = __fsub_rn(1.0f, expf(-__fmul_rn(sg, dist[b])));
+        f[b] = __fadd_rn(__fsub_rn(1.0f, alpha[b]), 1e-10f);
+      }
+      // forward transmittance, as composite_kernel
+      float incl = f[b];
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const float o = __shfl_up(incl, off);
+        if (lane >= off) incl = incl * o;
+      }
+      float excl = __shfl_up(incl, 1);
+      if (lane == 0) excl = 1.0f;
+      T[b] = carry * excl;
+      carry = carry * __shfl(incl, 63);
+      w_[b] = alpha[b] * T[b];
+      gw[b] = in ? (gC0 * c0 + gC1 * c1 + gC2 * c2 + gw_const + t * gD) : 0.f;
+      wgw[b] = in ? w_[b] * gw[b] : 0.f;
+    }
+  }
+  // suffix sums  Sfx_i = sum_{k>i} w_k gw_k, scanned from the far end (no subtractive cancellation)
+  float sfx_carry = 0.f;
+#pragma unroll
+  for (int b = 3; b >= 0; --b) {
+    if (b < nblk) {
+      float incl = wgw[b];
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const float o = __shfl_down(incl, off);
+        if (lane + off < 64) incl = incl + o;
+      }
+      float excl = __shfl_down(incl, 1);
+      if (lane == 63) excl = 0.f;
+      const float sfx = excl + sfx_carry;
+      sfx_carry = sfx_carry + __shfl(incl, 0);
+      const int s = b * 64 + lane;
+      if (s < S) {
+        // dL/dalpha_i = T_i gw_i - Sfx_i / (1 - alpha_i + 1e-10);  dalpha/dsigma = dist * exp(-sigma dist) = dist (1 - alpha)
+        const float dalpha = T[b] * gw[b] - sfx / f[b];
+        const float dsigma = dalpha * dist[b] * (1.0f - alpha[b]);
+        float4 o;
+        o.x = w_[b] * gC0 * dc0[b]; o.y = w_[b] * gC1 * dc1[b]; o.z = w_[b] * gC2 * dc2[b];
+        o.w = dsigma * dsig_draw[b];
+        reinterpret_cast<float4*>(a.d_raw)[ray * S + s] = o;
+      }
+    }
+  }
+}
+
+hipError_t launch_composite_bwd(const float* raw, const float* t_vals, const float* dirs, const float* g_rgb, const float* g_acc,
+                                const float* g_depth, int64_t n_rays, int S, int white_bkgd, int act, float* d_raw,
+                                hipStream_t stream) {
+  if (n_rays <= 0) return hipSuccess;
+  CompositeBwdArgs a{raw, t_vals, dirs, g_rgb, g_acc, g_depth, n_rays, S, white_bkgd, act, d_raw};
+  composite_bwd_kernel<<<dim3((unsigned)((n_rays + 3) / 4)), dim3(256), 0, stream>>>(a);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward data chain
+// ---------------------------------------------------------------------------------------------
+// Transposed weight stream: 68 chunks of 32 KiB; chunk = 32 OUTPUT features j of a layer x all 256 INPUT features:
+//   chunk[q][Tp][lane][c] = W[j = 32T + 8q + 4(lane>>5) + c][f = 32Tp + (lane&31)]
+constexpr int kBwView = 0;   // views_linear.0  (128 x 283): 4 chunks (cols 0..255 -> d bottleneck)
+constexpr int kBwBott = 4;   // bottleneck_layer: 8
+constexpr int kBwL7 = 12;    // pts_linears.7 ... pts_linears.1: 8 each, in backward order
+constexpr int kBwNumChunks = 68;
+
+struct BwdNet {
+  static constexpr int kNumChunks = kBwNumChunks;
+  static constexpr int chunk_bytes(int) { return kBigChunkBytes; }
+};
+constexpr int64_t kBwStreamBytes = (int64_t)kBwNumChunks * kBigChunkBytes;
+
+struct PackArgs24 {
+  const float* p[kNumVanillaParams];
+};
+
+__global__ void pack_vanilla_bwd_kernel(PackArgs24 a, float* __restrict__ packed) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= kBwStreamBytes / 4) return;
+  const int c = (int)(idx / (kBigChunkBytes / 4)), r = (int)(idx % (kBigChunkBytes / 4));
+  const int cc = r & 3, lane = (r >> 2) & 63, rest = r >> 8;
+  const int tp = rest & 7, q = rest >> 3;
+  const int h = lane >> 5, f = 32 * tp + (lane & 31);
+  const int jo = 8 * q + 4 * h + cc;
+  const float* W; int ld, j;
+  if (c < kBwBott) { W = a.p[16]; ld = 256 + kViewEnc; j = 32 * c + jo; }
+  else if (c < kBwL7) { W = a.p[18]; ld = 256; j = 32 * (c - kBwBott) + jo; }
+  else {
+    const int l = 7 - (c - kBwL7) / 8;  // 7,6,5,4,3,2,1
+    W = a.p[2 * l]; ld = l == 5 ? 256 + kPosEnc : 256; j = 32 * ((c - kBwL7) % 8) + jo;
+  }
+  packed[idx] = W[(int64_t)j * ld + f];
+}
+
+struct BwdArgs {
+  const char* packed_bwd;   // kBwStreamBytes
+  const float* small;       // forward small block (head weights): packed_fwd + kStreamBytes
+  const float* d_raw;       // (Np,4)   zero for padded samples
+  const float* planes;      // forward activation planes (ReLU masks)
+  float* dplanes;           // pre-activation gradient planes, same row map
+  int64_t Np;
+  int npass;
+};
+
+template <int NT>
+__device__ __forceinline__ void zero_tiles(f32x16 (&x)[NT]) {
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) x[t][r] = 0.f;
+}
+
+// dZ = (H > 0) ? dH : 0, written to the gradient plane; H read from the activation plane (same addressing)
+template <int NT>
+__device__ __forceinline__ void mask_and_store(f32x16 (&x)[NT], const float* hplane, float* dplane, const PlaneIO& io) {
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = 32 * t + (r & 3) + 8 * (r >> 2);
+      const float hv = *plane_addr(hplane, io, row);
+      const float v = hv > 0.f ? x[t][r] : 0.f;
+      x[t][r] = v;
+      *plane_addr(dplane, io, row) = v;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) mlp_bwd_chain_kernel(BwdArgs args) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* sm = reinterpret_cast<float*>(smem + kRingBytes);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int m = lane & 31, h = lane >> 5;
+  {
+    const f32x4* src = reinterpret_cast<const f32x4*>(args.small);
+    f32x4* dst = reinterpret_cast<f32x4*>(sm);
+    for (int i = tid; i < kSmallFloats / 4; i += 256) dst[i] = src[i];
+  }
+  Pipe p;
+  p.stream = args.packed_bwd; p.ring = smem;
+  p.voff = (unsigned)(wave * 1024 + lane * 16);
+  p.wave_off = wave * 1024; p.lane_off = lane * 16;
+  p.slot = 1; p.issue_off = 0;
+  issue_chunk<BwdNet, 0>(p, 0);
+  __syncthreads();
+
+  for (int pass = blockIdx.x; pass < args.npass; pass += gridDim.x) {
+    const int64_t col = (int64_t)pass * 128 + wave * 32 + m;
+    const PlaneIO io = make_plane_io(args.Np, col, h);
+    auto hp = [&](int row) { return reinterpret_cast<const float*>(reinterpret_cast<const char*>(args.planes) + (int64_t)row * io.row_bytes); };
+    auto dp = [&](int row) { return reinterpret_cast<float*>(reinterpret_cast<char*>(args.dplanes) + (int64_t)row * io.row_bytes); };
+    const float4 dr = reinterpret_cast<const float4*>(args.d_raw)[col];
+    // rgb head (model.py:118):  dHV[f] = sum_c W_rgb[c][f] * d_rgb[c]
+    f32x16 Z[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        const int fo = 32 * t + 8 * gq + 4 * h;
+        const f32x4 w0 = *reinterpret_cast<const f32x4*>(sm + kSmWRgb + 0 * kCondWidth + fo);
+        const f32x4 w1 = *reinterpret_cast<const f32x4*>(sm + kSmWRgb + 1 * kCondWidth + fo);
+        const f32x4 w2 = *reinterpret_cast<const f32x4*>(sm + kSmWRgb + 2 * kCondWidth + fo);
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc)
+          Z[t][4 * gq + cc] = __builtin_fmaf(w2[cc], dr.z, __builtin_fmaf(w1[cc], dr.y, w0[cc] * dr.x));
+      }
+    }
+    mask_and_store(Z, hp(kPlHV), dp(kPlHV), io);  // view layer ReLU (model.py:114-116)
+    f32x16 X[8], Y[8];
+    // d bottleneck = W_view[:, :256]^T . dZ_view   (bottleneck has no activation, model.py:109)
+    zero_tiles(X);
+    chunk_mma<BwdNet, kBwView + 0, 8, 16>(p, Z[0], X);
+    chunk_mma<BwdNet, kBwView + 1, 8, 16>(p, Z[1], X);
+    chunk_mma<BwdNet, kBwView + 2, 8, 16>(p, Z[2], X);
+    chunk_mma<BwdNet, kBwView + 3, 8, 16>(p, Z[3], X);
+    store_plane(X, dp(kPlBot), io);
+    // dH7 = W_bott^T . dBot + W_sigma^T * d_sigma   (density head reads the post-ReLU layer-7 output, model.py:105)
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        const f32x4 w = *reinterpret_cast<const f32x4*>(sm + kSmWSigma + 32 * t + 8 * gq + 4 * h);
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) Y[t][4 * gq + cc] = w[cc] * dr.w;
+      }
+    }
+    dense_layer<BwdNet, kBwBott, 8, 8>(p, X, Y);
+    mask_and_store(Y, hp(plane_h(7)), dp(plane_h(7)), io);
+    zero_tiles(X); dense_layer<BwdNet, kBwL7 + 0, 8, 8>(p, Y, X); mask_and_store(X, hp(plane_h(6)), dp(plane_h(6)), io);
+    zero_tiles(Y); dense_layer<BwdNet, kBwL7 + 8, 8, 8>(p, X, Y); mask_and_store(Y, hp(plane_h(5)), dp(plane_h(5)), io);
+    zero_tiles(X); dense_layer<BwdNet, kBwL7 + 16, 8, 8>(p, Y, X); mask_and_store(X, hp(plane_h(4)), dp(plane_h(4)), io);
+    zero_tiles(Y); dense_layer<BwdNet, kBwL7 + 24, 8, 8>(p, X, Y); mask_and_store(Y, hp(plane_h(3)), dp(plane_h(3)), io);
+    zero_tiles(X); dense_layer<BwdNet, kBwL7 + 32, 8, 8>(p, Y, X); mask_and_store(X, hp(plane_h(2)), dp(plane_h(2)), io);
+    zero_tiles(Y); dense_layer<BwdNet, kBwL7 + 40, 8, 8>(p, X, Y); mask_and_store(Y, hp(plane_h(1)), dp(plane_h(1)), io);
+    zero_tiles(X); dense_layer<BwdNet, kBwL7 + 48, 8, 8>(p, Y, X); mask_and_store(X, hp(plane_h(0)), dp(plane_h(0)), io);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight gradients
+// ---------------------------------------------------------------------------------------------
+// One workgroup: OUT[M x K] partial = A[M rows x n-range] . B[K rows x n-range]^T, M = 128*RT, K = 32*CT.
+// wave w owns rows [32*RT*w, 32*RT*(w+1)) x all K columns -> RT x CT accumulator tiles.
+constexpr int kWgLdsStride = 36;  // floats per 32-sample row in LDS (144 B: 16-byte aligned, conflict-free b128 reads)
+
+struct WgradArgs {
+  const float* A;  // dZ plane rows (row 0 of this block)
+  const float* B;  // activation plane rows
+  int64_t Np;
+  int nchunks;     // Np / 32
+  float* partial;  // [gridDim.x][M][K]
+  float* bias_partial;  // [gridDim.x][M] or null
+};
+
+template <int RT, int CT>
+__global__ void __launch_bounds__(256) wgrad_kernel(WgradArgs a) {
+  constexpr int M = 128 * RT, K = 32 * CT;
+  constexpr int ROWS = M + K;                   // rows staged per 32-sample step
+  constexpr int STAGE_FLOATS = ROWS * kWgLdsStride;
+  constexpr int LD4 = (ROWS * 8 + 255) / 256;   // float4 loads per thread per step
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* smem = reinterpret_cast<float*>(smem_raw);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, kh = lane >> 5;
+
+  // contiguous range of 32-sample steps for this workgroup
+  const int per = (a.nchunks + gridDim.x - 1) / gridDim.x;
+  const int c_begin = blockIdx.x * per;
+  const int c_end = c_begin + per < a.nchunks ? c_begin + per : a.nchunks;
+
+  f32x16 acc[RT][CT];
+#pragma unroll
+  for (int i = 0; i < RT; ++i)
+#pragma unroll
+    for (int j = 0; j < CT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  float bsum[RT];
+#pragma unroll
+  for (int i = 0; i < RT; ++i) bsum[i] = 0.f;
+
+  f32x4 stage[LD4];
+  auto gload = [&](int chunk) {
+#pragma unroll
+    for (int i = 0; i < LD4; ++i) {
+      const int e = tid + 256 * i;  // (row, col4)
+      const int row = e >> 3, c4 = e & 7;
+      if (row < ROWS) {
+        const float* src = row < M ? a.A + (int64_t)row * a.Np : a.B + (int64_t)(row - M) * a.Np;
+        stage[i] = *reinterpret_cast<const f32x4*>(src + (int64_t)chunk * 32 + 4 * c4);
+      }
+    }
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < LD4; ++i) {
+      const int e = tid + 256 * i;
+      const int row = e >> 3, c4 = e & 7;
+      if (row < ROWS) *reinterpret_cast<f32x4*>(smem + buf * STAGE_FLOATS + row * kWgLdsStride + 4 * c4) = stage[i];
+    }
+  };
+
+  if (c_begin < c_end) {
+    gload(c_begin);
+    lstore(0);
+  }
+  __syncthreads();
+  for (int c = c_begin; c < c_end; ++c) {
+    const int buf = (c - c_begin) & 1;
+    if (c + 1 < c_end) gload(c + 1);  // global loads in flight under the MFMAs below
+    const float* sa = smem + buf * STAGE_FLOATS + (32 * RT * wave + li) * kWgLdsStride + 4 * kh;
+    const float* sb = smem + buf * STAGE_FLOATS + (M + li) * kWgLdsStride + 4 * kh;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      f32x4 af[RT], bf[CT];
+#pragma unroll
+      for (int i = 0; i < RT; ++i) {
+        af[i] = *reinterpret_cast<const f32x4*>(sa + i * 32 * kWgLdsStride + 8 * s);
+        bsum[i] += (af[i][0] + af[i][1]) + (af[i][2] + af[i][3]);
+      }
+#pragma unroll
+      for (int j = 0; j < CT; ++j) bf[j] = *reinterpret_cast<const f32x4*>(sb + j * 32 * kWgLdsStride + 8 * s);
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc)
+#pragma unroll
+        for (int i = 0; i < RT; ++i)
+#pragma unroll
+          for (int j = 0; j < CT; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][cc], bf[j][cc], acc[i][j], 0, 0, 0);
+    }
+    if (c + 1 < c_end) lstore(buf ^ 1);
+    __syncthreads();
+  }
+  // partial[wg][row][col]; accumulator layout: col = lane&31, row = (r&3) + 8(r>>2) + 4(lane>>5)
+  float* out = a.partial + (int64_t)blockIdx.x * M * K;
+#pragma unroll
+  for (int i = 0; i < RT; ++i)
+#pragma unroll
+    for (int j = 0; j < CT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = 32 * (RT * wave + i) + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        out[(int64_t)row * K + 32 * j + li] = acc[i][j][r];
+      }
+  if (a.bias_partial) {
+#pragma unroll
+    for (int i = 0; i < RT; ++i) {
+      const float v = bsum[i] + __shfl_xor(bsum[i], 32);
+      if (kh == 0) a.bias_partial[(int64_t)blockIdx.x * M + 32 * (RT * wave + i) + li] = v;
+    }
+  }
+}
+
+// out[row*ld + col_off + col] = sum_wg partial[wg][row][col]   for col < k_valid
+__global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int nparts, int M, int K, int k_valid, float* __restrict__ out,
+                                    int ld, int col_off) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= M * K) return;
+  const int row = idx / K, col = idx % K;
+  if (col >= k_valid) return;
+  float s = 0.f;
+  for (int p = 0; p < nparts; ++p) s += partial[(int64_t)p * M * K + idx];
+  out[(int64_t)row * ld + col_off + col] = s;
+}
+
+__global__ void bias_reduce_kernel(const float* __restrict__ partial, int nparts, int M, float* __restrict__ out) {
+  const int row = blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= M) return;
+  float s = 0.f;
+  for (int p = 0; p < nparts; ++p) s += partial[(int64_t)p * M + row];
+  out[row] = s;
+}
+
+// Heads: dW_sigma[k] = sum_n d_raw[n].w * H7[k][n];  dW_rgb[c][k] = sum_n d_raw[n][c] * HV[k][n];  d bias = sum_n d_raw[n]
+// grid = (rows, nseg); block reduces one plane row over one segment of samples -> partial[seg][row][4]
+__global__ void __launch_bounds__(256) head_wgrad_kernel(const float* __restrict__ plane, int64_t Np, const float* __restrict__ d_raw,
+                                                         int64_t seg_len, float* __restrict__ partial, int rows) {
+  const int row = blockIdx.x, seg = blockIdx.y;
+  const int64_t n0 = (int64_t)seg * seg_len;
+  const int64_t n1 = n0 + seg_len < Np ? n0 + seg_len : Np;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  for (int64_t n = n0 + threadIdx.x; n < n1; n += 256) {
+    const float x = plane ? plane[(int64_t)row * Np + n] : 1.0f;  // plane == null: bias sums
+    const float4 d = reinterpret_cast<const float4*>(d_raw)[n];
+    s0 = __builtin_fmaf(x, d.x, s0); s1 = __builtin_fmaf(x, d.y, s1); s2 = __builtin_fmaf(x, d.z, s2); s3 = __builtin_fmaf(x, d.w, s3);
+  }
+  __shared__ float red[4][4];
+  s0 = wsum64(s0); s1 = wsum64(s1); s2 = wsum64(s2); s3 = wsum64(s3);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (lane == 0) { red[wv][0] = s0; red[wv][1] = s1; red[wv][2] = s2; red[wv][3] = s3; }
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    const float v = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    partial[((int64_t)seg * rows + row) * 4 + threadIdx.x] = v;
+  }
+}
+
+// out[c*ld_out + row] (channel-major rows of a (C,rows) weight) = sum_seg partial[seg][row][chan_of(c)]
+__global__ void head_reduce_kernel(const float* __restrict__ partial, int nseg, int rows, int chan0, int nchan, float* __restrict__ out,
+                                   int ld_out) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= rows * nchan) return;
+  const int row = idx / nchan, c = idx % nchan;
+  float s = 0.f;
+  for (int p = 0; p < nseg; ++p) s += partial[((int64_t)p * rows + row) * 4 + chan0 + c];
+  out[(int64_t)c * ld_out + row] = s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// host launchers
+// ---------------------------------------------------------------------------------------------
+int num_cus();  // aon_mlp.hip
+
+hipError_t launch_pack_vanilla_bwd(const float* const* params, float* packed, hipStream_t stream) {
+  PackArgs24 a;
+  for (int i = 0; i < kNumVanillaParams; ++i) a.p[i] = params[i];
+  const int64_t n = kBwStreamBytes / 4;
+  pack_vanilla_bwd_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream>>>(a, packed);
+  return hipGetLastError();
+}
+
+int64_t bwd_stream_bytes() { return kBwStreamBytes; }
+
+hipError_t launch_mlp_bwd_chain(const char* packed_bwd, const char* packed_fwd, const float* d_raw, const float* planes,
+                                float* dplanes, int64_t Np, hipStream_t stream) {
+  static bool attr = false;
+  constexpr int lds = kRingBytes + (int)kSmallBytes;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_bwd_chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return e;
+    attr = true;
+  }
+  BwdArgs a{packed_bwd, reinterpret_cast<const float*>(packed_fwd + kStreamBytes), d_raw, planes, dplanes, Np, (int)(Np / 128)};
+  const int cus = num_cus();
+  if (cus <= 0) return hipErrorInvalidDevice;
+  const int grid = a.npass < cus ? a.npass : cus;
+  if (grid <= 0) return hipSuccess;
+  mlp_bwd_chain_kernel<<<dim3(grid), dim3(256), lds, stream>>>(a);
+  return hipGetLastError();
+}
+
+template <int RT, int CT>
+static hipError_t run_wgrad(const float* A, const float* B, int64_t Np, int nparts, float* partial, float* bias_partial,
+                            float* out, int ld, int col_off, int k_valid, float* bias_out, hipStream_t stream) {
+  constexpr int M = 128 * RT, K = 32 * CT;
+  constexpr int lds = 2 * (M + K) * kWgLdsStride * 4;
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<RT, CT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return e;
+    attr = true;
+  }
+  WgradArgs a{A, B, Np, (int)(Np / 32), partial, bias_out ? bias_partial : nullptr};
+  wgrad_kernel<RT, CT><<<dim3(nparts), dim3(256), lds, stream>>>(a);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  wgrad_reduce_kernel<<<dim3((M * K + 255) / 256), dim3(256), 0, stream>>>(partial, nparts, M, K, k_valid, out, ld, col_off);
+  e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  if (bias_out) {
+    bias_reduce_kernel<<<dim3((M + 255) / 256), dim3(256), 0, stream>>>(bias_partial, nparts, M, bias_out);
+    e = hipGetLastError();
+  }
+  return e;
+}
+
+int64_t wgrad_workspace_bytes() {
+  // per-workgroup partial of the largest block (256 x 256) + bias partials + head partials, for up to 256 workgroups
+  return (int64_t)256 * (256 * 256 + 256) * 4 + (int64_t)256 * 257 * 4 * 4 + 4096;
+}
+
+// grads: 24 device pointers in the parameter order of aon_pack_vanilla_mlp (each the full (out,in) / (out,) tensor), overwritten.
+hipError_t launch_vanilla_wgrad(const float* planes, const float* dplanes, const float* d_raw, int64_t Np, float* const* grads,
+                                float* ws, hipStream_t stream) {
+  const int cus = num_cus();
+  if (cus <= 0) return hipErrorInvalidDevice;
+  const int nchunks = (int)(Np / 32);
+  int nparts = nchunks < cus ? nchunks : cus;
+  if (nparts > 256) nparts = 256;
+  float* partial = ws;
+  float* bias_partial = ws + (int64_t)256 * 256 * 256;
+  float* head_partial = bias_partial + (int64_t)256 * 256;
+  auto P = [&](int row) { return planes + (int64_t)row * Np; };
+  auto D = [&](int row) { return dplanes + (int64_t)row * Np; };
+  hipError_t e;
+  // trunk: dW_l = dZ_l . H_{l-1}^T  (+ the pos-enc columns for layers 0 and 5)
+  e = run_wgrad<2, 2>(D(plane_h(0)), P(kPlE), Np, nparts, partial, bias_partial, grads[0], kPosEnc, 0, kPosEnc, grads[1], stream);
+  if (e != hipSuccess) return e;
+  for (int l = 1; l < 8; ++l) {
+    const int ld = l == 5 ? 256 + kPosEnc : 256;
+    e = run_wgrad<2, 8>(D(plane_h(l)), P(plane_h(l - 1)), Np, nparts, partial, bias_partial, grads[2 * l], ld, 0, 256, grads[2 * l + 1], stream);
+    if (e != hipSuccess) return e;
+    if (l == 5) {
+      e = run_wgrad<2, 2>(D(plane_h(5)), P(kPlE), Np, nparts, partial, bias_partial, grads[10], ld, 256, kPosEnc, nullptr, stream);
+      if (e != hipSuccess) return e;
+    }
+  }
+  // bottleneck (input: post-ReLU layer-7 output)
+  e = run_wgrad<2, 8>(D(kPlBot), P(plane_h(7)), Np, nparts, partial, bias_partial, grads[18], 256, 0, 256, grads[19], stream);
+  if (e != hipSuccess) return e;
+  // view layer: cat[bottleneck(256), viewenc(27)]
+  e = run_wgrad<1, 8>(D(kPlHV), P(kPlBot), Np, nparts, partial, bias_partial, grads[16], 256 + kViewEnc, 0, 256, grads[17], stream);
+  if (e != hipSuccess) return e;
+  e = run_wgrad<1, 1>(D(kPlHV), P(kPlVE), Np, nparts, partial, bias_partial, grads[16], 256 + kViewEnc, 256, kViewEnc, nullptr, stream);
+  if (e != hipSuccess) return e;
+  // heads and their biases
+  int nseg = (int)((Np + 16383) / 16384);
+  if (nseg > 256) nseg = 256;
+  const int64_t seg_len = ((Np + nseg - 1) / nseg + 3) / 4 * 4;
+  nseg = (int)((Np + seg_len - 1) / seg_len);
+  head_wgrad_kernel<<<dim3(256, nseg), dim3(256), 0, stream>>>(P(plane_h(7)), Np, d_raw, seg_len, head_partial, 256);
+  head_reduce_kernel<<<dim3(1), dim3(256), 0, stream>>>(head_partial, nseg, 256, 3, 1, grads[20], 256);   // density_layer.weight (1,256)
+  head_wgrad_kernel<<<dim3(128, nseg), dim3(256), 0, stream>>>(P(kPlHV), Np, d_raw, seg_len, head_partial, 128);
+  head_reduce_kernel<<<dim3(2), dim3(256), 0, stream>>>(head_partial, nseg, 128, 0, 3, grads[22], 128);  // rgb_layer.weight (3,128)
+  head_wgrad_kernel<<<dim3(1, nseg), dim3(256), 0, stream>>>(nullptr, Np, d_raw, seg_len, head_partial, 1);
+  head_reduce_kernel<<<dim3(1), dim3(256), 0, stream>>>(head_partial, nseg, 1, 3, 1, grads[21], 1);      // density_layer.bias (1,)
+  head_reduce_kernel<<<dim3(1), dim3(256), 0, stream>>>(head_partial, nseg, 1, 0, 3, grads[23], 1);      // rgb_layer.bias (3,)
+  return hipGetLastError();
+}
+
+}  // namespace aon

@@ -13,6 +13,7 @@ import torch.nn as nn
 import torch.nn.init as init
 
 from ... import ops
+from ...autograd import RenderVanilla
 
 
 class NeRFMLP(nn.Module):
@@ -49,6 +50,26 @@ class NeRFMLP(nn.Module):
         init.xavier_uniform_(self.rgb_layer.weight)
         self._packed = None
         self._packed_key = None
+        self._packed_bwd = None
+        self._packed_bwd_key = None
+
+    def _param_key(self, params):
+        return tuple((p.data_ptr(), p._version, str(p.device)) for p in params.values())
+
+    def packed_bwd(self) -> torch.Tensor:
+        """Transposed weight stream for the backward data chain (training only)."""
+        params = dict(self.named_parameters())
+        key = self._param_key(params)
+        if self._packed_bwd is None or key != self._packed_bwd_key:
+            dev = next(iter(params.values())).device
+            out = self._packed_bwd if (self._packed_bwd is not None and self._packed_bwd.device == dev) else None
+            self._packed_bwd = ops.pack_vanilla_mlp_bwd(params, out=out)
+            self._packed_bwd_key = key
+        return self._packed_bwd
+
+    def ordered_params(self):
+        params = dict(self.named_parameters())
+        return [params[name] for name in ops.VANILLA_PARAM_ORDER]
 
     def packed(self) -> torch.Tensor:
         """The kernel-side weight stream; re-packed (one small HIP kernel) whenever a parameter was modified
@@ -91,10 +112,6 @@ class NeRF(nn.Module):
         self.fine_mlp = NeRFMLP(min_deg_point, max_deg_point, deg_view)
 
     def forward(self, rays, randomized, white_bkgd, near, far, t_rand=None, u=None):
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError(
-                "the HIP backward of the render path is not implemented yet: call under torch.no_grad() "
-                "(validation / test rendering); there is deliberately no eager-PyTorch fallback")
         rays_o = rays["rays_o"]
         n = rays_o.shape[0]
         if randomized:
@@ -104,6 +121,16 @@ class NeRF(nn.Module):
                 u = torch.rand((n, self.num_fine_samples), device=rays_o.device)
         else:
             t_rand, u = None, None
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            # training: fused forward that keeps the activation planes + HIP backward (autograd.RenderVanilla)
+            if n == 0:
+                raise ValueError("empty ray batch in training mode")
+            mlps = [self.coarse_mlp, self.fine_mlp][: self.num_levels]
+            packs = [(m.packed(), m.packed_bwd()) for m in mlps]
+            params = [p for m in mlps for p in m.ordered_params()]
+            flat = RenderVanilla.apply(rays_o, rays["rays_d"], rays["viewdirs"], float(near), float(far), bool(white_bkgd),
+                                       self.num_levels, t_rand, u, packs, *params)
+            return [tuple(flat[3 * i: 3 * i + 3]) for i in range(self.num_levels)]
         fine = self.fine_mlp.packed() if self.num_levels == 2 else None
         outs = ops.render_fwd(self.coarse_mlp.packed(), fine, rays_o, rays["rays_d"], rays["viewdirs"], near, far,
                               white_bkgd, self.num_levels, t_rand, u)

@@ -406,6 +406,77 @@ def art_render_fwd(packed_c, small_c, packed_f, small_f, rays_o, rays_d, viewdir
     return outs
 
 
+# ------------------------------------------------------------------ R14 training (vanilla)
+def pack_vanilla_mlp_bwd(params: dict, out: torch.Tensor | None = None) -> torch.Tensor:
+    """Transposed weight stream for the backward data chain (re-pack whenever the parameters change)."""
+    tensors = [_f32(params[name].detach(), name) for name in VANILLA_PARAM_ORDER]
+    dev = tensors[0].device
+    if out is None:
+        out = torch.empty(int(lib.aon_bwd_packed_bytes()), dtype=torch.uint8, device=dev)
+    arr = (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+    with torch.cuda.device(dev):
+        check(lib.aon_pack_vanilla_mlp_bwd(arr, _ptr(out), _stream()), "aon_pack_vanilla_mlp_bwd")
+    return out
+
+
+def padded_samples(n_samples: int) -> int:
+    return (n_samples + 127) // 128 * 128
+
+
+def mlp_fwd_train(packed, rays_o, rays_d, viewdirs, t_vals):
+    """Fused forward that also stores the feature-major activation planes -> (raw (n,S,4), planes (rows, Np))."""
+    o, d, v, t = _f32(rays_o, "rays_o"), _f32(rays_d, "rays_d"), _f32(viewdirs, "viewdirs"), _f32(t_vals, "t_vals")
+    n, S = t.shape
+    Np = padded_samples(n * S)
+    raw = torch.empty((n, S, 4), dtype=torch.float32, device=t.device)
+    planes = torch.zeros((int(lib.aon_train_plane_rows()), Np), dtype=torch.float32, device=t.device)
+    with torch.cuda.device(t.device):
+        check(lib.aon_mlp_fwd_train(_ptr(packed), _ptr(o), _ptr(d), _ptr(v), _ptr(t), n, S, _ptr(raw), _ptr(planes), _stream()),
+              "aon_mlp_fwd_train")
+    return raw, planes
+
+
+def composite_bwd(raw, t_vals, dirs, g_rgb, g_acc, g_depth, white_bkgd, act, Np: int):
+    """-> d_raw (Np,4): dL/d(raw rgb, raw sigma), zero in the padded tail."""
+    r, t, d, g = _f32(raw, "raw"), _f32(t_vals, "t_vals"), _f32(dirs, "dirs"), _f32(g_rgb, "g_rgb")
+    ga = None if g_acc is None else _f32(g_acc, "g_acc")
+    gd = None if g_depth is None else _f32(g_depth, "g_depth")
+    n, S = t.shape
+    d_raw = torch.zeros((Np, 4), dtype=torch.float32, device=t.device)
+    with torch.cuda.device(t.device):
+        check(lib.aon_composite_bwd(_ptr(r), _ptr(t), _ptr(d), _ptr(g), _ptr(ga), _ptr(gd), n, S, int(bool(white_bkgd)), act,
+                                    _ptr(d_raw), _stream()), "aon_composite_bwd")
+    return d_raw
+
+
+def mlp_bwd_chain(packed_bwd, packed_fwd, d_raw, planes):
+    dplanes = torch.zeros_like(planes)
+    Np = planes.shape[1]
+    with torch.cuda.device(planes.device):
+        check(lib.aon_mlp_bwd_chain(_ptr(packed_bwd), _ptr(packed_fwd), _ptr(d_raw), _ptr(planes), _ptr(dplanes), Np, _stream()),
+              "aon_mlp_bwd_chain")
+    return dplanes
+
+
+_WG_WS: dict = {}
+
+
+def vanilla_wgrad(planes, dplanes, d_raw):
+    """-> dict name -> gradient (the reference's NeRFMLP parameter names / shapes)."""
+    dev = planes.device
+    key = str(dev)
+    need = int(lib.aon_wgrad_workspace_bytes())
+    if key not in _WG_WS or _WG_WS[key].numel() < need:
+        _WG_WS[key] = torch.empty(need, dtype=torch.uint8, device=dev)
+    ws = _WG_WS[key]
+    grads = {name: torch.empty(VANILLA_PARAM_SHAPES[name], dtype=torch.float32, device=dev) for name in VANILLA_PARAM_ORDER}
+    arr = (C.c_void_p * len(VANILLA_PARAM_ORDER))(*[grads[n].data_ptr() for n in VANILLA_PARAM_ORDER])
+    with torch.cuda.device(dev):
+        check(lib.aon_vanilla_wgrad(_ptr(planes), _ptr(dplanes), _ptr(d_raw), planes.shape[1], arr, _ptr(ws), ws.numel(), _stream()),
+              "aon_vanilla_wgrad")
+    return grads
+
+
 # ------------------------------------------------------------------ measurement aid
 def profile_begin() -> None:
     check(lib.aon_profile_begin(), "aon_profile_begin")

@@ -163,7 +163,7 @@ def sorted_piecewise_constant_pdf(bins, weights, num_samples, randomized, u=None
 
 def sample_pdf(bins, weights, origins, directions, t_vals, num_samples, randomized, u=None):
     """helper.py:246-252: inverse-CDF draw, sort-merge with the coarse t's, cast."""
-    t_samples = sorted_piecewise_constant_pdf(bins, weights, num_samples, randomized, u)
+    t_samples = sorted_piecewise_constant_pdf(bins, weights, num_samples, randomized, u).detach()  # helper.py:249
     t_vals = torch.sort(torch.cat([t_vals, t_samples], dim=-1), dim=-1).values
     return t_vals, cast_rays(t_vals, origins, directions)
 

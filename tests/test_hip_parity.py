@@ -351,9 +351,9 @@ def test_coarse_only_and_edge_sizes(ops, dev, nerf_sd, packed):
     # CPU tensors are rejected loudly (no host fallback)
     with pytest.raises(RuntimeError):
         ops.pos_enc(torch.zeros(4, 3), 0, 10)
-    # gradient mode is refused rather than silently served by eager PyTorch
-    with pytest.raises(NotImplementedError):
-        model2({k: v.to(dev) for k, v in syn.random_rays(4, seed=0).items()}, False, True, 2.0, 6.0)
+    # gradient mode runs the HIP training path (tests/test_hip_training.py): outputs carry a graph to the parameters
+    out = model2({k: v.to(dev) for k, v in syn.random_rays(4, seed=0).items()}, False, True, 2.0, 6.0)
+    assert out[1][0].requires_grad and out[1][0].grad_fn is not None
 
 
 def test_full_frame_properties(ops, dev, nerf_sd):

@@ -1,0 +1,206 @@
+"""GPU parity of the backward path against torch.autograd run on the CPU oracle.
+
+Tolerances: composite backward on identical inputs 2e-5 relative to the largest gradient of the ray batch; stored
+activation planes 2e-5; parameter gradients of the whole path: relative L2 error <= 2e-3 per tensor (fp32, different
+summation order over ~10^4-10^5 samples), 1e-2 for fine-level tensors on the sharp density x30 field (ill-conditioned,
+see test_hip_articulated)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import nerf_oracle as orc  # noqa: E402  (checker only)
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return torch.device("cuda:0")
+
+
+def rel_l2(a, b):
+    return (torch.linalg.norm((a - b).double()) / torch.linalg.norm(b.double()).clamp_min(1e-30)).item()
+
+
+@pytest.mark.parametrize("act", [0, 1, 2])
+@pytest.mark.parametrize("white", [False, True])
+def test_composite_backward(dev, act, white):
+    from aon_amd import ops
+
+    gen = torch.Generator().manual_seed(100 + act)
+    for n, S in ((37, 65), (21, 193)):
+        raw = (torch.randn(n, S, 4, generator=gen) * 2).requires_grad_(True)
+        if act == 0:
+            raw = torch.cat([torch.rand(n, S, 3, generator=gen), torch.relu(torch.randn(n, S, 1, generator=gen) * 3)], -1).requires_grad_(True)
+        t = torch.sort(torch.rand(n, S, generator=gen) * 4 + 2, dim=-1).values
+        d = torch.nn.functional.normalize(torch.randn(n, 3, generator=gen), dim=-1)
+        if act == 1:
+            rgb, sig = torch.sigmoid(raw[..., :3]), torch.relu(raw[..., 3:])
+        elif act == 2:
+            rgb, sig = torch.sigmoid(raw[..., :3]) * 1.002 - 0.001, torch.nn.functional.softplus(raw[..., 3:] - 1.0)
+        else:
+            rgb, sig = raw[..., :3], raw[..., 3:]
+        comp, acc, w, depth = orc.volumetric_rendering(rgb, sig, t, d, white)
+        g_rgb, g_acc, g_depth = torch.randn(n, 3, generator=gen), torch.randn(n, generator=gen), torch.randn(n, generator=gen)
+        ((comp * g_rgb).sum() + (acc * g_acc).sum() + (depth * g_depth).sum()).backward()
+        Np = ops.padded_samples(n * S)
+        d_raw = ops.composite_bwd(raw.detach().to(dev), t.to(dev), d.to(dev), g_rgb.to(dev), g_acc.to(dev), g_depth.to(dev), white, act, Np)
+        assert d_raw.shape == (Np, 4) and (d_raw[n * S:] == 0).all()
+        got = d_raw[: n * S].reshape(n, S, 4).cpu()
+        scale = raw.grad.abs().amax(dim=(1, 2), keepdim=True).clamp_min(1e-12)
+        assert ((got - raw.grad).abs() / scale).max().item() < 2e-5
+        # rgb-only gradient (the training loss, model.py:271-273) with null g_acc / g_depth
+        raw.grad = None
+        comp2 = orc.volumetric_rendering(rgb.detach() if False else (torch.sigmoid(raw[..., :3]) if act == 1 else (torch.sigmoid(raw[..., :3]) * 1.002 - 0.001 if act == 2 else raw[..., :3])),
+                                         (torch.relu(raw[..., 3:]) if act == 1 else (torch.nn.functional.softplus(raw[..., 3:] - 1.0) if act == 2 else raw[..., 3:])),
+                                         t, d, white)[0]
+        (comp2 * g_rgb).sum().backward()
+        d_raw = ops.composite_bwd(raw.detach().to(dev), t.to(dev), d.to(dev), g_rgb.to(dev), None, None, white, act, Np)
+        got = d_raw[: n * S].reshape(n, S, 4).cpu()
+        scale = raw.grad.abs().amax(dim=(1, 2), keepdim=True).clamp_min(1e-12)
+        assert ((got - raw.grad).abs() / scale).max().item() < 2e-5
+
+
+def _layer_activations(sd, prefix, enc, venc):
+    """Oracle-side per-layer activations of model.py:95-120 (post-ReLU), for the plane check."""
+    import torch.nn.functional as F
+
+    n, s, _ = enc.shape
+    x = enc.reshape(-1, 63)
+    inputs, acts = x, []
+    for idx in range(8):
+        x = F.relu(F.linear(x, sd[f"{prefix}pts_linears.{idx}.weight"], sd[f"{prefix}pts_linears.{idx}.bias"]))
+        acts.append(x)
+        if idx == 4:
+            x = torch.cat([x, inputs], -1)
+    bott = F.linear(acts[7], sd[f"{prefix}bottleneck_layer.weight"], sd[f"{prefix}bottleneck_layer.bias"])
+    cond = venc[:, None, :].expand(n, s, 27).reshape(-1, 27)
+    hv = F.relu(F.linear(torch.cat([bott, cond], -1), sd[f"{prefix}views_linear.0.weight"], sd[f"{prefix}views_linear.0.bias"]))
+    return acts, bott, hv
+
+
+def test_forward_train_planes(dev, nerf_sd):
+    import aon_amd.synthetic as syn
+    from aon_amd import ops
+
+    params = {k[len("fine_mlp."):]: v.to(dev) for k, v in nerf_sd.items() if k.startswith("fine_mlp.")}
+    packed = ops.pack_vanilla_mlp(params)
+    n, S = 9, 65  # 585 samples -> Np = 640
+    rays = syn.random_rays(n, seed=5)
+    t = torch.sort(torch.rand(n, S, generator=torch.Generator().manual_seed(5)) * 4 + 2, dim=-1).values
+    args = [rays[k].to(dev) for k in ("rays_o", "rays_d", "viewdirs")] + [t.to(dev)]
+    raw, planes = ops.mlp_fwd_train(packed, *args)
+    assert torch.equal(raw, ops.mlp_fwd(packed, *args))  # same arithmetic as the inference kernel
+    assert planes.shape == (2528, 640)
+    enc = orc.pos_enc(orc.cast_rays(t, rays["rays_o"], rays["rays_d"]), 0, 10)
+    venc = orc.pos_enc(rays["viewdirs"], 0, 4)
+    acts, bott, hv = _layer_activations(nerf_sd, "fine_mlp.", enc, venc)
+    pl = planes.cpu()[:, : n * S]
+    torch.testing.assert_close(pl[0:63].T, enc.reshape(-1, 63), rtol=0, atol=2.5e-7)
+    assert (pl[63] == 0).all()
+    for l in range(8):
+        torch.testing.assert_close(pl[64 + 256 * l: 64 + 256 * (l + 1)].T, acts[l], rtol=2e-5, atol=2e-5)
+    torch.testing.assert_close(pl[2112:2368].T, bott, rtol=2e-5, atol=2e-5)
+    torch.testing.assert_close(pl[2368:2395].T, venc[:, None, :].expand(n, S, 27).reshape(-1, 27), rtol=0, atol=2.5e-7)
+    torch.testing.assert_close(pl[2400:2528].T, hv, rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("randomized,white,density_scale", [(False, True, 30.0), (True, False, 5.0)])
+def test_training_step_gradients_vs_oracle_autograd(dev, randomized, white, density_scale):
+    import aon_amd.synthetic as syn
+    from aon_amd.models.vanilla_nerf.model import NeRF
+
+    sd = syn.make_nerf_state_dict(seed=3, density_scale=density_scale)
+    n = 150
+    rays_cpu = syn.random_rays(n, seed=8)
+    gen = torch.Generator().manual_seed(8)
+    target = torch.rand(n, 3, generator=gen)
+    t_rand, u = torch.rand(n, 65, generator=gen), torch.rand(n, 128, generator=gen)
+    kw = dict(t_rand=t_rand, u=u) if randomized else {}
+    # oracle: autograd through the CPU restatement (the reference's training_step loss, model.py:271-273)
+    sd_o = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    out_o = orc.nerf_forward(sd_o, rays_cpu, randomized, white, 2.0, 6.0, **kw)
+    loss_o = orc.img2mse(out_o[0][0], target) + orc.img2mse(out_o[1][0], target)
+    loss_o.backward()
+    # HIP path through the drop-in module
+    model = NeRF().to(dev)
+    model.load_state_dict(sd)
+    rays = {k: v.to(dev) for k, v in rays_cpu.items()}
+    out = model(rays, randomized, white, 2.0, 6.0, **{k: v.to(dev) for k, v in kw.items()})
+    loss = torch.mean((out[0][0] - target.to(dev)) ** 2) + torch.mean((out[1][0] - target.to(dev)) ** 2)
+    loss.backward()
+    assert abs(loss.item() - loss_o.item()) <= 2e-5 * max(1.0, abs(loss_o.item()))
+    # Coarse level: identical sample positions on both sides -> the kernels themselves are compared (measured 3e-6).
+    # Fine level: the 128 inverse-CDF positions inherit 1-ulp differences of the coarse weights, so the two sides evaluate
+    # the network at slightly different points; that input sensitivity (not the backward kernels, which
+    # test_level_backward_with_shared_samples pins at 2e-5 for S = 193) bounds the agreement at the 1e-3 level.
+    errs = {}
+    for name, p in model.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all(), name
+        errs[name] = rel_l2(p.grad.cpu(), sd_o[name].grad)
+    print({k: f"{v:.1e}" for k, v in errs.items()})
+    for name, err in errs.items():
+        tol = 1e-2 if name.startswith("fine_mlp") else 2e-3  # coarse: 3e-6 measured unless a far-plane sigma sign flips
+        assert err <= tol, f"{name}: relative L2 gradient error {err:.3e} > {tol}"
+
+
+@pytest.mark.parametrize("n,S", [(40, 193), (3, 65)])
+def test_level_backward_with_shared_samples(dev, nerf_sd, n, S):
+    """One level in isolation with the SAME sample positions on both sides: forward-train -> composite -> loss ->
+    composite_bwd -> bwd chain -> wgrad against autograd on the oracle.  Pins the fine-level (S = 193) kernels tightly."""
+    import aon_amd.synthetic as syn
+    from aon_amd import ops
+
+    prefix = "fine_mlp."
+    params = {k[len(prefix):]: v.to(dev) for k, v in nerf_sd.items() if k.startswith(prefix)}
+    packed, packed_bwd = ops.pack_vanilla_mlp(params), ops.pack_vanilla_mlp_bwd(params)
+    rays = syn.random_rays(n, seed=12)
+    gen = torch.Generator().manual_seed(12)
+    t = torch.sort(torch.rand(n, S, generator=gen) * 4 + 2, dim=-1).values
+    target = torch.rand(n, 3, generator=gen)
+    sd_o = {k: v.clone().requires_grad_(True) for k, v in nerf_sd.items() if k.startswith(prefix)}
+    enc = orc.pos_enc(orc.cast_rays(t, rays["rays_o"], rays["rays_d"]), 0, 10)
+    raw_rgb, raw_sig = orc.nerf_mlp(sd_o, prefix, enc, orc.pos_enc(rays["viewdirs"], 0, 4))
+    comp = orc.volumetric_rendering(torch.sigmoid(raw_rgb), torch.relu(raw_sig), t, rays["rays_d"], True)[0]
+    orc.img2mse(comp, target).backward()
+    o, d, v, tt = (x.to(dev) for x in (rays["rays_o"], rays["rays_d"], rays["viewdirs"], t))
+    raw, planes = ops.mlp_fwd_train(packed, o, d, v, tt)
+    rgb = ops.composite_raw(raw, tt, d, True, ops.ACT_VANILLA)[0]
+    g_rgb = 2.0 * (rgb - target.to(dev)) / (n * 3)
+    d_raw = ops.composite_bwd(raw, tt, d, g_rgb, None, None, True, ops.ACT_VANILLA, planes.shape[1])
+    dplanes = ops.mlp_bwd_chain(packed_bwd, packed, d_raw, planes)
+    grads = ops.vanilla_wgrad(planes, dplanes, d_raw)
+    for name, g in grads.items():
+        err = rel_l2(g.cpu(), sd_o[prefix + name].grad)
+        assert err <= 2e-5, f"{name}: relative L2 gradient error {err:.3e}"
+
+
+def test_training_decreases_loss_and_is_deterministic(dev):
+    """A few Adam steps (the reference's optimiser, model.py:386-389) on a fixed ray batch: loss goes down, repeated runs
+    are bit-identical (the weight-gradient reduction is atomics-free), parameters are re-packed after every step."""
+    import aon_amd.synthetic as syn
+    from aon_amd.models.vanilla_nerf.model import NeRF
+
+    def run():
+        sd = syn.make_nerf_state_dict(seed=4, density_scale=5.0)
+        model = NeRF().to(dev)
+        model.load_state_dict(sd)
+        opt = torch.optim.Adam(model.parameters(), lr=5e-4, betas=(0.9, 0.999))
+        rays = {k: v.to(dev) for k, v in syn.random_rays(256, seed=9).items()}
+        target = torch.rand(256, 3, generator=torch.Generator().manual_seed(9)).to(dev)
+        t_rand = torch.rand(256, 65, generator=torch.Generator().manual_seed(10)).to(dev)
+        u = torch.rand(256, 128, generator=torch.Generator().manual_seed(11)).to(dev)
+        losses = []
+        for _ in range(6):
+            opt.zero_grad()
+            out = model(rays, True, True, 2.0, 6.0, t_rand=t_rand, u=u)
+            loss = torch.mean((out[0][0] - target) ** 2) + torch.mean((out[1][0] - target) ** 2)
+            loss.backward()
+            opt.step()
+            losses.append(loss.item())
+        return losses
+
+    a, b = run(), run()
+    assert a == b
+    assert a[-1] < a[0] and all(x == x for x in a)
