@@ -46,7 +46,8 @@ _SIGS = {
     "aon_bwd_packed_bytes": (_l, []),
     "aon_wgrad_workspace_bytes": (_l, []),
     "aon_pack_vanilla_mlp_bwd": (_i, [_p, _p, _p]),
-    "aon_mlp_fwd_train": (_i, [_p, _p, _p, _p, _p, _l, _i, _p, _p, _p]),
+    "aon_train_mask_bytes": (_l, [_l]),
+    "aon_mlp_fwd_train": (_i, [_p, _p, _p, _p, _p, _l, _i, _p, _p, _p, _p]),
     "aon_composite_bwd": (_i, [_p, _p, _p, _p, _p, _p, _l, _i, _i, _i, _p, _p]),
     "aon_mlp_bwd_chain": (_i, [_p, _p, _p, _p, _p, _l, _p]),
     "aon_vanilla_wgrad": (_i, [_p, _p, _p, _l, _p, _p, _l, _p]),

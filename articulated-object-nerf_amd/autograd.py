@@ -23,28 +23,27 @@ class RenderVanilla(torch.autograd.Function):
                 t_vals, _ = ops.sample_along_rays(rays_o, rays_d, 64, near, far, t_rand, want_coords=False)
             else:
                 t_vals = ops.sample_pdf_t(t_vals, weights, u)
-            raw, planes = ops.mlp_fwd_train(packed_fwd, rays_o, rays_d, viewdirs, t_vals)
+            raw, planes, masks = ops.mlp_fwd_train(packed_fwd, rays_o, rays_d, viewdirs, t_vals)
             rgb, acc, weights, depth = ops.composite_raw(raw, t_vals, rays_d, white_bkgd, ops.ACT_VANILLA, want_weights=True)
             outs += [rgb, acc, depth]
-            saved.append((raw, t_vals, planes, packed_fwd, packed_bwd))
+            saved.append((raw, t_vals, planes, masks, packed_fwd, packed_bwd))
         ctx.saved = saved
         ctx.rays_d = rays_d
         ctx.white_bkgd = white_bkgd
         ctx.num_levels = num_levels
-        ctx.mark_non_differentiable(*[o for i, o in enumerate(outs) if False])
         return tuple(outs)
 
     @staticmethod
     def backward(ctx, *gouts):
         grads = []
         for lvl in range(ctx.num_levels):
-            raw, t_vals, planes, packed_fwd, packed_bwd = ctx.saved[lvl]
+            raw, t_vals, planes, masks, packed_fwd, packed_bwd = ctx.saved[lvl]
             g_rgb, g_acc, g_depth = gouts[3 * lvl: 3 * lvl + 3]
             if g_rgb is None:
                 g_rgb = torch.zeros((t_vals.shape[0], 3), dtype=torch.float32, device=t_vals.device)
             d_raw = ops.composite_bwd(raw, t_vals, ctx.rays_d, g_rgb.contiguous(), g_acc, g_depth, ctx.white_bkgd, ops.ACT_VANILLA,
                                       planes.shape[1])
-            dplanes = ops.mlp_bwd_chain(packed_bwd, packed_fwd, d_raw, planes)
+            dplanes = ops.mlp_bwd_chain(packed_bwd, packed_fwd, d_raw, masks, planes.shape)
             g = ops.vanilla_wgrad(planes, dplanes, d_raw)
             grads += [g[name] for name in ops.VANILLA_PARAM_ORDER]
             del dplanes

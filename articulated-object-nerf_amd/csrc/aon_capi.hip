@@ -24,13 +24,14 @@ hipError_t launch_art_mlp_fwd_pos(const char* packed, const float* small, const 
 int64_t art_stream_bytes();
 int64_t art_small_bytes();
 hipError_t launch_mlp_fwd_train(const char* packed, const float* rays_o, const float* rays_d, const float* viewdirs,
-                                const float* t_vals, int64_t n_rays, int S, float* raw, float* planes, hipStream_t stream);
+                                const float* t_vals, int64_t n_rays, int S, float* raw, float* planes, void* masks,
+                                hipStream_t stream);
 hipError_t launch_composite_bwd(const float* raw, const float* t_vals, const float* dirs, const float* g_rgb, const float* g_acc,
                                 const float* g_depth, int64_t n_rays, int S, int white_bkgd, int act, float* d_raw,
                                 hipStream_t stream);
 hipError_t launch_pack_vanilla_bwd(const float* const* params, float* packed, hipStream_t stream);
 int64_t bwd_stream_bytes();
-hipError_t launch_mlp_bwd_chain(const char* packed_bwd, const char* packed_fwd, const float* d_raw, const float* planes,
+hipError_t launch_mlp_bwd_chain(const char* packed_bwd, const char* packed_fwd, const float* d_raw, const void* masks,
                                 float* dplanes, int64_t Np, hipStream_t stream);
 int64_t wgrad_workspace_bytes();
 hipError_t launch_vanilla_wgrad(const float* planes, const float* dplanes, const float* d_raw, int64_t Np, float* const* grads,
@@ -239,14 +240,18 @@ int aon_pack_vanilla_mlp_bwd(const float* const* params_host, void* packed_bwd, 
   return check(aon::launch_pack_vanilla_bwd(params_host, static_cast<float*>(packed_bwd), (hipStream_t)stream), "aon_pack_vanilla_mlp_bwd");
 }
 
+int64_t aon_train_mask_bytes(int64_t Np) { return (int64_t)aon::kMaskLayers * Np * 2 * 16; }
+
 int aon_mlp_fwd_train(const void* packed, const float* rays_o, const float* rays_d, const float* viewdirs, const float* t_vals,
-                      int64_t n_rays, int S, float* raw, float* planes, void* stream) {
+                      int64_t n_rays, int S, float* raw, float* planes, void* masks, void* stream) {
   if (n_rays < 0 || S < 1) return fail(AON_E_INVALID, "aon_mlp_fwd_train: bad size");
   if (n_rays == 0) return AON_OK;
-  if (!packed || !rays_o || !rays_d || !viewdirs || !t_vals || !raw || !planes) return fail(AON_E_INVALID, "aon_mlp_fwd_train: null pointer");
+  if (!packed || !rays_o || !rays_d || !viewdirs || !t_vals || !raw || !planes || !masks)
+    return fail(AON_E_INVALID, "aon_mlp_fwd_train: null pointer");
+  if (reinterpret_cast<uintptr_t>(masks) & 15) return fail(AON_E_INVALID, "aon_mlp_fwd_train: masks must be 16-byte aligned");
   MlpTimer timer((hipStream_t)stream, n_rays * S);
   return check(aon::launch_mlp_fwd_train(static_cast<const char*>(packed), rays_o, rays_d, viewdirs, t_vals, n_rays, S, raw, planes,
-                                         (hipStream_t)stream), "aon_mlp_fwd_train");
+                                         masks, (hipStream_t)stream), "aon_mlp_fwd_train");
 }
 
 int aon_composite_bwd(const float* raw, const float* t_vals, const float* dirs, const float* g_rgb, const float* g_acc,
@@ -258,12 +263,12 @@ int aon_composite_bwd(const float* raw, const float* t_vals, const float* dirs, 
                                          (hipStream_t)stream), "aon_composite_bwd");
 }
 
-int aon_mlp_bwd_chain(const void* packed_bwd, const void* packed_fwd, const float* d_raw, const float* planes, float* dplanes,
+int aon_mlp_bwd_chain(const void* packed_bwd, const void* packed_fwd, const float* d_raw, const void* masks, float* dplanes,
                       int64_t Np, void* stream) {
   if (Np < 0 || (Np & 127)) return fail(AON_E_INVALID, "aon_mlp_bwd_chain: Np must be a multiple of 128");
   if (Np == 0) return AON_OK;
-  if (!packed_bwd || !packed_fwd || !d_raw || !planes || !dplanes) return fail(AON_E_INVALID, "aon_mlp_bwd_chain: null pointer");
-  return check(aon::launch_mlp_bwd_chain(static_cast<const char*>(packed_bwd), static_cast<const char*>(packed_fwd), d_raw, planes,
+  if (!packed_bwd || !packed_fwd || !d_raw || !masks || !dplanes) return fail(AON_E_INVALID, "aon_mlp_bwd_chain: null pointer");
+  return check(aon::launch_mlp_bwd_chain(static_cast<const char*>(packed_bwd), static_cast<const char*>(packed_fwd), d_raw, masks,
                                          dplanes, Np, (hipStream_t)stream), "aon_mlp_bwd_chain");
 }
 

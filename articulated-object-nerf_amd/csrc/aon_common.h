@@ -92,6 +92,7 @@ constexpr int kPlBot = 64 + 8 * 256;           // 256 rows: bottleneck output (n
 constexpr int kPlVE = kPlBot + 256;            // 32 rows: view-enc (27 + zero pad)
 constexpr int kPlHV = kPlVE + 32;              // 128 rows: view-layer output (post-ReLU)
 constexpr int kPlRows = kPlHV + 128;           // 2528 rows = 10,112 B per sample
+constexpr int kMaskLayers = 9;                 // ReLU bit masks: trunk 0..7, view layer; [layer][Np*2] x 16 B
 
 // Parameter order of the `params` pointer array handed to aon_pack_vanilla_mlp (device pointers to the
 // unmodified torch nn.Linear storages, (out,in) row-major fp32):

@@ -92,6 +92,7 @@ struct MlpArgs {
   int S;
   int npass;                 // ceil(total/128)
   float* planes;             // [TRAIN] kPlRows x Np feature-major activation planes
+  u32x4* masks;              // [TRAIN] kMaskLayers x (Np*2) ReLU bit masks
   int64_t Np;                // npass * 128
 };
 
@@ -154,8 +155,11 @@ __global__ void __launch_bounds__(256) mlp_fwd_kernel(MlpArgs args) {
     const int64_t col = (int64_t)pass * 128 + wave * 32 + m;  // plane column of this lane's sample
     PlaneIO io{};
     if constexpr (TRAIN) io = make_plane_io(args.Np, col, h);
-    auto save = [&](auto& tiles, int row) {
-      if constexpr (TRAIN) store_plane(tiles, reinterpret_cast<float*>(reinterpret_cast<char*>(args.planes) + (int64_t)row * io.row_bytes), io);
+    auto save = [&](auto& tiles, int row, int mask_layer = -1) {
+      if constexpr (TRAIN) {
+        store_plane(tiles, reinterpret_cast<float*>(reinterpret_cast<char*>(args.planes) + (int64_t)row * io.row_bytes), io);
+        if (mask_layer >= 0) args.masks[(int64_t)mask_layer * args.Np * 2 + (int64_t)pass * 256 + tid] = relu_mask_bits(tiles);
+      }
     };
     if constexpr (TRAIN) {
       store_pos_enc_plane(E, reinterpret_cast<float*>(reinterpret_cast<char*>(args.planes) + (int64_t)kPlE * io.row_bytes), io, col, h);
@@ -166,21 +170,21 @@ __global__ void __launch_bounds__(256) mlp_fwd_kernel(MlpArgs args) {
     init_bias(X, sm + kSmBias + 0 * 256, h);
     chunk_mma<VanillaNet, kChL0 + 0, 8, 16>(p, E[0], X);
     chunk_mma<VanillaNet, kChL0 + 1, 8, 16>(p, E[1], X);
-    relu_tiles(X); save(X, plane_h(0));
+    relu_tiles(X); save(X, plane_h(0), 0);
     // L1..L4
-    init_bias(Y, sm + kSmBias + 1 * 256, h); dense_layer<VanillaNet, kChL1 + 0, 8, 8>(p, X, Y); relu_tiles(Y); save(Y, plane_h(1));
-    init_bias(X, sm + kSmBias + 2 * 256, h); dense_layer<VanillaNet, kChL1 + 8, 8, 8>(p, Y, X); relu_tiles(X); save(X, plane_h(2));
-    init_bias(Y, sm + kSmBias + 3 * 256, h); dense_layer<VanillaNet, kChL1 + 16, 8, 8>(p, X, Y); relu_tiles(Y); save(Y, plane_h(3));
-    init_bias(X, sm + kSmBias + 4 * 256, h); dense_layer<VanillaNet, kChL1 + 24, 8, 8>(p, Y, X); relu_tiles(X); save(X, plane_h(4));
+    init_bias(Y, sm + kSmBias + 1 * 256, h); dense_layer<VanillaNet, kChL1 + 0, 8, 8>(p, X, Y); relu_tiles(Y); save(Y, plane_h(1), 1);
+    init_bias(X, sm + kSmBias + 2 * 256, h); dense_layer<VanillaNet, kChL1 + 8, 8, 8>(p, Y, X); relu_tiles(X); save(X, plane_h(2), 2);
+    init_bias(Y, sm + kSmBias + 3 * 256, h); dense_layer<VanillaNet, kChL1 + 16, 8, 8>(p, X, Y); relu_tiles(Y); save(Y, plane_h(3), 3);
+    init_bias(X, sm + kSmBias + 4 * 256, h); dense_layer<VanillaNet, kChL1 + 24, 8, 8>(p, Y, X); relu_tiles(X); save(X, plane_h(4), 4);
     // L5: cat[h(256), enc(63)] -> 256     (model.py:102-103: concat after layer 4's ReLU)
     init_bias(Y, sm + kSmBias + 5 * 256, h);
     dense_layer<VanillaNet, kChL5, 8, 8>(p, X, Y);
     chunk_mma<VanillaNet, kChL5 + 8, 8, 16>(p, E[0], Y);
     chunk_mma<VanillaNet, kChL5 + 9, 8, 16>(p, E[1], Y);
-    relu_tiles(Y); save(Y, plane_h(5));
+    relu_tiles(Y); save(Y, plane_h(5), 5);
     // L6, L7
-    init_bias(X, sm + kSmBias + 6 * 256, h); dense_layer<VanillaNet, kChL6, 8, 8>(p, Y, X); relu_tiles(X); save(X, plane_h(6));
-    init_bias(Y, sm + kSmBias + 7 * 256, h); dense_layer<VanillaNet, kChL7, 8, 8>(p, X, Y); relu_tiles(Y); save(Y, plane_h(7));
+    init_bias(X, sm + kSmBias + 6 * 256, h); dense_layer<VanillaNet, kChL6, 8, 8>(p, Y, X); relu_tiles(X); save(X, plane_h(6), 6);
+    init_bias(Y, sm + kSmBias + 7 * 256, h); dense_layer<VanillaNet, kChL7, 8, 8>(p, X, Y); relu_tiles(Y); save(Y, plane_h(7), 7);
     // density head (model.py:105) on the post-ReLU layer-7 output
     float sigma = head_partial<8>(Y, sm + kSmWSigma, h);
     sigma = sigma + __shfl_xor(sigma, 32) + sm[kSmBSigma];
@@ -198,7 +202,7 @@ __global__ void __launch_bounds__(256) mlp_fwd_kernel(MlpArgs args) {
     chunk_mma<VanillaNet, kChView + 6, 4, 16>(p, X[6], Z);
     chunk_mma<VanillaNet, kChView + 7, 4, 16>(p, X[7], Z);
     chunk_mma<VanillaNet, kChView + 8, 4, 14>(p, V, Z);
-    relu_tiles(Z); save(Z, kPlHV);
+    relu_tiles(Z); save(Z, kPlHV, 8);
     // rgb head (model.py:118)
     float rgb[3];
 #pragma unroll
@@ -265,11 +269,12 @@ hipError_t launch_mlp_fwd(const char* packed, const float* rays_o, const float* 
 
 // Training forward: as launch_mlp_fwd, plus the activation planes (kPlRows x Np floats, Np = 128*ceil(n*S/128)).
 hipError_t launch_mlp_fwd_train(const char* packed, const float* rays_o, const float* rays_d, const float* viewdirs,
-                                const float* t_vals, int64_t n_rays, int S, float* raw, float* planes, hipStream_t stream) {
+                                const float* t_vals, int64_t n_rays, int S, float* raw, float* planes, void* masks,
+                                hipStream_t stream) {
   MlpArgs a{};
   a.packed = packed; a.rays_o = rays_o; a.rays_d = rays_d; a.viewdirs = viewdirs; a.t_vals = t_vals;
   a.raw = raw; a.total = n_rays * S; a.S = S; a.npass = (int)((a.total + 127) / 128);
-  a.planes = planes; a.Np = (int64_t)a.npass * 128;
+  a.planes = planes; a.masks = static_cast<u32x4*>(masks); a.Np = (int64_t)a.npass * 128;
   return launch_mlp_t<true, true>(a, stream);
 }
 

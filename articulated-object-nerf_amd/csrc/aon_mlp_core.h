@@ -153,6 +153,31 @@ __device__ __forceinline__ const float* plane_addr(const float* plane, const Pla
   return reinterpret_cast<const float*>(reinterpret_cast<const char*>(plane) + (int64_t)row * io.row_bytes + io.voff);
 }
 
+// ReLU masks of one layer as bits (bit (t&1)*16 + r of word t>>1 <-> tile t, register r): 16 bytes per lane per layer,
+// written lane-linearly (slot = pass*256 + tid) by the training forward and read back by the backward chain, instead of
+// re-reading 128 activation values per lane per layer.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+template <int NT>
+__device__ __forceinline__ u32x4 relu_mask_bits(const f32x16 (&x)[NT]) {
+  u32x4 w = {0u, 0u, 0u, 0u};
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) w[t >> 1] |= (x[t][r] > 0.f ? 1u : 0u) << ((t & 1) * 16 + r);
+  }
+  return w;
+}
+
+template <int NT>
+__device__ __forceinline__ void apply_mask_bits(f32x16 (&x)[NT], const u32x4 w) {
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) x[t][r] = ((w[t >> 1] >> ((t & 1) * 16 + r)) & 1u) ? x[t][r] : 0.f;
+  }
+}
+
 template <int NT>
 __device__ __forceinline__ void store_plane(const f32x16 (&x)[NT], float* plane, const PlaneIO& io) {
 #pragma unroll

@@ -184,7 +184,7 @@ struct BwdArgs {
   const char* packed_bwd;   // kBwStreamBytes
   const float* small;       // forward small block (head weights): packed_fwd + kStreamBytes
   const float* d_raw;       // (Np,4)   zero for padded samples
-  const float* planes;      // forward activation planes (ReLU masks)
+  const u32x4* masks;       // forward ReLU bit masks, kMaskLayers x (Np*2)
   float* dplanes;           // pre-activation gradient planes, same row map
   int64_t Np;
   int npass;
@@ -198,20 +198,11 @@ __device__ __forceinline__ void zero_tiles(f32x16 (&x)[NT]) {
     for (int r = 0; r < 16; ++r) x[t][r] = 0.f;
 }
 
-// dZ = (H > 0) ? dH : 0, written to the gradient plane; H read from the activation plane (same addressing)
+// dZ = relu'(Z) * dH from the forward's bit mask, written to the gradient plane
 template <int NT>
-__device__ __forceinline__ void mask_and_store(f32x16 (&x)[NT], const float* hplane, float* dplane, const PlaneIO& io) {
-#pragma unroll
-  for (int t = 0; t < NT; ++t) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = 32 * t + (r & 3) + 8 * (r >> 2);
-      const float hv = *plane_addr(hplane, io, row);
-      const float v = hv > 0.f ? x[t][r] : 0.f;
-      x[t][r] = v;
-      *plane_addr(dplane, io, row) = v;
-    }
-  }
+__device__ __forceinline__ void mask_and_store(f32x16 (&x)[NT], const u32x4 bits, float* dplane, const PlaneIO& io) {
+  apply_mask_bits(x, bits);
+  store_plane(x, dplane, io);
 }
 
 __global__ void __launch_bounds__(256) mlp_bwd_chain_kernel(BwdArgs args) {
@@ -236,7 +227,10 @@ __global__ void __launch_bounds__(256) mlp_bwd_chain_kernel(BwdArgs args) {
   for (int pass = blockIdx.x; pass < args.npass; pass += gridDim.x) {
     const int64_t col = (int64_t)pass * 128 + wave * 32 + m;
     const PlaneIO io = make_plane_io(args.Np, col, h);
-    auto hp = [&](int row) { return reinterpret_cast<const float*>(reinterpret_cast<const char*>(args.planes) + (int64_t)row * io.row_bytes); };
+    // all nine layer masks of this lane up front (9 x 16 B): their latency hides under the first MFMA chain
+    u32x4 mk[kMaskLayers];
+#pragma unroll
+    for (int l = 0; l < kMaskLayers; ++l) mk[l] = args.masks[(int64_t)l * args.Np * 2 + (int64_t)pass * 256 + tid];
     auto dp = [&](int row) { return reinterpret_cast<float*>(reinterpret_cast<char*>(args.dplanes) + (int64_t)row * io.row_bytes); };
     const float4 dr = reinterpret_cast<const float4*>(args.d_raw)[col];
     // rgb head (model.py:118):  dHV[f] = sum_c W_rgb[c][f] * d_rgb[c]
@@ -254,7 +248,7 @@ __global__ void __launch_bounds__(256) mlp_bwd_chain_kernel(BwdArgs args) {
           Z[t][4 * gq + cc] = __builtin_fmaf(w2[cc], dr.z, __builtin_fmaf(w1[cc], dr.y, w0[cc] * dr.x));
       }
     }
-    mask_and_store(Z, hp(kPlHV), dp(kPlHV), io);  // view layer ReLU (model.py:114-116)
+    mask_and_store(Z, mk[8], dp(kPlHV), io);  // view layer ReLU (model.py:114-116)
     f32x16 X[8], Y[8];
     // d bottleneck = W_view[:, :256]^T . dZ_view   (bottleneck has no activation, model.py:109)
     zero_tiles(X);
@@ -274,14 +268,14 @@ __global__ void __launch_bounds__(256) mlp_bwd_chain_kernel(BwdArgs args) {
       }
     }
     dense_layer<BwdNet, kBwBott, 8, 8>(p, X, Y);
-    mask_and_store(Y, hp(plane_h(7)), dp(plane_h(7)), io);
-    zero_tiles(X); dense_layer<BwdNet, kBwL7 + 0, 8, 8>(p, Y, X); mask_and_store(X, hp(plane_h(6)), dp(plane_h(6)), io);
-    zero_tiles(Y); dense_layer<BwdNet, kBwL7 + 8, 8, 8>(p, X, Y); mask_and_store(Y, hp(plane_h(5)), dp(plane_h(5)), io);
-    zero_tiles(X); dense_layer<BwdNet, kBwL7 + 16, 8, 8>(p, Y, X); mask_and_store(X, hp(plane_h(4)), dp(plane_h(4)), io);
-    zero_tiles(Y); dense_layer<BwdNet, kBwL7 + 24, 8, 8>(p, X, Y); mask_and_store(Y, hp(plane_h(3)), dp(plane_h(3)), io);
-    zero_tiles(X); dense_layer<BwdNet, kBwL7 + 32, 8, 8>(p, Y, X); mask_and_store(X, hp(plane_h(2)), dp(plane_h(2)), io);
-    zero_tiles(Y); dense_layer<BwdNet, kBwL7 + 40, 8, 8>(p, X, Y); mask_and_store(Y, hp(plane_h(1)), dp(plane_h(1)), io);
-    zero_tiles(X); dense_layer<BwdNet, kBwL7 + 48, 8, 8>(p, Y, X); mask_and_store(X, hp(plane_h(0)), dp(plane_h(0)), io);
+    mask_and_store(Y, mk[7], dp(plane_h(7)), io);
+    zero_tiles(X); dense_layer<BwdNet, kBwL7 + 0, 8, 8>(p, Y, X); mask_and_store(X, mk[6], dp(plane_h(6)), io);
+    zero_tiles(Y); dense_layer<BwdNet, kBwL7 + 8, 8, 8>(p, X, Y); mask_and_store(Y, mk[5], dp(plane_h(5)), io);
+    zero_tiles(X); dense_layer<BwdNet, kBwL7 + 16, 8, 8>(p, Y, X); mask_and_store(X, mk[4], dp(plane_h(4)), io);
+    zero_tiles(Y); dense_layer<BwdNet, kBwL7 + 24, 8, 8>(p, X, Y); mask_and_store(Y, mk[3], dp(plane_h(3)), io);
+    zero_tiles(X); dense_layer<BwdNet, kBwL7 + 32, 8, 8>(p, Y, X); mask_and_store(X, mk[2], dp(plane_h(2)), io);
+    zero_tiles(Y); dense_layer<BwdNet, kBwL7 + 40, 8, 8>(p, X, Y); mask_and_store(Y, mk[1], dp(plane_h(1)), io);
+    zero_tiles(X); dense_layer<BwdNet, kBwL7 + 48, 8, 8>(p, Y, X); mask_and_store(X, mk[0], dp(plane_h(0)), io);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
@@ -471,7 +465,7 @@ hipError_t launch_pack_vanilla_bwd(const float* const* params, float* packed, hi
 
 int64_t bwd_stream_bytes() { return kBwStreamBytes; }
 
-hipError_t launch_mlp_bwd_chain(const char* packed_bwd, const char* packed_fwd, const float* d_raw, const float* planes,
+hipError_t launch_mlp_bwd_chain(const char* packed_bwd, const char* packed_fwd, const float* d_raw, const void* masks,
                                 float* dplanes, int64_t Np, hipStream_t stream) {
   static bool attr = false;
   constexpr int lds = kRingBytes + (int)kSmallBytes;
@@ -480,7 +474,8 @@ hipError_t launch_mlp_bwd_chain(const char* packed_bwd, const char* packed_fwd, 
     if (e != hipSuccess) return e;
     attr = true;
   }
-  BwdArgs a{packed_bwd, reinterpret_cast<const float*>(packed_fwd + kStreamBytes), d_raw, planes, dplanes, Np, (int)(Np / 128)};
+  BwdArgs a{packed_bwd, reinterpret_cast<const float*>(packed_fwd + kStreamBytes), d_raw, static_cast<const u32x4*>(masks), dplanes, Np,
+            (int)(Np / 128)};
   const int cus = num_cus();
   if (cus <= 0) return hipErrorInvalidDevice;
   const int grid = a.npass < cus ? a.npass : cus;

@@ -424,16 +424,20 @@ def padded_samples(n_samples: int) -> int:
 
 
 def mlp_fwd_train(packed, rays_o, rays_d, viewdirs, t_vals):
-    """Fused forward that also stores the feature-major activation planes -> (raw (n,S,4), planes (rows, Np))."""
+    """Fused forward that also stores the feature-major activation planes and the ReLU bit masks
+    -> (raw (n,S,4), planes (rows, Np), masks)."""
     o, d, v, t = _f32(rays_o, "rays_o"), _f32(rays_d, "rays_d"), _f32(viewdirs, "viewdirs"), _f32(t_vals, "t_vals")
     n, S = t.shape
     Np = padded_samples(n * S)
     raw = torch.empty((n, S, 4), dtype=torch.float32, device=t.device)
-    planes = torch.zeros((int(lib.aon_train_plane_rows()), Np), dtype=torch.float32, device=t.device)
+    # every row the backward consumes is fully written by the kernel (padded columns included); the encoding pad rows
+    # (63, and 27..31 of the view block) only ever feed gradient columns that are never emitted -> no zero fill needed
+    planes = torch.empty((int(lib.aon_train_plane_rows()), Np), dtype=torch.float32, device=t.device)
+    masks = torch.empty(int(lib.aon_train_mask_bytes(Np)), dtype=torch.uint8, device=t.device)
     with torch.cuda.device(t.device):
-        check(lib.aon_mlp_fwd_train(_ptr(packed), _ptr(o), _ptr(d), _ptr(v), _ptr(t), n, S, _ptr(raw), _ptr(planes), _stream()),
-              "aon_mlp_fwd_train")
-    return raw, planes
+        check(lib.aon_mlp_fwd_train(_ptr(packed), _ptr(o), _ptr(d), _ptr(v), _ptr(t), n, S, _ptr(raw), _ptr(planes), _ptr(masks),
+                                    _stream()), "aon_mlp_fwd_train")
+    return raw, planes, masks
 
 
 def composite_bwd(raw, t_vals, dirs, g_rgb, g_acc, g_depth, white_bkgd, act, Np: int):
@@ -449,11 +453,12 @@ def composite_bwd(raw, t_vals, dirs, g_rgb, g_acc, g_depth, white_bkgd, act, Np:
     return d_raw
 
 
-def mlp_bwd_chain(packed_bwd, packed_fwd, d_raw, planes):
-    dplanes = torch.zeros_like(planes)
-    Np = planes.shape[1]
-    with torch.cuda.device(planes.device):
-        check(lib.aon_mlp_bwd_chain(_ptr(packed_bwd), _ptr(packed_fwd), _ptr(d_raw), _ptr(planes), _ptr(dplanes), Np, _stream()),
+def mlp_bwd_chain(packed_bwd, packed_fwd, d_raw, masks, plane_shape):
+    """-> dplanes (rows, Np): pre-activation gradient planes (rows of the encodings are not written / not used)."""
+    dplanes = torch.empty(plane_shape, dtype=torch.float32, device=d_raw.device)
+    Np = plane_shape[1]
+    with torch.cuda.device(d_raw.device):
+        check(lib.aon_mlp_bwd_chain(_ptr(packed_bwd), _ptr(packed_fwd), _ptr(d_raw), _ptr(masks), _ptr(dplanes), Np, _stream()),
               "aon_mlp_bwd_chain")
     return dplanes
 

@@ -147,22 +147,25 @@ int aon_art_render_fwd(const void* packed_coarse, const void* small_coarse, cons
 /* ---- R14  backward of the vanilla path (what autograd does for loss.backward(), model.py:264-273) ----
  * Gradients reach only the MLP parameters (t_samples is detached, helper.py:249).  Per level (S = 65 or 193):
  *   aon_mlp_fwd_train   as aon_mlp_fwd, and additionally stores the layer activations as feature-major planes:
- *                       planes[row * Np + sample], aon_train_plane_rows() rows, Np = 128 * ceil(n*S / 128).
+ *                       planes[row * Np + sample], aon_train_plane_rows() rows, Np = 128 * ceil(n*S / 128), and the
+ *                       ReLU decisions of the nine activated layers as bit masks (aon_train_mask_bytes(Np) bytes).
  *   aon_composite_bwd   (g_rgb (n,3), optional g_acc (n,), g_depth (n,)) -> d_raw (n*S,4) = dL/d(raw rgb, raw sigma);
  *                       the caller zero-fills d_raw up to Np rows (padded samples must carry zero gradient).
- *   aon_mlp_bwd_chain   data-gradient chain through the MLP; writes the pre-activation gradient planes `dplanes`
- *                       (same shape / row map as `planes`); needs the transposed stream of aon_pack_vanilla_mlp_bwd.
+ *   aon_mlp_bwd_chain   data-gradient chain through the MLP (ReLU derivatives from `masks`); writes the pre-activation
+ *                       gradient planes `dplanes` (same shape / row map as `planes`, every column written); needs the
+ *                       transposed stream of aon_pack_vanilla_mlp_bwd.
  *   aon_vanilla_wgrad   all 24 parameter gradients (order of aon_pack_vanilla_mlp, full nn.Linear shapes, overwritten)
  *                       from planes x dplanes; workspace >= aon_wgrad_workspace_bytes(); deterministic (no atomics). */
 int64_t aon_train_plane_rows(void);
+int64_t aon_train_mask_bytes(int64_t Np);
 int64_t aon_bwd_packed_bytes(void);
 int64_t aon_wgrad_workspace_bytes(void);
 int aon_pack_vanilla_mlp_bwd(const float* const* params_host, void* packed_bwd, void* stream);
 int aon_mlp_fwd_train(const void* packed, const float* rays_o, const float* rays_d, const float* viewdirs,
-                      const float* t_vals, int64_t n_rays, int S, float* raw, float* planes, void* stream);
+                      const float* t_vals, int64_t n_rays, int S, float* raw, float* planes, void* masks, void* stream);
 int aon_composite_bwd(const float* raw, const float* t_vals, const float* dirs, const float* g_rgb, const float* g_acc,
                       const float* g_depth, int64_t n_rays, int S, int white_bkgd, int act, float* d_raw, void* stream);
-int aon_mlp_bwd_chain(const void* packed_bwd, const void* packed_fwd, const float* d_raw, const float* planes,
+int aon_mlp_bwd_chain(const void* packed_bwd, const void* packed_fwd, const float* d_raw, const void* masks,
                       float* dplanes, int64_t Np, void* stream);
 int aon_vanilla_wgrad(const float* planes, const float* dplanes, const float* d_raw, int64_t Np,
                       float* const* grads_host, void* workspace, int64_t workspace_bytes, void* stream);

@@ -90,7 +90,7 @@ def test_forward_train_planes(dev, nerf_sd):
     rays = syn.random_rays(n, seed=5)
     t = torch.sort(torch.rand(n, S, generator=torch.Generator().manual_seed(5)) * 4 + 2, dim=-1).values
     args = [rays[k].to(dev) for k in ("rays_o", "rays_d", "viewdirs")] + [t.to(dev)]
-    raw, planes = ops.mlp_fwd_train(packed, *args)
+    raw, planes, masks = ops.mlp_fwd_train(packed, *args)
     assert torch.equal(raw, ops.mlp_fwd(packed, *args))  # same arithmetic as the inference kernel
     assert planes.shape == (2528, 640)
     enc = orc.pos_enc(orc.cast_rays(t, rays["rays_o"], rays["rays_d"]), 0, 10)
@@ -98,7 +98,6 @@ def test_forward_train_planes(dev, nerf_sd):
     acts, bott, hv = _layer_activations(nerf_sd, "fine_mlp.", enc, venc)
     pl = planes.cpu()[:, : n * S]
     torch.testing.assert_close(pl[0:63].T, enc.reshape(-1, 63), rtol=0, atol=2.5e-7)
-    assert (pl[63] == 0).all()
     for l in range(8):
         torch.testing.assert_close(pl[64 + 256 * l: 64 + 256 * (l + 1)].T, acts[l], rtol=2e-5, atol=2e-5)
     torch.testing.assert_close(pl[2112:2368].T, bott, rtol=2e-5, atol=2e-5)
@@ -165,11 +164,11 @@ def test_level_backward_with_shared_samples(dev, nerf_sd, n, S):
     comp = orc.volumetric_rendering(torch.sigmoid(raw_rgb), torch.relu(raw_sig), t, rays["rays_d"], True)[0]
     orc.img2mse(comp, target).backward()
     o, d, v, tt = (x.to(dev) for x in (rays["rays_o"], rays["rays_d"], rays["viewdirs"], t))
-    raw, planes = ops.mlp_fwd_train(packed, o, d, v, tt)
+    raw, planes, masks = ops.mlp_fwd_train(packed, o, d, v, tt)
     rgb = ops.composite_raw(raw, tt, d, True, ops.ACT_VANILLA)[0]
     g_rgb = 2.0 * (rgb - target.to(dev)) / (n * 3)
     d_raw = ops.composite_bwd(raw, tt, d, g_rgb, None, None, True, ops.ACT_VANILLA, planes.shape[1])
-    dplanes = ops.mlp_bwd_chain(packed_bwd, packed, d_raw, planes)
+    dplanes = ops.mlp_bwd_chain(packed_bwd, packed, d_raw, masks, planes.shape)
     grads = ops.vanilla_wgrad(planes, dplanes, d_raw)
     for name, g in grads.items():
         err = rel_l2(g.cpu(), sd_o[prefix + name].grad)

@@ -1,0 +1,60 @@
+"""Training-step timing of the HIP path (vanilla NeRF, reference training_step: model.py:256-282 + Adam :386-389).
+
+    python tools/train_bench.py --rays 2048 --steps 5
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rays", type=int, default=2048)   # the reference's hard-coded per-GPU batch (model.py:426)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    args = ap.parse_args()
+    import aon_amd.synthetic as syn
+    from aon_amd import ops
+    from aon_amd.models.vanilla_nerf.model import NeRF
+
+    dev = torch.device("cuda:0")
+    model = NeRF().to(dev)
+    model.load_state_dict(syn.make_nerf_state_dict(seed=0, density_scale=30.0))
+    opt = torch.optim.Adam(model.parameters(), lr=5e-4, betas=(0.9, 0.999))
+    H, W = 480, 640
+    ro, vd = ops.raygen(syn.look_at_pose(), H, W, syn.focal_from_fovy(H), device=dev)
+    g = torch.Generator(device=dev).manual_seed(0)
+    idx = torch.randint(0, H * W, (args.rays,), device=dev, generator=g)
+    rays = {"rays_o": ro[idx].contiguous(), "rays_d": vd[idx].contiguous(), "viewdirs": vd[idx].contiguous()}
+    target = torch.rand(args.rays, 3, device=dev, generator=g)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        out = model(rays, True, True, syn.NEAR, syn.FAR)
+        loss = torch.mean((out[0][0] - target) ** 2) + torch.mean((out[1][0] - target) ** 2)
+        loss.backward()
+        opt.step()
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+    flop = args.rays * 258 * 1_186_816 * 3  # fwd + 2x bwd, reference-literal
+    print(json.dumps({"rays_per_step": args.rays, "ms_per_step": dt * 1e3, "rays_per_s": args.rays / dt,
+                      "train_tflops_3x_fwd": flop / dt / 1e12, "loss": loss.item()}))
+
+
+if __name__ == "__main__":
+    main()
