@@ -135,3 +135,99 @@ class NeRF(nn.Module):
         outs = ops.render_fwd(self.coarse_mlp.packed(), fine, rays_o, rays["rays_d"], rays["viewdirs"], near, far,
                               white_bkgd, self.num_levels, t_rand, u)
         return [tuple(o) for o in outs]
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# Harness-level equivalents of the reference's LightningModule methods, without pytorch-lightning.
+# --------------------------------------------------------------------------------------------------------------------
+import math
+from collections import defaultdict
+from types import SimpleNamespace
+
+from . import helper
+from ..interface import LitModel
+
+
+class LitNeRF(LitModel):
+    """``models/vanilla_nerf/model.py:202-419`` minus Lightning: same method names, batch contracts and return
+    structures for ``training_step`` (:256-282), ``render_rays`` (:295-321, fine level only, chunked by ``hparams.chunk``,
+    logs val/psnr), ``render_rays_test`` (:323-348), ``validation_step`` (:353-375), ``test_step`` (:377-384),
+    ``configure_optimizers`` (:386-389) and the learning-rate rule of ``optimizer_step`` (:391-419).
+    Values the reference hands to ``self.log`` are collected in ``self.logged``.  near / far / white_bkgd, which the
+    reference copies from its dataset in ``setup`` (:245-254), are constructor arguments here (dataset IO is out of scope)."""
+
+    def __init__(self, hparams=None, lr_init: float = 5.0e-4, lr_final: float = 5.0e-6, lr_delay_steps: int = 2500,
+                 lr_delay_mult: float = 0.01, randomized: bool = True, near: float = 2.0, far: float = 6.0, white_bkgd: bool = True):
+        super().__init__()
+        hp = dict(chunk=3840, run_max_steps=100000, img_wh=(640, 480))  # opt.py:103,112,17
+        hp.update(vars(hparams) if hparams is not None and not isinstance(hparams, dict) else (hparams or {}))
+        self.hparams = SimpleNamespace(**hp)
+        self.lr_init, self.lr_final, self.lr_delay_steps, self.lr_delay_mult = lr_init, lr_final, lr_delay_steps, lr_delay_mult
+        self.randomized, self.near, self.far, self.white_bkgd = randomized, near, far, white_bkgd
+        self.model = NeRF()
+        self.logged = defaultdict(list)
+        self.global_step = 0
+
+    def log(self, name, value, **_):
+        self.logged[name].append(float(value))
+
+    def training_step(self, batch, batch_idx):
+        batch = {k: (v if k == "obj_idx" else v.squeeze(0)) for k, v in batch.items()}
+        rendered = self.model(batch, self.randomized, self.white_bkgd, self.near, self.far)
+        target = batch["target"]
+        loss0 = helper.img2mse(rendered[0][0], target)
+        loss1 = helper.img2mse(rendered[1][0], target)
+        loss = loss1 + loss0
+        self.log("train/psnr1", helper.mse2psnr(loss1.detach()))
+        self.log("train/psnr0", helper.mse2psnr(loss0.detach()))
+        self.log("train/loss", loss.detach())
+        return loss
+
+    @torch.no_grad()
+    def render_rays(self, batch, batch_idx):
+        B = batch["rays_o"].shape[0]
+        ret = defaultdict(list)
+        for i in range(0, B, self.hparams.chunk):
+            chunk = {k: (v if k == "obj_idx" else v[i: i + self.hparams.chunk]) for k, v in batch.items()}
+            out = self.model(chunk, False, self.white_bkgd, self.near, self.far)
+            ret["comp_rgb"] += [out[1][0]]
+            ret["acc"] += [out[1][1]]
+            ret["depth"] += [out[1][2]]
+        ret = {k: torch.cat(v, 0) for k, v in ret.items()}
+        self.log("val/psnr", self.psnr_legacy(ret["comp_rgb"], batch["target"]).mean().item())
+        return ret
+
+    @torch.no_grad()
+    def render_rays_test(self, batch, batch_idx):
+        B = batch["rays_o"].shape[0]
+        rgb = []
+        for i in range(0, B, self.hparams.chunk):
+            chunk = {k: v[i: i + self.hparams.chunk] for k, v in batch.items()}
+            rgb.append(self.model(chunk, False, self.white_bkgd, self.near, self.far)[1][0])
+        return {"target": batch["target"], "instance_mask": batch["instance_mask"], "rgb": torch.cat(rgb, 0)}
+
+    def validation_step(self, batch, batch_idx):
+        batch = {k: (v if k == "obj_idx" else v.squeeze(0)) for k, v in batch.items()}
+        return self.render_rays(batch, batch_idx)  # the reference renders twice (:367,:375); once is the same result
+
+    def test_step(self, batch, batch_idx):
+        batch = {k: v.squeeze(0) if v.dim() > 0 and v.shape[0] == 1 else v for k, v in batch.items()}
+        return self.render_rays_test(batch, batch_idx)
+
+    def configure_optimizers(self):
+        return torch.optim.Adam(params=self.parameters(), lr=self.lr_init, betas=(0.9, 0.999))
+
+    def lr_at_step(self, step: int) -> float:
+        """model.py:402-414: log-linear decay lr_init -> lr_final over run_max_steps with a sine warm-up."""
+        if self.lr_delay_steps > 0:
+            delay = self.lr_delay_mult + (1 - self.lr_delay_mult) * math.sin(0.5 * math.pi * min(max(step / self.lr_delay_steps, 0), 1))
+        else:
+            delay = 1.0
+        t = min(max(step / self.hparams.run_max_steps, 0), 1)
+        return delay * math.exp(math.log(self.lr_init) * (1 - t) + math.log(self.lr_final) * t)
+
+    def optimizer_step(self, optimizer, closure=None):
+        for pg in optimizer.param_groups:
+            pg["lr"] = self.lr_at_step(self.global_step)
+        optimizer.step(closure=closure)
+        self.global_step += 1

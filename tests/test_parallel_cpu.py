@@ -47,10 +47,52 @@ def _worker(rank, world, port, H, W, q):
         n = rank + 3
         lvl = (torch.full((n, 3), float(rank)), torch.arange(n, dtype=torch.float32) + 100 * rank, torch.full((n,), -1.0 * rank))
         g_rgb, g_acc, g_depth = par.all_gather_pixels(lvl)
-        q.put((rank, rgb, acc, depth, g_rgb, g_acc, g_depth))
+        q.put((rank, *[x.numpy().copy() for x in (rgb, acc, depth, g_rgb, g_acc, g_depth)]))
         dist.barrier()
     finally:
         dist.destroy_process_group()
+
+
+def _grad_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from aon_amd import parallel as par
+
+        torch.manual_seed(100 + rank)  # ranks start from different parameters and see different data
+        net = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.ReLU(), torch.nn.Linear(7, 3))
+        par.broadcast_parameters(net)
+        x = torch.randn(11, 5)
+        net(x).square().mean().backward()
+        local = [p.grad.clone() for p in net.parameters()]
+        par.allreduce_gradients(net)
+        # plain numpy payloads: torch tensors travel through shared-memory handles that die with the worker
+        q.put((rank, [p.detach().numpy().copy() for p in net.parameters()], [g.numpy().copy() for g in local],
+               [p.grad.numpy().copy() for p in net.parameters()]))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_data_parallel_gradient_exchange():
+    """broadcast_parameters + allreduce_gradients (the DDP duties of run.py:151) over gloo, world size 2."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_grad_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, params0, local0, avg0), (_, params1, local1, avg1) = [
+        (r[0], *[[torch.from_numpy(a) for a in part] for part in r[1:]]) for r in res]
+    for a, b in zip(params0, params1):
+        assert torch.equal(a, b)                      # same parameters everywhere after the broadcast
+    for l0, l1, a0, a1 in zip(local0, local1, avg0, avg1):
+        assert torch.equal(a0, a1)                    # same averaged gradient everywhere
+        torch.testing.assert_close(a0, (l0 + l1) / 2, rtol=1e-6, atol=1e-7)
 
 
 def test_shard_range_is_a_partition():
@@ -81,7 +123,8 @@ def test_sharded_frame_equals_single_process():
         assert p.exitcode == 0
     ro, vd = _cpu_raygen(H, W, syn.focal_from_fovy(H), syn.look_at_pose(), 0, H * W)
     full = FakeRenderer()({"rays_o": ro, "rays_d": vd, "viewdirs": vd}, False, True, 2.0, 6.0)[1]
-    for rank, rgb, acc, depth, g_rgb, g_acc, g_depth in results:
+    for rank, *arrs in results:
+        rgb, acc, depth, g_rgb, g_acc, g_depth = (torch.from_numpy(a) for a in arrs)
         assert torch.equal(rgb, full[0]) and torch.equal(acc, full[1]) and torch.equal(depth, full[2])
         assert g_rgb.shape == (3 + 4, 3)
         assert torch.equal(g_acc, torch.tensor([0., 1., 2., 100., 101., 102., 103.]))
