@@ -51,6 +51,13 @@ _SIGS = {
     "aon_composite_bwd": (_i, [_p, _p, _p, _p, _p, _p, _l, _i, _i, _i, _p, _p]),
     "aon_mlp_bwd_chain": (_i, [_p, _p, _p, _p, _p, _l, _p]),
     "aon_vanilla_wgrad": (_i, [_p, _p, _p, _l, _p, _p, _l, _p]),
+    "aon_art_train_plane_rows": (_l, []),
+    "aon_art_train_mask_bytes": (_l, [_l]),
+    "aon_art_bwd_packed_bytes": (_l, []),
+    "aon_pack_art_mlp_bwd": (_i, [_p, _p, _p]),
+    "aon_art_mlp_fwd_train": (_i, [_p, _p, _p, _p, _p, _p, _l, _i, _p, _p, _p, _p]),
+    "aon_art_bwd_chain": (_i, [_p, _p, _p, _p, _p, _p, _p, _l, _p]),
+    "aon_art_wgrad": (_i, [_p, _p, _p, _p, _l, _p, _p, _p, _p, _p, _p, _p, _p, _p, _l, _p]),
     "aon_profile_begin": (_i, []),
     "aon_profile_end": (_i, [C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "aon_render_workspace_bytes": (_l, [_l]),

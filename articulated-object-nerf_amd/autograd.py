@@ -49,3 +49,52 @@ class RenderVanilla(torch.autograd.Function):
             del dplanes
         ctx.saved = None
         return (None,) * 10 + tuple(grads)
+
+
+class RenderArticulated(torch.autograd.Function):
+    """NeRF_AE_Art.forward with gradients to the 2 x 40 MLP parameters and the three latents."""
+
+    @staticmethod
+    def forward(ctx, rays_o, rays_d, viewdirs, near, far, white_bkgd, num_levels, t_rand, u, packs, lat_density, lat_color,
+                lat_articulation, *params):
+        # packs: per level (packed_fwd, small, packed_bwd); params: 40 tensors per level in ops.ART_PARAM_ORDER
+        saved, outs = [], []
+        t_vals = weights = None
+        for lvl in range(num_levels):
+            packed_fwd, small, packed_bwd = packs[lvl]
+            if lvl == 0:
+                t_vals, _ = ops.sample_along_rays(rays_o, rays_d, 64, near, far, t_rand, want_coords=False)
+            else:
+                t_vals = ops.sample_pdf_t(t_vals, weights, u)
+            raw, planes, masks = ops.art_mlp_fwd_train(packed_fwd, small, rays_o, rays_d, viewdirs, t_vals)
+            rgb, acc, weights, depth = ops.composite_raw(raw, t_vals, rays_d, white_bkgd, ops.ACT_ARTICULATED, want_weights=True)
+            outs += [rgb, acc, depth]
+            saved.append((raw, t_vals, planes, masks, small, packed_bwd))
+        ctx.saved = saved
+        ctx.rays_d, ctx.white_bkgd, ctx.num_levels = rays_d, white_bkgd, num_levels
+        ctx.latents = {"density": lat_density.detach(), "color": lat_color.detach(), "articulation": lat_articulation.detach()}
+        ctx.lat_shapes = (lat_density.shape, lat_color.shape, lat_articulation.shape)
+        ctx.params = [p.detach() for p in params]
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        grads = []
+        g_lat_tot = None
+        n_per = len(ops.ART_PARAM_ORDER)
+        for lvl in range(ctx.num_levels):
+            raw, t_vals, planes, masks, small, packed_bwd = ctx.saved[lvl]
+            g_rgb, g_acc, g_depth = gouts[3 * lvl: 3 * lvl + 3]
+            if g_rgb is None:
+                g_rgb = torch.zeros((t_vals.shape[0], 3), dtype=torch.float32, device=t_vals.device)
+            d_raw = ops.composite_bwd(raw, t_vals, ctx.rays_d, g_rgb.contiguous(), g_acc, g_depth, ctx.white_bkgd, ops.ACT_ARTICULATED,
+                                      planes.shape[1])
+            dplanes, dxp = ops.art_bwd_chain(packed_bwd, small, d_raw, masks, planes)
+            params = dict(zip(ops.ART_PARAM_ORDER, ctx.params[lvl * n_per: (lvl + 1) * n_per]))
+            g, g_lat = ops.art_wgrad(planes, dplanes, d_raw, dxp, params, ctx.latents)
+            grads += [g[name] for name in ops.ART_PARAM_ORDER]
+            g_lat_tot = g_lat if g_lat_tot is None else {k: g_lat_tot[k] + g_lat[k] for k in g_lat}
+            del dplanes
+        ctx.saved = None
+        lat = tuple(g_lat_tot[k].reshape(shp) for k, shp in zip(("density", "color", "articulation"), ctx.lat_shapes))
+        return (None,) * 10 + lat + tuple(grads)

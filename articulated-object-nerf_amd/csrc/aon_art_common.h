@@ -1,0 +1,29 @@
+// Constants shared by the articulated forward (aon_mlp_art.hip) and backward (aon_train_art.hip).
+#pragma once
+#include "aon_mlp_core.h"
+
+namespace aon {
+
+// ---- per-call small block (floats), rebuilt by aon_art_prepare because it depends on the latents ----
+constexpr int kA_BD0 = 0;       // 128   effective bias of deformations_linear.0 (shape + articulation folded in)
+constexpr int kA_WD0 = 128;     // 3x128 deformations_linear.0 weight, [xyz][feature]
+constexpr int kA_BD = 512;      // 3x128 biases of deformations_linear.1..3
+constexpr int kA_WDL = 896;     // 3x128 deformation_layer weight rows
+constexpr int kA_BDL = 1280;    // 3 (+1 pad)
+constexpr int kA_BT = 1284;     // 8x256 trunk biases (layers 0 and 5 effective: shape latent folded in)
+constexpr int kA_BBOT = 3332;   // 256
+constexpr int kA_BV = 3588;     // 4x128 view-branch biases (layer 0 effective: appearance latent folded in)
+constexpr int kA_WSIG = 4100;   // 256
+constexpr int kA_WRGB = 4356;   // 3x128
+constexpr int kA_BSIG = 4740;   // 1
+constexpr int kA_BRGB = 4741;   // 3
+constexpr int kASmallFloats = 4744;
+constexpr int kALdsBytes = kRingBytes + kASmallFloats * 4;
+
+// parameter order of the articulated NeRFMLP (model_autodecoder.py:60-170):
+//   0..7   deformations_linear.{0..3}.{weight,bias}      8,9  deformation_layer.{weight,bias}
+//   10..25 pts_linears.{0..7}.{weight,bias}              26..33 views_linear.{0..3}.{weight,bias}
+//   34,35  bottleneck_layer   36,37 density_layer   38,39 rgb_layer
+constexpr int kNumArtParams = 40;
+
+}  // namespace aon

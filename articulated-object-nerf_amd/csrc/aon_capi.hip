@@ -36,6 +36,16 @@ hipError_t launch_mlp_bwd_chain(const char* packed_bwd, const char* packed_fwd, 
 int64_t wgrad_workspace_bytes();
 hipError_t launch_vanilla_wgrad(const float* planes, const float* dplanes, const float* d_raw, int64_t Np, float* const* grads,
                                 float* ws, hipStream_t stream);
+hipError_t launch_art_mlp_fwd_train(const char* packed, const float* small, const float* rays_o, const float* rays_d,
+                                    const float* viewdirs, const float* t_vals, int64_t n_rays, int S, float* raw, float* planes,
+                                    void* masks, hipStream_t stream);
+hipError_t launch_pack_art_bwd(const float* const* params, float* packed, hipStream_t stream);
+int64_t art_bwd_stream_bytes();
+hipError_t launch_art_bwd_chain(const char* packed_bwd, const float* small, const float* d_raw, const void* masks, const float* planes,
+                                float* dplanes, float* dxp, int64_t Np, hipStream_t stream);
+hipError_t launch_art_wgrad(const float* planes, const float* dplanes, const float* d_raw, const float* dxp, int64_t Np,
+                            const float* const* params, const float* shape, const float* app, const float* art,
+                            float* const* grads, float* g_shape, float* g_app, float* g_art, float* ws, hipStream_t stream);
 hipError_t launch_raygen(const float* c2w, int H, int W, float focal, const float* directions, int64_t pix_begin,
                          int64_t pix_end, float* rays_o, float* viewdirs, float* rays_d, hipStream_t stream);
 hipError_t launch_ray_directions(int H, int W, float focal, float* out, hipStream_t stream);
@@ -281,6 +291,55 @@ int aon_vanilla_wgrad(const float* planes, const float* dplanes, const float* d_
   if (workspace_bytes < aon::wgrad_workspace_bytes()) return fail(AON_E_WORKSPACE, "aon_vanilla_wgrad: workspace too small");
   return check(aon::launch_vanilla_wgrad(planes, dplanes, d_raw, Np, grads_host, static_cast<float*>(workspace), (hipStream_t)stream),
                "aon_vanilla_wgrad");
+}
+
+// ---- training, articulated network ----
+int64_t aon_art_train_plane_rows(void) { return aon::kAPlRows; }
+int64_t aon_art_train_mask_bytes(int64_t Np) { return (int64_t)aon::kAMaskLayers * Np * 2 * 16; }
+int64_t aon_art_bwd_packed_bytes(void) { return aon::art_bwd_stream_bytes(); }
+
+int aon_pack_art_mlp_bwd(const float* const* params_host, void* packed_bwd, void* stream) {
+  if (!params_host || !packed_bwd) return fail(AON_E_INVALID, "aon_pack_art_mlp_bwd: null pointer");
+  for (int i = 0; i < 40; ++i)
+    if (!params_host[i]) return fail(AON_E_INVALID, "aon_pack_art_mlp_bwd: null parameter pointer");
+  if (reinterpret_cast<uintptr_t>(packed_bwd) & 15) return fail(AON_E_INVALID, "aon_pack_art_mlp_bwd: buffer must be 16-byte aligned");
+  return check(aon::launch_pack_art_bwd(params_host, static_cast<float*>(packed_bwd), (hipStream_t)stream), "aon_pack_art_mlp_bwd");
+}
+
+int aon_art_mlp_fwd_train(const void* packed, const void* small, const float* rays_o, const float* rays_d, const float* viewdirs,
+                          const float* t_vals, int64_t n_rays, int S, float* raw, float* planes, void* masks, void* stream) {
+  if (n_rays < 0 || S < 1) return fail(AON_E_INVALID, "aon_art_mlp_fwd_train: bad size");
+  if (n_rays == 0) return AON_OK;
+  if (!packed || !small || !rays_o || !rays_d || !viewdirs || !t_vals || !raw || !planes || !masks)
+    return fail(AON_E_INVALID, "aon_art_mlp_fwd_train: null pointer");
+  if (reinterpret_cast<uintptr_t>(masks) & 15) return fail(AON_E_INVALID, "aon_art_mlp_fwd_train: masks must be 16-byte aligned");
+  MlpTimer timer((hipStream_t)stream, n_rays * S);
+  return check(aon::launch_art_mlp_fwd_train(static_cast<const char*>(packed), static_cast<const float*>(small), rays_o, rays_d, viewdirs,
+                                             t_vals, n_rays, S, raw, planes, masks, (hipStream_t)stream), "aon_art_mlp_fwd_train");
+}
+
+int aon_art_bwd_chain(const void* packed_bwd, const void* small, const float* d_raw, const void* masks, const float* planes,
+                      float* dplanes, float* dxp, int64_t Np, void* stream) {
+  if (Np < 0 || (Np & 127)) return fail(AON_E_INVALID, "aon_art_bwd_chain: Np must be a multiple of 128");
+  if (Np == 0) return AON_OK;
+  if (!packed_bwd || !small || !d_raw || !masks || !planes || !dplanes || !dxp) return fail(AON_E_INVALID, "aon_art_bwd_chain: null pointer");
+  return check(aon::launch_art_bwd_chain(static_cast<const char*>(packed_bwd), static_cast<const float*>(small), d_raw, masks, planes,
+                                         dplanes, dxp, Np, (hipStream_t)stream), "aon_art_bwd_chain");
+}
+
+int aon_art_wgrad(const float* planes, const float* dplanes, const float* d_raw, const float* dxp, int64_t Np,
+                  const float* const* params_host, const float* shape, const float* appearance, const float* articulation,
+                  float* const* grads_host, float* g_shape, float* g_appearance, float* g_articulation, void* workspace,
+                  int64_t workspace_bytes, void* stream) {
+  if (Np <= 0 || (Np & 127)) return fail(AON_E_INVALID, "aon_art_wgrad: Np must be a positive multiple of 128");
+  if (!planes || !dplanes || !d_raw || !dxp || !params_host || !shape || !appearance || !articulation || !grads_host || !g_shape ||
+      !g_appearance || !g_articulation || !workspace)
+    return fail(AON_E_INVALID, "aon_art_wgrad: null pointer");
+  for (int i = 0; i < 40; ++i)
+    if (!params_host[i] || !grads_host[i]) return fail(AON_E_INVALID, "aon_art_wgrad: null parameter / gradient pointer");
+  if (workspace_bytes < aon::wgrad_workspace_bytes()) return fail(AON_E_WORKSPACE, "aon_art_wgrad: workspace too small");
+  return check(aon::launch_art_wgrad(planes, dplanes, d_raw, dxp, Np, params_host, shape, appearance, articulation, grads_host, g_shape,
+                                     g_appearance, g_articulation, static_cast<float*>(workspace), (hipStream_t)stream), "aon_art_wgrad");
 }
 
 int aon_profile_begin(void) {

@@ -36,6 +36,26 @@ __device__ __forceinline__ float sin_f32(float x) {
   return x < 0.f ? -res : res;
 }
 
+// cos(x) with the same reduction / polynomials (the derivative of the encoding in the backward pass).
+__device__ __forceinline__ float cos_f32(float x) {
+  const float ax = __builtin_fabsf(x);
+  const float k = __builtin_rintf(ax * 0.636619747f);
+  const int q = (int)k;
+  float r = __builtin_fmaf(k, -0x1.921fb4p+0f, ax);
+  r = __builtin_fmaf(k, -0x1.4442d0p-24f, r);
+  r = __builtin_fmaf(k, -0x1.846988p-48f, r);
+  const float z = r * r;
+  float ps = __builtin_fmaf(z, -1.9515295891e-4f, 8.3321608736e-3f);
+  ps = __builtin_fmaf(z, ps, -1.6666654611e-1f);
+  const float s = __builtin_fmaf(r * z, ps, r);
+  float pc = __builtin_fmaf(z, 2.443315711809948e-5f, -1.388731625493765e-3f);
+  pc = __builtin_fmaf(z, pc, 4.166664568298827e-2f);
+  const float c = __builtin_fmaf(z * z, pc, __builtin_fmaf(z, -0.5f, 1.0f));
+  // cos(|x|) = cos(r + q pi/2): q=0: c, 1: -s, 2: -c, 3: s
+  float res = (q & 1) ? s : c;
+  return ((q + 1) & 2) ? -res : res;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Packed-weight stream of one vanilla NeRFMLP (models/vanilla_nerf/model.py:39-120).
 //
@@ -93,6 +113,17 @@ constexpr int kPlVE = kPlBot + 256;            // 32 rows: view-enc (27 + zero p
 constexpr int kPlHV = kPlVE + 32;              // 128 rows: view-layer output (post-ReLU)
 constexpr int kPlRows = kPlHV + 128;           // 2528 rows = 10,112 B per sample
 constexpr int kMaskLayers = 9;                 // ReLU bit masks: trunk 0..7, view layer; [layer][Np*2] x 16 B
+
+// Articulated network (model_autodecoder.py): plane rows and mask slots of one level
+constexpr int kAPlPos = 0;                                   // 32 rows: 0..2 = sample position x, 3..5 = deformed position x'
+__host__ __device__ constexpr int aplane_d(int l) { return 32 + 128 * l; }    // 4 x 128: deformation MLP outputs
+constexpr int kAPlE = 32 + 4 * 128;                          // 64 rows: pos-enc of x'
+__host__ __device__ constexpr int aplane_h(int l) { return kAPlE + 64 + 256 * l; }  // 8 x 256: trunk outputs
+constexpr int kAPlBot = kAPlE + 64 + 8 * 256;                // 256
+constexpr int kAPlVE = kAPlBot + 256;                        // 32
+__host__ __device__ constexpr int aplane_v(int l) { return kAPlVE + 32 + 128 * l; }  // 4 x 128: view-branch outputs
+constexpr int kAPlRows = kAPlVE + 32 + 4 * 128;              // 3456 rows = 13,824 B per sample
+constexpr int kAMaskLayers = 16;                             // slots: D0..3 -> 0..3, H0..7 -> 4..11, V0..3 -> 12..15
 
 // Parameter order of the `params` pointer array handed to aon_pack_vanilla_mlp (device pointers to the
 // unmodified torch nn.Linear storages, (out,in) row-major fp32):

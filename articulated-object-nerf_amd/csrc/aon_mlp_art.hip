@@ -11,7 +11,7 @@
 //     (163->3, 191->63, 447->319, 411->283 effective K), so the kernel never touches them.
 //   * the 3->128 first deformation layer and the 128->3 deformation head are VALU work on register tiles;
 //     the deformed point is encoded in registers exactly like the vanilla path.
-#include "aon_mlp_core.h"
+#include "aon_art_common.h"
 
 namespace aon {
 
@@ -39,27 +39,6 @@ struct ArtNet {
 };
 constexpr int64_t kAStreamBytes = ArtNet::chunk_offset(kANumChunks);  // 2,768,896 B
 
-// ---- per-call small block (floats), rebuilt by aon_art_prepare because it depends on the latents ----
-constexpr int kA_BD0 = 0;       // 128   effective bias of deformations_linear.0 (shape + articulation folded in)
-constexpr int kA_WD0 = 128;     // 3x128 deformations_linear.0 weight, [xyz][feature]
-constexpr int kA_BD = 512;      // 3x128 biases of deformations_linear.1..3
-constexpr int kA_WDL = 896;     // 3x128 deformation_layer weight rows
-constexpr int kA_BDL = 1280;    // 3 (+1 pad)
-constexpr int kA_BT = 1284;     // 8x256 trunk biases (layers 0 and 5 effective: shape latent folded in)
-constexpr int kA_BBOT = 3332;   // 256
-constexpr int kA_BV = 3588;     // 4x128 view-branch biases (layer 0 effective: appearance latent folded in)
-constexpr int kA_WSIG = 4100;   // 256
-constexpr int kA_WRGB = 4356;   // 3x128
-constexpr int kA_BSIG = 4740;   // 1
-constexpr int kA_BRGB = 4741;   // 3
-constexpr int kASmallFloats = 4744;
-constexpr int kALdsBytes = kRingBytes + kASmallFloats * 4;
-
-// parameter order of the articulated NeRFMLP (model_autodecoder.py:60-170):
-//   0..7   deformations_linear.{0..3}.{weight,bias}      8,9  deformation_layer.{weight,bias}
-//   10..25 pts_linears.{0..7}.{weight,bias}              26..33 views_linear.{0..3}.{weight,bias}
-//   34,35  bottleneck_layer   36,37 density_layer   38,39 rgb_layer
-constexpr int kNumArtParams = 40;
 struct ArtPackArgs {
   const float* p[kNumArtParams];
 };
@@ -155,9 +134,12 @@ struct ArtMlpArgs {
   int64_t total;
   int S;
   int npass;
+  float* planes;          // [TRAIN] kAPlRows x Np
+  u32x4* masks;           // [TRAIN] kAMaskLayers x (Np*2)
+  int64_t Np;
 };
 
-template <bool POS_IN_KERNEL>
+template <bool POS_IN_KERNEL, bool TRAIN>
 __global__ void __launch_bounds__(256) art_mlp_fwd_kernel(ArtMlpArgs args) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* sm = reinterpret_cast<float*>(smem + kRingBytes);
@@ -199,6 +181,24 @@ __global__ void __launch_bounds__(256) art_mlp_fwd_kernel(ArtMlpArgs args) {
       load_view_enc(args.viewdirs_enc + ray * kViewEnc, h, V);
     }
 
+    const int64_t col = (int64_t)pass * 128 + wave * 32 + m;
+    PlaneIO io{};
+    if constexpr (TRAIN) io = make_plane_io(args.Np, col, h);
+    auto save = [&](auto& tiles, int row, int mask_slot = -1) {
+      if constexpr (TRAIN) {
+        store_plane(tiles, reinterpret_cast<float*>(reinterpret_cast<char*>(args.planes) + (int64_t)row * io.row_bytes), io);
+        if (mask_slot >= 0) args.masks[(int64_t)mask_slot * args.Np * 2 + (int64_t)pass * 256 + tid] = relu_mask_bits(tiles);
+      }
+    };
+    auto save_row = [&](int row, float v) {  // one scalar per sample (lanes 0..31)
+      if constexpr (TRAIN) { if (h == 0) *reinterpret_cast<float*>(reinterpret_cast<char*>(args.planes) + (int64_t)row * io.row_bytes + col * 4) = v; }
+    };
+    if constexpr (TRAIN) {
+      store_view_enc_plane(V, reinterpret_cast<float*>(reinterpret_cast<char*>(args.planes) + (int64_t)kAPlVE * io.row_bytes), io, col, h);
+#pragma unroll
+      for (int a = 0; a < 3; ++a) save_row(kAPlPos + a, x[a]);
+    }
+
     // ---- deformation MLP (:196-205) ----
     f32x16 H0[4], H1[4];
     init_bias(H0, sm + kA_BD0, h);  // effective bias, then the three xyz columns on the VALU
@@ -214,10 +214,10 @@ __global__ void __launch_bounds__(256) art_mlp_fwd_kernel(ArtMlpArgs args) {
         }
       }
     }
-    relu_tiles(H0);
-    init_bias(H1, sm + kA_BD + 0 * 128, h); dense_layer<ArtNet, kAChD1 + 0, 4, 4>(p, H0, H1); relu_tiles(H1);
-    init_bias(H0, sm + kA_BD + 1 * 128, h); dense_layer<ArtNet, kAChD1 + 4, 4, 4>(p, H1, H0); relu_tiles(H0);
-    init_bias(H1, sm + kA_BD + 2 * 128, h); dense_layer<ArtNet, kAChD1 + 8, 4, 4>(p, H0, H1); relu_tiles(H1);
+    relu_tiles(H0); save(H0, aplane_d(0), 0);
+    init_bias(H1, sm + kA_BD + 0 * 128, h); dense_layer<ArtNet, kAChD1 + 0, 4, 4>(p, H0, H1); relu_tiles(H1); save(H1, aplane_d(1), 1);
+    init_bias(H0, sm + kA_BD + 1 * 128, h); dense_layer<ArtNet, kAChD1 + 4, 4, 4>(p, H1, H0); relu_tiles(H0); save(H0, aplane_d(2), 2);
+    init_bias(H1, sm + kA_BD + 2 * 128, h); dense_layer<ArtNet, kAChD1 + 8, 4, 4>(p, H0, H1); relu_tiles(H1); save(H1, aplane_d(3), 3);
     float xd[3];
 #pragma unroll
     for (int a = 0; a < 3; ++a) {  // x' = deformation_layer(h) + pos   (:205)
@@ -227,27 +227,32 @@ __global__ void __launch_bounds__(256) art_mlp_fwd_kernel(ArtMlpArgs args) {
     }
     f32x16 E[2];
     encode_pos(xd, h, E);  // pos_enc after the deformation (enc_after=True, :207-208)
+    if constexpr (TRAIN) {
+#pragma unroll
+      for (int a = 0; a < 3; ++a) save_row(kAPlPos + 3 + a, xd[a]);
+      store_pos_enc_plane(E, reinterpret_cast<float*>(reinterpret_cast<char*>(args.planes) + (int64_t)kAPlE * io.row_bytes), io, col, h);
+    }
 
     // ---- trunk (:212-217), shape latent folded into the biases of layers 0 and 5 ----
     f32x16 X[8], Y[8];
     init_bias(X, sm + kA_BT + 0 * 256, h);
     chunk_mma<ArtNet, kAChT0 + 0, 8, 16>(p, E[0], X);
     chunk_mma<ArtNet, kAChT0 + 1, 8, 16>(p, E[1], X);
-    relu_tiles(X);
-    init_bias(Y, sm + kA_BT + 1 * 256, h); dense_layer<ArtNet, kAChT1 + 0, 8, 8>(p, X, Y); relu_tiles(Y);
-    init_bias(X, sm + kA_BT + 2 * 256, h); dense_layer<ArtNet, kAChT1 + 8, 8, 8>(p, Y, X); relu_tiles(X);
-    init_bias(Y, sm + kA_BT + 3 * 256, h); dense_layer<ArtNet, kAChT1 + 16, 8, 8>(p, X, Y); relu_tiles(Y);
-    init_bias(X, sm + kA_BT + 4 * 256, h); dense_layer<ArtNet, kAChT1 + 24, 8, 8>(p, Y, X); relu_tiles(X);
+    relu_tiles(X); save(X, aplane_h(0), 4);
+    init_bias(Y, sm + kA_BT + 1 * 256, h); dense_layer<ArtNet, kAChT1 + 0, 8, 8>(p, X, Y); relu_tiles(Y); save(Y, aplane_h(1), 5);
+    init_bias(X, sm + kA_BT + 2 * 256, h); dense_layer<ArtNet, kAChT1 + 8, 8, 8>(p, Y, X); relu_tiles(X); save(X, aplane_h(2), 6);
+    init_bias(Y, sm + kA_BT + 3 * 256, h); dense_layer<ArtNet, kAChT1 + 16, 8, 8>(p, X, Y); relu_tiles(Y); save(Y, aplane_h(3), 7);
+    init_bias(X, sm + kA_BT + 4 * 256, h); dense_layer<ArtNet, kAChT1 + 24, 8, 8>(p, Y, X); relu_tiles(X); save(X, aplane_h(4), 8);
     init_bias(Y, sm + kA_BT + 5 * 256, h);
     dense_layer<ArtNet, kAChT5, 8, 8>(p, X, Y);
     chunk_mma<ArtNet, kAChT5 + 8, 8, 16>(p, E[0], Y);
     chunk_mma<ArtNet, kAChT5 + 9, 8, 16>(p, E[1], Y);
-    relu_tiles(Y);
-    init_bias(X, sm + kA_BT + 6 * 256, h); dense_layer<ArtNet, kAChT6, 8, 8>(p, Y, X); relu_tiles(X);
-    init_bias(Y, sm + kA_BT + 7 * 256, h); dense_layer<ArtNet, kAChT7, 8, 8>(p, X, Y); relu_tiles(Y);
+    relu_tiles(Y); save(Y, aplane_h(5), 9);
+    init_bias(X, sm + kA_BT + 6 * 256, h); dense_layer<ArtNet, kAChT6, 8, 8>(p, Y, X); relu_tiles(X); save(X, aplane_h(6), 10);
+    init_bias(Y, sm + kA_BT + 7 * 256, h); dense_layer<ArtNet, kAChT7, 8, 8>(p, X, Y); relu_tiles(Y); save(Y, aplane_h(7), 11);
     float sigma = head_partial<8>(Y, sm + kA_WSIG, h);  // density_layer (:219)
     sigma = sigma + __shfl_xor(sigma, 32) + sm[kA_BSIG];
-    init_bias(X, sm + kA_BBOT, h); dense_layer<ArtNet, kAChBott, 8, 8>(p, Y, X);  // bottleneck (:223)
+    init_bias(X, sm + kA_BBOT, h); dense_layer<ArtNet, kAChBott, 8, 8>(p, Y, X); save(X, kAPlBot);  // bottleneck (:223)
 
     // ---- view branch (:227-234): cat[bottleneck, viewenc, appearance] -> 4 x (128, ReLU) ----
     f32x16 Z0[4], Z1[4];
@@ -261,10 +266,10 @@ __global__ void __launch_bounds__(256) art_mlp_fwd_kernel(ArtMlpArgs args) {
     chunk_mma<ArtNet, kAChV0 + 6, 4, 16>(p, X[6], Z0);
     chunk_mma<ArtNet, kAChV0 + 7, 4, 16>(p, X[7], Z0);
     chunk_mma<ArtNet, kAChV0 + 8, 4, 14>(p, V, Z0);
-    relu_tiles(Z0);
-    init_bias(Z1, sm + kA_BV + 1 * 128, h); dense_layer<ArtNet, kAChV1 + 0, 4, 4>(p, Z0, Z1); relu_tiles(Z1);
-    init_bias(Z0, sm + kA_BV + 2 * 128, h); dense_layer<ArtNet, kAChV1 + 4, 4, 4>(p, Z1, Z0); relu_tiles(Z0);
-    init_bias(Z1, sm + kA_BV + 3 * 128, h); dense_layer<ArtNet, kAChV1 + 8, 4, 4>(p, Z0, Z1); relu_tiles(Z1);
+    relu_tiles(Z0); save(Z0, aplane_v(0), 12);
+    init_bias(Z1, sm + kA_BV + 1 * 128, h); dense_layer<ArtNet, kAChV1 + 0, 4, 4>(p, Z0, Z1); relu_tiles(Z1); save(Z1, aplane_v(1), 13);
+    init_bias(Z0, sm + kA_BV + 2 * 128, h); dense_layer<ArtNet, kAChV1 + 4, 4, 4>(p, Z1, Z0); relu_tiles(Z0); save(Z0, aplane_v(2), 14);
+    init_bias(Z1, sm + kA_BV + 3 * 128, h); dense_layer<ArtNet, kAChV1 + 8, 4, 4>(p, Z0, Z1); relu_tiles(Z1); save(Z1, aplane_v(3), 15);
     float rgb[3];
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) {  // rgb_layer (:236)
@@ -301,11 +306,11 @@ hipError_t launch_prepare_art(const float* const* params, const float* shape, co
 
 int num_cus();  // aon_mlp.hip
 
-template <bool POS>
+template <bool POS, bool TRAIN>
 static hipError_t launch_art_t(const ArtMlpArgs& args, hipStream_t stream) {
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&art_mlp_fwd_kernel<POS>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&art_mlp_fwd_kernel<POS, TRAIN>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, kALdsBytes);
     if (e != hipSuccess) return e;
     attr_set = true;
@@ -314,7 +319,7 @@ static hipError_t launch_art_t(const ArtMlpArgs& args, hipStream_t stream) {
   if (cus <= 0) return hipErrorInvalidDevice;
   const int grid = args.npass < cus ? args.npass : cus;
   if (grid <= 0) return hipSuccess;
-  art_mlp_fwd_kernel<POS><<<dim3(grid), dim3(256), kALdsBytes, stream>>>(args);
+  art_mlp_fwd_kernel<POS, TRAIN><<<dim3(grid), dim3(256), kALdsBytes, stream>>>(args);
   return hipGetLastError();
 }
 
@@ -324,7 +329,17 @@ hipError_t launch_art_mlp_fwd(const char* packed, const float* small, const floa
   ArtMlpArgs a{};
   a.packed = packed; a.small = small; a.rays_o = rays_o; a.rays_d = rays_d; a.viewdirs = viewdirs; a.t_vals = t_vals;
   a.raw = raw; a.total = n_rays * S; a.S = S; a.npass = (int)((a.total + 127) / 128);
-  return launch_art_t<true>(a, stream);
+  return launch_art_t<true, false>(a, stream);
+}
+
+hipError_t launch_art_mlp_fwd_train(const char* packed, const float* small, const float* rays_o, const float* rays_d,
+                                    const float* viewdirs, const float* t_vals, int64_t n_rays, int S, float* raw, float* planes,
+                                    void* masks, hipStream_t stream) {
+  ArtMlpArgs a{};
+  a.packed = packed; a.small = small; a.rays_o = rays_o; a.rays_d = rays_d; a.viewdirs = viewdirs; a.t_vals = t_vals;
+  a.raw = raw; a.total = n_rays * S; a.S = S; a.npass = (int)((a.total + 127) / 128);
+  a.planes = planes; a.masks = static_cast<u32x4*>(masks); a.Np = (int64_t)a.npass * 128;
+  return launch_art_t<true, true>(a, stream);
 }
 
 hipError_t launch_art_mlp_fwd_pos(const char* packed, const float* small, const float* pos, const float* viewdirs_enc,
@@ -332,7 +347,7 @@ hipError_t launch_art_mlp_fwd_pos(const char* packed, const float* small, const 
   ArtMlpArgs a{};
   a.packed = packed; a.small = small; a.pos = pos; a.viewdirs_enc = viewdirs_enc;
   a.raw = raw; a.total = n_rays * S; a.S = S; a.npass = (int)((a.total + 127) / 128);
-  return launch_art_t<false>(a, stream);
+  return launch_art_t<false, false>(a, stream);
 }
 
 int64_t art_stream_bytes() { return kAStreamBytes; }

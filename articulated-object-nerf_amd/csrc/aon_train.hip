@@ -13,15 +13,9 @@
 //                          split across workgroups, each holding a full M x K accumulator block in registers, and a
 //                          deterministic second stage sums the per-workgroup partials (no atomics).
 //   head_wgrad_kernel      the 1- and 3-row head weights and all bias sums (row reductions of planes).
-#include "aon_mlp_core.h"
+#include "aon_wgrad.h"
 
 namespace aon {
-
-__device__ __forceinline__ float wsum64(float v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-  return v;
-}
 
 // ---------------------------------------------------------------------------------------------
 // composite backward   (helper.volumetric_rendering, helper.py:157-195, + the activations of model.py:186-187 /
@@ -281,176 +275,6 @@ __global__ void __launch_bounds__(256) mlp_bwd_chain_kernel(BwdArgs args) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// weight gradients
-// ---------------------------------------------------------------------------------------------
-// One workgroup: OUT[M x K] partial = A[M rows x n-range] . B[K rows x n-range]^T, M = 128*RT, K = 32*CT.
-// wave w owns rows [32*RT*w, 32*RT*(w+1)) x all K columns -> RT x CT accumulator tiles.
-constexpr int kWgLdsStride = 36;  // floats per 32-sample row in LDS (144 B: 16-byte aligned, conflict-free b128 reads)
-
-struct WgradArgs {
-  const float* A;  // dZ plane rows (row 0 of this block)
-  const float* B;  // activation plane rows
-  int64_t Np;
-  int nchunks;     // Np / 32
-  float* partial;  // [gridDim.x][M][K]
-  float* bias_partial;  // [gridDim.x][M] or null
-};
-
-template <int RT, int CT>
-__global__ void __launch_bounds__(256) wgrad_kernel(WgradArgs a) {
-  constexpr int M = 128 * RT, K = 32 * CT;
-  constexpr int ROWS = M + K;                   // rows staged per 32-sample step
-  constexpr int STAGE_FLOATS = ROWS * kWgLdsStride;
-  constexpr int LD4 = (ROWS * 8 + 255) / 256;   // float4 loads per thread per step
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  float* smem = reinterpret_cast<float*>(smem_raw);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int li = lane & 31, kh = lane >> 5;
-
-  // contiguous range of 32-sample steps for this workgroup
-  const int per = (a.nchunks + gridDim.x - 1) / gridDim.x;
-  const int c_begin = blockIdx.x * per;
-  const int c_end = c_begin + per < a.nchunks ? c_begin + per : a.nchunks;
-
-  f32x16 acc[RT][CT];
-#pragma unroll
-  for (int i = 0; i < RT; ++i)
-#pragma unroll
-    for (int j = 0; j < CT; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  float bsum[RT];
-#pragma unroll
-  for (int i = 0; i < RT; ++i) bsum[i] = 0.f;
-
-  f32x4 stage[LD4];
-  auto gload = [&](int chunk) {
-#pragma unroll
-    for (int i = 0; i < LD4; ++i) {
-      const int e = tid + 256 * i;  // (row, col4)
-      const int row = e >> 3, c4 = e & 7;
-      if (row < ROWS) {
-        const float* src = row < M ? a.A + (int64_t)row * a.Np : a.B + (int64_t)(row - M) * a.Np;
-        stage[i] = *reinterpret_cast<const f32x4*>(src + (int64_t)chunk * 32 + 4 * c4);
-      }
-    }
-  };
-  auto lstore = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < LD4; ++i) {
-      const int e = tid + 256 * i;
-      const int row = e >> 3, c4 = e & 7;
-      if (row < ROWS) *reinterpret_cast<f32x4*>(smem + buf * STAGE_FLOATS + row * kWgLdsStride + 4 * c4) = stage[i];
-    }
-  };
-
-  if (c_begin < c_end) {
-    gload(c_begin);
-    lstore(0);
-  }
-  __syncthreads();
-  for (int c = c_begin; c < c_end; ++c) {
-    const int buf = (c - c_begin) & 1;
-    if (c + 1 < c_end) gload(c + 1);  // global loads in flight under the MFMAs below
-    const float* sa = smem + buf * STAGE_FLOATS + (32 * RT * wave + li) * kWgLdsStride + 4 * kh;
-    const float* sb = smem + buf * STAGE_FLOATS + (M + li) * kWgLdsStride + 4 * kh;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      f32x4 af[RT], bf[CT];
-#pragma unroll
-      for (int i = 0; i < RT; ++i) {
-        af[i] = *reinterpret_cast<const f32x4*>(sa + i * 32 * kWgLdsStride + 8 * s);
-        bsum[i] += (af[i][0] + af[i][1]) + (af[i][2] + af[i][3]);
-      }
-#pragma unroll
-      for (int j = 0; j < CT; ++j) bf[j] = *reinterpret_cast<const f32x4*>(sb + j * 32 * kWgLdsStride + 8 * s);
-#pragma unroll
-      for (int cc = 0; cc < 4; ++cc)
-#pragma unroll
-        for (int i = 0; i < RT; ++i)
-#pragma unroll
-          for (int j = 0; j < CT; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][cc], bf[j][cc], acc[i][j], 0, 0, 0);
-    }
-    if (c + 1 < c_end) lstore(buf ^ 1);
-    __syncthreads();
-  }
-  // partial[wg][row][col]; accumulator layout: col = lane&31, row = (r&3) + 8(r>>2) + 4(lane>>5)
-  float* out = a.partial + (int64_t)blockIdx.x * M * K;
-#pragma unroll
-  for (int i = 0; i < RT; ++i)
-#pragma unroll
-    for (int j = 0; j < CT; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = 32 * (RT * wave + i) + (r & 3) + 8 * (r >> 2) + 4 * kh;
-        out[(int64_t)row * K + 32 * j + li] = acc[i][j][r];
-      }
-  if (a.bias_partial) {
-#pragma unroll
-    for (int i = 0; i < RT; ++i) {
-      const float v = bsum[i] + __shfl_xor(bsum[i], 32);
-      if (kh == 0) a.bias_partial[(int64_t)blockIdx.x * M + 32 * (RT * wave + i) + li] = v;
-    }
-  }
-}
-
-// out[row*ld + col_off + col] = sum_wg partial[wg][row][col]   for col < k_valid
-__global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int nparts, int M, int K, int k_valid, float* __restrict__ out,
-                                    int ld, int col_off) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= M * K) return;
-  const int row = idx / K, col = idx % K;
-  if (col >= k_valid) return;
-  float s = 0.f;
-  for (int p = 0; p < nparts; ++p) s += partial[(int64_t)p * M * K + idx];
-  out[(int64_t)row * ld + col_off + col] = s;
-}
-
-__global__ void bias_reduce_kernel(const float* __restrict__ partial, int nparts, int M, float* __restrict__ out) {
-  const int row = blockIdx.x * blockDim.x + threadIdx.x;
-  if (row >= M) return;
-  float s = 0.f;
-  for (int p = 0; p < nparts; ++p) s += partial[(int64_t)p * M + row];
-  out[row] = s;
-}
-
-// Heads: dW_sigma[k] = sum_n d_raw[n].w * H7[k][n];  dW_rgb[c][k] = sum_n d_raw[n][c] * HV[k][n];  d bias = sum_n d_raw[n]
-// grid = (rows, nseg); block reduces one plane row over one segment of samples -> partial[seg][row][4]
-__global__ void __launch_bounds__(256) head_wgrad_kernel(const float* __restrict__ plane, int64_t Np, const float* __restrict__ d_raw,
-                                                         int64_t seg_len, float* __restrict__ partial, int rows) {
-  const int row = blockIdx.x, seg = blockIdx.y;
-  const int64_t n0 = (int64_t)seg * seg_len;
-  const int64_t n1 = n0 + seg_len < Np ? n0 + seg_len : Np;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  for (int64_t n = n0 + threadIdx.x; n < n1; n += 256) {
-    const float x = plane ? plane[(int64_t)row * Np + n] : 1.0f;  // plane == null: bias sums
-    const float4 d = reinterpret_cast<const float4*>(d_raw)[n];
-    s0 = __builtin_fmaf(x, d.x, s0); s1 = __builtin_fmaf(x, d.y, s1); s2 = __builtin_fmaf(x, d.z, s2); s3 = __builtin_fmaf(x, d.w, s3);
-  }
-  __shared__ float red[4][4];
-  s0 = wsum64(s0); s1 = wsum64(s1); s2 = wsum64(s2); s3 = wsum64(s3);
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  if (lane == 0) { red[wv][0] = s0; red[wv][1] = s1; red[wv][2] = s2; red[wv][3] = s3; }
-  __syncthreads();
-  if (threadIdx.x < 4) {
-    const float v = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
-    partial[((int64_t)seg * rows + row) * 4 + threadIdx.x] = v;
-  }
-}
-
-// out[c*ld_out + row] (channel-major rows of a (C,rows) weight) = sum_seg partial[seg][row][chan_of(c)]
-__global__ void head_reduce_kernel(const float* __restrict__ partial, int nseg, int rows, int chan0, int nchan, float* __restrict__ out,
-                                   int ld_out) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= rows * nchan) return;
-  const int row = idx / nchan, c = idx % nchan;
-  float s = 0.f;
-  for (int p = 0; p < nseg; ++p) s += partial[((int64_t)p * rows + row) * 4 + chan0 + c];
-  out[(int64_t)c * ld_out + row] = s;
-}
-
-// ---------------------------------------------------------------------------------------------
 // host launchers
 // ---------------------------------------------------------------------------------------------
 int num_cus();  // aon_mlp.hip
@@ -484,35 +308,7 @@ hipError_t launch_mlp_bwd_chain(const char* packed_bwd, const char* packed_fwd, 
   return hipGetLastError();
 }
 
-template <int RT, int CT>
-static hipError_t run_wgrad(const float* A, const float* B, int64_t Np, int nparts, float* partial, float* bias_partial,
-                            float* out, int ld, int col_off, int k_valid, float* bias_out, hipStream_t stream) {
-  constexpr int M = 128 * RT, K = 32 * CT;
-  constexpr int lds = 2 * (M + K) * kWgLdsStride * 4;
-  static bool attr = false;
-  if (!attr) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<RT, CT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return e;
-    attr = true;
-  }
-  WgradArgs a{A, B, Np, (int)(Np / 32), partial, bias_out ? bias_partial : nullptr};
-  wgrad_kernel<RT, CT><<<dim3(nparts), dim3(256), lds, stream>>>(a);
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return e;
-  wgrad_reduce_kernel<<<dim3((M * K + 255) / 256), dim3(256), 0, stream>>>(partial, nparts, M, K, k_valid, out, ld, col_off);
-  e = hipGetLastError();
-  if (e != hipSuccess) return e;
-  if (bias_out) {
-    bias_reduce_kernel<<<dim3((M + 255) / 256), dim3(256), 0, stream>>>(bias_partial, nparts, M, bias_out);
-    e = hipGetLastError();
-  }
-  return e;
-}
-
-int64_t wgrad_workspace_bytes() {
-  // per-workgroup partial of the largest block (256 x 256) + bias partials + head partials, for up to 256 workgroups
-  return (int64_t)256 * (256 * 256 + 256) * 4 + (int64_t)256 * 257 * 4 * 4 + 4096;
-}
+int64_t wgrad_workspace_bytes() { return wgrad_workspace_bytes_impl(); }
 
 // grads: 24 device pointers in the parameter order of aon_pack_vanilla_mlp (each the full (out,in) / (out,) tensor), overwritten.
 hipError_t launch_vanilla_wgrad(const float* planes, const float* dplanes, const float* d_raw, int64_t Np, float* const* grads,
@@ -522,9 +318,10 @@ hipError_t launch_vanilla_wgrad(const float* planes, const float* dplanes, const
   const int nchunks = (int)(Np / 32);
   int nparts = nchunks < cus ? nchunks : cus;
   if (nparts > 256) nparts = 256;
-  float* partial = ws;
-  float* bias_partial = ws + (int64_t)256 * 256 * 256;
-  float* head_partial = bias_partial + (int64_t)256 * 256;
+  const WgradWs w = carve_wgrad_ws(ws);
+  float* partial = w.partial;
+  float* bias_partial = w.bias_partial;
+  float* head_partial = w.head_partial;
   auto P = [&](int row) { return planes + (int64_t)row * Np; };
   auto D = [&](int row) { return dplanes + (int64_t)row * Np; };
   hipError_t e;
@@ -549,10 +346,8 @@ hipError_t launch_vanilla_wgrad(const float* planes, const float* dplanes, const
   e = run_wgrad<1, 1>(D(kPlHV), P(kPlVE), Np, nparts, partial, bias_partial, grads[16], 256 + kViewEnc, 256, kViewEnc, nullptr, stream);
   if (e != hipSuccess) return e;
   // heads and their biases
-  int nseg = (int)((Np + 16383) / 16384);
-  if (nseg > 256) nseg = 256;
-  const int64_t seg_len = ((Np + nseg - 1) / nseg + 3) / 4 * 4;
-  nseg = (int)((Np + seg_len - 1) / seg_len);
+  int nseg; int64_t seg_len;
+  head_segments(Np, nseg, seg_len);
   head_wgrad_kernel<<<dim3(256, nseg), dim3(256), 0, stream>>>(P(plane_h(7)), Np, d_raw, seg_len, head_partial, 256);
   head_reduce_kernel<<<dim3(1), dim3(256), 0, stream>>>(head_partial, nseg, 256, 3, 1, grads[20], 256);   // density_layer.weight (1,256)
   head_wgrad_kernel<<<dim3(128, nseg), dim3(256), 0, stream>>>(P(kPlHV), Np, d_raw, seg_len, head_partial, 128);

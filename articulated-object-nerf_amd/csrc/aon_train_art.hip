@@ -1,0 +1,362 @@
+// Backward pass of the articulated network for gfx950 (SURVEY 8(a) R14 for R10/R11: what autograd does for
+// model_autodecoder.py:395-477 training_step).  Gradients reach the MLP parameters AND the three latents
+// (model_autodecoder.py:172-178), through the view branch, the trunk, the positional encoding of the deformed point
+// and the deformation MLP.
+//
+// Same scheme as aon_train.hip: one register-resident data-gradient chain kernel (transposed weight stream as MFMA A
+// operands, gradient tiles as B operands), pre-activation gradient planes, split-N weight-gradient GEMMs.  Specific:
+//   * d(pos-enc) = W0[:, :63]^T dZ0 + W5[:, 256:319]^T dZ5 is accumulated in two 32x32 tiles in the encoding's permuted
+//     register order, then pulled back through sin(2^l x' + phase): d/dx' = 2^l sin(2^l x' + phase + pi/2);
+//   * every latent is broadcast to all samples, so  dW[:, latent cols] = db (x) latent  and  d latent = W[:, cols]^T db:
+//     both come from the bias gradients, no per-sample work.
+#include "aon_art_common.h"
+#include "aon_wgrad.h"
+
+namespace aon {
+
+// ---- transposed chunk stream (execution order of the backward chain) ----
+constexpr int kABwV3 = 0;      // views_linear.3^T, .2^T, .1^T : 4 chunks each, 4 output tiles (16 KiB)
+constexpr int kABwV0 = 12;     // views_linear.0[:, :256]^T : 4 chunks, 8 output tiles (32 KiB)
+constexpr int kABwBott = 16;   // bottleneck^T : 8
+constexpr int kABwL7 = 24;     // pts_linears.7^T, .6^T : 8 each
+constexpr int kABwL5E = 40;    // pts_linears.5[:, 256:319]^T : 8 chunks, 2 output tiles (8 KiB)  -> d pos-enc
+constexpr int kABwL5 = 48;     // pts_linears.5[:, :256]^T, then .4 .3 .2 .1 : 8 each
+constexpr int kABwL0E = 88;    // pts_linears.0[:, :63]^T : 8 chunks, 2 output tiles              -> d pos-enc
+constexpr int kABwD3 = 96;     // deformations_linear.3^T, .2^T, .1^T : 4 chunks each, 4 output tiles
+constexpr int kABwNumChunks = 108;
+constexpr int kTinyChunkBytes = 2 * 4096;
+
+struct ArtBwdNet {
+  static constexpr int kNumChunks = kABwNumChunks;
+  static constexpr int chunk_bytes(int c) {
+    return (c < kABwV0 || c >= kABwD3) ? kSmallChunkBytes
+         : ((c >= kABwL5E && c < kABwL5) || (c >= kABwL0E && c < kABwD3)) ? kTinyChunkBytes : kBigChunkBytes;
+  }
+};
+__host__ __device__ constexpr int64_t abw_offset(int c) {
+  int64_t off = 0;
+  for (int i = 0; i < c; ++i) off += ArtBwdNet::chunk_bytes(i);
+  return off;
+}
+constexpr int64_t kABwStreamBytes = abw_offset(kABwNumChunks);
+
+struct ArtParams {
+  const float* p[kNumArtParams];
+};
+
+__global__ void pack_art_bwd_kernel(ArtParams a, float* __restrict__ packed) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= kABwStreamBytes / 4) return;
+  // locate the chunk (108 chunks: linear scan is fine for a pack kernel)
+  int c = 0;
+  int64_t base = 0;
+  while (c < kABwNumChunks - 1 && idx >= base + ArtBwdNet::chunk_bytes(c) / 4) { base += ArtBwdNet::chunk_bytes(c) / 4; ++c; }
+  const int r = (int)(idx - base);
+  const int nt = ArtBwdNet::chunk_bytes(c) / 4096;
+  const int cc = r & 3, lane = (r >> 2) & 63, rest = r >> 8;
+  const int tp = rest % nt, q = rest / nt;
+  const int h = lane >> 5, i = lane & 31;
+  const int jo = 8 * q + 4 * h + cc;   // forward-output feature inside the chunk's 32-wide j tile
+  const int f = 32 * tp + i;            // forward-input feature (row of W^T)
+  const float* W; int ld, j, col = f;
+  auto enc_col = [&]() {  // accumulator row i of tile tp -> encoding register rho of half h'
+    const int rr = (i & 3) + 4 * (i >> 3), hh = (i >> 2) & 1;
+    return posenc_col(tp, rr >> 2, rr & 3, hh);
+  };
+  if (c < kABwV0) { const int l = 3 - c / 4; W = a.p[26 + 2 * l]; ld = 128; j = 32 * (c % 4) + jo; }
+  else if (c < kABwBott) { W = a.p[26]; ld = 411; j = 32 * (c - kABwV0) + jo; }
+  else if (c < kABwL7) { W = a.p[34]; ld = 256; j = 32 * (c - kABwBott) + jo; }
+  else if (c < kABwL5E) { const int l = 7 - (c - kABwL7) / 8; W = a.p[10 + 2 * l]; ld = 256; j = 32 * ((c - kABwL7) % 8) + jo; }
+  else if (c < kABwL5) { W = a.p[20]; ld = 447; j = 32 * (c - kABwL5E) + jo; col = enc_col(); if (col >= 0) col += 256; }
+  else if (c < kABwL0E) {
+    const int l = 5 - (c - kABwL5) / 8;  // 5,4,3,2,1
+    W = a.p[10 + 2 * l]; ld = l == 5 ? 447 : 256; j = 32 * ((c - kABwL5) % 8) + jo;
+  }
+  else if (c < kABwD3) { W = a.p[10]; ld = 191; j = 32 * (c - kABwL0E) + jo; col = enc_col(); }
+  else { const int l = 3 - (c - kABwD3) / 4; W = a.p[2 * l]; ld = 128; j = 32 * ((c - kABwD3) % 4) + jo; }
+  packed[idx] = col >= 0 ? W[(int64_t)j * ld + col] : 0.f;
+}
+
+struct ArtBwdArgs {
+  const char* packed_bwd;
+  const float* small;     // forward per-call small block (head weights)
+  const float* d_raw;     // (Np,4)
+  const u32x4* masks;     // kAMaskLayers x (Np*2)
+  const float* planes;    // forward planes (only the deformed position rows 3..5 are read)
+  float* dplanes;         // gradient planes, art row map
+  float* dxp;             // (Np,4): d x' per sample (for deformation_layer's weight gradient)
+  int64_t Np;
+  int npass;
+};
+
+template <int NT>
+__device__ __forceinline__ void zero_tiles_a(f32x16 (&x)[NT]) {
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) x[t][r] = 0.f;
+}
+
+template <int NT>
+__device__ __forceinline__ void mask_store_a(f32x16 (&x)[NT], const u32x4 bits, float* dplane, const PlaneIO& io) {
+  apply_mask_bits(x, bits);
+  store_plane(x, dplane, io);
+}
+
+__global__ void __launch_bounds__(256) art_bwd_chain_kernel(ArtBwdArgs args) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* sm = reinterpret_cast<float*>(smem + kRingBytes);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int m = lane & 31, h = lane >> 5;
+  {
+    const f32x4* src = reinterpret_cast<const f32x4*>(args.small);
+    f32x4* dst = reinterpret_cast<f32x4*>(sm);
+    for (int i = tid; i < kASmallFloats / 4; i += 256) dst[i] = src[i];
+  }
+  Pipe p;
+  p.stream = args.packed_bwd; p.ring = smem;
+  p.voff = (unsigned)(wave * 1024 + lane * 16);
+  p.wave_off = wave * 1024; p.lane_off = lane * 16;
+  p.slot = 1; p.issue_off = 0;
+  issue_chunk<ArtBwdNet, 0>(p, 0);
+  __syncthreads();
+  using N = ArtBwdNet;
+
+  for (int pass = blockIdx.x; pass < args.npass; pass += gridDim.x) {
+    const int64_t col = (int64_t)pass * 128 + wave * 32 + m;
+    const PlaneIO io = make_plane_io(args.Np, col, h);
+    auto dp = [&](int row) { return reinterpret_cast<float*>(reinterpret_cast<char*>(args.dplanes) + (int64_t)row * io.row_bytes); };
+    u32x4 mk[kAMaskLayers];
+#pragma unroll
+    for (int l = 0; l < kAMaskLayers; ++l) mk[l] = args.masks[(int64_t)l * args.Np * 2 + (int64_t)pass * 256 + tid];
+    const float4 dr = reinterpret_cast<const float4*>(args.d_raw)[col];
+    float xd[3];  // deformed position x' (forward stored it in rows 3..5 of the position block)
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+      xd[a] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(args.planes) + (int64_t)(kAPlPos + 3 + a) * io.row_bytes + col * 4);
+
+    // ---- view branch, backwards (model_autodecoder.py:231-236) ----
+    f32x16 Z0[4], Z1[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        const int fo = 32 * t + 8 * gq + 4 * h;
+        const f32x4 w0 = *reinterpret_cast<const f32x4*>(sm + kA_WRGB + 0 * kCondWidth + fo);
+        const f32x4 w1 = *reinterpret_cast<const f32x4*>(sm + kA_WRGB + 1 * kCondWidth + fo);
+        const f32x4 w2 = *reinterpret_cast<const f32x4*>(sm + kA_WRGB + 2 * kCondWidth + fo);
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc)
+          Z1[t][4 * gq + cc] = __builtin_fmaf(w2[cc], dr.z, __builtin_fmaf(w1[cc], dr.y, w0[cc] * dr.x));
+      }
+    }
+    mask_store_a(Z1, mk[15], dp(aplane_v(3)), io);
+    zero_tiles_a(Z0); dense_layer<N, kABwV3 + 0, 4, 4>(p, Z1, Z0); mask_store_a(Z0, mk[14], dp(aplane_v(2)), io);
+    zero_tiles_a(Z1); dense_layer<N, kABwV3 + 4, 4, 4>(p, Z0, Z1); mask_store_a(Z1, mk[13], dp(aplane_v(1)), io);
+    zero_tiles_a(Z0); dense_layer<N, kABwV3 + 8, 4, 4>(p, Z1, Z0); mask_store_a(Z0, mk[12], dp(aplane_v(0)), io);
+    f32x16 X[8], Y[8];
+    zero_tiles_a(X);
+    chunk_mma<N, kABwV0 + 0, 8, 16>(p, Z0[0], X);
+    chunk_mma<N, kABwV0 + 1, 8, 16>(p, Z0[1], X);
+    chunk_mma<N, kABwV0 + 2, 8, 16>(p, Z0[2], X);
+    chunk_mma<N, kABwV0 + 3, 8, 16>(p, Z0[3], X);
+    store_plane(X, dp(kAPlBot), io);  // bottleneck: no activation
+    // ---- trunk ----
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        const f32x4 w = *reinterpret_cast<const f32x4*>(sm + kA_WSIG + 32 * t + 8 * gq + 4 * h);
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) Y[t][4 * gq + cc] = w[cc] * dr.w;
+      }
+    }
+    dense_layer<N, kABwBott, 8, 8>(p, X, Y); mask_store_a(Y, mk[11], dp(aplane_h(7)), io);
+    zero_tiles_a(X); dense_layer<N, kABwL7 + 0, 8, 8>(p, Y, X); mask_store_a(X, mk[10], dp(aplane_h(6)), io);
+    zero_tiles_a(Y); dense_layer<N, kABwL7 + 8, 8, 8>(p, X, Y); mask_store_a(Y, mk[9], dp(aplane_h(5)), io);
+    f32x16 dE[2];
+    zero_tiles_a(dE);
+    dense_layer<N, kABwL5E, 8, 2>(p, Y, dE);  // skip connection: d enc += W5[:, 256:319]^T dZ5
+    zero_tiles_a(X); dense_layer<N, kABwL5 + 0, 8, 8>(p, Y, X); mask_store_a(X, mk[8], dp(aplane_h(4)), io);
+    zero_tiles_a(Y); dense_layer<N, kABwL5 + 8, 8, 8>(p, X, Y); mask_store_a(Y, mk[7], dp(aplane_h(3)), io);
+    zero_tiles_a(X); dense_layer<N, kABwL5 + 16, 8, 8>(p, Y, X); mask_store_a(X, mk[6], dp(aplane_h(2)), io);
+    zero_tiles_a(Y); dense_layer<N, kABwL5 + 24, 8, 8>(p, X, Y); mask_store_a(Y, mk[5], dp(aplane_h(1)), io);
+    zero_tiles_a(X); dense_layer<N, kABwL5 + 32, 8, 8>(p, Y, X); mask_store_a(X, mk[4], dp(aplane_h(0)), io);
+    dense_layer<N, kABwL0E, 8, 2>(p, X, dE);  // d enc += W0[:, :63]^T dZ0
+
+    // ---- positional encoding, backwards (helper.py:136-140 on the deformed point) ----
+    const float phase = h ? AON_HALF_PI_F32 : 0.f;
+    float dx[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int rho = 0; rho < 30; ++rho) {
+      const float scale = (float)(1 << (rho / 3));
+      const float arg = __fadd_rn(__fmul_rn(xd[rho % 3], scale), phase);
+      const float c = cos_f32(arg);  // d/d(arg) sin(arg), at the forward's own (rounded) argument
+      dx[rho % 3] = __builtin_fmaf(scale * c, dE[rho >> 4][rho & 15], dx[rho % 3]);
+    }
+    if (h) dx[2] += dE[1][14]; else { dx[0] += dE[1][14]; dx[1] += dE[1][15]; }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) dx[a] = dx[a] + __shfl_xor(dx[a], 32);
+    if (h == 0) {
+      float4 o; o.x = dx[0]; o.y = dx[1]; o.z = dx[2]; o.w = 0.f;
+      reinterpret_cast<float4*>(args.dxp)[col] = o;
+    }
+
+    // ---- deformation MLP, backwards (x' = deformation_layer(h3) + pos, :200-205) ----
+    f32x16 (&H1)[4] = Z1;
+    f32x16 (&H0)[4] = Z0;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        const int fo = 32 * t + 8 * gq + 4 * h;
+        const f32x4 w0 = *reinterpret_cast<const f32x4*>(sm + kA_WDL + 0 * 128 + fo);
+        const f32x4 w1 = *reinterpret_cast<const f32x4*>(sm + kA_WDL + 1 * 128 + fo);
+        const f32x4 w2 = *reinterpret_cast<const f32x4*>(sm + kA_WDL + 2 * 128 + fo);
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc)
+          H1[t][4 * gq + cc] = __builtin_fmaf(w2[cc], dx[2], __builtin_fmaf(w1[cc], dx[1], w0[cc] * dx[0]));
+      }
+    }
+    mask_store_a(H1, mk[3], dp(aplane_d(3)), io);
+    zero_tiles_a(H0); dense_layer<N, kABwD3 + 0, 4, 4>(p, H1, H0); mask_store_a(H0, mk[2], dp(aplane_d(2)), io);
+    zero_tiles_a(H1); dense_layer<N, kABwD3 + 4, 4, 4>(p, H0, H1); mask_store_a(H1, mk[1], dp(aplane_d(1)), io);
+    zero_tiles_a(H0); dense_layer<N, kABwD3 + 8, 4, 4>(p, H1, H0); mask_store_a(H0, mk[0], dp(aplane_d(0)), io);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// dW[f][col_off + k] = db[f] * latent[k]
+__global__ void outer_kernel(const float* __restrict__ db, const float* __restrict__ latent, int M, int L, float* __restrict__ out,
+                             int ld, int col_off) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= M * L) return;
+  const int f = idx / L, k = idx % L;
+  out[(int64_t)f * ld + col_off + k] = db[f] * latent[k];
+}
+
+// d latent[k] = sum_f W[f][col_off + k] * db[f]   (accumulated over up to three (W, db) pairs)
+struct LatentGradArgs {
+  const float* W[3]; const float* db[3]; int ld[3]; int col_off[3]; int M[3];
+  int npairs; int L;
+  float* out;
+};
+__global__ void latent_grad_kernel(LatentGradArgs a) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= a.L) return;
+  float s = 0.f;
+  for (int pi = 0; pi < a.npairs; ++pi)
+    for (int f = 0; f < a.M[pi]; ++f) s = __builtin_fmaf(a.W[pi][(int64_t)f * a.ld[pi] + a.col_off[pi] + k], a.db[pi][f], s);
+  a.out[k] = s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// host launchers
+// ---------------------------------------------------------------------------------------------
+int num_cus();
+
+hipError_t launch_pack_art_bwd(const float* const* params, float* packed, hipStream_t stream) {
+  ArtParams a;
+  for (int i = 0; i < kNumArtParams; ++i) a.p[i] = params[i];
+  const int64_t n = kABwStreamBytes / 4;
+  pack_art_bwd_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream>>>(a, packed);
+  return hipGetLastError();
+}
+
+int64_t art_bwd_stream_bytes() { return kABwStreamBytes; }
+
+hipError_t launch_art_bwd_chain(const char* packed_bwd, const float* small, const float* d_raw, const void* masks, const float* planes,
+                                float* dplanes, float* dxp, int64_t Np, hipStream_t stream) {
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&art_bwd_chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       kALdsBytes);
+    if (e != hipSuccess) return e;
+    attr = true;
+  }
+  ArtBwdArgs a{packed_bwd, small, d_raw, static_cast<const u32x4*>(masks), planes, dplanes, dxp, Np, (int)(Np / 128)};
+  const int cus = num_cus();
+  if (cus <= 0) return hipErrorInvalidDevice;
+  const int grid = a.npass < cus ? a.npass : cus;
+  if (grid <= 0) return hipSuccess;
+  art_bwd_chain_kernel<<<dim3(grid), dim3(256), kALdsBytes, stream>>>(a);
+  return hipGetLastError();
+}
+
+// grads: 40 parameter gradients (order of aon_pack_art_mlp, full shapes) + 3 latent gradients (shape 128, appearance 128,
+// articulation 32); params / latents: the forward's inputs (needed for the latent-column products).
+hipError_t launch_art_wgrad(const float* planes, const float* dplanes, const float* d_raw, const float* dxp, int64_t Np,
+                            const float* const* params, const float* shape, const float* app, const float* art,
+                            float* const* grads, float* g_shape, float* g_app, float* g_art, float* ws, hipStream_t stream) {
+  const int cus = num_cus();
+  if (cus <= 0) return hipErrorInvalidDevice;
+  const int nchunks = (int)(Np / 32);
+  int nparts = nchunks < cus ? nchunks : cus;
+  if (nparts > 256) nparts = 256;
+  const WgradWs w = carve_wgrad_ws(ws);
+  auto P = [&](int row) { return planes + (int64_t)row * Np; };
+  auto D = [&](int row) { return dplanes + (int64_t)row * Np; };
+  hipError_t e;
+#define AON_TRY(x) do { e = (x); if (e != hipSuccess) return e; } while (0)
+  // deformation MLP (model_autodecoder.py:196-203): input of layer 0 = cat[pos(3), shape(128), articulation(32)]
+  AON_TRY((run_wgrad<1, 1>(D(aplane_d(0)), P(kAPlPos), Np, nparts, w.partial, w.bias_partial, grads[0], 163, 0, 3, grads[1], stream)));
+  for (int l = 1; l < 4; ++l)
+    AON_TRY((run_wgrad<1, 4>(D(aplane_d(l)), P(aplane_d(l - 1)), Np, nparts, w.partial, w.bias_partial, grads[2 * l], 128, 0, 128,
+                             grads[2 * l + 1], stream)));
+  // trunk (:210-217): layer 0 input cat[enc(63), shape(128)], layer 5 input cat[h(256), enc(63), shape(128)]
+  AON_TRY((run_wgrad<2, 2>(D(aplane_h(0)), P(kAPlE), Np, nparts, w.partial, w.bias_partial, grads[10], 191, 0, kPosEnc, grads[11], stream)));
+  for (int l = 1; l < 8; ++l) {
+    const int ld = l == 5 ? 447 : 256;
+    AON_TRY((run_wgrad<2, 8>(D(aplane_h(l)), P(aplane_h(l - 1)), Np, nparts, w.partial, w.bias_partial, grads[10 + 2 * l], ld, 0, 256,
+                             grads[11 + 2 * l], stream)));
+    if (l == 5)
+      AON_TRY((run_wgrad<2, 2>(D(aplane_h(5)), P(kAPlE), Np, nparts, w.partial, w.bias_partial, grads[20], ld, 256, kPosEnc, nullptr, stream)));
+  }
+  AON_TRY((run_wgrad<2, 8>(D(kAPlBot), P(aplane_h(7)), Np, nparts, w.partial, w.bias_partial, grads[34], 256, 0, 256, grads[35], stream)));
+  // view branch (:227-234): layer 0 input cat[bottleneck(256), viewenc(27), appearance(128)]
+  AON_TRY((run_wgrad<1, 8>(D(aplane_v(0)), P(kAPlBot), Np, nparts, w.partial, w.bias_partial, grads[26], 411, 0, 256, grads[27], stream)));
+  AON_TRY((run_wgrad<1, 1>(D(aplane_v(0)), P(kAPlVE), Np, nparts, w.partial, w.bias_partial, grads[26], 411, 256, kViewEnc, nullptr, stream)));
+  for (int l = 1; l < 4; ++l)
+    AON_TRY((run_wgrad<1, 4>(D(aplane_v(l)), P(aplane_v(l - 1)), Np, nparts, w.partial, w.bias_partial, grads[26 + 2 * l], 128, 0, 128,
+                             grads[27 + 2 * l], stream)));
+  // heads: density (H7 x d_raw.w), rgb (V3 x d_raw.xyz), deformation_layer (D3 x dx') and their biases
+  int nseg; int64_t seg_len;
+  head_segments(Np, nseg, seg_len);
+  head_wgrad_kernel<<<dim3(256, nseg), dim3(256), 0, stream>>>(P(aplane_h(7)), Np, d_raw, seg_len, w.head_partial, 256);
+  head_reduce_kernel<<<dim3(1), dim3(256), 0, stream>>>(w.head_partial, nseg, 256, 3, 1, grads[36], 256);
+  head_wgrad_kernel<<<dim3(128, nseg), dim3(256), 0, stream>>>(P(aplane_v(3)), Np, d_raw, seg_len, w.head_partial, 128);
+  head_reduce_kernel<<<dim3(2), dim3(256), 0, stream>>>(w.head_partial, nseg, 128, 0, 3, grads[38], 128);
+  head_wgrad_kernel<<<dim3(1, nseg), dim3(256), 0, stream>>>(nullptr, Np, d_raw, seg_len, w.head_partial, 1);
+  head_reduce_kernel<<<dim3(1), dim3(256), 0, stream>>>(w.head_partial, nseg, 1, 3, 1, grads[37], 1);
+  head_reduce_kernel<<<dim3(1), dim3(256), 0, stream>>>(w.head_partial, nseg, 1, 0, 3, grads[39], 1);
+  head_wgrad_kernel<<<dim3(128, nseg), dim3(256), 0, stream>>>(P(aplane_d(3)), Np, dxp, seg_len, w.head_partial, 128);
+  head_reduce_kernel<<<dim3(2), dim3(256), 0, stream>>>(w.head_partial, nseg, 128, 0, 3, grads[8], 128);
+  head_wgrad_kernel<<<dim3(1, nseg), dim3(256), 0, stream>>>(nullptr, Np, dxp, seg_len, w.head_partial, 1);
+  head_reduce_kernel<<<dim3(1), dim3(256), 0, stream>>>(w.head_partial, nseg, 1, 0, 3, grads[9], 1);
+  // latent columns of the weights: dW[:, latent cols] = db (x) latent
+  outer_kernel<<<dim3((128 * 128 + 255) / 256), dim3(256), 0, stream>>>(grads[1], shape, 128, 128, grads[0], 163, 3);
+  outer_kernel<<<dim3((128 * 32 + 255) / 256), dim3(256), 0, stream>>>(grads[1], art, 128, 32, grads[0], 163, 131);
+  outer_kernel<<<dim3((256 * 128 + 255) / 256), dim3(256), 0, stream>>>(grads[11], shape, 256, 128, grads[10], 191, 63);
+  outer_kernel<<<dim3((256 * 128 + 255) / 256), dim3(256), 0, stream>>>(grads[21], shape, 256, 128, grads[20], 447, 319);
+  outer_kernel<<<dim3((128 * 128 + 255) / 256), dim3(256), 0, stream>>>(grads[27], app, 128, 128, grads[26], 411, 283);
+  // latent gradients: d latent = W[:, latent cols]^T db
+  LatentGradArgs ls{};
+  ls.W[0] = params[0]; ls.db[0] = grads[1]; ls.ld[0] = 163; ls.col_off[0] = 3; ls.M[0] = 128;
+  ls.W[1] = params[10]; ls.db[1] = grads[11]; ls.ld[1] = 191; ls.col_off[1] = 63; ls.M[1] = 256;
+  ls.W[2] = params[20]; ls.db[2] = grads[21]; ls.ld[2] = 447; ls.col_off[2] = 319; ls.M[2] = 256;
+  ls.npairs = 3; ls.L = 128; ls.out = g_shape;
+  latent_grad_kernel<<<dim3(1), dim3(128), 0, stream>>>(ls);
+  LatentGradArgs la{};
+  la.W[0] = params[26]; la.db[0] = grads[27]; la.ld[0] = 411; la.col_off[0] = 283; la.M[0] = 128;
+  la.npairs = 1; la.L = 128; la.out = g_app;
+  latent_grad_kernel<<<dim3(1), dim3(128), 0, stream>>>(la);
+  LatentGradArgs lt{};
+  lt.W[0] = params[0]; lt.db[0] = grads[1]; lt.ld[0] = 163; lt.col_off[0] = 131; lt.M[0] = 128;
+  lt.npairs = 1; lt.L = 32; lt.out = g_art;
+  latent_grad_kernel<<<dim3(1), dim3(128), 0, stream>>>(lt);
+#undef AON_TRY
+  return hipGetLastError();
+}
+
+}  // namespace aon

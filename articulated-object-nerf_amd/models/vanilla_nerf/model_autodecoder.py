@@ -10,6 +10,7 @@ import torch.nn as nn
 import torch.nn.init as init
 
 from ... import ops
+from ...autograd import RenderArticulated
 
 
 class NeRFMLP(nn.Module):
@@ -52,7 +53,23 @@ class NeRFMLP(nn.Module):
             init.xavier_uniform_(m.weight)  # views_linear[0] keeps the default init, like the reference (:147-151)
         self._packed = None
         self._packed_key = None
+        self._packed_bwd = None
+        self._packed_bwd_key = None
         self._small = None
+
+    def packed_bwd(self) -> torch.Tensor:
+        params = dict(self.named_parameters())
+        key = tuple((p.data_ptr(), p._version, str(p.device)) for p in params.values())
+        if self._packed_bwd is None or key != self._packed_bwd_key:
+            dev = next(iter(params.values())).device
+            out = self._packed_bwd if (self._packed_bwd is not None and self._packed_bwd.device == dev) else None
+            self._packed_bwd = ops.pack_art_mlp_bwd(params, out=out)
+            self._packed_bwd_key = key
+        return self._packed_bwd
+
+    def ordered_params(self):
+        params = dict(self.named_parameters())
+        return [params[name] for name in ops.ART_PARAM_ORDER]
 
     def packed(self) -> torch.Tensor:
         params = dict(self.named_parameters())
@@ -101,11 +118,6 @@ class NeRF_AE_Art(nn.Module):
         self.fine_mlp = NeRFMLP(min_deg_point, max_deg_point, deg_view)
 
     def forward(self, rays, randomized, white_bkgd, near, far, latents, train=True, t_rand=None, u=None):
-        if torch.is_grad_enabled() and (any(p.requires_grad for p in self.parameters())
-                                        or any(getattr(v, "requires_grad", False) for v in latents.values())):
-            raise NotImplementedError(
-                "the HIP backward of the render path is not implemented yet: call under torch.no_grad(); there is "
-                "deliberately no eager-PyTorch fallback")
         rays_o = rays["rays_o"]
         n = rays_o.shape[0]
         if randomized:
@@ -115,6 +127,20 @@ class NeRF_AE_Art(nn.Module):
                 u = torch.rand((n, self.num_fine_samples), device=rays_o.device)
         else:
             t_rand, u = None, None
+        if torch.is_grad_enabled() and (any(p.requires_grad for p in self.parameters())
+                                        or any(getattr(v, "requires_grad", False) for v in latents.values())):
+            # training: HIP forward that keeps the activation planes + HIP backward (autograd.RenderArticulated);
+            # the per-call block must not alias the cached inference buffer (it is saved for backward)
+            mlps = [self.coarse_mlp, self.fine_mlp][: self.num_levels]
+            packs = []
+            for mlp in mlps:
+                small = ops.art_prepare(dict(mlp.named_parameters()), latents)
+                packs.append((mlp.packed(), small, mlp.packed_bwd()))
+            params = [p for mlp in mlps for p in mlp.ordered_params()]
+            flat = RenderArticulated.apply(rays_o, rays["rays_d"], rays["viewdirs"], float(near), float(far), bool(white_bkgd),
+                                           self.num_levels, t_rand, u, packs, latents["density"], latents["color"],
+                                           latents["articulation"], *params)
+            return [tuple(flat[3 * i: 3 * i + 3]) for i in range(self.num_levels)]
         two = self.num_levels == 2
         outs = ops.art_render_fwd(self.coarse_mlp.packed(), self.coarse_mlp.prepared(latents),
                                   self.fine_mlp.packed() if two else None, self.fine_mlp.prepared(latents) if two else None,

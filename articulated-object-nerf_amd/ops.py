@@ -482,6 +482,61 @@ def vanilla_wgrad(planes, dplanes, d_raw):
     return grads
 
 
+# ------------------------------------------------------------------ R14 training (articulated)
+def pack_art_mlp_bwd(params: dict, out: torch.Tensor | None = None) -> torch.Tensor:
+    tensors, arr = _art_param_array(params)
+    dev = tensors[0].device
+    if out is None:
+        out = torch.empty(int(lib.aon_art_bwd_packed_bytes()), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        check(lib.aon_pack_art_mlp_bwd(arr, _ptr(out), _stream()), "aon_pack_art_mlp_bwd")
+    return out
+
+
+def art_mlp_fwd_train(packed, small, rays_o, rays_d, viewdirs, t_vals):
+    o, d, v, t = _f32(rays_o, "rays_o"), _f32(rays_d, "rays_d"), _f32(viewdirs, "viewdirs"), _f32(t_vals, "t_vals")
+    n, S = t.shape
+    Np = padded_samples(n * S)
+    raw = torch.empty((n, S, 4), dtype=torch.float32, device=t.device)
+    planes = torch.empty((int(lib.aon_art_train_plane_rows()), Np), dtype=torch.float32, device=t.device)
+    masks = torch.empty(int(lib.aon_art_train_mask_bytes(Np)), dtype=torch.uint8, device=t.device)
+    with torch.cuda.device(t.device):
+        check(lib.aon_art_mlp_fwd_train(_ptr(packed), _ptr(small), _ptr(o), _ptr(d), _ptr(v), _ptr(t), n, S, _ptr(raw), _ptr(planes),
+                                        _ptr(masks), _stream()), "aon_art_mlp_fwd_train")
+    return raw, planes, masks
+
+
+def art_bwd_chain(packed_bwd, small, d_raw, masks, planes):
+    """-> (dplanes (rows, Np), dxp (Np,4) = dL/d deformed position)"""
+    dplanes = torch.empty(planes.shape, dtype=torch.float32, device=planes.device)
+    Np = planes.shape[1]
+    dxp = torch.empty((Np, 4), dtype=torch.float32, device=planes.device)
+    with torch.cuda.device(planes.device):
+        check(lib.aon_art_bwd_chain(_ptr(packed_bwd), _ptr(small), _ptr(d_raw), _ptr(masks), _ptr(planes), _ptr(dplanes), _ptr(dxp), Np,
+                                    _stream()), "aon_art_bwd_chain")
+    return dplanes, dxp
+
+
+def art_wgrad(planes, dplanes, d_raw, dxp, params: dict, latents: dict):
+    """-> (dict name -> parameter gradient, dict latent key -> gradient (flat))."""
+    dev = planes.device
+    key = str(dev)
+    need = int(lib.aon_wgrad_workspace_bytes())
+    if key not in _WG_WS or _WG_WS[key].numel() < need:
+        _WG_WS[key] = torch.empty(need, dtype=torch.uint8, device=dev)
+    ws = _WG_WS[key]
+    tensors, parr = _art_param_array(params)
+    shape, app, art = _latent(latents, "density", 128), _latent(latents, "color", 128), _latent(latents, "articulation", 32)
+    grads = {name: torch.empty(ART_PARAM_SHAPES[name], dtype=torch.float32, device=dev) for name in ART_PARAM_ORDER}
+    garr = (C.c_void_p * len(ART_PARAM_ORDER))(*[grads[n].data_ptr() for n in ART_PARAM_ORDER])
+    g_lat = {"density": torch.empty(128, device=dev), "color": torch.empty(128, device=dev), "articulation": torch.empty(32, device=dev)}
+    with torch.cuda.device(dev):
+        check(lib.aon_art_wgrad(_ptr(planes), _ptr(dplanes), _ptr(d_raw), _ptr(dxp), planes.shape[1], parr, _ptr(shape), _ptr(app),
+                                _ptr(art), garr, _ptr(g_lat["density"]), _ptr(g_lat["color"]), _ptr(g_lat["articulation"]), _ptr(ws),
+                                ws.numel(), _stream()), "aon_art_wgrad")
+    return grads, g_lat
+
+
 # ------------------------------------------------------------------ measurement aid
 def profile_begin() -> None:
     check(lib.aon_profile_begin(), "aon_profile_begin")

@@ -170,6 +170,25 @@ int aon_mlp_bwd_chain(const void* packed_bwd, const void* packed_fwd, const floa
 int aon_vanilla_wgrad(const float* planes, const float* dplanes, const float* d_raw, int64_t Np,
                       float* const* grads_host, void* workspace, int64_t workspace_bytes, void* stream);
 
+/* ---- R14 for the articulated network (training_step, model_autodecoder.py:395-477) ----
+ * Same four stages as the vanilla backward, on the articulated row map (aon_art_train_plane_rows() rows).  Gradients reach
+ * the 40 parameters AND the three latents.  aon_art_bwd_chain also writes dxp (Np,4) = dL/d(deformed position) per sample,
+ * consumed by aon_art_wgrad for deformation_layer's gradient.  aon_art_wgrad needs the forward's parameters and latents
+ * again: the latent columns of the weights get db (x) latent, the latents get W[:, latent cols]^T db. */
+int64_t aon_art_train_plane_rows(void);
+int64_t aon_art_train_mask_bytes(int64_t Np);
+int64_t aon_art_bwd_packed_bytes(void);
+int aon_pack_art_mlp_bwd(const float* const* params_host, void* packed_bwd, void* stream);
+int aon_art_mlp_fwd_train(const void* packed, const void* small, const float* rays_o, const float* rays_d,
+                          const float* viewdirs, const float* t_vals, int64_t n_rays, int S, float* raw, float* planes,
+                          void* masks, void* stream);
+int aon_art_bwd_chain(const void* packed_bwd, const void* small, const float* d_raw, const void* masks,
+                      const float* planes, float* dplanes, float* dxp, int64_t Np, void* stream);
+int aon_art_wgrad(const float* planes, const float* dplanes, const float* d_raw, const float* dxp, int64_t Np,
+                  const float* const* params_host, const float* shape, const float* appearance,
+                  const float* articulation, float* const* grads_host, float* g_shape, float* g_appearance,
+                  float* g_articulation, void* workspace, int64_t workspace_bytes, void* stream);
+
 /* ---- measurement aid (no reference counterpart) ----
  * Between aon_profile_begin() and aon_profile_end() every launch of the fused MLP kernel (the dominant kernel of
  * the path) made through aon_mlp_fwd / aon_render_fwd is bracketed by HIP events recorded on the launch stream.

@@ -125,8 +125,9 @@ def test_nerf_ae_art_forward(dev, golden, art_sd):
         a = model(rays, False, True, 2.0, 6.0, _lat(g, "train", dev))[1][0]
         b = model(rays, False, True, 2.0, 6.0, _lat(g, "test", dev))[1][0]
     assert (a - b).abs().max().item() > 1e-3
-    with pytest.raises(NotImplementedError):
-        model(rays, False, True, 2.0, 6.0, _lat(g, "train", dev))
+    # grad mode runs the HIP training path (tests/test_hip_training_art.py)
+    out = model(rays, False, True, 2.0, 6.0, _lat(g, "train", dev))
+    assert out[1][0].requires_grad
 
 
 def test_articulated_frame_320x240_properties(dev, art_sd):
