@@ -19,15 +19,30 @@ def main():
     ap.add_argument("--rays", type=int, default=2048)   # the reference's hard-coded per-GPU batch (model.py:426)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--articulated", action="store_true", help="NeRF_AE_Art + CodeLibraryArticulated (BASELINE config 5 per GPU)")
     args = ap.parse_args()
     import aon_amd.synthetic as syn
     from aon_amd import ops
     from aon_amd.models.vanilla_nerf.model import NeRF
 
     dev = torch.device("cuda:0")
-    model = NeRF().to(dev)
-    model.load_state_dict(syn.make_nerf_state_dict(seed=0, density_scale=30.0))
-    opt = torch.optim.Adam(model.parameters(), lr=5e-4, betas=(0.9, 0.999))
+    lib = None
+    if args.articulated:
+        import types
+
+        from aon_amd.models.code_library import CodeLibraryArticulated
+        from aon_amd.models.vanilla_nerf.model_autodecoder import NeRF_AE_Art
+
+        model = NeRF_AE_Art().to(dev)
+        model.load_state_dict(syn.make_art_state_dict(seed=0, density_scale=30.0))
+        lib = CodeLibraryArticulated(types.SimpleNamespace(N_max_objs=1, N_obj_code_length=128)).to(dev)
+        lib.load_state_dict(syn.make_code_library_state(seed=0, n_max_objs=1))
+        batch = {"instance_id": torch.tensor([0], device=dev), "articulation_id": torch.tensor([3], device=dev)}
+        opt = torch.optim.Adam(list(model.parameters()) + list(lib.parameters()), lr=5e-4, betas=(0.9, 0.999))
+    else:
+        model = NeRF().to(dev)
+        model.load_state_dict(syn.make_nerf_state_dict(seed=0, density_scale=30.0))
+        opt = torch.optim.Adam(model.parameters(), lr=5e-4, betas=(0.9, 0.999))
     H, W = 480, 640
     ro, vd = ops.raygen(syn.look_at_pose(), H, W, syn.focal_from_fovy(H), device=dev)
     g = torch.Generator(device=dev).manual_seed(0)
@@ -37,8 +52,14 @@ def main():
 
     def step():
         opt.zero_grad(set_to_none=True)
-        out = model(rays, True, True, syn.NEAR, syn.FAR)
-        loss = torch.mean((out[0][0] - target) ** 2) + torch.mean((out[1][0] - target) ** 2)
+        if lib is not None:
+            latents = lib(batch)
+            out = model(rays, True, True, syn.NEAR, syn.FAR, latents)
+            reg = sum(torch.mean(torch.norm(latents[k], dim=0)) for k in ("density", "color", "articulation"))
+        else:
+            out = model(rays, True, True, syn.NEAR, syn.FAR)
+            reg = 0.0
+        loss = torch.mean((out[0][0] - target) ** 2) + torch.mean((out[1][0] - target) ** 2) + 1e-4 * reg
         loss.backward()
         opt.step()
         return loss
@@ -51,8 +72,8 @@ def main():
         loss = step()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.steps
-    flop = args.rays * 258 * 1_186_816 * 3  # fwd + 2x bwd, reference-literal
-    print(json.dumps({"rays_per_step": args.rays, "ms_per_step": dt * 1e3, "rays_per_s": args.rays / dt,
+    flop = args.rays * 258 * (1_589_760 if args.articulated else 1_186_816) * 3  # fwd + 2x bwd, reference-literal
+    print(json.dumps({"model": "articulated" if args.articulated else "vanilla", "rays_per_step": args.rays, "ms_per_step": dt * 1e3, "rays_per_s": args.rays / dt,
                       "train_tflops_3x_fwd": flop / dt / 1e12, "loss": loss.item()}))
 
 
