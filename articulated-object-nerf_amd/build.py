@@ -19,7 +19,7 @@ SOURCES = ["aon_mlp.hip", "aon_mlp_art.hip", "aon_train.hip", "aon_train_art.hip
 HEADERS = [os.path.join(CSRC, "aon_common.h"), os.path.join(CSRC, "aon_mlp_core.h"), os.path.join(CSRC, "aon_wgrad.h"), os.path.join(CSRC, "aon_art_common.h"),
            os.path.join(os.path.dirname(PKG), "include", "aon_hip.h")]
 # -ffp-contract=off: the stage kernels reproduce the reference's un-fused mul/add sequences; FMAs are explicit.
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wall", "-Wno-unused-function"]
+FLAGS = (os.environ.get("AON_EXTRA_FLAGS", "").split()) + ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 
 def hipcc() -> str:

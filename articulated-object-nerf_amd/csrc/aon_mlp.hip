@@ -115,14 +115,7 @@ __global__ void __launch_bounds__(256) mlp_fwd_kernel(MlpArgs args) {
   }
 
   Pipe p;
-  p.stream = args.packed;
-  p.ring = smem;
-  p.voff = (unsigned)(wave * 1024 + lane * 16);
-  p.issue_off = 0;
-  p.wave_off = wave * 1024;
-  p.lane_off = lane * 16;
-  p.slot = 1;  // acquire<0> flips to 0
-  issue_chunk<VanillaNet, 0>(p, 0);
+  pipe_init<VanillaNet>(p, args.packed, smem, wave, lane);  // also publishes the small block just written to LDS
 
   for (int pass = blockIdx.x; pass < args.npass; pass += gridDim.x) {
     const int64_t g = (int64_t)pass * 128 + wave * 32 + m;

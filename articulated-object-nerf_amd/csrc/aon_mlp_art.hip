@@ -152,12 +152,7 @@ __global__ void __launch_bounds__(256) art_mlp_fwd_kernel(ArtMlpArgs args) {
     for (int i = tid; i < kASmallFloats / 4; i += 256) dst[i] = src[i];
   }
   Pipe p;
-  p.stream = args.packed; p.ring = smem;
-  p.voff = (unsigned)(wave * 1024 + lane * 16);
-  p.wave_off = wave * 1024; p.lane_off = lane * 16;
-  p.slot = 1; p.issue_off = 0;
-  issue_chunk<ArtNet, 0>(p, 0);
-  __syncthreads();  // small block visible before the VALU first layer reads it
+  pipe_init<ArtNet>(p, args.packed, smem, wave, lane);  // also publishes the small block just written to LDS
 
   for (int pass = blockIdx.x; pass < args.npass; pass += gridDim.x) {
     const int64_t g = (int64_t)pass * 128 + wave * 32 + m;

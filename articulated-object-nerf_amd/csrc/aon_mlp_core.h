@@ -5,7 +5,11 @@
 
 namespace aon {
 
-constexpr int kRingBytes = 2 * kBigChunkBytes;  // two 32 KiB LDS slots for the weight stream
+// Weight-stream pipeline: two 32 KiB LDS slots, one workgroup barrier per chunk at the chunk boundary.
+// (A three-slot variant with the barrier in the middle of each chunk and the first A fragment of the next chunk
+// prefetched across the boundary was built and measured in round 1: correct, but 0.85-0.87 of the fp32-matrix peak
+// against 0.91 for this one -- the mid-chunk barrier splits hipcc's MFMA/ds_read scheduling region -- so it was dropped.)
+constexpr int kRingBytes = 2 * kBigChunkBytes;
 
 struct Pipe {
   const char* stream;  // packed stream base (wave-uniform -> SGPR pair)
@@ -36,6 +40,18 @@ __device__ __forceinline__ void issue_chunk(Pipe& p, int slot) {
                                      (lds_void*)(dst + r * 4096), 16, 0, 0);
   }
   p.issue_off = (C == Net::kNumChunks - 1) ? 0u : off + (unsigned)Net::chunk_bytes(C);
+}
+
+// Kernel prologue: chunk 0 in flight (acquire<0> waits for it).  The caller's LDS writes (resident small vectors) are
+// published by the barrier inside.
+template <class Net>
+__device__ __forceinline__ void pipe_init(Pipe& p, const char* stream, char* ring, int wave, int lane) {
+  p.stream = stream; p.ring = ring;
+  p.voff = (unsigned)(wave * 1024 + lane * 16);
+  p.wave_off = wave * 1024; p.lane_off = lane * 16;
+  p.slot = 1; p.issue_off = 0;  // acquire<0> flips to slot 0
+  issue_chunk<Net, 0>(p, 0);
+  __syncthreads();
 }
 
 // Wait for chunk C (DMA issued one chunk earlier), release the other slot, start streaming chunk C+1.
@@ -82,6 +98,8 @@ __device__ __forceinline__ void init_bias(f32x16 (&acc)[NT_OUT], const float* sm
   }
 }
 
+// ReLU on accumulator tiles.  (An AGPR->AGPR variant -- v_accvgpr_read / v_max / v_accvgpr_write in one asm block with
+// "a" constraints, which frees ~75 arch VGPRs -- was measured in round 1: 0.875 of peak against 0.908 for this form.)
 template <int NT>
 __device__ __forceinline__ void relu_tiles(f32x16 (&x)[NT]) {
 #pragma unroll

@@ -211,12 +211,7 @@ __global__ void __launch_bounds__(256) mlp_bwd_chain_kernel(BwdArgs args) {
     for (int i = tid; i < kSmallFloats / 4; i += 256) dst[i] = src[i];
   }
   Pipe p;
-  p.stream = args.packed_bwd; p.ring = smem;
-  p.voff = (unsigned)(wave * 1024 + lane * 16);
-  p.wave_off = wave * 1024; p.lane_off = lane * 16;
-  p.slot = 1; p.issue_off = 0;
-  issue_chunk<BwdNet, 0>(p, 0);
-  __syncthreads();
+  pipe_init<BwdNet>(p, args.packed_bwd, smem, wave, lane);  // also publishes the small block just written to LDS
 
   for (int pass = blockIdx.x; pass < args.npass; pass += gridDim.x) {
     const int64_t col = (int64_t)pass * 128 + wave * 32 + m;

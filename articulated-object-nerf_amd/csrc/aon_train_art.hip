@@ -115,12 +115,7 @@ __global__ void __launch_bounds__(256) art_bwd_chain_kernel(ArtBwdArgs args) {
     for (int i = tid; i < kASmallFloats / 4; i += 256) dst[i] = src[i];
   }
   Pipe p;
-  p.stream = args.packed_bwd; p.ring = smem;
-  p.voff = (unsigned)(wave * 1024 + lane * 16);
-  p.wave_off = wave * 1024; p.lane_off = lane * 16;
-  p.slot = 1; p.issue_off = 0;
-  issue_chunk<ArtBwdNet, 0>(p, 0);
-  __syncthreads();
+  pipe_init<ArtBwdNet>(p, args.packed_bwd, smem, wave, lane);  // also publishes the small block just written to LDS
   using N = ArtBwdNet;
 
   for (int pass = blockIdx.x; pass < args.npass; pass += gridDim.x) {
