@@ -35,6 +35,10 @@ _SIGS = {
     "aon_mlp_fwd_enc": (_i, [_p, _p, _p, _l, _i, _p, _p]),
     "aon_composite": (_i, [_p, _i, _p, _i, _p, _p, _l, _i, _i, _i, _p, _p, _p, _p, _p]),
     "aon_sample_pdf": (_i, [_p, _p, _l, _p, _p, _l, _l, _p, _p, _p]),
+    "aon_bf16x3_packed_bytes": (_l, []),
+    "aon_pack_vanilla_mlp_bf16x3": (_i, [_p, _p, _p]),
+    "aon_mlp_fwd_bf16x3": (_i, [_p, _p, _p, _p, _p, _l, _i, _p, _p]),
+    "aon_render_fwd_bf16x3": (_i, [_p, _p, _p, _p, _p, _l, _f, _f, _i, _i, _p, _p, _l, _p, _p, _p, _p, _p, _p, _p, _l, _p]),
     "aon_art_packed_bytes": (_l, []),
     "aon_art_small_bytes": (_l, []),
     "aon_pack_art_mlp": (_i, [_p, _p, _p]),

@@ -24,6 +24,7 @@
 namespace aon {
 
 struct VanillaNet {
+  static constexpr int kSlotBytes = kBigChunkBytes;
   static constexpr int kNumChunks = aon::kNumChunks;
   static constexpr int chunk_bytes(int c) { return aon::chunk_bytes(c); }
 };

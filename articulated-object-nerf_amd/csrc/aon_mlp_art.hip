@@ -28,6 +28,7 @@ constexpr int kAChV1 = 89;    // views_linear.1..3 : 4 chunks each
 constexpr int kANumChunks = 101;
 
 struct ArtNet {
+  static constexpr int kSlotBytes = kBigChunkBytes;
   static constexpr int kNumChunks = kANumChunks;
   static constexpr int chunk_bytes(int c) { return (c < kAChT0 || c >= kAChV0) ? kSmallChunkBytes : kBigChunkBytes; }
   static constexpr int64_t chunk_offset(int c) {

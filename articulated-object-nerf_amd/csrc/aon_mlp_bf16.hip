@@ -1,0 +1,364 @@
+// Opt-in "bf16x3" engine of the fused vanilla NeRFMLP forward: fp32-equivalent arithmetic on the bf16 matrix pipe.
+//
+// CDNA4's fp32 MFMA runs at the fp32 VECTOR rate (157 TFLOP/s), 1/16 of the bf16 MFMA rate.  Here every fp32 operand
+// (weight or activation) is split EXACTLY into three bf16 limbs  x = hi + mid + lo  (hi = bf16(x), mid = bf16(x - hi),
+// lo = bf16(x - hi - mid); the residual is below 2^-26 |x| because each limb carries its own exponent), and a product
+// a*b is evaluated as the six limb products whose magnitude is >= 2^-18 |ab|:
+//      hi*hi + (hi*mid + mid*hi) + (mid*mid + hi*lo + lo*hi)            (dropped: mid*lo, lo*mid, lo*lo <= 2^-25 |ab|)
+// Each limb product is exact in fp32 (8 x 8 significant bits) and v_mfma_f32_32x32x16_bf16 accumulates in fp32, so the
+// result carries fp32-class error (the parity suite runs unchanged at the fp32 kernel's tolerances with this engine
+// selected).  Six bf16 MFMAs of 32 cycles replace eight fp32 MFMAs of 64 cycles per 16-deep k step: 2.67x less matrix
+// time.  The exact-fp32 kernel (aon_mlp.hip) stays the default; this engine is selected explicitly.
+//
+// Structure = aon_mlp.hip (transposed layers, accumulator layout == next layer's B layout, register-resident activations,
+// LDS-DMA weight chunks), with two differences: the previous layer's fp32 accumulator tile is (ReLU'd and) split into limb
+// fragments just before the chunk that consumes it, and a chunk carries three limb images of the weights (48 KiB).
+#include "aon_mlp_core.h"
+
+namespace aon {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+struct Bf16Net {
+  static constexpr int kNumChunks = aon::kNumChunks;
+  static constexpr int kSlotBytes = 8 * 6144;  // 48 KiB
+  // chunk = [k16 step s (2)][out tile][limb (3)][lane (64)][8 bf16]  ->  6 KiB per output tile
+  static constexpr int chunk_bytes(int c) { return (c < kNumBigChunks ? 8 : 4) * 6144; }
+};
+constexpr int64_t kBfStreamBytes = (int64_t)kNumBigChunks * 8 * 6144 + (int64_t)(kNumChunks - kNumBigChunks) * 4 * 6144;
+constexpr int kBfRingBytes = 2 * Bf16Net::kSlotBytes;
+constexpr int kBfLdsBytes = kBfRingBytes + (int)kSmallBytes;
+
+__device__ __forceinline__ unsigned cvt_pk_bf16(float lo_elem, float hi_elem) {
+  unsigned p;  // round-to-nearest-even, element 0 in the low half
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(p) : "v"(lo_elem), "v"(hi_elem));
+  return p;
+}
+__device__ __forceinline__ float bf16_lo_as_f32(unsigned p) { return __builtin_bit_cast(float, p << 16); }
+__device__ __forceinline__ float bf16_hi_as_f32(unsigned p) { return __builtin_bit_cast(float, p & 0xffff0000u); }
+
+// host+device scalar version for the pack kernel
+__device__ __forceinline__ unsigned short bf16_rne_bits(float x) {
+  unsigned u = __builtin_bit_cast(unsigned, x);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ float bf16_bits_to_f32(unsigned short b) { return __builtin_bit_cast(float, (unsigned)b << 16); }
+
+// ---------------------------------------------------------------------------------------------
+// packing: three limb images per chunk
+// ---------------------------------------------------------------------------------------------
+struct PackArgsB {
+  const float* p[kNumVanillaParams];
+};
+
+__global__ void pack_vanilla_bf16x3_kernel(PackArgsB a, char* __restrict__ packed) {
+  // one thread per (chunk, s, tp, lane): 8 weights -> 3 x 16 bytes
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  constexpr int64_t big_threads = (int64_t)kNumBigChunks * 2 * 8 * 64;
+  constexpr int64_t all_threads = big_threads + (int64_t)(kNumChunks - kNumBigChunks) * 2 * 4 * 64;
+  if (idx >= all_threads) {
+    // resident small vectors (fp32, identical to the fp32 engine's block)
+    const int64_t s = idx - all_threads;
+    if (s >= kSmallFloats) return;
+    float v = 0.f;
+    if (s < kSmBiasBott) v = a.p[2 * (s >> 8) + 1][s & 255];
+    else if (s < kSmBiasView) v = a.p[19][s - kSmBiasBott];
+    else if (s < kSmWSigma) v = a.p[17][s - kSmBiasView];
+    else if (s < kSmWRgb) v = a.p[20][s - kSmWSigma];
+    else if (s < kSmBSigma) v = a.p[22][s - kSmWRgb];
+    else if (s < kSmBRgb) v = a.p[21][0];
+    else if (s < kSmBRgb + 3) v = a.p[23][s - kSmBRgb];
+    reinterpret_cast<float*>(packed + kBfStreamBytes)[s] = v;
+    return;
+  }
+  int c, r, nt;
+  int64_t chunk_base;
+  if (idx < big_threads) { c = (int)(idx / (2 * 8 * 64)); r = (int)(idx % (2 * 8 * 64)); nt = 8; chunk_base = (int64_t)c * 8 * 6144; }
+  else {
+    const int64_t i2 = idx - big_threads;
+    c = kNumBigChunks + (int)(i2 / (2 * 4 * 64)); r = (int)(i2 % (2 * 4 * 64)); nt = 4;
+    chunk_base = (int64_t)kNumBigChunks * 8 * 6144 + (int64_t)(c - kNumBigChunks) * 4 * 6144;
+  }
+  const int lane = r & 63, tp = (r >> 6) % nt, s = (r >> 6) / nt;
+  const int h = lane >> 5, row = 32 * tp + (lane & 31);
+  const float* W; int ld, n_out = 256;
+  int kind, tile;  // kind 0: hidden columns 32*tile + feature, 1: pos-enc (+off), 2: view-enc (+off)
+  int off = 0;
+  if (c < kChL1) { W = a.p[0]; ld = kPosEnc; kind = 1; tile = c; }
+  else if (c < kChL5) { const int l = 1 + (c - kChL1) / 8; W = a.p[2 * l]; ld = 256; kind = 0; tile = (c - kChL1) % 8; }
+  else if (c < kChL5 + 8) { W = a.p[10]; ld = 256 + kPosEnc; kind = 0; tile = c - kChL5; }
+  else if (c < kChL6) { W = a.p[10]; ld = 256 + kPosEnc; kind = 1; tile = c - kChL5 - 8; off = 256; }
+  else if (c < kChL7) { W = a.p[12]; ld = 256; kind = 0; tile = c - kChL6; }
+  else if (c < kChBott) { W = a.p[14]; ld = 256; kind = 0; tile = c - kChL7; }
+  else if (c < kChView) { W = a.p[18]; ld = 256; kind = 0; tile = c - kChBott; }
+  else if (c < kChView + 8) { W = a.p[16]; ld = 256 + kViewEnc; n_out = kCondWidth; kind = 0; tile = c - kChView; }
+  else { W = a.p[16]; ld = 256 + kViewEnc; n_out = kCondWidth; kind = 2; tile = 0; off = 256; }
+  unsigned short hi[8], mid[8], lo[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int reg = 8 * s + j;  // accumulator register of the producing tile that supplies k-slot j of step s
+    int col;
+    if (kind == 0) col = 32 * tile + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+    else if (kind == 1) { col = posenc_col(tile, reg >> 2, reg & 3, h); if (col >= 0) col += off; }
+    else { col = viewenc_col(reg >> 2, reg & 3, h); if (col >= 0) col += off; }
+    const float w = (col >= 0 && row < n_out) ? W[(int64_t)row * ld + col] : 0.f;
+    hi[j] = bf16_rne_bits(w);
+    const float r1 = w - bf16_bits_to_f32(hi[j]);
+    mid[j] = bf16_rne_bits(r1);
+    lo[j] = bf16_rne_bits(r1 - bf16_bits_to_f32(mid[j]));
+  }
+  char* dst = packed + chunk_base + ((int64_t)(s * nt + tp) * 3) * 1024 + lane * 16;
+  auto put = [&](int limb, const unsigned short (&v)[8]) {
+    u32x4 o;
+    o[0] = v[0] | ((unsigned)v[1] << 16); o[1] = v[2] | ((unsigned)v[3] << 16);
+    o[2] = v[4] | ((unsigned)v[5] << 16); o[3] = v[6] | ((unsigned)v[7] << 16);
+    *reinterpret_cast<u32x4*>(dst + limb * 1024) = o;
+  };
+  put(0, hi); put(1, mid); put(2, lo);
+}
+
+// ---------------------------------------------------------------------------------------------
+// kernel
+// ---------------------------------------------------------------------------------------------
+struct LimbFrag {  // B operand of one k16 step of one 32-feature tile
+  u32x4 hi, mid, lo;
+};
+
+// (ReLU +) exact 3-limb split of registers 8s .. 8s+7 of an accumulator tile
+template <bool RELU>
+__device__ __forceinline__ LimbFrag split_step(const f32x16& t, int s8) {
+  LimbFrag f;
+#pragma unroll
+  for (int jp = 0; jp < 4; ++jp) {
+    float x0 = t[s8 + 2 * jp], x1 = t[s8 + 2 * jp + 1];
+    if (RELU) { x0 = __builtin_fmaxf(x0, 0.f); x1 = __builtin_fmaxf(x1, 0.f); }
+    const unsigned ph = cvt_pk_bf16(x0, x1);
+    const float r0 = x0 - bf16_lo_as_f32(ph), r1 = x1 - bf16_hi_as_f32(ph);
+    const unsigned pm = cvt_pk_bf16(r0, r1);
+    const float q0 = r0 - bf16_lo_as_f32(pm), q1 = r1 - bf16_hi_as_f32(pm);
+    f.hi[jp] = ph; f.mid[jp] = pm; f.lo[jp] = cvt_pk_bf16(q0, q1);
+  }
+  return f;
+}
+
+__device__ __forceinline__ f32x16 mfma_bf16(const u32x4 a, const u32x4 b, const f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// One (ReLU +) split of a register pair: the unit of VALU work interleaved between MFMA groups.
+template <bool RELU>
+__device__ __forceinline__ void split_pair(const f32x16& t, int pi /*0..7*/, LimbFrag (&f)[2]) {
+  const int s = pi >> 2, jp = pi & 3;
+  float x0 = t[8 * s + 2 * jp], x1 = t[8 * s + 2 * jp + 1];
+  if (RELU) {  // plain v_max_f32 (fmaxf would add a canonicalising v_max in front of the real one)
+    asm("v_max_f32 %0, 0, %1" : "=v"(x0) : "v"(x0));
+    asm("v_max_f32 %0, 0, %1" : "=v"(x1) : "v"(x1));
+  }
+  const unsigned ph = cvt_pk_bf16(x0, x1);
+  const float r0 = x0 - bf16_lo_as_f32(ph), r1 = x1 - bf16_hi_as_f32(ph);
+  const unsigned pm = cvt_pk_bf16(r0, r1);
+  const float q0 = r0 - bf16_lo_as_f32(pm), q1 = r1 - bf16_hi_as_f32(pm);
+  f[s].hi[jp] = ph; f[s].mid[jp] = pm; f[s].lo[jp] = cvt_pk_bf16(q0, q1);
+}
+
+// Consumes chunk C with the B fragments `b` of the current input tile; meanwhile splits `next` (the input tile of chunk
+// C+1) into `bn`, one register pair per MFMA group, so the VALU work rides in the shadow of the matrix pipe.
+template <int C, int NT_OUT, bool HAS_NEXT, bool RELU_NEXT>
+__device__ __forceinline__ void chunk_mma_bf16(Pipe& p, const LimbFrag (&b)[2], f32x16 (&out)[NT_OUT], const f32x16& next,
+                                               LimbFrag (&bn)[2]) {
+  static_assert(Bf16Net::chunk_bytes(C) == NT_OUT * 6144, "chunk/out-tile mismatch");
+  // acquire, with the first A fragments requested BEFORE the next chunk's DMA is issued: their LDS latency then overlaps
+  // the twelve DMA issues instead of following them
+  __syncthreads();
+  p.slot ^= 1;
+  const char* buf = p.ring + p.slot * Bf16Net::kSlotBytes + p.lane_off;
+  // (round-1 experiment: alternating two accumulators per group -- to dodge a dependent-accumulator latency -- measured
+  //  slower than this single-accumulator chain; the six limb products of one output tile are issued back to back.)
+  constexpr int NSTEP = 2 * NT_OUT;
+  u32x4 ah = *reinterpret_cast<const u32x4*>(buf);
+  u32x4 am = *reinterpret_cast<const u32x4*>(buf + 1024);
+  u32x4 al = *reinterpret_cast<const u32x4*>(buf + 2048);
+  issue_chunk<Bf16Net, (C + 1) % Bf16Net::kNumChunks>(p, p.slot ^ 1);
+#pragma unroll
+  for (int i = 0; i < NSTEP; ++i) {
+    const int s = i / NT_OUT, tp = i % NT_OUT;
+    u32x4 nh = ah, nm = am, nl = al;
+    if (i + 1 < NSTEP) {
+      nh = *reinterpret_cast<const u32x4*>(buf + (i + 1) * 3072);
+      nm = *reinterpret_cast<const u32x4*>(buf + (i + 1) * 3072 + 1024);
+      nl = *reinterpret_cast<const u32x4*>(buf + (i + 1) * 3072 + 2048);
+    }
+    f32x16 acc = out[tp];
+    acc = mfma_bf16(al, b[s].hi, acc);   // smallest terms first
+    acc = mfma_bf16(ah, b[s].lo, acc);
+    acc = mfma_bf16(am, b[s].mid, acc);
+    if (HAS_NEXT) {  // 8 pair-splits of the next input tile spread over the NSTEP groups
+      if (NSTEP == 16) { if ((i & 1) == 0) split_pair<RELU_NEXT>(next, i >> 1, bn); }
+      else split_pair<RELU_NEXT>(next, i, bn);
+    }
+    acc = mfma_bf16(am, b[s].hi, acc);
+    acc = mfma_bf16(ah, b[s].mid, acc);
+    acc = mfma_bf16(ah, b[s].hi, acc);
+    out[tp] = acc;
+    ah = nh; am = nm; al = nl;
+  }
+}
+
+template <bool RELU>
+__device__ __forceinline__ void split_tile(const f32x16& t, LimbFrag (&f)[2]) {
+#pragma unroll
+  for (int pi = 0; pi < 8; ++pi) split_pair<RELU>(t, pi, f);
+}
+
+// 256 -> NT_OUT*32 layer over eight input tiles; `tail` = the tile consumed by the chunk that follows this layer's last
+// chunk (next layer's first input, or an encoding tile), pre-split during the last chunk when HAS_TAIL.
+// On entry `cur` holds the fragments of in[0]; on exit it holds the fragments of `tail` (if HAS_TAIL).
+template <int CBASE, int NT_OUT, bool RELU_IN, bool HAS_TAIL, bool RELU_TAIL>
+__device__ __forceinline__ void layer8_bf16(Pipe& p, LimbFrag (&cur)[2], const f32x16 (&in)[8], f32x16 (&out)[NT_OUT], const f32x16& tail) {
+  LimbFrag nxt[2];
+#define AON_BF_STEP(T)                                                                   \
+  chunk_mma_bf16<CBASE + T, NT_OUT, true, RELU_IN>(p, cur, out, in[T + 1], nxt);         \
+  cur[0] = nxt[0]; cur[1] = nxt[1];
+  AON_BF_STEP(0) AON_BF_STEP(1) AON_BF_STEP(2) AON_BF_STEP(3) AON_BF_STEP(4) AON_BF_STEP(5) AON_BF_STEP(6)
+#undef AON_BF_STEP
+  chunk_mma_bf16<CBASE + 7, NT_OUT, HAS_TAIL, RELU_TAIL>(p, cur, out, tail, nxt);
+  if (HAS_TAIL) { cur[0] = nxt[0]; cur[1] = nxt[1]; }
+}
+
+// w . relu(x) over the features this lane holds
+template <int NT>
+__device__ __forceinline__ float head_partial_relu(const f32x16 (&x)[NT], const float* sm_w, int h) {
+  float acc = 0.f;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 w = *reinterpret_cast<const f32x4*>(sm_w + 32 * t + 8 * g + 4 * h);
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) {
+        float r;
+        asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x[t][4 * g + cc]));
+        acc = __builtin_fmaf(w[cc], r, acc);
+      }
+    }
+  }
+  return acc;
+}
+
+struct BfArgs {
+  const char* packed;
+  const float* rays_o; const float* rays_d; const float* viewdirs; const float* t_vals;
+  float* raw;
+  int64_t total; int S; int npass;
+};
+
+__global__ void __launch_bounds__(256) mlp_fwd_bf16x3_kernel(BfArgs args) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* sm = reinterpret_cast<float*>(smem + kBfRingBytes);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform: LDS-DMA bases stay scalar
+  const int m = lane & 31, h = lane >> 5;
+  {
+    const f32x4* src = reinterpret_cast<const f32x4*>(args.packed + kBfStreamBytes);
+    f32x4* dst = reinterpret_cast<f32x4*>(sm);
+    for (int i = tid; i < kSmallFloats / 4; i += 256) dst[i] = src[i];
+  }
+  Pipe p;
+  pipe_init<Bf16Net>(p, args.packed, smem, wave, lane);
+
+  for (int pass = blockIdx.x; pass < args.npass; pass += gridDim.x) {
+    const int64_t g = (int64_t)pass * 128 + wave * 32 + m;
+    const bool valid = g < args.total;
+    const int64_t gc = valid ? g : args.total - 1;
+    const int64_t ray = gc / args.S;
+    f32x16 E[2], V;
+    {
+      const float t = args.t_vals[gc];
+      float x[3], vd[3];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        x[a] = __fadd_rn(args.rays_o[ray * 3 + a], __fmul_rn(t, args.rays_d[ray * 3 + a]));
+        vd[a] = args.viewdirs[ray * 3 + a];
+      }
+      encode_pos(x, h, E);
+      encode_view(vd, h, V);
+    }
+    // X / Y hold PRE-activation outputs; the ReLU is applied when a tile is split into limbs for the next layer.
+    // `cur` always holds the limb fragments of the tile the next chunk consumes; each chunk pre-splits its successor's
+    // tile between its own MFMA groups.  A layer's first input tile depends on the previous layer's LAST chunk, so it
+    // is split at the layer boundary (the only exposed VALU work besides the bias initialisation).
+    f32x16 X[8], Y[8];
+    LimbFrag cur[2], nxt[2];
+    split_tile<false>(E[0], cur);
+    init_bias(X, sm + kSmBias + 0 * 256, h);
+    chunk_mma_bf16<kChL0 + 0, 8, true, false>(p, cur, X, E[1], nxt); cur[0] = nxt[0]; cur[1] = nxt[1];
+    chunk_mma_bf16<kChL0 + 1, 8, false, false>(p, cur, X, E[1], nxt);
+    split_tile<true>(X[0], cur); init_bias(Y, sm + kSmBias + 1 * 256, h); layer8_bf16<kChL1 + 0, 8, true, false, false>(p, cur, X, Y, X[0]);
+    split_tile<true>(Y[0], cur); init_bias(X, sm + kSmBias + 2 * 256, h); layer8_bf16<kChL1 + 8, 8, true, false, false>(p, cur, Y, X, Y[0]);
+    split_tile<true>(X[0], cur); init_bias(Y, sm + kSmBias + 3 * 256, h); layer8_bf16<kChL1 + 16, 8, true, false, false>(p, cur, X, Y, X[0]);
+    split_tile<true>(Y[0], cur); init_bias(X, sm + kSmBias + 4 * 256, h); layer8_bf16<kChL1 + 24, 8, true, false, false>(p, cur, Y, X, Y[0]);
+    // L5: cat[relu(h4) (8 tiles), enc (2 tiles)]
+    split_tile<true>(X[0], cur); init_bias(Y, sm + kSmBias + 5 * 256, h);
+    layer8_bf16<kChL5, 8, true, true, false>(p, cur, X, Y, E[0]);
+    chunk_mma_bf16<kChL5 + 8, 8, true, false>(p, cur, Y, E[1], nxt); cur[0] = nxt[0]; cur[1] = nxt[1];
+    chunk_mma_bf16<kChL5 + 9, 8, false, false>(p, cur, Y, E[1], nxt);
+    split_tile<true>(Y[0], cur); init_bias(X, sm + kSmBias + 6 * 256, h); layer8_bf16<kChL6, 8, true, false, false>(p, cur, Y, X, Y[0]);
+    split_tile<true>(X[0], cur); init_bias(Y, sm + kSmBias + 7 * 256, h); layer8_bf16<kChL7, 8, true, false, false>(p, cur, X, Y, X[0]);
+    float sigma = head_partial_relu<8>(Y, sm + kSmWSigma, h);  // density head on relu(layer 7)
+    sigma = sigma + __shfl_xor(sigma, 32) + sm[kSmBSigma];
+    // bottleneck: input relu(h7), output linear
+    split_tile<true>(Y[0], cur); init_bias(X, sm + kSmBiasBott, h); layer8_bf16<kChBott, 8, true, false, false>(p, cur, Y, X, Y[0]);
+    // view layer: cat[bottleneck (8 tiles, no activation), viewenc (1 tile)]
+    f32x16 Z[4];
+    split_tile<false>(X[0], cur); init_bias(Z, sm + kSmBiasView, h);
+    layer8_bf16<kChView, 4, false, true, false>(p, cur, X, Z, V);
+    chunk_mma_bf16<kChView + 8, 4, false, false>(p, cur, Z, V, nxt);
+    float rgb[3];
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+      float v = head_partial_relu<4>(Z, sm + kSmWRgb + ch * kCondWidth, h);
+      rgb[ch] = v + __shfl_xor(v, 32) + sm[kSmBRgb + ch];
+    }
+    if (valid && h == 0) {
+      f32x4 o; o[0] = rgb[0]; o[1] = rgb[1]; o[2] = rgb[2]; o[3] = sigma;
+      reinterpret_cast<f32x4*>(args.raw)[g] = o;
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// ---------------------------------------------------------------------------------------------
+// host launchers
+// ---------------------------------------------------------------------------------------------
+int num_cus();
+
+int64_t bf16x3_packed_bytes() { return kBfStreamBytes + kSmallBytes; }
+
+hipError_t launch_pack_vanilla_bf16x3(const float* const* params, char* packed, hipStream_t stream) {
+  PackArgsB a;
+  for (int i = 0; i < kNumVanillaParams; ++i) a.p[i] = params[i];
+  const int64_t n = (int64_t)kNumBigChunks * 2 * 8 * 64 + (int64_t)(kNumChunks - kNumBigChunks) * 2 * 4 * 64 + kSmallFloats;
+  pack_vanilla_bf16x3_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream>>>(a, packed);
+  return hipGetLastError();
+}
+
+hipError_t launch_mlp_fwd_bf16x3(const char* packed, const float* rays_o, const float* rays_d, const float* viewdirs,
+                                 const float* t_vals, int64_t n_rays, int S, float* raw, hipStream_t stream) {
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fwd_bf16x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       kBfLdsBytes);
+    if (e != hipSuccess) return e;
+    attr = true;
+  }
+  BfArgs a{packed, rays_o, rays_d, viewdirs, t_vals, raw, n_rays * S, S, (int)((n_rays * S + 127) / 128)};
+  const int cus = num_cus();
+  if (cus <= 0) return hipErrorInvalidDevice;
+  const int grid = a.npass < cus ? a.npass : cus;
+  if (grid <= 0) return hipSuccess;
+  mlp_fwd_bf16x3_kernel<<<dim3(grid), dim3(256), kBfLdsBytes, stream>>>(a);
+  return hipGetLastError();
+}
+
+}  // namespace aon

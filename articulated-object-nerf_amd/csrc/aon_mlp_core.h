@@ -33,7 +33,7 @@ __device__ __forceinline__ void issue_chunk(Pipe& p, int slot) {
   unsigned off = p.issue_off;
   asm volatile("" : "+s"(off));
   gbl_char* src = (gbl_char*)(p.stream + off);
-  char* dst = p.ring + slot * kBigChunkBytes + p.wave_off;  // wave-uniform; hardware adds lane*16
+  char* dst = p.ring + slot * Net::kSlotBytes + p.wave_off;  // wave-uniform; hardware adds lane*16
 #pragma unroll
   for (int r = 0; r < rounds; ++r) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + r * 4096 + p.voff),
@@ -69,7 +69,7 @@ __device__ __forceinline__ void chunk_mma(Pipe& p, const f32x16& in, f32x16 (&ou
   static_assert(Net::chunk_bytes(C) == NT_OUT * 4096, "chunk/out-tile mismatch");
   static_assert(NREG % 2 == 0 && NREG > 12, "register count");
   acquire<Net, C>(p);
-  const char* buf = p.ring + p.slot * kBigChunkBytes + p.lane_off;
+  const char* buf = p.ring + p.slot * Net::kSlotBytes + p.lane_off;
   constexpr int NQ = (NREG + 3) / 4;
   constexpr int NSTEP = NQ * NT_OUT;
   // (round-1 experiment: a distance-2 prefetch with the issue order pinned by sched_barrier(0) per step measured 0.900 of

@@ -71,6 +71,15 @@ class NeRFMLP(nn.Module):
         params = dict(self.named_parameters())
         return [params[name] for name in ops.VANILLA_PARAM_ORDER]
 
+    def packed_bf16x3(self) -> torch.Tensor:
+        """Three-limb bf16 weight stream of the opt-in split-bf16 engine."""
+        params = dict(self.named_parameters())
+        key = self._param_key(params)
+        if getattr(self, "_packed_bf", None) is None or key != self._packed_bf_key:
+            self._packed_bf = ops.pack_vanilla_mlp_bf16x3(params)
+            self._packed_bf_key = key
+        return self._packed_bf
+
     def packed(self) -> torch.Tensor:
         """The kernel-side weight stream; re-packed (one small HIP kernel) whenever a parameter was modified
         in place, replaced, or moved."""
@@ -110,6 +119,8 @@ class NeRF(nn.Module):
         self.sigma_activation = nn.ReLU()
         self.coarse_mlp = NeRFMLP(min_deg_point, max_deg_point, deg_view)
         self.fine_mlp = NeRFMLP(min_deg_point, max_deg_point, deg_view)
+        # inference engine: "fp32" = exact fp32 MFMA (default); "bf16x3" = fp32-equivalent split-bf16 (opt-in, 2x+ faster)
+        self.engine = "fp32"
 
     def forward(self, rays, randomized, white_bkgd, near, far, t_rand=None, u=None):
         rays_o = rays["rays_o"]
@@ -131,9 +142,16 @@ class NeRF(nn.Module):
             flat = RenderVanilla.apply(rays_o, rays["rays_d"], rays["viewdirs"], float(near), float(far), bool(white_bkgd),
                                        self.num_levels, t_rand, u, packs, *params)
             return [tuple(flat[3 * i: 3 * i + 3]) for i in range(self.num_levels)]
-        fine = self.fine_mlp.packed() if self.num_levels == 2 else None
-        outs = ops.render_fwd(self.coarse_mlp.packed(), fine, rays_o, rays["rays_d"], rays["viewdirs"], near, far,
-                              white_bkgd, self.num_levels, t_rand, u)
+        if self.engine == "bf16x3":
+            coarse = self.coarse_mlp.packed_bf16x3()
+            fine = self.fine_mlp.packed_bf16x3() if self.num_levels == 2 else None
+        elif self.engine == "fp32":
+            coarse = self.coarse_mlp.packed()
+            fine = self.fine_mlp.packed() if self.num_levels == 2 else None
+        else:
+            raise ValueError(f"unknown engine {self.engine!r}")
+        outs = ops.render_fwd(coarse, fine, rays_o, rays["rays_d"], rays["viewdirs"], near, far,
+                              white_bkgd, self.num_levels, t_rand, u, engine=self.engine)
         return [tuple(o) for o in outs]
 
 

@@ -149,6 +149,32 @@ def pack_vanilla_mlp(params: dict, out: torch.Tensor | None = None) -> torch.Ten
     return out
 
 
+def pack_vanilla_mlp_bf16x3(params: dict, out: torch.Tensor | None = None) -> torch.Tensor:
+    """Packed three-limb bf16 weight stream of the opt-in split-bf16 engine (re-pack when the parameters change)."""
+    tensors = []
+    for name in VANILLA_PARAM_ORDER:
+        t = _f32(params[name].detach(), name)
+        if tuple(t.shape) != VANILLA_PARAM_SHAPES[name]:
+            raise ValueError(f"{name}: shape {tuple(t.shape)} != {VANILLA_PARAM_SHAPES[name]}")
+        tensors.append(t)
+    dev = tensors[0].device
+    if out is None:
+        out = torch.empty(int(lib.aon_bf16x3_packed_bytes()), dtype=torch.uint8, device=dev)
+    arr = (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+    with torch.cuda.device(dev):
+        check(lib.aon_pack_vanilla_mlp_bf16x3(arr, _ptr(out), _stream()), "aon_pack_vanilla_mlp_bf16x3")
+    return out
+
+
+def mlp_fwd_bf16x3(packed, rays_o, rays_d, viewdirs, t_vals):
+    o, d, v, t = _f32(rays_o, "rays_o"), _f32(rays_d, "rays_d"), _f32(viewdirs, "viewdirs"), _f32(t_vals, "t_vals")
+    n, S = t.shape
+    raw = torch.empty((n, S, 4), dtype=torch.float32, device=t.device)
+    with torch.cuda.device(t.device):
+        check(lib.aon_mlp_fwd_bf16x3(_ptr(packed), _ptr(o), _ptr(d), _ptr(v), _ptr(t), n, S, _ptr(raw), _stream()), "aon_mlp_fwd_bf16x3")
+    return raw
+
+
 def mlp_fwd(packed, rays_o, rays_d, viewdirs, t_vals):
     """cast_rays + pos_enc + NeRFMLP.forward fused.  Returns raw (n,S,4) = (raw_rgb, raw_density)."""
     o, d, v, t = _f32(rays_o, "rays_o"), _f32(rays_d, "rays_d"), _f32(viewdirs, "viewdirs"), _f32(t_vals, "t_vals")
@@ -271,8 +297,10 @@ def _workspace(device, n_rays: int) -> torch.Tensor:
     return ws
 
 
-def render_fwd(packed_coarse, packed_fine, rays_o, rays_d, viewdirs, near, far, white_bkgd, num_levels=2, t_rand=None, u=None):
-    """NeRF.forward: returns [(rgb, acc, depth)_coarse, (rgb, acc, depth)_fine] (fine omitted if num_levels == 1)."""
+def render_fwd(packed_coarse, packed_fine, rays_o, rays_d, viewdirs, near, far, white_bkgd, num_levels=2, t_rand=None, u=None,
+               engine: str = "fp32"):
+    """NeRF.forward: returns [(rgb, acc, depth)_coarse, (rgb, acc, depth)_fine] (fine omitted if num_levels == 1).
+    engine "fp32" (exact fp32 MFMA, default) or "bf16x3" (split-bf16, packed streams from pack_vanilla_mlp_bf16x3)."""
     o, d, v = _f32(rays_o, "rays_o"), _f32(rays_d, "rays_d"), _f32(viewdirs, "viewdirs")
     n, dev = o.shape[0], o.device
     tr = None if t_rand is None else _f32(t_rand, "t_rand")
@@ -285,8 +313,9 @@ def render_fwd(packed_coarse, packed_fine, rays_o, rays_d, viewdirs, near, far, 
                      torch.empty((n,), dtype=torch.float32, device=dev)))
     fine = outs[1] if num_levels == 2 else (None, None, None)
     ws = _workspace(dev, n)
+    fn = {"fp32": lib.aon_render_fwd, "bf16x3": lib.aon_render_fwd_bf16x3}[engine]
     with torch.cuda.device(dev):
-        check(lib.aon_render_fwd(_ptr(packed_coarse), _ptr(packed_fine), _ptr(o), _ptr(d), _ptr(v), n, float(near), float(far),
+        check(fn(_ptr(packed_coarse), _ptr(packed_fine), _ptr(o), _ptr(d), _ptr(v), n, float(near), float(far),
                                  int(bool(white_bkgd)), num_levels, _ptr(tr), _ptr(uu), us,
                                  _ptr(outs[0][0]), _ptr(outs[0][1]), _ptr(outs[0][2]), _ptr(fine[0]), _ptr(fine[1]), _ptr(fine[2]),
                                  _ptr(ws), ws.numel(), _stream()), "aon_render_fwd")

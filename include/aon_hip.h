@@ -117,6 +117,21 @@ int aon_render_fwd(const void* packed_coarse, const void* packed_fine, const flo
                    float* depth_c, float* rgb_f, float* acc_f, float* depth_f, void* workspace,
                    int64_t workspace_bytes, void* stream);
 
+/* ---- opt-in "bf16x3" engine for R5/R9 (no reference counterpart; same semantics as aon_mlp_fwd / aon_render_fwd) ----
+ * fp32-equivalent arithmetic on the bf16 matrix pipe: every fp32 weight / activation is split exactly into three bf16
+ * limbs and each product is evaluated as the six limb products >= 2^-18 of its magnitude, accumulated in fp32
+ * (csrc/aon_mlp_bf16.hip).  Needs its own packed stream (aon_bf16x3_packed_bytes()).  The exact-fp32 entry points
+ * above remain the default; callers select this engine explicitly. */
+int64_t aon_bf16x3_packed_bytes(void);
+int aon_pack_vanilla_mlp_bf16x3(const float* const* params_host, void* packed, void* stream);
+int aon_mlp_fwd_bf16x3(const void* packed, const float* rays_o, const float* rays_d, const float* viewdirs,
+                       const float* t_vals, int64_t n_rays, int S, float* raw, void* stream);
+int aon_render_fwd_bf16x3(const void* packed_coarse, const void* packed_fine, const float* rays_o, const float* rays_d,
+                          const float* viewdirs, int64_t n_rays, float near_, float far_, int white_bkgd, int num_levels,
+                          const float* t_rand, const float* u, int64_t u_stride, float* rgb_c, float* acc_c,
+                          float* depth_c, float* rgb_f, float* acc_f, float* depth_f, void* workspace,
+                          int64_t workspace_bytes, void* stream);
+
 /* ---- R10/R11  articulated network: NeRFMLP.forward(pos, condition, latents) (models/vanilla_nerf/
  * model_autodecoder.py:172-239, deformation_mlp=True, enc_after=True) and NeRF_AE_Art.forward (:278-337) ----
  * params: HOST array of 40 DEVICE pointers, order: deformations_linear.{0..3}.{weight,bias}, deformation_layer.{w,b},

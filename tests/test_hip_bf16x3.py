@@ -1,0 +1,79 @@
+"""GPU: the opt-in split-bf16 engine (csrc/aon_mlp_bf16.hip) is held to the SAME tolerances as the exact-fp32 kernel:
+it evaluates every fp32 product as six bf16 limb products accumulated in fp32, so its error against an fp64 evaluation of
+the network is of the fp32 kernel's class (measured: rgb max 2.3e-7 vs 2.6e-7)."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import nerf_oracle as orc  # noqa: E402  (checker only)
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return torch.device("cuda:0")
+
+
+def test_bf16x3_mlp_matches_oracle_at_fp32_tolerances(dev, nerf_sd):
+    import aon_amd.synthetic as syn
+    from aon_amd import ops
+
+    for lvl in ("coarse", "fine"):
+        params = {k[len(lvl) + 5:]: v.to(dev) for k, v in nerf_sd.items() if k.startswith(lvl + "_mlp.")}
+        p32, pbf = ops.pack_vanilla_mlp(params), ops.pack_vanilla_mlp_bf16x3(params)
+        for n, S, seed in ((1, 65, 1), (37, 65, 2), (50, 193, 3), (128, 1, 4)):
+            rays = syn.random_rays(n, seed=seed)
+            t = torch.sort(torch.rand(n, S, generator=torch.Generator().manual_seed(seed)) * 4 + 2, dim=-1).values
+            enc = orc.pos_enc(orc.cast_rays(t, rays["rays_o"], rays["rays_d"]), 0, 10)
+            venc = orc.pos_enc(rays["viewdirs"], 0, 4)
+            rgb_o, sig_o = orc.nerf_mlp(nerf_sd, f"{lvl}_mlp.", enc, venc)
+            args = [rays[k].to(dev) for k in ("rays_o", "rays_d", "viewdirs")] + [t.to(dev)]
+            raw = ops.mlp_fwd_bf16x3(pbf, *args).cpu()
+            torch.testing.assert_close(raw[..., :3], rgb_o, rtol=5e-5, atol=5e-5)      # = test_mlp_fused_encode_vs_oracle
+            torch.testing.assert_close(raw[..., 3:], sig_o, rtol=5e-5, atol=2e-3)
+            raw32 = ops.mlp_fwd(p32, *args).cpu()
+            torch.testing.assert_close(raw[..., :3], raw32[..., :3], rtol=0, atol=5e-6)  # the two engines agree far tighter
+    # against fp64: not worse than 1.5x the exact-fp32 kernel
+    n, S = 300, 193
+    rays = syn.random_rays(n, seed=9)
+    t = torch.sort(torch.rand(n, S, generator=torch.Generator().manual_seed(9)) * 4 + 2, dim=-1).values
+    enc = orc.pos_enc(orc.cast_rays(t, rays["rays_o"], rays["rays_d"]), 0, 10).double()
+    rgb64, _ = orc.nerf_mlp({k: v.double() for k, v in nerf_sd.items()}, "fine_mlp.", enc, orc.pos_enc(rays["viewdirs"], 0, 4).double())
+    args = [rays[k].to(dev) for k in ("rays_o", "rays_d", "viewdirs")] + [t.to(dev)]
+    e_bf = (ops.mlp_fwd_bf16x3(pbf, *args).cpu()[..., :3].double() - rgb64).abs()
+    e_32 = (ops.mlp_fwd(p32, *args).cpu()[..., :3].double() - rgb64).abs()
+    assert e_bf.max() <= 1.5 * e_32.max() + 1e-7 and e_bf.mean() <= 1.5 * e_32.mean() + 1e-8
+
+
+def test_bf16x3_render_end_to_end(dev, golden, nerf_sd):
+    from aon_amd.models.vanilla_nerf.model import NeRF
+
+    g = golden("g8_nerf_forward")
+    model = NeRF().to(dev)
+    model.load_state_dict(nerf_sd)
+    rays_cpu = {k: g[k] for k in ("rays_o", "rays_d", "viewdirs")}
+    rays = {k: v.to(dev) for k, v in rays_cpu.items()}
+    with torch.no_grad():
+        out32 = model(rays, False, True, g["near"], g["far"])
+        model.engine = "bf16x3"
+        out = model(rays, False, True, g["near"], g["far"])
+        part = model({k: v[40:100] for k, v in rays.items()}, False, True, g["near"], g["far"])
+    ref, aux = orc.nerf_forward(nerf_sd, rays_cpu, False, True, g["near"], g["far"], return_aux=True)
+    ok = torch.ones(rays_cpu["rays_o"].shape[0], dtype=torch.bool)
+    for a in aux:
+        ok &= a["raw_sigma"][:, -1, 0].abs() > 2e-2
+    for lvl in (0, 1):
+        rgb = out[lvl][0].cpu()
+        mse = torch.mean((rgb - ref[lvl][0]) ** 2).item()
+        assert -10.0 * math.log10(max(mse, 1e-20)) >= 70.0
+        torch.testing.assert_close(rgb[ok], ref[lvl][0][ok], rtol=0, atol=2e-4)          # = the fp32 engine's criterion
+        torch.testing.assert_close(rgb[ok], out32[lvl][0].cpu()[ok], rtol=0, atol=2e-4)
+        assert torch.equal(part[lvl][0], out[lvl][0][40:100])                              # chunk invariance
+    model.engine = "nope"
+    with pytest.raises(ValueError):
+        with torch.no_grad():
+            model(rays, False, True, 2.0, 6.0)
