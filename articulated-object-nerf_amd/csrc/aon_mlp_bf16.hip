@@ -27,7 +27,8 @@ struct Bf16Net {
 };
 constexpr int64_t kBfStreamBytes = (int64_t)kNumBigChunks * 8 * 6144 + (int64_t)(kNumChunks - kNumBigChunks) * 4 * 6144;
 constexpr int kBfRingBytes = 2 * Bf16Net::kSlotBytes;
-constexpr int kBfLdsBytes = kBfRingBytes + (int)kSmallBytes;
+constexpr int kBfEncStashBytes = 4 * 2 * 64 * 64;  // per wave: 2 encoding tiles x 64 lanes x 16 floats (parked in LDS between L0 and L5)
+constexpr int kBfLdsBytes = kBfRingBytes + (int)kSmallBytes + 16 /*pad to 16 B*/ + kBfEncStashBytes;
 
 __device__ __forceinline__ unsigned cvt_pk_bf16(float lo_elem, float hi_elem) {
   unsigned p;  // round-to-nearest-even, element 0 in the low half
@@ -162,6 +163,16 @@ __device__ __forceinline__ void split_pair(const f32x16& t, int pi /*0..7*/, Lim
   f[s].hi[jp] = ph; f[s].mid[jp] = pm; f[s].lo[jp] = cvt_pk_bf16(q0, q1);
 }
 
+// One 1-KiB-per-wave round of the LDS-DMA of chunk C (see issue_chunk): issued one per MFMA group so that the twelve
+// address-setup + issue sequences ride between MFMAs instead of forming a serial block at the chunk boundary.
+template <int C>
+__device__ __forceinline__ void issue_round(const Pipe& p, unsigned off, int slot, int r) {
+  gbl_char* src = (gbl_char*)(p.stream + off);
+  char* dst = p.ring + slot * Bf16Net::kSlotBytes + p.wave_off;
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + r * 4096 + p.voff),
+                                   (lds_void*)(dst + r * 4096), 16, 0, 0);
+}
+
 // Consumes chunk C with the B fragments `b` of the current input tile; meanwhile splits `next` (the input tile of chunk
 // C+1) into `bn`, one register pair per MFMA group, so the VALU work rides in the shadow of the matrix pipe.
 template <int C, int NT_OUT, bool HAS_NEXT, bool RELU_NEXT>
@@ -179,7 +190,11 @@ __device__ __forceinline__ void chunk_mma_bf16(Pipe& p, const LimbFrag (&b)[2], 
   u32x4 ah = *reinterpret_cast<const u32x4*>(buf);
   u32x4 am = *reinterpret_cast<const u32x4*>(buf + 1024);
   u32x4 al = *reinterpret_cast<const u32x4*>(buf + 2048);
-  issue_chunk<Bf16Net, (C + 1) % Bf16Net::kNumChunks>(p, p.slot ^ 1);
+  constexpr int CN = (C + 1) % Bf16Net::kNumChunks;           // chunk streamed in while this one is consumed
+  constexpr int ROUNDS = Bf16Net::chunk_bytes(CN) / 4096;     // 12 or 6
+  unsigned dma_off = p.issue_off;
+  asm volatile("" : "+s"(dma_off));
+  p.issue_off = (CN == Bf16Net::kNumChunks - 1) ? 0u : dma_off + (unsigned)Bf16Net::chunk_bytes(CN);
 #pragma unroll
   for (int i = 0; i < NSTEP; ++i) {
     const int s = i / NT_OUT, tp = i % NT_OUT;
@@ -189,14 +204,19 @@ __device__ __forceinline__ void chunk_mma_bf16(Pipe& p, const LimbFrag (&b)[2], 
       nm = *reinterpret_cast<const u32x4*>(buf + (i + 1) * 3072 + 1024);
       nl = *reinterpret_cast<const u32x4*>(buf + (i + 1) * 3072 + 2048);
     }
+    // keep the three reads of group i+1 ABOVE the six MFMAs of group i (hipcc otherwise sinks them next to their use and
+    // exposes the LDS latency once per group: a 32-cycle MFMA covers far less of it than the fp32 kernel's 64-cycle one)
+    __builtin_amdgcn_sched_barrier(0);
     f32x16 acc = out[tp];
     acc = mfma_bf16(al, b[s].hi, acc);   // smallest terms first
     acc = mfma_bf16(ah, b[s].lo, acc);
     acc = mfma_bf16(am, b[s].mid, acc);
-    if (HAS_NEXT) {  // 8 pair-splits of the next input tile spread over the NSTEP groups
-      if (NSTEP == 16) { if ((i & 1) == 0) split_pair<RELU_NEXT>(next, i >> 1, bn); }
-      else split_pair<RELU_NEXT>(next, i, bn);
+    if (HAS_NEXT) {  // the 8 pair-splits of the next input tile, one per group, finished by mid-chunk
+      if (i < 8) split_pair<RELU_NEXT>(next, i, bn);
     }
+    // DMA rounds of the next chunk, spread over the groups (all issued well before this chunk ends)
+    if (NSTEP >= ROUNDS) { if (i < ROUNDS) issue_round<CN>(p, dma_off, p.slot ^ 1, i); }
+    else { if (2 * i < ROUNDS) issue_round<CN>(p, dma_off, p.slot ^ 1, 2 * i); if (2 * i + 1 < ROUNDS) issue_round<CN>(p, dma_off, p.slot ^ 1, 2 * i + 1); }
     acc = mfma_bf16(am, b[s].hi, acc);
     acc = mfma_bf16(ah, b[s].mid, acc);
     acc = mfma_bf16(ah, b[s].hi, acc);
@@ -272,17 +292,36 @@ __global__ void __launch_bounds__(256) mlp_fwd_bf16x3_kernel(BfArgs args) {
     const bool valid = g < args.total;
     const int64_t gc = valid ? g : args.total - 1;
     const int64_t ray = gc / args.S;
-    f32x16 E[2], V;
+    // The 63-wide encoding is needed at layer 0 and again at the skip layer 5: it is parked in LDS (32 floats per lane)
+    // instead of occupying 32 VGPRs through layers 1-4; the view encoding is computed only when the view layer needs it.
+    float vd[3];
+    f32x4* stash = reinterpret_cast<f32x4*>(smem + kBfRingBytes + ((kSmallBytes + 15) / 16) * 16) + (wave * 2 * 64 + lane) * 4;
+    auto load_enc = [&](int tile) {
+      f32x16 e;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const f32x4 v4 = stash[tile * 64 * 4 + k];
+        e[4 * k] = v4[0]; e[4 * k + 1] = v4[1]; e[4 * k + 2] = v4[2]; e[4 * k + 3] = v4[3];
+      }
+      return e;
+    };
     {
       const float t = args.t_vals[gc];
-      float x[3], vd[3];
+      float x[3];
 #pragma unroll
       for (int a = 0; a < 3; ++a) {
         x[a] = __fadd_rn(args.rays_o[ray * 3 + a], __fmul_rn(t, args.rays_d[ray * 3 + a]));
         vd[a] = args.viewdirs[ray * 3 + a];
       }
+      f32x16 E[2];
       encode_pos(x, h, E);
-      encode_view(vd, h, V);
+#pragma unroll
+      for (int tile = 0; tile < 2; ++tile)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          f32x4 v4; v4[0] = E[tile][4 * k]; v4[1] = E[tile][4 * k + 1]; v4[2] = E[tile][4 * k + 2]; v4[3] = E[tile][4 * k + 3];
+          stash[tile * 64 * 4 + k] = v4;
+        }
     }
     // X / Y hold PRE-activation outputs; the ReLU is applied when a tile is split into limbs for the next layer.
     // `cur` always holds the limb fragments of the tile the next chunk consumes; each chunk pre-splits its successor's
@@ -290,19 +329,26 @@ __global__ void __launch_bounds__(256) mlp_fwd_bf16x3_kernel(BfArgs args) {
     // is split at the layer boundary (the only exposed VALU work besides the bias initialisation).
     f32x16 X[8], Y[8];
     LimbFrag cur[2], nxt[2];
-    split_tile<false>(E[0], cur);
-    init_bias(X, sm + kSmBias + 0 * 256, h);
-    chunk_mma_bf16<kChL0 + 0, 8, true, false>(p, cur, X, E[1], nxt); cur[0] = nxt[0]; cur[1] = nxt[1];
-    chunk_mma_bf16<kChL0 + 1, 8, false, false>(p, cur, X, E[1], nxt);
+    {
+      const f32x16 e0 = load_enc(0), e1 = load_enc(1);
+      split_tile<false>(e0, cur);
+      init_bias(X, sm + kSmBias + 0 * 256, h);
+      chunk_mma_bf16<kChL0 + 0, 8, true, false>(p, cur, X, e1, nxt); cur[0] = nxt[0]; cur[1] = nxt[1];
+      chunk_mma_bf16<kChL0 + 1, 8, false, false>(p, cur, X, e1, nxt);
+    }
     split_tile<true>(X[0], cur); init_bias(Y, sm + kSmBias + 1 * 256, h); layer8_bf16<kChL1 + 0, 8, true, false, false>(p, cur, X, Y, X[0]);
     split_tile<true>(Y[0], cur); init_bias(X, sm + kSmBias + 2 * 256, h); layer8_bf16<kChL1 + 8, 8, true, false, false>(p, cur, Y, X, Y[0]);
     split_tile<true>(X[0], cur); init_bias(Y, sm + kSmBias + 3 * 256, h); layer8_bf16<kChL1 + 16, 8, true, false, false>(p, cur, X, Y, X[0]);
     split_tile<true>(Y[0], cur); init_bias(X, sm + kSmBias + 4 * 256, h); layer8_bf16<kChL1 + 24, 8, true, false, false>(p, cur, Y, X, Y[0]);
     // L5: cat[relu(h4) (8 tiles), enc (2 tiles)]
     split_tile<true>(X[0], cur); init_bias(Y, sm + kSmBias + 5 * 256, h);
-    layer8_bf16<kChL5, 8, true, true, false>(p, cur, X, Y, E[0]);
-    chunk_mma_bf16<kChL5 + 8, 8, true, false>(p, cur, Y, E[1], nxt); cur[0] = nxt[0]; cur[1] = nxt[1];
-    chunk_mma_bf16<kChL5 + 9, 8, false, false>(p, cur, Y, E[1], nxt);
+    {
+      const f32x16 e0 = load_enc(0);
+      layer8_bf16<kChL5, 8, true, true, false>(p, cur, X, Y, e0);
+      const f32x16 e1 = load_enc(1);
+      chunk_mma_bf16<kChL5 + 8, 8, true, false>(p, cur, Y, e1, nxt); cur[0] = nxt[0]; cur[1] = nxt[1];
+      chunk_mma_bf16<kChL5 + 9, 8, false, false>(p, cur, Y, e1, nxt);
+    }
     split_tile<true>(Y[0], cur); init_bias(X, sm + kSmBias + 6 * 256, h); layer8_bf16<kChL6, 8, true, false, false>(p, cur, Y, X, Y[0]);
     split_tile<true>(X[0], cur); init_bias(Y, sm + kSmBias + 7 * 256, h); layer8_bf16<kChL7, 8, true, false, false>(p, cur, X, Y, X[0]);
     float sigma = head_partial_relu<8>(Y, sm + kSmWSigma, h);  // density head on relu(layer 7)
@@ -310,7 +356,8 @@ __global__ void __launch_bounds__(256) mlp_fwd_bf16x3_kernel(BfArgs args) {
     // bottleneck: input relu(h7), output linear
     split_tile<true>(Y[0], cur); init_bias(X, sm + kSmBiasBott, h); layer8_bf16<kChBott, 8, true, false, false>(p, cur, Y, X, Y[0]);
     // view layer: cat[bottleneck (8 tiles, no activation), viewenc (1 tile)]
-    f32x16 Z[4];
+    f32x16 Z[4], V;
+    encode_view(vd, h, V);
     split_tile<false>(X[0], cur); init_bias(Z, sm + kSmBiasView, h);
     layer8_bf16<kChView, 4, false, true, false>(p, cur, X, Z, V);
     chunk_mma_bf16<kChView + 8, 4, false, false>(p, cur, Z, V, nxt);
