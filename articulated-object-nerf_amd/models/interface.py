@@ -3,6 +3,7 @@ pytorch-lightning base class (Lightning is the reference's harness, not part of 
 from __future__ import annotations
 
 import math
+import os
 
 import torch
 import torch.distributed as dist
@@ -55,3 +56,76 @@ class LitModel(torch.nn.Module):
             ret.append(chunk.reshape(h, w, 3) if allv.dim() == 2 and allv.shape[-1] == 3 else chunk.reshape(h, w))
             curr += h * w
         return ret
+
+    @torch.no_grad()
+    def psnr(self, preds, gts, i_train=None, i_val=None, i_test=None):
+        """interface.py:127-140: {"name": "PSNR", "mean": m, "test": m} over per-image PSNRs."""
+        m = self.psnr_each(preds, gts).mean().item()
+        return {"name": "PSNR", "mean": m, "test": m}
+
+
+def get_obj_rgbs_from_segmap(all_segmap, all_pred_img, all_pred_target):
+    """models/utils.py:102-109: per image, the predicted / target colours of the pixels inside the instance mask."""
+    objs, tgts = [], []
+    for seg, pred, target in zip(all_segmap, all_pred_img, all_pred_target):
+        mask = seg.bool().unsqueeze(-1).expand(-1, -1, 3)
+        objs.append(pred[mask])
+        tgts.append(target[mask])
+    return objs, tgts
+
+
+class Harness(LitModel):
+    """What the two LightningModules of the reference share once Lightning is removed: the ``self.log`` sink, the
+    learning-rate rule of ``optimizer_step`` (model.py:391-419 == model_autodecoder.py:607-636) and the PSNR half of
+    ``test_epoch_end`` (model.py:450-485, model_autodecoder.py:665-701; SSIM / LPIPS need third-party networks and are
+    out of scope)."""
+
+    lr_init, lr_final, lr_delay_steps, lr_delay_mult = 5.0e-4, 5.0e-6, 2500, 0.01
+
+    def _init_harness(self, hparams, defaults):
+        from collections import defaultdict
+        from types import SimpleNamespace
+
+        hp = dict(defaults)
+        hp.update(vars(hparams) if hparams is not None and not isinstance(hparams, dict) else (hparams or {}))
+        self.hparams = SimpleNamespace(**hp)
+        self.logged = defaultdict(list)
+        self.global_step = 0
+
+    def log(self, name, value, **_):
+        self.logged[name].append(float(value))
+
+    def lr_at_step(self, step: int) -> float:
+        """log-linear decay lr_init -> lr_final over run_max_steps, times a sine warm-up over lr_delay_steps."""
+        if self.lr_delay_steps > 0:
+            delay = self.lr_delay_mult + (1 - self.lr_delay_mult) * math.sin(0.5 * math.pi * min(max(step / self.lr_delay_steps, 0), 1))
+        else:
+            delay = 1.0
+        t = min(max(step / self.hparams.run_max_steps, 0), 1)
+        return delay * math.exp(math.log(self.lr_init) * (1 - t) + math.log(self.lr_final) * t)
+
+    def optimizer_step(self, optimizer, closure=None):
+        for pg in optimizer.param_groups:
+            pg["lr"] = self.lr_at_step(self.global_step)
+        optimizer.step(closure=closure)
+        self.global_step += 1
+
+    @torch.no_grad()
+    def test_epoch_end(self, outputs, image_sizes, out_dir=None, name="image"):
+        """Gather the per-image test outputs over ranks, PSNR over whole images and over object pixels, and (rank 0,
+        when ``out_dir`` is given) the JPEG dump + results.json of the reference."""
+        from ..utils import store_image, write_stats
+
+        rgbs = self.alter_gather_cat(outputs, "rgb", image_sizes)
+        masks = self.alter_gather_cat(outputs, "instance_mask", image_sizes)
+        targets = self.alter_gather_cat(outputs, "target", image_sizes)
+        psnr = self.psnr(rgbs, targets)
+        objs, obj_targets = get_obj_rgbs_from_segmap(masks, rgbs, targets)
+        psnr_obj = self.psnr(objs, obj_targets)
+        psnr_obj["name"] = "PSNR_obj"
+        self.log("test/psnr", psnr["test"])
+        self.log("test/psnr_obj", psnr_obj["test"])
+        if out_dir is not None and (not dist.is_initialized() or dist.get_rank() == 0):
+            store_image(out_dir, rgbs, name)
+            write_stats(os.path.join(out_dir, "results.json"), psnr, psnr_obj)
+        return psnr, psnr_obj

@@ -163,10 +163,10 @@ from collections import defaultdict
 from types import SimpleNamespace
 
 from . import helper
-from ..interface import LitModel
+from ..interface import Harness
 
 
-class LitNeRF(LitModel):
+class LitNeRF(Harness):
     """``models/vanilla_nerf/model.py:202-419`` minus Lightning: same method names, batch contracts and return
     structures for ``training_step`` (:256-282), ``render_rays`` (:295-321, fine level only, chunked by ``hparams.chunk``,
     logs val/psnr), ``render_rays_test`` (:323-348), ``validation_step`` (:353-375), ``test_step`` (:377-384),
@@ -177,17 +177,10 @@ class LitNeRF(LitModel):
     def __init__(self, hparams=None, lr_init: float = 5.0e-4, lr_final: float = 5.0e-6, lr_delay_steps: int = 2500,
                  lr_delay_mult: float = 0.01, randomized: bool = True, near: float = 2.0, far: float = 6.0, white_bkgd: bool = True):
         super().__init__()
-        hp = dict(chunk=3840, run_max_steps=100000, img_wh=(640, 480))  # opt.py:103,112,17
-        hp.update(vars(hparams) if hparams is not None and not isinstance(hparams, dict) else (hparams or {}))
-        self.hparams = SimpleNamespace(**hp)
+        self._init_harness(hparams, dict(chunk=3840, run_max_steps=100000, img_wh=(640, 480)))  # opt.py:103,112,17
         self.lr_init, self.lr_final, self.lr_delay_steps, self.lr_delay_mult = lr_init, lr_final, lr_delay_steps, lr_delay_mult
         self.randomized, self.near, self.far, self.white_bkgd = randomized, near, far, white_bkgd
         self.model = NeRF()
-        self.logged = defaultdict(list)
-        self.global_step = 0
-
-    def log(self, name, value, **_):
-        self.logged[name].append(float(value))
 
     def training_step(self, batch, batch_idx):
         batch = {k: (v if k == "obj_idx" else v.squeeze(0)) for k, v in batch.items()}
@@ -234,18 +227,3 @@ class LitNeRF(LitModel):
 
     def configure_optimizers(self):
         return torch.optim.Adam(params=self.parameters(), lr=self.lr_init, betas=(0.9, 0.999))
-
-    def lr_at_step(self, step: int) -> float:
-        """model.py:402-414: log-linear decay lr_init -> lr_final over run_max_steps with a sine warm-up."""
-        if self.lr_delay_steps > 0:
-            delay = self.lr_delay_mult + (1 - self.lr_delay_mult) * math.sin(0.5 * math.pi * min(max(step / self.lr_delay_steps, 0), 1))
-        else:
-            delay = 1.0
-        t = min(max(step / self.hparams.run_max_steps, 0), 1)
-        return delay * math.exp(math.log(self.lr_init) * (1 - t) + math.log(self.lr_final) * t)
-
-    def optimizer_step(self, optimizer, closure=None):
-        for pg in optimizer.param_groups:
-            pg["lr"] = self.lr_at_step(self.global_step)
-        optimizer.step(closure=closure)
-        self.global_step += 1

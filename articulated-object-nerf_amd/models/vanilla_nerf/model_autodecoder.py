@@ -146,3 +146,93 @@ class NeRF_AE_Art(nn.Module):
                                   self.fine_mlp.packed() if two else None, self.fine_mlp.prepared(latents) if two else None,
                                   rays_o, rays["rays_d"], rays["viewdirs"], near, far, white_bkgd, self.num_levels, t_rand, u)
         return [tuple(o) for o in outs]
+
+
+# --------------------------------------------------------------------------------------------------------------------
+from collections import defaultdict  # noqa: E402
+
+from . import helper  # noqa: E402
+from ..code_library import CodeLibraryArticulated  # noqa: E402
+from ..interface import Harness  # noqa: E402
+
+_SCALAR_KEYS = ("deg", "instance_id", "articulation_id")
+
+
+class LitNeRF_AutoDecoder(Harness):
+    """``model_autodecoder.py:340-701`` minus Lightning: ``NeRF_AE_Art`` + ``CodeLibraryArticulated`` with the
+    reference's ``training_step`` (:393-477: mse(coarse)+mse(fine) + 1e-4 * latent-norm regulariser), ``render_rays``
+    (:479-513, fine level, chunked, logs val/psnr and the object-pixel PSNR), ``render_rays_test`` (:515-543),
+    ``validation_step`` (:548-586, wandb image grid dropped), ``test_step`` (:588-605, test-time interpolated
+    articulation codes), ``configure_optimizers`` (:607-609: one Adam over model + code library) and the
+    learning-rate rule (:611-640).  near / far / white_bkgd come from the dataset in the reference's ``setup``
+    (:359-391); ``setup(dataset)`` copies them the same way."""
+
+    def __init__(self, hparams=None, lr_init: float = 5.0e-4, lr_final: float = 5.0e-6, lr_delay_steps: int = 2500,
+                 lr_delay_mult: float = 0.01, randomized: bool = True, near: float = 2.0, far: float = 6.0, white_bkgd: bool = True):
+        super().__init__()
+        self._init_harness(hparams, dict(chunk=3840, run_max_steps=100000, img_wh=(320, 240), N_max_objs=1, N_obj_code_length=128))
+        self.lr_init, self.lr_final, self.lr_delay_steps, self.lr_delay_mult = lr_init, lr_final, lr_delay_steps, lr_delay_mult
+        self.randomized, self.near, self.far, self.white_bkgd = randomized, near, far, white_bkgd
+        self.model = NeRF_AE_Art()
+        self.code_library = CodeLibraryArticulated(self.hparams)
+
+    def setup(self, dataset):
+        self.near, self.far, self.white_bkgd = dataset.near, dataset.far, dataset.white_back
+
+    @staticmethod
+    def _unbatch(batch):
+        return {k: (v if k in _SCALAR_KEYS else v.squeeze(0)) for k, v in batch.items()}
+
+    def training_step(self, batch, batch_idx):
+        batch = self._unbatch(batch)
+        latents = self.code_library(batch)
+        rendered = self.model(batch, self.randomized, self.white_bkgd, self.near, self.far, latents)
+        target = batch["target"]
+        loss0 = helper.img2mse(rendered[0][0], target)
+        loss1 = helper.img2mse(rendered[1][0], target)
+        reg_loss = 1e-4 * (torch.mean(torch.norm(latents["density"], dim=0)) + torch.mean(torch.norm(latents["color"], dim=0))
+                           + torch.mean(torch.norm(latents["articulation"], dim=0)))
+        loss = loss1 + loss0 + reg_loss
+        self.log("train/psnr1", helper.mse2psnr(loss1.detach()))
+        self.log("train/psnr0", helper.mse2psnr(loss0.detach()))
+        self.log("train/loss", loss.detach())
+        self.log("train/loss/reg", reg_loss.detach())
+        return loss
+
+    def _render_chunks(self, batch, latents, skip=()):
+        B = batch["rays_o"].shape[0]
+        ret = defaultdict(list)
+        for i in range(0, B, self.hparams.chunk):
+            chunk = {k: v[i: i + self.hparams.chunk] for k, v in batch.items() if k not in skip and k not in _SCALAR_KEYS}
+            out = self.model(chunk, False, self.white_bkgd, self.near, self.far, latents)
+            ret["comp_rgb"] += [out[1][0]]
+            ret["acc"] += [out[1][1]]
+            ret["depth"] += [out[1][2]]
+        return {k: torch.cat(v, 0) for k, v in ret.items()}
+
+    @torch.no_grad()
+    def render_rays(self, batch, latents):
+        ret = self._render_chunks(batch, latents, skip=("img_wh", "src_imgs"))
+        self.log("val/psnr", self.psnr_legacy(ret["comp_rgb"], batch["target"]).mean().item())
+        mask = batch["instance_mask"].view(-1, 1).expand(-1, 3)
+        self.log("val/psnr_obj", self.psnr_legacy(ret["comp_rgb"][mask], batch["target"][mask]).mean().item())
+        return ret
+
+    @torch.no_grad()
+    def render_rays_test(self, batch, latents):
+        ret = self._render_chunks(batch, latents, skip=("img_wh", "src_imgs"))
+        return {"target": batch["target"], "instance_mask": batch["instance_mask"], "rgb": ret["comp_rgb"]}
+
+    @torch.no_grad()
+    def validation_step(self, batch, batch_idx):
+        batch = self._unbatch(batch)
+        return self.render_rays(batch, self.code_library(batch))
+
+    @torch.no_grad()
+    def test_step(self, batch, batch_idx):
+        batch = self._unbatch(batch)
+        return self.render_rays_test(batch, self.code_library(batch, is_test=True))
+
+    def configure_optimizers(self):
+        params = list(self.model.parameters()) + list(self.code_library.parameters())
+        return torch.optim.Adam(params=params, lr=self.lr_init, betas=(0.9, 0.999))

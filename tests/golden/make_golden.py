@@ -57,8 +57,36 @@ def _install_stubs():
     mod("torch_optimizer")
     mod("numba", jit=lambda *a, **k: (lambda f: f))
     tv = mod("torchvision")
-    tv.transforms = mod("torchvision.transforms", ToTensor=_Anything, Compose=_Anything, Resize=_Anything,
-                        Normalize=_Anything)
+
+    # torchvision.transforms pieces the articulated dataset calls (sapien_multi.py:144,209-213); published semantics
+    # restated: ToTensor = HWC uint8 PIL/ndarray -> CHW float32 / 255 (non-uint8 ndarrays keep dtype and values, a 2-D
+    # array gains a leading channel axis); Normalize = (x - mean) / std per channel; Compose = apply in order.
+    class ToTensor:
+        def __call__(self, pic):
+            arr = np.asarray(pic)
+            if arr.ndim == 2:
+                arr = arr[:, :, None]
+            t = torch.from_numpy(np.ascontiguousarray(arr.transpose(2, 0, 1)))
+            return t.to(torch.float32).div(255) if t.dtype == torch.uint8 else t
+
+    class Normalize:
+        def __init__(self, mean, std):
+            self.mean, self.std = torch.tensor(mean).view(-1, 1, 1), torch.tensor(std).view(-1, 1, 1)
+
+        def __call__(self, x):
+            return (x - self.mean) / self.std
+
+    class Compose:
+        def __init__(self, ts):
+            self.ts = ts
+
+        def __call__(self, x):
+            for t in self.ts:
+                x = t(x)
+            return x
+
+    tv.transforms = mod("torchvision.transforms", ToTensor=ToTensor, Compose=Compose, Resize=_Anything,
+                        Normalize=Normalize)
     tv.utils = mod("torchvision.utils", make_grid=_Anything, save_image=_Anything)
     tv.ops = mod("torchvision.ops")
     tv.models = mod("torchvision.models")
@@ -98,7 +126,12 @@ def patched_rand(values):
         torch.rand = orig
 
 
+ONLY = set()   # --only g9_backward,g14_sapien_multi : write just these files (the others keep their committed bytes)
+
+
 def save(name, **arrays):
+    if ONLY and name not in ONLY:
+        return
     out = {}
     for k, v in arrays.items():
         out[k] = v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)
@@ -285,6 +318,69 @@ def main():
             arrs[f"{tag}_{name}_depth"] = out[lvl][2]
     save("g11_nerf_ae_art", **arrs)
 
+
+    # ---------------- G9 backward (R14): the reference's own autograd ----------------
+    # 64 rays, deterministic sampling, loss = mse(coarse) + mse(fine) as in training_step (model.py:271-273).  Stored per
+    # parameter: float64 L2 norm and sum of the gradient plus 48 entries at seeded positions (the full gradients are
+    # 4.8 / 6.4 MB); articulated adds the regulariser-free latent gradients in full.
+    g9 = torch.Generator().manual_seed(99)
+    n_b = 64
+    rays_b = {k: v[:n_b].contiguous() for k, v in rays8.items()}
+    target_b = torch.rand((n_b, 3), generator=g9)
+    arrs = dict(seed=0, density_scale=30.0, near=2.0, far=6.0, target=target_b, **rays_b)
+
+    def grad_summary(prefix, named):
+        for name, p in named:
+            gflat = p.grad.detach().reshape(-1)
+            idx = torch.randint(0, gflat.numel(), (48,), generator=torch.Generator().manual_seed(len(name) * 7919 + gflat.numel()))
+            arrs[f"{prefix}|{name}|norm"] = gflat.double().norm()
+            arrs[f"{prefix}|{name}|sum"] = gflat.double().sum()
+            arrs[f"{prefix}|{name}|idx"] = idx
+            arrs[f"{prefix}|{name}|val"] = gflat[idx]
+
+    model.zero_grad()
+    out = model(rays_b, False, True, 2.0, 6.0)
+    loss = helper.img2mse(out[0][0], target_b) + helper.img2mse(out[1][0], target_b)
+    loss.backward()
+    arrs["vanilla_loss"] = loss.detach()
+    grad_summary("vanilla", model.named_parameters())
+    lat_b = {k: v.detach().clone().requires_grad_(True) for k, v in lat_train.items()}
+    amodel.zero_grad()
+    aout = amodel(rays_b, False, True, 2.0, 6.0, lat_b)
+    aloss = helper.img2mse(aout[0][0], target_b) + helper.img2mse(aout[1][0], target_b)
+    aloss.backward()
+    arrs["art_loss"] = aloss.detach()
+    grad_summary("art", amodel.named_parameters())
+    for k, v in lat_b.items():
+        arrs[f"art_latgrad_{k}"] = v.grad
+    save("g9_backward", **arrs)
+
+    # ---------------- G14 articulated dataset (R0): spheric test poses + SapienDatasetMulti items ----------------
+    import random
+    import tempfile
+    from datasets.sapien_multi import SapienDatasetMulti, create_spheric_poses
+    from aon_amd.datasets.sapien_multi import write_synthetic_multi_scene
+
+    arrs = dict(spheric_poses=create_spheric_poses(radius=4.0))
+    real_listdir = os.listdir
+    os.listdir = lambda p: sorted(real_listdir(p))     # the train split indexes an unsorted listdir (:257); fix the order
+    try:
+        with tempfile.TemporaryDirectory() as tmp:
+            root = write_synthetic_multi_scene(os.path.join(tmp, "multi"), n_instances=2, n_degrees=3, n_views=60, img_wh=(32, 24), seed=0)
+            for split, kw in (("train", {}), ("val", {}), ("test_val", {"eval_inference": "render"})):
+                ds = SapienDatasetMulti(root, split=split, img_wh=(32, 24), white_back=True, **kw)
+                random.seed(5); np.random.seed(6); torch.manual_seed(7)
+                item = ds[3]
+                arrs[f"{split}_len"] = len(ds)
+                for k, v in item.items():
+                    v = torch.as_tensor(np.asarray(v)) if not isinstance(v, torch.Tensor) else v
+                    arrs[f"{split}_{k}"] = v[:256] if (split == "train" and v.dim() >= 1 and v.shape[0] == 4096) else v
+                    if split == "train" and v.dim() >= 1 and v.shape[0] == 4096:
+                        arrs[f"{split}_{k}_sum"] = v.double().sum(0)
+    finally:
+        os.listdir = real_listdir
+    save("g14_sapien_multi", **arrs)
+
     # ---------------- G13 metrics ----------------
     a = torch.rand((5, 16, 16, 3), generator=g) * 1.2 - 0.1
     b = torch.rand((5, 16, 16, 3), generator=g)
@@ -294,4 +390,6 @@ def main():
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 2 and sys.argv[1] == "--only":
+        ONLY.update(sys.argv[2].split(","))
     main()

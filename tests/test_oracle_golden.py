@@ -128,3 +128,41 @@ def test_g11_articulated(golden):
             torch.testing.assert_close(out[lvl][0], g[f"{tag}_{name}_rgb"], rtol=0, atol=2e-6)
             torch.testing.assert_close(out[lvl][1], g[f"{tag}_{name}_acc"], rtol=0, atol=2e-6)
             torch.testing.assert_close(out[lvl][2], g[f"{tag}_{name}_depth"], rtol=0, atol=2e-5)
+
+
+def _check_grad_summary(g, prefix, grads, rtol):
+    names = sorted({k.split("|")[1] for k in g if isinstance(k, str) and k.startswith(prefix + "|")})
+    assert len(names) == len(grads), (len(names), len(grads))
+    for name in names:
+        gr = grads[name].reshape(-1)
+        ref_norm = g[f"{prefix}|{name}|norm"]
+        assert abs(gr.double().norm().item() - ref_norm) <= rtol * max(ref_norm, 1e-12), name
+        scale = ref_norm / max(gr.numel(), 1) ** 0.5
+        err = (gr[g[f"{prefix}|{name}|idx"]] - g[f"{prefix}|{name}|val"]).abs().max().item()
+        assert err <= rtol * max(g[f"{prefix}|{name}|val"].abs().max().item(), scale), (name, err)
+
+
+def test_g9_backward(golden, nerf_sd):
+    """R14: gradients of mse(coarse)+mse(fine) from the oracle's autograd equal the reference's own (same torch
+    kernels, same graph up to the searchsorted restatement of the inverse CDF, whose outputs are detached)."""
+    import aon_amd.synthetic as syn
+
+    g = golden("g9_backward")
+    rays = {k: g[k] for k in ("rays_o", "rays_d", "viewdirs")}
+    sd = {k: v.clone().requires_grad_(True) for k, v in nerf_sd.items()}
+    out = orc.nerf_forward(sd, rays, False, True, g["near"], g["far"])
+    loss = orc.img2mse(out[0][0], g["target"]) + orc.img2mse(out[1][0], g["target"])
+    loss.backward()
+    assert abs(loss.item() - g["vanilla_loss"]) <= 1e-6
+    _check_grad_summary(g, "vanilla", {k: v.grad for k, v in sd.items()}, rtol=2e-4)
+    asd = {k: v.clone().requires_grad_(True) for k, v in syn.make_art_state_dict(seed=0, density_scale=30.0).items()}
+    ga = golden("g11_nerf_ae_art")
+    lat = {k: ga[f"lat_train_{k}"].clone().requires_grad_(True) for k in ("density", "color", "articulation")}
+    out = orc.nerf_ae_art_forward(asd, rays, False, True, g["near"], g["far"], lat)
+    loss = orc.img2mse(out[0][0], g["target"]) + orc.img2mse(out[1][0], g["target"])
+    loss.backward()
+    assert abs(loss.item() - g["art_loss"]) <= 1e-6
+    _check_grad_summary(g, "art", {k: v.grad for k, v in asd.items()}, rtol=2e-3)
+    for k, v in lat.items():
+        ref = g[f"art_latgrad_{k}"]
+        assert (v.grad - ref).abs().max().item() <= 2e-3 * ref.abs().max().item(), k
