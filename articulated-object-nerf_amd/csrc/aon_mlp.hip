@@ -149,54 +149,49 @@ __global__ void __launch_bounds__(256) mlp_fwd_kernel(MlpArgs args) {
     const int64_t col = (int64_t)pass * 128 + wave * 32 + m;  // plane column of this lane's sample
     PlaneIO io{};
     if constexpr (TRAIN) io = make_plane_io(args.Np, col, h);
-    auto save = [&](auto& tiles, int row, int mask_layer = -1) {
-      if constexpr (TRAIN) {
-        store_plane(tiles, reinterpret_cast<float*>(reinterpret_cast<char*>(args.planes) + (int64_t)row * io.row_bytes), io);
-        if (mask_layer >= 0) args.masks[(int64_t)mask_layer * args.Np * 2 + (int64_t)pass * 256 + tid] = relu_mask_bits(tiles);
-      }
+    // [TRAIN] ReLU decisions now, activation planes later: every hidden activation is stored by the layer that consumes
+    // it (dense_layer<.., TRAIN>), one register per MFMA group, so no store burst sits in front of a chunk barrier.
+    auto mask = [&](auto& tiles, int mask_layer) {
+      if constexpr (TRAIN) args.masks[(int64_t)mask_layer * args.Np * 2 + (int64_t)pass * 256 + tid] = relu_mask_bits(tiles);
     };
+    auto rows = [&](int row) { return reinterpret_cast<float*>(reinterpret_cast<char*>(args.planes) + (int64_t)row * io.row_bytes); };
+    const int64_t tile_bytes = 32 * io.row_bytes;
     if constexpr (TRAIN) {
-      store_pos_enc_plane(E, reinterpret_cast<float*>(reinterpret_cast<char*>(args.planes) + (int64_t)kPlE * io.row_bytes), io, col, h);
-      store_view_enc_plane(V, reinterpret_cast<float*>(reinterpret_cast<char*>(args.planes) + (int64_t)kPlVE * io.row_bytes), io, col, h);
+      store_pos_enc_plane(E, rows(kPlE), io, col, h);
+      store_view_enc_plane(V, rows(kPlVE), io, col, h);
     }
     f32x16 X[8], Y[8];
     // L0: enc(63) -> 256
     init_bias(X, sm + kSmBias + 0 * 256, h);
     chunk_mma<VanillaNet, kChL0 + 0, 8, 16>(p, E[0], X);
     chunk_mma<VanillaNet, kChL0 + 1, 8, 16>(p, E[1], X);
-    relu_tiles(X); save(X, plane_h(0), 0);
+    relu_tiles(X); mask(X, 0);
     // L1..L4
-    init_bias(Y, sm + kSmBias + 1 * 256, h); dense_layer<VanillaNet, kChL1 + 0, 8, 8>(p, X, Y); relu_tiles(Y); save(Y, plane_h(1), 1);
-    init_bias(X, sm + kSmBias + 2 * 256, h); dense_layer<VanillaNet, kChL1 + 8, 8, 8>(p, Y, X); relu_tiles(X); save(X, plane_h(2), 2);
-    init_bias(Y, sm + kSmBias + 3 * 256, h); dense_layer<VanillaNet, kChL1 + 16, 8, 8>(p, X, Y); relu_tiles(Y); save(Y, plane_h(3), 3);
-    init_bias(X, sm + kSmBias + 4 * 256, h); dense_layer<VanillaNet, kChL1 + 24, 8, 8>(p, Y, X); relu_tiles(X); save(X, plane_h(4), 4);
+    init_bias(Y, sm + kSmBias + 1 * 256, h); dense_layer<VanillaNet, kChL1 + 0, 8, 8, TRAIN>(p, X, Y, rows(plane_h(0)), &io, tile_bytes); relu_tiles(Y); mask(Y, 1);
+    init_bias(X, sm + kSmBias + 2 * 256, h); dense_layer<VanillaNet, kChL1 + 8, 8, 8, TRAIN>(p, Y, X, rows(plane_h(1)), &io, tile_bytes); relu_tiles(X); mask(X, 2);
+    init_bias(Y, sm + kSmBias + 3 * 256, h); dense_layer<VanillaNet, kChL1 + 16, 8, 8, TRAIN>(p, X, Y, rows(plane_h(2)), &io, tile_bytes); relu_tiles(Y); mask(Y, 3);
+    init_bias(X, sm + kSmBias + 4 * 256, h); dense_layer<VanillaNet, kChL1 + 24, 8, 8, TRAIN>(p, Y, X, rows(plane_h(3)), &io, tile_bytes); relu_tiles(X); mask(X, 4);
     // L5: cat[h(256), enc(63)] -> 256     (model.py:102-103: concat after layer 4's ReLU)
     init_bias(Y, sm + kSmBias + 5 * 256, h);
-    dense_layer<VanillaNet, kChL5, 8, 8>(p, X, Y);
+    dense_layer<VanillaNet, kChL5, 8, 8, TRAIN>(p, X, Y, rows(plane_h(4)), &io, tile_bytes);
     chunk_mma<VanillaNet, kChL5 + 8, 8, 16>(p, E[0], Y);
     chunk_mma<VanillaNet, kChL5 + 9, 8, 16>(p, E[1], Y);
-    relu_tiles(Y); save(Y, plane_h(5), 5);
+    relu_tiles(Y); mask(Y, 5);
     // L6, L7
-    init_bias(X, sm + kSmBias + 6 * 256, h); dense_layer<VanillaNet, kChL6, 8, 8>(p, Y, X); relu_tiles(X); save(X, plane_h(6), 6);
-    init_bias(Y, sm + kSmBias + 7 * 256, h); dense_layer<VanillaNet, kChL7, 8, 8>(p, X, Y); relu_tiles(Y); save(Y, plane_h(7), 7);
+    init_bias(X, sm + kSmBias + 6 * 256, h); dense_layer<VanillaNet, kChL6, 8, 8, TRAIN>(p, Y, X, rows(plane_h(5)), &io, tile_bytes); relu_tiles(X); mask(X, 6);
+    init_bias(Y, sm + kSmBias + 7 * 256, h); dense_layer<VanillaNet, kChL7, 8, 8, TRAIN>(p, X, Y, rows(plane_h(6)), &io, tile_bytes); relu_tiles(Y); mask(Y, 7);
     // density head (model.py:105) on the post-ReLU layer-7 output
     float sigma = head_partial<8>(Y, sm + kSmWSigma, h);
     sigma = sigma + __shfl_xor(sigma, 32) + sm[kSmBSigma];
     // bottleneck, no activation (model.py:109)
-    init_bias(X, sm + kSmBiasBott, h); dense_layer<VanillaNet, kChBott, 8, 8>(p, Y, X); save(X, kPlBot);
+    init_bias(X, sm + kSmBiasBott, h); dense_layer<VanillaNet, kChBott, 8, 8, TRAIN>(p, Y, X, rows(plane_h(7)), &io, tile_bytes);
     // view branch: cat[bottleneck(256), viewenc(27)] -> 128, ReLU (model.py:110-116)
     f32x16 Z[4];
     init_bias(Z, sm + kSmBiasView, h);
-    chunk_mma<VanillaNet, kChView + 0, 4, 16>(p, X[0], Z);
-    chunk_mma<VanillaNet, kChView + 1, 4, 16>(p, X[1], Z);
-    chunk_mma<VanillaNet, kChView + 2, 4, 16>(p, X[2], Z);
-    chunk_mma<VanillaNet, kChView + 3, 4, 16>(p, X[3], Z);
-    chunk_mma<VanillaNet, kChView + 4, 4, 16>(p, X[4], Z);
-    chunk_mma<VanillaNet, kChView + 5, 4, 16>(p, X[5], Z);
-    chunk_mma<VanillaNet, kChView + 6, 4, 16>(p, X[6], Z);
-    chunk_mma<VanillaNet, kChView + 7, 4, 16>(p, X[7], Z);
+    dense_layer<VanillaNet, kChView, 8, 4, TRAIN>(p, X, Z, rows(kPlBot), &io, tile_bytes);
     chunk_mma<VanillaNet, kChView + 8, 4, 14>(p, V, Z);
-    relu_tiles(Z); save(Z, kPlHV, 8);
+    relu_tiles(Z); mask(Z, 8);
+    if constexpr (TRAIN) store_plane(Z, rows(kPlHV), io);
     // rgb head (model.py:118)
     float rgb[3];
 #pragma unroll

@@ -64,8 +64,15 @@ __device__ __forceinline__ void acquire(Pipe& p) {
 
 // out[Tp] += W_chunk[Tp] * in   for one 32-feature input tile held in accumulator layout.
 // The A-operand reads are software-pipelined one ds_read_b128 (= 4 MFMA steps, 256 matrix-pipe cycles) ahead.
-template <class Net, int C, int NT_OUT, int NREG>
-__device__ __forceinline__ void chunk_mma(Pipe& p, const f32x16& in, f32x16 (&out)[NT_OUT]) {
+struct PlaneIO;
+__device__ __forceinline__ float* plane_addr(float* plane, const PlaneIO& io, int row);
+
+// STORE (training forward): the input tile -- an activation the backward pass needs -- is written to its plane rows
+// one register per step between the MFMAs of this chunk, so the stores drain under the matrix pipe instead of in a
+// burst in front of the next chunk's barrier (whose s_waitcnt vmcnt(0) also waits for every outstanding store).
+template <class Net, int C, int NT_OUT, int NREG, bool STORE = false>
+__device__ __forceinline__ void chunk_mma(Pipe& p, const f32x16& in, f32x16 (&out)[NT_OUT], float* tile_plane = nullptr,
+                                          const PlaneIO* io = nullptr) {
   static_assert(Net::chunk_bytes(C) == NT_OUT * 4096, "chunk/out-tile mismatch");
   static_assert(NREG % 2 == 0 && NREG > 12, "register count");
   acquire<Net, C>(p);
@@ -80,6 +87,11 @@ __device__ __forceinline__ void chunk_mma(Pipe& p, const f32x16& in, f32x16 (&ou
     const int q = i / NT_OUT, tp = i % NT_OUT;
     f32x4 a_nxt = a_cur;
     if (i + 1 < NSTEP) a_nxt = *reinterpret_cast<const f32x4*>(buf + (i + 1) * 1024);
+    if constexpr (STORE) {
+#ifndef AON_EXP_NOSTORE
+      if (i < 16) *plane_addr(tile_plane, *io, (i & 3) + 8 * (i >> 2)) = in[i];
+#endif
+    }
 #pragma unroll
     for (int cc = 0; cc < 4; ++cc) {
       if (4 * q + cc < NREG) out[tp] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[cc], in[4 * q + cc], out[tp], 0, 0, 0);
@@ -116,17 +128,20 @@ __device__ __forceinline__ void relu_tiles(f32x16 (&x)[NT]) {
 }
 
 // NT_IN*32 -> NT_OUT*32 layer, input/output both in accumulator layout; chunks CBASE .. CBASE+NT_IN-1.
-template <class Net, int CBASE, int NT_IN, int NT_OUT>
-__device__ __forceinline__ void dense_layer(Pipe& p, const f32x16 (&in)[NT_IN], f32x16 (&out)[NT_OUT]) {
-  chunk_mma<Net, CBASE + 0, NT_OUT, 16>(p, in[0], out);
-  chunk_mma<Net, CBASE + 1, NT_OUT, 16>(p, in[1], out);
-  chunk_mma<Net, CBASE + 2, NT_OUT, 16>(p, in[2], out);
-  chunk_mma<Net, CBASE + 3, NT_OUT, 16>(p, in[3], out);
+// STORE: the input tiles go to the plane rows starting at `in_plane` (32 rows per tile) while the layer computes.
+template <class Net, int CBASE, int NT_IN, int NT_OUT, bool STORE = false>
+__device__ __forceinline__ void dense_layer(Pipe& p, const f32x16 (&in)[NT_IN], f32x16 (&out)[NT_OUT], float* in_plane = nullptr,
+                                            const PlaneIO* io = nullptr, int64_t tile_stride_bytes = 0) {
+  auto tp = [&](int j) { return STORE ? reinterpret_cast<float*>(reinterpret_cast<char*>(in_plane) + j * tile_stride_bytes) : nullptr; };
+  chunk_mma<Net, CBASE + 0, NT_OUT, 16, STORE>(p, in[0], out, tp(0), io);
+  chunk_mma<Net, CBASE + 1, NT_OUT, 16, STORE>(p, in[1], out, tp(1), io);
+  chunk_mma<Net, CBASE + 2, NT_OUT, 16, STORE>(p, in[2], out, tp(2), io);
+  chunk_mma<Net, CBASE + 3, NT_OUT, 16, STORE>(p, in[3], out, tp(3), io);
   if constexpr (NT_IN == 8) {
-    chunk_mma<Net, CBASE + 4, NT_OUT, 16>(p, in[4], out);
-    chunk_mma<Net, CBASE + 5, NT_OUT, 16>(p, in[5], out);
-    chunk_mma<Net, CBASE + 6, NT_OUT, 16>(p, in[6], out);
-    chunk_mma<Net, CBASE + 7, NT_OUT, 16>(p, in[7], out);
+    chunk_mma<Net, CBASE + 4, NT_OUT, 16, STORE>(p, in[4], out, tp(4), io);
+    chunk_mma<Net, CBASE + 5, NT_OUT, 16, STORE>(p, in[5], out, tp(5), io);
+    chunk_mma<Net, CBASE + 6, NT_OUT, 16, STORE>(p, in[6], out, tp(6), io);
+    chunk_mma<Net, CBASE + 7, NT_OUT, 16, STORE>(p, in[7], out, tp(7), io);
   }
 }
 

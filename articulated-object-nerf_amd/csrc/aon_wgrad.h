@@ -125,24 +125,58 @@ __global__ void __launch_bounds__(256) wgrad_kernel(WgradArgs a) {
   }
 }
 
-// out[row*ld + col_off + col] = sum_wg partial[wg][row][col]   for col < k_valid
-static __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int nparts, int M, int K, int k_valid, float* __restrict__ out,
-                                    int ld, int col_off) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= M * K) return;
-  const int row = idx / K, col = idx % K;
-  if (col >= k_valid) return;
-  float s = 0.f;
-  for (int p = 0; p < nparts; ++p) s += partial[(int64_t)p * M * K + idx];
-  out[(int64_t)row * ld + col_off + col] = s;
-}
-
-static __global__ void bias_reduce_kernel(const float* __restrict__ partial, int nparts, int M, float* __restrict__ out) {
-  const int row = blockIdx.x * blockDim.x + threadIdx.x;
-  if (row >= M) return;
-  float s = 0.f;
-  for (int p = 0; p < nparts; ++p) s += partial[(int64_t)p * M + row];
-  out[row] = s;
+// Second stage (deterministic, no atomics):
+//   out[row*ld + col_off + col] = sum_wg partial[wg][row][col]   for col < k_valid      (blocks [0, M*K/256))
+//   bias_out[row]               = sum_wg bias_partial[wg][row]                           (blocks [M*K/256, +M/16))
+// Weight blocks: 64 float4 columns x 4 waves; wave w sums the partials p = w, w+4, ... with 8 independent 16-byte loads in
+// flight per lane, then the four wave sums are added in wave order through LDS.  64 MB of partials per 256x256 layer are
+// read at HBM/MALL speed instead of through one dependent 4-byte load chain per thread.
+static __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ partial, int nparts, int M, int K, int k_valid,
+                                                                  float* __restrict__ out, int ld, int col_off,
+                                                                  const float* __restrict__ bias_partial, float* __restrict__ bias_out) {
+  __shared__ f32x4 red[4][64];
+  const int nb_w = M * K / 256;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if ((int)blockIdx.x < nb_w) {
+    const int idx = (blockIdx.x * 64 + lane) * 4;  // first of 4 consecutive columns of one row (K is a multiple of 32)
+    const f32x4* src = reinterpret_cast<const f32x4*>(partial + idx);
+    const int64_t stride4 = (int64_t)M * K / 4;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    int pp = wave;
+    for (; pp + 28 < nparts; pp += 32) {
+      f32x4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = src[(int64_t)(pp + 4 * u) * stride4];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; pp < nparts; pp += 4) s += src[(int64_t)pp * stride4];
+    red[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0) {
+      const f32x4 t = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+      const int row = idx / K, col = idx % K;
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        if (col + c < k_valid) out[(int64_t)row * ld + col_off + col + c] = t[c];
+    }
+  } else if (bias_out) {
+    // 16 rows per block; thread (r, g) sums partials g, g+16, ...; the 16 group sums are added in group order
+    float* redf = reinterpret_cast<float*>(&red[0][0]);
+    const int r = threadIdx.x & 15, g = threadIdx.x >> 4;
+    const int row = ((int)blockIdx.x - nb_w) * 16 + r;
+    float s = 0.f;
+    if (row < M)
+      for (int pp = g; pp < nparts; pp += 16) s += bias_partial[(int64_t)pp * M + row];
+    redf[g * 16 + r] = s;
+    __syncthreads();
+    if (g == 0 && row < M) {
+      float t = 0.f;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) t += redf[q * 16 + r];
+      bias_out[row] = t;
+    }
+  }
 }
 
 // Heads: dW_sigma[k] = sum_n d_raw[n].w * H7[k][n];  dW_rgb[c][k] = sum_n d_raw[n][c] * HV[k][n];  d bias = sum_n d_raw[n]
@@ -198,14 +232,9 @@ static hipError_t run_wgrad(const float* A, const float* B, int64_t Np, int npar
   wgrad_kernel<RT, CT><<<dim3(nparts), dim3(256), lds, stream>>>(a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  wgrad_reduce_kernel<<<dim3((M * K + 255) / 256), dim3(256), 0, stream>>>(partial, nparts, M, K, k_valid, out, ld, col_off);
-  e = hipGetLastError();
-  if (e != hipSuccess) return e;
-  if (bias_out) {
-    bias_reduce_kernel<<<dim3((M + 255) / 256), dim3(256), 0, stream>>>(bias_partial, nparts, M, bias_out);
-    e = hipGetLastError();
-  }
-  return e;
+  const int nblocks = M * K / 256 + (bias_out ? (M + 15) / 16 : 0);
+  wgrad_reduce_kernel<<<dim3(nblocks), dim3(256), 0, stream>>>(partial, nparts, M, K, k_valid, out, ld, col_off, bias_partial, bias_out);
+  return hipGetLastError();
 }
 
 inline int64_t wgrad_workspace_bytes_impl() {
