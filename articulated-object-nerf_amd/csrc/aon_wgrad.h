@@ -15,7 +15,16 @@ __device__ __forceinline__ float wsum64(float v) {
 // ---------------------------------------------------------------------------------------------
 // One workgroup: OUT[M x K] partial = A[M rows x n-range] . B[K rows x n-range]^T, M = 128*RT, K = 32*CT.
 // wave w owns rows [32*RT*w, 32*RT*(w+1)) x all K columns -> RT x CT accumulator tiles.
-constexpr int kWgLdsStride = 36;  // floats per 32-sample row in LDS (144 B: 16-byte aligned, conflict-free b128 reads)
+//
+// Operand staging is LDS-DMA (global_load_lds, 16 bytes per lane), no vector registers and no ds_write spent on it:
+// one DMA instruction moves 8 rows x 128 bytes (each row segment a full, coalesced 128-byte line).  The LDS image
+// keeps rows at their natural 128-byte pitch; bank conflicts of the fragment reads (32 lanes reading the same 16-byte
+// column of 32 different rows) are removed by an XOR swizzle applied on the GLOBAL side: the lane that fills 16-byte
+// slot p of row r fetches column p ^ (r & 7) of that row, so column c of row r lives in slot c ^ (r & 7) and any 8
+// consecutive rows hit 8 distinct slots.  (Round-1 measurements, tools/ubench/wgrad_layout.hip, 256x256 block,
+// 790,528 samples: register-staged global_load + padded ds_write_b128 126 TFLOP/s; DMA gathering 32-byte pieces
+// directly into fragment order 109; this form: see DESIGN.md.)
+constexpr int kWgTileFloats = 32 * 32;  // one 32-row tile of one 32-sample step
 
 struct WgradArgs {
   const float* A;  // dZ plane rows (row 0 of this block)
@@ -29,9 +38,12 @@ struct WgradArgs {
 template <int RT, int CT>
 __global__ void __launch_bounds__(256) wgrad_kernel(WgradArgs a) {
   constexpr int M = 128 * RT, K = 32 * CT;
-  constexpr int ROWS = M + K;                   // rows staged per 32-sample step
-  constexpr int STAGE_FLOATS = ROWS * kWgLdsStride;
-  constexpr int LD4 = (ROWS * 8 + 255) / 256;   // float4 loads per thread per step
+  constexpr int NTILE = (M + K) / 32;           // 32-row tiles staged per 32-sample step
+#ifndef DMA_EVERY_N
+#define DMA_EVERY_N 4
+#endif
+  constexpr int DMA_EVERY = CT < DMA_EVERY_N ? CT : DMA_EVERY_N;
+  constexpr int STAGE_FLOATS = NTILE * kWgTileFloats;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* smem = reinterpret_cast<float*>(smem_raw);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -53,57 +65,62 @@ __global__ void __launch_bounds__(256) wgrad_kernel(WgradArgs a) {
 #pragma unroll
   for (int i = 0; i < RT; ++i) bsum[i] = 0.f;
 
-  f32x4 stage[LD4];
-  auto gload = [&](int chunk) {
-#pragma unroll
-    for (int i = 0; i < LD4; ++i) {
-      const int e = tid + 256 * i;  // (row, col4)
-      const int row = e >> 3, c4 = e & 7;
-      if (row < ROWS) {
-        const float* src = row < M ? a.A + (int64_t)row * a.Np : a.B + (int64_t)(row - M) * a.Np;
-        stage[i] = *reinterpret_cast<const f32x4*>(src + (int64_t)chunk * 32 + 4 * c4);
-      }
-    }
+  // DMA lane map: lane = (r, p) = (lane >> 3, lane & 7) fills slot p of row r of an 8-row group with column p ^ r
+  const int64_t lane_off = (int64_t)(lane >> 3) * a.Np * 4 + (((lane & 7) ^ (lane >> 3)) << 4);
+  // one of this wave's NTILE DMA instructions of a step: 8-row group G = 4*d + wave
+  auto dma_one = [&](int chunk, int buf, int d) {
+    int64_t step_off = (int64_t)chunk * 128;
+    asm volatile("" : "+s"(step_off));  // keep the per-group addresses on the scalar unit (no hoisted VGPR pairs)
+    const int G = 4 * d + wave;
+    const float* rows = 8 * G < M ? a.A + (int64_t)(8 * G) * a.Np : a.B + (int64_t)(8 * G - M) * a.Np;
+    const char* g = reinterpret_cast<const char*>(rows) + step_off + lane_off;
+    char* l = reinterpret_cast<char*>(smem + buf * STAGE_FLOATS + G * 256);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (lds_void*)l, 16, 0, 0);
   };
-  auto lstore = [&](int buf) {
+  // fragment of k-step s for this lane: row li of a tile, column 2s + kh -> slot (2s + kh) ^ (li & 7)
+  int frag_off[4];
 #pragma unroll
-    for (int i = 0; i < LD4; ++i) {
-      const int e = tid + 256 * i;
-      const int row = e >> 3, c4 = e & 7;
-      if (row < ROWS) *reinterpret_cast<f32x4*>(smem + buf * STAGE_FLOATS + row * kWgLdsStride + 4 * c4) = stage[i];
-    }
-  };
+  for (int s = 0; s < 4; ++s) frag_off[s] = li * 32 + (((2 * s + kh) ^ (li & 7)) << 2);
 
   if (c_begin < c_end) {
-    gload(c_begin);
-    lstore(0);
+#pragma unroll
+    for (int d = 0; d < NTILE; ++d) dma_one(c_begin, 0, d);
   }
-  __syncthreads();
+  __syncthreads();  // vmcnt(0) + barrier: step c_begin is in LDS for every wave
   for (int c = c_begin; c < c_end; ++c) {
     const int buf = (c - c_begin) & 1;
-    if (c + 1 < c_end) gload(c + 1);  // global loads in flight under the MFMAs below
-    const float* sa = smem + buf * STAGE_FLOATS + (32 * RT * wave + li) * kWgLdsStride + 4 * kh;
-    const float* sb = smem + buf * STAGE_FLOATS + (M + li) * kWgLdsStride + 4 * kh;
+    const bool more = c + 1 < c_end;
+    const float* sa = smem + buf * STAGE_FLOATS + (RT * wave) * kWgTileFloats;
+    const float* sb = smem + buf * STAGE_FLOATS + (M / 32) * kWgTileFloats;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       f32x4 af[RT], bf[CT];
 #pragma unroll
       for (int i = 0; i < RT; ++i) {
-        af[i] = *reinterpret_cast<const f32x4*>(sa + i * 32 * kWgLdsStride + 8 * s);
+        af[i] = *reinterpret_cast<const f32x4*>(sa + i * kWgTileFloats + frag_off[s]);
         bsum[i] += (af[i][0] + af[i][1]) + (af[i][2] + af[i][3]);
       }
 #pragma unroll
-      for (int j = 0; j < CT; ++j) bf[j] = *reinterpret_cast<const f32x4*>(sb + j * 32 * kWgLdsStride + 8 * s);
+      for (int j = 0; j < CT; ++j) bf[j] = *reinterpret_cast<const f32x4*>(sb + j * kWgTileFloats + frag_off[s]);
 #pragma unroll
-      for (int cc = 0; cc < 4; ++cc)
+      for (int cc = 0; cc < 4; ++cc) {
 #pragma unroll
-        for (int i = 0; i < RT; ++i)
+        for (int i = 0; i < RT; ++i) {
+          // The next step's DMA instructions are issued one per CT MFMAs over the FIRST part of this step.  A wave issues
+          // in order: a burst of all of them in front of the MFMAs stalls the matrix pipe while the memory pipeline
+          // accepts them (-4 %); issued too late, the vmcnt(0) in front of the barrier waits out their HBM latency (-8 %).
 #pragma unroll
-          for (int j = 0; j < CT; ++j)
+          for (int j = 0; j < CT; ++j) {
+            if (j % DMA_EVERY == 0) {
+              const int d = ((4 * s + cc) * RT + i) * ((CT + DMA_EVERY - 1) / DMA_EVERY) + j / DMA_EVERY;
+              if (d < NTILE && more) dma_one(c + 1, buf ^ 1, d);
+            }
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][cc], bf[j][cc], acc[i][j], 0, 0, 0);
+          }
+        }
+      }
     }
-    if (c + 1 < c_end) lstore(buf ^ 1);
-    __syncthreads();
+    __syncthreads();  // drains this wave's DMA of step c+1 and publishes it; everyone is done reading `buf`
   }
   // partial[wg][row][col]; accumulator layout: col = lane&31, row = (r&3) + 8(r>>2) + 4(lane>>5)
   float* out = a.partial + (int64_t)blockIdx.x * M * K;
@@ -221,7 +238,7 @@ template <int RT, int CT>
 static hipError_t run_wgrad(const float* A, const float* B, int64_t Np, int nparts, float* partial, float* bias_partial,
                             float* out, int ld, int col_off, int k_valid, float* bias_out, hipStream_t stream) {
   constexpr int M = 128 * RT, K = 32 * CT;
-  constexpr int lds = 2 * (M + K) * kWgLdsStride * 4;
+  constexpr int lds = 2 * (M + K) * 32 * 4;
   static bool attr = false;
   if (!attr) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<RT, CT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
