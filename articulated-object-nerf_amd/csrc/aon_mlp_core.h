@@ -54,12 +54,28 @@ __device__ __forceinline__ void pipe_init(Pipe& p, const char* stream, char* rin
   __syncthreads();
 }
 
-// Wait for chunk C (DMA issued one chunk earlier), release the other slot, start streaming chunk C+1.
+// Wait for chunk C (DMA issued one chunk earlier) and release the other slot.  Chunk C+1 is then streamed in by
+// dma_round calls placed between the first MFMA groups of chunk C (chunk_mma): a wave issues in order, so the
+// 8 address-setup + DMA instructions of a chunk issued as one block at the boundary hold back the MFMAs behind them
+// while the memory pipeline accepts them; issued one per group they cost nothing, and being in the first quarter of
+// the chunk they have landed long before the next boundary's vmcnt(0).
 template <class Net, int C>
-__device__ __forceinline__ void acquire(Pipe& p) {
+__device__ __forceinline__ unsigned acquire(Pipe& p) {
   __syncthreads();  // drains this wave's LDS-DMA (vmcnt(0)) + workgroup barrier
   p.slot ^= 1;
-  issue_chunk<Net, (C + 1) % Net::kNumChunks>(p, p.slot ^ 1);
+  constexpr int CN = (C + 1) % Net::kNumChunks;
+  unsigned off = p.issue_off;
+  asm volatile("" : "+s"(off));
+  p.issue_off = (CN == Net::kNumChunks - 1) ? 0u : off + (unsigned)Net::chunk_bytes(CN);
+  return off;
+}
+
+template <class Net>
+__device__ __forceinline__ void dma_round(const Pipe& p, unsigned off, int r) {
+  gbl_char* src = (gbl_char*)(p.stream + off);
+  char* dst = p.ring + (p.slot ^ 1) * Net::kSlotBytes + p.wave_off;
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + r * 4096 + p.voff),
+                                   (lds_void*)(dst + r * 4096), 16, 0, 0);
 }
 
 // out[Tp] += W_chunk[Tp] * in   for one 32-feature input tile held in accumulator layout.
@@ -75,7 +91,8 @@ __device__ __forceinline__ void chunk_mma(Pipe& p, const f32x16& in, f32x16 (&ou
                                           const PlaneIO* io = nullptr) {
   static_assert(Net::chunk_bytes(C) == NT_OUT * 4096, "chunk/out-tile mismatch");
   static_assert(NREG % 2 == 0 && NREG > 12, "register count");
-  acquire<Net, C>(p);
+  const unsigned dma_off = acquire<Net, C>(p);
+  constexpr int ROUNDS = Net::chunk_bytes((C + 1) % Net::kNumChunks) / 4096;
   const char* buf = p.ring + p.slot * Net::kSlotBytes + p.lane_off;
   constexpr int NQ = (NREG + 3) / 4;
   constexpr int NSTEP = NQ * NT_OUT;
@@ -87,6 +104,8 @@ __device__ __forceinline__ void chunk_mma(Pipe& p, const f32x16& in, f32x16 (&ou
     const int q = i / NT_OUT, tp = i % NT_OUT;
     f32x4 a_nxt = a_cur;
     if (i + 1 < NSTEP) a_nxt = *reinterpret_cast<const f32x4*>(buf + (i + 1) * 1024);
+    static_assert(ROUNDS <= NSTEP, "one DMA round per step");
+    if (i < ROUNDS) dma_round<Net>(p, dma_off, i);
     if constexpr (STORE) {
 #ifndef AON_EXP_NOSTORE
       if (i < 16) *plane_addr(tile_plane, *io, (i & 3) + 8 * (i >> 2)) = in[i];
