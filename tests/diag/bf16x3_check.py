@@ -1,7 +1,7 @@
 """Accuracy and speed of the opt-in bf16x3 engine against the exact-fp32 kernel and an fp64 evaluation of the network."""
 import json, os, sys, time
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import aon_amd.synthetic as syn
 from aon_amd import ops
 from oracle import nerf_oracle as orc

@@ -1,6 +1,6 @@
 import sys, os, torch
 import torch.nn.functional as F
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import aon_amd.synthetic as syn
 from aon_amd import ops
 from oracle import nerf_oracle as orc

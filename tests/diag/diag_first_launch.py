@@ -1,5 +1,5 @@
 import sys, os, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import aon_amd.synthetic as syn
 from aon_amd import ops
 from oracle import nerf_oracle as orc

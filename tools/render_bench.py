@@ -14,13 +14,18 @@ def main():
     import aon_amd.synthetic as syn
     from aon_amd import ops
     from aon_amd.models.vanilla_nerf.model_autodecoder import NeRF_AE_Art
-    from oracle import nerf_oracle as orc
+    import types
+
+    from aon_amd.models.code_library import CodeLibraryArticulated
 
     dev = torch.device("cuda:0")
     H, W = (240, 320) if "--full" not in sys.argv else (480, 640)
     model = NeRF_AE_Art().to(dev)
     model.load_state_dict(syn.make_art_state_dict(seed=0, density_scale=30.0))
-    lat = {k: v.to(dev) for k, v in orc.code_library(syn.make_code_library_state(0, 1), torch.tensor([0]), torch.tensor([3])).items()}
+    lib = CodeLibraryArticulated(types.SimpleNamespace(N_max_objs=1, N_obj_code_length=128)).to(dev)
+    lib.load_state_dict(syn.make_code_library_state(0, 1))
+    with torch.no_grad():
+        lat = lib({"instance_id": torch.tensor([0], device=dev), "articulation_id": torch.tensor([3], device=dev)})
     ro, vd = ops.raygen(syn.look_at_pose(), H, W, syn.focal_from_fovy(H), device=dev)
     rays = {"rays_o": ro, "rays_d": vd, "viewdirs": vd}
     with torch.no_grad():
