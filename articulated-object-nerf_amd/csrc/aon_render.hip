@@ -12,21 +12,32 @@ namespace aon {
 // ---------------------------------------------------------------------------------------------
 // wave64 helpers
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+// Cross-lane data movement by DPP modifiers (no LDS-path ds_bpermute): row_shr:n inside rows of 16 lanes,
+// row_bcast:15 / row_bcast:31 to carry a row's last lane into the following rows (GFX9 DPP controls).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_f32(float identity, float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, identity), __builtin_bit_cast(int, v), CTRL,
+                                                               ROW_MASK, 0xf, false));
+}
+
+// inclusive scan over the 64 lanes; lanes without a source keep the identity
+template <bool MUL>
+__device__ __forceinline__ float wave_inclusive_scan(float v, int /*lane*/) {
+  const float id = MUL ? 1.0f : 0.0f;
+  auto op = [](float a, float b) { return MUL ? a * b : a + b; };
+  v = op(v, dpp_f32<0x111, 0xf>(id, v));  // row_shr:1
+  v = op(v, dpp_f32<0x112, 0xf>(id, v));  // row_shr:2
+  v = op(v, dpp_f32<0x114, 0xf>(id, v));  // row_shr:4
+  v = op(v, dpp_f32<0x118, 0xf>(id, v));  // row_shr:8
+  v = op(v, dpp_f32<0x142, 0xa>(id, v));  // row_bcast:15 -> rows 1 and 3
+  v = op(v, dpp_f32<0x143, 0xc>(id, v));  // row_bcast:31 -> rows 2 and 3
   return v;
 }
 
-// inclusive scan over the 64 lanes (Hillis-Steele); OP is + or *
-template <bool MUL>
-__device__ __forceinline__ float wave_inclusive_scan(float v, int lane) {
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const float o = __shfl_up(v, off);
-    if (lane >= off) v = MUL ? v * o : v + o;
-  }
-  return v;
+// sum over the 64 lanes, returned in every lane
+__device__ __forceinline__ float wave_sum(float v) {
+  v = wave_inclusive_scan<false>(v, 0);
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -212,6 +223,9 @@ __device__ __forceinline__ float softplus_f32(float x) {  // torch Softplus(beta
   return x > 20.0f ? x : log1pf(expf(x));
 }
 
+// PACKED: rgb and sigma are the (n*S,4) float4 records the MLP kernels write (rgb_stride = sigma_stride = 4,
+// sigma = rgb + 3): one 16-byte load per sample instead of four 4-byte ones.
+template <bool PACKED>
 __global__ void __launch_bounds__(256) composite_kernel(CompositeArgs a) {
   const int lane = threadIdx.x & 63;
   const int64_t ray = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -231,8 +245,14 @@ __global__ void __launch_bounds__(256) composite_kernel(CompositeArgs a) {
       const int64_t g = ray * S + s;
       t = tv[s];
       const float dist = __fmul_rn(s == S - 1 ? 1e10f : __fsub_rn(tv[s + 1], t), dn);
-      float sg = a.sigma[g * a.sigma_stride];
-      c0 = a.rgb[g * a.rgb_stride + 0]; c1 = a.rgb[g * a.rgb_stride + 1]; c2 = a.rgb[g * a.rgb_stride + 2];
+      float sg;
+      if constexpr (PACKED) {
+        const float4 r = reinterpret_cast<const float4*>(a.rgb)[g];
+        c0 = r.x; c1 = r.y; c2 = r.z; sg = r.w;
+      } else {
+        sg = a.sigma[g * a.sigma_stride];
+        c0 = a.rgb[g * a.rgb_stride + 0]; c1 = a.rgb[g * a.rgb_stride + 1]; c2 = a.rgb[g * a.rgb_stride + 2];
+      }
       if (a.act == 1) {
         sg = __builtin_fmaxf(sg, 0.f);
         c0 = sigmoid_f32(c0); c1 = sigmoid_f32(c1); c2 = sigmoid_f32(c2);
@@ -245,12 +265,14 @@ __global__ void __launch_bounds__(256) composite_kernel(CompositeArgs a) {
       alpha = __fsub_rn(1.0f, expf(-__fmul_rn(sg, dist)));
     }
     // T_i = prod_{j<i} (1 - alpha_j + 1e-10)   (helper.py:169-176)
-    const float f = in ? __fadd_rn(__fsub_rn(1.0f, alpha), 1e-10f) : 1.0f;
-    const float incl = wave_inclusive_scan<true>(f, lane);
-    float excl = __shfl_up(incl, 1);
-    if (lane == 0) excl = 1.0f;
-    const float T = __fmul_rn(carry, excl);
-    carry = __fmul_rn(carry, __shfl(incl, 63));
+    float T = carry;
+    if (S - base > 1) {  // wave-uniform; a one-sample tail block (S = 65, 193) needs no scan: T = carry in lane 0
+      const float f = in ? __fadd_rn(__fsub_rn(1.0f, alpha), 1e-10f) : 1.0f;
+      const float incl = wave_inclusive_scan<true>(f, lane);
+      const float excl = dpp_f32<0x138, 0xf>(1.0f, incl);  // wave_shr:1, lane 0 keeps 1
+      T = __fmul_rn(carry, excl);
+      carry = __fmul_rn(carry, __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, incl), 63)));
+    }
     const float w = __fmul_rn(alpha, T);
     if (in) {
       s_r = __fadd_rn(s_r, __fmul_rn(w, c0));
@@ -279,7 +301,9 @@ hipError_t launch_composite(const float* rgb, int rgb_stride, const float* sigma
                             float* acc, float* depth, float* weights, hipStream_t stream) {
   if (n_rays <= 0) return hipSuccess;
   CompositeArgs a{rgb, rgb_stride, sigma, sigma_stride, t_vals, dirs, n_rays, S, white_bkgd, act, comp_rgb, acc, depth, weights};
-  composite_kernel<<<dim3((unsigned)((n_rays + 3) / 4)), dim3(256), 0, stream>>>(a);
+  const bool packed = rgb_stride == 4 && sigma_stride == 4 && sigma == rgb + 3 && (reinterpret_cast<uintptr_t>(rgb) & 15) == 0;
+  if (packed) composite_kernel<true><<<dim3((unsigned)((n_rays + 3) / 4)), dim3(256), 0, stream>>>(a);
+  else composite_kernel<false><<<dim3((unsigned)((n_rays + 3) / 4)), dim3(256), 0, stream>>>(a);
   return hipGetLastError();
 }
 
@@ -369,15 +393,16 @@ __global__ void __launch_bounds__(256) sample_pdf_kernel(PdfArgs a) {
   w = __fadd_rn(w, __fdiv_rn(padding, 63.0f));
   wsum = __fadd_rn(wsum, padding);
   const float pdf = __fdiv_rn(w, wsum);
-  // cdf64 = [0, min(1, cumsum(pdf[:-1])) (62 entries), 1].  The running sum is taken in index order (a
-  // wave-uniform scalar fed by v_readlane), exactly like torch.cumsum: a tree scan would break the exact
-  // flatness of zero-weight zones and the monotonicity the binary search below relies on.
-  float run = 0.f, mine = 0.f;
+  // cdf64 = [0, min(1, cumsum(pdf[:-1])) (62 entries), 1].  The running sum is taken in INDEX ORDER, exactly like
+  // torch.cumsum (a tree scan would break the exact flatness of zero-weight zones and the monotonicity the binary search
+  // below relies on), but for all lanes at once: iterating  c <- wave_shr1(c) + pdf  (zero shifted into lane 0) gives
+  // lane i, after k >= i steps,  (((p0 + p1) + p2) + ...) + p_i  -- the oldest term is innermost, and the leading
+  // "0 + p0" of lanes that are already complete is exact.  61 dependent one-instruction DPP adds instead of 62 x
+  // (readlane, add, select).
+  float run = pdf;
 #pragma unroll
-  for (int j = 0; j < 62; ++j) {
-    run = __fadd_rn(run, __shfl(pdf, j));
-    if (lane == j + 1) mine = __builtin_fminf(1.f, run);
-  }
+  for (int j = 0; j < 61; ++j) run = __fadd_rn(dpp_f32<0x138, 0xf>(0.f, run), pdf);
+  const float mine = __builtin_fminf(1.f, dpp_f32<0x138, 0xf>(0.f, run));  // lane j+1 <- prefix[j]; lane 0 <- 0
   cdf[lane] = lane == 63 ? 1.f : mine;  // lane 0 keeps 0
   wave_lds_sync();
 
@@ -413,14 +438,31 @@ __global__ void __launch_bounds__(256) sample_pdf_kernel(PdfArgs a) {
   stage[65 + lane] = smp[0];
   stage[129 + lane] = smp[1];
   wave_lds_sync();
+  // Fast path: t_coarse is non-decreasing (it always is out of sample_along_rays) and so are the 128 draws (they are
+  // when u is: the deterministic grid, or pre-sorted random u).  [t_0..t_64, +inf x 63, s_127..s_0] is then a bitonic
+  // sequence and ONE 8-stage bitonic merge sorts it; otherwise the full 36-stage sort runs.  Both give sort(cat[...])
+  // exactly (a sorted multiset is unique), which a wave-uniform order check decides.
   float v[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int e = lane * 4 + r;
-    v[r] = e < 193 ? stage[e] : __builtin_inff();
+    v[r] = e < 65 ? stage[e] : (e < 128 ? __builtin_inff() : stage[65 + (255 - e)]);
   }
-  bitonic_merge<2>(v, lane); bitonic_merge<4>(v, lane); bitonic_merge<8>(v, lane); bitonic_merge<16>(v, lane);
-  bitonic_merge<32>(v, lane); bitonic_merge<64>(v, lane); bitonic_merge<128>(v, lane); bitonic_merge<256>(v, lane);
+  const float nxt = dpp_f32<0x130, 0xf>(0.f, v[0]);  // wave_shl:1 -> lane+1's first element
+  const bool asc = lane < 32;
+  bool ok = asc ? (v[0] <= v[1] && v[1] <= v[2] && v[2] <= v[3] && (lane == 31 || v[3] <= nxt))
+                : (v[0] >= v[1] && v[1] >= v[2] && v[2] >= v[3] && (lane == 63 || v[3] >= nxt));
+  if (__builtin_amdgcn_ballot_w64(ok) == ~0ull) {
+    bitonic_merge<256>(v, lane);
+  } else {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int e = lane * 4 + r;
+      v[r] = e < 193 ? stage[e] : __builtin_inff();
+    }
+    bitonic_merge<2>(v, lane); bitonic_merge<4>(v, lane); bitonic_merge<8>(v, lane); bitonic_merge<16>(v, lane);
+    bitonic_merge<32>(v, lane); bitonic_merge<64>(v, lane); bitonic_merge<128>(v, lane); bitonic_merge<256>(v, lane);
+  }
   float* out = a.t_fine + ray * 193;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
