@@ -24,7 +24,8 @@
 namespace aon {
 
 struct VanillaNet {
-  static constexpr int kSlotBytes = kBigChunkBytes;
+  static constexpr int kSlotBytes = kPairSlotBytes;  // a slot holds a pair of chunks
+  static constexpr bool kPair = true;
   static constexpr int kNumChunks = aon::kNumChunks;
   static constexpr int chunk_bytes(int c) { return aon::chunk_bytes(c); }
 };

@@ -28,7 +28,8 @@ constexpr int kAChV1 = 89;    // views_linear.1..3 : 4 chunks each
 constexpr int kANumChunks = 101;
 
 struct ArtNet {
-  static constexpr int kSlotBytes = kBigChunkBytes;
+  static constexpr int kSlotBytes = kPairSlotBytes;  // a slot holds a pair of chunks
+  static constexpr bool kPair = true;
   static constexpr int kNumChunks = kANumChunks;
   static constexpr int chunk_bytes(int c) { return (c < kAChT0 || c >= kAChV0) ? kSmallChunkBytes : kBigChunkBytes; }
   static constexpr int64_t chunk_offset(int c) {

@@ -22,6 +22,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 struct Bf16Net {
   static constexpr int kNumChunks = aon::kNumChunks;
   static constexpr int kSlotBytes = 8 * 6144;  // 48 KiB
+  static constexpr bool kPair = false;         // own single-chunk schedule (chunk_mma_bf16)
   // chunk = [k16 step s (2)][out tile][limb (3)][lane (64)][8 bf16]  ->  6 KiB per output tile
   static constexpr int chunk_bytes(int c) { return (c < kNumBigChunks ? 8 : 4) * 6144; }
 };

@@ -5,11 +5,24 @@
 
 namespace aon {
 
-// Weight-stream pipeline: two 32 KiB LDS slots, one workgroup barrier per chunk at the chunk boundary.
-// (A three-slot variant with the barrier in the middle of each chunk and the first A fragment of the next chunk
-// prefetched across the boundary was built and measured in round 1: correct, but 0.85-0.87 of the fp32-matrix peak
-// against 0.91 for this one -- the mid-chunk barrier splits hipcc's MFMA/ds_read scheduling region -- so it was dropped.)
-constexpr int kRingBytes = 2 * kBigChunkBytes;
+// Weight-stream pipeline of the fp32 kernels: two 64 KiB LDS slots, each holding a PAIR of consecutive chunks, and one
+// workgroup barrier per pair (39 instead of 77 per pass for the vanilla network): the barrier itself, the wave skew it
+// exposes and the LDS latency of the first fragment after it are paid half as often.  With an odd chunk count the last
+// chunk forms a "pair" of one.  Chunk C streams in chunk C+2 (the same position of the next pair) between its own first
+// MFMA groups; the last chunk of an odd-length stream brings in chunks 0 and 1 of the next pass, and its predecessor
+// nothing.  (A three-slot variant with the barrier in the middle of each chunk and the first A fragment of the next chunk
+// prefetched across the boundary was built and measured in round 1: correct, but 0.85-0.87 of the fp32-matrix peak --
+// the mid-chunk barrier splits hipcc's MFMA/ds_read scheduling region -- so it was dropped.)
+constexpr int kPairSlotBytes = 2 * kBigChunkBytes;
+constexpr int kRingBytes = 2 * kPairSlotBytes;
+
+template <class Net> constexpr int pair_offset(int C) { return (C & 1) ? Net::chunk_bytes(C - 1) : 0; }
+template <class Net> constexpr int dma_count(int C) {
+  return (Net::kNumChunks & 1) ? (C == Net::kNumChunks - 1 ? 2 : (C == Net::kNumChunks - 2 ? 0 : 1)) : 1;
+}
+template <class Net> constexpr int dma_target(int C, int k) {
+  return ((Net::kNumChunks & 1) && C == Net::kNumChunks - 1) ? k : (C + 2) % Net::kNumChunks;
+}
 
 struct Pipe {
   const char* stream;  // packed stream base (wave-uniform -> SGPR pair)
@@ -42,40 +55,60 @@ __device__ __forceinline__ void issue_chunk(Pipe& p, int slot) {
   p.issue_off = (C == Net::kNumChunks - 1) ? 0u : off + (unsigned)Net::chunk_bytes(C);
 }
 
-// Kernel prologue: chunk 0 in flight (acquire<0> waits for it).  The caller's LDS writes (resident small vectors) are
-// published by the barrier inside.
+// Kernel prologue: the first pair (fp32 nets) / chunk 0 (bf16x3 net, which runs its own single-chunk schedule) in flight.
+// The caller's LDS writes (resident small vectors) are published by the barrier inside.
 template <class Net>
 __device__ __forceinline__ void pipe_init(Pipe& p, const char* stream, char* ring, int wave, int lane) {
   p.stream = stream; p.ring = ring;
   p.voff = (unsigned)(wave * 1024 + lane * 16);
   p.wave_off = wave * 1024; p.lane_off = lane * 16;
-  p.slot = 1; p.issue_off = 0;  // acquire<0> flips to slot 0
+  p.slot = 1; p.issue_off = 0;  // the first acquire flips to slot 0
   issue_chunk<Net, 0>(p, 0);
+  if constexpr (Net::kPair) {
+    gbl_char* src = (gbl_char*)(p.stream + Net::chunk_bytes(0));
+    char* dst = p.ring + Net::chunk_bytes(0) + p.wave_off;
+#pragma unroll
+    for (int r = 0; r < Net::chunk_bytes(1) / 4096; ++r)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + r * 4096 + p.voff),
+                                       (lds_void*)(dst + r * 4096), 16, 0, 0);
+    p.issue_off = (unsigned)(Net::chunk_bytes(0) + Net::chunk_bytes(1));
+  }
   __syncthreads();
 }
 
-// Wait for chunk C (DMA issued one chunk earlier) and release the other slot.  Chunk C+1 is then streamed in by
-// dma_round calls placed between the first MFMA groups of chunk C (chunk_mma): a wave issues in order, so the
-// 8 address-setup + DMA instructions of a chunk issued as one block at the boundary hold back the MFMAs behind them
-// while the memory pipeline accepts them; issued one per group they cost nothing, and being in the first quarter of
-// the chunk they have landed long before the next boundary's vmcnt(0).
+// Start of chunk C: the first chunk of a pair waits for the pair (DMA issued one pair earlier) and releases the other
+// slot.  Returns the stream offset of this chunk's DMA targets, which chunk_mma issues between its first MFMA groups: a
+// wave issues in order, so the address-setup + DMA instructions issued as one block at the boundary would hold back the
+// MFMAs behind them while the memory pipeline accepts them; spread out they cost nothing, and being early in the chunk
+// they have landed long before the next barrier's vmcnt(0).
 template <class Net, int C>
 __device__ __forceinline__ unsigned acquire(Pipe& p) {
-  __syncthreads();  // drains this wave's LDS-DMA (vmcnt(0)) + workgroup barrier
-  p.slot ^= 1;
-  constexpr int CN = (C + 1) % Net::kNumChunks;
+  if constexpr ((C & 1) == 0) {
+    __syncthreads();  // drains this wave's LDS-DMA (vmcnt(0)) + workgroup barrier
+    p.slot ^= 1;
+  }
   unsigned off = p.issue_off;
   asm volatile("" : "+s"(off));
-  p.issue_off = (CN == Net::kNumChunks - 1) ? 0u : off + (unsigned)Net::chunk_bytes(CN);
+  constexpr int n = dma_count<Net>(C);
+  if constexpr (n > 0) {
+    constexpr int last = dma_target<Net>(C, n - 1);
+    constexpr int bytes = Net::chunk_bytes(dma_target<Net>(C, 0)) + (n > 1 ? Net::chunk_bytes(dma_target<Net>(C, 1)) : 0);
+    p.issue_off = (last == Net::kNumChunks - 1) ? 0u : off + (unsigned)bytes;
+  }
   return off;
 }
 
-template <class Net>
+// round r of the DMA targets of chunk C (targets are consecutive in the stream; each lands at its pair position in the
+// other slot)
+template <class Net, int C>
 __device__ __forceinline__ void dma_round(const Pipe& p, unsigned off, int r) {
+  constexpr int T0 = dma_target<Net>(C, 0);
+  constexpr int R0 = Net::chunk_bytes(T0) / 4096;
   gbl_char* src = (gbl_char*)(p.stream + off);
-  char* dst = p.ring + (p.slot ^ 1) * Net::kSlotBytes + p.wave_off;
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + r * 4096 + p.voff),
-                                   (lds_void*)(dst + r * 4096), 16, 0, 0);
+  char* slot = p.ring + (p.slot ^ 1) * kPairSlotBytes + p.wave_off;
+  char* dst = r < R0 ? slot + pair_offset<Net>(T0) + r * 4096
+                     : slot + pair_offset<Net>(dma_target<Net>(C, 1)) + (r - R0) * 4096;
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + r * 4096 + p.voff), (lds_void*)dst, 16, 0, 0);
 }
 
 // out[Tp] += W_chunk[Tp] * in   for one 32-feature input tile held in accumulator layout.
@@ -92,8 +125,9 @@ __device__ __forceinline__ void chunk_mma(Pipe& p, const f32x16& in, f32x16 (&ou
   static_assert(Net::chunk_bytes(C) == NT_OUT * 4096, "chunk/out-tile mismatch");
   static_assert(NREG % 2 == 0 && NREG > 12, "register count");
   const unsigned dma_off = acquire<Net, C>(p);
-  constexpr int ROUNDS = Net::chunk_bytes((C + 1) % Net::kNumChunks) / 4096;
-  const char* buf = p.ring + p.slot * Net::kSlotBytes + p.lane_off;
+  constexpr int NDMA = dma_count<Net>(C);
+  constexpr int ROUNDS = NDMA == 0 ? 0 : (Net::chunk_bytes(dma_target<Net>(C, 0)) + (NDMA > 1 ? Net::chunk_bytes(dma_target<Net>(C, 1)) : 0)) / 4096;
+  const char* buf = p.ring + p.slot * kPairSlotBytes + pair_offset<Net>(C) + p.lane_off;
   constexpr int NQ = (NREG + 3) / 4;
   constexpr int NSTEP = NQ * NT_OUT;
   // (round-1 experiment: a distance-2 prefetch with the issue order pinned by sched_barrier(0) per step measured 0.900 of
@@ -105,12 +139,19 @@ __device__ __forceinline__ void chunk_mma(Pipe& p, const f32x16& in, f32x16 (&ou
     f32x4 a_nxt = a_cur;
     if (i + 1 < NSTEP) a_nxt = *reinterpret_cast<const f32x4*>(buf + (i + 1) * 1024);
     static_assert(ROUNDS <= NSTEP, "one DMA round per step");
-    if (i < ROUNDS) dma_round<Net>(p, dma_off, i);
+    if constexpr (ROUNDS > 0) {
+      if (i < ROUNDS) dma_round<Net, C>(p, dma_off, i);
+    }
     if constexpr (STORE) {
 #ifndef AON_EXP_NOSTORE
       if (i < 16) *plane_addr(tile_plane, *io, (i & 3) + 8 * (i >> 2)) = in[i];
 #endif
     }
+#ifdef AON_PIN_PREFETCH
+    // keep the read of step i+1 ABOVE the four MFMAs of step i: hipcc otherwise sinks it next to its use (it wants to reuse
+    // a_cur's registers) and the LDS latency is exposed once per step
+    __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
     for (int cc = 0; cc < 4; ++cc) {
       if (4 * q + cc < NREG) out[tp] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[cc], in[4 * q + cc], out[tp], 0, 0, 0);

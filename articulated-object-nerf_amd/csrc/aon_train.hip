@@ -147,7 +147,8 @@ constexpr int kBwL7 = 12;    // pts_linears.7 ... pts_linears.1: 8 each, in back
 constexpr int kBwNumChunks = 68;
 
 struct BwdNet {
-  static constexpr int kSlotBytes = kBigChunkBytes;
+  static constexpr int kSlotBytes = kPairSlotBytes;  // a slot holds a pair of chunks
+  static constexpr bool kPair = true;
   static constexpr int kNumChunks = kBwNumChunks;
   static constexpr int chunk_bytes(int) { return kBigChunkBytes; }
 };

@@ -27,7 +27,8 @@ constexpr int kABwNumChunks = 108;
 constexpr int kTinyChunkBytes = 2 * 4096;
 
 struct ArtBwdNet {
-  static constexpr int kSlotBytes = kBigChunkBytes;
+  static constexpr int kSlotBytes = kPairSlotBytes;  // a slot holds a pair of chunks
+  static constexpr bool kPair = true;
   static constexpr int kNumChunks = kABwNumChunks;
   static constexpr int chunk_bytes(int c) {
     return (c < kABwV0 || c >= kABwD3) ? kSmallChunkBytes
