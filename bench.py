@@ -85,6 +85,66 @@ def pmc_traffic():
     return {"traffic": None}
 
 
+def train_leg(dev, rank, world, distributed, steps=3, n_rays=4096):
+    """Informational only (never `value`): BASELINE config 5 per GPU -- articulated NeRF_AE_Art + code library, 4096 rays,
+    randomized sampling, loss of model_autodecoder.py:395-477, HIP forward+backward, ONE flat gradient all-reduce over RCCL
+    when world > 1 (parallel.allreduce_gradients), Adam.  Returns a dict for the JSON line (or {"error": ...})."""
+    try:
+        import types
+
+        import aon_amd.synthetic as syn
+        from aon_amd import ops
+        from aon_amd.models.code_library import CodeLibraryArticulated
+        from aon_amd.models.vanilla_nerf.model_autodecoder import NeRF_AE_Art
+        from aon_amd.parallel import allreduce_gradients
+
+        model = NeRF_AE_Art().to(dev)
+        model.load_state_dict(syn.make_art_state_dict(seed=0, density_scale=30.0))
+        lib = CodeLibraryArticulated(types.SimpleNamespace(N_max_objs=1, N_obj_code_length=128)).to(dev)
+        lib.load_state_dict(syn.make_code_library_state(seed=0, n_max_objs=1))
+        both = torch.nn.ModuleList([model, lib])
+        opt = torch.optim.Adam(both.parameters(), lr=5e-4, betas=(0.9, 0.999))
+        batch = {"instance_id": torch.tensor([0], device=dev), "articulation_id": torch.tensor([3], device=dev)}
+        H, W = 480, 640
+        ro, vd = ops.raygen(syn.look_at_pose(4.0, 30.0 + 45.0 * rank, 30.0), H, W, syn.focal_from_fovy(H), device=dev)
+        g = torch.Generator(device=dev).manual_seed(rank)
+        idx = torch.randint(0, H * W, (n_rays,), device=dev, generator=g)
+        rays = {"rays_o": ro[idx].contiguous(), "rays_d": vd[idx].contiguous(), "viewdirs": vd[idx].contiguous()}
+        target = torch.rand(n_rays, 3, device=dev, generator=g)
+
+        def step():
+            opt.zero_grad(set_to_none=True)
+            latents = lib(batch)
+            out = model(rays, True, True, syn.NEAR, syn.FAR, latents)
+            reg = sum(torch.mean(torch.norm(latents[k], dim=0)) for k in ("density", "color", "articulation"))
+            loss = torch.mean((out[0][0] - target) ** 2) + torch.mean((out[1][0] - target) ** 2) + 1e-4 * reg
+            loss.backward()
+            allreduce_gradients(both)
+            opt.step()
+            return loss
+
+        def fence():
+            torch.cuda.synchronize()
+            if distributed:
+                dist.barrier()
+                torch.cuda.synchronize()
+
+        step()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = step()
+        fence()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        if distributed:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item() / steps
+        return {"workload": f"articulated NeRF_AE_Art training step, {n_rays} rays/GPU, fwd+bwd" + (" + RCCL gradient all-reduce (6.4 MB, one bucket)" if world > 1 else "") + " + Adam",
+                "ms_per_step": dt * 1e3, "rays_per_s": world * n_rays / dt, "steps": steps, "loss": float(loss)}
+    except Exception as e:  # informational leg: never take the headline down with it
+        return {"error": f"{type(e).__name__}: {e}"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -96,6 +156,7 @@ def main():
     ap.add_argument("--engine", choices=["fp32", "bf16x3"], default="fp32",
                     help="MLP arithmetic of the timed region: exact fp32 MFMA (default) or the opt-in fp32-equivalent split-bf16 engine")
     ap.add_argument("--no-alt", action="store_true", help="skip the extra (untimed-for-`value`) run of the other engine")
+    ap.add_argument("--no-train-leg", action="store_true", help="skip the extra (informational) articulated training-step timing")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -184,6 +245,8 @@ def main():
                        "passes the parity suite at the fp32 kernel's tolerances); opt-in, not the default"}
         model.engine = args.engine
 
+    train = None if args.no_train_leg else train_leg(dev, rank, world, distributed)
+
     if rank == 0:
         rays_per_s = world * n_rays * args.steps / dt
         mlp_tflops = mlp_samples * FLOP_PER_SAMPLE / (mlp_ms * 1e-3) / 1e12 if mlp_ms > 0 else 0.0
@@ -207,6 +270,8 @@ def main():
         res["roofline"].update(pmc_traffic())
         if alt is not None:
             res["alt_engine"] = alt
+        if train is not None:
+            res["train_step"] = train
         if world == 1 and not args.no_cpu_baseline:
             rays_cpu = {k: v.cpu() for k, v in rays.items()}
             base, ref_rgb, (a, b) = cpu_baseline(sd, rays_cpu)
