@@ -39,10 +39,7 @@ template <int RT, int CT>
 __global__ void __launch_bounds__(256) wgrad_kernel(WgradArgs a) {
   constexpr int M = 128 * RT, K = 32 * CT;
   constexpr int NTILE = (M + K) / 32;           // 32-row tiles staged per 32-sample step
-#ifndef DMA_EVERY_N
-#define DMA_EVERY_N 4
-#endif
-  constexpr int DMA_EVERY = CT < DMA_EVERY_N ? CT : DMA_EVERY_N;
+  constexpr int DMA_EVERY = CT < 4 ? CT : 4;   // one DMA instruction per DMA_EVERY MFMAs
   constexpr int STAGE_FLOATS = NTILE * kWgTileFloats;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* smem = reinterpret_cast<float*>(smem_raw);
