@@ -1,0 +1,156 @@
+"""Randomised sweep of the HIP path against the oracle: ragged ray counts, both networks, both sampling modes, both
+backgrounds, unusual near/far, non-unit directions, weights of several density scales -- forward renders and training
+gradients.  Tolerances are those of the parity tests (PSNR >= 70 dB and max error stated per case); the point of this
+file is breadth (sizes and flag combinations the hand-picked cases do not visit), seeds are fixed."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import nerf_oracle as orc  # noqa: E402  (checker only)
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return torch.device("cuda:0")
+
+
+def psnr(a, b):
+    return -10.0 * torch.log10(torch.clamp(torch.mean((a - b) ** 2), min=1e-20)).item()
+
+
+def rel_l2(a, b):
+    return ((a - b).norm() / (b.norm() + 1e-30)).item()
+
+
+def _rays(n, rng, unit):
+    o = torch.from_numpy(rng.normal(size=(n, 3)).astype(np.float32))
+    o = 4.0 * o / o.norm(dim=-1, keepdim=True) * torch.from_numpy(rng.uniform(0.9, 1.1, size=(n, 1)).astype(np.float32))
+    tgt = torch.from_numpy(rng.uniform(-0.5, 0.5, size=(n, 3)).astype(np.float32))
+    d = tgt - o
+    v = d / d.norm(dim=-1, keepdim=True)
+    return {"rays_o": o.contiguous(), "rays_d": (v if unit else d * 0.3).contiguous(), "viewdirs": v.contiguous()}
+
+
+CASES = [(seed, n) for seed, n in zip(range(24), (1, 3, 31, 32, 33, 63, 64, 65, 127, 128, 129, 191, 255, 257, 300, 383, 500, 511, 513, 640, 777, 96,
+                                                  160, 224))]
+
+
+@pytest.mark.parametrize("seed,n", CASES)
+def test_forward_sweep(dev, seed, n):
+    import aon_amd.synthetic as syn
+    from aon_amd.models.vanilla_nerf.model import NeRF
+    from aon_amd.models.vanilla_nerf.model_autodecoder import NeRF_AE_Art
+
+    rng = np.random.Generator(np.random.PCG64(1000 + seed))
+    art = seed % 3 == 2
+    randomized, white, unit = bool(seed & 1), bool(seed & 2), seed % 5 != 4
+    near, far = ((2.0, 6.0), (1.5, 7.0), (2.5, 5.5))[seed % 3]
+    scale = (30.0, 5.0, 60.0)[(seed // 3) % 3]
+    rays_cpu = _rays(n, rng, unit)
+    rays = {k: v.to(dev) for k, v in rays_cpu.items()}
+    g = torch.Generator().manual_seed(seed)
+    draws = dict(t_rand=torch.rand(n, 65, generator=g), u=torch.rand(n, 128, generator=g)) if randomized else {}
+    draws_dev = {k: v.to(dev) for k, v in draws.items()}
+    robust = torch.ones(n, dtype=torch.bool)
+    if art:
+        sd = syn.make_art_state_dict(seed=seed, density_scale=scale)
+        lat = orc.code_library(syn.make_code_library_state(seed=seed, n_max_objs=2), torch.tensor([seed % 2]), torch.tensor([seed % 10]))
+        model = NeRF_AE_Art().to(dev)
+        model.load_state_dict(sd)
+        with torch.no_grad():
+            out = model(rays, randomized, white, near, far, {k: v.to(dev) for k, v in lat.items()}, **draws_dev)
+        ref = orc.nerf_ae_art_forward(sd, rays_cpu, randomized, white, near, far, lat, **draws)
+        ref64 = orc.nerf_ae_art_forward({k: v.double() for k, v in sd.items()}, {k: v.double() for k, v in rays_cpu.items()}, randomized,
+                                        white, near, far, {k: v.double() for k, v in lat.items()}, **{k: v.double() for k, v in draws.items()})
+    else:
+        sd = syn.make_nerf_state_dict(seed=seed, density_scale=scale)
+        model = NeRF().to(dev)
+        model.load_state_dict(sd)
+        with torch.no_grad():
+            out = model(rays, randomized, white, near, far, **draws_dev)
+        ref, aux = orc.nerf_forward(sd, rays_cpu, randomized, white, near, far, return_aux=True, **draws)
+        ref64 = orc.nerf_forward({k: v.double() for k, v in sd.items()}, {k: v.double() for k, v in rays_cpu.items()}, randomized, white,
+                                 near, far, **{k: v.double() for k, v in draws.items()})
+        # the 1e10-long last interval makes alpha_last a step function of sign(raw sigma_last) in the vanilla model (a
+        # discontinuity of the reference's own math): rays whose far-plane density is not robustly signed are
+        # compared at the stated end-to-end tolerance only
+        for a in aux:
+            robust &= a["raw_sigma"][:, -1, 0].abs() > 2e-2 * scale / 30.0
+    for lvl in (0, 1):
+        rgb, acc, depth = (x.cpu() for x in out[lvl])
+        assert rgb.shape == (n, 3) and acc.shape == (n,) and depth.shape == (n,)
+        assert torch.isfinite(rgb).all() and torch.isfinite(acc).all()
+        err = (rgb - ref[lvl][0]).abs().max(dim=-1).values
+        assert (err <= 1e-3).double().mean().item() >= (0.99 if n >= 200 else 1.0 - 2.0 / max(n, 2)), (lvl, err.max().item())
+        if robust.any():
+            # The fine level is ill-conditioned on sharp random fields: 1-ulp differences of the coarse weights move
+            # inverse-CDF draws across thin shells, and the ORACLE ITSELF differs between fp32 and fp64 by up to 2e-2 on such
+            # rays while the coarse level agrees to 3e-7 (tests/diag/diag_fuzz_case.py).  So each ray is held to the base
+            # tolerance plus three times the oracle's own fp32-vs-fp64 spread on that ray.
+            spread = (ref[lvl][0].double() - ref64[lvl][0]).abs().max(dim=-1).values.float()
+            spread_acc = (ref[lvl][1].double() - ref64[lvl][1]).abs().float()
+            base, base_acc = (1e-3, 2e-3) if art else (2e-4, 2e-4)
+            bad = robust & (err > base + 3 * spread)
+            assert not bad.any(), (lvl, err[bad].max().item(), spread[bad].max().item())
+            bad = robust & ((acc - ref[lvl][1]).abs() > base_acc + 3 * torch.maximum(spread, spread_acc))
+            assert not bad.any(), (lvl, (acc - ref[lvl][1]).abs()[bad].max().item())
+            if lvl == 0:
+                assert psnr(rgb[robust], ref[lvl][0][robust]) >= 70.0
+
+
+@pytest.mark.parametrize("seed,n", [(0, 1), (1, 5), (2, 33), (3, 100), (4, 130), (5, 200)])
+def test_training_gradient_sweep(dev, seed, n):
+    """Coarse-level gradients (identical sample positions on both sides) are compared tightly; fine-level ones inherit the
+    inverse-CDF input sensitivity and are bounded at the level the dedicated tests state."""
+    import aon_amd.synthetic as syn
+    from aon_amd.models.vanilla_nerf.model import NeRF
+    from aon_amd.models.vanilla_nerf.model_autodecoder import NeRF_AE_Art
+
+    rng = np.random.Generator(np.random.PCG64(2000 + seed))
+    art = seed % 2 == 1
+    white = bool(seed & 2)
+    rays_cpu = _rays(n, rng, True)
+    g = torch.Generator().manual_seed(100 + seed)
+    target = torch.rand(n, 3, generator=g)
+    t_rand, u = torch.rand(n, 65, generator=g), torch.rand(n, 128, generator=g)
+    rays = {k: v.to(dev) for k, v in rays_cpu.items()}
+    if art:
+        sd = syn.make_art_state_dict(seed=seed, density_scale=10.0)
+        lat_cpu = orc.code_library(syn.make_code_library_state(seed=seed, n_max_objs=1), torch.tensor([0]), torch.tensor([seed % 10]))
+        model = NeRF_AE_Art().to(dev)
+        model.load_state_dict(sd)
+        lat = {k: v.to(dev).requires_grad_(True) for k, v in lat_cpu.items()}
+        out = model(rays, True, white, 2.0, 6.0, lat, t_rand=t_rand.to(dev), u=u.to(dev))
+        sd_o = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        out_o = orc.nerf_ae_art_forward(sd_o, rays_cpu, True, white, 2.0, 6.0, lat_cpu, t_rand=t_rand, u=u)
+    else:
+        sd = syn.make_nerf_state_dict(seed=seed, density_scale=10.0)
+        model = NeRF().to(dev)
+        model.load_state_dict(sd)
+        out = model(rays, True, white, 2.0, 6.0, t_rand=t_rand.to(dev), u=u.to(dev))
+        sd_o = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        out_o, aux = orc.nerf_forward(sd_o, rays_cpu, True, white, 2.0, 6.0, t_rand=t_rand, u=u, return_aux=True)
+        robust = all((a["raw_sigma"][:, -1, 0].abs() > 2e-2 * 10.0 / 30.0).all().item() for a in aux)
+    if art:
+        robust = True   # softplus density: no far-plane sign discontinuity
+    loss = torch.mean((out[0][0] - target.to(dev)) ** 2) + torch.mean((out[1][0] - target.to(dev)) ** 2)
+    loss.backward()
+    loss_o = orc.img2mse(out_o[0][0], target) + orc.img2mse(out_o[1][0], target)
+    loss_o.backward()
+    assert abs(loss.item() - loss_o.item()) <= 1e-4 * max(1.0, abs(loss_o.item()))
+    for name, p in model.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all(), name
+        ref = sd_o[name].grad
+        if ref.norm().item() < 1e-12:
+            assert p.grad.abs().max().item() <= 1e-9, name
+            continue
+        tol = 5e-2 if art else (1e-2 if name.startswith("fine_mlp") else 2e-3)
+        if not robust:   # a ray whose far-plane sigma is within rounding of zero flips a whole alpha_last = {0,1} term
+            tol = 5e-2
+        assert rel_l2(p.grad.cpu(), ref) <= tol, (name, rel_l2(p.grad.cpu(), ref))
