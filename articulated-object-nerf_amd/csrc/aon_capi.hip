@@ -46,6 +46,8 @@ hipError_t launch_art_bwd_chain(const char* packed_bwd, const float* small, cons
 hipError_t launch_art_wgrad(const float* planes, const float* dplanes, const float* d_raw, const float* dxp, int64_t Np,
                             const float* const* params, const float* shape, const float* app, const float* art,
                             float* const* grads, float* g_shape, float* g_app, float* g_art, float* ws, hipStream_t stream);
+void set_train_engine(int e);
+int get_train_engine();
 int64_t bf16x3_packed_bytes();
 hipError_t launch_pack_vanilla_bf16x3(const float* const* params, char* packed, hipStream_t stream);
 hipError_t launch_mlp_fwd_bf16x3(const char* packed, const float* rays_o, const float* rays_d, const float* viewdirs,
@@ -457,6 +459,13 @@ int aon_render_fwd(const void* packed_coarse, const void* packed_fine, const flo
 }
 
 // ---- opt-in split-bf16 engine (fp32-equivalent arithmetic on the bf16 matrix pipe; see aon_mlp_bf16.hip) ----
+int aon_set_train_engine(int engine) {
+  if (engine != 0 && engine != 1) return fail(AON_E_INVALID, "aon_set_train_engine: engine must be 0 (fp32) or 1 (bf16x3)");
+  aon::set_train_engine(engine);
+  return AON_OK;
+}
+int aon_get_train_engine(void) { return aon::get_train_engine(); }
+
 int64_t aon_bf16x3_packed_bytes(void) { return aon::bf16x3_packed_bytes(); }
 
 int aon_pack_vanilla_mlp_bf16x3(const float* const* params_host, void* packed, void* stream) {

@@ -14,10 +14,9 @@
 // LDS-DMA weight chunks), with two differences: the previous layer's fp32 accumulator tile is (ReLU'd and) split into limb
 // fragments just before the chunk that consumes it, and a chunk carries three limb images of the weights (48 KiB).
 #include "aon_mlp_core.h"
+#include "aon_bf16_split.h"
 
 namespace aon {
-
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 struct Bf16Net {
   static constexpr int kNumChunks = aon::kNumChunks;
@@ -30,14 +29,6 @@ constexpr int64_t kBfStreamBytes = (int64_t)kNumBigChunks * 8 * 6144 + (int64_t)
 constexpr int kBfRingBytes = 2 * Bf16Net::kSlotBytes;
 constexpr int kBfEncStashBytes = 4 * 2 * 64 * 64;  // per wave: 2 encoding tiles x 64 lanes x 16 floats (parked in LDS between L0 and L5)
 constexpr int kBfLdsBytes = kBfRingBytes + (int)kSmallBytes + 16 /*pad to 16 B*/ + kBfEncStashBytes;
-
-__device__ __forceinline__ unsigned cvt_pk_bf16(float lo_elem, float hi_elem) {
-  unsigned p;  // round-to-nearest-even, element 0 in the low half
-  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(p) : "v"(lo_elem), "v"(hi_elem));
-  return p;
-}
-__device__ __forceinline__ float bf16_lo_as_f32(unsigned p) { return __builtin_bit_cast(float, p << 16); }
-__device__ __forceinline__ float bf16_hi_as_f32(unsigned p) { return __builtin_bit_cast(float, p & 0xffff0000u); }
 
 // host+device scalar version for the pack kernel
 __device__ __forceinline__ unsigned short bf16_rne_bits(float x) {
@@ -142,10 +133,6 @@ __device__ __forceinline__ LimbFrag split_step(const f32x16& t, int s8) {
     f.hi[jp] = ph; f.mid[jp] = pm; f.lo[jp] = cvt_pk_bf16(q0, q1);
   }
   return f;
-}
-
-__device__ __forceinline__ f32x16 mfma_bf16(const u32x4 a, const u32x4 b, const f32x16 c) {
-  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
 // One (ReLU +) split of a register pair: the unit of VALU work interleaved between MFMA groups.

@@ -355,4 +355,7 @@ hipError_t launch_vanilla_wgrad(const float* planes, const float* dplanes, const
   return hipGetLastError();
 }
 
+void set_train_engine(int e) { train_engine() = e; }
+int get_train_engine() { return train_engine(); }
+
 }  // namespace aon

@@ -1,6 +1,7 @@
 // Weight-gradient machinery shared by the vanilla (aon_train.hip) and articulated (aon_train_art.hip) backward passes.
 #pragma once
 #include "aon_mlp_core.h"
+#include "aon_bf16_split.h"
 
 namespace aon {
 
@@ -139,6 +140,109 @@ __global__ void __launch_bounds__(256) wgrad_kernel(WgradArgs a) {
   }
 }
 
+// Split-precision form of wgrad_kernel (opt-in "bf16x3" training engine): identical staging, partials and epilogue;
+// the contraction runs on v_mfma_f32_32x32x16_bf16 with both operands split exactly into three bf16 limbs in registers
+// (fragment = 8 consecutive samples of a row = two ds_read_b128) and the six limb products of weight >= 2^-24 accumulated
+// in fp32 -- fp32-class error at 6 x 32 instead of 8 x 64 matrix-pipe cycles per (tile pair, 16 samples).  The B tile of
+// column block j is split while the MFMAs of block j-1 run.
+template <int RT, int CT>
+__global__ void __launch_bounds__(256) wgrad_bf16x3_kernel(WgradArgs a) {
+  constexpr int M = 128 * RT, K = 32 * CT;
+  constexpr int NTILE = (M + K) / 32;
+  constexpr int STAGE_FLOATS = NTILE * kWgTileFloats;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* smem = reinterpret_cast<float*>(smem_raw);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, kh = lane >> 5;
+  const int per = (a.nchunks + gridDim.x - 1) / gridDim.x;
+  const int c_begin = blockIdx.x * per;
+  const int c_end = c_begin + per < a.nchunks ? c_begin + per : a.nchunks;
+
+  f32x16 acc[RT][CT];
+#pragma unroll
+  for (int i = 0; i < RT; ++i)
+#pragma unroll
+    for (int j = 0; j < CT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  float bsum[RT];
+#pragma unroll
+  for (int i = 0; i < RT; ++i) bsum[i] = 0.f;
+
+  const int64_t lane_off = (int64_t)(lane >> 3) * a.Np * 4 + (((lane & 7) ^ (lane >> 3)) << 4);
+  auto dma_one = [&](int chunk, int buf, int d) {
+    int64_t step_off = (int64_t)chunk * 128;
+    asm volatile("" : "+s"(step_off));
+    const int G = 4 * d + wave;
+    const float* rows = 8 * G < M ? a.A + (int64_t)(8 * G) * a.Np : a.B + (int64_t)(8 * G - M) * a.Np;
+    const char* g = reinterpret_cast<const char*>(rows) + step_off + lane_off;
+    char* l = reinterpret_cast<char*>(smem + buf * STAGE_FLOATS + G * 256);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (lds_void*)l, 16, 0, 0);
+  };
+  // fragment of k16-step ks: row li, 16-byte columns 4ks + 2kh and 4ks + 2kh + 1 (8 consecutive samples), swizzled slots
+  int frag_off[2][2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+    for (int c = 0; c < 2; ++c) frag_off[ks][c] = li * 32 + (((4 * ks + 2 * kh + c) ^ (li & 7)) << 2);
+
+  if (c_begin < c_end) {
+#pragma unroll
+    for (int d = 0; d < NTILE; ++d) dma_one(c_begin, 0, d);
+  }
+  __syncthreads();
+  for (int c = c_begin; c < c_end; ++c) {
+    const int buf = (c - c_begin) & 1;
+    const bool more = c + 1 < c_end;
+    const float* sa = smem + buf * STAGE_FLOATS + (RT * wave) * kWgTileFloats;
+    const float* sb = smem + buf * STAGE_FLOATS + (M / 32) * kWgTileFloats;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      Limb8 la[RT];
+#pragma unroll
+      for (int i = 0; i < RT; ++i) {
+        const f32x4 r0 = *reinterpret_cast<const f32x4*>(sa + i * kWgTileFloats + frag_off[ks][0]);
+        const f32x4 r1 = *reinterpret_cast<const f32x4*>(sa + i * kWgTileFloats + frag_off[ks][1]);
+        bsum[i] += ((r0[0] + r0[1]) + (r0[2] + r0[3])) + ((r1[0] + r1[1]) + (r1[2] + r1[3]));
+        la[i] = split8(r0, r1);
+      }
+#pragma unroll
+      for (int j = 0; j < CT; ++j) {
+        const f32x4 r0 = *reinterpret_cast<const f32x4*>(sb + j * kWgTileFloats + frag_off[ks][0]);
+        const f32x4 r1 = *reinterpret_cast<const f32x4*>(sb + j * kWgTileFloats + frag_off[ks][1]);
+        const Limb8 lb = split8(r0, r1);
+        // the next step's DMA instructions, spread over the 2*CT column-block groups of this step (early ones first)
+        constexpr int PER = (NTILE + 2 * CT - 1) / (2 * CT);
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+          const int d = (ks * CT + j) * PER + q;
+          if (d < NTILE && more) dma_one(c + 1, buf ^ 1, d);
+        }
+#pragma unroll
+        for (int i = 0; i < RT; ++i) acc[i][j] = mfma_bf16x3(la[i], lb, acc[i][j]);
+      }
+    }
+    __syncthreads();
+  }
+  float* out = a.partial + (int64_t)blockIdx.x * M * K;
+#pragma unroll
+  for (int i = 0; i < RT; ++i)
+#pragma unroll
+    for (int j = 0; j < CT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = 32 * (RT * wave + i) + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        out[(int64_t)row * K + 32 * j + li] = acc[i][j][r];
+      }
+  if (a.bias_partial) {
+#pragma unroll
+    for (int i = 0; i < RT; ++i) {
+      const float v = bsum[i] + __shfl_xor(bsum[i], 32);
+      if (kh == 0) a.bias_partial[(int64_t)blockIdx.x * M + 32 * (RT * wave + i) + li] = v;
+    }
+  }
+}
+
 // Second stage (deterministic, no atomics):
 //   out[row*ld + col_off + col] = sum_wg partial[wg][row][col]   for col < k_valid      (blocks [0, M*K/256))
 //   bias_out[row]               = sum_wg bias_partial[wg][row]                           (blocks [M*K/256, +M/16))
@@ -231,6 +335,13 @@ static __global__ void head_reduce_kernel(const float* __restrict__ partial, int
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
+// Training engine of the weight-gradient GEMMs: 0 = exact fp32 MFMA (default), 1 = split-bf16 ("bf16x3", fp32-equivalent
+// products).  Process-wide (one process drives one GPU from one thread); set through aon_set_train_engine().
+inline int& train_engine() {
+  static int e = 0;
+  return e;
+}
+
 template <int RT, int CT>
 static hipError_t run_wgrad(const float* A, const float* B, int64_t Np, int nparts, float* partial, float* bias_partial,
                             float* out, int ld, int col_off, int k_valid, float* bias_out, hipStream_t stream) {
@@ -240,10 +351,13 @@ static hipError_t run_wgrad(const float* A, const float* B, int64_t Np, int npar
   if (!attr) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<RT, CT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_bf16x3_kernel<RT, CT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return e;
     attr = true;
   }
   WgradArgs a{A, B, Np, (int)(Np / 32), partial, bias_out ? bias_partial : nullptr};
-  wgrad_kernel<RT, CT><<<dim3(nparts), dim3(256), lds, stream>>>(a);
+  if (train_engine() == 1) wgrad_bf16x3_kernel<RT, CT><<<dim3(nparts), dim3(256), lds, stream>>>(a);
+  else wgrad_kernel<RT, CT><<<dim3(nparts), dim3(256), lds, stream>>>(a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   const int nblocks = M * K / 256 + (bias_out ? (M + 15) / 16 : 0);

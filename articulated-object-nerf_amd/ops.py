@@ -149,6 +149,16 @@ def pack_vanilla_mlp(params: dict, out: torch.Tensor | None = None) -> torch.Ten
     return out
 
 
+def set_train_engine(engine: str) -> None:
+    """Engine of the training-side GEMM kernels: "fp32" (exact fp32 MFMA, default) or "bf16x3" (split-bf16, fp32-equivalent
+    products; currently the weight-gradient kernels).  Process-wide."""
+    check(lib.aon_set_train_engine({"fp32": 0, "bf16x3": 1}[engine]), "aon_set_train_engine")
+
+
+def get_train_engine() -> str:
+    return ("fp32", "bf16x3")[int(lib.aon_get_train_engine())]
+
+
 def pack_vanilla_mlp_bf16x3(params: dict, out: torch.Tensor | None = None) -> torch.Tensor:
     """Packed three-limb bf16 weight stream of the opt-in split-bf16 engine (re-pack when the parameters change)."""
     tensors = []

@@ -123,6 +123,11 @@ int aon_render_fwd(const void* packed_coarse, const void* packed_fine, const flo
  * (csrc/aon_mlp_bf16.hip).  Needs its own packed stream (aon_bf16x3_packed_bytes()).  The exact-fp32 entry points
  * above remain the default; callers select this engine explicitly. */
 int64_t aon_bf16x3_packed_bytes(void);
+/* Training-side engine switch (process-wide; one process drives one GPU from one thread): 0 = exact fp32 MFMA (default),
+ * 1 = "bf16x3" -- the weight-gradient GEMMs of aon_vanilla_wgrad / aon_art_wgrad run on the bf16 matrix pipe with both
+ * operands split exactly into three bf16 limbs and six limb products accumulated in fp32 (fp32-class error). */
+int aon_set_train_engine(int engine);
+int aon_get_train_engine(void);
 int aon_pack_vanilla_mlp_bf16x3(const float* const* params_host, void* packed, void* stream);
 int aon_mlp_fwd_bf16x3(const void* packed, const float* rays_o, const float* rays_d, const float* viewdirs,
                        const float* t_vals, int64_t n_rays, int S, float* raw, void* stream);

@@ -77,3 +77,21 @@ def test_bf16x3_render_end_to_end(dev, golden, nerf_sd):
     with pytest.raises(ValueError):
         with torch.no_grad():
             model(rays, False, True, 2.0, 6.0)
+
+
+@pytest.mark.parametrize("n,S,n_art,S_art", [(40, 193, 24, 193), (3, 65, 5, 65)])
+def test_bf16x3_train_engine_gradients(dev, nerf_sd, n, S, n_art, S_art):
+    """The opt-in training engine (split-bf16 weight-gradient GEMMs) against autograd on the oracle at the SAME tolerance
+    as the fp32 engine's shared-sample level test (2e-5 relative L2 per parameter), vanilla and articulated."""
+    from aon_amd import ops
+    from test_hip_training import test_level_backward_with_shared_samples as vanilla_level
+    from test_hip_training_art import test_art_level_backward_with_shared_samples as art_level
+
+    assert ops.get_train_engine() == "fp32"
+    ops.set_train_engine("bf16x3")
+    try:
+        assert ops.get_train_engine() == "bf16x3"
+        vanilla_level(dev, nerf_sd, n, S)
+        art_level(dev, n_art, S_art)   # the cases the fp32 engine is held to (tests/test_hip_training_art.py)
+    finally:
+        ops.set_train_engine("fp32")

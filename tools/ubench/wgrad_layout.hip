@@ -22,5 +22,14 @@ int main() {
     printf("wgrad<2,8> Np=%lld: %.3f ms per launch, %.1f TFLOP/s, %.2f TB/s operand reads\n", (long long)Np, ms / 8,
            2.0 * 256 * 256 * Np / (ms / 8) / 1e9, 512.0 * Np * 4 / (ms / 8) / 1e9);
   }
+  hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_bf16x3_kernel<2, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  for (int rep = 0; rep < 3; ++rep) {
+    hipEventRecord(e0);
+    for (int i = 0; i < 8; ++i) wgrad_bf16x3_kernel<2, 8><<<256, 256, lds>>>(a);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    printf("wgrad_bf16x3<2,8> Np=%lld: %.3f ms per launch, %.1f TFLOP/s algorithmic, %.2f TB/s operand reads\n", (long long)Np, ms / 8,
+           2.0 * 256 * 256 * Np / (ms / 8) / 1e9, 512.0 * Np * 4 / (ms / 8) / 1e9);
+  }
   return 0;
 }
