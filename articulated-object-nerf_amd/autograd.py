@@ -14,16 +14,21 @@ from . import ops
 class RenderVanilla(torch.autograd.Function):
     @staticmethod
     def forward(ctx, rays_o, rays_d, viewdirs, near, far, white_bkgd, num_levels, t_rand, u, packs, *params):
-        # packs: [(packed_fwd, packed_bwd)] per level; params: 24 tensors per level in ops.VANILLA_PARAM_ORDER
+        # packs: [(packed_fwd, packed_bwd[, packed_bf16x3])] per level; params: 24 tensors per level in ops.VANILLA_PARAM_ORDER
+        # (a third element selects the bf16x3 training forward; the fp32 stream is still needed by the backward chain)
         saved, outs = [], []
         t_vals = weights = None
         for lvl in range(num_levels):
-            packed_fwd, packed_bwd = packs[lvl]
+            packed_fwd, packed_bwd = packs[lvl][:2]
+            packed_bf = packs[lvl][2] if len(packs[lvl]) > 2 else None
             if lvl == 0:
                 t_vals, _ = ops.sample_along_rays(rays_o, rays_d, 64, near, far, t_rand, want_coords=False)
             else:
                 t_vals = ops.sample_pdf_t(t_vals, weights, u)
-            raw, planes, masks = ops.mlp_fwd_train(packed_fwd, rays_o, rays_d, viewdirs, t_vals)
+            if packed_bf is not None:
+                raw, planes, masks = ops.mlp_fwd_train(packed_bf, rays_o, rays_d, viewdirs, t_vals, engine="bf16x3")
+            else:
+                raw, planes, masks = ops.mlp_fwd_train(packed_fwd, rays_o, rays_d, viewdirs, t_vals)
             rgb, acc, weights, depth = ops.composite_raw(raw, t_vals, rays_d, white_bkgd, ops.ACT_VANILLA, want_weights=True)
             outs += [rgb, acc, depth]
             saved.append((raw, t_vals, planes, masks, packed_fwd, packed_bwd))

@@ -46,6 +46,9 @@ hipError_t launch_art_bwd_chain(const char* packed_bwd, const float* small, cons
 hipError_t launch_art_wgrad(const float* planes, const float* dplanes, const float* d_raw, const float* dxp, int64_t Np,
                             const float* const* params, const float* shape, const float* app, const float* art,
                             float* const* grads, float* g_shape, float* g_app, float* g_art, float* ws, hipStream_t stream);
+hipError_t launch_mlp_fwd_train_bf16x3(const char* packed, const float* rays_o, const float* rays_d, const float* viewdirs,
+                                       const float* t_vals, int64_t n_rays, int S, float* raw, float* planes, void* masks,
+                                       hipStream_t stream);
 void set_train_engine(int e);
 int get_train_engine();
 int64_t bf16x3_packed_bytes();
@@ -459,6 +462,18 @@ int aon_render_fwd(const void* packed_coarse, const void* packed_fine, const flo
 }
 
 // ---- opt-in split-bf16 engine (fp32-equivalent arithmetic on the bf16 matrix pipe; see aon_mlp_bf16.hip) ----
+int aon_mlp_fwd_train_bf16x3(const void* packed_bf16x3, const float* rays_o, const float* rays_d, const float* viewdirs,
+                             const float* t_vals, int64_t n_rays, int S, float* raw, float* planes, void* masks, void* stream) {
+  if (n_rays < 0 || S < 1) return fail(AON_E_INVALID, "aon_mlp_fwd_train_bf16x3: bad size");
+  if (n_rays == 0) return AON_OK;
+  if (!packed_bf16x3 || !rays_o || !rays_d || !viewdirs || !t_vals || !raw || !planes || !masks)
+    return fail(AON_E_INVALID, "aon_mlp_fwd_train_bf16x3: null pointer");
+  if (reinterpret_cast<uintptr_t>(masks) & 15) return fail(AON_E_INVALID, "aon_mlp_fwd_train_bf16x3: masks must be 16-byte aligned");
+  MlpTimer timer((hipStream_t)stream, n_rays * S);
+  return check(aon::launch_mlp_fwd_train_bf16x3(static_cast<const char*>(packed_bf16x3), rays_o, rays_d, viewdirs, t_vals, n_rays, S,
+                                                raw, planes, masks, (hipStream_t)stream), "aon_mlp_fwd_train_bf16x3");
+}
+
 int aon_set_train_engine(int engine) {
   if (engine != 0 && engine != 1) return fail(AON_E_INVALID, "aon_set_train_engine: engine must be 0 (fp32) or 1 (bf16x3)");
   aon::set_train_engine(engine);

@@ -136,18 +136,26 @@ __device__ __forceinline__ LimbFrag split_step(const f32x16& t, int s8) {
 }
 
 // One (ReLU +) split of a register pair: the unit of VALU work interleaved between MFMA groups.
-template <bool RELU>
-__device__ __forceinline__ void split_pair(const f32x16& t, int pi /*0..7*/, LimbFrag (&f)[2]) {
+// STORE (training forward): the (ReLU'd) fp32 values -- the activation the backward pass needs -- also go to their plane
+// rows, two stores per pair, so a tile's 16 stores ride between the MFMA groups of the chunk that pre-splits it.
+template <bool RELU, bool STORE = false>
+__device__ __forceinline__ void split_pair(const f32x16& t, int pi /*0..7*/, LimbFrag (&f)[2], float* tile_plane = nullptr,
+                                           const PlaneIO* io = nullptr) {
   const int s = pi >> 2, jp = pi & 3;
   float x0 = t[8 * s + 2 * jp], x1 = t[8 * s + 2 * jp + 1];
   if (RELU) {  // plain v_max_f32 (fmaxf would add a canonicalising v_max in front of the real one)
     asm("v_max_f32 %0, 0, %1" : "=v"(x0) : "v"(x0));
     asm("v_max_f32 %0, 0, %1" : "=v"(x1) : "v"(x1));
   }
+  if constexpr (STORE) {
+    const int r0 = 8 * s + 2 * jp, r1 = r0 + 1;
+    *plane_addr(tile_plane, *io, (r0 & 3) + 8 * (r0 >> 2)) = x0;
+    *plane_addr(tile_plane, *io, (r1 & 3) + 8 * (r1 >> 2)) = x1;
+  }
   const unsigned ph = cvt_pk_bf16(x0, x1);
-  const float r0 = x0 - bf16_lo_as_f32(ph), r1 = x1 - bf16_hi_as_f32(ph);
-  const unsigned pm = cvt_pk_bf16(r0, r1);
-  const float q0 = r0 - bf16_lo_as_f32(pm), q1 = r1 - bf16_hi_as_f32(pm);
+  const float r0f = x0 - bf16_lo_as_f32(ph), r1f = x1 - bf16_hi_as_f32(ph);
+  const unsigned pm = cvt_pk_bf16(r0f, r1f);
+  const float q0 = r0f - bf16_lo_as_f32(pm), q1 = r1f - bf16_hi_as_f32(pm);
   f[s].hi[jp] = ph; f[s].mid[jp] = pm; f[s].lo[jp] = cvt_pk_bf16(q0, q1);
 }
 
@@ -163,9 +171,9 @@ __device__ __forceinline__ void issue_round(const Pipe& p, unsigned off, int slo
 
 // Consumes chunk C with the B fragments `b` of the current input tile; meanwhile splits `next` (the input tile of chunk
 // C+1) into `bn`, one register pair per MFMA group, so the VALU work rides in the shadow of the matrix pipe.
-template <int C, int NT_OUT, bool HAS_NEXT, bool RELU_NEXT>
+template <int C, int NT_OUT, bool HAS_NEXT, bool RELU_NEXT, bool TRAIN = false>
 __device__ __forceinline__ void chunk_mma_bf16(Pipe& p, const LimbFrag (&b)[2], f32x16 (&out)[NT_OUT], const f32x16& next,
-                                               LimbFrag (&bn)[2]) {
+                                               LimbFrag (&bn)[2], float* next_plane = nullptr, const PlaneIO* io = nullptr) {
   static_assert(Bf16Net::chunk_bytes(C) == NT_OUT * 6144, "chunk/out-tile mismatch");
   // acquire, with the first A fragments requested BEFORE the next chunk's DMA is issued: their LDS latency then overlaps
   // the twelve DMA issues instead of following them
@@ -200,7 +208,7 @@ __device__ __forceinline__ void chunk_mma_bf16(Pipe& p, const LimbFrag (&b)[2], 
     acc = mfma_bf16(ah, b[s].lo, acc);
     acc = mfma_bf16(am, b[s].mid, acc);
     if (HAS_NEXT) {  // the 8 pair-splits of the next input tile, one per group, finished by mid-chunk
-      if (i < 8) split_pair<RELU_NEXT>(next, i, bn);
+      if (i < 8) split_pair<RELU_NEXT, TRAIN>(next, i, bn, next_plane, io);
     }
     // DMA rounds of the next chunk, spread over the groups (all issued well before this chunk ends)
     if (NSTEP >= ROUNDS) { if (i < ROUNDS) issue_round<CN>(p, dma_off, p.slot ^ 1, i); }
@@ -213,24 +221,27 @@ __device__ __forceinline__ void chunk_mma_bf16(Pipe& p, const LimbFrag (&b)[2], 
   }
 }
 
-template <bool RELU>
-__device__ __forceinline__ void split_tile(const f32x16& t, LimbFrag (&f)[2]) {
+template <bool RELU, bool STORE = false>
+__device__ __forceinline__ void split_tile(const f32x16& t, LimbFrag (&f)[2], float* tile_plane = nullptr, const PlaneIO* io = nullptr) {
 #pragma unroll
-  for (int pi = 0; pi < 8; ++pi) split_pair<RELU>(t, pi, f);
+  for (int pi = 0; pi < 8; ++pi) split_pair<RELU, STORE>(t, pi, f, tile_plane, io);
 }
 
 // 256 -> NT_OUT*32 layer over eight input tiles; `tail` = the tile consumed by the chunk that follows this layer's last
 // chunk (next layer's first input, or an encoding tile), pre-split during the last chunk when HAS_TAIL.
 // On entry `cur` holds the fragments of in[0]; on exit it holds the fragments of `tail` (if HAS_TAIL).
-template <int CBASE, int NT_OUT, bool RELU_IN, bool HAS_TAIL, bool RELU_TAIL>
-__device__ __forceinline__ void layer8_bf16(Pipe& p, LimbFrag (&cur)[2], const f32x16 (&in)[8], f32x16 (&out)[NT_OUT], const f32x16& tail) {
+template <int CBASE, int NT_OUT, bool RELU_IN, bool HAS_TAIL, bool RELU_TAIL, bool TRAIN = false, bool STORE_TAIL = false>
+__device__ __forceinline__ void layer8_bf16(Pipe& p, LimbFrag (&cur)[2], const f32x16 (&in)[8], f32x16 (&out)[NT_OUT], const f32x16& tail,
+                                            float* in_plane = nullptr, const PlaneIO* io = nullptr, int64_t tile_bytes = 0,
+                                            float* tail_plane = nullptr) {
   LimbFrag nxt[2];
-#define AON_BF_STEP(T)                                                                   \
-  chunk_mma_bf16<CBASE + T, NT_OUT, true, RELU_IN>(p, cur, out, in[T + 1], nxt);         \
+  auto tp = [&](int j) { return TRAIN ? reinterpret_cast<float*>(reinterpret_cast<char*>(in_plane) + j * tile_bytes) : nullptr; };
+#define AON_BF_STEP(T)                                                                                     \
+  chunk_mma_bf16<CBASE + T, NT_OUT, true, RELU_IN, TRAIN>(p, cur, out, in[T + 1], nxt, tp(T + 1), io);     \
   cur[0] = nxt[0]; cur[1] = nxt[1];
   AON_BF_STEP(0) AON_BF_STEP(1) AON_BF_STEP(2) AON_BF_STEP(3) AON_BF_STEP(4) AON_BF_STEP(5) AON_BF_STEP(6)
 #undef AON_BF_STEP
-  chunk_mma_bf16<CBASE + 7, NT_OUT, HAS_TAIL, RELU_TAIL>(p, cur, out, tail, nxt);
+  chunk_mma_bf16<CBASE + 7, NT_OUT, HAS_TAIL, RELU_TAIL, STORE_TAIL>(p, cur, out, tail, nxt, tail_plane, io);
   if (HAS_TAIL) { cur[0] = nxt[0]; cur[1] = nxt[1]; }
 }
 
@@ -259,8 +270,12 @@ struct BfArgs {
   const float* rays_o; const float* rays_d; const float* viewdirs; const float* t_vals;
   float* raw;
   int64_t total; int S; int npass;
+  float* planes;   // [TRAIN] kPlRows x Np feature-major activation planes (layout of aon_mlp.hip's training forward)
+  u32x4* masks;    // [TRAIN] kMaskLayers x (Np*2) ReLU bit masks
+  int64_t Np;
 };
 
+template <bool TRAIN>
 __global__ void __launch_bounds__(256) mlp_fwd_bf16x3_kernel(BfArgs args) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* sm = reinterpret_cast<float*>(smem + kBfRingBytes);
@@ -283,6 +298,13 @@ __global__ void __launch_bounds__(256) mlp_fwd_bf16x3_kernel(BfArgs args) {
     // The 63-wide encoding is needed at layer 0 and again at the skip layer 5: it is parked in LDS (32 floats per lane)
     // instead of occupying 32 VGPRs through layers 1-4; the view encoding is computed only when the view layer needs it.
     float vd[3];
+    PlaneIO io{};
+    if constexpr (TRAIN) io = make_plane_io(args.Np, g, h);
+    auto rows = [&](int row) { return reinterpret_cast<float*>(reinterpret_cast<char*>(args.planes) + (int64_t)row * io.row_bytes); };
+    const int64_t tile_bytes = 32 * io.row_bytes;
+    auto mask = [&](auto& tiles, int layer) {
+      if constexpr (TRAIN) args.masks[(int64_t)layer * args.Np * 2 + (int64_t)pass * 256 + tid] = relu_mask_bits(tiles);
+    };
     f32x4* stash = reinterpret_cast<f32x4*>(smem + kBfRingBytes + ((kSmallBytes + 15) / 16) * 16) + (wave * 2 * 64 + lane) * 4;
     auto load_enc = [&](int tile) {
       f32x16 e;
@@ -303,6 +325,7 @@ __global__ void __launch_bounds__(256) mlp_fwd_bf16x3_kernel(BfArgs args) {
       }
       f32x16 E[2];
       encode_pos(x, h, E);
+      if constexpr (TRAIN) store_pos_enc_plane(E, rows(kPlE), io, g, h);
 #pragma unroll
       for (int tile = 0; tile < 2; ++tile)
 #pragma unroll
@@ -315,6 +338,8 @@ __global__ void __launch_bounds__(256) mlp_fwd_bf16x3_kernel(BfArgs args) {
     // `cur` always holds the limb fragments of the tile the next chunk consumes; each chunk pre-splits its successor's
     // tile between its own MFMA groups.  A layer's first input tile depends on the previous layer's LAST chunk, so it
     // is split at the layer boundary (the only exposed VALU work besides the bias initialisation).
+    // [TRAIN] the (ReLU'd) fp32 value of every tile is stored to its plane rows by the split that consumes it; the ReLU
+    // decisions go out as bit masks (sign of the pre-activation) right after each layer.
     f32x16 X[8], Y[8];
     LimbFrag cur[2], nxt[2];
     {
@@ -324,31 +349,46 @@ __global__ void __launch_bounds__(256) mlp_fwd_bf16x3_kernel(BfArgs args) {
       chunk_mma_bf16<kChL0 + 0, 8, true, false>(p, cur, X, e1, nxt); cur[0] = nxt[0]; cur[1] = nxt[1];
       chunk_mma_bf16<kChL0 + 1, 8, false, false>(p, cur, X, e1, nxt);
     }
-    split_tile<true>(X[0], cur); init_bias(Y, sm + kSmBias + 1 * 256, h); layer8_bf16<kChL1 + 0, 8, true, false, false>(p, cur, X, Y, X[0]);
-    split_tile<true>(Y[0], cur); init_bias(X, sm + kSmBias + 2 * 256, h); layer8_bf16<kChL1 + 8, 8, true, false, false>(p, cur, Y, X, Y[0]);
-    split_tile<true>(X[0], cur); init_bias(Y, sm + kSmBias + 3 * 256, h); layer8_bf16<kChL1 + 16, 8, true, false, false>(p, cur, X, Y, X[0]);
-    split_tile<true>(Y[0], cur); init_bias(X, sm + kSmBias + 4 * 256, h); layer8_bf16<kChL1 + 24, 8, true, false, false>(p, cur, Y, X, Y[0]);
+    mask(X, 0);
+    split_tile<true, TRAIN>(X[0], cur, rows(plane_h(0)), &io); init_bias(Y, sm + kSmBias + 1 * 256, h);
+    layer8_bf16<kChL1 + 0, 8, true, false, false, TRAIN>(p, cur, X, Y, X[0], rows(plane_h(0)), &io, tile_bytes); mask(Y, 1);
+    split_tile<true, TRAIN>(Y[0], cur, rows(plane_h(1)), &io); init_bias(X, sm + kSmBias + 2 * 256, h);
+    layer8_bf16<kChL1 + 8, 8, true, false, false, TRAIN>(p, cur, Y, X, Y[0], rows(plane_h(1)), &io, tile_bytes); mask(X, 2);
+    split_tile<true, TRAIN>(X[0], cur, rows(plane_h(2)), &io); init_bias(Y, sm + kSmBias + 3 * 256, h);
+    layer8_bf16<kChL1 + 16, 8, true, false, false, TRAIN>(p, cur, X, Y, X[0], rows(plane_h(2)), &io, tile_bytes); mask(Y, 3);
+    split_tile<true, TRAIN>(Y[0], cur, rows(plane_h(3)), &io); init_bias(X, sm + kSmBias + 4 * 256, h);
+    layer8_bf16<kChL1 + 24, 8, true, false, false, TRAIN>(p, cur, Y, X, Y[0], rows(plane_h(3)), &io, tile_bytes); mask(X, 4);
     // L5: cat[relu(h4) (8 tiles), enc (2 tiles)]
-    split_tile<true>(X[0], cur); init_bias(Y, sm + kSmBias + 5 * 256, h);
+    split_tile<true, TRAIN>(X[0], cur, rows(plane_h(4)), &io); init_bias(Y, sm + kSmBias + 5 * 256, h);
     {
       const f32x16 e0 = load_enc(0);
-      layer8_bf16<kChL5, 8, true, true, false>(p, cur, X, Y, e0);
+      layer8_bf16<kChL5, 8, true, true, false, TRAIN, false>(p, cur, X, Y, e0, rows(plane_h(4)), &io, tile_bytes);
       const f32x16 e1 = load_enc(1);
       chunk_mma_bf16<kChL5 + 8, 8, true, false>(p, cur, Y, e1, nxt); cur[0] = nxt[0]; cur[1] = nxt[1];
       chunk_mma_bf16<kChL5 + 9, 8, false, false>(p, cur, Y, e1, nxt);
     }
-    split_tile<true>(Y[0], cur); init_bias(X, sm + kSmBias + 6 * 256, h); layer8_bf16<kChL6, 8, true, false, false>(p, cur, Y, X, Y[0]);
-    split_tile<true>(X[0], cur); init_bias(Y, sm + kSmBias + 7 * 256, h); layer8_bf16<kChL7, 8, true, false, false>(p, cur, X, Y, X[0]);
+    mask(Y, 5);
+    split_tile<true, TRAIN>(Y[0], cur, rows(plane_h(5)), &io); init_bias(X, sm + kSmBias + 6 * 256, h);
+    layer8_bf16<kChL6, 8, true, false, false, TRAIN>(p, cur, Y, X, Y[0], rows(plane_h(5)), &io, tile_bytes); mask(X, 6);
+    split_tile<true, TRAIN>(X[0], cur, rows(plane_h(6)), &io); init_bias(Y, sm + kSmBias + 7 * 256, h);
+    layer8_bf16<kChL7, 8, true, false, false, TRAIN>(p, cur, X, Y, X[0], rows(plane_h(6)), &io, tile_bytes); mask(Y, 7);
     float sigma = head_partial_relu<8>(Y, sm + kSmWSigma, h);  // density head on relu(layer 7)
     sigma = sigma + __shfl_xor(sigma, 32) + sm[kSmBSigma];
     // bottleneck: input relu(h7), output linear
-    split_tile<true>(Y[0], cur); init_bias(X, sm + kSmBiasBott, h); layer8_bf16<kChBott, 8, true, false, false>(p, cur, Y, X, Y[0]);
+    split_tile<true, TRAIN>(Y[0], cur, rows(plane_h(7)), &io); init_bias(X, sm + kSmBiasBott, h);
+    layer8_bf16<kChBott, 8, true, false, false, TRAIN>(p, cur, Y, X, Y[0], rows(plane_h(7)), &io, tile_bytes);
     // view layer: cat[bottleneck (8 tiles, no activation), viewenc (1 tile)]
     f32x16 Z[4], V;
     encode_view(vd, h, V);
-    split_tile<false>(X[0], cur); init_bias(Z, sm + kSmBiasView, h);
-    layer8_bf16<kChView, 4, false, true, false>(p, cur, X, Z, V);
+    if constexpr (TRAIN) store_view_enc_plane(V, rows(kPlVE), io, g, h);
+    split_tile<false, TRAIN>(X[0], cur, rows(kPlBot), &io); init_bias(Z, sm + kSmBiasView, h);
+    layer8_bf16<kChView, 4, false, true, false, TRAIN, false>(p, cur, X, Z, V, rows(kPlBot), &io, tile_bytes);
     chunk_mma_bf16<kChView + 8, 4, false, false>(p, cur, Z, V, nxt);
+    if constexpr (TRAIN) {
+      mask(Z, 8);
+      relu_tiles(Z);
+      store_plane(Z, rows(kPlHV), io);
+    }
     float rgb[3];
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) {
@@ -378,22 +418,37 @@ hipError_t launch_pack_vanilla_bf16x3(const float* const* params, char* packed, 
   return hipGetLastError();
 }
 
-hipError_t launch_mlp_fwd_bf16x3(const char* packed, const float* rays_o, const float* rays_d, const float* viewdirs,
-                                 const float* t_vals, int64_t n_rays, int S, float* raw, hipStream_t stream) {
+template <bool TRAIN>
+static hipError_t launch_bf16x3_t(BfArgs a, hipStream_t stream) {
   static bool attr = false;
   if (!attr) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fwd_bf16x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fwd_bf16x3_kernel<TRAIN>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        kBfLdsBytes);
     if (e != hipSuccess) return e;
     attr = true;
   }
-  BfArgs a{packed, rays_o, rays_d, viewdirs, t_vals, raw, n_rays * S, S, (int)((n_rays * S + 127) / 128)};
   const int cus = num_cus();
   if (cus <= 0) return hipErrorInvalidDevice;
   const int grid = a.npass < cus ? a.npass : cus;
   if (grid <= 0) return hipSuccess;
-  mlp_fwd_bf16x3_kernel<<<dim3(grid), dim3(256), kBfLdsBytes, stream>>>(a);
+  mlp_fwd_bf16x3_kernel<TRAIN><<<dim3(grid), dim3(256), kBfLdsBytes, stream>>>(a);
   return hipGetLastError();
+}
+
+hipError_t launch_mlp_fwd_bf16x3(const char* packed, const float* rays_o, const float* rays_d, const float* viewdirs,
+                                 const float* t_vals, int64_t n_rays, int S, float* raw, hipStream_t stream) {
+  BfArgs a{packed, rays_o, rays_d, viewdirs, t_vals, raw, n_rays * S, S, (int)((n_rays * S + 127) / 128), nullptr, nullptr, 0};
+  return launch_bf16x3_t<false>(a, stream);
+}
+
+// training forward of the bf16x3 engine: same planes / masks contract as launch_mlp_fwd_train (aon_mlp.hip)
+hipError_t launch_mlp_fwd_train_bf16x3(const char* packed, const float* rays_o, const float* rays_d, const float* viewdirs,
+                                       const float* t_vals, int64_t n_rays, int S, float* raw, float* planes, void* masks,
+                                       hipStream_t stream) {
+  BfArgs a{packed, rays_o, rays_d, viewdirs, t_vals, raw, n_rays * S, S, (int)((n_rays * S + 127) / 128), planes,
+           static_cast<u32x4*>(masks), 0};
+  a.Np = (int64_t)a.npass * 128;
+  return launch_bf16x3_t<true>(a, stream);
 }
 
 }  // namespace aon

@@ -137,7 +137,10 @@ class NeRF(nn.Module):
             if n == 0:
                 raise ValueError("empty ray batch in training mode")
             mlps = [self.coarse_mlp, self.fine_mlp][: self.num_levels]
-            packs = [(m.packed(), m.packed_bwd()) for m in mlps]
+            if ops.get_train_engine() == "bf16x3":   # opt-in: split-bf16 training forward + weight gradients
+                packs = [(m.packed(), m.packed_bwd(), m.packed_bf16x3()) for m in mlps]
+            else:
+                packs = [(m.packed(), m.packed_bwd()) for m in mlps]
             params = [p for m in mlps for p in m.ordered_params()]
             flat = RenderVanilla.apply(rays_o, rays["rays_d"], rays["viewdirs"], float(near), float(far), bool(white_bkgd),
                                        self.num_levels, t_rand, u, packs, *params)

@@ -462,9 +462,9 @@ def padded_samples(n_samples: int) -> int:
     return (n_samples + 127) // 128 * 128
 
 
-def mlp_fwd_train(packed, rays_o, rays_d, viewdirs, t_vals):
+def mlp_fwd_train(packed, rays_o, rays_d, viewdirs, t_vals, engine: str = "fp32"):
     """Fused forward that also stores the feature-major activation planes and the ReLU bit masks
-    -> (raw (n,S,4), planes (rows, Np), masks)."""
+    -> (raw (n,S,4), planes (rows, Np), masks).  engine "bf16x3": `packed` is the stream of pack_vanilla_mlp_bf16x3."""
     o, d, v, t = _f32(rays_o, "rays_o"), _f32(rays_d, "rays_d"), _f32(viewdirs, "viewdirs"), _f32(t_vals, "t_vals")
     n, S = t.shape
     Np = padded_samples(n * S)
@@ -474,8 +474,8 @@ def mlp_fwd_train(packed, rays_o, rays_d, viewdirs, t_vals):
     planes = torch.empty((int(lib.aon_train_plane_rows()), Np), dtype=torch.float32, device=t.device)
     masks = torch.empty(int(lib.aon_train_mask_bytes(Np)), dtype=torch.uint8, device=t.device)
     with torch.cuda.device(t.device):
-        check(lib.aon_mlp_fwd_train(_ptr(packed), _ptr(o), _ptr(d), _ptr(v), _ptr(t), n, S, _ptr(raw), _ptr(planes), _ptr(masks),
-                                    _stream()), "aon_mlp_fwd_train")
+        fn = lib.aon_mlp_fwd_train if engine == "fp32" else lib.aon_mlp_fwd_train_bf16x3
+        check(fn(_ptr(packed), _ptr(o), _ptr(d), _ptr(v), _ptr(t), n, S, _ptr(raw), _ptr(planes), _ptr(masks), _stream()), "aon_mlp_fwd_train")
     return raw, planes, masks
 
 

@@ -3,6 +3,7 @@ it evaluates every fp32 product as six bf16 limb products accumulated in fp32, s
 the network is of the fp32 kernel's class (measured: rgb max 2.3e-7 vs 2.6e-7)."""
 import math
 
+import numpy as np
 import pytest
 import torch
 
@@ -93,5 +94,38 @@ def test_bf16x3_train_engine_gradients(dev, nerf_sd, n, S, n_art, S_art):
         assert ops.get_train_engine() == "bf16x3"
         vanilla_level(dev, nerf_sd, n, S)
         art_level(dev, n_art, S_art)   # the cases the fp32 engine is held to (tests/test_hip_training_art.py)
+    finally:
+        ops.set_train_engine("fp32")
+
+
+def test_bf16x3_training_forward_planes_and_module_gradients(dev, nerf_sd):
+    """The bf16x3 training forward writes the same planes / masks / raw outputs as the fp32 one (to fp32-class
+    differences), and a full training step through the module on the bf16x3 engine meets the fp32 engine's gradient
+    tolerances against the oracle's autograd."""
+    import aon_amd.synthetic as syn
+    from aon_amd import ops
+    from test_hip_training import test_training_step_gradients_vs_oracle_autograd as step_vs_oracle
+
+    n, S = 37, 193
+    params = {k[len("fine_mlp."):]: v.to(dev) for k, v in nerf_sd.items() if k.startswith("fine_mlp.")}
+    pk, pb = ops.pack_vanilla_mlp(params), ops.pack_vanilla_mlp_bf16x3(params)
+    rays = {k: v.to(dev) for k, v in syn.random_rays(n, seed=5).items()}
+    t = torch.sort(torch.rand(n, S, generator=torch.Generator().manual_seed(5)) * 4 + 2, dim=-1).values.to(dev)
+    raw_a, pl_a, mk_a = ops.mlp_fwd_train(pk, rays["rays_o"], rays["rays_d"], rays["viewdirs"], t)
+    raw_b, pl_b, mk_b = ops.mlp_fwd_train(pb, rays["rays_o"], rays["rays_d"], rays["viewdirs"], t, engine="bf16x3")
+    torch.testing.assert_close(raw_b[..., :3], raw_a[..., :3], rtol=2e-5, atol=2e-5)
+    torch.testing.assert_close(raw_b[..., 3], raw_a[..., 3], rtol=2e-5, atol=2e-3)   # density head x30
+    valid = n * S
+    rows_written = [r for r in range(pl_a.shape[0]) if r not in (63,) + tuple(range(2368 + 27, 2400))]   # encoding pad rows are never written
+    da = (pl_a[rows_written][:, :valid] - pl_b[rows_written][:, :valid]).abs()
+    assert da.max().item() <= 5e-5 * max(1.0, pl_a[rows_written][:, :valid].abs().max().item()), da.max().item()
+    diff = (mk_a.view(torch.uint8) ^ mk_b.view(torch.uint8)).cpu().numpy()
+    flipped = int(np.unpackbits(diff).sum())   # ReLU decisions that differ: pre-activations within rounding of zero
+    assert flipped <= 1e-3 * diff.size * 8, (flipped, diff.size * 8)
+    assert ops.get_train_engine() == "fp32"
+    ops.set_train_engine("bf16x3")
+    try:
+        step_vs_oracle(dev, False, True, 30.0)
+        step_vs_oracle(dev, True, False, 5.0)
     finally:
         ops.set_train_engine("fp32")
