@@ -36,6 +36,9 @@ _SIGS = {
     "aon_composite": (_i, [_p, _i, _p, _i, _p, _p, _l, _i, _i, _i, _p, _p, _p, _p, _p]),
     "aon_sample_pdf": (_i, [_p, _p, _l, _p, _p, _l, _l, _p, _p, _p]),
     "aon_set_train_engine": (_i, [_i]),
+    "aon_bwd_bf16x3_packed_bytes": (_l, []),
+    "aon_pack_vanilla_mlp_bwd_bf16x3": (_i, [_p, _p, _p]),
+    "aon_mlp_bwd_chain_bf16x3": (_i, [_p, _p, _p, _p, _p, _l, _p]),
     "aon_mlp_fwd_train_bf16x3": (_i, [_p, _p, _p, _p, _p, _l, _i, _p, _p, _p, _p]),
     "aon_get_train_engine": (_i, []),
     "aon_bf16x3_packed_bytes": (_l, []),

@@ -14,13 +14,15 @@ from . import ops
 class RenderVanilla(torch.autograd.Function):
     @staticmethod
     def forward(ctx, rays_o, rays_d, viewdirs, near, far, white_bkgd, num_levels, t_rand, u, packs, *params):
-        # packs: [(packed_fwd, packed_bwd[, packed_bf16x3])] per level; params: 24 tensors per level in ops.VANILLA_PARAM_ORDER
-        # (a third element selects the bf16x3 training forward; the fp32 stream is still needed by the backward chain)
+        # packs: [(packed_fwd, packed_bwd[, packed_bf16x3, packed_bwd_bf16x3])] per level; params: 24 tensors per level in
+        # ops.VANILLA_PARAM_ORDER.  The optional elements select the bf16x3 training forward / backward chain; the fp32
+        # forward stream is still read by the backward chain for its head weights.
         saved, outs = [], []
         t_vals = weights = None
         for lvl in range(num_levels):
             packed_fwd, packed_bwd = packs[lvl][:2]
             packed_bf = packs[lvl][2] if len(packs[lvl]) > 2 else None
+            packed_bwd_bf = packs[lvl][3] if len(packs[lvl]) > 3 else None
             if lvl == 0:
                 t_vals, _ = ops.sample_along_rays(rays_o, rays_d, 64, near, far, t_rand, want_coords=False)
             else:
@@ -31,7 +33,7 @@ class RenderVanilla(torch.autograd.Function):
                 raw, planes, masks = ops.mlp_fwd_train(packed_fwd, rays_o, rays_d, viewdirs, t_vals)
             rgb, acc, weights, depth = ops.composite_raw(raw, t_vals, rays_d, white_bkgd, ops.ACT_VANILLA, want_weights=True)
             outs += [rgb, acc, depth]
-            saved.append((raw, t_vals, planes, masks, packed_fwd, packed_bwd))
+            saved.append((raw, t_vals, planes, masks, packed_fwd, packed_bwd, packed_bwd_bf))
         ctx.saved = saved
         ctx.rays_d = rays_d
         ctx.white_bkgd = white_bkgd
@@ -42,13 +44,16 @@ class RenderVanilla(torch.autograd.Function):
     def backward(ctx, *gouts):
         grads = []
         for lvl in range(ctx.num_levels):
-            raw, t_vals, planes, masks, packed_fwd, packed_bwd = ctx.saved[lvl]
+            raw, t_vals, planes, masks, packed_fwd, packed_bwd, packed_bwd_bf = ctx.saved[lvl]
             g_rgb, g_acc, g_depth = gouts[3 * lvl: 3 * lvl + 3]
             if g_rgb is None:
                 g_rgb = torch.zeros((t_vals.shape[0], 3), dtype=torch.float32, device=t_vals.device)
             d_raw = ops.composite_bwd(raw, t_vals, ctx.rays_d, g_rgb.contiguous(), g_acc, g_depth, ctx.white_bkgd, ops.ACT_VANILLA,
                                       planes.shape[1])
-            dplanes = ops.mlp_bwd_chain(packed_bwd, packed_fwd, d_raw, masks, planes.shape)
+            if packed_bwd_bf is not None:
+                dplanes = ops.mlp_bwd_chain(packed_bwd_bf, packed_fwd, d_raw, masks, planes.shape, engine="bf16x3")
+            else:
+                dplanes = ops.mlp_bwd_chain(packed_bwd, packed_fwd, d_raw, masks, planes.shape)
             g = ops.vanilla_wgrad(planes, dplanes, d_raw)
             grads += [g[name] for name in ops.VANILLA_PARAM_ORDER]
             del dplanes

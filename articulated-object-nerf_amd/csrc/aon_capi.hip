@@ -49,6 +49,10 @@ hipError_t launch_art_wgrad(const float* planes, const float* dplanes, const flo
 hipError_t launch_mlp_fwd_train_bf16x3(const char* packed, const float* rays_o, const float* rays_d, const float* viewdirs,
                                        const float* t_vals, int64_t n_rays, int S, float* raw, float* planes, void* masks,
                                        hipStream_t stream);
+int64_t bwd_bf16x3_stream_bytes();
+hipError_t launch_pack_vanilla_bwd_bf16x3(const float* const* params, char* packed, hipStream_t stream);
+hipError_t launch_mlp_bwd_chain_bf16x3(const char* packed_bwd, const float* packed_fwd_small, const float* d_raw, const void* masks,
+                                       float* dplanes, int64_t Np, hipStream_t stream);
 void set_train_engine(int e);
 int get_train_engine();
 int64_t bf16x3_packed_bytes();
@@ -472,6 +476,27 @@ int aon_mlp_fwd_train_bf16x3(const void* packed_bf16x3, const float* rays_o, con
   MlpTimer timer((hipStream_t)stream, n_rays * S);
   return check(aon::launch_mlp_fwd_train_bf16x3(static_cast<const char*>(packed_bf16x3), rays_o, rays_d, viewdirs, t_vals, n_rays, S,
                                                 raw, planes, masks, (hipStream_t)stream), "aon_mlp_fwd_train_bf16x3");
+}
+
+int64_t aon_bwd_bf16x3_packed_bytes(void) { return aon::bwd_bf16x3_stream_bytes(); }
+
+int aon_pack_vanilla_mlp_bwd_bf16x3(const float* const* params_host, void* packed_bwd, void* stream) {
+  if (!params_host || !packed_bwd) return fail(AON_E_INVALID, "aon_pack_vanilla_mlp_bwd_bf16x3: null pointer");
+  for (int i = 0; i < aon::kNumVanillaParams; ++i)
+    if (!params_host[i]) return fail(AON_E_INVALID, "aon_pack_vanilla_mlp_bwd_bf16x3: null parameter pointer");
+  if (reinterpret_cast<uintptr_t>(packed_bwd) & 15) return fail(AON_E_INVALID, "aon_pack_vanilla_mlp_bwd_bf16x3: buffer must be 16-byte aligned");
+  return check(aon::launch_pack_vanilla_bwd_bf16x3(params_host, static_cast<char*>(packed_bwd), (hipStream_t)stream),
+               "aon_pack_vanilla_mlp_bwd_bf16x3");
+}
+
+int aon_mlp_bwd_chain_bf16x3(const void* packed_bwd_bf16x3, const void* packed_fwd, const float* d_raw, const void* masks,
+                             float* dplanes, int64_t Np, void* stream) {
+  if (Np < 0 || (Np & 127)) return fail(AON_E_INVALID, "aon_mlp_bwd_chain_bf16x3: Np must be a multiple of 128");
+  if (Np == 0) return AON_OK;
+  if (!packed_bwd_bf16x3 || !packed_fwd || !d_raw || !masks || !dplanes) return fail(AON_E_INVALID, "aon_mlp_bwd_chain_bf16x3: null pointer");
+  const float* small = reinterpret_cast<const float*>(static_cast<const char*>(packed_fwd) + aon::kStreamBytes);
+  return check(aon::launch_mlp_bwd_chain_bf16x3(static_cast<const char*>(packed_bwd_bf16x3), small, d_raw, masks, dplanes, Np,
+                                                (hipStream_t)stream), "aon_mlp_bwd_chain_bf16x3");
 }
 
 int aon_set_train_engine(int engine) {

@@ -138,17 +138,23 @@ __device__ __forceinline__ LimbFrag split_step(const f32x16& t, int s8) {
 // One (ReLU +) split of a register pair: the unit of VALU work interleaved between MFMA groups.
 // STORE (training forward): the (ReLU'd) fp32 values -- the activation the backward pass needs -- also go to their plane
 // rows, two stores per pair, so a tile's 16 stores ride between the MFMA groups of the chunk that pre-splits it.
-template <bool RELU, bool STORE = false>
+// PRE: what happens to the fp32 values before the split -- 0 nothing, 1 ReLU (forward), 2 multiply by the forward's ReLU
+// decision bits (backward: dZ = relu'(Z) * dH; `bits` holds the 16 decisions of this tile, bit r <-> register r).
+template <int PRE, bool STORE = false>
 __device__ __forceinline__ void split_pair(const f32x16& t, int pi /*0..7*/, LimbFrag (&f)[2], float* tile_plane = nullptr,
-                                           const PlaneIO* io = nullptr) {
+                                           const PlaneIO* io = nullptr, unsigned bits = 0u) {
   const int s = pi >> 2, jp = pi & 3;
-  float x0 = t[8 * s + 2 * jp], x1 = t[8 * s + 2 * jp + 1];
-  if (RELU) {  // plain v_max_f32 (fmaxf would add a canonicalising v_max in front of the real one)
+  const int r0 = 8 * s + 2 * jp, r1 = r0 + 1;
+  float x0 = t[r0], x1 = t[r1];
+  if (PRE == 1) {  // plain v_max_f32 (fmaxf would add a canonicalising v_max in front of the real one)
     asm("v_max_f32 %0, 0, %1" : "=v"(x0) : "v"(x0));
     asm("v_max_f32 %0, 0, %1" : "=v"(x1) : "v"(x1));
   }
+  if (PRE == 2) {
+    x0 = ((bits >> r0) & 1u) ? x0 : 0.f;
+    x1 = ((bits >> r1) & 1u) ? x1 : 0.f;
+  }
   if constexpr (STORE) {
-    const int r0 = 8 * s + 2 * jp, r1 = r0 + 1;
     *plane_addr(tile_plane, *io, (r0 & 3) + 8 * (r0 >> 2)) = x0;
     *plane_addr(tile_plane, *io, (r1 & 3) + 8 * (r1 >> 2)) = x1;
   }
@@ -161,36 +167,37 @@ __device__ __forceinline__ void split_pair(const f32x16& t, int pi /*0..7*/, Lim
 
 // One 1-KiB-per-wave round of the LDS-DMA of chunk C (see issue_chunk): issued one per MFMA group so that the twelve
 // address-setup + issue sequences ride between MFMAs instead of forming a serial block at the chunk boundary.
-template <int C>
+template <class Net>
 __device__ __forceinline__ void issue_round(const Pipe& p, unsigned off, int slot, int r) {
   gbl_char* src = (gbl_char*)(p.stream + off);
-  char* dst = p.ring + slot * Bf16Net::kSlotBytes + p.wave_off;
+  char* dst = p.ring + slot * Net::kSlotBytes + p.wave_off;
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + r * 4096 + p.voff),
                                    (lds_void*)(dst + r * 4096), 16, 0, 0);
 }
 
 // Consumes chunk C with the B fragments `b` of the current input tile; meanwhile splits `next` (the input tile of chunk
 // C+1) into `bn`, one register pair per MFMA group, so the VALU work rides in the shadow of the matrix pipe.
-template <int C, int NT_OUT, bool HAS_NEXT, bool RELU_NEXT, bool TRAIN = false>
+template <int C, int NT_OUT, bool HAS_NEXT, int PRE_NEXT, bool TRAIN = false, class Net = Bf16Net>
 __device__ __forceinline__ void chunk_mma_bf16(Pipe& p, const LimbFrag (&b)[2], f32x16 (&out)[NT_OUT], const f32x16& next,
-                                               LimbFrag (&bn)[2], float* next_plane = nullptr, const PlaneIO* io = nullptr) {
-  static_assert(Bf16Net::chunk_bytes(C) == NT_OUT * 6144, "chunk/out-tile mismatch");
+                                               LimbFrag (&bn)[2], float* next_plane = nullptr, const PlaneIO* io = nullptr,
+                                               unsigned next_bits = 0u) {
+  static_assert(Net::chunk_bytes(C) == NT_OUT * 6144, "chunk/out-tile mismatch");
   // acquire, with the first A fragments requested BEFORE the next chunk's DMA is issued: their LDS latency then overlaps
   // the twelve DMA issues instead of following them
   __syncthreads();
   p.slot ^= 1;
-  const char* buf = p.ring + p.slot * Bf16Net::kSlotBytes + p.lane_off;
+  const char* buf = p.ring + p.slot * Net::kSlotBytes + p.lane_off;
   // (round-1 experiment: alternating two accumulators per group -- to dodge a dependent-accumulator latency -- measured
   //  slower than this single-accumulator chain; the six limb products of one output tile are issued back to back.)
   constexpr int NSTEP = 2 * NT_OUT;
   u32x4 ah = *reinterpret_cast<const u32x4*>(buf);
   u32x4 am = *reinterpret_cast<const u32x4*>(buf + 1024);
   u32x4 al = *reinterpret_cast<const u32x4*>(buf + 2048);
-  constexpr int CN = (C + 1) % Bf16Net::kNumChunks;           // chunk streamed in while this one is consumed
-  constexpr int ROUNDS = Bf16Net::chunk_bytes(CN) / 4096;     // 12 or 6
+  constexpr int CN = (C + 1) % Net::kNumChunks;           // chunk streamed in while this one is consumed
+  constexpr int ROUNDS = Net::chunk_bytes(CN) / 4096;     // 12 or 6
   unsigned dma_off = p.issue_off;
   asm volatile("" : "+s"(dma_off));
-  p.issue_off = (CN == Bf16Net::kNumChunks - 1) ? 0u : dma_off + (unsigned)Bf16Net::chunk_bytes(CN);
+  p.issue_off = (CN == Net::kNumChunks - 1) ? 0u : dma_off + (unsigned)Net::chunk_bytes(CN);
 #pragma unroll
   for (int i = 0; i < NSTEP; ++i) {
     const int s = i / NT_OUT, tp = i % NT_OUT;
@@ -208,11 +215,11 @@ __device__ __forceinline__ void chunk_mma_bf16(Pipe& p, const LimbFrag (&b)[2], 
     acc = mfma_bf16(ah, b[s].lo, acc);
     acc = mfma_bf16(am, b[s].mid, acc);
     if (HAS_NEXT) {  // the 8 pair-splits of the next input tile, one per group, finished by mid-chunk
-      if (i < 8) split_pair<RELU_NEXT, TRAIN>(next, i, bn, next_plane, io);
+      if (i < 8) split_pair<PRE_NEXT, TRAIN>(next, i, bn, next_plane, io, next_bits);
     }
     // DMA rounds of the next chunk, spread over the groups (all issued well before this chunk ends)
-    if (NSTEP >= ROUNDS) { if (i < ROUNDS) issue_round<CN>(p, dma_off, p.slot ^ 1, i); }
-    else { if (2 * i < ROUNDS) issue_round<CN>(p, dma_off, p.slot ^ 1, 2 * i); if (2 * i + 1 < ROUNDS) issue_round<CN>(p, dma_off, p.slot ^ 1, 2 * i + 1); }
+    if (NSTEP >= ROUNDS) { if (i < ROUNDS) issue_round<Net>(p, dma_off, p.slot ^ 1, i); }
+    else { if (2 * i < ROUNDS) issue_round<Net>(p, dma_off, p.slot ^ 1, 2 * i); if (2 * i + 1 < ROUNDS) issue_round<Net>(p, dma_off, p.slot ^ 1, 2 * i + 1); }
     acc = mfma_bf16(am, b[s].hi, acc);
     acc = mfma_bf16(ah, b[s].mid, acc);
     acc = mfma_bf16(ah, b[s].hi, acc);
@@ -221,27 +228,31 @@ __device__ __forceinline__ void chunk_mma_bf16(Pipe& p, const LimbFrag (&b)[2], 
   }
 }
 
-template <bool RELU, bool STORE = false>
-__device__ __forceinline__ void split_tile(const f32x16& t, LimbFrag (&f)[2], float* tile_plane = nullptr, const PlaneIO* io = nullptr) {
+template <int PRE, bool STORE = false>
+__device__ __forceinline__ void split_tile(const f32x16& t, LimbFrag (&f)[2], float* tile_plane = nullptr, const PlaneIO* io = nullptr,
+                                           unsigned bits = 0u) {
 #pragma unroll
-  for (int pi = 0; pi < 8; ++pi) split_pair<RELU, STORE>(t, pi, f, tile_plane, io);
+  for (int pi = 0; pi < 8; ++pi) split_pair<PRE, STORE>(t, pi, f, tile_plane, io, bits);
 }
+
+// the 16 ReLU decisions of tile t inside a layer's mask word (relu_mask_bits layout)
+__device__ __forceinline__ unsigned tile_bits(const u32x4 w, int t) { return (w[t >> 1] >> ((t & 1) * 16)) & 0xffffu; }
 
 // 256 -> NT_OUT*32 layer over eight input tiles; `tail` = the tile consumed by the chunk that follows this layer's last
 // chunk (next layer's first input, or an encoding tile), pre-split during the last chunk when HAS_TAIL.
 // On entry `cur` holds the fragments of in[0]; on exit it holds the fragments of `tail` (if HAS_TAIL).
-template <int CBASE, int NT_OUT, bool RELU_IN, bool HAS_TAIL, bool RELU_TAIL, bool TRAIN = false, bool STORE_TAIL = false>
+template <int CBASE, int NT_OUT, int PRE_IN, bool HAS_TAIL, int PRE_TAIL, bool TRAIN = false, bool STORE_TAIL = false, class Net = Bf16Net>
 __device__ __forceinline__ void layer8_bf16(Pipe& p, LimbFrag (&cur)[2], const f32x16 (&in)[8], f32x16 (&out)[NT_OUT], const f32x16& tail,
                                             float* in_plane = nullptr, const PlaneIO* io = nullptr, int64_t tile_bytes = 0,
-                                            float* tail_plane = nullptr) {
+                                            float* tail_plane = nullptr, const u32x4 in_mask = u32x4{0u, 0u, 0u, 0u}) {
   LimbFrag nxt[2];
   auto tp = [&](int j) { return TRAIN ? reinterpret_cast<float*>(reinterpret_cast<char*>(in_plane) + j * tile_bytes) : nullptr; };
-#define AON_BF_STEP(T)                                                                                     \
-  chunk_mma_bf16<CBASE + T, NT_OUT, true, RELU_IN, TRAIN>(p, cur, out, in[T + 1], nxt, tp(T + 1), io);     \
+#define AON_BF_STEP(T)                                                                                                          \
+  chunk_mma_bf16<CBASE + T, NT_OUT, true, PRE_IN, TRAIN, Net>(p, cur, out, in[T + 1], nxt, tp(T + 1), io, tile_bits(in_mask, T + 1)); \
   cur[0] = nxt[0]; cur[1] = nxt[1];
   AON_BF_STEP(0) AON_BF_STEP(1) AON_BF_STEP(2) AON_BF_STEP(3) AON_BF_STEP(4) AON_BF_STEP(5) AON_BF_STEP(6)
 #undef AON_BF_STEP
-  chunk_mma_bf16<CBASE + 7, NT_OUT, HAS_TAIL, RELU_TAIL, STORE_TAIL>(p, cur, out, tail, nxt, tail_plane, io);
+  chunk_mma_bf16<CBASE + 7, NT_OUT, HAS_TAIL, PRE_TAIL, STORE_TAIL, Net>(p, cur, out, tail, nxt, tail_plane, io);
   if (HAS_TAIL) { cur[0] = nxt[0]; cur[1] = nxt[1]; }
 }
 
@@ -404,6 +415,158 @@ __global__ void __launch_bounds__(256) mlp_fwd_bf16x3_kernel(BfArgs args) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// backward data chain on the bf16x3 engine (fp32 twin: mlp_bwd_chain_kernel, aon_train.hip)
+// ---------------------------------------------------------------------------------------------
+// Transposed weight stream in limb form: 68 chunks of 48 KiB; chunk c = the 32 gradient features j of one tile x all 256
+// features f of the layer's input, A operand = W^T: [k16 step s][out tile tp][limb][lane][8 bf16] with
+//   lane (i = lane&31, h = lane>>5), k-slot jj of step s  <->  W[j = 32T + (r&3) + 8(r>>2) + 4h][f = 32tp + i],  r = 8s + jj
+// (the accumulator register order of the producing tile, exactly as in the forward stream).
+constexpr int kBbView = 0;    // views_linear.0 (cols 0..255): 4 chunks
+constexpr int kBbBott = 4;    // bottleneck_layer: 8
+constexpr int kBbL7 = 12;     // pts_linears.7 ... pts_linears.1: 8 each, backward order
+constexpr int kBbNumChunks = 68;
+
+struct Bf16BwdNet {
+  static constexpr int kNumChunks = kBbNumChunks;
+  static constexpr int kSlotBytes = 8 * 6144;
+  static constexpr bool kPair = false;
+  static constexpr int chunk_bytes(int) { return 8 * 6144; }
+};
+constexpr int64_t kBbStreamBytes = (int64_t)kBbNumChunks * 8 * 6144;
+
+__global__ void pack_vanilla_bwd_bf16x3_kernel(PackArgsB a, char* __restrict__ packed) {
+  // one thread per (chunk, s, tp, lane): 8 transposed weights -> 3 x 16 bytes
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)kBbNumChunks * 2 * 8 * 64) return;
+  const int c = (int)(idx / (2 * 8 * 64)), r = (int)(idx % (2 * 8 * 64));
+  const int lane = r & 63, tp = (r >> 6) & 7, s = r >> 9;
+  const int h = lane >> 5, f = 32 * tp + (lane & 31);
+  const float* W; int ld, T;
+  if (c < kBbBott) { W = a.p[16]; ld = 256 + kViewEnc; T = c; }
+  else if (c < kBbL7) { W = a.p[18]; ld = 256; T = c - kBbBott; }
+  else {
+    const int l = 7 - (c - kBbL7) / 8;  // 7,6,5,4,3,2,1
+    W = a.p[2 * l]; ld = l == 5 ? 256 + kPosEnc : 256; T = (c - kBbL7) % 8;
+  }
+  unsigned short hi[8], mid[8], lo[8];
+#pragma unroll
+  for (int jj = 0; jj < 8; ++jj) {
+    const int reg = 8 * s + jj;
+    const int j = 32 * T + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+    const float w = W[(int64_t)j * ld + f];
+    hi[jj] = bf16_rne_bits(w);
+    const float r1 = w - bf16_bits_to_f32(hi[jj]);
+    mid[jj] = bf16_rne_bits(r1);
+    lo[jj] = bf16_rne_bits(r1 - bf16_bits_to_f32(mid[jj]));
+  }
+  char* dst = packed + (int64_t)c * 8 * 6144 + ((int64_t)(s * 8 + tp) * 3) * 1024 + lane * 16;
+  auto put = [&](int limb, const unsigned short (&v)[8]) {
+    u32x4 o;
+    o[0] = v[0] | ((unsigned)v[1] << 16); o[1] = v[2] | ((unsigned)v[3] << 16);
+    o[2] = v[4] | ((unsigned)v[5] << 16); o[3] = v[6] | ((unsigned)v[7] << 16);
+    *reinterpret_cast<u32x4*>(dst + limb * 1024) = o;
+  };
+  put(0, hi); put(1, mid); put(2, lo);
+}
+
+struct BfBwdArgs {
+  const char* packed_bwd;   // kBbStreamBytes
+  const float* small;       // fp32 small block of the forward stream (head weights)
+  const float* d_raw;       // (Np,4)
+  const u32x4* masks;       // forward ReLU bit masks, kMaskLayers x (Np*2)
+  float* dplanes;           // pre-activation gradient planes
+  int64_t Np; int npass;
+};
+
+template <int NT>
+__device__ __forceinline__ void zero_tiles_bf(f32x16 (&x)[NT]) {
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) x[t][r] = 0.f;
+}
+
+__global__ void __launch_bounds__(256) mlp_bwd_chain_bf16x3_kernel(BfBwdArgs args) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* sm = reinterpret_cast<float*>(smem + kBfRingBytes);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m = lane & 31, h = lane >> 5;
+  {
+    const f32x4* src = reinterpret_cast<const f32x4*>(args.small);
+    f32x4* dst = reinterpret_cast<f32x4*>(sm);
+    for (int i = tid; i < kSmallFloats / 4; i += 256) dst[i] = src[i];
+  }
+  Pipe p;
+  pipe_init<Bf16BwdNet>(p, args.packed_bwd, smem, wave, lane);
+
+  for (int pass = blockIdx.x; pass < args.npass; pass += gridDim.x) {
+    const int64_t col = (int64_t)pass * 128 + wave * 32 + m;
+    const PlaneIO io = make_plane_io(args.Np, col, h);
+    u32x4 mk[kMaskLayers];
+#pragma unroll
+    for (int l = 0; l < kMaskLayers; ++l) mk[l] = args.masks[(int64_t)l * args.Np * 2 + (int64_t)pass * 256 + tid];
+    auto dp = [&](int row) { return reinterpret_cast<float*>(reinterpret_cast<char*>(args.dplanes) + (int64_t)row * io.row_bytes); };
+    const int64_t tile_bytes = 32 * io.row_bytes;
+    const float4 dr = reinterpret_cast<const float4*>(args.d_raw)[col];
+    // rgb head (model.py:118): dHV[f] = sum_c W_rgb[c][f] * d_rgb[c];  view-layer ReLU; plane kPlHV
+    f32x16 Z[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        const int fo = 32 * t + 8 * gq + 4 * h;
+        const f32x4 w0 = *reinterpret_cast<const f32x4*>(sm + kSmWRgb + 0 * kCondWidth + fo);
+        const f32x4 w1 = *reinterpret_cast<const f32x4*>(sm + kSmWRgb + 1 * kCondWidth + fo);
+        const f32x4 w2 = *reinterpret_cast<const f32x4*>(sm + kSmWRgb + 2 * kCondWidth + fo);
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc)
+          Z[t][4 * gq + cc] = __builtin_fmaf(w2[cc], dr.z, __builtin_fmaf(w1[cc], dr.y, w0[cc] * dr.x));
+      }
+    }
+    apply_mask_bits(Z, mk[8]);
+    store_plane(Z, dp(kPlHV), io);
+    f32x16 X[8], Y[8];
+    LimbFrag cur[2], nxt[2];
+    // d bottleneck = W_view[:, :256]^T . dZ_view   (no activation on the bottleneck, model.py:109)
+    zero_tiles_bf(X);
+    split_tile<0>(Z[0], cur);
+    chunk_mma_bf16<kBbView + 0, 8, true, 0, false, Bf16BwdNet>(p, cur, X, Z[1], nxt); cur[0] = nxt[0]; cur[1] = nxt[1];
+    chunk_mma_bf16<kBbView + 1, 8, true, 0, false, Bf16BwdNet>(p, cur, X, Z[2], nxt); cur[0] = nxt[0]; cur[1] = nxt[1];
+    chunk_mma_bf16<kBbView + 2, 8, true, 0, false, Bf16BwdNet>(p, cur, X, Z[3], nxt); cur[0] = nxt[0]; cur[1] = nxt[1];
+    chunk_mma_bf16<kBbView + 3, 8, false, 0, false, Bf16BwdNet>(p, cur, X, Z[3], nxt);
+    // dH7 = W_bott^T . dBot + W_sigma^T * d_sigma; the consumer of X stores it (plane kPlBot, no mask)
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        const f32x4 w = *reinterpret_cast<const f32x4*>(sm + kSmWSigma + 32 * t + 8 * gq + 4 * h);
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) Y[t][4 * gq + cc] = w[cc] * dr.w;
+      }
+    }
+    split_tile<0, true>(X[0], cur, dp(kPlBot), &io);
+    layer8_bf16<kBbBott, 8, 0, false, 0, true, false, Bf16BwdNet>(p, cur, X, Y, X[0], dp(kPlBot), &io, tile_bytes);
+    // trunk, layers 7 .. 1: dZ_l = mask_l * dH_l (stored by the consumer), dH_{l-1} = W_l^T . dZ_l
+#define AON_BB_LAYER(IN, OUT, L, CB)                                                                                         \
+    zero_tiles_bf(OUT);                                                                                                        \
+    split_tile<2, true>(IN[0], cur, dp(plane_h(L)), &io, tile_bits(mk[L], 0));                                                 \
+    layer8_bf16<CB, 8, 2, false, 0, true, false, Bf16BwdNet>(p, cur, IN, OUT, IN[0], dp(plane_h(L)), &io, tile_bytes, nullptr, mk[L]);
+    AON_BB_LAYER(Y, X, 7, kBbL7 + 0)
+    AON_BB_LAYER(X, Y, 6, kBbL7 + 8)
+    AON_BB_LAYER(Y, X, 5, kBbL7 + 16)
+    AON_BB_LAYER(X, Y, 4, kBbL7 + 24)
+    AON_BB_LAYER(Y, X, 3, kBbL7 + 32)
+    AON_BB_LAYER(X, Y, 2, kBbL7 + 40)
+    AON_BB_LAYER(Y, X, 1, kBbL7 + 48)
+#undef AON_BB_LAYER
+    apply_mask_bits(X, mk[0]);
+    store_plane(X, dp(plane_h(0)), io);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// ---------------------------------------------------------------------------------------------
 // host launchers
 // ---------------------------------------------------------------------------------------------
 int num_cus();
@@ -449,6 +612,35 @@ hipError_t launch_mlp_fwd_train_bf16x3(const char* packed, const float* rays_o, 
            static_cast<u32x4*>(masks), 0};
   a.Np = (int64_t)a.npass * 128;
   return launch_bf16x3_t<true>(a, stream);
+}
+
+int64_t bwd_bf16x3_stream_bytes() { return kBbStreamBytes; }
+
+hipError_t launch_pack_vanilla_bwd_bf16x3(const float* const* params, char* packed, hipStream_t stream) {
+  PackArgsB a;
+  for (int i = 0; i < kNumVanillaParams; ++i) a.p[i] = params[i];
+  const int64_t n = (int64_t)kBbNumChunks * 2 * 8 * 64;
+  pack_vanilla_bwd_bf16x3_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream>>>(a, packed);
+  return hipGetLastError();
+}
+
+// packed_fwd_small: the fp32 small block (biases / head weights) = fp32 forward stream + kStreamBytes
+hipError_t launch_mlp_bwd_chain_bf16x3(const char* packed_bwd, const float* packed_fwd_small, const float* d_raw, const void* masks,
+                                       float* dplanes, int64_t Np, hipStream_t stream) {
+  static bool attr = false;
+  constexpr int lds = kBfRingBytes + (int)kSmallBytes;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_bwd_chain_bf16x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return e;
+    attr = true;
+  }
+  BfBwdArgs a{packed_bwd, packed_fwd_small, d_raw, static_cast<const u32x4*>(masks), dplanes, Np, (int)(Np / 128)};
+  const int cus = num_cus();
+  if (cus <= 0) return hipErrorInvalidDevice;
+  const int grid = a.npass < cus ? a.npass : cus;
+  if (grid <= 0) return hipSuccess;
+  mlp_bwd_chain_bf16x3_kernel<<<dim3(grid), dim3(256), lds, stream>>>(a);
+  return hipGetLastError();
 }
 
 }  // namespace aon

@@ -80,6 +80,15 @@ class NeRFMLP(nn.Module):
             self._packed_bf_key = key
         return self._packed_bf
 
+    def packed_bwd_bf16x3(self) -> torch.Tensor:
+        """Transposed three-limb bf16 stream of the bf16x3 backward chain."""
+        params = dict(self.named_parameters())
+        key = self._param_key(params)
+        if getattr(self, "_packed_bwd_bf", None) is None or key != self._packed_bwd_bf_key:
+            self._packed_bwd_bf = ops.pack_vanilla_mlp_bwd_bf16x3(params)
+            self._packed_bwd_bf_key = key
+        return self._packed_bwd_bf
+
     def packed(self) -> torch.Tensor:
         """The kernel-side weight stream; re-packed (one small HIP kernel) whenever a parameter was modified
         in place, replaced, or moved."""
@@ -138,7 +147,7 @@ class NeRF(nn.Module):
                 raise ValueError("empty ray batch in training mode")
             mlps = [self.coarse_mlp, self.fine_mlp][: self.num_levels]
             if ops.get_train_engine() == "bf16x3":   # opt-in: split-bf16 training forward + weight gradients
-                packs = [(m.packed(), m.packed_bwd(), m.packed_bf16x3()) for m in mlps]
+                packs = [(m.packed(), None, m.packed_bf16x3(), m.packed_bwd_bf16x3()) for m in mlps]
             else:
                 packs = [(m.packed(), m.packed_bwd()) for m in mlps]
             params = [p for m in mlps for p in m.ordered_params()]

@@ -458,6 +458,18 @@ def pack_vanilla_mlp_bwd(params: dict, out: torch.Tensor | None = None) -> torch
     return out
 
 
+def pack_vanilla_mlp_bwd_bf16x3(params: dict, out: torch.Tensor | None = None) -> torch.Tensor:
+    """Transposed weight stream in three-limb bf16 form for the bf16x3 backward chain (re-pack when the parameters change)."""
+    tensors = [_f32(params[name].detach(), name) for name in VANILLA_PARAM_ORDER]
+    dev = tensors[0].device
+    if out is None:
+        out = torch.empty(int(lib.aon_bwd_bf16x3_packed_bytes()), dtype=torch.uint8, device=dev)
+    arr = (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+    with torch.cuda.device(dev):
+        check(lib.aon_pack_vanilla_mlp_bwd_bf16x3(arr, _ptr(out), _stream()), "aon_pack_vanilla_mlp_bwd_bf16x3")
+    return out
+
+
 def padded_samples(n_samples: int) -> int:
     return (n_samples + 127) // 128 * 128
 
@@ -492,13 +504,14 @@ def composite_bwd(raw, t_vals, dirs, g_rgb, g_acc, g_depth, white_bkgd, act, Np:
     return d_raw
 
 
-def mlp_bwd_chain(packed_bwd, packed_fwd, d_raw, masks, plane_shape):
-    """-> dplanes (rows, Np): pre-activation gradient planes (rows of the encodings are not written / not used)."""
+def mlp_bwd_chain(packed_bwd, packed_fwd, d_raw, masks, plane_shape, engine: str = "fp32"):
+    """-> dplanes (rows, Np): pre-activation gradient planes (rows of the encodings are not written / not used).
+    engine "bf16x3": `packed_bwd` is the stream of pack_vanilla_mlp_bwd_bf16x3 (packed_fwd stays the fp32 forward stream)."""
     dplanes = torch.empty(plane_shape, dtype=torch.float32, device=d_raw.device)
     Np = plane_shape[1]
+    fn = lib.aon_mlp_bwd_chain if engine == "fp32" else lib.aon_mlp_bwd_chain_bf16x3
     with torch.cuda.device(d_raw.device):
-        check(lib.aon_mlp_bwd_chain(_ptr(packed_bwd), _ptr(packed_fwd), _ptr(d_raw), _ptr(masks), _ptr(dplanes), Np, _stream()),
-              "aon_mlp_bwd_chain")
+        check(fn(_ptr(packed_bwd), _ptr(packed_fwd), _ptr(d_raw), _ptr(masks), _ptr(dplanes), Np, _stream()), "aon_mlp_bwd_chain")
     return dplanes
 
 

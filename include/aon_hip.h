@@ -127,6 +127,12 @@ int64_t aon_bf16x3_packed_bytes(void);
  * 1 = "bf16x3" -- the weight-gradient GEMMs of aon_vanilla_wgrad / aon_art_wgrad run on the bf16 matrix pipe with both
  * operands split exactly into three bf16 limbs and six limb products accumulated in fp32 (fp32-class error). */
 int aon_set_train_engine(int engine);
+/* backward data chain on the bf16x3 engine: transposed weight stream in limb form (aon_bwd_bf16x3_packed_bytes()), otherwise the
+ * contract of aon_mlp_bwd_chain (packed_fwd = the fp32 forward stream, read for its head weights only) */
+int64_t aon_bwd_bf16x3_packed_bytes(void);
+int aon_pack_vanilla_mlp_bwd_bf16x3(const float* const* params_host, void* packed_bwd, void* stream);
+int aon_mlp_bwd_chain_bf16x3(const void* packed_bwd_bf16x3, const void* packed_fwd, const float* d_raw, const void* masks,
+                             float* dplanes, int64_t Np, void* stream);
 /* aon_mlp_fwd_train on the bf16x3 engine: same planes / masks / raw contract, packed stream from aon_pack_vanilla_mlp_bf16x3 */
 int aon_mlp_fwd_train_bf16x3(const void* packed_bf16x3, const float* rays_o, const float* rays_d, const float* viewdirs,
                              const float* t_vals, int64_t n_rays, int S, float* raw, float* planes, void* masks, void* stream);

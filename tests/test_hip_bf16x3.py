@@ -129,3 +129,29 @@ def test_bf16x3_training_forward_planes_and_module_gradients(dev, nerf_sd):
         step_vs_oracle(dev, True, False, 5.0)
     finally:
         ops.set_train_engine("fp32")
+
+
+def test_bf16x3_backward_chain_matches_fp32_chain(dev, nerf_sd):
+    """Same forward planes / masks / d_raw into both backward chains: every gradient plane the weight-gradient kernels read
+    agrees to fp32-class differences (relative L2 per 256-row block <= 2e-6; the two differ in summation order only)."""
+    import aon_amd.synthetic as syn
+    from aon_amd import ops
+
+    n, S = 50, 193
+    params = {k[len("fine_mlp."):]: v.to(dev) for k, v in nerf_sd.items() if k.startswith("fine_mlp.")}
+    pk, pbwd, pbwd_bf = ops.pack_vanilla_mlp(params), ops.pack_vanilla_mlp_bwd(params), ops.pack_vanilla_mlp_bwd_bf16x3(params)
+    rays = {k: v.to(dev) for k, v in syn.random_rays(n, seed=6).items()}
+    g = torch.Generator().manual_seed(6)
+    t = torch.sort(torch.rand(n, S, generator=g) * 4 + 2, dim=-1).values.to(dev)
+    raw, planes, masks = ops.mlp_fwd_train(pk, rays["rays_o"], rays["rays_d"], rays["viewdirs"], t)
+    g_rgb = torch.randn(n, 3, generator=g).to(dev)
+    d_raw = ops.composite_bwd(raw, t, rays["rays_d"], g_rgb, None, None, True, ops.ACT_VANILLA, planes.shape[1])
+    da = ops.mlp_bwd_chain(pbwd, pk, d_raw, masks, planes.shape)
+    db = ops.mlp_bwd_chain(pbwd_bf, pk, d_raw, masks, planes.shape, engine="bf16x3")
+    valid = n * S
+    blocks = {f"h{l}": (64 + 256 * l, 64 + 256 * (l + 1)) for l in range(8)}
+    blocks.update({"bottleneck": (2112, 2368), "view_hidden": (2400, 2528)})
+    for name, (r0, r1) in blocks.items():
+        a, b = da[r0:r1, :valid].double(), db[r0:r1, :valid].double()
+        err = ((a - b).norm() / (a.norm() + 1e-300)).item()
+        assert err <= 2e-6, (name, err)
