@@ -129,18 +129,29 @@ def train_leg(dev, rank, world, distributed, steps=3, n_rays=4096):
                 dist.barrier()
                 torch.cuda.synchronize()
 
-        step()
-        fence()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            loss = step()
-        fence()
-        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
-        if distributed:
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = t.item() / steps
-        return {"workload": f"articulated NeRF_AE_Art training step, {n_rays} rays/GPU, fwd+bwd" + (" + RCCL gradient all-reduce (6.4 MB, one bucket)" if world > 1 else "") + " + Adam",
-                "ms_per_step": dt * 1e3, "rays_per_s": world * n_rays / dt, "steps": steps, "loss": float(loss)}
+        def timed():
+            step()
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                loss = step()
+            fence()
+            t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+            if distributed:
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return t.item() / steps, float(loss)
+
+        dt, loss = timed()
+        res = {"workload": f"articulated NeRF_AE_Art training step, {n_rays} rays/GPU, fwd+bwd" + (" + RCCL gradient all-reduce (6.4 MB, one bucket)" if world > 1 else "") + " + Adam",
+               "ms_per_step": dt * 1e3, "rays_per_s": world * n_rays / dt, "steps": steps, "loss": loss}
+        # the opt-in split-bf16 training engine (for the articulated network: the weight-gradient GEMMs), same step
+        ops.set_train_engine("bf16x3")
+        try:
+            dt_b, _ = timed()
+            res["bf16x3_engine_ms_per_step"] = dt_b * 1e3
+        finally:
+            ops.set_train_engine("fp32")
+        return res
     except Exception as e:  # informational leg: never take the headline down with it
         return {"error": f"{type(e).__name__}: {e}"}
 
