@@ -52,6 +52,10 @@ _SIGS = {
     "aon_art_mlp_fwd": (_i, [_p, _p, _p, _p, _p, _p, _l, _i, _p, _p]),
     "aon_art_mlp_fwd_pos": (_i, [_p, _p, _p, _p, _l, _i, _p, _p]),
     "aon_art_render_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _l, _f, _f, _i, _i, _p, _p, _l, _p, _p, _p, _p, _p, _p, _p, _l, _p]),
+    "aon_art_bf16x3_packed_bytes": (_l, []),
+    "aon_pack_art_mlp_bf16x3": (_i, [_p, _p, _p]),
+    "aon_art_mlp_fwd_bf16x3": (_i, [_p, _p, _p, _p, _p, _p, _l, _i, _p, _p]),
+    "aon_art_render_fwd_bf16x3": (_i, [_p, _p, _p, _p, _p, _p, _p, _l, _f, _f, _i, _i, _p, _p, _l, _p, _p, _p, _p, _p, _p, _p, _l, _p]),
     "aon_train_plane_rows": (_l, []),
     "aon_bwd_packed_bytes": (_l, []),
     "aon_wgrad_workspace_bytes": (_l, []),

@@ -15,7 +15,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 OBJ = os.path.join(PKG, "build")
 LIB = os.path.join(PKG, "libaon_hip.so")
-SOURCES = ["aon_mlp.hip", "aon_mlp_bf16.hip", "aon_mlp_art.hip", "aon_train.hip", "aon_train_art.hip", "aon_render.hip", "aon_capi.hip"]
+SOURCES = ["aon_mlp.hip", "aon_mlp_bf16.hip", "aon_mlp_art.hip", "aon_mlp_art_bf16.hip", "aon_train.hip", "aon_train_art.hip", "aon_render.hip", "aon_capi.hip"]
 HEADERS = [os.path.join(CSRC, "aon_common.h"), os.path.join(CSRC, "aon_mlp_core.h"), os.path.join(CSRC, "aon_wgrad.h"), os.path.join(CSRC, "aon_art_common.h"),
            os.path.join(os.path.dirname(PKG), "include", "aon_hip.h")]
 # -ffp-contract=off: the stage kernels reproduce the reference's un-fused mul/add sequences; FMAs are explicit.

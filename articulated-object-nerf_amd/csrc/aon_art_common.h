@@ -26,4 +26,17 @@ constexpr int kALdsBytes = kRingBytes + kASmallFloats * 4;
 //   34,35  bottleneck_layer   36,37 density_layer   38,39 rgb_layer
 constexpr int kNumArtParams = 40;
 
+// ---- chunk stream of one articulated MLP (execution order) ----
+constexpr int kAChD1 = 0;     // deformations_linear.1..3 : 4 chunks each, 4 output tiles (16 KiB)
+constexpr int kAChT0 = 12;    // pts_linears.0 : 2 pos-enc chunks (32 KiB)
+constexpr int kAChT1 = 14;    // pts_linears.1..4 : 8 chunks each
+constexpr int kAChT5 = 46;    // pts_linears.5 : 8 hidden + 2 pos-enc
+constexpr int kAChT6 = 56;
+constexpr int kAChT7 = 64;
+constexpr int kAChBott = 72;
+constexpr int kAChV0 = 80;    // views_linear.0 : 8 hidden + 1 view-enc, 4 output tiles (16 KiB)
+constexpr int kAChV1 = 89;    // views_linear.1..3 : 4 chunks each
+constexpr int kANumChunks = 101;
+
+
 }  // namespace aon

@@ -53,6 +53,10 @@ int64_t bwd_bf16x3_stream_bytes();
 hipError_t launch_pack_vanilla_bwd_bf16x3(const float* const* params, char* packed, hipStream_t stream);
 hipError_t launch_mlp_bwd_chain_bf16x3(const char* packed_bwd, const float* packed_fwd_small, const float* d_raw, const void* masks,
                                        float* dplanes, int64_t Np, hipStream_t stream);
+int64_t art_bf16x3_packed_bytes();
+hipError_t launch_pack_art_bf16x3(const float* const* params, char* packed, hipStream_t stream);
+hipError_t launch_art_mlp_fwd_bf16x3(const char* packed, const float* small, const float* rays_o, const float* rays_d,
+                                     const float* viewdirs, const float* t_vals, int64_t n_rays, int S, float* raw, hipStream_t stream);
 void set_train_engine(int e);
 int get_train_engine();
 int64_t bf16x3_packed_bytes();
@@ -391,12 +395,14 @@ struct NetRef {
   bool articulated;
   const void* packed;
   const float* small;  // articulated only
-  bool bf16x3 = false; // vanilla only: split-bf16 engine (aon_mlp_bf16.hip)
+  bool bf16x3 = false; // split-bf16 engine (aon_mlp_bf16.hip / aon_mlp_art_bf16.hip): `packed` is that engine's stream
 };
 
 static hipError_t launch_net(const NetRef& net, const float* o, const float* d, const float* v, const float* t, int64_t n, int S,
                              float* raw, hipStream_t stream) {
   MlpTimer timer(stream, n * S);
+  if (net.articulated && net.bf16x3)
+    return aon::launch_art_mlp_fwd_bf16x3(static_cast<const char*>(net.packed), net.small, o, d, v, t, n, S, raw, stream);
   if (net.articulated)
     return aon::launch_art_mlp_fwd(static_cast<const char*>(net.packed), net.small, o, d, v, t, n, S, raw, stream);
   if (net.bf16x3) return aon::launch_mlp_fwd_bf16x3(static_cast<const char*>(net.packed), o, d, v, t, n, S, raw, stream);
@@ -584,6 +590,38 @@ int aon_art_render_fwd(const void* packed_coarse, const void* small_coarse, cons
                        int64_t workspace_bytes, void* stream) {
   const NetRef c{true, packed_coarse, static_cast<const float*>(small_coarse)}, f{true, packed_fine, static_cast<const float*>(small_fine)};
   return render_impl("aon_art_render_fwd", c, f, rays_o, rays_d, viewdirs, n_rays, near_, far_, white_bkgd, num_levels, t_rand, u,
+                     u_stride, rgb_c, acc_c, depth_c, rgb_f, acc_f, depth_f, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int64_t aon_art_bf16x3_packed_bytes(void) { return aon::art_bf16x3_packed_bytes(); }
+
+int aon_pack_art_mlp_bf16x3(const float* const* params_host, void* packed, void* stream) {
+  if (!params_host || !packed) return fail(AON_E_INVALID, "aon_pack_art_mlp_bf16x3: null pointer");
+  for (int i = 0; i < 40; ++i)
+    if (!params_host[i]) return fail(AON_E_INVALID, "aon_pack_art_mlp_bf16x3: null parameter pointer");
+  if (reinterpret_cast<uintptr_t>(packed) & 15) return fail(AON_E_INVALID, "aon_pack_art_mlp_bf16x3: packed must be 16-byte aligned");
+  return check(aon::launch_pack_art_bf16x3(params_host, static_cast<char*>(packed), (hipStream_t)stream), "aon_pack_art_mlp_bf16x3");
+}
+
+int aon_art_mlp_fwd_bf16x3(const void* packed_bf16x3, const void* small, const float* rays_o, const float* rays_d,
+                           const float* viewdirs, const float* t_vals, int64_t n_rays, int S, float* raw, void* stream) {
+  if (n_rays < 0 || S < 1) return fail(AON_E_INVALID, "aon_art_mlp_fwd_bf16x3: bad size");
+  if (n_rays == 0) return AON_OK;
+  if (!packed_bf16x3 || !small || !rays_o || !rays_d || !viewdirs || !t_vals || !raw)
+    return fail(AON_E_INVALID, "aon_art_mlp_fwd_bf16x3: null pointer");
+  MlpTimer timer((hipStream_t)stream, n_rays * S);
+  return check(aon::launch_art_mlp_fwd_bf16x3(static_cast<const char*>(packed_bf16x3), static_cast<const float*>(small), rays_o, rays_d,
+                                              viewdirs, t_vals, n_rays, S, raw, (hipStream_t)stream), "aon_art_mlp_fwd_bf16x3");
+}
+
+int aon_art_render_fwd_bf16x3(const void* packed_coarse, const void* small_coarse, const void* packed_fine, const void* small_fine,
+                              const float* rays_o, const float* rays_d, const float* viewdirs, int64_t n_rays, float near_, float far_,
+                              int white_bkgd, int num_levels, const float* t_rand, const float* u, int64_t u_stride, float* rgb_c,
+                              float* acc_c, float* depth_c, float* rgb_f, float* acc_f, float* depth_f, void* workspace,
+                              int64_t workspace_bytes, void* stream) {
+  NetRef c{true, packed_coarse, static_cast<const float*>(small_coarse)}, f{true, packed_fine, static_cast<const float*>(small_fine)};
+  c.bf16x3 = true; f.bf16x3 = true;
+  return render_impl("aon_art_render_fwd_bf16x3", c, f, rays_o, rays_d, viewdirs, n_rays, near_, far_, white_bkgd, num_levels, t_rand, u,
                      u_stride, rgb_c, acc_c, depth_c, rgb_f, acc_f, depth_f, workspace, workspace_bytes, (hipStream_t)stream);
 }
 

@@ -1,0 +1,265 @@
+// Split-precision ("bf16x3") form of the fused articulated NeRFMLP forward (fp32 twin: aon_mlp_art.hip;
+// reference: models/vanilla_nerf/model_autodecoder.py:172-239 with deformation_mlp=True, enc_after=True).
+// Same chunk order (101 chunks) and the same per-call small block (aon_art_prepare: latents folded into effective
+// biases); every MFMA layer runs on v_mfma_f32_32x32x16_bf16 with weights and activations as three exact bf16 limbs and
+// the six limb products of weight >= 2^-24 accumulated in fp32 (aon_bf16_core.h).  Opt-in, like the vanilla bf16x3 engine.
+#include "aon_bf16_core.h"
+#include "aon_art_common.h"
+
+namespace aon {
+
+struct Bf16ArtNet {
+  static constexpr int kNumChunks = kANumChunks;
+  static constexpr int kSlotBytes = 8 * 6144;  // 48 KiB
+  static constexpr bool kPair = false;
+  static constexpr int chunk_tiles(int c) { return (c < kAChT0 || c >= kAChV0) ? 4 : 8; }  // 32-feature output tiles
+  static constexpr int chunk_bytes(int c) { return chunk_tiles(c) * 6144; }
+};
+constexpr int64_t kBaStreamBytes =
+    ((int64_t)kAChT0 * 4 + (int64_t)(kAChV0 - kAChT0) * 8 + (int64_t)(kANumChunks - kAChV0) * 4) * 6144;
+constexpr int kBaSmallBytes = kASmallFloats * 4;
+constexpr int kBaLdsBytes = kBfRingBytes + kBaSmallBytes + kBfEncStashBytes;
+static_assert((kBfRingBytes + kBaSmallBytes) % 16 == 0, "stash alignment");
+
+struct ArtPackArgsB {
+  const float* p[kNumArtParams];
+};
+
+__global__ void pack_art_bf16x3_kernel(ArtPackArgsB a, char* __restrict__ packed) {
+  // one thread per (chunk, k16 step s, out tile tp, lane): 8 weights -> 3 x 16 bytes
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  constexpr int64_t t0 = (int64_t)kAChT0 * 2 * 4 * 64;                      // 16 KiB-class chunks of the deformation MLP
+  constexpr int64_t t1 = t0 + (int64_t)(kAChV0 - kAChT0) * 2 * 8 * 64;      // trunk + bottleneck
+  constexpr int64_t t2 = t1 + (int64_t)(kANumChunks - kAChV0) * 2 * 4 * 64; // view branch
+  if (idx >= t2) return;
+  int c, r, nt;
+  int64_t chunk_base;
+  if (idx < t0) { c = (int)(idx / (2 * 4 * 64)); r = (int)(idx % (2 * 4 * 64)); nt = 4; chunk_base = (int64_t)c * 4 * 6144; }
+  else if (idx < t1) {
+    const int64_t i2 = idx - t0;
+    c = kAChT0 + (int)(i2 / (2 * 8 * 64)); r = (int)(i2 % (2 * 8 * 64)); nt = 8;
+    chunk_base = (int64_t)kAChT0 * 4 * 6144 + (int64_t)(c - kAChT0) * 8 * 6144;
+  } else {
+    const int64_t i2 = idx - t1;
+    c = kAChV0 + (int)(i2 / (2 * 4 * 64)); r = (int)(i2 % (2 * 4 * 64)); nt = 4;
+    chunk_base = (int64_t)kAChT0 * 4 * 6144 + (int64_t)(kAChV0 - kAChT0) * 8 * 6144 + (int64_t)(c - kAChV0) * 4 * 6144;
+  }
+  const int lane = r & 63, tp = (r >> 6) % nt, s = (r >> 6) / nt;
+  const int h = lane >> 5, row = 32 * tp + (lane & 31);
+  const float* W; int ld;
+  int kind, tile, off = 0;  // kind 0: hidden columns 32*tile + feature, 1: pos-enc (+off), 2: view-enc (+off)
+  if (c < kAChT0) { const int l = 1 + c / 4; W = a.p[2 * l]; ld = 128; kind = 0; tile = c % 4; }
+  else if (c < kAChT1) { W = a.p[10]; ld = 191; kind = 1; tile = c - kAChT0; }
+  else if (c < kAChT5) { const int l = 1 + (c - kAChT1) / 8; W = a.p[10 + 2 * l]; ld = 256; kind = 0; tile = (c - kAChT1) % 8; }
+  else if (c < kAChT5 + 8) { W = a.p[20]; ld = 447; kind = 0; tile = c - kAChT5; }
+  else if (c < kAChT6) { W = a.p[20]; ld = 447; kind = 1; tile = c - kAChT5 - 8; off = 256; }
+  else if (c < kAChT7) { W = a.p[22]; ld = 256; kind = 0; tile = c - kAChT6; }
+  else if (c < kAChBott) { W = a.p[24]; ld = 256; kind = 0; tile = c - kAChT7; }
+  else if (c < kAChV0) { W = a.p[34]; ld = 256; kind = 0; tile = c - kAChBott; }
+  else if (c < kAChV0 + 8) { W = a.p[26]; ld = 411; kind = 0; tile = c - kAChV0; }
+  else if (c < kAChV1) { W = a.p[26]; ld = 411; kind = 2; tile = 0; off = 256; }
+  else { const int l = 1 + (c - kAChV1) / 4; W = a.p[26 + 2 * l]; ld = 128; kind = 0; tile = (c - kAChV1) % 4; }
+  unsigned short hi[8], mid[8], lo[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int reg = 8 * s + j;  // accumulator register of the producing tile that supplies k-slot j of step s
+    int col;
+    if (kind == 0) col = 32 * tile + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+    else if (kind == 1) { col = posenc_col(tile, reg >> 2, reg & 3, h); if (col >= 0) col += off; }
+    else { col = viewenc_col(reg >> 2, reg & 3, h); if (col >= 0) col += off; }
+    const float w = col >= 0 ? W[(int64_t)row * ld + col] : 0.f;  // every layer here has a multiple of 32 outputs
+    hi[j] = bf16_rne_bits(w);
+    const float r1 = w - bf16_bits_to_f32(hi[j]);
+    mid[j] = bf16_rne_bits(r1);
+    lo[j] = bf16_rne_bits(r1 - bf16_bits_to_f32(mid[j]));
+  }
+  char* dst = packed + chunk_base + ((int64_t)(s * nt + tp) * 3) * 1024 + lane * 16;
+  auto put = [&](int limb, const unsigned short (&v)[8]) {
+    u32x4 o;
+    o[0] = v[0] | ((unsigned)v[1] << 16); o[1] = v[2] | ((unsigned)v[3] << 16);
+    o[2] = v[4] | ((unsigned)v[5] << 16); o[3] = v[6] | ((unsigned)v[7] << 16);
+    *reinterpret_cast<u32x4*>(dst + limb * 1024) = o;
+  };
+  put(0, hi); put(1, mid); put(2, lo);
+}
+
+// 128 -> 128 layer over four input tiles (deformation layers 1-3, view layers 1-3): the input is the previous layer's
+// pre-activation (ReLU applied in the split).  On entry `cur` holds the fragments of in[0].
+template <int CBASE>
+__device__ __forceinline__ void layer4_bf16(Pipe& p, LimbFrag (&cur)[2], const f32x16 (&in)[4], f32x16 (&out)[4]) {
+  LimbFrag nxt[2];
+  chunk_mma_bf16<CBASE + 0, 4, true, 1, false, Bf16ArtNet>(p, cur, out, in[1], nxt); cur[0] = nxt[0]; cur[1] = nxt[1];
+  chunk_mma_bf16<CBASE + 1, 4, true, 1, false, Bf16ArtNet>(p, cur, out, in[2], nxt); cur[0] = nxt[0]; cur[1] = nxt[1];
+  chunk_mma_bf16<CBASE + 2, 4, true, 1, false, Bf16ArtNet>(p, cur, out, in[3], nxt); cur[0] = nxt[0]; cur[1] = nxt[1];
+  chunk_mma_bf16<CBASE + 3, 4, false, 0, false, Bf16ArtNet>(p, cur, out, in[3], nxt);
+}
+
+struct ArtBfArgs {
+  const char* packed;   // kBaStreamBytes
+  const float* small;   // kASmallFloats (aon_art_prepare)
+  const float* rays_o; const float* rays_d; const float* viewdirs; const float* t_vals;
+  float* raw;
+  int64_t total; int S; int npass;
+};
+
+__global__ void __launch_bounds__(256) art_mlp_fwd_bf16x3_kernel(ArtBfArgs args) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* sm = reinterpret_cast<float*>(smem + kBfRingBytes);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m = lane & 31, h = lane >> 5;
+  {
+    const f32x4* src = reinterpret_cast<const f32x4*>(args.small);
+    f32x4* dst = reinterpret_cast<f32x4*>(sm);
+    for (int i = tid; i < kASmallFloats / 4; i += 256) dst[i] = src[i];
+  }
+  Pipe p;
+  pipe_init<Bf16ArtNet>(p, args.packed, smem, wave, lane);
+
+  for (int pass = blockIdx.x; pass < args.npass; pass += gridDim.x) {
+    const int64_t g = (int64_t)pass * 128 + wave * 32 + m;
+    const bool valid = g < args.total;
+    const int64_t gc = valid ? g : args.total - 1;
+    const int64_t ray = gc / args.S;
+    const float t = args.t_vals[gc];
+    float x[3], vd[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      x[a] = __fadd_rn(args.rays_o[ray * 3 + a], __fmul_rn(t, args.rays_d[ray * 3 + a]));  // helper.cast_rays
+      vd[a] = args.viewdirs[ray * 3 + a];
+    }
+    f32x4* stash = reinterpret_cast<f32x4*>(smem + kBfRingBytes + kBaSmallBytes) + (wave * 2 * 64 + lane) * 4;
+    auto load_enc = [&](int tile) {
+      f32x16 e;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const f32x4 v4 = stash[tile * 64 * 4 + k];
+        e[4 * k] = v4[0]; e[4 * k + 1] = v4[1]; e[4 * k + 2] = v4[2]; e[4 * k + 3] = v4[3];
+      }
+      return e;
+    };
+    LimbFrag cur[2], nxt[2];
+
+    // ---- deformation MLP (:196-205): layer 0 (3 -> 128, effective bias) on the VALU, layers 1-3 on the matrix pipe ----
+    f32x16 H0[4], H1[4];   // PRE-activations; the ReLU is applied by the split / head that consumes them
+    init_bias(H0, sm + kA_BD0, h);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt) {
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+          const f32x4 w = *reinterpret_cast<const f32x4*>(sm + kA_WD0 + a * 128 + 32 * tt + 8 * gq + 4 * h);
+#pragma unroll
+          for (int cc = 0; cc < 4; ++cc) H0[tt][4 * gq + cc] = __builtin_fmaf(w[cc], x[a], H0[tt][4 * gq + cc]);
+        }
+      }
+    }
+    split_tile<1>(H0[0], cur); init_bias(H1, sm + kA_BD + 0 * 128, h); layer4_bf16<kAChD1 + 0>(p, cur, H0, H1);
+    split_tile<1>(H1[0], cur); init_bias(H0, sm + kA_BD + 1 * 128, h); layer4_bf16<kAChD1 + 4>(p, cur, H1, H0);
+    split_tile<1>(H0[0], cur); init_bias(H1, sm + kA_BD + 2 * 128, h); layer4_bf16<kAChD1 + 8>(p, cur, H0, H1);
+    float xd[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {  // x' = deformation_layer(relu(h)) + pos   (:205)
+      float v = head_partial_relu<4>(H1, sm + kA_WDL + a * 128, h);
+      v = v + __shfl_xor(v, 32) + sm[kA_BDL + a];
+      xd[a] = __fadd_rn(v, x[a]);
+    }
+    {  // pos_enc of the deformed point (enc_after=True, :207-208), parked in LDS between trunk layers 0 and 5
+      f32x16 E[2];
+      encode_pos(xd, h, E);
+#pragma unroll
+      for (int tile = 0; tile < 2; ++tile)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          f32x4 v4; v4[0] = E[tile][4 * k]; v4[1] = E[tile][4 * k + 1]; v4[2] = E[tile][4 * k + 2]; v4[3] = E[tile][4 * k + 3];
+          stash[tile * 64 * 4 + k] = v4;
+        }
+    }
+
+    // ---- trunk (:212-217), shape latent folded into the biases of layers 0 and 5 ----
+    f32x16 X[8], Y[8];
+    {
+      const f32x16 e0 = load_enc(0), e1 = load_enc(1);
+      split_tile<0>(e0, cur);
+      init_bias(X, sm + kA_BT + 0 * 256, h);
+      chunk_mma_bf16<kAChT0 + 0, 8, true, 0, false, Bf16ArtNet>(p, cur, X, e1, nxt); cur[0] = nxt[0]; cur[1] = nxt[1];
+      chunk_mma_bf16<kAChT0 + 1, 8, false, 0, false, Bf16ArtNet>(p, cur, X, e1, nxt);
+    }
+#define AON_BA_LAYER(IN, OUT, BIAS, CB)                                                                       \
+    split_tile<1>(IN[0], cur); init_bias(OUT, sm + (BIAS), h);                                                  \
+    layer8_bf16<CB, 8, 1, false, 0, false, false, Bf16ArtNet>(p, cur, IN, OUT, IN[0]);
+    AON_BA_LAYER(X, Y, kA_BT + 1 * 256, kAChT1 + 0)
+    AON_BA_LAYER(Y, X, kA_BT + 2 * 256, kAChT1 + 8)
+    AON_BA_LAYER(X, Y, kA_BT + 3 * 256, kAChT1 + 16)
+    AON_BA_LAYER(Y, X, kA_BT + 4 * 256, kAChT1 + 24)
+    // layer 5: cat[relu(h4) (8 tiles), enc (2 tiles)]
+    split_tile<1>(X[0], cur); init_bias(Y, sm + kA_BT + 5 * 256, h);
+    {
+      const f32x16 e0 = load_enc(0);
+      layer8_bf16<kAChT5, 8, 1, true, 0, false, false, Bf16ArtNet>(p, cur, X, Y, e0);
+      const f32x16 e1 = load_enc(1);
+      chunk_mma_bf16<kAChT5 + 8, 8, true, 0, false, Bf16ArtNet>(p, cur, Y, e1, nxt); cur[0] = nxt[0]; cur[1] = nxt[1];
+      chunk_mma_bf16<kAChT5 + 9, 8, false, 0, false, Bf16ArtNet>(p, cur, Y, e1, nxt);
+    }
+    AON_BA_LAYER(Y, X, kA_BT + 6 * 256, kAChT6)
+    AON_BA_LAYER(X, Y, kA_BT + 7 * 256, kAChT7)
+    float sigma = head_partial_relu<8>(Y, sm + kA_WSIG, h);  // density_layer on relu(layer 7) (:219)
+    sigma = sigma + __shfl_xor(sigma, 32) + sm[kA_BSIG];
+    AON_BA_LAYER(Y, X, kA_BBOT, kAChBott)                       // bottleneck, linear output (:223)
+#undef AON_BA_LAYER
+
+    // ---- view branch (:227-234): cat[bottleneck, viewenc, appearance (folded)] -> 4 x (128, ReLU) ----
+    f32x16 Z0[4], Z1[4], V;
+    encode_view(vd, h, V);
+    split_tile<0>(X[0], cur); init_bias(Z0, sm + kA_BV + 0 * 128, h);
+    layer8_bf16<kAChV0, 4, 0, true, 0, false, false, Bf16ArtNet>(p, cur, X, Z0, V);
+    chunk_mma_bf16<kAChV0 + 8, 4, false, 0, false, Bf16ArtNet>(p, cur, Z0, V, nxt);
+    split_tile<1>(Z0[0], cur); init_bias(Z1, sm + kA_BV + 1 * 128, h); layer4_bf16<kAChV1 + 0>(p, cur, Z0, Z1);
+    split_tile<1>(Z1[0], cur); init_bias(Z0, sm + kA_BV + 2 * 128, h); layer4_bf16<kAChV1 + 4>(p, cur, Z1, Z0);
+    split_tile<1>(Z0[0], cur); init_bias(Z1, sm + kA_BV + 3 * 128, h); layer4_bf16<kAChV1 + 8>(p, cur, Z0, Z1);
+    float rgb[3];
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {  // rgb_layer on relu(view layer 3) (:236)
+      float v = head_partial_relu<4>(Z1, sm + kA_WRGB + ch * kCondWidth, h);
+      rgb[ch] = v + __shfl_xor(v, 32) + sm[kA_BRGB + ch];
+    }
+    if (valid && h == 0) {
+      f32x4 o; o[0] = rgb[0]; o[1] = rgb[1]; o[2] = rgb[2]; o[3] = sigma;
+      reinterpret_cast<f32x4*>(args.raw)[g] = o;
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+int num_cus();
+
+int64_t art_bf16x3_packed_bytes() { return kBaStreamBytes; }
+
+hipError_t launch_pack_art_bf16x3(const float* const* params, char* packed, hipStream_t stream) {
+  ArtPackArgsB a;
+  for (int i = 0; i < kNumArtParams; ++i) a.p[i] = params[i];
+  const int64_t n = ((int64_t)kAChT0 * 4 + (int64_t)(kAChV0 - kAChT0) * 8 + (int64_t)(kANumChunks - kAChV0) * 4) * 2 * 64;
+  pack_art_bf16x3_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream>>>(a, packed);
+  return hipGetLastError();
+}
+
+hipError_t launch_art_mlp_fwd_bf16x3(const char* packed, const float* small, const float* rays_o, const float* rays_d,
+                                     const float* viewdirs, const float* t_vals, int64_t n_rays, int S, float* raw, hipStream_t stream) {
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&art_mlp_fwd_bf16x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       kBaLdsBytes);
+    if (e != hipSuccess) return e;
+    attr = true;
+  }
+  ArtBfArgs a{packed, small, rays_o, rays_d, viewdirs, t_vals, raw, n_rays * S, S, (int)((n_rays * S + 127) / 128)};
+  const int cus = num_cus();
+  if (cus <= 0) return hipErrorInvalidDevice;
+  const int grid = a.npass < cus ? a.npass : cus;
+  if (grid <= 0) return hipSuccess;
+  art_mlp_fwd_bf16x3_kernel<<<dim3(grid), dim3(256), kBaLdsBytes, stream>>>(a);
+  return hipGetLastError();
+}
+
+}  // namespace aon

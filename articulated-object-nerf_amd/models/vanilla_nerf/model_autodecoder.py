@@ -81,6 +81,15 @@ class NeRFMLP(nn.Module):
             self._packed_key = key
         return self._packed
 
+    def packed_bf16x3(self) -> torch.Tensor:
+        """Three-limb bf16 weight stream of the opt-in split-bf16 engine."""
+        params = dict(self.named_parameters())
+        key = tuple((p.data_ptr(), p._version, str(p.device)) for p in params.values())
+        if getattr(self, "_packed_bf", None) is None or key != self._packed_bf_key:
+            self._packed_bf = ops.pack_art_mlp_bf16x3(params)
+            self._packed_bf_key = key
+        return self._packed_bf
+
     def prepared(self, latents: dict) -> torch.Tensor:
         """Per-call latent-folded block (cheap: ~0.1 MFLOP); always rebuilt because latents are call arguments."""
         params = dict(self.named_parameters())
@@ -116,6 +125,8 @@ class NeRF_AE_Art(nn.Module):
         self.sigma_activation = nn.Softplus()
         self.coarse_mlp = NeRFMLP(min_deg_point, max_deg_point, deg_view)
         self.fine_mlp = NeRFMLP(min_deg_point, max_deg_point, deg_view)
+        # inference engine: "fp32" = exact fp32 MFMA (default); "bf16x3" = fp32-equivalent split-bf16 (opt-in)
+        self.engine = "fp32"
 
     def forward(self, rays, randomized, white_bkgd, near, far, latents, train=True, t_rand=None, u=None):
         rays_o = rays["rays_o"]
@@ -142,9 +153,12 @@ class NeRF_AE_Art(nn.Module):
                                            latents["articulation"], *params)
             return [tuple(flat[3 * i: 3 * i + 3]) for i in range(self.num_levels)]
         two = self.num_levels == 2
-        outs = ops.art_render_fwd(self.coarse_mlp.packed(), self.coarse_mlp.prepared(latents),
-                                  self.fine_mlp.packed() if two else None, self.fine_mlp.prepared(latents) if two else None,
-                                  rays_o, rays["rays_d"], rays["viewdirs"], near, far, white_bkgd, self.num_levels, t_rand, u)
+        bf = getattr(self, "engine", "fp32") == "bf16x3"   # opt-in split-bf16 inference engine (fp32-equivalent products)
+        pc = self.coarse_mlp.packed_bf16x3() if bf else self.coarse_mlp.packed()
+        pf = (self.fine_mlp.packed_bf16x3() if bf else self.fine_mlp.packed()) if two else None
+        outs = ops.art_render_fwd(pc, self.coarse_mlp.prepared(latents), pf, self.fine_mlp.prepared(latents) if two else None,
+                                  rays_o, rays["rays_d"], rays["viewdirs"], near, far, white_bkgd, self.num_levels, t_rand, u,
+                                  engine="bf16x3" if bf else "fp32")
         return [tuple(o) for o in outs]
 
 

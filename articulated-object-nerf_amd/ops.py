@@ -380,6 +380,27 @@ def pack_art_mlp(params: dict, out: torch.Tensor | None = None) -> torch.Tensor:
     return out
 
 
+def pack_art_mlp_bf16x3(params: dict, out: torch.Tensor | None = None) -> torch.Tensor:
+    """Three-limb bf16 weight stream of one articulated NeRFMLP for the opt-in split-bf16 engine."""
+    tensors, arr = _art_param_array(params)
+    dev = tensors[0].device
+    if out is None:
+        out = torch.empty(int(lib.aon_art_bf16x3_packed_bytes()), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        check(lib.aon_pack_art_mlp_bf16x3(arr, _ptr(out), _stream()), "aon_pack_art_mlp_bf16x3")
+    return out
+
+
+def art_mlp_fwd_bf16x3(packed_bf, small, rays_o, rays_d, viewdirs, t_vals):
+    o, d, v, t = _f32(rays_o, "rays_o"), _f32(rays_d, "rays_d"), _f32(viewdirs, "viewdirs"), _f32(t_vals, "t_vals")
+    n, S = t.shape
+    raw = torch.empty((n, S, 4), dtype=torch.float32, device=t.device)
+    with torch.cuda.device(t.device):
+        check(lib.aon_art_mlp_fwd_bf16x3(_ptr(packed_bf), _ptr(small), _ptr(o), _ptr(d), _ptr(v), _ptr(t), n, S, _ptr(raw), _stream()),
+              "aon_art_mlp_fwd_bf16x3")
+    return raw
+
+
 def _latent(latents: dict, key: str, width: int) -> torch.Tensor:
     t = _f32(latents[key].detach(), f"latents[{key!r}]").reshape(-1)
     if t.numel() != width:
@@ -423,8 +444,9 @@ def art_mlp_fwd_pos(packed, small, pos, viewdirs_enc):
 
 
 def art_render_fwd(packed_c, small_c, packed_f, small_f, rays_o, rays_d, viewdirs, near, far, white_bkgd, num_levels=2,
-                   t_rand=None, u=None):
-    """NeRF_AE_Art.forward: [(rgb, acc, depth)_coarse, (rgb, acc, depth)_fine]."""
+                   t_rand=None, u=None, engine: str = "fp32"):
+    """NeRF_AE_Art.forward: [(rgb, acc, depth)_coarse, (rgb, acc, depth)_fine].  engine "bf16x3": the packed streams come
+    from pack_art_mlp_bf16x3 (the small blocks of art_prepare are shared)."""
     o, d, v = _f32(rays_o, "rays_o"), _f32(rays_d, "rays_d"), _f32(viewdirs, "viewdirs")
     n, dev = o.shape[0], o.device
     tr = None if t_rand is None else _f32(t_rand, "t_rand")
@@ -438,10 +460,11 @@ def art_render_fwd(packed_c, small_c, packed_f, small_f, rays_o, rays_d, viewdir
     fine = outs[1] if num_levels == 2 else (None, None, None)
     ws = _workspace(dev, n)
     with torch.cuda.device(dev):
-        check(lib.aon_art_render_fwd(_ptr(packed_c), _ptr(small_c), _ptr(packed_f), _ptr(small_f), _ptr(o), _ptr(d), _ptr(v), n,
-                                     float(near), float(far), int(bool(white_bkgd)), num_levels, _ptr(tr), _ptr(uu), us,
-                                     _ptr(outs[0][0]), _ptr(outs[0][1]), _ptr(outs[0][2]), _ptr(fine[0]), _ptr(fine[1]), _ptr(fine[2]),
-                                     _ptr(ws), ws.numel(), _stream()), "aon_art_render_fwd")
+        fn = {"fp32": lib.aon_art_render_fwd, "bf16x3": lib.aon_art_render_fwd_bf16x3}[engine]
+        check(fn(_ptr(packed_c), _ptr(small_c), _ptr(packed_f), _ptr(small_f), _ptr(o), _ptr(d), _ptr(v), n,
+                 float(near), float(far), int(bool(white_bkgd)), num_levels, _ptr(tr), _ptr(uu), us,
+                 _ptr(outs[0][0]), _ptr(outs[0][1]), _ptr(outs[0][2]), _ptr(fine[0]), _ptr(fine[1]), _ptr(fine[2]),
+                 _ptr(ws), ws.numel(), _stream()), "aon_art_render_fwd")
     return outs
 
 

@@ -226,6 +226,19 @@ int aon_art_wgrad(const float* planes, const float* dplanes, const float* d_raw,
 int aon_profile_begin(void);
 int aon_profile_end(double* mlp_ms, int64_t* mlp_launches, int64_t* mlp_samples);
 
+/* ---- opt-in "bf16x3" engine for the articulated path (R10/R11): same semantics as aon_art_mlp_fwd / aon_art_render_fwd,
+ * split-bf16 MFMA with fp32-equivalent products (csrc/aon_mlp_art_bf16.hip); own packed stream, the small block of
+ * aon_art_prepare is shared with the fp32 engine. ---- */
+int64_t aon_art_bf16x3_packed_bytes(void);
+int aon_pack_art_mlp_bf16x3(const float* const* params_host, void* packed, void* stream);
+int aon_art_mlp_fwd_bf16x3(const void* packed_bf16x3, const void* small, const float* rays_o, const float* rays_d,
+                           const float* viewdirs, const float* t_vals, int64_t n_rays, int S, float* raw, void* stream);
+int aon_art_render_fwd_bf16x3(const void* packed_coarse, const void* small_coarse, const void* packed_fine, const void* small_fine,
+                              const float* rays_o, const float* rays_d, const float* viewdirs, int64_t n_rays, float near_, float far_,
+                              int white_bkgd, int num_levels, const float* t_rand, const float* u, int64_t u_stride, float* rgb_c,
+                              float* acc_c, float* depth_c, float* rgb_f, float* acc_f, float* depth_f, void* workspace,
+                              int64_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

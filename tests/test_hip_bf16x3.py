@@ -155,3 +155,39 @@ def test_bf16x3_backward_chain_matches_fp32_chain(dev, nerf_sd):
         a, b = da[r0:r1, :valid].double(), db[r0:r1, :valid].double()
         err = ((a - b).norm() / (a.norm() + 1e-300)).item()
         assert err <= 2e-6, (name, err)
+
+
+def test_bf16x3_articulated_engine(dev, golden):
+    """Articulated bf16x3 engine: raw MLP outputs against the oracle at the fp32 kernel's tolerances, and the whole render
+    against the fp32 engine (PSNR >= 80 dB: the two differ like two fp32 summation orders do)."""
+    import aon_amd.synthetic as syn
+    from aon_amd import ops
+    from aon_amd.models.vanilla_nerf.model_autodecoder import NeRF_AE_Art
+
+    g = golden("g11_nerf_ae_art")
+    art_sd = syn.make_art_state_dict(seed=0, density_scale=30.0)
+    model = NeRF_AE_Art().to(dev)
+    model.load_state_dict(art_sd)
+    lat_cpu = {k: g[f"lat_test_{k}"] for k in ("density", "color", "articulation")}
+    lat = {k: v.to(dev) for k, v in lat_cpu.items()}
+    for n, S, seed, lvl in ((1, 65, 1, "coarse"), (33, 193, 2, "fine"), (130, 2, 3, "fine")):
+        rays = syn.random_rays(n, seed=seed)
+        t = torch.sort(torch.rand(n, S, generator=torch.Generator().manual_seed(seed)) * 4 + 2, dim=-1).values
+        pos = orc.cast_rays(t, rays["rays_o"], rays["rays_d"])
+        rgb_o, sig_o = orc.art_mlp(art_sd, f"{lvl}_mlp.", pos, orc.pos_enc(rays["viewdirs"], 0, 4), lat_cpu)
+        mlp = getattr(model, f"{lvl}_mlp")
+        raw = ops.art_mlp_fwd_bf16x3(mlp.packed_bf16x3(), mlp.prepared(lat), rays["rays_o"].to(dev), rays["rays_d"].to(dev),
+                                     rays["viewdirs"].to(dev), t.to(dev)).cpu()
+        torch.testing.assert_close(raw[..., :3], rgb_o, rtol=5e-5, atol=5e-5)
+        torch.testing.assert_close(raw[..., 3:], sig_o, rtol=5e-5, atol=2e-3)
+    rays = {k: g[k].to(dev) for k in ("rays_o", "rays_d", "viewdirs")}
+    with torch.no_grad():
+        a = model(rays, False, True, g["near"], g["far"], lat)
+        model.engine = "bf16x3"
+        b = model(rays, False, True, g["near"], g["far"], lat)
+        again = model(rays, False, True, g["near"], g["far"], lat)
+    for lvl in (0, 1):
+        assert torch.equal(b[lvl][0], again[lvl][0])
+        mse = torch.mean((a[lvl][0] - b[lvl][0]) ** 2).item()
+        assert -10.0 * math.log10(max(mse, 1e-20)) >= 80.0, (lvl, mse)
+        assert (a[lvl][1] - b[lvl][1]).abs().max().item() <= 2e-4
