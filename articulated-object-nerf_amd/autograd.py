@@ -71,12 +71,16 @@ class RenderArticulated(torch.autograd.Function):
         saved, outs = [], []
         t_vals = weights = None
         for lvl in range(num_levels):
-            packed_fwd, small, packed_bwd = packs[lvl]
+            packed_fwd, small, packed_bwd = packs[lvl][:3]
+            packed_bf = packs[lvl][3] if len(packs[lvl]) > 3 else None   # selects the bf16x3 training forward
             if lvl == 0:
                 t_vals, _ = ops.sample_along_rays(rays_o, rays_d, 64, near, far, t_rand, want_coords=False)
             else:
                 t_vals = ops.sample_pdf_t(t_vals, weights, u)
-            raw, planes, masks = ops.art_mlp_fwd_train(packed_fwd, small, rays_o, rays_d, viewdirs, t_vals)
+            if packed_bf is not None:
+                raw, planes, masks = ops.art_mlp_fwd_train(packed_bf, small, rays_o, rays_d, viewdirs, t_vals, engine="bf16x3")
+            else:
+                raw, planes, masks = ops.art_mlp_fwd_train(packed_fwd, small, rays_o, rays_d, viewdirs, t_vals)
             rgb, acc, weights, depth = ops.composite_raw(raw, t_vals, rays_d, white_bkgd, ops.ACT_ARTICULATED, want_weights=True)
             outs += [rgb, acc, depth]
             saved.append((raw, t_vals, planes, masks, small, packed_bwd))

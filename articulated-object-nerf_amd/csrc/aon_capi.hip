@@ -57,6 +57,9 @@ int64_t art_bf16x3_packed_bytes();
 hipError_t launch_pack_art_bf16x3(const float* const* params, char* packed, hipStream_t stream);
 hipError_t launch_art_mlp_fwd_bf16x3(const char* packed, const float* small, const float* rays_o, const float* rays_d,
                                      const float* viewdirs, const float* t_vals, int64_t n_rays, int S, float* raw, hipStream_t stream);
+hipError_t launch_art_mlp_fwd_train_bf16x3(const char* packed, const float* small, const float* rays_o, const float* rays_d,
+                                           const float* viewdirs, const float* t_vals, int64_t n_rays, int S, float* raw, float* planes,
+                                           void* masks, hipStream_t stream);
 void set_train_engine(int e);
 int get_train_engine();
 int64_t bf16x3_packed_bytes();
@@ -623,6 +626,20 @@ int aon_art_render_fwd_bf16x3(const void* packed_coarse, const void* small_coars
   c.bf16x3 = true; f.bf16x3 = true;
   return render_impl("aon_art_render_fwd_bf16x3", c, f, rays_o, rays_d, viewdirs, n_rays, near_, far_, white_bkgd, num_levels, t_rand, u,
                      u_stride, rgb_c, acc_c, depth_c, rgb_f, acc_f, depth_f, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int aon_art_mlp_fwd_train_bf16x3(const void* packed_bf16x3, const void* small, const float* rays_o, const float* rays_d,
+                                 const float* viewdirs, const float* t_vals, int64_t n_rays, int S, float* raw, float* planes,
+                                 void* masks, void* stream) {
+  if (n_rays < 0 || S < 1) return fail(AON_E_INVALID, "aon_art_mlp_fwd_train_bf16x3: bad size");
+  if (n_rays == 0) return AON_OK;
+  if (!packed_bf16x3 || !small || !rays_o || !rays_d || !viewdirs || !t_vals || !raw || !planes || !masks)
+    return fail(AON_E_INVALID, "aon_art_mlp_fwd_train_bf16x3: null pointer");
+  if (reinterpret_cast<uintptr_t>(masks) & 15) return fail(AON_E_INVALID, "aon_art_mlp_fwd_train_bf16x3: masks must be 16-byte aligned");
+  MlpTimer timer((hipStream_t)stream, n_rays * S);
+  return check(aon::launch_art_mlp_fwd_train_bf16x3(static_cast<const char*>(packed_bf16x3), static_cast<const float*>(small), rays_o,
+                                                    rays_d, viewdirs, t_vals, n_rays, S, raw, planes, masks, (hipStream_t)stream),
+               "aon_art_mlp_fwd_train_bf16x3");
 }
 
 }  // extern "C"

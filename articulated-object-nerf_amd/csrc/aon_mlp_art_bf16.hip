@@ -85,12 +85,14 @@ __global__ void pack_art_bf16x3_kernel(ArtPackArgsB a, char* __restrict__ packed
 
 // 128 -> 128 layer over four input tiles (deformation layers 1-3, view layers 1-3): the input is the previous layer's
 // pre-activation (ReLU applied in the split).  On entry `cur` holds the fragments of in[0].
-template <int CBASE>
-__device__ __forceinline__ void layer4_bf16(Pipe& p, LimbFrag (&cur)[2], const f32x16 (&in)[4], f32x16 (&out)[4]) {
+template <int CBASE, bool TRAIN = false>
+__device__ __forceinline__ void layer4_bf16(Pipe& p, LimbFrag (&cur)[2], const f32x16 (&in)[4], f32x16 (&out)[4], float* in_plane = nullptr,
+                                            const PlaneIO* io = nullptr, int64_t tile_bytes = 0) {
   LimbFrag nxt[2];
-  chunk_mma_bf16<CBASE + 0, 4, true, 1, false, Bf16ArtNet>(p, cur, out, in[1], nxt); cur[0] = nxt[0]; cur[1] = nxt[1];
-  chunk_mma_bf16<CBASE + 1, 4, true, 1, false, Bf16ArtNet>(p, cur, out, in[2], nxt); cur[0] = nxt[0]; cur[1] = nxt[1];
-  chunk_mma_bf16<CBASE + 2, 4, true, 1, false, Bf16ArtNet>(p, cur, out, in[3], nxt); cur[0] = nxt[0]; cur[1] = nxt[1];
+  auto tp = [&](int j) { return TRAIN ? reinterpret_cast<float*>(reinterpret_cast<char*>(in_plane) + j * tile_bytes) : nullptr; };
+  chunk_mma_bf16<CBASE + 0, 4, true, 1, TRAIN, Bf16ArtNet>(p, cur, out, in[1], nxt, tp(1), io); cur[0] = nxt[0]; cur[1] = nxt[1];
+  chunk_mma_bf16<CBASE + 1, 4, true, 1, TRAIN, Bf16ArtNet>(p, cur, out, in[2], nxt, tp(2), io); cur[0] = nxt[0]; cur[1] = nxt[1];
+  chunk_mma_bf16<CBASE + 2, 4, true, 1, TRAIN, Bf16ArtNet>(p, cur, out, in[3], nxt, tp(3), io); cur[0] = nxt[0]; cur[1] = nxt[1];
   chunk_mma_bf16<CBASE + 3, 4, false, 0, false, Bf16ArtNet>(p, cur, out, in[3], nxt);
 }
 
@@ -100,8 +102,12 @@ struct ArtBfArgs {
   const float* rays_o; const float* rays_d; const float* viewdirs; const float* t_vals;
   float* raw;
   int64_t total; int S; int npass;
+  float* planes;   // [TRAIN] kAPlRows x Np activation planes (row map of aon_mlp_art.hip's training forward)
+  u32x4* masks;    // [TRAIN] kAMaskLayers x (Np*2) ReLU bit masks
+  int64_t Np;
 };
 
+template <bool TRAIN>
 __global__ void __launch_bounds__(256) art_mlp_fwd_bf16x3_kernel(ArtBfArgs args) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* sm = reinterpret_cast<float*>(smem + kBfRingBytes);
@@ -139,8 +145,24 @@ __global__ void __launch_bounds__(256) art_mlp_fwd_bf16x3_kernel(ArtBfArgs args)
       return e;
     };
     LimbFrag cur[2], nxt[2];
+    PlaneIO io{};
+    if constexpr (TRAIN) io = make_plane_io(args.Np, g, h);
+    auto rows = [&](int row) { return reinterpret_cast<float*>(reinterpret_cast<char*>(args.planes) + (int64_t)row * io.row_bytes); };
+    const int64_t tile_bytes = 32 * io.row_bytes;
+    auto mask = [&](auto& tiles, int slot) {
+      if constexpr (TRAIN) args.masks[(int64_t)slot * args.Np * 2 + (int64_t)pass * 256 + tid] = relu_mask_bits(tiles);
+    };
+    auto save_row = [&](int row, float v) {  // one scalar per sample (lanes 0..31)
+      if constexpr (TRAIN) { if (h == 0) *reinterpret_cast<float*>(reinterpret_cast<char*>(args.planes) + (int64_t)row * io.row_bytes + g * 4) = v; }
+    };
+    if constexpr (TRAIN) {
+#pragma unroll
+      for (int a = 0; a < 3; ++a) save_row(kAPlPos + a, x[a]);
+    }
 
     // ---- deformation MLP (:196-205): layer 0 (3 -> 128, effective bias) on the VALU, layers 1-3 on the matrix pipe ----
+    // [TRAIN] every tile's ReLU'd fp32 values are stored by the split that consumes it; tiles consumed by a VALU head
+    // (deformation layer 3, view layer 3) are stored directly; the ReLU decisions go out as bit masks after each layer.
     f32x16 H0[4], H1[4];   // PRE-activations; the ReLU is applied by the split / head that consumes them
     init_bias(H0, sm + kA_BD0, h);
 #pragma unroll
@@ -155,9 +177,14 @@ __global__ void __launch_bounds__(256) art_mlp_fwd_bf16x3_kernel(ArtBfArgs args)
         }
       }
     }
-    split_tile<1>(H0[0], cur); init_bias(H1, sm + kA_BD + 0 * 128, h); layer4_bf16<kAChD1 + 0>(p, cur, H0, H1);
-    split_tile<1>(H1[0], cur); init_bias(H0, sm + kA_BD + 1 * 128, h); layer4_bf16<kAChD1 + 4>(p, cur, H1, H0);
-    split_tile<1>(H0[0], cur); init_bias(H1, sm + kA_BD + 2 * 128, h); layer4_bf16<kAChD1 + 8>(p, cur, H0, H1);
+    mask(H0, 0);
+    split_tile<1, TRAIN>(H0[0], cur, rows(aplane_d(0)), &io); init_bias(H1, sm + kA_BD + 0 * 128, h);
+    layer4_bf16<kAChD1 + 0, TRAIN>(p, cur, H0, H1, rows(aplane_d(0)), &io, tile_bytes); mask(H1, 1);
+    split_tile<1, TRAIN>(H1[0], cur, rows(aplane_d(1)), &io); init_bias(H0, sm + kA_BD + 1 * 128, h);
+    layer4_bf16<kAChD1 + 4, TRAIN>(p, cur, H1, H0, rows(aplane_d(1)), &io, tile_bytes); mask(H0, 2);
+    split_tile<1, TRAIN>(H0[0], cur, rows(aplane_d(2)), &io); init_bias(H1, sm + kA_BD + 2 * 128, h);
+    layer4_bf16<kAChD1 + 8, TRAIN>(p, cur, H0, H1, rows(aplane_d(2)), &io, tile_bytes); mask(H1, 3);
+    if constexpr (TRAIN) { relu_tiles(H1); store_plane(H1, rows(aplane_d(3)), io); }
     float xd[3];
 #pragma unroll
     for (int a = 0; a < 3; ++a) {  // x' = deformation_layer(relu(h)) + pos   (:205)
@@ -168,6 +195,11 @@ __global__ void __launch_bounds__(256) art_mlp_fwd_bf16x3_kernel(ArtBfArgs args)
     {  // pos_enc of the deformed point (enc_after=True, :207-208), parked in LDS between trunk layers 0 and 5
       f32x16 E[2];
       encode_pos(xd, h, E);
+      if constexpr (TRAIN) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) save_row(kAPlPos + 3 + a, xd[a]);
+        store_pos_enc_plane(E, rows(kAPlE), io, g, h);
+      }
 #pragma unroll
       for (int tile = 0; tile < 2; ++tile)
 #pragma unroll
@@ -186,38 +218,46 @@ __global__ void __launch_bounds__(256) art_mlp_fwd_bf16x3_kernel(ArtBfArgs args)
       chunk_mma_bf16<kAChT0 + 0, 8, true, 0, false, Bf16ArtNet>(p, cur, X, e1, nxt); cur[0] = nxt[0]; cur[1] = nxt[1];
       chunk_mma_bf16<kAChT0 + 1, 8, false, 0, false, Bf16ArtNet>(p, cur, X, e1, nxt);
     }
-#define AON_BA_LAYER(IN, OUT, BIAS, CB)                                                                       \
-    split_tile<1>(IN[0], cur); init_bias(OUT, sm + (BIAS), h);                                                  \
-    layer8_bf16<CB, 8, 1, false, 0, false, false, Bf16ArtNet>(p, cur, IN, OUT, IN[0]);
-    AON_BA_LAYER(X, Y, kA_BT + 1 * 256, kAChT1 + 0)
-    AON_BA_LAYER(Y, X, kA_BT + 2 * 256, kAChT1 + 8)
-    AON_BA_LAYER(X, Y, kA_BT + 3 * 256, kAChT1 + 16)
-    AON_BA_LAYER(Y, X, kA_BT + 4 * 256, kAChT1 + 24)
+    mask(X, 4);
+#define AON_BA_LAYER(IN, OUT, L_IN, BIAS, CB)                                                                          \
+    split_tile<1, TRAIN>(IN[0], cur, rows(aplane_h(L_IN)), &io); init_bias(OUT, sm + (BIAS), h);                         \
+    layer8_bf16<CB, 8, 1, false, 0, TRAIN, false, Bf16ArtNet>(p, cur, IN, OUT, IN[0], rows(aplane_h(L_IN)), &io, tile_bytes);
+    AON_BA_LAYER(X, Y, 0, kA_BT + 1 * 256, kAChT1 + 0)  mask(Y, 5);
+    AON_BA_LAYER(Y, X, 1, kA_BT + 2 * 256, kAChT1 + 8)  mask(X, 6);
+    AON_BA_LAYER(X, Y, 2, kA_BT + 3 * 256, kAChT1 + 16) mask(Y, 7);
+    AON_BA_LAYER(Y, X, 3, kA_BT + 4 * 256, kAChT1 + 24) mask(X, 8);
     // layer 5: cat[relu(h4) (8 tiles), enc (2 tiles)]
-    split_tile<1>(X[0], cur); init_bias(Y, sm + kA_BT + 5 * 256, h);
+    split_tile<1, TRAIN>(X[0], cur, rows(aplane_h(4)), &io); init_bias(Y, sm + kA_BT + 5 * 256, h);
     {
       const f32x16 e0 = load_enc(0);
-      layer8_bf16<kAChT5, 8, 1, true, 0, false, false, Bf16ArtNet>(p, cur, X, Y, e0);
+      layer8_bf16<kAChT5, 8, 1, true, 0, TRAIN, false, Bf16ArtNet>(p, cur, X, Y, e0, rows(aplane_h(4)), &io, tile_bytes);
       const f32x16 e1 = load_enc(1);
       chunk_mma_bf16<kAChT5 + 8, 8, true, 0, false, Bf16ArtNet>(p, cur, Y, e1, nxt); cur[0] = nxt[0]; cur[1] = nxt[1];
       chunk_mma_bf16<kAChT5 + 9, 8, false, 0, false, Bf16ArtNet>(p, cur, Y, e1, nxt);
     }
-    AON_BA_LAYER(Y, X, kA_BT + 6 * 256, kAChT6)
-    AON_BA_LAYER(X, Y, kA_BT + 7 * 256, kAChT7)
+    mask(Y, 9);
+    AON_BA_LAYER(Y, X, 5, kA_BT + 6 * 256, kAChT6) mask(X, 10);
+    AON_BA_LAYER(X, Y, 6, kA_BT + 7 * 256, kAChT7) mask(Y, 11);
     float sigma = head_partial_relu<8>(Y, sm + kA_WSIG, h);  // density_layer on relu(layer 7) (:219)
     sigma = sigma + __shfl_xor(sigma, 32) + sm[kA_BSIG];
-    AON_BA_LAYER(Y, X, kA_BBOT, kAChBott)                       // bottleneck, linear output (:223)
+    AON_BA_LAYER(Y, X, 7, kA_BBOT, kAChBott)                    // bottleneck, linear output (:223)
 #undef AON_BA_LAYER
 
     // ---- view branch (:227-234): cat[bottleneck, viewenc, appearance (folded)] -> 4 x (128, ReLU) ----
     f32x16 Z0[4], Z1[4], V;
     encode_view(vd, h, V);
-    split_tile<0>(X[0], cur); init_bias(Z0, sm + kA_BV + 0 * 128, h);
-    layer8_bf16<kAChV0, 4, 0, true, 0, false, false, Bf16ArtNet>(p, cur, X, Z0, V);
+    if constexpr (TRAIN) store_view_enc_plane(V, rows(kAPlVE), io, g, h);
+    split_tile<0, TRAIN>(X[0], cur, rows(kAPlBot), &io); init_bias(Z0, sm + kA_BV + 0 * 128, h);
+    layer8_bf16<kAChV0, 4, 0, true, 0, TRAIN, false, Bf16ArtNet>(p, cur, X, Z0, V, rows(kAPlBot), &io, tile_bytes);
     chunk_mma_bf16<kAChV0 + 8, 4, false, 0, false, Bf16ArtNet>(p, cur, Z0, V, nxt);
-    split_tile<1>(Z0[0], cur); init_bias(Z1, sm + kA_BV + 1 * 128, h); layer4_bf16<kAChV1 + 0>(p, cur, Z0, Z1);
-    split_tile<1>(Z1[0], cur); init_bias(Z0, sm + kA_BV + 2 * 128, h); layer4_bf16<kAChV1 + 4>(p, cur, Z1, Z0);
-    split_tile<1>(Z0[0], cur); init_bias(Z1, sm + kA_BV + 3 * 128, h); layer4_bf16<kAChV1 + 8>(p, cur, Z0, Z1);
+    mask(Z0, 12);
+    split_tile<1, TRAIN>(Z0[0], cur, rows(aplane_v(0)), &io); init_bias(Z1, sm + kA_BV + 1 * 128, h);
+    layer4_bf16<kAChV1 + 0, TRAIN>(p, cur, Z0, Z1, rows(aplane_v(0)), &io, tile_bytes); mask(Z1, 13);
+    split_tile<1, TRAIN>(Z1[0], cur, rows(aplane_v(1)), &io); init_bias(Z0, sm + kA_BV + 2 * 128, h);
+    layer4_bf16<kAChV1 + 4, TRAIN>(p, cur, Z1, Z0, rows(aplane_v(1)), &io, tile_bytes); mask(Z0, 14);
+    split_tile<1, TRAIN>(Z0[0], cur, rows(aplane_v(2)), &io); init_bias(Z1, sm + kA_BV + 3 * 128, h);
+    layer4_bf16<kAChV1 + 8, TRAIN>(p, cur, Z0, Z1, rows(aplane_v(2)), &io, tile_bytes); mask(Z1, 15);
+    if constexpr (TRAIN) { relu_tiles(Z1); store_plane(Z1, rows(aplane_v(3)), io); }
     float rgb[3];
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) {  // rgb_layer on relu(view layer 3) (:236)
@@ -244,22 +284,37 @@ hipError_t launch_pack_art_bf16x3(const float* const* params, char* packed, hipS
   return hipGetLastError();
 }
 
-hipError_t launch_art_mlp_fwd_bf16x3(const char* packed, const float* small, const float* rays_o, const float* rays_d,
-                                     const float* viewdirs, const float* t_vals, int64_t n_rays, int S, float* raw, hipStream_t stream) {
+template <bool TRAIN>
+static hipError_t launch_art_bf16x3_t(ArtBfArgs a, hipStream_t stream) {
   static bool attr = false;
   if (!attr) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&art_mlp_fwd_bf16x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&art_mlp_fwd_bf16x3_kernel<TRAIN>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        kBaLdsBytes);
     if (e != hipSuccess) return e;
     attr = true;
   }
-  ArtBfArgs a{packed, small, rays_o, rays_d, viewdirs, t_vals, raw, n_rays * S, S, (int)((n_rays * S + 127) / 128)};
   const int cus = num_cus();
   if (cus <= 0) return hipErrorInvalidDevice;
   const int grid = a.npass < cus ? a.npass : cus;
   if (grid <= 0) return hipSuccess;
-  art_mlp_fwd_bf16x3_kernel<<<dim3(grid), dim3(256), kBaLdsBytes, stream>>>(a);
+  art_mlp_fwd_bf16x3_kernel<TRAIN><<<dim3(grid), dim3(256), kBaLdsBytes, stream>>>(a);
   return hipGetLastError();
+}
+
+hipError_t launch_art_mlp_fwd_bf16x3(const char* packed, const float* small, const float* rays_o, const float* rays_d,
+                                     const float* viewdirs, const float* t_vals, int64_t n_rays, int S, float* raw, hipStream_t stream) {
+  ArtBfArgs a{packed, small, rays_o, rays_d, viewdirs, t_vals, raw, n_rays * S, S, (int)((n_rays * S + 127) / 128), nullptr, nullptr, 0};
+  return launch_art_bf16x3_t<false>(a, stream);
+}
+
+// training forward of the bf16x3 engine: planes / masks contract of launch_art_mlp_fwd_train (aon_mlp_art.hip)
+hipError_t launch_art_mlp_fwd_train_bf16x3(const char* packed, const float* small, const float* rays_o, const float* rays_d,
+                                           const float* viewdirs, const float* t_vals, int64_t n_rays, int S, float* raw, float* planes,
+                                           void* masks, hipStream_t stream) {
+  ArtBfArgs a{packed, small, rays_o, rays_d, viewdirs, t_vals, raw, n_rays * S, S, (int)((n_rays * S + 127) / 128), planes,
+              static_cast<u32x4*>(masks), 0};
+  a.Np = (int64_t)a.npass * 128;
+  return launch_art_bf16x3_t<true>(a, stream);
 }
 
 }  // namespace aon

@@ -146,7 +146,10 @@ class NeRF_AE_Art(nn.Module):
             packs = []
             for mlp in mlps:
                 small = ops.art_prepare(dict(mlp.named_parameters()), latents)
-                packs.append((mlp.packed(), small, mlp.packed_bwd()))
+                if ops.get_train_engine() == "bf16x3":   # opt-in: split-bf16 training forward (+ weight gradients)
+                    packs.append((None, small, mlp.packed_bwd(), mlp.packed_bf16x3()))
+                else:
+                    packs.append((mlp.packed(), small, mlp.packed_bwd()))
             params = [p for mlp in mlps for p in mlp.ordered_params()]
             flat = RenderArticulated.apply(rays_o, rays["rays_d"], rays["viewdirs"], float(near), float(far), bool(white_bkgd),
                                            self.num_levels, t_rand, u, packs, latents["density"], latents["color"],

@@ -568,7 +568,7 @@ def pack_art_mlp_bwd(params: dict, out: torch.Tensor | None = None) -> torch.Ten
     return out
 
 
-def art_mlp_fwd_train(packed, small, rays_o, rays_d, viewdirs, t_vals):
+def art_mlp_fwd_train(packed, small, rays_o, rays_d, viewdirs, t_vals, engine: str = "fp32"):
     o, d, v, t = _f32(rays_o, "rays_o"), _f32(rays_d, "rays_d"), _f32(viewdirs, "viewdirs"), _f32(t_vals, "t_vals")
     n, S = t.shape
     Np = padded_samples(n * S)
@@ -576,8 +576,9 @@ def art_mlp_fwd_train(packed, small, rays_o, rays_d, viewdirs, t_vals):
     planes = torch.empty((int(lib.aon_art_train_plane_rows()), Np), dtype=torch.float32, device=t.device)
     masks = torch.empty(int(lib.aon_art_train_mask_bytes(Np)), dtype=torch.uint8, device=t.device)
     with torch.cuda.device(t.device):
-        check(lib.aon_art_mlp_fwd_train(_ptr(packed), _ptr(small), _ptr(o), _ptr(d), _ptr(v), _ptr(t), n, S, _ptr(raw), _ptr(planes),
-                                        _ptr(masks), _stream()), "aon_art_mlp_fwd_train")
+        fn = lib.aon_art_mlp_fwd_train if engine == "fp32" else lib.aon_art_mlp_fwd_train_bf16x3   # bf16x3: packed = pack_art_mlp_bf16x3
+        check(fn(_ptr(packed), _ptr(small), _ptr(o), _ptr(d), _ptr(v), _ptr(t), n, S, _ptr(raw), _ptr(planes), _ptr(masks), _stream()),
+              "aon_art_mlp_fwd_train")
     return raw, planes, masks
 
 

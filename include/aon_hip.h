@@ -233,6 +233,10 @@ int64_t aon_art_bf16x3_packed_bytes(void);
 int aon_pack_art_mlp_bf16x3(const float* const* params_host, void* packed, void* stream);
 int aon_art_mlp_fwd_bf16x3(const void* packed_bf16x3, const void* small, const float* rays_o, const float* rays_d,
                            const float* viewdirs, const float* t_vals, int64_t n_rays, int S, float* raw, void* stream);
+/* aon_art_mlp_fwd_train on the bf16x3 engine: same planes / masks / raw contract */
+int aon_art_mlp_fwd_train_bf16x3(const void* packed_bf16x3, const void* small, const float* rays_o, const float* rays_d,
+                                 const float* viewdirs, const float* t_vals, int64_t n_rays, int S, float* raw, float* planes,
+                                 void* masks, void* stream);
 int aon_art_render_fwd_bf16x3(const void* packed_coarse, const void* small_coarse, const void* packed_fine, const void* small_fine,
                               const float* rays_o, const float* rays_d, const float* viewdirs, int64_t n_rays, float near_, float far_,
                               int white_bkgd, int num_levels, const float* t_rand, const float* u, int64_t u_stride, float* rgb_c,

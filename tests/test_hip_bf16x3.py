@@ -191,3 +191,60 @@ def test_bf16x3_articulated_engine(dev, golden):
         mse = torch.mean((a[lvl][0] - b[lvl][0]) ** 2).item()
         assert -10.0 * math.log10(max(mse, 1e-20)) >= 80.0, (lvl, mse)
         assert (a[lvl][1] - b[lvl][1]).abs().max().item() <= 2e-4
+
+
+def test_bf16x3_articulated_training_forward(dev, golden):
+    """Articulated bf16x3 training forward: same planes / masks / raw as the fp32 training forward (fp32-class
+    differences), and a training step through NeRF_AE_Art on the bf16x3 engine stays within the articulated path's
+    gradient tolerance against the fp32 engine's gradients."""
+    import aon_amd.synthetic as syn
+    from aon_amd import ops
+    from aon_amd.models.vanilla_nerf.model_autodecoder import NeRF_AE_Art
+
+    g = golden("g11_nerf_ae_art")
+    art_sd = syn.make_art_state_dict(seed=0, density_scale=30.0)
+    params = {k[len("fine_mlp."):]: v.to(dev) for k, v in art_sd.items() if k.startswith("fine_mlp.")}
+    lat = {k: g[f"lat_train_{k}"].to(dev) for k in ("density", "color", "articulation")}
+    pk, pb, small = ops.pack_art_mlp(params), ops.pack_art_mlp_bf16x3(params), ops.art_prepare(params, lat)
+    n, S = 29, 193
+    rays = {k: v.to(dev) for k, v in syn.random_rays(n, seed=8).items()}
+    t = torch.sort(torch.rand(n, S, generator=torch.Generator().manual_seed(8)) * 4 + 2, dim=-1).values.to(dev)
+    raw_a, pl_a, mk_a = ops.art_mlp_fwd_train(pk, small, rays["rays_o"], rays["rays_d"], rays["viewdirs"], t)
+    raw_b, pl_b, mk_b = ops.art_mlp_fwd_train(pb, small, rays["rays_o"], rays["rays_d"], rays["viewdirs"], t, engine="bf16x3")
+    torch.testing.assert_close(raw_b[..., :3], raw_a[..., :3], rtol=5e-5, atol=5e-5)
+    torch.testing.assert_close(raw_b[..., 3], raw_a[..., 3], rtol=5e-5, atol=2e-3)
+    valid = n * S
+    # rows the backward reads: positions (0..5), deformation / trunk / bottleneck / view blocks, encodings without their pad rows
+    blocks = [(0, 6), (32, 544), (544, 607), (608, 2912), (2912, 2939), (2944, 3456)]
+    for r0, r1 in blocks:
+        a, b = pl_a[r0:r1, :valid], pl_b[r0:r1, :valid]
+        # the deformed position feeds a 2^9-octave encoding: a 1e-7 difference in x' is 5e-5 in the highest octave
+        assert (a - b).abs().max().item() <= 2e-4 * max(1.0, a.abs().max().item()), (r0, r1, (a - b).abs().max().item())
+    diff = (mk_a.view(torch.uint8) ^ mk_b.view(torch.uint8)).cpu().numpy()
+    assert int(np.unpackbits(diff).sum()) <= 2e-3 * diff.size * 8
+
+    def grads(engine):
+        ops.set_train_engine(engine)
+        try:
+            model = NeRF_AE_Art().to(dev)
+            model.load_state_dict(art_sd)
+            latg = {k: v.clone().requires_grad_(True) for k, v in lat.items()}
+            gen = torch.Generator().manual_seed(3)
+            m = 96
+            r = {k: g[k][:m].to(dev) for k in ("rays_o", "rays_d", "viewdirs")}
+            out = model(r, True, True, g["near"], g["far"], latg, t_rand=torch.rand(m, 65, generator=gen).to(dev),
+                        u=torch.rand(m, 128, generator=gen).to(dev))
+            loss = torch.mean((out[0][0] - 0.5) ** 2) + torch.mean((out[1][0] - 0.5) ** 2)
+            loss.backward()
+            return loss.item(), {k: p.grad.clone() for k, p in model.named_parameters()}, {k: v.grad.clone() for k, v in latg.items()}
+        finally:
+            ops.set_train_engine("fp32")
+
+    la, ga, lga = grads("fp32")
+    lb, gb, lgb = grads("bf16x3")
+    assert abs(la - lb) <= 1e-5 * max(1.0, abs(la))
+    for k in ga:   # tolerance of the articulated e2e gradient tests (ReLU decision flips along the 17-layer chain)
+        err = ((ga[k] - gb[k]).norm() / (ga[k].norm() + 1e-30)).item()
+        assert err <= 5e-2, (k, err)
+    for k in lga:
+        assert ((lga[k] - lgb[k]).norm() / (lga[k].norm() + 1e-30)).item() <= 5e-2, k
