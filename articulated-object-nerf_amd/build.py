@@ -19,10 +19,15 @@ SOURCES = ["aon_mlp.hip", "aon_mlp_bf16.hip", "aon_mlp_art.hip", "aon_mlp_art_bf
 HEADERS = [os.path.join(CSRC, "aon_common.h"), os.path.join(CSRC, "aon_mlp_core.h"), os.path.join(CSRC, "aon_wgrad.h"), os.path.join(CSRC, "aon_art_common.h"),
            os.path.join(os.path.dirname(PKG), "include", "aon_hip.h")]
 # -ffp-contract=off: the stage kernels reproduce the reference's un-fused mul/add sequences; FMAs are explicit.
-# Per-file code-generation choices, measured on MI355X (round 1): forcing MFMA results into architectural VGPRs helps the
-# vanilla backward chain (5.47 -> 4.96 ms per 4096-ray level pair) and hurts the forward kernels (144.0 -> 139.7 TFLOP/s),
-# so it is applied to that translation unit only.
-PER_FILE_FLAGS = {"aon_train.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+# Per-file code-generation choices, A/B-measured on MI355X (round 1, tools/ab_train.sh, 4096-ray vanilla training step):
+# pinning the A-fragment read of step i+1 above the MFMAs of step i (AON_PIN_PREFETCH, aon_mlp_core.h) helps the vanilla
+# backward chain (5.62 -> 4.95 ms per level pair) but costs the forward kernels 2.7 % (144.0 -> 140.2 TFLOP/s) and does
+# nothing for the articulated chains, so it is applied to aon_train.hip only.  (-mllvm -amdgpu-mfma-vgpr-form on the same
+# file: backward chain 5.26 ms but the weight-gradient kernel 0.525 -> 0.643 ms -- a net loss.)
+PER_FILE_FLAGS = {"aon_train.hip": ["-DAON_PIN_PREFETCH"]}
+if "AON_PER_FILE_FLAGS" in os.environ:   # experiments: JSON {"file.hip": ["flag", ...]} replaces the table
+    import json as _json
+    PER_FILE_FLAGS = _json.loads(os.environ["AON_PER_FILE_FLAGS"])
 FLAGS = (os.environ.get("AON_EXTRA_FLAGS", "").split()) + ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 
@@ -47,13 +52,19 @@ def build(force: bool = False, verbose: bool = True) -> str:
     for src in SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(OBJ, src.replace(".hip", ".o"))
-        if force or _stale(o, [s] + HEADERS):
-            jobs.append([cc, *FLAGS, *PER_FILE_FLAGS.get(src, []), "-c", s, "-o", o])
+        cmd = [cc, *FLAGS, *PER_FILE_FLAGS.get(src, []), "-c", s, "-o", o]
+        # an object is also stale when it was built with other flags (AON_EXTRA_FLAGS experiments must not reuse objects)
+        stamp = o + ".cmd"
+        same_cmd = os.path.exists(stamp) and open(stamp).read() == " ".join(cmd)
+        if force or not same_cmd or _stale(o, [s] + HEADERS):
+            jobs.append(cmd)
 
     def run(cmd):
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True, timeout=1800)
+        with open(cmd[-1] + ".cmd", "w") as f:
+            f.write(" ".join(cmd))
 
     with ThreadPoolExecutor(max_workers=7) as ex:
         list(ex.map(run, jobs))

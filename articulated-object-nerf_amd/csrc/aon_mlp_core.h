@@ -130,9 +130,10 @@ __device__ __forceinline__ void chunk_mma(Pipe& p, const f32x16& in, f32x16 (&ou
   const char* buf = p.ring + p.slot * kPairSlotBytes + pair_offset<Net>(C) + p.lane_off;
   constexpr int NQ = (NREG + 3) / 4;
   constexpr int NSTEP = NQ * NT_OUT;
-  // (round-1 experiments, all slower than the compiler's own interleave of this distance-1 form at 0.915 of peak: a
-  // distance-2 prefetch pinned by sched_barrier(0) per step 0.900; this distance-1 read pinned above its four MFMAs 0.891;
-  // ReLU applied lazily here on the input tile instead of as a block between layers 0.869 -- 16 more live registers.)
+  // (round-1 experiments on the forward kernels, all slower than the compiler's own interleave of this distance-1 form at
+  // 0.915 of peak: a distance-2 prefetch pinned by sched_barrier(0) per step 0.900; this distance-1 read pinned above its
+  // four MFMAs 0.891 -- which does pay in the vanilla backward chain, see AON_PIN_PREFETCH; ReLU applied lazily here on
+  // the input tile instead of as a block between layers 0.869 -- 16 more live registers.)
   f32x4 a_cur = *reinterpret_cast<const f32x4*>(buf);
 #pragma unroll
   for (int i = 0; i < NSTEP; ++i) {
@@ -146,6 +147,9 @@ __device__ __forceinline__ void chunk_mma(Pipe& p, const f32x16& in, f32x16 (&ou
     if constexpr (STORE) {
       if (i < 16) *plane_addr(tile_plane, *io, (i & 3) + 8 * (i >> 2)) = in[i];
     }
+#ifdef AON_PIN_PREFETCH   // per translation unit (build.py): keeps the read of step i+1 above the four MFMAs of step i
+    __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
     for (int cc = 0; cc < 4; ++cc) {
       if (4 * q + cc < NREG) out[tp] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[cc], in[4 * q + cc], out[tp], 0, 0, 0);

@@ -25,11 +25,15 @@ run rocprofv3 --kernel-trace --stats -d $OUT/train_van -o $TAG -- python $REPO/t
 # 4. articulated render (BASELINE config 4) + bf16x3 engine
 run rocprofv3 --kernel-trace --stats -d $OUT/render_art -o $TAG -- python $REPO/tools/render_bench.py > $OUT/render_art.log 2>&1
 run rocprofv3 --kernel-trace --stats -d $OUT/bf16x3 -o $TAG -- python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-train-leg --engine bf16x3 > $OUT/bf16x3.log 2>&1
+# 5. opt-in bf16x3 engines outside the headline: articulated render, training steps (plain timings, no profiler)
+run python $REPO/tools/render_bench.py --bf16x3 > $OUT/render_art_bf16x3.log 2>&1
+run python $REPO/tools/train_bench.py --rays 4096 --steps 10 --train-engine bf16x3 > $OUT/train_van_bf16x3.log 2>&1
+run python $REPO/tools/train_bench.py --rays 4096 --steps 10 --articulated --train-engine bf16x3 > $OUT/train_art_bf16x3.log 2>&1
 cd $REPO
 python tools/summarize_rocprof.py $OUT $SUM/${TAG} > $SUM/summary.log 2>&1
 for d in train_art train_van render_art bf16x3; do
   f=$(ls $OUT/$d/*_results.db 2>/dev/null | head -1)
   [ -n "$f" ] && python tools/kstats.py $f 16 > $SUM/${TAG}_${d}_kernel_stats.txt 2>&1
 done
-for l in stats_run pmc_fetch pmc_write pmc_sq pmc_sq2 train_art train_van render_art bf16x3; do grep -h '^{' $OUT/$l.log | tail -1 > $SUM/$l.json; done
-cat $SUM/train_art.json $SUM/train_van.json $SUM/render_art.json; cut -c1-300 $SUM/stats_run.json; cut -c1-200 $SUM/bf16x3.json
+for l in stats_run pmc_fetch pmc_write pmc_sq pmc_sq2 train_art train_van render_art bf16x3 render_art_bf16x3 train_van_bf16x3 train_art_bf16x3; do grep -h '^{' $OUT/$l.log | tail -1 > $SUM/$l.json; done
+cat $SUM/train_art.json $SUM/train_van.json $SUM/render_art.json $SUM/render_art_bf16x3.json $SUM/train_van_bf16x3.json $SUM/train_art_bf16x3.json; cut -c1-300 $SUM/stats_run.json; cut -c1-200 $SUM/bf16x3.json
