@@ -72,6 +72,9 @@ _SIGS = {
     "aon_art_mlp_fwd_train": (_i, [_p, _p, _p, _p, _p, _p, _l, _i, _p, _p, _p, _p]),
     "aon_art_mlp_fwd_train_bf16x3": (_i, [_p, _p, _p, _p, _p, _p, _l, _i, _p, _p, _p, _p]),
     "aon_art_bwd_chain": (_i, [_p, _p, _p, _p, _p, _p, _p, _l, _p]),
+    "aon_art_bwd_bf16x3_packed_bytes": (_l, []),
+    "aon_pack_art_mlp_bwd_bf16x3": (_i, [_p, _p, _p]),
+    "aon_art_bwd_chain_bf16x3": (_i, [_p, _p, _p, _p, _p, _p, _p, _l, _p]),
     "aon_art_wgrad": (_i, [_p, _p, _p, _p, _l, _p, _p, _p, _p, _p, _p, _p, _p, _p, _l, _p]),
     "aon_profile_begin": (_i, []),
     "aon_profile_end": (_i, [C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),

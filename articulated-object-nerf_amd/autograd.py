@@ -73,6 +73,7 @@ class RenderArticulated(torch.autograd.Function):
         for lvl in range(num_levels):
             packed_fwd, small, packed_bwd = packs[lvl][:3]
             packed_bf = packs[lvl][3] if len(packs[lvl]) > 3 else None   # selects the bf16x3 training forward
+            packed_bwd_bf = packs[lvl][4] if len(packs[lvl]) > 4 else None   # ... and the bf16x3 backward chain
             if lvl == 0:
                 t_vals, _ = ops.sample_along_rays(rays_o, rays_d, 64, near, far, t_rand, want_coords=False)
             else:
@@ -83,7 +84,7 @@ class RenderArticulated(torch.autograd.Function):
                 raw, planes, masks = ops.art_mlp_fwd_train(packed_fwd, small, rays_o, rays_d, viewdirs, t_vals)
             rgb, acc, weights, depth = ops.composite_raw(raw, t_vals, rays_d, white_bkgd, ops.ACT_ARTICULATED, want_weights=True)
             outs += [rgb, acc, depth]
-            saved.append((raw, t_vals, planes, masks, small, packed_bwd))
+            saved.append((raw, t_vals, planes, masks, small, packed_bwd, packed_bwd_bf))
         ctx.saved = saved
         ctx.rays_d, ctx.white_bkgd, ctx.num_levels = rays_d, white_bkgd, num_levels
         ctx.latents = {"density": lat_density.detach(), "color": lat_color.detach(), "articulation": lat_articulation.detach()}
@@ -97,13 +98,16 @@ class RenderArticulated(torch.autograd.Function):
         g_lat_tot = None
         n_per = len(ops.ART_PARAM_ORDER)
         for lvl in range(ctx.num_levels):
-            raw, t_vals, planes, masks, small, packed_bwd = ctx.saved[lvl]
+            raw, t_vals, planes, masks, small, packed_bwd, packed_bwd_bf = ctx.saved[lvl]
             g_rgb, g_acc, g_depth = gouts[3 * lvl: 3 * lvl + 3]
             if g_rgb is None:
                 g_rgb = torch.zeros((t_vals.shape[0], 3), dtype=torch.float32, device=t_vals.device)
             d_raw = ops.composite_bwd(raw, t_vals, ctx.rays_d, g_rgb.contiguous(), g_acc, g_depth, ctx.white_bkgd, ops.ACT_ARTICULATED,
                                       planes.shape[1])
-            dplanes, dxp = ops.art_bwd_chain(packed_bwd, small, d_raw, masks, planes)
+            if packed_bwd_bf is not None:
+                dplanes, dxp = ops.art_bwd_chain(packed_bwd_bf, small, d_raw, masks, planes, engine="bf16x3")
+            else:
+                dplanes, dxp = ops.art_bwd_chain(packed_bwd, small, d_raw, masks, planes)
             params = dict(zip(ops.ART_PARAM_ORDER, ctx.params[lvl * n_per: (lvl + 1) * n_per]))
             g, g_lat = ops.art_wgrad(planes, dplanes, d_raw, dxp, params, ctx.latents)
             grads += [g[name] for name in ops.ART_PARAM_ORDER]

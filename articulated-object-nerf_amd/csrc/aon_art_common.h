@@ -38,5 +38,16 @@ constexpr int kAChV0 = 80;    // views_linear.0 : 8 hidden + 1 view-enc, 4 outpu
 constexpr int kAChV1 = 89;    // views_linear.1..3 : 4 chunks each
 constexpr int kANumChunks = 101;
 
+// ---- transposed chunk stream (execution order of the backward chain) ----
+constexpr int kABwV3 = 0;      // views_linear.3^T, .2^T, .1^T : 4 chunks each, 4 output tiles (16 KiB)
+constexpr int kABwV0 = 12;     // views_linear.0[:, :256]^T : 4 chunks, 8 output tiles (32 KiB)
+constexpr int kABwBott = 16;   // bottleneck^T : 8
+constexpr int kABwL7 = 24;     // pts_linears.7^T, .6^T : 8 each
+constexpr int kABwL5E = 40;    // pts_linears.5[:, 256:319]^T : 8 chunks, 2 output tiles (8 KiB)  -> d pos-enc
+constexpr int kABwL5 = 48;     // pts_linears.5[:, :256]^T, then .4 .3 .2 .1 : 8 each
+constexpr int kABwL0E = 88;    // pts_linears.0[:, :63]^T : 8 chunks, 2 output tiles              -> d pos-enc
+constexpr int kABwD3 = 96;     // deformations_linear.3^T, .2^T, .1^T : 4 chunks each, 4 output tiles
+constexpr int kABwNumChunks = 108;
+
 
 }  // namespace aon

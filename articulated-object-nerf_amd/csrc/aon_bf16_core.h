@@ -130,12 +130,19 @@ __device__ __forceinline__ void chunk_mma_bf16(Pipe& p, const LimbFrag (&b)[2], 
     acc = mfma_bf16(al, b[s].hi, acc);   // smallest terms first
     acc = mfma_bf16(ah, b[s].lo, acc);
     acc = mfma_bf16(am, b[s].mid, acc);
-    if (HAS_NEXT) {  // the 8 pair-splits of the next input tile, one per group, finished by mid-chunk
-      if (i < 8) split_pair<PRE_NEXT, TRAIN>(next, i, bn, next_plane, io, next_bits);
+    if (HAS_NEXT) {  // the 8 pair-splits of the next input tile, spread over the groups (one per group when there are >= 8)
+      constexpr int PPG = (8 + NSTEP - 1) / NSTEP;
+#pragma unroll
+      for (int q = 0; q < PPG; ++q)
+        if (i * PPG + q < 8) split_pair<PRE_NEXT, TRAIN>(next, i * PPG + q, bn, next_plane, io, next_bits);
     }
     // DMA rounds of the next chunk, spread over the groups (all issued well before this chunk ends)
-    if (NSTEP >= ROUNDS) { if (i < ROUNDS) issue_round<Net>(p, dma_off, p.slot ^ 1, i); }
-    else { if (2 * i < ROUNDS) issue_round<Net>(p, dma_off, p.slot ^ 1, 2 * i); if (2 * i + 1 < ROUNDS) issue_round<Net>(p, dma_off, p.slot ^ 1, 2 * i + 1); }
+    {
+      constexpr int RPG = (ROUNDS + NSTEP - 1) / NSTEP;
+#pragma unroll
+      for (int q = 0; q < RPG; ++q)
+        if (i * RPG + q < ROUNDS) issue_round<Net>(p, dma_off, p.slot ^ 1, i * RPG + q);
+    }
     acc = mfma_bf16(am, b[s].hi, acc);
     acc = mfma_bf16(ah, b[s].mid, acc);
     acc = mfma_bf16(ah, b[s].hi, acc);

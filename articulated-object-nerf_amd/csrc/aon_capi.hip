@@ -60,6 +60,10 @@ hipError_t launch_art_mlp_fwd_bf16x3(const char* packed, const float* small, con
 hipError_t launch_art_mlp_fwd_train_bf16x3(const char* packed, const float* small, const float* rays_o, const float* rays_d,
                                            const float* viewdirs, const float* t_vals, int64_t n_rays, int S, float* raw, float* planes,
                                            void* masks, hipStream_t stream);
+int64_t art_bwd_bf16x3_packed_bytes();
+hipError_t launch_pack_art_bwd_bf16x3(const float* const* params, char* packed, hipStream_t stream);
+hipError_t launch_art_bwd_chain_bf16x3(const char* packed_bwd, const float* small, const float* d_raw, const void* masks,
+                                       const float* planes, float* dplanes, float* dxp, int64_t Np, hipStream_t stream);
 void set_train_engine(int e);
 int get_train_engine();
 int64_t bf16x3_packed_bytes();
@@ -640,6 +644,26 @@ int aon_art_mlp_fwd_train_bf16x3(const void* packed_bf16x3, const void* small, c
   return check(aon::launch_art_mlp_fwd_train_bf16x3(static_cast<const char*>(packed_bf16x3), static_cast<const float*>(small), rays_o,
                                                     rays_d, viewdirs, t_vals, n_rays, S, raw, planes, masks, (hipStream_t)stream),
                "aon_art_mlp_fwd_train_bf16x3");
+}
+
+int64_t aon_art_bwd_bf16x3_packed_bytes(void) { return aon::art_bwd_bf16x3_packed_bytes(); }
+
+int aon_pack_art_mlp_bwd_bf16x3(const float* const* params_host, void* packed_bwd, void* stream) {
+  if (!params_host || !packed_bwd) return fail(AON_E_INVALID, "aon_pack_art_mlp_bwd_bf16x3: null pointer");
+  for (int i = 0; i < 40; ++i)
+    if (!params_host[i]) return fail(AON_E_INVALID, "aon_pack_art_mlp_bwd_bf16x3: null parameter pointer");
+  if (reinterpret_cast<uintptr_t>(packed_bwd) & 15) return fail(AON_E_INVALID, "aon_pack_art_mlp_bwd_bf16x3: buffer must be 16-byte aligned");
+  return check(aon::launch_pack_art_bwd_bf16x3(params_host, static_cast<char*>(packed_bwd), (hipStream_t)stream), "aon_pack_art_mlp_bwd_bf16x3");
+}
+
+int aon_art_bwd_chain_bf16x3(const void* packed_bwd_bf16x3, const void* small, const float* d_raw, const void* masks, const float* planes,
+                             float* dplanes, float* dxp, int64_t Np, void* stream) {
+  if (Np < 0 || (Np & 127)) return fail(AON_E_INVALID, "aon_art_bwd_chain_bf16x3: Np must be a multiple of 128");
+  if (Np == 0) return AON_OK;
+  if (!packed_bwd_bf16x3 || !small || !d_raw || !masks || !planes || !dplanes || !dxp)
+    return fail(AON_E_INVALID, "aon_art_bwd_chain_bf16x3: null pointer");
+  return check(aon::launch_art_bwd_chain_bf16x3(static_cast<const char*>(packed_bwd_bf16x3), static_cast<const float*>(small), d_raw, masks,
+                                                planes, dplanes, dxp, Np, (hipStream_t)stream), "aon_art_bwd_chain_bf16x3");
 }
 
 }  // extern "C"

@@ -272,6 +272,232 @@ __global__ void __launch_bounds__(256) art_mlp_fwd_bf16x3_kernel(ArtBfArgs args)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+// ---------------------------------------------------------------------------------------------
+// backward data chain of the articulated network on the bf16x3 engine (fp32 twin: art_bwd_chain_kernel, aon_train_art.hip)
+// ---------------------------------------------------------------------------------------------
+// Same 108-chunk transposed order; chunk c = the 32 gradient features j of one tile x the F features f of the layer's input
+// (F = 64 for the two pos-enc pull-backs, 128 or 256 otherwise), A operand = W^T in limb form:
+//   [k16 step s][out tile tp][limb][lane][8 bf16], lane (i, h), k-slot jj of step s <-> W[j = 32T + (r&3)+8(r>>2)+4h][f], r = 8s+jj
+// with f = 32tp + i, or, for the pos-enc tiles, the encoding column whose register/half is accumulator row i.
+struct Bf16ArtBwdNet {
+  static constexpr int kNumChunks = kABwNumChunks;
+  static constexpr int kSlotBytes = 8 * 6144;
+  static constexpr bool kPair = false;
+  static constexpr int chunk_tiles(int c) {
+    return (c < kABwV0 || c >= kABwD3) ? 4 : ((c >= kABwL5E && c < kABwL5) || (c >= kABwL0E && c < kABwD3)) ? 2 : 8;
+  }
+  static constexpr int chunk_bytes(int c) { return chunk_tiles(c) * 6144; }
+};
+__host__ __device__ constexpr int64_t babw_offset(int c) {
+  int64_t off = 0;
+  for (int i = 0; i < c; ++i) off += Bf16ArtBwdNet::chunk_bytes(i);
+  return off;
+}
+constexpr int64_t kBaBwStreamBytes = babw_offset(kABwNumChunks);
+
+__global__ void pack_art_bwd_bf16x3_kernel(ArtPackArgsB a, char* __restrict__ packed) {
+  // one thread per 16-byte limb vector triple: (chunk, s, tp, lane)
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int c = 0;
+  int64_t base = 0;  // in threads; a chunk has 2 * tiles * 64 threads
+  while (c < kABwNumChunks && idx >= base + 2 * Bf16ArtBwdNet::chunk_tiles(c) * 64) { base += 2 * Bf16ArtBwdNet::chunk_tiles(c) * 64; ++c; }
+  if (c >= kABwNumChunks) return;
+  const int r = (int)(idx - base), nt = Bf16ArtBwdNet::chunk_tiles(c);
+  const int lane = r & 63, tp = (r >> 6) % nt, s = (r >> 6) / nt;
+  const int h = lane >> 5, i = lane & 31;
+  int col = 32 * tp + i;  // forward-input feature (row of W^T)
+  auto enc_col = [&]() {  // accumulator row i of tile tp -> encoding register rho of half h'
+    const int rr = (i & 3) + 4 * (i >> 3), hh = (i >> 2) & 1;
+    return posenc_col(tp, rr >> 2, rr & 3, hh);
+  };
+  const float* W; int ld, T;
+  if (c < kABwV0) { const int l = 3 - c / 4; W = a.p[26 + 2 * l]; ld = 128; T = c % 4; }
+  else if (c < kABwBott) { W = a.p[26]; ld = 411; T = c - kABwV0; }
+  else if (c < kABwL7) { W = a.p[34]; ld = 256; T = c - kABwBott; }
+  else if (c < kABwL5E) { const int l = 7 - (c - kABwL7) / 8; W = a.p[10 + 2 * l]; ld = 256; T = (c - kABwL7) % 8; }
+  else if (c < kABwL5) { W = a.p[20]; ld = 447; T = c - kABwL5E; col = enc_col(); if (col >= 0) col += 256; }
+  else if (c < kABwL0E) { const int l = 5 - (c - kABwL5) / 8; W = a.p[10 + 2 * l]; ld = l == 5 ? 447 : 256; T = (c - kABwL5) % 8; }
+  else if (c < kABwD3) { W = a.p[10]; ld = 191; T = c - kABwL0E; col = enc_col(); }
+  else { const int l = 3 - (c - kABwD3) / 4; W = a.p[2 * l]; ld = 128; T = (c - kABwD3) % 4; }
+  unsigned short hi[8], mid[8], lo[8];
+#pragma unroll
+  for (int jj = 0; jj < 8; ++jj) {
+    const int reg = 8 * s + jj;
+    const int j = 32 * T + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+    const float w = col >= 0 ? W[(int64_t)j * ld + col] : 0.f;
+    hi[jj] = bf16_rne_bits(w);
+    const float r1 = w - bf16_bits_to_f32(hi[jj]);
+    mid[jj] = bf16_rne_bits(r1);
+    lo[jj] = bf16_rne_bits(r1 - bf16_bits_to_f32(mid[jj]));
+  }
+  char* dst = packed + babw_offset(c) + ((int64_t)(s * nt + tp) * 3) * 1024 + lane * 16;
+  auto put = [&](int limb, const unsigned short (&v)[8]) {
+    u32x4 o;
+    o[0] = v[0] | ((unsigned)v[1] << 16); o[1] = v[2] | ((unsigned)v[3] << 16);
+    o[2] = v[4] | ((unsigned)v[5] << 16); o[3] = v[6] | ((unsigned)v[7] << 16);
+    *reinterpret_cast<u32x4*>(dst + limb * 1024) = o;
+  };
+  put(0, hi); put(1, mid); put(2, lo);
+}
+
+// out += W^T-chunks . in  over NT_IN gradient tiles (already masked fp32), out = NT_OUT tiles
+template <int CBASE, int NT_IN, int NT_OUT>
+__device__ __forceinline__ void bwd_layer_bf16(Pipe& p, const f32x16 (&in)[NT_IN], f32x16 (&out)[NT_OUT]) {
+  LimbFrag cur[2], nxt[2];
+  split_tile<0>(in[0], cur);
+  chunk_mma_bf16<CBASE + 0, NT_OUT, true, 0, false, Bf16ArtBwdNet>(p, cur, out, in[1], nxt); cur[0] = nxt[0]; cur[1] = nxt[1];
+  chunk_mma_bf16<CBASE + 1, NT_OUT, true, 0, false, Bf16ArtBwdNet>(p, cur, out, in[2], nxt); cur[0] = nxt[0]; cur[1] = nxt[1];
+  chunk_mma_bf16<CBASE + 2, NT_OUT, true, 0, false, Bf16ArtBwdNet>(p, cur, out, in[3], nxt); cur[0] = nxt[0]; cur[1] = nxt[1];
+  if constexpr (NT_IN == 4) {
+    chunk_mma_bf16<CBASE + 3, NT_OUT, false, 0, false, Bf16ArtBwdNet>(p, cur, out, in[3], nxt);
+  } else {
+    chunk_mma_bf16<CBASE + 3, NT_OUT, true, 0, false, Bf16ArtBwdNet>(p, cur, out, in[4], nxt); cur[0] = nxt[0]; cur[1] = nxt[1];
+    chunk_mma_bf16<CBASE + 4, NT_OUT, true, 0, false, Bf16ArtBwdNet>(p, cur, out, in[5], nxt); cur[0] = nxt[0]; cur[1] = nxt[1];
+    chunk_mma_bf16<CBASE + 5, NT_OUT, true, 0, false, Bf16ArtBwdNet>(p, cur, out, in[6], nxt); cur[0] = nxt[0]; cur[1] = nxt[1];
+    chunk_mma_bf16<CBASE + 6, NT_OUT, true, 0, false, Bf16ArtBwdNet>(p, cur, out, in[7], nxt); cur[0] = nxt[0]; cur[1] = nxt[1];
+    chunk_mma_bf16<CBASE + 7, NT_OUT, false, 0, false, Bf16ArtBwdNet>(p, cur, out, in[7], nxt);
+  }
+}
+
+struct ArtBfBwdArgs {
+  const char* packed_bwd;   // kBaBwStreamBytes
+  const float* small;       // per-call small block (head weights)
+  const float* d_raw;       // (Np,4)
+  const u32x4* masks;       // kAMaskLayers x (Np*2)
+  const float* planes;      // forward planes (deformed position rows 3..5 are read)
+  float* dplanes;
+  float* dxp;               // (Np,4)
+  int64_t Np; int npass;
+};
+
+template <int NT>
+__device__ __forceinline__ void zero_tiles_ba(f32x16 (&x)[NT]) {
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) x[t][r] = 0.f;
+}
+template <int NT>
+__device__ __forceinline__ void mask_store_ba(f32x16 (&x)[NT], const u32x4 bits, float* dplane, const PlaneIO& io) {
+  apply_mask_bits(x, bits);
+  store_plane(x, dplane, io);
+}
+
+__global__ void __launch_bounds__(256) art_bwd_chain_bf16x3_kernel(ArtBfBwdArgs args) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* sm = reinterpret_cast<float*>(smem + kBfRingBytes);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m = lane & 31, h = lane >> 5;
+  {
+    const f32x4* src = reinterpret_cast<const f32x4*>(args.small);
+    f32x4* dst = reinterpret_cast<f32x4*>(sm);
+    for (int i = tid; i < kASmallFloats / 4; i += 256) dst[i] = src[i];
+  }
+  Pipe p;
+  pipe_init<Bf16ArtBwdNet>(p, args.packed_bwd, smem, wave, lane);
+
+  for (int pass = blockIdx.x; pass < args.npass; pass += gridDim.x) {
+    const int64_t col = (int64_t)pass * 128 + wave * 32 + m;
+    const PlaneIO io = make_plane_io(args.Np, col, h);
+    auto dp = [&](int row) { return reinterpret_cast<float*>(reinterpret_cast<char*>(args.dplanes) + (int64_t)row * io.row_bytes); };
+    u32x4 mk[kAMaskLayers];
+#pragma unroll
+    for (int l = 0; l < kAMaskLayers; ++l) mk[l] = args.masks[(int64_t)l * args.Np * 2 + (int64_t)pass * 256 + tid];
+    const float4 dr = reinterpret_cast<const float4*>(args.d_raw)[col];
+    float xd[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+      xd[a] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(args.planes) + (int64_t)(kAPlPos + 3 + a) * io.row_bytes + col * 4);
+
+    // ---- view branch, backwards (model_autodecoder.py:231-236) ----
+    f32x16 Z0[4], Z1[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        const int fo = 32 * t + 8 * gq + 4 * h;
+        const f32x4 w0 = *reinterpret_cast<const f32x4*>(sm + kA_WRGB + 0 * kCondWidth + fo);
+        const f32x4 w1 = *reinterpret_cast<const f32x4*>(sm + kA_WRGB + 1 * kCondWidth + fo);
+        const f32x4 w2 = *reinterpret_cast<const f32x4*>(sm + kA_WRGB + 2 * kCondWidth + fo);
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc)
+          Z1[t][4 * gq + cc] = __builtin_fmaf(w2[cc], dr.z, __builtin_fmaf(w1[cc], dr.y, w0[cc] * dr.x));
+      }
+    }
+    mask_store_ba(Z1, mk[15], dp(aplane_v(3)), io);
+    zero_tiles_ba(Z0); bwd_layer_bf16<kABwV3 + 0, 4, 4>(p, Z1, Z0); mask_store_ba(Z0, mk[14], dp(aplane_v(2)), io);
+    zero_tiles_ba(Z1); bwd_layer_bf16<kABwV3 + 4, 4, 4>(p, Z0, Z1); mask_store_ba(Z1, mk[13], dp(aplane_v(1)), io);
+    zero_tiles_ba(Z0); bwd_layer_bf16<kABwV3 + 8, 4, 4>(p, Z1, Z0); mask_store_ba(Z0, mk[12], dp(aplane_v(0)), io);
+    f32x16 X[8], Y[8];
+    zero_tiles_ba(X);
+    bwd_layer_bf16<kABwV0, 4, 8>(p, Z0, X);
+    store_plane(X, dp(kAPlBot), io);  // bottleneck: no activation
+    // ---- trunk ----
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        const f32x4 w = *reinterpret_cast<const f32x4*>(sm + kA_WSIG + 32 * t + 8 * gq + 4 * h);
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) Y[t][4 * gq + cc] = w[cc] * dr.w;
+      }
+    }
+    bwd_layer_bf16<kABwBott, 8, 8>(p, X, Y); mask_store_ba(Y, mk[11], dp(aplane_h(7)), io);
+    zero_tiles_ba(X); bwd_layer_bf16<kABwL7 + 0, 8, 8>(p, Y, X); mask_store_ba(X, mk[10], dp(aplane_h(6)), io);
+    zero_tiles_ba(Y); bwd_layer_bf16<kABwL7 + 8, 8, 8>(p, X, Y); mask_store_ba(Y, mk[9], dp(aplane_h(5)), io);
+    f32x16 dE[2];
+    zero_tiles_ba(dE);
+    bwd_layer_bf16<kABwL5E, 8, 2>(p, Y, dE);  // skip connection: d enc += W5[:, 256:319]^T dZ5
+    zero_tiles_ba(X); bwd_layer_bf16<kABwL5 + 0, 8, 8>(p, Y, X); mask_store_ba(X, mk[8], dp(aplane_h(4)), io);
+    zero_tiles_ba(Y); bwd_layer_bf16<kABwL5 + 8, 8, 8>(p, X, Y); mask_store_ba(Y, mk[7], dp(aplane_h(3)), io);
+    zero_tiles_ba(X); bwd_layer_bf16<kABwL5 + 16, 8, 8>(p, Y, X); mask_store_ba(X, mk[6], dp(aplane_h(2)), io);
+    zero_tiles_ba(Y); bwd_layer_bf16<kABwL5 + 24, 8, 8>(p, X, Y); mask_store_ba(Y, mk[5], dp(aplane_h(1)), io);
+    zero_tiles_ba(X); bwd_layer_bf16<kABwL5 + 32, 8, 8>(p, Y, X); mask_store_ba(X, mk[4], dp(aplane_h(0)), io);
+    bwd_layer_bf16<kABwL0E, 8, 2>(p, X, dE);  // d enc += W0[:, :63]^T dZ0
+
+    // ---- positional encoding, backwards (helper.py:136-140 on the deformed point) ----
+    const float phase = h ? AON_HALF_PI_F32 : 0.f;
+    float dx[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int rho = 0; rho < 30; ++rho) {
+      const float scale = (float)(1 << (rho / 3));
+      const float arg = __fadd_rn(__fmul_rn(xd[rho % 3], scale), phase);
+      const float c = cos_f32(arg);
+      dx[rho % 3] = __builtin_fmaf(scale * c, dE[rho >> 4][rho & 15], dx[rho % 3]);
+    }
+    if (h) dx[2] += dE[1][14]; else { dx[0] += dE[1][14]; dx[1] += dE[1][15]; }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) dx[a] = dx[a] + __shfl_xor(dx[a], 32);
+    if (h == 0) {
+      float4 o; o.x = dx[0]; o.y = dx[1]; o.z = dx[2]; o.w = 0.f;
+      reinterpret_cast<float4*>(args.dxp)[col] = o;
+    }
+
+    // ---- deformation MLP, backwards (x' = deformation_layer(h3) + pos, :200-205) ----
+    f32x16 (&H1)[4] = Z1;
+    f32x16 (&H0)[4] = Z0;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        const int fo = 32 * t + 8 * gq + 4 * h;
+        const f32x4 w0 = *reinterpret_cast<const f32x4*>(sm + kA_WDL + 0 * 128 + fo);
+        const f32x4 w1 = *reinterpret_cast<const f32x4*>(sm + kA_WDL + 1 * 128 + fo);
+        const f32x4 w2 = *reinterpret_cast<const f32x4*>(sm + kA_WDL + 2 * 128 + fo);
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc)
+          H1[t][4 * gq + cc] = __builtin_fmaf(w2[cc], dx[2], __builtin_fmaf(w1[cc], dx[1], w0[cc] * dx[0]));
+      }
+    }
+    mask_store_ba(H1, mk[3], dp(aplane_d(3)), io);
+    zero_tiles_ba(H0); bwd_layer_bf16<kABwD3 + 0, 4, 4>(p, H1, H0); mask_store_ba(H0, mk[2], dp(aplane_d(2)), io);
+    zero_tiles_ba(H1); bwd_layer_bf16<kABwD3 + 4, 4, 4>(p, H0, H1); mask_store_ba(H1, mk[1], dp(aplane_d(1)), io);
+    zero_tiles_ba(H0); bwd_layer_bf16<kABwD3 + 8, 4, 4>(p, H1, H0); mask_store_ba(H0, mk[0], dp(aplane_d(0)), io);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 int num_cus();
 
 int64_t art_bf16x3_packed_bytes() { return kBaStreamBytes; }
@@ -315,6 +541,34 @@ hipError_t launch_art_mlp_fwd_train_bf16x3(const char* packed, const float* smal
               static_cast<u32x4*>(masks), 0};
   a.Np = (int64_t)a.npass * 128;
   return launch_art_bf16x3_t<true>(a, stream);
+}
+
+int64_t art_bwd_bf16x3_packed_bytes() { return kBaBwStreamBytes; }
+
+hipError_t launch_pack_art_bwd_bf16x3(const float* const* params, char* packed, hipStream_t stream) {
+  ArtPackArgsB a;
+  for (int i = 0; i < kNumArtParams; ++i) a.p[i] = params[i];
+  const int64_t n = kBaBwStreamBytes / 6144 * 2 * 64;  // (tiles in the stream) x 2 k16 steps x 64 lanes
+  pack_art_bwd_bf16x3_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream>>>(a, packed);
+  return hipGetLastError();
+}
+
+hipError_t launch_art_bwd_chain_bf16x3(const char* packed_bwd, const float* small, const float* d_raw, const void* masks,
+                                       const float* planes, float* dplanes, float* dxp, int64_t Np, hipStream_t stream) {
+  static bool attr = false;
+  constexpr int lds = kBfRingBytes + kBaSmallBytes;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&art_bwd_chain_bf16x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return e;
+    attr = true;
+  }
+  ArtBfBwdArgs a{packed_bwd, small, d_raw, static_cast<const u32x4*>(masks), planes, dplanes, dxp, Np, (int)(Np / 128)};
+  const int cus = num_cus();
+  if (cus <= 0) return hipErrorInvalidDevice;
+  const int grid = a.npass < cus ? a.npass : cus;
+  if (grid <= 0) return hipSuccess;
+  art_bwd_chain_bf16x3_kernel<<<dim3(grid), dim3(256), lds, stream>>>(a);
+  return hipGetLastError();
 }
 
 }  // namespace aon

@@ -67,6 +67,15 @@ class NeRFMLP(nn.Module):
             self._packed_bwd_key = key
         return self._packed_bwd
 
+    def packed_bwd_bf16x3(self) -> torch.Tensor:
+        """Transposed three-limb bf16 stream of the bf16x3 backward chain."""
+        params = dict(self.named_parameters())
+        key = tuple((p.data_ptr(), p._version, str(p.device)) for p in params.values())
+        if getattr(self, "_packed_bwd_bf", None) is None or key != self._packed_bwd_bf_key:
+            self._packed_bwd_bf = ops.pack_art_mlp_bwd_bf16x3(params)
+            self._packed_bwd_bf_key = key
+        return self._packed_bwd_bf
+
     def ordered_params(self):
         params = dict(self.named_parameters())
         return [params[name] for name in ops.ART_PARAM_ORDER]
@@ -147,7 +156,7 @@ class NeRF_AE_Art(nn.Module):
             for mlp in mlps:
                 small = ops.art_prepare(dict(mlp.named_parameters()), latents)
                 if ops.get_train_engine() == "bf16x3":   # opt-in: split-bf16 training forward (+ weight gradients)
-                    packs.append((None, small, mlp.packed_bwd(), mlp.packed_bf16x3()))
+                    packs.append((None, small, None, mlp.packed_bf16x3(), mlp.packed_bwd_bf16x3()))
                 else:
                     packs.append((mlp.packed(), small, mlp.packed_bwd()))
             params = [p for mlp in mlps for p in mlp.ordered_params()]

@@ -582,14 +582,26 @@ def art_mlp_fwd_train(packed, small, rays_o, rays_d, viewdirs, t_vals, engine: s
     return raw, planes, masks
 
 
-def art_bwd_chain(packed_bwd, small, d_raw, masks, planes):
-    """-> (dplanes (rows, Np), dxp (Np,4) = dL/d deformed position)"""
+def pack_art_mlp_bwd_bf16x3(params: dict, out: torch.Tensor | None = None) -> torch.Tensor:
+    """Transposed three-limb bf16 stream of the articulated bf16x3 backward chain."""
+    tensors, arr = _art_param_array(params)
+    dev = tensors[0].device
+    if out is None:
+        out = torch.empty(int(lib.aon_art_bwd_bf16x3_packed_bytes()), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        check(lib.aon_pack_art_mlp_bwd_bf16x3(arr, _ptr(out), _stream()), "aon_pack_art_mlp_bwd_bf16x3")
+    return out
+
+
+def art_bwd_chain(packed_bwd, small, d_raw, masks, planes, engine: str = "fp32"):
+    """-> (dplanes (rows, Np), dxp (Np,4) = dL/d deformed position).  engine "bf16x3": packed_bwd from pack_art_mlp_bwd_bf16x3."""
     dplanes = torch.empty(planes.shape, dtype=torch.float32, device=planes.device)
     Np = planes.shape[1]
     dxp = torch.empty((Np, 4), dtype=torch.float32, device=planes.device)
     with torch.cuda.device(planes.device):
-        check(lib.aon_art_bwd_chain(_ptr(packed_bwd), _ptr(small), _ptr(d_raw), _ptr(masks), _ptr(planes), _ptr(dplanes), _ptr(dxp), Np,
-                                    _stream()), "aon_art_bwd_chain")
+        fn = lib.aon_art_bwd_chain if engine == "fp32" else lib.aon_art_bwd_chain_bf16x3
+        check(fn(_ptr(packed_bwd), _ptr(small), _ptr(d_raw), _ptr(masks), _ptr(planes), _ptr(dplanes), _ptr(dxp), Np, _stream()),
+              "aon_art_bwd_chain")
     return dplanes, dxp
 
 

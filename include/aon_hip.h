@@ -237,6 +237,11 @@ int aon_art_mlp_fwd_bf16x3(const void* packed_bf16x3, const void* small, const f
 int aon_art_mlp_fwd_train_bf16x3(const void* packed_bf16x3, const void* small, const float* rays_o, const float* rays_d,
                                  const float* viewdirs, const float* t_vals, int64_t n_rays, int S, float* raw, float* planes,
                                  void* masks, void* stream);
+/* aon_art_bwd_chain on the bf16x3 engine: transposed weight stream in limb form, otherwise the same contract */
+int64_t aon_art_bwd_bf16x3_packed_bytes(void);
+int aon_pack_art_mlp_bwd_bf16x3(const float* const* params_host, void* packed_bwd, void* stream);
+int aon_art_bwd_chain_bf16x3(const void* packed_bwd_bf16x3, const void* small, const float* d_raw, const void* masks, const float* planes,
+                             float* dplanes, float* dxp, int64_t Np, void* stream);
 int aon_art_render_fwd_bf16x3(const void* packed_coarse, const void* small_coarse, const void* packed_fine, const void* small_fine,
                               const float* rays_o, const float* rays_d, const float* viewdirs, int64_t n_rays, float near_, float far_,
                               int white_bkgd, int num_levels, const float* t_rand, const float* u, int64_t u_stride, float* rgb_c,

@@ -248,3 +248,34 @@ def test_bf16x3_articulated_training_forward(dev, golden):
         assert err <= 5e-2, (k, err)
     for k in lga:
         assert ((lga[k] - lgb[k]).norm() / (lga[k].norm() + 1e-30)).item() <= 5e-2, k
+
+
+def test_bf16x3_articulated_backward_chain_matches_fp32_chain(dev, golden):
+    """Same forward planes / masks / d_raw into both articulated backward chains: every gradient plane block and the
+    deformed-position gradient agree to fp32-class differences."""
+    import aon_amd.synthetic as syn
+    from aon_amd import ops
+
+    g = golden("g11_nerf_ae_art")
+    art_sd = syn.make_art_state_dict(seed=0, density_scale=30.0)
+    params = {k[len("fine_mlp."):]: v.to(dev) for k, v in art_sd.items() if k.startswith("fine_mlp.")}
+    lat = {k: g[f"lat_train_{k}"].to(dev) for k in ("density", "color", "articulation")}
+    pk, small = ops.pack_art_mlp(params), ops.art_prepare(params, lat)
+    pbwd, pbwd_bf = ops.pack_art_mlp_bwd(params), ops.pack_art_mlp_bwd_bf16x3(params)
+    n, S = 31, 193
+    rays = {k: v.to(dev) for k, v in syn.random_rays(n, seed=9).items()}
+    gen = torch.Generator().manual_seed(9)
+    t = torch.sort(torch.rand(n, S, generator=gen) * 4 + 2, dim=-1).values.to(dev)
+    raw, planes, masks = ops.art_mlp_fwd_train(pk, small, rays["rays_o"], rays["rays_d"], rays["viewdirs"], t)
+    g_rgb = torch.randn(n, 3, generator=gen).to(dev)
+    d_raw = ops.composite_bwd(raw, t, rays["rays_d"], g_rgb, None, None, True, ops.ACT_ARTICULATED, planes.shape[1])
+    da, xa = ops.art_bwd_chain(pbwd, small, d_raw, masks, planes)
+    db, xb = ops.art_bwd_chain(pbwd_bf, small, d_raw, masks, planes, engine="bf16x3")
+    valid = n * S
+    blocks = {"deform": (32, 544), "trunk": (608, 2656), "bottleneck": (2656, 2912), "view": (2944, 3456)}
+    for name, (r0, r1) in blocks.items():
+        a, b = da[r0:r1, :valid].double(), db[r0:r1, :valid].double()
+        err = ((a - b).norm() / (a.norm() + 1e-300)).item()
+        assert err <= 5e-6, (name, err)
+    err = ((xa[:valid, :3].double() - xb[:valid, :3].double()).norm() / (xa[:valid, :3].double().norm() + 1e-300)).item()
+    assert err <= 5e-6, ("dxp", err)
