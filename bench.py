@@ -144,7 +144,7 @@ def train_leg(dev, rank, world, distributed, steps=3, n_rays=4096):
         dt, loss = timed()
         res = {"workload": f"articulated NeRF_AE_Art training step, {n_rays} rays/GPU, fwd+bwd" + (" + RCCL gradient all-reduce (6.4 MB, one bucket)" if world > 1 else "") + " + Adam",
                "ms_per_step": dt * 1e3, "rays_per_s": world * n_rays / dt, "steps": steps, "loss": loss}
-        # the opt-in split-bf16 training engine (for the articulated network: the weight-gradient GEMMs), same step
+        # the opt-in split-bf16 training engine (forward, backward chain and weight gradients), same step
         ops.set_train_engine("bf16x3")
         try:
             dt_b, _ = timed()
