@@ -167,6 +167,7 @@ def main():
     ap.add_argument("--engine", choices=["fp32", "bf16x3"], default="fp32",
                     help="MLP arithmetic of the timed region: exact fp32 MFMA (default) or the opt-in fp32-equivalent split-bf16 engine")
     ap.add_argument("--no-alt", action="store_true", help="skip the extra (untimed-for-`value`) run of the other engine")
+    ap.add_argument("--sharded-leg", action="store_true", help="run the informational sharded-frame leg even at world size 1")
     ap.add_argument("--no-train-leg", action="store_true", help="skip the extra (informational) articulated training-step timing")
     args = ap.parse_args()
 
@@ -256,6 +257,31 @@ def main():
                        "passes the parity suite at the fp32 kernel's tolerances); opt-in, not the default"}
         model.engine = args.engine
 
+    # BASELINE config 3 literally (informational, never `value`): ONE 640x480 frame, contiguous ray ranges sharded over the
+    # ranks, fine-level pixels all-gathered (RCCL) -- strong scaling of a single frame, where `value` above is weak scaling.
+    sharded = None
+    if world > 1 or args.sharded_leg:
+        try:
+            from aon_amd.parallel import render_frame_sharded
+
+            focal0, c2w0 = syn.focal_from_fovy(H), syn.look_at_pose(4.0, 30.0, 30.0)
+            raygen = lambda h, w, f, c, b, e: get_frame_rays(h, w, f, c, b, e, device=dev)
+            with torch.no_grad():
+                render_frame_sharded(model, H, W, focal0, c2w0, syn.NEAR, syn.FAR, True, raygen)
+                fence()
+                ts = time.perf_counter()
+                for _ in range(args.steps):
+                    frame = render_frame_sharded(model, H, W, focal0, c2w0, syn.NEAR, syn.FAR, True, raygen)
+                fence()
+                tsd = torch.tensor([time.perf_counter() - ts], dtype=torch.float64, device=dev)
+            if distributed:
+                dist.all_reduce(tsd, op=dist.ReduceOp.MAX)
+            dts = tsd.item() / args.steps
+            sharded = {"workload": f"one {W}x{H} frame sharded over {world} rank(s) + pixel all-gather", "ms_per_frame": dts * 1e3,
+                       "rays_per_s": n_rays / dts, "frame_rows": int(frame[0].shape[0])}
+        except Exception as e:  # informational leg
+            sharded = {"error": f"{type(e).__name__}: {e}"}
+
     train = None if args.no_train_leg else train_leg(dev, rank, world, distributed)
 
     if rank == 0:
@@ -281,6 +307,8 @@ def main():
         res["roofline"].update(pmc_traffic())
         if alt is not None:
             res["alt_engine"] = alt
+        if sharded is not None:
+            res["sharded_frame"] = sharded
         if train is not None:
             res["train_step"] = train
         if world == 1 and not args.no_cpu_baseline:
