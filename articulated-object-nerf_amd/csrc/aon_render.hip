@@ -217,7 +217,13 @@ struct CompositeArgs {
   float* weights;   // (n,S) or null
 };
 
-__device__ __forceinline__ float sigmoid_f32(float x) { return __fdiv_rn(1.0f, __fadd_rn(1.0f, expf(-x))); }
+// 1 / (1 + exp(-x)): v_rcp_f32 (1 ulp) refined by one Newton step (<= 0.5 ulp + rounding) instead of the ten-instruction
+// correctly rounded division -- torch's own vectorised sigmoid differs from any of them by an ulp of exp anyway
+__device__ __forceinline__ float sigmoid_f32(float x) {
+  const float d = __fadd_rn(1.0f, expf(-x));
+  const float r = __builtin_amdgcn_rcpf(d);
+  return __builtin_fmaf(__builtin_fmaf(-d, r, 1.0f), r, r);
+}
 
 __device__ __forceinline__ float softplus_f32(float x) {  // torch Softplus(beta=1, threshold=20)
   return x > 20.0f ? x : log1pf(expf(x));
