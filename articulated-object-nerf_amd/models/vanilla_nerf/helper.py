@@ -69,3 +69,21 @@ def sample_pdf(bins, weights, origins, directions, t_vals, num_samples, randomiz
         u = torch.rand((bins.shape[0], num_samples), device=bins.device)
     t_fine = ops.sample_pdf_t(t_vals, weights, u if randomized else None, bins=bins)
     return t_fine, ops.cast_rays(t_fine, origins, directions)
+
+
+def get_learning_rate(optimizer):
+    """helper.py:198-200: the learning rate of the (first) parameter group, as logged by the training steps."""
+    for group in optimizer.param_groups:
+        return group["lr"]
+
+
+def get_parameters(models):
+    """helper.py:143-154: flat parameter list of a module, or of a list / dict of modules."""
+    if isinstance(models, dict):
+        models = list(models.values())
+    if not isinstance(models, (list, tuple)):
+        models = [models]
+    params = []
+    for m in models:
+        params += get_parameters(m) if isinstance(m, (list, tuple, dict)) else list(m.parameters())
+    return params
