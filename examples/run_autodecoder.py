@@ -39,7 +39,10 @@ def main():
     ap.add_argument("--val_every", type=int, default=20)
     ap.add_argument("--exp_dir", default="ckpts/demo_autodecoder")
     ap.add_argument("--train_engine", choices=["fp32", "bf16x3"], default="fp32")
+    ap.add_argument("--seed", type=int, default=0, help="torch / numpy / random seed (model init, ray batches, stratified draws)")
     args = ap.parse_args()
+    import random as _random
+    _random.seed(args.seed); np.random.seed(args.seed); torch.manual_seed(args.seed)
 
     import aon_amd  # noqa: F401
     from aon_amd import ops
