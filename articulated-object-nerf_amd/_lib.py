@@ -26,6 +26,7 @@ _SIGS = {
     "aon_raygen": (_i, [_p, _i, _i, _f, _l, _l, _p, _p, _p, _p]),
     "aon_ray_directions": (_i, [_i, _i, _f, _p, _p]),
     "aon_get_rays": (_i, [_p, _p, _l, _p, _p, _p, _p]),
+    "aon_ray_radii": (_i, [_p, _p, _i, _i, _p, _p]),
     "aon_cast_rays": (_i, [_p, _p, _p, _l, _i, _p, _p]),
     "aon_sample_along_rays": (_i, [_p, _p, _l, _i, _f, _f, _p, _p, _p, _p]),
     "aon_pos_enc": (_i, [_p, _l, _i, _i, _p, _p]),

@@ -73,6 +73,7 @@ hipError_t launch_mlp_fwd_bf16x3(const char* packed, const float* rays_o, const 
 hipError_t launch_raygen(const float* c2w, int H, int W, float focal, const float* directions, int64_t pix_begin,
                          int64_t pix_end, float* rays_o, float* viewdirs, float* rays_d, hipStream_t stream);
 hipError_t launch_ray_directions(int H, int W, float focal, float* out, hipStream_t stream);
+hipError_t launch_ray_radii(const float* directions, const float* c2w, int H, int W, float* radii, hipStream_t stream);
 hipError_t launch_cast_rays(const float* t_vals, const float* o, const float* d, int64_t n_rays, int S, float* coords,
                             hipStream_t stream);
 hipError_t launch_sample_along_rays(const float* rays_o, const float* rays_d, int64_t n_rays, int S, float near, float far,
@@ -184,6 +185,12 @@ int aon_get_rays(const float* directions, const float* c2w_host, int64_t n, floa
   // geometry arguments are unused when directions are supplied; W = n keeps the pixel index math in range
   return check(aon::launch_raygen(c2w_host, 1, (int)(n > INT32_MAX ? INT32_MAX : n), 1.0f, directions, 0, n, rays_o, viewdirs,
                                   rays_d, (hipStream_t)stream), "aon_get_rays");
+}
+
+int aon_ray_radii(const float* directions, const float* c2w_host, int H, int W, float* radii, void* stream) {
+  if (!directions || !c2w_host || !radii) return fail(AON_E_INVALID, "aon_ray_radii: null pointer");
+  if (H < 3 || W < 1) return fail(AON_E_INVALID, "aon_ray_radii: needs H >= 3 image rows (ray_utils.py:141 indexes dx[-2])");
+  return check(aon::launch_ray_radii(directions, c2w_host, H, W, radii, (hipStream_t)stream), "aon_ray_radii");
 }
 
 int aon_cast_rays(const float* t_vals, const float* origins, const float* directions, int64_t n_rays, int S, float* coords,

@@ -106,6 +106,46 @@ hipError_t launch_raygen(const float* c2w, int H, int W, float focal, const floa
   return hipGetLastError();
 }
 
+// radii of get_rays(..., output_radii=True)  (datasets/ray_utils.py:138-143; a mip-NeRF leftover the render path never
+// reads, but part of the only call form the reference datasets use: sapien.py:102,145, sapien_multi.py:301,343):
+//   d = directions @ c2w[:, :3].T (un-normalised);  dx[j,i] = || d[j,i] - d[j+1,i] ||  for j < H-1,
+//   row H-1 <- row H-3 (`cat([dx, dx[-2:-1]])`: dx has H-1 rows, so -2 is image row H-3);  radius = dx * 2 / sqrt(12)
+struct RadiiArgs {
+  float c2w[12];
+  int H, W;
+  const float* directions;  // (H*W,3)
+  float* radii;             // (H*W,)
+};
+
+__global__ void ray_radii_kernel(RadiiArgs a) {
+  const int64_t pix = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (pix >= (int64_t)a.H * a.W) return;
+  int j = (int)(pix / a.W);
+  const int i = (int)(pix % a.W);
+  if (j == a.H - 1) j = a.H - 3;
+  auto world = [&](int64_t q, float (&d)[3]) {
+    const float dx = a.directions[q * 3], dy = a.directions[q * 3 + 1], dz = a.directions[q * 3 + 2];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+      d[r] = __builtin_fmaf(dz, a.c2w[4 * r + 2], __builtin_fmaf(dy, a.c2w[4 * r + 1], __fmul_rn(dx, a.c2w[4 * r + 0])));
+  };
+  float d0[3], d1[3];
+  world((int64_t)j * a.W + i, d0);
+  world((int64_t)(j + 1) * a.W + i, d1);
+  const float e0 = __fsub_rn(d0[0], d1[0]), e1 = __fsub_rn(d0[1], d1[1]), e2 = __fsub_rn(d0[2], d1[2]);
+  const float dx = __fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(e0, e0), __fmul_rn(e1, e1)), __fmul_rn(e2, e2)));
+  a.radii[pix] = __fdiv_rn(__fmul_rn(dx, 2.0f), 3.4641016151377544f);  // sqrt(tensor(12, int8)) -> fp32 sqrt(12)
+}
+
+hipError_t launch_ray_radii(const float* directions, const float* c2w, int H, int W, float* radii, hipStream_t stream) {
+  RadiiArgs a;
+  for (int i = 0; i < 12; ++i) a.c2w[i] = c2w[i];
+  a.H = H; a.W = W; a.directions = directions; a.radii = radii;
+  const int64_t n = (int64_t)H * W;
+  ray_radii_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream>>>(a);
+  return hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------------------------
 // R3  stratified sampling   (models/vanilla_nerf/helper.py:106-133, lindisp=False)
 // ---------------------------------------------------------------------------------------------

@@ -15,11 +15,14 @@ def get_ray_directions(H, W, focal, device=None):
 def get_rays(directions, c2w, output_view_dirs=False, output_radii=False):
     """ray_utils.py:118-159.  Returns (rays_o, rays_d) or, with output_view_dirs, (rays_o, viewdirs, rays_d)
     where rays_d is the same tensor as viewdirs (the reference normalises rays_d in place through its viewdirs
-    alias, :146-147).  ``output_radii`` (mip-NeRF leftover, unused downstream) is not supported."""
-    if output_radii:
-        raise NotImplementedError("radii are never consumed by the render path (SURVEY 8(a) R2)")
+    alias, :146-147); with ``output_view_dirs=True, output_radii=True`` -- the only call form the reference's
+    datasets use (sapien.py:102,145; sapien_multi.py:301,343) -- the 4-tuple (rays_o, viewdirs, rays_d, radii)
+    with radii (H*W,) as ray_utils.py:138-143 computes them (needs (H,W,3) directions).  Like the reference,
+    ``output_radii`` without ``output_view_dirs`` returns the 2-tuple."""
     rays_o, viewdirs = ops.get_rays(directions, c2w)
     if output_view_dirs:
+        if output_radii:
+            return rays_o, viewdirs, viewdirs, ops.ray_radii(directions, c2w)
         return rays_o, viewdirs, viewdirs
     return rays_o, viewdirs
 

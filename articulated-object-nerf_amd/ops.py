@@ -73,6 +73,18 @@ def get_rays(directions: torch.Tensor, c2w):
     return rays_o, viewdirs
 
 
+def ray_radii(directions: torch.Tensor, c2w):
+    """radii (H*W,) of get_rays(..., output_radii=True) (ray_utils.py:138-143) from (H,W,3) camera-space directions."""
+    d = _f32(directions, "directions")
+    if d.dim() != 3 or d.shape[-1] != 3 or d.shape[0] < 3:
+        raise ValueError(f"output_radii needs directions of shape (H>=3, W, 3) like the reference (it differences image rows), got {tuple(d.shape)}")
+    H, W = int(d.shape[0]), int(d.shape[1])
+    radii = torch.empty((H * W,), dtype=torch.float32, device=d.device)
+    with torch.cuda.device(d.device):
+        check(lib.aon_ray_radii(_ptr(d), _c2w_host(c2w), H, W, _ptr(radii), _stream()), "aon_ray_radii")
+    return radii
+
+
 # ------------------------------------------------------------------ R3 sampling
 def cast_rays(t_vals, origins, directions):
     t, o, d = _f32(t_vals, "t_vals"), _f32(origins, "origins"), _f32(directions, "directions")

@@ -53,6 +53,10 @@ int aon_ray_directions(int H, int W, float focal, float* directions, void* strea
 int aon_get_rays(const float* directions, const float* c2w_host, int64_t n, float* rays_o, float* viewdirs,
                  float* rays_d, void* stream);
 
+/* The `radii` output of get_rays(..., output_radii=True) (ray_utils.py:138-143), the call form of every reference
+ * dataset (sapien.py:102,145; sapien_multi.py:301,343): directions (H,W,3) row-major -> radii (H*W,).  H >= 3. */
+int aon_ray_radii(const float* directions, const float* c2w_host, int H, int W, float* radii, void* stream);
+
 /* helper.cast_rays (helper.py:25-26): coords (n,S,3) = origins[:,None,:] + t_vals[...,None] * directions[:,None,:] */
 int aon_cast_rays(const float* t_vals, const float* origins, const float* directions, int64_t n_rays, int S,
                   float* coords, void* stream);

@@ -40,13 +40,23 @@ def get_ray_directions(H: int, W: int, focal: float) -> torch.Tensor:
 def get_rays(directions: torch.Tensor, c2w: torch.Tensor):
     """datasets/ray_utils.py:118-159 with output_view_dirs=True.  Returns (rays_o, viewdirs, rays_d),
     each (H*W,3); the reference normalises ``rays_d`` in place through its ``viewdirs`` alias
-    (:146-147), so rays_d == viewdirs (unit norm).  ``radii`` (:138-143) is unused downstream and not
-    produced."""
+    (:146-147), so rays_d == viewdirs (unit norm).  ``radii`` (:138-143): see ray_radii below."""
     rays_d = directions @ c2w[:, :3].T
     rays_d = rays_d / torch.norm(rays_d, dim=-1, keepdim=True)
     rays_o = c2w[:, 3].expand(rays_d.shape)
     rays_d = rays_d.reshape(-1, 3)
     return rays_o.reshape(-1, 3), rays_d, rays_d
+
+
+def ray_radii(directions: torch.Tensor, c2w: torch.Tensor) -> torch.Tensor:
+    """datasets/ray_utils.py:138-143, the 4th output of get_rays(..., output_view_dirs=True, output_radii=True):
+    row-to-row distance of the un-normalised world directions, last image row copied from row H-3
+    (``dx[-2:-1]`` of the (H-1)-row difference), times 2 / sqrt(12) (the sqrt of an int8 tensor is fp32)."""
+    d = directions @ c2w[:, :3].T
+    dx = torch.sqrt(torch.sum((d[:-1, :, :] - d[1:, :, :]) ** 2, dim=-1))
+    dx = torch.cat([dx, dx[-2:-1, :]], dim=0)
+    radius = dx[..., None] * 2 / torch.sqrt(torch.tensor(12, dtype=torch.int8))
+    return radius.reshape(-1)
 
 
 # --------------------------------------------------------------------------------------------------

@@ -159,18 +159,19 @@ def main():
     poses = [syn.look_at_pose(4.0, az, el) for az, el in [(30, 30), (200, -30), (91, 5)]]
     H, W = 8, 12
     focal_small = syn.focal_from_fovy(H)
-    o_all, v_all, d_all = [], [], []
+    o_all, v_all, d_all, r_all = [], [], [], []
     for c2w in poses:
         dirs = get_ray_directions(H, W, focal_small)
-        ro, vd, rd, _rad = get_rays(dirs, c2w, output_view_dirs=True, output_radii=True)
-        o_all.append(ro.clone()); v_all.append(vd.clone()); d_all.append(rd.clone())
+        ro, vd, rd, rad = get_rays(dirs, c2w, output_view_dirs=True, output_radii=True)  # the call form of sapien.py:102,145
+        o_all.append(ro.clone()); v_all.append(vd.clone()); d_all.append(rd.clone()); r_all.append(rad.clone())
     Hf, Wf = 480, 640
     focal_full = syn.focal_from_fovy(Hf)
     dirs_f = get_ray_directions(Hf, Wf, focal_full)
-    ro, vd, rd, _ = get_rays(dirs_f, poses[0], True, True)
+    ro, vd, rd, rad_f = get_rays(dirs_f, poses[0], True, True)
     pick = torch.tensor([0, 1, 639, 640, 153_600, 307_199, 12_345, 200_001])
     save("g1_raygen", H=H, W=W, focal=focal_small, c2w=torch.stack(poses), directions=get_ray_directions(H, W, focal_small),
-         rays_o=torch.stack(o_all), viewdirs=torch.stack(v_all), rays_d=torch.stack(d_all),
+         rays_o=torch.stack(o_all), viewdirs=torch.stack(v_all), rays_d=torch.stack(d_all), radii=torch.stack(r_all),
+         full_radii_pick=rad_f[pick], full_radii_sum=rad_f.double().sum(), full_radii_last_rows=rad_f.view(Hf, Wf)[-3:, ::80],
          full_H=Hf, full_W=Wf, full_focal=focal_full, full_pick=pick, full_viewdirs_pick=vd[pick],
          full_rays_o_pick=ro[pick], full_viewdirs_sum=vd.double().sum(0), full_viewdirs_abs_sum=vd.double().abs().sum(0))
 

@@ -71,6 +71,60 @@ def test_raygen_matches_oracle_and_golden(ops, dev, golden):
     assert torch.equal(vd_part, vd[38_400:76_800])
 
 
+def test_get_rays_reference_call_form(dev, golden):
+    """The literal call of every reference dataset (datasets/sapien.py:102,145; sapien_multi.py:301,343):
+    ``rays_o, view_dirs, rays_d, radii = get_rays(directions, c2w, output_view_dirs=True, output_radii=True)``
+    through the name-compatible mirror, against G1 (the reference's own four outputs)."""
+    from aon_amd.datasets.ray_utils import get_ray_directions, get_rays
+
+    g = golden("g1_raygen")
+    directions = get_ray_directions(g["H"], g["W"], g["focal"], device=dev)
+    for p in range(g["c2w"].shape[0]):
+        c2w = g["c2w"][p]
+        rays_o, view_dirs, rays_d, radii = get_rays(directions, c2w, output_view_dirs=True, output_radii=True)
+        assert torch.equal(rays_o.cpu(), g["rays_o"][p])
+        torch.testing.assert_close(view_dirs.cpu(), g["viewdirs"][p], rtol=0, atol=2e-7)
+        torch.testing.assert_close(rays_d.cpu(), g["rays_d"][p], rtol=0, atol=2e-7)
+        assert rays_d.data_ptr() == view_dirs.data_ptr()   # the reference's rays_d IS its viewdirs storage (ray_utils.py:146-147)
+        assert radii.shape == (g["H"] * g["W"],)
+        # fp32: differences of O(1) world directions (each within an ulp of the CPU matmul's) -> 2e-7 absolute on ~4e-3 values
+        torch.testing.assert_close(radii.cpu(), g["radii"][p], rtol=0, atol=2e-7)
+    # full 640x480 frame: picks, the copied last row (image row H-1 <- row H-3) and the checksum
+    Hf, Wf = g["full_H"], g["full_W"]
+    dirs_f = get_ray_directions(Hf, Wf, g["full_focal"], device=dev)
+    out = get_rays(dirs_f, g["c2w"][0], output_view_dirs=True, output_radii=True)
+    assert len(out) == 4
+    rad = out[3].cpu()
+    torch.testing.assert_close(rad[g["full_pick"]], g["full_radii_pick"], rtol=0, atol=2e-7)
+    torch.testing.assert_close(rad.view(Hf, Wf)[-3:, ::80], g["full_radii_last_rows"], rtol=0, atol=2e-7)
+    assert torch.equal(rad.view(Hf, Wf)[-1], rad.view(Hf, Wf)[-3])
+    torch.testing.assert_close(rad.double().sum(), torch.as_tensor(g["full_radii_sum"], dtype=torch.float64), rtol=1e-5, atol=0)
+    # the other call forms keep the reference's arity
+    assert len(get_rays(dirs_f, g["c2w"][0])) == 2 and len(get_rays(dirs_f, g["c2w"][0], output_view_dirs=True)) == 3
+
+
+# ------------------------------------------------------------------ R13
+def test_metrics_product_side_vs_golden(dev, golden):
+    """R13: the PRODUCT's metric functions (helper.img2mse / mse2psnr, LitModel.psnr_legacy / psnr_each / mse) on device
+    tensors against G13, the reference's own outputs (helper.py:17-22, models/interface.py:54-74)."""
+    from aon_amd.models.interface import LitModel
+    from aon_amd.models.vanilla_nerf import helper
+
+    g = golden("g13_metrics")
+    a, b = g["a"].to(dev), g["b"].to(dev)
+    mse = helper.img2mse(a, b)
+    assert mse.is_cuda
+    # fp32 mean over 3,840 elements: the CPU and device reductions associate differently -> 2e-6 relative (PSNR: 2e-5 dB)
+    torch.testing.assert_close(mse.cpu(), torch.as_tensor(g["mse"]), rtol=2e-6, atol=0)
+    torch.testing.assert_close(helper.mse2psnr(mse).cpu(), torch.as_tensor(g["mse2psnr"]), rtol=2e-6, atol=2e-5)
+    lit = LitModel()
+    torch.testing.assert_close(lit.mse(a, b).cpu(), torch.as_tensor(g["mse"]), rtol=2e-6, atol=0)
+    torch.testing.assert_close(lit.psnr_legacy(a, b).cpu(), torch.as_tensor(g["psnr_legacy"]), rtol=2e-6, atol=2e-5)
+    torch.testing.assert_close(lit.psnr_each(list(a), list(b)).cpu(), g["psnr_each"], rtol=2e-6, atol=2e-5)
+    # the training loss of model.py:271-273 is img2mse(coarse) + img2mse(fine): same function, sum of two
+    torch.testing.assert_close((helper.img2mse(a, b) + helper.img2mse(b, a)).cpu(), 2 * torch.as_tensor(g["mse"]), rtol=2e-6, atol=0)
+
+
 # ------------------------------------------------------------------ R3
 def test_sample_along_rays_bit_exact(ops, dev, golden):
     g = golden("g2_sample_along_rays")

@@ -14,6 +14,7 @@ def test_g1_raygen(golden):
         assert torch.equal(ro, g["rays_o"][p])
         torch.testing.assert_close(vd, g["viewdirs"][p], rtol=0, atol=1e-7)
         torch.testing.assert_close(rd, g["rays_d"][p], rtol=0, atol=1e-7)
+        assert torch.equal(orc.ray_radii(dirs, g["c2w"][p]), g["radii"][p])   # 4th output of the reference's call form
     # full 480x640 frame: picked pixels + checksums
     dirs = orc.get_ray_directions(g["full_H"], g["full_W"], g["full_focal"])
     ro, vd, _ = orc.get_rays(dirs, g["c2w"][0])
@@ -21,6 +22,12 @@ def test_g1_raygen(golden):
     assert torch.equal(ro[g["full_pick"]], g["full_rays_o_pick"])
     torch.testing.assert_close(vd.double().sum(0), g["full_viewdirs_sum"], rtol=0, atol=1e-3)
     torch.testing.assert_close(vd.double().abs().sum(0), g["full_viewdirs_abs_sum"], rtol=0, atol=1e-3)
+    rad = orc.ray_radii(dirs, g["c2w"][0])
+    # the (H*W,3)@(3,3) product associates differently with the thread count: each direction within an ulp (as for viewdirs)
+    torch.testing.assert_close(rad[g["full_pick"]], g["full_radii_pick"], rtol=0, atol=2e-7)
+    torch.testing.assert_close(rad.view(g["full_H"], g["full_W"])[-3:, ::80], g["full_radii_last_rows"], rtol=0, atol=2e-7)
+    assert torch.equal(rad.view(g["full_H"], g["full_W"])[-1], rad.view(g["full_H"], g["full_W"])[-3])
+    torch.testing.assert_close(rad.double().sum(), torch.as_tensor(g["full_radii_sum"], dtype=torch.float64), rtol=1e-5, atol=0)
 
 
 def test_g2_sample_along_rays(golden):
