@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 namespace aon {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -133,5 +135,31 @@ constexpr int kAMaskLayers = 16;                             // slots: D0..3 -> 
 //   20,21  density_layer.{weight,bias}
 //   22,23  rgb_layer.{weight,bias}
 constexpr int kNumVanillaParams = 24;
+
+// ------------------------------------------------------------------------------------------------
+// Host side.  A kernel's dynamic-LDS limit (hipFuncAttributeMaxDynamicSharedMemorySize) is a per-DEVICE function
+// attribute and the CU count is a per-device property: both are remembered per device ordinal, lock-free (a racing
+// second thread merely repeats an idempotent call), so a process that drives cuda:0 and later cuda:1 launches correctly
+// on both.
+// ------------------------------------------------------------------------------------------------
+constexpr int kMaxDevices = 64;
+
+struct DeviceOnce {
+  std::atomic<uint64_t> done{0};
+};
+
+template <class Kernel>
+inline hipError_t set_max_lds(Kernel* kernel, int bytes, DeviceOnce& once) {
+  int dev = 0;
+  if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
+  if (dev < 0 || dev >= kMaxDevices) return hipErrorInvalidDevice;
+  const uint64_t bit = 1ull << dev;
+  if (once.done.load(std::memory_order_acquire) & bit) return hipSuccess;
+  if (hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+      e != hipSuccess)
+    return e;
+  once.done.fetch_or(bit, std::memory_order_release);
+  return hipSuccess;
+}
 
 }  // namespace aon

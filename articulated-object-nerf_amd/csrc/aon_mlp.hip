@@ -219,28 +219,25 @@ hipError_t launch_pack_vanilla(const float* const* params, float* packed, hipStr
   return hipGetLastError();
 }
 
-static bool g_attr_set[3] = {false, false, false};
-
-int num_cus() {  // CUs of the current device (one process drives one GPU)
-  static int cus = 0;
+int num_cus() {  // CUs of the CURRENT device, cached per device ordinal (ops.py may drive any tensor.device)
+  static std::atomic<int> cache[kMaxDevices];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return -1;
+  if (dev < 0 || dev >= kMaxDevices) return -1;
+  int cus = cache[dev].load(std::memory_order_relaxed);
   if (cus == 0) {
-    int dev = 0;
     hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return -1;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return -1;
     cus = prop.multiProcessorCount;
+    cache[dev].store(cus, std::memory_order_relaxed);
   }
   return cus;
 }
 
 template <bool ENC, bool TRAIN>
 static hipError_t launch_mlp_t(const MlpArgs& args, hipStream_t stream) {
-  constexpr int slot = TRAIN ? 2 : (ENC ? 1 : 0);
-  if (!g_attr_set[slot]) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fwd_kernel<ENC, TRAIN>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
-    if (e != hipSuccess) return e;
-    g_attr_set[slot] = true;
-  }
+  static DeviceOnce lds_once;  // one per template instance
+  if (hipError_t e = set_max_lds(&mlp_fwd_kernel<ENC, TRAIN>, kLdsBytes, lds_once); e != hipSuccess) return e;
   const int g_num_cus = num_cus();
   if (g_num_cus <= 0) return hipErrorInvalidDevice;
   const int grid = args.npass < g_num_cus ? args.npass : g_num_cus;

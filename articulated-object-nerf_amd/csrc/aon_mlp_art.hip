@@ -293,13 +293,8 @@ int num_cus();  // aon_mlp.hip
 
 template <bool POS, bool TRAIN>
 static hipError_t launch_art_t(const ArtMlpArgs& args, hipStream_t stream) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&art_mlp_fwd_kernel<POS, TRAIN>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, kALdsBytes);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  static DeviceOnce lds_once;
+  if (hipError_t e = set_max_lds(&art_mlp_fwd_kernel<POS, TRAIN>, kALdsBytes, lds_once); e != hipSuccess) return e;
   const int cus = num_cus();
   if (cus <= 0) return hipErrorInvalidDevice;
   const int grid = args.npass < cus ? args.npass : cus;

@@ -512,13 +512,8 @@ hipError_t launch_pack_art_bf16x3(const float* const* params, char* packed, hipS
 
 template <bool TRAIN>
 static hipError_t launch_art_bf16x3_t(ArtBfArgs a, hipStream_t stream) {
-  static bool attr = false;
-  if (!attr) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&art_mlp_fwd_bf16x3_kernel<TRAIN>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       kBaLdsBytes);
-    if (e != hipSuccess) return e;
-    attr = true;
-  }
+  static DeviceOnce lds_once;
+  if (hipError_t e = set_max_lds(&art_mlp_fwd_bf16x3_kernel<TRAIN>, kBaLdsBytes, lds_once); e != hipSuccess) return e;
   const int cus = num_cus();
   if (cus <= 0) return hipErrorInvalidDevice;
   const int grid = a.npass < cus ? a.npass : cus;
@@ -555,13 +550,9 @@ hipError_t launch_pack_art_bwd_bf16x3(const float* const* params, char* packed, 
 
 hipError_t launch_art_bwd_chain_bf16x3(const char* packed_bwd, const float* small, const float* d_raw, const void* masks,
                                        const float* planes, float* dplanes, float* dxp, int64_t Np, hipStream_t stream) {
-  static bool attr = false;
+  static DeviceOnce lds_once;
   constexpr int lds = kBfRingBytes + kBaSmallBytes;
-  if (!attr) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&art_bwd_chain_bf16x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return e;
-    attr = true;
-  }
+  if (hipError_t e = set_max_lds(&art_bwd_chain_bf16x3_kernel, lds, lds_once); e != hipSuccess) return e;
   ArtBfBwdArgs a{packed_bwd, small, d_raw, static_cast<const u32x4*>(masks), planes, dplanes, dxp, Np, (int)(Np / 128)};
   const int cus = num_cus();
   if (cus <= 0) return hipErrorInvalidDevice;

@@ -397,13 +397,8 @@ hipError_t launch_pack_vanilla_bf16x3(const float* const* params, char* packed, 
 
 template <bool TRAIN>
 static hipError_t launch_bf16x3_t(BfArgs a, hipStream_t stream) {
-  static bool attr = false;
-  if (!attr) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fwd_bf16x3_kernel<TRAIN>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       kBfLdsBytes);
-    if (e != hipSuccess) return e;
-    attr = true;
-  }
+  static DeviceOnce lds_once;
+  if (hipError_t e = set_max_lds(&mlp_fwd_bf16x3_kernel<TRAIN>, kBfLdsBytes, lds_once); e != hipSuccess) return e;
   const int cus = num_cus();
   if (cus <= 0) return hipErrorInvalidDevice;
   const int grid = a.npass < cus ? a.npass : cus;
@@ -441,13 +436,9 @@ hipError_t launch_pack_vanilla_bwd_bf16x3(const float* const* params, char* pack
 // packed_fwd_small: the fp32 small block (biases / head weights) = fp32 forward stream + kStreamBytes
 hipError_t launch_mlp_bwd_chain_bf16x3(const char* packed_bwd, const float* packed_fwd_small, const float* d_raw, const void* masks,
                                        float* dplanes, int64_t Np, hipStream_t stream) {
-  static bool attr = false;
+  static DeviceOnce lds_once;
   constexpr int lds = kBfRingBytes + (int)kSmallBytes;
-  if (!attr) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_bwd_chain_bf16x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return e;
-    attr = true;
-  }
+  if (hipError_t e = set_max_lds(&mlp_bwd_chain_bf16x3_kernel, lds, lds_once); e != hipSuccess) return e;
   BfBwdArgs a{packed_bwd, packed_fwd_small, d_raw, static_cast<const u32x4*>(masks), dplanes, Np, (int)(Np / 128)};
   const int cus = num_cus();
   if (cus <= 0) return hipErrorInvalidDevice;

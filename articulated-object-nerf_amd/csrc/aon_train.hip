@@ -288,13 +288,9 @@ int64_t bwd_stream_bytes() { return kBwStreamBytes; }
 
 hipError_t launch_mlp_bwd_chain(const char* packed_bwd, const char* packed_fwd, const float* d_raw, const void* masks,
                                 float* dplanes, int64_t Np, hipStream_t stream) {
-  static bool attr = false;
+  static DeviceOnce lds_once;
   constexpr int lds = kRingBytes + (int)kSmallBytes;
-  if (!attr) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_bwd_chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return e;
-    attr = true;
-  }
+  if (hipError_t e = set_max_lds(&mlp_bwd_chain_kernel, lds, lds_once); e != hipSuccess) return e;
   BwdArgs a{packed_bwd, reinterpret_cast<const float*>(packed_fwd + kStreamBytes), d_raw, static_cast<const u32x4*>(masks), dplanes, Np,
             (int)(Np / 128)};
   const int cus = num_cus();

@@ -255,13 +255,8 @@ int64_t art_bwd_stream_bytes() { return kABwStreamBytes; }
 
 hipError_t launch_art_bwd_chain(const char* packed_bwd, const float* small, const float* d_raw, const void* masks, const float* planes,
                                 float* dplanes, float* dxp, int64_t Np, hipStream_t stream) {
-  static bool attr = false;
-  if (!attr) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&art_bwd_chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       kALdsBytes);
-    if (e != hipSuccess) return e;
-    attr = true;
-  }
+  static DeviceOnce lds_once;
+  if (hipError_t e = set_max_lds(&art_bwd_chain_kernel, kALdsBytes, lds_once); e != hipSuccess) return e;
   ArtBwdArgs a{packed_bwd, small, d_raw, static_cast<const u32x4*>(masks), planes, dplanes, dxp, Np, (int)(Np / 128)};
   const int cus = num_cus();
   if (cus <= 0) return hipErrorInvalidDevice;

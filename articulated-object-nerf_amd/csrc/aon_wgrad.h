@@ -347,14 +347,9 @@ static hipError_t run_wgrad(const float* A, const float* B, int64_t Np, int npar
                             float* out, int ld, int col_off, int k_valid, float* bias_out, hipStream_t stream) {
   constexpr int M = 128 * RT, K = 32 * CT;
   constexpr int lds = 2 * (M + K) * 32 * 4;
-  static bool attr = false;
-  if (!attr) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<RT, CT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_bf16x3_kernel<RT, CT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return e;
-    attr = true;
-  }
+  static DeviceOnce once_f32, once_bf16;
+  if (hipError_t e = set_max_lds(&wgrad_kernel<RT, CT>, lds, once_f32); e != hipSuccess) return e;
+  if (hipError_t e = set_max_lds(&wgrad_bf16x3_kernel<RT, CT>, lds, once_bf16); e != hipSuccess) return e;
   WgradArgs a{A, B, Np, (int)(Np / 32), partial, bias_out ? bias_partial : nullptr};
   if (train_engine() == 1) wgrad_bf16x3_kernel<RT, CT><<<dim3(nparts), dim3(256), lds, stream>>>(a);
   else wgrad_kernel<RT, CT><<<dim3(nparts), dim3(256), lds, stream>>>(a);

@@ -85,11 +85,12 @@ class SapienDataset(torch.utils.data.Dataset):
         img, mask = self.image_of(f)
         return {"rays_o": ro, "rays_d": vd, "viewdirs": vd, "instance_mask": mask, "target": img}
 
-    def train_batches(self, batch_size=2048, generator=None):
-        """Shuffled ray batches of the reference's hard-coded size (model.py:421-428), sampled on the device."""
+    def train_batches(self, batch_size=2048, generator=None, drop_last=False):
+        """Shuffled ray batches of the reference's hard-coded size (model.py:421-428), sampled on the device.  The
+        reference's DataLoader does not set drop_last, so the shorter tail batch of an epoch is yielded too."""
         n = len(self)
         perm = torch.randperm(n, device=self.device, generator=generator)
-        for i in range(0, n - batch_size + 1, batch_size):
+        for i in range(0, n - batch_size + 1 if drop_last else n, batch_size):
             idx = perm[i: i + batch_size]
             yield {"rays_o": self.all_rays_o[idx], "rays_d": self.all_rays_d[idx], "viewdirs": self.all_rays_d[idx],
                    "target": self.all_rgbs[idx]}

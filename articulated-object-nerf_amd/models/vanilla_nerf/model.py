@@ -48,57 +48,46 @@ class NeRFMLP(nn.Module):
         init.xavier_uniform_(self.bottleneck_layer.weight)
         init.xavier_uniform_(self.density_layer.weight)
         init.xavier_uniform_(self.rgb_layer.weight)
-        self._packed = None
-        self._packed_key = None
-        self._packed_bwd = None
-        self._packed_bwd_key = None
+        self._streams = {}
 
-    def _param_key(self, params):
-        return tuple((p.data_ptr(), p._version, str(p.device)) for p in params.values())
+    # Kernel-side weight streams.  They are rebuilt from the LIVE parameters on every call (one ~6 us HIP pack kernel,
+    # 2.4 MB): no version/pointer key can go stale, so `p.data.copy_()`, `dist.broadcast(p.data)`, EMA or clipping code
+    # that mutates parameters without bumping `p._version` is seen exactly as nn.Linear would see it.  `fresh=True`
+    # (training) writes into a new buffer, because autograd saves the stream for backward and a later forward must not
+    # overwrite what an earlier graph still needs; inference reuses one buffer per stream kind (stream-ordered).
+    _PACKERS = {"fwd": "pack_vanilla_mlp", "bwd": "pack_vanilla_mlp_bwd", "fwd_bf16x3": "pack_vanilla_mlp_bf16x3",
+                "bwd_bf16x3": "pack_vanilla_mlp_bwd_bf16x3"}
 
-    def packed_bwd(self) -> torch.Tensor:
-        """Transposed weight stream for the backward data chain (training only)."""
+    def _pack(self, kind: str, fresh: bool) -> torch.Tensor:
         params = dict(self.named_parameters())
-        key = self._param_key(params)
-        if self._packed_bwd is None or key != self._packed_bwd_key:
-            dev = next(iter(params.values())).device
-            out = self._packed_bwd if (self._packed_bwd is not None and self._packed_bwd.device == dev) else None
-            self._packed_bwd = ops.pack_vanilla_mlp_bwd(params, out=out)
-            self._packed_bwd_key = key
-        return self._packed_bwd
+        dev = next(iter(params.values())).device
+        out = None if fresh else self._streams.get(kind)
+        if out is not None and out.device != dev:
+            out = None
+        out = getattr(ops, self._PACKERS[kind])(params, out=out)
+        if not fresh:
+            self._streams[kind] = out
+        return out
+
+    def packed(self, fresh: bool = False) -> torch.Tensor:
+        """Forward weight stream of the fp32 kernels."""
+        return self._pack("fwd", fresh)
+
+    def packed_bwd(self, fresh: bool = False) -> torch.Tensor:
+        """Transposed weight stream for the backward data chain (training only)."""
+        return self._pack("bwd", fresh)
+
+    def packed_bf16x3(self, fresh: bool = False) -> torch.Tensor:
+        """Three-limb bf16 weight stream of the opt-in split-bf16 engine."""
+        return self._pack("fwd_bf16x3", fresh)
+
+    def packed_bwd_bf16x3(self, fresh: bool = False) -> torch.Tensor:
+        """Transposed three-limb bf16 stream of the bf16x3 backward chain."""
+        return self._pack("bwd_bf16x3", fresh)
 
     def ordered_params(self):
         params = dict(self.named_parameters())
         return [params[name] for name in ops.VANILLA_PARAM_ORDER]
-
-    def packed_bf16x3(self) -> torch.Tensor:
-        """Three-limb bf16 weight stream of the opt-in split-bf16 engine."""
-        params = dict(self.named_parameters())
-        key = self._param_key(params)
-        if getattr(self, "_packed_bf", None) is None or key != self._packed_bf_key:
-            self._packed_bf = ops.pack_vanilla_mlp_bf16x3(params)
-            self._packed_bf_key = key
-        return self._packed_bf
-
-    def packed_bwd_bf16x3(self) -> torch.Tensor:
-        """Transposed three-limb bf16 stream of the bf16x3 backward chain."""
-        params = dict(self.named_parameters())
-        key = self._param_key(params)
-        if getattr(self, "_packed_bwd_bf", None) is None or key != self._packed_bwd_bf_key:
-            self._packed_bwd_bf = ops.pack_vanilla_mlp_bwd_bf16x3(params)
-            self._packed_bwd_bf_key = key
-        return self._packed_bwd_bf
-
-    def packed(self) -> torch.Tensor:
-        """The kernel-side weight stream; re-packed (one small HIP kernel) whenever a parameter was modified
-        in place, replaced, or moved."""
-        params = dict(self.named_parameters())
-        key = tuple((p.data_ptr(), p._version, str(p.device)) for p in params.values())
-        if self._packed is None or key != self._packed_key:
-            out = self._packed if (self._packed is not None and self._packed.device == next(iter(params.values())).device) else None
-            self._packed = ops.pack_vanilla_mlp(params, out=out)
-            self._packed_key = key
-        return self._packed
 
     def forward(self, x, condition):
         raw = ops.mlp_fwd_enc(self.packed(), x, condition)
@@ -147,9 +136,9 @@ class NeRF(nn.Module):
                 raise ValueError("empty ray batch in training mode")
             mlps = [self.coarse_mlp, self.fine_mlp][: self.num_levels]
             if ops.get_train_engine() == "bf16x3":   # opt-in: split-bf16 training forward + weight gradients
-                packs = [(m.packed(), None, m.packed_bf16x3(), m.packed_bwd_bf16x3()) for m in mlps]
+                packs = [(m.packed(True), None, m.packed_bf16x3(True), m.packed_bwd_bf16x3(True)) for m in mlps]
             else:
-                packs = [(m.packed(), m.packed_bwd()) for m in mlps]
+                packs = [(m.packed(True), m.packed_bwd(True)) for m in mlps]
             params = [p for m in mlps for p in m.ordered_params()]
             flat = RenderVanilla.apply(rays_o, rays["rays_d"], rays["viewdirs"], float(near), float(far), bool(white_bkgd),
                                        self.num_levels, t_rand, u, packs, *params)

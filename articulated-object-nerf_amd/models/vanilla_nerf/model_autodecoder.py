@@ -51,53 +51,41 @@ class NeRFMLP(nn.Module):
         for m in list(self.deformations_linear) + [self.deformation_layer] + list(self.pts_linears) + \
                 list(self.views_linear)[1:] + [self.bottleneck_layer, self.density_layer, self.rgb_layer]:
             init.xavier_uniform_(m.weight)  # views_linear[0] keeps the default init, like the reference (:147-151)
-        self._packed = None
-        self._packed_key = None
-        self._packed_bwd = None
-        self._packed_bwd_key = None
+        self._streams = {}
         self._small = None
 
-    def packed_bwd(self) -> torch.Tensor:
-        params = dict(self.named_parameters())
-        key = tuple((p.data_ptr(), p._version, str(p.device)) for p in params.values())
-        if self._packed_bwd is None or key != self._packed_bwd_key:
-            dev = next(iter(params.values())).device
-            out = self._packed_bwd if (self._packed_bwd is not None and self._packed_bwd.device == dev) else None
-            self._packed_bwd = ops.pack_art_mlp_bwd(params, out=out)
-            self._packed_bwd_key = key
-        return self._packed_bwd
+    # weight streams are rebuilt from the live parameters on every call (see vanilla NeRFMLP._pack: nothing can go stale)
+    _PACKERS = {"fwd": "pack_art_mlp", "bwd": "pack_art_mlp_bwd", "fwd_bf16x3": "pack_art_mlp_bf16x3",
+                "bwd_bf16x3": "pack_art_mlp_bwd_bf16x3"}
 
-    def packed_bwd_bf16x3(self) -> torch.Tensor:
-        """Transposed three-limb bf16 stream of the bf16x3 backward chain."""
+    def _pack(self, kind: str, fresh: bool) -> torch.Tensor:
         params = dict(self.named_parameters())
-        key = tuple((p.data_ptr(), p._version, str(p.device)) for p in params.values())
-        if getattr(self, "_packed_bwd_bf", None) is None or key != self._packed_bwd_bf_key:
-            self._packed_bwd_bf = ops.pack_art_mlp_bwd_bf16x3(params)
-            self._packed_bwd_bf_key = key
-        return self._packed_bwd_bf
+        dev = next(iter(params.values())).device
+        out = None if fresh else self._streams.get(kind)
+        if out is not None and out.device != dev:
+            out = None
+        out = getattr(ops, self._PACKERS[kind])(params, out=out)
+        if not fresh:
+            self._streams[kind] = out
+        return out
+
+    def packed(self, fresh: bool = False) -> torch.Tensor:
+        return self._pack("fwd", fresh)
+
+    def packed_bwd(self, fresh: bool = False) -> torch.Tensor:
+        return self._pack("bwd", fresh)
+
+    def packed_bf16x3(self, fresh: bool = False) -> torch.Tensor:
+        """Three-limb bf16 weight stream of the opt-in split-bf16 engine."""
+        return self._pack("fwd_bf16x3", fresh)
+
+    def packed_bwd_bf16x3(self, fresh: bool = False) -> torch.Tensor:
+        """Transposed three-limb bf16 stream of the bf16x3 backward chain."""
+        return self._pack("bwd_bf16x3", fresh)
 
     def ordered_params(self):
         params = dict(self.named_parameters())
         return [params[name] for name in ops.ART_PARAM_ORDER]
-
-    def packed(self) -> torch.Tensor:
-        params = dict(self.named_parameters())
-        key = tuple((p.data_ptr(), p._version, str(p.device)) for p in params.values())
-        if self._packed is None or key != self._packed_key:
-            dev = next(iter(params.values())).device
-            out = self._packed if (self._packed is not None and self._packed.device == dev) else None
-            self._packed = ops.pack_art_mlp(params, out=out)
-            self._packed_key = key
-        return self._packed
-
-    def packed_bf16x3(self) -> torch.Tensor:
-        """Three-limb bf16 weight stream of the opt-in split-bf16 engine."""
-        params = dict(self.named_parameters())
-        key = tuple((p.data_ptr(), p._version, str(p.device)) for p in params.values())
-        if getattr(self, "_packed_bf", None) is None or key != self._packed_bf_key:
-            self._packed_bf = ops.pack_art_mlp_bf16x3(params)
-            self._packed_bf_key = key
-        return self._packed_bf
 
     def prepared(self, latents: dict) -> torch.Tensor:
         """Per-call latent-folded block (cheap: ~0.1 MFLOP); always rebuilt because latents are call arguments."""
@@ -156,9 +144,9 @@ class NeRF_AE_Art(nn.Module):
             for mlp in mlps:
                 small = ops.art_prepare(dict(mlp.named_parameters()), latents)
                 if ops.get_train_engine() == "bf16x3":   # opt-in: split-bf16 training forward (+ weight gradients)
-                    packs.append((None, small, None, mlp.packed_bf16x3(), mlp.packed_bwd_bf16x3()))
+                    packs.append((None, small, None, mlp.packed_bf16x3(True), mlp.packed_bwd_bf16x3(True)))
                 else:
-                    packs.append((mlp.packed(), small, mlp.packed_bwd()))
+                    packs.append((mlp.packed(True), small, mlp.packed_bwd(True)))
             params = [p for mlp in mlps for p in mlp.ordered_params()]
             flat = RenderArticulated.apply(rays_o, rays["rays_d"], rays["viewdirs"], float(near), float(far), bool(white_bkgd),
                                            self.num_levels, t_rand, u, packs, latents["density"], latents["color"],

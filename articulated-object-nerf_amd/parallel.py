@@ -28,22 +28,33 @@ def unpack_pixels(p: torch.Tensor):
     return p[:, :3], p[:, 3], p[:, 4]
 
 
-def all_gather_pixels(level, group=None):
+def _active(group) -> bool:
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+
+
+def all_gather_pixels(level, group=None, total: int | None = None, counts=None, force: bool = False):
     """level = (rgb (n,3), acc (n,), depth (n,)) of this rank's ray range -> the same triple for ALL ranks' rays,
-    rank-major (rank 0's range first).  Ranges may differ in length by one ray (see shard_range): shorter ranks are
-    padded to the longest so a single all_gather_into_tensor moves everything."""
+    rank-major (rank 0's range first), with ONE all_gather_into_tensor and no host synchronisation.
+
+    Every rank must be able to name every rank's ray count without asking: `total` = number of rays of the sharded
+    frame (counts follow from `shard_range`, the layout `render_frame_sharded` uses), or `counts` = explicit per-rank
+    list, or neither = every rank holds the same number of rays as this one.  Equal counts gather in place into the
+    final (total,5) buffer; uneven ones (they differ by at most one ray under shard_range) pad to the longest and the
+    padding rows are dropped with host-known offsets.  `force` runs the collective even at world size 1 (tests)."""
     rgb, acc, depth = level
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (_active(group) or (force and dist.is_available() and dist.is_initialized())):
         return rgb, acc, depth
-    world = dist.get_world_size(group)
-    mine = pack_pixels(rgb, acc, depth)
-    n = torch.tensor([mine.shape[0]], dtype=torch.int64, device=mine.device)
-    counts = [torch.zeros_like(n) for _ in range(world)]
-    dist.all_gather(counts, n, group=group)
-    counts = [int(c.item()) for c in counts]
+    world, n = dist.get_world_size(group), rgb.shape[0]
+    if counts is None:
+        counts = [n] * world if total is None else [e - b for b, e in (shard_range(total, r, world) for r in range(world))]
+    counts = [int(c) for c in counts]
+    if len(counts) != world or counts[dist.get_rank(group)] != n:
+        raise ValueError(f"all_gather_pixels: this rank holds {n} rays but the stated layout is {counts}")
     nmax = max(counts)
-    if mine.shape[0] < nmax:
-        mine = torch.cat([mine, mine.new_zeros(nmax - mine.shape[0], 5)], dim=0)
+    mine = rgb.new_empty((nmax, 5))
+    mine[:n, :3] = rgb
+    mine[:n, 3] = acc
+    mine[:n, 4] = depth
     out = mine.new_empty((world * nmax, 5))
     dist.all_gather_into_tensor(out, mine, group=group)
     if min(counts) != nmax:
@@ -52,7 +63,7 @@ def all_gather_pixels(level, group=None):
 
 
 def render_frame_sharded(model, H: int, W: int, focal: float, c2w, near: float, far: float, white_bkgd: bool,
-                         raygen, group=None):
+                         raygen, group=None, force: bool = False):
     """Config 3: one frame, ray ranges sharded over the ranks of `group`, pixels all-gathered.
     `raygen(H, W, focal, c2w, begin, end)` -> (rays_o, viewdirs) for the rank's row-major pixel range
     (aon_amd.datasets.ray_utils.get_frame_rays on GPUs).  Returns the full-frame fine-level (rgb, acc, depth)."""
@@ -61,38 +72,59 @@ def render_frame_sharded(model, H: int, W: int, focal: float, c2w, near: float, 
     begin, end = shard_range(H * W, rank, world)
     rays_o, viewdirs = raygen(H, W, focal, c2w, begin, end)
     out = model({"rays_o": rays_o, "rays_d": viewdirs, "viewdirs": viewdirs}, False, white_bkgd, near, far)
-    return all_gather_pixels(out[-1], group=group)
+    return all_gather_pixels(out[-1], group=group, total=H * W, force=force)
 
 
 # --------------------------------------------------------------------------------------------------------------------
 # training: data-parallel gradient exchange (the reference wraps its module in Lightning's DDPPlugin, run.py:151)
 # --------------------------------------------------------------------------------------------------------------------
-def broadcast_parameters(module, src: int = 0, group=None) -> None:
-    """What DDP does at wrap time: every rank starts from rank `src`'s parameters."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+def broadcast_parameters(module, src: int = 0, group=None, force: bool = False) -> None:
+    """What DDP does at wrap time: every rank starts from rank `src`'s parameters (one flat broadcast)."""
+    if not (_active(group) or (force and dist.is_available() and dist.is_initialized())):
         return
     with torch.no_grad():
-        flat = torch.cat([p.detach().reshape(-1) for p in module.parameters()])
+        params = list(module.parameters())
+        flat = torch.cat([p.detach().reshape(-1) for p in params])
         dist.broadcast(flat, src=src, group=group)
-        off = 0
-        for p in module.parameters():
-            p.copy_(flat[off: off + p.numel()].view_as(p))
-            off += p.numel()
+        torch._foreach_copy_([p.data for p in params], [c.view_as(p) for c, p in zip(flat.split([p.numel() for p in params]), params)])
 
 
-def allreduce_gradients(module, group=None) -> None:
-    """Mean of the per-rank gradients in ONE flat bucket (vanilla: 1,191,688 fp32 = 4.77 MB; articulated 6.4 MB --
-    a single message per step, which on 8 fully connected xGMI peers is latency- rather than bandwidth-bound, so one
-    bucket beats DDP's default 25 MB bucketing logic trivially).  Call between loss.backward() and optimizer.step()."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+def allreduce_gradients(module, group=None, force: bool = False) -> None:
+    """Mean of the per-rank gradients in ONE flat bucket (vanilla: 1,191,688 fp32 = 4.77 MB; articulated 6.4 MB), call
+    between loss.backward() and optimizer.step().
+
+    The bucket spans EVERY parameter that requires grad, in module order, with zeros where this rank produced no gradient
+    (num_levels=1 leaves fine_mlp untouched; a rank may skip a code-library row) -- ranks therefore always agree on the
+    message size -- and the mean is written back as `.grad` for all of them.  On RCCL the exchange is the direct
+    reduce-scatter + all-gather pair (each of the 8 fully connected xGMI peers reduces one eighth of the bucket, scales
+    it, and the eighths are gathered: 2 x 7/8 of the bucket per link instead of a ring's 2 x 7 hops); gloo (CPU tests)
+    has no reduce_scatter_tensor and takes one all_reduce."""
+    if not (_active(group) or (force and dist.is_available() and dist.is_initialized())):
         return
-    params = [p for p in module.parameters() if p.grad is not None]
+    params = [p for p in module.parameters() if p.requires_grad]
     if not params:
         return
-    flat = torch.cat([p.grad.reshape(-1) for p in params])
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
-    flat /= dist.get_world_size(group)
-    off = 0
-    for p in params:
-        p.grad.copy_(flat[off: off + p.numel()].view_as(p.grad))
-        off += p.numel()
+    world = dist.get_world_size(group)
+    sizes = [p.numel() for p in params]
+    total = sum(sizes)
+    padded = (total + world - 1) // world * world
+    ref = params[0]
+    flat = torch.zeros(padded, dtype=ref.dtype, device=ref.device)
+    with torch.no_grad():
+        chunks = flat[:total].split(sizes)
+        had = [p.grad is not None for p in params]
+        if any(had):
+            torch._foreach_copy_([c for c, h in zip(chunks, had) if h], [p.grad.reshape(-1) for p, h in zip(params, had) if h])
+        if dist.get_backend(group) == "nccl":
+            shard = flat.new_empty(padded // world)
+            dist.reduce_scatter_tensor(shard, flat, op=dist.ReduceOp.SUM, group=group)
+            shard /= world
+            dist.all_gather_into_tensor(flat, shard, group=group)
+        else:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+            flat /= world
+        if any(had):
+            torch._foreach_copy_([p.grad for p, h in zip(params, had) if h], [c.view_as(p) for c, p, h in zip(chunks, params, had) if h])
+        for c, p, h in zip(chunks, params, had):
+            if not h:
+                p.grad = c.view_as(p).clone()

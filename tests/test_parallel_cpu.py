@@ -43,10 +43,10 @@ def _worker(rank, world, port, H, W, q):
 
         c2w, focal = syn.look_at_pose(), syn.focal_from_fovy(H)
         rgb, acc, depth = par.render_frame_sharded(FakeRenderer(), H, W, focal, c2w, 2.0, 6.0, True, _cpu_raygen)
-        # uneven explicit gather: rank r contributes r+3 rays
+        # uneven explicit gather: rank r contributes r+3 rays; every rank states the layout (no count exchange, no host sync)
         n = rank + 3
         lvl = (torch.full((n, 3), float(rank)), torch.arange(n, dtype=torch.float32) + 100 * rank, torch.full((n,), -1.0 * rank))
-        g_rgb, g_acc, g_depth = par.all_gather_pixels(lvl)
+        g_rgb, g_acc, g_depth = par.all_gather_pixels(lvl, counts=[r + 3 for r in range(world)])
         q.put((rank, *[x.numpy().copy() for x in (rgb, acc, depth, g_rgb, g_acc, g_depth)]))
         dist.barrier()
     finally:
@@ -64,7 +64,9 @@ def _grad_worker(rank, world, port, q):
         par.broadcast_parameters(net)
         x = torch.randn(11, 5)
         net(x).square().mean().backward()
-        local = [p.grad.clone() for p in net.parameters()]
+        if rank == 1:
+            net[2].bias.grad = None   # a rank that produced no gradient for a parameter still takes part with zeros
+        local = [torch.zeros_like(p) if p.grad is None else p.grad.clone() for p in net.parameters()]
         par.allreduce_gradients(net)
         # plain numpy payloads: torch tensors travel through shared-memory handles that die with the worker
         q.put((rank, [p.detach().numpy().copy() for p in net.parameters()], [g.numpy().copy() for g in local],
