@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libaon_hip.so")
+# AON_HIP_LIB: an alternative build of the SAME library (A/B experiments, tools/kernel_bench.py); never a different backend
+LIB_PATH = os.environ.get("AON_HIP_LIB") or os.path.join(_PKG, "libaon_hip.so")
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(

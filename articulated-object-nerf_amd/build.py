@@ -13,8 +13,10 @@ from concurrent.futures import ThreadPoolExecutor
 
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
-OBJ = os.path.join(PKG, "build")
-LIB = os.path.join(PKG, "libaon_hip.so")
+# experiments: AON_BUILD_TAG=x builds build_x/ -> libaon_hip_x.so next to the product library (select it with AON_HIP_LIB)
+_TAG = os.environ.get("AON_BUILD_TAG", "")
+OBJ = os.path.join(PKG, "build" + ("_" + _TAG if _TAG else ""))
+LIB = os.path.join(PKG, "libaon_hip" + ("_" + _TAG if _TAG else "") + ".so")
 SOURCES = ["aon_mlp.hip", "aon_mlp_bf16.hip", "aon_mlp_art.hip", "aon_mlp_art_bf16.hip", "aon_train.hip", "aon_train_art.hip", "aon_render.hip", "aon_capi.hip"]
 HEADERS = [os.path.join(CSRC, "aon_common.h"), os.path.join(CSRC, "aon_mlp_core.h"), os.path.join(CSRC, "aon_wgrad.h"), os.path.join(CSRC, "aon_art_common.h"),
            os.path.join(os.path.dirname(PKG), "include", "aon_hip.h")]

@@ -191,9 +191,7 @@ __device__ __forceinline__ float head_partial_relu(const f32x16 (&x)[NT], const 
       const f32x4 w = *reinterpret_cast<const f32x4*>(sm_w + 32 * t + 8 * g + 4 * h);
 #pragma unroll
       for (int cc = 0; cc < 4; ++cc) {
-        float r;
-        asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x[t][4 * g + cc]));
-        acc = __builtin_fmaf(w[cc], r, acc);
+        acc = __builtin_fmaf(w[cc], relu1(x[t][4 * g + cc]), acc);  // (no asm on MFMA results: aon_mlp_core.h, hazard rule)
       }
     }
   }

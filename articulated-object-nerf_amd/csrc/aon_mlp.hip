@@ -127,9 +127,9 @@ __global__ void __launch_bounds__(256) mlp_fwd_kernel(MlpArgs args) {
 
     // ---- encode: E[0..1] = 63-wide positional encoding, V = 27-wide view encoding, accumulator layout ----
     f32x16 E[2], V;
+    float x[3] = {0.f, 0.f, 0.f}, vd[3] = {0.f, 0.f, 0.f};
     if constexpr (ENC_IN_KERNEL) {
       const float t = args.t_vals[gc];
-      float x[3], vd[3];
 #pragma unroll
       for (int a = 0; a < 3; ++a) {
         // helper.cast_rays (helper.py:25-26): origins + t * directions, multiply then add
@@ -149,50 +149,82 @@ __global__ void __launch_bounds__(256) mlp_fwd_kernel(MlpArgs args) {
 
     const int64_t col = (int64_t)pass * 128 + wave * 32 + m;  // plane column of this lane's sample
     PlaneIO io{};
-    if constexpr (TRAIN) io = make_plane_io(args.Np, col, h);
-    // [TRAIN] ReLU decisions now, activation planes later: every hidden activation is stored by the layer that consumes
-    // it (dense_layer<.., TRAIN>), one register per MFMA group, so no store burst sits in front of a chunk barrier.
-    auto mask = [&](auto& tiles, int mask_layer) {
-      if constexpr (TRAIN) args.masks[(int64_t)mask_layer * args.Np * 2 + (int64_t)pass * 256 + tid] = relu_mask_bits(tiles);
-    };
+    unsigned moff = 0;
+    if constexpr (TRAIN) { io = make_plane_io(args.Np, col, h); moff = mask_lane_off(pass, tid); }
     auto rows = [&](int row) { return reinterpret_cast<float*>(reinterpret_cast<char*>(args.planes) + (int64_t)row * io.row_bytes); };
     const int64_t tile_bytes = 32 * io.row_bytes;
     if constexpr (TRAIN) {
       store_pos_enc_plane(E, rows(kPlE), io, col, h);
       store_view_enc_plane(V, rows(kPlVE), io, col, h);
     }
+    // [TRAIN] Every hidden activation tile is stored, and its ReLU decision bits are collected, by the chunk that CONSUMES
+    // it (side job of chunk_mma: one value per MFMA group), so neither a store burst nor a block of mask arithmetic sits at
+    // a layer boundary.  `in_row` = plane row of input tile 0, `in_mask` = mask slot of the layer that produced `in`
+    // (-1: the bottleneck output has no activation).
+    auto consume = [&](const f32x16 (&in)[8], int in_row, u32x4& mw, bool with_mask) {
+      return [&, in_row, with_mask](int j) {
+        return [&, in_row, with_mask, j](int i) {
+          if constexpr (TRAIN) {
+            if (i < 16) {
+#ifndef AON_EXP_NOSTORE
+              *plane_addr(reinterpret_cast<float*>(reinterpret_cast<char*>(rows(in_row)) + j * tile_bytes), io, (i & 3) + 8 * (i >> 2)) = in[j][i];
+#endif
+#ifndef AON_EXP_NOMASK
+              if (with_mask) mw[j >> 1] = mask_push_post(mw[j >> 1], in[j][i]);
+#endif
+            }
+          }
+        };
+      };
+    };
+    auto put_mask = [&](const u32x4& mw, int mask_layer) {   // all 8 tiles (32 pushes per word) of the layer have been consumed
+      if constexpr (TRAIN)
+        *mask_ptr(args.masks, args.Np, mask_layer, moff) = u32x4{mask_word_finish(mw[0]), mask_word_finish(mw[1]), mask_word_finish(mw[2]), mask_word_finish(mw[3])};
+    };
     f32x16 X[8], Y[8];
+    u32x4 mw;
     // L0: enc(63) -> 256
     init_bias(X, sm + kSmBias + 0 * 256, h);
     chunk_mma<VanillaNet, kChL0 + 0, 8, 16>(p, E[0], X);
     chunk_mma<VanillaNet, kChL0 + 1, 8, 16>(p, E[1], X);
-    relu_tiles(X); mask(X, 0);
+    relu_tiles(X);
     // L1..L4
-    init_bias(Y, sm + kSmBias + 1 * 256, h); dense_layer<VanillaNet, kChL1 + 0, 8, 8, TRAIN>(p, X, Y, rows(plane_h(0)), &io, tile_bytes); relu_tiles(Y); mask(Y, 1);
-    init_bias(X, sm + kSmBias + 2 * 256, h); dense_layer<VanillaNet, kChL1 + 8, 8, 8, TRAIN>(p, Y, X, rows(plane_h(1)), &io, tile_bytes); relu_tiles(X); mask(X, 2);
-    init_bias(Y, sm + kSmBias + 3 * 256, h); dense_layer<VanillaNet, kChL1 + 16, 8, 8, TRAIN>(p, X, Y, rows(plane_h(2)), &io, tile_bytes); relu_tiles(Y); mask(Y, 3);
-    init_bias(X, sm + kSmBias + 4 * 256, h); dense_layer<VanillaNet, kChL1 + 24, 8, 8, TRAIN>(p, Y, X, rows(plane_h(3)), &io, tile_bytes); relu_tiles(X); mask(X, 4);
+    mw = u32x4{0u, 0u, 0u, 0u}; init_bias(Y, sm + kSmBias + 1 * 256, h); dense_layer<VanillaNet, kChL1 + 0, 8, 8>(p, X, Y, consume(X, plane_h(0), mw, true)); put_mask(mw, 0); relu_tiles(Y);
+    mw = u32x4{0u, 0u, 0u, 0u}; init_bias(X, sm + kSmBias + 2 * 256, h); dense_layer<VanillaNet, kChL1 + 8, 8, 8>(p, Y, X, consume(Y, plane_h(1), mw, true)); put_mask(mw, 1); relu_tiles(X);
+    mw = u32x4{0u, 0u, 0u, 0u}; init_bias(Y, sm + kSmBias + 3 * 256, h); dense_layer<VanillaNet, kChL1 + 16, 8, 8>(p, X, Y, consume(X, plane_h(2), mw, true)); put_mask(mw, 2); relu_tiles(Y);
+    mw = u32x4{0u, 0u, 0u, 0u}; init_bias(X, sm + kSmBias + 4 * 256, h); dense_layer<VanillaNet, kChL1 + 24, 8, 8>(p, Y, X, consume(Y, plane_h(3), mw, true)); put_mask(mw, 3); relu_tiles(X);
     // L5: cat[h(256), enc(63)] -> 256     (model.py:102-103: concat after layer 4's ReLU)
-    init_bias(Y, sm + kSmBias + 5 * 256, h);
-    dense_layer<VanillaNet, kChL5, 8, 8, TRAIN>(p, X, Y, rows(plane_h(4)), &io, tile_bytes);
+    mw = u32x4{0u, 0u, 0u, 0u}; init_bias(Y, sm + kSmBias + 5 * 256, h);
+    dense_layer<VanillaNet, kChL5, 8, 8>(p, X, Y, consume(X, plane_h(4), mw, true)); put_mask(mw, 4);
+    if constexpr (TRAIN) {  // (x made opaque: otherwise the two identical encodings are merged and the first stays live)
+      asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]));
+      encode_pos(x, h, E);
+    }  // re-encoded (same function, same bits) instead of 32 registers held live across layers 1-4
     chunk_mma<VanillaNet, kChL5 + 8, 8, 16>(p, E[0], Y);
     chunk_mma<VanillaNet, kChL5 + 9, 8, 16>(p, E[1], Y);
-    relu_tiles(Y); mask(Y, 5);
+    relu_tiles(Y);
     // L6, L7
-    init_bias(X, sm + kSmBias + 6 * 256, h); dense_layer<VanillaNet, kChL6, 8, 8, TRAIN>(p, Y, X, rows(plane_h(5)), &io, tile_bytes); relu_tiles(X); mask(X, 6);
-    init_bias(Y, sm + kSmBias + 7 * 256, h); dense_layer<VanillaNet, kChL7, 8, 8, TRAIN>(p, X, Y, rows(plane_h(6)), &io, tile_bytes); relu_tiles(Y); mask(Y, 7);
+    mw = u32x4{0u, 0u, 0u, 0u}; init_bias(X, sm + kSmBias + 6 * 256, h); dense_layer<VanillaNet, kChL6, 8, 8>(p, Y, X, consume(Y, plane_h(5), mw, true)); put_mask(mw, 5); relu_tiles(X);
+    mw = u32x4{0u, 0u, 0u, 0u}; init_bias(Y, sm + kSmBias + 7 * 256, h); dense_layer<VanillaNet, kChL7, 8, 8>(p, X, Y, consume(X, plane_h(6), mw, true)); put_mask(mw, 6); relu_tiles(Y);
     // density head (model.py:105) on the post-ReLU layer-7 output
     float sigma = head_partial<8>(Y, sm + kSmWSigma, h);
     sigma = sigma + __shfl_xor(sigma, 32) + sm[kSmBSigma];
     // bottleneck, no activation (model.py:109)
-    init_bias(X, sm + kSmBiasBott, h); dense_layer<VanillaNet, kChBott, 8, 8, TRAIN>(p, Y, X, rows(plane_h(7)), &io, tile_bytes);
+    mw = u32x4{0u, 0u, 0u, 0u}; init_bias(X, sm + kSmBiasBott, h); dense_layer<VanillaNet, kChBott, 8, 8>(p, Y, X, consume(Y, plane_h(7), mw, true)); put_mask(mw, 7);
     // view branch: cat[bottleneck(256), viewenc(27)] -> 128, ReLU (model.py:110-116)
     f32x16 Z[4];
     init_bias(Z, sm + kSmBiasView, h);
-    dense_layer<VanillaNet, kChView, 8, 4, TRAIN>(p, X, Z, rows(kPlBot), &io, tile_bytes);
+    dense_layer<VanillaNet, kChView, 8, 4>(p, X, Z, consume(X, kPlBot, mw, false));
+    if constexpr (TRAIN) {
+      asm volatile("" : "+v"(vd[0]), "+v"(vd[1]), "+v"(vd[2]));
+      encode_view(vd, h, V);
+    }  // likewise: 16 registers not held across the trunk
     chunk_mma<VanillaNet, kChView + 8, 4, 14>(p, V, Z);
-    relu_tiles(Z); mask(Z, 8);
-    if constexpr (TRAIN) store_plane(Z, rows(kPlHV), io);
+    relu_tiles(Z);
+    if constexpr (TRAIN) {  // the view layer's output feeds the rgb head on the VALU: no consuming chunk, 64 values stored here
+      *mask_ptr(args.masks, args.Np, 8, moff) = relu_mask_bits(Z);   // burst form: already in the stored bit layout
+      store_plane(Z, rows(kPlHV), io);
+    }
     // rgb head (model.py:118)
     float rgb[3];
 #pragma unroll

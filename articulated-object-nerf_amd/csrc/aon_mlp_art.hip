@@ -149,17 +149,16 @@ __global__ void __launch_bounds__(256) art_mlp_fwd_kernel(ArtMlpArgs args) {
     const bool valid = g < args.total;
     const int64_t gc = valid ? g : args.total - 1;
     const int64_t ray = gc / args.S;
-    float x[3];
+    float x[3], vd[3] = {0.f, 0.f, 0.f};
     f32x16 V;
     if constexpr (POS_IN_KERNEL) {
       const float t = args.t_vals[gc];
-      float vd[3];
 #pragma unroll
       for (int a = 0; a < 3; ++a) {
         x[a] = __fadd_rn(args.rays_o[ray * 3 + a], __fmul_rn(t, args.rays_d[ray * 3 + a]));
         vd[a] = args.viewdirs[ray * 3 + a];
       }
-      encode_view(vd, h, V);
+      if constexpr (!TRAIN) encode_view(vd, h, V);  // [TRAIN] encoded where the view branch needs it: 16 registers not held across the trunk
     } else {
 #pragma unroll
       for (int a = 0; a < 3; ++a) x[a] = args.pos[gc * 3 + a];
@@ -168,18 +167,48 @@ __global__ void __launch_bounds__(256) art_mlp_fwd_kernel(ArtMlpArgs args) {
 
     const int64_t col = (int64_t)pass * 128 + wave * 32 + m;
     PlaneIO io{};
-    if constexpr (TRAIN) io = make_plane_io(args.Np, col, h);
-    auto save = [&](auto& tiles, int row, int mask_slot = -1) {
+    unsigned moff = 0;
+    if constexpr (TRAIN) { io = make_plane_io(args.Np, col, h); moff = mask_lane_off(pass, tid); }
+    auto rows = [&](int row) { return reinterpret_cast<float*>(reinterpret_cast<char*>(args.planes) + (int64_t)row * io.row_bytes); };
+    // [TRAIN] activation tiles are stored, and their ReLU decision bits collected, by the chunk that CONSUMES them (side job
+    // of chunk_mma, one value per MFMA group); only the tiles consumed on the VALU (deformation head, rgb head) and the
+    // VALU-computed first deformation layer's output go out in a burst of 64 values.
+    auto side = [&](const f32x16& tile, int row, unsigned& word, bool with_mask) {
+      return [&, row, with_mask](int i) {
+        if constexpr (TRAIN) {
+          if (i < 16) {
+#ifndef AON_EXP_NOSTORE
+            *plane_addr(rows(row), io, (i & 3) + 8 * (i >> 2)) = tile[i];
+#endif
+#ifndef AON_EXP_NOMASK
+            if (with_mask) word = mask_push_post(word, tile[i]);
+#endif
+          }
+        }
+      };
+    };
+    unsigned mw[4] = {0u, 0u, 0u, 0u};
+    auto consume4 = [&](const f32x16 (&in)[4], int in_row, bool with_mask) {
+      return [&, in_row, with_mask](int j) { return side(in[j], in_row + 32 * j, mw[j >> 1], with_mask); };
+    };
+    auto consume8 = [&](const f32x16 (&in)[8], int in_row, bool with_mask) {
+      return [&, in_row, with_mask](int j) { return side(in[j], in_row + 32 * j, mw[j >> 1], with_mask); };
+    };
+    auto put_mask = [&](int slot) {
+      if constexpr (TRAIN)   // every word took 0 or 32 pushes (4- and 8-tile layers)
+        *mask_ptr(args.masks, args.Np, slot, moff) = u32x4{mask_word_finish(mw[0]), mask_word_finish(mw[1]), mask_word_finish(mw[2]), mask_word_finish(mw[3])};
+      mw[0] = mw[1] = mw[2] = mw[3] = 0u;
+    };
+    auto burst = [&](auto& tiles, int row, int mask_slot) {   // VALU-consumed tiles
       if constexpr (TRAIN) {
-        store_plane(tiles, reinterpret_cast<float*>(reinterpret_cast<char*>(args.planes) + (int64_t)row * io.row_bytes), io);
-        if (mask_slot >= 0) args.masks[(int64_t)mask_slot * args.Np * 2 + (int64_t)pass * 256 + tid] = relu_mask_bits(tiles);
+        store_plane(tiles, rows(row), io);
+        *mask_ptr(args.masks, args.Np, mask_slot, moff) = relu_mask_bits(tiles);
       }
     };
     auto save_row = [&](int row, float v) {  // one scalar per sample (lanes 0..31)
       if constexpr (TRAIN) { if (h == 0) *reinterpret_cast<float*>(reinterpret_cast<char*>(args.planes) + (int64_t)row * io.row_bytes + col * 4) = v; }
     };
     if constexpr (TRAIN) {
-      store_view_enc_plane(V, reinterpret_cast<float*>(reinterpret_cast<char*>(args.planes) + (int64_t)kAPlVE * io.row_bytes), io, col, h);
 #pragma unroll
       for (int a = 0; a < 3; ++a) save_row(kAPlPos + a, x[a]);
     }
@@ -199,10 +228,11 @@ __global__ void __launch_bounds__(256) art_mlp_fwd_kernel(ArtMlpArgs args) {
         }
       }
     }
-    relu_tiles(H0); save(H0, aplane_d(0), 0);
-    init_bias(H1, sm + kA_BD + 0 * 128, h); dense_layer<ArtNet, kAChD1 + 0, 4, 4>(p, H0, H1); relu_tiles(H1); save(H1, aplane_d(1), 1);
-    init_bias(H0, sm + kA_BD + 1 * 128, h); dense_layer<ArtNet, kAChD1 + 4, 4, 4>(p, H1, H0); relu_tiles(H0); save(H0, aplane_d(2), 2);
-    init_bias(H1, sm + kA_BD + 2 * 128, h); dense_layer<ArtNet, kAChD1 + 8, 4, 4>(p, H0, H1); relu_tiles(H1); save(H1, aplane_d(3), 3);
+    relu_tiles(H0);
+    init_bias(H1, sm + kA_BD + 0 * 128, h); dense_layer<ArtNet, kAChD1 + 0, 4, 4>(p, H0, H1, consume4(H0, aplane_d(0), true)); put_mask(0); relu_tiles(H1);
+    init_bias(H0, sm + kA_BD + 1 * 128, h); dense_layer<ArtNet, kAChD1 + 4, 4, 4>(p, H1, H0, consume4(H1, aplane_d(1), true)); put_mask(1); relu_tiles(H0);
+    init_bias(H1, sm + kA_BD + 2 * 128, h); dense_layer<ArtNet, kAChD1 + 8, 4, 4>(p, H0, H1, consume4(H0, aplane_d(2), true)); put_mask(2); relu_tiles(H1);
+    burst(H1, aplane_d(3), 3);
     float xd[3];
 #pragma unroll
     for (int a = 0; a < 3; ++a) {  // x' = deformation_layer(h) + pos   (:205)
@@ -215,7 +245,7 @@ __global__ void __launch_bounds__(256) art_mlp_fwd_kernel(ArtMlpArgs args) {
     if constexpr (TRAIN) {
 #pragma unroll
       for (int a = 0; a < 3; ++a) save_row(kAPlPos + 3 + a, xd[a]);
-      store_pos_enc_plane(E, reinterpret_cast<float*>(reinterpret_cast<char*>(args.planes) + (int64_t)kAPlE * io.row_bytes), io, col, h);
+      store_pos_enc_plane(E, rows(kAPlE), io, col, h);
     }
 
     // ---- trunk (:212-217), shape latent folded into the biases of layers 0 and 5 ----
@@ -223,38 +253,40 @@ __global__ void __launch_bounds__(256) art_mlp_fwd_kernel(ArtMlpArgs args) {
     init_bias(X, sm + kA_BT + 0 * 256, h);
     chunk_mma<ArtNet, kAChT0 + 0, 8, 16>(p, E[0], X);
     chunk_mma<ArtNet, kAChT0 + 1, 8, 16>(p, E[1], X);
-    relu_tiles(X); save(X, aplane_h(0), 4);
-    init_bias(Y, sm + kA_BT + 1 * 256, h); dense_layer<ArtNet, kAChT1 + 0, 8, 8>(p, X, Y); relu_tiles(Y); save(Y, aplane_h(1), 5);
-    init_bias(X, sm + kA_BT + 2 * 256, h); dense_layer<ArtNet, kAChT1 + 8, 8, 8>(p, Y, X); relu_tiles(X); save(X, aplane_h(2), 6);
-    init_bias(Y, sm + kA_BT + 3 * 256, h); dense_layer<ArtNet, kAChT1 + 16, 8, 8>(p, X, Y); relu_tiles(Y); save(Y, aplane_h(3), 7);
-    init_bias(X, sm + kA_BT + 4 * 256, h); dense_layer<ArtNet, kAChT1 + 24, 8, 8>(p, Y, X); relu_tiles(X); save(X, aplane_h(4), 8);
+    relu_tiles(X);
+    init_bias(Y, sm + kA_BT + 1 * 256, h); dense_layer<ArtNet, kAChT1 + 0, 8, 8>(p, X, Y, consume8(X, aplane_h(0), true)); put_mask(4); relu_tiles(Y);
+    init_bias(X, sm + kA_BT + 2 * 256, h); dense_layer<ArtNet, kAChT1 + 8, 8, 8>(p, Y, X, consume8(Y, aplane_h(1), true)); put_mask(5); relu_tiles(X);
+    init_bias(Y, sm + kA_BT + 3 * 256, h); dense_layer<ArtNet, kAChT1 + 16, 8, 8>(p, X, Y, consume8(X, aplane_h(2), true)); put_mask(6); relu_tiles(Y);
+    init_bias(X, sm + kA_BT + 4 * 256, h); dense_layer<ArtNet, kAChT1 + 24, 8, 8>(p, Y, X, consume8(Y, aplane_h(3), true)); put_mask(7); relu_tiles(X);
     init_bias(Y, sm + kA_BT + 5 * 256, h);
-    dense_layer<ArtNet, kAChT5, 8, 8>(p, X, Y);
+    dense_layer<ArtNet, kAChT5, 8, 8>(p, X, Y, consume8(X, aplane_h(4), true)); put_mask(8);
+    if constexpr (TRAIN) {  // re-encoded (same function, same bits; xd made opaque so the two encodings are not merged) instead of
+      asm volatile("" : "+v"(xd[0]), "+v"(xd[1]), "+v"(xd[2]));   // 32 registers held live across layers 1-4
+      encode_pos(xd, h, E);
+    }
     chunk_mma<ArtNet, kAChT5 + 8, 8, 16>(p, E[0], Y);
     chunk_mma<ArtNet, kAChT5 + 9, 8, 16>(p, E[1], Y);
-    relu_tiles(Y); save(Y, aplane_h(5), 9);
-    init_bias(X, sm + kA_BT + 6 * 256, h); dense_layer<ArtNet, kAChT6, 8, 8>(p, Y, X); relu_tiles(X); save(X, aplane_h(6), 10);
-    init_bias(Y, sm + kA_BT + 7 * 256, h); dense_layer<ArtNet, kAChT7, 8, 8>(p, X, Y); relu_tiles(Y); save(Y, aplane_h(7), 11);
+    relu_tiles(Y);
+    init_bias(X, sm + kA_BT + 6 * 256, h); dense_layer<ArtNet, kAChT6, 8, 8>(p, Y, X, consume8(Y, aplane_h(5), true)); put_mask(9); relu_tiles(X);
+    init_bias(Y, sm + kA_BT + 7 * 256, h); dense_layer<ArtNet, kAChT7, 8, 8>(p, X, Y, consume8(X, aplane_h(6), true)); put_mask(10); relu_tiles(Y);
     float sigma = head_partial<8>(Y, sm + kA_WSIG, h);  // density_layer (:219)
     sigma = sigma + __shfl_xor(sigma, 32) + sm[kA_BSIG];
-    init_bias(X, sm + kA_BBOT, h); dense_layer<ArtNet, kAChBott, 8, 8>(p, Y, X); save(X, kAPlBot);  // bottleneck (:223)
+    init_bias(X, sm + kA_BBOT, h); dense_layer<ArtNet, kAChBott, 8, 8>(p, Y, X, consume8(Y, aplane_h(7), true)); put_mask(11);  // bottleneck (:223)
 
     // ---- view branch (:227-234): cat[bottleneck, viewenc, appearance] -> 4 x (128, ReLU) ----
     f32x16 Z0[4], Z1[4];
     init_bias(Z0, sm + kA_BV + 0 * 128, h);
-    chunk_mma<ArtNet, kAChV0 + 0, 4, 16>(p, X[0], Z0);
-    chunk_mma<ArtNet, kAChV0 + 1, 4, 16>(p, X[1], Z0);
-    chunk_mma<ArtNet, kAChV0 + 2, 4, 16>(p, X[2], Z0);
-    chunk_mma<ArtNet, kAChV0 + 3, 4, 16>(p, X[3], Z0);
-    chunk_mma<ArtNet, kAChV0 + 4, 4, 16>(p, X[4], Z0);
-    chunk_mma<ArtNet, kAChV0 + 5, 4, 16>(p, X[5], Z0);
-    chunk_mma<ArtNet, kAChV0 + 6, 4, 16>(p, X[6], Z0);
-    chunk_mma<ArtNet, kAChV0 + 7, 4, 16>(p, X[7], Z0);
+    dense_layer<ArtNet, kAChV0, 8, 4>(p, X, Z0, consume8(X, kAPlBot, false));
+    if constexpr (TRAIN) {
+      encode_view(vd, h, V);
+      store_view_enc_plane(V, rows(kAPlVE), io, col, h);
+    }
     chunk_mma<ArtNet, kAChV0 + 8, 4, 14>(p, V, Z0);
-    relu_tiles(Z0); save(Z0, aplane_v(0), 12);
-    init_bias(Z1, sm + kA_BV + 1 * 128, h); dense_layer<ArtNet, kAChV1 + 0, 4, 4>(p, Z0, Z1); relu_tiles(Z1); save(Z1, aplane_v(1), 13);
-    init_bias(Z0, sm + kA_BV + 2 * 128, h); dense_layer<ArtNet, kAChV1 + 4, 4, 4>(p, Z1, Z0); relu_tiles(Z0); save(Z0, aplane_v(2), 14);
-    init_bias(Z1, sm + kA_BV + 3 * 128, h); dense_layer<ArtNet, kAChV1 + 8, 4, 4>(p, Z0, Z1); relu_tiles(Z1); save(Z1, aplane_v(3), 15);
+    relu_tiles(Z0);
+    init_bias(Z1, sm + kA_BV + 1 * 128, h); dense_layer<ArtNet, kAChV1 + 0, 4, 4>(p, Z0, Z1, consume4(Z0, aplane_v(0), true)); put_mask(12); relu_tiles(Z1);
+    init_bias(Z0, sm + kA_BV + 2 * 128, h); dense_layer<ArtNet, kAChV1 + 4, 4, 4>(p, Z1, Z0, consume4(Z1, aplane_v(1), true)); put_mask(13); relu_tiles(Z0);
+    init_bias(Z1, sm + kA_BV + 3 * 128, h); dense_layer<ArtNet, kAChV1 + 8, 4, 4>(p, Z0, Z1, consume4(Z0, aplane_v(2), true)); put_mask(14); relu_tiles(Z1);
+    burst(Z1, aplane_v(3), 15);
     float rgb[3];
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) {  // rgb_layer (:236)

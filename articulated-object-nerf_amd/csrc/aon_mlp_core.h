@@ -3,6 +3,8 @@
 #pragma once
 #include "aon_common.h"
 
+#include <type_traits>
+
 namespace aon {
 
 // Weight-stream pipeline of the fp32 kernels: two 64 KiB LDS slots, each holding a PAIR of consecutive chunks, and one
@@ -116,12 +118,19 @@ __device__ __forceinline__ void dma_round(const Pipe& p, unsigned off, int r) {
 struct PlaneIO;
 __device__ __forceinline__ float* plane_addr(float* plane, const PlaneIO& io, int row);
 
-// STORE (training forward): the input tile -- an activation the backward pass needs -- is written to its plane rows
-// one register per step between the MFMAs of this chunk, so the stores drain under the matrix pipe instead of in a
-// burst in front of the next chunk's barrier (whose s_waitcnt vmcnt(0) also waits for every outstanding store).
-template <class Net, int C, int NT_OUT, int NREG, bool STORE = false>
-__device__ __forceinline__ void chunk_mma(Pipe& p, const f32x16& in, f32x16 (&out)[NT_OUT], float* tile_plane = nullptr,
-                                          const PlaneIO* io = nullptr) {
+// SIDE JOB: `side(i)` is called for i = 0 .. max(16, NSTEP)-1, spread over the chunk's steps (a step = a group of four
+// MFMAs, 256 matrix-pipe cycles), between the MFMA groups of the chunk.  The training kernels hang their per-value bookkeeping on it -- storing the input tile
+// to its activation / gradient plane, collecting or applying ReLU decision bits -- one value per step, so that this VALU
+// and store work drains in the shadow of the matrix pipe instead of in a burst at a layer boundary, where no MFMA is in
+// flight (and in front of the next chunk barrier, whose s_waitcnt vmcnt(0) also waits for every outstanding store).
+// Measured round 2 (tools/kernel_bench.py, 4096 x 193 samples): producer-side bursts cost the articulated training forward
+// 25 % (stores) + 8 % (masks), its backward chain 18 %; the vanilla forward 5.5 % + 4.7 %.
+struct NoSide {
+  __device__ __forceinline__ void operator()(int) const {}
+};
+
+template <class Net, int C, int NT_OUT, int NREG, class Side = NoSide>
+__device__ __forceinline__ void chunk_mma(Pipe& p, const f32x16& in, f32x16 (&out)[NT_OUT], Side side = Side{}) {
   static_assert(Net::chunk_bytes(C) == NT_OUT * 4096, "chunk/out-tile mismatch");
   static_assert(NREG % 2 == 0 && NREG > 12, "register count");
   const unsigned dma_off = acquire<Net, C>(p);
@@ -144,9 +153,11 @@ __device__ __forceinline__ void chunk_mma(Pipe& p, const f32x16& in, f32x16 (&ou
     if constexpr (ROUNDS > 0) {
       if (i < ROUNDS) dma_round<Net, C>(p, dma_off, i);
     }
-    if constexpr (STORE) {
-      if (i < 16) *plane_addr(tile_plane, *io, (i & 3) + 8 * (i >> 2)) = in[i];
-    }
+    // a side job has 16 slots (one per register of the input tile); chunks with fewer than 16 steps (two output tiles)
+    // take several per step
+    constexpr int SIDE_PER_STEP = NSTEP >= 16 ? 1 : (16 + NSTEP - 1) / NSTEP;
+#pragma unroll
+    for (int k = 0; k < SIDE_PER_STEP; ++k) side(i * SIDE_PER_STEP + k);
 #ifdef AON_PIN_PREFETCH   // per translation unit (build.py): keeps the read of step i+1 above the four MFMAs of step i
     __builtin_amdgcn_sched_barrier(0);
 #endif
@@ -170,6 +181,22 @@ __device__ __forceinline__ void init_bias(f32x16 (&acc)[NT_OUT], const float* sm
   }
 }
 
+// HAZARD RULE for this code base: no inline-asm INSTRUCTION may read a register written by an MFMA.  The hardware needs up
+// to 18 wait states between an MFMA's VGPR write and a VALU read of it; hipcc inserts them for instructions it knows, but
+// an asm block is opaque to its hazard recognizer.  Round 1's `asm("v_max_f32 ...")` ReLU and round 2's first mask helpers
+// broke this: harmless while the allocator kept accumulators in AGPRs (the v_accvgpr_read in front is hazard-checked), wrong
+// results as soon as a tile was allocated in architectural VGPRs and the scheduler moved the asm next to the producing MFMA
+// (articulated training forward, view layer 1, output tile 0: tests/diag/diag_art_planes.py).  Empty asm statements
+// ("value barriers") on VALU-produced values are fine: they emit nothing.
+//
+// ReLU as ONE integer instruction the compiler knows: max(int(bits(x)), 0).  Non-negative floats are non-negative integers
+// and keep their bits; anything with the sign bit set (negative values, -0) is a negative integer and becomes +0.  No
+// canonicalising second v_max as with fmaxf(), and relu(NaN) stays NaN as in torch.
+__device__ __forceinline__ float relu1(float x) {
+  const int b = __builtin_bit_cast(int, x);
+  return __builtin_bit_cast(float, b > 0 ? b : 0);
+}
+
 // ReLU on accumulator tiles.  (An AGPR->AGPR variant -- v_accvgpr_read / v_max / v_accvgpr_write in one asm block with
 // "a" constraints, which frees ~75 arch VGPRs -- was measured in round 1: 0.875 of peak against 0.908 for this form.)
 template <int NT>
@@ -178,28 +205,30 @@ __device__ __forceinline__ void relu_tiles(f32x16 (&x)[NT]) {
   for (int t = 0; t < NT; ++t) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      float y;  // plain v_max_f32: fmaxf() would add a canonicalising v_max in front of the real one
-      asm("v_max_f32 %0, 0, %1" : "=v"(y) : "v"(x[t][r]));
+      float y = relu1(x[t][r]);  // the instruction that reads the accumulator is the compiler's (hazard rule)
+      asm("" : "+v"(y));         // ... and its result is opaque, as the asm ReLU's was (see kernel_resources notes in DESIGN.md)
       x[t][r] = y;
     }
   }
 }
 
 // NT_IN*32 -> NT_OUT*32 layer, input/output both in accumulator layout; chunks CBASE .. CBASE+NT_IN-1.
-// STORE: the input tiles go to the plane rows starting at `in_plane` (32 rows per tile) while the layer computes.
-template <class Net, int CBASE, int NT_IN, int NT_OUT, bool STORE = false>
-__device__ __forceinline__ void dense_layer(Pipe& p, const f32x16 (&in)[NT_IN], f32x16 (&out)[NT_OUT], float* in_plane = nullptr,
-                                            const PlaneIO* io = nullptr, int64_t tile_stride_bytes = 0) {
-  auto tp = [&](int j) { return STORE ? reinterpret_cast<float*>(reinterpret_cast<char*>(in_plane) + j * tile_stride_bytes) : nullptr; };
-  chunk_mma<Net, CBASE + 0, NT_OUT, 16, STORE>(p, in[0], out, tp(0), io);
-  chunk_mma<Net, CBASE + 1, NT_OUT, 16, STORE>(p, in[1], out, tp(1), io);
-  chunk_mma<Net, CBASE + 2, NT_OUT, 16, STORE>(p, in[2], out, tp(2), io);
-  chunk_mma<Net, CBASE + 3, NT_OUT, 16, STORE>(p, in[3], out, tp(3), io);
+// `side_of(j)` returns the side job of the chunk that consumes input tile j (see chunk_mma).
+struct NoSideOf {
+  __device__ __forceinline__ NoSide operator()(int) const { return NoSide{}; }
+};
+
+template <class Net, int CBASE, int NT_IN, int NT_OUT, class SideOf = NoSideOf>
+__device__ __forceinline__ void dense_layer(Pipe& p, const f32x16 (&in)[NT_IN], f32x16 (&out)[NT_OUT], SideOf side_of = SideOf{}) {
+  chunk_mma<Net, CBASE + 0, NT_OUT, 16>(p, in[0], out, side_of(0));
+  chunk_mma<Net, CBASE + 1, NT_OUT, 16>(p, in[1], out, side_of(1));
+  chunk_mma<Net, CBASE + 2, NT_OUT, 16>(p, in[2], out, side_of(2));
+  chunk_mma<Net, CBASE + 3, NT_OUT, 16>(p, in[3], out, side_of(3));
   if constexpr (NT_IN == 8) {
-    chunk_mma<Net, CBASE + 4, NT_OUT, 16, STORE>(p, in[4], out, tp(4), io);
-    chunk_mma<Net, CBASE + 5, NT_OUT, 16, STORE>(p, in[5], out, tp(5), io);
-    chunk_mma<Net, CBASE + 6, NT_OUT, 16, STORE>(p, in[6], out, tp(6), io);
-    chunk_mma<Net, CBASE + 7, NT_OUT, 16, STORE>(p, in[7], out, tp(7), io);
+    chunk_mma<Net, CBASE + 4, NT_OUT, 16>(p, in[4], out, side_of(4));
+    chunk_mma<Net, CBASE + 5, NT_OUT, 16>(p, in[5], out, side_of(5));
+    chunk_mma<Net, CBASE + 6, NT_OUT, 16>(p, in[6], out, side_of(6));
+    chunk_mma<Net, CBASE + 7, NT_OUT, 16>(p, in[7], out, side_of(7));
   }
 }
 
@@ -251,14 +280,53 @@ __device__ __forceinline__ const float* plane_addr(const float* plane, const Pla
 // re-reading 128 activation values per lane per layer.
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
+// Address of a lane's 16-byte decision-bit word: masks[slot][pass * 256 + tid].  [uniform slot base on the scalar unit] +
+// [one 32-bit per-lane byte offset, made opaque once per pass]: written as one 64-bit per-lane index, the loop-invariant
+// part (slot * Np * 2 + tid) of every slot is hoisted out of the pass loop into its own register pair.
+__device__ __forceinline__ unsigned mask_lane_off(int pass, int tid) {
+  unsigned off = (unsigned)(pass * 256 + tid) * 16u;
+  asm volatile("" : "+v"(off));
+  return off;
+}
+template <class T>
+__device__ __forceinline__ T* mask_ptr(T* masks, int64_t Np, int slot, unsigned lane_off) {
+  int64_t sb = (int64_t)slot * Np * 32;
+  asm volatile("" : "+s"(sb));
+  using C = std::conditional_t<std::is_const_v<T>, const char, char>;
+  return reinterpret_cast<T*>(reinterpret_cast<C*>(masks) + sb + lane_off);
+}
+
+// Decision bits, two plain VALU instructions per value in both directions, no SGPR / VCC (a v_cmp + v_cndmask pair costs
+// the compare, the select, an or, and on gfx950 two wait states between a VALU SGPR write and its VALU read).  The
+// arithmetic is left to the compiler (hazard rule above); where it would fold the sequence back into compare + select an
+// empty asm makes the intermediate opaque.
+//   forward, on a POST-ReLU value y (>= +0, never -0: relu1):  w <- (w << 1) | (y > 0)  =  alignbit(w, 0 - bits(y), 31),
+//             because 0 - b has its top bit set exactly for 0 < b <= 0x7fffffff.  Values are pushed in register order, tile
+//             2k then tile 2k+1, into word k; 32 pushes later the first value sits in bit 31, so the finished word is
+//             bit-reversed once (mask_word_finish) into the stored layout: bit (t&1)*16 + r of word t>>1 <-> tile t, register r.
+//   backward  m = sign-extended one-bit field of w at pos (0 or 0xffffffff);  dz = dh & m
+__device__ __forceinline__ unsigned mask_push_post(unsigned w, float y_post_relu) {
+  const unsigned nb = 0u - __builtin_bit_cast(unsigned, y_post_relu);
+  return __builtin_amdgcn_alignbit(w, nb, 31);
+}
+__device__ __forceinline__ unsigned mask_word_finish(unsigned w) { return __builtin_bitreverse32(w); }
+
+__device__ __forceinline__ float mask_apply(unsigned w, float dh, int pos) {
+  int m = __builtin_amdgcn_sbfe((int)w, (unsigned)pos, 1u);  // v_bfe_i32: 0 or 0xffffffff
+  asm("" : "+v"(m));
+  return __builtin_bit_cast(float, __builtin_bit_cast(int, dh) & m);
+}
+
 template <int NT>
 __device__ __forceinline__ u32x4 relu_mask_bits(const f32x16 (&x)[NT]) {
   u32x4 w = {0u, 0u, 0u, 0u};
+#ifndef AON_EXP_NOMASK
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) w[t >> 1] |= (x[t][r] > 0.f ? 1u : 0u) << ((t & 1) * 16 + r);
+    for (int r = 0; r < 16; ++r) w[t >> 1] |= (x[t][r] > 0.f ? 1u : 0u) << ((t & 1) * 16 + r);  // any x (pre- or post-ReLU)
   }
+#endif
   return w;
 }
 
@@ -267,12 +335,49 @@ __device__ __forceinline__ void apply_mask_bits(f32x16 (&x)[NT], const u32x4 w) 
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) x[t][r] = ((w[t >> 1] >> ((t & 1) * 16 + r)) & 1u) ? x[t][r] : 0.f;
+    for (int r = 0; r < 16; ++r) x[t][r] = mask_apply(w[t >> 1], x[t][r], (t & 1) * 16 + r);
   }
 }
 
+__device__ __forceinline__ void apply_mask_tile(f32x16& x, const u32x4 w, int t) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) x[r] = mask_apply(w[t >> 1], x[r], (t & 1) * 16 + r);
+}
+
+// Side jobs of the backward data chains (see chunk_mma).  The chunk that consumes gradient tile j of a layer
+//   * stores it -- it IS the pre-activation gradient dZ the weight-gradient kernels read -- to its plane rows, and
+//   * [MASKED] turns tile j+1 from dH into dZ = relu'(Z) . dH with the forward's decision bits,
+// one value per MFMA group; tile 0 is masked by the caller before the layer starts (16 values).
+template <int NT, bool MASKED>
+struct BwdSideOf {
+  f32x16 (&tiles)[NT];
+  float* plane;        // row 0 of tile 0 in the gradient planes
+  const PlaneIO& io;
+  int64_t tile_bytes;
+  const u32x4& mk;
+  __device__ __forceinline__ auto operator()(int j) const {
+    f32x16 (&t)[NT] = tiles;
+    float* tp = reinterpret_cast<float*>(reinterpret_cast<char*>(plane) + j * tile_bytes);
+    const PlaneIO& pio = io;
+    const u32x4& m = mk;
+    return [&t, tp, &pio, &m, j](int i) {
+      if (i < 16) {
+#ifndef AON_EXP_NOSTORE
+        *plane_addr(tp, pio, (i & 3) + 8 * (i >> 2)) = t[j][i];
+#endif
+        if constexpr (MASKED) {
+          if (j + 1 < NT) t[j + 1][i] = mask_apply(m[(j + 1) >> 1], t[j + 1][i], ((j + 1) & 1) * 16 + i);
+        }
+      }
+    };
+  }
+};
+
 template <int NT>
 __device__ __forceinline__ void store_plane(const f32x16 (&x)[NT], float* plane, const PlaneIO& io) {
+#ifdef AON_EXP_NOSTORE
+  return;
+#endif
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
 #pragma unroll
@@ -280,22 +385,40 @@ __device__ __forceinline__ void store_plane(const f32x16 (&x)[NT], float* plane,
   }
 }
 
-// encodings are held in a permuted register order (posenc_col / viewenc_col); planes use the reference's columns.
-// `col_off` = byte offset of the lane's sample inside a row (col*4), rows are addressed individually here.
-__device__ __forceinline__ void store_pos_enc_plane(const f32x16 (&E)[2], float* plane, const PlaneIO& io, int64_t col, int h) {
-  char* base = reinterpret_cast<char*>(plane) + col * 4;
+template <int NT>
+__device__ __forceinline__ void load_plane(f32x16 (&x)[NT], const float* plane, const PlaneIO& io) {
 #pragma unroll
-  for (int rho = 0; rho < 30; ++rho) *reinterpret_cast<float*>(base + (int64_t)(3 + rho + 30 * h) * io.row_bytes) = E[rho >> 4][rho & 15];
-  *reinterpret_cast<float*>(base + (int64_t)(h ? 2 : 0) * io.row_bytes) = E[1][14];
-  if (!h) *reinterpret_cast<float*>(base + io.row_bytes) = E[1][15];
+  for (int t = 0; t < NT; ++t) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) x[t][r] = *plane_addr(plane, io, 32 * t + (r & 3) + 8 * (r >> 2));
+  }
+}
+
+// encodings are held in a permuted register order (posenc_col / viewenc_col); planes use the reference's columns.
+// Addressing as everywhere: [uniform row base on the scalar unit] + [one 32-bit per-lane byte offset].  The half-wave
+// dependent part of the row index (sin rows for h = 0, sin(. + pi/2) rows for h = 1) goes into the lane offset; written as
+// a per-lane ROW index times the pitch, the compiler hoists one 64-bit product per row out of the pass loop (30 + 12 register
+// pairs, which it then spills).
+__device__ __forceinline__ unsigned enc_lane_off(const PlaneIO& io, int64_t col, int h, int rows_per_half) {
+  return (unsigned)(col * 4 + (h ? (int64_t)rows_per_half * io.row_bytes : 0));
+}
+
+__device__ __forceinline__ void store_pos_enc_plane(const f32x16 (&E)[2], float* plane, const PlaneIO& io, int64_t col, int h) {
+  char* base = reinterpret_cast<char*>(plane);
+  const unsigned off_sin = enc_lane_off(io, col, h, 30), off_id = enc_lane_off(io, col, h, 2);
+#pragma unroll
+  for (int rho = 0; rho < 30; ++rho) *reinterpret_cast<float*>(base + (int64_t)(3 + rho) * io.row_bytes + off_sin) = E[rho >> 4][rho & 15];
+  *reinterpret_cast<float*>(base + off_id) = E[1][14];                       // row 0 (h = 0) / row 2 (h = 1)
+  if (!h) *reinterpret_cast<float*>(base + io.row_bytes + off_id) = E[1][15];  // row 1
 }
 
 __device__ __forceinline__ void store_view_enc_plane(const f32x16& V, float* plane, const PlaneIO& io, int64_t col, int h) {
-  char* base = reinterpret_cast<char*>(plane) + col * 4;
+  char* base = reinterpret_cast<char*>(plane);
+  const unsigned off_sin = enc_lane_off(io, col, h, 12), off_id = enc_lane_off(io, col, h, 2);
 #pragma unroll
-  for (int rho = 0; rho < 12; ++rho) *reinterpret_cast<float*>(base + (int64_t)(3 + rho + 12 * h) * io.row_bytes) = V[rho];
-  *reinterpret_cast<float*>(base + (int64_t)(h ? 2 : 0) * io.row_bytes) = V[12];
-  if (!h) *reinterpret_cast<float*>(base + io.row_bytes) = V[13];
+  for (int rho = 0; rho < 12; ++rho) *reinterpret_cast<float*>(base + (int64_t)(3 + rho) * io.row_bytes + off_sin) = V[rho];
+  *reinterpret_cast<float*>(base + off_id) = V[12];
+  if (!h) *reinterpret_cast<float*>(base + io.row_bytes + off_id) = V[13];
 }
 
 // Positional / view encodings directly in accumulator (= next layer's B operand) layout: lanes 0-31 hold the sin

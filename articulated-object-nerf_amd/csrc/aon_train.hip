@@ -194,13 +194,6 @@ __device__ __forceinline__ void zero_tiles(f32x16 (&x)[NT]) {
     for (int r = 0; r < 16; ++r) x[t][r] = 0.f;
 }
 
-// dZ = relu'(Z) * dH from the forward's bit mask, written to the gradient plane
-template <int NT>
-__device__ __forceinline__ void mask_and_store(f32x16 (&x)[NT], const u32x4 bits, float* dplane, const PlaneIO& io) {
-  apply_mask_bits(x, bits);
-  store_plane(x, dplane, io);
-}
-
 __global__ void __launch_bounds__(256) mlp_bwd_chain_kernel(BwdArgs args) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* sm = reinterpret_cast<float*>(smem + kRingBytes);
@@ -218,19 +211,25 @@ __global__ void __launch_bounds__(256) mlp_bwd_chain_kernel(BwdArgs args) {
   for (int pass = blockIdx.x; pass < args.npass; pass += gridDim.x) {
     const int64_t col = (int64_t)pass * 128 + wave * 32 + m;
     const PlaneIO io = make_plane_io(args.Np, col, h);
-    // all nine layer masks of this lane up front (9 x 16 B): their latency hides under the first MFMA chain
-    u32x4 mk[kMaskLayers];
-#pragma unroll
-    for (int l = 0; l < kMaskLayers; ++l) mk[l] = args.masks[(int64_t)l * args.Np * 2 + (int64_t)pass * 256 + tid];
+    const int64_t tile_bytes = 32 * io.row_bytes;
+    // The 16-byte decision-bit word of a layer is fetched ONE layer ahead of its use (round 1 fetched all nine up front:
+    // 36 registers held through the whole pass).  The offset is made opaque at the point of use so the load stays there.
+    const unsigned moff = mask_lane_off(pass, tid);
+    auto load_mask = [&](int layer) { return *mask_ptr(args.masks, args.Np, layer, moff); };
     auto dp = [&](int row) { return reinterpret_cast<float*>(reinterpret_cast<char*>(args.dplanes) + (int64_t)row * io.row_bytes); };
     const float4 dr = reinterpret_cast<const float4*>(args.d_raw)[col];
+    // half-wave index as the LDS reads below see it: opaque per pass, otherwise every head-weight address (the small block
+    // sits beyond the 64 KiB immediate-offset range of the ring) is hoisted out of the pass loop into its own register
+    int hl = h;
+    asm volatile("" : "+v"(hl));
+    u32x4 mk = load_mask(8), mk_next;
     // rgb head (model.py:118):  dHV[f] = sum_c W_rgb[c][f] * d_rgb[c]
     f32x16 Z[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
 #pragma unroll
       for (int gq = 0; gq < 4; ++gq) {
-        const int fo = 32 * t + 8 * gq + 4 * h;
+        const int fo = 32 * t + 8 * gq + 4 * hl;
         const f32x4 w0 = *reinterpret_cast<const f32x4*>(sm + kSmWRgb + 0 * kCondWidth + fo);
         const f32x4 w1 = *reinterpret_cast<const f32x4*>(sm + kSmWRgb + 1 * kCondWidth + fo);
         const f32x4 w2 = *reinterpret_cast<const f32x4*>(sm + kSmWRgb + 2 * kCondWidth + fo);
@@ -239,34 +238,40 @@ __global__ void __launch_bounds__(256) mlp_bwd_chain_kernel(BwdArgs args) {
           Z[t][4 * gq + cc] = __builtin_fmaf(w2[cc], dr.z, __builtin_fmaf(w1[cc], dr.y, w0[cc] * dr.x));
       }
     }
-    mask_and_store(Z, mk[8], dp(kPlHV), io);  // view layer ReLU (model.py:114-116)
     f32x16 X[8], Y[8];
-    // d bottleneck = W_view[:, :256]^T . dZ_view   (bottleneck has no activation, model.py:109)
+    // d bottleneck = W_view[:, :256]^T . dZ_view, dZ_view = view-layer ReLU mask . dHV   (model.py:109-116)
+    mk_next = load_mask(7);
+    apply_mask_tile(Z[0], mk, 0);
     zero_tiles(X);
-    chunk_mma<BwdNet, kBwView + 0, 8, 16>(p, Z[0], X);
-    chunk_mma<BwdNet, kBwView + 1, 8, 16>(p, Z[1], X);
-    chunk_mma<BwdNet, kBwView + 2, 8, 16>(p, Z[2], X);
-    chunk_mma<BwdNet, kBwView + 3, 8, 16>(p, Z[3], X);
-    store_plane(X, dp(kPlBot), io);
-    // dH7 = W_bott^T . dBot + W_sigma^T * d_sigma   (density head reads the post-ReLU layer-7 output, model.py:105)
+    dense_layer<BwdNet, kBwView, 4, 8>(p, Z, X, BwdSideOf<4, true>{Z, dp(kPlHV), io, tile_bytes, mk});
+    // dH7 = W_bott^T . dBot + W_sigma^T * d_sigma   (the bottleneck has no activation; the density head reads the
+    // post-ReLU layer-7 output, model.py:105)
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
 #pragma unroll
       for (int gq = 0; gq < 4; ++gq) {
-        const f32x4 w = *reinterpret_cast<const f32x4*>(sm + kSmWSigma + 32 * t + 8 * gq + 4 * h);
+        const f32x4 w = *reinterpret_cast<const f32x4*>(sm + kSmWSigma + 32 * t + 8 * gq + 4 * hl);
 #pragma unroll
         for (int cc = 0; cc < 4; ++cc) Y[t][4 * gq + cc] = w[cc] * dr.w;
       }
     }
-    dense_layer<BwdNet, kBwBott, 8, 8>(p, X, Y);
-    mask_and_store(Y, mk[7], dp(plane_h(7)), io);
-    zero_tiles(X); dense_layer<BwdNet, kBwL7 + 0, 8, 8>(p, Y, X); mask_and_store(X, mk[6], dp(plane_h(6)), io);
-    zero_tiles(Y); dense_layer<BwdNet, kBwL7 + 8, 8, 8>(p, X, Y); mask_and_store(Y, mk[5], dp(plane_h(5)), io);
-    zero_tiles(X); dense_layer<BwdNet, kBwL7 + 16, 8, 8>(p, Y, X); mask_and_store(X, mk[4], dp(plane_h(4)), io);
-    zero_tiles(Y); dense_layer<BwdNet, kBwL7 + 24, 8, 8>(p, X, Y); mask_and_store(Y, mk[3], dp(plane_h(3)), io);
-    zero_tiles(X); dense_layer<BwdNet, kBwL7 + 32, 8, 8>(p, Y, X); mask_and_store(X, mk[2], dp(plane_h(2)), io);
-    zero_tiles(Y); dense_layer<BwdNet, kBwL7 + 40, 8, 8>(p, X, Y); mask_and_store(Y, mk[1], dp(plane_h(1)), io);
-    zero_tiles(X); dense_layer<BwdNet, kBwL7 + 48, 8, 8>(p, Y, X); mask_and_store(X, mk[0], dp(plane_h(0)), io);
+    dense_layer<BwdNet, kBwBott, 8, 8>(p, X, Y, BwdSideOf<8, false>{X, dp(kPlBot), io, tile_bytes, mk});
+    // trunk: dZ_l = mask_l . dH_l (stored by the chunks that consume it), dH_{l-1} = W_l^T . dZ_l
+#define AON_BWD_LAYER(IN, OUT, CB, L)                                                                                  \
+    mk = mk_next; if (L > 0) mk_next = load_mask(L - 1);                                                               \
+    apply_mask_tile(IN[0], mk, 0); zero_tiles(OUT);                                                                    \
+    dense_layer<BwdNet, CB, 8, 8>(p, IN, OUT, BwdSideOf<8, true>{IN, dp(plane_h(L)), io, tile_bytes, mk});
+    AON_BWD_LAYER(Y, X, kBwL7 + 0, 7)
+    AON_BWD_LAYER(X, Y, kBwL7 + 8, 6)
+    AON_BWD_LAYER(Y, X, kBwL7 + 16, 5)
+    AON_BWD_LAYER(X, Y, kBwL7 + 24, 4)
+    AON_BWD_LAYER(Y, X, kBwL7 + 32, 3)
+    AON_BWD_LAYER(X, Y, kBwL7 + 40, 2)
+    AON_BWD_LAYER(Y, X, kBwL7 + 48, 1)
+#undef AON_BWD_LAYER
+    // dZ0: no data gradient flows into the encoding, so no chunk consumes it -- masked and stored here (128 values)
+    apply_mask_bits(X, mk_next);
+    store_plane(X, dp(plane_h(0)), io);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }

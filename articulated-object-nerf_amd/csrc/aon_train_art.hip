@@ -89,12 +89,6 @@ __device__ __forceinline__ void zero_tiles_a(f32x16 (&x)[NT]) {
     for (int r = 0; r < 16; ++r) x[t][r] = 0.f;
 }
 
-template <int NT>
-__device__ __forceinline__ void mask_store_a(f32x16 (&x)[NT], const u32x4 bits, float* dplane, const PlaneIO& io) {
-  apply_mask_bits(x, bits);
-  store_plane(x, dplane, io);
-}
-
 __global__ void __launch_bounds__(256) art_bwd_chain_kernel(ArtBwdArgs args) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* sm = reinterpret_cast<float*>(smem + kRingBytes);
@@ -113,15 +107,16 @@ __global__ void __launch_bounds__(256) art_bwd_chain_kernel(ArtBwdArgs args) {
   for (int pass = blockIdx.x; pass < args.npass; pass += gridDim.x) {
     const int64_t col = (int64_t)pass * 128 + wave * 32 + m;
     const PlaneIO io = make_plane_io(args.Np, col, h);
+    const int64_t tile_bytes = 32 * io.row_bytes;
     auto dp = [&](int row) { return reinterpret_cast<float*>(reinterpret_cast<char*>(args.dplanes) + (int64_t)row * io.row_bytes); };
-    u32x4 mk[kAMaskLayers];
-#pragma unroll
-    for (int l = 0; l < kAMaskLayers; ++l) mk[l] = args.masks[(int64_t)l * args.Np * 2 + (int64_t)pass * 256 + tid];
+    // decision bits of a layer: fetched one layer ahead of their use, offset opaque so the load stays where it is written
+    // (round 1 fetched all sixteen words up front: 64 registers held through the pass)
+    const unsigned moff = mask_lane_off(pass, tid);
+    auto load_mask = [&](int slot) { return *mask_ptr(args.masks, args.Np, slot, moff); };
+    int hl = h;  // half-wave index for the LDS reads of head weights: opaque per pass (see mlp_bwd_chain_kernel)
+    asm volatile("" : "+v"(hl));
     const float4 dr = reinterpret_cast<const float4*>(args.d_raw)[col];
-    float xd[3];  // deformed position x' (forward stored it in rows 3..5 of the position block)
-#pragma unroll
-    for (int a = 0; a < 3; ++a)
-      xd[a] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(args.planes) + (int64_t)(kAPlPos + 3 + a) * io.row_bytes + col * 4);
+    u32x4 mk = load_mask(15), mk_next;
 
     // ---- view branch, backwards (model_autodecoder.py:231-236) ----
     f32x16 Z0[4], Z1[4];
@@ -129,7 +124,7 @@ __global__ void __launch_bounds__(256) art_bwd_chain_kernel(ArtBwdArgs args) {
     for (int t = 0; t < 4; ++t) {
 #pragma unroll
       for (int gq = 0; gq < 4; ++gq) {
-        const int fo = 32 * t + 8 * gq + 4 * h;
+        const int fo = 32 * t + 8 * gq + 4 * hl;
         const f32x4 w0 = *reinterpret_cast<const f32x4*>(sm + kA_WRGB + 0 * kCondWidth + fo);
         const f32x4 w1 = *reinterpret_cast<const f32x4*>(sm + kA_WRGB + 1 * kCondWidth + fo);
         const f32x4 w2 = *reinterpret_cast<const f32x4*>(sm + kA_WRGB + 2 * kCondWidth + fo);
@@ -138,41 +133,60 @@ __global__ void __launch_bounds__(256) art_bwd_chain_kernel(ArtBwdArgs args) {
           Z1[t][4 * gq + cc] = __builtin_fmaf(w2[cc], dr.z, __builtin_fmaf(w1[cc], dr.y, w0[cc] * dr.x));
       }
     }
-    mask_store_a(Z1, mk[15], dp(aplane_v(3)), io);
-    zero_tiles_a(Z0); dense_layer<N, kABwV3 + 0, 4, 4>(p, Z1, Z0); mask_store_a(Z0, mk[14], dp(aplane_v(2)), io);
-    zero_tiles_a(Z1); dense_layer<N, kABwV3 + 4, 4, 4>(p, Z0, Z1); mask_store_a(Z1, mk[13], dp(aplane_v(1)), io);
-    zero_tiles_a(Z0); dense_layer<N, kABwV3 + 8, 4, 4>(p, Z1, Z0); mask_store_a(Z0, mk[12], dp(aplane_v(0)), io);
+    // one layer of the chain: IN holds dH of the layer in mask slot SLOT -> dZ (masked, stored by the consuming chunks),
+    // OUT = W^T . dZ
+#define AON_ABWD_LAYER(NT_IN, NT_OUT, IN, OUT, CB, ROW, NEXT_SLOT)                                                   \
+    if (NEXT_SLOT >= 0) mk_next = load_mask(NEXT_SLOT);                                                               \
+    apply_mask_tile(IN[0], mk, 0); zero_tiles_a(OUT);                                                                \
+    dense_layer<N, CB, NT_IN, NT_OUT>(p, IN, OUT, BwdSideOf<NT_IN, true>{IN, dp(ROW), io, tile_bytes, mk});         \
+    mk = mk_next;
+    AON_ABWD_LAYER(4, 4, Z1, Z0, kABwV3 + 0, aplane_v(3), 14)
+    AON_ABWD_LAYER(4, 4, Z0, Z1, kABwV3 + 4, aplane_v(2), 13)
+    AON_ABWD_LAYER(4, 4, Z1, Z0, kABwV3 + 8, aplane_v(1), 12)
     f32x16 X[8], Y[8];
-    zero_tiles_a(X);
-    chunk_mma<N, kABwV0 + 0, 8, 16>(p, Z0[0], X);
-    chunk_mma<N, kABwV0 + 1, 8, 16>(p, Z0[1], X);
-    chunk_mma<N, kABwV0 + 2, 8, 16>(p, Z0[2], X);
-    chunk_mma<N, kABwV0 + 3, 8, 16>(p, Z0[3], X);
-    store_plane(X, dp(kAPlBot), io);  // bottleneck: no activation
+    AON_ABWD_LAYER(4, 8, Z0, X, kABwV0, aplane_v(0), 11)   // X = d bottleneck (no activation)
     // ---- trunk ----
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
 #pragma unroll
       for (int gq = 0; gq < 4; ++gq) {
-        const f32x4 w = *reinterpret_cast<const f32x4*>(sm + kA_WSIG + 32 * t + 8 * gq + 4 * h);
+        const f32x4 w = *reinterpret_cast<const f32x4*>(sm + kA_WSIG + 32 * t + 8 * gq + 4 * hl);
 #pragma unroll
         for (int cc = 0; cc < 4; ++cc) Y[t][4 * gq + cc] = w[cc] * dr.w;
       }
     }
-    dense_layer<N, kABwBott, 8, 8>(p, X, Y); mask_store_a(Y, mk[11], dp(aplane_h(7)), io);
-    zero_tiles_a(X); dense_layer<N, kABwL7 + 0, 8, 8>(p, Y, X); mask_store_a(X, mk[10], dp(aplane_h(6)), io);
-    zero_tiles_a(Y); dense_layer<N, kABwL7 + 8, 8, 8>(p, X, Y); mask_store_a(Y, mk[9], dp(aplane_h(5)), io);
+    dense_layer<N, kABwBott, 8, 8>(p, X, Y, BwdSideOf<8, false>{X, dp(kAPlBot), io, tile_bytes, mk});   // Y = dH7
+    AON_ABWD_LAYER(8, 8, Y, X, kABwL7 + 0, aplane_h(7), 10)
+    AON_ABWD_LAYER(8, 8, X, Y, kABwL7 + 8, aplane_h(6), 9)
+    // Y = dH5 -> dZ5, consumed twice: by the skip-connection chunks (d enc += W5[:, 256:319]^T dZ5), which mask and store it,
+    // then by layer 5's own transposed chunks
     f32x16 dE[2];
     zero_tiles_a(dE);
-    dense_layer<N, kABwL5E, 8, 2>(p, Y, dE);  // skip connection: d enc += W5[:, 256:319]^T dZ5
-    zero_tiles_a(X); dense_layer<N, kABwL5 + 0, 8, 8>(p, Y, X); mask_store_a(X, mk[8], dp(aplane_h(4)), io);
-    zero_tiles_a(Y); dense_layer<N, kABwL5 + 8, 8, 8>(p, X, Y); mask_store_a(Y, mk[7], dp(aplane_h(3)), io);
-    zero_tiles_a(X); dense_layer<N, kABwL5 + 16, 8, 8>(p, Y, X); mask_store_a(X, mk[6], dp(aplane_h(2)), io);
-    zero_tiles_a(Y); dense_layer<N, kABwL5 + 24, 8, 8>(p, X, Y); mask_store_a(Y, mk[5], dp(aplane_h(1)), io);
-    zero_tiles_a(X); dense_layer<N, kABwL5 + 32, 8, 8>(p, Y, X); mask_store_a(X, mk[4], dp(aplane_h(0)), io);
-    dense_layer<N, kABwL0E, 8, 2>(p, X, dE);  // d enc += W0[:, :63]^T dZ0
+    mk_next = load_mask(8);
+    apply_mask_tile(Y[0], mk, 0);
+    dense_layer<N, kABwL5E, 8, 2>(p, Y, dE, BwdSideOf<8, true>{Y, dp(aplane_h(5)), io, tile_bytes, mk});
+    mk = mk_next;
+    // The partial d enc (32 accumulator registers) would have to stay live across layers 5..1 on top of the two 128-register
+    // activation sets; it is parked in the (otherwise unused) pos-enc rows of the gradient planes instead -- 128 B per lane out
+    // and back per pass, against 13.8 KB of plane traffic -- rather than left to the register allocator's scratch spills.
+    store_plane(dE, dp(kAPlE), io);
+    zero_tiles_a(X); dense_layer<N, kABwL5 + 0, 8, 8>(p, Y, X);   // X = dH4
+    AON_ABWD_LAYER(8, 8, X, Y, kABwL5 + 8, aplane_h(4), 7)
+    AON_ABWD_LAYER(8, 8, Y, X, kABwL5 + 16, aplane_h(3), 6)
+    AON_ABWD_LAYER(8, 8, X, Y, kABwL5 + 24, aplane_h(2), 5)
+    AON_ABWD_LAYER(8, 8, Y, X, kABwL5 + 32, aplane_h(1), 4)
+    // X = dH0 -> dZ0, consumed by the encoding chunks: d enc += W0[:, :63]^T dZ0
+    mk_next = load_mask(3);
+    apply_mask_tile(X[0], mk, 0);
+    load_plane(dE, dp(kAPlE), io);
+    dense_layer<N, kABwL0E, 8, 2>(p, X, dE, BwdSideOf<8, true>{X, dp(aplane_h(0)), io, tile_bytes, mk});
+    mk = mk_next;
 
     // ---- positional encoding, backwards (helper.py:136-140 on the deformed point) ----
+    float xd[3];  // deformed position x' (forward stored it in rows 3..5 of the position block)
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+      xd[a] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(args.planes) + (int64_t)(kAPlPos + 3 + a) * io.row_bytes + col * 4);
     const float phase = h ? AON_HALF_PI_F32 : 0.f;
     float dx[3] = {0.f, 0.f, 0.f};
 #pragma unroll
@@ -197,7 +211,7 @@ __global__ void __launch_bounds__(256) art_bwd_chain_kernel(ArtBwdArgs args) {
     for (int t = 0; t < 4; ++t) {
 #pragma unroll
       for (int gq = 0; gq < 4; ++gq) {
-        const int fo = 32 * t + 8 * gq + 4 * h;
+        const int fo = 32 * t + 8 * gq + 4 * hl;
         const f32x4 w0 = *reinterpret_cast<const f32x4*>(sm + kA_WDL + 0 * 128 + fo);
         const f32x4 w1 = *reinterpret_cast<const f32x4*>(sm + kA_WDL + 1 * 128 + fo);
         const f32x4 w2 = *reinterpret_cast<const f32x4*>(sm + kA_WDL + 2 * 128 + fo);
@@ -206,10 +220,13 @@ __global__ void __launch_bounds__(256) art_bwd_chain_kernel(ArtBwdArgs args) {
           H1[t][4 * gq + cc] = __builtin_fmaf(w2[cc], dx[2], __builtin_fmaf(w1[cc], dx[1], w0[cc] * dx[0]));
       }
     }
-    mask_store_a(H1, mk[3], dp(aplane_d(3)), io);
-    zero_tiles_a(H0); dense_layer<N, kABwD3 + 0, 4, 4>(p, H1, H0); mask_store_a(H0, mk[2], dp(aplane_d(2)), io);
-    zero_tiles_a(H1); dense_layer<N, kABwD3 + 4, 4, 4>(p, H0, H1); mask_store_a(H1, mk[1], dp(aplane_d(1)), io);
-    zero_tiles_a(H0); dense_layer<N, kABwD3 + 8, 4, 4>(p, H1, H0); mask_store_a(H0, mk[0], dp(aplane_d(0)), io);
+    AON_ABWD_LAYER(4, 4, H1, H0, kABwD3 + 0, aplane_d(3), 2)
+    AON_ABWD_LAYER(4, 4, H0, H1, kABwD3 + 4, aplane_d(2), 1)
+    AON_ABWD_LAYER(4, 4, H1, H0, kABwD3 + 8, aplane_d(1), 0)
+#undef AON_ABWD_LAYER
+    // dZ of deformation layer 0: its input is (pos, latents) -- no data gradient continues, no consuming chunk: 64 values here
+    apply_mask_bits(H0, mk);
+    store_plane(H0, dp(aplane_d(0)), io);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }

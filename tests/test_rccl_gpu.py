@@ -104,12 +104,12 @@ def test_data_mutation_is_seen_by_the_kernels(rccl, nerf_sd):
     with torch.no_grad():
         a = model(rays, False, True, 2.0, 6.0)[1][0].clone()
         w = model.fine_mlp.rgb_layer.bias
-        v0 = w._version
+        v0, saved = w._version, w.detach().clone()
         w.data.add_(0.5)
         dist.broadcast(model.coarse_mlp.rgb_layer.bias.data, src=0)
         assert w._version == v0                          # the hazard: no version bump
         b = model(rays, False, True, 2.0, 6.0)[1][0]
         assert (b - a).abs().max().item() > 1e-3          # the fine-level colours moved
-        w.data.sub_(0.5)
+        w.data.copy_(saved)
         c = model(rays, False, True, 2.0, 6.0)[1][0]
     assert torch.equal(c, a)

@@ -1,0 +1,115 @@
+"""Per-kernel timing of the training / render kernels with HIP events on the launch stream (no profiler needed):
+
+    python tools/kernel_bench.py [--rays 4096] [--reps 5] [--only fwd_train,art_fwd_train,...]
+    AON_HIP_LIB=articulated-object-nerf_amd/libaon_hip_x.so python tools/kernel_bench.py     # an experiment build
+
+One JSON line per kernel: ms per launch, executed and reference-literal TFLOP/s.  Sizes default to one level pair of a
+4096-ray training step (65 and 193 samples per ray)."""
+import argparse
+import json
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+VAN_MAC = 593_408                 # reference-literal MACs / sample, vanilla
+ART_MAC = 794_880                 # articulated, latent columns included
+ART_MAC_EXEC = 794_880 - 102_400  # latent columns folded into biases: 128*(128+32) + 2*256*128 + 128*128
+
+
+def timeit(fn, reps):
+    fn()
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for a, b in ev:
+        a.record()
+        fn()
+        b.record()
+    torch.cuda.synchronize()
+    t = sorted(a.elapsed_time(b) for a, b in ev)
+    return t[len(t) // 2]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rays", type=int, default=4096)
+    ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--only", default="")
+    ap.add_argument("--tag", default=os.environ.get("AON_HIP_LIB", "product"))
+    args = ap.parse_args()
+    only = set(filter(None, args.only.split(",")))
+    import aon_amd.synthetic as syn
+    from aon_amd import ops
+
+    dev = torch.device("cuda:0")
+    n = args.rays
+    H, W = 480, 640
+    ro, vd = ops.raygen(syn.look_at_pose(), H, W, syn.focal_from_fovy(H), device=dev)
+    g = torch.Generator(device=dev).manual_seed(0)
+    idx = torch.randint(0, H * W, (n,), device=dev, generator=g)
+    o, d = ro[idx].contiguous(), vd[idx].contiguous()
+    sd = {k: v.to(dev) for k, v in syn.make_nerf_state_dict(seed=0, density_scale=30.0).items()}
+    van = {k[len("fine_mlp."):]: v for k, v in sd.items() if k.startswith("fine_mlp.")}
+    asd = {k: v.to(dev) for k, v in syn.make_art_state_dict(seed=0, density_scale=30.0).items()}
+    art = {k[len("fine_mlp."):]: v for k, v in asd.items() if k.startswith("fine_mlp.")}
+    lat = {"density": torch.randn(1, 128, device=dev) * 0.1, "color": torch.randn(1, 128, device=dev) * 0.1,
+           "articulation": torch.randn(1, 32, device=dev) * 0.1}
+    pv, pvb = ops.pack_vanilla_mlp(van), ops.pack_vanilla_mlp_bwd(van)
+    pa, pab, small = ops.pack_art_mlp(art), ops.pack_art_mlp_bwd(art), ops.art_prepare(art, lat)
+
+    def emit(name, S, ms, mac_exec, mac_lit, extra=None):
+        smp = n * S
+        rec = {"tag": args.tag, "kernel": name, "rays": n, "S": S, "ms": round(ms, 4),
+               "tflops_executed": round(smp * mac_exec * 2 / (ms * 1e-3) / 1e12, 2),
+               "tflops_literal": round(smp * mac_lit * 2 / (ms * 1e-3) / 1e12, 2)}
+        rec["frac_executed"] = round(rec["tflops_executed"] / 157.3, 4)
+        if extra:
+            rec.update(extra)
+        print(json.dumps(rec), flush=True)
+
+    def want(k):
+        return not only or k in only
+
+    for S in (65, 193):
+        t, _ = ops.sample_along_rays(o, d, S - 1, 2.0, 6.0, want_coords=False)
+        t = t.contiguous()
+        if want("fwd"):
+            emit("mlp_fwd", S, timeit(lambda: ops.mlp_fwd(pv, o, d, d, t), args.reps), VAN_MAC, VAN_MAC)
+        if want("art_fwd"):
+            emit("art_mlp_fwd", S, timeit(lambda: ops.art_mlp_fwd(pa, small, o, d, d, t), args.reps), ART_MAC_EXEC, ART_MAC)
+        if want("fwd_train") or want("bwd_chain") or want("wgrad"):
+            raw, planes, masks = ops.mlp_fwd_train(pv, o, d, d, t)
+            if want("fwd_train"):
+                emit("mlp_fwd_train", S, timeit(lambda: ops.mlp_fwd_train(pv, o, d, d, t), args.reps), VAN_MAC, VAN_MAC,
+                     {"plane_GB": round(planes.numel() * 4 / 1e9, 3)})
+            d_raw = torch.randn(planes.shape[1], 4, device=dev) * 1e-3
+            if want("bwd_chain"):
+                bw_mac = VAN_MAC - 256 * 63 * 2 - 128 * 27 - 256 - 3 * 128   # no data gradient into the encodings / heads on the VALU
+                emit("mlp_bwd_chain", S, timeit(lambda: ops.mlp_bwd_chain(pvb, pv, d_raw, masks, planes.shape), args.reps), bw_mac, VAN_MAC)
+            if want("wgrad"):
+                dpl = ops.mlp_bwd_chain(pvb, pv, d_raw, masks, planes.shape)
+                emit("vanilla_wgrad(all layers)", S, timeit(lambda: ops.vanilla_wgrad(planes, dpl, d_raw), args.reps), VAN_MAC, VAN_MAC)
+                del dpl
+            del raw, planes, masks
+        if want("art_fwd_train") or want("art_bwd_chain") or want("art_wgrad"):
+            raw, planes, masks = ops.art_mlp_fwd_train(pa, small, o, d, d, t)
+            if want("art_fwd_train"):
+                emit("art_mlp_fwd_train", S, timeit(lambda: ops.art_mlp_fwd_train(pa, small, o, d, d, t), args.reps), ART_MAC_EXEC, ART_MAC,
+                     {"plane_GB": round(planes.numel() * 4 / 1e9, 3)})
+            d_raw = torch.randn(planes.shape[1], 4, device=dev) * 1e-3
+            if want("art_bwd_chain"):
+                bw_mac = ART_MAC_EXEC - 128 * 3 - 128 * 27 - 256 - 3 * 128 + 0
+                emit("art_bwd_chain", S, timeit(lambda: ops.art_bwd_chain(pab, small, d_raw, masks, planes), args.reps), bw_mac, ART_MAC)
+            if want("art_wgrad"):
+                dpl, dxp = ops.art_bwd_chain(pab, small, d_raw, masks, planes)
+                emit("art_wgrad(all layers)", S, timeit(lambda: ops.art_wgrad(planes, dpl, d_raw, dxp, art, lat), args.reps), ART_MAC_EXEC, ART_MAC)
+                del dpl, dxp
+            del raw, planes, masks
+        torch.cuda.empty_cache()
+
+
+if __name__ == "__main__":
+    main()
