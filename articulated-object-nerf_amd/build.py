@@ -30,7 +30,7 @@ PER_FILE_FLAGS = {"aon_train.hip": ["-DAON_PIN_PREFETCH"]}
 if "AON_PER_FILE_FLAGS" in os.environ:   # experiments: JSON {"file.hip": ["flag", ...]} replaces the table
     import json as _json
     PER_FILE_FLAGS = _json.loads(os.environ["AON_PER_FILE_FLAGS"])
-FLAGS = (os.environ.get("AON_EXTRA_FLAGS", "").split()) + ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wall", "-Wno-unused-function"]
+FLAGS = (os.environ.get("AON_EXTRA_FLAGS", "").split()) + ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-lambda-capture"]
 
 
 def hipcc() -> str:

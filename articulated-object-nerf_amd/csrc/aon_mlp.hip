@@ -166,12 +166,8 @@ __global__ void __launch_bounds__(256) mlp_fwd_kernel(MlpArgs args) {
         return [&, in_row, with_mask, j](int i) {
           if constexpr (TRAIN) {
             if (i < 16) {
-#ifndef AON_EXP_NOSTORE
               *plane_addr(reinterpret_cast<float*>(reinterpret_cast<char*>(rows(in_row)) + j * tile_bytes), io, (i & 3) + 8 * (i >> 2)) = in[j][i];
-#endif
-#ifndef AON_EXP_NOMASK
               if (with_mask) mw[j >> 1] = mask_push_post(mw[j >> 1], in[j][i]);
-#endif
             }
           }
         };

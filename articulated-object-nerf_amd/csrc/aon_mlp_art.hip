@@ -177,12 +177,8 @@ __global__ void __launch_bounds__(256) art_mlp_fwd_kernel(ArtMlpArgs args) {
       return [&, row, with_mask](int i) {
         if constexpr (TRAIN) {
           if (i < 16) {
-#ifndef AON_EXP_NOSTORE
             *plane_addr(rows(row), io, (i & 3) + 8 * (i >> 2)) = tile[i];
-#endif
-#ifndef AON_EXP_NOMASK
             if (with_mask) word = mask_push_post(word, tile[i]);
-#endif
           }
         }
       };

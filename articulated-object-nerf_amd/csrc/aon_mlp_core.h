@@ -123,8 +123,14 @@ __device__ __forceinline__ float* plane_addr(float* plane, const PlaneIO& io, in
 // to its activation / gradient plane, collecting or applying ReLU decision bits -- one value per step, so that this VALU
 // and store work drains in the shadow of the matrix pipe instead of in a burst at a layer boundary, where no MFMA is in
 // flight (and in front of the next chunk barrier, whose s_waitcnt vmcnt(0) also waits for every outstanding store).
-// Measured round 2 (tools/kernel_bench.py, 4096 x 193 samples): producer-side bursts cost the articulated training forward
-// 25 % (stores) + 8 % (masks), its backward chain 18 %; the vanilla forward 5.5 % + 4.7 %.
+// Measured round 2 (tools/kernel_bench.py, 4096 x 193 samples, experiment builds with the stores / the mask arithmetic compiled
+// out): producer-side bursts cost the articulated training forward 25 % (stores) + 8 % (masks), its backward chain 18 %, the
+// vanilla forward 5.5 % + 4.7 %; as side jobs the articulated forward went 10.67 -> 9.29 ms, its chain 10.18 -> 9.50 ms.
+// What is left of the store cost (articulated forward 9.29 ms, 8.33 without stores) did NOT respond to: storing only in the
+// first chunk of each barrier pair so the pair's vmcnt(0) never waits on a fresh store (9.25); pinning the side job outside
+// the four-MFMA accumulator chain with sched_barrier (9.37-9.40); 16-byte stores into a [pass][feature/4][sample][4] layout,
+// 512 contiguous bytes per half-wave (9.02; with `nt` 10.2, with write-through `sc1` 11.9); it halves when every pass writes
+// the same cache-resident 1024 columns (8.83), i.e. about half of it is the L2 -> HBM write path itself.
 struct NoSide {
   __device__ __forceinline__ void operator()(int) const {}
 };
@@ -320,13 +326,11 @@ __device__ __forceinline__ float mask_apply(unsigned w, float dh, int pos) {
 template <int NT>
 __device__ __forceinline__ u32x4 relu_mask_bits(const f32x16 (&x)[NT]) {
   u32x4 w = {0u, 0u, 0u, 0u};
-#ifndef AON_EXP_NOMASK
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) w[t >> 1] |= (x[t][r] > 0.f ? 1u : 0u) << ((t & 1) * 16 + r);  // any x (pre- or post-ReLU)
   }
-#endif
   return w;
 }
 
@@ -362,9 +366,7 @@ struct BwdSideOf {
     const u32x4& m = mk;
     return [&t, tp, &pio, &m, j](int i) {
       if (i < 16) {
-#ifndef AON_EXP_NOSTORE
         *plane_addr(tp, pio, (i & 3) + 8 * (i >> 2)) = t[j][i];
-#endif
         if constexpr (MASKED) {
           if (j + 1 < NT) t[j + 1][i] = mask_apply(m[(j + 1) >> 1], t[j + 1][i], ((j + 1) & 1) * 16 + i);
         }
@@ -375,9 +377,6 @@ struct BwdSideOf {
 
 template <int NT>
 __device__ __forceinline__ void store_plane(const f32x16 (&x)[NT], float* plane, const PlaneIO& io) {
-#ifdef AON_EXP_NOSTORE
-  return;
-#endif
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
 #pragma unroll

@@ -240,19 +240,40 @@ __global__ void outer_kernel(const float* __restrict__ db, const float* __restri
   out[(int64_t)f * ld + col_off + k] = db[f] * latent[k];
 }
 
-// d latent[k] = sum_f W[f][col_off + k] * db[f]   (accumulated over up to three (W, db) pairs)
-struct LatentGradArgs {
+// d latent[k] = sum over (W, db) pairs, sum_f W[f][col_off + k] * db[f].  ONE launch for the three latents (block = latent);
+// 1024 threads = 8 row groups x 128 columns: group g takes rows f = g, g+8, ... (independent loads, coalesced over k), the
+// eight group sums are added in group order through LDS (deterministic).  Round 1 ran three launches of one 128-thread block
+// each with a serial f loop: 107 us per launch, 0.64 ms per training step.
+struct LatentJob {
   const float* W[3]; const float* db[3]; int ld[3]; int col_off[3]; int M[3];
   int npairs; int L;
   float* out;
 };
-__global__ void latent_grad_kernel(LatentGradArgs a) {
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= a.L) return;
+struct LatentGradArgs {
+  LatentJob job[3];
+};
+__global__ void __launch_bounds__(1024) latent_grad_kernel(LatentGradArgs a) {
+  __shared__ float red[8][128];
+  const LatentJob& j = a.job[blockIdx.x];
+  const int k = threadIdx.x & 127, g = threadIdx.x >> 7;
   float s = 0.f;
-  for (int pi = 0; pi < a.npairs; ++pi)
-    for (int f = 0; f < a.M[pi]; ++f) s = __builtin_fmaf(a.W[pi][(int64_t)f * a.ld[pi] + a.col_off[pi] + k], a.db[pi][f], s);
-  a.out[k] = s;
+  if (k < j.L) {
+    for (int pi = 0; pi < j.npairs; ++pi) {
+      const float* W = j.W[pi] + j.col_off[pi] + k;
+      const float* db = j.db[pi];
+      const int ld = j.ld[pi];
+#pragma unroll 4
+      for (int f = g; f < j.M[pi]; f += 8) s = __builtin_fmaf(W[(int64_t)f * ld], db[f], s);
+    }
+  }
+  red[g][k] = s;
+  __syncthreads();
+  if (g == 0 && k < j.L) {
+    float t = red[0][k];
+#pragma unroll
+    for (int q = 1; q < 8; ++q) t += red[q][k];
+    j.out[k] = t;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -340,20 +361,19 @@ hipError_t launch_art_wgrad(const float* planes, const float* dplanes, const flo
   outer_kernel<<<dim3((256 * 128 + 255) / 256), dim3(256), 0, stream>>>(grads[21], shape, 256, 128, grads[20], 447, 319);
   outer_kernel<<<dim3((128 * 128 + 255) / 256), dim3(256), 0, stream>>>(grads[27], app, 128, 128, grads[26], 411, 283);
   // latent gradients: d latent = W[:, latent cols]^T db
-  LatentGradArgs ls{};
+  LatentGradArgs lg{};
+  LatentJob& ls = lg.job[0];   // shape: deformation layer 0, trunk layers 0 and 5
   ls.W[0] = params[0]; ls.db[0] = grads[1]; ls.ld[0] = 163; ls.col_off[0] = 3; ls.M[0] = 128;
   ls.W[1] = params[10]; ls.db[1] = grads[11]; ls.ld[1] = 191; ls.col_off[1] = 63; ls.M[1] = 256;
   ls.W[2] = params[20]; ls.db[2] = grads[21]; ls.ld[2] = 447; ls.col_off[2] = 319; ls.M[2] = 256;
   ls.npairs = 3; ls.L = 128; ls.out = g_shape;
-  latent_grad_kernel<<<dim3(1), dim3(128), 0, stream>>>(ls);
-  LatentGradArgs la{};
+  LatentJob& la = lg.job[1];   // appearance: view layer 0
   la.W[0] = params[26]; la.db[0] = grads[27]; la.ld[0] = 411; la.col_off[0] = 283; la.M[0] = 128;
   la.npairs = 1; la.L = 128; la.out = g_app;
-  latent_grad_kernel<<<dim3(1), dim3(128), 0, stream>>>(la);
-  LatentGradArgs lt{};
+  LatentJob& lt = lg.job[2];   // articulation: deformation layer 0
   lt.W[0] = params[0]; lt.db[0] = grads[1]; lt.ld[0] = 163; lt.col_off[0] = 131; lt.M[0] = 128;
   lt.npairs = 1; lt.L = 32; lt.out = g_art;
-  latent_grad_kernel<<<dim3(1), dim3(128), 0, stream>>>(lt);
+  latent_grad_kernel<<<dim3(3), dim3(1024), 0, stream>>>(lg);
 #undef AON_TRY
   return hipGetLastError();
 }
