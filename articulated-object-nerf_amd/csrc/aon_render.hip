@@ -34,6 +34,14 @@ __device__ __forceinline__ float wave_inclusive_scan(float v, int /*lane*/) {
   return v;
 }
 
+// wave_shr:1 of a double (two 32-bit DPP moves), zero into lane 0
+__device__ __forceinline__ double dpp_shr1_f64(double v) {
+  const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)b, 0x138, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), 0x138, 0xf, 0xf, false);
+  return __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+}
+
 // sum over the 64 lanes, returned in every lane
 __device__ __forceinline__ float wave_sum(float v) {
   v = wave_inclusive_scan<false>(v, 0);
@@ -412,6 +420,31 @@ __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
+// weights.sum(-1) over the 63 pdf weights in EXACTLY the association torch's CPU sum kernel uses for a contiguous fp32 row
+// (helper.py:205; ATen cpu/SumKernel.cpp `vectorized_inner_sum` -> `row_sum`, 8-float vectors, ILP factor 4), measured on
+// torch 2.10 with three-element probes (1, 2^-24, 2^-24) over all position triples and confirmed bit-for-bit on 20,000 rows:
+//   P[l] = (((((x[l] + x[32+l]) + x[40+l]) + x[48+l]) + x[8+l]) + x[16+l]) + x[24+l]          l = 0..7   (vector lanes)
+//   s    = (((((x56 + x57) + x58) + x59) + x60) + x61) + x62                                               (scalar remainder)
+//   s    = (((((((s + P0) + P1) + P2) + P3) + P4) + P5) + P6) + P7
+// A tree reduction differs from this in the last bit on ~30 % of rows, the cdf inherits that bit, and every draw that falls
+// next to the affected knot moves: the whole reason round 1's inverse CDF was "99 % within 2e-6" instead of exact.
+__device__ __forceinline__ float torch_sum63(float x, int lane) {
+  float P = x;                                                   // lanes 0..7: vector accumulator lane l
+  P = __fadd_rn(P, __shfl(x, lane + 32));
+  P = __fadd_rn(P, __shfl(x, lane + 40));
+  P = __fadd_rn(P, __shfl(x, lane + 48));
+  P = __fadd_rn(P, __shfl(x, lane + 8));
+  P = __fadd_rn(P, __shfl(x, lane + 16));
+  P = __fadd_rn(P, __shfl(x, lane + 24));
+  // y[0..14] = x56..x62, P0..P7 in lanes 0..14; the running sum in index order by the shifted-add chain used for the cdf
+  const float y_tail = __shfl(x, lane + 56), y_part = __shfl(P, lane - 7);   // both shuffles by ALL lanes (a shuffle inside
+  const float y = lane < 7 ? y_tail : y_part;                                 // a divergent branch cannot read disabled lanes)
+  float run = y;
+#pragma unroll
+  for (int k = 0; k < 14; ++k) run = __fadd_rn(dpp_f32<0x138, 0xf>(0.f, run), y);   // wave_shr:1, zero into lane 0
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, run), 14));
+}
+
 __global__ void __launch_bounds__(256) sample_pdf_kernel(PdfArgs a) {
   __shared__ float lds[4][256];  // per wave: cdf[64] | bins[64], later reused as the 193-entry merge stage
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -434,21 +467,24 @@ __global__ void __launch_bounds__(256) sample_pdf_kernel(PdfArgs a) {
 
   // pdf / cdf  (helper.py:206-222)
   float w = lane < 63 ? a.weights[ray * a.w_stride + lane] : 0.f;
-  float wsum = wave_sum(w);
+  float wsum = torch_sum63(w, lane);
   const float padding = __builtin_fmaxf(0.f, __fsub_rn(1e-5f, wsum));
   w = __fadd_rn(w, __fdiv_rn(padding, 63.0f));
   wsum = __fadd_rn(wsum, padding);
   const float pdf = __fdiv_rn(w, wsum);
-  // cdf64 = [0, min(1, cumsum(pdf[:-1])) (62 entries), 1].  The running sum is taken in INDEX ORDER, exactly like
-  // torch.cumsum (a tree scan would break the exact flatness of zero-weight zones and the monotonicity the binary search
-  // below relies on), but for all lanes at once: iterating  c <- wave_shr1(c) + pdf  (zero shifted into lane 0) gives
-  // lane i, after k >= i steps,  (((p0 + p1) + p2) + ...) + p_i  -- the oldest term is innermost, and the leading
-  // "0 + p0" of lanes that are already complete is exact.  61 dependent one-instruction DPP adds instead of 62 x
-  // (readlane, add, select).
-  float run = pdf;
+  // cdf64 = [0, min(1, cumsum(pdf[:-1])) (62 entries), 1].  torch.cumsum on the CPU keeps its running sum in DOUBLE for a
+  // float tensor (at::acc_type<float, false>) and rounds every prefix to float on store -- verified on torch 2.10: a float
+  // running sum reproduces only 44 % of the prefixes bit for bit, a double one all of them.  The sum is taken in INDEX ORDER (a
+  // tree scan would also break the exact flatness of zero-weight zones and the monotonicity the binary search below relies on)
+  // for all lanes at once: iterating  c <- wave_shr1(c) + pdf  (zero shifted into lane 0) gives lane i, after k >= i steps,
+  // (((p0 + p1) + p2) + ...) + p_i  -- the oldest term is innermost, and the leading "0 + p0" of lanes that are already
+  // complete is exact.
+  const double pd = (double)pdf;
+  double run = pd;
 #pragma unroll
-  for (int j = 0; j < 61; ++j) run = __fadd_rn(dpp_f32<0x138, 0xf>(0.f, run), pdf);
-  const float mine = __builtin_fminf(1.f, dpp_f32<0x138, 0xf>(0.f, run));  // lane j+1 <- prefix[j]; lane 0 <- 0
+  for (int j = 0; j < 61; ++j) run = dpp_shr1_f64(run) + pd;
+  const float prefix = (float)dpp_shr1_f64(run);                 // lane j+1 <- prefix[j] rounded to float; lane 0 <- 0
+  const float mine = __builtin_fminf(1.f, prefix);
   cdf[lane] = lane == 63 ? 1.f : mine;  // lane 0 keeps 0
   wave_lds_sync();
 
