@@ -104,33 +104,48 @@ int check(hipError_t e, const char* where) {
 
 constexpr int kSc = 65, kSf = 193;
 
-// Optional live timing of the dominant kernel (the fused MLP) with HIP events on the launch stream.
+// Optional live timing of the path's kernels with HIP events on the LAUNCH stream (torch.cuda.Event would only see torch's
+// current stream), by kernel class; bench.py turns the totals into roofline figures.  Off unless aon_profile_begin() was
+// called: one mutex-guarded branch per launch otherwise.
+enum KClass { kMlpFwd = AON_PROF_MLP_FWD, kBwdChain = AON_PROF_BWD_CHAIN, kWgrad = AON_PROF_WGRAD, kComposite = AON_PROF_COMPOSITE,
+              kSamplePdf = AON_PROF_SAMPLE_PDF, kCompositeBwd = AON_PROF_COMPOSITE_BWD, kNumClasses = AON_PROF_NUM_CLASSES };
+
 struct Profiler {
   std::mutex mu;
   bool on = false;
-  std::vector<hipEvent_t> pool;  // pairs (start, stop)
+  struct Rec { int cls; hipEvent_t start, stop; };
+  std::vector<hipEvent_t> pool;
   size_t used = 0;
-  int64_t samples = 0;
+  std::vector<Rec> recs;
+  int64_t units[kNumClasses] = {};
+  // totals of the last completed aon_profile_end()
+  double last_ms[kNumClasses] = {};
+  int64_t last_launches[kNumClasses] = {};
+  int64_t last_units[kNumClasses] = {};
 } g_prof;
 
-struct MlpTimer {
+struct KTimer {
   hipEvent_t stop = nullptr;
   hipStream_t stream;
-  MlpTimer(hipStream_t s, int64_t samples) : stream(s) {
+  KTimer(int cls, hipStream_t s, int64_t units) : stream(s) {
     std::lock_guard<std::mutex> lk(g_prof.mu);
     if (!g_prof.on) return;
-    if (g_prof.used + 2 > g_prof.pool.size()) {
-      hipEvent_t a, b;
-      if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
-      g_prof.pool.push_back(a); g_prof.pool.push_back(b);
+    while (g_prof.used + 2 > g_prof.pool.size()) {
+      hipEvent_t e;
+      if (hipEventCreate(&e) != hipSuccess) return;
+      g_prof.pool.push_back(e);
     }
     hipEvent_t start = g_prof.pool[g_prof.used];
     stop = g_prof.pool[g_prof.used + 1];
     g_prof.used += 2;
-    g_prof.samples += samples;
+    g_prof.recs.push_back({cls, start, stop});
+    g_prof.units[cls] += units;
     (void)hipEventRecord(start, stream);
   }
-  ~MlpTimer() { if (stop) (void)hipEventRecord(stop, stream); }
+  ~KTimer() { if (stop) (void)hipEventRecord(stop, stream); }
+};
+struct MlpTimer : KTimer {
+  MlpTimer(hipStream_t s, int64_t samples) : KTimer(kMlpFwd, s, samples) {}
 };
 
 int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
@@ -254,6 +269,7 @@ int aon_composite(const float* rgb, int rgb_stride, const float* sigma, int sigm
     return fail(AON_E_INVALID, "aon_composite: bad size / stride / act");
   if (n_rays == 0) return AON_OK;
   if (!rgb || !sigma || !t_vals || !dirs || !comp_rgb || !acc || !depth) return fail(AON_E_INVALID, "aon_composite: null pointer");
+  KTimer timer(kComposite, (hipStream_t)stream, n_rays);
   return check(aon::launch_composite(rgb, rgb_stride, sigma, sigma_stride, t_vals, dirs, n_rays, S, white_bkgd, act, comp_rgb,
                                      acc, depth, weights, (hipStream_t)stream), "aon_composite");
 }
@@ -264,6 +280,7 @@ int aon_sample_pdf(const float* bins, const float* weights, int64_t w_stride, co
   if (n_rays == 0) return AON_OK;
   if (!weights || !u || (!bins && !t_coarse) || (t_fine && !t_coarse) || (!samples && !t_fine))
     return fail(AON_E_INVALID, "aon_sample_pdf: null pointer");
+  KTimer timer(kSamplePdf, (hipStream_t)stream, n_rays);
   return check(aon::launch_sample_pdf(bins, weights, w_stride, t_coarse, u, u_stride, n_rays, samples, t_fine,
                                       (hipStream_t)stream), "aon_sample_pdf");
 }
@@ -300,6 +317,7 @@ int aon_composite_bwd(const float* raw, const float* t_vals, const float* dirs, 
   if (n_rays < 0 || S < 1 || S > 256 || act < 0 || act > 2) return fail(AON_E_INVALID, "aon_composite_bwd: bad size / act (S <= 256)");
   if (n_rays == 0) return AON_OK;
   if (!raw || !t_vals || !dirs || !g_rgb || !d_raw) return fail(AON_E_INVALID, "aon_composite_bwd: null pointer");
+  KTimer timer(kCompositeBwd, (hipStream_t)stream, n_rays);
   return check(aon::launch_composite_bwd(raw, t_vals, dirs, g_rgb, g_acc, g_depth, n_rays, S, white_bkgd, act, d_raw,
                                          (hipStream_t)stream), "aon_composite_bwd");
 }
@@ -309,6 +327,7 @@ int aon_mlp_bwd_chain(const void* packed_bwd, const void* packed_fwd, const floa
   if (Np < 0 || (Np & 127)) return fail(AON_E_INVALID, "aon_mlp_bwd_chain: Np must be a multiple of 128");
   if (Np == 0) return AON_OK;
   if (!packed_bwd || !packed_fwd || !d_raw || !masks || !dplanes) return fail(AON_E_INVALID, "aon_mlp_bwd_chain: null pointer");
+  KTimer timer(kBwdChain, (hipStream_t)stream, Np);
   return check(aon::launch_mlp_bwd_chain(static_cast<const char*>(packed_bwd), static_cast<const char*>(packed_fwd), d_raw, masks,
                                          dplanes, Np, (hipStream_t)stream), "aon_mlp_bwd_chain");
 }
@@ -320,6 +339,7 @@ int aon_vanilla_wgrad(const float* planes, const float* dplanes, const float* d_
   for (int i = 0; i < aon::kNumVanillaParams; ++i)
     if (!grads_host[i]) return fail(AON_E_INVALID, "aon_vanilla_wgrad: null gradient pointer");
   if (workspace_bytes < aon::wgrad_workspace_bytes()) return fail(AON_E_WORKSPACE, "aon_vanilla_wgrad: workspace too small");
+  KTimer timer(kWgrad, (hipStream_t)stream, Np);
   return check(aon::launch_vanilla_wgrad(planes, dplanes, d_raw, Np, grads_host, static_cast<float*>(workspace), (hipStream_t)stream),
                "aon_vanilla_wgrad");
 }
@@ -354,6 +374,7 @@ int aon_art_bwd_chain(const void* packed_bwd, const void* small, const float* d_
   if (Np < 0 || (Np & 127)) return fail(AON_E_INVALID, "aon_art_bwd_chain: Np must be a multiple of 128");
   if (Np == 0) return AON_OK;
   if (!packed_bwd || !small || !d_raw || !masks || !planes || !dplanes || !dxp) return fail(AON_E_INVALID, "aon_art_bwd_chain: null pointer");
+  KTimer timer(kBwdChain, (hipStream_t)stream, Np);
   return check(aon::launch_art_bwd_chain(static_cast<const char*>(packed_bwd), static_cast<const float*>(small), d_raw, masks, planes,
                                          dplanes, dxp, Np, (hipStream_t)stream), "aon_art_bwd_chain");
 }
@@ -369,32 +390,44 @@ int aon_art_wgrad(const float* planes, const float* dplanes, const float* d_raw,
   for (int i = 0; i < 40; ++i)
     if (!params_host[i] || !grads_host[i]) return fail(AON_E_INVALID, "aon_art_wgrad: null parameter / gradient pointer");
   if (workspace_bytes < aon::wgrad_workspace_bytes()) return fail(AON_E_WORKSPACE, "aon_art_wgrad: workspace too small");
+  KTimer timer(kWgrad, (hipStream_t)stream, Np);
   return check(aon::launch_art_wgrad(planes, dplanes, d_raw, dxp, Np, params_host, shape, appearance, articulation, grads_host, g_shape,
                                      g_appearance, g_articulation, static_cast<float*>(workspace), (hipStream_t)stream), "aon_art_wgrad");
 }
 
 int aon_profile_begin(void) {
   std::lock_guard<std::mutex> lk(g_prof.mu);
-  g_prof.on = true; g_prof.used = 0; g_prof.samples = 0;
+  g_prof.on = true; g_prof.used = 0; g_prof.recs.clear();
+  for (int c = 0; c < kNumClasses; ++c) g_prof.units[c] = 0;
   return AON_OK;
 }
 
 int aon_profile_end(double* mlp_ms, int64_t* mlp_launches, int64_t* mlp_samples) {
   std::lock_guard<std::mutex> lk(g_prof.mu);
   g_prof.on = false;
-  double total = 0.0;
-  for (size_t i = 0; i + 1 < g_prof.used; i += 2) {
-    hipError_t e = hipEventSynchronize(g_prof.pool[i + 1]);
+  for (int c = 0; c < kNumClasses; ++c) { g_prof.last_ms[c] = 0.0; g_prof.last_launches[c] = 0; g_prof.last_units[c] = g_prof.units[c]; }
+  for (const auto& r : g_prof.recs) {
+    hipError_t e = hipEventSynchronize(r.stop);
     if (e != hipSuccess) return check(e, "aon_profile_end");
     float ms = 0.f;
-    e = hipEventElapsedTime(&ms, g_prof.pool[i], g_prof.pool[i + 1]);
+    e = hipEventElapsedTime(&ms, r.start, r.stop);
     if (e != hipSuccess) return check(e, "aon_profile_end");
-    total += ms;
+    g_prof.last_ms[r.cls] += ms;
+    g_prof.last_launches[r.cls] += 1;
   }
-  if (mlp_ms) *mlp_ms = total;
-  if (mlp_launches) *mlp_launches = (int64_t)(g_prof.used / 2);
-  if (mlp_samples) *mlp_samples = g_prof.samples;
-  g_prof.used = 0; g_prof.samples = 0;
+  if (mlp_ms) *mlp_ms = g_prof.last_ms[kMlpFwd];
+  if (mlp_launches) *mlp_launches = g_prof.last_launches[kMlpFwd];
+  if (mlp_samples) *mlp_samples = g_prof.last_units[kMlpFwd];
+  g_prof.used = 0; g_prof.recs.clear();
+  return AON_OK;
+}
+
+int aon_profile_class(int cls, double* ms, int64_t* launches, int64_t* units) {
+  if (cls < 0 || cls >= kNumClasses) return fail(AON_E_INVALID, "aon_profile_class: unknown kernel class");
+  std::lock_guard<std::mutex> lk(g_prof.mu);
+  if (ms) *ms = g_prof.last_ms[cls];
+  if (launches) *launches = g_prof.last_launches[cls];
+  if (units) *units = g_prof.last_units[cls];
   return AON_OK;
 }
 
@@ -459,18 +492,27 @@ static int render_impl(const char* who, const NetRef& coarse, const NetRef& fine
     if (rc) return rc;
     rc = check(launch_net(coarse, o, d, v, w.t_c, n, kSc, w.raw, stream), who);
     if (rc) return rc;
-    rc = check(aon::launch_composite(w.raw, 4, w.raw + 3, 4, w.t_c, d, n, kSc, white_bkgd, act, rgb_c + r0 * 3, acc_c + r0,
-                                     depth_c + r0, num_levels == 2 ? w.w_c : nullptr, stream), who);
+    {
+      KTimer timer(kComposite, stream, n);
+      rc = check(aon::launch_composite(w.raw, 4, w.raw + 3, 4, w.t_c, d, n, kSc, white_bkgd, act, rgb_c + r0 * 3, acc_c + r0,
+                                       depth_c + r0, num_levels == 2 ? w.w_c : nullptr, stream), who);
+    }
     if (rc) return rc;
     if (num_levels == 1) continue;
     // level 1 (model.py:162-173, :175-197)
-    rc = check(aon::launch_sample_pdf(nullptr, w.w_c + 1, kSc, w.t_c, u_stride ? u + r0 * u_stride : u, u_stride, n, nullptr, w.t_f,
-                                      stream), who);
+    {
+      KTimer timer(kSamplePdf, stream, n);
+      rc = check(aon::launch_sample_pdf(nullptr, w.w_c + 1, kSc, w.t_c, u_stride ? u + r0 * u_stride : u, u_stride, n, nullptr, w.t_f,
+                                        stream), who);
+    }
     if (rc) return rc;
     rc = check(launch_net(fine, o, d, v, w.t_f, n, kSf, w.raw, stream), who);
     if (rc) return rc;
-    rc = check(aon::launch_composite(w.raw, 4, w.raw + 3, 4, w.t_f, d, n, kSf, white_bkgd, act, rgb_f + r0 * 3, acc_f + r0,
-                                     depth_f + r0, nullptr, stream), who);
+    {
+      KTimer timer(kComposite, stream, n);
+      rc = check(aon::launch_composite(w.raw, 4, w.raw + 3, 4, w.t_f, d, n, kSf, white_bkgd, act, rgb_f + r0 * 3, acc_f + r0,
+                                       depth_f + r0, nullptr, stream), who);
+    }
     if (rc) return rc;
   }
   return AON_OK;
@@ -514,6 +556,7 @@ int aon_mlp_bwd_chain_bf16x3(const void* packed_bwd_bf16x3, const void* packed_f
   if (Np < 0 || (Np & 127)) return fail(AON_E_INVALID, "aon_mlp_bwd_chain_bf16x3: Np must be a multiple of 128");
   if (Np == 0) return AON_OK;
   if (!packed_bwd_bf16x3 || !packed_fwd || !d_raw || !masks || !dplanes) return fail(AON_E_INVALID, "aon_mlp_bwd_chain_bf16x3: null pointer");
+  KTimer timer(kBwdChain, (hipStream_t)stream, Np);
   const float* small = reinterpret_cast<const float*>(static_cast<const char*>(packed_fwd) + aon::kStreamBytes);
   return check(aon::launch_mlp_bwd_chain_bf16x3(static_cast<const char*>(packed_bwd_bf16x3), small, d_raw, masks, dplanes, Np,
                                                 (hipStream_t)stream), "aon_mlp_bwd_chain_bf16x3");
@@ -669,6 +712,7 @@ int aon_art_bwd_chain_bf16x3(const void* packed_bwd_bf16x3, const void* small, c
   if (Np == 0) return AON_OK;
   if (!packed_bwd_bf16x3 || !small || !d_raw || !masks || !planes || !dplanes || !dxp)
     return fail(AON_E_INVALID, "aon_art_bwd_chain_bf16x3: null pointer");
+  KTimer timer(kBwdChain, (hipStream_t)stream, Np);
   return check(aon::launch_art_bwd_chain_bf16x3(static_cast<const char*>(packed_bwd_bf16x3), static_cast<const float*>(small), d_raw, masks,
                                                 planes, dplanes, dxp, Np, (hipStream_t)stream), "aon_art_bwd_chain_bf16x3");
 }

@@ -49,12 +49,12 @@ __global__ void __launch_bounds__(256) composite_bwd_kernel(CompositeBwdArgs a) 
   // dL/dw_i = gC.c_i - [white] sum(gC) + g_acc + t_i g_depth     (comp_rgb += 1 - acc, helper.py:187-188)
   const float gw_const = gA - (a.white_bkgd ? (gC0 + gC1 + gC2) : 0.f);
 
-  float alpha[4], T[4], f[4], dist[4], wgw[4], gw[4], dsig_draw[4], w_[4];
+  float alpha[4], ex[4], T[4], f[4], dist[4], wgw[4], gw[4], dsig_draw[4], w_[4];
   float dc0[4], dc1[4], dc2[4];  // d c / d raw  (activation derivative), later reused as gC.c' products
   float carry = 1.0f;
 #pragma unroll
   for (int b = 0; b < 4; ++b) {
-    alpha[b] = 0.f; T[b] = 0.f; f[b] = 1.f; dist[b] = 0.f; wgw[b] = 0.f; gw[b] = 0.f; dsig_draw[b] = 0.f; w_[b] = 0.f;
+    alpha[b] = 0.f; ex[b] = 1.f; T[b] = 0.f; f[b] = 1.f; dist[b] = 0.f; wgw[b] = 0.f; gw[b] = 0.f; dsig_draw[b] = 0.f; w_[b] = 0.f;
     dc0[b] = dc1[b] = dc2[b] = 0.f;
     if (b < nblk) {
       const int s = b * 64 + lane;
@@ -79,7 +79,8 @@ __global__ void __launch_bounds__(256) composite_bwd_kernel(CompositeBwdArgs a) 
         } else {
           sg = r.w; dsig_draw[b] = 1.f; c0 = r.x; c1 = r.y; c2 = r.z; dc0[b] = dc1[b] = dc2[b] = 1.f;
         }
-        alpha[b] = __fsub_rn(1.0f, expf(-__fmul_rn(sg, dist[b])));
+        ex[b] = expf(-__fmul_rn(sg, dist[b]));
+        alpha[b] = __fsub_rn(1.0f, ex[b]);
         f[b] = __fadd_rn(__fsub_rn(1.0f, alpha[b]), 1e-10f);
       }
       // forward transmittance, as composite_kernel
@@ -115,9 +116,10 @@ __global__ void __launch_bounds__(256) composite_bwd_kernel(CompositeBwdArgs a) 
       sfx_carry = sfx_carry + __shfl(incl, 0);
       const int s = b * 64 + lane;
       if (s < S) {
-        // dL/dalpha_i = T_i gw_i - Sfx_i / (1 - alpha_i + 1e-10);  dalpha/dsigma = dist * exp(-sigma dist) = dist (1 - alpha)
+        // dL/dalpha_i = T_i gw_i - Sfx_i / (1 - alpha_i + 1e-10);  dalpha/dsigma = dist * exp(-sigma dist): the exponential
+        // itself, as autograd saves it -- re-deriving it as 1 - alpha loses its low bits once alpha is close to 1
         const float dalpha = T[b] * gw[b] - sfx / f[b];
-        const float dsigma = dalpha * dist[b] * (1.0f - alpha[b]);
+        const float dsigma = dalpha * dist[b] * ex[b];
         float4 o;
         o.x = w_[b] * gC0 * dc0[b]; o.y = w_[b] * gC1 * dc1[b]; o.z = w_[b] * gC2 * dc2[b];
         o.w = dsigma * dsig_draw[b];

@@ -647,3 +647,17 @@ def profile_end():
     ms, launches, samples = C.c_double(0), C.c_int64(0), C.c_int64(0)
     check(lib.aon_profile_end(C.byref(ms), C.byref(launches), C.byref(samples)), "aon_profile_end")
     return ms.value, launches.value, samples.value
+
+
+PROF_CLASSES = {"mlp_fwd": 0, "bwd_chain": 1, "wgrad": 2, "composite": 3, "sample_pdf": 4, "composite_bwd": 5}
+
+
+def profile_classes() -> dict:
+    """Per kernel class of the interval closed by the last profile_end(): {name: (ms_total, launches, units)}; units are
+    samples for mlp_fwd / bwd_chain / wgrad and rays for the per-ray kernels."""
+    out = {}
+    for name, cls in PROF_CLASSES.items():
+        ms, launches, units = C.c_double(0), C.c_int64(0), C.c_int64(0)
+        check(lib.aon_profile_class(cls, C.byref(ms), C.byref(launches), C.byref(units)), "aon_profile_class")
+        out[name] = (ms.value, launches.value, units.value)
+    return out

@@ -91,6 +91,16 @@ def make_nerf_state_dict(seed: int = 0, density_scale: float = 30.0, **layout_kw
 
 
 # articulated NeRFMLP (models/vanilla_nerf/model_autodecoder.py:60-170, default geometry)
+def make_smooth_nerf_state_dict(seed: int = 5, density_scale: float = 2.0, density_bias: float = 0.75):
+    """A "trained-like" smooth field for tight end-to-end parity (density x1-3 instead of the x30 of the
+    structure fixtures): small density gain and a positive density bias, so the far sample's raw sigma -- whose sign alone
+    decides the 1e10-long last interval (helper.py:163) -- sits well away from zero on almost every ray."""
+    sd = make_nerf_state_dict(seed=seed, density_scale=density_scale)
+    for lvl in ("coarse_mlp", "fine_mlp"):
+        sd[f"{lvl}.density_layer.bias"] = sd[f"{lvl}.density_layer.bias"] + density_bias
+    return sd
+
+
 def art_mlp_layout():
     layout = [("deformations_linear.0", 128, 163, "xavier")]
     layout += [(f"deformations_linear.{i}", 128, 128, "xavier") for i in (1, 2, 3)]

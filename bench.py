@@ -26,6 +26,21 @@ if ROOT not in sys.path:
 FLOP_PER_SAMPLE = 1_186_816          # reference-literal MACs x 2 of one NeRFMLP evaluation
 EVALS_PER_RAY = 65 + 193
 PEAK_FP32_MATRIX_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense fp32 matrix peak
+PEAK_HBM_TBS = 8.0                   # MI355X_MICROARCH.md: HBM3E
+# articulated network: reference-literal MACs per sample, and the MACs the kernels execute once the latent
+# columns are folded into per-call biases (128*(128+32) + 2*256*128 + 128*128 = 102,400 fewer)
+ART_MAC_LITERAL = 794_880
+ART_MAC_FWD = ART_MAC_LITERAL - 102_400
+ART_MAC_BWD_CHAIN = ART_MAC_FWD - 128 * 3 - 128 * 27      # no data gradient into the raw position / the view encoding
+ART_MAC_WGRAD = ART_MAC_FWD                                # latent-column weight gradients are outer products of bias gradients
+VAN_MAC = 593_408
+VAN_MAC_BWD_CHAIN = VAN_MAC - 2 * 256 * 63 - 128 * 27     # no data gradient into the encodings
+# algorithmic HBM bytes per ray of the per-ray kernels: compositing reads float4(rgb, sigma) + t per sample and
+# the direction, writes rgb/acc/depth (+ the 65 weights at the coarse level); the inverse CDF reads t (65) and 63 weights and
+# writes 193 sorted t values
+BYTES_COMPOSITE_COARSE = 65 * 20 + 12 + 20 + 65 * 4
+BYTES_COMPOSITE_FINE = 193 * 20 + 12 + 20
+BYTES_SAMPLE_PDF = 65 * 4 + 63 * 4 + 193 * 4
 
 
 def cpu_baseline(sd, rays_cpu, budget_s=20.0):
@@ -62,9 +77,111 @@ def cpu_baseline(sd, rays_cpu, budget_s=20.0):
             if time.perf_counter() - t0 > budget_s:
                 break
         dt = time.perf_counter() - t0
-    return {"value": done * chunk / dt, "unit": "rays/s", "cores": threads, "kind": "port",
-            "sample": f"{done} x 3840-ray chunks of the same 640x480 frame, fp32, torch {torch.__version__} CPU, {dt:.1f} s"}, \
+    phys, model_name = host_cpu()
+    return {"value": done * chunk / dt, "unit": "rays/s", "cores": phys, "threads": threads, "logical_cpus": ncpu, "cpu": model_name, "kind": "port",
+            "sample": f"{done} x 3840-ray chunks of the same 640x480 frame, fp32, torch {torch.__version__} CPU, {dt:.1f} s; "
+                      f"torch intra-op threads = {threads} (fastest of a probe over 8..{ncpu}) on a host with {phys} physical cores"}, \
         torch.cat(outs), (starts[0], starts[0] + done * chunk)
+
+
+def host_cpu():
+    """(physical cores, model name) of the host, from lscpu; falls back to os.cpu_count()."""
+    import subprocess
+
+    try:
+        txt = subprocess.run(["lscpu"], capture_output=True, text=True, timeout=10).stdout
+        kv = {l.split(":", 1)[0].strip(): l.split(":", 1)[1].strip() for l in txt.splitlines() if ":" in l}
+        return int(kv["Core(s) per socket"]) * int(kv["Socket(s)"]), kv.get("Model name", "?")
+    except Exception:
+        return os.cpu_count() or 1, "?"
+
+
+def mfma_roofline(kernel, ms, launches, samples, mac_executed, mac_literal):
+    """Roofline object of an MFMA-bound kernel class from live HIP-event totals: executed and reference-literal FLOP rates."""
+    if ms <= 0 or launches <= 0:
+        return None
+    ex = samples * mac_executed * 2 / (ms * 1e-3) / 1e12
+    lit = samples * mac_literal * 2 / (ms * 1e-3) / 1e12
+    return {"bound": "mfma", "kernel": kernel, "achieved": ex, "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s", "frac": ex / PEAK_FP32_MATRIX_TFLOPS,
+            "achieved_reference_literal": lit, "frac_reference_literal": lit / PEAK_FP32_MATRIX_TFLOPS, "traffic": None,
+            "launches": launches, "avg_launch_ms": ms / launches, "samples": samples,
+            "flop_per_sample_executed": 2 * mac_executed, "flop_per_sample_reference_literal": 2 * mac_literal}
+
+
+def hbm_roofline(kernel, ms, launches, nbytes):
+    if ms <= 0 or launches <= 0:
+        return None
+    tbs = nbytes / (ms * 1e-3) / 1e12
+    return {"bound": "hbm", "kernel": kernel, "achieved": tbs * 1e3, "peak": PEAK_HBM_TBS * 1e3, "unit": "GB/s", "frac": tbs / PEAK_HBM_TBS,
+            "traffic": None, "launches": launches, "avg_launch_us": ms / launches * 1e3, "algorithmic_bytes": nbytes}
+
+
+def per_ray_rooflines(classes):
+    """HBM rooflines of the per-ray kernels of a two-level render from the profile classes (composite launches come in
+    coarse / fine pairs over the same rays)."""
+    out = {}
+    ms, launches, rays = classes["composite"]
+    if launches:
+        out["composite"] = hbm_roofline("aon::composite_kernel (coarse + fine launches)", ms, launches, rays / 2 * (BYTES_COMPOSITE_COARSE + BYTES_COMPOSITE_FINE))
+    ms, launches, rays = classes["sample_pdf"]
+    if launches:
+        out["sample_pdf"] = hbm_roofline("aon::sample_pdf_kernel", ms, launches, rays * BYTES_SAMPLE_PDF)
+    return out
+
+
+def render_leg(dev, kind, H, W, steps=3):
+    """Informational (never `value`): BASELINE config 1 (`kind` "config1": vanilla, coarse level only, 320x240 -- the reference's
+    own CPU-runnable case) or config 4 ("art": articulated NeRF_AE_Art render, 320x240) on this rank's GPU, with the dominant
+    kernel's roofline from live HIP events."""
+    try:
+        import types
+
+        import aon_amd.synthetic as syn
+        from aon_amd import ops
+        from aon_amd.datasets.ray_utils import get_frame_rays
+
+        ro, vd = get_frame_rays(H, W, syn.focal_from_fovy(H), syn.look_at_pose(), device=dev)
+        rays = {"rays_o": ro, "rays_d": vd, "viewdirs": vd}
+        if kind == "config1":
+            from aon_amd.models.vanilla_nerf.model import NeRF
+
+            model = NeRF(num_levels=1).to(dev)
+            model.load_state_dict(syn.make_nerf_state_dict(seed=0, density_scale=30.0))
+            call = lambda: model(rays, False, True, syn.NEAR, syn.FAR)
+            evals, mac_ex, mac_lit = 65, VAN_MAC, VAN_MAC
+            name = "aon::mlp_fwd_kernel<true,false> (fused encode+MLP, fp32 MFMA)"
+            work = f"vanilla NeRF {W}x{H}, 65 coarse evals/ray only (num_levels=1), {H * W} rays"
+        else:
+            from aon_amd.models.code_library import CodeLibraryArticulated
+            from aon_amd.models.vanilla_nerf.model_autodecoder import NeRF_AE_Art
+
+            model = NeRF_AE_Art().to(dev)
+            model.load_state_dict(syn.make_art_state_dict(seed=0, density_scale=30.0))
+            lib = CodeLibraryArticulated(types.SimpleNamespace(N_max_objs=1, N_obj_code_length=128)).to(dev)
+            lib.load_state_dict(syn.make_code_library_state(0, 1))
+            with torch.no_grad():
+                lat = lib({"instance_id": torch.tensor([0], device=dev), "articulation_id": torch.tensor([3], device=dev)})
+            call = lambda: model(rays, False, True, syn.NEAR, syn.FAR, lat)
+            evals, mac_ex, mac_lit = EVALS_PER_RAY, ART_MAC_FWD, ART_MAC_LITERAL
+            name = "aon::art_mlp_fwd_kernel<true,false> (deformation + trunk + view branch, latents folded into biases, fp32 MFMA)"
+            work = f"articulated NeRF_AE_Art {W}x{H}, 65 coarse + 193 fine evals/ray, {H * W} rays"
+        with torch.no_grad():
+            call()
+            torch.cuda.synchronize()
+            ops.profile_begin()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                call()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / steps
+            ms, launches, samples = ops.profile_end()
+        res = {"workload": work, "value": H * W / dt, "unit": "rays/s", "ms_per_frame": dt * 1e3, "steps": steps, "evals_per_ray": evals,
+               "roofline": mfma_roofline(name, ms, launches, samples, mac_ex, mac_lit)}
+        if kind != "config1":
+            res["hbm_kernels"] = per_ray_rooflines(ops.profile_classes())
+        return res
+    except Exception as e:  # informational leg: never take the headline down with it
+        return {"error": f"{type(e).__name__}: {e}"}
 
 
 def pmc_traffic():
@@ -132,22 +249,45 @@ def train_leg(dev, rank, world, distributed, steps=3, n_rays=4096):
         def timed():
             step()
             fence()
+            ops.profile_begin()
             t0 = time.perf_counter()
             for _ in range(steps):
                 loss = step()
             fence()
             t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+            ops.profile_end()
             if distributed:
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            return t.item() / steps, float(loss)
+            return t.item() / steps, float(loss), ops.profile_classes()
 
-        dt, loss = timed()
+        dt, loss, classes = timed()
+        samples = n_rays * EVALS_PER_RAY
+        mac_lit, mac_ex = 3 * ART_MAC_LITERAL, ART_MAC_FWD + ART_MAC_BWD_CHAIN + ART_MAC_WGRAD
+        kernels = {}
+        for key, name, mac in (("mlp_fwd", "aon::art_mlp_fwd_kernel<true,true> (training forward: + activation planes, ReLU bits)", ART_MAC_FWD),
+                               ("bwd_chain", "aon::art_bwd_chain_kernel (data-gradient chain + gradient planes)", ART_MAC_BWD_CHAIN),
+                               ("wgrad", "aon::wgrad_kernel<*> + partial reductions + head / latent gradients (one launch = one level)", ART_MAC_WGRAD)):
+            ms, launches, units = classes[key]
+            r = mfma_roofline(name, ms, launches, samples * steps, mac, ART_MAC_LITERAL)   # units are padded samples: price the real ones
+            if r is not None:
+                r["ms_per_step"] = ms / steps
+                kernels[key] = r
+        other_ms = sum(classes[k][0] for k in ("composite", "sample_pdf", "composite_bwd")) / steps
         res = {"workload": f"articulated NeRF_AE_Art training step, {n_rays} rays/GPU, fwd+bwd" + (" + RCCL gradient all-reduce (6.4 MB, one bucket)" if world > 1 else "") + " + Adam",
-               "ms_per_step": dt * 1e3, "rays_per_s": world * n_rays / dt, "steps": steps, "loss": loss}
+               "ms_per_step": dt * 1e3, "rays_per_s": world * n_rays / dt, "steps": steps, "loss": loss,
+               "roofline": {"bound": "mfma", "unit": "TFLOP/s", "peak": PEAK_FP32_MATRIX_TFLOPS,
+                            "achieved": samples * mac_ex * 2 / dt / 1e12, "frac": samples * mac_ex * 2 / dt / 1e12 / PEAK_FP32_MATRIX_TFLOPS,
+                            "achieved_reference_literal": samples * mac_lit * 2 / dt / 1e12,
+                            "frac_reference_literal": samples * mac_lit * 2 / dt / 1e12 / PEAK_FP32_MATRIX_TFLOPS,
+                            "flop_per_ray_executed": 2 * mac_ex * EVALS_PER_RAY, "flop_per_ray_reference_literal": 2 * mac_lit * EVALS_PER_RAY,
+                            "note": "whole step (kernels + Adam + harness) priced against the fp32-matrix peak; executed = MACs the kernels issue "
+                                    "(latent columns folded into biases), reference-literal = 3 x the forward MACs of SURVEY R10",
+                            "kernels": kernels, "per_ray_kernels_ms_per_step": other_ms,
+                            "kernel_ms_per_step": sum(k["ms_per_step"] for k in kernels.values()) + other_ms, "traffic": None}}
         # the opt-in split-bf16 training engine (forward, backward chain and weight gradients), same step
         ops.set_train_engine("bf16x3")
         try:
-            dt_b, _ = timed()
+            dt_b, _, _ = timed()
             res["bf16x3_engine_ms_per_step"] = dt_b * 1e3
         finally:
             ops.set_train_engine("fp32")
@@ -169,6 +309,7 @@ def main():
     ap.add_argument("--no-alt", action="store_true", help="skip the extra (untimed-for-`value`) run of the other engine")
     ap.add_argument("--sharded-leg", action="store_true", help="run the informational sharded-frame leg even at world size 1")
     ap.add_argument("--no-train-leg", action="store_true", help="skip the extra (informational) articulated training-step timing")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the informational BASELINE config 1 / config 4 render legs")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -224,6 +365,7 @@ def main():
         fence()
         dt = time.perf_counter() - t0
         mlp_ms, mlp_launches, mlp_samples = ops.profile_end()
+        headline_classes = ops.profile_classes()
 
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if distributed:
@@ -283,6 +425,9 @@ def main():
             sharded = {"error": f"{type(e).__name__}: {e}"}
 
     train = None if args.no_train_leg else train_leg(dev, rank, world, distributed)
+    # BASELINE configs 1 and 4 on this rank's GPU (informational, never `value`)
+    config1 = None if args.no_extra_legs else render_leg(dev, "config1", 240, 320)
+    art_render = None if args.no_extra_legs else render_leg(dev, "art", 240, 320)
 
     if rank == 0:
         rays_per_s = world * n_rays * args.steps / dt
@@ -305,6 +450,11 @@ def main():
                          "whole_path_frac": rays_per_s / world * EVALS_PER_RAY * FLOP_PER_SAMPLE / (PEAK_FP32_MATRIX_TFLOPS * 1e12)},
         }
         res["roofline"].update(pmc_traffic())
+        res["hbm_kernels"] = per_ray_rooflines(headline_classes)   # the non-GEMM kernels of the same timed region (>= 50 % of HBM peak each)
+        if config1 is not None:
+            res["config1"] = config1
+        if art_render is not None:
+            res["art_render"] = art_render
         if alt is not None:
             res["alt_engine"] = alt
         if sharded is not None:

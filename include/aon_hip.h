@@ -223,12 +223,22 @@ int aon_art_wgrad(const float* planes, const float* dplanes, const float* d_raw,
                   float* g_articulation, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ---- measurement aid (no reference counterpart) ----
- * Between aon_profile_begin() and aon_profile_end() every launch of the fused MLP kernel (the dominant kernel of
- * the path) made through aon_mlp_fwd / aon_render_fwd is bracketed by HIP events recorded on the launch stream.
- * aon_profile_end() waits for those events and returns the summed kernel time (ms), the number of launches and
- * the number of samples (network evaluations) they covered. */
+ * Between aon_profile_begin() and aon_profile_end() every launch of the path's kernels made through this library is
+ * bracketed by HIP events recorded on the LAUNCH stream, by kernel class.  aon_profile_end() waits for those events
+ * and returns the totals of the dominant class -- the fused MLP forward: summed kernel time (ms), launches, samples
+ * (network evaluations); aon_profile_class() then reads the totals of any class of that same interval
+ * (units: samples for the MLP / backward-chain / weight-gradient classes, rays for the per-ray kernels;
+ * a weight-gradient "launch" is one aon_*_wgrad call = all layers of one level). */
+#define AON_PROF_MLP_FWD 0       /* fused encode + MLP forward (inference and training) */
+#define AON_PROF_BWD_CHAIN 1     /* backward data-gradient chain */
+#define AON_PROF_WGRAD 2         /* weight-gradient GEMMs + partial reductions of one level */
+#define AON_PROF_COMPOSITE 3     /* alpha compositing (R8) */
+#define AON_PROF_SAMPLE_PDF 4    /* inverse-CDF sampling + merge (R6/R7) */
+#define AON_PROF_COMPOSITE_BWD 5 /* compositing backward */
+#define AON_PROF_NUM_CLASSES 6
 int aon_profile_begin(void);
 int aon_profile_end(double* mlp_ms, int64_t* mlp_launches, int64_t* mlp_samples);
+int aon_profile_class(int kernel_class, double* ms, int64_t* launches, int64_t* units);
 
 /* ---- opt-in "bf16x3" engine for the articulated path (R10/R11): same semantics as aon_art_mlp_fwd / aon_art_render_fwd,
  * split-bf16 MFMA with fp32-equivalent products (csrc/aon_mlp_art_bf16.hip); own packed stream, the small block of

@@ -113,11 +113,14 @@ def test_nerf_ae_art_forward(dev, golden, art_sd):
             # field -- a 1-ulp change of a coarse weight moves inverse-CDF draws across thin high-density shells; the
             # ORACLE ITSELF differs between fp32 and fp64 by 0.06 (deterministic) / 0.28 (randomized) in fine depth on
             # these very rays while its rgb agrees to 2e-4.  So: most rays tight, worst ray inside that spread.
+            # Measured round 2 against the reference's outputs (tests/diag/diag_tolerances.py): coarse depth 1.8e-5; fine depth
+            # 1.3e-2 deterministic, 0.17 randomized (p99 3e-2); on the smooth field of test_hip_smooth.py the same kernels hold 2e-5.
             derr = (depth - ref[lvl][2]).abs()
             if lvl == 0:
-                assert derr.max().item() <= 1e-3
+                assert derr.max().item() <= 1e-4
+                torch.testing.assert_close(rgb, ref[lvl][0], rtol=0, atol=2e-6)
             else:
-                assert (derr <= 5e-3).double().mean().item() >= 0.9 and derr.max().item() <= 0.3
+                assert (derr <= 5e-3).double().mean().item() >= 0.9 and derr.max().item() <= (0.3 if kw["randomized"] else 5e-2)
             assert_render_close(rgb, g[f"{tag}_{name}_rgb"], f"{tag}/{name} rgb vs reference")   # the reference's own output
             torch.testing.assert_close(acc, g[f"{tag}_{name}_acc"], rtol=0, atol=2e-4)
     # latents matter (different articulation code -> different image) and grad mode is refused loudly

@@ -369,10 +369,18 @@ def test_nerf_forward_vs_oracle_and_golden(dev, golden, nerf_sd, white):
         assert _psnr(rgb, ref[lvl][0]) >= 70.0
         assert frac_within(rgb, ref[lvl][0], 1e-3) >= 0.999 or ok.double().mean() < 0.999
         # tight check on robustly-signed rays, against the oracle and against the reference's own outputs
-        torch.testing.assert_close(rgb[ok], ref[lvl][0][ok], rtol=0, atol=2e-4)
-        torch.testing.assert_close(acc[ok], ref[lvl][1][ok], rtol=0, atol=2e-4)
-        torch.testing.assert_close(depth[ok], ref[lvl][2][ok], rtol=0, atol=2e-3)
-        torch.testing.assert_close(rgb[ok], g[f"{tag}_{name}_rgb"][ok], rtol=0, atol=2e-4)
+        # (round 2, with the inverse CDF bit-exact: measured 9.5e-7 rgb / 3.4e-5 fine depth on this sharp x30 field; the bounds
+        # were 2e-4 / 2e-3 in round 1.  The smooth fixture of test_hip_smooth.py holds 2e-6 / 1e-5 on every ray.)
+        torch.testing.assert_close(rgb[ok], ref[lvl][0][ok], rtol=0, atol=1e-5)
+        torch.testing.assert_close(acc[ok], ref[lvl][1][ok], rtol=0, atol=1e-5)
+        torch.testing.assert_close(depth[ok], ref[lvl][2][ok], rtol=0, atol=2e-4)
+        torch.testing.assert_close(rgb[ok], g[f"{tag}_{name}_rgb"][ok], rtol=0, atol=1e-5)
+        torch.testing.assert_close(depth[ok], g[f"{tag}_{name}_depth"][ok], rtol=0, atol=2e-4)
+        # a ray whose far raw sigma sits inside the margin must still land on one of the two legal values of the reference's
+        # step function at the far plane (helper.py:163): here, on the reference's own output or differ only by that step
+        if (~ok).any():
+            bad = (rgb[~ok] - g[f"{tag}_{name}_rgb"][~ok]).abs().amax(-1)
+            assert ((bad <= 1e-5) | (bad >= 1e-3)).all(), bad
 
 
 def test_nerf_forward_randomized(dev, golden, nerf_sd):

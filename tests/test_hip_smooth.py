@@ -1,0 +1,123 @@
+"""GPU, smooth ("trained-like") fields -- density x2 instead of the x30 of the structure fixtures (G15, generated from the
+reference).  On the sharp fixtures a 1e-7 difference of a coarse weight moves fine-level samples across thin dense shells,
+so fine-level outputs of two correct fp32 implementations differ at the 1e-4 (rgb) / 1e-2 (depth) level there; here nothing
+amplifies the per-stage rounding and the WHOLE path is held to 2e-6 (rgb, acc) / 1e-5..2e-5 (depth) against the reference's
+own outputs on every ray, and the gradients of the training loss to 1e-4 (coarse) / 2e-3 (fine) against the oracle's autograd.
+Measured (MI355X, round 2): rgb <= 3.6e-7, depth <= 1.9e-6 vanilla / 8.1e-6 articulated."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import nerf_oracle as orc  # noqa: E402  (checker only)
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return torch.device("cuda:0")
+
+
+def rel_l2(a, b):
+    return ((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30)).item()
+
+
+def test_smooth_vanilla_end_to_end(dev, golden):
+    import aon_amd.synthetic as syn
+    from aon_amd.models.vanilla_nerf.model import NeRF
+
+    g = golden("g15_smooth")
+    assert g["min_margin"] > 0.05          # every far-plane raw sigma is robustly signed: nothing is masked below
+    model = NeRF().to(dev)
+    model.load_state_dict(syn.make_smooth_nerf_state_dict())
+    rays = {k: g[k].to(dev) for k in ("rays_o", "rays_d", "viewdirs")}
+    with torch.no_grad():
+        outs = {"van_det": model(rays, False, True, g["near"], g["far"]),
+                "van_rnd": model(rays, True, False, g["near"], g["far"], t_rand=g["t_rand"].to(dev), u=g["u"].to(dev))}
+    for tag, out in outs.items():
+        for lvl, name in ((0, "coarse"), (1, "fine")):
+            rgb, acc, depth = (x.cpu() for x in out[lvl])
+            torch.testing.assert_close(rgb, g[f"{tag}_{name}_rgb"], rtol=0, atol=2e-6)
+            torch.testing.assert_close(acc, g[f"{tag}_{name}_acc"], rtol=0, atol=2e-6)
+            torch.testing.assert_close(depth, g[f"{tag}_{name}_depth"], rtol=0, atol=1e-5)
+
+
+def test_smooth_articulated_end_to_end(dev, golden):
+    import aon_amd.synthetic as syn
+    from aon_amd.models.vanilla_nerf.model_autodecoder import NeRF_AE_Art
+
+    g = golden("g15_smooth")
+    model = NeRF_AE_Art().to(dev)
+    model.load_state_dict(syn.make_art_state_dict(seed=5, density_scale=2.0))
+    rays = {k: g["art_" + k].to(dev) for k in ("rays_o", "rays_d", "viewdirs")}
+    lat = {k: g["art_lat_" + k].to(dev) for k in ("density", "color", "articulation")}
+    with torch.no_grad():
+        out = model(rays, False, True, g["near"], g["far"], lat)
+    for lvl, name in ((0, "coarse"), (1, "fine")):
+        rgb, acc, depth = (x.cpu() for x in out[lvl])
+        torch.testing.assert_close(rgb, g[f"art_det_{name}_rgb"], rtol=0, atol=2e-6)
+        torch.testing.assert_close(acc, g[f"art_det_{name}_acc"], rtol=0, atol=2e-6)
+        torch.testing.assert_close(depth, g[f"art_det_{name}_depth"], rtol=0, atol=2e-5)
+
+
+@pytest.mark.parametrize("net", ["vanilla", "articulated"])
+def test_smooth_training_gradients(dev, golden, net):
+    """Gradients of mse(coarse) + mse(fine) on the smooth field, every parameter (and latent).  Truth = the oracle's autograd
+    in fp64; yardstick = the oracle's own fp32 autograd (the reference's arithmetic) against that truth.  The HIP gradients
+    must be as close to the truth as the reference's fp32 is, up to a factor 5 (floor 1e-4 relative L2): an fp32 gradient that
+    passes through the 2^9-octave encoding of the deformed point is itself only good to ~1e-2 on some deformation parameters.
+    Measured round 2: every parameter within 3x except the density head (a signed sum over all samples: 4.8e-5 against the
+    reference's 6.7e-6 coarse, 2.7e-4 against 6.6e-5 fine)."""
+    import aon_amd.synthetic as syn
+
+    g = golden("g15_smooth")
+    gen = torch.Generator().manual_seed(21)
+    art = net != "vanilla"
+    if not art:
+        from aon_amd.models.vanilla_nerf.model import NeRF
+
+        sd = syn.make_smooth_nerf_state_dict()
+        rays_cpu = {k: g[k][:96] for k in ("rays_o", "rays_d", "viewdirs")}
+        model, lat0 = NeRF().to(dev), None
+    else:
+        from aon_amd.models.vanilla_nerf.model_autodecoder import NeRF_AE_Art
+
+        sd = syn.make_art_state_dict(seed=5, density_scale=2.0)
+        rays_cpu = {k: g["art_" + k][:96] for k in ("rays_o", "rays_d", "viewdirs")}
+        model = NeRF_AE_Art().to(dev)
+        lat0 = {k: g["art_lat_" + k] for k in ("density", "color", "articulation")}
+    model.load_state_dict(sd)
+    n = rays_cpu["rays_o"].shape[0]
+    target = torch.rand(n, 3, generator=gen)
+
+    def oracle_grads(dtype):
+        sd_o = {k: v.detach().clone().to(dtype).requires_grad_(True) for k, v in sd.items()}
+        r = {k: v.to(dtype) for k, v in rays_cpu.items()}
+        lat = None if lat0 is None else {k: v.detach().clone().to(dtype).requires_grad_(True) for k, v in lat0.items()}
+        out = orc.nerf_ae_art_forward(sd_o, r, False, True, 2.0, 6.0, lat) if art else orc.nerf_forward(sd_o, r, False, True, 2.0, 6.0)
+        (orc.img2mse(out[0][0], target.to(dtype)) + orc.img2mse(out[1][0], target.to(dtype))).backward()
+        gr = {k: v.grad for k, v in sd_o.items()}
+        if lat is not None:
+            gr.update({f"latent[{k}]": v.grad for k, v in lat.items()})
+        return gr
+
+    truth, ref32 = oracle_grads(torch.float64), oracle_grads(torch.float32)
+    rays = {k: v.to(dev) for k, v in rays_cpu.items()}
+    if art:
+        lat = {k: v.detach().clone().to(dev).requires_grad_(True) for k, v in lat0.items()}
+        out = model(rays, False, True, 2.0, 6.0, lat)
+    else:
+        out = model(rays, False, True, 2.0, 6.0)
+    (torch.mean((out[0][0] - target.to(dev)) ** 2) + torch.mean((out[1][0] - target.to(dev)) ** 2)).backward()
+    hip = {name: p.grad.cpu() for name, p in model.named_parameters()}
+    if art:
+        hip.update({f"latent[{k}]": lat[k].grad.cpu() for k in lat})
+    bad, worst = {}, (0.0, 0.0)
+    for name, gh in hip.items():
+        e_hip, e_ref = rel_l2(gh, truth[name]), rel_l2(ref32[name], truth[name])
+        worst = max(worst, (e_hip, e_ref))
+        if e_hip > max(1e-4, 5.0 * e_ref):
+            bad[name] = f"hip {e_hip:.1e} vs reference-fp32 {e_ref:.1e}"
+    print(f"{net}: worst gradient distance to the fp64 truth: hip {worst[0]:.2e} (reference fp32 on the same parameter: {worst[1]:.2e})")
+    assert not bad, bad

@@ -240,7 +240,8 @@ def test_gradients_vs_reference_golden(dev, golden, nerf_sd):
     loss = torch.mean((out[0][0] - target) ** 2) + torch.mean((out[1][0] - target) ** 2)
     loss.backward()
     assert abs(loss.item() - g["vanilla_loss"]) <= 2e-5
-    check("vanilla", model.named_parameters(), lambda n: 1e-2 if n.startswith("fine_mlp") else 2e-3)
+    # measured round 2 (tests/diag/diag_tolerances.py): coarse 6.9e-7 (norm) / 1.5e-5 (entries); fine 2.2e-4 / 2.5e-3
+    check("vanilla", model.named_parameters(), lambda n: 3e-3 if n.startswith("fine_mlp") else 1e-4)
 
     ga = golden("g11_nerf_ae_art")
     amodel = NeRF_AE_Art().to(dev)
@@ -250,10 +251,11 @@ def test_gradients_vs_reference_golden(dev, golden, nerf_sd):
     loss = torch.mean((out[0][0] - target) ** 2) + torch.mean((out[1][0] - target) ** 2)
     loss.backward()
     assert abs(loss.item() - g["art_loss"]) <= 1e-4
-    check("art", amodel.named_parameters(), lambda n: 5e-2)
+    # measured: coarse 1.2e-4 (norm) / 3.1e-4 (entries); fine 4.6e-3 / 4.7e-2 (sharp x30 field: fine samples move); latents 1.6e-2
+    check("art", amodel.named_parameters(), lambda n: 2e-2 if n.startswith("fine_mlp") else 1e-3)
     for k, v in lat.items():
         ref = g[f"art_latgrad_{k}"]
-        assert (v.grad.cpu() - ref).abs().max().item() <= 5e-2 * ref.abs().max().item(), k
+        assert (v.grad.cpu() - ref).abs().max().item() <= 3e-2 * ref.abs().max().item(), k
 
 
 def test_training_trajectory_vs_oracle(dev):

@@ -173,3 +173,24 @@ def test_g9_backward(golden, nerf_sd):
     for k, v in lat.items():
         ref = g[f"art_latgrad_{k}"]
         assert (v.grad - ref).abs().max().item() <= 2e-3 * ref.abs().max().item(), k
+
+
+def test_g15_smooth_fields(golden):
+    """The oracle against the reference's outputs on the smooth ("trained-like") fields, both networks, every ray."""
+    import aon_amd.synthetic as syn
+
+    g = golden("g15_smooth")
+    rays = {k: g[k] for k in ("rays_o", "rays_d", "viewdirs")}
+    sd = syn.make_smooth_nerf_state_dict()
+    for tag, kw in (("van_det", dict(randomized=False, white_bkgd=True)),
+                    ("van_rnd", dict(randomized=True, white_bkgd=False, t_rand=g["t_rand"], u=g["u"]))):
+        out = orc.nerf_forward(sd, rays, near=g["near"], far=g["far"], **kw)
+        for lvl, name in ((0, "coarse"), (1, "fine")):
+            torch.testing.assert_close(out[lvl][0], g[f"{tag}_{name}_rgb"], rtol=0, atol=2e-6)
+            torch.testing.assert_close(out[lvl][2], g[f"{tag}_{name}_depth"], rtol=0, atol=2e-5)
+    arays = {k: g["art_" + k] for k in ("rays_o", "rays_d", "viewdirs")}
+    lat = {k: g["art_lat_" + k] for k in ("density", "color", "articulation")}
+    out = orc.nerf_ae_art_forward(syn.make_art_state_dict(seed=5, density_scale=2.0), arays, False, True, g["near"], g["far"], lat)
+    for lvl, name in ((0, "coarse"), (1, "fine")):
+        torch.testing.assert_close(out[lvl][0], g[f"art_det_{name}_rgb"], rtol=0, atol=2e-6)
+        torch.testing.assert_close(out[lvl][2], g[f"art_det_{name}_depth"], rtol=0, atol=2e-5)

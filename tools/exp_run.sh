@@ -1,2 +1,2 @@
 cd $GRAFT_REPO_ROOT
-python -m pytest tests/test_hip_parity.py -q -m gpu 2>&1 | grep -E "^(FAILED|ERROR)|passed|failed|^E  " | head -30
+python -m pytest tests -q -m gpu 2>&1 | grep -E "^(FAILED|ERROR)|passed|failed|^E  " | head -30
