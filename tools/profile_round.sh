@@ -5,7 +5,7 @@
 # Kernel trace and PMC counters are collected in SEPARATE runs (never --pmc together with a trace domain other than
 # --kernel-trace); FETCH_SIZE and WRITE_SIZE need a pass each (TCC counter budget, MI355X_MICROARCH.md HBM section).
 set -u
-TAG=${1:-r01}
+TAG=${1:-r02}
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=/tmp/prof_$TAG          # raw rocpd databases stay on the box (tens of MB); only the summaries travel back
 SUM=$REPO/gpurun_out/prof_$TAG
@@ -13,12 +13,12 @@ mkdir -p $OUT $SUM
 cd /tmp && export TMPDIR=/tmp
 run() { timeout 600 "$@"; }
 # 1. headline render bench: per-kernel durations
-run rocprofv3 --kernel-trace --stats -d $OUT/stats -o $TAG -- python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-train-leg > $OUT/stats_run.log 2>&1
+run rocprofv3 --kernel-trace --stats -d $OUT/stats -o $TAG -- python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-train-leg --no-extra-legs --no-alt > $OUT/stats_run.log 2>&1
 # 2. counters, one pass per group
-run rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -o $TAG -- python $REPO/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-train-leg > $OUT/pmc_fetch.log 2>&1
-run rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -o $TAG -- python $REPO/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-train-leg > $OUT/pmc_write.log 2>&1
-run rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES -d $OUT/pmc_sq -o $TAG -- python $REPO/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-train-leg > $OUT/pmc_sq.log 2>&1
-run rocprofv3 --kernel-trace --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY -d $OUT/pmc_sq2 -o $TAG -- python $REPO/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-train-leg > $OUT/pmc_sq2.log 2>&1
+run rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -o $TAG -- python $REPO/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-train-leg --no-extra-legs --no-alt > $OUT/pmc_fetch.log 2>&1
+run rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -o $TAG -- python $REPO/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-train-leg --no-extra-legs --no-alt > $OUT/pmc_write.log 2>&1
+run rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES -d $OUT/pmc_sq -o $TAG -- python $REPO/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-train-leg --no-extra-legs --no-alt > $OUT/pmc_sq.log 2>&1
+run rocprofv3 --kernel-trace --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY -d $OUT/pmc_sq2 -o $TAG -- python $REPO/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-train-leg --no-extra-legs --no-alt > $OUT/pmc_sq2.log 2>&1
 # 3. training steps (BASELINE config 5 per GPU, and the reference's vanilla batch)
 run rocprofv3 --kernel-trace --stats -d $OUT/train_art -o $TAG -- python $REPO/tools/train_bench.py --rays 4096 --steps 10 --articulated > $OUT/train_art.log 2>&1
 run rocprofv3 --kernel-trace --stats -d $OUT/train_van -o $TAG -- python $REPO/tools/train_bench.py --rays 4096 --steps 10 > $OUT/train_van.log 2>&1
@@ -31,6 +31,8 @@ run python $REPO/tools/train_bench.py --rays 4096 --steps 10 --train-engine bf16
 run python $REPO/tools/train_bench.py --rays 4096 --steps 10 --articulated --train-engine bf16x3 > $OUT/train_art_bf16x3.log 2>&1
 cd $REPO
 python tools/summarize_rocprof.py $OUT $SUM/${TAG} > $SUM/summary.log 2>&1
+f=$(ls $OUT/stats/*_results.db 2>/dev/null | head -1)
+[ -n "$f" ] && python tools/roofline_table.py $f > $SUM/${TAG}_roofline_table.txt 2>&1
 for d in train_art train_van render_art bf16x3; do
   f=$(ls $OUT/$d/*_results.db 2>/dev/null | head -1)
   [ -n "$f" ] && python tools/kstats.py $f 16 > $SUM/${TAG}_${d}_kernel_stats.txt 2>&1
