@@ -17,6 +17,15 @@ class RenderVanilla(torch.autograd.Function):
         # packs: [(packed_fwd, packed_bwd[, packed_bf16x3, packed_bwd_bf16x3])] per level; params: 24 tensors per level in
         # ops.VANILLA_PARAM_ORDER.  The optional elements select the bf16x3 training forward / backward chain; the fp32
         # forward stream is still read by the backward chain for its head weights.
+        ctx.rays_d = rays_d
+        ctx.white_bkgd = white_bkgd
+        ctx.num_levels = num_levels
+        if all(len(pk) == 2 for pk in packs):   # exact-fp32 engine: the whole forward is ONE C call (aon_render_fwd_train)
+            levels, ws = ops.render_fwd_train(packs[0][0], packs[1][0] if num_levels == 2 else None, rays_o, rays_d, viewdirs, near, far,
+                                              white_bkgd, num_levels, t_rand, u)
+            ctx.fused = (ws, [pk[1] for pk in packs], [pk[0] for pk in packs])
+            return tuple(x for lvl in levels for x in lvl)
+        ctx.fused = None
         saved, outs = [], []
         t_vals = weights = None
         for lvl in range(num_levels):
@@ -35,14 +44,20 @@ class RenderVanilla(torch.autograd.Function):
             outs += [rgb, acc, depth]
             saved.append((raw, t_vals, planes, masks, packed_fwd, packed_bwd, packed_bwd_bf))
         ctx.saved = saved
-        ctx.rays_d = rays_d
-        ctx.white_bkgd = white_bkgd
-        ctx.num_levels = num_levels
         return tuple(outs)
 
     @staticmethod
     def backward(ctx, *gouts):
         grads = []
+        if ctx.fused is not None:               # ... and so is the whole backward (aon_render_bwd)
+            ws, packs_bwd, packs_fwd = ctx.fused
+            n = ctx.rays_d.shape[0]
+            g_rgb = [gouts[3 * l] if gouts[3 * l] is not None else torch.zeros((n, 3), dtype=torch.float32, device=ctx.rays_d.device)
+                     for l in range(ctx.num_levels)]
+            per_level = ops.render_bwd(ws, packs_bwd, packs_fwd, ctx.rays_d, ctx.white_bkgd, ctx.num_levels, g_rgb,
+                                       [gouts[3 * l + 1] for l in range(ctx.num_levels)], [gouts[3 * l + 2] for l in range(ctx.num_levels)])
+            ctx.fused = None
+            return (None,) * 10 + tuple(g[name] for g in per_level for name in ops.VANILLA_PARAM_ORDER)
         for lvl in range(ctx.num_levels):
             raw, t_vals, planes, masks, packed_fwd, packed_bwd, packed_bwd_bf = ctx.saved[lvl]
             g_rgb, g_acc, g_depth = gouts[3 * lvl: 3 * lvl + 3]
@@ -68,6 +83,16 @@ class RenderArticulated(torch.autograd.Function):
     def forward(ctx, rays_o, rays_d, viewdirs, near, far, white_bkgd, num_levels, t_rand, u, packs, lat_density, lat_color,
                 lat_articulation, *params):
         # packs: per level (packed_fwd, small, packed_bwd); params: 40 tensors per level in ops.ART_PARAM_ORDER
+        ctx.rays_d, ctx.white_bkgd, ctx.num_levels = rays_d, white_bkgd, num_levels
+        ctx.latents = {"density": lat_density.detach(), "color": lat_color.detach(), "articulation": lat_articulation.detach()}
+        ctx.lat_shapes = (lat_density.shape, lat_color.shape, lat_articulation.shape)
+        ctx.params = [p.detach() for p in params]
+        if all(len(pk) == 3 for pk in packs):   # exact-fp32 engine: ONE C call (aon_art_render_fwd_train)
+            levels, ws = ops.render_fwd_train(packs[0][0], packs[1][0] if num_levels == 2 else None, rays_o, rays_d, viewdirs, near, far,
+                                              white_bkgd, num_levels, t_rand, u, small_c=packs[0][1], small_f=packs[1][1] if num_levels == 2 else None)
+            ctx.fused = (ws, [pk[2] for pk in packs], [pk[1] for pk in packs])
+            return tuple(x for lvl in levels for x in lvl)
+        ctx.fused = None
         saved, outs = [], []
         t_vals = weights = None
         for lvl in range(num_levels):
@@ -86,10 +111,6 @@ class RenderArticulated(torch.autograd.Function):
             outs += [rgb, acc, depth]
             saved.append((raw, t_vals, planes, masks, small, packed_bwd, packed_bwd_bf))
         ctx.saved = saved
-        ctx.rays_d, ctx.white_bkgd, ctx.num_levels = rays_d, white_bkgd, num_levels
-        ctx.latents = {"density": lat_density.detach(), "color": lat_color.detach(), "articulation": lat_articulation.detach()}
-        ctx.lat_shapes = (lat_density.shape, lat_color.shape, lat_articulation.shape)
-        ctx.params = [p.detach() for p in params]
         return tuple(outs)
 
     @staticmethod
@@ -97,6 +118,18 @@ class RenderArticulated(torch.autograd.Function):
         grads = []
         g_lat_tot = None
         n_per = len(ops.ART_PARAM_ORDER)
+        if ctx.fused is not None:               # the whole backward in ONE C call (aon_art_render_bwd)
+            ws, packs_bwd, smalls = ctx.fused
+            n = ctx.rays_d.shape[0]
+            g_rgb = [gouts[3 * l] if gouts[3 * l] is not None else torch.zeros((n, 3), dtype=torch.float32, device=ctx.rays_d.device)
+                     for l in range(ctx.num_levels)]
+            params = [dict(zip(ops.ART_PARAM_ORDER, ctx.params[l * n_per: (l + 1) * n_per])) for l in range(ctx.num_levels)]
+            per_level, g_lat = ops.art_render_bwd(ws, packs_bwd, smalls, ctx.rays_d, ctx.white_bkgd, ctx.num_levels, g_rgb,
+                                                  [gouts[3 * l + 1] for l in range(ctx.num_levels)], [gouts[3 * l + 2] for l in range(ctx.num_levels)],
+                                                  params, ctx.latents)
+            ctx.fused = None
+            lat = tuple(g_lat[k].reshape(shp) for k, shp in zip(("density", "color", "articulation"), ctx.lat_shapes))
+            return (None,) * 10 + lat + tuple(g[name] for g in per_level for name in ops.ART_PARAM_ORDER)
         for lvl in range(ctx.num_levels):
             raw, t_vals, planes, masks, small, packed_bwd, packed_bwd_bf = ctx.saved[lvl]
             g_rgb, g_acc, g_depth = gouts[3 * lvl: 3 * lvl + 3]

@@ -527,6 +527,231 @@ int aon_render_fwd(const void* packed_coarse, const void* packed_fine, const flo
                      u_stride, rgb_c, acc_c, depth_c, rgb_f, acc_f, depth_f, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
+// ---- training step in two calls (aon_render_fwd_train + aon_render_bwd) ----
+// The whole forward of NeRF.forward / NeRF_AE_Art.forward under grad mode, then the whole backward of the reference's
+// training loss, each as ONE C call on the exact-fp32 engine: the per-level staging that autograd.py used to drive from
+// Python (sample -> fused MLP + planes -> composite -> inverse CDF | composite backward -> chain -> weight gradients)
+// happens here.  Everything the backward needs stays in the caller's workspace between the two calls.
+namespace {
+
+struct TrainLevel {
+  float* t;        // n*S
+  float* raw;      // Np*4 (first n*S records valid)
+  float* planes;   // rows*Np
+  char* masks;     // mask_layers*Np*32
+  int S; int64_t Np;
+};
+struct TrainWs {
+  TrainLevel lvl[2];
+  float* w_c;      // n*65 coarse weights
+  float* d_raw;    // Np_max*4
+  float* dplanes;  // rows*Np_max
+  float* dxp;      // Np_max*4 (articulated)
+  float* wgrad_ws;
+  float* lat_tmp;  // 288 floats: second level's latent gradients before they are added (articulated)
+  int64_t bytes;
+};
+
+TrainWs carve_train(char* base, int64_t n, bool art) {
+  TrainWs w{};
+  const int64_t rows = art ? aon::kAPlRows : aon::kPlRows;
+  const int64_t mlayers = art ? aon::kAMaskLayers : aon::kMaskLayers;
+  int64_t off = 0;
+  auto take = [&](int64_t bytes) { char* p = base + off; off += align_up(bytes, 256); return p; };
+  int64_t np_max = 0;
+  for (int l = 0; l < 2; ++l) {
+    const int S = l == 0 ? kSc : kSf;
+    const int64_t Np = align_up(n * S, 128);
+    np_max = Np > np_max ? Np : np_max;
+    w.lvl[l].S = S; w.lvl[l].Np = Np;
+    w.lvl[l].t = reinterpret_cast<float*>(take(n * S * 4));
+    w.lvl[l].raw = reinterpret_cast<float*>(take(Np * 16));
+    w.lvl[l].planes = reinterpret_cast<float*>(take(rows * Np * 4));
+    w.lvl[l].masks = take(mlayers * Np * 32);
+  }
+  w.w_c = reinterpret_cast<float*>(take(n * kSc * 4));
+  w.d_raw = reinterpret_cast<float*>(take(np_max * 16));
+  w.dplanes = reinterpret_cast<float*>(take(rows * np_max * 4));
+  w.dxp = reinterpret_cast<float*>(take(np_max * 16));
+  w.wgrad_ws = reinterpret_cast<float*>(take(aon::wgrad_workspace_bytes()));
+  w.lat_tmp = reinterpret_cast<float*>(take(288 * 4));
+  w.bytes = off;
+  return w;
+}
+
+__global__ void add_into_kernel(float* __restrict__ dst, const float* __restrict__ src, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] += src[i];
+}
+
+struct TrainNet {   // one level's network handles
+  const void* packed_fwd; const float* small; const void* packed_bwd;
+};
+
+int train_fwd_impl(const char* who, bool art, const TrainNet* nets, const float* rays_o, const float* rays_d, const float* viewdirs,
+                   int64_t n, float near_, float far_, int white_bkgd, int num_levels, const float* t_rand, const float* u, int64_t u_stride,
+                   float* const* rgb, float* const* acc, float* const* depth, void* workspace, int64_t workspace_bytes, hipStream_t stream) {
+  if (n <= 0 || (num_levels != 1 && num_levels != 2)) return fail(AON_E_INVALID, "train forward: bad size / num_levels");
+  if (!rays_o || !rays_d || !viewdirs || !workspace) return fail(AON_E_INVALID, "train forward: null pointer");
+  if (reinterpret_cast<uintptr_t>(workspace) & 255) return fail(AON_E_INVALID, "train forward: workspace must be 256-byte aligned");
+  const TrainWs w = carve_train(static_cast<char*>(workspace), n, art);
+  if (w.bytes > workspace_bytes) return fail(AON_E_WORKSPACE, "train forward: workspace smaller than aon_train_workspace_bytes()");
+  if (num_levels == 2 && (!u || (u_stride != 0 && u_stride < 128))) return fail(AON_E_INVALID, "train forward: bad u / u_stride");
+  const int act = art ? AON_ACT_ARTICULATED : AON_ACT_VANILLA;
+  for (int l = 0; l < num_levels; ++l) {
+    const TrainLevel& L = w.lvl[l];
+    if (!nets[l].packed_fwd || (art && !nets[l].small) || !rgb[l] || !acc[l] || !depth[l]) return fail(AON_E_INVALID, "train forward: null level pointer");
+    int rc;
+    if (l == 0) {
+      rc = check(aon::launch_sample_along_rays(rays_o, rays_d, n, kSc, near_, far_, t_rand, L.t, nullptr, stream), who);
+    } else {
+      KTimer timer(kSamplePdf, stream, n);
+      rc = check(aon::launch_sample_pdf(nullptr, w.w_c + 1, kSc, w.lvl[0].t, u, u_stride, n, nullptr, L.t, stream), who);
+    }
+    if (rc) return rc;
+    {
+      MlpTimer timer(stream, n * L.S);
+      rc = check(art ? aon::launch_art_mlp_fwd_train(static_cast<const char*>(nets[l].packed_fwd), nets[l].small, rays_o, rays_d, viewdirs, L.t, n, L.S,
+                                                     L.raw, L.planes, L.masks, stream)
+                     : aon::launch_mlp_fwd_train(static_cast<const char*>(nets[l].packed_fwd), rays_o, rays_d, viewdirs, L.t, n, L.S, L.raw, L.planes,
+                                                 L.masks, stream), who);
+    }
+    if (rc) return rc;
+    {
+      KTimer timer(kComposite, stream, n);
+      rc = check(aon::launch_composite(L.raw, 4, L.raw + 3, 4, L.t, rays_d, n, L.S, white_bkgd, act, rgb[l], acc[l], depth[l],
+                                       (l == 0 && num_levels == 2) ? w.w_c : nullptr, stream), who);
+    }
+    if (rc) return rc;
+  }
+  return AON_OK;
+}
+
+}  // namespace
+
+int64_t aon_train_workspace_bytes(int64_t n_rays, int articulated) {
+  if (n_rays < 1) n_rays = 1;
+  return carve_train(nullptr, n_rays, articulated != 0).bytes;
+}
+
+int aon_render_fwd_train(const void* packed_coarse, const void* packed_fine, const float* rays_o, const float* rays_d, const float* viewdirs,
+                         int64_t n_rays, float near_, float far_, int white_bkgd, int num_levels, const float* t_rand, const float* u,
+                         int64_t u_stride, float* rgb_c, float* acc_c, float* depth_c, float* rgb_f, float* acc_f, float* depth_f,
+                         void* workspace, int64_t workspace_bytes, void* stream) {
+  const TrainNet nets[2] = {{packed_coarse, nullptr, nullptr}, {packed_fine, nullptr, nullptr}};
+  float* const rgb[2] = {rgb_c, rgb_f}; float* const acc[2] = {acc_c, acc_f}; float* const dep[2] = {depth_c, depth_f};
+  return train_fwd_impl("aon_render_fwd_train", false, nets, rays_o, rays_d, viewdirs, n_rays, near_, far_, white_bkgd, num_levels, t_rand, u,
+                        u_stride, rgb, acc, dep, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int aon_art_render_fwd_train(const void* packed_coarse, const void* small_coarse, const void* packed_fine, const void* small_fine,
+                             const float* rays_o, const float* rays_d, const float* viewdirs, int64_t n_rays, float near_, float far_,
+                             int white_bkgd, int num_levels, const float* t_rand, const float* u, int64_t u_stride, float* rgb_c,
+                             float* acc_c, float* depth_c, float* rgb_f, float* acc_f, float* depth_f, void* workspace,
+                             int64_t workspace_bytes, void* stream) {
+  const TrainNet nets[2] = {{packed_coarse, static_cast<const float*>(small_coarse), nullptr}, {packed_fine, static_cast<const float*>(small_fine), nullptr}};
+  float* const rgb[2] = {rgb_c, rgb_f}; float* const acc[2] = {acc_c, acc_f}; float* const dep[2] = {depth_c, depth_f};
+  return train_fwd_impl("aon_art_render_fwd_train", true, nets, rays_o, rays_d, viewdirs, n_rays, near_, far_, white_bkgd, num_levels, t_rand, u,
+                        u_stride, rgb, acc, dep, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int aon_render_bwd(const void* packed_bwd_coarse, const void* packed_fwd_coarse, const void* packed_bwd_fine, const void* packed_fwd_fine,
+                   const float* rays_d, int64_t n_rays, int white_bkgd, int num_levels, const float* const* g_rgb_host,
+                   const float* const* g_acc_host, const float* const* g_depth_host, float* const* grads_coarse_host,
+                   float* const* grads_fine_host, void* workspace, int64_t workspace_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (n_rays <= 0 || (num_levels != 1 && num_levels != 2)) return fail(AON_E_INVALID, "aon_render_bwd: bad size / num_levels");
+  if (!rays_d || !g_rgb_host || !workspace || !grads_coarse_host) return fail(AON_E_INVALID, "aon_render_bwd: null pointer");
+  const TrainWs w = carve_train(static_cast<char*>(workspace), n_rays, false);
+  if (w.bytes > workspace_bytes) return fail(AON_E_WORKSPACE, "aon_render_bwd: workspace smaller than aon_train_workspace_bytes()");
+  const void* pb[2] = {packed_bwd_coarse, packed_bwd_fine};
+  const void* pf[2] = {packed_fwd_coarse, packed_fwd_fine};
+  float* const* grads[2] = {grads_coarse_host, grads_fine_host};
+  for (int l = 0; l < num_levels; ++l) {
+    const TrainLevel& L = w.lvl[l];
+    if (!pb[l] || !pf[l] || !grads[l] || !g_rgb_host[l]) return fail(AON_E_INVALID, "aon_render_bwd: null level pointer");
+    for (int i = 0; i < aon::kNumVanillaParams; ++i)
+      if (!grads[l][i]) return fail(AON_E_INVALID, "aon_render_bwd: null gradient pointer");
+    const int64_t valid = n_rays * L.S;
+    int rc = check(hipMemsetAsync(w.d_raw + valid * 4, 0, (size_t)(L.Np - valid) * 16, stream), "aon_render_bwd");
+    if (rc) return rc;
+    {
+      KTimer timer(kCompositeBwd, stream, n_rays);
+      rc = check(aon::launch_composite_bwd(L.raw, L.t, rays_d, g_rgb_host[l], g_acc_host ? g_acc_host[l] : nullptr, g_depth_host ? g_depth_host[l] : nullptr,
+                                           n_rays, L.S, white_bkgd, AON_ACT_VANILLA, w.d_raw, stream), "aon_render_bwd");
+    }
+    if (rc) return rc;
+    {
+      KTimer timer(kBwdChain, stream, L.Np);
+      rc = check(aon::launch_mlp_bwd_chain(static_cast<const char*>(pb[l]), static_cast<const char*>(pf[l]), w.d_raw, L.masks, w.dplanes, L.Np, stream),
+                 "aon_render_bwd");
+    }
+    if (rc) return rc;
+    {
+      KTimer timer(kWgrad, stream, L.Np);
+      rc = check(aon::launch_vanilla_wgrad(L.planes, w.dplanes, w.d_raw, L.Np, grads[l], w.wgrad_ws, stream), "aon_render_bwd");
+    }
+    if (rc) return rc;
+  }
+  return AON_OK;
+}
+
+int aon_art_render_bwd(const void* packed_bwd_coarse, const void* small_coarse, const void* packed_bwd_fine, const void* small_fine,
+                       const float* rays_d, int64_t n_rays, int white_bkgd, int num_levels, const float* const* g_rgb_host,
+                       const float* const* g_acc_host, const float* const* g_depth_host, const float* const* params_coarse_host,
+                       const float* const* params_fine_host, const float* shape, const float* appearance, const float* articulation,
+                       float* const* grads_coarse_host, float* const* grads_fine_host, float* g_shape, float* g_appearance,
+                       float* g_articulation, void* workspace, int64_t workspace_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (n_rays <= 0 || (num_levels != 1 && num_levels != 2)) return fail(AON_E_INVALID, "aon_art_render_bwd: bad size / num_levels");
+  if (!rays_d || !g_rgb_host || !workspace || !grads_coarse_host || !params_coarse_host || !shape || !appearance || !articulation || !g_shape ||
+      !g_appearance || !g_articulation)
+    return fail(AON_E_INVALID, "aon_art_render_bwd: null pointer");
+  const TrainWs w = carve_train(static_cast<char*>(workspace), n_rays, true);
+  if (w.bytes > workspace_bytes) return fail(AON_E_WORKSPACE, "aon_art_render_bwd: workspace smaller than aon_train_workspace_bytes()");
+  const void* pb[2] = {packed_bwd_coarse, packed_bwd_fine};
+  const float* sm[2] = {static_cast<const float*>(small_coarse), static_cast<const float*>(small_fine)};
+  const float* const* params[2] = {params_coarse_host, params_fine_host};
+  float* const* grads[2] = {grads_coarse_host, grads_fine_host};
+  for (int l = 0; l < num_levels; ++l) {
+    const TrainLevel& L = w.lvl[l];
+    if (!pb[l] || !sm[l] || !grads[l] || !params[l] || !g_rgb_host[l]) return fail(AON_E_INVALID, "aon_art_render_bwd: null level pointer");
+    for (int i = 0; i < 40; ++i)
+      if (!grads[l][i] || !params[l][i]) return fail(AON_E_INVALID, "aon_art_render_bwd: null parameter / gradient pointer");
+    const int64_t valid = n_rays * L.S;
+    int rc = check(hipMemsetAsync(w.d_raw + valid * 4, 0, (size_t)(L.Np - valid) * 16, stream), "aon_art_render_bwd");
+    if (rc) return rc;
+    {
+      KTimer timer(kCompositeBwd, stream, n_rays);
+      rc = check(aon::launch_composite_bwd(L.raw, L.t, rays_d, g_rgb_host[l], g_acc_host ? g_acc_host[l] : nullptr, g_depth_host ? g_depth_host[l] : nullptr,
+                                           n_rays, L.S, white_bkgd, AON_ACT_ARTICULATED, w.d_raw, stream), "aon_art_render_bwd");
+    }
+    if (rc) return rc;
+    {
+      KTimer timer(kBwdChain, stream, L.Np);
+      rc = check(aon::launch_art_bwd_chain(static_cast<const char*>(pb[l]), sm[l], w.d_raw, L.masks, L.planes, w.dplanes, w.dxp, L.Np, stream),
+                 "aon_art_render_bwd");
+    }
+    if (rc) return rc;
+    {
+      KTimer timer(kWgrad, stream, L.Np);
+      // level 0 writes the latent gradients, level 1 adds its own (both MLPs see the same latents)
+      float* gs = l == 0 ? g_shape : w.lat_tmp, *ga = l == 0 ? g_appearance : w.lat_tmp + 128, *gt = l == 0 ? g_articulation : w.lat_tmp + 256;
+      rc = check(aon::launch_art_wgrad(L.planes, w.dplanes, w.d_raw, w.dxp, L.Np, params[l], shape, appearance, articulation, grads[l], gs, ga, gt,
+                                       w.wgrad_ws, stream), "aon_art_render_bwd");
+      if (rc) return rc;
+      if (l == 1) {
+        add_into_kernel<<<dim3(1), dim3(128), 0, stream>>>(g_shape, w.lat_tmp, 128);
+        add_into_kernel<<<dim3(1), dim3(128), 0, stream>>>(g_appearance, w.lat_tmp + 128, 128);
+        add_into_kernel<<<dim3(1), dim3(32), 0, stream>>>(g_articulation, w.lat_tmp + 256, 32);
+        rc = check(hipGetLastError(), "aon_art_render_bwd");
+      }
+    }
+    if (rc) return rc;
+  }
+  return AON_OK;
+}
+
 // ---- opt-in split-bf16 engine (fp32-equivalent arithmetic on the bf16 matrix pipe; see aon_mlp_bf16.hip) ----
 int aon_mlp_fwd_train_bf16x3(const void* packed_bf16x3, const float* rays_o, const float* rays_d, const float* viewdirs,
                              const float* t_vals, int64_t n_rays, int S, float* raw, float* planes, void* masks, void* stream) {

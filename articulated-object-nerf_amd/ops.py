@@ -637,6 +637,86 @@ def art_wgrad(planes, dplanes, d_raw, dxp, params: dict, latents: dict):
     return grads, g_lat
 
 
+# ------------------------------------------------------------------ R14 training step in two C calls
+def train_workspace(device, n_rays: int, articulated: bool) -> torch.Tensor:
+    """Fresh workspace of one training forward/backward pair (it carries the forward's planes to the backward, so it is
+    owned by the autograd graph, not cached)."""
+    return torch.empty(int(lib.aon_train_workspace_bytes(n_rays, int(articulated))), dtype=torch.uint8, device=device)
+
+
+def _level_outs(n, dev, num_levels):
+    outs = [(torch.empty((n, 3), dtype=torch.float32, device=dev), torch.empty((n,), dtype=torch.float32, device=dev),
+             torch.empty((n,), dtype=torch.float32, device=dev)) for _ in range(num_levels)]
+    return outs, (outs[1] if num_levels == 2 else (None, None, None))
+
+
+def render_fwd_train(packed_c, packed_f, rays_o, rays_d, viewdirs, near, far, white_bkgd, num_levels, t_rand, u, small_c=None, small_f=None):
+    """NeRF.forward / NeRF_AE_Art.forward (small blocks given) under grad mode in ONE C call -> (outs, workspace)."""
+    o, d, v = _f32(rays_o, "rays_o"), _f32(rays_d, "rays_d"), _f32(viewdirs, "viewdirs")
+    n, dev = o.shape[0], o.device
+    art = small_c is not None
+    tr = None if t_rand is None else _f32(t_rand, "t_rand")
+    if tr is not None and tuple(tr.shape) != (n, 65):
+        raise ValueError(f"t_rand must be ({n},65)")
+    uu, us = _u_args(u, n, dev) if num_levels == 2 else (None, 0)
+    outs, fine = _level_outs(n, dev, num_levels)
+    ws = train_workspace(dev, n, art)
+    common = (_ptr(o), _ptr(d), _ptr(v), n, float(near), float(far), int(bool(white_bkgd)), num_levels, _ptr(tr), _ptr(uu), us,
+              _ptr(outs[0][0]), _ptr(outs[0][1]), _ptr(outs[0][2]), _ptr(fine[0]), _ptr(fine[1]), _ptr(fine[2]), _ptr(ws), ws.numel(), _stream())
+    with torch.cuda.device(dev):
+        if art:
+            check(lib.aon_art_render_fwd_train(_ptr(packed_c), _ptr(small_c), _ptr(packed_f), _ptr(small_f), *common), "aon_art_render_fwd_train")
+        else:
+            check(lib.aon_render_fwd_train(_ptr(packed_c), _ptr(packed_f), *common), "aon_render_fwd_train")
+    return outs, ws
+
+
+def _ptr_array(tensors):
+    return (C.c_void_p * len(tensors))(*[0 if t is None else t.data_ptr() for t in tensors])
+
+
+def render_bwd(ws, packs_bwd, packs_fwd, rays_d, white_bkgd, num_levels, g_rgb, g_acc, g_depth):
+    """loss.backward() through render_fwd_train (vanilla): g_* = per-level lists (entries may be None except g_rgb)
+    -> per-level dicts of the 24 parameter gradients."""
+    d = _f32(rays_d, "rays_d")
+    n, dev = d.shape[0], d.device
+    grads = [{name: torch.empty(VANILLA_PARAM_SHAPES[name], dtype=torch.float32, device=dev) for name in VANILLA_PARAM_ORDER} for _ in range(num_levels)]
+    garr = [_ptr_array([g[nm] for nm in VANILLA_PARAM_ORDER]) for g in grads] + [None] * (2 - num_levels)
+    pb, pf = list(packs_bwd) + [None] * (2 - num_levels), list(packs_fwd) + [None] * (2 - num_levels)
+    keep = [None if t is None else _f32(t, "grad") for t in list(g_rgb) + list(g_acc) + list(g_depth)]
+    k = num_levels
+    with torch.cuda.device(dev):
+        check(lib.aon_render_bwd(_ptr(pb[0]), _ptr(pf[0]), _ptr(pb[1]), _ptr(pf[1]), _ptr(d), n, int(bool(white_bkgd)), num_levels,
+                                 _ptr_array(keep[:k]), _ptr_array(keep[k:2 * k]), _ptr_array(keep[2 * k:3 * k]), garr[0], garr[1], _ptr(ws), ws.numel(),
+                                 _stream()), "aon_render_bwd")
+    return grads
+
+
+def art_render_bwd(ws, packs_bwd, smalls, rays_d, white_bkgd, num_levels, g_rgb, g_acc, g_depth, params_per_level, latents: dict):
+    """Articulated twin -> (per-level dicts of the 40 parameter gradients, dict of latent gradients summed over the levels)."""
+    d = _f32(rays_d, "rays_d")
+    n, dev = d.shape[0], d.device
+    grads = [{name: torch.empty(ART_PARAM_SHAPES[name], dtype=torch.float32, device=dev) for name in ART_PARAM_ORDER} for _ in range(num_levels)]
+    garr = [_ptr_array([g[nm] for nm in ART_PARAM_ORDER]) for g in grads] + [None] * (2 - num_levels)
+    tens, parr = [], []
+    for params in params_per_level:
+        t, arr = _art_param_array(params)
+        tens.append(t)
+        parr.append(arr)
+    parr += [None] * (2 - num_levels)
+    pb, sm = list(packs_bwd) + [None] * (2 - num_levels), list(smalls) + [None] * (2 - num_levels)
+    shape, app, art = _latent(latents, "density", 128), _latent(latents, "color", 128), _latent(latents, "articulation", 32)
+    g_lat = {"density": torch.empty(128, device=dev), "color": torch.empty(128, device=dev), "articulation": torch.empty(32, device=dev)}
+    keep = [None if t is None else _f32(t, "grad") for t in list(g_rgb) + list(g_acc) + list(g_depth)]
+    k = num_levels
+    with torch.cuda.device(dev):
+        check(lib.aon_art_render_bwd(_ptr(pb[0]), _ptr(sm[0]), _ptr(pb[1]), _ptr(sm[1]), _ptr(d), n, int(bool(white_bkgd)), num_levels,
+                                     _ptr_array(keep[:k]), _ptr_array(keep[k:2 * k]), _ptr_array(keep[2 * k:3 * k]), parr[0], parr[1],
+                                     _ptr(shape), _ptr(app), _ptr(art), garr[0], garr[1], _ptr(g_lat["density"]), _ptr(g_lat["color"]),
+                                     _ptr(g_lat["articulation"]), _ptr(ws), ws.numel(), _stream()), "aon_art_render_bwd")
+    return grads, g_lat
+
+
 # ------------------------------------------------------------------ measurement aid
 def profile_begin() -> None:
     check(lib.aon_profile_begin(), "aon_profile_begin")
