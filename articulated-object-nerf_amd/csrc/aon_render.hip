@@ -37,8 +37,9 @@ __device__ __forceinline__ float wave_inclusive_scan(float v, int /*lane*/) {
 // wave_shr:1 of a double (two 32-bit DPP moves), zero into lane 0
 __device__ __forceinline__ double dpp_shr1_f64(double v) {
   const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
-  const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)b, 0x138, 0xf, 0xf, false);
-  const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), 0x138, 0xf, 0xf, false);
+  // bound_ctrl: a lane without a source reads 0 -- no separate "old = 0" move per half per step
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)b, 0x138, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), 0x138, 0xf, 0xf, true);
   return __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
 }
 

@@ -348,11 +348,11 @@ hipError_t launch_vanilla_wgrad(const float* planes, const float* dplanes, const
   // heads and their biases
   int nseg; int64_t seg_len;
   head_segments(Np, nseg, seg_len);
-  head_wgrad_kernel<<<dim3(256, nseg), dim3(256), 0, stream>>>(P(plane_h(7)), Np, d_raw, seg_len, head_partial, 256);
+  head_wgrad_kernel<<<dim3((256 + kHeadRows - 1) / kHeadRows, nseg), dim3(256), 0, stream>>>(P(plane_h(7)), Np, d_raw, seg_len, head_partial, 256);
   head_reduce_kernel<<<dim3(1), dim3(256), 0, stream>>>(head_partial, nseg, 256, 3, 1, grads[20], 256);   // density_layer.weight (1,256)
-  head_wgrad_kernel<<<dim3(128, nseg), dim3(256), 0, stream>>>(P(kPlHV), Np, d_raw, seg_len, head_partial, 128);
+  head_wgrad_kernel<<<dim3((128 + kHeadRows - 1) / kHeadRows, nseg), dim3(256), 0, stream>>>(P(kPlHV), Np, d_raw, seg_len, head_partial, 128);
   head_reduce_kernel<<<dim3(2), dim3(256), 0, stream>>>(head_partial, nseg, 128, 0, 3, grads[22], 128);  // rgb_layer.weight (3,128)
-  head_wgrad_kernel<<<dim3(1, nseg), dim3(256), 0, stream>>>(nullptr, Np, d_raw, seg_len, head_partial, 1);
+  head_wgrad_kernel<<<dim3((1 + kHeadRows - 1) / kHeadRows, nseg), dim3(256), 0, stream>>>(nullptr, Np, d_raw, seg_len, head_partial, 1);
   head_reduce_kernel<<<dim3(1), dim3(256), 0, stream>>>(head_partial, nseg, 1, 3, 1, grads[21], 1);      // density_layer.bias (1,)
   head_reduce_kernel<<<dim3(1), dim3(256), 0, stream>>>(head_partial, nseg, 1, 0, 3, grads[23], 1);      // rgb_layer.bias (3,)
   return hipGetLastError();

@@ -146,13 +146,14 @@ __global__ void __launch_bounds__(256) art_bwd_chain_kernel(ArtBwdArgs args) {
     f32x16 X[8], Y[8];
     AON_ABWD_LAYER(4, 8, Z0, X, kABwV0, aplane_v(0), 11)   // X = d bottleneck (no activation)
     // ---- trunk ----
+    const float dsig = args.d_raw[col * 4 + 3];   // re-read here (L2-hot) instead of carried through the view branch
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
 #pragma unroll
       for (int gq = 0; gq < 4; ++gq) {
         const f32x4 w = *reinterpret_cast<const f32x4*>(sm + kA_WSIG + 32 * t + 8 * gq + 4 * hl);
 #pragma unroll
-        for (int cc = 0; cc < 4; ++cc) Y[t][4 * gq + cc] = w[cc] * dr.w;
+        for (int cc = 0; cc < 4; ++cc) Y[t][4 * gq + cc] = w[cc] * dsig;
       }
     }
     dense_layer<N, kABwBott, 8, 8>(p, X, Y, BwdSideOf<8, false>{X, dp(kAPlBot), io, tile_bytes, mk});   // Y = dH7
@@ -343,16 +344,16 @@ hipError_t launch_art_wgrad(const float* planes, const float* dplanes, const flo
   // heads: density (H7 x d_raw.w), rgb (V3 x d_raw.xyz), deformation_layer (D3 x dx') and their biases
   int nseg; int64_t seg_len;
   head_segments(Np, nseg, seg_len);
-  head_wgrad_kernel<<<dim3(256, nseg), dim3(256), 0, stream>>>(P(aplane_h(7)), Np, d_raw, seg_len, w.head_partial, 256);
+  head_wgrad_kernel<<<dim3((256 + kHeadRows - 1) / kHeadRows, nseg), dim3(256), 0, stream>>>(P(aplane_h(7)), Np, d_raw, seg_len, w.head_partial, 256);
   head_reduce_kernel<<<dim3(1), dim3(256), 0, stream>>>(w.head_partial, nseg, 256, 3, 1, grads[36], 256);
-  head_wgrad_kernel<<<dim3(128, nseg), dim3(256), 0, stream>>>(P(aplane_v(3)), Np, d_raw, seg_len, w.head_partial, 128);
+  head_wgrad_kernel<<<dim3((128 + kHeadRows - 1) / kHeadRows, nseg), dim3(256), 0, stream>>>(P(aplane_v(3)), Np, d_raw, seg_len, w.head_partial, 128);
   head_reduce_kernel<<<dim3(2), dim3(256), 0, stream>>>(w.head_partial, nseg, 128, 0, 3, grads[38], 128);
-  head_wgrad_kernel<<<dim3(1, nseg), dim3(256), 0, stream>>>(nullptr, Np, d_raw, seg_len, w.head_partial, 1);
+  head_wgrad_kernel<<<dim3((1 + kHeadRows - 1) / kHeadRows, nseg), dim3(256), 0, stream>>>(nullptr, Np, d_raw, seg_len, w.head_partial, 1);
   head_reduce_kernel<<<dim3(1), dim3(256), 0, stream>>>(w.head_partial, nseg, 1, 3, 1, grads[37], 1);
   head_reduce_kernel<<<dim3(1), dim3(256), 0, stream>>>(w.head_partial, nseg, 1, 0, 3, grads[39], 1);
-  head_wgrad_kernel<<<dim3(128, nseg), dim3(256), 0, stream>>>(P(aplane_d(3)), Np, dxp, seg_len, w.head_partial, 128);
+  head_wgrad_kernel<<<dim3((128 + kHeadRows - 1) / kHeadRows, nseg), dim3(256), 0, stream>>>(P(aplane_d(3)), Np, dxp, seg_len, w.head_partial, 128);
   head_reduce_kernel<<<dim3(2), dim3(256), 0, stream>>>(w.head_partial, nseg, 128, 0, 3, grads[8], 128);
-  head_wgrad_kernel<<<dim3(1, nseg), dim3(256), 0, stream>>>(nullptr, Np, dxp, seg_len, w.head_partial, 1);
+  head_wgrad_kernel<<<dim3((1 + kHeadRows - 1) / kHeadRows, nseg), dim3(256), 0, stream>>>(nullptr, Np, dxp, seg_len, w.head_partial, 1);
   head_reduce_kernel<<<dim3(1), dim3(256), 0, stream>>>(w.head_partial, nseg, 1, 0, 3, grads[9], 1);
   // latent columns of the weights: dW[:, latent cols] = db (x) latent
   outer_kernel<<<dim3((128 * 128 + 255) / 256), dim3(256), 0, stream>>>(grads[1], shape, 128, 128, grads[0], 163, 3);

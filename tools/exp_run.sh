@@ -1,4 +1,5 @@
 cd $GRAFT_REPO_ROOT
-python -m pytest tests -q -m gpu 2>&1 | grep -E "^(FAILED|ERROR)|passed|failed|^E  " | head -20
-python tools/train_bench.py --rays 4096 --steps 10 --articulated | tail -1
-python tools/train_bench.py --rays 4096 --steps 10 | tail -1
+python -m pytest tests/test_hip_parity.py -q -m gpu 2>&1 | grep -E "^(FAILED|ERROR)|passed|failed|^E  " | head -20
+cd /tmp && export TMPDIR=/tmp
+timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/pp -o x -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-alt --no-train-leg --no-extra-legs > /tmp/log 2>&1
+cd $GRAFT_REPO_ROOT && python tools/roofline_table.py /tmp/pp/*results.db | grep -v mlp
