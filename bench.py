@@ -258,7 +258,7 @@ def train_leg(dev, rank, world, distributed, steps=3, n_rays=4096):
             ops.profile_end()
             if distributed:
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            return t.item() / steps, float(loss), ops.profile_classes()
+            return t.item() / steps, float(loss.detach()), ops.profile_classes()
 
         dt, loss, classes = timed()
         samples = n_rays * EVALS_PER_RAY
