@@ -544,10 +544,11 @@ struct TrainLevel {
 struct TrainWs {
   TrainLevel lvl[2];
   float* w_c;      // n*65 coarse weights
-  float* d_raw;    // Np_max*4
-  float* dplanes;  // rows*Np_max
-  float* dxp;      // Np_max*4 (articulated)
-  float* wgrad_ws;
+  // backward temporaries, one set per level: the two levels' backward passes are independent and run on two streams
+  float* d_raw[2];    // Np*4
+  float* dplanes[2];  // rows*Np
+  float* dxp[2];      // Np*4 (articulated)
+  float* wgrad_ws[2];
   float* lat_tmp;  // 288 floats: second level's latent gradients before they are added (articulated)
   int64_t bytes;
 };
@@ -570,10 +571,13 @@ TrainWs carve_train(char* base, int64_t n, bool art) {
     w.lvl[l].masks = take(mlayers * Np * 32);
   }
   w.w_c = reinterpret_cast<float*>(take(n * kSc * 4));
-  w.d_raw = reinterpret_cast<float*>(take(np_max * 16));
-  w.dplanes = reinterpret_cast<float*>(take(rows * np_max * 4));
-  w.dxp = reinterpret_cast<float*>(take(np_max * 16));
-  w.wgrad_ws = reinterpret_cast<float*>(take(aon::wgrad_workspace_bytes()));
+  (void)np_max;
+  for (int l = 0; l < 2; ++l) {
+    w.d_raw[l] = reinterpret_cast<float*>(take(w.lvl[l].Np * 16));
+    w.dplanes[l] = reinterpret_cast<float*>(take(rows * w.lvl[l].Np * 4));
+    w.dxp[l] = reinterpret_cast<float*>(take(w.lvl[l].Np * 16));
+    w.wgrad_ws[l] = reinterpret_cast<float*>(take(aon::wgrad_workspace_bytes()));
+  }
   w.lat_tmp = reinterpret_cast<float*>(take(288 * 4));
   w.bytes = off;
   return w;
@@ -583,6 +587,31 @@ __global__ void add_into_kernel(float* __restrict__ dst, const float* __restrict
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) dst[i] += src[i];
 }
+
+// Two library-owned streams per device for the backward of the two levels (independent until the latent gradients are
+// added): kernels of one level fill the CUs the other level's tail rounds leave idle.  Ordered against the caller's stream by
+// events on both sides, so from the caller's view the whole backward is enqueued on its stream.
+struct LevelStreams {
+  hipStream_t s[2] = {nullptr, nullptr};
+  hipEvent_t fork = nullptr, join[2] = {nullptr, nullptr};
+};
+LevelStreams* level_streams() {
+  static LevelStreams per_dev[aon::kMaxDevices];
+  static std::mutex mu;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= aon::kMaxDevices) return nullptr;
+  std::lock_guard<std::mutex> lk(mu);
+  LevelStreams& ls = per_dev[dev];
+  if (!ls.fork) {
+    for (int i = 0; i < 2; ++i) {
+      if (hipStreamCreateWithFlags(&ls.s[i], hipStreamNonBlocking) != hipSuccess) return nullptr;
+      if (hipEventCreateWithFlags(&ls.join[i], hipEventDisableTiming) != hipSuccess) return nullptr;
+    }
+    if (hipEventCreateWithFlags(&ls.fork, hipEventDisableTiming) != hipSuccess) return nullptr;
+  }
+  return &ls;
+}
+int g_bwd_overlap = 1;
 
 struct TrainNet {   // one level's network handles
   const void* packed_fwd; const float* small; const void* packed_bwd;
@@ -629,6 +658,11 @@ int train_fwd_impl(const char* who, bool art, const TrainNet* nets, const float*
 
 }  // namespace
 
+int aon_set_bwd_overlap(int on) {
+  g_bwd_overlap = on ? 1 : 0;
+  return AON_OK;
+}
+
 int64_t aon_train_workspace_bytes(int64_t n_rays, int articulated) {
   if (n_rays < 1) n_rays = 1;
   return carve_train(nullptr, n_rays, articulated != 0).bytes;
@@ -667,31 +701,53 @@ int aon_render_bwd(const void* packed_bwd_coarse, const void* packed_fwd_coarse,
   const void* pb[2] = {packed_bwd_coarse, packed_bwd_fine};
   const void* pf[2] = {packed_fwd_coarse, packed_fwd_fine};
   float* const* grads[2] = {grads_coarse_host, grads_fine_host};
+  // fork: with two levels each runs on its own library stream, ordered after everything already enqueued on the caller's
+  LevelStreams* ls = (num_levels == 2 && g_bwd_overlap) ? level_streams() : nullptr;
+  hipStream_t caller = stream;
+  if (ls) {
+    int rc0 = check(hipEventRecord(ls->fork, caller), "aon_render_bwd");
+    if (rc0) return rc0;
+  }
   for (int l = 0; l < num_levels; ++l) {
     const TrainLevel& L = w.lvl[l];
+    if (ls) {
+      stream = ls->s[l];
+      int rc0 = check(hipStreamWaitEvent(stream, ls->fork, 0), "aon_render_bwd");
+      if (rc0) return rc0;
+    }
     if (!pb[l] || !pf[l] || !grads[l] || !g_rgb_host[l]) return fail(AON_E_INVALID, "aon_render_bwd: null level pointer");
     for (int i = 0; i < aon::kNumVanillaParams; ++i)
       if (!grads[l][i]) return fail(AON_E_INVALID, "aon_render_bwd: null gradient pointer");
     const int64_t valid = n_rays * L.S;
-    int rc = check(hipMemsetAsync(w.d_raw + valid * 4, 0, (size_t)(L.Np - valid) * 16, stream), "aon_render_bwd");
+    int rc = check(hipMemsetAsync(w.d_raw[l] + valid * 4, 0, (size_t)(L.Np - valid) * 16, stream), "aon_render_bwd");
     if (rc) return rc;
     {
       KTimer timer(kCompositeBwd, stream, n_rays);
       rc = check(aon::launch_composite_bwd(L.raw, L.t, rays_d, g_rgb_host[l], g_acc_host ? g_acc_host[l] : nullptr, g_depth_host ? g_depth_host[l] : nullptr,
-                                           n_rays, L.S, white_bkgd, AON_ACT_VANILLA, w.d_raw, stream), "aon_render_bwd");
+                                           n_rays, L.S, white_bkgd, AON_ACT_VANILLA, w.d_raw[l], stream), "aon_render_bwd");
     }
     if (rc) return rc;
     {
       KTimer timer(kBwdChain, stream, L.Np);
-      rc = check(aon::launch_mlp_bwd_chain(static_cast<const char*>(pb[l]), static_cast<const char*>(pf[l]), w.d_raw, L.masks, w.dplanes, L.Np, stream),
+      rc = check(aon::launch_mlp_bwd_chain(static_cast<const char*>(pb[l]), static_cast<const char*>(pf[l]), w.d_raw[l], L.masks, w.dplanes[l], L.Np, stream),
                  "aon_render_bwd");
     }
     if (rc) return rc;
     {
       KTimer timer(kWgrad, stream, L.Np);
-      rc = check(aon::launch_vanilla_wgrad(L.planes, w.dplanes, w.d_raw, L.Np, grads[l], w.wgrad_ws, stream), "aon_render_bwd");
+      rc = check(aon::launch_vanilla_wgrad(L.planes, w.dplanes[l], w.d_raw[l], L.Np, grads[l], w.wgrad_ws[l], stream), "aon_render_bwd");
     }
     if (rc) return rc;
+    if (ls) {
+      rc = check(hipEventRecord(ls->join[l], stream), "aon_render_bwd");
+      if (rc) return rc;
+    }
+  }
+  if (ls) {   // join: the caller's stream continues after both levels
+    for (int l = 0; l < 2; ++l) {
+      int rc = check(hipStreamWaitEvent(caller, ls->join[l], 0), "aon_render_bwd");
+      if (rc) return rc;
+    }
   }
   return AON_OK;
 }
@@ -713,23 +769,35 @@ int aon_art_render_bwd(const void* packed_bwd_coarse, const void* small_coarse, 
   const float* sm[2] = {static_cast<const float*>(small_coarse), static_cast<const float*>(small_fine)};
   const float* const* params[2] = {params_coarse_host, params_fine_host};
   float* const* grads[2] = {grads_coarse_host, grads_fine_host};
+  // fork: with two levels each runs on its own library stream, ordered after everything already enqueued on the caller's
+  LevelStreams* ls = (num_levels == 2 && g_bwd_overlap) ? level_streams() : nullptr;
+  hipStream_t caller = stream;
+  if (ls) {
+    int rc0 = check(hipEventRecord(ls->fork, caller), "aon_art_render_bwd");
+    if (rc0) return rc0;
+  }
   for (int l = 0; l < num_levels; ++l) {
     const TrainLevel& L = w.lvl[l];
+    if (ls) {
+      stream = ls->s[l];
+      int rc0 = check(hipStreamWaitEvent(stream, ls->fork, 0), "aon_art_render_bwd");
+      if (rc0) return rc0;
+    }
     if (!pb[l] || !sm[l] || !grads[l] || !params[l] || !g_rgb_host[l]) return fail(AON_E_INVALID, "aon_art_render_bwd: null level pointer");
     for (int i = 0; i < 40; ++i)
       if (!grads[l][i] || !params[l][i]) return fail(AON_E_INVALID, "aon_art_render_bwd: null parameter / gradient pointer");
     const int64_t valid = n_rays * L.S;
-    int rc = check(hipMemsetAsync(w.d_raw + valid * 4, 0, (size_t)(L.Np - valid) * 16, stream), "aon_art_render_bwd");
+    int rc = check(hipMemsetAsync(w.d_raw[l] + valid * 4, 0, (size_t)(L.Np - valid) * 16, stream), "aon_art_render_bwd");
     if (rc) return rc;
     {
       KTimer timer(kCompositeBwd, stream, n_rays);
       rc = check(aon::launch_composite_bwd(L.raw, L.t, rays_d, g_rgb_host[l], g_acc_host ? g_acc_host[l] : nullptr, g_depth_host ? g_depth_host[l] : nullptr,
-                                           n_rays, L.S, white_bkgd, AON_ACT_ARTICULATED, w.d_raw, stream), "aon_art_render_bwd");
+                                           n_rays, L.S, white_bkgd, AON_ACT_ARTICULATED, w.d_raw[l], stream), "aon_art_render_bwd");
     }
     if (rc) return rc;
     {
       KTimer timer(kBwdChain, stream, L.Np);
-      rc = check(aon::launch_art_bwd_chain(static_cast<const char*>(pb[l]), sm[l], w.d_raw, L.masks, L.planes, w.dplanes, w.dxp, L.Np, stream),
+      rc = check(aon::launch_art_bwd_chain(static_cast<const char*>(pb[l]), sm[l], w.d_raw[l], L.masks, L.planes, w.dplanes[l], w.dxp[l], L.Np, stream),
                  "aon_art_render_bwd");
     }
     if (rc) return rc;
@@ -737,17 +805,26 @@ int aon_art_render_bwd(const void* packed_bwd_coarse, const void* small_coarse, 
       KTimer timer(kWgrad, stream, L.Np);
       // level 0 writes the latent gradients, level 1 adds its own (both MLPs see the same latents)
       float* gs = l == 0 ? g_shape : w.lat_tmp, *ga = l == 0 ? g_appearance : w.lat_tmp + 128, *gt = l == 0 ? g_articulation : w.lat_tmp + 256;
-      rc = check(aon::launch_art_wgrad(L.planes, w.dplanes, w.d_raw, w.dxp, L.Np, params[l], shape, appearance, articulation, grads[l], gs, ga, gt,
-                                       w.wgrad_ws, stream), "aon_art_render_bwd");
-      if (rc) return rc;
-      if (l == 1) {
-        add_into_kernel<<<dim3(1), dim3(128), 0, stream>>>(g_shape, w.lat_tmp, 128);
-        add_into_kernel<<<dim3(1), dim3(128), 0, stream>>>(g_appearance, w.lat_tmp + 128, 128);
-        add_into_kernel<<<dim3(1), dim3(32), 0, stream>>>(g_articulation, w.lat_tmp + 256, 32);
-        rc = check(hipGetLastError(), "aon_art_render_bwd");
-      }
+      rc = check(aon::launch_art_wgrad(L.planes, w.dplanes[l], w.d_raw[l], w.dxp[l], L.Np, params[l], shape, appearance, articulation, grads[l], gs, ga, gt,
+                                       w.wgrad_ws[l], stream), "aon_art_render_bwd");
     }
     if (rc) return rc;
+    if (ls) {
+      rc = check(hipEventRecord(ls->join[l], stream), "aon_art_render_bwd");
+      if (rc) return rc;
+    }
+  }
+  if (ls) {   // join: the caller's stream continues after both levels
+    for (int l = 0; l < 2; ++l) {
+      int rc = check(hipStreamWaitEvent(caller, ls->join[l], 0), "aon_art_render_bwd");
+      if (rc) return rc;
+    }
+  }
+  if (num_levels == 2) {
+    add_into_kernel<<<dim3(1), dim3(128), 0, caller>>>(g_shape, w.lat_tmp, 128);
+    add_into_kernel<<<dim3(1), dim3(128), 0, caller>>>(g_appearance, w.lat_tmp + 128, 128);
+    add_into_kernel<<<dim3(1), dim3(32), 0, caller>>>(g_articulation, w.lat_tmp + 256, 32);
+    return check(hipGetLastError(), "aon_art_render_bwd");
   }
   return AON_OK;
 }

@@ -638,6 +638,11 @@ def art_wgrad(planes, dplanes, d_raw, dxp, params: dict, latents: dict):
 
 
 # ------------------------------------------------------------------ R14 training step in two C calls
+def set_bwd_overlap(on: bool) -> None:
+    """Two-level backward on two library streams (default on) or everything on the caller's stream."""
+    check(lib.aon_set_bwd_overlap(int(bool(on))), "aon_set_bwd_overlap")
+
+
 def train_workspace(device, n_rays: int, articulated: bool) -> torch.Tensor:
     """Fresh workspace of one training forward/backward pair (it carries the forward's planes to the backward, so it is
     owned by the autograd graph, not cached)."""

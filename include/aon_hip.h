@@ -232,7 +232,12 @@ int aon_art_wgrad(const float* planes, const float* dplanes, const float* d_raw,
  * aon_pack_vanilla_mlp, full nn.Linear shapes, overwritten).  packed_bwd_* from aon_pack_vanilla_mlp_bwd, packed_fwd_* the
  * forward streams (head weights).  Exact-fp32 engine.  The articulated twins (model_autodecoder.py:278-337, :395-477) take
  * the per-call small blocks of aon_art_prepare, the 40 parameters per level and the three latents, and also return the
- * latent gradients summed over the levels. */
+ * latent gradients summed over the levels.
+ * With two levels the backward of each level (independent of the other) runs on its own library-owned stream so that one
+ * level's kernels fill the CUs the other's tail rounds leave idle; both are ordered after everything already enqueued on
+ * `stream` and `stream` continues only after both (events) -- from the caller's view the call is enqueued on `stream`.
+ * aon_set_bwd_overlap(0) keeps everything on `stream` (default 1). */
+int aon_set_bwd_overlap(int on);
 int64_t aon_train_workspace_bytes(int64_t n_rays, int articulated);
 int aon_render_fwd_train(const void* packed_coarse, const void* packed_fine, const float* rays_o, const float* rays_d,
                          const float* viewdirs, int64_t n_rays, float near_, float far_, int white_bkgd, int num_levels,

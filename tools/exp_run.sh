@@ -1,5 +1,8 @@
-cd /tmp && export TMPDIR=/tmp
-for t in "" _rpw2 _rpw4; do
-rm -rf /tmp/pp; AON_HIP_LIB=$GRAFT_REPO_ROOT/articulated-object-nerf_amd/libaon_hip$t.so timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/pp -o x -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-alt --no-train-leg --no-extra-legs > /tmp/log 2>&1
-echo "== $t"; python $GRAFT_REPO_ROOT/tools/roofline_table.py /tmp/pp/*results.db | grep composite
+cd $GRAFT_REPO_ROOT
+python -m pytest tests/test_hip_training.py tests/test_hip_training_art.py tests/test_hip_smooth.py tests/test_hip_fuzz.py tests/test_harness.py tests/test_dataset_ckpt.py -q -m gpu 2>&1 | tail -2
+for i in 1 2; do
+python tools/train_bench.py --rays 4096 --steps 10 --articulated | tail -1 | cut -c1-120
+python tools/train_bench.py --rays 4096 --steps 10 --articulated --no-overlap | tail -1 | cut -c1-120
+python tools/train_bench.py --rays 4096 --steps 10 | tail -1 | cut -c1-120
+python tools/train_bench.py --rays 4096 --steps 10 --no-overlap | tail -1 | cut -c1-120
 done

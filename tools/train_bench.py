@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--train-engine", choices=["fp32", "bf16x3"], default="fp32")
+    ap.add_argument("--no-overlap", action="store_true", help="backward of both levels on the caller's stream (A/B of the two-stream backward)")
     ap.add_argument("--articulated", action="store_true", help="NeRF_AE_Art + CodeLibraryArticulated (BASELINE config 5 per GPU)")
     args = ap.parse_args()
     import aon_amd.synthetic as syn
@@ -28,6 +29,7 @@ def main():
 
     dev = torch.device("cuda:0")
     ops.set_train_engine(args.train_engine)
+    ops.set_bwd_overlap(not args.no_overlap)
     lib = None
     if args.articulated:
         import types
