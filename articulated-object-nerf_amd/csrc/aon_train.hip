@@ -341,9 +341,8 @@ hipError_t launch_vanilla_wgrad(const float* planes, const float* dplanes, const
   e = run_wgrad<2, 8>(D(kPlBot), P(plane_h(7)), Np, nparts, partial, bias_partial, grads[18], 256, 0, 256, grads[19], stream);
   if (e != hipSuccess) return e;
   // view layer: cat[bottleneck(256), viewenc(27)]
-  e = run_wgrad<1, 8>(D(kPlHV), P(kPlBot), Np, nparts, partial, bias_partial, grads[16], 256 + kViewEnc, 0, 256, grads[17], stream);
-  if (e != hipSuccess) return e;
-  e = run_wgrad<1, 1>(D(kPlHV), P(kPlVE), Np, nparts, partial, bias_partial, grads[16], 256 + kViewEnc, 256, kViewEnc, nullptr, stream);
+  static_assert(kPlVE == kPlBot + 256, "bottleneck and view-encoding rows must be adjacent");   // one 128 x 288 GEMM (see aon_train_art.hip)
+  e = run_wgrad<1, 9>(D(kPlHV), P(kPlBot), Np, nparts, partial, bias_partial, grads[16], 256 + kViewEnc, 0, 256 + kViewEnc, grads[17], stream);
   if (e != hipSuccess) return e;
   // heads and their biases
   int nseg; int64_t seg_len;

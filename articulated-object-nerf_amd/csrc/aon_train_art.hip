@@ -336,8 +336,10 @@ hipError_t launch_art_wgrad(const float* planes, const float* dplanes, const flo
   }
   AON_TRY((run_wgrad<2, 8>(D(kAPlBot), P(aplane_h(7)), Np, nparts, w.partial, w.bias_partial, grads[34], 256, 0, 256, grads[35], stream)));
   // view branch (:227-234): layer 0 input cat[bottleneck(256), viewenc(27), appearance(128)]
-  AON_TRY((run_wgrad<1, 8>(D(aplane_v(0)), P(kAPlBot), Np, nparts, w.partial, w.bias_partial, grads[26], 411, 0, 256, grads[27], stream)));
-  AON_TRY((run_wgrad<1, 1>(D(aplane_v(0)), P(kAPlVE), Np, nparts, w.partial, w.bias_partial, grads[26], 411, 256, kViewEnc, nullptr, stream)));
+  // (the 256 bottleneck rows and the 32 view-encoding rows are adjacent in the plane row map AND in the weight's columns: one
+  // 128 x 288 GEMM instead of a 128 x 256 and a 128 x 32 one that re-reads the 128 gradient rows)
+  static_assert(kAPlVE == kAPlBot + 256, "bottleneck and view-encoding rows must be adjacent");
+  AON_TRY((run_wgrad<1, 9>(D(aplane_v(0)), P(kAPlBot), Np, nparts, w.partial, w.bias_partial, grads[26], 411, 0, 256 + kViewEnc, grads[27], stream)));
   for (int l = 1; l < 4; ++l)
     AON_TRY((run_wgrad<1, 4>(D(aplane_v(l)), P(aplane_v(l - 1)), Np, nparts, w.partial, w.bias_partial, grads[26 + 2 * l], 128, 0, 128,
                              grads[27 + 2 * l], stream)));
