@@ -101,3 +101,31 @@ def test_engine_switch_and_bf16x3_entry_points_validate_without_gpu():
     assert lib.aon_art_mlp_fwd_train_bf16x3(None, None, None, None, None, None, 0, 65, None, None, None, None) == 0   # empty batch
     assert lib.aon_art_render_fwd_bf16x3(None, None, None, None, None, None, None, 5, 2.0, 6.0, 1, 3, None, None, 0, None, None, None, None,
                                          None, None, None, 0, None) != 0
+
+
+def test_two_call_training_entries_validate_without_gpu():
+    """aon_render_fwd_train / aon_render_bwd and the articulated twins: argument checking and workspace
+    sizing happen before any HIP call; aon_profile_class knows its classes."""
+    import ctypes as C
+
+    from aon_amd import _lib
+
+    lib = _lib.lib
+    van, art = lib.aon_train_workspace_bytes(4096, 0), lib.aon_train_workspace_bytes(4096, 1)
+    planes_van = 2528 * (128 * ((4096 * 65 + 127) // 128) + 128 * ((4096 * 193 + 127) // 128)) * 4
+    assert van > planes_van and art > van and lib.aon_train_workspace_bytes(2048, 0) < van
+    assert lib.aon_render_fwd_train(None, None, None, None, None, 0, 2.0, 6.0, 1, 2, None, None, 0, None, None, None, None, None, None,
+                                    None, 0, None) != 0 and b"bad size" in lib.aon_last_error()
+    assert lib.aon_render_fwd_train(None, None, None, None, None, 8, 2.0, 6.0, 1, 3, None, None, 0, None, None, None, None, None, None,
+                                    None, 0, None) != 0
+    assert lib.aon_render_fwd_train(None, None, None, None, None, 8, 2.0, 6.0, 1, 2, None, None, 0, None, None, None, None, None, None,
+                                    None, 0, None) != 0 and b"null" in lib.aon_last_error()
+    assert lib.aon_render_bwd(None, None, None, None, None, 8, 1, 2, None, None, None, None, None, None, 0, None) != 0 and b"null" in lib.aon_last_error()
+    assert lib.aon_art_render_bwd(None, None, None, None, None, 0, 1, 2, None, None, None, None, None, None, None, None, None, None, None, None,
+                                  None, None, 0, None) != 0
+    assert lib.aon_set_bwd_overlap(0) == 0 and lib.aon_set_bwd_overlap(1) == 0
+    ms, n, u = C.c_double(-1), C.c_int64(-1), C.c_int64(-1)
+    for cls in range(6):
+        assert lib.aon_profile_class(cls, C.byref(ms), C.byref(n), C.byref(u)) == 0 and ms.value == 0.0 and n.value == 0
+    assert lib.aon_profile_class(6, C.byref(ms), C.byref(n), C.byref(u)) != 0
+    assert lib.aon_ray_radii(None, None, 8, 8, None, None) != 0 and b"null" in lib.aon_last_error()

@@ -307,3 +307,51 @@ def test_training_trajectory_vs_oracle(dev):
         assert diff.max().item() <= 2.2 * steps * lr, (name, diff.max().item())
         worst = max(worst, diff.mean().item() / max(moved, 1e-6))
     print("worst mean-difference / movement:", worst)
+
+
+def test_two_call_step_equals_the_staged_entry_points(dev, nerf_sd):
+    """The training step through aon_render_fwd_train / aon_render_bwd (what the drop-in module runs) against the same step
+    assembled from the stage-level entry points: outputs and all 48 gradients bit for bit; and the two-stream backward equals
+    the single-stream one."""
+    import aon_amd.synthetic as syn
+    from aon_amd import ops
+    from aon_amd.models.vanilla_nerf.model import NeRF
+
+    n = 200
+    rays = {k: v.to(dev) for k, v in syn.random_rays(n, seed=31).items()}
+    gen = torch.Generator().manual_seed(31)
+    t_rand, u, target = (torch.rand(n, 65, generator=gen).to(dev), torch.rand(n, 128, generator=gen).to(dev), torch.rand(n, 3, generator=gen).to(dev))
+
+    def fused(overlap):
+        ops.set_bwd_overlap(overlap)
+        model = NeRF().to(dev)
+        model.load_state_dict(nerf_sd)
+        out = model(rays, True, False, 2.0, 6.0, t_rand=t_rand, u=u)
+        (torch.mean((out[0][0] - target) ** 2) + torch.mean((out[1][0] - target) ** 2)).backward()
+        return [o.detach() for lvl in out for o in lvl], {k: p.grad.clone() for k, p in model.named_parameters()}
+
+    try:
+        outs_a, grads_a = fused(True)
+        outs_b, grads_b = fused(False)
+    finally:
+        ops.set_bwd_overlap(True)
+    assert all(torch.equal(a, b) for a, b in zip(outs_a, outs_b))
+    assert all(torch.equal(grads_a[k], grads_b[k]) for k in grads_a)
+    # staged: the same launches driven from Python
+    outs_s, grads_s = [], {}
+    t_vals = weights = None
+    for lvl, name in enumerate(("coarse_mlp", "fine_mlp")):
+        params = {k[len(name) + 1:]: v.to(dev) for k, v in nerf_sd.items() if k.startswith(name + ".")}
+        pf, pb = ops.pack_vanilla_mlp(params), ops.pack_vanilla_mlp_bwd(params)
+        t_vals = ops.sample_along_rays(rays["rays_o"], rays["rays_d"], 64, 2.0, 6.0, t_rand, want_coords=False)[0] if lvl == 0 else ops.sample_pdf_t(t_vals, weights, u)
+        raw, planes, masks = ops.mlp_fwd_train(pf, rays["rays_o"], rays["rays_d"], rays["viewdirs"], t_vals)
+        rgb, acc, weights, depth = ops.composite_raw(raw, t_vals, rays["rays_d"], False, ops.ACT_VANILLA, want_weights=True)
+        outs_s += [rgb, acc, depth]
+        g_rgb = 2.0 * (rgb - target) / (3 * n)
+        d_raw = ops.composite_bwd(raw, t_vals, rays["rays_d"], g_rgb.contiguous(), None, None, False, ops.ACT_VANILLA, planes.shape[1])
+        dpl = ops.mlp_bwd_chain(pb, pf, d_raw, masks, planes.shape)
+        for k, v in ops.vanilla_wgrad(planes, dpl, d_raw).items():
+            grads_s[f"{name}.{k}"] = v
+    assert all(torch.equal(a, b) for a, b in zip(outs_a, outs_s))
+    for k in grads_a:
+        assert torch.equal(grads_a[k], grads_s[k]), k
