@@ -94,7 +94,6 @@ __global__ void __launch_bounds__(256) art_bwd_chain_kernel(ArtBwdArgs args) {
   float* sm = reinterpret_cast<float*>(smem + kRingBytes);
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
-  const int m = lane & 31, h = lane >> 5;
   {
     const f32x4* src = reinterpret_cast<const f32x4*>(args.small);
     f32x4* dst = reinterpret_cast<f32x4*>(sm);
@@ -103,15 +102,23 @@ __global__ void __launch_bounds__(256) art_bwd_chain_kernel(ArtBwdArgs args) {
   Pipe p;
   pipe_init<ArtBwdNet>(p, args.packed_bwd, smem, wave, lane);  // also publishes the small block just written to LDS
   using N = ArtBwdNet;
+  const int wave_s = __builtin_amdgcn_readfirstlane(wave);
 
   for (int pass = blockIdx.x; pass < args.npass; pass += gridDim.x) {
-    const int64_t col = (int64_t)pass * 128 + wave * 32 + m;
+    // Lane coordinates are RE-DERIVED once per pass (v_mbcnt + the wave index in an SGPR) instead of kept: with all 256 + 256
+    // registers taken by the two activation sets, every loop-invariant per-lane value -- the thread id itself, lane ^ 32, the
+    // 64-bit row offset built from it -- was hoisted out of the pass loop and spilled (24 B/lane of scratch).
+    int lane_p;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_p));
+    const int tid_p = (wave_s << 6) | lane_p;
+    const int m = lane_p & 31, h = lane_p >> 5;
+    const int64_t col = (int64_t)pass * 128 + (tid_p >> 6) * 32 + m;
     const PlaneIO io = make_plane_io(args.Np, col, h);
     const int64_t tile_bytes = 32 * io.row_bytes;
     auto dp = [&](int row) { return reinterpret_cast<float*>(reinterpret_cast<char*>(args.dplanes) + (int64_t)row * io.row_bytes); };
     // decision bits of a layer: fetched one layer ahead of their use, offset opaque so the load stays where it is written
     // (round 1 fetched all sixteen words up front: 64 registers held through the pass)
-    const unsigned moff = mask_lane_off(pass, tid);
+    const unsigned moff = mask_lane_off(pass, tid_p);
     auto load_mask = [&](int slot) { return *mask_ptr(args.masks, args.Np, slot, moff); };
     int hl = h;  // half-wave index for the LDS reads of head weights: opaque per pass (see mlp_bwd_chain_kernel)
     asm volatile("" : "+v"(hl));
@@ -199,7 +206,8 @@ __global__ void __launch_bounds__(256) art_bwd_chain_kernel(ArtBwdArgs args) {
     }
     if (h) dx[2] += dE[1][14]; else { dx[0] += dE[1][14]; dx[1] += dE[1][15]; }
 #pragma unroll
-    for (int a = 0; a < 3; ++a) dx[a] = dx[a] + __shfl_xor(dx[a], 32);
+    for (int a = 0; a < 3; ++a)   // + the other half-wave's partial (lane ^ 32, index from this pass's lane id)
+      dx[a] = dx[a] + __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((lane_p ^ 32) << 2, __builtin_bit_cast(int, dx[a])));
     if (h == 0) {
       float4 o; o.x = dx[0]; o.y = dx[1]; o.z = dx[2]; o.w = 0.f;
       reinterpret_cast<float4*>(args.dxp)[col] = o;
