@@ -305,6 +305,10 @@ def test_inverse_cdf_bit_exact_on_many_rows(ops, dev):
     w[600:800] = 0.0
     w[600:800, 31] = 1.0                                    # one bin
     w[800:1000] = torch.rand(200, 63, generator=gen) * 30   # large unnormalised weights
+    # weights over 17 decades: prefixes that are NOT exact in a double (the kernel's tree-scan fast path must then prove itself
+    # far from a float rounding boundary, or fall back to the index-order chain)
+    w[1000:4000] = torch.rand(3000, 63, generator=gen) * torch.exp(-40 * torch.rand(3000, 63, generator=gen))
+    w[4000:4200, 20:] *= 1e-30                              # a surface followed by vanishing weights
     t = torch.sort(torch.rand(n, 65, generator=gen) * 4 + 2, -1).values
     bins = 0.5 * (t[:, 1:] + t[:, :-1])
     u = torch.rand(n, 128, generator=gen)
@@ -314,6 +318,15 @@ def test_inverse_cdf_bit_exact_on_many_rows(ops, dev):
         assert torch.equal(got, want), f"{int((got != want).sum())} of {got.numel()} draws differ"
         tf = ops.sample_pdf_t(t.to(dev), w.to(dev), u=None if uu is None else uu.to(dev), bins=bins.to(dev)).cpu()
         assert torch.equal(tf, torch.sort(torch.cat([t, want], -1), -1).values)
+    # sorted random draws take the rank-merge fast path; bins unrelated to t_coarse make its rank walk start from a wrong guess
+    us = torch.sort(u, -1).values
+    want = orc.sorted_piecewise_constant_pdf(bins, w, 128, True, us)
+    tf = ops.sample_pdf_t(t.to(dev), w.to(dev), u=us.to(dev), bins=bins.to(dev)).cpu()
+    assert torch.equal(tf, torch.sort(torch.cat([t, want], -1), -1).values)
+    bins2 = torch.sort(torch.rand(n, 64, generator=gen) * 6 + 1, -1).values
+    want2 = orc.sorted_piecewise_constant_pdf(bins2, w, 128, True, us)
+    tf2 = ops.sample_pdf_t(t.to(dev), w.to(dev), u=us.to(dev), bins=bins2.to(dev)).cpu()
+    assert torch.equal(tf2, torch.sort(torch.cat([t, want2], -1), -1).values)
 
 
 def test_sample_pdf_merge(ops, dev, golden):

@@ -19,9 +19,13 @@ run rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -o $TAG -- pytho
 run rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -o $TAG -- python $REPO/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-train-leg --no-extra-legs --no-alt > $OUT/pmc_write.log 2>&1
 run rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES -d $OUT/pmc_sq -o $TAG -- python $REPO/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-train-leg --no-extra-legs --no-alt > $OUT/pmc_sq.log 2>&1
 run rocprofv3 --kernel-trace --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY -d $OUT/pmc_sq2 -o $TAG -- python $REPO/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-train-leg --no-extra-legs --no-alt > $OUT/pmc_sq2.log 2>&1
-# 3. training steps (BASELINE config 5 per GPU, and the reference's vanilla batch)
-run rocprofv3 --kernel-trace --stats -d $OUT/train_art -o $TAG -- python $REPO/tools/train_bench.py --rays 4096 --steps 10 --articulated > $OUT/train_art.log 2>&1
-run rocprofv3 --kernel-trace --stats -d $OUT/train_van -o $TAG -- python $REPO/tools/train_bench.py --rays 4096 --steps 10 > $OUT/train_van.log 2>&1
+# 3. training steps (BASELINE config 5 per GPU, and the reference's vanilla batch).  Kernel statistics with the two levels'
+#    backward SERIALISED on one stream (--no-overlap): on the product's two library streams kernels of the two levels share the
+#    CUs and their individual durations stretch; the product's step time comes from the un-profiled runs below.
+run rocprofv3 --kernel-trace --stats -d $OUT/train_art -o $TAG -- python $REPO/tools/train_bench.py --rays 4096 --steps 10 --articulated --no-overlap > $OUT/train_art_serial.log 2>&1
+run rocprofv3 --kernel-trace --stats -d $OUT/train_van -o $TAG -- python $REPO/tools/train_bench.py --rays 4096 --steps 10 --no-overlap > $OUT/train_van_serial.log 2>&1
+run python $REPO/tools/train_bench.py --rays 4096 --steps 20 --articulated > $OUT/train_art.log 2>&1
+run python $REPO/tools/train_bench.py --rays 4096 --steps 20 > $OUT/train_van.log 2>&1
 # 4. articulated render (BASELINE config 4) + bf16x3 engine
 run rocprofv3 --kernel-trace --stats -d $OUT/render_art -o $TAG -- python $REPO/tools/render_bench.py > $OUT/render_art.log 2>&1
 run rocprofv3 --kernel-trace --stats -d $OUT/bf16x3 -o $TAG -- python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-train-leg --engine bf16x3 > $OUT/bf16x3.log 2>&1
@@ -37,5 +41,5 @@ for d in train_art train_van render_art bf16x3; do
   f=$(ls $OUT/$d/*_results.db 2>/dev/null | head -1)
   [ -n "$f" ] && python tools/kstats.py $f 16 > $SUM/${TAG}_${d}_kernel_stats.txt 2>&1
 done
-for l in stats_run pmc_fetch pmc_write pmc_sq pmc_sq2 train_art train_van render_art bf16x3 render_art_bf16x3 train_van_bf16x3 train_art_bf16x3; do grep -h '^{' $OUT/$l.log | tail -1 > $SUM/$l.json; done
-cat $SUM/train_art.json $SUM/train_van.json $SUM/render_art.json $SUM/render_art_bf16x3.json $SUM/train_van_bf16x3.json $SUM/train_art_bf16x3.json; cut -c1-300 $SUM/stats_run.json; cut -c1-200 $SUM/bf16x3.json
+for l in stats_run pmc_fetch pmc_write pmc_sq pmc_sq2 train_art train_van train_art_serial train_van_serial render_art bf16x3 render_art_bf16x3 train_van_bf16x3 train_art_bf16x3; do grep -h '^{' $OUT/$l.log | tail -1 > $SUM/$l.json; done
+cat $SUM/train_art.json $SUM/train_van.json $SUM/train_art_serial.json $SUM/train_van_serial.json $SUM/render_art.json $SUM/render_art_bf16x3.json $SUM/train_van_bf16x3.json $SUM/train_art_bf16x3.json; cut -c1-300 $SUM/stats_run.json; cut -c1-200 $SUM/bf16x3.json
