@@ -87,6 +87,8 @@ _SIGS = {
     "aon_profile_begin": (_i, []),
     "aon_profile_end": (_i, [C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "aon_profile_class": (_i, [_i, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "aon_composite_pdf": (_i, [_p, _p, _p, _l, _i, _i, _p, _l, _p, _p, _p, _p, _p, _p]),
+    "aon_set_coarse_fusion": (_i, [_i]),
     "aon_render_workspace_bytes": (_l, [_l]),
     "aon_render_fwd": (_i, [_p, _p, _p, _p, _p, _l, _f, _f, _i, _i, _p, _p, _l, _p, _p, _p, _p, _p, _p, _p, _l, _p]),
 }

@@ -85,6 +85,9 @@ hipError_t launch_composite(const float* rgb, int rgb_stride, const float* sigma
 hipError_t launch_sample_pdf(const float* bins, const float* weights, int64_t w_stride, const float* t_coarse,
                              const float* u, int64_t u_stride, int64_t n_rays, float* samples, float* t_fine,
                              hipStream_t stream);
+hipError_t launch_composite_pdf(const float* raw, const float* t_coarse, const float* dirs, int64_t n_rays, int white_bkgd, int act,
+                                const float* u, int64_t u_stride, float* comp_rgb, float* acc, float* depth, float* weights,
+                                float* t_fine, hipStream_t stream);
 }  // namespace aon
 
 namespace {
@@ -108,7 +111,8 @@ constexpr int kSc = 65, kSf = 193;
 // current stream), by kernel class; bench.py turns the totals into roofline figures.  Off unless aon_profile_begin() was
 // called: one mutex-guarded branch per launch otherwise.
 enum KClass { kMlpFwd = AON_PROF_MLP_FWD, kBwdChain = AON_PROF_BWD_CHAIN, kWgrad = AON_PROF_WGRAD, kComposite = AON_PROF_COMPOSITE,
-              kSamplePdf = AON_PROF_SAMPLE_PDF, kCompositeBwd = AON_PROF_COMPOSITE_BWD, kNumClasses = AON_PROF_NUM_CLASSES };
+              kSamplePdf = AON_PROF_SAMPLE_PDF, kCompositeBwd = AON_PROF_COMPOSITE_BWD, kCompositePdf = AON_PROF_COMPOSITE_PDF,
+              kNumClasses = AON_PROF_NUM_CLASSES };
 
 struct Profiler {
   std::mutex mu;
@@ -283,6 +287,26 @@ int aon_sample_pdf(const float* bins, const float* weights, int64_t w_stride, co
   KTimer timer(kSamplePdf, (hipStream_t)stream, n_rays);
   return check(aon::launch_sample_pdf(bins, weights, w_stride, t_coarse, u, u_stride, n_rays, samples, t_fine,
                                       (hipStream_t)stream), "aon_sample_pdf");
+}
+
+// The coarse level's compositing and the fine level's sampling as ONE kernel (model.py:160-173): the whole-path entry points
+// use it; aon_set_coarse_fusion(0) puts them back on the two stage kernels (A/B measurements, equality tests).
+static int g_fuse_coarse = 1;
+int aon_set_coarse_fusion(int on) {
+  g_fuse_coarse = on ? 1 : 0;
+  return AON_OK;
+}
+
+int aon_composite_pdf(const float* raw, const float* t_coarse, const float* dirs, int64_t n_rays, int white_bkgd, int act,
+                      const float* u, int64_t u_stride, float* comp_rgb, float* acc, float* depth, float* weights, float* t_fine,
+                      void* stream) {
+  if (n_rays < 0 || act < 0 || act > 2 || (u_stride != 0 && u_stride < 128)) return fail(AON_E_INVALID, "aon_composite_pdf: bad size / stride / act");
+  if (n_rays == 0) return AON_OK;
+  if (!raw || !t_coarse || !dirs || !u || !comp_rgb || !acc || !depth || !t_fine) return fail(AON_E_INVALID, "aon_composite_pdf: null pointer");
+  if (reinterpret_cast<uintptr_t>(raw) & 15) return fail(AON_E_INVALID, "aon_composite_pdf: raw must be 16-byte aligned");
+  KTimer timer(kCompositePdf, (hipStream_t)stream, n_rays);
+  return check(aon::launch_composite_pdf(raw, t_coarse, dirs, n_rays, white_bkgd, act, u, u_stride, comp_rgb, acc, depth, weights,
+                                         t_fine, (hipStream_t)stream), "aon_composite_pdf");
 }
 
 // ---- training (R14) ----
@@ -492,7 +516,12 @@ static int render_impl(const char* who, const NetRef& coarse, const NetRef& fine
     if (rc) return rc;
     rc = check(launch_net(coarse, o, d, v, w.t_c, n, kSc, w.raw, stream), who);
     if (rc) return rc;
-    {
+    if (num_levels == 2 && g_fuse_coarse) {
+      // compositing + the fine level's sampling (model.py:162-173) in one kernel: the coarse weights stay in registers
+      KTimer timer(kCompositePdf, stream, n);
+      rc = check(aon::launch_composite_pdf(w.raw, w.t_c, d, n, white_bkgd, act, u_stride ? u + r0 * u_stride : u, u_stride, rgb_c + r0 * 3,
+                                           acc_c + r0, depth_c + r0, nullptr, w.t_f, stream), who);
+    } else {
       KTimer timer(kComposite, stream, n);
       rc = check(aon::launch_composite(w.raw, 4, w.raw + 3, 4, w.t_c, d, n, kSc, white_bkgd, act, rgb_c + r0 * 3, acc_c + r0,
                                        depth_c + r0, num_levels == 2 ? w.w_c : nullptr, stream), who);
@@ -500,12 +529,12 @@ static int render_impl(const char* who, const NetRef& coarse, const NetRef& fine
     if (rc) return rc;
     if (num_levels == 1) continue;
     // level 1 (model.py:162-173, :175-197)
-    {
+    if (!g_fuse_coarse) {
       KTimer timer(kSamplePdf, stream, n);
       rc = check(aon::launch_sample_pdf(nullptr, w.w_c + 1, kSc, w.t_c, u_stride ? u + r0 * u_stride : u, u_stride, n, nullptr, w.t_f,
                                         stream), who);
+      if (rc) return rc;
     }
-    if (rc) return rc;
     rc = check(launch_net(fine, o, d, v, w.t_f, n, kSf, w.raw, stream), who);
     if (rc) return rc;
     {
@@ -630,10 +659,11 @@ int train_fwd_impl(const char* who, bool art, const TrainNet* nets, const float*
   for (int l = 0; l < num_levels; ++l) {
     const TrainLevel& L = w.lvl[l];
     if (!nets[l].packed_fwd || (art && !nets[l].small) || !rgb[l] || !acc[l] || !depth[l]) return fail(AON_E_INVALID, "train forward: null level pointer");
-    int rc;
+    const bool fuse = num_levels == 2 && g_fuse_coarse;
+    int rc = AON_OK;
     if (l == 0) {
       rc = check(aon::launch_sample_along_rays(rays_o, rays_d, n, kSc, near_, far_, t_rand, L.t, nullptr, stream), who);
-    } else {
+    } else if (!fuse) {
       KTimer timer(kSamplePdf, stream, n);
       rc = check(aon::launch_sample_pdf(nullptr, w.w_c + 1, kSc, w.lvl[0].t, u, u_stride, n, nullptr, L.t, stream), who);
     }
@@ -646,7 +676,11 @@ int train_fwd_impl(const char* who, bool art, const TrainNet* nets, const float*
                                                  L.masks, stream), who);
     }
     if (rc) return rc;
-    {
+    if (l == 0 && fuse) {
+      KTimer timer(kCompositePdf, stream, n);
+      rc = check(aon::launch_composite_pdf(L.raw, L.t, rays_d, n, white_bkgd, act, u, u_stride, rgb[0], acc[0], depth[0], nullptr,
+                                           w.lvl[1].t, stream), who);
+    } else {
       KTimer timer(kComposite, stream, n);
       rc = check(aon::launch_composite(L.raw, 4, L.raw + 3, 4, L.t, rays_d, n, L.S, white_bkgd, act, rgb[l], acc[l], depth[l],
                                        (l == 0 && num_levels == 2) ? w.w_c : nullptr, stream), who);

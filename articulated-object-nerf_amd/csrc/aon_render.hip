@@ -242,10 +242,51 @@ hipError_t launch_cast_rays(const float* t_vals, const float* o, const float* d,
   return hipGetLastError();
 }
 
+// The render / training paths want only t (the fused MLP kernels cast the rays themselves): four consecutive elements of the
+// flat (n*S) array per thread, one 16-byte store (and one 16-byte load of t_rand) each -- a pure streaming write.
+__global__ void sample_t4_kernel(int64_t total, int S, float near, float far, const float* __restrict__ t_rand, float* __restrict__ t_vals) {
+  const int64_t g0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (g0 >= total) return;
+  int s = (int)(g0 % S);
+  float r[4] = {0.f, 0.f, 0.f, 0.f};
+  const bool full = g0 + 4 <= total;
+  if (t_rand) {
+    if (full) {
+      const float4 q = *reinterpret_cast<const float4*>(t_rand + g0);
+      r[0] = q.x; r[1] = q.y; r[2] = q.z; r[3] = q.w;
+    } else {
+      for (int e = 0; e < 4; ++e) if (g0 + e < total) r[e] = t_rand[g0 + e];
+    }
+  }
+  float v[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    float t = coarse_t(s, S, near, far);
+    if (t_rand) {  // stratified jitter between interval mid-points (helper.py:122-127)
+      const float lo = s == 0 ? t : __fmul_rn(0.5f, __fadd_rn(t, coarse_t(s - 1, S, near, far)));
+      const float hi = s == S - 1 ? t : __fmul_rn(0.5f, __fadd_rn(coarse_t(s + 1, S, near, far), t));
+      t = __fadd_rn(lo, __fmul_rn(__fsub_rn(hi, lo), r[e]));
+    }
+    v[e] = t;
+    s = s + 1 == S ? 0 : s + 1;
+  }
+  if (full) {
+    *reinterpret_cast<float4*>(t_vals + g0) = make_float4(v[0], v[1], v[2], v[3]);
+  } else {
+    for (int e = 0; e < 4; ++e) if (g0 + e < total) t_vals[g0 + e] = v[e];
+  }
+}
+
 hipError_t launch_sample_along_rays(const float* rays_o, const float* rays_d, int64_t n_rays, int S, float near,
                                     float far, const float* t_rand, float* t_vals, float* coords, hipStream_t stream) {
   const int64_t n = n_rays * S;
   if (n <= 0) return hipSuccess;
+  const bool aligned = (reinterpret_cast<uintptr_t>(t_vals) & 15) == 0 && (reinterpret_cast<uintptr_t>(t_rand) & 15) == 0;
+  if (!coords && aligned) {
+    const int64_t threads = (n + 3) / 4;
+    sample_t4_kernel<<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream>>>(n, S, near, far, t_rand, t_vals);
+    return hipGetLastError();
+  }
   sample_along_rays_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream>>>(rays_o, rays_d, n_rays, S, near, far,
                                                                                        t_rand, t_vals, coords);
   return hipGetLastError();
@@ -278,120 +319,6 @@ hipError_t launch_pos_enc(const float* x, int64_t n, int min_deg, int max_deg, f
   const int64_t tot = n * (3 + 6 * (max_deg - min_deg));
   if (tot <= 0) return hipSuccess;
   pos_enc_kernel<<<dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream>>>(x, n, min_deg, max_deg, out);
-  return hipGetLastError();
-}
-
-// ---------------------------------------------------------------------------------------------
-// R8  alpha compositing   (helper.py:157-195), one wavefront per ray
-// ---------------------------------------------------------------------------------------------
-// act: 0 = inputs already activated (stage-level parity with volumetric_rendering)
-//      1 = vanilla NeRF: rgb = sigmoid(raw), sigma = relu(raw)                     (model.py:186-187)
-//      2 = articulated:  rgb = sigmoid(raw)*(1+2*0.001)-0.001, sigma = softplus(raw-1)  (model_autodecoder.py:321-323)
-struct CompositeArgs {
-  const float* rgb;    int rgb_stride;    // floats between consecutive samples (3 or 4)
-  const float* sigma;  int sigma_stride;  // 1 or 4
-  const float* t_vals;  // (n,S)
-  const float* dirs;    // (n,3)
-  int64_t n_rays; int S; int white_bkgd; int act;
-  float* comp_rgb;  // (n,3)
-  float* acc;       // (n,)
-  float* depth;     // (n,)
-  float* weights;   // (n,S) or null
-};
-
-// 1 / (1 + exp(-x)): v_rcp_f32 (1 ulp) refined by one Newton step (<= 0.5 ulp + rounding) instead of the ten-instruction
-// correctly rounded division -- torch's own vectorised sigmoid differs from any of them by an ulp of exp anyway
-__device__ __forceinline__ float sigmoid_f32(float x) {
-  const float d = __fadd_rn(1.0f, expf(-x));
-  const float r = __builtin_amdgcn_rcpf(d);
-  return __builtin_fmaf(__builtin_fmaf(-d, r, 1.0f), r, r);
-}
-
-__device__ __forceinline__ float softplus_f32(float x) {  // torch Softplus(beta=1, threshold=20)
-  return x > 20.0f ? x : log1pf(expf(x));
-}
-
-// PACKED: rgb and sigma are the (n*S,4) float4 records the MLP kernels write (rgb_stride = sigma_stride = 4,
-// sigma = rgb + 3): one 16-byte load per sample instead of four 4-byte ones.
-template <bool PACKED>
-__global__ void __launch_bounds__(256) composite_kernel(CompositeArgs a) {
-  const int lane = threadIdx.x & 63;
-  const int64_t ray = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (ray >= a.n_rays) return;  // wave-uniform
-  const int S = a.S;
-  const float* tv = a.t_vals + ray * S;
-  const float dn = __fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(a.dirs[ray * 3], a.dirs[ray * 3]),
-                                                  __fmul_rn(a.dirs[ray * 3 + 1], a.dirs[ray * 3 + 1])),
-                                        __fmul_rn(a.dirs[ray * 3 + 2], a.dirs[ray * 3 + 2])));
-  float carry = 1.0f;  // transmittance entering this 64-sample block
-  float s_r = 0.f, s_g = 0.f, s_b = 0.f, s_w = 0.f, s_d = 0.f;
-  for (int base = 0; base < S; base += 64) {
-    const int s = base + lane;
-    const bool in = s < S;
-    float alpha = 0.f, c0 = 0.f, c1 = 0.f, c2 = 0.f, t = 0.f;
-    if (in) {
-      const int64_t g = ray * S + s;
-      t = tv[s];
-      const float dist = __fmul_rn(s == S - 1 ? 1e10f : __fsub_rn(tv[s + 1], t), dn);
-      float sg;
-      if constexpr (PACKED) {
-        const float4 r = reinterpret_cast<const float4*>(a.rgb)[g];
-        c0 = r.x; c1 = r.y; c2 = r.z; sg = r.w;
-      } else {
-        sg = a.sigma[g * a.sigma_stride];
-        c0 = a.rgb[g * a.rgb_stride + 0]; c1 = a.rgb[g * a.rgb_stride + 1]; c2 = a.rgb[g * a.rgb_stride + 2];
-      }
-      if (a.act == 1) {
-        sg = __builtin_fmaxf(sg, 0.f);
-        c0 = sigmoid_f32(c0); c1 = sigmoid_f32(c1); c2 = sigmoid_f32(c2);
-      } else if (a.act == 2) {
-        sg = softplus_f32(__fadd_rn(sg, -1.0f));
-        c0 = __fsub_rn(__fmul_rn(sigmoid_f32(c0), 1.002f), 0.001f);
-        c1 = __fsub_rn(__fmul_rn(sigmoid_f32(c1), 1.002f), 0.001f);
-        c2 = __fsub_rn(__fmul_rn(sigmoid_f32(c2), 1.002f), 0.001f);
-      }
-      alpha = __fsub_rn(1.0f, expf(-__fmul_rn(sg, dist)));
-    }
-    // T_i = prod_{j<i} (1 - alpha_j + 1e-10)   (helper.py:169-176)
-    float T = carry;
-    if (S - base > 1) {  // wave-uniform; a one-sample tail block (S = 65, 193) needs no scan: T = carry in lane 0
-      const float f = in ? __fadd_rn(__fsub_rn(1.0f, alpha), 1e-10f) : 1.0f;
-      const float incl = wave_inclusive_scan<true>(f, lane);
-      const float excl = dpp_f32<0x138, 0xf>(1.0f, incl);  // wave_shr:1, lane 0 keeps 1
-      T = __fmul_rn(carry, excl);
-      carry = __fmul_rn(carry, __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, incl), 63)));
-    }
-    const float w = __fmul_rn(alpha, T);
-    if (in) {
-      s_r = __fadd_rn(s_r, __fmul_rn(w, c0));
-      s_g = __fadd_rn(s_g, __fmul_rn(w, c1));
-      s_b = __fadd_rn(s_b, __fmul_rn(w, c2));
-      s_w = __fadd_rn(s_w, w);
-      s_d = __fadd_rn(s_d, __fmul_rn(w, t));
-      if (a.weights) a.weights[ray * S + s] = w;
-    }
-  }
-  s_r = wave_sum(s_r); s_g = wave_sum(s_g); s_b = wave_sum(s_b); s_w = wave_sum(s_w); s_d = wave_sum(s_d);
-  if (lane == 0) {
-    if (a.white_bkgd) {  // comp_rgb + (1 - acc)
-      const float bg = __fsub_rn(1.0f, s_w);
-      s_r = __fadd_rn(s_r, bg); s_g = __fadd_rn(s_g, bg); s_b = __fadd_rn(s_b, bg);
-    }
-    a.comp_rgb[ray * 3 + 0] = s_r; a.comp_rgb[ray * 3 + 1] = s_g; a.comp_rgb[ray * 3 + 2] = s_b;
-    a.acc[ray] = s_w;
-    // helper.py:182-183: nan_to_num(depth, nan=inf); the clamp to the batch's own [min,max] is the identity
-    a.depth[ray] = (s_d != s_d) ? __builtin_inff() : s_d;
-  }
-}
-
-hipError_t launch_composite(const float* rgb, int rgb_stride, const float* sigma, int sigma_stride, const float* t_vals,
-                            const float* dirs, int64_t n_rays, int S, int white_bkgd, int act, float* comp_rgb,
-                            float* acc, float* depth, float* weights, hipStream_t stream) {
-  if (n_rays <= 0) return hipSuccess;
-  CompositeArgs a{rgb, rgb_stride, sigma, sigma_stride, t_vals, dirs, n_rays, S, white_bkgd, act, comp_rgb, acc, depth, weights};
-  const bool packed = rgb_stride == 4 && sigma_stride == 4 && sigma == rgb + 3 && (reinterpret_cast<uintptr_t>(rgb) & 15) == 0;
-  if (packed) composite_kernel<true><<<dim3((unsigned)((n_rays + 3) / 4)), dim3(256), 0, stream>>>(a);
-  else composite_kernel<false><<<dim3((unsigned)((n_rays + 3) / 4)), dim3(256), 0, stream>>>(a);
   return hipGetLastError();
 }
 
@@ -658,6 +585,213 @@ __device__ __forceinline__ void inverse_cdf_merge(float* L, int lane, float tc, 
     const int e = lane * 4 + r;
     if (e < 193) t_fine[e] = v[r];
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// R8  alpha compositing   (helper.py:157-195), one wavefront per ray -- optionally fused with R6 + R7 of the coarse level
+// ---------------------------------------------------------------------------------------------
+// act: 0 = inputs already activated (stage-level parity with volumetric_rendering)
+//      1 = vanilla NeRF: rgb = sigmoid(raw), sigma = relu(raw)                     (model.py:186-187)
+//      2 = articulated:  rgb = sigmoid(raw)*(1+2*0.001)-0.001, sigma = softplus(raw-1)  (model_autodecoder.py:321-323)
+struct CompositeArgs {
+  const float* rgb;    int rgb_stride;    // floats between consecutive samples (3 or 4)
+  const float* sigma;  int sigma_stride;  // 1 or 4
+  const float* t_vals;  // (n,S)
+  const float* dirs;    // (n,3)
+  int64_t n_rays; int S; int white_bkgd; int act;
+  float* comp_rgb;  // (n,3)
+  float* acc;       // (n,)
+  float* depth;     // (n,)
+  float* weights;   // (n,S) or null
+  // fused coarse level (S == 65 only): the level's weights never leave the registers, the kernel goes on to draw the
+  // fine samples (model.py:162-173) and writes sort(cat[t_coarse, draws]) itself
+  const float* u; int64_t u_stride;   // (128,) if u_stride == 0 else (n,128)
+  float* t_fine;                      // (n,193)
+};
+
+// 1 / (1 + exp(-x)): v_rcp_f32 (1 ulp) refined by one Newton step (<= 0.5 ulp + rounding) instead of the ten-instruction
+// correctly rounded division -- torch's own vectorised sigmoid differs from any of them by an ulp of exp anyway
+__device__ __forceinline__ float sigmoid_f32(float x) {
+  const float d = __fadd_rn(1.0f, expf(-x));
+  const float r = __builtin_amdgcn_rcpf(d);
+  return __builtin_fmaf(__builtin_fmaf(-d, r, 1.0f), r, r);
+}
+
+__device__ __forceinline__ float softplus_f32(float x) {  // torch Softplus(beta=1, threshold=20)
+  return x > 20.0f ? x : log1pf(expf(x));
+}
+
+// output activations of the two networks on one (rgb, sigma) record; `act` is wave-uniform
+__device__ __forceinline__ void activate_record(int act, float& c0, float& c1, float& c2, float& sg) {
+  if (act == 1) {
+    sg = __builtin_fmaxf(sg, 0.f);
+    c0 = sigmoid_f32(c0); c1 = sigmoid_f32(c1); c2 = sigmoid_f32(c2);
+  } else if (act == 2) {
+    sg = softplus_f32(__fadd_rn(sg, -1.0f));
+    c0 = __fsub_rn(__fmul_rn(sigmoid_f32(c0), 1.002f), 0.001f);
+    c1 = __fsub_rn(__fmul_rn(sigmoid_f32(c1), 1.002f), 0.001f);
+    c2 = __fsub_rn(__fmul_rn(sigmoid_f32(c2), 1.002f), 0.001f);
+  }
+}
+
+// gfx950 lane-swap instructions: permlane32_swap exchanges lanes 32..63 of `a` with lanes 0..31 of `b`, permlane16_swap the
+// odd 16-lane rows of `a` with the even rows of `b`.  `a + b` afterwards holds pair sums of BOTH inputs: one swap and one add
+// take two values one reduction level down.
+// (inline asm, not __builtin_amdgcn_permlane32_swap: hipcc 7.2 extracts the builtin's second result from the FIRST register in
+// this kernel -- `v_add_f32 v2, v9, v9` -- and every sum came out as 4 x its first row; the asm names both in/out registers.
+// s_nop 1: the two wait states a lane-swap needs after a VALU write of its operands, which the compiler cannot see in here.)
+__device__ __forceinline__ float swap32_add(float a, float b) {
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  return __fadd_rn(a, b);   // [a_i + a_{i+32} | b_i + b_{i+32}]
+}
+__device__ __forceinline__ float swap16_add(float a, float b) {
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  return __fadd_rn(a, b);   // rows [a0+a1, b0+b1, a2+a3, b2+b3]
+}
+// sums over the 64 lanes of four values at once: 3 swaps + 3 adds + 4 row-rotate adds (24 DPP adds done one value at a
+// time); every lane of row 0 / 1 / 2 / 3 ends up holding the total of v0 / v2 / v1 / v3.  The association is a fixed tree
+// (lane pairs 32 apart, then 16, 8, 4, 2, 1), the same for every ray.
+__device__ __forceinline__ void wave_sum4(float& v0, float& v1, float& v2, float& v3) {
+  float z = swap16_add(swap32_add(v0, v1), swap32_add(v2, v3));   // rows: v0, v2, v1, v3 -- 16 partial sums each
+  z = __fadd_rn(z, dpp_f32<0x128, 0xf>(0.f, z));  // row_ror:8
+  z = __fadd_rn(z, dpp_f32<0x124, 0xf>(0.f, z));  // row_ror:4
+  z = __fadd_rn(z, dpp_f32<0x122, 0xf>(0.f, z));  // row_ror:2
+  z = __fadd_rn(z, dpp_f32<0x121, 0xf>(0.f, z));  // row_ror:1
+  const int zi = __builtin_bit_cast(int, z);
+  v0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(zi, 0));
+  v2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(zi, 16));
+  v1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(zi, 32));
+  v3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(zi, 48));
+}
+
+// One wavefront per ray, lanes over samples (the transmittance product is a wave scan); FUSE_PDF: the coarse level's kernel,
+// which goes on to the inverse CDF with the weights still in registers.
+// PACKED: rgb and sigma are the (n*S,4) float4 records the MLP kernels write (rgb_stride = sigma_stride = 4,
+// sigma = rgb + 3): one 16-byte load per sample instead of four 4-byte ones.
+// The kernel is bound by VALU issue (round-2 counters: ~300 wave instructions per ray against 1,592 bytes), so: 64-sample
+// blocks over the first S-1 samples only -- the LAST sample (the 1e10-long interval, helper.py:163) sits alone in a 65th /
+// 193rd position and is evaluated once, wave-uniformly, from operands fetched ahead of the blocks, instead of as a further
+// block with one live lane; four of the five ray sums are reduced together (wave_sum4).
+// SC: the sample count as a compile-time constant (65 / 193: the two levels of the reference geometry; full 64-sample blocks
+// lose their bounds predicates and the row addressing its multiplies) or 0 = read it from the arguments.
+template <bool PACKED, bool FUSE_PDF, int SC>
+__global__ void __launch_bounds__(256) composite_kernel(CompositeArgs a) {
+  __shared__ __attribute__((aligned(16))) float lds[FUSE_PDF ? 4 : 1][FUSE_PDF ? kPdfLdsFloats : 4];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t ray = (int64_t)blockIdx.x * 4 + wv;
+  if (ray >= a.n_rays) return;  // wave-uniform; no block-level barrier below
+  const int S = SC ? SC : a.S, last = S - 1;
+  const int act = a.act;
+  const float* tv = a.t_vals + ray * S;
+  // the last sample's operands (same address in every lane: one request), in flight while the blocks run
+  const int64_t gl = ray * S + last;
+  const float t_last = tv[last];
+  float l0, l1, l2, lsg;
+  if constexpr (PACKED) {
+    const float4 r = reinterpret_cast<const float4*>(a.rgb)[gl];
+    l0 = r.x; l1 = r.y; l2 = r.z; lsg = r.w;
+  } else {
+    lsg = a.sigma[gl * a.sigma_stride];
+    l0 = a.rgb[gl * a.rgb_stride + 0]; l1 = a.rgb[gl * a.rgb_stride + 1]; l2 = a.rgb[gl * a.rgb_stride + 2];
+  }
+  const float dn = __fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(a.dirs[ray * 3], a.dirs[ray * 3]),
+                                                  __fmul_rn(a.dirs[ray * 3 + 1], a.dirs[ray * 3 + 1])),
+                                        __fmul_rn(a.dirs[ray * 3 + 2], a.dirs[ray * 3 + 2])));
+  float carry = 1.0f;  // transmittance entering this 64-sample block
+  float s_r = 0.f, s_g = 0.f, s_b = 0.f, s_w = 0.f, s_d = 0.f;
+  float w0 = 0.f, t0 = 0.f, tn0 = 0.f;   // block 0's weights and t, t_next (the fused inverse CDF's operands)
+  for (int base = 0; base < last; base += 64) {
+    const int s = base + lane;
+    const bool in = s < last;
+    float alpha = 0.f, c0 = 0.f, c1 = 0.f, c2 = 0.f, t = 0.f, tn = 0.f;
+    if (in) {
+      const int64_t g = ray * S + s;
+      t = tv[s];
+      tn = tv[s + 1];
+      const float dist = __fmul_rn(__fsub_rn(tn, t), dn);
+      float sg;
+      if constexpr (PACKED) {
+        const float4 r = reinterpret_cast<const float4*>(a.rgb)[g];
+        c0 = r.x; c1 = r.y; c2 = r.z; sg = r.w;
+      } else {
+        sg = a.sigma[g * a.sigma_stride];
+        c0 = a.rgb[g * a.rgb_stride + 0]; c1 = a.rgb[g * a.rgb_stride + 1]; c2 = a.rgb[g * a.rgb_stride + 2];
+      }
+      activate_record(act, c0, c1, c2, sg);
+      alpha = __fsub_rn(1.0f, expf(-__fmul_rn(sg, dist)));
+    }
+    // T_i = prod_{j<i} (1 - alpha_j + 1e-10)   (helper.py:169-176)
+    const float f = in ? __fadd_rn(__fsub_rn(1.0f, alpha), 1e-10f) : 1.0f;
+    const float incl = wave_inclusive_scan<true>(f, lane);
+    const float excl = dpp_f32<0x138, 0xf>(1.0f, incl);  // wave_shr:1, lane 0 keeps 1
+    const float T = __fmul_rn(carry, excl);
+    carry = __fmul_rn(carry, __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, incl), 63)));
+    const float w = __fmul_rn(alpha, T);
+    if (FUSE_PDF && base == 0) { w0 = w; t0 = t; tn0 = tn; }
+    if (in) {
+      s_r = __fadd_rn(s_r, __fmul_rn(w, c0));
+      s_g = __fadd_rn(s_g, __fmul_rn(w, c1));
+      s_b = __fadd_rn(s_b, __fmul_rn(w, c2));
+      s_w = __fadd_rn(s_w, w);
+      s_d = __fadd_rn(s_d, __fmul_rn(w, t));
+      if (a.weights) a.weights[ray * S + s] = w;
+    }
+  }
+  // the last sample: delta = 1e10 (helper.py:163), T = everything before it
+  activate_record(act, l0, l1, l2, lsg);
+  const float a_last = __fsub_rn(1.0f, expf(-__fmul_rn(lsg, __fmul_rn(1e10f, dn))));
+  const float w_last = __fmul_rn(a_last, carry);
+  if (a.weights && lane == 0) a.weights[gl] = w_last;
+  wave_sum4(s_r, s_g, s_b, s_w);
+  s_d = wave_sum(s_d);
+  s_r = __fadd_rn(s_r, __fmul_rn(w_last, l0));
+  s_g = __fadd_rn(s_g, __fmul_rn(w_last, l1));
+  s_b = __fadd_rn(s_b, __fmul_rn(w_last, l2));
+  s_w = __fadd_rn(s_w, w_last);
+  s_d = __fadd_rn(s_d, __fmul_rn(w_last, t_last));
+  if (lane == 0) {
+    if (a.white_bkgd) {  // comp_rgb + (1 - acc)
+      const float bg = __fsub_rn(1.0f, s_w);
+      s_r = __fadd_rn(s_r, bg); s_g = __fadd_rn(s_g, bg); s_b = __fadd_rn(s_b, bg);
+    }
+    a.comp_rgb[ray * 3 + 0] = s_r; a.comp_rgb[ray * 3 + 1] = s_g; a.comp_rgb[ray * 3 + 2] = s_b;
+    a.acc[ray] = s_w;
+    // helper.py:182-183: nan_to_num(depth, nan=inf); the clamp to the batch's own [min,max] is the identity
+    a.depth[ray] = (s_d != s_d) ? __builtin_inff() : s_d;
+  }
+  if constexpr (FUSE_PDF) {
+    // model.py:162-166: bins = mids of t_coarse, pdf weights = weights[..., 1:-1] -> lane i takes w_{i+1} (i < 63)
+    const float w_next = dpp_f32<0x130, 0xf>(0.f, w0);   // wave_shl:1; lane 63 reads 0
+    const float b = __fmul_rn(0.5f, __fadd_rn(tn0, t0));
+    inverse_cdf_merge(lds[wv], lane, t0, t_last, b, lane < 63 ? w_next : 0.f, a.u + ray * a.u_stride, nullptr, a.t_fine + ray * 193);
+  }
+}
+
+hipError_t launch_composite(const float* rgb, int rgb_stride, const float* sigma, int sigma_stride, const float* t_vals,
+                            const float* dirs, int64_t n_rays, int S, int white_bkgd, int act, float* comp_rgb,
+                            float* acc, float* depth, float* weights, hipStream_t stream) {
+  if (n_rays <= 0) return hipSuccess;
+  CompositeArgs a{rgb, rgb_stride, sigma, sigma_stride, t_vals, dirs, n_rays, S, white_bkgd, act, comp_rgb, acc, depth, weights,
+                  nullptr, 0, nullptr};
+  const bool packed = rgb_stride == 4 && sigma_stride == 4 && sigma == rgb + 3 && (reinterpret_cast<uintptr_t>(rgb) & 15) == 0;
+  const dim3 grid((unsigned)((n_rays + 3) / 4)), block(256);
+  if (packed && S == 193) composite_kernel<true, false, 193><<<grid, block, 0, stream>>>(a);
+  else if (packed && S == 65) composite_kernel<true, false, 65><<<grid, block, 0, stream>>>(a);
+  else if (packed) composite_kernel<true, false, 0><<<grid, block, 0, stream>>>(a);
+  else composite_kernel<false, false, 0><<<grid, block, 0, stream>>>(a);
+  return hipGetLastError();
+}
+
+// coarse level of NeRF.forward in one launch: compositing of the 65 coarse samples (outputs as launch_composite; `weights`
+// optional) + the 128 inverse-CDF draws from weights[..., 1:-1] over the mids of t_coarse + the sorted union -> t_fine (n,193).
+// `raw` are the MLP kernels' packed (rgb, sigma) records.
+hipError_t launch_composite_pdf(const float* raw, const float* t_coarse, const float* dirs, int64_t n_rays, int white_bkgd, int act,
+                                const float* u, int64_t u_stride, float* comp_rgb, float* acc, float* depth, float* weights,
+                                float* t_fine, hipStream_t stream) {
+  if (n_rays <= 0) return hipSuccess;
+  CompositeArgs a{raw, 4, raw + 3, 4, t_coarse, dirs, n_rays, 65, white_bkgd, act, comp_rgb, acc, depth, weights, u, u_stride, t_fine};
+  composite_kernel<true, true, 65><<<dim3((unsigned)((n_rays + 3) / 4)), dim3(256), 0, stream>>>(a);
+  return hipGetLastError();
 }
 
 __global__ void __launch_bounds__(256) sample_pdf_kernel(PdfArgs a) {

@@ -304,9 +304,37 @@ def sample_pdf_t(t_coarse, coarse_weights, u=None, bins=None):
     return t_fine
 
 
+def composite_pdf(raw, t_coarse, dirs, white_bkgd, act=ACT_VANILLA, u=None, want_weights=False):
+    """Coarse level of NeRF.forward in ONE kernel (model.py:160-173): compositing of the packed raw (n,65,4) records and the
+    fine level's sampling -> (comp_rgb, acc, weights | None, depth, t_fine (n,193)).  Same bits as composite_raw followed by
+    sample_pdf_t."""
+    r, t, d = _f32(raw, "raw"), _f32(t_coarse, "t_coarse"), _f32(dirs, "dirs")
+    n, dev = t.shape[0], t.device
+    if tuple(t.shape) != (n, 65) or r.numel() != n * 65 * 4:
+        raise ValueError("composite_pdf: t_coarse must be (n,65) and raw (n,65,4)")
+    uu, us = _u_args(u, n, dev)
+    comp = torch.empty((n, 3), dtype=torch.float32, device=dev)
+    acc = torch.empty((n,), dtype=torch.float32, device=dev)
+    depth = torch.empty((n,), dtype=torch.float32, device=dev)
+    weights = torch.empty((n, 65), dtype=torch.float32, device=dev) if want_weights else None
+    t_fine = torch.empty((n, 193), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        check(lib.aon_composite_pdf(_ptr(r), _ptr(t), _ptr(d), n, int(bool(white_bkgd)), act, _ptr(uu), us, _ptr(comp), _ptr(acc),
+                                    _ptr(depth), _ptr(weights), _ptr(t_fine), _stream()), "aon_composite_pdf")
+    return comp, acc, weights, depth, t_fine
+
+
+def set_coarse_fusion(on: bool) -> None:
+    """Whole-path entry points: coarse compositing + inverse CDF as one kernel (default) or as the two stage kernels."""
+    check(lib.aon_set_coarse_fusion(int(bool(on))), "aon_set_coarse_fusion")
+
+
 # ------------------------------------------------------------------ R9 whole path
 _WS_CACHE: dict = {}
-MAX_CHUNK_RAYS = 65536  # rays rendered per internal chunk (bounds the workspace to ~290 MB)
+# rays rendered per internal chunk: a whole 640x480 frame (307,200 rays) in one pass -- 4,380 B/ray of per-ray sample buffers =
+# 1.35 GB of the 288 GB, so that every per-ray kernel is ONE launch per frame (round 2: 65,536-ray chunks, five 30-60 us launches
+# each of which spent a fifth of its time ramping up and draining)
+MAX_CHUNK_RAYS = 327680
 
 
 def _workspace(device, n_rays: int) -> torch.Tensor:
@@ -734,7 +762,7 @@ def profile_end():
     return ms.value, launches.value, samples.value
 
 
-PROF_CLASSES = {"mlp_fwd": 0, "bwd_chain": 1, "wgrad": 2, "composite": 3, "sample_pdf": 4, "composite_bwd": 5}
+PROF_CLASSES = {"mlp_fwd": 0, "bwd_chain": 1, "wgrad": 2, "composite": 3, "sample_pdf": 4, "composite_bwd": 5, "composite_pdf": 6}
 
 
 def profile_classes() -> dict:

@@ -41,6 +41,7 @@ VAN_MAC_BWD_CHAIN = VAN_MAC - 2 * 256 * 63 - 128 * 27     # no data gradient int
 BYTES_COMPOSITE_COARSE = 65 * 20 + 12 + 20 + 65 * 4
 BYTES_COMPOSITE_FINE = 193 * 20 + 12 + 20
 BYTES_SAMPLE_PDF = 65 * 4 + 63 * 4 + 193 * 4
+BYTES_COARSE_FUSED = 65 * 20 + 12 + 20 + 193 * 4   # fused coarse level: records + t + dir in, outputs + t_fine out (weights stay in registers)
 
 
 def cpu_baseline(sd, rays_cpu, budget_s=20.0):
@@ -120,8 +121,14 @@ def per_ray_rooflines(classes):
     """HBM rooflines of the per-ray kernels of a two-level render from the profile classes (composite launches come in
     coarse / fine pairs over the same rays)."""
     out = {}
+    fused_ms, fused_launches, fused_rays = classes.get("composite_pdf", (0.0, 0, 0))
+    if fused_launches:   # the coarse level is ONE kernel: compositing + inverse CDF + merge
+        out["coarse_fused"] = hbm_roofline("aon::composite_kernel<true,true> (coarse compositing + inverse CDF + merge)", fused_ms, fused_launches,
+                                           fused_rays * BYTES_COARSE_FUSED)
     ms, launches, rays = classes["composite"]
-    if launches:
+    if launches and fused_launches:
+        out["composite"] = hbm_roofline("aon::composite_kernel<true,false> (fine level, 193 samples)", ms, launches, rays * BYTES_COMPOSITE_FINE)
+    elif launches:
         out["composite"] = hbm_roofline("aon::composite_kernel (coarse + fine launches)", ms, launches, rays / 2 * (BYTES_COMPOSITE_COARSE + BYTES_COMPOSITE_FINE))
     ms, launches, rays = classes["sample_pdf"]
     if launches:
@@ -282,7 +289,7 @@ def train_leg(dev, rank, world, distributed, steps=6, n_rays=4096):
             if r is not None:
                 r["ms_per_step"] = ms / steps
                 kernels[key] = r
-        other_ms = sum(classes[k][0] for k in ("composite", "sample_pdf", "composite_bwd")) / steps
+        other_ms = sum(classes[k][0] for k in ("composite", "sample_pdf", "composite_pdf", "composite_bwd") if k in classes) / steps
         res = {"workload": f"articulated NeRF_AE_Art training step, {n_rays} rays/GPU, fwd+bwd" + (" + RCCL gradient all-reduce (6.4 MB, one bucket)" if world > 1 else "") + " + Adam",
                "ms_per_step": dt * 1e3, "rays_per_s": world * n_rays / dt, "steps": steps, "loss": loss,
                "roofline": {"bound": "mfma", "unit": "TFLOP/s", "peak": PEAK_FP32_MATRIX_TFLOPS,

@@ -109,6 +109,18 @@ int aon_composite(const float* rgb, int rgb_stride, const float* sigma, int sigm
 int aon_sample_pdf(const float* bins, const float* weights, int64_t w_stride, const float* t_coarse, const float* u,
                    int64_t u_stride, int64_t n_rays, float* samples, float* t_fine, void* stream);
 
+/* ---- R8 + R6/R7 of the coarse level in one kernel: NeRF.forward, model.py:160-173 (helper.volumetric_rendering on the 65
+ * coarse samples, then helper.sample_pdf on weights[..., 1:-1] over the mid-points of t_coarse) ----
+ *   raw      (n*65,4) packed (raw rgb, raw sigma) records as the MLP entry points write them, 16-byte aligned
+ *   t_coarse (n,65), dirs (n,3), u / u_stride as aon_sample_pdf
+ * Outputs as aon_composite (weights (n,65) may be NULL: they never leave the registers) plus t_fine (n,193).  Same bits
+ * as aon_composite followed by aon_sample_pdf.  The whole-path entry points use this kernel for the coarse level;
+ * aon_set_coarse_fusion(0) makes them run the two stage kernels instead (measurements, equality tests). */
+int aon_composite_pdf(const float* raw, const float* t_coarse, const float* dirs, int64_t n_rays, int white_bkgd, int act,
+                      const float* u, int64_t u_stride, float* comp_rgb, float* acc, float* depth, float* weights,
+                      float* t_fine, void* stream);
+int aon_set_coarse_fusion(int on);
+
 /* ---- R9  NeRF.forward (model.py:147-199): the whole path in one call ----
  * num_levels 1 (coarse only) or 2.  t_rand (n,65) / u as above, NULL t_rand = randomized False (then u must be
  * the deterministic (128,) vector with u_stride 0).  Outputs: per level comp_rgb (n,3), acc (n,), depth (n,);
@@ -274,7 +286,8 @@ int aon_art_render_bwd(const void* packed_bwd_coarse, const void* small_coarse, 
 #define AON_PROF_COMPOSITE 3     /* alpha compositing (R8) */
 #define AON_PROF_SAMPLE_PDF 4    /* inverse-CDF sampling + merge (R6/R7) */
 #define AON_PROF_COMPOSITE_BWD 5 /* compositing backward */
-#define AON_PROF_NUM_CLASSES 6
+#define AON_PROF_COMPOSITE_PDF 6 /* coarse compositing fused with the inverse CDF + merge (R8 + R6/R7) */
+#define AON_PROF_NUM_CLASSES 7
 int aon_profile_begin(void);
 int aon_profile_end(double* mlp_ms, int64_t* mlp_launches, int64_t* mlp_samples);
 int aon_profile_class(int kernel_class, double* ms, int64_t* launches, int64_t* units);

@@ -360,6 +360,71 @@ def _psnr(a, b):
     return -10.0 * math.log10(max(torch.mean((a - b) ** 2).item(), 1e-20))
 
 
+def test_fused_coarse_level_equals_the_stage_kernels(ops, dev, nerf_sd):
+    """aon_composite_pdf (coarse compositing + inverse CDF + merge in one kernel, model.py:160-173) gives the same BITS as
+    aon_composite followed by aon_sample_pdf -- both activations, shared and per-ray u, degenerate rows -- and the whole-path
+    entry points render the same bits with the fusion on and off."""
+    import aon_amd.synthetic as syn
+    from aon_amd.models.vanilla_nerf.model import NeRF
+
+    gen = torch.Generator().manual_seed(21)
+    n = 777
+    raw = torch.randn(n, 65, 4, generator=gen) * 3
+    raw[:40, :, 3] = -5.0                      # empty rays: all-zero weights -> padded pdf
+    raw[40:80, 20, 3] = 80.0                   # one opaque shell
+    raw[80:90, :, 3] = 50.0                    # opaque from the first sample
+    raw[90:100, 64, 3] = -1.0                  # far sample transparent
+    t = torch.sort(torch.rand(n, 65, generator=gen) * 4 + 2, dim=-1).values
+    t[100:110] = torch.linspace(2.0, 6.0, 65)
+    t[110:115, 10:14] = t[110:115, 10:11]      # repeated t: zero-length intervals / equal bins
+    d = torch.nn.functional.normalize(torch.randn(n, 3, generator=gen), dim=-1) * (0.5 + torch.rand(n, 1, generator=gen))
+    u_rand = torch.rand(n, 128, generator=gen)
+    raw, t, d, u_rand = raw.to(dev), t.to(dev), d.to(dev), u_rand.to(dev)
+    for act, white in ((ops.ACT_VANILLA, True), (ops.ACT_ARTICULATED, False)):
+        for u in (None, u_rand):
+            cr, acc, w, dep = ops.composite_raw(raw, t, d, white, act)
+            tf = ops.sample_pdf_t(t, w, u)
+            cr2, acc2, w2, dep2, tf2 = ops.composite_pdf(raw, t, d, white, act, u, want_weights=True)
+            assert torch.equal(cr, cr2) and torch.equal(acc, acc2) and torch.equal(dep, dep2) and torch.equal(w, w2)
+            assert torch.equal(tf, tf2), f"{int((tf != tf2).sum())} of {tf.numel()} fine t differ"
+            cr3, _, w3, _, tf3 = ops.composite_pdf(raw, t, d, white, act, u)   # weights never written
+            assert w3 is None and torch.equal(cr, cr3) and torch.equal(tf, tf3)
+    # whole path: fusion on (default) == fusion off, deterministic and randomized
+    model = NeRF().to(dev)
+    model.load_state_dict(nerf_sd)
+    rays = {k: v.to(dev) for k, v in syn.random_rays(1500, seed=3).items()}
+    try:
+        for randomized in (False, True):
+            outs = []
+            for on in (True, False):
+                ops.set_coarse_fusion(on)
+                torch.manual_seed(5)
+                with torch.no_grad():
+                    outs.append(model(rays, randomized, True, 2.0, 6.0))
+            for lvl in (0, 1):
+                for a, b in zip(outs[0][lvl], outs[1][lvl]):
+                    assert torch.equal(a, b)
+    finally:
+        ops.set_coarse_fusion(True)
+
+
+def test_wave_reductions_of_the_compositing_kernel(ops, dev):
+    """The four-at-a-time lane-swap reduction (wave_sum4: v_permlane32_swap / v_permlane16_swap) routes every value to its own
+    total: channels with very different magnitudes must not leak into each other, and the sums must match fp64 sums of the
+    kernel's own weights."""
+    gen = torch.Generator().manual_seed(4)
+    n, S = 64, 65
+    rgb = torch.rand(n, S, 3, generator=gen) * torch.tensor([1.0, 1e3, 1e-3])
+    sig = torch.rand(n, S, 1, generator=gen) * 0.5
+    t = torch.sort(torch.rand(n, S, generator=gen) * 4 + 2, dim=-1).values
+    d = torch.nn.functional.normalize(torch.randn(n, 3, generator=gen), dim=-1)
+    cr, acc, w, dep = ops.volumetric_rendering(rgb.to(dev), sig.to(dev), t.to(dev), d.to(dev), False)
+    w64 = w.double().cpu()
+    torch.testing.assert_close(cr.double().cpu(), (w64[..., None] * rgb.double()).sum(1), rtol=2e-6, atol=1e-9)
+    torch.testing.assert_close(acc.double().cpu(), w64.sum(1), rtol=2e-6, atol=1e-9)
+    torch.testing.assert_close(dep.double().cpu(), (w64 * t.double()).sum(1), rtol=2e-6, atol=1e-9)
+
+
 @pytest.mark.parametrize("white", [True, False])
 def test_nerf_forward_vs_oracle_and_golden(dev, golden, nerf_sd, white):
     from aon_amd.models.vanilla_nerf.model import NeRF

@@ -1,12 +1,13 @@
 """Per-kernel roofline table from a rocprofv3 kernel trace (rocpd database) of `bench.py` (the two-level 640x480 render):
 
-    python tools/roofline_table.py <x_results.db> [rays_per_launch=61440]
+    python tools/roofline_table.py <x_results.db> [rays_per_launch=307200]
 
 For every kernel of the path: launches, average duration, ALGORITHMIC bytes (HBM-bound kernels, SURVEY 8(d) per-ray figures)
 or FLOPs (the fused MLP, reference-literal 1,186,816 FLOP per network evaluation) per launch, the achieved rate and the
 fraction of the peak that bounds it (8 TB/s HBM, 157.3 TFLOP/s fp32 matrix; MI355X_MICROARCH.md).  DESIGN.md cites this file.
-Launches of the MLP and compositing kernels alternate coarse (65 samples per ray) / fine (193) in a two-level render; rays per
-launch of the per-ray kernels are read from the dispatch grid (one 64-lane wavefront per ray)."""
+Launches of the MLP kernel alternate coarse (65 samples per ray) / fine (193) in a two-level render; rays per launch of the
+per-ray kernels are read from the dispatch grid (one 64-lane wavefront per ray); the coarse level's compositing is fused with the
+inverse CDF (composite_kernel<true, true>), composite_kernel<true, false> is the fine level."""
 import sqlite3
 import sys
 
@@ -15,11 +16,12 @@ FLOP_PER_EVAL = 1_186_816
 B_COMP = {65: 65 * 20 + 12 + 20 + 65 * 4, 193: 193 * 20 + 12 + 20}
 B_PDF = 65 * 4 + 63 * 4 + 193 * 4
 B_SAR = 65 * 4          # sample_along_rays: writes 65 t per ray (reads nothing per ray when deterministic)
+B_FUSED = 65 * 20 + 12 + 20 + 193 * 4   # fused coarse level (composite_kernel<true, true>): weights stay in registers, t_fine written
 
 
 def main():
     db = sys.argv[1]
-    rays_default = int(sys.argv[2]) if len(sys.argv) > 2 else 61440
+    rays_default = int(sys.argv[2]) if len(sys.argv) > 2 else 307200
     cur = sqlite3.connect(db).cursor()
     rows = list(cur.execute("select name, duration, grid_x, workgroup_x, start from kernels order by start"))
     by = {}
@@ -35,10 +37,12 @@ def main():
             for i, (dur, gx, wx) in enumerate(ds):
                 S = 65 if i % 2 == 0 else 193
                 groups.setdefault(f"S={S}", []).append((dur, rays_default * S * FLOP_PER_EVAL, "mfma"))
-        elif "composite_kernel" in name:
-            for i, (dur, gx, wx) in enumerate(ds):
-                S = 65 if i % 2 == 0 else 193
-                groups.setdefault(f"S={S}", []).append((dur, gx // 64 * B_COMP[S], "hbm"))
+        elif "composite_kernel<true, true>" in name:   # coarse level: compositing + inverse CDF + merge
+            for dur, gx, wx in ds:
+                groups.setdefault("S=65 fused", []).append((dur, gx // 64 * B_FUSED, "hbm"))
+        elif "composite_kernel" in name:   # two-level render with the fused coarse level: only the fine level launches this one
+            for dur, gx, wx in ds:
+                groups.setdefault("S=193", []).append((dur, gx // 64 * B_COMP[193], "hbm"))
         elif "sample_pdf" in name:
             for dur, gx, wx in ds:
                 groups.setdefault("", []).append((dur, gx // 64 * B_PDF, "hbm"))
