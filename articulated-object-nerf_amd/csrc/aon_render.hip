@@ -23,15 +23,30 @@ __device__ __forceinline__ float dpp_f32(float identity, float v) {
 // inclusive scan over the 64 lanes; lanes without a source keep the identity
 template <bool MUL>
 __device__ __forceinline__ float wave_inclusive_scan(float v, int /*lane*/) {
-  const float id = MUL ? 1.0f : 0.0f;
-  auto op = [](float a, float b) { return MUL ? a * b : a + b; };
-  v = op(v, dpp_f32<0x111, 0xf>(id, v));  // row_shr:1
-  v = op(v, dpp_f32<0x112, 0xf>(id, v));  // row_shr:2
-  v = op(v, dpp_f32<0x114, 0xf>(id, v));  // row_shr:4
-  v = op(v, dpp_f32<0x118, 0xf>(id, v));  // row_shr:8
-  v = op(v, dpp_f32<0x142, 0xa>(id, v));  // row_bcast:15 -> rows 1 and 3
-  v = op(v, dpp_f32<0x143, 0xc>(id, v));  // row_bcast:31 -> rows 2 and 3
-  return v;
+  if constexpr (MUL) {
+    // v <- dpp(v) * v with the DPP modifier on the multiply itself: a lane without a source (or outside the row mask) is
+    // disabled and keeps its value, which is what multiplying by the identity did -- one instruction per step instead of
+    // [move 1.0, v_mov_b32_dpp, v_mul_f32] (hipcc folds the DPP move into an add but not into a multiply).  s_nop 1: the two
+    // wait states a DPP read needs after the VALU write of its source, which the compiler cannot see inside the asm.
+    asm volatile(
+        "s_nop 1\n\tv_mul_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_mul_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_mul_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_mul_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_mul_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_mul_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "+v"(v));
+    return v;
+  } else {
+    v = v + dpp_f32<0x111, 0xf>(0.f, v);  // row_shr:1
+    v = v + dpp_f32<0x112, 0xf>(0.f, v);  // row_shr:2
+    v = v + dpp_f32<0x114, 0xf>(0.f, v);  // row_shr:4
+    v = v + dpp_f32<0x118, 0xf>(0.f, v);  // row_shr:8
+    v = v + dpp_f32<0x142, 0xa>(0.f, v);  // row_bcast:15 -> rows 1 and 3
+    v = v + dpp_f32<0x143, 0xc>(0.f, v);  // row_bcast:31 -> rows 2 and 3
+    return v;
+  }
 }
 
 // wave_shr:1 of a double (two 32-bit DPP moves), zero into lane 0
@@ -609,12 +624,19 @@ struct CompositeArgs {
   float* t_fine;                      // (n,193)
 };
 
-// 1 / (1 + exp(-x)): v_rcp_f32 (1 ulp) refined by one Newton step (<= 0.5 ulp + rounding) instead of the ten-instruction
-// correctly rounded division -- torch's own vectorised sigmoid differs from any of them by an ulp of exp anyway
+// 1 / (1 + exp(-x)).  The compositing kernels are bound by VALU issue (SQ_INSTS_VALU: 437 wave instructions per 193-sample ray,
+// three sigmoids per sample among them), so this is the short form: e = 2^(-x log2 e) straight on the transcendental unit --
+// the rounding of the product costs |x| 4e-8 relative on e, which reaches the RESULT as at most 1e-8 absolute (e / (1 + e)^2
+// is 0.25 at x = 0, where the product is exact, and 0.0066 at |x| = 5) -- then v_rcp_f32 (1 ulp) refined by one Newton step;
+// 8 instructions against 18 with the library expf and its range fix-ups.  x < -87: e overflows, the true value is below
+// 1.7e-38 -> 0 (a NaN input fails the comparison and stays NaN).  The density's alpha = 1 - exp(-sigma delta) keeps the
+// library expf: its error goes into the transmittance product and the inverse CDF's weights.
 __device__ __forceinline__ float sigmoid_f32(float x) {
-  const float d = __fadd_rn(1.0f, expf(-x));
+  const float e = __builtin_amdgcn_exp2f(__fmul_rn(x, -1.44269502162933349609375f));
+  const float d = __fadd_rn(1.0f, e);
   const float r = __builtin_amdgcn_rcpf(d);
-  return __builtin_fmaf(__builtin_fmaf(-d, r, 1.0f), r, r);
+  const float s = __builtin_fmaf(__builtin_fmaf(-d, r, 1.0f), r, r);
+  return x < -87.0f ? 0.f : s;
 }
 
 __device__ __forceinline__ float softplus_f32(float x) {  // torch Softplus(beta=1, threshold=20)

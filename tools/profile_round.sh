@@ -33,6 +33,9 @@ run rocprofv3 --kernel-trace --stats -d $OUT/bf16x3 -o $TAG -- python $REPO/benc
 run python $REPO/tools/render_bench.py --bf16x3 > $OUT/render_art_bf16x3.log 2>&1
 run python $REPO/tools/train_bench.py --rays 4096 --steps 10 --train-engine bf16x3 > $OUT/train_van_bf16x3.log 2>&1
 run python $REPO/tools/train_bench.py --rays 4096 --steps 10 --articulated --train-engine bf16x3 > $OUT/train_art_bf16x3.log 2>&1
+# 6. per-ray kernels one by one at the round-2 chunk size and at a whole frame (HIP events, no profiler)
+run python $REPO/tools/ray_kernel_bench.py > $OUT/ray_kernels.log 2>&1
+grep -h '^{' $OUT/ray_kernels.log > $SUM/${TAG}_ray_kernels.jsonl
 cd $REPO
 python tools/summarize_rocprof.py $OUT $SUM/${TAG} > $SUM/summary.log 2>&1
 f=$(ls $OUT/stats/*_results.db 2>/dev/null | head -1)

@@ -43,7 +43,7 @@ def main():
     ap.add_argument("--rays", default="61440,307200")
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--tag", default=os.environ.get("AON_HIP_LIB", "product"))
-    ap.add_argument("--only", default="", help="substring of the kernel label to run")
+    ap.add_argument("--only", default="", help="substring of the kernel label to run ('=label' for an exact match)")
     args = ap.parse_args()
     import aon_amd.synthetic as syn
     from aon_amd import ops
@@ -64,7 +64,7 @@ def main():
         u_rand = torch.rand(n, 128, device=dev)
 
         def emit(name, fn, bytes_per_ray):
-            if args.only and args.only not in name:
+            if args.only and (args.only[1:] != name if args.only.startswith("=") else args.only not in name):
                 return
             us = timeit(fn, args.reps)
             tbs = n * bytes_per_ray / (us * 1e-6) / 1e12

@@ -37,7 +37,7 @@ def main():
             for i, (dur, gx, wx) in enumerate(ds):
                 S = 65 if i % 2 == 0 else 193
                 groups.setdefault(f"S={S}", []).append((dur, rays_default * S * FLOP_PER_EVAL, "mfma"))
-        elif "composite_kernel<true, true>" in name:   # coarse level: compositing + inverse CDF + merge
+        elif "composite_kernel<true, true" in name:   # coarse level: compositing + inverse CDF + merge
             for dur, gx, wx in ds:
                 groups.setdefault("S=65 fused", []).append((dur, gx // 64 * B_FUSED, "hbm"))
         elif "composite_kernel" in name:   # two-level render with the fused coarse level: only the fine level launches this one
@@ -49,6 +49,9 @@ def main():
         elif "sample_along_rays" in name:
             for dur, gx, wx in ds:
                 groups.setdefault("", []).append((dur, gx // 65 * B_SAR, "hbm"))
+        elif "sample_t4_kernel" in name:   # four t values per thread: grid_x threads x 16 bytes written
+            for dur, gx, wx in ds:
+                groups.setdefault("", []).append((dur, gx * 16, "hbm"))
         else:
             groups[""] = [(dur, 0, "-") for dur, _, _ in ds]
         for tag, items in groups.items():
