@@ -141,6 +141,20 @@ def test_sample_along_rays_bit_exact(ops, dev, golden):
         t, c = ops.sample_along_rays(o, d, ns, 0.5, 3.25)
         torch.testing.assert_close(t.cpu(), t_or.contiguous(), rtol=0, atol=2.5e-7)
         torch.testing.assert_close(c.cpu(), c_or, rtol=0, atol=1e-6)
+    # the t-only form the render / training paths use (four elements per thread, 16-byte stores) gives the same bits as the
+    # per-element kernel, deterministic and randomized, at ray counts that leave every kind of tail
+    t_ref, _ = ops.sample_along_rays(o, d, 64, g["near"], g["far"], t_rand=g["t_rand"].to(dev))
+    t4, none = ops.sample_along_rays(o, d, 64, g["near"], g["far"], t_rand=g["t_rand"].to(dev), want_coords=False)
+    assert none is None and torch.equal(t4, t_ref) and torch.equal(t4.cpu(), g["t_rnd"])
+    gen = torch.Generator().manual_seed(17)
+    for n in (1, 2, 3, 5, 63, 1001):
+        oo, dd = torch.randn(n, 3, generator=gen).to(dev), torch.randn(n, 3, generator=gen).to(dev)
+        for ns in (64, 6, 2):
+            tr = torch.rand(n, ns + 1, generator=gen).to(dev)
+            for rnd in (None, tr):
+                a, _ = ops.sample_along_rays(oo, dd, ns, 2.0, 6.0, t_rand=rnd)
+                b, _ = ops.sample_along_rays(oo, dd, ns, 2.0, 6.0, t_rand=rnd, want_coords=False)
+                assert torch.equal(a, b), (n, ns, rnd is None)
 
 
 # ------------------------------------------------------------------ R4
