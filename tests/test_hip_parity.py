@@ -422,6 +422,55 @@ def test_fused_coarse_level_equals_the_stage_kernels(ops, dev, nerf_sd):
         ops.set_coarse_fusion(True)
 
 
+def test_compositing_at_every_block_shape(ops, dev):
+    """Sample counts around the 64-sample block boundaries (the last sample is evaluated outside the blocks; 65 and 193 are
+    compiled as constants, the rest take the run-time path), packed and unpacked inputs, against the oracle."""
+    gen = torch.Generator().manual_seed(31)
+    for S in (1, 2, 3, 63, 64, 65, 66, 128, 129, 130, 193, 194):
+        n = 37
+        raw = torch.randn(n, S, 4, generator=gen) * 3
+        t = torch.sort(torch.rand(n, S, generator=gen) * 4 + 2, dim=-1).values
+        d = torch.nn.functional.normalize(torch.randn(n, 3, generator=gen), dim=-1)
+        rgb, sig = torch.sigmoid(raw[..., :3]), torch.relu(raw[..., 3:])
+        cr_o, acc_o, w_o, dep_o = orc.volumetric_rendering(rgb, sig, t, d, True)
+        for packed in (True, False):
+            if packed:
+                cr, acc, w, dep = ops.composite_raw(raw.to(dev), t.to(dev), d.to(dev), True, ops.ACT_VANILLA)
+            else:
+                cr, acc, w, dep = ops.volumetric_rendering(rgb.to(dev), sig.to(dev), t.to(dev), d.to(dev), True)
+            torch.testing.assert_close(cr.cpu(), cr_o, rtol=0, atol=2e-6)
+            torch.testing.assert_close(acc.cpu(), acc_o, rtol=0, atol=2e-6)
+            torch.testing.assert_close(w.cpu(), w_o, rtol=0, atol=1e-6)
+            torch.testing.assert_close(dep.cpu(), dep_o, rtol=0, atol=1e-5)
+
+
+def test_render_is_independent_of_the_internal_chunking(ops, dev, nerf_sd):
+    """aon_render_fwd walks the rays in chunks as large as the workspace admits (a whole frame with the default workspace): a
+    workspace for 1,000 rays renders 2,500 rays in three chunks -- same bits as one chunk, deterministic and randomized."""
+    import aon_amd.synthetic as syn
+    from aon_amd.models.vanilla_nerf.model import NeRF
+
+    model = NeRF().to(dev)
+    model.load_state_dict(nerf_sd)
+    rays = {k: v.to(dev) for k, v in syn.random_rays(2500, seed=11).items()}
+    keep = ops.MAX_CHUNK_RAYS
+    try:
+        outs = []
+        for chunk in (keep, 1000):
+            ops.MAX_CHUNK_RAYS = chunk
+            ops._WS_CACHE.clear()
+            torch.manual_seed(3)
+            with torch.no_grad():
+                outs.append((model(rays, False, True, 2.0, 6.0), model(rays, True, True, 2.0, 6.0)))
+        for a, b in zip(outs[0], outs[1]):
+            for lvl in (0, 1):
+                for x, y in zip(a[lvl], b[lvl]):
+                    assert torch.equal(x, y)
+    finally:
+        ops.MAX_CHUNK_RAYS = keep
+        ops._WS_CACHE.clear()
+
+
 def test_wave_reductions_of_the_compositing_kernel(ops, dev):
     """The four-at-a-time lane-swap reduction (wave_sum4: v_permlane32_swap / v_permlane16_swap) routes every value to its own
     total: channels with very different magnitudes must not leak into each other, and the sums must match fp64 sums of the
