@@ -8,6 +8,12 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+# torch FIRST: it carries its own copy of the HIP runtime (torch/lib/libamdhip64.so), and the process must run on ONE runtime --
+# the one that owns torch's allocations and streams.  Loading libaon_hip.so before torch binds it to /opt/rocm's copy instead, and
+# its first launch on torch's memory fails with "no ROCm-capable device is detected" (seen when __graft_entry__.build() and
+# smoke() ran in one process on a GPU box).
+import torch  # noqa: F401
+
 _PKG = os.path.dirname(os.path.abspath(__file__))
 # AON_HIP_LIB: an alternative build of the SAME library (A/B experiments, tools/kernel_bench.py); never a different backend
 LIB_PATH = os.environ.get("AON_HIP_LIB") or os.path.join(_PKG, "libaon_hip.so")

@@ -2,6 +2,7 @@
 #include "../../include/aon_hip.h"
 #include "aon_common.h"
 
+#include <atomic>
 #include <cstdio>
 #include <cstring>
 #include <mutex>
@@ -291,9 +292,9 @@ int aon_sample_pdf(const float* bins, const float* weights, int64_t w_stride, co
 
 // The coarse level's compositing and the fine level's sampling as ONE kernel (model.py:160-173): the whole-path entry points
 // use it; aon_set_coarse_fusion(0) puts them back on the two stage kernels (A/B measurements, equality tests).
-static int g_fuse_coarse = 1;
+static std::atomic<int> g_fuse_coarse{1};   // process-wide switch; every call reads it ONCE
 int aon_set_coarse_fusion(int on) {
-  g_fuse_coarse = on ? 1 : 0;
+  g_fuse_coarse.store(on ? 1 : 0, std::memory_order_relaxed);
   return AON_OK;
 }
 
@@ -494,6 +495,7 @@ static int render_impl(const char* who, const NetRef& coarse, const NetRef& fine
   if (num_levels == 2 && u_stride != 0 && u_stride < 128) return fail(AON_E_INVALID, "render: bad u_stride");
   if (reinterpret_cast<uintptr_t>(workspace) & 255) return fail(AON_E_INVALID, "render: workspace must be 256-byte aligned");
   const int act = coarse.articulated ? AON_ACT_ARTICULATED : AON_ACT_VANILLA;
+  const bool fuse_coarse = num_levels == 2 && g_fuse_coarse.load(std::memory_order_relaxed) != 0;
 
   // largest chunk the workspace admits
   int64_t chunk = n_rays;
@@ -516,7 +518,7 @@ static int render_impl(const char* who, const NetRef& coarse, const NetRef& fine
     if (rc) return rc;
     rc = check(launch_net(coarse, o, d, v, w.t_c, n, kSc, w.raw, stream), who);
     if (rc) return rc;
-    if (num_levels == 2 && g_fuse_coarse) {
+    if (fuse_coarse) {
       // compositing + the fine level's sampling (model.py:162-173) in one kernel: the coarse weights stay in registers
       KTimer timer(kCompositePdf, stream, n);
       rc = check(aon::launch_composite_pdf(w.raw, w.t_c, d, n, white_bkgd, act, u_stride ? u + r0 * u_stride : u, u_stride, rgb_c + r0 * 3,
@@ -529,7 +531,7 @@ static int render_impl(const char* who, const NetRef& coarse, const NetRef& fine
     if (rc) return rc;
     if (num_levels == 1) continue;
     // level 1 (model.py:162-173, :175-197)
-    if (!g_fuse_coarse) {
+    if (!fuse_coarse) {
       KTimer timer(kSamplePdf, stream, n);
       rc = check(aon::launch_sample_pdf(nullptr, w.w_c + 1, kSc, w.t_c, u_stride ? u + r0 * u_stride : u, u_stride, n, nullptr, w.t_f,
                                         stream), who);
@@ -640,7 +642,7 @@ LevelStreams* level_streams() {
   }
   return &ls;
 }
-int g_bwd_overlap = 1;
+std::atomic<int> g_bwd_overlap{1};
 
 struct TrainNet {   // one level's network handles
   const void* packed_fwd; const float* small; const void* packed_bwd;
@@ -656,10 +658,10 @@ int train_fwd_impl(const char* who, bool art, const TrainNet* nets, const float*
   if (w.bytes > workspace_bytes) return fail(AON_E_WORKSPACE, "train forward: workspace smaller than aon_train_workspace_bytes()");
   if (num_levels == 2 && (!u || (u_stride != 0 && u_stride < 128))) return fail(AON_E_INVALID, "train forward: bad u / u_stride");
   const int act = art ? AON_ACT_ARTICULATED : AON_ACT_VANILLA;
+  const bool fuse = num_levels == 2 && g_fuse_coarse.load(std::memory_order_relaxed) != 0;
   for (int l = 0; l < num_levels; ++l) {
     const TrainLevel& L = w.lvl[l];
     if (!nets[l].packed_fwd || (art && !nets[l].small) || !rgb[l] || !acc[l] || !depth[l]) return fail(AON_E_INVALID, "train forward: null level pointer");
-    const bool fuse = num_levels == 2 && g_fuse_coarse;
     int rc = AON_OK;
     if (l == 0) {
       rc = check(aon::launch_sample_along_rays(rays_o, rays_d, n, kSc, near_, far_, t_rand, L.t, nullptr, stream), who);
@@ -693,7 +695,7 @@ int train_fwd_impl(const char* who, bool art, const TrainNet* nets, const float*
 }  // namespace
 
 int aon_set_bwd_overlap(int on) {
-  g_bwd_overlap = on ? 1 : 0;
+  g_bwd_overlap.store(on ? 1 : 0, std::memory_order_relaxed);
   return AON_OK;
 }
 
@@ -736,7 +738,7 @@ int aon_render_bwd(const void* packed_bwd_coarse, const void* packed_fwd_coarse,
   const void* pf[2] = {packed_fwd_coarse, packed_fwd_fine};
   float* const* grads[2] = {grads_coarse_host, grads_fine_host};
   // fork: with two levels each runs on its own library stream, ordered after everything already enqueued on the caller's
-  LevelStreams* ls = (num_levels == 2 && g_bwd_overlap) ? level_streams() : nullptr;
+  LevelStreams* ls = (num_levels == 2 && g_bwd_overlap.load(std::memory_order_relaxed)) ? level_streams() : nullptr;
   hipStream_t caller = stream;
   if (ls) {
     int rc0 = check(hipEventRecord(ls->fork, caller), "aon_render_bwd");
@@ -804,7 +806,7 @@ int aon_art_render_bwd(const void* packed_bwd_coarse, const void* small_coarse, 
   const float* const* params[2] = {params_coarse_host, params_fine_host};
   float* const* grads[2] = {grads_coarse_host, grads_fine_host};
   // fork: with two levels each runs on its own library stream, ordered after everything already enqueued on the caller's
-  LevelStreams* ls = (num_levels == 2 && g_bwd_overlap) ? level_streams() : nullptr;
+  LevelStreams* ls = (num_levels == 2 && g_bwd_overlap.load(std::memory_order_relaxed)) ? level_streams() : nullptr;
   hipStream_t caller = stream;
   if (ls) {
     int rc0 = check(hipEventRecord(ls->fork, caller), "aon_art_render_bwd");

@@ -490,8 +490,10 @@ __device__ __forceinline__ void inverse_cdf_merge(float* L, int lane, float tc, 
   // pdf / cdf  (helper.py:206-222)
   float wsum = torch_sum63(w, lane);
   const float padding = __builtin_fmaxf(0.f, __fsub_rn(1e-5f, wsum));
-  w = __fadd_rn(w, __fdiv_rn(padding, 63.0f));
-  wsum = __fadd_rn(wsum, padding);
+  if (padding != 0.f) {   // wave-uniform (wsum is); w + 0/63 and wsum + 0 are the identity, so the common case skips a division
+    w = __fadd_rn(w, __fdiv_rn(padding, 63.0f));
+    wsum = __fadd_rn(wsum, padding);
+  }
   const float pdf = __fdiv_rn(w, wsum);
   // cdf64 = [0, min(1, cumsum(pdf[:-1])) (62 entries), 1]
   const float prefix = exact_prefix_f64(pdf, lane);   // lane j+1 <- float(p0 + ... + pj) in torch's arithmetic; lane 0 <- 0
