@@ -112,7 +112,7 @@ constexpr int kSc = 65, kSf = 193;
 // current stream), by kernel class; bench.py turns the totals into roofline figures.  Off unless aon_profile_begin() was
 // called: one mutex-guarded branch per launch otherwise.
 enum KClass { kMlpFwd = AON_PROF_MLP_FWD, kBwdChain = AON_PROF_BWD_CHAIN, kWgrad = AON_PROF_WGRAD, kComposite = AON_PROF_COMPOSITE,
-              kSamplePdf = AON_PROF_SAMPLE_PDF, kCompositeBwd = AON_PROF_COMPOSITE_BWD, kCompositePdf = AON_PROF_COMPOSITE_PDF,
+              kSamplePdf = AON_PROF_SAMPLE_PDF, kCompositeBwd = AON_PROF_COMPOSITE_BWD, kCompositePdf = AON_PROF_COMPOSITE_PDF, kSampleT = AON_PROF_SAMPLE_T,
               kNumClasses = AON_PROF_NUM_CLASSES };
 
 struct Profiler {
@@ -514,7 +514,10 @@ static int render_impl(const char* who, const NetRef& coarse, const NetRef& fine
     const float* v = viewdirs + r0 * 3;
     int rc;
     // level 0 (model.py:150-160, :175-197)
-    rc = check(aon::launch_sample_along_rays(o, d, n, kSc, near_, far_, t_rand ? t_rand + r0 * kSc : nullptr, w.t_c, nullptr, stream), who);
+    {
+      KTimer timer(kSampleT, stream, n);
+      rc = check(aon::launch_sample_along_rays(o, d, n, kSc, near_, far_, t_rand ? t_rand + r0 * kSc : nullptr, w.t_c, nullptr, stream), who);
+    }
     if (rc) return rc;
     rc = check(launch_net(coarse, o, d, v, w.t_c, n, kSc, w.raw, stream), who);
     if (rc) return rc;
@@ -664,6 +667,7 @@ int train_fwd_impl(const char* who, bool art, const TrainNet* nets, const float*
     if (!nets[l].packed_fwd || (art && !nets[l].small) || !rgb[l] || !acc[l] || !depth[l]) return fail(AON_E_INVALID, "train forward: null level pointer");
     int rc = AON_OK;
     if (l == 0) {
+      KTimer timer(kSampleT, stream, n);
       rc = check(aon::launch_sample_along_rays(rays_o, rays_d, n, kSc, near_, far_, t_rand, L.t, nullptr, stream), who);
     } else if (!fuse) {
       KTimer timer(kSamplePdf, stream, n);

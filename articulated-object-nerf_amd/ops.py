@@ -762,7 +762,7 @@ def profile_end():
     return ms.value, launches.value, samples.value
 
 
-PROF_CLASSES = {"mlp_fwd": 0, "bwd_chain": 1, "wgrad": 2, "composite": 3, "sample_pdf": 4, "composite_bwd": 5, "composite_pdf": 6}
+PROF_CLASSES = {"mlp_fwd": 0, "bwd_chain": 1, "wgrad": 2, "composite": 3, "sample_pdf": 4, "composite_bwd": 5, "composite_pdf": 6, "sample_t": 7}
 
 
 def profile_classes() -> dict:

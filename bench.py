@@ -133,6 +133,9 @@ def per_ray_rooflines(classes):
     ms, launches, rays = classes["sample_pdf"]
     if launches:
         out["sample_pdf"] = hbm_roofline("aon::sample_pdf_kernel", ms, launches, rays * BYTES_SAMPLE_PDF)
+    ms, launches, rays = classes.get("sample_t", (0.0, 0, 0))
+    if launches:   # deterministic stratified t: a pure write of 65 floats per ray
+        out["sample_t"] = hbm_roofline("aon::sample_t4_kernel (stratified t, 65 per ray)", ms, launches, rays * 65 * 4)
     return out
 
 
@@ -289,7 +292,7 @@ def train_leg(dev, rank, world, distributed, steps=6, n_rays=4096):
             if r is not None:
                 r["ms_per_step"] = ms / steps
                 kernels[key] = r
-        other_ms = sum(classes[k][0] for k in ("composite", "sample_pdf", "composite_pdf", "composite_bwd") if k in classes) / steps
+        other_ms = sum(classes[k][0] for k in ("composite", "sample_pdf", "composite_pdf", "composite_bwd", "sample_t") if k in classes) / steps
         res = {"workload": f"articulated NeRF_AE_Art training step, {n_rays} rays/GPU, fwd+bwd" + (" + RCCL gradient all-reduce (6.4 MB, one bucket)" if world > 1 else "") + " + Adam",
                "ms_per_step": dt * 1e3, "rays_per_s": world * n_rays / dt, "steps": steps, "loss": loss,
                "roofline": {"bound": "mfma", "unit": "TFLOP/s", "peak": PEAK_FP32_MATRIX_TFLOPS,

@@ -287,7 +287,8 @@ int aon_art_render_bwd(const void* packed_bwd_coarse, const void* small_coarse, 
 #define AON_PROF_SAMPLE_PDF 4    /* inverse-CDF sampling + merge (R6/R7) */
 #define AON_PROF_COMPOSITE_BWD 5 /* compositing backward */
 #define AON_PROF_COMPOSITE_PDF 6 /* coarse compositing fused with the inverse CDF + merge (R8 + R6/R7) */
-#define AON_PROF_NUM_CLASSES 7
+#define AON_PROF_SAMPLE_T 7      /* stratified t of the coarse level (R3) inside the whole-path calls */
+#define AON_PROF_NUM_CLASSES 8
 int aon_profile_begin(void);
 int aon_profile_end(double* mlp_ms, int64_t* mlp_launches, int64_t* mlp_samples);
 int aon_profile_class(int kernel_class, double* ms, int64_t* launches, int64_t* units);

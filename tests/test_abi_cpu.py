@@ -125,9 +125,9 @@ def test_two_call_training_entries_validate_without_gpu():
                                   None, None, 0, None) != 0
     assert lib.aon_set_bwd_overlap(0) == 0 and lib.aon_set_bwd_overlap(1) == 0
     ms, n, u = C.c_double(-1), C.c_int64(-1), C.c_int64(-1)
-    for cls in range(7):
+    for cls in range(8):
         assert lib.aon_profile_class(cls, C.byref(ms), C.byref(n), C.byref(u)) == 0 and ms.value == 0.0 and n.value == 0
-    assert lib.aon_profile_class(7, C.byref(ms), C.byref(n), C.byref(u)) != 0
+    assert lib.aon_profile_class(8, C.byref(ms), C.byref(n), C.byref(u)) != 0
     # fused coarse level (aon_composite_pdf): validation before any HIP call; the fusion switch of the whole-path entry points
     assert lib.aon_composite_pdf(None, None, None, 4, 1, 1, None, 0, None, None, None, None, None, None) != 0 and b"null" in lib.aon_last_error()
     assert lib.aon_composite_pdf(None, None, None, 4, 1, 3, None, 0, None, None, None, None, None, None) != 0 and b"bad size" in lib.aon_last_error()
