@@ -11,6 +11,14 @@ import torch
 from . import ops
 
 
+def _check_not_released(ctx):
+    """The activation planes (10-14 KB per sample) are handed back after the first backward, like autograd's own saved
+    tensors without retain_graph: a second backward through the same forward gets the error autograd would give."""
+    if getattr(ctx, "released", False):
+        raise RuntimeError("aon render: the activation workspace of this forward was released by its first backward "
+                           "(a second backward / retain_graph=True is not supported; run the forward again)")
+
+
 class RenderVanilla(torch.autograd.Function):
     @staticmethod
     def forward(ctx, rays_o, rays_d, viewdirs, near, far, white_bkgd, num_levels, t_rand, u, packs, *params):
@@ -49,6 +57,7 @@ class RenderVanilla(torch.autograd.Function):
     @staticmethod
     def backward(ctx, *gouts):
         grads = []
+        _check_not_released(ctx)
         if ctx.fused is not None:               # ... and so is the whole backward (aon_render_bwd)
             ws, packs_bwd, packs_fwd = ctx.fused
             n = ctx.rays_d.shape[0]
@@ -56,7 +65,7 @@ class RenderVanilla(torch.autograd.Function):
                      for l in range(ctx.num_levels)]
             per_level = ops.render_bwd(ws, packs_bwd, packs_fwd, ctx.rays_d, ctx.white_bkgd, ctx.num_levels, g_rgb,
                                        [gouts[3 * l + 1] for l in range(ctx.num_levels)], [gouts[3 * l + 2] for l in range(ctx.num_levels)])
-            ctx.fused = None
+            ctx.fused, ctx.released = None, True
             return (None,) * 10 + tuple(g[name] for g in per_level for name in ops.VANILLA_PARAM_ORDER)
         for lvl in range(ctx.num_levels):
             raw, t_vals, planes, masks, packed_fwd, packed_bwd, packed_bwd_bf = ctx.saved[lvl]
@@ -72,7 +81,7 @@ class RenderVanilla(torch.autograd.Function):
             g = ops.vanilla_wgrad(planes, dplanes, d_raw)
             grads += [g[name] for name in ops.VANILLA_PARAM_ORDER]
             del dplanes
-        ctx.saved = None
+        ctx.saved, ctx.released = None, True
         return (None,) * 10 + tuple(grads)
 
 
@@ -118,6 +127,7 @@ class RenderArticulated(torch.autograd.Function):
         grads = []
         g_lat_tot = None
         n_per = len(ops.ART_PARAM_ORDER)
+        _check_not_released(ctx)
         if ctx.fused is not None:               # the whole backward in ONE C call (aon_art_render_bwd)
             ws, packs_bwd, smalls = ctx.fused
             n = ctx.rays_d.shape[0]
@@ -127,7 +137,7 @@ class RenderArticulated(torch.autograd.Function):
             per_level, g_lat = ops.art_render_bwd(ws, packs_bwd, smalls, ctx.rays_d, ctx.white_bkgd, ctx.num_levels, g_rgb,
                                                   [gouts[3 * l + 1] for l in range(ctx.num_levels)], [gouts[3 * l + 2] for l in range(ctx.num_levels)],
                                                   params, ctx.latents)
-            ctx.fused = None
+            ctx.fused, ctx.released = None, True
             lat = tuple(g_lat[k].reshape(shp) for k, shp in zip(("density", "color", "articulation"), ctx.lat_shapes))
             return (None,) * 10 + lat + tuple(g[name] for g in per_level for name in ops.ART_PARAM_ORDER)
         for lvl in range(ctx.num_levels):
@@ -146,6 +156,6 @@ class RenderArticulated(torch.autograd.Function):
             grads += [g[name] for name in ops.ART_PARAM_ORDER]
             g_lat_tot = g_lat if g_lat_tot is None else {k: g_lat_tot[k] + g_lat[k] for k in g_lat}
             del dplanes
-        ctx.saved = None
+        ctx.saved, ctx.released = None, True
         lat = tuple(g_lat_tot[k].reshape(shp) for k, shp in zip(("density", "color", "articulation"), ctx.lat_shapes))
         return (None,) * 10 + lat + tuple(grads)

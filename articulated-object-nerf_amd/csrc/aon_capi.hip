@@ -628,6 +628,7 @@ __global__ void add_into_kernel(float* __restrict__ dst, const float* __restrict
 struct LevelStreams {
   hipStream_t s[2] = {nullptr, nullptr};
   hipEvent_t fork = nullptr, join[2] = {nullptr, nullptr};
+  std::mutex enqueue;   // held from the fork record to the join waits: the one event set is re-recorded by every call
 };
 LevelStreams* level_streams() {
   static LevelStreams per_dev[aon::kMaxDevices];
@@ -645,6 +646,46 @@ LevelStreams* level_streams() {
   }
   return &ls;
 }
+
+// One backward's use of the two streams.  The constructor takes the device's enqueue lock and forks (fork event on the
+// caller's stream, both side streams wait for it); join() -- also run by the destructor, so on EVERY return path, error
+// returns included -- records a join event behind whatever was enqueued on each side stream and makes the caller's stream
+// wait for both.  Two host threads driving the same device from different caller streams therefore cannot interleave their
+// event records, and no side-stream work is ever left un-joined while the caller frees the workspace on its stream.
+class LevelFork {
+ public:
+  LevelFork(bool overlap, hipStream_t caller, const char* who) : caller_(caller), who_(who) {
+    if (!overlap) return;
+    ls_ = level_streams();
+    if (!ls_) return;   // no streams: run serially on the caller's stream
+    lk_ = std::unique_lock<std::mutex>(ls_->enqueue);
+    rc_ = check(hipEventRecord(ls_->fork, caller_), who_);
+    for (int l = 0; l < 2 && !rc_; ++l) rc_ = check(hipStreamWaitEvent(ls_->s[l], ls_->fork, 0), who_);
+    forked_ = true;     // even on a partial failure: join() is harmless and keeps the caller ordered behind the side streams
+  }
+  ~LevelFork() { (void)join(); }
+  int rc() const { return rc_; }
+  hipStream_t stream(int level) const { return forked_ ? ls_->s[level] : caller_; }
+  int join() {
+    if (!forked_) return AON_OK;
+    forked_ = false;
+    int rc = AON_OK;
+    for (int l = 0; l < 2; ++l) {
+      hipError_t e = hipEventRecord(ls_->join[l], ls_->s[l]);
+      if (e == hipSuccess) e = hipStreamWaitEvent(caller_, ls_->join[l], 0);
+      if (e != hipSuccess && !rc) rc = check(e, who_);
+    }
+    lk_.unlock();
+    return rc;
+  }
+ private:
+  LevelStreams* ls_ = nullptr;
+  hipStream_t caller_;
+  const char* who_;
+  std::unique_lock<std::mutex> lk_;
+  int rc_ = AON_OK;
+  bool forked_ = false;
+};
 std::atomic<int> g_bwd_overlap{1};
 
 struct TrainNet {   // one level's network handles
@@ -742,19 +783,12 @@ int aon_render_bwd(const void* packed_bwd_coarse, const void* packed_fwd_coarse,
   const void* pf[2] = {packed_fwd_coarse, packed_fwd_fine};
   float* const* grads[2] = {grads_coarse_host, grads_fine_host};
   // fork: with two levels each runs on its own library stream, ordered after everything already enqueued on the caller's
-  LevelStreams* ls = (num_levels == 2 && g_bwd_overlap.load(std::memory_order_relaxed)) ? level_streams() : nullptr;
   hipStream_t caller = stream;
-  if (ls) {
-    int rc0 = check(hipEventRecord(ls->fork, caller), "aon_render_bwd");
-    if (rc0) return rc0;
-  }
+  LevelFork fork(num_levels == 2 && g_bwd_overlap.load(std::memory_order_relaxed), caller, "aon_render_bwd");
+  if (fork.rc()) return fork.rc();
   for (int l = 0; l < num_levels; ++l) {
     const TrainLevel& L = w.lvl[l];
-    if (ls) {
-      stream = ls->s[l];
-      int rc0 = check(hipStreamWaitEvent(stream, ls->fork, 0), "aon_render_bwd");
-      if (rc0) return rc0;
-    }
+    stream = fork.stream(l);
     if (!pb[l] || !pf[l] || !grads[l] || !g_rgb_host[l]) return fail(AON_E_INVALID, "aon_render_bwd: null level pointer");
     for (int i = 0; i < aon::kNumVanillaParams; ++i)
       if (!grads[l][i]) return fail(AON_E_INVALID, "aon_render_bwd: null gradient pointer");
@@ -778,17 +812,8 @@ int aon_render_bwd(const void* packed_bwd_coarse, const void* packed_fwd_coarse,
       rc = check(aon::launch_vanilla_wgrad(L.planes, w.dplanes[l], w.d_raw[l], L.Np, grads[l], w.wgrad_ws[l], stream), "aon_render_bwd");
     }
     if (rc) return rc;
-    if (ls) {
-      rc = check(hipEventRecord(ls->join[l], stream), "aon_render_bwd");
-      if (rc) return rc;
-    }
   }
-  if (ls) {   // join: the caller's stream continues after both levels
-    for (int l = 0; l < 2; ++l) {
-      int rc = check(hipStreamWaitEvent(caller, ls->join[l], 0), "aon_render_bwd");
-      if (rc) return rc;
-    }
-  }
+  if (int rc = fork.join()) return rc;   // the caller's stream continues after both levels
   return AON_OK;
 }
 
@@ -810,19 +835,12 @@ int aon_art_render_bwd(const void* packed_bwd_coarse, const void* small_coarse, 
   const float* const* params[2] = {params_coarse_host, params_fine_host};
   float* const* grads[2] = {grads_coarse_host, grads_fine_host};
   // fork: with two levels each runs on its own library stream, ordered after everything already enqueued on the caller's
-  LevelStreams* ls = (num_levels == 2 && g_bwd_overlap.load(std::memory_order_relaxed)) ? level_streams() : nullptr;
   hipStream_t caller = stream;
-  if (ls) {
-    int rc0 = check(hipEventRecord(ls->fork, caller), "aon_art_render_bwd");
-    if (rc0) return rc0;
-  }
+  LevelFork fork(num_levels == 2 && g_bwd_overlap.load(std::memory_order_relaxed), caller, "aon_art_render_bwd");
+  if (fork.rc()) return fork.rc();
   for (int l = 0; l < num_levels; ++l) {
     const TrainLevel& L = w.lvl[l];
-    if (ls) {
-      stream = ls->s[l];
-      int rc0 = check(hipStreamWaitEvent(stream, ls->fork, 0), "aon_art_render_bwd");
-      if (rc0) return rc0;
-    }
+    stream = fork.stream(l);
     if (!pb[l] || !sm[l] || !grads[l] || !params[l] || !g_rgb_host[l]) return fail(AON_E_INVALID, "aon_art_render_bwd: null level pointer");
     for (int i = 0; i < 40; ++i)
       if (!grads[l][i] || !params[l][i]) return fail(AON_E_INVALID, "aon_art_render_bwd: null parameter / gradient pointer");
@@ -849,17 +867,8 @@ int aon_art_render_bwd(const void* packed_bwd_coarse, const void* small_coarse, 
                                        w.wgrad_ws[l], stream), "aon_art_render_bwd");
     }
     if (rc) return rc;
-    if (ls) {
-      rc = check(hipEventRecord(ls->join[l], stream), "aon_art_render_bwd");
-      if (rc) return rc;
-    }
   }
-  if (ls) {   // join: the caller's stream continues after both levels
-    for (int l = 0; l < 2; ++l) {
-      int rc = check(hipStreamWaitEvent(caller, ls->join[l], 0), "aon_art_render_bwd");
-      if (rc) return rc;
-    }
-  }
+  if (int rc = fork.join()) return rc;   // the caller's stream continues after both levels
   if (num_levels == 2) {
     add_into_kernel<<<dim3(1), dim3(128), 0, caller>>>(g_shape, w.lat_tmp, 128);
     add_into_kernel<<<dim3(1), dim3(128), 0, caller>>>(g_appearance, w.lat_tmp + 128, 128);

@@ -103,6 +103,7 @@ constexpr int kLdsBytes = kRingBytes + (int)kSmallBytes;
 // TRAIN additionally stores every layer's input/output activations as feature-major planes for the backward pass.
 template <bool ENC_IN_KERNEL, bool TRAIN>
 __global__ void __launch_bounds__(256) mlp_fwd_kernel(MlpArgs args) {
+  static_assert(!TRAIN || ENC_IN_KERNEL, "the training path re-encodes from x[] / vd[], which only the in-kernel encoding fills");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* sm = reinterpret_cast<float*>(smem + kRingBytes);
 

@@ -131,6 +131,7 @@ struct ArtMlpArgs {
 
 template <bool POS_IN_KERNEL, bool TRAIN>
 __global__ void __launch_bounds__(256) art_mlp_fwd_kernel(ArtMlpArgs args) {
+  static_assert(!TRAIN || POS_IN_KERNEL, "the training path encodes the view direction from vd[], which only the in-kernel ray cast fills");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* sm = reinterpret_cast<float*>(smem + kRingBytes);
   const int tid = threadIdx.x;

@@ -32,25 +32,32 @@ def _active(group) -> bool:
     return dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
 
 
-def all_gather_pixels(level, group=None, total: int | None = None, counts=None, force: bool = False):
+def all_gather_pixels(level, group=None, total: int | None = None, counts=None, force: bool = False, _pad_to: int = 0):
     """level = (rgb (n,3), acc (n,), depth (n,)) of this rank's ray range -> the same triple for ALL ranks' rays,
     rank-major (rank 0's range first), with ONE all_gather_into_tensor and no host synchronisation.
 
-    Every rank must be able to name every rank's ray count without asking: `total` = number of rays of the sharded
-    frame (counts follow from `shard_range`, the layout `render_frame_sharded` uses), or `counts` = explicit per-rank
-    list, or neither = every rank holds the same number of rays as this one.  Equal counts gather in place into the
-    final (total,5) buffer; uneven ones (they differ by at most one ray under shard_range) pad to the longest and the
-    padding rows are dropped with host-known offsets.  `force` runs the collective even at world size 1 (tests)."""
+    Every rank must be able to name every rank's ray count without asking, so with more than one rank the layout is a
+    REQUIRED argument: `total` = number of rays of the sharded frame (counts follow from `shard_range`, the layout
+    `render_frame_sharded` uses) or `counts` = explicit per-rank list.  (Guessing "everyone holds what I hold" would pass
+    the local check on every rank of an uneven layout and then hang or corrupt inside RCCL on mismatched buffers.)  Equal
+    counts gather in place into the final (total,5) buffer; uneven ones (they differ by at most one ray under shard_range)
+    pad to the longest and the padding rows are dropped with host-known offsets.  `force` runs the collective even at
+    world size 1 (tests); `_pad_to` (tests) pads every rank's message to at least that many rows, which drives the
+    uneven-layout branch -- padding, gather, drop -- through the real collective on a one-GPU box."""
     rgb, acc, depth = level
     if not (_active(group) or (force and dist.is_available() and dist.is_initialized())):
         return rgb, acc, depth
     world, n = dist.get_world_size(group), rgb.shape[0]
     if counts is None:
-        counts = [n] * world if total is None else [e - b for b, e in (shard_range(total, r, world) for r in range(world))]
+        if total is None:
+            if world > 1:
+                raise ValueError("all_gather_pixels: with more than one rank pass `total` (shard_range layout) or `counts`")
+            total = n
+        counts = [e - b for b, e in (shard_range(total, r, world) for r in range(world))]
     counts = [int(c) for c in counts]
     if len(counts) != world or counts[dist.get_rank(group)] != n:
         raise ValueError(f"all_gather_pixels: this rank holds {n} rays but the stated layout is {counts}")
-    nmax = max(counts)
+    nmax = max(max(counts), int(_pad_to))
     mine = rgb.new_empty((nmax, 5))
     mine[:n, :3] = rgb
     mine[:n, 3] = acc
@@ -89,16 +96,19 @@ def broadcast_parameters(module, src: int = 0, group=None, force: bool = False) 
         torch._foreach_copy_([p.data for p in params], [c.view_as(p) for c, p in zip(flat.split([p.numel() for p in params]), params)])
 
 
-def allreduce_gradients(module, group=None, force: bool = False) -> None:
+def allreduce_gradients(module, group=None, force: bool = False, shard_align: int = 64) -> None:
     """Mean of the per-rank gradients in ONE flat bucket (vanilla: 1,191,688 fp32 = 4.77 MB; articulated 6.4 MB), call
     between loss.backward() and optimizer.step().
 
     The bucket spans EVERY parameter that requires grad, in module order, with zeros where this rank produced no gradient
-    (num_levels=1 leaves fine_mlp untouched; a rank may skip a code-library row) -- ranks therefore always agree on the
-    message size -- and the mean is written back as `.grad` for all of them.  On RCCL the exchange is the direct
+    (a rank may skip a code-library row) -- ranks therefore always agree on the message size -- followed by one "had a
+    gradient" flag per parameter, summed in the same exchange.  The mean is written back as `.grad` for every parameter
+    that SOME rank produced a gradient for; a parameter no rank touched (num_levels=1 leaves fine_mlp alone) keeps
+    `.grad = None` exactly as under torch DDP (run.py:151), so the optimizer skips it and its Adam state does not
+    advance.  On RCCL the exchange is the direct
     reduce-scatter + all-gather pair (each of the 8 fully connected xGMI peers reduces one eighth of the bucket, scales
-    it, and the eighths are gathered: 2 x 7/8 of the bucket per link instead of a ring's 2 x 7 hops); gloo (CPU tests)
-    has no reduce_scatter_tensor and takes one all_reduce."""
+    it, and the eighths are gathered: 2 x 7/8 of the bucket per link instead of a ring's 2 x 7 hops).  Every rank's shard is
+    a multiple of `shard_align` elements (256 B): the bucket is zero-padded to world x that."""
     if not (_active(group) or (force and dist.is_available() and dist.is_initialized())):
         return
     params = [p for p in module.parameters() if p.requires_grad]
@@ -107,7 +117,8 @@ def allreduce_gradients(module, group=None, force: bool = False) -> None:
     world = dist.get_world_size(group)
     sizes = [p.numel() for p in params]
     total = sum(sizes)
-    padded = (total + world - 1) // world * world
+    quantum = world * max(1, int(shard_align))
+    padded = (total + len(params) + quantum - 1) // quantum * quantum
     ref = params[0]
     flat = torch.zeros(padded, dtype=ref.dtype, device=ref.device)
     with torch.no_grad():
@@ -115,16 +126,25 @@ def allreduce_gradients(module, group=None, force: bool = False) -> None:
         had = [p.grad is not None for p in params]
         if any(had):
             torch._foreach_copy_([c for c, h in zip(chunks, had) if h], [p.grad.reshape(-1) for p, h in zip(params, had) if h])
+        flat[total: total + len(params)] = torch.tensor([float(h) for h in had], dtype=ref.dtype).to(ref.device, non_blocking=True)
+        # one code path for both backends: reduce-scatter -> scale the shard -> all-gather.  gloo has no
+        # reduce_scatter_tensor, so there the scatter is an all_reduce of which every rank keeps its own shard -- the shard
+        # arithmetic (padding, offsets, rank order) is then exactly what RCCL runs and the world-2 CPU tests cover it.
+        per = padded // world
         if dist.get_backend(group) == "nccl":
-            shard = flat.new_empty(padded // world)
+            shard = flat.new_empty(per)
             dist.reduce_scatter_tensor(shard, flat, op=dist.ReduceOp.SUM, group=group)
-            shard /= world
-            dist.all_gather_into_tensor(flat, shard, group=group)
         else:
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
-            flat /= world
+            r = dist.get_rank(group)
+            shard = flat[r * per: (r + 1) * per].clone()
+            flat.fill_(float("nan"))   # nothing below may depend on what the all_reduce left outside this rank's shard
+        shard /= world
+        dist.all_gather_into_tensor(flat, shard, group=group)
         if any(had):
             torch._foreach_copy_([p.grad for p, h in zip(params, had) if h], [c.view_as(p) for c, p, h in zip(chunks, params, had) if h])
-        for c, p, h in zip(chunks, params, had):
-            if not h:
-                p.grad = c.view_as(p).clone()
+        if not all(had):   # the one host read of the exchange, and only on ranks that lack a gradient some other rank may have
+            any_rank = (flat[total: total + len(params)] > 0).tolist()
+            for c, p, h, a in zip(chunks, params, had, any_rank):
+                if not h and a:
+                    p.grad = c.view_as(p).clone()

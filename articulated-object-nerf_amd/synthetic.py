@@ -153,6 +153,13 @@ def make_rays(H: int, W: int, c2w: torch.Tensor | None = None, focal: float | No
     return {"rays_o": rays_o, "rays_d": rays_d, "viewdirs": rays_d.clone()}
 
 
+def seeded_uniform(seed: int, *shape) -> torch.Tensor:
+    """U[0,1) fp32 draws from PCG64(seed): the stratified-sampling / inverse-CDF draws of the larger fixtures are named by
+    their seed instead of being stored (tests/golden/make_golden.py and the tests regenerate the same bits)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    return torch.from_numpy(rng.random(shape, dtype=np.float32))
+
+
 def random_rays(n: int, seed: int = 0, radius: float = 4.0):
     """n rays from random camera positions on the radius-4 sphere pointing roughly at the origin
     (unit-norm directions, as the datasets deliver them)."""

@@ -81,7 +81,9 @@ def cpu_baseline(sd, rays_cpu, budget_s=20.0):
     phys, model_name = host_cpu()
     return {"value": done * chunk / dt, "unit": "rays/s", "cores": phys, "threads": threads, "logical_cpus": ncpu, "cpu": model_name, "kind": "port",
             "sample": f"{done} x 3840-ray chunks of the same 640x480 frame, fp32, torch {torch.__version__} CPU, {dt:.1f} s; "
-                      f"torch intra-op threads = {threads} (fastest of a probe over 8..{ncpu}) on a host with {phys} physical cores"}, \
+                      f"torch intra-op threads = {threads} (fastest of a probe over 8..{ncpu}) on a host with {phys} physical cores",
+            "form": "oracle/nerf_oracle.py: searchsorted restatement of the inverse CDF, bit-identical to and faster than helper.py:232-238's "
+                    "(N,64,128) mask/max/min form -- a conservative (fast) CPU baseline"}, \
         torch.cat(outs), (starts[0], starts[0] + done * chunk)
 
 
@@ -330,7 +332,8 @@ def main():
     ap.add_argument("--engine", choices=["fp32", "bf16x3"], default="fp32",
                     help="MLP arithmetic of the timed region: exact fp32 MFMA (default) or the opt-in fp32-equivalent split-bf16 engine")
     ap.add_argument("--no-alt", action="store_true", help="skip the extra (untimed-for-`value`) run of the other engine")
-    ap.add_argument("--sharded-leg", action="store_true", help="run the informational sharded-frame leg even at world size 1")
+    ap.add_argument("--sharded-leg", action="store_true", help="(default now) kept for old command lines: the sharded-frame leg always runs")
+    ap.add_argument("--no-sharded-leg", action="store_true", help="skip the informational BASELINE config 3 leg (one frame sharded over the ranks + RCCL all-gather)")
     ap.add_argument("--no-train-leg", action="store_true", help="skip the extra (informational) articulated training-step timing")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the informational BASELINE config 1 / config 4 render legs")
     args = ap.parse_args()
@@ -368,7 +371,7 @@ def main():
     def step():
         out = model(rays, False, True, syn.NEAR, syn.FAR)
         if distributed:
-            return all_gather_pixels(out[1])  # one RCCL all-gather of 20 B/ray; (world*n, .) rank-major
+            return all_gather_pixels(out[1], counts=[n_rays] * world)  # one RCCL all-gather of 20 B/ray; (world*n, .) rank-major
         return out[1]
 
     def fence():
@@ -425,27 +428,42 @@ def main():
     # BASELINE config 3 literally (informational, never `value`): ONE 640x480 frame, contiguous ray ranges sharded over the
     # ranks, fine-level pixels all-gathered (RCCL) -- strong scaling of a single frame, where `value` above is weak scaling.
     sharded = None
-    if world > 1 or args.sharded_leg:
+    if not args.no_sharded_leg:
+        own_group = False
         try:
             from aon_amd.parallel import render_frame_sharded
 
+            if not distributed:   # plain `python bench.py` at N = 1: bring RCCL up for this leg so the all-gather is the real collective
+                import socket
+
+                with socket.socket() as sk:
+                    sk.bind(("127.0.0.1", 0))
+                    port = sk.getsockname()[1]
+                os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+                dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+                own_group = True
             focal0, c2w0 = syn.focal_from_fovy(H), syn.look_at_pose(4.0, 30.0, 30.0)
             raygen = lambda h, w, f, c, b, e: get_frame_rays(h, w, f, c, b, e, device=dev)
             with torch.no_grad():
-                render_frame_sharded(model, H, W, focal0, c2w0, syn.NEAR, syn.FAR, True, raygen)
+                render_frame_sharded(model, H, W, focal0, c2w0, syn.NEAR, syn.FAR, True, raygen, force=True)
                 fence()
                 ts = time.perf_counter()
                 for _ in range(args.steps):
-                    frame = render_frame_sharded(model, H, W, focal0, c2w0, syn.NEAR, syn.FAR, True, raygen)
+                    frame = render_frame_sharded(model, H, W, focal0, c2w0, syn.NEAR, syn.FAR, True, raygen, force=True)
                 fence()
                 tsd = torch.tensor([time.perf_counter() - ts], dtype=torch.float64, device=dev)
             if distributed:
                 dist.all_reduce(tsd, op=dist.ReduceOp.MAX)
             dts = tsd.item() / args.steps
-            sharded = {"workload": f"one {W}x{H} frame sharded over {world} rank(s) + pixel all-gather", "ms_per_frame": dts * 1e3,
-                       "rays_per_s": n_rays / dts, "frame_rows": int(frame[0].shape[0])}
+            sharded = {"workload": f"BASELINE config 3: one {W}x{H} frame, contiguous ray ranges sharded over {world} rank(s), raygen on the GPU, "
+                                   "fine-level pixels all-gathered over RCCL (the collective runs at world size 1 too)",
+                       "ms_per_frame": dts * 1e3, "rays_per_s": n_rays / dts, "frame_rows": int(frame[0].shape[0]), "world": world,
+                       "collective": "all_gather_into_tensor (nccl = RCCL), 20 B/ray"}
         except Exception as e:  # informational leg
             sharded = {"error": f"{type(e).__name__}: {e}"}
+        finally:
+            if own_group and dist.is_initialized():
+                dist.destroy_process_group()
 
     train = None if args.no_train_leg else train_leg(dev, rank, world, distributed)
     # BASELINE configs 1 and 4 on this rank's GPU (informational, never `value`)

@@ -524,6 +524,9 @@ def test_nerf_forward_vs_oracle_and_golden(dev, golden, nerf_sd, white):
             assert ((bad <= 1e-5) | (bad >= 1e-3)).all(), bad
 
 
+RND_ATOL = 1e-5   # measured on MI355X (round 3): see the printed maxima
+
+
 def test_nerf_forward_randomized(dev, golden, nerf_sd):
     from aon_amd.models.vanilla_nerf.model import NeRF
 
@@ -539,8 +542,11 @@ def test_nerf_forward_randomized(dev, golden, nerf_sd):
     for lvl, name in ((0, "coarse"), (1, "fine")):
         rgb = out[lvl][0].cpu()
         assert _psnr(rgb, ref[lvl][0]) >= 70.0
-        torch.testing.assert_close(rgb[ok], ref[lvl][0][ok], rtol=0, atol=2e-4)
-        torch.testing.assert_close(rgb[ok], g[f"rnd_{name}_rgb"][ok], rtol=0, atol=2e-4)
+        print(f"randomized {name}: max |rgb - oracle| on robust rays {(rgb[ok] - ref[lvl][0][ok]).abs().max():.2e}, "
+              f"vs the reference's own output {(rgb[ok] - g[f'rnd_{name}_rgb'][ok]).abs().max():.2e}")
+        # round 3: the bound follows the measured level like the deterministic case (round 2 still carried round 1's 2e-4)
+        torch.testing.assert_close(rgb[ok], ref[lvl][0][ok], rtol=0, atol=RND_ATOL)
+        torch.testing.assert_close(rgb[ok], g[f"rnd_{name}_rgb"][ok], rtol=0, atol=RND_ATOL)
     # without supplied draws the module draws its own: different result, still a valid render
     with torch.no_grad():
         out2 = model(rays, True, True, g["near"], g["far"])
@@ -573,6 +579,45 @@ def test_coarse_only_and_edge_sizes(ops, dev, nerf_sd, packed):
     # gradient mode runs the HIP training path (tests/test_hip_training.py): outputs carry a graph to the parameters
     out = model2({k: v.to(dev) for k, v in syn.random_rays(4, seed=0).items()}, False, True, 2.0, 6.0)
     assert out[1][0].requires_grad and out[1][0].grad_fn is not None
+
+
+def test_config1_coarse_only_frame_vs_oracle(ops, dev, nerf_sd):
+    """BASELINE config 1 -- 320x240, `num_levels=1` (65 coarse evaluations per ray, model.py:149), the reference's own CPU-runnable
+    case -- against the oracle run in the same mode (round 2 only compared the HIP path with itself): 1e-5 rgb / acc on a strided
+    sample of the frame (far-plane-robust rays), plus the size-independent properties on the whole frame."""
+    import aon_amd.synthetic as syn
+    from aon_amd.models.vanilla_nerf.model import NeRF
+
+    H, W = 240, 320
+    model = NeRF(num_levels=1).to(dev)
+    model.load_state_dict(nerf_sd)
+    ro, vd = ops.raygen(syn.look_at_pose(), H, W, syn.focal_from_fovy(H), device=dev)
+    rays = {"rays_o": ro, "rays_d": vd, "viewdirs": vd}
+    with torch.no_grad():
+        full = model(rays, False, True, 2.0, 6.0)
+        again = model(rays, False, True, 2.0, 6.0)
+        sl = slice(30_000, 33_840)   # one reference-sized chunk (opt.py:103)
+        part = model({k: v[sl] for k, v in rays.items()}, False, True, 2.0, 6.0)
+        nowb = model({k: v[sl] for k, v in rays.items()}, False, False, 2.0, 6.0)
+    assert len(full) == 1 and full[0][0].shape == (H * W, 3)
+    rgb, acc, depth = full[0]
+    assert torch.equal(rgb, again[0][0]) and torch.equal(depth, again[0][2])                      # determinism
+    assert torch.equal(part[0][0], rgb[sl]) and torch.equal(part[0][1], acc[sl]) and torch.equal(part[0][2], depth[sl])   # chunk invariance
+    assert torch.isfinite(rgb).all() and acc.min().item() >= 0.0 and acc.max().item() <= 1.0 + 1e-5
+    torch.testing.assert_close(part[0][0], nowb[0][0] + (1.0 - nowb[0][1])[:, None], rtol=0, atol=1e-6)   # helper.py:187-188
+    pick = torch.arange(0, H * W, 37)
+    rays_cpu = {k: v[pick.to(dev)].cpu() for k, v in rays.items()}
+    ref, aux = orc.nerf_forward(nerf_sd, rays_cpu, False, True, 2.0, 6.0, num_levels=1, return_aux=True)
+    assert len(ref) == 1
+    ok = _robust_rays(aux)
+    assert ok.double().mean() > 0.8
+    got = [x[pick.to(dev)].cpu() for x in full[0]]
+    print(f"config 1: {int(ok.sum())}/{ok.numel()} robust rays, max |rgb - oracle| {(got[0][ok] - ref[0][0][ok]).abs().max():.2e}, "
+          f"depth {(got[2][ok] - ref[0][2][ok]).abs().max():.2e}")
+    torch.testing.assert_close(got[0][ok], ref[0][0][ok], rtol=0, atol=1e-5)
+    torch.testing.assert_close(got[1][ok], ref[0][1][ok], rtol=0, atol=1e-5)
+    torch.testing.assert_close(got[2][ok], ref[0][2][ok], rtol=0, atol=2e-4)
+    assert _psnr(got[0], ref[0][0]) >= 70.0
 
 
 def test_full_frame_properties(ops, dev, nerf_sd):

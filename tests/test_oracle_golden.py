@@ -181,16 +181,22 @@ def test_g15_smooth_fields(golden):
 
     g = golden("g15_smooth")
     rays = {k: g[k] for k in ("rays_o", "rays_d", "viewdirs")}
+    n = rays["rays_o"].shape[0]
+    assert n >= 1024 and g["art_rays_o"].shape[0] >= 1024
     sd = syn.make_smooth_nerf_state_dict()
+    t_rand, u = syn.seeded_uniform(g["seed_t_rand"], n, 65), syn.seeded_uniform(g["seed_u"], n, 128)   # draws are named by seed
     for tag, kw in (("van_det", dict(randomized=False, white_bkgd=True)),
-                    ("van_rnd", dict(randomized=True, white_bkgd=False, t_rand=g["t_rand"], u=g["u"]))):
+                    ("van_rnd", dict(randomized=True, white_bkgd=False, t_rand=t_rand, u=u))):
         out = orc.nerf_forward(sd, rays, near=g["near"], far=g["far"], **kw)
         for lvl, name in ((0, "coarse"), (1, "fine")):
             torch.testing.assert_close(out[lvl][0], g[f"{tag}_{name}_rgb"], rtol=0, atol=2e-6)
             torch.testing.assert_close(out[lvl][2], g[f"{tag}_{name}_depth"], rtol=0, atol=2e-5)
     arays = {k: g["art_" + k] for k in ("rays_o", "rays_d", "viewdirs")}
     lat = {k: g["art_lat_" + k] for k in ("density", "color", "articulation")}
-    out = orc.nerf_ae_art_forward(syn.make_art_state_dict(seed=5, density_scale=2.0), arays, False, True, g["near"], g["far"], lat)
-    for lvl, name in ((0, "coarse"), (1, "fine")):
-        torch.testing.assert_close(out[lvl][0], g[f"art_det_{name}_rgb"], rtol=0, atol=2e-6)
-        torch.testing.assert_close(out[lvl][2], g[f"art_det_{name}_depth"], rtol=0, atol=2e-5)
+    asd = syn.make_art_state_dict(seed=5, density_scale=2.0)
+    ta, ua = syn.seeded_uniform(g["seed_art_t_rand"], n, 65), syn.seeded_uniform(g["seed_art_u"], n, 128)
+    for tag, kw in (("art_det", dict(randomized=False, white_bkgd=True)), ("art_rnd", dict(randomized=True, white_bkgd=False, t_rand=ta, u=ua))):
+        out = orc.nerf_ae_art_forward(asd, arays, kw["randomized"], kw["white_bkgd"], g["near"], g["far"], lat, t_rand=kw.get("t_rand"), u=kw.get("u"))
+        for lvl, name in ((0, "coarse"), (1, "fine")):
+            torch.testing.assert_close(out[lvl][0], g[f"{tag}_{name}_rgb"], rtol=0, atol=2e-6)
+            torch.testing.assert_close(out[lvl][2], g[f"{tag}_{name}_depth"], rtol=0, atol=2e-5)

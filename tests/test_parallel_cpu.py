@@ -61,6 +61,9 @@ def _grad_worker(rank, world, port, q):
 
         torch.manual_seed(100 + rank)  # ranks start from different parameters and see different data
         net = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.ReLU(), torch.nn.Linear(7, 3))
+        # a parameter NO rank produces a gradient for (num_levels=1 leaves fine_mlp alone): 68 values + 5 flags = 73, so the
+        # bucket is padded to 74 and the two shards of 37 cut through a parameter
+        net.register_parameter("unused", torch.nn.Parameter(torch.ones(2)))
         par.broadcast_parameters(net)
         x = torch.randn(11, 5)
         net(x).square().mean().backward()
@@ -68,9 +71,12 @@ def _grad_worker(rank, world, port, q):
             net[2].bias.grad = None   # a rank that produced no gradient for a parameter still takes part with zeros
         local = [torch.zeros_like(p) if p.grad is None else p.grad.clone() for p in net.parameters()]
         par.allreduce_gradients(net)
+        assert net.unused.grad is None   # as under torch DDP: globally unused parameters keep grad None (Adam skips them)
+        used = [p for n_, p in net.named_parameters() if n_ != "unused"]
+        local = [g for g, (n_, _) in zip(local, net.named_parameters()) if n_ != "unused"]
         # plain numpy payloads: torch tensors travel through shared-memory handles that die with the worker
-        q.put((rank, [p.detach().numpy().copy() for p in net.parameters()], [g.numpy().copy() for g in local],
-               [p.grad.numpy().copy() for p in net.parameters()]))
+        q.put((rank, [p.detach().numpy().copy() for p in used], [g.numpy().copy() for g in local],
+               [p.grad.numpy().copy() for p in used]))
         dist.barrier()
     finally:
         dist.destroy_process_group()

@@ -58,6 +58,12 @@ def test_gather_layouts_over_rccl(rccl):
         assert all(torch.equal(a, b) for a, b in zip(out, lvl))
     with pytest.raises(ValueError):
         all_gather_pixels(lvl, force=True, total=999)
+    # the uneven-layout branch (pad every message to the longest, gather, drop the padding rows with host-known offsets) through
+    # the real collective: at world size 1 the padding is forced
+    for n in (1, 999, 1000):
+        part = tuple(x[:n] for x in lvl)
+        out = all_gather_pixels(part, force=True, counts=[n], _pad_to=n + 37)
+        assert out[0].shape == (n, 3) and all(torch.equal(a, b) for a, b in zip(out, part))
 
 
 def test_ddp_duties_over_rccl(rccl):
@@ -83,12 +89,20 @@ def test_ddp_duties_over_rccl(rccl):
     out = model(rays, True, True, 2.0, 6.0, latents, t_rand=torch.rand(64, 65, generator=g).to(dev), u=torch.rand(64, 128, generator=g).to(dev))
     target = torch.rand(64, 3, generator=g).to(dev)
     (torch.mean((out[0][0] - target) ** 2) + torch.mean((out[1][0] - target) ** 2)).backward()
+    both.register_parameter("untouched", torch.nn.Parameter(torch.ones(3, device=dev)))   # no rank produces a gradient for it
     local = [None if p.grad is None else p.grad.clone() for p in both.parameters()]
+    n_el, n_par = sum(p.numel() for p in both.parameters()), len(list(both.parameters()))
+    assert (n_el + n_par) % 64 != 0                    # the bucket is padded: reduce_scatter_tensor sees padded != total
     allreduce_gradients(both, force=True)
     for p, g_ in zip(both.parameters(), local):
-        assert p.grad is not None                      # every requires_grad parameter is in the bucket
-        want = torch.zeros_like(p) if g_ is None else g_
-        assert torch.equal(p.grad, want)               # mean over one rank = the local gradient, bit for bit
+        if g_ is None:
+            assert p.grad is None                      # as under torch DDP: globally unused parameters keep grad None
+        else:
+            assert torch.equal(p.grad, g_)             # mean over one rank = the local gradient, bit for bit
+    assert both.untouched.grad is None
+    # a smaller shard quantum moves every shard boundary; the result may not
+    allreduce_gradients(both, force=True, shard_align=1)
+    assert all(torch.equal(p.grad, g_) for p, g_ in zip(both.parameters(), local) if g_ is not None)
 
 
 def test_data_mutation_is_seen_by_the_kernels(rccl, nerf_sd):
