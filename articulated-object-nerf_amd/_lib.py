@@ -43,16 +43,6 @@ _SIGS = {
     "aon_mlp_fwd_enc": (_i, [_p, _p, _p, _l, _i, _p, _p]),
     "aon_composite": (_i, [_p, _i, _p, _i, _p, _p, _l, _i, _i, _i, _p, _p, _p, _p, _p]),
     "aon_sample_pdf": (_i, [_p, _p, _l, _p, _p, _l, _l, _p, _p, _p]),
-    "aon_set_train_engine": (_i, [_i]),
-    "aon_bwd_bf16x3_packed_bytes": (_l, []),
-    "aon_pack_vanilla_mlp_bwd_bf16x3": (_i, [_p, _p, _p]),
-    "aon_mlp_bwd_chain_bf16x3": (_i, [_p, _p, _p, _p, _p, _l, _p]),
-    "aon_mlp_fwd_train_bf16x3": (_i, [_p, _p, _p, _p, _p, _l, _i, _p, _p, _p, _p]),
-    "aon_get_train_engine": (_i, []),
-    "aon_bf16x3_packed_bytes": (_l, []),
-    "aon_pack_vanilla_mlp_bf16x3": (_i, [_p, _p, _p]),
-    "aon_mlp_fwd_bf16x3": (_i, [_p, _p, _p, _p, _p, _l, _i, _p, _p]),
-    "aon_render_fwd_bf16x3": (_i, [_p, _p, _p, _p, _p, _l, _f, _f, _i, _i, _p, _p, _l, _p, _p, _p, _p, _p, _p, _p, _l, _p]),
     "aon_art_packed_bytes": (_l, []),
     "aon_art_small_bytes": (_l, []),
     "aon_pack_art_mlp": (_i, [_p, _p, _p]),
@@ -60,10 +50,6 @@ _SIGS = {
     "aon_art_mlp_fwd": (_i, [_p, _p, _p, _p, _p, _p, _l, _i, _p, _p]),
     "aon_art_mlp_fwd_pos": (_i, [_p, _p, _p, _p, _l, _i, _p, _p]),
     "aon_art_render_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _l, _f, _f, _i, _i, _p, _p, _l, _p, _p, _p, _p, _p, _p, _p, _l, _p]),
-    "aon_art_bf16x3_packed_bytes": (_l, []),
-    "aon_pack_art_mlp_bf16x3": (_i, [_p, _p, _p]),
-    "aon_art_mlp_fwd_bf16x3": (_i, [_p, _p, _p, _p, _p, _p, _l, _i, _p, _p]),
-    "aon_art_render_fwd_bf16x3": (_i, [_p, _p, _p, _p, _p, _p, _p, _l, _f, _f, _i, _i, _p, _p, _l, _p, _p, _p, _p, _p, _p, _p, _l, _p]),
     "aon_train_plane_rows": (_l, []),
     "aon_bwd_packed_bytes": (_l, []),
     "aon_wgrad_workspace_bytes": (_l, []),
@@ -78,11 +64,7 @@ _SIGS = {
     "aon_art_bwd_packed_bytes": (_l, []),
     "aon_pack_art_mlp_bwd": (_i, [_p, _p, _p]),
     "aon_art_mlp_fwd_train": (_i, [_p, _p, _p, _p, _p, _p, _l, _i, _p, _p, _p, _p]),
-    "aon_art_mlp_fwd_train_bf16x3": (_i, [_p, _p, _p, _p, _p, _p, _l, _i, _p, _p, _p, _p]),
     "aon_art_bwd_chain": (_i, [_p, _p, _p, _p, _p, _p, _p, _l, _p]),
-    "aon_art_bwd_bf16x3_packed_bytes": (_l, []),
-    "aon_pack_art_mlp_bwd_bf16x3": (_i, [_p, _p, _p]),
-    "aon_art_bwd_chain_bf16x3": (_i, [_p, _p, _p, _p, _p, _p, _p, _l, _p]),
     "aon_art_wgrad": (_i, [_p, _p, _p, _p, _l, _p, _p, _p, _p, _p, _p, _p, _p, _p, _l, _p]),
     "aon_set_bwd_overlap": (_i, [_i]),
     "aon_train_workspace_bytes": (_l, [_l, _i]),

@@ -47,30 +47,6 @@ hipError_t launch_art_bwd_chain(const char* packed_bwd, const float* small, cons
 hipError_t launch_art_wgrad(const float* planes, const float* dplanes, const float* d_raw, const float* dxp, int64_t Np,
                             const float* const* params, const float* shape, const float* app, const float* art,
                             float* const* grads, float* g_shape, float* g_app, float* g_art, float* ws, hipStream_t stream);
-hipError_t launch_mlp_fwd_train_bf16x3(const char* packed, const float* rays_o, const float* rays_d, const float* viewdirs,
-                                       const float* t_vals, int64_t n_rays, int S, float* raw, float* planes, void* masks,
-                                       hipStream_t stream);
-int64_t bwd_bf16x3_stream_bytes();
-hipError_t launch_pack_vanilla_bwd_bf16x3(const float* const* params, char* packed, hipStream_t stream);
-hipError_t launch_mlp_bwd_chain_bf16x3(const char* packed_bwd, const float* packed_fwd_small, const float* d_raw, const void* masks,
-                                       float* dplanes, int64_t Np, hipStream_t stream);
-int64_t art_bf16x3_packed_bytes();
-hipError_t launch_pack_art_bf16x3(const float* const* params, char* packed, hipStream_t stream);
-hipError_t launch_art_mlp_fwd_bf16x3(const char* packed, const float* small, const float* rays_o, const float* rays_d,
-                                     const float* viewdirs, const float* t_vals, int64_t n_rays, int S, float* raw, hipStream_t stream);
-hipError_t launch_art_mlp_fwd_train_bf16x3(const char* packed, const float* small, const float* rays_o, const float* rays_d,
-                                           const float* viewdirs, const float* t_vals, int64_t n_rays, int S, float* raw, float* planes,
-                                           void* masks, hipStream_t stream);
-int64_t art_bwd_bf16x3_packed_bytes();
-hipError_t launch_pack_art_bwd_bf16x3(const float* const* params, char* packed, hipStream_t stream);
-hipError_t launch_art_bwd_chain_bf16x3(const char* packed_bwd, const float* small, const float* d_raw, const void* masks,
-                                       const float* planes, float* dplanes, float* dxp, int64_t Np, hipStream_t stream);
-void set_train_engine(int e);
-int get_train_engine();
-int64_t bf16x3_packed_bytes();
-hipError_t launch_pack_vanilla_bf16x3(const float* const* params, char* packed, hipStream_t stream);
-hipError_t launch_mlp_fwd_bf16x3(const char* packed, const float* rays_o, const float* rays_d, const float* viewdirs,
-                                 const float* t_vals, int64_t n_rays, int S, float* raw, hipStream_t stream);
 hipError_t launch_raygen(const float* c2w, int H, int W, float focal, const float* directions, int64_t pix_begin,
                          int64_t pix_end, float* rays_o, float* viewdirs, float* rays_d, hipStream_t stream);
 hipError_t launch_ray_directions(int H, int W, float focal, float* out, hipStream_t stream);
@@ -467,17 +443,13 @@ struct NetRef {
   bool articulated;
   const void* packed;
   const float* small;  // articulated only
-  bool bf16x3 = false; // split-bf16 engine (aon_mlp_bf16.hip / aon_mlp_art_bf16.hip): `packed` is that engine's stream
 };
 
 static hipError_t launch_net(const NetRef& net, const float* o, const float* d, const float* v, const float* t, int64_t n, int S,
                              float* raw, hipStream_t stream) {
   MlpTimer timer(stream, n * S);
-  if (net.articulated && net.bf16x3)
-    return aon::launch_art_mlp_fwd_bf16x3(static_cast<const char*>(net.packed), net.small, o, d, v, t, n, S, raw, stream);
   if (net.articulated)
     return aon::launch_art_mlp_fwd(static_cast<const char*>(net.packed), net.small, o, d, v, t, n, S, raw, stream);
-  if (net.bf16x3) return aon::launch_mlp_fwd_bf16x3(static_cast<const char*>(net.packed), o, d, v, t, n, S, raw, stream);
   return aon::launch_mlp_fwd(static_cast<const char*>(net.packed), o, d, v, t, n, S, raw, stream);
 }
 
@@ -878,78 +850,6 @@ int aon_art_render_bwd(const void* packed_bwd_coarse, const void* small_coarse, 
   return AON_OK;
 }
 
-// ---- opt-in split-bf16 engine (fp32-equivalent arithmetic on the bf16 matrix pipe; see aon_mlp_bf16.hip) ----
-int aon_mlp_fwd_train_bf16x3(const void* packed_bf16x3, const float* rays_o, const float* rays_d, const float* viewdirs,
-                             const float* t_vals, int64_t n_rays, int S, float* raw, float* planes, void* masks, void* stream) {
-  if (n_rays < 0 || S < 1) return fail(AON_E_INVALID, "aon_mlp_fwd_train_bf16x3: bad size");
-  if (n_rays == 0) return AON_OK;
-  if (!packed_bf16x3 || !rays_o || !rays_d || !viewdirs || !t_vals || !raw || !planes || !masks)
-    return fail(AON_E_INVALID, "aon_mlp_fwd_train_bf16x3: null pointer");
-  if (reinterpret_cast<uintptr_t>(masks) & 15) return fail(AON_E_INVALID, "aon_mlp_fwd_train_bf16x3: masks must be 16-byte aligned");
-  MlpTimer timer((hipStream_t)stream, n_rays * S);
-  return check(aon::launch_mlp_fwd_train_bf16x3(static_cast<const char*>(packed_bf16x3), rays_o, rays_d, viewdirs, t_vals, n_rays, S,
-                                                raw, planes, masks, (hipStream_t)stream), "aon_mlp_fwd_train_bf16x3");
-}
-
-int64_t aon_bwd_bf16x3_packed_bytes(void) { return aon::bwd_bf16x3_stream_bytes(); }
-
-int aon_pack_vanilla_mlp_bwd_bf16x3(const float* const* params_host, void* packed_bwd, void* stream) {
-  if (!params_host || !packed_bwd) return fail(AON_E_INVALID, "aon_pack_vanilla_mlp_bwd_bf16x3: null pointer");
-  for (int i = 0; i < aon::kNumVanillaParams; ++i)
-    if (!params_host[i]) return fail(AON_E_INVALID, "aon_pack_vanilla_mlp_bwd_bf16x3: null parameter pointer");
-  if (reinterpret_cast<uintptr_t>(packed_bwd) & 15) return fail(AON_E_INVALID, "aon_pack_vanilla_mlp_bwd_bf16x3: buffer must be 16-byte aligned");
-  return check(aon::launch_pack_vanilla_bwd_bf16x3(params_host, static_cast<char*>(packed_bwd), (hipStream_t)stream),
-               "aon_pack_vanilla_mlp_bwd_bf16x3");
-}
-
-int aon_mlp_bwd_chain_bf16x3(const void* packed_bwd_bf16x3, const void* packed_fwd, const float* d_raw, const void* masks,
-                             float* dplanes, int64_t Np, void* stream) {
-  if (Np < 0 || (Np & 127)) return fail(AON_E_INVALID, "aon_mlp_bwd_chain_bf16x3: Np must be a multiple of 128");
-  if (Np == 0) return AON_OK;
-  if (!packed_bwd_bf16x3 || !packed_fwd || !d_raw || !masks || !dplanes) return fail(AON_E_INVALID, "aon_mlp_bwd_chain_bf16x3: null pointer");
-  KTimer timer(kBwdChain, (hipStream_t)stream, Np);
-  const float* small = reinterpret_cast<const float*>(static_cast<const char*>(packed_fwd) + aon::kStreamBytes);
-  return check(aon::launch_mlp_bwd_chain_bf16x3(static_cast<const char*>(packed_bwd_bf16x3), small, d_raw, masks, dplanes, Np,
-                                                (hipStream_t)stream), "aon_mlp_bwd_chain_bf16x3");
-}
-
-int aon_set_train_engine(int engine) {
-  if (engine != 0 && engine != 1) return fail(AON_E_INVALID, "aon_set_train_engine: engine must be 0 (fp32) or 1 (bf16x3)");
-  aon::set_train_engine(engine);
-  return AON_OK;
-}
-int aon_get_train_engine(void) { return aon::get_train_engine(); }
-
-int64_t aon_bf16x3_packed_bytes(void) { return aon::bf16x3_packed_bytes(); }
-
-int aon_pack_vanilla_mlp_bf16x3(const float* const* params_host, void* packed, void* stream) {
-  if (!params_host || !packed) return fail(AON_E_INVALID, "aon_pack_vanilla_mlp_bf16x3: null pointer");
-  for (int i = 0; i < aon::kNumVanillaParams; ++i)
-    if (!params_host[i]) return fail(AON_E_INVALID, "aon_pack_vanilla_mlp_bf16x3: null parameter pointer");
-  if (reinterpret_cast<uintptr_t>(packed) & 15) return fail(AON_E_INVALID, "aon_pack_vanilla_mlp_bf16x3: packed must be 16-byte aligned");
-  return check(aon::launch_pack_vanilla_bf16x3(params_host, static_cast<char*>(packed), (hipStream_t)stream), "aon_pack_vanilla_mlp_bf16x3");
-}
-
-int aon_mlp_fwd_bf16x3(const void* packed, const float* rays_o, const float* rays_d, const float* viewdirs, const float* t_vals,
-                       int64_t n_rays, int S, float* raw, void* stream) {
-  if (n_rays < 0 || S < 1) return fail(AON_E_INVALID, "aon_mlp_fwd_bf16x3: bad size");
-  if (n_rays == 0) return AON_OK;
-  if (!packed || !rays_o || !rays_d || !viewdirs || !t_vals || !raw) return fail(AON_E_INVALID, "aon_mlp_fwd_bf16x3: null pointer");
-  MlpTimer timer((hipStream_t)stream, n_rays * S);
-  return check(aon::launch_mlp_fwd_bf16x3(static_cast<const char*>(packed), rays_o, rays_d, viewdirs, t_vals, n_rays, S, raw,
-                                          (hipStream_t)stream), "aon_mlp_fwd_bf16x3");
-}
-
-int aon_render_fwd_bf16x3(const void* packed_coarse, const void* packed_fine, const float* rays_o, const float* rays_d,
-                          const float* viewdirs, int64_t n_rays, float near_, float far_, int white_bkgd, int num_levels,
-                          const float* t_rand, const float* u, int64_t u_stride, float* rgb_c, float* acc_c, float* depth_c,
-                          float* rgb_f, float* acc_f, float* depth_f, void* workspace, int64_t workspace_bytes, void* stream) {
-  NetRef c{false, packed_coarse, nullptr}, f{false, packed_fine, nullptr};
-  c.bf16x3 = true; f.bf16x3 = true;
-  return render_impl("aon_render_fwd_bf16x3", c, f, rays_o, rays_d, viewdirs, n_rays, near_, far_, white_bkgd, num_levels, t_rand, u,
-                     u_stride, rgb_c, acc_c, depth_c, rgb_f, acc_f, depth_f, workspace, workspace_bytes, (hipStream_t)stream);
-}
-
 // ---- articulated network (model_autodecoder.py) ----
 int64_t aon_art_packed_bytes(void) { return aon::art_stream_bytes(); }
 int64_t aon_art_small_bytes(void) { return aon::art_small_bytes(); }
@@ -999,73 +899,6 @@ int aon_art_render_fwd(const void* packed_coarse, const void* small_coarse, cons
   const NetRef c{true, packed_coarse, static_cast<const float*>(small_coarse)}, f{true, packed_fine, static_cast<const float*>(small_fine)};
   return render_impl("aon_art_render_fwd", c, f, rays_o, rays_d, viewdirs, n_rays, near_, far_, white_bkgd, num_levels, t_rand, u,
                      u_stride, rgb_c, acc_c, depth_c, rgb_f, acc_f, depth_f, workspace, workspace_bytes, (hipStream_t)stream);
-}
-
-int64_t aon_art_bf16x3_packed_bytes(void) { return aon::art_bf16x3_packed_bytes(); }
-
-int aon_pack_art_mlp_bf16x3(const float* const* params_host, void* packed, void* stream) {
-  if (!params_host || !packed) return fail(AON_E_INVALID, "aon_pack_art_mlp_bf16x3: null pointer");
-  for (int i = 0; i < 40; ++i)
-    if (!params_host[i]) return fail(AON_E_INVALID, "aon_pack_art_mlp_bf16x3: null parameter pointer");
-  if (reinterpret_cast<uintptr_t>(packed) & 15) return fail(AON_E_INVALID, "aon_pack_art_mlp_bf16x3: packed must be 16-byte aligned");
-  return check(aon::launch_pack_art_bf16x3(params_host, static_cast<char*>(packed), (hipStream_t)stream), "aon_pack_art_mlp_bf16x3");
-}
-
-int aon_art_mlp_fwd_bf16x3(const void* packed_bf16x3, const void* small, const float* rays_o, const float* rays_d,
-                           const float* viewdirs, const float* t_vals, int64_t n_rays, int S, float* raw, void* stream) {
-  if (n_rays < 0 || S < 1) return fail(AON_E_INVALID, "aon_art_mlp_fwd_bf16x3: bad size");
-  if (n_rays == 0) return AON_OK;
-  if (!packed_bf16x3 || !small || !rays_o || !rays_d || !viewdirs || !t_vals || !raw)
-    return fail(AON_E_INVALID, "aon_art_mlp_fwd_bf16x3: null pointer");
-  MlpTimer timer((hipStream_t)stream, n_rays * S);
-  return check(aon::launch_art_mlp_fwd_bf16x3(static_cast<const char*>(packed_bf16x3), static_cast<const float*>(small), rays_o, rays_d,
-                                              viewdirs, t_vals, n_rays, S, raw, (hipStream_t)stream), "aon_art_mlp_fwd_bf16x3");
-}
-
-int aon_art_render_fwd_bf16x3(const void* packed_coarse, const void* small_coarse, const void* packed_fine, const void* small_fine,
-                              const float* rays_o, const float* rays_d, const float* viewdirs, int64_t n_rays, float near_, float far_,
-                              int white_bkgd, int num_levels, const float* t_rand, const float* u, int64_t u_stride, float* rgb_c,
-                              float* acc_c, float* depth_c, float* rgb_f, float* acc_f, float* depth_f, void* workspace,
-                              int64_t workspace_bytes, void* stream) {
-  NetRef c{true, packed_coarse, static_cast<const float*>(small_coarse)}, f{true, packed_fine, static_cast<const float*>(small_fine)};
-  c.bf16x3 = true; f.bf16x3 = true;
-  return render_impl("aon_art_render_fwd_bf16x3", c, f, rays_o, rays_d, viewdirs, n_rays, near_, far_, white_bkgd, num_levels, t_rand, u,
-                     u_stride, rgb_c, acc_c, depth_c, rgb_f, acc_f, depth_f, workspace, workspace_bytes, (hipStream_t)stream);
-}
-
-int aon_art_mlp_fwd_train_bf16x3(const void* packed_bf16x3, const void* small, const float* rays_o, const float* rays_d,
-                                 const float* viewdirs, const float* t_vals, int64_t n_rays, int S, float* raw, float* planes,
-                                 void* masks, void* stream) {
-  if (n_rays < 0 || S < 1) return fail(AON_E_INVALID, "aon_art_mlp_fwd_train_bf16x3: bad size");
-  if (n_rays == 0) return AON_OK;
-  if (!packed_bf16x3 || !small || !rays_o || !rays_d || !viewdirs || !t_vals || !raw || !planes || !masks)
-    return fail(AON_E_INVALID, "aon_art_mlp_fwd_train_bf16x3: null pointer");
-  if (reinterpret_cast<uintptr_t>(masks) & 15) return fail(AON_E_INVALID, "aon_art_mlp_fwd_train_bf16x3: masks must be 16-byte aligned");
-  MlpTimer timer((hipStream_t)stream, n_rays * S);
-  return check(aon::launch_art_mlp_fwd_train_bf16x3(static_cast<const char*>(packed_bf16x3), static_cast<const float*>(small), rays_o,
-                                                    rays_d, viewdirs, t_vals, n_rays, S, raw, planes, masks, (hipStream_t)stream),
-               "aon_art_mlp_fwd_train_bf16x3");
-}
-
-int64_t aon_art_bwd_bf16x3_packed_bytes(void) { return aon::art_bwd_bf16x3_packed_bytes(); }
-
-int aon_pack_art_mlp_bwd_bf16x3(const float* const* params_host, void* packed_bwd, void* stream) {
-  if (!params_host || !packed_bwd) return fail(AON_E_INVALID, "aon_pack_art_mlp_bwd_bf16x3: null pointer");
-  for (int i = 0; i < 40; ++i)
-    if (!params_host[i]) return fail(AON_E_INVALID, "aon_pack_art_mlp_bwd_bf16x3: null parameter pointer");
-  if (reinterpret_cast<uintptr_t>(packed_bwd) & 15) return fail(AON_E_INVALID, "aon_pack_art_mlp_bwd_bf16x3: buffer must be 16-byte aligned");
-  return check(aon::launch_pack_art_bwd_bf16x3(params_host, static_cast<char*>(packed_bwd), (hipStream_t)stream), "aon_pack_art_mlp_bwd_bf16x3");
-}
-
-int aon_art_bwd_chain_bf16x3(const void* packed_bwd_bf16x3, const void* small, const float* d_raw, const void* masks, const float* planes,
-                             float* dplanes, float* dxp, int64_t Np, void* stream) {
-  if (Np < 0 || (Np & 127)) return fail(AON_E_INVALID, "aon_art_bwd_chain_bf16x3: Np must be a multiple of 128");
-  if (Np == 0) return AON_OK;
-  if (!packed_bwd_bf16x3 || !small || !d_raw || !masks || !planes || !dplanes || !dxp)
-    return fail(AON_E_INVALID, "aon_art_bwd_chain_bf16x3: null pointer");
-  KTimer timer(kBwdChain, (hipStream_t)stream, Np);
-  return check(aon::launch_art_bwd_chain_bf16x3(static_cast<const char*>(packed_bwd_bf16x3), static_cast<const float*>(small), d_raw, masks,
-                                                planes, dplanes, dxp, Np, (hipStream_t)stream), "aon_art_bwd_chain_bf16x3");
 }
 
 }  // extern "C"

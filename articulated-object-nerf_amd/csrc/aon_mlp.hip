@@ -110,6 +110,7 @@ __global__ void __launch_bounds__(256) mlp_fwd_kernel(MlpArgs args) {
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int m = lane & 31, h = lane >> 5;
+  const int wave_s = __builtin_amdgcn_readfirstlane(wave);   // the step base of the training planes is wave-uniform: keep it scalar
 
   {  // resident small vectors -> LDS (visible after the first acquire's barrier)
     const f32x4* src = reinterpret_cast<const f32x4*>(args.packed + kStreamBytes);
@@ -148,26 +149,23 @@ __global__ void __launch_bounds__(256) mlp_fwd_kernel(MlpArgs args) {
       load_view_enc(args.viewdirs_enc + ray * kViewEnc, h, V);
     }
 
-    const int64_t col = (int64_t)pass * 128 + wave * 32 + m;  // plane column of this lane's sample
     PlaneIO io{};
     unsigned moff = 0;
-    if constexpr (TRAIN) { io = make_plane_io(args.Np, col, h); moff = mask_lane_off(pass, tid); }
-    auto rows = [&](int row) { return reinterpret_cast<float*>(reinterpret_cast<char*>(args.planes) + (int64_t)row * io.row_bytes); };
-    const int64_t tile_bytes = 32 * io.row_bytes;
+    if constexpr (TRAIN) { io = make_plane_io(args.planes, kPlRows, (int64_t)pass * 4 + wave_s, m, h); moff = mask_lane_off(pass, tid); }
     if constexpr (TRAIN) {
-      store_pos_enc_plane(E, rows(kPlE), io, col, h);
-      store_view_enc_plane(V, rows(kPlVE), io, col, h);
+      store_pos_enc_plane(E, io, kPlE, h);
+      store_view_enc_plane(V, io, kPlVE, h);
     }
     // [TRAIN] Every hidden activation tile is stored, and its ReLU decision bits are collected, by the chunk that CONSUMES
-    // it (side job of chunk_mma: one value per MFMA group), so neither a store burst nor a block of mask arithmetic sits at
-    // a layer boundary.  `in_row` = plane row of input tile 0, `in_mask` = mask slot of the layer that produced `in`
-    // (-1: the bottleneck output has no activation).
+    // it (side job of chunk_mma: one value per MFMA group, one 16-byte store per four), so neither a store burst nor a block of
+    // mask arithmetic sits at a layer boundary.  `in_row` = plane row of input tile 0; `with_mask` false: the bottleneck output
+    // has no activation.
     auto consume = [&](const f32x16 (&in)[8], int in_row, u32x4& mw, bool with_mask) {
       return [&, in_row, with_mask](int j) {
         return [&, in_row, with_mask, j](int i) {
           if constexpr (TRAIN) {
             if (i < 16) {
-              *plane_addr(reinterpret_cast<float*>(reinterpret_cast<char*>(rows(in_row)) + j * tile_bytes), io, (i & 3) + 8 * (i >> 2)) = in[j][i];
+              if ((i & 3) == 0) store_quad(io, in_row + 32 * j, i >> 2, in[j]);
               if (with_mask) mw[j >> 1] = mask_push_post(mw[j >> 1], in[j][i]);
             }
           }
@@ -220,7 +218,7 @@ __global__ void __launch_bounds__(256) mlp_fwd_kernel(MlpArgs args) {
     relu_tiles(Z);
     if constexpr (TRAIN) {  // the view layer's output feeds the rgb head on the VALU: no consuming chunk, 64 values stored here
       *mask_ptr(args.masks, args.Np, 8, moff) = relu_mask_bits(Z);   // burst form: already in the stored bit layout
-      store_plane(Z, rows(kPlHV), io);
+      store_plane(Z, io, kPlHV);
     }
     // rgb head (model.py:118)
     float rgb[3];

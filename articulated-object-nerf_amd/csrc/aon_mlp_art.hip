@@ -137,6 +137,7 @@ __global__ void __launch_bounds__(256) art_mlp_fwd_kernel(ArtMlpArgs args) {
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int m = lane & 31, h = lane >> 5;
+  const int wave_s = __builtin_amdgcn_readfirstlane(wave);   // the step base of the training planes is wave-uniform: keep it scalar
   {
     const f32x4* src = reinterpret_cast<const f32x4*>(args.small);
     f32x4* dst = reinterpret_cast<f32x4*>(sm);
@@ -166,19 +167,17 @@ __global__ void __launch_bounds__(256) art_mlp_fwd_kernel(ArtMlpArgs args) {
       load_view_enc(args.viewdirs_enc + ray * kViewEnc, h, V);
     }
 
-    const int64_t col = (int64_t)pass * 128 + wave * 32 + m;
     PlaneIO io{};
     unsigned moff = 0;
-    if constexpr (TRAIN) { io = make_plane_io(args.Np, col, h); moff = mask_lane_off(pass, tid); }
-    auto rows = [&](int row) { return reinterpret_cast<float*>(reinterpret_cast<char*>(args.planes) + (int64_t)row * io.row_bytes); };
+    if constexpr (TRAIN) { io = make_plane_io(args.planes, kAPlRows, (int64_t)pass * 4 + wave_s, m, h); moff = mask_lane_off(pass, tid); }
     // [TRAIN] activation tiles are stored, and their ReLU decision bits collected, by the chunk that CONSUMES them (side job
-    // of chunk_mma, one value per MFMA group); only the tiles consumed on the VALU (deformation head, rgb head) and the
-    // VALU-computed first deformation layer's output go out in a burst of 64 values.
+    // of chunk_mma, one value per MFMA group, one 16-byte store per four); only the tiles consumed on the VALU (deformation head,
+    // rgb head) and the VALU-computed first deformation layer's output go out in a burst of 64 values.
     auto side = [&](const f32x16& tile, int row, unsigned& word, bool with_mask) {
       return [&, row, with_mask](int i) {
         if constexpr (TRAIN) {
           if (i < 16) {
-            *plane_addr(rows(row), io, (i & 3) + 8 * (i >> 2)) = tile[i];
+            if ((i & 3) == 0) store_quad(io, row, i >> 2, tile);
             if (with_mask) word = mask_push_post(word, tile[i]);
           }
         }
@@ -198,12 +197,12 @@ __global__ void __launch_bounds__(256) art_mlp_fwd_kernel(ArtMlpArgs args) {
     };
     auto burst = [&](auto& tiles, int row, int mask_slot) {   // VALU-consumed tiles
       if constexpr (TRAIN) {
-        store_plane(tiles, rows(row), io);
+        store_plane(tiles, io, row);
         *mask_ptr(args.masks, args.Np, mask_slot, moff) = relu_mask_bits(tiles);
       }
     };
     auto save_row = [&](int row, float v) {  // one scalar per sample (lanes 0..31)
-      if constexpr (TRAIN) { if (h == 0) *reinterpret_cast<float*>(reinterpret_cast<char*>(args.planes) + (int64_t)row * io.row_bytes + col * 4) = v; }
+      if constexpr (TRAIN) { if (h == 0) *row_ptr(io, row) = v; }
     };
     if constexpr (TRAIN) {
 #pragma unroll
@@ -242,7 +241,7 @@ __global__ void __launch_bounds__(256) art_mlp_fwd_kernel(ArtMlpArgs args) {
     if constexpr (TRAIN) {
 #pragma unroll
       for (int a = 0; a < 3; ++a) save_row(kAPlPos + 3 + a, xd[a]);
-      store_pos_enc_plane(E, rows(kAPlE), io, col, h);
+      store_pos_enc_plane(E, io, kAPlE, h);
     }
 
     // ---- trunk (:212-217), shape latent folded into the biases of layers 0 and 5 ----
@@ -276,7 +275,7 @@ __global__ void __launch_bounds__(256) art_mlp_fwd_kernel(ArtMlpArgs args) {
     dense_layer<ArtNet, kAChV0, 8, 4>(p, X, Z0, consume8(X, kAPlBot, false));
     if constexpr (TRAIN) {
       encode_view(vd, h, V);
-      store_view_enc_plane(V, rows(kAPlVE), io, col, h);
+      store_view_enc_plane(V, io, kAPlVE, h);
     }
     chunk_mma<ArtNet, kAChV0 + 8, 4, 14>(p, V, Z0);
     relu_tiles(Z0);

@@ -115,9 +115,6 @@ __device__ __forceinline__ void dma_round(const Pipe& p, unsigned off, int r) {
 
 // out[Tp] += W_chunk[Tp] * in   for one 32-feature input tile held in accumulator layout.
 // The A-operand reads are software-pipelined one ds_read_b128 (= 4 MFMA steps, 256 matrix-pipe cycles) ahead.
-struct PlaneIO;
-__device__ __forceinline__ float* plane_addr(float* plane, const PlaneIO& io, int row);
-
 // SIDE JOB: `side(i)` is called for i = 0 .. max(16, NSTEP)-1, spread over the chunk's steps (a step = a group of four
 // MFMAs, 256 matrix-pipe cycles), between the MFMA groups of the chunk.  The training kernels hang their per-value bookkeeping on it -- storing the input tile
 // to its activation / gradient plane, collecting or applying ReLU decision bits -- one value per step, so that this VALU
@@ -255,30 +252,43 @@ __device__ __forceinline__ float head_partial(const f32x16 (&x)[NT], const float
 }
 
 
-// Training: register tiles <-> feature-major planes (row = true feature, column = sample).  Per memory
-// instruction the two half-waves touch two 128-byte row segments (32 consecutive samples of features f and f+4).
-// Addressing is  [uniform 64-bit row base in SGPRs]  +  [one 32-bit per-lane byte offset]: `row_bytes` is re-made
-// opaque every pass so that the hundreds of distinct row bases are recomputed on the scalar unit instead of being
-// hoisted out of the pass loop into (spilled) vector registers.
+// Training planes, STEP-MAJOR (round 3).  A *step* is the 32 samples one wave carries through the network in a pass (pass p,
+// wave w -> step 4p + w); a *unit* is 16 bytes = FOUR consecutive feature rows of ONE sample.  Feature row f of sample n lives at
+//   float offset  ((n >> 5) * (rows / 4) + (f >> 2)) * 128 + (n & 31) * 4 + (f & 3)          [step][f / 4][sample][f % 4]
+// * the forward / the backward chain hold rows 8g + 4h + {0..3} of a tile in four consecutive accumulator registers: ONE 16-byte
+//   store per lane, the 64 lanes of a wave writing 1 KiB contiguous (round 2: two 128-byte row segments per 4-byte store,
+//   3,456 rows x 512 B scattered per pass);
+// * the weight-gradient kernel fetches an operand of a step -- the (rows_of_layer / 4) x 512 B of consecutive units -- as one
+//   contiguous run with LDS-DMA and reads a unit per lane as 4 features x 1 sample: 16 MFMAs per pair of ds_read_b128.
+// Addressing:  [wave-uniform 64-bit base of the step, re-made opaque every pass so it lives on the scalar unit]  +
+//              [compile-time row offset]  +  [one 32-bit per-lane offset h * 512 + m * 16 that never changes].
 struct PlaneIO {
-  int64_t row_bytes;  // Np * 4
-  unsigned voff;      // (col + 4*h*Np) * 4 : this lane's offset from the base of row (32t + (r&3) + 8(r>>2))
+  char* base;      // planes + step * rows * 128 bytes (wave-uniform)
+  unsigned voff;   // h * 512 + m * 16: unit (row group + h, sample m)
+  unsigned soff;   // m * 16: this lane's sample inside a unit row (scalar accesses)
 };
 
-__device__ __forceinline__ PlaneIO make_plane_io(int64_t Np, int64_t col, int h) {
+__device__ __forceinline__ PlaneIO make_plane_io(const float* planes, int rows, int64_t step, int m, int h) {
   PlaneIO io;
-  int64_t rb = Np * 4;
-  asm volatile("" : "+s"(rb));
-  io.row_bytes = rb;
-  io.voff = (unsigned)((col + (int64_t)(4 * h) * Np) * 4);
+  int64_t sb = step * (int64_t)rows * 128;
+  asm volatile("" : "+s"(sb));
+  io.base = const_cast<char*>(reinterpret_cast<const char*>(planes)) + sb;
+  io.voff = (unsigned)(h * 512 + m * 16);
+  io.soff = (unsigned)(m * 16);
   return io;
 }
 
-__device__ __forceinline__ float* plane_addr(float* plane, const PlaneIO& io, int row) {
-  return reinterpret_cast<float*>(reinterpret_cast<char*>(plane) + (int64_t)row * io.row_bytes + io.voff);
+// registers 4g .. 4g+3 of the tile whose first plane row is `row` (a multiple of 32): rows row + 8g + 4h + {0..3}
+__device__ __forceinline__ f32x4* quad_ptr(const PlaneIO& io, int row, int g) {
+  return reinterpret_cast<f32x4*>(io.base + (int64_t)(row * 128 + g * 1024) + io.voff);
 }
-__device__ __forceinline__ const float* plane_addr(const float* plane, const PlaneIO& io, int row) {
-  return reinterpret_cast<const float*>(reinterpret_cast<const char*>(plane) + (int64_t)row * io.row_bytes + io.voff);
+// one row of this lane's sample (any row)
+__device__ __forceinline__ float* row_ptr(const PlaneIO& io, int row) {
+  return reinterpret_cast<float*>(io.base + (int64_t)((row >> 2) * 512 + (row & 3) * 4) + io.soff);
+}
+__device__ __forceinline__ void store_quad(const PlaneIO& io, int row, int g, const f32x16& t) {
+  f32x4 v; v[0] = t[4 * g]; v[1] = t[4 * g + 1]; v[2] = t[4 * g + 2]; v[3] = t[4 * g + 3];
+  *quad_ptr(io, row, g) = v;
 }
 
 // ReLU masks of one layer as bits (bit (t&1)*16 + r of word t>>1 <-> tile t, register r): 16 bytes per lane per layer,
@@ -355,18 +365,17 @@ __device__ __forceinline__ void apply_mask_tile(f32x16& x, const u32x4 w, int t)
 template <int NT, bool MASKED>
 struct BwdSideOf {
   f32x16 (&tiles)[NT];
-  float* plane;        // row 0 of tile 0 in the gradient planes
+  int row;             // plane row of tile 0 in the gradient planes
   const PlaneIO& io;
-  int64_t tile_bytes;
   const u32x4& mk;
   __device__ __forceinline__ auto operator()(int j) const {
     f32x16 (&t)[NT] = tiles;
-    float* tp = reinterpret_cast<float*>(reinterpret_cast<char*>(plane) + j * tile_bytes);
+    const int trow = row + 32 * j;
     const PlaneIO& pio = io;
     const u32x4& m = mk;
-    return [&t, tp, &pio, &m, j](int i) {
+    return [&t, trow, &pio, &m, j](int i) {
       if (i < 16) {
-        *plane_addr(tp, pio, (i & 3) + 8 * (i >> 2)) = t[j][i];
+        if ((i & 3) == 0) store_quad(pio, trow, i >> 2, t[j]);   // one 16-byte store per four slots
         if constexpr (MASKED) {
           if (j + 1 < NT) t[j + 1][i] = mask_apply(m[(j + 1) >> 1], t[j + 1][i], ((j + 1) & 1) * 16 + i);
         }
@@ -376,48 +385,48 @@ struct BwdSideOf {
 };
 
 template <int NT>
-__device__ __forceinline__ void store_plane(const f32x16 (&x)[NT], float* plane, const PlaneIO& io) {
+__device__ __forceinline__ void store_plane(const f32x16 (&x)[NT], const PlaneIO& io, int row) {
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) *plane_addr(plane, io, 32 * t + (r & 3) + 8 * (r >> 2)) = x[t][r];
+    for (int g = 0; g < 4; ++g) store_quad(io, row + 32 * t, g, x[t]);
   }
 }
 
 template <int NT>
-__device__ __forceinline__ void load_plane(f32x16 (&x)[NT], const float* plane, const PlaneIO& io) {
+__device__ __forceinline__ void load_plane(f32x16 (&x)[NT], const PlaneIO& io, int row) {
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) x[t][r] = *plane_addr(plane, io, 32 * t + (r & 3) + 8 * (r >> 2));
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 v = *quad_ptr(io, row + 32 * t, g);
+      x[t][4 * g] = v[0]; x[t][4 * g + 1] = v[1]; x[t][4 * g + 2] = v[2]; x[t][4 * g + 3] = v[3];
+    }
   }
 }
 
-// encodings are held in a permuted register order (posenc_col / viewenc_col); planes use the reference's columns.
-// Addressing as everywhere: [uniform row base on the scalar unit] + [one 32-bit per-lane byte offset].  The half-wave
-// dependent part of the row index (sin rows for h = 0, sin(. + pi/2) rows for h = 1) goes into the lane offset; written as
-// a per-lane ROW index times the pitch, the compiler hoists one 64-bit product per row out of the pass loop (30 + 12 register
-// pairs, which it then spills).
-__device__ __forceinline__ unsigned enc_lane_off(const PlaneIO& io, int64_t col, int h, int rows_per_half) {
-  return (unsigned)(col * 4 + (h ? (int64_t)rows_per_half * io.row_bytes : 0));
+// encodings are held in a permuted register order (posenc_col / viewenc_col); planes use the reference's columns, so these
+// rows are written one value at a time (62 + 26 four-byte stores per sample against 3,400 rows in 16-byte stores).  The row of
+// a register depends on the half-wave (sin rows for h = 0, sin(. + pi/2) rows for h = 1): both byte offsets are compile-time
+// constants and the lane picks one.
+__device__ __forceinline__ unsigned enc_row_off(int row) { return (unsigned)((row >> 2) * 512 + (row & 3) * 4); }
+
+__device__ __forceinline__ void store_pos_enc_plane(const f32x16 (&E)[2], const PlaneIO& io, int row0, int h) {
+  char* base = io.base + io.soff;
+#pragma unroll
+  for (int rho = 0; rho < 30; ++rho)
+    *reinterpret_cast<float*>(base + (h ? enc_row_off(row0 + 33 + rho) : enc_row_off(row0 + 3 + rho))) = E[rho >> 4][rho & 15];
+  *reinterpret_cast<float*>(base + (h ? enc_row_off(row0 + 2) : enc_row_off(row0))) = E[1][14];
+  if (!h) *reinterpret_cast<float*>(base + enc_row_off(row0 + 1)) = E[1][15];
 }
 
-__device__ __forceinline__ void store_pos_enc_plane(const f32x16 (&E)[2], float* plane, const PlaneIO& io, int64_t col, int h) {
-  char* base = reinterpret_cast<char*>(plane);
-  const unsigned off_sin = enc_lane_off(io, col, h, 30), off_id = enc_lane_off(io, col, h, 2);
+__device__ __forceinline__ void store_view_enc_plane(const f32x16& V, const PlaneIO& io, int row0, int h) {
+  char* base = io.base + io.soff;
 #pragma unroll
-  for (int rho = 0; rho < 30; ++rho) *reinterpret_cast<float*>(base + (int64_t)(3 + rho) * io.row_bytes + off_sin) = E[rho >> 4][rho & 15];
-  *reinterpret_cast<float*>(base + off_id) = E[1][14];                       // row 0 (h = 0) / row 2 (h = 1)
-  if (!h) *reinterpret_cast<float*>(base + io.row_bytes + off_id) = E[1][15];  // row 1
-}
-
-__device__ __forceinline__ void store_view_enc_plane(const f32x16& V, float* plane, const PlaneIO& io, int64_t col, int h) {
-  char* base = reinterpret_cast<char*>(plane);
-  const unsigned off_sin = enc_lane_off(io, col, h, 12), off_id = enc_lane_off(io, col, h, 2);
-#pragma unroll
-  for (int rho = 0; rho < 12; ++rho) *reinterpret_cast<float*>(base + (int64_t)(3 + rho) * io.row_bytes + off_sin) = V[rho];
-  *reinterpret_cast<float*>(base + off_id) = V[12];
-  if (!h) *reinterpret_cast<float*>(base + io.row_bytes + off_id) = V[13];
+  for (int rho = 0; rho < 12; ++rho)
+    *reinterpret_cast<float*>(base + (h ? enc_row_off(row0 + 15 + rho) : enc_row_off(row0 + 3 + rho))) = V[rho];
+  *reinterpret_cast<float*>(base + (h ? enc_row_off(row0 + 2) : enc_row_off(row0))) = V[12];
+  if (!h) *reinterpret_cast<float*>(base + enc_row_off(row0 + 1)) = V[13];
 }
 
 // Positional / view encodings directly in accumulator (= next layer's B operand) layout: lanes 0-31 hold the sin

@@ -13,6 +13,7 @@
 //                          split across workgroups, each holding a full M x K accumulator block in registers, and a
 //                          deterministic second stage sums the per-workgroup partials (no atomics).
 //   head_wgrad_kernel      the 1- and 3-row head weights and all bias sums (row reductions of planes).
+#define AON_WGRAD_KERNELS
 #include "aon_wgrad.h"
 
 namespace aon {
@@ -202,6 +203,7 @@ __global__ void __launch_bounds__(256) mlp_bwd_chain_kernel(BwdArgs args) {
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int m = lane & 31, h = lane >> 5;
+  const int wave_s = __builtin_amdgcn_readfirstlane(wave);
   {
     const f32x4* src = reinterpret_cast<const f32x4*>(args.small);
     f32x4* dst = reinterpret_cast<f32x4*>(sm);
@@ -212,13 +214,11 @@ __global__ void __launch_bounds__(256) mlp_bwd_chain_kernel(BwdArgs args) {
 
   for (int pass = blockIdx.x; pass < args.npass; pass += gridDim.x) {
     const int64_t col = (int64_t)pass * 128 + wave * 32 + m;
-    const PlaneIO io = make_plane_io(args.Np, col, h);
-    const int64_t tile_bytes = 32 * io.row_bytes;
+    const PlaneIO io = make_plane_io(args.dplanes, kPlRows, (int64_t)pass * 4 + wave_s, m, h);
     // The 16-byte decision-bit word of a layer is fetched ONE layer ahead of its use (round 1 fetched all nine up front:
     // 36 registers held through the whole pass).  The offset is made opaque at the point of use so the load stays there.
     const unsigned moff = mask_lane_off(pass, tid);
     auto load_mask = [&](int layer) { return *mask_ptr(args.masks, args.Np, layer, moff); };
-    auto dp = [&](int row) { return reinterpret_cast<float*>(reinterpret_cast<char*>(args.dplanes) + (int64_t)row * io.row_bytes); };
     const float4 dr = reinterpret_cast<const float4*>(args.d_raw)[col];
     // half-wave index as the LDS reads below see it: opaque per pass, otherwise every head-weight address (the small block
     // sits beyond the 64 KiB immediate-offset range of the ring) is hoisted out of the pass loop into its own register
@@ -245,7 +245,7 @@ __global__ void __launch_bounds__(256) mlp_bwd_chain_kernel(BwdArgs args) {
     mk_next = load_mask(7);
     apply_mask_tile(Z[0], mk, 0);
     zero_tiles(X);
-    dense_layer<BwdNet, kBwView, 4, 8>(p, Z, X, BwdSideOf<4, true>{Z, dp(kPlHV), io, tile_bytes, mk});
+    dense_layer<BwdNet, kBwView, 4, 8>(p, Z, X, BwdSideOf<4, true>{Z, kPlHV, io, mk});
     // dH7 = W_bott^T . dBot + W_sigma^T * d_sigma   (the bottleneck has no activation; the density head reads the
     // post-ReLU layer-7 output, model.py:105)
 #pragma unroll
@@ -257,12 +257,12 @@ __global__ void __launch_bounds__(256) mlp_bwd_chain_kernel(BwdArgs args) {
         for (int cc = 0; cc < 4; ++cc) Y[t][4 * gq + cc] = w[cc] * dr.w;
       }
     }
-    dense_layer<BwdNet, kBwBott, 8, 8>(p, X, Y, BwdSideOf<8, false>{X, dp(kPlBot), io, tile_bytes, mk});
+    dense_layer<BwdNet, kBwBott, 8, 8>(p, X, Y, BwdSideOf<8, false>{X, kPlBot, io, mk});
     // trunk: dZ_l = mask_l . dH_l (stored by the chunks that consume it), dH_{l-1} = W_l^T . dZ_l
 #define AON_BWD_LAYER(IN, OUT, CB, L)                                                                                  \
     mk = mk_next; if (L > 0) mk_next = load_mask(L - 1);                                                               \
     apply_mask_tile(IN[0], mk, 0); zero_tiles(OUT);                                                                    \
-    dense_layer<BwdNet, CB, 8, 8>(p, IN, OUT, BwdSideOf<8, true>{IN, dp(plane_h(L)), io, tile_bytes, mk});
+    dense_layer<BwdNet, CB, 8, 8>(p, IN, OUT, BwdSideOf<8, true>{IN, plane_h(L), io, mk});
     AON_BWD_LAYER(Y, X, kBwL7 + 0, 7)
     AON_BWD_LAYER(X, Y, kBwL7 + 8, 6)
     AON_BWD_LAYER(Y, X, kBwL7 + 16, 5)
@@ -273,7 +273,7 @@ __global__ void __launch_bounds__(256) mlp_bwd_chain_kernel(BwdArgs args) {
 #undef AON_BWD_LAYER
     // dZ0: no data gradient flows into the encoding, so no chunk consumes it -- masked and stored here (128 values)
     apply_mask_bits(X, mk_next);
-    store_plane(X, dp(plane_h(0)), io);
+    store_plane(X, io, plane_h(0));
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
@@ -310,54 +310,58 @@ hipError_t launch_mlp_bwd_chain(const char* packed_bwd, const char* packed_fwd, 
 
 int64_t wgrad_workspace_bytes() { return wgrad_workspace_bytes_impl(); }
 
-// grads: 24 device pointers in the parameter order of aon_pack_vanilla_mlp (each the full (out,in) / (out,) tensor), overwritten.
-hipError_t launch_vanilla_wgrad(const float* planes, const float* dplanes, const float* d_raw, int64_t Np, float* const* grads,
-                                float* ws, hipStream_t stream) {
+// Launch sequence shared by both networks: grouped weight gradients, heads, ONE second stage for both.
+hipError_t run_wgrad_plan(const WgLayerDesc* layers, int nlayers, const HeadDesc* heads, int nheads, const HeadOut* outs, const int* out_head, int nouts,
+                          const float* planes, const float* dplanes, int rows_total, int64_t Np, float* ws, hipStream_t stream) {
+  static DeviceOnce lds_once;
+  if (hipError_t e = set_max_lds(&wgrad_grouped_kernel, kWgLdsBytes, lds_once); e != hipSuccess) return e;
   const int cus = num_cus();
   if (cus <= 0) return hipErrorInvalidDevice;
-  const int nchunks = (int)(Np / 32);
-  int nparts = nchunks < cus ? nchunks : cus;
-  if (nparts > 256) nparts = 256;
-  const WgradWs w = carve_wgrad_ws(ws);
-  float* partial = w.partial;
-  float* bias_partial = w.bias_partial;
-  float* head_partial = w.head_partial;
-  auto P = [&](int row) { return planes + (int64_t)row * Np; };
-  auto D = [&](int row) { return dplanes + (int64_t)row * Np; };
-  hipError_t e;
-  // trunk: dW_l = dZ_l . H_{l-1}^T  (+ the pos-enc columns for layers 0 and 5)
-  e = run_wgrad<2, 2>(D(plane_h(0)), P(kPlE), Np, nparts, partial, bias_partial, grads[0], kPosEnc, 0, kPosEnc, grads[1], stream);
-  if (e != hipSuccess) return e;
-  for (int l = 1; l < 8; ++l) {
-    const int ld = l == 5 ? 256 + kPosEnc : 256;
-    e = run_wgrad<2, 8>(D(plane_h(l)), P(plane_h(l - 1)), Np, nparts, partial, bias_partial, grads[2 * l], ld, 0, 256, grads[2 * l + 1], stream);
-    if (e != hipSuccess) return e;
-    if (l == 5) {
-      e = run_wgrad<2, 2>(D(plane_h(5)), P(kPlE), Np, nparts, partial, bias_partial, grads[10], ld, 256, kPosEnc, nullptr, stream);
-      if (e != hipSuccess) return e;
-    }
-  }
-  // bottleneck (input: post-ReLU layer-7 output)
-  e = run_wgrad<2, 8>(D(kPlBot), P(plane_h(7)), Np, nparts, partial, bias_partial, grads[18], 256, 0, 256, grads[19], stream);
-  if (e != hipSuccess) return e;
-  // view layer: cat[bottleneck(256), viewenc(27)]
-  static_assert(kPlVE == kPlBot + 256, "bottleneck and view-encoding rows must be adjacent");   // one 128 x 288 GEMM (see aon_train_art.hip)
-  e = run_wgrad<1, 9>(D(kPlHV), P(kPlBot), Np, nparts, partial, bias_partial, grads[16], 256 + kViewEnc, 0, 256 + kViewEnc, grads[17], stream);
-  if (e != hipSuccess) return e;
-  // heads and their biases
+  if (Np <= 0 || (Np & 31)) return hipErrorInvalidValue;
+  WgPlan plan;
+  if (!wg_make_plan(layers, nlayers, planes, dplanes, rows_total, Np, cus < 304 ? cus : 304, ws, 0, plan)) return hipErrorInvalidValue;
+  int64_t off = plan.ws_floats;
+  HeadArgs H{};
+  int part_offs[kHeadMaxJobs];
+  if (nheads > kHeadMaxJobs || nouts > kHeadMaxOut) return hipErrorInvalidValue;
+  const int head_blocks = head_make_plan(heads, nheads, rows_total, Np, ws, off, H, part_offs);
+  if (off * 4 > wgrad_workspace_bytes_impl()) return hipErrorInvalidValue;
   int nseg; int64_t seg_len;
   head_segments(Np, nseg, seg_len);
-  head_wgrad_kernel<<<dim3((256 + kHeadRows - 1) / kHeadRows, nseg), dim3(256), 0, stream>>>(P(plane_h(7)), Np, d_raw, seg_len, head_partial, 256);
-  head_reduce_kernel<<<dim3(1), dim3(256), 0, stream>>>(head_partial, nseg, 256, 3, 1, grads[20], 256);   // density_layer.weight (1,256)
-  head_wgrad_kernel<<<dim3((128 + kHeadRows - 1) / kHeadRows, nseg), dim3(256), 0, stream>>>(P(kPlHV), Np, d_raw, seg_len, head_partial, 128);
-  head_reduce_kernel<<<dim3(2), dim3(256), 0, stream>>>(head_partial, nseg, 128, 0, 3, grads[22], 128);  // rgb_layer.weight (3,128)
-  head_wgrad_kernel<<<dim3((1 + kHeadRows - 1) / kHeadRows, nseg), dim3(256), 0, stream>>>(nullptr, Np, d_raw, seg_len, head_partial, 1);
-  head_reduce_kernel<<<dim3(1), dim3(256), 0, stream>>>(head_partial, nseg, 1, 3, 1, grads[21], 1);      // density_layer.bias (1,)
-  head_reduce_kernel<<<dim3(1), dim3(256), 0, stream>>>(head_partial, nseg, 1, 0, 3, grads[23], 1);      // rgb_layer.bias (3,)
+  ReduceArgs& R = plan.red;
+  R.nhead = nouts; R.nseg = nseg; R.head_blk_begin = plan.reduce_blocks;
+  for (int o = 0; o < nouts; ++o) { R.head[o] = outs[o]; R.head[o].part_off = part_offs[out_head[o]]; }
+  wgrad_grouped_kernel<<<dim3(plan.total_wgs), dim3(256), kWgLdsBytes, stream>>>(plan.args);
+  if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
+  head_wgrad_kernel<<<dim3(head_blocks, nseg), dim3(256), 0, stream>>>(H);
+  if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
+  wgrad_reduce_kernel<<<dim3(plan.reduce_blocks + nouts), dim3(256), 0, stream>>>(R);
   return hipGetLastError();
 }
 
-void set_train_engine(int e) { train_engine() = e; }
-int get_train_engine() { return train_engine(); }
+// grads: 24 device pointers in the parameter order of aon_pack_vanilla_mlp (each the full (out,in) / (out,) tensor), overwritten.
+hipError_t launch_vanilla_wgrad(const float* planes, const float* dplanes, const float* d_raw, int64_t Np, float* const* grads,
+                                float* ws, hipStream_t stream) {
+  WgLayerDesc L[11];
+  int n = 0;
+  // trunk: dW_l = dZ_l . H_{l-1}^T  (+ the pos-enc columns for layers 0 and 5)
+  L[n++] = WgLayerDesc{kWg256x64, plane_h(0), kPlE, grads[0], kPosEnc, 0, kPosEnc, grads[1], 0};
+  for (int l = 1; l < 8; ++l) {
+    const int ld = l == 5 ? 256 + kPosEnc : 256;
+    L[n++] = WgLayerDesc{kWg256x256, plane_h(l), plane_h(l - 1), grads[2 * l], ld, 0, 256, grads[2 * l + 1], 0};
+    if (l == 5) L[n++] = WgLayerDesc{kWg256x64, plane_h(5), kPlE, grads[10], ld, 256, kPosEnc, nullptr, 0};
+  }
+  // bottleneck (input: post-ReLU layer-7 output)
+  L[n++] = WgLayerDesc{kWg256x256, kPlBot, plane_h(7), grads[18], 256, 0, 256, grads[19], 0};
+  // view layer: cat[bottleneck(256), viewenc(27)] -- the view-encoding rows follow the bottleneck rows in the planes
+  static_assert(kPlVE == kPlBot + 256, "bottleneck and view-encoding rows must be adjacent");
+  L[n++] = WgLayerDesc{kWg128x288, kPlHV, kPlBot, grads[16], 256 + kViewEnc, 0, 256, grads[17], kViewEnc};
+  // heads and their biases: density_layer (1,256) <- H7 x d_raw.w, rgb_layer (3,128) <- HV x d_raw.xyz, bias sums of d_raw
+  const HeadDesc H[3] = {{planes, plane_h(7), 256, d_raw, 128}, {planes, kPlHV, 128, d_raw, 128}, {nullptr, 0, 1, d_raw, 128}};
+  const HeadOut O[4] = {{0, 256, 3, 1, 256, 1, grads[20]}, {0, 128, 0, 3, 128, 1, grads[22]}, {0, 1, 3, 1, 1, 1, grads[21]}, {0, 1, 0, 3, 1, 1, grads[23]}};
+  const int OH[4] = {0, 1, 2, 2};
+  return run_wgrad_plan(L, n, H, 3, O, OH, 4, planes, dplanes, kPlRows, Np, ws, stream);
+}
+
 
 }  // namespace aon

@@ -113,9 +113,8 @@ __global__ void __launch_bounds__(256) art_bwd_chain_kernel(ArtBwdArgs args) {
     const int tid_p = (wave_s << 6) | lane_p;
     const int m = lane_p & 31, h = lane_p >> 5;
     const int64_t col = (int64_t)pass * 128 + (tid_p >> 6) * 32 + m;
-    const PlaneIO io = make_plane_io(args.Np, col, h);
-    const int64_t tile_bytes = 32 * io.row_bytes;
-    auto dp = [&](int row) { return reinterpret_cast<float*>(reinterpret_cast<char*>(args.dplanes) + (int64_t)row * io.row_bytes); };
+    const int64_t step = (int64_t)pass * 4 + wave_s;
+    const PlaneIO io = make_plane_io(args.dplanes, kAPlRows, step, m, h);
     // decision bits of a layer: fetched one layer ahead of their use, offset opaque so the load stays where it is written
     // (round 1 fetched all sixteen words up front: 64 registers held through the pass)
     const unsigned moff = mask_lane_off(pass, tid_p);
@@ -145,7 +144,7 @@ __global__ void __launch_bounds__(256) art_bwd_chain_kernel(ArtBwdArgs args) {
 #define AON_ABWD_LAYER(NT_IN, NT_OUT, IN, OUT, CB, ROW, NEXT_SLOT)                                                   \
     if (NEXT_SLOT >= 0) mk_next = load_mask(NEXT_SLOT);                                                               \
     apply_mask_tile(IN[0], mk, 0); zero_tiles_a(OUT);                                                                \
-    dense_layer<N, CB, NT_IN, NT_OUT>(p, IN, OUT, BwdSideOf<NT_IN, true>{IN, dp(ROW), io, tile_bytes, mk});         \
+    dense_layer<N, CB, NT_IN, NT_OUT>(p, IN, OUT, BwdSideOf<NT_IN, true>{IN, ROW, io, mk});                          \
     mk = mk_next;
     AON_ABWD_LAYER(4, 4, Z1, Z0, kABwV3 + 0, aplane_v(3), 14)
     AON_ABWD_LAYER(4, 4, Z0, Z1, kABwV3 + 4, aplane_v(2), 13)
@@ -163,7 +162,7 @@ __global__ void __launch_bounds__(256) art_bwd_chain_kernel(ArtBwdArgs args) {
         for (int cc = 0; cc < 4; ++cc) Y[t][4 * gq + cc] = w[cc] * dsig;
       }
     }
-    dense_layer<N, kABwBott, 8, 8>(p, X, Y, BwdSideOf<8, false>{X, dp(kAPlBot), io, tile_bytes, mk});   // Y = dH7
+    dense_layer<N, kABwBott, 8, 8>(p, X, Y, BwdSideOf<8, false>{X, kAPlBot, io, mk});   // Y = dH7
     AON_ABWD_LAYER(8, 8, Y, X, kABwL7 + 0, aplane_h(7), 10)
     AON_ABWD_LAYER(8, 8, X, Y, kABwL7 + 8, aplane_h(6), 9)
     // Y = dH5 -> dZ5, consumed twice: by the skip-connection chunks (d enc += W5[:, 256:319]^T dZ5), which mask and store it,
@@ -172,12 +171,12 @@ __global__ void __launch_bounds__(256) art_bwd_chain_kernel(ArtBwdArgs args) {
     zero_tiles_a(dE);
     mk_next = load_mask(8);
     apply_mask_tile(Y[0], mk, 0);
-    dense_layer<N, kABwL5E, 8, 2>(p, Y, dE, BwdSideOf<8, true>{Y, dp(aplane_h(5)), io, tile_bytes, mk});
+    dense_layer<N, kABwL5E, 8, 2>(p, Y, dE, BwdSideOf<8, true>{Y, aplane_h(5), io, mk});
     mk = mk_next;
     // The partial d enc (32 accumulator registers) would have to stay live across layers 5..1 on top of the two 128-register
     // activation sets; it is parked in the (otherwise unused) pos-enc rows of the gradient planes instead -- 128 B per lane out
     // and back per pass, against 13.8 KB of plane traffic -- rather than left to the register allocator's scratch spills.
-    store_plane(dE, dp(kAPlE), io);
+    store_plane(dE, io, kAPlE);
     zero_tiles_a(X); dense_layer<N, kABwL5 + 0, 8, 8>(p, Y, X);   // X = dH4
     AON_ABWD_LAYER(8, 8, X, Y, kABwL5 + 8, aplane_h(4), 7)
     AON_ABWD_LAYER(8, 8, Y, X, kABwL5 + 16, aplane_h(3), 6)
@@ -186,15 +185,16 @@ __global__ void __launch_bounds__(256) art_bwd_chain_kernel(ArtBwdArgs args) {
     // X = dH0 -> dZ0, consumed by the encoding chunks: d enc += W0[:, :63]^T dZ0
     mk_next = load_mask(3);
     apply_mask_tile(X[0], mk, 0);
-    load_plane(dE, dp(kAPlE), io);
-    dense_layer<N, kABwL0E, 8, 2>(p, X, dE, BwdSideOf<8, true>{X, dp(aplane_h(0)), io, tile_bytes, mk});
+    load_plane(dE, io, kAPlE);
+    dense_layer<N, kABwL0E, 8, 2>(p, X, dE, BwdSideOf<8, true>{X, aplane_h(0), io, mk});
     mk = mk_next;
 
     // ---- positional encoding, backwards (helper.py:136-140 on the deformed point) ----
     float xd[3];  // deformed position x' (forward stored it in rows 3..5 of the position block)
+    const PlaneIO fio = make_plane_io(args.planes, kAPlRows, step, m, h);
 #pragma unroll
     for (int a = 0; a < 3; ++a)
-      xd[a] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(args.planes) + (int64_t)(kAPlPos + 3 + a) * io.row_bytes + col * 4);
+      xd[a] = *row_ptr(fio, kAPlPos + 3 + a);
     const float phase = h ? AON_HALF_PI_F32 : 0.f;
     float dx[3] = {0.f, 0.f, 0.f};
 #pragma unroll
@@ -235,35 +235,46 @@ __global__ void __launch_bounds__(256) art_bwd_chain_kernel(ArtBwdArgs args) {
 #undef AON_ABWD_LAYER
     // dZ of deformation layer 0: its input is (pos, latents) -- no data gradient continues, no consuming chunk: 64 values here
     apply_mask_bits(H0, mk);
-    store_plane(H0, dp(aplane_d(0)), io);
+    store_plane(H0, io, aplane_d(0));
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-// dW[f][col_off + k] = db[f] * latent[k]
-__global__ void outer_kernel(const float* __restrict__ db, const float* __restrict__ latent, int M, int L, float* __restrict__ out,
-                             int ld, int col_off) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= M * L) return;
-  const int f = idx / L, k = idx % L;
-  out[(int64_t)f * ld + col_off + k] = db[f] * latent[k];
-}
-
-// d latent[k] = sum over (W, db) pairs, sum_f W[f][col_off + k] * db[f].  ONE launch for the three latents (block = latent);
-// 1024 threads = 8 row groups x 128 columns: group g takes rows f = g, g+8, ... (independent loads, coalesced over k), the
-// eight group sums are added in group order through LDS (deterministic).  Round 1 ran three launches of one 128-thread block
-// each with a serial f loop: 107 us per launch, 0.64 ms per training step.
+// Everything that follows from the bias gradients, ONE launch (1,024-thread blocks):
+//   blocks 0..2   d latent[k] = sum over (W, db) pairs, sum_f W[f][col_off + k] * db[f]  (block = latent).  8 row groups x 128
+//                 columns: group g takes rows f = g, g+8, ... (independent loads, coalesced over k), the eight group sums are
+//                 added in group order through LDS (deterministic);
+//   blocks 3..    the latent columns of the weights, dW[f][col_off + k] = db[f] * latent[k]  (every latent is broadcast to all
+//                 samples by the reference, model_autodecoder.py:186-194).
 struct LatentJob {
   const float* W[3]; const float* db[3]; int ld[3]; int col_off[3]; int M[3];
   int npairs; int L;
   float* out;
 };
-struct LatentGradArgs {
-  LatentJob job[3];
+struct OuterJob {
+  const float* db; const float* latent; float* out;
+  int M, L, ld, col_off, blk_begin;
 };
-__global__ void __launch_bounds__(1024) latent_grad_kernel(LatentGradArgs a) {
+struct ArtFinishArgs {
+  LatentJob lat[3];
+  OuterJob outer[5];
+};
+__global__ void __launch_bounds__(1024) art_finish_kernel(ArtFinishArgs a) {
   __shared__ float red[8][128];
-  const LatentJob& j = a.job[blockIdx.x];
+  if (blockIdx.x >= 3) {
+    int j = 0;
+#pragma unroll 1
+    for (int t = 1; t < 5; ++t)
+      if ((int)blockIdx.x >= a.outer[t].blk_begin) j = t;
+    const OuterJob& O = a.outer[j];
+    const int idx = ((int)blockIdx.x - O.blk_begin) * 1024 + threadIdx.x;
+    if (idx < O.M * O.L) {
+      const int f = idx / O.L, k = idx % O.L;
+      O.out[(int64_t)f * O.ld + O.col_off + k] = O.db[f] * O.latent[k];
+    }
+    return;
+  }
+  const LatentJob& j = a.lat[blockIdx.x];
   const int k = threadIdx.x & 127, g = threadIdx.x >> 7;
   float s = 0.f;
   if (k < j.L) {
@@ -313,79 +324,67 @@ hipError_t launch_art_bwd_chain(const char* packed_bwd, const float* small, cons
   return hipGetLastError();
 }
 
+hipError_t run_wgrad_plan(const WgLayerDesc* layers, int nlayers, const HeadDesc* heads, int nheads, const HeadOut* outs, const int* out_head, int nouts,
+                          const float* planes, const float* dplanes, int rows_total, int64_t Np, float* ws, hipStream_t stream);   // aon_train.hip
+
 // grads: 40 parameter gradients (order of aon_pack_art_mlp, full shapes) + 3 latent gradients (shape 128, appearance 128,
 // articulation 32); params / latents: the forward's inputs (needed for the latent-column products).
 hipError_t launch_art_wgrad(const float* planes, const float* dplanes, const float* d_raw, const float* dxp, int64_t Np,
                             const float* const* params, const float* shape, const float* app, const float* art,
                             float* const* grads, float* g_shape, float* g_app, float* g_art, float* ws, hipStream_t stream) {
-  const int cus = num_cus();
-  if (cus <= 0) return hipErrorInvalidDevice;
-  const int nchunks = (int)(Np / 32);
-  int nparts = nchunks < cus ? nchunks : cus;
-  if (nparts > 256) nparts = 256;
-  const WgradWs w = carve_wgrad_ws(ws);
-  auto P = [&](int row) { return planes + (int64_t)row * Np; };
-  auto D = [&](int row) { return dplanes + (int64_t)row * Np; };
-  hipError_t e;
-#define AON_TRY(x) do { e = (x); if (e != hipSuccess) return e; } while (0)
-  // deformation MLP (model_autodecoder.py:196-203): input of layer 0 = cat[pos(3), shape(128), articulation(32)]
-  AON_TRY((run_wgrad<1, 1>(D(aplane_d(0)), P(kAPlPos), Np, nparts, w.partial, w.bias_partial, grads[0], 163, 0, 3, grads[1], stream)));
-  for (int l = 1; l < 4; ++l)
-    AON_TRY((run_wgrad<1, 4>(D(aplane_d(l)), P(aplane_d(l - 1)), Np, nparts, w.partial, w.bias_partial, grads[2 * l], 128, 0, 128,
-                             grads[2 * l + 1], stream)));
+  WgLayerDesc L[kWgMaxJobs];
+  int n = 0;
+  // deformation MLP (model_autodecoder.py:196-203): layers 1..3 here; layer 0's three position columns go with the heads below
+  // (its input is cat[pos(3), shape(128), articulation(32)]: a 16-byte record per sample, not a plane operand)
+  for (int l = 1; l < 4; ++l) L[n++] = WgLayerDesc{kWg128x128, aplane_d(l), aplane_d(l - 1), grads[2 * l], 128, 0, 128, grads[2 * l + 1], 0};
   // trunk (:210-217): layer 0 input cat[enc(63), shape(128)], layer 5 input cat[h(256), enc(63), shape(128)]
-  AON_TRY((run_wgrad<2, 2>(D(aplane_h(0)), P(kAPlE), Np, nparts, w.partial, w.bias_partial, grads[10], 191, 0, kPosEnc, grads[11], stream)));
+  L[n++] = WgLayerDesc{kWg256x64, aplane_h(0), kAPlE, grads[10], 191, 0, kPosEnc, grads[11], 0};
   for (int l = 1; l < 8; ++l) {
     const int ld = l == 5 ? 447 : 256;
-    AON_TRY((run_wgrad<2, 8>(D(aplane_h(l)), P(aplane_h(l - 1)), Np, nparts, w.partial, w.bias_partial, grads[10 + 2 * l], ld, 0, 256,
-                             grads[11 + 2 * l], stream)));
-    if (l == 5)
-      AON_TRY((run_wgrad<2, 2>(D(aplane_h(5)), P(kAPlE), Np, nparts, w.partial, w.bias_partial, grads[20], ld, 256, kPosEnc, nullptr, stream)));
+    L[n++] = WgLayerDesc{kWg256x256, aplane_h(l), aplane_h(l - 1), grads[10 + 2 * l], ld, 0, 256, grads[11 + 2 * l], 0};
+    if (l == 5) L[n++] = WgLayerDesc{kWg256x64, aplane_h(5), kAPlE, grads[20], ld, 256, kPosEnc, nullptr, 0};
   }
-  AON_TRY((run_wgrad<2, 8>(D(kAPlBot), P(aplane_h(7)), Np, nparts, w.partial, w.bias_partial, grads[34], 256, 0, 256, grads[35], stream)));
-  // view branch (:227-234): layer 0 input cat[bottleneck(256), viewenc(27), appearance(128)]
-  // (the 256 bottleneck rows and the 32 view-encoding rows are adjacent in the plane row map AND in the weight's columns: one
-  // 128 x 288 GEMM instead of a 128 x 256 and a 128 x 32 one that re-reads the 128 gradient rows)
+  L[n++] = WgLayerDesc{kWg256x256, kAPlBot, aplane_h(7), grads[34], 256, 0, 256, grads[35], 0};
+  // view branch (:227-234): layer 0 input cat[bottleneck(256), viewenc(27), appearance(128)]; the view-encoding rows follow the
+  // bottleneck rows in the planes AND in the weight's columns: one 128 x 288 job
   static_assert(kAPlVE == kAPlBot + 256, "bottleneck and view-encoding rows must be adjacent");
-  AON_TRY((run_wgrad<1, 9>(D(aplane_v(0)), P(kAPlBot), Np, nparts, w.partial, w.bias_partial, grads[26], 411, 0, 256 + kViewEnc, grads[27], stream)));
-  for (int l = 1; l < 4; ++l)
-    AON_TRY((run_wgrad<1, 4>(D(aplane_v(l)), P(aplane_v(l - 1)), Np, nparts, w.partial, w.bias_partial, grads[26 + 2 * l], 128, 0, 128,
-                             grads[27 + 2 * l], stream)));
-  // heads: density (H7 x d_raw.w), rgb (V3 x d_raw.xyz), deformation_layer (D3 x dx') and their biases
-  int nseg; int64_t seg_len;
-  head_segments(Np, nseg, seg_len);
-  head_wgrad_kernel<<<dim3((256 + kHeadRows - 1) / kHeadRows, nseg), dim3(256), 0, stream>>>(P(aplane_h(7)), Np, d_raw, seg_len, w.head_partial, 256);
-  head_reduce_kernel<<<dim3(1), dim3(256), 0, stream>>>(w.head_partial, nseg, 256, 3, 1, grads[36], 256);
-  head_wgrad_kernel<<<dim3((128 + kHeadRows - 1) / kHeadRows, nseg), dim3(256), 0, stream>>>(P(aplane_v(3)), Np, d_raw, seg_len, w.head_partial, 128);
-  head_reduce_kernel<<<dim3(2), dim3(256), 0, stream>>>(w.head_partial, nseg, 128, 0, 3, grads[38], 128);
-  head_wgrad_kernel<<<dim3((1 + kHeadRows - 1) / kHeadRows, nseg), dim3(256), 0, stream>>>(nullptr, Np, d_raw, seg_len, w.head_partial, 1);
-  head_reduce_kernel<<<dim3(1), dim3(256), 0, stream>>>(w.head_partial, nseg, 1, 3, 1, grads[37], 1);
-  head_reduce_kernel<<<dim3(1), dim3(256), 0, stream>>>(w.head_partial, nseg, 1, 0, 3, grads[39], 1);
-  head_wgrad_kernel<<<dim3((128 + kHeadRows - 1) / kHeadRows, nseg), dim3(256), 0, stream>>>(P(aplane_d(3)), Np, dxp, seg_len, w.head_partial, 128);
-  head_reduce_kernel<<<dim3(2), dim3(256), 0, stream>>>(w.head_partial, nseg, 128, 0, 3, grads[8], 128);
-  head_wgrad_kernel<<<dim3((1 + kHeadRows - 1) / kHeadRows, nseg), dim3(256), 0, stream>>>(nullptr, Np, dxp, seg_len, w.head_partial, 1);
-  head_reduce_kernel<<<dim3(1), dim3(256), 0, stream>>>(w.head_partial, nseg, 1, 0, 3, grads[9], 1);
-  // latent columns of the weights: dW[:, latent cols] = db (x) latent
-  outer_kernel<<<dim3((128 * 128 + 255) / 256), dim3(256), 0, stream>>>(grads[1], shape, 128, 128, grads[0], 163, 3);
-  outer_kernel<<<dim3((128 * 32 + 255) / 256), dim3(256), 0, stream>>>(grads[1], art, 128, 32, grads[0], 163, 131);
-  outer_kernel<<<dim3((256 * 128 + 255) / 256), dim3(256), 0, stream>>>(grads[11], shape, 256, 128, grads[10], 191, 63);
-  outer_kernel<<<dim3((256 * 128 + 255) / 256), dim3(256), 0, stream>>>(grads[21], shape, 256, 128, grads[20], 447, 319);
-  outer_kernel<<<dim3((128 * 128 + 255) / 256), dim3(256), 0, stream>>>(grads[27], app, 128, 128, grads[26], 411, 283);
-  // latent gradients: d latent = W[:, latent cols]^T db
-  LatentGradArgs lg{};
-  LatentJob& ls = lg.job[0];   // shape: deformation layer 0, trunk layers 0 and 5
+  L[n++] = WgLayerDesc{kWg128x288, aplane_v(0), kAPlBot, grads[26], 411, 0, 256, grads[27], kViewEnc};
+  for (int l = 1; l < 4; ++l) L[n++] = WgLayerDesc{kWg128x128, aplane_v(l), aplane_v(l - 1), grads[26 + 2 * l], 128, 0, 128, grads[27 + 2 * l], 0};
+  // heads: density (H7 x d_raw.w), rgb (V3 x d_raw.xyz), deformation_layer (D3 x dx'), their bias sums, and deformation layer 0:
+  // dW[:, 0:3] = dZ_D0 x pos (the position is rows 0..2 of unit row kAPlPos / 4 of the forward planes), db = row sums of dZ_D0
+  const int64_t unit_step = (int64_t)kAPlRows * 32;
+  const HeadDesc H[6] = {{planes, aplane_h(7), 256, d_raw, 128}, {planes, aplane_v(3), 128, d_raw, 128}, {nullptr, 0, 1, d_raw, 128},
+                         {planes, aplane_d(3), 128, dxp, 128},   {nullptr, 0, 1, dxp, 128},
+                         {dplanes, aplane_d(0), 128, planes + (int64_t)(kAPlPos / 4) * 128, unit_step}};
+  const HeadOut O[8] = {{0, 256, 3, 1, 256, 1, grads[36]}, {0, 128, 0, 3, 128, 1, grads[38]}, {0, 1, 3, 1, 1, 1, grads[37]}, {0, 1, 0, 3, 1, 1, grads[39]},
+                        {0, 128, 0, 3, 128, 1, grads[8]},  {0, 1, 0, 3, 1, 1, grads[9]},
+                        {0, 128, 0, 3, 1, 163, grads[0]},  {0, 128, 4, 1, 1, 1, grads[1]}};
+  const int OH[8] = {0, 1, 2, 2, 3, 4, 5, 5};
+  if (hipError_t e = run_wgrad_plan(L, n, H, 6, O, OH, 8, planes, dplanes, kAPlRows, Np, ws, stream); e != hipSuccess) return e;
+  // latent columns of the weights and the latent gradients, both from the bias gradients
+  ArtFinishArgs F{};
+  LatentJob& ls = F.lat[0];   // shape: deformation layer 0, trunk layers 0 and 5
   ls.W[0] = params[0]; ls.db[0] = grads[1]; ls.ld[0] = 163; ls.col_off[0] = 3; ls.M[0] = 128;
   ls.W[1] = params[10]; ls.db[1] = grads[11]; ls.ld[1] = 191; ls.col_off[1] = 63; ls.M[1] = 256;
   ls.W[2] = params[20]; ls.db[2] = grads[21]; ls.ld[2] = 447; ls.col_off[2] = 319; ls.M[2] = 256;
   ls.npairs = 3; ls.L = 128; ls.out = g_shape;
-  LatentJob& la = lg.job[1];   // appearance: view layer 0
+  LatentJob& la = F.lat[1];   // appearance: view layer 0
   la.W[0] = params[26]; la.db[0] = grads[27]; la.ld[0] = 411; la.col_off[0] = 283; la.M[0] = 128;
   la.npairs = 1; la.L = 128; la.out = g_app;
-  LatentJob& lt = lg.job[2];   // articulation: deformation layer 0
+  LatentJob& lt = F.lat[2];   // articulation: deformation layer 0
   lt.W[0] = params[0]; lt.db[0] = grads[1]; lt.ld[0] = 163; lt.col_off[0] = 131; lt.M[0] = 128;
   lt.npairs = 1; lt.L = 32; lt.out = g_art;
-  latent_grad_kernel<<<dim3(3), dim3(1024), 0, stream>>>(lg);
-#undef AON_TRY
+  int blk = 3;
+  auto outer = [&](int i, const float* db, const float* latent, float* out, int M, int Ll, int ld, int col_off) {
+    F.outer[i] = OuterJob{db, latent, out, M, Ll, ld, col_off, blk};
+    blk += (M * Ll + 1023) / 1024;
+  };
+  outer(0, grads[1], shape, grads[0], 128, 128, 163, 3);
+  outer(1, grads[1], art, grads[0], 128, 32, 163, 131);
+  outer(2, grads[11], shape, grads[10], 256, 128, 191, 63);
+  outer(3, grads[21], shape, grads[20], 256, 128, 447, 319);
+  outer(4, grads[27], app, grads[26], 128, 128, 411, 283);
+  art_finish_kernel<<<dim3(blk), dim3(1024), 0, stream>>>(F);
   return hipGetLastError();
 }
 

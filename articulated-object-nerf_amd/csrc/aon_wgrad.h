@@ -1,7 +1,25 @@
 // Weight-gradient machinery shared by the vanilla (aon_train.hip) and articulated (aon_train_art.hip) backward passes.
+//
+// Round 3: ONE grouped launch per level for every layer's  dW_l = dZ_l^T[M x N] . H_{l-1}[N x K]  (N = samples), one launch
+// for every head / bias-only reduction, one for all second-stage sums, one for the latent outer products -- 4 launches per
+// level where round 2 issued ~75 (9 GEMM launches + 36 partial reductions + 22 head kernels + fills).
+//
+// Operands are the STEP-MAJOR planes of aon_mlp_core.h: a 16-byte unit = four consecutive feature rows of one sample, a step =
+// 32 samples, an operand of a step = (rows / 4) consecutive 512-byte unit rows = one contiguous run.
+//   * staging: LDS-DMA, 1 KiB (two unit rows) per wave-instruction, contiguous in HBM; NSTAGE-deep ring, the DMA of step
+//     c + NSTAGE - 1 issued between the MFMA groups of step c, s_waitcnt vmcnt(N) keeps the younger stages in flight across the
+//     workgroup barrier; the loop body is branch-free (a DMA past the end of the range re-reads the last step).
+//   * fragments: lane (i, kh) reads the unit (unit row g0 + i, sample 2p + kh) with ONE ds_read_b128 = the A (or B) values of
+//     FOUR feature rows for k-index kh: one A read and one B read feed 16 MFMAs (128 x 128 outputs x 2 samples).  Round 2
+//     read one row x 4 samples per lane: 10 reads per 64 MFMAs in a batch with the full LDS latency exposed every 64 MFMAs.
+//     Bank conflicts are removed on the GLOBAL side of the DMA: the lane that fills slot s of unit row g fetches sample
+//     s ^ (g & 15), so the 16 lanes of a ds_read_b128 group (16 different unit rows, same sample) hit 16 different slots.
+//   * the sample range of a layer is split over a number of workgroups proportional to its cost (all layers of a level run
+//     concurrently and finish together); a workgroup keeps its output block in accumulator registers and writes one partial,
+//     a deterministic second stage (fixed order, no atomics) sums the partials.  ~8x fewer partial bytes than round 2, which
+//     split EVERY layer over all 256 workgroups.
 #pragma once
 #include "aon_mlp_core.h"
-#include "aon_bf16_split.h"
 
 namespace aon {
 
@@ -12,395 +30,554 @@ __device__ __forceinline__ float wsum64(float v) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// weight gradients
+// grouped weight gradients
 // ---------------------------------------------------------------------------------------------
-// One workgroup: OUT[M x K] partial = A[M rows x n-range] . B[K rows x n-range]^T, M = 128*RT, K = 32*CT.
-// wave w owns rows [32*RT*w, 32*RT*(w+1)) x all K columns -> RT x CT accumulator tiles.
-//
-// Operand staging is LDS-DMA (global_load_lds, 16 bytes per lane), no vector registers and no ds_write spent on it:
-// one DMA instruction moves 8 rows x 128 bytes (each row segment a full, coalesced 128-byte line).  The LDS image
-// keeps rows at their natural 128-byte pitch; bank conflicts of the fragment reads (32 lanes reading the same 16-byte
-// column of 32 different rows) are removed by an XOR swizzle applied on the GLOBAL side: the lane that fills 16-byte
-// slot p of row r fetches column p ^ (r & 7) of that row, so column c of row r lives in slot c ^ (r & 7) and any 8
-// consecutive rows hit 8 distinct slots.  (Round-1 measurements, tools/ubench/wgrad_layout.hip, 256x256 block,
-// 790,528 samples: register-staged global_load + padded ds_write_b128 126 TFLOP/s; DMA gathering 32-byte pieces
-// directly into fragment order 109; this form: see DESIGN.md.)
-constexpr int kWgTileFloats = 32 * 32;  // one 32-row tile of one 32-sample step
+// Job kinds (M = rows of dZ, K = rows of the activation operand; a wave owns a 128 x (32 NB) block of 4 x NB accumulator tiles):
+//   kWg256x256   4 waves = 2 x 2 blocks of 128 x 128, every wave takes all 16 sample pairs of a step
+//   kWg128x128   one block, the four waves take 4 sample pairs each (four partials)
+//   kWg256x64    two 128 x 64 blocks x two sample halves                      (positional-encoding inputs, 63 valid columns)
+//   kWg128x288   128 x 256 as two blocks x two sample halves + the adjacent 32 plane rows (view encoding, 27 valid) as a
+//                128 x 32 extension each wave computes on half of its own pairs (the A fragment is already in registers)
+enum : int { kWg256x256 = 0, kWg128x128 = 1, kWg256x64 = 2, kWg128x288 = 3, kWgNumKinds = 4 };
 
-struct WgradArgs {
-  const float* A;  // dZ plane rows (row 0 of this block)
-  const float* B;  // activation plane rows
-  int64_t Np;
-  int nchunks;     // Np / 32
-  float* partial;  // [gridDim.x][M][K]
-  float* bias_partial;  // [gridDim.x][M] or null
+struct WgJob {
+  int a_unit;      // first unit row (plane row / 4) of dZ in the gradient planes
+  int b_unit;      // first unit row of the layer input in the forward planes
+  int kind;
+  int wg_begin, wg_count;   // workgroups [wg_begin, wg_begin + wg_count) split the steps of this layer
+  int part_off;    // float offset in the workspace of partial[wg_count * nsplit][M][K]
+  int bias_off;    // float offset of bias_partial[wg_count * nsplit][M], or -1
+  int ext_off;     // kWg128x288: float offset of the extension's partial[wg_count * 4][128][32]
 };
 
-template <int RT, int CT>
-__global__ void __launch_bounds__(256) wgrad_kernel(WgradArgs a) {
-  constexpr int M = 128 * RT, K = 32 * CT;
-  constexpr int NTILE = (M + K) / 32;           // 32-row tiles staged per 32-sample step
-  constexpr int DMA_EVERY = CT < 4 ? CT : 4;   // one DMA instruction per DMA_EVERY MFMAs
-  constexpr int STAGE_FLOATS = NTILE * kWgTileFloats;
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  float* smem = reinterpret_cast<float*>(smem_raw);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int li = lane & 31, kh = lane >> 5;
+// second stage: out[row * ld + col_off + col] = sum_p partial[p][row][col]  (col < k_valid);  bias_out[row] = sum_p bias_partial[p][row]
+struct WgReduce {
+  int part_off, nparts, M, K, k_valid, ld, col_off;
+  int bias_off;          // -1: none
+  int blk_begin;         // first block of the reduce launch for this entry (weights: M*K/256 blocks, then bias: ceil(M/16))
+  int nblk_w;
+  float* out;
+  float* bias_out;
+};
 
-  // contiguous range of 32-sample steps for this workgroup
-  const int per = (a.nchunks + gridDim.x - 1) / gridDim.x;
-  const int c_begin = blockIdx.x * per;
-  const int c_end = c_begin + per < a.nchunks ? c_begin + per : a.nchunks;
+constexpr int kWgMaxJobs = 20;
+constexpr int kWgMaxReduce = 24;
 
-  f32x16 acc[RT][CT];
-#pragma unroll
-  for (int i = 0; i < RT; ++i)
-#pragma unroll
-    for (int j = 0; j < CT; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  float bsum[RT];
-#pragma unroll
-  for (int i = 0; i < RT; ++i) bsum[i] = 0.f;
+struct WgArgs {
+  const float* dplanes;
+  const float* planes;
+  int64_t step_bytes;   // rows * 128
+  int nsteps;           // Np / 32
+  int njobs;
+  float* ws;
+  WgJob job[kWgMaxJobs];
+};
 
-  // DMA lane map: lane = (r, p) = (lane >> 3, lane & 7) fills slot p of row r of an 8-row group with column p ^ r
-  const int64_t lane_off = (int64_t)(lane >> 3) * a.Np * 4 + (((lane & 7) ^ (lane >> 3)) << 4);
-  // one of this wave's NTILE DMA instructions of a step: 8-row group G = 4*d + wave
-  auto dma_one = [&](int chunk, int buf, int d) {
-    int64_t step_off = (int64_t)chunk * 128;
-    asm volatile("" : "+s"(step_off));  // keep the per-group addresses on the scalar unit (no hoisted VGPR pairs)
-    const int G = 4 * d + wave;
-    const float* rows = 8 * G < M ? a.A + (int64_t)(8 * G) * a.Np : a.B + (int64_t)(8 * G - M) * a.Np;
-    const char* g = reinterpret_cast<const char*>(rows) + step_off + lane_off;
-    char* l = reinterpret_cast<char*>(smem + buf * STAGE_FLOATS + G * 256);
+template <int KIND> struct WgTraits;
+template <> struct WgTraits<kWg256x256> { static constexpr int NGA = 64, NGB = 64, NB = 4, NAB = 2, NBB = 2, NSPLIT = 1, NSTAGE = 2, NGX = 0; };
+template <> struct WgTraits<kWg128x128> { static constexpr int NGA = 32, NGB = 32, NB = 4, NAB = 1, NBB = 1, NSPLIT = 4, NSTAGE = 4, NGX = 0; };
+template <> struct WgTraits<kWg256x64>  { static constexpr int NGA = 64, NGB = 16, NB = 2, NAB = 2, NBB = 1, NSPLIT = 2, NSTAGE = 3, NGX = 0; };
+template <> struct WgTraits<kWg128x288> { static constexpr int NGA = 32, NGB = 64, NB = 4, NAB = 1, NBB = 2, NSPLIT = 2, NSTAGE = 2, NGX = 8; };
+
+template <int KIND> constexpr int wg_stage_bytes() { return (WgTraits<KIND>::NGA + WgTraits<KIND>::NGB + WgTraits<KIND>::NGX) * 512; }
+constexpr int kWgLdsBytes = 128 * 1024;   // max over kinds of NSTAGE * stage bytes (2 x 64 KiB, 4 x 32 KiB, 3 x 40 KiB, 2 x 52 KiB)
+
+__host__ __device__ constexpr int wg_nsplit(int kind) { return kind == kWg256x256 ? 1 : kind == kWg128x128 ? 4 : 2; }
+__host__ __device__ constexpr int wg_M(int kind) { return (kind == kWg256x256 || kind == kWg256x64) ? 256 : 128; }
+__host__ __device__ constexpr int wg_K(int kind) { return kind == kWg256x256 ? 256 : kind == kWg128x128 ? 128 : kind == kWg256x64 ? 64 : 256; }
+
+#ifdef AON_WGRAD_KERNELS   // the kernels are compiled once, in aon_train.hip (run_wgrad_plan is the only launcher)
+// workgroup barrier that leaves the N youngest vector-memory operations (LDS-DMA of later stages) in flight.  __syncthreads()
+// would drain them all (its release fence is an s_waitcnt vmcnt(0)); everything this barrier has to order is spelled out:
+// the stage about to be read has landed (vmcnt), this wave's LDS reads of the stage about to be overwritten have returned
+// (lgkmcnt), and the "memory" clobber keeps the compiler from moving LDS accesses across it.
+template <int N>
+__device__ __forceinline__ void stage_barrier() {
+  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
+template <int KIND>
+__device__ __forceinline__ void wgrad_job(const WgArgs& a, const WgJob& J, char* smem) {
+  using T = WgTraits<KIND>;
+  constexpr int NB = T::NB, NSTAGE = T::NSTAGE, NSPLIT = T::NSPLIT;
+  constexpr int STAGE = wg_stage_bytes<KIND>();
+  constexpr int ND = (T::NGA + T::NGB + T::NGX) / 2;   // 1 KiB DMA instructions per step
+  static_assert(ND % 4 == 0 && (T::NGA / 2) % 4 == 0, "DMA instructions split evenly over the four waves, A/B boundary on a multiple of 4");
+  constexpr int D = ND / 4;                            // per wave
+  constexpr int PW = 16 / NSPLIT;                      // sample pairs per wave per step
+  constexpr bool EXT = T::NGX > 0;
+  static_assert(NSTAGE * STAGE <= kWgLdsBytes, "LDS ring");
+  static_assert((NSTAGE - 2) * D <= 63, "vmcnt range");
+
+  const int tid = threadIdx.x;
+  int lane;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i = lane & 31, kh = lane >> 5;
+  const int wb = wave % T::NBB, wa = (wave / T::NBB) % T::NAB, split = wave / (T::NBB * T::NAB);
+
+  // steps of this workgroup
+  const int part_wg = (int)blockIdx.x - J.wg_begin;
+  const int per = (a.nsteps + J.wg_count - 1) / J.wg_count;
+  const int c_begin = part_wg * per;
+  const int c_end = c_begin + per < a.nsteps ? c_begin + per : a.nsteps;
+  const int c_last = c_end - 1;   // (c_end > c_begin is guaranteed by the host: wg_count <= nsteps)
+
+  f32x16 acc[4][NB];
+#pragma unroll
+  for (int ca = 0; ca < 4; ++ca)
+#pragma unroll
+    for (int cb = 0; cb < NB; ++cb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[ca][cb][r] = 0.f;
+  f32x16 accx[EXT ? 4 : 1];
+  if constexpr (EXT) {
+#pragma unroll
+    for (int ca = 0; ca < 4; ++ca)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) accx[ca][r] = 0.f;
+  }
+  float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+
+  // ---- DMA side: instruction d = 4k + wave moves unit rows 2d, 2d+1 of the concatenated [A | B] operand list ----
+  // lane (gl = lane >> 5, slot = lane & 31) fills slot `slot` of unit row 2d + gl with sample slot ^ ((2d + gl) & 15);
+  // (2d) & 15 = 8 (k & 1) + 2 wave, so two per-lane offsets cover every instruction of this wave
+  const unsigned v0 = (unsigned)((lane >> 5) * 512 + (((lane & 31) ^ (lane >> 5)) << 4));
+  const unsigned voff_e = v0 ^ (unsigned)((2 * wave) << 4), voff_o = v0 ^ (unsigned)((8 + 2 * wave) << 4);
+  const char* gA = reinterpret_cast<const char*>(a.dplanes) + (int64_t)J.a_unit * 512;
+  const char* gB = reinterpret_cast<const char*>(a.planes) + (int64_t)J.b_unit * 512;
+  auto dma_step = [&](int c, int stage, int k) {   // k-th instruction of this wave for step c (clamped) into `stage`
+    const int cc = c < c_last ? c : c_last;
+    int64_t soff = (int64_t)cc * a.step_bytes;
+    asm volatile("" : "+s"(soff));
+    const int d = 4 * k + wave;
+    const char* g = (k < T::NGA / 8 ? gA + (int64_t)d * 1024 : gB + (int64_t)(d - T::NGA / 2) * 1024) + soff + ((k & 1) ? voff_o : voff_e);
+    char* l = smem + stage * STAGE + d * 1024;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (lds_void*)l, 16, 0, 0);
   };
-  // fragment of k-step s for this lane: row li of a tile, column 2s + kh -> slot (2s + kh) ^ (li & 7)
-  int frag_off[4];
-#pragma unroll
-  for (int s = 0; s < 4; ++s) frag_off[s] = li * 32 + (((2 * s + kh) ^ (li & 7)) << 2);
 
-  if (c_begin < c_end) {
-#pragma unroll
-    for (int d = 0; d < NTILE; ++d) dma_one(c_begin, 0, d);
-  }
-  __syncthreads();  // vmcnt(0) + barrier: step c_begin is in LDS for every wave
-  for (int c = c_begin; c < c_end; ++c) {
-    const int buf = (c - c_begin) & 1;
-    const bool more = c + 1 < c_end;
-    const float* sa = smem + buf * STAGE_FLOATS + (RT * wave) * kWgTileFloats;
-    const float* sb = smem + buf * STAGE_FLOATS + (M / 32) * kWgTileFloats;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      f32x4 af[RT], bf[CT];
-#pragma unroll
-      for (int i = 0; i < RT; ++i) {
-        af[i] = *reinterpret_cast<const f32x4*>(sa + i * kWgTileFloats + frag_off[s]);
-        bsum[i] += (af[i][0] + af[i][1]) + (af[i][2] + af[i][3]);
-      }
-#pragma unroll
-      for (int j = 0; j < CT; ++j) bf[j] = *reinterpret_cast<const f32x4*>(sb + j * kWgTileFloats + frag_off[s]);
-#pragma unroll
-      for (int cc = 0; cc < 4; ++cc) {
-#pragma unroll
-        for (int i = 0; i < RT; ++i) {
-          // The next step's DMA instructions are issued one per CT MFMAs over the FIRST part of this step.  A wave issues
-          // in order: a burst of all of them in front of the MFMAs stalls the matrix pipe while the memory pipeline
-          // accepts them (-4 %); issued too late, the vmcnt(0) in front of the barrier waits out their HBM latency (-8 %).
-#pragma unroll
-          for (int j = 0; j < CT; ++j) {
-            if (j % DMA_EVERY == 0) {
-              const int d = ((4 * s + cc) * RT + i) * ((CT + DMA_EVERY - 1) / DMA_EVERY) + j / DMA_EVERY;
-              if (d < NTILE && more) dma_one(c + 1, buf ^ 1, d);
-            }
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][cc], bf[j][cc], acc[i][j], 0, 0, 0);
-          }
-        }
-      }
-    }
-    __syncthreads();  // drains this wave's DMA of step c+1 and publishes it; everyone is done reading `buf`
-  }
-  // partial[wg][row][col]; accumulator layout: col = lane&31, row = (r&3) + 8(r>>2) + 4(lane>>5)
-  float* out = a.partial + (int64_t)blockIdx.x * M * K;
-#pragma unroll
-  for (int i = 0; i < RT; ++i)
-#pragma unroll
-    for (int j = 0; j < CT; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = 32 * (RT * wave + i) + (r & 3) + 8 * (r >> 2) + 4 * kh;
-        out[(int64_t)row * K + 32 * j + li] = acc[i][j][r];
-      }
-  if (a.bias_partial) {
-#pragma unroll
-    for (int i = 0; i < RT; ++i) {
-      const float v = bsum[i] + __shfl_xor(bsum[i], 32);
-      if (kh == 0) a.bias_partial[(int64_t)blockIdx.x * M + 32 * (RT * wave + i) + li] = v;
-    }
-  }
-}
-
-// Split-precision form of wgrad_kernel (opt-in "bf16x3" training engine): identical staging, partials and epilogue;
-// the contraction runs on v_mfma_f32_32x32x16_bf16 with both operands split exactly into three bf16 limbs in registers
-// (fragment = 8 consecutive samples of a row = two ds_read_b128) and the six limb products of weight >= 2^-24 accumulated
-// in fp32 -- fp32-class error at 6 x 32 instead of 8 x 64 matrix-pipe cycles per (tile pair, 16 samples).  The B tile of
-// column block j is split while the MFMAs of block j-1 run.
-template <int RT, int CT>
-__global__ void __launch_bounds__(256) wgrad_bf16x3_kernel(WgradArgs a) {
-  constexpr int M = 128 * RT, K = 32 * CT;
-  constexpr int NTILE = (M + K) / 32;
-  constexpr int STAGE_FLOATS = NTILE * kWgTileFloats;
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  float* smem = reinterpret_cast<float*>(smem_raw);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int li = lane & 31, kh = lane >> 5;
-  const int per = (a.nchunks + gridDim.x - 1) / gridDim.x;
-  const int c_begin = blockIdx.x * per;
-  const int c_end = c_begin + per < a.nchunks ? c_begin + per : a.nchunks;
-
-  f32x16 acc[RT][CT];
-#pragma unroll
-  for (int i = 0; i < RT; ++i)
-#pragma unroll
-    for (int j = 0; j < CT; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  float bsum[RT];
-#pragma unroll
-  for (int i = 0; i < RT; ++i) bsum[i] = 0.f;
-
-  const int64_t lane_off = (int64_t)(lane >> 3) * a.Np * 4 + (((lane & 7) ^ (lane >> 3)) << 4);
-  auto dma_one = [&](int chunk, int buf, int d) {
-    int64_t step_off = (int64_t)chunk * 128;
-    asm volatile("" : "+s"(step_off));
-    const int G = 4 * d + wave;
-    const float* rows = 8 * G < M ? a.A + (int64_t)(8 * G) * a.Np : a.B + (int64_t)(8 * G - M) * a.Np;
-    const char* g = reinterpret_cast<const char*>(rows) + step_off + lane_off;
-    char* l = reinterpret_cast<char*>(smem + buf * STAGE_FLOATS + G * 256);
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (lds_void*)l, 16, 0, 0);
+  // ---- fragment side ----
+  // unit (unit row g, sample S) sits at g * 512 + ((S ^ (g & 15)) << 4); S = 2p + kh  ->  (lane part) ^ (p << 5)
+  const unsigned offA = (unsigned)(wa * 32 * 512 + i * 512 + ((kh ^ (i & 15)) << 4));
+  unsigned offB;
+  if constexpr (NB == 4) offB = (unsigned)(T::NGA * 512 + wb * 32 * 512 + i * 512 + ((kh ^ (i & 15)) << 4));
+  else offB = (unsigned)(T::NGA * 512 + (i & 15) * 512 + ((kh ^ (i & 15)) << 4));       // NB == 2: lanes i and i + 16 share a unit
+  const unsigned offX = (unsigned)((T::NGA + T::NGB) * 512 + (i & 7) * 512 + ((kh ^ (i & 7)) << 4));   // extension: 8 unit rows
+  // this wave's pairs of a step: p = split * PW + q;  with the extension, the first PW/2 of them (those of parity wb) also feed it
+  auto pair_of = [&](int q) {
+    if constexpr (EXT) return split * PW + 2 * (q % (PW / 2)) + (q < PW / 2 ? wb : 1 - wb);
+    else return split * PW + q;
   };
-  // fragment of k16-step ks: row li, 16-byte columns 4ks + 2kh and 4ks + 2kh + 1 (8 consecutive samples), swizzled slots
-  int frag_off[2][2];
-#pragma unroll
-  for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-    for (int c = 0; c < 2; ++c) frag_off[ks][c] = li * 32 + (((4 * ks + 2 * kh + c) ^ (li & 7)) << 2);
+  struct Frag { f32x4 a, b, x; };
+  auto read_frag = [&](int stage, int q) {
+    Frag f;
+    const unsigned px = (unsigned)pair_of(q) << 5;
+    const char* sb = smem + stage * STAGE;
+    f.a = *reinterpret_cast<const f32x4*>(sb + (offA ^ px));
+    f.b = *reinterpret_cast<const f32x4*>(sb + (offB ^ px));
+    if constexpr (EXT) { if (q < PW / 2) f.x = *reinterpret_cast<const f32x4*>(sb + (offX ^ px)); }
+    return f;
+  };
 
-  if (c_begin < c_end) {
+  // prologue: NSTAGE - 1 steps in flight, the first one landed
 #pragma unroll
-    for (int d = 0; d < NTILE; ++d) dma_one(c_begin, 0, d);
-  }
-  __syncthreads();
+  for (int s = 0; s < NSTAGE - 1; ++s)
+#pragma unroll
+    for (int k = 0; k < D; ++k) dma_step(c_begin + s, s, k);
+  stage_barrier<(NSTAGE - 2) * D>();
+  int stage = 0;
+  Frag cur = read_frag(0, 0);
   for (int c = c_begin; c < c_end; ++c) {
-    const int buf = (c - c_begin) & 1;
-    const bool more = c + 1 < c_end;
-    const float* sa = smem + buf * STAGE_FLOATS + (RT * wave) * kWgTileFloats;
-    const float* sb = smem + buf * STAGE_FLOATS + (M / 32) * kWgTileFloats;
+    const int stage_dma = stage == 0 ? NSTAGE - 1 : stage - 1;     // (stage + NSTAGE - 1) % NSTAGE: consumed in step c - 1
+    const int stage_next = stage == NSTAGE - 1 ? 0 : stage + 1;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      Limb8 la[RT];
+    for (int q = 0; q < PW; ++q) {
+      Frag nxt;
+      if (q + 1 < PW) {
+        nxt = read_frag(stage, q + 1);
+      } else {
+        // every DMA of step c + NSTAGE - 1 has been issued (below, q <= PW - 2 ... or just above for PW == 1): step c + 1 must
+        // have landed, all waves are done reading `stage` except through registers
+        stage_barrier<(NSTAGE - 2) * D>();
+        nxt = read_frag(stage_next, 0);
+      }
+      // DMA instructions of step c + NSTAGE - 1, spread over the first PW - 1 pairs
+      constexpr int PER = (D + (PW - 1) - 1) / (PW - 1);
 #pragma unroll
-      for (int i = 0; i < RT; ++i) {
-        const f32x4 r0 = *reinterpret_cast<const f32x4*>(sa + i * kWgTileFloats + frag_off[ks][0]);
-        const f32x4 r1 = *reinterpret_cast<const f32x4*>(sa + i * kWgTileFloats + frag_off[ks][1]);
-        bsum[i] += ((r0[0] + r0[1]) + (r0[2] + r0[3])) + ((r1[0] + r1[1]) + (r1[2] + r1[3]));
-        la[i] = split8(r0, r1);
+      for (int u = 0; u < PER; ++u) {
+        const int k = q * PER + u;
+        if (q < PW - 1 && k < D) dma_step(c + NSTAGE - 1, stage_dma, k);
       }
 #pragma unroll
-      for (int j = 0; j < CT; ++j) {
-        const f32x4 r0 = *reinterpret_cast<const f32x4*>(sb + j * kWgTileFloats + frag_off[ks][0]);
-        const f32x4 r1 = *reinterpret_cast<const f32x4*>(sb + j * kWgTileFloats + frag_off[ks][1]);
-        const Limb8 lb = split8(r0, r1);
-        // the next step's DMA instructions, spread over the 2*CT column-block groups of this step (early ones first)
-        constexpr int PER = (NTILE + 2 * CT - 1) / (2 * CT);
+      for (int ca = 0; ca < 4; ++ca) bsum[ca] += cur.a[ca];   // bias gradient = row sums of dZ (written once per A block below)
+      f32x4 be = cur.b;
+      if constexpr (NB == 2) { if (i >= 16) { be[0] = cur.b[2]; be[1] = cur.b[3]; } }
 #pragma unroll
-        for (int q = 0; q < PER; ++q) {
-          const int d = (ks * CT + j) * PER + q;
-          if (d < NTILE && more) dma_one(c + 1, buf ^ 1, d);
+      for (int ca = 0; ca < 4; ++ca)
+#pragma unroll
+        for (int cb = 0; cb < NB; ++cb) acc[ca][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[ca], be[cb], acc[ca][cb], 0, 0, 0);
+      if constexpr (EXT) {
+        if (q < PW / 2) {
+          const int sel = i >> 3;   // column n of the extension block = row 4 (n & 7) + (n >> 3) of its 32
+          const float bx = sel == 0 ? cur.x[0] : sel == 1 ? cur.x[1] : sel == 2 ? cur.x[2] : cur.x[3];
+#pragma unroll
+          for (int ca = 0; ca < 4; ++ca) accx[ca] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[ca], bx, accx[ca], 0, 0, 0);
         }
+      }
+      cur = nxt;
+    }
+    stage = stage_next;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clamped look-ahead DMAs must land before the LDS is released
+
+  // ---- partials ----
+  // accumulator (ca, cb), register r, lane (n, hh): row 4 (32 wa + (r&3) + 8 (r>>2) + 4 hh) + ca, column 128 wb + 4 n + cb
+  constexpr int M = 128 * T::NAB, K = NB == 2 ? 64 : 128 * T::NBB;
+  const int part = part_wg * NSPLIT + split;
+  float* P = a.ws + J.part_off + (int64_t)part * M * K;
 #pragma unroll
-        for (int i = 0; i < RT; ++i) acc[i][j] = mfma_bf16x3(la[i], lb, acc[i][j]);
+  for (int ca = 0; ca < 4; ++ca)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = 128 * wa + 4 * ((r & 3) + 8 * (r >> 2) + 4 * kh) + ca;
+      if constexpr (NB == 4) {
+        f32x4 v; v[0] = acc[ca][0][r]; v[1] = acc[ca][1][r]; v[2] = acc[ca][2][r]; v[3] = acc[ca][3][r];
+        *reinterpret_cast<f32x4*>(P + (int64_t)row * K + 128 * wb + 4 * i) = v;
+      } else {
+        float2 v; v.x = acc[ca][0][r]; v.y = acc[ca][1][r];
+        *reinterpret_cast<float2*>(P + (int64_t)row * K + 4 * (i & 15) + 2 * (i >> 4)) = v;
       }
     }
-    __syncthreads();
-  }
-  float* out = a.partial + (int64_t)blockIdx.x * M * K;
+  if constexpr (EXT) {
+    float* PX = a.ws + J.ext_off + (int64_t)(part_wg * 4 + wave) * 128 * 32;
 #pragma unroll
-  for (int i = 0; i < RT; ++i)
-#pragma unroll
-    for (int j = 0; j < CT; ++j)
+    for (int ca = 0; ca < 4; ++ca)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = 32 * (RT * wave + i) + (r & 3) + 8 * (r >> 2) + 4 * kh;
-        out[(int64_t)row * K + 32 * j + li] = acc[i][j][r];
+        const int row = 4 * ((r & 3) + 8 * (r >> 2) + 4 * kh) + ca;
+        PX[row * 32 + 4 * (i & 7) + (i >> 3)] = accx[ca][r];
       }
-  if (a.bias_partial) {
+  }
+  if (J.bias_off >= 0 && wb == 0) {
+    f32x4 v;
 #pragma unroll
-    for (int i = 0; i < RT; ++i) {
-      const float v = bsum[i] + __shfl_xor(bsum[i], 32);
-      if (kh == 0) a.bias_partial[(int64_t)blockIdx.x * M + 32 * (RT * wave + i) + li] = v;
-    }
+    for (int ca = 0; ca < 4; ++ca) v[ca] = bsum[ca] + __shfl_xor(bsum[ca], 32);
+    if (kh == 0) *reinterpret_cast<f32x4*>(a.ws + J.bias_off + (int64_t)part * M + 128 * wa + 4 * i) = v;
   }
 }
 
-// Second stage (deterministic, no atomics):
-//   out[row*ld + col_off + col] = sum_wg partial[wg][row][col]   for col < k_valid      (blocks [0, M*K/256))
-//   bias_out[row]               = sum_wg bias_partial[wg][row]                           (blocks [M*K/256, +M/16))
-// Weight blocks: 64 float4 columns x 4 waves; wave w sums the partials p = w, w+4, ... with 8 independent 16-byte loads in
-// flight per lane, then the four wave sums are added in wave order through LDS.  64 MB of partials per 256x256 layer are
-// read at HBM/MALL speed instead of through one dependent 4-byte load chain per thread.
-static __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ partial, int nparts, int M, int K, int k_valid,
-                                                                  float* __restrict__ out, int ld, int col_off,
-                                                                  const float* __restrict__ bias_partial, float* __restrict__ bias_out) {
-  __shared__ f32x4 red[4][64];
-  const int nb_w = M * K / 256;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if ((int)blockIdx.x < nb_w) {
-    const int idx = (blockIdx.x * 64 + lane) * 4;  // first of 4 consecutive columns of one row (K is a multiple of 32)
-    const f32x4* src = reinterpret_cast<const f32x4*>(partial + idx);
-    const int64_t stride4 = (int64_t)M * K / 4;
-    f32x4 s = {0.f, 0.f, 0.f, 0.f};
-    int pp = wave;
-    for (; pp + 28 < nparts; pp += 32) {
-      f32x4 v[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = src[(int64_t)(pp + 4 * u) * stride4];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) s += v[u];
-    }
-    for (; pp < nparts; pp += 4) s += src[(int64_t)pp * stride4];
-    red[wave][lane] = s;
-    __syncthreads();
-    if (wave == 0) {
-      const f32x4 t = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
-      const int row = idx / K, col = idx % K;
-#pragma unroll
-      for (int c = 0; c < 4; ++c)
-        if (col + c < k_valid) out[(int64_t)row * ld + col_off + col + c] = t[c];
-    }
-  } else if (bias_out) {
-    // 16 rows per block; thread (r, g) sums partials g, g+16, ...; the 16 group sums are added in group order
-    float* redf = reinterpret_cast<float*>(&red[0][0]);
-    const int r = threadIdx.x & 15, g = threadIdx.x >> 4;
-    const int row = ((int)blockIdx.x - nb_w) * 16 + r;
-    float s = 0.f;
-    if (row < M)
-      for (int pp = g; pp < nparts; pp += 16) s += bias_partial[(int64_t)pp * M + row];
-    redf[g * 16 + r] = s;
-    __syncthreads();
-    if (g == 0 && row < M) {
-      float t = 0.f;
-#pragma unroll
-      for (int q = 0; q < 16; ++q) t += redf[q * 16 + r];
-      bias_out[row] = t;
-    }
+__global__ void __launch_bounds__(256) wgrad_grouped_kernel(WgArgs a) {
+  extern __shared__ __attribute__((aligned(1024))) char wg_smem[];
+  int j = 0;
+#pragma unroll 1
+  for (int t = 1; t < a.njobs; ++t)
+    if ((int)blockIdx.x >= a.job[t].wg_begin) j = t;
+  j = __builtin_amdgcn_readfirstlane(j);
+  const WgJob& J = a.job[j];
+  switch (J.kind) {
+    case kWg256x256: wgrad_job<kWg256x256>(a, J, wg_smem); break;
+    case kWg128x128: wgrad_job<kWg128x128>(a, J, wg_smem); break;
+    case kWg256x64: wgrad_job<kWg256x64>(a, J, wg_smem); break;
+    default: wgrad_job<kWg128x288>(a, J, wg_smem); break;
   }
 }
 
-// Heads: dW_sigma[k] = sum_n d_raw[n].w * H7[k][n];  dW_rgb[c][k] = sum_n d_raw[n][c] * HV[k][n];  d bias = sum_n d_raw[n]
-// grid = (ceil(rows / 8), nseg); a block reduces EIGHT plane rows over one segment of samples -> partial[seg][row][4].  The
-// 16-byte d_raw record of a sample is read once per eight rows (round 1 read it once per row: 16 of every 20 bytes the kernel
-// moved were that re-read; 95 us per launch, 0.95 ms per articulated training step).
-constexpr int kHeadRows = 8;
-static __global__ void __launch_bounds__(256) head_wgrad_kernel(const float* __restrict__ plane, int64_t Np, const float* __restrict__ d_raw,
-                                                         int64_t seg_len, float* __restrict__ partial, int rows) {
-  const int row0 = blockIdx.x * kHeadRows, seg = blockIdx.y;
-  const int nr = rows - row0 < kHeadRows ? rows - row0 : kHeadRows;
-  const int64_t n0 = (int64_t)seg * seg_len;
-  const int64_t n1 = n0 + seg_len < Np ? n0 + seg_len : Np;
-  float s[kHeadRows][4];
+#endif  // AON_WGRAD_KERNELS
+
+// ---------------------------------------------------------------------------------------------
+// heads, biases of the heads, and the first deformation layer: rows of a plane against ONE 16-byte record per sample
+// ---------------------------------------------------------------------------------------------
+//   s[row][c] = sum_n plane[row][n] * vec[n][c]  (c = 0..3),   s[row][4] = sum_n plane[row][n]
+// `vec` is either a sample-major (Np,4) buffer (d_raw, dx') or a unit row of the forward planes (the sample position: the
+// first deformation layer's three input columns); plane == null: the bias sums  s[0][c] = sum_n vec[n][c].
+// A block reduces EIGHT plane rows (two unit rows) over one segment of samples -> partial[seg][row][8].
+struct HeadJob {
+  const float* plane;      // dplanes / planes base, or null
+  int unit;                // first unit row
+  int rows;                // 1 when plane == null
+  const float* vec;        // record of sample n at vec + (n >> 5) * vec_step + (n & 31) * 4
+  int64_t vec_step;        // floats per 32 samples: 128 (sample-major) or rows_total * 32 (a plane unit row)
+  int blk_begin;           // first blockIdx.x of this job (ceil(rows / 8) blocks)
+  int part_off;            // float offset of partial[nseg][rows][8]
+};
+constexpr int kHeadMaxJobs = 8;
+struct HeadArgs {
+  HeadJob job[kHeadMaxJobs];
+  int njobs;
+  int64_t step_floats;     // rows_total * 32
+  int64_t Np, seg_len;
+  float* ws;
+};
+
+#ifdef AON_WGRAD_KERNELS
+__global__ void __launch_bounds__(256) head_wgrad_kernel(HeadArgs a) {
+  int j = 0;
+#pragma unroll 1
+  for (int t = 1; t < a.njobs; ++t)
+    if ((int)blockIdx.x >= a.job[t].blk_begin) j = t;
+  const HeadJob& J = a.job[j];
+  const int row0 = ((int)blockIdx.x - J.blk_begin) * 8, seg = blockIdx.y;
+  const int nr = J.rows - row0 < 8 ? J.rows - row0 : 8;
+  const int64_t n0 = (int64_t)seg * a.seg_len;
+  const int64_t n1 = n0 + a.seg_len < a.Np ? n0 + a.seg_len : a.Np;
+  float s[8][5];
 #pragma unroll
-  for (int r = 0; r < kHeadRows; ++r) s[r][0] = s[r][1] = s[r][2] = s[r][3] = 0.f;
+  for (int r = 0; r < 8; ++r)
+#pragma unroll
+    for (int c = 0; c < 5; ++c) s[r][c] = 0.f;
+  const float* u0 = J.plane ? J.plane + (int64_t)(J.unit + row0 / 4) * 128 : nullptr;
   for (int64_t n = n0 + threadIdx.x; n < n1; n += 256) {
-    const float4 d = reinterpret_cast<const float4*>(d_raw)[n];
+    const int64_t st = n >> 5;
+    const int sl = (int)(n & 31);
+    const f32x4 d = *reinterpret_cast<const f32x4*>(J.vec + st * J.vec_step + sl * 4);
+    f32x4 x0 = {1.f, 0.f, 0.f, 0.f}, x1 = {0.f, 0.f, 0.f, 0.f};
+    if (u0) {
+      x0 = *reinterpret_cast<const f32x4*>(u0 + st * a.step_floats + sl * 4);
+      if (nr > 4) x1 = *reinterpret_cast<const f32x4*>(u0 + 128 + st * a.step_floats + sl * 4);
+    }
 #pragma unroll
-    for (int r = 0; r < kHeadRows; ++r) {
-      const float x = plane ? (r < nr ? plane[(int64_t)(row0 + r) * Np + n] : 0.f) : 1.0f;  // plane == null: bias sums
-      s[r][0] = __builtin_fmaf(x, d.x, s[r][0]); s[r][1] = __builtin_fmaf(x, d.y, s[r][1]);
-      s[r][2] = __builtin_fmaf(x, d.z, s[r][2]); s[r][3] = __builtin_fmaf(x, d.w, s[r][3]);
+    for (int r = 0; r < 8; ++r) {
+      const float x = r < 4 ? x0[r] : x1[r - 4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) s[r][c] = __builtin_fmaf(x, d[c], s[r][c]);
+      s[r][4] += x;
     }
   }
-  __shared__ float red[4][kHeadRows][4];
+  __shared__ float red[4][8][5];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
-  for (int r = 0; r < kHeadRows; ++r)
+  for (int r = 0; r < 8; ++r)
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
+    for (int c = 0; c < 5; ++c) {
       const float v = wsum64(s[r][c]);
       if (lane == 0) red[wv][r][c] = v;
     }
   __syncthreads();
-  if (threadIdx.x < kHeadRows * 4) {
-    const int r = threadIdx.x >> 2, c = threadIdx.x & 3;
-    if (r < nr) partial[((int64_t)seg * rows + row0 + r) * 4 + c] = (red[0][r][c] + red[1][r][c]) + (red[2][r][c] + red[3][r][c]);
+  if (threadIdx.x < 40) {
+    const int r = threadIdx.x / 5, c = threadIdx.x % 5;
+    if (r < nr) a.ws[J.part_off + ((int64_t)seg * J.rows + row0 + r) * 8 + c] = (red[0][r][c] + red[1][r][c]) + (red[2][r][c] + red[3][r][c]);
   }
 }
 
-// out[c*ld_out + row] (channel-major rows of a (C,rows) weight) = sum_seg partial[seg][row][chan_of(c)]
-static __global__ void head_reduce_kernel(const float* __restrict__ partial, int nseg, int rows, int chan0, int nchan, float* __restrict__ out,
-                                   int ld_out) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= rows * nchan) return;
-  const int row = idx / nchan, c = idx % nchan;
-  float s = 0.f;
-  for (int p = 0; p < nseg; ++p) s += partial[((int64_t)p * rows + row) * 4 + chan0 + c];
-  out[(int64_t)c * ld_out + row] = s;
-}
+#endif  // AON_WGRAD_KERNELS
+
+// second stage of the heads: out[c * stride_c + row * stride_r] = sum_seg partial[seg][row][chan0 + c]
+struct HeadOut {
+  int part_off, rows, chan0, nchan, stride_c, stride_r;
+  float* out;
+};
+constexpr int kHeadMaxOut = 12;
 
 // ---------------------------------------------------------------------------------------------
-// host side
+// second stage (deterministic, no atomics), ONE launch for every layer and every head of a level
 // ---------------------------------------------------------------------------------------------
-// Training engine of the weight-gradient GEMMs: 0 = exact fp32 MFMA (default), 1 = split-bf16 ("bf16x3", fp32-equivalent
-// products).  Process-wide (one process drives one GPU from one thread); set through aon_set_train_engine().
-inline int& train_engine() {
-  static int e = 0;
-  return e;
+// Weight blocks: 64 float4 columns x 4 waves; wave w sums the partials p = w, w+4, ... with 8 independent 16-byte loads in
+// flight per lane, then the four wave sums are added in wave order through LDS.
+struct ReduceArgs {
+  WgReduce red[kWgMaxReduce];
+  HeadOut head[kHeadMaxOut];
+  int nred, nhead, nseg;
+  int head_blk_begin;      // blocks >= this one belong to the heads (one block per HeadOut)
+  float* ws;
+};
+
+#ifdef AON_WGRAD_KERNELS
+__global__ void __launch_bounds__(256) wgrad_reduce_kernel(ReduceArgs a) {
+  __shared__ f32x4 red[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if ((int)blockIdx.x >= a.head_blk_begin) {
+    const HeadOut& H = a.head[(int)blockIdx.x - a.head_blk_begin];
+    for (int idx = threadIdx.x; idx < H.rows * H.nchan; idx += 256) {
+      const int row = idx / H.nchan, c = idx % H.nchan;
+      float s = 0.f;
+      for (int p = 0; p < a.nseg; ++p) s += a.ws[H.part_off + ((int64_t)p * H.rows + row) * 8 + H.chan0 + c];
+      H.out[(int64_t)c * H.stride_c + (int64_t)row * H.stride_r] = s;
+    }
+    return;
+  }
+  int e = 0;
+#pragma unroll 1
+  for (int t = 1; t < a.nred; ++t)
+    if ((int)blockIdx.x >= a.red[t].blk_begin) e = t;
+  const WgReduce& R = a.red[e];
+  const int blk = (int)blockIdx.x - R.blk_begin;
+  if (blk < R.nblk_w) {
+    const int idx = (blk * 64 + lane) * 4;  // first of 4 consecutive columns of one row (K is a multiple of 32)
+    if (idx < R.M * R.K) {
+      const f32x4* src = reinterpret_cast<const f32x4*>(a.ws + R.part_off + idx);
+      const int64_t stride4 = (int64_t)R.M * R.K / 4;
+      f32x4 s = {0.f, 0.f, 0.f, 0.f};
+      int pp = wave;
+      for (; pp + 28 < R.nparts; pp += 32) {
+        f32x4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = src[(int64_t)(pp + 4 * u) * stride4];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+      }
+      for (; pp < R.nparts; pp += 4) s += src[(int64_t)pp * stride4];
+      red[wave][lane] = s;
+    }
+    __syncthreads();
+    if (wave == 0 && idx < R.M * R.K) {
+      const f32x4 t = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+      const int row = idx / R.K, col = idx % R.K;
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        if (col + c < R.k_valid) R.out[(int64_t)row * R.ld + R.col_off + col + c] = t[c];
+    }
+  } else if (R.bias_off >= 0) {
+    // 16 rows per block; thread (r, g) sums partials g, g+16, ...; the 16 group sums are added in group order
+    float* redf = reinterpret_cast<float*>(&red[0][0]);
+    const int r = threadIdx.x & 15, g = threadIdx.x >> 4;
+    const int row = (blk - R.nblk_w) * 16 + r;
+    float s = 0.f;
+    if (row < R.M)
+      for (int pp = g; pp < R.nparts; pp += 16) s += a.ws[R.bias_off + (int64_t)pp * R.M + row];
+    redf[g * 16 + r] = s;
+    __syncthreads();
+    if (g == 0 && row < R.M) {
+      float t = 0.f;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) t += redf[q * 16 + r];
+      R.bias_out[row] = t;
+    }
+  }
 }
 
-template <int RT, int CT>
-static hipError_t run_wgrad(const float* A, const float* B, int64_t Np, int nparts, float* partial, float* bias_partial,
-                            float* out, int ld, int col_off, int k_valid, float* bias_out, hipStream_t stream) {
-  constexpr int M = 128 * RT, K = 32 * CT;
-  constexpr int lds = 2 * (M + K) * 32 * 4;
-  static DeviceOnce once_f32, once_bf16;
-  if (hipError_t e = set_max_lds(&wgrad_kernel<RT, CT>, lds, once_f32); e != hipSuccess) return e;
-  if (hipError_t e = set_max_lds(&wgrad_bf16x3_kernel<RT, CT>, lds, once_bf16); e != hipSuccess) return e;
-  WgradArgs a{A, B, Np, (int)(Np / 32), partial, bias_out ? bias_partial : nullptr};
-  if (train_engine() == 1) wgrad_bf16x3_kernel<RT, CT><<<dim3(nparts), dim3(256), lds, stream>>>(a);
-  else wgrad_kernel<RT, CT><<<dim3(nparts), dim3(256), lds, stream>>>(a);
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return e;
-  const int nblocks = M * K / 256 + (bias_out ? (M + 15) / 16 : 0);
-  wgrad_reduce_kernel<<<dim3(nblocks), dim3(256), 0, stream>>>(partial, nparts, M, K, k_valid, out, ld, col_off, bias_partial, bias_out);
-  return hipGetLastError();
+#endif  // AON_WGRAD_KERNELS
+
+// ---------------------------------------------------------------------------------------------
+// host side: the plan of one level
+// ---------------------------------------------------------------------------------------------
+struct WgLayerDesc {   // one nn.Linear weight (or a column block of one)
+  int kind;
+  int a_row, b_row;    // first plane rows of dZ (gradient planes) and of the layer input (forward planes)
+  float* out; int ld, col_off, k_valid;
+  float* bias_out;     // or null
+  int x_k_valid;       // kWg128x288: valid columns of the extension (written at col_off + 256)
+};
+
+// relative cost of one step of a job (matrix-pipe cycles of the busiest wave; the 128-wide kinds are bound by their operand
+// traffic per flop as much as by the pipe).  Tuned on MI355X, tools/kernel_bench.py --wgrad-kinds.
+inline double wg_cost(int kind) {
+  switch (kind) {
+    case kWg256x256: return 16384.0;
+    case kWg128x128: return 4096.0 * 1.15;
+    case kWg256x64: return 4096.0 * 1.15;
+    default: return 9216.0 * 1.05;
+  }
+}
+
+struct WgPlan {
+  WgArgs args;
+  ReduceArgs red;
+  int total_wgs, reduce_blocks;
+  int64_t ws_floats;   // workspace floats used by the partials (heads are appended behind by the caller)
+};
+
+// Split the workgroups of one launch (<= cus, all co-resident: ONE round) over the layers in proportion to their cost:
+// the smallest makespan T with sum ceil(cost_l / T) <= cus.
+inline bool wg_make_plan(const WgLayerDesc* layers, int nlayers, const float* planes, const float* dplanes, int rows_total, int64_t Np,
+                         int cus, float* ws, int64_t ws_off, WgPlan& plan) {
+  if (nlayers > kWgMaxJobs || cus < nlayers) return false;
+  const int nsteps = (int)(Np / 32);
+  double lo = 0.0, hi = 0.0;
+  for (int l = 0; l < nlayers; ++l) hi += wg_cost(layers[l].kind);
+  auto count = [&](double T, int* out) {
+    int tot = 0;
+    for (int l = 0; l < nlayers; ++l) {
+      int w = (int)(wg_cost(layers[l].kind) / T);
+      if (w * T < wg_cost(layers[l].kind)) ++w;
+      if (w < 1) w = 1;
+      if (w > nsteps) w = nsteps;
+      if (out) out[l] = w;
+      tot += w;
+    }
+    return tot;
+  };
+  lo = hi / cus * 0.5;   // below the ideal makespan: infeasible
+  for (int it = 0; it < 60; ++it) {
+    const double mid = 0.5 * (lo + hi);
+    if (count(mid, nullptr) <= cus) hi = mid; else lo = mid;
+  }
+  int wgs[kWgMaxJobs];
+  plan.total_wgs = count(hi, wgs);
+  if (plan.total_wgs > cus) return false;
+  WgArgs& A = plan.args;
+  A.dplanes = dplanes; A.planes = planes; A.step_bytes = (int64_t)rows_total * 128; A.nsteps = nsteps; A.njobs = nlayers; A.ws = ws;
+  ReduceArgs& R = plan.red;
+  R.nred = 0; R.ws = ws;
+  int64_t off = ws_off;
+  int wg = 0, blk = 0;
+  for (int l = 0; l < nlayers; ++l) {
+    const WgLayerDesc& L = layers[l];
+    WgJob& J = A.job[l];
+    const int M = wg_M(L.kind), K = wg_K(L.kind), nsplit = wg_nsplit(L.kind);
+    J.a_unit = L.a_row / 4; J.b_unit = L.b_row / 4; J.kind = L.kind; J.wg_begin = wg; J.wg_count = wgs[l];
+    // steps per workgroup are ceil(nsteps / count): trailing workgroups of a short range would start past the end -- shrink
+    {
+      const int per = (nsteps + J.wg_count - 1) / J.wg_count;
+      J.wg_count = (nsteps + per - 1) / per;
+    }
+    wg += J.wg_count;
+    const int nparts = J.wg_count * nsplit;
+    J.part_off = (int)off; off += (int64_t)nparts * M * K;
+    J.bias_off = -1; J.ext_off = -1;
+    if (L.bias_out) { J.bias_off = (int)off; off += (int64_t)nparts * M; }
+    if (R.nred >= kWgMaxReduce) return false;
+    WgReduce& E = R.red[R.nred++];
+    E.part_off = J.part_off; E.nparts = nparts; E.M = M; E.K = K; E.k_valid = L.k_valid; E.ld = L.ld; E.col_off = L.col_off;
+    E.bias_off = J.bias_off; E.out = L.out; E.bias_out = L.bias_out;
+    E.blk_begin = blk; E.nblk_w = (M * K / 4 + 63) / 64; blk += E.nblk_w + (L.bias_out ? (M + 15) / 16 : 0);
+    if (L.kind == kWg128x288) {
+      J.ext_off = (int)off; off += (int64_t)J.wg_count * 4 * 128 * 32;
+      if (R.nred >= kWgMaxReduce) return false;
+      WgReduce& X = R.red[R.nred++];
+      X.part_off = J.ext_off; X.nparts = J.wg_count * 4; X.M = 128; X.K = 32; X.k_valid = L.x_k_valid; X.ld = L.ld; X.col_off = L.col_off + 256;
+      X.bias_off = -1; X.out = L.out; X.bias_out = nullptr;
+      X.blk_begin = blk; X.nblk_w = (128 * 32 / 4 + 63) / 64; blk += X.nblk_w;
+    }
+  }
+  plan.total_wgs = wg;
+  plan.reduce_blocks = blk;
+  plan.ws_floats = off;
+  return off < (int64_t)1 << 31;
 }
 
 inline int64_t wgrad_workspace_bytes_impl() {
-  // per-workgroup partial of the largest block (256 x 256) + bias partials + head partials, for up to 256 workgroups
-  return (int64_t)256 * (256 * 256 + 256) * 4 + (int64_t)256 * 257 * 4 * 4 + 4096;
+  // one 256 x 256 partial per workgroup of a 256-CU launch at most, + the four-way partials of the narrow layers, bias
+  // partials, the extension blocks and the head partials: 80 MiB covers every plan wg_make_plan can produce for <= 304 CUs
+  return (int64_t)80 << 20;
 }
 
-
-// workspace carve shared by both networks
-struct WgradWs {
-  float* partial;       // 256 x (256 x 256)
-  float* bias_partial;  // 256 x 256
-  float* head_partial;  // 256 segments x 257 rows x 4
-};
-inline WgradWs carve_wgrad_ws(float* ws) {
-  WgradWs w;
-  w.partial = ws;
-  w.bias_partial = ws + (int64_t)256 * 256 * 256;
-  w.head_partial = w.bias_partial + (int64_t)256 * 256;
-  return w;
-}
-
-// rows x 4-channel reductions of a plane against a sample-major (Np,4) gradient buffer (heads, biases)
+// rows x 4-channel reductions of a plane against a 16-byte record per sample (heads, biases)
 inline void head_segments(int64_t Np, int& nseg, int64_t& seg_len) {
   nseg = (int)((Np + 16383) / 16384);
   if (nseg > 256) nseg = 256;
-  seg_len = ((Np + nseg - 1) / nseg + 3) / 4 * 4;
+  seg_len = ((Np + nseg - 1) / nseg + 31) / 32 * 32;
   nseg = (int)((Np + seg_len - 1) / seg_len);
+}
+
+struct HeadDesc {
+  const float* plane; int row; int rows;   // plane == null: record sums only (rows = 1)
+  const float* vec; int64_t vec_step;
+};
+
+// builds the head launch; returns the grid's x extent; `outs` are appended to the reduce launch by the caller
+inline int head_make_plan(const HeadDesc* heads, int nheads, int rows_total, int64_t Np, float* ws, int64_t& ws_off, HeadArgs& H, int* part_offs) {
+  int nseg; int64_t seg_len;
+  head_segments(Np, nseg, seg_len);
+  H.njobs = nheads; H.step_floats = (int64_t)rows_total * 32; H.Np = Np; H.seg_len = seg_len; H.ws = ws;
+  int blk = 0;
+  for (int j = 0; j < nheads; ++j) {
+    HeadJob& J = H.job[j];
+    J.plane = heads[j].plane; J.unit = heads[j].row / 4; J.rows = heads[j].rows; J.vec = heads[j].vec; J.vec_step = heads[j].vec_step;
+    J.blk_begin = blk; blk += (heads[j].rows + 7) / 8;
+    J.part_off = (int)ws_off; part_offs[j] = J.part_off;
+    ws_off += (int64_t)nseg * heads[j].rows * 8;
+  }
+  return blk;
 }
 
 }  // namespace aon

@@ -55,8 +55,7 @@ class NeRFMLP(nn.Module):
     # that mutates parameters without bumping `p._version` is seen exactly as nn.Linear would see it.  `fresh=True`
     # (training) writes into a new buffer, because autograd saves the stream for backward and a later forward must not
     # overwrite what an earlier graph still needs; inference reuses one buffer per stream kind (stream-ordered).
-    _PACKERS = {"fwd": "pack_vanilla_mlp", "bwd": "pack_vanilla_mlp_bwd", "fwd_bf16x3": "pack_vanilla_mlp_bf16x3",
-                "bwd_bf16x3": "pack_vanilla_mlp_bwd_bf16x3"}
+    _PACKERS = {"fwd": "pack_vanilla_mlp", "bwd": "pack_vanilla_mlp_bwd"}
 
     def _pack(self, kind: str, fresh: bool) -> torch.Tensor:
         params = dict(self.named_parameters())
@@ -76,14 +75,6 @@ class NeRFMLP(nn.Module):
     def packed_bwd(self, fresh: bool = False) -> torch.Tensor:
         """Transposed weight stream for the backward data chain (training only)."""
         return self._pack("bwd", fresh)
-
-    def packed_bf16x3(self, fresh: bool = False) -> torch.Tensor:
-        """Three-limb bf16 weight stream of the opt-in split-bf16 engine."""
-        return self._pack("fwd_bf16x3", fresh)
-
-    def packed_bwd_bf16x3(self, fresh: bool = False) -> torch.Tensor:
-        """Transposed three-limb bf16 stream of the bf16x3 backward chain."""
-        return self._pack("bwd_bf16x3", fresh)
 
     def ordered_params(self):
         params = dict(self.named_parameters())
@@ -117,8 +108,6 @@ class NeRF(nn.Module):
         self.sigma_activation = nn.ReLU()
         self.coarse_mlp = NeRFMLP(min_deg_point, max_deg_point, deg_view)
         self.fine_mlp = NeRFMLP(min_deg_point, max_deg_point, deg_view)
-        # inference engine: "fp32" = exact fp32 MFMA (default); "bf16x3" = fp32-equivalent split-bf16 (opt-in, 2x+ faster)
-        self.engine = "fp32"
 
     def forward(self, rays, randomized, white_bkgd, near, far, t_rand=None, u=None):
         rays_o = rays["rays_o"]
@@ -135,24 +124,15 @@ class NeRF(nn.Module):
             if n == 0:
                 raise ValueError("empty ray batch in training mode")
             mlps = [self.coarse_mlp, self.fine_mlp][: self.num_levels]
-            if ops.get_train_engine() == "bf16x3":   # opt-in: split-bf16 training forward + weight gradients
-                packs = [(m.packed(True), None, m.packed_bf16x3(True), m.packed_bwd_bf16x3(True)) for m in mlps]
-            else:
-                packs = [(m.packed(True), m.packed_bwd(True)) for m in mlps]
+            packs = [(m.packed(True), m.packed_bwd(True)) for m in mlps]
             params = [p for m in mlps for p in m.ordered_params()]
             flat = RenderVanilla.apply(rays_o, rays["rays_d"], rays["viewdirs"], float(near), float(far), bool(white_bkgd),
                                        self.num_levels, t_rand, u, packs, *params)
             return [tuple(flat[3 * i: 3 * i + 3]) for i in range(self.num_levels)]
-        if self.engine == "bf16x3":
-            coarse = self.coarse_mlp.packed_bf16x3()
-            fine = self.fine_mlp.packed_bf16x3() if self.num_levels == 2 else None
-        elif self.engine == "fp32":
-            coarse = self.coarse_mlp.packed()
-            fine = self.fine_mlp.packed() if self.num_levels == 2 else None
-        else:
-            raise ValueError(f"unknown engine {self.engine!r}")
+        coarse = self.coarse_mlp.packed()
+        fine = self.fine_mlp.packed() if self.num_levels == 2 else None
         outs = ops.render_fwd(coarse, fine, rays_o, rays["rays_d"], rays["viewdirs"], near, far,
-                              white_bkgd, self.num_levels, t_rand, u, engine=self.engine)
+                              white_bkgd, self.num_levels, t_rand, u)
         return [tuple(o) for o in outs]
 
 

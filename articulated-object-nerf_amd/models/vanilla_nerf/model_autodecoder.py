@@ -55,8 +55,7 @@ class NeRFMLP(nn.Module):
         self._small = None
 
     # weight streams are rebuilt from the live parameters on every call (see vanilla NeRFMLP._pack: nothing can go stale)
-    _PACKERS = {"fwd": "pack_art_mlp", "bwd": "pack_art_mlp_bwd", "fwd_bf16x3": "pack_art_mlp_bf16x3",
-                "bwd_bf16x3": "pack_art_mlp_bwd_bf16x3"}
+    _PACKERS = {"fwd": "pack_art_mlp", "bwd": "pack_art_mlp_bwd"}
 
     def _pack(self, kind: str, fresh: bool) -> torch.Tensor:
         params = dict(self.named_parameters())
@@ -74,14 +73,6 @@ class NeRFMLP(nn.Module):
 
     def packed_bwd(self, fresh: bool = False) -> torch.Tensor:
         return self._pack("bwd", fresh)
-
-    def packed_bf16x3(self, fresh: bool = False) -> torch.Tensor:
-        """Three-limb bf16 weight stream of the opt-in split-bf16 engine."""
-        return self._pack("fwd_bf16x3", fresh)
-
-    def packed_bwd_bf16x3(self, fresh: bool = False) -> torch.Tensor:
-        """Transposed three-limb bf16 stream of the bf16x3 backward chain."""
-        return self._pack("bwd_bf16x3", fresh)
 
     def ordered_params(self):
         params = dict(self.named_parameters())
@@ -122,8 +113,6 @@ class NeRF_AE_Art(nn.Module):
         self.sigma_activation = nn.Softplus()
         self.coarse_mlp = NeRFMLP(min_deg_point, max_deg_point, deg_view)
         self.fine_mlp = NeRFMLP(min_deg_point, max_deg_point, deg_view)
-        # inference engine: "fp32" = exact fp32 MFMA (default); "bf16x3" = fp32-equivalent split-bf16 (opt-in)
-        self.engine = "fp32"
 
     def forward(self, rays, randomized, white_bkgd, near, far, latents, train=True, t_rand=None, u=None):
         rays_o = rays["rays_o"]
@@ -143,22 +132,17 @@ class NeRF_AE_Art(nn.Module):
             packs = []
             for mlp in mlps:
                 small = ops.art_prepare(dict(mlp.named_parameters()), latents)
-                if ops.get_train_engine() == "bf16x3":   # opt-in: split-bf16 training forward (+ weight gradients)
-                    packs.append((None, small, None, mlp.packed_bf16x3(True), mlp.packed_bwd_bf16x3(True)))
-                else:
-                    packs.append((mlp.packed(True), small, mlp.packed_bwd(True)))
+                packs.append((mlp.packed(True), small, mlp.packed_bwd(True)))
             params = [p for mlp in mlps for p in mlp.ordered_params()]
             flat = RenderArticulated.apply(rays_o, rays["rays_d"], rays["viewdirs"], float(near), float(far), bool(white_bkgd),
                                            self.num_levels, t_rand, u, packs, latents["density"], latents["color"],
                                            latents["articulation"], *params)
             return [tuple(flat[3 * i: 3 * i + 3]) for i in range(self.num_levels)]
         two = self.num_levels == 2
-        bf = getattr(self, "engine", "fp32") == "bf16x3"   # opt-in split-bf16 inference engine (fp32-equivalent products)
-        pc = self.coarse_mlp.packed_bf16x3() if bf else self.coarse_mlp.packed()
-        pf = (self.fine_mlp.packed_bf16x3() if bf else self.fine_mlp.packed()) if two else None
+        pc = self.coarse_mlp.packed()
+        pf = self.fine_mlp.packed() if two else None
         outs = ops.art_render_fwd(pc, self.coarse_mlp.prepared(latents), pf, self.fine_mlp.prepared(latents) if two else None,
-                                  rays_o, rays["rays_d"], rays["viewdirs"], near, far, white_bkgd, self.num_levels, t_rand, u,
-                                  engine="bf16x3" if bf else "fp32")
+                                  rays_o, rays["rays_d"], rays["viewdirs"], near, far, white_bkgd, self.num_levels, t_rand, u)
         return [tuple(o) for o in outs]
 
 

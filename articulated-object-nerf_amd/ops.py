@@ -161,42 +161,6 @@ def pack_vanilla_mlp(params: dict, out: torch.Tensor | None = None) -> torch.Ten
     return out
 
 
-def set_train_engine(engine: str) -> None:
-    """Engine of the training-side GEMM kernels: "fp32" (exact fp32 MFMA, default) or "bf16x3" (split-bf16, fp32-equivalent
-    products; currently the weight-gradient kernels).  Process-wide."""
-    check(lib.aon_set_train_engine({"fp32": 0, "bf16x3": 1}[engine]), "aon_set_train_engine")
-
-
-def get_train_engine() -> str:
-    return ("fp32", "bf16x3")[int(lib.aon_get_train_engine())]
-
-
-def pack_vanilla_mlp_bf16x3(params: dict, out: torch.Tensor | None = None) -> torch.Tensor:
-    """Packed three-limb bf16 weight stream of the opt-in split-bf16 engine (re-pack when the parameters change)."""
-    tensors = []
-    for name in VANILLA_PARAM_ORDER:
-        t = _f32(params[name].detach(), name)
-        if tuple(t.shape) != VANILLA_PARAM_SHAPES[name]:
-            raise ValueError(f"{name}: shape {tuple(t.shape)} != {VANILLA_PARAM_SHAPES[name]}")
-        tensors.append(t)
-    dev = tensors[0].device
-    if out is None:
-        out = torch.empty(int(lib.aon_bf16x3_packed_bytes()), dtype=torch.uint8, device=dev)
-    arr = (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
-    with torch.cuda.device(dev):
-        check(lib.aon_pack_vanilla_mlp_bf16x3(arr, _ptr(out), _stream()), "aon_pack_vanilla_mlp_bf16x3")
-    return out
-
-
-def mlp_fwd_bf16x3(packed, rays_o, rays_d, viewdirs, t_vals):
-    o, d, v, t = _f32(rays_o, "rays_o"), _f32(rays_d, "rays_d"), _f32(viewdirs, "viewdirs"), _f32(t_vals, "t_vals")
-    n, S = t.shape
-    raw = torch.empty((n, S, 4), dtype=torch.float32, device=t.device)
-    with torch.cuda.device(t.device):
-        check(lib.aon_mlp_fwd_bf16x3(_ptr(packed), _ptr(o), _ptr(d), _ptr(v), _ptr(t), n, S, _ptr(raw), _stream()), "aon_mlp_fwd_bf16x3")
-    return raw
-
-
 def mlp_fwd(packed, rays_o, rays_d, viewdirs, t_vals):
     """cast_rays + pos_enc + NeRFMLP.forward fused.  Returns raw (n,S,4) = (raw_rgb, raw_density)."""
     o, d, v, t = _f32(rays_o, "rays_o"), _f32(rays_d, "rays_d"), _f32(viewdirs, "viewdirs"), _f32(t_vals, "t_vals")
@@ -347,10 +311,8 @@ def _workspace(device, n_rays: int) -> torch.Tensor:
     return ws
 
 
-def render_fwd(packed_coarse, packed_fine, rays_o, rays_d, viewdirs, near, far, white_bkgd, num_levels=2, t_rand=None, u=None,
-               engine: str = "fp32"):
-    """NeRF.forward: returns [(rgb, acc, depth)_coarse, (rgb, acc, depth)_fine] (fine omitted if num_levels == 1).
-    engine "fp32" (exact fp32 MFMA, default) or "bf16x3" (split-bf16, packed streams from pack_vanilla_mlp_bf16x3)."""
+def render_fwd(packed_coarse, packed_fine, rays_o, rays_d, viewdirs, near, far, white_bkgd, num_levels=2, t_rand=None, u=None):
+    """NeRF.forward: returns [(rgb, acc, depth)_coarse, (rgb, acc, depth)_fine] (fine omitted if num_levels == 1)."""
     o, d, v = _f32(rays_o, "rays_o"), _f32(rays_d, "rays_d"), _f32(viewdirs, "viewdirs")
     n, dev = o.shape[0], o.device
     tr = None if t_rand is None else _f32(t_rand, "t_rand")
@@ -363,9 +325,8 @@ def render_fwd(packed_coarse, packed_fine, rays_o, rays_d, viewdirs, near, far, 
                      torch.empty((n,), dtype=torch.float32, device=dev)))
     fine = outs[1] if num_levels == 2 else (None, None, None)
     ws = _workspace(dev, n)
-    fn = {"fp32": lib.aon_render_fwd, "bf16x3": lib.aon_render_fwd_bf16x3}[engine]
     with torch.cuda.device(dev):
-        check(fn(_ptr(packed_coarse), _ptr(packed_fine), _ptr(o), _ptr(d), _ptr(v), n, float(near), float(far),
+        check(lib.aon_render_fwd(_ptr(packed_coarse), _ptr(packed_fine), _ptr(o), _ptr(d), _ptr(v), n, float(near), float(far),
                                  int(bool(white_bkgd)), num_levels, _ptr(tr), _ptr(uu), us,
                                  _ptr(outs[0][0]), _ptr(outs[0][1]), _ptr(outs[0][2]), _ptr(fine[0]), _ptr(fine[1]), _ptr(fine[2]),
                                  _ptr(ws), ws.numel(), _stream()), "aon_render_fwd")
@@ -420,27 +381,6 @@ def pack_art_mlp(params: dict, out: torch.Tensor | None = None) -> torch.Tensor:
     return out
 
 
-def pack_art_mlp_bf16x3(params: dict, out: torch.Tensor | None = None) -> torch.Tensor:
-    """Three-limb bf16 weight stream of one articulated NeRFMLP for the opt-in split-bf16 engine."""
-    tensors, arr = _art_param_array(params)
-    dev = tensors[0].device
-    if out is None:
-        out = torch.empty(int(lib.aon_art_bf16x3_packed_bytes()), dtype=torch.uint8, device=dev)
-    with torch.cuda.device(dev):
-        check(lib.aon_pack_art_mlp_bf16x3(arr, _ptr(out), _stream()), "aon_pack_art_mlp_bf16x3")
-    return out
-
-
-def art_mlp_fwd_bf16x3(packed_bf, small, rays_o, rays_d, viewdirs, t_vals):
-    o, d, v, t = _f32(rays_o, "rays_o"), _f32(rays_d, "rays_d"), _f32(viewdirs, "viewdirs"), _f32(t_vals, "t_vals")
-    n, S = t.shape
-    raw = torch.empty((n, S, 4), dtype=torch.float32, device=t.device)
-    with torch.cuda.device(t.device):
-        check(lib.aon_art_mlp_fwd_bf16x3(_ptr(packed_bf), _ptr(small), _ptr(o), _ptr(d), _ptr(v), _ptr(t), n, S, _ptr(raw), _stream()),
-              "aon_art_mlp_fwd_bf16x3")
-    return raw
-
-
 def _latent(latents: dict, key: str, width: int) -> torch.Tensor:
     t = _f32(latents[key].detach(), f"latents[{key!r}]").reshape(-1)
     if t.numel() != width:
@@ -484,9 +424,8 @@ def art_mlp_fwd_pos(packed, small, pos, viewdirs_enc):
 
 
 def art_render_fwd(packed_c, small_c, packed_f, small_f, rays_o, rays_d, viewdirs, near, far, white_bkgd, num_levels=2,
-                   t_rand=None, u=None, engine: str = "fp32"):
-    """NeRF_AE_Art.forward: [(rgb, acc, depth)_coarse, (rgb, acc, depth)_fine].  engine "bf16x3": the packed streams come
-    from pack_art_mlp_bf16x3 (the small blocks of art_prepare are shared)."""
+                   t_rand=None, u=None):
+    """NeRF_AE_Art.forward: [(rgb, acc, depth)_coarse, (rgb, acc, depth)_fine]."""
     o, d, v = _f32(rays_o, "rays_o"), _f32(rays_d, "rays_d"), _f32(viewdirs, "viewdirs")
     n, dev = o.shape[0], o.device
     tr = None if t_rand is None else _f32(t_rand, "t_rand")
@@ -500,8 +439,7 @@ def art_render_fwd(packed_c, small_c, packed_f, small_f, rays_o, rays_d, viewdir
     fine = outs[1] if num_levels == 2 else (None, None, None)
     ws = _workspace(dev, n)
     with torch.cuda.device(dev):
-        fn = {"fp32": lib.aon_art_render_fwd, "bf16x3": lib.aon_art_render_fwd_bf16x3}[engine]
-        check(fn(_ptr(packed_c), _ptr(small_c), _ptr(packed_f), _ptr(small_f), _ptr(o), _ptr(d), _ptr(v), n,
+        check(lib.aon_art_render_fwd(_ptr(packed_c), _ptr(small_c), _ptr(packed_f), _ptr(small_f), _ptr(o), _ptr(d), _ptr(v), n,
                  float(near), float(far), int(bool(white_bkgd)), num_levels, _ptr(tr), _ptr(uu), us,
                  _ptr(outs[0][0]), _ptr(outs[0][1]), _ptr(outs[0][2]), _ptr(fine[0]), _ptr(fine[1]), _ptr(fine[2]),
                  _ptr(ws), ws.numel(), _stream()), "aon_art_render_fwd")
@@ -521,36 +459,40 @@ def pack_vanilla_mlp_bwd(params: dict, out: torch.Tensor | None = None) -> torch
     return out
 
 
-def pack_vanilla_mlp_bwd_bf16x3(params: dict, out: torch.Tensor | None = None) -> torch.Tensor:
-    """Transposed weight stream in three-limb bf16 form for the bf16x3 backward chain (re-pack when the parameters change)."""
-    tensors = [_f32(params[name].detach(), name) for name in VANILLA_PARAM_ORDER]
-    dev = tensors[0].device
-    if out is None:
-        out = torch.empty(int(lib.aon_bwd_bf16x3_packed_bytes()), dtype=torch.uint8, device=dev)
-    arr = (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
-    with torch.cuda.device(dev):
-        check(lib.aon_pack_vanilla_mlp_bwd_bf16x3(arr, _ptr(out), _stream()), "aon_pack_vanilla_mlp_bwd_bf16x3")
-    return out
-
-
 def padded_samples(n_samples: int) -> int:
     return (n_samples + 127) // 128 * 128
 
 
-def mlp_fwd_train(packed, rays_o, rays_d, viewdirs, t_vals, engine: str = "fp32"):
-    """Fused forward that also stores the feature-major activation planes and the ReLU bit masks
-    -> (raw (n,S,4), planes (rows, Np), masks).  engine "bf16x3": `packed` is the stream of pack_vanilla_mlp_bf16x3."""
+# Training planes are STEP-MAJOR (include/aon_hip.h, csrc/aon_mlp_core.h): a tensor of shape (Np / 32, rows / 4, 32, 4) =
+# [step of 32 samples][feature row / 4][sample in step][feature row % 4].
+def _new_planes(rows: int, Np: int, device) -> torch.Tensor:
+    return torch.empty((Np // 32, rows // 4, 32, 4), dtype=torch.float32, device=device)
+
+
+def plane_samples(planes: torch.Tensor) -> int:
+    """Np, the padded sample count of a plane buffer."""
+    return planes.shape[0] * 32
+
+
+def plane_rows_view(planes: torch.Tensor) -> torch.Tensor:
+    """(rows, Np) view-copy of step-major planes: row f, column s = feature row f of sample s (tests, diagnostics)."""
+    nst, ng = planes.shape[0], planes.shape[1]
+    return planes.permute(1, 3, 0, 2).reshape(ng * 4, nst * 32)
+
+
+def mlp_fwd_train(packed, rays_o, rays_d, viewdirs, t_vals):
+    """Fused forward that also stores the step-major activation planes and the ReLU bit masks
+    -> (raw (n,S,4), planes (Np/32, rows/4, 32, 4), masks)."""
     o, d, v, t = _f32(rays_o, "rays_o"), _f32(rays_d, "rays_d"), _f32(viewdirs, "viewdirs"), _f32(t_vals, "t_vals")
     n, S = t.shape
     Np = padded_samples(n * S)
     raw = torch.empty((n, S, 4), dtype=torch.float32, device=t.device)
     # every row the backward consumes is fully written by the kernel (padded columns included); the encoding pad rows
     # (63, and 27..31 of the view block) only ever feed gradient columns that are never emitted -> no zero fill needed
-    planes = torch.empty((int(lib.aon_train_plane_rows()), Np), dtype=torch.float32, device=t.device)
+    planes = _new_planes(int(lib.aon_train_plane_rows()), Np, t.device)
     masks = torch.empty(int(lib.aon_train_mask_bytes(Np)), dtype=torch.uint8, device=t.device)
     with torch.cuda.device(t.device):
-        fn = lib.aon_mlp_fwd_train if engine == "fp32" else lib.aon_mlp_fwd_train_bf16x3
-        check(fn(_ptr(packed), _ptr(o), _ptr(d), _ptr(v), _ptr(t), n, S, _ptr(raw), _ptr(planes), _ptr(masks), _stream()), "aon_mlp_fwd_train")
+        check(lib.aon_mlp_fwd_train(_ptr(packed), _ptr(o), _ptr(d), _ptr(v), _ptr(t), n, S, _ptr(raw), _ptr(planes), _ptr(masks), _stream()), "aon_mlp_fwd_train")
     return raw, planes, masks
 
 
@@ -567,14 +509,12 @@ def composite_bwd(raw, t_vals, dirs, g_rgb, g_acc, g_depth, white_bkgd, act, Np:
     return d_raw
 
 
-def mlp_bwd_chain(packed_bwd, packed_fwd, d_raw, masks, plane_shape, engine: str = "fp32"):
-    """-> dplanes (rows, Np): pre-activation gradient planes (rows of the encodings are not written / not used).
-    engine "bf16x3": `packed_bwd` is the stream of pack_vanilla_mlp_bwd_bf16x3 (packed_fwd stays the fp32 forward stream)."""
-    dplanes = torch.empty(plane_shape, dtype=torch.float32, device=d_raw.device)
-    Np = plane_shape[1]
-    fn = lib.aon_mlp_bwd_chain if engine == "fp32" else lib.aon_mlp_bwd_chain_bf16x3
+def mlp_bwd_chain(packed_bwd, packed_fwd, d_raw, masks, plane_shape):
+    """-> dplanes (layout of the forward planes): pre-activation gradient planes (rows of the encodings are not written / not used)."""
+    dplanes = torch.empty(tuple(plane_shape), dtype=torch.float32, device=d_raw.device)
+    Np = plane_shape[0] * 32
     with torch.cuda.device(d_raw.device):
-        check(fn(_ptr(packed_bwd), _ptr(packed_fwd), _ptr(d_raw), _ptr(masks), _ptr(dplanes), Np, _stream()), "aon_mlp_bwd_chain")
+        check(lib.aon_mlp_bwd_chain(_ptr(packed_bwd), _ptr(packed_fwd), _ptr(d_raw), _ptr(masks), _ptr(dplanes), Np, _stream()), "aon_mlp_bwd_chain")
     return dplanes
 
 
@@ -592,7 +532,7 @@ def vanilla_wgrad(planes, dplanes, d_raw):
     grads = {name: torch.empty(VANILLA_PARAM_SHAPES[name], dtype=torch.float32, device=dev) for name in VANILLA_PARAM_ORDER}
     arr = (C.c_void_p * len(VANILLA_PARAM_ORDER))(*[grads[n].data_ptr() for n in VANILLA_PARAM_ORDER])
     with torch.cuda.device(dev):
-        check(lib.aon_vanilla_wgrad(_ptr(planes), _ptr(dplanes), _ptr(d_raw), planes.shape[1], arr, _ptr(ws), ws.numel(), _stream()),
+        check(lib.aon_vanilla_wgrad(_ptr(planes), _ptr(dplanes), _ptr(d_raw), plane_samples(planes), arr, _ptr(ws), ws.numel(), _stream()),
               "aon_vanilla_wgrad")
     return grads
 
@@ -608,39 +548,26 @@ def pack_art_mlp_bwd(params: dict, out: torch.Tensor | None = None) -> torch.Ten
     return out
 
 
-def art_mlp_fwd_train(packed, small, rays_o, rays_d, viewdirs, t_vals, engine: str = "fp32"):
+def art_mlp_fwd_train(packed, small, rays_o, rays_d, viewdirs, t_vals):
     o, d, v, t = _f32(rays_o, "rays_o"), _f32(rays_d, "rays_d"), _f32(viewdirs, "viewdirs"), _f32(t_vals, "t_vals")
     n, S = t.shape
     Np = padded_samples(n * S)
     raw = torch.empty((n, S, 4), dtype=torch.float32, device=t.device)
-    planes = torch.empty((int(lib.aon_art_train_plane_rows()), Np), dtype=torch.float32, device=t.device)
+    planes = _new_planes(int(lib.aon_art_train_plane_rows()), Np, t.device)
     masks = torch.empty(int(lib.aon_art_train_mask_bytes(Np)), dtype=torch.uint8, device=t.device)
     with torch.cuda.device(t.device):
-        fn = lib.aon_art_mlp_fwd_train if engine == "fp32" else lib.aon_art_mlp_fwd_train_bf16x3   # bf16x3: packed = pack_art_mlp_bf16x3
-        check(fn(_ptr(packed), _ptr(small), _ptr(o), _ptr(d), _ptr(v), _ptr(t), n, S, _ptr(raw), _ptr(planes), _ptr(masks), _stream()),
+        check(lib.aon_art_mlp_fwd_train(_ptr(packed), _ptr(small), _ptr(o), _ptr(d), _ptr(v), _ptr(t), n, S, _ptr(raw), _ptr(planes), _ptr(masks), _stream()),
               "aon_art_mlp_fwd_train")
     return raw, planes, masks
 
 
-def pack_art_mlp_bwd_bf16x3(params: dict, out: torch.Tensor | None = None) -> torch.Tensor:
-    """Transposed three-limb bf16 stream of the articulated bf16x3 backward chain."""
-    tensors, arr = _art_param_array(params)
-    dev = tensors[0].device
-    if out is None:
-        out = torch.empty(int(lib.aon_art_bwd_bf16x3_packed_bytes()), dtype=torch.uint8, device=dev)
-    with torch.cuda.device(dev):
-        check(lib.aon_pack_art_mlp_bwd_bf16x3(arr, _ptr(out), _stream()), "aon_pack_art_mlp_bwd_bf16x3")
-    return out
-
-
-def art_bwd_chain(packed_bwd, small, d_raw, masks, planes, engine: str = "fp32"):
-    """-> (dplanes (rows, Np), dxp (Np,4) = dL/d deformed position).  engine "bf16x3": packed_bwd from pack_art_mlp_bwd_bf16x3."""
+def art_bwd_chain(packed_bwd, small, d_raw, masks, planes):
+    """-> (dplanes (layout of the forward planes), dxp (Np,4) = dL/d deformed position)."""
     dplanes = torch.empty(planes.shape, dtype=torch.float32, device=planes.device)
-    Np = planes.shape[1]
+    Np = plane_samples(planes)
     dxp = torch.empty((Np, 4), dtype=torch.float32, device=planes.device)
     with torch.cuda.device(planes.device):
-        fn = lib.aon_art_bwd_chain if engine == "fp32" else lib.aon_art_bwd_chain_bf16x3
-        check(fn(_ptr(packed_bwd), _ptr(small), _ptr(d_raw), _ptr(masks), _ptr(planes), _ptr(dplanes), _ptr(dxp), Np, _stream()),
+        check(lib.aon_art_bwd_chain(_ptr(packed_bwd), _ptr(small), _ptr(d_raw), _ptr(masks), _ptr(planes), _ptr(dplanes), _ptr(dxp), Np, _stream()),
               "aon_art_bwd_chain")
     return dplanes, dxp
 
@@ -659,7 +586,7 @@ def art_wgrad(planes, dplanes, d_raw, dxp, params: dict, latents: dict):
     garr = (C.c_void_p * len(ART_PARAM_ORDER))(*[grads[n].data_ptr() for n in ART_PARAM_ORDER])
     g_lat = {"density": torch.empty(128, device=dev), "color": torch.empty(128, device=dev), "articulation": torch.empty(32, device=dev)}
     with torch.cuda.device(dev):
-        check(lib.aon_art_wgrad(_ptr(planes), _ptr(dplanes), _ptr(d_raw), _ptr(dxp), planes.shape[1], parr, _ptr(shape), _ptr(app),
+        check(lib.aon_art_wgrad(_ptr(planes), _ptr(dplanes), _ptr(d_raw), _ptr(dxp), plane_samples(planes), parr, _ptr(shape), _ptr(app),
                                 _ptr(art), garr, _ptr(g_lat["density"]), _ptr(g_lat["color"]), _ptr(g_lat["articulation"]), _ptr(ws),
                                 ws.numel(), _stream()), "aon_art_wgrad")
     return grads, g_lat

@@ -288,7 +288,7 @@ def train_leg(dev, rank, world, distributed, steps=6, n_rays=4096):
         kernels = {}
         for key, name, mac in (("mlp_fwd", "aon::art_mlp_fwd_kernel<true,true> (training forward: + activation planes, ReLU bits)", ART_MAC_FWD),
                                ("bwd_chain", "aon::art_bwd_chain_kernel (data-gradient chain + gradient planes)", ART_MAC_BWD_CHAIN),
-                               ("wgrad", "aon::wgrad_kernel<*> + partial reductions + head / latent gradients (one launch = one level)", ART_MAC_WGRAD)):
+                               ("wgrad", "aon::wgrad_grouped_kernel (all layers of a level in one launch) + heads + second stage + latent outer products", ART_MAC_WGRAD)):
             ms, launches, units = classes[key]
             r = mfma_roofline(name, ms, launches, samples * steps, mac, ART_MAC_LITERAL)   # units are padded samples: price the real ones
             if r is not None:
@@ -309,13 +309,6 @@ def train_leg(dev, rank, world, distributed, steps=6, n_rays=4096):
                             "kernels_measured_on": "a second pass with the two levels' backward serialised on one stream "
                                                    f"({dt_serial * 1e3:.2f} ms per step; the product overlaps them on two streams: ms_per_step)",
                             "traffic": None}}
-        # the opt-in split-bf16 training engine (forward, backward chain and weight gradients), same step
-        ops.set_train_engine("bf16x3")
-        try:
-            dt_b, _, _ = timed()
-            res["bf16x3_engine_ms_per_step"] = dt_b * 1e3
-        finally:
-            ops.set_train_engine("fp32")
         return res
     except Exception as e:  # informational leg: never take the headline down with it
         return {"error": f"{type(e).__name__}: {e}"}
@@ -329,9 +322,7 @@ def main():
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--engine", choices=["fp32", "bf16x3"], default="fp32",
-                    help="MLP arithmetic of the timed region: exact fp32 MFMA (default) or the opt-in fp32-equivalent split-bf16 engine")
-    ap.add_argument("--no-alt", action="store_true", help="skip the extra (untimed-for-`value`) run of the other engine")
+    ap.add_argument("--no-alt", action="store_true", help="(no-op since round 3: the split-bf16 engine was removed; kept for old command lines)")
     ap.add_argument("--sharded-leg", action="store_true", help="(default now) kept for old command lines: the sharded-frame leg always runs")
     ap.add_argument("--no-sharded-leg", action="store_true", help="skip the informational BASELINE config 3 leg (one frame sharded over the ranks + RCCL all-gather)")
     ap.add_argument("--no-train-leg", action="store_true", help="skip the extra (informational) articulated training-step timing")
@@ -360,7 +351,6 @@ def main():
     sd = syn.make_nerf_state_dict(seed=0, density_scale=30.0)
     model = NeRF().to(dev)
     model.load_state_dict(sd)
-    model.engine = args.engine
     # weak scaling: rank r renders its own frame (pose r of a ring around the object)
     c2w = syn.look_at_pose(4.0, 30.0 + 45.0 * rank, 30.0)
     rays_o, viewdirs = get_frame_rays(H, W, syn.focal_from_fovy(H), c2w, device=dev)
@@ -397,33 +387,6 @@ def main():
     if distributed:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = t.item()
-
-    # the other engine, same workload, for information only (never `value`)
-    alt = None
-    if not args.no_alt:
-        other = "bf16x3" if args.engine == "fp32" else "fp32"
-        model.engine = other
-        with torch.no_grad():
-            step()
-            fence()
-            ops.profile_begin()
-            ta = time.perf_counter()
-            for _ in range(args.steps):
-                fine_alt = step()
-            fence()
-            dta = time.perf_counter() - ta
-            a_ms, a_launches, a_samples = ops.profile_end()
-        tt = torch.tensor([dta], dtype=torch.float64, device=dev)
-        if distributed:
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dta = tt.item()
-        mse = torch.mean((fine_alt[0] - fine[0]) ** 2).item()
-        alt = {"engine": other, "value": world * n_rays * args.steps / dta, "unit": "rays/s", "ms_per_step": dta / args.steps * 1e3,
-               "mlp_kernel_tflops_algorithmic": a_samples * FLOP_PER_SAMPLE / (a_ms * 1e-3) / 1e12 if a_ms > 0 else 0.0,
-               "psnr_vs_timed_engine_db": float(-10.0 * torch.log10(torch.tensor(max(mse, 1e-20)))),
-               "note": "bf16x3 = every fp32 product as six bf16 limb products accumulated in fp32 (fp32-class error; "
-                       "passes the parity suite at the fp32 kernel's tolerances); opt-in, not the default"}
-        model.engine = args.engine
 
     # BASELINE config 3 literally (informational, never `value`): ONE 640x480 frame, contiguous ray ranges sharded over the
     # ranks, fine-level pixels all-gathered (RCCL) -- strong scaling of a single frame, where `value` above is weak scaling.
@@ -476,14 +439,13 @@ def main():
         res = {
             "metric": "rays/sec (64c+128f samples)", "value": rays_per_s, "unit": "rays/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.engine == "fp32" else "f32 via 3xbf16 limbs (6 MFMA products, fp32 accumulate)",
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"sapien-single-scene vanilla NeRF full-frame render {W}x{H}, 65 coarse + 193 fine evals/ray, "
                                    f"{n_rays} rays per GPU per step, randomized=False, white_bkgd=True",
                        "rays_per_gpu": n_rays, "evals_per_ray": EVALS_PER_RAY,
                        "exchange": "RCCL all_gather of (rgb,acc,depth)=20 B/ray" if world > 1 else "none"},
-            "roofline": {"bound": "mfma", "kernel": "aon::mlp_fwd_kernel<true> (fused encode+MLP, fp32 MFMA)" if args.engine == "fp32"
-                         else "aon::mlp_fwd_bf16x3_kernel (fused encode+MLP, split-bf16 MFMA; priced against the fp32-matrix peak)",
+            "roofline": {"bound": "mfma", "kernel": "aon::mlp_fwd_kernel<true> (fused encode+MLP, fp32 MFMA)",
                          "achieved": mlp_tflops, "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
                          "frac": mlp_tflops / PEAK_FP32_MATRIX_TFLOPS, "traffic": None,
                          "launches": mlp_launches, "avg_launch_ms": mlp_ms / max(mlp_launches, 1),
@@ -496,8 +458,6 @@ def main():
             res["config1"] = config1
         if art_render is not None:
             res["art_render"] = art_render
-        if alt is not None:
-            res["alt_engine"] = alt
         if sharded is not None:
             res["sharded_frame"] = sharded
         if train is not None:

@@ -38,7 +38,6 @@ def main():
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--val_every", type=int, default=20)
     ap.add_argument("--exp_dir", default="ckpts/demo_autodecoder")
-    ap.add_argument("--train_engine", choices=["fp32", "bf16x3"], default="fp32")
     ap.add_argument("--seed", type=int, default=0, help="torch / numpy / random seed (model init, ray batches, stratified draws)")
     args = ap.parse_args()
     import random as _random
@@ -54,7 +53,6 @@ def main():
         args.root_dir = write_synthetic_multi_scene(args.synthetic, n_instances=2, n_degrees=3, n_views=60, img_wh=tuple(args.img_wh))
     assert args.root_dir, "--root_dir or --synthetic"
     dev = torch.device("cuda:0")
-    ops.set_train_engine(args.train_engine)
     kw = dict(img_wh=tuple(args.img_wh), white_back=True, device=dev)
     train = SapienDatasetMulti(args.root_dir, "train", **kw)
     val = SapienDatasetMulti(args.root_dir, "val", **kw)
@@ -82,7 +80,6 @@ def main():
     outs = [lit.test_step(collate(test[i], dev), i) for i in range(len(test))]
     psnr, psnr_obj = lit.test_epoch_end(outs, test.image_sizes, out_dir=os.path.join(args.exp_dir, "render"))
     print(json.dumps({"test_psnr": psnr["test"], "test_psnr_obj": psnr_obj["test"], "images": len(outs)}))
-    ops.set_train_engine("fp32")
     return log, psnr
 
 

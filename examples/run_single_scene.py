@@ -30,7 +30,6 @@ def main():
     ap.add_argument("--val_every", type=int, default=100)
     ap.add_argument("--exp_dir", default="ckpts/demo")
     ap.add_argument("--resume", default=None)
-    ap.add_argument("--train_engine", choices=["fp32", "bf16x3"], default="fp32")
     ap.add_argument("--seed", type=int, default=0, help="torch / numpy / random seed (model init, ray batches, stratified draws)")
     args = ap.parse_args()
     import random as _random
@@ -46,7 +45,6 @@ def main():
     assert args.root_dir, "--root_dir or --synthetic"
     dev = torch.device("cuda:0")
     from aon_amd import ops
-    ops.set_train_engine(args.train_engine)
     train = SapienDataset(args.root_dir, "train", tuple(args.img_wh), white_back=True, device=dev)
     val = SapienDataset(args.root_dir, "val", tuple(args.img_wh), white_back=True, device=dev)
     test = SapienDataset(args.root_dir, "test", tuple(args.img_wh), white_back=True, eval_inference="render", device=dev)
@@ -79,7 +77,6 @@ def main():
     outs = [lit.test_step({k: v.unsqueeze(0) for k, v in test[i].items()}, i) for i in range(len(test))]
     psnr, psnr_obj = lit.test_epoch_end(outs, test.image_sizes, out_dir=os.path.join(args.exp_dir, "render"))
     print(json.dumps({"test_psnr": psnr["test"], "test_psnr_obj": psnr_obj["test"], "ckpt": os.path.join(args.exp_dir, "last.ckpt")}))
-    ops.set_train_engine("fp32")
     return log, psnr
 
 

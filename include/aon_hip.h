@@ -133,35 +133,6 @@ int aon_render_fwd(const void* packed_coarse, const void* packed_fine, const flo
                    float* depth_c, float* rgb_f, float* acc_f, float* depth_f, void* workspace,
                    int64_t workspace_bytes, void* stream);
 
-/* ---- opt-in "bf16x3" engine for R5/R9 (no reference counterpart; same semantics as aon_mlp_fwd / aon_render_fwd) ----
- * fp32-equivalent arithmetic on the bf16 matrix pipe: every fp32 weight / activation is split exactly into three bf16
- * limbs and each product is evaluated as the six limb products >= 2^-18 of its magnitude, accumulated in fp32
- * (csrc/aon_mlp_bf16.hip).  Needs its own packed stream (aon_bf16x3_packed_bytes()).  The exact-fp32 entry points
- * above remain the default; callers select this engine explicitly. */
-int64_t aon_bf16x3_packed_bytes(void);
-/* Training-side engine switch (process-wide; one process drives one GPU from one thread): 0 = exact fp32 MFMA (default),
- * 1 = "bf16x3" -- the weight-gradient GEMMs of aon_vanilla_wgrad / aon_art_wgrad run on the bf16 matrix pipe with both
- * operands split exactly into three bf16 limbs and six limb products accumulated in fp32 (fp32-class error). */
-int aon_set_train_engine(int engine);
-/* backward data chain on the bf16x3 engine: transposed weight stream in limb form (aon_bwd_bf16x3_packed_bytes()), otherwise the
- * contract of aon_mlp_bwd_chain (packed_fwd = the fp32 forward stream, read for its head weights only) */
-int64_t aon_bwd_bf16x3_packed_bytes(void);
-int aon_pack_vanilla_mlp_bwd_bf16x3(const float* const* params_host, void* packed_bwd, void* stream);
-int aon_mlp_bwd_chain_bf16x3(const void* packed_bwd_bf16x3, const void* packed_fwd, const float* d_raw, const void* masks,
-                             float* dplanes, int64_t Np, void* stream);
-/* aon_mlp_fwd_train on the bf16x3 engine: same planes / masks / raw contract, packed stream from aon_pack_vanilla_mlp_bf16x3 */
-int aon_mlp_fwd_train_bf16x3(const void* packed_bf16x3, const float* rays_o, const float* rays_d, const float* viewdirs,
-                             const float* t_vals, int64_t n_rays, int S, float* raw, float* planes, void* masks, void* stream);
-int aon_get_train_engine(void);
-int aon_pack_vanilla_mlp_bf16x3(const float* const* params_host, void* packed, void* stream);
-int aon_mlp_fwd_bf16x3(const void* packed, const float* rays_o, const float* rays_d, const float* viewdirs,
-                       const float* t_vals, int64_t n_rays, int S, float* raw, void* stream);
-int aon_render_fwd_bf16x3(const void* packed_coarse, const void* packed_fine, const float* rays_o, const float* rays_d,
-                          const float* viewdirs, int64_t n_rays, float near_, float far_, int white_bkgd, int num_levels,
-                          const float* t_rand, const float* u, int64_t u_stride, float* rgb_c, float* acc_c,
-                          float* depth_c, float* rgb_f, float* acc_f, float* depth_f, void* workspace,
-                          int64_t workspace_bytes, void* stream);
-
 /* ---- R10/R11  articulated network: NeRFMLP.forward(pos, condition, latents) (models/vanilla_nerf/
  * model_autodecoder.py:172-239, deformation_mlp=True, enc_after=True) and NeRF_AE_Art.forward (:278-337) ----
  * params: HOST array of 40 DEVICE pointers, order: deformations_linear.{0..3}.{weight,bias}, deformation_layer.{w,b},
@@ -191,16 +162,21 @@ int aon_art_render_fwd(const void* packed_coarse, const void* small_coarse, cons
 
 /* ---- R14  backward of the vanilla path (what autograd does for loss.backward(), model.py:264-273) ----
  * Gradients reach only the MLP parameters (t_samples is detached, helper.py:249).  Per level (S = 65 or 193):
- *   aon_mlp_fwd_train   as aon_mlp_fwd, and additionally stores the layer activations as feature-major planes:
- *                       planes[row * Np + sample], aon_train_plane_rows() rows, Np = 128 * ceil(n*S / 128), and the
+ *   aon_mlp_fwd_train   as aon_mlp_fwd, and additionally stores the layer activations as STEP-MAJOR planes (round 3; rounds 1-2
+ *                       were feature-major): rows = aon_train_plane_rows() feature rows (a multiple of 4), Np = 128 *
+ *                       ceil(n*S / 128) samples, rows * Np floats; feature row f of sample s lives at float offset
+ *                           ((s / 32) * (rows / 4) + f / 4) * 128 + (s % 32) * 4 + f % 4
+ *                       i.e. [step of 32 samples][f / 4][sample in step][f % 4]: a 16-byte unit holds four consecutive
+ *                       feature rows of one sample, the kernels store / fetch whole units (csrc/aon_mlp_core.h); and the
  *                       ReLU decisions of the nine activated layers as bit masks (aon_train_mask_bytes(Np) bytes).
  *   aon_composite_bwd   (g_rgb (n,3), optional g_acc (n,), g_depth (n,)) -> d_raw (n*S,4) = dL/d(raw rgb, raw sigma);
  *                       the caller zero-fills d_raw up to Np rows (padded samples must carry zero gradient).
  *   aon_mlp_bwd_chain   data-gradient chain through the MLP (ReLU derivatives from `masks`); writes the pre-activation
- *                       gradient planes `dplanes` (same shape / row map as `planes`, every column written); needs the
+ *                       gradient planes `dplanes` (same layout / row map as `planes`, every sample written); needs the
  *                       transposed stream of aon_pack_vanilla_mlp_bwd.
  *   aon_vanilla_wgrad   all 24 parameter gradients (order of aon_pack_vanilla_mlp, full nn.Linear shapes, overwritten)
- *                       from planes x dplanes; workspace >= aon_wgrad_workspace_bytes(); deterministic (no atomics). */
+ *                       from planes x dplanes: one grouped launch over all layers + one over the heads + one second stage
+ *                       (csrc/aon_wgrad.h); workspace >= aon_wgrad_workspace_bytes(); deterministic (no atomics). */
 int64_t aon_train_plane_rows(void);
 int64_t aon_train_mask_bytes(int64_t Np);
 int64_t aon_bwd_packed_bytes(void);
@@ -292,28 +268,6 @@ int aon_art_render_bwd(const void* packed_bwd_coarse, const void* small_coarse, 
 int aon_profile_begin(void);
 int aon_profile_end(double* mlp_ms, int64_t* mlp_launches, int64_t* mlp_samples);
 int aon_profile_class(int kernel_class, double* ms, int64_t* launches, int64_t* units);
-
-/* ---- opt-in "bf16x3" engine for the articulated path (R10/R11): same semantics as aon_art_mlp_fwd / aon_art_render_fwd,
- * split-bf16 MFMA with fp32-equivalent products (csrc/aon_mlp_art_bf16.hip); own packed stream, the small block of
- * aon_art_prepare is shared with the fp32 engine. ---- */
-int64_t aon_art_bf16x3_packed_bytes(void);
-int aon_pack_art_mlp_bf16x3(const float* const* params_host, void* packed, void* stream);
-int aon_art_mlp_fwd_bf16x3(const void* packed_bf16x3, const void* small, const float* rays_o, const float* rays_d,
-                           const float* viewdirs, const float* t_vals, int64_t n_rays, int S, float* raw, void* stream);
-/* aon_art_mlp_fwd_train on the bf16x3 engine: same planes / masks / raw contract */
-int aon_art_mlp_fwd_train_bf16x3(const void* packed_bf16x3, const void* small, const float* rays_o, const float* rays_d,
-                                 const float* viewdirs, const float* t_vals, int64_t n_rays, int S, float* raw, float* planes,
-                                 void* masks, void* stream);
-/* aon_art_bwd_chain on the bf16x3 engine: transposed weight stream in limb form, otherwise the same contract */
-int64_t aon_art_bwd_bf16x3_packed_bytes(void);
-int aon_pack_art_mlp_bwd_bf16x3(const float* const* params_host, void* packed_bwd, void* stream);
-int aon_art_bwd_chain_bf16x3(const void* packed_bwd_bf16x3, const void* small, const float* d_raw, const void* masks, const float* planes,
-                             float* dplanes, float* dxp, int64_t Np, void* stream);
-int aon_art_render_fwd_bf16x3(const void* packed_coarse, const void* small_coarse, const void* packed_fine, const void* small_fine,
-                              const float* rays_o, const float* rays_d, const float* viewdirs, int64_t n_rays, float near_, float far_,
-                              int white_bkgd, int num_levels, const float* t_rand, const float* u, int64_t u_stride, float* rgb_c,
-                              float* acc_c, float* depth_c, float* rgb_f, float* acc_f, float* depth_f, void* workspace,
-                              int64_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -21,7 +21,7 @@ o, d, v, tt = (x.to(dev) for x in (rays["rays_o"], rays["rays_d"], rays["viewdir
 raw, planes, masks = ops.art_mlp_fwd_train(packed, small, o, d, v, tt)
 rgb = ops.composite_raw(raw, tt, d, True, ops.ACT_ARTICULATED)[0]
 g_rgb = 2.0 * (rgb - target.to(dev)) / (n * 3)
-d_raw = ops.composite_bwd(raw, tt, d, g_rgb, None, None, True, ops.ACT_ARTICULATED, planes.shape[1])
+d_raw = ops.composite_bwd(raw, tt, d, g_rgb, None, None, True, ops.ACT_ARTICULATED, ops.plane_samples(planes))
 dplanes, dxp = ops.art_bwd_chain(packed_bwd, small, d_raw, masks, planes)
 N = n * S
 dt = torch.float64
@@ -50,7 +50,7 @@ rgbraw = F.linear(x, W["rgb_layer.weight"], W["rgb_layer.bias"])
 rawo = torch.cat([rgbraw, sig], -1)
 rawo.backward(d_raw[:N].cpu().to(dt))   # inject the HIP d_raw so only the chain is compared
 def rel(a, b): return (torch.linalg.norm(a.double() - b.double()) / torch.linalg.norm(b.double()).clamp_min(1e-300)).item()
-dp = dplanes.cpu()
+dp = ops.plane_rows_view(dplanes).cpu()
 rows = {"v3": 2944 + 384, "v2": 2944 + 256, "v1": 2944 + 128, "v0": 2944, "bot": 2656}
 for i in range(8): rows[f"h{i}"] = 608 + 256 * i
 for i in range(4): rows[f"d{i}"] = 32 + 128 * i
@@ -59,5 +59,5 @@ for tag in ["v3", "v2", "v1", "v0", "bot", "h7", "h6", "h5", "h4", "h3", "h2", "
     print(tag, f"{rel(dp[rows[tag]: rows[tag] + width, :N].T, zs[tag].grad):.2e}")
 print("dxp", f"{rel(dxp[:N, :3].cpu(), zs['xd'].grad):.2e}")
 # forward check too
-pl = planes.cpu()
+pl = ops.plane_rows_view(planes).cpu()
 print("fwd h6", rel(pl[608 + 256 * 6: 608 + 256 * 7, :N].T, F.relu(zs["h6"]).detach()), "fwd xd", rel(pl[3:6, :N].T, zs["xd"].detach()))

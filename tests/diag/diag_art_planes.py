@@ -20,7 +20,7 @@ a = ops.art_mlp_fwd(pa, small, rays["rays_o"], rays["rays_d"], rays["viewdirs"],
 b, planes, masks = ops.art_mlp_fwd_train(pa, small, rays["rays_o"], rays["rays_d"], rays["viewdirs"], t)
 n = 300 * 65
 print("raw train vs inference: max abs diff per channel", (a - b).abs().amax(dim=(0, 1)).tolist())
-pl = planes[:, :n]
+pl = ops.plane_rows_view(planes)[:, :n]
 D = lambda l: pl[32 + 128 * l: 32 + 128 * (l + 1)]
 E = pl[544:544 + 63]
 Hh = lambda l: pl[608 + 256 * l: 608 + 256 * (l + 1)]

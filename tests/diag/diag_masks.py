@@ -14,7 +14,8 @@ pv = ops.pack_vanilla_mlp(P)
 rays = {k: v.to(dev) for k, v in syn.random_rays(256, seed=3).items()}
 t, _ = ops.sample_along_rays(rays["rays_o"], rays["rays_d"], 64, 2.0, 6.0, want_coords=False)
 raw, planes, masks = ops.mlp_fwd_train(pv, rays["rays_o"], rays["rays_d"], rays["viewdirs"], t)
-Np = planes.shape[1]
+Np = ops.plane_samples(planes)
+planes = ops.plane_rows_view(planes)
 mk = masks.view(torch.int32).view(9, Np * 2, 4)          # [layer][pass*256 + tid][word]
 for layer in range(9):
     rows = planes[64 + 256 * layer: 64 + 256 * (layer + 1)] if layer < 8 else planes[64 + 2048 + 256 + 32: 64 + 2048 + 256 + 32 + 128]

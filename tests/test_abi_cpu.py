@@ -80,29 +80,6 @@ def test_missing_library_fails_loudly(tmp_path):
     assert r.returncode == 0 and "LOUD:" in r.stdout and "no CPU/eager fallback" in r.stdout, r.stdout + r.stderr
 
 
-def test_engine_switch_and_bf16x3_entry_points_validate_without_gpu():
-    """The opt-in engine's entry points: same argument checking before any HIP call; the process-wide training-engine
-    switch accepts 0 / 1 only and defaults to the exact fp32 engine."""
-    from aon_amd import _lib
-
-    lib = _lib.lib
-    assert lib.aon_get_train_engine() == 0
-    assert lib.aon_set_train_engine(2) != 0 and b"engine" in lib.aon_last_error()
-    assert lib.aon_set_train_engine(1) == 0 and lib.aon_get_train_engine() == 1
-    assert lib.aon_set_train_engine(0) == 0 and lib.aon_get_train_engine() == 0
-    small = 3076 * 4
-    assert (lib.aon_bf16x3_packed_bytes() - small) % 6144 == 0 and lib.aon_bf16x3_packed_bytes() > 3_000_000   # whole 6 KiB limb tiles + fp32 small block
-    for name in ("aon_bwd_bf16x3_packed_bytes", "aon_art_bf16x3_packed_bytes", "aon_art_bwd_bf16x3_packed_bytes"):
-        n = getattr(lib, name)()
-        assert n > 3_000_000 and n % 6144 == 0, (name, n)
-    assert lib.aon_mlp_bwd_chain_bf16x3(None, None, None, None, None, 100, None) != 0 and b"multiple of 128" in lib.aon_last_error()
-    assert lib.aon_mlp_bwd_chain_bf16x3(None, None, None, None, None, 128, None) != 0 and b"null" in lib.aon_last_error()
-    assert lib.aon_art_mlp_fwd_train_bf16x3(None, None, None, None, None, None, 4, 65, None, None, None, None) != 0
-    assert lib.aon_art_mlp_fwd_train_bf16x3(None, None, None, None, None, None, 0, 65, None, None, None, None) == 0   # empty batch
-    assert lib.aon_art_render_fwd_bf16x3(None, None, None, None, None, None, None, 5, 2.0, 6.0, 1, 3, None, None, 0, None, None, None, None,
-                                         None, None, None, 0, None) != 0
-
-
 def test_two_call_training_entries_validate_without_gpu():
     """aon_render_fwd_train / aon_render_bwd and the articulated twins: argument checking and workspace
     sizing happen before any HIP call; aon_profile_class knows its classes."""

@@ -121,27 +121,3 @@ def test_example_run_single_scene(tmp_path, monkeypatch):
     assert len(log) == 3 and log[-1]["train_psnr_fine"] > log[0]["train_psnr_fine"] - 0.5 and np.isfinite(psnr["test"])
     assert os.path.exists(tmp_path / "ck" / "last.ckpt") and os.path.exists(tmp_path / "ck" / "render" / "results.json")
     assert os.path.exists(tmp_path / "ck" / "render" / "image000.jpg")
-
-
-@pytest.mark.gpu
-def test_training_engines_follow_the_same_trajectory(tmp_path, monkeypatch):
-    """Same seed, batches and stratified draws, 60 Adam steps through the harness: the opt-in bf16x3 training engine ends
-    at the fp32 engine's validation PSNR to 0.02 dB (measured over 400 steps: 15.42372 vs 15.42376 dB,
-    profiles/r01_train_engines_trajectory.txt)."""
-    if not torch.cuda.is_available():
-        pytest.skip("needs a GPU")
-    import importlib.util
-    import sys
-
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    spec = importlib.util.spec_from_file_location("run_single_scene", os.path.join(root, "examples", "run_single_scene.py"))
-    mod = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(mod)
-    final = {}
-    for engine in ("fp32", "bf16x3"):
-        monkeypatch.setattr(sys, "argv", ["run_single_scene.py", "--synthetic", str(tmp_path / f"scene_{engine}"), "--img_wh", "32", "24",
-                                          "--steps", "60", "--val_every", "60", "--batch", "512", "--exp_dir", str(tmp_path / f"ck_{engine}"),
-                                          "--train_engine", engine, "--seed", "3"])
-        log, psnr = mod.main()
-        final[engine] = (log[-1]["val_psnr"], psnr["test"])
-    assert abs(final["fp32"][0] - final["bf16x3"][0]) <= 0.02 and abs(final["fp32"][1] - final["bf16x3"][1]) <= 0.02, final

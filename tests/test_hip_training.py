@@ -92,11 +92,11 @@ def test_forward_train_planes(dev, nerf_sd):
     args = [rays[k].to(dev) for k in ("rays_o", "rays_d", "viewdirs")] + [t.to(dev)]
     raw, planes, masks = ops.mlp_fwd_train(packed, *args)
     assert torch.equal(raw, ops.mlp_fwd(packed, *args))  # same arithmetic as the inference kernel
-    assert planes.shape == (2528, 640)
+    assert planes.shape == (640 // 32, 2528 // 4, 32, 4)      # step-major: [step][row / 4][sample][row % 4] (include/aon_hip.h)
     enc = orc.pos_enc(orc.cast_rays(t, rays["rays_o"], rays["rays_d"]), 0, 10)
     venc = orc.pos_enc(rays["viewdirs"], 0, 4)
     acts, bott, hv = _layer_activations(nerf_sd, "fine_mlp.", enc, venc)
-    pl = planes.cpu()[:, : n * S]
+    pl = ops.plane_rows_view(planes).cpu()[:, : n * S]    # (rows, samples) view of the step-major planes
     torch.testing.assert_close(pl[0:63].T, enc.reshape(-1, 63), rtol=0, atol=2.5e-7)
     for l in range(8):
         torch.testing.assert_close(pl[64 + 256 * l: 64 + 256 * (l + 1)].T, acts[l], rtol=2e-5, atol=2e-5)
@@ -167,7 +167,7 @@ def test_level_backward_with_shared_samples(dev, nerf_sd, n, S):
     raw, planes, masks = ops.mlp_fwd_train(packed, o, d, v, tt)
     rgb = ops.composite_raw(raw, tt, d, True, ops.ACT_VANILLA)[0]
     g_rgb = 2.0 * (rgb - target.to(dev)) / (n * 3)
-    d_raw = ops.composite_bwd(raw, tt, d, g_rgb, None, None, True, ops.ACT_VANILLA, planes.shape[1])
+    d_raw = ops.composite_bwd(raw, tt, d, g_rgb, None, None, True, ops.ACT_VANILLA, ops.plane_samples(planes))
     dplanes = ops.mlp_bwd_chain(packed_bwd, packed, d_raw, masks, planes.shape)
     grads = ops.vanilla_wgrad(planes, dplanes, d_raw)
     for name, g in grads.items():
@@ -348,7 +348,7 @@ def test_two_call_step_equals_the_staged_entry_points(dev, nerf_sd):
         rgb, acc, weights, depth = ops.composite_raw(raw, t_vals, rays["rays_d"], False, ops.ACT_VANILLA, want_weights=True)
         outs_s += [rgb, acc, depth]
         g_rgb = 2.0 * (rgb - target) / (3 * n)
-        d_raw = ops.composite_bwd(raw, t_vals, rays["rays_d"], g_rgb.contiguous(), None, None, False, ops.ACT_VANILLA, planes.shape[1])
+        d_raw = ops.composite_bwd(raw, t_vals, rays["rays_d"], g_rgb.contiguous(), None, None, False, ops.ACT_VANILLA, ops.plane_samples(planes))
         dpl = ops.mlp_bwd_chain(pb, pf, d_raw, masks, planes.shape)
         for k, v in ops.vanilla_wgrad(planes, dpl, d_raw).items():
             grads_s[f"{name}.{k}"] = v

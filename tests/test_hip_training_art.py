@@ -65,7 +65,7 @@ def test_art_level_backward_with_shared_samples(dev, n, S):
     rgb = ops.composite_raw(raw, tt, d, True, ops.ACT_ARTICULATED)[0]
     torch.testing.assert_close(rgb.cpu(), comp, rtol=0, atol=1e-5)
     g_rgb = 2.0 * (rgb - target.to(dev)) / (n * 3)
-    d_raw = ops.composite_bwd(raw, tt, d, g_rgb, None, None, True, ops.ACT_ARTICULATED, planes.shape[1])
+    d_raw = ops.composite_bwd(raw, tt, d, g_rgb, None, None, True, ops.ACT_ARTICULATED, ops.plane_samples(planes))
     dplanes, dxp = ops.art_bwd_chain(packed_bwd, small, d_raw, masks, planes)
     grads, g_lat = ops.art_wgrad(planes, dplanes, d_raw, dxp, params, lat)
     got = {name: g.cpu() for name, g in grads.items()}

@@ -108,9 +108,8 @@ def test_items_on_gpu_and_autodecoder_harness(tmp_path, golden, monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("engine", ["fp32", "bf16x3"])
-def test_example_run_autodecoder(tmp_path, monkeypatch, engine):
-    """examples/run_autodecoder.py end to end on a synthetic tree, on both training engines: items -> training steps ->
+def test_example_run_autodecoder(tmp_path, monkeypatch):
+    """examples/run_autodecoder.py end to end on a synthetic tree: items -> training steps ->
     validation -> checkpoint (model + code library keys) -> 19 interpolated-articulation test renders + results.json."""
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
@@ -122,7 +121,7 @@ def test_example_run_autodecoder(tmp_path, monkeypatch, engine):
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     monkeypatch.setattr(sys, "argv", ["run_autodecoder.py", "--synthetic", str(tmp_path / "multi"), "--img_wh", "32", "24", "--steps", "12",
-                                      "--val_every", "6", "--exp_dir", str(tmp_path / "ck"), "--train_engine", engine])
+                                      "--val_every", "6", "--exp_dir", str(tmp_path / "ck")])
     log, psnr = mod.main()
     assert len(log) == 2 and all(np.isfinite(r["val_psnr"]) for r in log) and np.isfinite(psnr["test"])
     ck = torch.load(tmp_path / "ck" / "last.ckpt", map_location="cpu", weights_only=False)

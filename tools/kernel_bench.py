@@ -85,7 +85,7 @@ def main():
             if want("fwd_train"):
                 emit("mlp_fwd_train", S, timeit(lambda: ops.mlp_fwd_train(pv, o, d, d, t), args.reps), VAN_MAC, VAN_MAC,
                      {"plane_GB": round(planes.numel() * 4 / 1e9, 3)})
-            d_raw = torch.randn(planes.shape[1], 4, device=dev) * 1e-3
+            d_raw = torch.randn(ops.plane_samples(planes), 4, device=dev) * 1e-3
             if want("bwd_chain"):
                 bw_mac = VAN_MAC - 256 * 63 * 2 - 128 * 27 - 256 - 3 * 128   # no data gradient into the encodings / heads on the VALU
                 emit("mlp_bwd_chain", S, timeit(lambda: ops.mlp_bwd_chain(pvb, pv, d_raw, masks, planes.shape), args.reps), bw_mac, VAN_MAC)
@@ -99,7 +99,7 @@ def main():
             if want("art_fwd_train"):
                 emit("art_mlp_fwd_train", S, timeit(lambda: ops.art_mlp_fwd_train(pa, small, o, d, d, t), args.reps), ART_MAC_EXEC, ART_MAC,
                      {"plane_GB": round(planes.numel() * 4 / 1e9, 3)})
-            d_raw = torch.randn(planes.shape[1], 4, device=dev) * 1e-3
+            d_raw = torch.randn(ops.plane_samples(planes), 4, device=dev) * 1e-3
             if want("art_bwd_chain"):
                 bw_mac = ART_MAC_EXEC - 128 * 3 - 128 * 27 - 256 - 3 * 128 + 0
                 emit("art_bwd_chain", S, timeit(lambda: ops.art_bwd_chain(pab, small, d_raw, masks, planes), args.reps), bw_mac, ART_MAC)

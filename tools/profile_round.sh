@@ -5,7 +5,7 @@
 # Kernel trace and PMC counters are collected in SEPARATE runs (never --pmc together with a trace domain other than
 # --kernel-trace); FETCH_SIZE and WRITE_SIZE need a pass each (TCC counter budget, MI355X_MICROARCH.md HBM section).
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=/tmp/prof_$TAG          # raw rocpd databases stay on the box (tens of MB); only the summaries travel back
 SUM=$REPO/gpurun_out/prof_$TAG
@@ -26,23 +26,18 @@ run rocprofv3 --kernel-trace --stats -d $OUT/train_art -o $TAG -- python $REPO/t
 run rocprofv3 --kernel-trace --stats -d $OUT/train_van -o $TAG -- python $REPO/tools/train_bench.py --rays 4096 --steps 10 --no-overlap > $OUT/train_van_serial.log 2>&1
 run python $REPO/tools/train_bench.py --rays 4096 --steps 20 --articulated > $OUT/train_art.log 2>&1
 run python $REPO/tools/train_bench.py --rays 4096 --steps 20 > $OUT/train_van.log 2>&1
-# 4. articulated render (BASELINE config 4) + bf16x3 engine
+# 4. articulated render (BASELINE config 4)
 run rocprofv3 --kernel-trace --stats -d $OUT/render_art -o $TAG -- python $REPO/tools/render_bench.py > $OUT/render_art.log 2>&1
-run rocprofv3 --kernel-trace --stats -d $OUT/bf16x3 -o $TAG -- python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-train-leg --engine bf16x3 > $OUT/bf16x3.log 2>&1
-# 5. opt-in bf16x3 engines outside the headline: articulated render, training steps (plain timings, no profiler)
-run python $REPO/tools/render_bench.py --bf16x3 > $OUT/render_art_bf16x3.log 2>&1
-run python $REPO/tools/train_bench.py --rays 4096 --steps 10 --train-engine bf16x3 > $OUT/train_van_bf16x3.log 2>&1
-run python $REPO/tools/train_bench.py --rays 4096 --steps 10 --articulated --train-engine bf16x3 > $OUT/train_art_bf16x3.log 2>&1
-# 6. per-ray kernels one by one at the round-2 chunk size and at a whole frame (HIP events, no profiler)
+# 5. per-ray kernels one by one at the round-2 chunk size and at a whole frame (HIP events, no profiler)
 run python $REPO/tools/ray_kernel_bench.py > $OUT/ray_kernels.log 2>&1
 grep -h '^{' $OUT/ray_kernels.log > $SUM/${TAG}_ray_kernels.jsonl
 cd $REPO
 python tools/summarize_rocprof.py $OUT $SUM/${TAG} > $SUM/summary.log 2>&1
 f=$(ls $OUT/stats/*_results.db 2>/dev/null | head -1)
 [ -n "$f" ] && python tools/roofline_table.py $f > $SUM/${TAG}_roofline_table.txt 2>&1
-for d in train_art train_van render_art bf16x3; do
+for d in train_art train_van render_art; do
   f=$(ls $OUT/$d/*_results.db 2>/dev/null | head -1)
   [ -n "$f" ] && python tools/kstats.py $f 16 > $SUM/${TAG}_${d}_kernel_stats.txt 2>&1
 done
-for l in stats_run pmc_fetch pmc_write pmc_sq pmc_sq2 train_art train_van train_art_serial train_van_serial render_art bf16x3 render_art_bf16x3 train_van_bf16x3 train_art_bf16x3; do grep -h '^{' $OUT/$l.log | tail -1 > $SUM/$l.json; done
-cat $SUM/train_art.json $SUM/train_van.json $SUM/train_art_serial.json $SUM/train_van_serial.json $SUM/render_art.json $SUM/render_art_bf16x3.json $SUM/train_van_bf16x3.json $SUM/train_art_bf16x3.json; cut -c1-300 $SUM/stats_run.json; cut -c1-200 $SUM/bf16x3.json
+for l in stats_run pmc_fetch pmc_write pmc_sq pmc_sq2 train_art train_van train_art_serial train_van_serial render_art; do grep -h '^{' $OUT/$l.log | tail -1 > $SUM/$l.json; done
+cat $SUM/train_art.json $SUM/train_van.json $SUM/train_art_serial.json $SUM/train_van_serial.json $SUM/render_art.json; cut -c1-300 $SUM/stats_run.json

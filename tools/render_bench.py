@@ -22,8 +22,6 @@ def main():
     H, W = (240, 320) if "--full" not in sys.argv else (480, 640)
     model = NeRF_AE_Art().to(dev)
     model.load_state_dict(syn.make_art_state_dict(seed=0, density_scale=30.0))
-    if "--bf16x3" in sys.argv:
-        model.engine = "bf16x3"
     lib = CodeLibraryArticulated(types.SimpleNamespace(N_max_objs=1, N_obj_code_length=128)).to(dev)
     lib.load_state_dict(syn.make_code_library_state(0, 1))
     with torch.no_grad():
@@ -42,7 +40,7 @@ def main():
         dt = (time.perf_counter() - t0) / steps
         ms, launches, samples = ops.profile_end()
     flop_lit = 1_589_760  # reference-literal FLOP per sample, latent columns included
-    print(json.dumps({"workload": f"articulated render {W}x{H}", "engine": model.engine, "rays_per_s": H * W / dt, "ms_per_frame": dt * 1e3,
+    print(json.dumps({"workload": f"articulated render {W}x{H}", "rays_per_s": H * W / dt, "ms_per_frame": dt * 1e3,
                       "mlp_kernel_tflops_reference_literal": samples * flop_lit / (ms * 1e-3) / 1e12,
                       "mlp_kernel_frac_of_fp32_matrix_peak": samples * flop_lit / (ms * 1e-3) / 1e12 / 157.3}))
 

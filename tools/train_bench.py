@@ -19,7 +19,6 @@ def main():
     ap.add_argument("--rays", type=int, default=2048)   # the reference's hard-coded per-GPU batch (model.py:426)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--train-engine", choices=["fp32", "bf16x3"], default="fp32")
     ap.add_argument("--no-overlap", action="store_true", help="backward of both levels on the caller's stream (A/B of the two-stream backward)")
     ap.add_argument("--articulated", action="store_true", help="NeRF_AE_Art + CodeLibraryArticulated (BASELINE config 5 per GPU)")
     args = ap.parse_args()
@@ -28,7 +27,6 @@ def main():
     from aon_amd.models.vanilla_nerf.model import NeRF
 
     dev = torch.device("cuda:0")
-    ops.set_train_engine(args.train_engine)
     ops.set_bwd_overlap(not args.no_overlap)
     lib = None
     if args.articulated:
@@ -77,7 +75,7 @@ def main():
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.steps
     flop = args.rays * 258 * (1_589_760 if args.articulated else 1_186_816) * 3  # fwd + 2x bwd, reference-literal
-    print(json.dumps({"model": "articulated" if args.articulated else "vanilla", "train_engine": args.train_engine, "rays_per_step": args.rays, "ms_per_step": dt * 1e3, "rays_per_s": args.rays / dt,
+    print(json.dumps({"model": "articulated" if args.articulated else "vanilla", "rays_per_step": args.rays, "ms_per_step": dt * 1e3, "rays_per_s": args.rays / dt,
                       "train_tflops_3x_fwd": flop / dt / 1e12, "loss": loss.item()}))
 
 
