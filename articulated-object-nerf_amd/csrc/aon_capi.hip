@@ -35,6 +35,8 @@ int64_t bwd_stream_bytes();
 hipError_t launch_mlp_bwd_chain(const char* packed_bwd, const char* packed_fwd, const float* d_raw, const void* masks,
                                 float* dplanes, int64_t Np, hipStream_t stream);
 int64_t wgrad_workspace_bytes();
+hipError_t launch_wgrad_kind_bench(int kind, int nlayers, const float* planes, const float* dplanes, int rows_total, int64_t Np, float* ws,
+                                   float* out_scratch, hipStream_t stream);
 hipError_t launch_vanilla_wgrad(const float* planes, const float* dplanes, const float* d_raw, int64_t Np, float* const* grads,
                                 float* ws, hipStream_t stream);
 hipError_t launch_art_mlp_fwd_train(const char* packed, const float* small, const float* rays_o, const float* rays_d,
@@ -290,6 +292,16 @@ int aon_composite_pdf(const float* raw, const float* t_coarse, const float* dirs
 int64_t aon_train_plane_rows(void) { return aon::kPlRows; }
 int64_t aon_bwd_packed_bytes(void) { return aon::bwd_stream_bytes(); }
 int64_t aon_wgrad_workspace_bytes(void) { return aon::wgrad_workspace_bytes(); }
+
+int aon_wgrad_kind_bench(int kind, int nlayers, const float* planes, const float* dplanes, int rows, int64_t Np, void* workspace,
+                         int64_t workspace_bytes, void* stream) {
+  if (!planes || !dplanes || !workspace || rows < 512 || (rows & 31) || Np <= 0 || (Np & 127))
+    return fail(AON_E_INVALID, "aon_wgrad_kind_bench: bad argument");
+  if (workspace_bytes < aon::wgrad_workspace_bytes()) return fail(AON_E_WORKSPACE, "aon_wgrad_kind_bench: workspace too small");
+  KTimer timer(kWgrad, (hipStream_t)stream, Np);
+  return check(aon::launch_wgrad_kind_bench(kind, nlayers, planes, dplanes, rows, Np, static_cast<float*>(workspace), nullptr,
+                                            (hipStream_t)stream), "aon_wgrad_kind_bench");
+}
 
 int aon_pack_vanilla_mlp_bwd(const float* const* params_host, void* packed_bwd, void* stream) {
   if (!params_host || !packed_bwd) return fail(AON_E_INVALID, "aon_pack_vanilla_mlp_bwd: null pointer");

@@ -161,6 +161,14 @@ __device__ __forceinline__ void chunk_mma(Pipe& p, const f32x16& in, f32x16 (&ou
     constexpr int SIDE_PER_STEP = NSTEP >= 16 ? 1 : (16 + NSTEP - 1) / NSTEP;
 #pragma unroll
     for (int k = 0; k < SIDE_PER_STEP; ++k) side(i * SIDE_PER_STEP + k);
+#ifndef AON_NO_PIN_VMEM
+    // Vector-memory instructions (the DMA round and the side job's plane store of this step) stay in this step: everything else
+    // -- MFMA, VALU, SALU, LDS -- may still cross (mask = all classes but VMEM).  Left free, hipcc's scheduler sinks the stores of
+    // a chunk to its END, i.e. right in front of the next pair's barrier, whose s_waitcnt vmcnt(0) then waits out the full store
+    // latency: 42 of the 55 barriers of the articulated backward chain had 2-12 stores within the 40 instructions before them,
+    // and the chain ran 9.51 ms against 7.86 ms without stores (round 3, tools/exp_train.sh).
+    __builtin_amdgcn_sched_barrier(0x78F);
+#endif
 #ifdef AON_PIN_PREFETCH   // per translation unit (build.py): keeps the read of step i+1 above the four MFMAs of step i
     __builtin_amdgcn_sched_barrier(0);
 #endif
@@ -287,8 +295,23 @@ __device__ __forceinline__ float* row_ptr(const PlaneIO& io, int row) {
   return reinterpret_cast<float*>(io.base + (int64_t)((row >> 2) * 512 + (row & 3) * 4) + io.soff);
 }
 __device__ __forceinline__ void store_quad(const PlaneIO& io, int row, int g, const f32x16& t) {
+#ifndef AON_EXP_NOSTORE   // experiment builds only (tools/exp_train.sh): what the plane stores cost
   f32x4 v; v[0] = t[4 * g]; v[1] = t[4 * g + 1]; v[2] = t[4 * g + 2]; v[3] = t[4 * g + 3];
+  // The store's data is staged in architectural VGPRs (four v_accvgpr_read where the tile sits in AGPRs, as the gradient
+  // tiles of the backward chains do): a global_store whose data operand is an AGPR range reads it while MFMAs are streaming
+  // their accumulators through the same register banks and holds the wave's issue port meanwhile.  Measured round 3
+  // (tools/exp_train.sh): articulated backward chain 9.60 -> 9.03 ms (4096 x 193 samples), 3.42 -> 3.25 (x 65).
+  asm volatile("" : "+v"(v));
+  // ... and it is a streaming (`nt`) store: the 10.9 GB of planes a level writes are read back once, much later, by the
+  // weight-gradient kernel; written with the default policy they push the 2.8-3.3 MB weight stream, which every workgroup
+  // re-reads every pass, out of the 4 MB L2 of its XCD.  (Round 2 measured `nt` as a loss on the feature-major layout, 4-byte
+  // stores to 3,456 scattered rows; on 1 KiB contiguous units: forward 9.04 -> 8.67 ms, chain 9.01 -> 8.68 ms.)
+#ifdef AON_EXP_NO_NT
   *quad_ptr(io, row, g) = v;
+#else
+  __builtin_nontemporal_store(v, quad_ptr(io, row, g));
+#endif
+#endif
 }
 
 // ReLU masks of one layer as bits (bit (t&1)*16 + r of word t>>1 <-> tile t, register r): 16 bytes per lane per layer,
@@ -322,8 +345,12 @@ __device__ __forceinline__ T* mask_ptr(T* masks, int64_t Np, int slot, unsigned 
 //             bit-reversed once (mask_word_finish) into the stored layout: bit (t&1)*16 + r of word t>>1 <-> tile t, register r.
 //   backward  m = sign-extended one-bit field of w at pos (0 or 0xffffffff);  dz = dh & m
 __device__ __forceinline__ unsigned mask_push_post(unsigned w, float y_post_relu) {
+#ifdef AON_EXP_NOMASK     // experiment builds only: what the decision-bit arithmetic costs
+  return w;
+#else
   const unsigned nb = 0u - __builtin_bit_cast(unsigned, y_post_relu);
   return __builtin_amdgcn_alignbit(w, nb, 31);
+#endif
 }
 __device__ __forceinline__ unsigned mask_word_finish(unsigned w) { return __builtin_bitreverse32(w); }
 
@@ -377,7 +404,13 @@ struct BwdSideOf {
       if (i < 16) {
         if ((i & 3) == 0) store_quad(pio, trow, i >> 2, t[j]);   // one 16-byte store per four slots
         if constexpr (MASKED) {
-          if (j + 1 < NT) t[j + 1][i] = mask_apply(m[(j + 1) >> 1], t[j + 1][i], ((j + 1) & 1) * 16 + i);
+          if (j + 1 < NT) {
+            float z = mask_apply(m[(j + 1) >> 1], t[j + 1][i], ((j + 1) & 1) * 16 + i);
+#ifdef AON_EXP_MASK_VGPR   // experiment: the masked gradient lives in an architectural VGPR from here on (B operand + store source)
+            asm volatile("" : "+v"(z));
+#endif
+            t[j + 1][i] = z;
+          }
         }
       }
     };
@@ -411,21 +444,31 @@ __device__ __forceinline__ void load_plane(f32x16 (&x)[NT], const PlaneIO& io, i
 // constants and the lane picks one.
 __device__ __forceinline__ unsigned enc_row_off(int row) { return (unsigned)((row >> 2) * 512 + (row & 3) * 4); }
 
+// (`h` is re-made opaque at every call: the selects below are loop-invariant per lane, and hoisted out of the pass loop each
+// of the 44 offsets becomes a 64-bit register pair the allocator then spills -- 26 scratch instructions per pass.)
 __device__ __forceinline__ void store_pos_enc_plane(const f32x16 (&E)[2], const PlaneIO& io, int row0, int h) {
+  asm volatile("" : "+v"(h));
   char* base = io.base + io.soff;
 #pragma unroll
-  for (int rho = 0; rho < 30; ++rho)
-    *reinterpret_cast<float*>(base + (h ? enc_row_off(row0 + 33 + rho) : enc_row_off(row0 + 3 + rho))) = E[rho >> 4][rho & 15];
-  *reinterpret_cast<float*>(base + (h ? enc_row_off(row0 + 2) : enc_row_off(row0))) = E[1][14];
+  for (int rho = 0; rho < 30; ++rho) {
+    const unsigned off = h ? enc_row_off(row0 + 33 + rho) : enc_row_off(row0 + 3 + rho);
+    *reinterpret_cast<float*>(base + off) = E[rho >> 4][rho & 15];
+  }
+  const unsigned off_id = h ? enc_row_off(row0 + 2) : enc_row_off(row0);
+  *reinterpret_cast<float*>(base + off_id) = E[1][14];
   if (!h) *reinterpret_cast<float*>(base + enc_row_off(row0 + 1)) = E[1][15];
 }
 
 __device__ __forceinline__ void store_view_enc_plane(const f32x16& V, const PlaneIO& io, int row0, int h) {
+  asm volatile("" : "+v"(h));
   char* base = io.base + io.soff;
 #pragma unroll
-  for (int rho = 0; rho < 12; ++rho)
-    *reinterpret_cast<float*>(base + (h ? enc_row_off(row0 + 15 + rho) : enc_row_off(row0 + 3 + rho))) = V[rho];
-  *reinterpret_cast<float*>(base + (h ? enc_row_off(row0 + 2) : enc_row_off(row0))) = V[12];
+  for (int rho = 0; rho < 12; ++rho) {
+    const unsigned off = h ? enc_row_off(row0 + 15 + rho) : enc_row_off(row0 + 3 + rho);
+    *reinterpret_cast<float*>(base + off) = V[rho];
+  }
+  const unsigned off_id = h ? enc_row_off(row0 + 2) : enc_row_off(row0);
+  *reinterpret_cast<float*>(base + off_id) = V[12];
   if (!h) *reinterpret_cast<float*>(base + enc_row_off(row0 + 1)) = V[13];
 }
 

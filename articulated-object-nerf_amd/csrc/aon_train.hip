@@ -339,23 +339,44 @@ hipError_t run_wgrad_plan(const WgLayerDesc* layers, int nlayers, const HeadDesc
   return hipGetLastError();
 }
 
+// Measurement aid (tools/kernel_bench.py --wgrad-kinds): `nlayers` identical jobs of one kind on arbitrary plane rows, the
+// grouped kernel only -- the isolated rate of a kind with the whole chip running it (what wg_cost() is tuned from).
+hipError_t launch_wgrad_kind_bench(int kind, int nlayers, const float* planes, const float* dplanes, int rows_total, int64_t Np, float* ws,
+                                   float* out_scratch, hipStream_t stream) {
+  static DeviceOnce lds_once;
+  if (hipError_t e = set_max_lds(&wgrad_grouped_kernel, kWgLdsBytes, lds_once); e != hipSuccess) return e;
+  const int cus = num_cus();
+  if (cus <= 0 || kind < 0 || kind >= kWgNumKinds || nlayers < 1 || nlayers > kWgMaxJobs) return hipErrorInvalidValue;
+  WgLayerDesc L[kWgMaxJobs];
+  const int M = wg_M(kind), K = wg_K(kind);
+  for (int l = 0; l < nlayers; ++l) {
+    const int a_row = (l * 256) % (rows_total - M + 1) / 32 * 32, b_row = (l * 256 + 128) % (rows_total - K + 1) / 32 * 32;
+    L[l] = WgLayerDesc{kind, a_row, b_row, out_scratch, K, 0, K, nullptr};
+  }
+  WgPlan plan;
+  if (!wg_make_plan(L, nlayers, planes, dplanes, rows_total, Np, cus < 304 ? cus : 304, ws, 0, plan)) return hipErrorInvalidValue;
+  if (plan.ws_floats * 4 > wgrad_workspace_bytes_impl()) return hipErrorInvalidValue;
+  wgrad_grouped_kernel<<<dim3(plan.total_wgs), dim3(256), kWgLdsBytes, stream>>>(plan.args);
+  return hipGetLastError();
+}
+
 // grads: 24 device pointers in the parameter order of aon_pack_vanilla_mlp (each the full (out,in) / (out,) tensor), overwritten.
 hipError_t launch_vanilla_wgrad(const float* planes, const float* dplanes, const float* d_raw, int64_t Np, float* const* grads,
                                 float* ws, hipStream_t stream) {
-  WgLayerDesc L[11];
+  WgLayerDesc L[12];
   int n = 0;
   // trunk: dW_l = dZ_l . H_{l-1}^T  (+ the pos-enc columns for layers 0 and 5)
-  L[n++] = WgLayerDesc{kWg256x64, plane_h(0), kPlE, grads[0], kPosEnc, 0, kPosEnc, grads[1], 0};
+  L[n++] = WgLayerDesc{kWg256x64, plane_h(0), kPlE, grads[0], kPosEnc, 0, kPosEnc, grads[1]};
   for (int l = 1; l < 8; ++l) {
     const int ld = l == 5 ? 256 + kPosEnc : 256;
-    L[n++] = WgLayerDesc{kWg256x256, plane_h(l), plane_h(l - 1), grads[2 * l], ld, 0, 256, grads[2 * l + 1], 0};
-    if (l == 5) L[n++] = WgLayerDesc{kWg256x64, plane_h(5), kPlE, grads[10], ld, 256, kPosEnc, nullptr, 0};
+    L[n++] = WgLayerDesc{kWg256x256, plane_h(l), plane_h(l - 1), grads[2 * l], ld, 0, 256, grads[2 * l + 1]};
+    if (l == 5) L[n++] = WgLayerDesc{kWg256x64, plane_h(5), kPlE, grads[10], ld, 256, kPosEnc, nullptr};
   }
   // bottleneck (input: post-ReLU layer-7 output)
-  L[n++] = WgLayerDesc{kWg256x256, kPlBot, plane_h(7), grads[18], 256, 0, 256, grads[19], 0};
-  // view layer: cat[bottleneck(256), viewenc(27)] -- the view-encoding rows follow the bottleneck rows in the planes
-  static_assert(kPlVE == kPlBot + 256, "bottleneck and view-encoding rows must be adjacent");
-  L[n++] = WgLayerDesc{kWg128x288, kPlHV, kPlBot, grads[16], 256 + kViewEnc, 0, 256, grads[17], kViewEnc};
+  L[n++] = WgLayerDesc{kWg256x256, kPlBot, plane_h(7), grads[18], 256, 0, 256, grads[19]};
+  // view layer: cat[bottleneck(256), viewenc(27)]: two column blocks of one weight
+  L[n++] = WgLayerDesc{kWg128x256, kPlHV, kPlBot, grads[16], 256 + kViewEnc, 0, 256, grads[17]};
+  L[n++] = WgLayerDesc{kWg128x32, kPlHV, kPlVE, grads[16], 256 + kViewEnc, 256, kViewEnc, nullptr};
   // heads and their biases: density_layer (1,256) <- H7 x d_raw.w, rgb_layer (3,128) <- HV x d_raw.xyz, bias sums of d_raw
   const HeadDesc H[3] = {{planes, plane_h(7), 256, d_raw, 128}, {planes, kPlHV, 128, d_raw, 128}, {nullptr, 0, 1, d_raw, 128}};
   const HeadOut O[4] = {{0, 256, 3, 1, 256, 1, grads[20]}, {0, 128, 0, 3, 128, 1, grads[22]}, {0, 1, 3, 1, 1, 1, grads[21]}, {0, 1, 0, 3, 1, 1, grads[23]}};

@@ -152,7 +152,14 @@ __global__ void __launch_bounds__(256) art_bwd_chain_kernel(ArtBwdArgs args) {
     f32x16 X[8], Y[8];
     AON_ABWD_LAYER(4, 8, Z0, X, kABwV0, aplane_v(0), 11)   // X = d bottleneck (no activation)
     // ---- trunk ----
-    const float dsig = args.d_raw[col * 4 + 3];   // re-read here (L2-hot) instead of carried through the view branch
+    // the sample index is re-derived where it is needed (one v_mbcnt pair) instead of held in a register pair across the view
+    // branch / the trunk: that pair was the kernel's last scratch spill
+    auto sample_now = [&]() {
+      int l;
+      asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+      return (int64_t)pass * 128 + wave_s * 32 + (l & 31);
+    };
+    const float dsig = args.d_raw[sample_now() * 4 + 3];   // re-read here (L2-hot) instead of carried through the view branch
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
 #pragma unroll
@@ -210,7 +217,7 @@ __global__ void __launch_bounds__(256) art_bwd_chain_kernel(ArtBwdArgs args) {
       dx[a] = dx[a] + __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((lane_p ^ 32) << 2, __builtin_bit_cast(int, dx[a])));
     if (h == 0) {
       float4 o; o.x = dx[0]; o.y = dx[1]; o.z = dx[2]; o.w = 0.f;
-      reinterpret_cast<float4*>(args.dxp)[col] = o;
+      reinterpret_cast<float4*>(args.dxp)[sample_now()] = o;
     }
 
     // ---- deformation MLP, backwards (x' = deformation_layer(h3) + pos, :200-205) ----
@@ -336,20 +343,19 @@ hipError_t launch_art_wgrad(const float* planes, const float* dplanes, const flo
   int n = 0;
   // deformation MLP (model_autodecoder.py:196-203): layers 1..3 here; layer 0's three position columns go with the heads below
   // (its input is cat[pos(3), shape(128), articulation(32)]: a 16-byte record per sample, not a plane operand)
-  for (int l = 1; l < 4; ++l) L[n++] = WgLayerDesc{kWg128x128, aplane_d(l), aplane_d(l - 1), grads[2 * l], 128, 0, 128, grads[2 * l + 1], 0};
+  for (int l = 1; l < 4; ++l) L[n++] = WgLayerDesc{kWg128x128, aplane_d(l), aplane_d(l - 1), grads[2 * l], 128, 0, 128, grads[2 * l + 1]};
   // trunk (:210-217): layer 0 input cat[enc(63), shape(128)], layer 5 input cat[h(256), enc(63), shape(128)]
-  L[n++] = WgLayerDesc{kWg256x64, aplane_h(0), kAPlE, grads[10], 191, 0, kPosEnc, grads[11], 0};
+  L[n++] = WgLayerDesc{kWg256x64, aplane_h(0), kAPlE, grads[10], 191, 0, kPosEnc, grads[11]};
   for (int l = 1; l < 8; ++l) {
     const int ld = l == 5 ? 447 : 256;
-    L[n++] = WgLayerDesc{kWg256x256, aplane_h(l), aplane_h(l - 1), grads[10 + 2 * l], ld, 0, 256, grads[11 + 2 * l], 0};
-    if (l == 5) L[n++] = WgLayerDesc{kWg256x64, aplane_h(5), kAPlE, grads[20], ld, 256, kPosEnc, nullptr, 0};
+    L[n++] = WgLayerDesc{kWg256x256, aplane_h(l), aplane_h(l - 1), grads[10 + 2 * l], ld, 0, 256, grads[11 + 2 * l]};
+    if (l == 5) L[n++] = WgLayerDesc{kWg256x64, aplane_h(5), kAPlE, grads[20], ld, 256, kPosEnc, nullptr};
   }
-  L[n++] = WgLayerDesc{kWg256x256, kAPlBot, aplane_h(7), grads[34], 256, 0, 256, grads[35], 0};
-  // view branch (:227-234): layer 0 input cat[bottleneck(256), viewenc(27), appearance(128)]; the view-encoding rows follow the
-  // bottleneck rows in the planes AND in the weight's columns: one 128 x 288 job
-  static_assert(kAPlVE == kAPlBot + 256, "bottleneck and view-encoding rows must be adjacent");
-  L[n++] = WgLayerDesc{kWg128x288, aplane_v(0), kAPlBot, grads[26], 411, 0, 256, grads[27], kViewEnc};
-  for (int l = 1; l < 4; ++l) L[n++] = WgLayerDesc{kWg128x128, aplane_v(l), aplane_v(l - 1), grads[26 + 2 * l], 128, 0, 128, grads[27 + 2 * l], 0};
+  L[n++] = WgLayerDesc{kWg256x256, kAPlBot, aplane_h(7), grads[34], 256, 0, 256, grads[35]};
+  // view branch (:227-234): layer 0 input cat[bottleneck(256), viewenc(27), appearance(128)]: two column blocks from the planes
+  L[n++] = WgLayerDesc{kWg128x256, aplane_v(0), kAPlBot, grads[26], 411, 0, 256, grads[27]};
+  L[n++] = WgLayerDesc{kWg128x32, aplane_v(0), kAPlVE, grads[26], 411, 256, kViewEnc, nullptr};
+  for (int l = 1; l < 4; ++l) L[n++] = WgLayerDesc{kWg128x128, aplane_v(l), aplane_v(l - 1), grads[26 + 2 * l], 128, 0, 128, grads[27 + 2 * l]};
   // heads: density (H7 x d_raw.w), rgb (V3 x d_raw.xyz), deformation_layer (D3 x dx'), their bias sums, and deformation layer 0:
   // dW[:, 0:3] = dZ_D0 x pos (the position is rows 0..2 of unit row kAPlPos / 4 of the forward planes), db = row sums of dZ_D0
   const int64_t unit_step = (int64_t)kAPlRows * 32;

@@ -36,9 +36,11 @@ __device__ __forceinline__ float wsum64(float v) {
 //   kWg256x256   4 waves = 2 x 2 blocks of 128 x 128, every wave takes all 16 sample pairs of a step
 //   kWg128x128   one block, the four waves take 4 sample pairs each (four partials)
 //   kWg256x64    two 128 x 64 blocks x two sample halves                      (positional-encoding inputs, 63 valid columns)
-//   kWg128x288   128 x 256 as two blocks x two sample halves + the adjacent 32 plane rows (view encoding, 27 valid) as a
-//                128 x 32 extension each wave computes on half of its own pairs (the A fragment is already in registers)
-enum : int { kWg256x256 = 0, kWg128x128 = 1, kWg256x64 = 2, kWg128x288 = 3, kWgNumKinds = 4 };
+//   kWg128x256   two 128 x 128 blocks x two sample halves                     (view layer 0 on the bottleneck output)
+//   kWg128x32    one 128 x 32 block (one B register per lane), four sample quarters   (view-encoding inputs, 27 valid columns)
+// No wave holds more than 16 accumulator tiles = the 256 AGPRs: a 128 x 288 kind with a 4-tile extension (320 registers) made
+// hipcc shuttle tiles between AGPRs and VGPRs around every MFMA group (160 v_accvgpr moves per 20 MFMAs, 0.60 of peak).
+enum : int { kWg256x256 = 0, kWg128x128 = 1, kWg256x64 = 2, kWg128x256 = 3, kWg128x32 = 4, kWgNumKinds = 5 };
 
 struct WgJob {
   int a_unit;      // first unit row (plane row / 4) of dZ in the gradient planes
@@ -47,7 +49,6 @@ struct WgJob {
   int wg_begin, wg_count;   // workgroups [wg_begin, wg_begin + wg_count) split the steps of this layer
   int part_off;    // float offset in the workspace of partial[wg_count * nsplit][M][K]
   int bias_off;    // float offset of bias_partial[wg_count * nsplit][M], or -1
-  int ext_off;     // kWg128x288: float offset of the extension's partial[wg_count * 4][128][32]
 };
 
 // second stage: out[row * ld + col_off + col] = sum_p partial[p][row][col]  (col < k_valid);  bias_out[row] = sum_p bias_partial[p][row]
@@ -74,17 +75,20 @@ struct WgArgs {
 };
 
 template <int KIND> struct WgTraits;
-template <> struct WgTraits<kWg256x256> { static constexpr int NGA = 64, NGB = 64, NB = 4, NAB = 2, NBB = 2, NSPLIT = 1, NSTAGE = 2, NGX = 0; };
-template <> struct WgTraits<kWg128x128> { static constexpr int NGA = 32, NGB = 32, NB = 4, NAB = 1, NBB = 1, NSPLIT = 4, NSTAGE = 4, NGX = 0; };
-template <> struct WgTraits<kWg256x64>  { static constexpr int NGA = 64, NGB = 16, NB = 2, NAB = 2, NBB = 1, NSPLIT = 2, NSTAGE = 3, NGX = 0; };
-template <> struct WgTraits<kWg128x288> { static constexpr int NGA = 32, NGB = 64, NB = 4, NAB = 1, NBB = 2, NSPLIT = 2, NSTAGE = 2, NGX = 8; };
+template <> struct WgTraits<kWg256x256> { static constexpr int NGA = 64, NGB = 64, NB = 4, NAB = 2, NBB = 2, NSPLIT = 1, NSTAGE = 2; };
+template <> struct WgTraits<kWg128x128> { static constexpr int NGA = 32, NGB = 32, NB = 4, NAB = 1, NBB = 1, NSPLIT = 4, NSTAGE = 4; };
+template <> struct WgTraits<kWg256x64>  { static constexpr int NGA = 64, NGB = 16, NB = 2, NAB = 2, NBB = 1, NSPLIT = 2, NSTAGE = 3; };
+template <> struct WgTraits<kWg128x256> { static constexpr int NGA = 32, NGB = 64, NB = 4, NAB = 1, NBB = 2, NSPLIT = 2, NSTAGE = 3; };
+template <> struct WgTraits<kWg128x32>  { static constexpr int NGA = 32, NGB = 8,  NB = 1, NAB = 1, NBB = 1, NSPLIT = 4, NSTAGE = 4; };
 
-template <int KIND> constexpr int wg_stage_bytes() { return (WgTraits<KIND>::NGA + WgTraits<KIND>::NGB + WgTraits<KIND>::NGX) * 512; }
-constexpr int kWgLdsBytes = 128 * 1024;   // max over kinds of NSTAGE * stage bytes (2 x 64 KiB, 4 x 32 KiB, 3 x 40 KiB, 2 x 52 KiB)
+template <int KIND> constexpr int wg_stage_bytes() { return (WgTraits<KIND>::NGA + WgTraits<KIND>::NGB) * 512; }
+constexpr int kWgLdsBytes = 144 * 1024;   // max over kinds of NSTAGE * stage bytes (2 x 64 KiB, 4 x 32 KiB, 3 x 40 KiB, 3 x 48 KiB, 4 x 20 KiB)
 
-__host__ __device__ constexpr int wg_nsplit(int kind) { return kind == kWg256x256 ? 1 : kind == kWg128x128 ? 4 : 2; }
+__host__ __device__ constexpr int wg_nsplit(int kind) { return kind == kWg256x256 ? 1 : (kind == kWg128x128 || kind == kWg128x32) ? 4 : 2; }
 __host__ __device__ constexpr int wg_M(int kind) { return (kind == kWg256x256 || kind == kWg256x64) ? 256 : 128; }
-__host__ __device__ constexpr int wg_K(int kind) { return kind == kWg256x256 ? 256 : kind == kWg128x128 ? 128 : kind == kWg256x64 ? 64 : 256; }
+__host__ __device__ constexpr int wg_K(int kind) {
+  return kind == kWg256x256 ? 256 : kind == kWg128x128 ? 128 : kind == kWg256x64 ? 64 : kind == kWg128x256 ? 256 : 32;
+}
 
 #ifdef AON_WGRAD_KERNELS   // the kernels are compiled once, in aon_train.hip (run_wgrad_plan is the only launcher)
 // workgroup barrier that leaves the N youngest vector-memory operations (LDS-DMA of later stages) in flight.  __syncthreads()
@@ -101,11 +105,10 @@ __device__ __forceinline__ void wgrad_job(const WgArgs& a, const WgJob& J, char*
   using T = WgTraits<KIND>;
   constexpr int NB = T::NB, NSTAGE = T::NSTAGE, NSPLIT = T::NSPLIT;
   constexpr int STAGE = wg_stage_bytes<KIND>();
-  constexpr int ND = (T::NGA + T::NGB + T::NGX) / 2;   // 1 KiB DMA instructions per step
+  constexpr int ND = (T::NGA + T::NGB) / 2;   // 1 KiB DMA instructions per step
   static_assert(ND % 4 == 0 && (T::NGA / 2) % 4 == 0, "DMA instructions split evenly over the four waves, A/B boundary on a multiple of 4");
   constexpr int D = ND / 4;                            // per wave
   constexpr int PW = 16 / NSPLIT;                      // sample pairs per wave per step
-  constexpr bool EXT = T::NGX > 0;
   static_assert(NSTAGE * STAGE <= kWgLdsBytes, "LDS ring");
   static_assert((NSTAGE - 2) * D <= 63, "vmcnt range");
 
@@ -130,13 +133,6 @@ __device__ __forceinline__ void wgrad_job(const WgArgs& a, const WgJob& J, char*
     for (int cb = 0; cb < NB; ++cb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[ca][cb][r] = 0.f;
-  f32x16 accx[EXT ? 4 : 1];
-  if constexpr (EXT) {
-#pragma unroll
-    for (int ca = 0; ca < 4; ++ca)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) accx[ca][r] = 0.f;
-  }
   float bsum[4] = {0.f, 0.f, 0.f, 0.f};
 
   // ---- DMA side: instruction d = 4k + wave moves unit rows 2d, 2d+1 of the concatenated [A | B] operand list ----
@@ -161,21 +157,29 @@ __device__ __forceinline__ void wgrad_job(const WgArgs& a, const WgJob& J, char*
   const unsigned offA = (unsigned)(wa * 32 * 512 + i * 512 + ((kh ^ (i & 15)) << 4));
   unsigned offB;
   if constexpr (NB == 4) offB = (unsigned)(T::NGA * 512 + wb * 32 * 512 + i * 512 + ((kh ^ (i & 15)) << 4));
-  else offB = (unsigned)(T::NGA * 512 + (i & 15) * 512 + ((kh ^ (i & 15)) << 4));       // NB == 2: lanes i and i + 16 share a unit
-  const unsigned offX = (unsigned)((T::NGA + T::NGB) * 512 + (i & 7) * 512 + ((kh ^ (i & 7)) << 4));   // extension: 8 unit rows
-  // this wave's pairs of a step: p = split * PW + q;  with the extension, the first PW/2 of them (those of parity wb) also feed it
-  auto pair_of = [&](int q) {
-    if constexpr (EXT) return split * PW + 2 * (q % (PW / 2)) + (q < PW / 2 ? wb : 1 - wb);
-    else return split * PW + q;
+  else if constexpr (NB == 2) offB = (unsigned)(T::NGA * 512 + (i & 15) * 512 + ((kh ^ (i & 15)) << 4));   // lanes i and i + 16 share a unit
+  else offB = (unsigned)(T::NGA * 512 + (i & 7) * 512 + ((kh ^ (i & 7)) << 4));                             // NB == 1: four lanes share a unit
+  auto pair_of = [&](int q) { return split * PW + q; };   // this wave's pairs of a step
+  // Fragment reads are inline asm with hand-placed waits.  Written as plain loads, hipcc (ROCm 7.2) (a) sinks each ds_read to
+  // just in front of its first use unless pinned, and (b) pinned, still guards every second MFMA group with s_waitcnt
+  // lgkmcnt(0), i.e. waits for the reads it has JUST issued for the next pair: the full LDS latency exposed per 32 MFMAs
+  // (measured: 256 x 256 jobs 0.864 of peak).  Here the reads of pair q + 1 are issued, then `wait_frag<N>` waits until only
+  // those N reads are outstanding (LDS returns in order) and hands the registers of pair q to the MFMAs through a data
+  // dependence.  The compiler never copies a fragment between its read and its wait (straight-line, fully unrolled code;
+  // the one loop-carried fragment is waited for before the back edge).
+  struct Frag { f32x4 a, b; };
+  const unsigned lds0 = (unsigned)(uintptr_t)(lds_void*)smem;
+  auto lds_read = [](unsigned addr) {
+    f32x4 v;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
+    return v;
   };
-  struct Frag { f32x4 a, b, x; };
   auto read_frag = [&](int stage, int q) {
     Frag f;
     const unsigned px = (unsigned)pair_of(q) << 5;
-    const char* sb = smem + stage * STAGE;
-    f.a = *reinterpret_cast<const f32x4*>(sb + (offA ^ px));
-    f.b = *reinterpret_cast<const f32x4*>(sb + (offB ^ px));
-    if constexpr (EXT) { if (q < PW / 2) f.x = *reinterpret_cast<const f32x4*>(sb + (offX ^ px)); }
+    const unsigned sb = lds0 + (unsigned)(stage * STAGE);
+    f.a = lds_read(sb + (offA ^ px));
+    f.b = lds_read(sb + (offB ^ px));
     return f;
   };
 
@@ -187,6 +191,7 @@ __device__ __forceinline__ void wgrad_job(const WgArgs& a, const WgJob& J, char*
   stage_barrier<(NSTAGE - 2) * D>();
   int stage = 0;
   Frag cur = read_frag(0, 0);
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cur.a), "+v"(cur.b));
   for (int c = c_begin; c < c_end; ++c) {
     const int stage_dma = stage == 0 ? NSTAGE - 1 : stage - 1;     // (stage + NSTAGE - 1) % NSTAGE: consumed in step c - 1
     const int stage_next = stage == NSTAGE - 1 ? 0 : stage + 1;
@@ -196,43 +201,45 @@ __device__ __forceinline__ void wgrad_job(const WgArgs& a, const WgJob& J, char*
       if (q + 1 < PW) {
         nxt = read_frag(stage, q + 1);
       } else {
-        // every DMA of step c + NSTAGE - 1 has been issued (below, q <= PW - 2 ... or just above for PW == 1): step c + 1 must
-        // have landed, all waves are done reading `stage` except through registers
+        // every DMA of step c + NSTAGE - 1 has been issued (first half of the step): step c + 1 must have landed, all waves
+        // are done reading `stage` except through registers
         stage_barrier<(NSTAGE - 2) * D>();
         nxt = read_frag(stage_next, 0);
       }
-      // DMA instructions of step c + NSTAGE - 1, spread over the first PW - 1 pairs
-      constexpr int PER = (D + (PW - 1) - 1) / (PW - 1);
+      // DMA instructions of step c + NSTAGE - 1, spread over the FIRST HALF of the step's pairs: with two stages they must
+      // land before this step's barrier, and the HBM latency is a good part of a step of the narrow kinds
+      constexpr int HALF = PW / 2 > 0 ? PW / 2 : 1;
+      constexpr int PER = (D + HALF - 1) / HALF;
 #pragma unroll
       for (int u = 0; u < PER; ++u) {
         const int k = q * PER + u;
-        if (q < PW - 1 && k < D) dma_step(c + NSTAGE - 1, stage_dma, k);
+        if (q < HALF && k < D) dma_step(c + NSTAGE - 1, stage_dma, k);
       }
+      __builtin_amdgcn_sched_barrier(0);   // the reads / DMA instructions above stay above the MFMAs below
+      if (q > 0) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(cur.a), "+v"(cur.b));   // (q == 0: waited for at the end of the previous step)
 #pragma unroll
       for (int ca = 0; ca < 4; ++ca) bsum[ca] += cur.a[ca];   // bias gradient = row sums of dZ (written once per A block below)
       f32x4 be = cur.b;
       if constexpr (NB == 2) { if (i >= 16) { be[0] = cur.b[2]; be[1] = cur.b[3]; } }
+      if constexpr (NB == 1) {   // column n of the 32-wide block = row 4 (n & 7) + (n >> 3)
+        const int sel = i >> 3;
+        be[0] = sel == 0 ? cur.b[0] : sel == 1 ? cur.b[1] : sel == 2 ? cur.b[2] : cur.b[3];
+      }
 #pragma unroll
       for (int ca = 0; ca < 4; ++ca)
 #pragma unroll
         for (int cb = 0; cb < NB; ++cb) acc[ca][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[ca], be[cb], acc[ca][cb], 0, 0, 0);
-      if constexpr (EXT) {
-        if (q < PW / 2) {
-          const int sel = i >> 3;   // column n of the extension block = row 4 (n & 7) + (n >> 3) of its 32
-          const float bx = sel == 0 ? cur.x[0] : sel == 1 ? cur.x[1] : sel == 2 ? cur.x[2] : cur.x[3];
-#pragma unroll
-          for (int ca = 0; ca < 4; ++ca) accx[ca] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[ca], bx, accx[ca], 0, 0, 0);
-        }
-      }
       cur = nxt;
     }
+    // the loop-carried fragment (pair 0 of the next step) is complete before the back edge
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cur.a), "+v"(cur.b));
     stage = stage_next;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clamped look-ahead DMAs must land before the LDS is released
 
   // ---- partials ----
   // accumulator (ca, cb), register r, lane (n, hh): row 4 (32 wa + (r&3) + 8 (r>>2) + 4 hh) + ca, column 128 wb + 4 n + cb
-  constexpr int M = 128 * T::NAB, K = NB == 2 ? 64 : 128 * T::NBB;
+  constexpr int M = 128 * T::NAB, K = NB == 2 ? 64 : NB == 1 ? 32 : 128 * T::NBB;
   const int part = part_wg * NSPLIT + split;
   float* P = a.ws + J.part_off + (int64_t)part * M * K;
 #pragma unroll
@@ -243,21 +250,13 @@ __device__ __forceinline__ void wgrad_job(const WgArgs& a, const WgJob& J, char*
       if constexpr (NB == 4) {
         f32x4 v; v[0] = acc[ca][0][r]; v[1] = acc[ca][1][r]; v[2] = acc[ca][2][r]; v[3] = acc[ca][3][r];
         *reinterpret_cast<f32x4*>(P + (int64_t)row * K + 128 * wb + 4 * i) = v;
-      } else {
+      } else if constexpr (NB == 2) {
         float2 v; v.x = acc[ca][0][r]; v.y = acc[ca][1][r];
         *reinterpret_cast<float2*>(P + (int64_t)row * K + 4 * (i & 15) + 2 * (i >> 4)) = v;
+      } else {
+        P[(int64_t)row * K + 4 * (i & 7) + (i >> 3)] = acc[ca][0][r];
       }
     }
-  if constexpr (EXT) {
-    float* PX = a.ws + J.ext_off + (int64_t)(part_wg * 4 + wave) * 128 * 32;
-#pragma unroll
-    for (int ca = 0; ca < 4; ++ca)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = 4 * ((r & 3) + 8 * (r >> 2) + 4 * kh) + ca;
-        PX[row * 32 + 4 * (i & 7) + (i >> 3)] = accx[ca][r];
-      }
-  }
   if (J.bias_off >= 0 && wb == 0) {
     f32x4 v;
 #pragma unroll
@@ -278,7 +277,8 @@ __global__ void __launch_bounds__(256) wgrad_grouped_kernel(WgArgs a) {
     case kWg256x256: wgrad_job<kWg256x256>(a, J, wg_smem); break;
     case kWg128x128: wgrad_job<kWg128x128>(a, J, wg_smem); break;
     case kWg256x64: wgrad_job<kWg256x64>(a, J, wg_smem); break;
-    default: wgrad_job<kWg128x288>(a, J, wg_smem); break;
+    case kWg128x256: wgrad_job<kWg128x256>(a, J, wg_smem); break;
+    default: wgrad_job<kWg128x32>(a, J, wg_smem); break;
   }
 }
 
@@ -455,7 +455,6 @@ struct WgLayerDesc {   // one nn.Linear weight (or a column block of one)
   int a_row, b_row;    // first plane rows of dZ (gradient planes) and of the layer input (forward planes)
   float* out; int ld, col_off, k_valid;
   float* bias_out;     // or null
-  int x_k_valid;       // kWg128x288: valid columns of the extension (written at col_off + 256)
 };
 
 // relative cost of one step of a job (matrix-pipe cycles of the busiest wave; the 128-wide kinds are bound by their operand
@@ -463,9 +462,10 @@ struct WgLayerDesc {   // one nn.Linear weight (or a column block of one)
 inline double wg_cost(int kind) {
   switch (kind) {
     case kWg256x256: return 16384.0;
-    case kWg128x128: return 4096.0 * 1.15;
-    case kWg256x64: return 4096.0 * 1.15;
-    default: return 9216.0 * 1.05;
+    case kWg128x128: return 4096.0 * 1.10;
+    case kWg256x64: return 4096.0 * 1.20;
+    case kWg128x256: return 8192.0 * 1.05;
+    default: return 2600.0;   // kWg128x32: 1,024 matrix-pipe cycles per step, but 20 KB of operands -- DMA-bound
   }
 }
 
@@ -523,21 +523,13 @@ inline bool wg_make_plan(const WgLayerDesc* layers, int nlayers, const float* pl
     wg += J.wg_count;
     const int nparts = J.wg_count * nsplit;
     J.part_off = (int)off; off += (int64_t)nparts * M * K;
-    J.bias_off = -1; J.ext_off = -1;
+    J.bias_off = -1;
     if (L.bias_out) { J.bias_off = (int)off; off += (int64_t)nparts * M; }
     if (R.nred >= kWgMaxReduce) return false;
     WgReduce& E = R.red[R.nred++];
     E.part_off = J.part_off; E.nparts = nparts; E.M = M; E.K = K; E.k_valid = L.k_valid; E.ld = L.ld; E.col_off = L.col_off;
     E.bias_off = J.bias_off; E.out = L.out; E.bias_out = L.bias_out;
     E.blk_begin = blk; E.nblk_w = (M * K / 4 + 63) / 64; blk += E.nblk_w + (L.bias_out ? (M + 15) / 16 : 0);
-    if (L.kind == kWg128x288) {
-      J.ext_off = (int)off; off += (int64_t)J.wg_count * 4 * 128 * 32;
-      if (R.nred >= kWgMaxReduce) return false;
-      WgReduce& X = R.red[R.nred++];
-      X.part_off = J.ext_off; X.nparts = J.wg_count * 4; X.M = 128; X.K = 32; X.k_valid = L.x_k_valid; X.ld = L.ld; X.col_off = L.col_off + 256;
-      X.bias_off = -1; X.out = L.out; X.bias_out = nullptr;
-      X.blk_begin = blk; X.nblk_w = (128 * 32 / 4 + 63) / 64; blk += X.nblk_w;
-    }
   }
   plan.total_wgs = wg;
   plan.reduce_blocks = blk;

@@ -190,6 +190,10 @@ int aon_mlp_bwd_chain(const void* packed_bwd, const void* packed_fwd, const floa
                       float* dplanes, int64_t Np, void* stream);
 int aon_vanilla_wgrad(const float* planes, const float* dplanes, const float* d_raw, int64_t Np,
                       float* const* grads_host, void* workspace, int64_t workspace_bytes, void* stream);
+/* Measurement aid: `nlayers` (<= 20) identical weight-gradient jobs of one kind (0: 256x256, 1: 128x128, 2: 256x64, 3: 128x256, 4: 128x32;
+ * csrc/aon_wgrad.h) on arbitrary rows of two plane buffers, the grouped kernel only, partials left in the workspace. */
+int aon_wgrad_kind_bench(int kind, int nlayers, const float* planes, const float* dplanes, int rows, int64_t Np, void* workspace,
+                         int64_t workspace_bytes, void* stream);
 
 /* ---- R14 for the articulated network (training_step, model_autodecoder.py:395-477) ----
  * Same four stages as the vanilla backward, on the articulated row map (aon_art_train_plane_rows() rows).  Gradients reach

@@ -33,13 +33,39 @@ def timeit(fn, reps):
     return t[len(t) // 2]
 
 
+def wgrad_kinds(args):
+    """Each job kind of the grouped weight-gradient kernel alone, `nl` identical layers filling the chip: executed TFLOP/s per kind
+    (the costs of wg_cost() in csrc/aon_wgrad.h are these rates' reciprocals)."""
+    from aon_amd import _lib, ops
+
+    lib = _lib.lib
+    dev = torch.device("cuda:0")
+    rows = 3456
+    for S in (65, 193):
+        Np = ops.padded_samples(args.rays * S)
+        planes = torch.randn((Np // 32, rows // 4, 32, 4), device=dev)
+        dplanes = torch.randn((Np // 32, rows // 4, 32, 4), device=dev) * 1e-3
+        ws = torch.empty(int(lib.aon_wgrad_workspace_bytes()), dtype=torch.uint8, device=dev)
+        for kind, name, M, K, nl in ((0, "256x256", 256, 256, 8), (1, "128x128", 128, 128, 16), (2, "256x64", 256, 64, 16), (3, "128x256", 128, 256, 16), (4, "128x32", 128, 32, 16)):
+            def run():
+                rc = lib.aon_wgrad_kind_bench(kind, nl, planes.data_ptr(), dplanes.data_ptr(), rows, Np, ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream)
+                assert rc == 0, lib.aon_last_error()
+            ms = timeit(run, args.reps)
+            flops = 2.0 * M * K * Np * nl
+            print(json.dumps({"kernel": f"wgrad kind {name} x {nl} layers", "S": S, "ms": round(ms, 4), "tflops": round(flops / ms / 1e9, 2),
+                              "frac": round(flops / ms / 1e9 / 157.3, 4), "operand_GBs": round((M + K) * 4 * Np * nl / ms / 1e6, 1)}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rays", type=int, default=4096)
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--only", default="")
     ap.add_argument("--tag", default=os.environ.get("AON_HIP_LIB", "product"))
+    ap.add_argument("--wgrad-kinds", action="store_true", help="isolated rate of each weight-gradient job kind (aon_wgrad_kind_bench)")
     args = ap.parse_args()
+    if args.wgrad_kinds:
+        return wgrad_kinds(args)
     only = set(filter(None, args.only.split(",")))
     import aon_amd.synthetic as syn
     from aon_amd import ops
