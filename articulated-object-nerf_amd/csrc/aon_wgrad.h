@@ -149,6 +149,7 @@ __device__ __forceinline__ void wgrad_job(const WgArgs& a, const WgJob& J, char*
     const int d = 4 * k + wave;
     const char* g = (k < T::NGA / 8 ? gA + (int64_t)d * 1024 : gB + (int64_t)(d - T::NGA / 2) * 1024) + soff + ((k & 1) ? voff_o : voff_e);
     char* l = smem + stage * STAGE + d * 1024;
+    // (default cache policy: `nt` on these loads measured no different, 9.18 vs 9.22 ms for a 4096 x 193 level)
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (lds_void*)l, 16, 0, 0);
   };
 
@@ -457,15 +458,17 @@ struct WgLayerDesc {   // one nn.Linear weight (or a column block of one)
   float* bias_out;     // or null
 };
 
-// relative cost of one step of a job (matrix-pipe cycles of the busiest wave; the 128-wide kinds are bound by their operand
-// traffic per flop as much as by the pipe).  Tuned on MI355X, tools/kernel_bench.py --wgrad-kinds.
+// relative cost of one step of a job: 16,384 matrix-pipe cycles for a 256 x 256 job, the others scaled by their MEASURED time per
+// step and workgroup with the whole chip running one kind (tools/kernel_bench.py --wgrad-kinds, 4096 x 193 samples, two boxes:
+// 128x128 0.274-0.276, 256x64 0.298-0.301, 128x256 0.51-0.53, 128x32 0.107-0.108 of a 256x256 job).  The narrow kinds are bound
+// by operand traffic per flop (3.9-6.3 TB/s when they run alone), not by the pipe.
 inline double wg_cost(int kind) {
   switch (kind) {
     case kWg256x256: return 16384.0;
-    case kWg128x128: return 4096.0 * 1.10;
-    case kWg256x64: return 4096.0 * 1.20;
-    case kWg128x256: return 8192.0 * 1.05;
-    default: return 2600.0;   // kWg128x32: 1,024 matrix-pipe cycles per step, but 20 KB of operands -- DMA-bound
+    case kWg128x128: return 4500.0;
+    case kWg256x64: return 4900.0;
+    case kWg128x256: return 8500.0;
+    default: return 1800.0;   // kWg128x32: 1,024 matrix-pipe cycles per step, but 20 KB of operands -- DMA-bound
   }
 }
 

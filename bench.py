@@ -393,6 +393,11 @@ def main():
     sharded = None
     if not args.no_sharded_leg:
         own_group = False
+        # RCCL prints a version banner on C-level stdout when it comes up; this script's stdout carries ONE JSON line, so file
+        # descriptor 1 points at stderr while the leg runs (the banner would otherwise land behind the JSON at exit)
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
         try:
             from aon_amd.parallel import render_frame_sharded
 
@@ -427,6 +432,14 @@ def main():
         finally:
             if own_group and dist.is_initialized():
                 dist.destroy_process_group()
+            try:
+                import ctypes
+
+                ctypes.CDLL(None).fflush(None)   # the C library's buffered banner goes out while fd 1 is still stderr
+            except Exception:
+                pass
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
 
     train = None if args.no_train_leg else train_leg(dev, rank, world, distributed)
     # BASELINE configs 1 and 4 on this rank's GPU (informational, never `value`)

@@ -52,7 +52,7 @@ def wgrad_kinds(args):
                 assert rc == 0, lib.aon_last_error()
             ms = timeit(run, args.reps)
             flops = 2.0 * M * K * Np * nl
-            print(json.dumps({"kernel": f"wgrad kind {name} x {nl} layers", "S": S, "ms": round(ms, 4), "tflops": round(flops / ms / 1e9, 2),
+            print(json.dumps({"tag": args.tag, "kernel": f"wgrad kind {name} x {nl} layers", "S": S, "ms": round(ms, 4), "tflops": round(flops / ms / 1e9, 2),
                               "frac": round(flops / ms / 1e9 / 157.3, 4), "operand_GBs": round((M + K) * 4 * Np * nl / ms / 1e6, 1)}), flush=True)
 
 
