@@ -355,3 +355,104 @@ def test_two_call_step_equals_the_staged_entry_points(dev, nerf_sd):
     assert all(torch.equal(a, b) for a, b in zip(outs_a, outs_s))
     for k in grads_a:
         assert torch.equal(grads_a[k], grads_s[k]), k
+
+
+def _to_step_major(rows_view):
+    """(rows, Np) -> the step-major plane tensor (Np/32, rows/4, 32, 4) of include/aon_hip.h."""
+    rows, Np = rows_view.shape
+    return rows_view.reshape(rows // 4, 4, Np // 32, 32).permute(2, 0, 3, 1).contiguous()
+
+
+@pytest.mark.parametrize("net,n_samples", [("vanilla", 640), ("vanilla", 4096 * 3 + 128), ("articulated", 1152), ("articulated", 9984)])
+def test_grouped_wgrad_against_fp64_matmul(dev, net, n_samples):
+    """The grouped weight-gradient launch on RANDOM step-major planes against dW = dZ . H^T in fp64, every parameter of the network
+    -- all five job kinds (256x256, 128x128, 256x64, 128x256, 128x32), the head / bias / first-deformation-layer reductions, the
+    second stage, the latent outer products and latent gradients -- independent of the forward and the chain (round 3; until now
+    the weight gradients were only checked through whole-path gradients).  Also: the layout helpers are inverse to each other,
+    sample counts that leave trailing workgroups of a layer with a short range, and bit-equal repeats (no atomics)."""
+    import aon_amd.synthetic as syn
+    from aon_amd import ops
+
+    gen = torch.Generator().manual_seed(n_samples)
+    Np = n_samples
+    assert Np % 128 == 0
+    art = net == "articulated"
+    rows = 3456 if art else 2528
+    P = torch.randn(rows, Np, generator=gen)
+    D = torch.randn(rows, Np, generator=gen) * 0.1
+    d_raw = torch.randn(Np, 4, generator=gen) * 0.1
+    planes, dplanes = _to_step_major(P).to(dev), _to_step_major(D).to(dev)
+    assert torch.equal(ops.plane_rows_view(planes).cpu(), P)
+    P64, D64, R64 = P.double(), D.double(), d_raw.double()
+
+    def close(name, got, want, tol=2e-5):
+        err = (got.double().cpu() - want).abs().max().item() / max(want.abs().max().item(), 1e-30)
+        assert err <= tol, (name, err)
+
+    if not art:
+        g = ops.vanilla_wgrad(planes, dplanes, d_raw.to(dev))
+        g2 = ops.vanilla_wgrad(planes, dplanes, d_raw.to(dev))
+        assert all(torch.equal(g[k], g2[k]) for k in g)
+        E, VE = P64[0:63], P64[2368:2395]
+        H = lambda l: P64[64 + 256 * l: 64 + 256 * (l + 1)]
+        dZ = lambda l: D64[64 + 256 * l: 64 + 256 * (l + 1)]
+        close("pts_linears.0.weight", g["pts_linears.0.weight"], dZ(0) @ E.T)
+        close("pts_linears.0.bias", g["pts_linears.0.bias"], dZ(0).sum(1))
+        for l in range(1, 8):
+            want = dZ(l) @ H(l - 1).T
+            if l == 5:
+                want = torch.cat([want, dZ(5) @ E.T], 1)
+            close(f"pts_linears.{l}.weight", g[f"pts_linears.{l}.weight"], want)
+            close(f"pts_linears.{l}.bias", g[f"pts_linears.{l}.bias"], dZ(l).sum(1))
+        dbot, dhv, bott, hv = D64[2112:2368], D64[2400:2528], P64[2112:2368], P64[2400:2528]
+        close("bottleneck_layer.weight", g["bottleneck_layer.weight"], dbot @ H(7).T)
+        close("bottleneck_layer.bias", g["bottleneck_layer.bias"], dbot.sum(1))
+        close("views_linear.0.weight", g["views_linear.0.weight"], torch.cat([dhv @ bott.T, dhv @ VE.T], 1))
+        close("views_linear.0.bias", g["views_linear.0.bias"], dhv.sum(1))
+        close("density_layer.weight", g["density_layer.weight"], (H(7) @ R64[:, 3:4]).T)
+        close("density_layer.bias", g["density_layer.bias"], R64[:, 3].sum(0, keepdim=True))
+        close("rgb_layer.weight", g["rgb_layer.weight"], (hv @ R64[:, :3]).T)
+        close("rgb_layer.bias", g["rgb_layer.bias"], R64[:, :3].sum(0))
+        return
+    sd = {k[len("fine_mlp."):]: v.to(dev) for k, v in syn.make_art_state_dict(seed=2, density_scale=1.0).items() if k.startswith("fine_mlp.")}
+    lat = {"density": torch.randn(1, 128, generator=gen).to(dev), "color": torch.randn(1, 128, generator=gen).to(dev),
+           "articulation": torch.randn(1, 32, generator=gen).to(dev)}
+    dxp = torch.randn(Np, 4, generator=gen) * 0.1
+    g, gl = ops.art_wgrad(planes, dplanes, d_raw.to(dev), dxp.to(dev), sd, lat)
+    g2, gl2 = ops.art_wgrad(planes, dplanes, d_raw.to(dev), dxp.to(dev), sd, lat)
+    assert all(torch.equal(g[k], g2[k]) for k in g) and all(torch.equal(gl[k], gl2[k]) for k in gl)
+    X64 = dxp.double()
+    d_ = lambda l: slice(32 + 128 * l, 32 + 128 * (l + 1))
+    h_ = lambda l: slice(608 + 256 * l, 608 + 256 * (l + 1))
+    v_ = lambda l: slice(2944 + 128 * l, 2944 + 128 * (l + 1))
+    E, bot, VE, pos = P64[544:607], slice(2656, 2912), P64[2912:2939], P64[0:3]
+    shape, app, artc = (lat[k].double().cpu().reshape(-1) for k in ("density", "color", "articulation"))
+    db0 = D64[d_(0)].sum(1)
+    close("deformations_linear.0.weight", g["deformations_linear.0.weight"],
+          torch.cat([D64[d_(0)] @ pos.T, torch.outer(db0, shape), torch.outer(db0, artc)], 1))
+    close("deformations_linear.0.bias", g["deformations_linear.0.bias"], db0)
+    for l in range(1, 4):
+        close(f"deformations_linear.{l}.weight", g[f"deformations_linear.{l}.weight"], D64[d_(l)] @ P64[d_(l - 1)].T)
+        close(f"deformations_linear.{l}.bias", g[f"deformations_linear.{l}.bias"], D64[d_(l)].sum(1))
+        close(f"views_linear.{l}.weight", g[f"views_linear.{l}.weight"], D64[v_(l)] @ P64[v_(l - 1)].T)
+        close(f"views_linear.{l}.bias", g[f"views_linear.{l}.bias"], D64[v_(l)].sum(1))
+    close("deformation_layer.weight", g["deformation_layer.weight"], (P64[d_(3)] @ X64[:, :3]).T)
+    close("deformation_layer.bias", g["deformation_layer.bias"], X64[:, :3].sum(0))
+    db_t0, db_t5, db_v0 = D64[h_(0)].sum(1), D64[h_(5)].sum(1), D64[v_(0)].sum(1)
+    close("pts_linears.0.weight", g["pts_linears.0.weight"], torch.cat([D64[h_(0)] @ E.T, torch.outer(db_t0, shape)], 1))
+    for l in range(1, 8):
+        want = D64[h_(l)] @ P64[h_(l - 1)].T
+        if l == 5:
+            want = torch.cat([want, D64[h_(5)] @ E.T, torch.outer(db_t5, shape)], 1)
+        close(f"pts_linears.{l}.weight", g[f"pts_linears.{l}.weight"], want)
+        close(f"pts_linears.{l}.bias", g[f"pts_linears.{l}.bias"], D64[h_(l)].sum(1))
+    close("bottleneck_layer.weight", g["bottleneck_layer.weight"], D64[bot] @ P64[h_(7)].T)
+    close("views_linear.0.weight", g["views_linear.0.weight"], torch.cat([D64[v_(0)] @ P64[bot].T, D64[v_(0)] @ VE.T, torch.outer(db_v0, app)], 1))
+    close("density_layer.weight", g["density_layer.weight"], (P64[h_(7)] @ R64[:, 3:4]).T)
+    close("rgb_layer.weight", g["rgb_layer.weight"], (P64[v_(3)] @ R64[:, :3]).T)
+    close("rgb_layer.bias", g["rgb_layer.bias"], R64[:, :3].sum(0))
+    W = {k: v.double().cpu() for k, v in sd.items()}
+    close("latent density", gl["density"], W["deformations_linear.0.weight"][:, 3:131].T @ db0 + W["pts_linears.0.weight"][:, 63:191].T @ db_t0 +
+          W["pts_linears.5.weight"][:, 319:447].T @ db_t5)
+    close("latent color", gl["color"], W["views_linear.0.weight"][:, 283:411].T @ db_v0)
+    close("latent articulation", gl["articulation"], W["deformations_linear.0.weight"][:, 131:163].T @ db0)
