@@ -132,7 +132,10 @@ struct NoSide {
   __device__ __forceinline__ void operator()(int) const {}
 };
 
-template <class Net, int C, int NT_OUT, int NREG, class Side = NoSide>
+// ZERO_C: `out` holds nothing yet -- the first MFMA into each output tile takes the constant 0 as its C operand instead of the
+// tile, so a layer that starts from zero (the backward chains: dH = W^T dZ) needs no 128 accumulator writes per wave in front
+// of it, where no MFMA is in flight.  Same bits: fma(a, b, 0) is what the first step on a zeroed tile computes.
+template <class Net, int C, int NT_OUT, int NREG, class Side = NoSide, bool ZERO_C = false>
 __device__ __forceinline__ void chunk_mma(Pipe& p, const f32x16& in, f32x16 (&out)[NT_OUT], Side side = Side{}) {
   static_assert(Net::chunk_bytes(C) == NT_OUT * 4096, "chunk/out-tile mismatch");
   static_assert(NREG % 2 == 0 && NREG > 12, "register count");
@@ -161,20 +164,22 @@ __device__ __forceinline__ void chunk_mma(Pipe& p, const f32x16& in, f32x16 (&ou
     constexpr int SIDE_PER_STEP = NSTEP >= 16 ? 1 : (16 + NSTEP - 1) / NSTEP;
 #pragma unroll
     for (int k = 0; k < SIDE_PER_STEP; ++k) side(i * SIDE_PER_STEP + k);
-#ifndef AON_NO_PIN_VMEM
-    // Vector-memory instructions (the DMA round and the side job's plane store of this step) stay in this step: everything else
-    // -- MFMA, VALU, SALU, LDS -- may still cross (mask = all classes but VMEM).  Left free, hipcc's scheduler sinks the stores of
-    // a chunk to its END, i.e. right in front of the next pair's barrier, whose s_waitcnt vmcnt(0) then waits out the full store
-    // latency: 42 of the 55 barriers of the articulated backward chain had 2-12 stores within the 40 instructions before them,
-    // and the chain ran 9.51 ms against 7.86 ms without stores (round 3, tools/exp_train.sh).
-    __builtin_amdgcn_sched_barrier(0x78F);
-#endif
+    // (Round 3 experiment: a sched_barrier here that keeps this step's vector-memory instructions -- DMA round, plane store --
+    // inside the step while letting MFMA / VALU / LDS cross.  hipcc does sink a chunk's stores to its end, in front of the next
+    // pair's barrier, but pinning them changed nothing: forward 8.66 vs 8.61 ms, chains within 0.1 %.  Not kept.)
 #ifdef AON_PIN_PREFETCH   // per translation unit (build.py): keeps the read of step i+1 above the four MFMAs of step i
     __builtin_amdgcn_sched_barrier(0);
 #endif
 #pragma unroll
     for (int cc = 0; cc < 4; ++cc) {
-      if (4 * q + cc < NREG) out[tp] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[cc], in[4 * q + cc], out[tp], 0, 0, 0);
+      if (4 * q + cc < NREG) {
+        if (ZERO_C && q == 0 && cc == 0) {
+          const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          out[tp] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[cc], in[4 * q + cc], zero, 0, 0, 0);
+        } else {
+          out[tp] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[cc], in[4 * q + cc], out[tp], 0, 0, 0);
+        }
+      }
     }
     a_cur = a_nxt;
   }
@@ -229,9 +234,9 @@ struct NoSideOf {
   __device__ __forceinline__ NoSide operator()(int) const { return NoSide{}; }
 };
 
-template <class Net, int CBASE, int NT_IN, int NT_OUT, class SideOf = NoSideOf>
+template <class Net, int CBASE, int NT_IN, int NT_OUT, class SideOf = NoSideOf, bool ZERO_OUT = false>
 __device__ __forceinline__ void dense_layer(Pipe& p, const f32x16 (&in)[NT_IN], f32x16 (&out)[NT_OUT], SideOf side_of = SideOf{}) {
-  chunk_mma<Net, CBASE + 0, NT_OUT, 16>(p, in[0], out, side_of(0));
+  chunk_mma<Net, CBASE + 0, NT_OUT, 16, decltype(side_of(0)), ZERO_OUT>(p, in[0], out, side_of(0));
   chunk_mma<Net, CBASE + 1, NT_OUT, 16>(p, in[1], out, side_of(1));
   chunk_mma<Net, CBASE + 2, NT_OUT, 16>(p, in[2], out, side_of(2));
   chunk_mma<Net, CBASE + 3, NT_OUT, 16>(p, in[3], out, side_of(3));

@@ -244,8 +244,7 @@ __global__ void __launch_bounds__(256) mlp_bwd_chain_kernel(BwdArgs args) {
     // d bottleneck = W_view[:, :256]^T . dZ_view, dZ_view = view-layer ReLU mask . dHV   (model.py:109-116)
     mk_next = load_mask(7);
     apply_mask_tile(Z[0], mk, 0);
-    zero_tiles(X);
-    dense_layer<BwdNet, kBwView, 4, 8>(p, Z, X, BwdSideOf<4, true>{Z, kPlHV, io, mk});
+    dense_layer<BwdNet, kBwView, 4, 8, BwdSideOf<4, true>, true>(p, Z, X, BwdSideOf<4, true>{Z, kPlHV, io, mk});   // X starts from zero
     // dH7 = W_bott^T . dBot + W_sigma^T * d_sigma   (the bottleneck has no activation; the density head reads the
     // post-ReLU layer-7 output, model.py:105)
 #pragma unroll
@@ -261,8 +260,8 @@ __global__ void __launch_bounds__(256) mlp_bwd_chain_kernel(BwdArgs args) {
     // trunk: dZ_l = mask_l . dH_l (stored by the chunks that consume it), dH_{l-1} = W_l^T . dZ_l
 #define AON_BWD_LAYER(IN, OUT, CB, L)                                                                                  \
     mk = mk_next; if (L > 0) mk_next = load_mask(L - 1);                                                               \
-    apply_mask_tile(IN[0], mk, 0); zero_tiles(OUT);                                                                    \
-    dense_layer<BwdNet, CB, 8, 8>(p, IN, OUT, BwdSideOf<8, true>{IN, plane_h(L), io, mk});
+    apply_mask_tile(IN[0], mk, 0);                                                                                     \
+    dense_layer<BwdNet, CB, 8, 8, BwdSideOf<8, true>, true>(p, IN, OUT, BwdSideOf<8, true>{IN, plane_h(L), io, mk});   /* OUT starts from zero */
     AON_BWD_LAYER(Y, X, kBwL7 + 0, 7)
     AON_BWD_LAYER(X, Y, kBwL7 + 8, 6)
     AON_BWD_LAYER(Y, X, kBwL7 + 16, 5)

@@ -143,8 +143,8 @@ __global__ void __launch_bounds__(256) art_bwd_chain_kernel(ArtBwdArgs args) {
     // OUT = W^T . dZ
 #define AON_ABWD_LAYER(NT_IN, NT_OUT, IN, OUT, CB, ROW, NEXT_SLOT)                                                   \
     if (NEXT_SLOT >= 0) mk_next = load_mask(NEXT_SLOT);                                                               \
-    apply_mask_tile(IN[0], mk, 0); zero_tiles_a(OUT);                                                                \
-    dense_layer<N, CB, NT_IN, NT_OUT>(p, IN, OUT, BwdSideOf<NT_IN, true>{IN, ROW, io, mk});                          \
+    apply_mask_tile(IN[0], mk, 0);                                                                                   \
+    dense_layer<N, CB, NT_IN, NT_OUT, BwdSideOf<NT_IN, true>, true>(p, IN, OUT, BwdSideOf<NT_IN, true>{IN, ROW, io, mk});   /* OUT starts from zero */ \
     mk = mk_next;
     AON_ABWD_LAYER(4, 4, Z1, Z0, kABwV3 + 0, aplane_v(3), 14)
     AON_ABWD_LAYER(4, 4, Z0, Z1, kABwV3 + 4, aplane_v(2), 13)
@@ -175,16 +175,15 @@ __global__ void __launch_bounds__(256) art_bwd_chain_kernel(ArtBwdArgs args) {
     // Y = dH5 -> dZ5, consumed twice: by the skip-connection chunks (d enc += W5[:, 256:319]^T dZ5), which mask and store it,
     // then by layer 5's own transposed chunks
     f32x16 dE[2];
-    zero_tiles_a(dE);
     mk_next = load_mask(8);
     apply_mask_tile(Y[0], mk, 0);
-    dense_layer<N, kABwL5E, 8, 2>(p, Y, dE, BwdSideOf<8, true>{Y, aplane_h(5), io, mk});
+    dense_layer<N, kABwL5E, 8, 2, BwdSideOf<8, true>, true>(p, Y, dE, BwdSideOf<8, true>{Y, aplane_h(5), io, mk});   // dE starts from zero
     mk = mk_next;
     // The partial d enc (32 accumulator registers) would have to stay live across layers 5..1 on top of the two 128-register
     // activation sets; it is parked in the (otherwise unused) pos-enc rows of the gradient planes instead -- 128 B per lane out
     // and back per pass, against 13.8 KB of plane traffic -- rather than left to the register allocator's scratch spills.
     store_plane(dE, io, kAPlE);
-    zero_tiles_a(X); dense_layer<N, kABwL5 + 0, 8, 8>(p, Y, X);   // X = dH4
+    dense_layer<N, kABwL5 + 0, 8, 8, NoSideOf, true>(p, Y, X);   // X = dH4 (from zero)
     AON_ABWD_LAYER(8, 8, X, Y, kABwL5 + 8, aplane_h(4), 7)
     AON_ABWD_LAYER(8, 8, Y, X, kABwL5 + 16, aplane_h(3), 6)
     AON_ABWD_LAYER(8, 8, X, Y, kABwL5 + 24, aplane_h(2), 5)
