@@ -196,22 +196,46 @@ def render_leg(dev, kind, H, W, steps=3):
         return {"error": f"{type(e).__name__}: {e}"}
 
 
-def pmc_traffic():
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command
-    (profiles/*_pmc.json; FETCH_SIZE/WRITE_SIZE are in KiB, and on gfx950 FETCH_SIZE counts half the bytes of a
-    wide coalesced read -- MI355X_MICROARCH.md, HBM section -- hence the factor 2).  bench.py cannot run the profiler
-    on itself, so this is the last committed measurement, not a live one; null when no profile is present."""
+def _pmc_file():
+    """The newest committed rocprofv3 PMC summary of this same command (profiles/*_pmc.json), or (None, None)."""
     import glob
 
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")), reverse=True):
         try:
-            pmc = json.load(open(path))
-            k = next(v for name, v in pmc.items() if "mlp_fwd_kernel" in name)
-            traffic = (2.0 * k["FETCH_SIZE"]["avg_per_dispatch"] + k["WRITE_SIZE"]["avg_per_dispatch"]) * 1024.0
-            return {"traffic": traffic, "traffic_unit": "B/launch", "traffic_source": os.path.relpath(path, ROOT)}
+            return json.load(open(path)), os.path.relpath(path, ROOT)
         except Exception:
             continue
-    return {"traffic": None}
+    return None, None
+
+
+def _pmc_bytes(pmc, needle):
+    """HBM bytes per launch of the kernel whose name contains `needle`: FETCH_SIZE / WRITE_SIZE are in KiB, and on gfx950
+    FETCH_SIZE counts half the bytes of a wide coalesced read (MI355X_MICROARCH.md, HBM section), hence the factor 2."""
+    k = next(v for name, v in pmc.items() if needle in name)
+    return (2.0 * k["FETCH_SIZE"]["avg_per_dispatch"] + k["WRITE_SIZE"]["avg_per_dispatch"]) * 1024.0
+
+
+def pmc_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command.  bench.py
+    cannot run the profiler on itself, so this is the last committed measurement, not a live one; null when no profile is present."""
+    pmc, src = _pmc_file()
+    try:
+        return {"traffic": _pmc_bytes(pmc, "mlp_fwd_kernel"), "traffic_unit": "B/launch", "traffic_source": src}
+    except Exception:
+        return {"traffic": None}
+
+
+def pmc_traffic_ray_kernels(hbm):
+    """Same for the per-ray kernels of the headline region (`hbm_kernels`), each a frame-sized launch in the profiled command."""
+    pmc, src = _pmc_file()
+    for key, needle in (("coarse_fused", "composite_kernel<true, true, 65>"), ("composite", "composite_kernel<true, false, 193>"),
+                        ("sample_t", "sample_t4_kernel"), ("sample_pdf", "sample_pdf_kernel")):
+        if key in hbm and hbm[key] is not None:
+            try:
+                hbm[key].update({"traffic": _pmc_bytes(pmc, needle), "traffic_unit": "B/launch", "traffic_source": src})
+            except Exception:
+                pass
+    return hbm
 
 
 def train_leg(dev, rank, world, distributed, steps=6, n_rays=4096):
@@ -466,7 +490,7 @@ def main():
                          "whole_path_frac": rays_per_s / world * EVALS_PER_RAY * FLOP_PER_SAMPLE / (PEAK_FP32_MATRIX_TFLOPS * 1e12)},
         }
         res["roofline"].update(pmc_traffic())
-        res["hbm_kernels"] = per_ray_rooflines(headline_classes)   # the non-GEMM kernels of the same timed region (>= 50 % of HBM peak each)
+        res["hbm_kernels"] = pmc_traffic_ray_kernels(per_ray_rooflines(headline_classes))   # the non-GEMM kernels of the same timed region (>= 50 % of HBM peak each)
         if config1 is not None:
             res["config1"] = config1
         if art_render is not None:
