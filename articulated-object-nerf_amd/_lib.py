@@ -68,11 +68,12 @@ _SIGS = {
     "aon_art_bwd_chain": (_i, [_p, _p, _p, _p, _p, _p, _p, _l, _p]),
     "aon_art_wgrad": (_i, [_p, _p, _p, _p, _l, _p, _p, _p, _p, _p, _p, _p, _p, _p, _l, _p]),
     "aon_set_bwd_overlap": (_i, [_i]),
-    "aon_train_workspace_bytes": (_l, [_l, _i]),
+    "aon_train_workspace_bytes": (_l, [_l, _i, _i]),
+    "aon_train_scratch_bytes": (_l, [_l, _i, _i]),
     "aon_render_fwd_train": (_i, [_p, _p, _p, _p, _p, _l, _f, _f, _i, _i, _p, _p, _l, _p, _p, _p, _p, _p, _p, _p, _l, _p]),
-    "aon_render_bwd": (_i, [_p, _p, _p, _p, _p, _l, _i, _i, _p, _p, _p, _p, _p, _p, _l, _p]),
+    "aon_render_bwd": (_i, [_p, _p, _p, _p, _p, _l, _i, _i, _p, _p, _p, _p, _p, _p, _l, _p, _l, _p]),
     "aon_art_render_fwd_train": (_i, [_p, _p, _p, _p, _p, _p, _p, _l, _f, _f, _i, _i, _p, _p, _l, _p, _p, _p, _p, _p, _p, _p, _l, _p]),
-    "aon_art_render_bwd": (_i, [_p, _p, _p, _p, _p, _l, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _l, _p]),
+    "aon_art_render_bwd": (_i, [_p, _p, _p, _p, _p, _l, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _l, _p, _l, _p]),
     "aon_profile_begin": (_i, []),
     "aon_profile_end": (_i, [C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "aon_profile_class": (_i, [_i, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),

@@ -559,29 +559,36 @@ struct TrainLevel {
   char* masks;     // mask_layers*Np*32
   int S; int64_t Np;
 };
+// What the forward leaves for the backward (caller-owned, pinned by the autograd graph): per level t, raw, planes, ReLU bits.
 struct TrainWs {
   TrainLevel lvl[2];
   float* w_c;      // n*65 coarse weights
-  // backward temporaries, one set per level: the two levels' backward passes are independent and run on two streams
+  int64_t bytes;
+};
+// Backward-only temporaries (round 3: a separate `scratch` of aon_render_bwd, allocated when the backward runs -- round 2 carved
+// them into the forward's workspace, so every live graph pinned 26 GB instead of 15 GB at 4096 articulated rays), one set per
+// level: the two levels' backward passes are independent and run on two streams.
+struct TrainScratch {
   float* d_raw[2];    // Np*4
   float* dplanes[2];  // rows*Np
   float* dxp[2];      // Np*4 (articulated)
   float* wgrad_ws[2];
-  float* lat_tmp;  // 288 floats: second level's latent gradients before they are added (articulated)
+  float* lat_tmp;     // 288 floats: second level's latent gradients before they are added (articulated)
   int64_t bytes;
 };
 
-TrainWs carve_train(char* base, int64_t n, bool art) {
+int64_t level_np(int64_t n, int l) { return align_up(n * (l == 0 ? kSc : kSf), 128); }
+
+// both carves cover only the levels in use: num_levels = 1 (BASELINE config 1) takes a quarter of the two-level size
+TrainWs carve_train(char* base, int64_t n, bool art, int num_levels) {
   TrainWs w{};
   const int64_t rows = art ? aon::kAPlRows : aon::kPlRows;
   const int64_t mlayers = art ? aon::kAMaskLayers : aon::kMaskLayers;
   int64_t off = 0;
   auto take = [&](int64_t bytes) { char* p = base + off; off += align_up(bytes, 256); return p; };
-  int64_t np_max = 0;
-  for (int l = 0; l < 2; ++l) {
+  for (int l = 0; l < num_levels; ++l) {
     const int S = l == 0 ? kSc : kSf;
-    const int64_t Np = align_up(n * S, 128);
-    np_max = Np > np_max ? Np : np_max;
+    const int64_t Np = level_np(n, l);
     w.lvl[l].S = S; w.lvl[l].Np = Np;
     w.lvl[l].t = reinterpret_cast<float*>(take(n * S * 4));
     w.lvl[l].raw = reinterpret_cast<float*>(take(Np * 16));
@@ -589,16 +596,25 @@ TrainWs carve_train(char* base, int64_t n, bool art) {
     w.lvl[l].masks = take(mlayers * Np * 32);
   }
   w.w_c = reinterpret_cast<float*>(take(n * kSc * 4));
-  (void)np_max;
-  for (int l = 0; l < 2; ++l) {
-    w.d_raw[l] = reinterpret_cast<float*>(take(w.lvl[l].Np * 16));
-    w.dplanes[l] = reinterpret_cast<float*>(take(rows * w.lvl[l].Np * 4));
-    w.dxp[l] = reinterpret_cast<float*>(take(w.lvl[l].Np * 16));
-    w.wgrad_ws[l] = reinterpret_cast<float*>(take(aon::wgrad_workspace_bytes()));
-  }
-  w.lat_tmp = reinterpret_cast<float*>(take(288 * 4));
   w.bytes = off;
   return w;
+}
+
+TrainScratch carve_scratch(char* base, int64_t n, bool art, int num_levels) {
+  TrainScratch sc{};
+  const int64_t rows = art ? aon::kAPlRows : aon::kPlRows;
+  int64_t off = 0;
+  auto take = [&](int64_t bytes) { char* p = base + off; off += align_up(bytes, 256); return p; };
+  for (int l = 0; l < num_levels; ++l) {
+    const int64_t Np = level_np(n, l);
+    sc.d_raw[l] = reinterpret_cast<float*>(take(Np * 16));
+    sc.dplanes[l] = reinterpret_cast<float*>(take(rows * Np * 4));
+    sc.dxp[l] = reinterpret_cast<float*>(take(Np * 16));
+    sc.wgrad_ws[l] = reinterpret_cast<float*>(take(aon::wgrad_workspace_bytes()));
+  }
+  sc.lat_tmp = reinterpret_cast<float*>(take(288 * 4));
+  sc.bytes = off;
+  return sc;
 }
 
 __global__ void add_into_kernel(float* __restrict__ dst, const float* __restrict__ src, int n) {
@@ -682,7 +698,7 @@ int train_fwd_impl(const char* who, bool art, const TrainNet* nets, const float*
   if (n <= 0 || (num_levels != 1 && num_levels != 2)) return fail(AON_E_INVALID, "train forward: bad size / num_levels");
   if (!rays_o || !rays_d || !viewdirs || !workspace) return fail(AON_E_INVALID, "train forward: null pointer");
   if (reinterpret_cast<uintptr_t>(workspace) & 255) return fail(AON_E_INVALID, "train forward: workspace must be 256-byte aligned");
-  const TrainWs w = carve_train(static_cast<char*>(workspace), n, art);
+  const TrainWs w = carve_train(static_cast<char*>(workspace), n, art, num_levels);
   if (w.bytes > workspace_bytes) return fail(AON_E_WORKSPACE, "train forward: workspace smaller than aon_train_workspace_bytes()");
   if (num_levels == 2 && (!u || (u_stride != 0 && u_stride < 128))) return fail(AON_E_INVALID, "train forward: bad u / u_stride");
   const int act = art ? AON_ACT_ARTICULATED : AON_ACT_VANILLA;
@@ -728,9 +744,14 @@ int aon_set_bwd_overlap(int on) {
   return AON_OK;
 }
 
-int64_t aon_train_workspace_bytes(int64_t n_rays, int articulated) {
+int64_t aon_train_workspace_bytes(int64_t n_rays, int articulated, int num_levels) {
   if (n_rays < 1) n_rays = 1;
-  return carve_train(nullptr, n_rays, articulated != 0).bytes;
+  return carve_train(nullptr, n_rays, articulated != 0, num_levels == 1 ? 1 : 2).bytes;
+}
+
+int64_t aon_train_scratch_bytes(int64_t n_rays, int articulated, int num_levels) {
+  if (n_rays < 1) n_rays = 1;
+  return carve_scratch(nullptr, n_rays, articulated != 0, num_levels == 1 ? 1 : 2).bytes;
 }
 
 int aon_render_fwd_train(const void* packed_coarse, const void* packed_fine, const float* rays_o, const float* rays_d, const float* viewdirs,
@@ -757,12 +778,16 @@ int aon_art_render_fwd_train(const void* packed_coarse, const void* small_coarse
 int aon_render_bwd(const void* packed_bwd_coarse, const void* packed_fwd_coarse, const void* packed_bwd_fine, const void* packed_fwd_fine,
                    const float* rays_d, int64_t n_rays, int white_bkgd, int num_levels, const float* const* g_rgb_host,
                    const float* const* g_acc_host, const float* const* g_depth_host, float* const* grads_coarse_host,
-                   float* const* grads_fine_host, void* workspace, int64_t workspace_bytes, void* stream_) {
+                   float* const* grads_fine_host, void* workspace, int64_t workspace_bytes, void* scratch, int64_t scratch_bytes,
+                   void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (n_rays <= 0 || (num_levels != 1 && num_levels != 2)) return fail(AON_E_INVALID, "aon_render_bwd: bad size / num_levels");
-  if (!rays_d || !g_rgb_host || !workspace || !grads_coarse_host) return fail(AON_E_INVALID, "aon_render_bwd: null pointer");
-  const TrainWs w = carve_train(static_cast<char*>(workspace), n_rays, false);
+  if (!rays_d || !g_rgb_host || !workspace || !scratch || !grads_coarse_host) return fail(AON_E_INVALID, "aon_render_bwd: null pointer");
+  if (reinterpret_cast<uintptr_t>(scratch) & 255) return fail(AON_E_INVALID, "aon_render_bwd: scratch must be 256-byte aligned");
+  const TrainWs w = carve_train(static_cast<char*>(workspace), n_rays, false, num_levels);
   if (w.bytes > workspace_bytes) return fail(AON_E_WORKSPACE, "aon_render_bwd: workspace smaller than aon_train_workspace_bytes()");
+  const TrainScratch sc = carve_scratch(static_cast<char*>(scratch), n_rays, false, num_levels);
+  if (sc.bytes > scratch_bytes) return fail(AON_E_WORKSPACE, "aon_render_bwd: scratch smaller than aon_train_scratch_bytes()");
   const void* pb[2] = {packed_bwd_coarse, packed_bwd_fine};
   const void* pf[2] = {packed_fwd_coarse, packed_fwd_fine};
   float* const* grads[2] = {grads_coarse_host, grads_fine_host};
@@ -777,23 +802,23 @@ int aon_render_bwd(const void* packed_bwd_coarse, const void* packed_fwd_coarse,
     for (int i = 0; i < aon::kNumVanillaParams; ++i)
       if (!grads[l][i]) return fail(AON_E_INVALID, "aon_render_bwd: null gradient pointer");
     const int64_t valid = n_rays * L.S;
-    int rc = check(hipMemsetAsync(w.d_raw[l] + valid * 4, 0, (size_t)(L.Np - valid) * 16, stream), "aon_render_bwd");
+    int rc = check(hipMemsetAsync(sc.d_raw[l] + valid * 4, 0, (size_t)(L.Np - valid) * 16, stream), "aon_render_bwd");
     if (rc) return rc;
     {
       KTimer timer(kCompositeBwd, stream, n_rays);
       rc = check(aon::launch_composite_bwd(L.raw, L.t, rays_d, g_rgb_host[l], g_acc_host ? g_acc_host[l] : nullptr, g_depth_host ? g_depth_host[l] : nullptr,
-                                           n_rays, L.S, white_bkgd, AON_ACT_VANILLA, w.d_raw[l], stream), "aon_render_bwd");
+                                           n_rays, L.S, white_bkgd, AON_ACT_VANILLA, sc.d_raw[l], stream), "aon_render_bwd");
     }
     if (rc) return rc;
     {
       KTimer timer(kBwdChain, stream, L.Np);
-      rc = check(aon::launch_mlp_bwd_chain(static_cast<const char*>(pb[l]), static_cast<const char*>(pf[l]), w.d_raw[l], L.masks, w.dplanes[l], L.Np, stream),
+      rc = check(aon::launch_mlp_bwd_chain(static_cast<const char*>(pb[l]), static_cast<const char*>(pf[l]), sc.d_raw[l], L.masks, sc.dplanes[l], L.Np, stream),
                  "aon_render_bwd");
     }
     if (rc) return rc;
     {
       KTimer timer(kWgrad, stream, L.Np);
-      rc = check(aon::launch_vanilla_wgrad(L.planes, w.dplanes[l], w.d_raw[l], L.Np, grads[l], w.wgrad_ws[l], stream), "aon_render_bwd");
+      rc = check(aon::launch_vanilla_wgrad(L.planes, sc.dplanes[l], sc.d_raw[l], L.Np, grads[l], sc.wgrad_ws[l], stream), "aon_render_bwd");
     }
     if (rc) return rc;
   }
@@ -806,14 +831,17 @@ int aon_art_render_bwd(const void* packed_bwd_coarse, const void* small_coarse, 
                        const float* const* g_acc_host, const float* const* g_depth_host, const float* const* params_coarse_host,
                        const float* const* params_fine_host, const float* shape, const float* appearance, const float* articulation,
                        float* const* grads_coarse_host, float* const* grads_fine_host, float* g_shape, float* g_appearance,
-                       float* g_articulation, void* workspace, int64_t workspace_bytes, void* stream_) {
+                       float* g_articulation, void* workspace, int64_t workspace_bytes, void* scratch, int64_t scratch_bytes, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (n_rays <= 0 || (num_levels != 1 && num_levels != 2)) return fail(AON_E_INVALID, "aon_art_render_bwd: bad size / num_levels");
-  if (!rays_d || !g_rgb_host || !workspace || !grads_coarse_host || !params_coarse_host || !shape || !appearance || !articulation || !g_shape ||
-      !g_appearance || !g_articulation)
+  if (!rays_d || !g_rgb_host || !workspace || !scratch || !grads_coarse_host || !params_coarse_host || !shape || !appearance || !articulation ||
+      !g_shape || !g_appearance || !g_articulation)
     return fail(AON_E_INVALID, "aon_art_render_bwd: null pointer");
-  const TrainWs w = carve_train(static_cast<char*>(workspace), n_rays, true);
+  if (reinterpret_cast<uintptr_t>(scratch) & 255) return fail(AON_E_INVALID, "aon_art_render_bwd: scratch must be 256-byte aligned");
+  const TrainWs w = carve_train(static_cast<char*>(workspace), n_rays, true, num_levels);
   if (w.bytes > workspace_bytes) return fail(AON_E_WORKSPACE, "aon_art_render_bwd: workspace smaller than aon_train_workspace_bytes()");
+  const TrainScratch sc = carve_scratch(static_cast<char*>(scratch), n_rays, true, num_levels);
+  if (sc.bytes > scratch_bytes) return fail(AON_E_WORKSPACE, "aon_art_render_bwd: scratch smaller than aon_train_scratch_bytes()");
   const void* pb[2] = {packed_bwd_coarse, packed_bwd_fine};
   const float* sm[2] = {static_cast<const float*>(small_coarse), static_cast<const float*>(small_fine)};
   const float* const* params[2] = {params_coarse_host, params_fine_host};
@@ -829,34 +857,34 @@ int aon_art_render_bwd(const void* packed_bwd_coarse, const void* small_coarse, 
     for (int i = 0; i < 40; ++i)
       if (!grads[l][i] || !params[l][i]) return fail(AON_E_INVALID, "aon_art_render_bwd: null parameter / gradient pointer");
     const int64_t valid = n_rays * L.S;
-    int rc = check(hipMemsetAsync(w.d_raw[l] + valid * 4, 0, (size_t)(L.Np - valid) * 16, stream), "aon_art_render_bwd");
+    int rc = check(hipMemsetAsync(sc.d_raw[l] + valid * 4, 0, (size_t)(L.Np - valid) * 16, stream), "aon_art_render_bwd");
     if (rc) return rc;
     {
       KTimer timer(kCompositeBwd, stream, n_rays);
       rc = check(aon::launch_composite_bwd(L.raw, L.t, rays_d, g_rgb_host[l], g_acc_host ? g_acc_host[l] : nullptr, g_depth_host ? g_depth_host[l] : nullptr,
-                                           n_rays, L.S, white_bkgd, AON_ACT_ARTICULATED, w.d_raw[l], stream), "aon_art_render_bwd");
+                                           n_rays, L.S, white_bkgd, AON_ACT_ARTICULATED, sc.d_raw[l], stream), "aon_art_render_bwd");
     }
     if (rc) return rc;
     {
       KTimer timer(kBwdChain, stream, L.Np);
-      rc = check(aon::launch_art_bwd_chain(static_cast<const char*>(pb[l]), sm[l], w.d_raw[l], L.masks, L.planes, w.dplanes[l], w.dxp[l], L.Np, stream),
+      rc = check(aon::launch_art_bwd_chain(static_cast<const char*>(pb[l]), sm[l], sc.d_raw[l], L.masks, L.planes, sc.dplanes[l], sc.dxp[l], L.Np, stream),
                  "aon_art_render_bwd");
     }
     if (rc) return rc;
     {
       KTimer timer(kWgrad, stream, L.Np);
       // level 0 writes the latent gradients, level 1 adds its own (both MLPs see the same latents)
-      float* gs = l == 0 ? g_shape : w.lat_tmp, *ga = l == 0 ? g_appearance : w.lat_tmp + 128, *gt = l == 0 ? g_articulation : w.lat_tmp + 256;
-      rc = check(aon::launch_art_wgrad(L.planes, w.dplanes[l], w.d_raw[l], w.dxp[l], L.Np, params[l], shape, appearance, articulation, grads[l], gs, ga, gt,
-                                       w.wgrad_ws[l], stream), "aon_art_render_bwd");
+      float* gs = l == 0 ? g_shape : sc.lat_tmp, *ga = l == 0 ? g_appearance : sc.lat_tmp + 128, *gt = l == 0 ? g_articulation : sc.lat_tmp + 256;
+      rc = check(aon::launch_art_wgrad(L.planes, sc.dplanes[l], sc.d_raw[l], sc.dxp[l], L.Np, params[l], shape, appearance, articulation, grads[l], gs, ga, gt,
+                                       sc.wgrad_ws[l], stream), "aon_art_render_bwd");
     }
     if (rc) return rc;
   }
   if (int rc = fork.join()) return rc;   // the caller's stream continues after both levels
   if (num_levels == 2) {
-    add_into_kernel<<<dim3(1), dim3(128), 0, caller>>>(g_shape, w.lat_tmp, 128);
-    add_into_kernel<<<dim3(1), dim3(128), 0, caller>>>(g_appearance, w.lat_tmp + 128, 128);
-    add_into_kernel<<<dim3(1), dim3(32), 0, caller>>>(g_articulation, w.lat_tmp + 256, 32);
+    add_into_kernel<<<dim3(1), dim3(128), 0, caller>>>(g_shape, sc.lat_tmp, 128);
+    add_into_kernel<<<dim3(1), dim3(128), 0, caller>>>(g_appearance, sc.lat_tmp + 128, 128);
+    add_into_kernel<<<dim3(1), dim3(32), 0, caller>>>(g_articulation, sc.lat_tmp + 256, 32);
     return check(hipGetLastError(), "aon_art_render_bwd");
   }
   return AON_OK;

@@ -86,7 +86,13 @@ __device__ __forceinline__ void pipe_init(Pipe& p, const char* stream, char* rin
 template <class Net, int C>
 __device__ __forceinline__ unsigned acquire(Pipe& p) {
   if constexpr ((C & 1) == 0) {
+#if defined(AON_EXP_NOVMWAIT)    // timing experiment only (WRONG results): the barrier without waiting for this wave's DMA
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#elif defined(AON_EXP_NOBARRIER) // timing experiment only (WRONG results): the DMA wait without the workgroup barrier
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#else
     __syncthreads();  // drains this wave's LDS-DMA (vmcnt(0)) + workgroup barrier
+#endif
     p.slot ^= 1;
   }
   unsigned off = p.issue_off;

@@ -598,10 +598,16 @@ def set_bwd_overlap(on: bool) -> None:
     check(lib.aon_set_bwd_overlap(int(bool(on))), "aon_set_bwd_overlap")
 
 
-def train_workspace(device, n_rays: int, articulated: bool) -> torch.Tensor:
+def train_workspace(device, n_rays: int, articulated: bool, num_levels: int = 2) -> torch.Tensor:
     """Fresh workspace of one training forward/backward pair (it carries the forward's planes to the backward, so it is
-    owned by the autograd graph, not cached)."""
-    return torch.empty(int(lib.aon_train_workspace_bytes(n_rays, int(articulated))), dtype=torch.uint8, device=device)
+    owned by the autograd graph, not cached); sized by the levels in use."""
+    return torch.empty(int(lib.aon_train_workspace_bytes(n_rays, int(articulated), num_levels)), dtype=torch.uint8, device=device)
+
+
+def train_scratch(device, n_rays: int, articulated: bool, num_levels: int = 2) -> torch.Tensor:
+    """The backward's own temporaries (gradient planes, d_raw, weight-gradient partials): allocated when the backward runs and
+    handed back to torch's caching allocator right after, so a live graph pins the forward's workspace only."""
+    return torch.empty(int(lib.aon_train_scratch_bytes(n_rays, int(articulated), num_levels)), dtype=torch.uint8, device=device)
 
 
 def _level_outs(n, dev, num_levels):
@@ -620,7 +626,7 @@ def render_fwd_train(packed_c, packed_f, rays_o, rays_d, viewdirs, near, far, wh
         raise ValueError(f"t_rand must be ({n},65)")
     uu, us = _u_args(u, n, dev) if num_levels == 2 else (None, 0)
     outs, fine = _level_outs(n, dev, num_levels)
-    ws = train_workspace(dev, n, art)
+    ws = train_workspace(dev, n, art, num_levels)
     common = (_ptr(o), _ptr(d), _ptr(v), n, float(near), float(far), int(bool(white_bkgd)), num_levels, _ptr(tr), _ptr(uu), us,
               _ptr(outs[0][0]), _ptr(outs[0][1]), _ptr(outs[0][2]), _ptr(fine[0]), _ptr(fine[1]), _ptr(fine[2]), _ptr(ws), ws.numel(), _stream())
     with torch.cuda.device(dev):
@@ -645,10 +651,11 @@ def render_bwd(ws, packs_bwd, packs_fwd, rays_d, white_bkgd, num_levels, g_rgb, 
     pb, pf = list(packs_bwd) + [None] * (2 - num_levels), list(packs_fwd) + [None] * (2 - num_levels)
     keep = [None if t is None else _f32(t, "grad") for t in list(g_rgb) + list(g_acc) + list(g_depth)]
     k = num_levels
+    scratch = train_scratch(dev, n, False, num_levels)
     with torch.cuda.device(dev):
         check(lib.aon_render_bwd(_ptr(pb[0]), _ptr(pf[0]), _ptr(pb[1]), _ptr(pf[1]), _ptr(d), n, int(bool(white_bkgd)), num_levels,
                                  _ptr_array(keep[:k]), _ptr_array(keep[k:2 * k]), _ptr_array(keep[2 * k:3 * k]), garr[0], garr[1], _ptr(ws), ws.numel(),
-                                 _stream()), "aon_render_bwd")
+                                 _ptr(scratch), scratch.numel(), _stream()), "aon_render_bwd")
     return grads
 
 
@@ -669,11 +676,12 @@ def art_render_bwd(ws, packs_bwd, smalls, rays_d, white_bkgd, num_levels, g_rgb,
     g_lat = {"density": torch.empty(128, device=dev), "color": torch.empty(128, device=dev), "articulation": torch.empty(32, device=dev)}
     keep = [None if t is None else _f32(t, "grad") for t in list(g_rgb) + list(g_acc) + list(g_depth)]
     k = num_levels
+    scratch = train_scratch(dev, n, True, num_levels)
     with torch.cuda.device(dev):
         check(lib.aon_art_render_bwd(_ptr(pb[0]), _ptr(sm[0]), _ptr(pb[1]), _ptr(sm[1]), _ptr(d), n, int(bool(white_bkgd)), num_levels,
                                      _ptr_array(keep[:k]), _ptr_array(keep[k:2 * k]), _ptr_array(keep[2 * k:3 * k]), parr[0], parr[1],
                                      _ptr(shape), _ptr(app), _ptr(art), garr[0], garr[1], _ptr(g_lat["density"]), _ptr(g_lat["color"]),
-                                     _ptr(g_lat["articulation"]), _ptr(ws), ws.numel(), _stream()), "aon_art_render_bwd")
+                                     _ptr(g_lat["articulation"]), _ptr(ws), ws.numel(), _ptr(scratch), scratch.numel(), _stream()), "aon_art_render_bwd")
     return grads, g_lat
 
 

@@ -217,8 +217,11 @@ int aon_art_wgrad(const float* planes, const float* dplanes, const float* d_raw,
 /* ---- R14, the training step in two calls ----
  * aon_render_fwd_train = NeRF.forward under grad mode (model.py:147-199 as called by training_step :264): both levels,
  * same arguments and outputs as aon_render_fwd, plus everything the backward needs (per-level t values, raw outputs,
- * activation planes, ReLU bits, coarse weights) left in `workspace` (>= aon_train_workspace_bytes(n_rays, articulated),
- * 256-byte aligned; NOT to be touched until the backward ran).  aon_render_bwd = loss.backward() through that forward
+ * activation planes, ReLU bits, coarse weights) left in `workspace` (>= aon_train_workspace_bytes(n_rays, articulated,
+ * num_levels), 256-byte aligned; NOT to be touched until the backward ran: 15 GB at 4096 articulated rays and two levels, a
+ * quarter of that with one).  aon_render_bwd = loss.backward() through that forward; its temporaries (gradient planes,
+ * d_raw, weight-gradient partials: 11 GB) live in a separate `scratch` (>= aon_train_scratch_bytes(...), 256-byte aligned)
+ * that only has to exist during the call, so a live graph pins the forward's workspace alone.  aon_render_bwd
  * (model.py:271-282): given dL/d(comp_rgb, acc, depth) of each level (HOST arrays of num_levels device pointers; the acc /
  * depth arrays or their entries may be NULL) it writes all 24 parameter gradients per level (order of
  * aon_pack_vanilla_mlp, full nn.Linear shapes, overwritten).  packed_bwd_* from aon_pack_vanilla_mlp_bwd, packed_fwd_* the
@@ -230,7 +233,8 @@ int aon_art_wgrad(const float* planes, const float* dplanes, const float* d_raw,
  * `stream` and `stream` continues only after both (events) -- from the caller's view the call is enqueued on `stream`.
  * aon_set_bwd_overlap(0) keeps everything on `stream` (default 1). */
 int aon_set_bwd_overlap(int on);
-int64_t aon_train_workspace_bytes(int64_t n_rays, int articulated);
+int64_t aon_train_workspace_bytes(int64_t n_rays, int articulated, int num_levels);
+int64_t aon_train_scratch_bytes(int64_t n_rays, int articulated, int num_levels);
 int aon_render_fwd_train(const void* packed_coarse, const void* packed_fine, const float* rays_o, const float* rays_d,
                          const float* viewdirs, int64_t n_rays, float near_, float far_, int white_bkgd, int num_levels,
                          const float* t_rand, const float* u, int64_t u_stride, float* rgb_c, float* acc_c, float* depth_c,
@@ -239,7 +243,7 @@ int aon_render_bwd(const void* packed_bwd_coarse, const void* packed_fwd_coarse,
                    const void* packed_fwd_fine, const float* rays_d, int64_t n_rays, int white_bkgd, int num_levels,
                    const float* const* g_rgb_host, const float* const* g_acc_host, const float* const* g_depth_host,
                    float* const* grads_coarse_host, float* const* grads_fine_host, void* workspace,
-                   int64_t workspace_bytes, void* stream);
+                   int64_t workspace_bytes, void* scratch, int64_t scratch_bytes, void* stream);
 int aon_art_render_fwd_train(const void* packed_coarse, const void* small_coarse, const void* packed_fine,
                              const void* small_fine, const float* rays_o, const float* rays_d, const float* viewdirs,
                              int64_t n_rays, float near_, float far_, int white_bkgd, int num_levels, const float* t_rand,
@@ -251,7 +255,7 @@ int aon_art_render_bwd(const void* packed_bwd_coarse, const void* small_coarse, 
                        const float* const* params_coarse_host, const float* const* params_fine_host, const float* shape,
                        const float* appearance, const float* articulation, float* const* grads_coarse_host,
                        float* const* grads_fine_host, float* g_shape, float* g_appearance, float* g_articulation,
-                       void* workspace, int64_t workspace_bytes, void* stream);
+                       void* workspace, int64_t workspace_bytes, void* scratch, int64_t scratch_bytes, void* stream);
 
 /* ---- measurement aid (no reference counterpart) ----
  * Between aon_profile_begin() and aon_profile_end() every launch of the path's kernels made through this library is

@@ -88,18 +88,21 @@ def test_two_call_training_entries_validate_without_gpu():
     from aon_amd import _lib
 
     lib = _lib.lib
-    van, art = lib.aon_train_workspace_bytes(4096, 0), lib.aon_train_workspace_bytes(4096, 1)
+    van, art = lib.aon_train_workspace_bytes(4096, 0, 2), lib.aon_train_workspace_bytes(4096, 1, 2)
     planes_van = 2528 * (128 * ((4096 * 65 + 127) // 128) + 128 * ((4096 * 193 + 127) // 128)) * 4
-    assert van > planes_van and art > van and lib.aon_train_workspace_bytes(2048, 0) < van
+    assert van > planes_van and art > van and lib.aon_train_workspace_bytes(2048, 0, 2) < van
+    # sized by the levels in use: one level = the 65-sample share; the backward's temporaries are a separate scratch
+    assert lib.aon_train_workspace_bytes(4096, 1, 1) < 0.3 * art and lib.aon_train_scratch_bytes(4096, 1, 1) < 0.45 * lib.aon_train_scratch_bytes(4096, 1, 2)
+    assert 10e9 < lib.aon_train_scratch_bytes(4096, 1, 2) < 16e9 and 13e9 < art < 17e9
     assert lib.aon_render_fwd_train(None, None, None, None, None, 0, 2.0, 6.0, 1, 2, None, None, 0, None, None, None, None, None, None,
                                     None, 0, None) != 0 and b"bad size" in lib.aon_last_error()
     assert lib.aon_render_fwd_train(None, None, None, None, None, 8, 2.0, 6.0, 1, 3, None, None, 0, None, None, None, None, None, None,
                                     None, 0, None) != 0
     assert lib.aon_render_fwd_train(None, None, None, None, None, 8, 2.0, 6.0, 1, 2, None, None, 0, None, None, None, None, None, None,
                                     None, 0, None) != 0 and b"null" in lib.aon_last_error()
-    assert lib.aon_render_bwd(None, None, None, None, None, 8, 1, 2, None, None, None, None, None, None, 0, None) != 0 and b"null" in lib.aon_last_error()
+    assert lib.aon_render_bwd(None, None, None, None, None, 8, 1, 2, None, None, None, None, None, None, 0, None, 0, None) != 0 and b"null" in lib.aon_last_error()
     assert lib.aon_art_render_bwd(None, None, None, None, None, 0, 1, 2, None, None, None, None, None, None, None, None, None, None, None, None,
-                                  None, None, 0, None) != 0
+                                  None, None, 0, None, 0, None) != 0
     assert lib.aon_set_bwd_overlap(0) == 0 and lib.aon_set_bwd_overlap(1) == 0
     ms, n, u = C.c_double(-1), C.c_int64(-1), C.c_int64(-1)
     for cls in range(8):
