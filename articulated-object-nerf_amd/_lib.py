@@ -59,6 +59,7 @@ _SIGS = {
     "aon_composite_bwd": (_i, [_p, _p, _p, _p, _p, _p, _l, _i, _i, _i, _p, _p]),
     "aon_mlp_bwd_chain": (_i, [_p, _p, _p, _p, _p, _l, _p]),
     "aon_vanilla_wgrad": (_i, [_p, _p, _p, _l, _p, _p, _l, _p]),
+    "aon_wgrad_plan": (_i, [_i, _l, _i, _p, _i, _p]),
     "aon_wgrad_kind_bench": (_i, [_i, _i, _p, _p, _i, _l, _p, _l, _p]),
     "aon_art_train_plane_rows": (_l, []),
     "aon_art_train_mask_bytes": (_l, [_l]),

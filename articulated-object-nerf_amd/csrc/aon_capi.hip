@@ -35,6 +35,7 @@ int64_t bwd_stream_bytes();
 hipError_t launch_mlp_bwd_chain(const char* packed_bwd, const char* packed_fwd, const float* d_raw, const void* masks,
                                 float* dplanes, int64_t Np, hipStream_t stream);
 int64_t wgrad_workspace_bytes();
+int wgrad_plan_describe(bool art, int64_t Np, int cus, int32_t* out6, int max_jobs, int64_t* ws_bytes);
 hipError_t launch_wgrad_kind_bench(int kind, int nlayers, const float* planes, const float* dplanes, int rows_total, int64_t Np, float* ws,
                                    float* out_scratch, hipStream_t stream);
 hipError_t launch_vanilla_wgrad(const float* planes, const float* dplanes, const float* d_raw, int64_t Np, float* const* grads,
@@ -292,6 +293,14 @@ int aon_composite_pdf(const float* raw, const float* t_coarse, const float* dirs
 int64_t aon_train_plane_rows(void) { return aon::kPlRows; }
 int64_t aon_bwd_packed_bytes(void) { return aon::bwd_stream_bytes(); }
 int64_t aon_wgrad_workspace_bytes(void) { return aon::wgrad_workspace_bytes(); }
+
+int aon_wgrad_plan(int articulated, int64_t Np, int cus, int32_t* jobs6, int max_jobs, int64_t* ws_bytes) {
+  if (!jobs6 || max_jobs < 1) return fail(AON_E_INVALID, "aon_wgrad_plan: null / empty output");
+  const int n = aon::wgrad_plan_describe(articulated != 0, Np, cus, jobs6, max_jobs, ws_bytes);
+  if (n < 0) return fail(AON_E_INVALID, n == -1 ? "aon_wgrad_plan: Np must be a positive multiple of 32, cus >= 1"
+                                       : n == -2 ? "aon_wgrad_plan: no plan (fewer compute units than layers?)" : "aon_wgrad_plan: max_jobs too small");
+  return n;
+}
 
 int aon_wgrad_kind_bench(int kind, int nlayers, const float* planes, const float* dplanes, int rows, int64_t Np, void* workspace,
                          int64_t workspace_bytes, void* stream) {

@@ -104,10 +104,10 @@ constexpr int64_t kSmallBytes = kSmallFloats * 4;
 
 constexpr int64_t kPackedBytes = kStreamBytes + kSmallBytes;  // one packed MLP
 
-// Training: feature-major activation planes of one vanilla NeRFMLP level, plane[row * Np + sample] (Np = samples padded
-// to a multiple of 128).  Rows are TRUE feature indices (encodings: the reference's column order), so weight
-// gradients come out in nn.Linear's (out,in) order without un-permuting.  The same row map is used for the
-// pre-activation gradient planes written by the backward chain.
+// Training: ROW MAP of the activation planes of one vanilla NeRFMLP level (the memory layout of a row is step-major, see
+// aon_mlp_core.h: [step of 32 samples][row / 4][sample][row % 4]; Np = samples padded to a multiple of 128).  Rows are TRUE
+// feature indices (encodings: the reference's column order), so weight gradients come out in nn.Linear's (out,in) order
+// without un-permuting.  The same row map is used for the pre-activation gradient planes written by the backward chain.
 constexpr int kPlE = 0;                        // 64 rows: pos-enc (63 + zero pad)            input of L0 / L5 skip
 __host__ __device__ constexpr int plane_h(int l) { return 64 + 256 * l; }  // 8 x 256 rows: trunk outputs (post-ReLU)
 constexpr int kPlBot = 64 + 8 * 256;           // 256 rows: bottleneck output (no activation)

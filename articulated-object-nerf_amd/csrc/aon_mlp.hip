@@ -93,14 +93,14 @@ struct MlpArgs {
   int64_t total;             // n_rays*S
   int S;
   int npass;                 // ceil(total/128)
-  float* planes;             // [TRAIN] kPlRows x Np feature-major activation planes
+  float* planes;             // [TRAIN] kPlRows x Np activation planes, step-major (aon_mlp_core.h)
   u32x4* masks;              // [TRAIN] kMaskLayers x (Np*2) ReLU bit masks
   int64_t Np;                // npass * 128
 };
 
 constexpr int kLdsBytes = kRingBytes + (int)kSmallBytes;
 
-// TRAIN additionally stores every layer's input/output activations as feature-major planes for the backward pass.
+// TRAIN additionally stores every layer's input/output activations as step-major planes (aon_mlp_core.h) for the backward pass.
 template <bool ENC_IN_KERNEL, bool TRAIN>
 __global__ void __launch_bounds__(256) mlp_fwd_kernel(MlpArgs args) {
   static_assert(!TRAIN || ENC_IN_KERNEL, "the training path re-encodes from x[] / vd[], which only the in-kernel encoding fills");

@@ -2,17 +2,17 @@
 // models/vanilla_nerf/model.py:264-273 loss.backward()).  Gradients reach only the MLP parameters: t_samples is
 // detached (helper.py:249) and rays / t are data.
 //
-// Four kernels, all in the feature-major ("transposed") register/plane layout of the fused forward:
+// Kernels, all in the register layout of the fused forward (lane = sample, registers = features) and the step-major planes of
+// aon_mlp_core.h:
 //   composite_bwd_kernel   d(comp_rgb, acc, depth) -> d(raw rgb, raw sigma) per sample, one wavefront per ray.
 //   mlp_bwd_chain_kernel   the data-gradient chain rgb head -> view layer -> bottleneck (+sigma head) -> trunk 7..1,
 //                          register-resident exactly like the forward: dH_{l-1}^T = W_l^T . dZ_l^T with the
 //                          TRANSPOSED weights streamed as MFMA A operands and the gradient tiles as B operands;
-//                          writes every layer's pre-activation gradient dZ_l as a feature-major plane.
-//   wgrad_kernel           dW_l = dZ_l^T[M x N] . H_{l-1}^T[K x N]^T : both operands are planes whose contiguous axis
-//                          is the contraction axis (samples), so fragments are plain ds_read_b128; the sample range is
-//                          split across workgroups, each holding a full M x K accumulator block in registers, and a
-//                          deterministic second stage sums the per-workgroup partials (no atomics).
-//   head_wgrad_kernel      the 1- and 3-row head weights and all bias sums (row reductions of planes).
+//                          writes every layer's pre-activation gradient dZ_l to the gradient planes.
+//   wgrad_grouped_kernel   (aon_wgrad.h) dW_l = dZ_l^T[M x N] . H_{l-1}[N x K] for every layer of a level in one launch: the
+//                          sample range of each layer split over workgroups in proportion to its cost, each holding its
+//                          output block in accumulator registers; a deterministic second stage sums the partials (no atomics).
+//   head_wgrad_kernel      the 1- and 3-row head weights and all bias sums (plane rows x one 16-byte record per sample).
 #define AON_WGRAD_KERNELS
 #include "aon_wgrad.h"
 
@@ -360,9 +360,8 @@ hipError_t launch_wgrad_kind_bench(int kind, int nlayers, const float* planes, c
 }
 
 // grads: 24 device pointers in the parameter order of aon_pack_vanilla_mlp (each the full (out,in) / (out,) tensor), overwritten.
-hipError_t launch_vanilla_wgrad(const float* planes, const float* dplanes, const float* d_raw, int64_t Np, float* const* grads,
-                                float* ws, hipStream_t stream) {
-  WgLayerDesc L[12];
+// the weight-gradient jobs of one vanilla level
+int vanilla_wgrad_layers(float* const* grads, WgLayerDesc* L) {
   int n = 0;
   // trunk: dW_l = dZ_l . H_{l-1}^T  (+ the pos-enc columns for layers 0 and 5)
   L[n++] = WgLayerDesc{kWg256x64, plane_h(0), kPlE, grads[0], kPosEnc, 0, kPosEnc, grads[1]};
@@ -376,6 +375,13 @@ hipError_t launch_vanilla_wgrad(const float* planes, const float* dplanes, const
   // view layer: cat[bottleneck(256), viewenc(27)]: two column blocks of one weight
   L[n++] = WgLayerDesc{kWg128x256, kPlHV, kPlBot, grads[16], 256 + kViewEnc, 0, 256, grads[17]};
   L[n++] = WgLayerDesc{kWg128x32, kPlHV, kPlVE, grads[16], 256 + kViewEnc, 256, kViewEnc, nullptr};
+  return n;
+}
+
+hipError_t launch_vanilla_wgrad(const float* planes, const float* dplanes, const float* d_raw, int64_t Np, float* const* grads,
+                                float* ws, hipStream_t stream) {
+  WgLayerDesc L[kWgMaxJobs];
+  const int n = vanilla_wgrad_layers(grads, L);
   // heads and their biases: density_layer (1,256) <- H7 x d_raw.w, rgb_layer (3,128) <- HV x d_raw.xyz, bias sums of d_raw
   const HeadDesc H[3] = {{planes, plane_h(7), 256, d_raw, 128}, {planes, kPlHV, 128, d_raw, 128}, {nullptr, 0, 1, d_raw, 128}};
   const HeadOut O[4] = {{0, 256, 3, 1, 256, 1, grads[20]}, {0, 128, 0, 3, 128, 1, grads[22]}, {0, 1, 3, 1, 1, 1, grads[21]}, {0, 1, 0, 3, 1, 1, grads[23]}};
@@ -383,5 +389,27 @@ hipError_t launch_vanilla_wgrad(const float* planes, const float* dplanes, const
   return run_wgrad_plan(L, n, H, 3, O, OH, 4, planes, dplanes, kPlRows, Np, ws, stream);
 }
 
+int art_wgrad_layers(float* const* grads, WgLayerDesc* L);   // aon_train_art.hip
+
+// Host-only view of the plan a level would run on `cus` compute units (tests/test_abi_cpu.py checks its invariants without a
+// GPU): per job (kind, wg_begin, wg_count, steps per workgroup, partial offset in floats, partial count).
+int wgrad_plan_describe(bool art, int64_t Np, int cus, int32_t* out6, int max_jobs, int64_t* ws_bytes) {
+  if (Np <= 0 || (Np & 31) || cus < 1) return -1;
+  float* grads[40];   // >= both parameter counts (24 vanilla, 40 articulated)
+  for (int i = 0; i < 40; ++i) grads[i] = reinterpret_cast<float*>((uintptr_t)0x1000 + 64 * i);   // never dereferenced
+  WgLayerDesc L[kWgMaxJobs];
+  const int n = art ? art_wgrad_layers(grads, L) : vanilla_wgrad_layers(grads, L);
+  WgPlan plan;
+  if (!wg_make_plan(L, n, nullptr, nullptr, art ? kAPlRows : kPlRows, Np, cus < 304 ? cus : 304, nullptr, 0, plan)) return -2;
+  if (n > max_jobs) return -3;
+  for (int j = 0; j < n; ++j) {
+    const WgJob& J = plan.args.job[j];
+    const int per = (plan.args.nsteps + J.wg_count - 1) / J.wg_count;
+    int32_t* o = out6 + 6 * j;
+    o[0] = J.kind; o[1] = J.wg_begin; o[2] = J.wg_count; o[3] = per; o[4] = J.part_off; o[5] = J.wg_count * wg_nsplit(J.kind);
+  }
+  if (ws_bytes) *ws_bytes = plan.ws_floats * 4;
+  return n;
+}
 
 }  // namespace aon

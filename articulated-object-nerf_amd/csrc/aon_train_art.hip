@@ -333,12 +333,8 @@ hipError_t launch_art_bwd_chain(const char* packed_bwd, const float* small, cons
 hipError_t run_wgrad_plan(const WgLayerDesc* layers, int nlayers, const HeadDesc* heads, int nheads, const HeadOut* outs, const int* out_head, int nouts,
                           const float* planes, const float* dplanes, int rows_total, int64_t Np, float* ws, hipStream_t stream);   // aon_train.hip
 
-// grads: 40 parameter gradients (order of aon_pack_art_mlp, full shapes) + 3 latent gradients (shape 128, appearance 128,
-// articulation 32); params / latents: the forward's inputs (needed for the latent-column products).
-hipError_t launch_art_wgrad(const float* planes, const float* dplanes, const float* d_raw, const float* dxp, int64_t Np,
-                            const float* const* params, const float* shape, const float* app, const float* art,
-                            float* const* grads, float* g_shape, float* g_app, float* g_art, float* ws, hipStream_t stream) {
-  WgLayerDesc L[kWgMaxJobs];
+// the weight-gradient jobs of one articulated level
+int art_wgrad_layers(float* const* grads, WgLayerDesc* L) {
   int n = 0;
   // deformation MLP (model_autodecoder.py:196-203): layers 1..3 here; layer 0's three position columns go with the heads below
   // (its input is cat[pos(3), shape(128), articulation(32)]: a 16-byte record per sample, not a plane operand)
@@ -355,6 +351,16 @@ hipError_t launch_art_wgrad(const float* planes, const float* dplanes, const flo
   L[n++] = WgLayerDesc{kWg128x256, aplane_v(0), kAPlBot, grads[26], 411, 0, 256, grads[27]};
   L[n++] = WgLayerDesc{kWg128x32, aplane_v(0), kAPlVE, grads[26], 411, 256, kViewEnc, nullptr};
   for (int l = 1; l < 4; ++l) L[n++] = WgLayerDesc{kWg128x128, aplane_v(l), aplane_v(l - 1), grads[26 + 2 * l], 128, 0, 128, grads[27 + 2 * l]};
+  return n;
+}
+
+// grads: 40 parameter gradients (order of aon_pack_art_mlp, full shapes) + 3 latent gradients (shape 128, appearance 128,
+// articulation 32); params / latents: the forward's inputs (needed for the latent-column products).
+hipError_t launch_art_wgrad(const float* planes, const float* dplanes, const float* d_raw, const float* dxp, int64_t Np,
+                            const float* const* params, const float* shape, const float* app, const float* art,
+                            float* const* grads, float* g_shape, float* g_app, float* g_art, float* ws, hipStream_t stream) {
+  WgLayerDesc L[kWgMaxJobs];
+  const int n = art_wgrad_layers(grads, L);
   // heads: density (H7 x d_raw.w), rgb (V3 x d_raw.xyz), deformation_layer (D3 x dx'), their bias sums, and deformation layer 0:
   // dW[:, 0:3] = dZ_D0 x pos (the position is rows 0..2 of unit row kAPlPos / 4 of the forward planes), db = row sums of dZ_D0
   const int64_t unit_step = (int64_t)kAPlRows * 32;

@@ -542,8 +542,9 @@ inline bool wg_make_plan(const WgLayerDesc* layers, int nlayers, const float* pl
 
 inline int64_t wgrad_workspace_bytes_impl() {
   // one 256 x 256 partial per workgroup of a 256-CU launch at most, + the four-way partials of the narrow layers, bias
-  // partials, the extension blocks and the head partials: 80 MiB covers every plan wg_make_plan can produce for <= 304 CUs
-  return (int64_t)80 << 20;
+  // partials and the head partials: 70 MB for the articulated network on 256 CUs; 96 MiB covers every plan wg_make_plan can
+  // produce for <= 304 CUs (run_wgrad_plan checks the plan against it)
+  return (int64_t)96 << 20;
 }
 
 // rows x 4-channel reductions of a plane against a 16-byte record per sample (heads, biases)

@@ -116,7 +116,8 @@ def hbm_roofline(kernel, ms, launches, nbytes):
         return None
     tbs = nbytes / (ms * 1e-3) / 1e12
     return {"bound": "hbm", "kernel": kernel, "achieved": tbs * 1e3, "peak": PEAK_HBM_TBS * 1e3, "unit": "GB/s", "frac": tbs / PEAK_HBM_TBS,
-            "traffic": None, "launches": launches, "avg_launch_us": ms / launches * 1e3, "algorithmic_bytes": nbytes}
+            "traffic": None, "launches": launches, "avg_launch_us": ms / launches * 1e3, "algorithmic_bytes": nbytes,
+            "algorithmic_bytes_per_launch": nbytes / launches}
 
 
 def per_ray_rooflines(classes):

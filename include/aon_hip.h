@@ -190,6 +190,10 @@ int aon_mlp_bwd_chain(const void* packed_bwd, const void* packed_fwd, const floa
                       float* dplanes, int64_t Np, void* stream);
 int aon_vanilla_wgrad(const float* planes, const float* dplanes, const float* d_raw, int64_t Np,
                       float* const* grads_host, void* workspace, int64_t workspace_bytes, void* stream);
+/* Host-only: the plan aon_vanilla_wgrad / aon_art_wgrad would run for a level of Np samples on `cus` compute units -- per job six
+ * ints (kind, first workgroup, workgroups, 32-sample steps per workgroup, partial offset in floats, partials) -- and the workspace
+ * bytes it uses.  Returns the number of jobs (<= max_jobs) or a negative status.  No GPU needed (tests). */
+int aon_wgrad_plan(int articulated, int64_t Np, int cus, int32_t* jobs6, int max_jobs, int64_t* ws_bytes);
 /* Measurement aid: `nlayers` (<= 20) identical weight-gradient jobs of one kind (0: 256x256, 1: 128x128, 2: 256x64, 3: 128x256, 4: 128x32;
  * csrc/aon_wgrad.h) on arbitrary rows of two plane buffers, the grouped kernel only, partials left in the workspace. */
 int aon_wgrad_kind_bench(int kind, int nlayers, const float* planes, const float* dplanes, int rows, int64_t Np, void* workspace,

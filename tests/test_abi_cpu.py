@@ -115,3 +115,47 @@ def test_two_call_training_entries_validate_without_gpu():
     assert lib.aon_composite_pdf(None, None, None, 0, 1, 1, None, 0, None, None, None, None, None, None) == 0   # empty batch
     assert lib.aon_set_coarse_fusion(0) == 0 and lib.aon_set_coarse_fusion(1) == 0
     assert lib.aon_ray_radii(None, None, 8, 8, None, None) != 0 and b"null" in lib.aon_last_error()
+
+
+def test_wgrad_plan_invariants_without_gpu():
+    """The grouped weight-gradient launch's plan (csrc/aon_wgrad.h:wg_make_plan, host-only): for both networks, sample counts from
+    one pass to a 4096-ray fine level, and compute-unit counts from barely enough to 304 -- every job gets >= 1 workgroup, the
+    workgroups tile [0, total) without gaps, the launch never exceeds the compute units (ONE co-resident round), every workgroup has
+    a non-empty step range, partial regions do not overlap and fit aon_wgrad_workspace_bytes(), and the split follows the cost
+    model (a 256x256 job gets ~3.6x the workgroups of a 128x128 one)."""
+    import ctypes as C
+
+    from aon_amd import _lib
+
+    lib = _lib.lib
+    blk = {0: 256 * 256, 1: 128 * 128, 2: 256 * 64, 3: 128 * 256, 4: 128 * 32}
+    for art, njobs in ((0, 12), (1, 18)):
+        for Np in (128, 640, 4096 * 65 + 0, 128 * ((4096 * 193 + 127) // 128)):
+            if Np % 128:
+                Np += 128 - Np % 128
+            for cus in (njobs, 64, 255, 256, 304, 1000):
+                out = (C.c_int32 * (6 * 20))()
+                ws = C.c_int64(0)
+                n = lib.aon_wgrad_plan(art, Np, cus, out, 20, C.byref(ws))
+                assert n == njobs, (art, Np, cus, n, lib.aon_last_error())
+                jobs = [tuple(out[6 * j: 6 * j + 6]) for j in range(n)]
+                nsteps, nxt, regions = Np // 32, 0, []
+                for kind, wg_begin, wg_count, per, part_off, nparts in jobs:
+                    assert wg_begin == nxt and wg_count >= 1 and per >= 1
+                    assert (wg_count - 1) * per < nsteps <= wg_count * per          # every workgroup's range is non-empty, the last may be short
+                    nxt += wg_count
+                    regions.append((part_off, part_off + nparts * blk[kind]))
+                assert nxt <= min(cus, 304)
+                regions.sort()
+                assert all(a[1] <= b[0] for a, b in zip(regions, regions[1:])) and regions[0][0] >= 0
+                assert ws.value <= lib.aon_wgrad_workspace_bytes() and ws.value >= regions[-1][1] * 4
+                if cus == 256 and Np > 100_000:
+                    big = [j[2] for j in jobs if j[0] == 0]
+                    small = [j[2] for j in jobs if j[0] == 1]
+                    assert max(big) - min(big) <= 1 and nxt >= 250
+                    if small:
+                        assert 3.0 <= big[0] / small[0] <= 4.5
+    out = (C.c_int32 * 120)()
+    assert lib.aon_wgrad_plan(1, 100, 256, out, 20, None) < 0 and b"multiple of 32" in lib.aon_last_error()
+    assert lib.aon_wgrad_plan(1, 1024, 5, out, 20, None) < 0      # fewer compute units than layers: refused, not mis-planned
+    assert lib.aon_wgrad_plan(1, 1024, 256, out, 3, None) < 0
