@@ -38,8 +38,9 @@ int64_t wgrad_workspace_bytes();
 int wgrad_plan_describe(bool art, int64_t Np, int cus, int32_t* out6, int max_jobs, int64_t* ws_bytes);
 hipError_t launch_wgrad_kind_bench(int kind, int nlayers, const float* planes, const float* dplanes, int rows_total, int64_t Np, float* ws,
                                    float* out_scratch, hipStream_t stream);
+struct WgAux { hipStream_t stream; hipEvent_t fork, join; };   // aon_wgrad.h: optional side stream of a level's head reductions
 hipError_t launch_vanilla_wgrad(const float* planes, const float* dplanes, const float* d_raw, int64_t Np, float* const* grads,
-                                float* ws, hipStream_t stream);
+                                float* ws, hipStream_t stream, const WgAux* aux);
 hipError_t launch_art_mlp_fwd_train(const char* packed, const float* small, const float* rays_o, const float* rays_d,
                                     const float* viewdirs, const float* t_vals, int64_t n_rays, int S, float* raw, float* planes,
                                     void* masks, hipStream_t stream);
@@ -49,7 +50,7 @@ hipError_t launch_art_bwd_chain(const char* packed_bwd, const float* small, cons
                                 float* dplanes, float* dxp, int64_t Np, hipStream_t stream);
 hipError_t launch_art_wgrad(const float* planes, const float* dplanes, const float* d_raw, const float* dxp, int64_t Np,
                             const float* const* params, const float* shape, const float* app, const float* art,
-                            float* const* grads, float* g_shape, float* g_app, float* g_art, float* ws, hipStream_t stream);
+                            float* const* grads, float* g_shape, float* g_app, float* g_art, float* ws, hipStream_t stream, const WgAux* aux);
 hipError_t launch_raygen(const float* c2w, int H, int W, float focal, const float* directions, int64_t pix_begin,
                          int64_t pix_end, float* rays_o, float* viewdirs, float* rays_d, hipStream_t stream);
 hipError_t launch_ray_directions(int H, int W, float focal, float* out, hipStream_t stream);
@@ -362,7 +363,7 @@ int aon_vanilla_wgrad(const float* planes, const float* dplanes, const float* d_
     if (!grads_host[i]) return fail(AON_E_INVALID, "aon_vanilla_wgrad: null gradient pointer");
   if (workspace_bytes < aon::wgrad_workspace_bytes()) return fail(AON_E_WORKSPACE, "aon_vanilla_wgrad: workspace too small");
   KTimer timer(kWgrad, (hipStream_t)stream, Np);
-  return check(aon::launch_vanilla_wgrad(planes, dplanes, d_raw, Np, grads_host, static_cast<float*>(workspace), (hipStream_t)stream),
+  return check(aon::launch_vanilla_wgrad(planes, dplanes, d_raw, Np, grads_host, static_cast<float*>(workspace), (hipStream_t)stream, nullptr),
                "aon_vanilla_wgrad");
 }
 
@@ -414,7 +415,7 @@ int aon_art_wgrad(const float* planes, const float* dplanes, const float* d_raw,
   if (workspace_bytes < aon::wgrad_workspace_bytes()) return fail(AON_E_WORKSPACE, "aon_art_wgrad: workspace too small");
   KTimer timer(kWgrad, (hipStream_t)stream, Np);
   return check(aon::launch_art_wgrad(planes, dplanes, d_raw, dxp, Np, params_host, shape, appearance, articulation, grads_host, g_shape,
-                                     g_appearance, g_articulation, static_cast<float*>(workspace), (hipStream_t)stream), "aon_art_wgrad");
+                                     g_appearance, g_articulation, static_cast<float*>(workspace), (hipStream_t)stream, nullptr), "aon_art_wgrad");
 }
 
 int aon_profile_begin(void) {
@@ -637,6 +638,7 @@ __global__ void add_into_kernel(float* __restrict__ dst, const float* __restrict
 struct LevelStreams {
   hipStream_t s[2] = {nullptr, nullptr};
   hipEvent_t fork = nullptr, join[2] = {nullptr, nullptr};
+  aon::WgAux aux[2] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};   // per level: side stream of the head reductions
   std::mutex enqueue;   // held from the fork record to the join waits: the one event set is re-recorded by every call
 };
 LevelStreams* level_streams() {
@@ -650,6 +652,9 @@ LevelStreams* level_streams() {
     for (int i = 0; i < 2; ++i) {
       if (hipStreamCreateWithFlags(&ls.s[i], hipStreamNonBlocking) != hipSuccess) return nullptr;
       if (hipEventCreateWithFlags(&ls.join[i], hipEventDisableTiming) != hipSuccess) return nullptr;
+      if (hipStreamCreateWithFlags(&ls.aux[i].stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
+      if (hipEventCreateWithFlags(&ls.aux[i].fork, hipEventDisableTiming) != hipSuccess) return nullptr;
+      if (hipEventCreateWithFlags(&ls.aux[i].join, hipEventDisableTiming) != hipSuccess) return nullptr;
     }
     if (hipEventCreateWithFlags(&ls.fork, hipEventDisableTiming) != hipSuccess) return nullptr;
   }
@@ -675,6 +680,8 @@ class LevelFork {
   ~LevelFork() { (void)join(); }
   int rc() const { return rc_; }
   hipStream_t stream(int level) const { return forked_ ? ls_->s[level] : caller_; }
+  // side stream of a level's head reductions (only while this object holds the device's enqueue lock: the events are shared)
+  const aon::WgAux* aux(int level) const { return forked_ ? &ls_->aux[level] : nullptr; }
   int join() {
     if (!forked_) return AON_OK;
     forked_ = false;
@@ -827,7 +834,7 @@ int aon_render_bwd(const void* packed_bwd_coarse, const void* packed_fwd_coarse,
     if (rc) return rc;
     {
       KTimer timer(kWgrad, stream, L.Np);
-      rc = check(aon::launch_vanilla_wgrad(L.planes, sc.dplanes[l], sc.d_raw[l], L.Np, grads[l], sc.wgrad_ws[l], stream), "aon_render_bwd");
+      rc = check(aon::launch_vanilla_wgrad(L.planes, sc.dplanes[l], sc.d_raw[l], L.Np, grads[l], sc.wgrad_ws[l], stream, fork.aux(l)), "aon_render_bwd");
     }
     if (rc) return rc;
   }
@@ -885,7 +892,7 @@ int aon_art_render_bwd(const void* packed_bwd_coarse, const void* small_coarse, 
       // level 0 writes the latent gradients, level 1 adds its own (both MLPs see the same latents)
       float* gs = l == 0 ? g_shape : sc.lat_tmp, *ga = l == 0 ? g_appearance : sc.lat_tmp + 128, *gt = l == 0 ? g_articulation : sc.lat_tmp + 256;
       rc = check(aon::launch_art_wgrad(L.planes, sc.dplanes[l], sc.d_raw[l], sc.dxp[l], L.Np, params[l], shape, appearance, articulation, grads[l], gs, ga, gt,
-                                       sc.wgrad_ws[l], stream), "aon_art_render_bwd");
+                                       sc.wgrad_ws[l], stream, fork.aux(l)), "aon_art_render_bwd");
     }
     if (rc) return rc;
   }

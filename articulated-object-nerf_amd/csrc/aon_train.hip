@@ -311,7 +311,7 @@ int64_t wgrad_workspace_bytes() { return wgrad_workspace_bytes_impl(); }
 
 // Launch sequence shared by both networks: grouped weight gradients, heads, ONE second stage for both.
 hipError_t run_wgrad_plan(const WgLayerDesc* layers, int nlayers, const HeadDesc* heads, int nheads, const HeadOut* outs, const int* out_head, int nouts,
-                          const float* planes, const float* dplanes, int rows_total, int64_t Np, float* ws, hipStream_t stream) {
+                          const float* planes, const float* dplanes, int rows_total, int64_t Np, float* ws, hipStream_t stream, const WgAux* aux) {
   static DeviceOnce lds_once;
   if (hipError_t e = set_max_lds(&wgrad_grouped_kernel, kWgLdsBytes, lds_once); e != hipSuccess) return e;
   const int cus = num_cus();
@@ -330,10 +330,28 @@ hipError_t run_wgrad_plan(const WgLayerDesc* layers, int nlayers, const HeadDesc
   ReduceArgs& R = plan.red;
   R.nhead = nouts; R.nseg = nseg; R.head_blk_begin = plan.reduce_blocks;
   for (int o = 0; o < nouts; ++o) { R.head[o] = outs[o]; R.head[o].part_off = part_offs[out_head[o]]; }
-  wgrad_grouped_kernel<<<dim3(plan.total_wgs), dim3(256), kWgLdsBytes, stream>>>(plan.args);
-  if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
-  head_wgrad_kernel<<<dim3(head_blocks, nseg), dim3(256), 0, stream>>>(H);
-  if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
+  // the heads go first, on the side stream when there is one (their workgroups are resident before the weight-gradient launch
+  // fills every compute unit) and run beside it; the second stage waits for both
+  hipStream_t hs = aux ? aux->stream : stream;
+  if (aux) {
+    if (hipError_t e = hipEventRecord(aux->fork, stream); e != hipSuccess) return e;
+    if (hipError_t e = hipStreamWaitEvent(hs, aux->fork, 0); e != hipSuccess) return e;
+  }
+  head_wgrad_kernel<<<dim3(head_blocks, nseg), dim3(256), 0, hs>>>(H);
+  hipError_t err = hipGetLastError();
+  if (aux) {
+    const hipError_t e = hipEventRecord(aux->join, hs);
+    if (err == hipSuccess) err = e;
+  }
+  if (err == hipSuccess) {
+    wgrad_grouped_kernel<<<dim3(plan.total_wgs), dim3(256), kWgLdsBytes, stream>>>(plan.args);
+    err = hipGetLastError();
+  }
+  if (aux) {   // joined whatever happened above: the side stream never runs past the caller's view of this call
+    const hipError_t e = hipStreamWaitEvent(stream, aux->join, 0);
+    if (err == hipSuccess) err = e;
+  }
+  if (err != hipSuccess) return err;
   wgrad_reduce_kernel<<<dim3(plan.reduce_blocks + nouts), dim3(256), 0, stream>>>(R);
   return hipGetLastError();
 }
@@ -379,14 +397,14 @@ int vanilla_wgrad_layers(float* const* grads, WgLayerDesc* L) {
 }
 
 hipError_t launch_vanilla_wgrad(const float* planes, const float* dplanes, const float* d_raw, int64_t Np, float* const* grads,
-                                float* ws, hipStream_t stream) {
+                                float* ws, hipStream_t stream, const WgAux* aux) {
   WgLayerDesc L[kWgMaxJobs];
   const int n = vanilla_wgrad_layers(grads, L);
   // heads and their biases: density_layer (1,256) <- H7 x d_raw.w, rgb_layer (3,128) <- HV x d_raw.xyz, bias sums of d_raw
   const HeadDesc H[3] = {{planes, plane_h(7), 256, d_raw, 128}, {planes, kPlHV, 128, d_raw, 128}, {nullptr, 0, 1, d_raw, 128}};
   const HeadOut O[4] = {{0, 256, 3, 1, 256, 1, grads[20]}, {0, 128, 0, 3, 128, 1, grads[22]}, {0, 1, 3, 1, 1, 1, grads[21]}, {0, 1, 0, 3, 1, 1, grads[23]}};
   const int OH[4] = {0, 1, 2, 2};
-  return run_wgrad_plan(L, n, H, 3, O, OH, 4, planes, dplanes, kPlRows, Np, ws, stream);
+  return run_wgrad_plan(L, n, H, 3, O, OH, 4, planes, dplanes, kPlRows, Np, ws, stream, aux);
 }
 
 int art_wgrad_layers(float* const* grads, WgLayerDesc* L);   // aon_train_art.hip

@@ -331,7 +331,7 @@ hipError_t launch_art_bwd_chain(const char* packed_bwd, const float* small, cons
 }
 
 hipError_t run_wgrad_plan(const WgLayerDesc* layers, int nlayers, const HeadDesc* heads, int nheads, const HeadOut* outs, const int* out_head, int nouts,
-                          const float* planes, const float* dplanes, int rows_total, int64_t Np, float* ws, hipStream_t stream);   // aon_train.hip
+                          const float* planes, const float* dplanes, int rows_total, int64_t Np, float* ws, hipStream_t stream, const WgAux* aux);   // aon_train.hip
 
 // the weight-gradient jobs of one articulated level
 int art_wgrad_layers(float* const* grads, WgLayerDesc* L) {
@@ -358,7 +358,7 @@ int art_wgrad_layers(float* const* grads, WgLayerDesc* L) {
 // articulation 32); params / latents: the forward's inputs (needed for the latent-column products).
 hipError_t launch_art_wgrad(const float* planes, const float* dplanes, const float* d_raw, const float* dxp, int64_t Np,
                             const float* const* params, const float* shape, const float* app, const float* art,
-                            float* const* grads, float* g_shape, float* g_app, float* g_art, float* ws, hipStream_t stream) {
+                            float* const* grads, float* g_shape, float* g_app, float* g_art, float* ws, hipStream_t stream, const WgAux* aux) {
   WgLayerDesc L[kWgMaxJobs];
   const int n = art_wgrad_layers(grads, L);
   // heads: density (H7 x d_raw.w), rgb (V3 x d_raw.xyz), deformation_layer (D3 x dx'), their bias sums, and deformation layer 0:
@@ -371,7 +371,7 @@ hipError_t launch_art_wgrad(const float* planes, const float* dplanes, const flo
                         {0, 128, 0, 3, 128, 1, grads[8]},  {0, 1, 0, 3, 1, 1, grads[9]},
                         {0, 128, 0, 3, 1, 163, grads[0]},  {0, 128, 4, 1, 1, 1, grads[1]}};
   const int OH[8] = {0, 1, 2, 2, 3, 4, 5, 5};
-  if (hipError_t e = run_wgrad_plan(L, n, H, 6, O, OH, 8, planes, dplanes, kAPlRows, Np, ws, stream); e != hipSuccess) return e;
+  if (hipError_t e = run_wgrad_plan(L, n, H, 6, O, OH, 8, planes, dplanes, kAPlRows, Np, ws, stream, aux); e != hipSuccess) return e;
   // latent columns of the weights and the latent gradients, both from the bias gradients
   ArtFinishArgs F{};
   LatentJob& ls = F.lat[0];   // shape: deformation layer 0, trunk layers 0 and 5

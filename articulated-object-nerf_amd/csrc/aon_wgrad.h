@@ -555,6 +555,14 @@ inline void head_segments(int64_t Np, int& nseg, int64_t& seg_len) {
   nseg = (int)((Np + seg_len - 1) / seg_len);
 }
 
+// An optional side stream for the head reductions of a level (with its fork / join events): they are HBM-bound plane-row sums
+// with a small register / LDS footprint, so their workgroups fit next to the weight-gradient workgroups (384 of the 512 registers
+// per SIMD, 144 of the 160 KB of LDS) and run in their shadow instead of behind them.  Null: everything on one stream.
+struct WgAux {
+  hipStream_t stream;
+  hipEvent_t fork, join;
+};
+
 struct HeadDesc {
   const float* plane; int row; int rows;   // plane == null: record sums only (rows = 1)
   const float* vec; int64_t vec_step;
