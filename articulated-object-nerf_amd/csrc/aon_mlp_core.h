@@ -155,6 +155,12 @@ __device__ __forceinline__ void chunk_mma(Pipe& p, const f32x16& in, f32x16 (&ou
   // 0.915 of peak: a distance-2 prefetch pinned by sched_barrier(0) per step 0.900; this distance-1 read pinned above its
   // four MFMAs 0.891 -- which does pay in the vanilla backward chain, see AON_PIN_PREFETCH; ReLU applied lazily here on
   // the input tile instead of as a block between layers 0.869 -- 16 more live registers.)
+  // (Round 3: hipcc sinks the read of step i+1 from here to just in front of its own use -- `ds_read_b128; s_waitcnt lgkmcnt(0);
+  // 4 x v_mfma` -- in 32 % of the steps of the inference kernel and 71 % of the articulated chain's, and after any LDS-DMA
+  // instruction its waits are lgkmcnt(0) whatever is in flight (SIInsertWaitcnts' pending-FLAT state).  It does not matter: with
+  // the reads as inline asm, distance 1 enforced and `s_waitcnt lgkmcnt(1)` placed by hand the loop looked ideal in the ISA and
+  // ran SLOWER, 9.08 vs 8.65 ms for the one kernel that did not spill (the others lost 230-1,600 B/lane to the address
+  // registers): the four queued MFMAs of the previous step cover the LDS latency of a read issued right behind them.)
   f32x4 a_cur = *reinterpret_cast<const f32x4*>(buf);
 #pragma unroll
   for (int i = 0; i < NSTEP; ++i) {
