@@ -169,7 +169,7 @@ def test_art_training_step_full_size_properties(dev):
     t_rand, u = torch.rand(n, 65, device=dev, generator=g), torch.rand(n, 128, device=dev, generator=g)
     batch = {"instance_id": torch.tensor([0], device=dev), "articulation_id": torch.tensor([5], device=dev)}
 
-    def grads(perm=None):
+    def grads(perm=None, scale=1.0, reduce="mean"):
         model = NeRF_AE_Art().to(dev)
         model.load_state_dict(syn.make_art_state_dict(seed=0, density_scale=30.0))
         lib = CodeLibraryArticulated(types.SimpleNamespace(N_max_objs=1, N_obj_code_length=128)).to(dev)
@@ -178,7 +178,8 @@ def test_art_training_step_full_size_properties(dev):
         rays = {"rays_o": ro[sel].contiguous(), "rays_d": vd[sel].contiguous(), "viewdirs": vd[sel].contiguous()}
         tg, tr, uu = (target, t_rand, u) if perm is None else (target[perm], t_rand[perm], u[perm])
         out = model(rays, True, True, 2.0, 6.0, lib(batch), t_rand=tr, u=uu)
-        loss = torch.mean((out[0][0] - tg) ** 2) + torch.mean((out[1][0] - tg) ** 2)
+        red = torch.mean if reduce == "mean" else torch.sum
+        loss = scale * (red((out[0][0] - tg) ** 2) + red((out[1][0] - tg) ** 2))
         loss.backward()
         named = dict(model.named_parameters())
         named.update({"lib." + k: v for k, v in lib.named_parameters()})
@@ -194,3 +195,18 @@ def test_art_training_step_full_size_properties(dev):
     assert abs(l3 - l1) <= 1e-6 * max(1.0, abs(l1))
     for k in g1:   # (a bias gradient that is itself a cancelling sum of ~1e-8 gets an absolute floor)
         assert rel_l2(g3[k].cpu(), g1[k].cpu()) <= 1e-5 or (g3[k] - g1[k]).abs().max().item() <= 1e-9, k
+    # linearity in the upstream gradient (round 3): the whole backward -- compositing backward, chain, grouped weight gradients,
+    # heads, latent products -- is linear in dL/d(comp_rgb), and doubling is exact in fp32, so twice the loss gives EXACTLY twice
+    # every gradient (any data-dependent branch, atomics or uninitialised partial would break the bit equality)
+    _, g4 = grads(scale=2.0)
+    for k in g1:
+        assert torch.equal(g4[k], 2.0 * g1[k]), k
+    # additivity over rays: with a SUM loss the gradient of the batch is the sum of the gradients of its halves (different
+    # workgroup splits, different partial sums: fp32 summation order only)
+    half = n // 2
+    perm_a, perm_b = torch.arange(0, half, device=dev), torch.arange(half, n, device=dev)
+    _, ga = grads(perm_a, reduce="sum")
+    _, gb = grads(perm_b, reduce="sum")
+    _, gs = grads(reduce="sum")
+    for k in g1:
+        assert rel_l2((ga[k] + gb[k]).cpu(), gs[k].cpu()) <= 2e-5 or ((ga[k] + gb[k]) - gs[k]).abs().max().item() <= 1e-6, k
