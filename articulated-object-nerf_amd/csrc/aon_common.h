@@ -136,6 +136,20 @@ constexpr int kAMaskLayers = 16;                             // slots: D0..3 -> 
 //   22,23  rgb_layer.{weight,bias}
 constexpr int kNumVanillaParams = 24;
 
+// Output activations of a level (model.py:183-187, model_autodecoder.py:318-323) with the constructor's scalars as the reference's
+// fp32 tensor arithmetic sees them, shared by the compositing kernel and its backward:
+//   raw_sigma <- raw_sigma + noise * noise_std        when `noise` is given (the caller's torch.rand_like draw; model.py:183-184)
+//   act 1: rgb = sigmoid(raw), sigma = relu(raw_sigma)
+//   act 2: rgb = sigmoid(raw) * rgb_scale - rgb_shift  (rgb_scale = fp32(1 + 2 rgb_padding), rgb_shift = fp32(rgb_padding)),
+//          sigma = softplus(raw_sigma + sigma_bias)     (sigma_bias = fp32(density_bias))
+struct ActParams {
+  int act;
+  float rgb_scale, rgb_shift, sigma_bias;
+  const float* noise;   // (n*S,) or null
+  float noise_std;
+};
+inline ActParams default_act(int act) { return ActParams{act, 1.002f, 0.001f, -1.0f, nullptr, 0.f}; }
+
 // ------------------------------------------------------------------------------------------------
 // Host side.  A kernel's dynamic-LDS limit (hipFuncAttributeMaxDynamicSharedMemorySize) is a per-DEVICE function
 // attribute and the CU count is a per-device property: both are remembered per device ordinal, lock-free (a racing

@@ -119,7 +119,7 @@ hipError_t launch_ray_radii(const float* directions, const float* c2w, int H, in
 }
 
 // ---------------------------------------------------------------------------------------------
-// R3  stratified sampling   (models/vanilla_nerf/helper.py:106-133, lindisp=False)
+// R3  stratified sampling   (models/vanilla_nerf/helper.py:106-133, both branches of `lindisp`)
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ float linspace01(int idx, int steps) {
   // torch.linspace(0, 1, steps) (CPU kernel): step = 1/(steps-1); first half counts up from start,
@@ -128,23 +128,33 @@ __device__ __forceinline__ float linspace01(int idx, int steps) {
   return idx < steps / 2 ? __fmul_rn(step, (float)idx) : __fsub_rn(1.0f, __fmul_rn(step, (float)(steps - idx - 1)));
 }
 
-__device__ __forceinline__ float coarse_t(int idx, int steps, float near, float far) {
+// The planes of a level: near / far as the reference's fp32 tensor arithmetic sees its Python scalars, and -- lindisp, helper.py:117 --
+// fp32(1.0 / near), fp32(1.0 / far), which the reference evaluates in Python DOUBLE precision before they meet the tensor (so they are
+// the caller's to compute: from the fp32 `near` alone the last bit can differ).
+struct TRange {
+  float near, far, inv_near, inv_far;
+  int lindisp;
+};
+
+__device__ __forceinline__ float coarse_t(int idx, int steps, const TRange& r) {
   const float s = linspace01(idx, steps);
-  return __fadd_rn(__fmul_rn(near, __fsub_rn(1.0f, s)), __fmul_rn(far, s));  // near*(1-s) + far*s
+  if (r.lindisp)  // 1.0 / (1.0/near * (1 - s) + 1.0/far * s); `1.0 / tensor` is tensor.reciprocal() * 1.0: one IEEE division
+    return __fdiv_rn(1.0f, __fadd_rn(__fmul_rn(r.inv_near, __fsub_rn(1.0f, s)), __fmul_rn(r.inv_far, s)));
+  return __fadd_rn(__fmul_rn(r.near, __fsub_rn(1.0f, s)), __fmul_rn(r.far, s));  // near*(1-s) + far*s
 }
 
 __global__ void sample_along_rays_kernel(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
-                                         int64_t n_rays, int S, float near, float far,
+                                         int64_t n_rays, int S, TRange tr,
                                          const float* __restrict__ t_rand, float* __restrict__ t_vals,
                                          float* __restrict__ coords) {
   const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= n_rays * S) return;
   const int64_t ray = g / S;
   const int s = (int)(g - ray * S);
-  float t = coarse_t(s, S, near, far);
+  float t = coarse_t(s, S, tr);
   if (t_rand) {  // stratified jitter between interval mid-points (helper.py:122-127)
-    const float lo = s == 0 ? t : __fmul_rn(0.5f, __fadd_rn(t, coarse_t(s - 1, S, near, far)));
-    const float hi = s == S - 1 ? t : __fmul_rn(0.5f, __fadd_rn(coarse_t(s + 1, S, near, far), t));
+    const float lo = s == 0 ? t : __fmul_rn(0.5f, __fadd_rn(t, coarse_t(s - 1, S, tr)));
+    const float hi = s == S - 1 ? t : __fmul_rn(0.5f, __fadd_rn(coarse_t(s + 1, S, tr), t));
     t = __fadd_rn(lo, __fmul_rn(__fsub_rn(hi, lo), t_rand[g]));
   }
   t_vals[g] = t;
@@ -174,7 +184,7 @@ hipError_t launch_cast_rays(const float* t_vals, const float* o, const float* d,
 
 // The render / training paths want only t (the fused MLP kernels cast the rays themselves): four consecutive elements of the
 // flat (n*S) array per thread, one 16-byte store (and one 16-byte load of t_rand) each -- a pure streaming write.
-__global__ void sample_t4_kernel(int64_t total, int S, float near, float far, const float* __restrict__ t_rand, float* __restrict__ t_vals) {
+__global__ void sample_t4_kernel(int64_t total, int S, TRange tr, const float* __restrict__ t_rand, float* __restrict__ t_vals) {
   const int64_t g0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
   if (g0 >= total) return;
   int s = (int)(g0 % S);
@@ -191,10 +201,10 @@ __global__ void sample_t4_kernel(int64_t total, int S, float near, float far, co
   float v[4];
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
-    float t = coarse_t(s, S, near, far);
+    float t = coarse_t(s, S, tr);
     if (t_rand) {  // stratified jitter between interval mid-points (helper.py:122-127)
-      const float lo = s == 0 ? t : __fmul_rn(0.5f, __fadd_rn(t, coarse_t(s - 1, S, near, far)));
-      const float hi = s == S - 1 ? t : __fmul_rn(0.5f, __fadd_rn(coarse_t(s + 1, S, near, far), t));
+      const float lo = s == 0 ? t : __fmul_rn(0.5f, __fadd_rn(t, coarse_t(s - 1, S, tr)));
+      const float hi = s == S - 1 ? t : __fmul_rn(0.5f, __fadd_rn(coarse_t(s + 1, S, tr), t));
       t = __fadd_rn(lo, __fmul_rn(__fsub_rn(hi, lo), r[e]));
     }
     v[e] = t;
@@ -208,16 +218,18 @@ __global__ void sample_t4_kernel(int64_t total, int S, float near, float far, co
 }
 
 hipError_t launch_sample_along_rays(const float* rays_o, const float* rays_d, int64_t n_rays, int S, float near,
-                                    float far, const float* t_rand, float* t_vals, float* coords, hipStream_t stream) {
+                                    float far, const float* t_rand, float* t_vals, float* coords, hipStream_t stream,
+                                    int lindisp, float inv_near, float inv_far) {
   const int64_t n = n_rays * S;
   if (n <= 0) return hipSuccess;
+  const TRange tr{near, far, inv_near, inv_far, lindisp};
   const bool aligned = (reinterpret_cast<uintptr_t>(t_vals) & 15) == 0 && (reinterpret_cast<uintptr_t>(t_rand) & 15) == 0;
   if (!coords && aligned) {
     const int64_t threads = (n + 3) / 4;
-    sample_t4_kernel<<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream>>>(n, S, near, far, t_rand, t_vals);
+    sample_t4_kernel<<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream>>>(n, S, tr, t_rand, t_vals);
     return hipGetLastError();
   }
-  sample_along_rays_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream>>>(rays_o, rays_d, n_rays, S, near, far,
+  sample_along_rays_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream>>>(rays_o, rays_d, n_rays, S, tr,
                                                                                        t_rand, t_vals, coords);
   return hipGetLastError();
 }
@@ -280,7 +292,7 @@ struct CompositeArgs {
   const float* sigma;  int sigma_stride;  // 1 or 4
   const float* t_vals;  // (n,S)
   const float* dirs;    // (n,3)
-  int64_t n_rays; int S; int white_bkgd; int act;
+  int64_t n_rays; int S; int white_bkgd; ActParams ap;
   float* comp_rgb;  // (n,3)
   float* acc;       // (n,)
   float* depth;     // (n,)
@@ -328,16 +340,17 @@ __device__ __forceinline__ float softplus_f32(float x) {
   return __fadd_rn(__builtin_fmaxf(x, 0.f), __fmul_rn(z, p));
 }
 
-// output activations of the two networks on one (rgb, sigma) record; `act` is wave-uniform
-__device__ __forceinline__ void activate_record(int act, float& c0, float& c1, float& c2, float& sg) {
-  if (act == 1) {
+// output activations of the two networks on one (rgb, sigma) record of sample g; everything in `ap` is wave-uniform
+__device__ __forceinline__ void activate_record(const ActParams& ap, int64_t g, float& c0, float& c1, float& c2, float& sg) {
+  if (ap.noise) sg = __fadd_rn(sg, __fmul_rn(ap.noise[g], ap.noise_std));   // model.py:183-184
+  if (ap.act == 1) {
     sg = __builtin_fmaxf(sg, 0.f);
     c0 = sigmoid_f32(c0); c1 = sigmoid_f32(c1); c2 = sigmoid_f32(c2);
-  } else if (act == 2) {
-    sg = softplus_f32(__fadd_rn(sg, -1.0f));
-    c0 = __fsub_rn(__fmul_rn(sigmoid_f32(c0), 1.002f), 0.001f);
-    c1 = __fsub_rn(__fmul_rn(sigmoid_f32(c1), 1.002f), 0.001f);
-    c2 = __fsub_rn(__fmul_rn(sigmoid_f32(c2), 1.002f), 0.001f);
+  } else if (ap.act == 2) {
+    sg = softplus_f32(__fadd_rn(sg, ap.sigma_bias));
+    c0 = __fsub_rn(__fmul_rn(sigmoid_f32(c0), ap.rgb_scale), ap.rgb_shift);
+    c1 = __fsub_rn(__fmul_rn(sigmoid_f32(c1), ap.rgb_scale), ap.rgb_shift);
+    c2 = __fsub_rn(__fmul_rn(sigmoid_f32(c2), ap.rgb_scale), ap.rgb_shift);
   }
 }
 
@@ -388,7 +401,7 @@ __global__ void __launch_bounds__(256) composite_kernel(CompositeArgs a) {
   const int64_t ray = (int64_t)blockIdx.x * 4 + wv;
   if (ray >= a.n_rays) return;  // wave-uniform; no block-level barrier below
   const int S = SC ? SC : a.S, last = S - 1;
-  const int act = a.act;
+  const ActParams ap = a.ap;
   const float* tv = a.t_vals + ray * S;
   // the last sample's operands (same address in every lane: one request), in flight while the blocks run
   const int64_t gl = ray * S + last;
@@ -424,7 +437,7 @@ __global__ void __launch_bounds__(256) composite_kernel(CompositeArgs a) {
         sg = a.sigma[g * a.sigma_stride];
         c0 = a.rgb[g * a.rgb_stride + 0]; c1 = a.rgb[g * a.rgb_stride + 1]; c2 = a.rgb[g * a.rgb_stride + 2];
       }
-      activate_record(act, c0, c1, c2, sg);
+      activate_record(ap, g, c0, c1, c2, sg);
       alpha = __fsub_rn(1.0f, expf(-__fmul_rn(sg, dist)));
     }
     // T_i = prod_{j<i} (1 - alpha_j + 1e-10)   (helper.py:169-176)
@@ -445,7 +458,7 @@ __global__ void __launch_bounds__(256) composite_kernel(CompositeArgs a) {
     }
   }
   // the last sample: delta = 1e10 (helper.py:163), T = everything before it
-  activate_record(act, l0, l1, l2, lsg);
+  activate_record(ap, gl, l0, l1, l2, lsg);
   const float a_last = __fsub_rn(1.0f, expf(-__fmul_rn(lsg, __fmul_rn(1e10f, dn))));
   const float w_last = __fmul_rn(a_last, carry);
   if (a.weights && lane == 0) a.weights[gl] = w_last;
@@ -475,10 +488,10 @@ __global__ void __launch_bounds__(256) composite_kernel(CompositeArgs a) {
 }
 
 hipError_t launch_composite(const float* rgb, int rgb_stride, const float* sigma, int sigma_stride, const float* t_vals,
-                            const float* dirs, int64_t n_rays, int S, int white_bkgd, int act, float* comp_rgb,
+                            const float* dirs, int64_t n_rays, int S, int white_bkgd, const ActParams& ap, float* comp_rgb,
                             float* acc, float* depth, float* weights, hipStream_t stream) {
   if (n_rays <= 0) return hipSuccess;
-  CompositeArgs a{rgb, rgb_stride, sigma, sigma_stride, t_vals, dirs, n_rays, S, white_bkgd, act, comp_rgb, acc, depth, weights,
+  CompositeArgs a{rgb, rgb_stride, sigma, sigma_stride, t_vals, dirs, n_rays, S, white_bkgd, ap, comp_rgb, acc, depth, weights,
                   nullptr, 0, nullptr};
   const bool packed = rgb_stride == 4 && sigma_stride == 4 && sigma == rgb + 3 && (reinterpret_cast<uintptr_t>(rgb) & 15) == 0;
   const dim3 grid((unsigned)((n_rays + 3) / 4)), block(256);
@@ -492,11 +505,11 @@ hipError_t launch_composite(const float* rgb, int rgb_stride, const float* sigma
 // coarse level of NeRF.forward in one launch: compositing of the 65 coarse samples (outputs as launch_composite; `weights`
 // optional) + the 128 inverse-CDF draws from weights[..., 1:-1] over the mids of t_coarse + the sorted union -> t_fine (n,193).
 // `raw` are the MLP kernels' packed (rgb, sigma) records.
-hipError_t launch_composite_pdf(const float* raw, const float* t_coarse, const float* dirs, int64_t n_rays, int white_bkgd, int act,
+hipError_t launch_composite_pdf(const float* raw, const float* t_coarse, const float* dirs, int64_t n_rays, int white_bkgd, const ActParams& ap,
                                 const float* u, int64_t u_stride, float* comp_rgb, float* acc, float* depth, float* weights,
                                 float* t_fine, hipStream_t stream) {
   if (n_rays <= 0) return hipSuccess;
-  CompositeArgs a{raw, 4, raw + 3, 4, t_coarse, dirs, n_rays, 65, white_bkgd, act, comp_rgb, acc, depth, weights, u, u_stride, t_fine};
+  CompositeArgs a{raw, 4, raw + 3, 4, t_coarse, dirs, n_rays, 65, white_bkgd, ap, comp_rgb, acc, depth, weights, u, u_stride, t_fine};
   composite_kernel<true, true, 65><<<dim3((unsigned)((n_rays + 3) / 4)), dim3(256), 0, stream>>>(a);
   return hipGetLastError();
 }

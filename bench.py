@@ -198,10 +198,13 @@ def render_leg(dev, kind, H, W, steps=3):
 
 
 def _pmc_file():
-    """The newest committed rocprofv3 PMC summary of this same command (profiles/*_pmc.json), or (None, None)."""
+    """The newest committed rocprofv3 PMC summary of this same command (profiles/rNN_pmc.json -- NOT rNN_train_pmc.json, the
+    counters of the training kernels), or (None, None)."""
     import glob
+    import re
 
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")), reverse=True):
+    paths = [p for p in glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")) if re.fullmatch(r"r\d+_pmc\.json", os.path.basename(p))]
+    for path in sorted(paths, reverse=True):
         try:
             return json.load(open(path)), os.path.relpath(path, ROOT)
         except Exception:
