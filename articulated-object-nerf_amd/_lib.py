@@ -82,13 +82,37 @@ _SIGS = {
     "aon_set_coarse_fusion": (_i, [_i]),
     "aon_render_workspace_bytes": (_l, [_l]),
     "aon_render_fwd": (_i, [_p, _p, _p, _p, _p, _l, _f, _f, _i, _i, _p, _p, _l, _p, _p, _p, _p, _p, _p, _p, _l, _p]),
+    # constructor arguments beyond the defaults (aon_render_opts; the *_ex forms take the struct pointer last)
+    "aon_render_opts_init": (None, [_p]),
+    "aon_sample_along_rays_ex": (_i, [_p, _p, _l, _i, _f, _f, _i, _f, _f, _p, _p, _p, _p]),
+    "aon_composite_ex": (_i, [_p, _i, _p, _i, _p, _p, _l, _i, _i, _i, _p, _p, _p, _p, _p, _p]),
+    "aon_sample_pdf_n": (_i, [_p, _p, _l, _p, _p, _l, _l, _i, _i, _i, _p, _p, _p]),
+    "aon_render_workspace_bytes_ex": (_l, [_l, _p]),
+    "aon_render_fwd_ex": (_i, [_p, _p, _p, _p, _p, _l, _f, _f, _i, _i, _p, _p, _l, _p, _p, _p, _p, _p, _p, _p, _l, _p, _p]),
+    "aon_art_render_fwd_ex": (_i, [_p, _p, _p, _p, _p, _p, _p, _l, _f, _f, _i, _i, _p, _p, _l, _p, _p, _p, _p, _p, _p, _p, _l, _p, _p]),
+    "aon_train_workspace_bytes_ex": (_l, [_l, _i, _i, _p]),
+    "aon_train_scratch_bytes_ex": (_l, [_l, _i, _i, _p]),
+    "aon_render_fwd_train_ex": (_i, [_p, _p, _p, _p, _p, _l, _f, _f, _i, _i, _p, _p, _l, _p, _p, _p, _p, _p, _p, _p, _l, _p, _p]),
+    "aon_render_bwd_ex": (_i, [_p, _p, _p, _p, _p, _l, _i, _i, _p, _p, _p, _p, _p, _p, _l, _p, _l, _p, _p]),
+    "aon_art_render_fwd_train_ex": (_i, [_p, _p, _p, _p, _p, _p, _p, _l, _f, _f, _i, _i, _p, _p, _l, _p, _p, _p, _p, _p, _p, _p, _l, _p, _p]),
+    "aon_art_render_bwd_ex": (_i, [_p, _p, _p, _p, _p, _l, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _l, _p, _l, _p, _p]),
 }
+
+
+class RenderOptsC(C.Structure):
+    """aon_render_opts (include/aon_hip.h)."""
+    _fields_ = [("num_coarse_samples", C.c_int32), ("num_fine_samples", C.c_int32), ("lindisp", C.c_int32),
+                ("inv_near", C.c_float), ("inv_far", C.c_float), ("noise_std", C.c_float),
+                ("noise_c", C.c_void_p), ("noise_f", C.c_void_p),
+                ("rgb_scale", C.c_float), ("rgb_shift", C.c_float), ("sigma_bias", C.c_float)]
+
+
 for _name, (_res, _args) in _SIGS.items():
     _fn = getattr(lib, _name)  # AttributeError here = the .so does not export what the header declares
     _fn.restype = _res
     _fn.argtypes = _args
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 if lib.aon_abi_version() != ABI_VERSION:
     raise ImportError(f"libaon_hip.so ABI {lib.aon_abi_version()} != binding ABI {ABI_VERSION}; rebuild")
 

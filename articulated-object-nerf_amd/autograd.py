@@ -21,14 +21,14 @@ def _check_not_released(ctx):
 
 class RenderVanilla(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, rays_o, rays_d, viewdirs, near, far, white_bkgd, num_levels, t_rand, u, packs, *params):
+    def forward(ctx, rays_o, rays_d, viewdirs, near, far, white_bkgd, num_levels, t_rand, u, packs, opts, noise, *params):
         # packs: [(packed_fwd, packed_bwd)] per level; params: 24 tensors per level in ops.VANILLA_PARAM_ORDER.  The whole
         # forward is ONE C call (aon_render_fwd_train); the backward chain reads the forward stream for its head weights.
         ctx.rays_d = rays_d
         ctx.white_bkgd = white_bkgd
         ctx.num_levels = num_levels
-        levels, ws = ops.render_fwd_train(packs[0][0], packs[1][0] if num_levels == 2 else None, rays_o, rays_d, viewdirs, near, far,
-                                          white_bkgd, num_levels, t_rand, u)
+        levels, ws, ctx.geometry = ops.render_fwd_train(packs[0][0], packs[1][0] if num_levels == 2 else None, rays_o, rays_d, viewdirs, near, far,
+                                                        white_bkgd, num_levels, t_rand, u, opts=opts, noise=noise)
         ctx.fused = (ws, [pk[1] for pk in packs], [pk[0] for pk in packs])
         return tuple(x for lvl in levels for x in lvl)
 
@@ -40,24 +40,26 @@ class RenderVanilla(torch.autograd.Function):
         g_rgb = [gouts[3 * l] if gouts[3 * l] is not None else torch.zeros((n, 3), dtype=torch.float32, device=ctx.rays_d.device)
                  for l in range(ctx.num_levels)]
         per_level = ops.render_bwd(ws, packs_bwd, packs_fwd, ctx.rays_d, ctx.white_bkgd, ctx.num_levels, g_rgb,
-                                   [gouts[3 * l + 1] for l in range(ctx.num_levels)], [gouts[3 * l + 2] for l in range(ctx.num_levels)])
-        ctx.fused, ctx.released = None, True
-        return (None,) * 10 + tuple(g[name] for g in per_level for name in ops.VANILLA_PARAM_ORDER)
+                                   [gouts[3 * l + 1] for l in range(ctx.num_levels)], [gouts[3 * l + 2] for l in range(ctx.num_levels)],
+                                   geometry=ctx.geometry)
+        ctx.fused, ctx.released, ctx.geometry = None, True, None
+        return (None,) * 12 + tuple(g[name] for g in per_level for name in ops.VANILLA_PARAM_ORDER)
 
 
 class RenderArticulated(torch.autograd.Function):
     """NeRF_AE_Art.forward with gradients to the 2 x 40 MLP parameters and the three latents."""
 
     @staticmethod
-    def forward(ctx, rays_o, rays_d, viewdirs, near, far, white_bkgd, num_levels, t_rand, u, packs, lat_density, lat_color,
+    def forward(ctx, rays_o, rays_d, viewdirs, near, far, white_bkgd, num_levels, t_rand, u, packs, opts, noise, lat_density, lat_color,
                 lat_articulation, *params):
         # packs: per level (packed_fwd, small, packed_bwd); params: 40 tensors per level in ops.ART_PARAM_ORDER
         ctx.rays_d, ctx.white_bkgd, ctx.num_levels = rays_d, white_bkgd, num_levels
         ctx.latents = {"density": lat_density.detach(), "color": lat_color.detach(), "articulation": lat_articulation.detach()}
         ctx.lat_shapes = (lat_density.shape, lat_color.shape, lat_articulation.shape)
         ctx.params = [p.detach() for p in params]
-        levels, ws = ops.render_fwd_train(packs[0][0], packs[1][0] if num_levels == 2 else None, rays_o, rays_d, viewdirs, near, far,
-                                          white_bkgd, num_levels, t_rand, u, small_c=packs[0][1], small_f=packs[1][1] if num_levels == 2 else None)
+        levels, ws, ctx.geometry = ops.render_fwd_train(packs[0][0], packs[1][0] if num_levels == 2 else None, rays_o, rays_d, viewdirs, near, far,
+                                                        white_bkgd, num_levels, t_rand, u, small_c=packs[0][1],
+                                                        small_f=packs[1][1] if num_levels == 2 else None, opts=opts, noise=noise)
         ctx.fused = (ws, [pk[2] for pk in packs], [pk[1] for pk in packs])   # ONE C call (aon_art_render_fwd_train)
         return tuple(x for lvl in levels for x in lvl)
 
@@ -72,7 +74,7 @@ class RenderArticulated(torch.autograd.Function):
         params = [dict(zip(ops.ART_PARAM_ORDER, ctx.params[l * n_per: (l + 1) * n_per])) for l in range(ctx.num_levels)]
         per_level, g_lat = ops.art_render_bwd(ws, packs_bwd, smalls, ctx.rays_d, ctx.white_bkgd, ctx.num_levels, g_rgb,
                                               [gouts[3 * l + 1] for l in range(ctx.num_levels)], [gouts[3 * l + 2] for l in range(ctx.num_levels)],
-                                              params, ctx.latents)
-        ctx.fused, ctx.released = None, True
+                                              params, ctx.latents, geometry=ctx.geometry)
+        ctx.fused, ctx.released, ctx.geometry = None, True, None
         lat = tuple(g_lat[k].reshape(shp) for k, shp in zip(("density", "color", "articulation"), ctx.lat_shapes))
-        return (None,) * 10 + lat + tuple(g[name] for g in per_level for name in ops.ART_PARAM_ORDER)
+        return (None,) * 12 + lat + tuple(g[name] for g in per_level for name in ops.ART_PARAM_ORDER)

@@ -28,7 +28,7 @@ hipError_t launch_mlp_fwd_train(const char* packed, const float* rays_o, const f
                                 const float* t_vals, int64_t n_rays, int S, float* raw, float* planes, void* masks,
                                 hipStream_t stream);
 hipError_t launch_composite_bwd(const float* raw, const float* t_vals, const float* dirs, const float* g_rgb, const float* g_acc,
-                                const float* g_depth, int64_t n_rays, int S, int white_bkgd, int act, float* d_raw,
+                                const float* g_depth, int64_t n_rays, int S, int white_bkgd, const ActParams& ap, float* d_raw,
                                 hipStream_t stream);
 hipError_t launch_pack_vanilla_bwd(const float* const* params, float* packed, hipStream_t stream);
 int64_t bwd_stream_bytes();
@@ -58,17 +58,21 @@ hipError_t launch_ray_radii(const float* directions, const float* c2w, int H, in
 hipError_t launch_cast_rays(const float* t_vals, const float* o, const float* d, int64_t n_rays, int S, float* coords,
                             hipStream_t stream);
 hipError_t launch_sample_along_rays(const float* rays_o, const float* rays_d, int64_t n_rays, int S, float near, float far,
-                                    const float* t_rand, float* t_vals, float* coords, hipStream_t stream);
+                                    const float* t_rand, float* t_vals, float* coords, hipStream_t stream, int lindisp = 0,
+                                    float inv_near = 0.f, float inv_far = 0.f);
 hipError_t launch_pos_enc(const float* x, int64_t n, int min_deg, int max_deg, float* out, hipStream_t stream);
 hipError_t launch_composite(const float* rgb, int rgb_stride, const float* sigma, int sigma_stride, const float* t_vals,
-                            const float* dirs, int64_t n_rays, int S, int white_bkgd, int act, float* comp_rgb, float* acc,
-                            float* depth, float* weights, hipStream_t stream);
+                            const float* dirs, int64_t n_rays, int S, int white_bkgd, const ActParams& ap, float* comp_rgb,
+                            float* acc, float* depth, float* weights, hipStream_t stream);
 hipError_t launch_sample_pdf(const float* bins, const float* weights, int64_t w_stride, const float* t_coarse,
                              const float* u, int64_t u_stride, int64_t n_rays, float* samples, float* t_fine,
                              hipStream_t stream);
-hipError_t launch_composite_pdf(const float* raw, const float* t_coarse, const float* dirs, int64_t n_rays, int white_bkgd, int act,
+hipError_t launch_composite_pdf(const float* raw, const float* t_coarse, const float* dirs, int64_t n_rays, int white_bkgd, const ActParams& ap,
                                 const float* u, int64_t u_stride, float* comp_rgb, float* acc, float* depth, float* weights,
                                 float* t_fine, hipStream_t stream);
+hipError_t launch_sample_pdf_n(const float* bins, const float* weights, int64_t w_stride, const float* t_coarse, const float* u,
+                               int64_t u_stride, int64_t n_rays, int nb, int nf, int nt, float* samples, float* t_fine, hipStream_t stream);
+int64_t sample_pdf_n_lds_bytes(int nb, int nf, int nt, int* P_out);
 }  // namespace aon
 
 namespace {
@@ -135,22 +139,53 @@ struct MlpTimer : KTimer {
 
 int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 
+// The sampler / activation geometry of one call: aon_render_opts resolved against the reference's defaults.
+struct Geo {
+  int Sc, Sf, nf;          // t values of level 0 / level 1, draws of the inverse CDF
+  bool default_sizes;      // 65 / 193: the specialised per-ray kernels apply
+  int lindisp; float inv_near, inv_far;
+  const float* noise[2]; float noise_std;
+  float rgb_scale, rgb_shift, sigma_bias;
+  int S(int l) const { return l == 0 ? Sc : Sf; }
+  aon::ActParams act(bool art, int level, int64_t ray0) const {
+    aon::ActParams ap{art ? AON_ACT_ARTICULATED : AON_ACT_VANILLA, rgb_scale, rgb_shift, sigma_bias, nullptr, noise_std};
+    if (noise[level] && noise_std > 0.f) ap.noise = noise[level] + ray0 * S(level);
+    return ap;
+  }
+};
+
+// returns nullptr when fine, else what is wrong
+const char* make_geo(const aon_render_opts* o, Geo& g) {
+  aon_render_opts d;
+  aon_render_opts_init(&d);
+  if (o) d = *o;
+  if (d.num_coarse_samples < 2 || d.num_coarse_samples > 1023) return "num_coarse_samples must be in [2, 1023]";
+  if (d.num_fine_samples < 1) return "num_fine_samples must be >= 1";
+  g.Sc = d.num_coarse_samples + 1; g.nf = d.num_fine_samples; g.Sf = g.Sc + g.nf;
+  g.default_sizes = g.Sc == kSc && g.Sf == kSf;
+  if (!g.default_sizes && aon::sample_pdf_n_lds_bytes(g.Sc - 1, g.nf, g.Sc, nullptr) > 64 * 1024) return "num_coarse_samples / num_fine_samples too large for the per-ray LDS image";
+  g.lindisp = d.lindisp != 0; g.inv_near = d.inv_near; g.inv_far = d.inv_far;
+  g.noise[0] = d.noise_c; g.noise[1] = d.noise_f; g.noise_std = d.noise_std;
+  g.rgb_scale = d.rgb_scale; g.rgb_shift = d.rgb_shift; g.sigma_bias = d.sigma_bias;
+  return nullptr;
+}
+
 // workspace layout for a chunk of n rays
 struct Ws {
-  float* t_c;   // n*65
-  float* w_c;   // n*65
-  float* t_f;   // n*193
-  float* raw;   // n*193*4 (coarse raw uses the first n*65*4)
+  float* t_c;   // n*Sc
+  float* w_c;   // n*Sc
+  float* t_f;   // n*Sf
+  float* raw;   // n*Sf*4 (coarse raw uses the first n*Sc*4)
   int64_t bytes;
 };
 
-Ws carve(char* base, int64_t n) {
+Ws carve(char* base, int64_t n, const Geo& g) {
   Ws w;
   int64_t off = 0;
-  w.t_c = reinterpret_cast<float*>(base + off); off += align_up(n * kSc * 4, 256);
-  w.w_c = reinterpret_cast<float*>(base + off); off += align_up(n * kSc * 4, 256);
-  w.t_f = reinterpret_cast<float*>(base + off); off += align_up(n * kSf * 4, 256);
-  w.raw = reinterpret_cast<float*>(base + off); off += align_up(n * kSf * 16, 256);
+  w.t_c = reinterpret_cast<float*>(base + off); off += align_up(n * g.Sc * 4, 256);
+  w.w_c = reinterpret_cast<float*>(base + off); off += align_up(n * g.Sc * 4, 256);
+  w.t_f = reinterpret_cast<float*>(base + off); off += align_up(n * g.Sf * 4, 256);
+  w.raw = reinterpret_cast<float*>(base + off); off += align_up(n * g.Sf * 16, 256);
   w.bytes = off;
   return w;
 }
@@ -255,8 +290,56 @@ int aon_composite(const float* rgb, int rgb_stride, const float* sigma, int sigm
   if (n_rays == 0) return AON_OK;
   if (!rgb || !sigma || !t_vals || !dirs || !comp_rgb || !acc || !depth) return fail(AON_E_INVALID, "aon_composite: null pointer");
   KTimer timer(kComposite, (hipStream_t)stream, n_rays);
-  return check(aon::launch_composite(rgb, rgb_stride, sigma, sigma_stride, t_vals, dirs, n_rays, S, white_bkgd, act, comp_rgb,
+  return check(aon::launch_composite(rgb, rgb_stride, sigma, sigma_stride, t_vals, dirs, n_rays, S, white_bkgd, aon::default_act(act), comp_rgb,
                                      acc, depth, weights, (hipStream_t)stream), "aon_composite");
+}
+
+void aon_render_opts_init(aon_render_opts* o) {
+  if (!o) return;
+  o->num_coarse_samples = 64; o->num_fine_samples = 128; o->lindisp = 0; o->inv_near = 0.f; o->inv_far = 0.f;
+  o->noise_std = 0.f; o->noise_c = nullptr; o->noise_f = nullptr;
+  o->rgb_scale = 1.002f; o->rgb_shift = 0.001f; o->sigma_bias = -1.0f;
+}
+
+int aon_sample_along_rays_ex(const float* rays_o, const float* rays_d, int64_t n_rays, int S, float near_, float far_, int lindisp,
+                             float inv_near, float inv_far, const float* t_rand, float* t_vals, float* coords, void* stream) {
+  if (n_rays < 0 || S < 2) return fail(AON_E_INVALID, "aon_sample_along_rays_ex: bad size");
+  if (n_rays == 0) return AON_OK;
+  if (!t_vals || (coords && (!rays_o || !rays_d))) return fail(AON_E_INVALID, "aon_sample_along_rays_ex: null pointer");
+  return check(aon::launch_sample_along_rays(rays_o, rays_d, n_rays, S, near_, far_, t_rand, t_vals, coords, (hipStream_t)stream,
+                                             lindisp != 0, inv_near, inv_far), "aon_sample_along_rays_ex");
+}
+
+int aon_composite_ex(const float* rgb, int rgb_stride, const float* sigma, int sigma_stride, const float* t_vals, const float* dirs,
+                     int64_t n_rays, int S, int white_bkgd, int act, const aon_render_opts* opts, float* comp_rgb, float* acc,
+                     float* depth, float* weights, void* stream) {
+  if (n_rays < 0 || S < 1 || rgb_stride < 3 || sigma_stride < 1 || act < 0 || act > 2)
+    return fail(AON_E_INVALID, "aon_composite_ex: bad size / stride / act");
+  if (n_rays == 0) return AON_OK;
+  if (!rgb || !sigma || !t_vals || !dirs || !comp_rgb || !acc || !depth) return fail(AON_E_INVALID, "aon_composite_ex: null pointer");
+  aon::ActParams ap = aon::default_act(act);
+  if (opts) {
+    ap.rgb_scale = opts->rgb_scale; ap.rgb_shift = opts->rgb_shift; ap.sigma_bias = opts->sigma_bias;
+    if (opts->noise_c && opts->noise_std > 0.f) { ap.noise = opts->noise_c; ap.noise_std = opts->noise_std; }
+  }
+  KTimer timer(kComposite, (hipStream_t)stream, n_rays);
+  return check(aon::launch_composite(rgb, rgb_stride, sigma, sigma_stride, t_vals, dirs, n_rays, S, white_bkgd, ap, comp_rgb, acc, depth,
+                                     weights, (hipStream_t)stream), "aon_composite_ex");
+}
+
+int aon_sample_pdf_n(const float* bins, const float* weights, int64_t w_stride, const float* t_coarse, const float* u,
+                     int64_t u_stride, int64_t n_rays, int num_bins, int num_samples, int num_t, float* samples, float* t_fine,
+                     void* stream) {
+  if (n_rays < 0 || num_bins < 2 || num_samples < 1 || num_t < 0 || w_stride < num_bins - 1 || (u_stride != 0 && u_stride < num_samples))
+    return fail(AON_E_INVALID, "aon_sample_pdf_n: bad size / stride");
+  if (!bins && num_t != num_bins + 1) return fail(AON_E_INVALID, "aon_sample_pdf_n: bins == NULL needs num_t == num_bins + 1 (mid-points of t_coarse)");
+  if (aon::sample_pdf_n_lds_bytes(num_bins, num_samples, num_t, nullptr) > 64 * 1024) return fail(AON_E_INVALID, "aon_sample_pdf_n: sizes exceed the per-ray LDS image");
+  if (n_rays == 0) return AON_OK;
+  if (!weights || !u || (!bins && !t_coarse) || (t_fine && !t_coarse) || (!samples && !t_fine))
+    return fail(AON_E_INVALID, "aon_sample_pdf_n: null pointer");
+  KTimer timer(kSamplePdf, (hipStream_t)stream, n_rays);
+  return check(aon::launch_sample_pdf_n(bins, weights, w_stride, t_coarse, u, u_stride, n_rays, num_bins, num_samples, t_coarse ? num_t : 0,
+                                        samples, t_fine, (hipStream_t)stream), "aon_sample_pdf_n");
 }
 
 int aon_sample_pdf(const float* bins, const float* weights, int64_t w_stride, const float* t_coarse, const float* u,
@@ -286,7 +369,7 @@ int aon_composite_pdf(const float* raw, const float* t_coarse, const float* dirs
   if (!raw || !t_coarse || !dirs || !u || !comp_rgb || !acc || !depth || !t_fine) return fail(AON_E_INVALID, "aon_composite_pdf: null pointer");
   if (reinterpret_cast<uintptr_t>(raw) & 15) return fail(AON_E_INVALID, "aon_composite_pdf: raw must be 16-byte aligned");
   KTimer timer(kCompositePdf, (hipStream_t)stream, n_rays);
-  return check(aon::launch_composite_pdf(raw, t_coarse, dirs, n_rays, white_bkgd, act, u, u_stride, comp_rgb, acc, depth, weights,
+  return check(aon::launch_composite_pdf(raw, t_coarse, dirs, n_rays, white_bkgd, aon::default_act(act), u, u_stride, comp_rgb, acc, depth, weights,
                                          t_fine, (hipStream_t)stream), "aon_composite_pdf");
 }
 
@@ -341,7 +424,7 @@ int aon_composite_bwd(const float* raw, const float* t_vals, const float* dirs, 
   if (n_rays == 0) return AON_OK;
   if (!raw || !t_vals || !dirs || !g_rgb || !d_raw) return fail(AON_E_INVALID, "aon_composite_bwd: null pointer");
   KTimer timer(kCompositeBwd, (hipStream_t)stream, n_rays);
-  return check(aon::launch_composite_bwd(raw, t_vals, dirs, g_rgb, g_acc, g_depth, n_rays, S, white_bkgd, act, d_raw,
+  return check(aon::launch_composite_bwd(raw, t_vals, dirs, g_rgb, g_acc, g_depth, n_rays, S, white_bkgd, aon::default_act(act), d_raw,
                                          (hipStream_t)stream), "aon_composite_bwd");
 }
 
@@ -454,10 +537,13 @@ int aon_profile_class(int cls, double* ms, int64_t* launches, int64_t* units) {
   return AON_OK;
 }
 
-int64_t aon_render_workspace_bytes(int64_t n_rays) {
+int64_t aon_render_workspace_bytes_ex(int64_t n_rays, const aon_render_opts* opts) {
   if (n_rays < 1) n_rays = 1;
-  return carve(nullptr, n_rays).bytes;
+  Geo g;
+  if (const char* bad = make_geo(opts, g)) return fail(AON_E_INVALID, bad);
+  return carve(nullptr, n_rays, g).bytes;
 }
+int64_t aon_render_workspace_bytes(int64_t n_rays) { return aon_render_workspace_bytes_ex(n_rays, nullptr); }
 
 // Whole-path orchestration shared by the vanilla and the articulated network (NeRF.forward, model.py:147-199;
 // NeRF_AE_Art.forward, model_autodecoder.py:278-337): only the MLP launch and the output activation differ.
@@ -478,7 +564,10 @@ static hipError_t launch_net(const NetRef& net, const float* o, const float* d, 
 static int render_impl(const char* who, const NetRef& coarse, const NetRef& fine, const float* rays_o, const float* rays_d,
                        const float* viewdirs, int64_t n_rays, float near_, float far_, int white_bkgd, int num_levels,
                        const float* t_rand, const float* u, int64_t u_stride, float* rgb_c, float* acc_c, float* depth_c,
-                       float* rgb_f, float* acc_f, float* depth_f, void* workspace, int64_t workspace_bytes, hipStream_t stream) {
+                       float* rgb_f, float* acc_f, float* depth_f, void* workspace, int64_t workspace_bytes, hipStream_t stream,
+                       const aon_render_opts* opts) {
+  Geo g;
+  if (const char* bad = make_geo(opts, g)) return fail(AON_E_INVALID, bad);
   if (n_rays < 0 || (num_levels != 1 && num_levels != 2)) return fail(AON_E_INVALID, "render: bad size / num_levels");
   if (n_rays == 0) return AON_OK;
   if (!coarse.packed || !rays_o || !rays_d || !viewdirs || !rgb_c || !acc_c || !depth_c || !workspace)
@@ -486,43 +575,45 @@ static int render_impl(const char* who, const NetRef& coarse, const NetRef& fine
   if (num_levels == 2 && (!fine.packed || !rgb_f || !acc_f || !depth_f || !u))
     return fail(AON_E_INVALID, "render: null fine-level pointer");
   if (coarse.articulated && (!coarse.small || (num_levels == 2 && !fine.small))) return fail(AON_E_INVALID, "render: null latent block");
-  if (num_levels == 2 && u_stride != 0 && u_stride < 128) return fail(AON_E_INVALID, "render: bad u_stride");
+  if (num_levels == 2 && u_stride != 0 && u_stride < g.nf) return fail(AON_E_INVALID, "render: bad u_stride");
   if (reinterpret_cast<uintptr_t>(workspace) & 255) return fail(AON_E_INVALID, "render: workspace must be 256-byte aligned");
-  const int act = coarse.articulated ? AON_ACT_ARTICULATED : AON_ACT_VANILLA;
-  const bool fuse_coarse = num_levels == 2 && g_fuse_coarse.load(std::memory_order_relaxed) != 0;
+  const bool art = coarse.articulated;
+  const bool fuse_coarse = num_levels == 2 && g.default_sizes && g_fuse_coarse.load(std::memory_order_relaxed) != 0;
 
   // largest chunk the workspace admits
   int64_t chunk = n_rays;
-  if (carve(nullptr, chunk).bytes > workspace_bytes) {
-    const int64_t per_ray = (kSc + kSc + kSf + 4 * kSf) * 4;
+  if (carve(nullptr, chunk, g).bytes > workspace_bytes) {
+    const int64_t per_ray = (int64_t)(g.Sc + g.Sc + g.Sf + 4 * g.Sf) * 4;
     chunk = (workspace_bytes - 4 * 256) / per_ray;
-    while (chunk > 0 && carve(nullptr, chunk).bytes > workspace_bytes) --chunk;
+    while (chunk > 0 && carve(nullptr, chunk, g).bytes > workspace_bytes) --chunk;
     if (chunk < 1) return fail(AON_E_WORKSPACE, "render: workspace smaller than aon_render_workspace_bytes(1)");
   }
-  const Ws w = carve(static_cast<char*>(workspace), chunk);
+  const Ws w = carve(static_cast<char*>(workspace), chunk, g);
 
   for (int64_t r0 = 0; r0 < n_rays; r0 += chunk) {
     const int64_t n = n_rays - r0 < chunk ? n_rays - r0 : chunk;
     const float* o = rays_o + r0 * 3;
     const float* d = rays_d + r0 * 3;
     const float* v = viewdirs + r0 * 3;
+    const float* uu = u_stride ? u + r0 * u_stride : u;
     int rc;
     // level 0 (model.py:150-160, :175-197)
     {
       KTimer timer(kSampleT, stream, n);
-      rc = check(aon::launch_sample_along_rays(o, d, n, kSc, near_, far_, t_rand ? t_rand + r0 * kSc : nullptr, w.t_c, nullptr, stream), who);
+      rc = check(aon::launch_sample_along_rays(o, d, n, g.Sc, near_, far_, t_rand ? t_rand + r0 * g.Sc : nullptr, w.t_c, nullptr, stream,
+                                               g.lindisp, g.inv_near, g.inv_far), who);
     }
     if (rc) return rc;
-    rc = check(launch_net(coarse, o, d, v, w.t_c, n, kSc, w.raw, stream), who);
+    rc = check(launch_net(coarse, o, d, v, w.t_c, n, g.Sc, w.raw, stream), who);
     if (rc) return rc;
     if (fuse_coarse) {
       // compositing + the fine level's sampling (model.py:162-173) in one kernel: the coarse weights stay in registers
       KTimer timer(kCompositePdf, stream, n);
-      rc = check(aon::launch_composite_pdf(w.raw, w.t_c, d, n, white_bkgd, act, u_stride ? u + r0 * u_stride : u, u_stride, rgb_c + r0 * 3,
+      rc = check(aon::launch_composite_pdf(w.raw, w.t_c, d, n, white_bkgd, g.act(art, 0, r0), uu, u_stride, rgb_c + r0 * 3,
                                            acc_c + r0, depth_c + r0, nullptr, w.t_f, stream), who);
     } else {
       KTimer timer(kComposite, stream, n);
-      rc = check(aon::launch_composite(w.raw, 4, w.raw + 3, 4, w.t_c, d, n, kSc, white_bkgd, act, rgb_c + r0 * 3, acc_c + r0,
+      rc = check(aon::launch_composite(w.raw, 4, w.raw + 3, 4, w.t_c, d, n, g.Sc, white_bkgd, g.act(art, 0, r0), rgb_c + r0 * 3, acc_c + r0,
                                        depth_c + r0, num_levels == 2 ? w.w_c : nullptr, stream), who);
     }
     if (rc) return rc;
@@ -530,15 +621,16 @@ static int render_impl(const char* who, const NetRef& coarse, const NetRef& fine
     // level 1 (model.py:162-173, :175-197)
     if (!fuse_coarse) {
       KTimer timer(kSamplePdf, stream, n);
-      rc = check(aon::launch_sample_pdf(nullptr, w.w_c + 1, kSc, w.t_c, u_stride ? u + r0 * u_stride : u, u_stride, n, nullptr, w.t_f,
-                                        stream), who);
+      rc = check(g.default_sizes ? aon::launch_sample_pdf(nullptr, w.w_c + 1, kSc, w.t_c, uu, u_stride, n, nullptr, w.t_f, stream)
+                                 : aon::launch_sample_pdf_n(nullptr, w.w_c + 1, g.Sc, w.t_c, uu, u_stride, n, g.Sc - 1, g.nf, g.Sc, nullptr,
+                                                            w.t_f, stream), who);
       if (rc) return rc;
     }
-    rc = check(launch_net(fine, o, d, v, w.t_f, n, kSf, w.raw, stream), who);
+    rc = check(launch_net(fine, o, d, v, w.t_f, n, g.Sf, w.raw, stream), who);
     if (rc) return rc;
     {
       KTimer timer(kComposite, stream, n);
-      rc = check(aon::launch_composite(w.raw, 4, w.raw + 3, 4, w.t_f, d, n, kSf, white_bkgd, act, rgb_f + r0 * 3, acc_f + r0,
+      rc = check(aon::launch_composite(w.raw, 4, w.raw + 3, 4, w.t_f, d, n, g.Sf, white_bkgd, g.act(art, 1, r0), rgb_f + r0 * 3, acc_f + r0,
                                        depth_f + r0, nullptr, stream), who);
     }
     if (rc) return rc;
@@ -546,13 +638,21 @@ static int render_impl(const char* who, const NetRef& coarse, const NetRef& fine
   return AON_OK;
 }
 
+int aon_render_fwd_ex(const void* packed_coarse, const void* packed_fine, const float* rays_o, const float* rays_d,
+                      const float* viewdirs, int64_t n_rays, float near_, float far_, int white_bkgd, int num_levels,
+                      const float* t_rand, const float* u, int64_t u_stride, float* rgb_c, float* acc_c, float* depth_c,
+                      float* rgb_f, float* acc_f, float* depth_f, void* workspace, int64_t workspace_bytes, void* stream,
+                      const aon_render_opts* opts) {
+  const NetRef c{false, packed_coarse, nullptr}, f{false, packed_fine, nullptr};
+  return render_impl("aon_render_fwd", c, f, rays_o, rays_d, viewdirs, n_rays, near_, far_, white_bkgd, num_levels, t_rand, u,
+                     u_stride, rgb_c, acc_c, depth_c, rgb_f, acc_f, depth_f, workspace, workspace_bytes, (hipStream_t)stream, opts);
+}
 int aon_render_fwd(const void* packed_coarse, const void* packed_fine, const float* rays_o, const float* rays_d,
                    const float* viewdirs, int64_t n_rays, float near_, float far_, int white_bkgd, int num_levels,
                    const float* t_rand, const float* u, int64_t u_stride, float* rgb_c, float* acc_c, float* depth_c,
                    float* rgb_f, float* acc_f, float* depth_f, void* workspace, int64_t workspace_bytes, void* stream) {
-  const NetRef c{false, packed_coarse, nullptr}, f{false, packed_fine, nullptr};
-  return render_impl("aon_render_fwd", c, f, rays_o, rays_d, viewdirs, n_rays, near_, far_, white_bkgd, num_levels, t_rand, u,
-                     u_stride, rgb_c, acc_c, depth_c, rgb_f, acc_f, depth_f, workspace, workspace_bytes, (hipStream_t)stream);
+  return aon_render_fwd_ex(packed_coarse, packed_fine, rays_o, rays_d, viewdirs, n_rays, near_, far_, white_bkgd, num_levels, t_rand, u,
+                           u_stride, rgb_c, acc_c, depth_c, rgb_f, acc_f, depth_f, workspace, workspace_bytes, stream, nullptr);
 }
 
 // ---- training step in two calls (aon_render_fwd_train + aon_render_bwd) ----
@@ -572,7 +672,7 @@ struct TrainLevel {
 // What the forward leaves for the backward (caller-owned, pinned by the autograd graph): per level t, raw, planes, ReLU bits.
 struct TrainWs {
   TrainLevel lvl[2];
-  float* w_c;      // n*65 coarse weights
+  float* w_c;      // n*Sc coarse weights
   int64_t bytes;
 };
 // Backward-only temporaries (round 3: a separate `scratch` of aon_render_bwd, allocated when the backward runs -- round 2 carved
@@ -587,36 +687,36 @@ struct TrainScratch {
   int64_t bytes;
 };
 
-int64_t level_np(int64_t n, int l) { return align_up(n * (l == 0 ? kSc : kSf), 128); }
+int64_t level_np(int64_t n, int l, const Geo& g) { return align_up(n * g.S(l), 128); }
 
 // both carves cover only the levels in use: num_levels = 1 (BASELINE config 1) takes a quarter of the two-level size
-TrainWs carve_train(char* base, int64_t n, bool art, int num_levels) {
+TrainWs carve_train(char* base, int64_t n, bool art, int num_levels, const Geo& g) {
   TrainWs w{};
   const int64_t rows = art ? aon::kAPlRows : aon::kPlRows;
   const int64_t mlayers = art ? aon::kAMaskLayers : aon::kMaskLayers;
   int64_t off = 0;
   auto take = [&](int64_t bytes) { char* p = base + off; off += align_up(bytes, 256); return p; };
   for (int l = 0; l < num_levels; ++l) {
-    const int S = l == 0 ? kSc : kSf;
-    const int64_t Np = level_np(n, l);
+    const int S = g.S(l);
+    const int64_t Np = level_np(n, l, g);
     w.lvl[l].S = S; w.lvl[l].Np = Np;
     w.lvl[l].t = reinterpret_cast<float*>(take(n * S * 4));
     w.lvl[l].raw = reinterpret_cast<float*>(take(Np * 16));
     w.lvl[l].planes = reinterpret_cast<float*>(take(rows * Np * 4));
     w.lvl[l].masks = take(mlayers * Np * 32);
   }
-  w.w_c = reinterpret_cast<float*>(take(n * kSc * 4));
+  w.w_c = reinterpret_cast<float*>(take(n * g.Sc * 4));
   w.bytes = off;
   return w;
 }
 
-TrainScratch carve_scratch(char* base, int64_t n, bool art, int num_levels) {
+TrainScratch carve_scratch(char* base, int64_t n, bool art, int num_levels, const Geo& g) {
   TrainScratch sc{};
   const int64_t rows = art ? aon::kAPlRows : aon::kPlRows;
   int64_t off = 0;
   auto take = [&](int64_t bytes) { char* p = base + off; off += align_up(bytes, 256); return p; };
   for (int l = 0; l < num_levels; ++l) {
-    const int64_t Np = level_np(n, l);
+    const int64_t Np = level_np(n, l, g);
     sc.d_raw[l] = reinterpret_cast<float*>(take(Np * 16));
     sc.dplanes[l] = reinterpret_cast<float*>(take(rows * Np * 4));
     sc.dxp[l] = reinterpret_cast<float*>(take(Np * 16));
@@ -710,25 +810,31 @@ struct TrainNet {   // one level's network handles
 
 int train_fwd_impl(const char* who, bool art, const TrainNet* nets, const float* rays_o, const float* rays_d, const float* viewdirs,
                    int64_t n, float near_, float far_, int white_bkgd, int num_levels, const float* t_rand, const float* u, int64_t u_stride,
-                   float* const* rgb, float* const* acc, float* const* depth, void* workspace, int64_t workspace_bytes, hipStream_t stream) {
+                   float* const* rgb, float* const* acc, float* const* depth, void* workspace, int64_t workspace_bytes, hipStream_t stream,
+                   const aon_render_opts* opts) {
+  Geo g;
+  if (const char* bad = make_geo(opts, g)) return fail(AON_E_INVALID, bad);
+  if (g.Sf > 1024) return fail(AON_E_INVALID, "train forward: more than 1024 samples per ray at the fine level");
   if (n <= 0 || (num_levels != 1 && num_levels != 2)) return fail(AON_E_INVALID, "train forward: bad size / num_levels");
   if (!rays_o || !rays_d || !viewdirs || !workspace) return fail(AON_E_INVALID, "train forward: null pointer");
   if (reinterpret_cast<uintptr_t>(workspace) & 255) return fail(AON_E_INVALID, "train forward: workspace must be 256-byte aligned");
-  const TrainWs w = carve_train(static_cast<char*>(workspace), n, art, num_levels);
+  const TrainWs w = carve_train(static_cast<char*>(workspace), n, art, num_levels, g);
   if (w.bytes > workspace_bytes) return fail(AON_E_WORKSPACE, "train forward: workspace smaller than aon_train_workspace_bytes()");
-  if (num_levels == 2 && (!u || (u_stride != 0 && u_stride < 128))) return fail(AON_E_INVALID, "train forward: bad u / u_stride");
-  const int act = art ? AON_ACT_ARTICULATED : AON_ACT_VANILLA;
-  const bool fuse = num_levels == 2 && g_fuse_coarse.load(std::memory_order_relaxed) != 0;
+  if (num_levels == 2 && (!u || (u_stride != 0 && u_stride < g.nf))) return fail(AON_E_INVALID, "train forward: bad u / u_stride");
+  const bool fuse = num_levels == 2 && g.default_sizes && g_fuse_coarse.load(std::memory_order_relaxed) != 0;
   for (int l = 0; l < num_levels; ++l) {
     const TrainLevel& L = w.lvl[l];
     if (!nets[l].packed_fwd || (art && !nets[l].small) || !rgb[l] || !acc[l] || !depth[l]) return fail(AON_E_INVALID, "train forward: null level pointer");
     int rc = AON_OK;
     if (l == 0) {
       KTimer timer(kSampleT, stream, n);
-      rc = check(aon::launch_sample_along_rays(rays_o, rays_d, n, kSc, near_, far_, t_rand, L.t, nullptr, stream), who);
+      rc = check(aon::launch_sample_along_rays(rays_o, rays_d, n, g.Sc, near_, far_, t_rand, L.t, nullptr, stream, g.lindisp, g.inv_near,
+                                               g.inv_far), who);
     } else if (!fuse) {
       KTimer timer(kSamplePdf, stream, n);
-      rc = check(aon::launch_sample_pdf(nullptr, w.w_c + 1, kSc, w.lvl[0].t, u, u_stride, n, nullptr, L.t, stream), who);
+      rc = check(g.default_sizes ? aon::launch_sample_pdf(nullptr, w.w_c + 1, kSc, w.lvl[0].t, u, u_stride, n, nullptr, L.t, stream)
+                                 : aon::launch_sample_pdf_n(nullptr, w.w_c + 1, g.Sc, w.lvl[0].t, u, u_stride, n, g.Sc - 1, g.nf, g.Sc, nullptr,
+                                                            L.t, stream), who);
     }
     if (rc) return rc;
     {
@@ -741,11 +847,11 @@ int train_fwd_impl(const char* who, bool art, const TrainNet* nets, const float*
     if (rc) return rc;
     if (l == 0 && fuse) {
       KTimer timer(kCompositePdf, stream, n);
-      rc = check(aon::launch_composite_pdf(L.raw, L.t, rays_d, n, white_bkgd, act, u, u_stride, rgb[0], acc[0], depth[0], nullptr,
+      rc = check(aon::launch_composite_pdf(L.raw, L.t, rays_d, n, white_bkgd, g.act(art, 0, 0), u, u_stride, rgb[0], acc[0], depth[0], nullptr,
                                            w.lvl[1].t, stream), who);
     } else {
       KTimer timer(kComposite, stream, n);
-      rc = check(aon::launch_composite(L.raw, 4, L.raw + 3, 4, L.t, rays_d, n, L.S, white_bkgd, act, rgb[l], acc[l], depth[l],
+      rc = check(aon::launch_composite(L.raw, 4, L.raw + 3, 4, L.t, rays_d, n, L.S, white_bkgd, g.act(art, l, 0), rgb[l], acc[l], depth[l],
                                        (l == 0 && num_levels == 2) ? w.w_c : nullptr, stream), who);
     }
     if (rc) return rc;
@@ -760,35 +866,61 @@ int aon_set_bwd_overlap(int on) {
   return AON_OK;
 }
 
+int64_t aon_train_workspace_bytes_ex(int64_t n_rays, int articulated, int num_levels, const aon_render_opts* opts) {
+  if (n_rays < 1) n_rays = 1;
+  Geo g;
+  if (const char* bad = make_geo(opts, g)) return fail(AON_E_INVALID, bad);
+  return carve_train(nullptr, n_rays, articulated != 0, num_levels == 1 ? 1 : 2, g).bytes;
+}
 int64_t aon_train_workspace_bytes(int64_t n_rays, int articulated, int num_levels) {
-  if (n_rays < 1) n_rays = 1;
-  return carve_train(nullptr, n_rays, articulated != 0, num_levels == 1 ? 1 : 2).bytes;
+  return aon_train_workspace_bytes_ex(n_rays, articulated, num_levels, nullptr);
 }
 
+int64_t aon_train_scratch_bytes_ex(int64_t n_rays, int articulated, int num_levels, const aon_render_opts* opts) {
+  if (n_rays < 1) n_rays = 1;
+  Geo g;
+  if (const char* bad = make_geo(opts, g)) return fail(AON_E_INVALID, bad);
+  return carve_scratch(nullptr, n_rays, articulated != 0, num_levels == 1 ? 1 : 2, g).bytes;
+}
 int64_t aon_train_scratch_bytes(int64_t n_rays, int articulated, int num_levels) {
-  if (n_rays < 1) n_rays = 1;
-  return carve_scratch(nullptr, n_rays, articulated != 0, num_levels == 1 ? 1 : 2).bytes;
+  return aon_train_scratch_bytes_ex(n_rays, articulated, num_levels, nullptr);
 }
 
+int aon_render_fwd_train_ex(const void* packed_coarse, const void* packed_fine, const float* rays_o, const float* rays_d, const float* viewdirs,
+                            int64_t n_rays, float near_, float far_, int white_bkgd, int num_levels, const float* t_rand, const float* u,
+                            int64_t u_stride, float* rgb_c, float* acc_c, float* depth_c, float* rgb_f, float* acc_f, float* depth_f,
+                            void* workspace, int64_t workspace_bytes, void* stream, const aon_render_opts* opts) {
+  const TrainNet nets[2] = {{packed_coarse, nullptr, nullptr}, {packed_fine, nullptr, nullptr}};
+  float* const rgb[2] = {rgb_c, rgb_f}; float* const acc[2] = {acc_c, acc_f}; float* const dep[2] = {depth_c, depth_f};
+  return train_fwd_impl("aon_render_fwd_train", false, nets, rays_o, rays_d, viewdirs, n_rays, near_, far_, white_bkgd, num_levels, t_rand, u,
+                        u_stride, rgb, acc, dep, workspace, workspace_bytes, (hipStream_t)stream, opts);
+}
 int aon_render_fwd_train(const void* packed_coarse, const void* packed_fine, const float* rays_o, const float* rays_d, const float* viewdirs,
                          int64_t n_rays, float near_, float far_, int white_bkgd, int num_levels, const float* t_rand, const float* u,
                          int64_t u_stride, float* rgb_c, float* acc_c, float* depth_c, float* rgb_f, float* acc_f, float* depth_f,
                          void* workspace, int64_t workspace_bytes, void* stream) {
-  const TrainNet nets[2] = {{packed_coarse, nullptr, nullptr}, {packed_fine, nullptr, nullptr}};
-  float* const rgb[2] = {rgb_c, rgb_f}; float* const acc[2] = {acc_c, acc_f}; float* const dep[2] = {depth_c, depth_f};
-  return train_fwd_impl("aon_render_fwd_train", false, nets, rays_o, rays_d, viewdirs, n_rays, near_, far_, white_bkgd, num_levels, t_rand, u,
-                        u_stride, rgb, acc, dep, workspace, workspace_bytes, (hipStream_t)stream);
+  return aon_render_fwd_train_ex(packed_coarse, packed_fine, rays_o, rays_d, viewdirs, n_rays, near_, far_, white_bkgd, num_levels, t_rand, u,
+                                 u_stride, rgb_c, acc_c, depth_c, rgb_f, acc_f, depth_f, workspace, workspace_bytes, stream, nullptr);
 }
 
+int aon_art_render_fwd_train_ex(const void* packed_coarse, const void* small_coarse, const void* packed_fine, const void* small_fine,
+                                const float* rays_o, const float* rays_d, const float* viewdirs, int64_t n_rays, float near_, float far_,
+                                int white_bkgd, int num_levels, const float* t_rand, const float* u, int64_t u_stride, float* rgb_c,
+                                float* acc_c, float* depth_c, float* rgb_f, float* acc_f, float* depth_f, void* workspace,
+                                int64_t workspace_bytes, void* stream, const aon_render_opts* opts) {
+  const TrainNet nets[2] = {{packed_coarse, static_cast<const float*>(small_coarse), nullptr}, {packed_fine, static_cast<const float*>(small_fine), nullptr}};
+  float* const rgb[2] = {rgb_c, rgb_f}; float* const acc[2] = {acc_c, acc_f}; float* const dep[2] = {depth_c, depth_f};
+  return train_fwd_impl("aon_art_render_fwd_train", true, nets, rays_o, rays_d, viewdirs, n_rays, near_, far_, white_bkgd, num_levels, t_rand, u,
+                        u_stride, rgb, acc, dep, workspace, workspace_bytes, (hipStream_t)stream, opts);
+}
 int aon_art_render_fwd_train(const void* packed_coarse, const void* small_coarse, const void* packed_fine, const void* small_fine,
                              const float* rays_o, const float* rays_d, const float* viewdirs, int64_t n_rays, float near_, float far_,
                              int white_bkgd, int num_levels, const float* t_rand, const float* u, int64_t u_stride, float* rgb_c,
                              float* acc_c, float* depth_c, float* rgb_f, float* acc_f, float* depth_f, void* workspace,
                              int64_t workspace_bytes, void* stream) {
-  const TrainNet nets[2] = {{packed_coarse, static_cast<const float*>(small_coarse), nullptr}, {packed_fine, static_cast<const float*>(small_fine), nullptr}};
-  float* const rgb[2] = {rgb_c, rgb_f}; float* const acc[2] = {acc_c, acc_f}; float* const dep[2] = {depth_c, depth_f};
-  return train_fwd_impl("aon_art_render_fwd_train", true, nets, rays_o, rays_d, viewdirs, n_rays, near_, far_, white_bkgd, num_levels, t_rand, u,
-                        u_stride, rgb, acc, dep, workspace, workspace_bytes, (hipStream_t)stream);
+  return aon_art_render_fwd_train_ex(packed_coarse, small_coarse, packed_fine, small_fine, rays_o, rays_d, viewdirs, n_rays, near_, far_, white_bkgd,
+                                     num_levels, t_rand, u, u_stride, rgb_c, acc_c, depth_c, rgb_f, acc_f, depth_f, workspace, workspace_bytes,
+                                     stream, nullptr);
 }
 
 int aon_render_bwd(const void* packed_bwd_coarse, const void* packed_fwd_coarse, const void* packed_bwd_fine, const void* packed_fwd_fine,
@@ -796,13 +928,24 @@ int aon_render_bwd(const void* packed_bwd_coarse, const void* packed_fwd_coarse,
                    const float* const* g_acc_host, const float* const* g_depth_host, float* const* grads_coarse_host,
                    float* const* grads_fine_host, void* workspace, int64_t workspace_bytes, void* scratch, int64_t scratch_bytes,
                    void* stream_) {
+  return aon_render_bwd_ex(packed_bwd_coarse, packed_fwd_coarse, packed_bwd_fine, packed_fwd_fine, rays_d, n_rays, white_bkgd, num_levels, g_rgb_host,
+                           g_acc_host, g_depth_host, grads_coarse_host, grads_fine_host, workspace, workspace_bytes, scratch, scratch_bytes, stream_,
+                           nullptr);
+}
+int aon_render_bwd_ex(const void* packed_bwd_coarse, const void* packed_fwd_coarse, const void* packed_bwd_fine, const void* packed_fwd_fine,
+                      const float* rays_d, int64_t n_rays, int white_bkgd, int num_levels, const float* const* g_rgb_host,
+                      const float* const* g_acc_host, const float* const* g_depth_host, float* const* grads_coarse_host,
+                      float* const* grads_fine_host, void* workspace, int64_t workspace_bytes, void* scratch, int64_t scratch_bytes,
+                      void* stream_, const aon_render_opts* opts) {
   hipStream_t stream = (hipStream_t)stream_;
+  Geo g;
+  if (const char* bad = make_geo(opts, g)) return fail(AON_E_INVALID, bad);
   if (n_rays <= 0 || (num_levels != 1 && num_levels != 2)) return fail(AON_E_INVALID, "aon_render_bwd: bad size / num_levels");
   if (!rays_d || !g_rgb_host || !workspace || !scratch || !grads_coarse_host) return fail(AON_E_INVALID, "aon_render_bwd: null pointer");
   if (reinterpret_cast<uintptr_t>(scratch) & 255) return fail(AON_E_INVALID, "aon_render_bwd: scratch must be 256-byte aligned");
-  const TrainWs w = carve_train(static_cast<char*>(workspace), n_rays, false, num_levels);
+  const TrainWs w = carve_train(static_cast<char*>(workspace), n_rays, false, num_levels, g);
   if (w.bytes > workspace_bytes) return fail(AON_E_WORKSPACE, "aon_render_bwd: workspace smaller than aon_train_workspace_bytes()");
-  const TrainScratch sc = carve_scratch(static_cast<char*>(scratch), n_rays, false, num_levels);
+  const TrainScratch sc = carve_scratch(static_cast<char*>(scratch), n_rays, false, num_levels, g);
   if (sc.bytes > scratch_bytes) return fail(AON_E_WORKSPACE, "aon_render_bwd: scratch smaller than aon_train_scratch_bytes()");
   const void* pb[2] = {packed_bwd_coarse, packed_bwd_fine};
   const void* pf[2] = {packed_fwd_coarse, packed_fwd_fine};
@@ -823,7 +966,7 @@ int aon_render_bwd(const void* packed_bwd_coarse, const void* packed_fwd_coarse,
     {
       KTimer timer(kCompositeBwd, stream, n_rays);
       rc = check(aon::launch_composite_bwd(L.raw, L.t, rays_d, g_rgb_host[l], g_acc_host ? g_acc_host[l] : nullptr, g_depth_host ? g_depth_host[l] : nullptr,
-                                           n_rays, L.S, white_bkgd, AON_ACT_VANILLA, sc.d_raw[l], stream), "aon_render_bwd");
+                                           n_rays, L.S, white_bkgd, g.act(false, l, 0), sc.d_raw[l], stream), "aon_render_bwd");
     }
     if (rc) return rc;
     {
@@ -848,15 +991,28 @@ int aon_art_render_bwd(const void* packed_bwd_coarse, const void* small_coarse, 
                        const float* const* params_fine_host, const float* shape, const float* appearance, const float* articulation,
                        float* const* grads_coarse_host, float* const* grads_fine_host, float* g_shape, float* g_appearance,
                        float* g_articulation, void* workspace, int64_t workspace_bytes, void* scratch, int64_t scratch_bytes, void* stream_) {
+  return aon_art_render_bwd_ex(packed_bwd_coarse, small_coarse, packed_bwd_fine, small_fine, rays_d, n_rays, white_bkgd, num_levels, g_rgb_host, g_acc_host,
+                               g_depth_host, params_coarse_host, params_fine_host, shape, appearance, articulation, grads_coarse_host, grads_fine_host,
+                               g_shape, g_appearance, g_articulation, workspace, workspace_bytes, scratch, scratch_bytes, stream_, nullptr);
+}
+int aon_art_render_bwd_ex(const void* packed_bwd_coarse, const void* small_coarse, const void* packed_bwd_fine, const void* small_fine,
+                          const float* rays_d, int64_t n_rays, int white_bkgd, int num_levels, const float* const* g_rgb_host,
+                          const float* const* g_acc_host, const float* const* g_depth_host, const float* const* params_coarse_host,
+                          const float* const* params_fine_host, const float* shape, const float* appearance, const float* articulation,
+                          float* const* grads_coarse_host, float* const* grads_fine_host, float* g_shape, float* g_appearance,
+                          float* g_articulation, void* workspace, int64_t workspace_bytes, void* scratch, int64_t scratch_bytes, void* stream_,
+                          const aon_render_opts* opts) {
   hipStream_t stream = (hipStream_t)stream_;
+  Geo g;
+  if (const char* bad = make_geo(opts, g)) return fail(AON_E_INVALID, bad);
   if (n_rays <= 0 || (num_levels != 1 && num_levels != 2)) return fail(AON_E_INVALID, "aon_art_render_bwd: bad size / num_levels");
   if (!rays_d || !g_rgb_host || !workspace || !scratch || !grads_coarse_host || !params_coarse_host || !shape || !appearance || !articulation ||
       !g_shape || !g_appearance || !g_articulation)
     return fail(AON_E_INVALID, "aon_art_render_bwd: null pointer");
   if (reinterpret_cast<uintptr_t>(scratch) & 255) return fail(AON_E_INVALID, "aon_art_render_bwd: scratch must be 256-byte aligned");
-  const TrainWs w = carve_train(static_cast<char*>(workspace), n_rays, true, num_levels);
+  const TrainWs w = carve_train(static_cast<char*>(workspace), n_rays, true, num_levels, g);
   if (w.bytes > workspace_bytes) return fail(AON_E_WORKSPACE, "aon_art_render_bwd: workspace smaller than aon_train_workspace_bytes()");
-  const TrainScratch sc = carve_scratch(static_cast<char*>(scratch), n_rays, true, num_levels);
+  const TrainScratch sc = carve_scratch(static_cast<char*>(scratch), n_rays, true, num_levels, g);
   if (sc.bytes > scratch_bytes) return fail(AON_E_WORKSPACE, "aon_art_render_bwd: scratch smaller than aon_train_scratch_bytes()");
   const void* pb[2] = {packed_bwd_coarse, packed_bwd_fine};
   const float* sm[2] = {static_cast<const float*>(small_coarse), static_cast<const float*>(small_fine)};
@@ -878,7 +1034,7 @@ int aon_art_render_bwd(const void* packed_bwd_coarse, const void* small_coarse, 
     {
       KTimer timer(kCompositeBwd, stream, n_rays);
       rc = check(aon::launch_composite_bwd(L.raw, L.t, rays_d, g_rgb_host[l], g_acc_host ? g_acc_host[l] : nullptr, g_depth_host ? g_depth_host[l] : nullptr,
-                                           n_rays, L.S, white_bkgd, AON_ACT_ARTICULATED, sc.d_raw[l], stream), "aon_art_render_bwd");
+                                           n_rays, L.S, white_bkgd, g.act(true, l, 0), sc.d_raw[l], stream), "aon_art_render_bwd");
     }
     if (rc) return rc;
     {
@@ -947,14 +1103,23 @@ int aon_art_mlp_fwd_pos(const void* packed, const void* small, const float* pos,
                                            n_rays, S, raw, (hipStream_t)stream), "aon_art_mlp_fwd_pos");
 }
 
+int aon_art_render_fwd_ex(const void* packed_coarse, const void* small_coarse, const void* packed_fine, const void* small_fine,
+                          const float* rays_o, const float* rays_d, const float* viewdirs, int64_t n_rays, float near_, float far_,
+                          int white_bkgd, int num_levels, const float* t_rand, const float* u, int64_t u_stride, float* rgb_c,
+                          float* acc_c, float* depth_c, float* rgb_f, float* acc_f, float* depth_f, void* workspace,
+                          int64_t workspace_bytes, void* stream, const aon_render_opts* opts) {
+  const NetRef c{true, packed_coarse, static_cast<const float*>(small_coarse)}, f{true, packed_fine, static_cast<const float*>(small_fine)};
+  return render_impl("aon_art_render_fwd", c, f, rays_o, rays_d, viewdirs, n_rays, near_, far_, white_bkgd, num_levels, t_rand, u,
+                     u_stride, rgb_c, acc_c, depth_c, rgb_f, acc_f, depth_f, workspace, workspace_bytes, (hipStream_t)stream, opts);
+}
 int aon_art_render_fwd(const void* packed_coarse, const void* small_coarse, const void* packed_fine, const void* small_fine,
                        const float* rays_o, const float* rays_d, const float* viewdirs, int64_t n_rays, float near_, float far_,
                        int white_bkgd, int num_levels, const float* t_rand, const float* u, int64_t u_stride, float* rgb_c,
                        float* acc_c, float* depth_c, float* rgb_f, float* acc_f, float* depth_f, void* workspace,
                        int64_t workspace_bytes, void* stream) {
-  const NetRef c{true, packed_coarse, static_cast<const float*>(small_coarse)}, f{true, packed_fine, static_cast<const float*>(small_fine)};
-  return render_impl("aon_art_render_fwd", c, f, rays_o, rays_d, viewdirs, n_rays, near_, far_, white_bkgd, num_levels, t_rand, u,
-                     u_stride, rgb_c, acc_c, depth_c, rgb_f, acc_f, depth_f, workspace, workspace_bytes, (hipStream_t)stream);
+  return aon_art_render_fwd_ex(packed_coarse, small_coarse, packed_fine, small_fine, rays_o, rays_d, viewdirs, n_rays, near_, far_, white_bkgd,
+                               num_levels, t_rand, u, u_stride, rgb_c, acc_c, depth_c, rgb_f, acc_f, depth_f, workspace, workspace_bytes, stream,
+                               nullptr);
 }
 
 }  // extern "C"

@@ -547,4 +547,178 @@ hipError_t launch_sample_pdf(const float* bins, const float* weights, int64_t w_
   return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------
+// R6 + R7 for ANY geometry (num_coarse_samples, num_fine_samples of NeRF.__init__, model.py:129-130): nb bins, nb - 1 weights,
+// nf draws, nt coarse t's -> nt + nf sorted t's.  One wavefront per ray, everything of the ray in LDS.  Same arithmetic contract
+// as the 64/128 kernel above -- the draws are bit-exact against torch's CPU kernels -- with ATen's reductions followed literally
+// instead of being unrolled for one length:
+//   weights.sum(-1): cpu/SumKernel.cpp.  K >= 8: `vectorized_inner_sum` = `row_sum` over 8-float vectors (vector lane l of this
+//     wave plays SIMD lane l), ILP factor 4, `multi_row_sum`'s four-level cascade (level step max(16, 2^(ceil(log2 n)/4)));
+//     then the K % 8 tail and the eight lane sums in order.  K < 8: the same row_sum on scalars.  (Checked against torch.sum on
+//     K = 1 .. 1000 in tests/test_oracle_golden.py::test_aten_sum_model, and through the reference's draws in G16.)
+//   torch.cumsum: a double running sum in index order, every prefix rounded to float.
+//   torch.sort: the sorted multiset is unique -- a bitonic network over the +inf-padded union.
+// ---------------------------------------------------------------------------------------------
+struct PdfNArgs {
+  const float* bins;     // (n,nb) or null -> mids of t_coarse (then nt == nb + 1)
+  const float* weights;  // first of ray 0's nb-1 weights
+  int64_t w_stride;
+  const float* t_coarse; // (n,nt) or null (samples-only call)
+  const float* u; int64_t u_stride;   // (nf,) shared when u_stride == 0, else (n,nf)
+  int64_t n_rays;
+  int nb, nf, nt, P;     // P = power of two >= nt + nf
+  float* samples;        // (n,nf) or null
+  float* t_fine;         // (n,nt+nf) or null
+};
+
+// ATen's multi_row_sum on four interleaved rows: element (i, k) = x[(4 i + k) * stride + off], i < size
+__device__ __forceinline__ void aten_multi_row_sum4(const float* x, int stride, int off, int size, float (&out)[4]) {
+  float acc[4][4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[j][k] = 0.f;
+  int cl = 0;
+  while ((1 << cl) < size) ++cl;                       // ceil(log2(size)) (0 for size <= 1)
+  const int level_power = cl / 4 > 4 ? cl / 4 : 4;
+  const int level_step = 1 << level_power, level_mask = level_step - 1;
+  int i = 0;
+  while (i + level_step <= size) {
+    for (int j = 0; j < level_step; ++j, ++i) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) acc[0][k] = __fadd_rn(acc[0][k], x[(4 * i + k) * stride + off]);
+    }
+    bool go = true;
+#pragma unroll
+    for (int j = 1; j < 4; ++j) {
+      if (go) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { acc[j][k] = __fadd_rn(acc[j][k], acc[j - 1][k]); acc[j - 1][k] = 0.f; }
+        if ((i & (level_mask << (j * level_power))) != 0) go = false;
+      }
+    }
+  }
+  for (; i < size; ++i) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[0][k] = __fadd_rn(acc[0][k], x[(4 * i + k) * stride + off]);
+  }
+#pragma unroll
+  for (int j = 1; j < 4; ++j)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[0][k] = __fadd_rn(acc[0][k], acc[j][k]);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) out[k] = acc[0][k];
+}
+
+// torch's CPU sum of the K floats x[0..K) (LDS), returned in every lane
+__device__ __forceinline__ float aten_row_sum(const float* x, int K, int lane) {
+  if (K < 8) {   // scalar_inner_sum -> row_sum with the scalar load policy (wave-uniform: every lane does the same work)
+    const int size_ilp = K / 4;
+    float part[4];
+    aten_multi_row_sum4(x, 1, 0, size_ilp, part);
+    for (int i = size_ilp * 4; i < K; ++i) part[0] = __fadd_rn(part[0], x[i]);
+    for (int k = 1; k < 4; ++k) part[0] = __fadd_rn(part[0], part[k]);
+    return part[0];
+  }
+  const int vec = K / 8, size_ilp = vec / 4;
+  const int l = lane & 7;   // lanes 8..63 repeat lanes 0..7 (in-bounds reads, no divergence)
+  float part[4];
+  aten_multi_row_sum4(x, 8, l, size_ilp, part);
+  for (int i = size_ilp * 4; i < vec; ++i) part[0] = __fadd_rn(part[0], x[i * 8 + l]);
+  for (int k = 1; k < 4; ++k) part[0] = __fadd_rn(part[0], part[k]);
+  float fin = 0.f;
+  for (int k = vec * 8; k < K; ++k) fin = __fadd_rn(fin, x[k]);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) fin = __fadd_rn(fin, __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, part[0]), k)));
+  return fin;
+}
+
+__global__ void __launch_bounds__(64) sample_pdf_n_kernel(PdfNArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float L[];
+  const int lane = threadIdx.x;
+  const int64_t ray = blockIdx.x;
+  const int nb = a.nb, K = nb - 1, nf = a.nf, nt = a.nt;
+  float* w = L;              // K weights -> pdf
+  float* cdf = L + nb;       // nb
+  float* bin = L + 2 * nb;   // nb
+  float* key = L + 3 * nb;   // P: coarse t, draws, +inf padding
+  if (a.t_coarse)
+    for (int i = lane; i < nt; i += 64) key[i] = a.t_coarse[ray * nt + i];
+  for (int i = lane; i < K; i += 64) w[i] = a.weights[ray * a.w_stride + i];
+  if (a.bins)
+    for (int i = lane; i < nb; i += 64) bin[i] = a.bins[ray * nb + i];
+  wave_lds_sync();
+  if (!a.bins)   // model.py:163  0.5 * (t[1:] + t[:-1])
+    for (int i = lane; i < nb; i += 64) bin[i] = __fmul_rn(0.5f, __fadd_rn(key[i + 1], key[i]));
+  // helper.py:205-211
+  float wsum = aten_row_sum(w, K, lane);
+  const float padding = __builtin_fmaxf(0.f, __fsub_rn(1e-5f, wsum));
+  const float pad_each = __fdiv_rn(padding, (float)K);
+  wsum = __fadd_rn(wsum, padding);
+  wave_lds_sync();
+  for (int i = lane; i < K; i += 64) w[i] = __fdiv_rn(__fadd_rn(w[i], pad_each), wsum);
+  wave_lds_sync();
+  // helper.py:212-222: cdf = [0, min(1, cumsum(pdf[:-1])), 1]
+  double run = 0.0;
+  for (int i = 0; i + 1 < K; ++i) {   // wave-uniform chain (broadcast LDS reads); lane i % 64 keeps prefix i
+    run += (double)w[i];
+    if ((i & 63) == lane) cdf[i + 1] = __builtin_fminf(1.f, (float)run);
+  }
+  if (lane == 0) { cdf[0] = 0.f; cdf[nb - 1] = 1.f; }
+  wave_lds_sync();
+  // helper.py:224-243
+  for (int j = lane; j < nf; j += 64) {
+    const float u = a.u[ray * a.u_stride + j];
+    int lo = 0, hi = nb;               // idx = #(cdf <= u): the mask `u >= cdf` of the reference is a prefix (cdf non-decreasing)
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (cdf[mid] <= u) lo = mid + 1; else hi = mid;
+    }
+    const int i0 = lo - 1 < 0 ? 0 : lo - 1, i1 = lo > nb - 1 ? nb - 1 : lo;
+    const float c0 = cdf[i0], c1 = cdf[i1], b0 = bin[i0], b1 = bin[i1];
+    float t = __fdiv_rn(__fsub_rn(u, c0), __fsub_rn(c1, c0));
+    if (t != t) t = 0.f;
+    t = __builtin_fminf(__builtin_fmaxf(t, 0.f), 1.f);
+    const float smp = __fadd_rn(b0, __fmul_rn(t, __fsub_rn(b1, b0)));
+    if (a.samples) a.samples[ray * nf + j] = smp;
+    key[nt + j] = smp;
+  }
+  if (!a.t_fine) return;
+  const int P = a.P, tot = nt + nf;
+  for (int i = tot + lane; i < P; i += 64) key[i] = __builtin_inff();
+  wave_lds_sync();
+  for (int k = 2; k <= P; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int p = lane; p < P / 2; p += 64) {
+        const int i = ((p & ~(j - 1)) << 1) | (p & (j - 1));   // the pair's lower index: bit j clear
+        const int q = i | j;
+        const float x = key[i], y = key[q];
+        const bool up = (i & k) == 0;
+        const float mn = __builtin_fminf(x, y), mx = __builtin_fmaxf(x, y);
+        key[i] = up ? mn : mx;
+        key[q] = up ? mx : mn;
+      }
+      wave_lds_sync();
+    }
+  }
+  for (int i = lane; i < tot; i += 64) a.t_fine[ray * tot + i] = key[i];
+}
+
+int64_t sample_pdf_n_lds_bytes(int nb, int nf, int nt, int* P_out) {
+  int P = 2;
+  while (P < nt + nf) P <<= 1;
+  if (P_out) *P_out = P;
+  return (int64_t)(3 * nb + P) * 4;
+}
+
+hipError_t launch_sample_pdf_n(const float* bins, const float* weights, int64_t w_stride, const float* t_coarse, const float* u,
+                               int64_t u_stride, int64_t n_rays, int nb, int nf, int nt, float* samples, float* t_fine, hipStream_t stream) {
+  if (n_rays <= 0) return hipSuccess;
+  PdfNArgs a{bins, weights, w_stride, t_coarse, u, u_stride, n_rays, nb, nf, nt, 0, samples, t_fine};
+  const int64_t lds = sample_pdf_n_lds_bytes(nb, nf, nt, &a.P);
+  if (lds > 64 * 1024) return hipErrorInvalidValue;
+  sample_pdf_n_kernel<<<dim3((unsigned)n_rays), dim3(64), (size_t)lds, stream>>>(a);
+  return hipGetLastError();
+}
+
 }  // namespace aon

@@ -29,18 +29,21 @@ struct CompositeBwdArgs {
   const float* g_rgb;   // (n,3) dL/d comp_rgb
   const float* g_acc;   // (n,) or null
   const float* g_depth; // (n,) or null
-  int64_t n_rays; int S; int white_bkgd; int act;
+  int64_t n_rays; int S; int white_bkgd; ActParams ap;
   float* d_raw;         // (n*S,4) dL/d raw
 };
 
 __device__ __forceinline__ float sigmoidf_(float x) { return __fdiv_rn(1.0f, __fadd_rn(1.0f, expf(-x))); }
 
+// NB: blocks of 64 samples held in registers -- 4 for the reference geometry (S <= 256), 16 for anything up to S = 1024
+template <int NB>
 __global__ void __launch_bounds__(256) composite_bwd_kernel(CompositeBwdArgs a) {
   const int lane = threadIdx.x & 63;
   const int64_t ray = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (ray >= a.n_rays) return;
   const int S = a.S;
-  const int nblk = (S + 63) >> 6;  // <= 4 (S <= 256)
+  const ActParams ap = a.ap;
+  const int nblk = (S + 63) >> 6;  // <= NB
   const float* tv = a.t_vals + ray * S;
   const float dn = __fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(a.dirs[ray * 3], a.dirs[ray * 3]),
                                                   __fmul_rn(a.dirs[ray * 3 + 1], a.dirs[ray * 3 + 1])),
@@ -50,11 +53,11 @@ __global__ void __launch_bounds__(256) composite_bwd_kernel(CompositeBwdArgs a) 
   // dL/dw_i = gC.c_i - [white] sum(gC) + g_acc + t_i g_depth     (comp_rgb += 1 - acc, helper.py:187-188)
   const float gw_const = gA - (a.white_bkgd ? (gC0 + gC1 + gC2) : 0.f);
 
-  float alpha[4], ex[4], T[4], f[4], dist[4], wgw[4], gw[4], dsig_draw[4], w_[4];
-  float dc0[4], dc1[4], dc2[4];  // d c / d raw  (activation derivative), later reused as gC.c' products
+  float alpha[NB], ex[NB], T[NB], f[NB], dist[NB], wgw[NB], gw[NB], dsig_draw[NB], w_[NB];
+  float dc0[NB], dc1[NB], dc2[NB];  // d c / d raw  (activation derivative), later reused as gC.c' products
   float carry = 1.0f;
 #pragma unroll
-  for (int b = 0; b < 4; ++b) {
+  for (int b = 0; b < NB; ++b) {
     alpha[b] = 0.f; ex[b] = 1.f; T[b] = 0.f; f[b] = 1.f; dist[b] = 0.f; wgw[b] = 0.f; gw[b] = 0.f; dsig_draw[b] = 0.f; w_[b] = 0.f;
     dc0[b] = dc1[b] = dc2[b] = 0.f;
     if (b < nblk) {
@@ -65,18 +68,19 @@ __global__ void __launch_bounds__(256) composite_bwd_kernel(CompositeBwdArgs a) 
         const int64_t g = ray * S + s;
         t = tv[s];
         dist[b] = __fmul_rn(s == S - 1 ? 1e10f : __fsub_rn(tv[s + 1], t), dn);
-        const float4 r = reinterpret_cast<const float4*>(a.raw)[g];
+        float4 r = reinterpret_cast<const float4*>(a.raw)[g];
+        if (ap.noise) r.w = __fadd_rn(r.w, __fmul_rn(ap.noise[g], ap.noise_std));   // model.py:183-184 (d/d raw_sigma = 1)
         float sg;
-        if (a.act == 1) {
+        if (ap.act == 1) {
           sg = __builtin_fmaxf(r.w, 0.f); dsig_draw[b] = r.w > 0.f ? 1.f : 0.f;
           c0 = sigmoidf_(r.x); c1 = sigmoidf_(r.y); c2 = sigmoidf_(r.z);
           dc0[b] = c0 * (1.f - c0); dc1[b] = c1 * (1.f - c1); dc2[b] = c2 * (1.f - c2);
-        } else if (a.act == 2) {
-          const float xs = r.w - 1.0f;
+        } else if (ap.act == 2) {
+          const float xs = __fadd_rn(r.w, ap.sigma_bias);
           sg = xs > 20.0f ? xs : log1pf(expf(xs)); dsig_draw[b] = xs > 20.0f ? 1.f : sigmoidf_(xs);
           const float s0 = sigmoidf_(r.x), s1 = sigmoidf_(r.y), s2 = sigmoidf_(r.z);
-          c0 = s0 * 1.002f - 0.001f; c1 = s1 * 1.002f - 0.001f; c2 = s2 * 1.002f - 0.001f;
-          dc0[b] = 1.002f * s0 * (1.f - s0); dc1[b] = 1.002f * s1 * (1.f - s1); dc2[b] = 1.002f * s2 * (1.f - s2);
+          c0 = s0 * ap.rgb_scale - ap.rgb_shift; c1 = s1 * ap.rgb_scale - ap.rgb_shift; c2 = s2 * ap.rgb_scale - ap.rgb_shift;
+          dc0[b] = ap.rgb_scale * s0 * (1.f - s0); dc1[b] = ap.rgb_scale * s1 * (1.f - s1); dc2[b] = ap.rgb_scale * s2 * (1.f - s2);
         } else {
           sg = r.w; dsig_draw[b] = 1.f; c0 = r.x; c1 = r.y; c2 = r.z; dc0[b] = dc1[b] = dc2[b] = 1.f;
         }
@@ -103,7 +107,7 @@ __global__ void __launch_bounds__(256) composite_bwd_kernel(CompositeBwdArgs a) 
   // suffix sums  Sfx_i = sum_{k>i} w_k gw_k, scanned from the far end (no subtractive cancellation)
   float sfx_carry = 0.f;
 #pragma unroll
-  for (int b = 3; b >= 0; --b) {
+  for (int b = NB - 1; b >= 0; --b) {
     if (b < nblk) {
       float incl = wgw[b];
 #pragma unroll
@@ -131,11 +135,13 @@ __global__ void __launch_bounds__(256) composite_bwd_kernel(CompositeBwdArgs a) 
 }
 
 hipError_t launch_composite_bwd(const float* raw, const float* t_vals, const float* dirs, const float* g_rgb, const float* g_acc,
-                                const float* g_depth, int64_t n_rays, int S, int white_bkgd, int act, float* d_raw,
+                                const float* g_depth, int64_t n_rays, int S, int white_bkgd, const ActParams& ap, float* d_raw,
                                 hipStream_t stream) {
   if (n_rays <= 0) return hipSuccess;
-  CompositeBwdArgs a{raw, t_vals, dirs, g_rgb, g_acc, g_depth, n_rays, S, white_bkgd, act, d_raw};
-  composite_bwd_kernel<<<dim3((unsigned)((n_rays + 3) / 4)), dim3(256), 0, stream>>>(a);
+  if (S > 1024) return hipErrorInvalidValue;
+  CompositeBwdArgs a{raw, t_vals, dirs, g_rgb, g_acc, g_depth, n_rays, S, white_bkgd, ap, d_raw};
+  if (S <= 256) composite_bwd_kernel<4><<<dim3((unsigned)((n_rays + 3) / 4)), dim3(256), 0, stream>>>(a);
+  else composite_bwd_kernel<16><<<dim3((unsigned)((n_rays + 3) / 4)), dim3(256), 0, stream>>>(a);
   return hipGetLastError();
 }
 

@@ -4,8 +4,9 @@ return structure), every function backed by a HIP kernel through the C ABI (``ao
 Differences a caller can observe, all additive:
   * the random draws the reference takes from ``torch.rand`` inside ``sample_along_rays`` (helper.py:126) and
     ``sorted_piecewise_constant_pdf`` (helper.py:227) can be supplied (``t_rand=`` / ``u=``) for reproducibility;
-    when omitted and ``randomized`` is true they are drawn with ``torch.rand`` on the inputs' device;
-  * ``lindisp=True`` (never taken on the reference's path, model.py:134) is not implemented and raises.
+    when omitted and ``randomized`` is true they are drawn with ``torch.rand`` on the inputs' device.
+``lindisp``, any ``num_samples`` and any ``float_min_eps`` are served (round 3): the reference geometry (64 bins, 128 draws)
+by the specialised kernels, everything else by ``aon_sample_pdf_n`` -- same bits where they overlap.
 """
 from __future__ import annotations
 
@@ -33,11 +34,9 @@ def cast_rays(t_vals, origins, directions):
 
 def sample_along_rays(rays_o, rays_d, num_samples, near, far, randomized, lindisp, t_rand=None):
     """helper.py:106-133 -> (t_vals (N,num_samples+1), coords (N,num_samples+1,3))"""
-    if lindisp:
-        raise NotImplementedError("lindisp sampling is never used on the reference path (model.py:134) and has no HIP kernel")
     if randomized and t_rand is None:
         t_rand = torch.rand((rays_o.shape[0], num_samples + 1), device=rays_o.device)
-    return ops.sample_along_rays(rays_o, rays_d, num_samples, near, far, t_rand if randomized else None)
+    return ops.sample_along_rays(rays_o, rays_d, num_samples, near, far, t_rand if randomized else None, lindisp=bool(lindisp))
 
 
 def pos_enc(x, min_deg, max_deg):
@@ -54,20 +53,21 @@ def volumetric_rendering(rgb, density, t_vals, dirs, white_bkgd, nocs=None):
 
 def sorted_piecewise_constant_pdf(bins, weights, num_samples, randomized, float_min_eps=2 ** -32, u=None):
     """helper.py:203-243 -> samples (N,num_samples)"""
-    if num_samples != 128 or float_min_eps != 2 ** -32:
-        raise NotImplementedError("the HIP inverse-CDF kernel is fixed to the reference geometry (128 samples, eps 2^-32)")
     if randomized and u is None:
         u = torch.rand((bins.shape[0], num_samples), device=bins.device)
-    return ops.sorted_piecewise_constant_pdf(bins, weights, u if randomized else None)
+    if not randomized:   # helper.py:229; the default eps takes the cached vector
+        u = None if float_min_eps == 2 ** -32 else torch.linspace(0.0, 1.0 - float_min_eps, num_samples).to(bins.device)
+    return ops.sorted_piecewise_constant_pdf(bins, weights, u, num_samples=num_samples)
 
 
 def sample_pdf(bins, weights, origins, directions, t_vals, num_samples, randomized, u=None):
-    """helper.py:246-252 -> (t_vals (N,193), coords (N,193,3))"""
-    if num_samples != 128:
-        raise NotImplementedError("the HIP inverse-CDF kernel is fixed to 128 fine samples")
+    """helper.py:246-252 -> (t_vals (N, S + num_samples), coords (N, S + num_samples, 3))"""
     if randomized and u is None:
         u = torch.rand((bins.shape[0], num_samples), device=bins.device)
-    t_fine = ops.sample_pdf_t(t_vals, weights, u if randomized else None, bins=bins)
+    if (t_vals.shape[1], bins.shape[1], num_samples) == (65, 64, 128):
+        t_fine = ops.sample_pdf_t(t_vals, weights, u if randomized else None, bins=bins)
+    else:
+        t_fine = ops.sample_pdf_t_n(t_vals, weights, num_samples, u if randomized else None, bins=bins)
     return t_fine, ops.cast_rays(t_fine, origins, directions)
 
 

@@ -90,17 +90,18 @@ class NeRF(nn.Module):
     ``rays_o``, ``rays_d``, ``viewdirs`` (extra keys are ignored, as in the reference) returns
     ``[(comp_rgb, acc, depth)_coarse, (comp_rgb, acc, depth)_fine]``.
 
-    ``t_rand`` (N,65) / ``u`` (N,128) optionally replace the reference's in-function ``torch.rand`` draws."""
+    ``t_rand`` (N,num_coarse+1) / ``u`` (N,num_fine) / ``noise`` (per level (N,S), read when ``noise_std > 0 and randomized``,
+    model.py:183-184) optionally replace the reference's in-function ``torch.rand`` / ``torch.rand_like`` draws."""
 
     def __init__(self, num_levels: int = 2, min_deg_point: int = 0, max_deg_point: int = 10, deg_view: int = 4,
                  num_coarse_samples: int = 64, num_fine_samples: int = 128, use_viewdirs: bool = True,
                  noise_std: float = 0.0, lindisp: bool = False):
         super().__init__()
-        if (num_coarse_samples, num_fine_samples, use_viewdirs, lindisp) != (64, 128, True, False) or num_levels not in (1, 2):
-            raise NotImplementedError("only the reference's default sampling geometry (64 coarse + 128 fine, viewdirs, "
-                                      "no lindisp) has HIP kernels")
-        if noise_std != 0.0:
-            raise NotImplementedError("noise_std > 0 is dead code on the reference path (model.py:183-184, default 0)")
+        if num_levels not in (1, 2):
+            raise NotImplementedError("num_levels must be 1 or 2 (a third level would resample from the fine level's 193 weights)")
+        # sample counts, lindisp and noise_std are runtime arguments of the C calls (aon_render_opts); use_viewdirs is stored and
+        # never read by the reference's forward (model.py:147-199 always encodes rays["viewdirs"])
+        self._opts = ops.RenderOpts(num_coarse_samples, num_fine_samples, lindisp, noise_std)
         self.num_levels, self.min_deg_point, self.max_deg_point, self.deg_view = num_levels, min_deg_point, max_deg_point, deg_view
         self.num_coarse_samples, self.num_fine_samples = num_coarse_samples, num_fine_samples
         self.use_viewdirs, self.noise_std, self.lindisp = use_viewdirs, noise_std, lindisp
@@ -109,7 +110,15 @@ class NeRF(nn.Module):
         self.coarse_mlp = NeRFMLP(min_deg_point, max_deg_point, deg_view)
         self.fine_mlp = NeRFMLP(min_deg_point, max_deg_point, deg_view)
 
-    def forward(self, rays, randomized, white_bkgd, near, far, t_rand=None, u=None):
+    def _draw_noise(self, noise, randomized, n, device):
+        if not (self.noise_std > 0 and randomized):
+            return None
+        noise = list(noise) if noise is not None else []
+        noise += [None] * (self.num_levels - len(noise))
+        return [noise[lvl] if noise[lvl] is not None else torch.rand((n, self._opts.S(lvl)), device=device)
+                for lvl in range(self.num_levels)]
+
+    def forward(self, rays, randomized, white_bkgd, near, far, t_rand=None, u=None, noise=None):
         rays_o = rays["rays_o"]
         n = rays_o.shape[0]
         if randomized:
@@ -119,6 +128,7 @@ class NeRF(nn.Module):
                 u = torch.rand((n, self.num_fine_samples), device=rays_o.device)
         else:
             t_rand, u = None, None
+        noise = self._draw_noise(noise, randomized, n, rays_o.device)
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             # training: fused forward that keeps the activation planes + HIP backward (autograd.RenderVanilla)
             if n == 0:
@@ -127,12 +137,12 @@ class NeRF(nn.Module):
             packs = [(m.packed(True), m.packed_bwd(True)) for m in mlps]
             params = [p for m in mlps for p in m.ordered_params()]
             flat = RenderVanilla.apply(rays_o, rays["rays_d"], rays["viewdirs"], float(near), float(far), bool(white_bkgd),
-                                       self.num_levels, t_rand, u, packs, *params)
+                                       self.num_levels, t_rand, u, packs, self._opts, noise, *params)
             return [tuple(flat[3 * i: 3 * i + 3]) for i in range(self.num_levels)]
         coarse = self.coarse_mlp.packed()
         fine = self.fine_mlp.packed() if self.num_levels == 2 else None
         outs = ops.render_fwd(coarse, fine, rays_o, rays["rays_d"], rays["viewdirs"], near, far,
-                              white_bkgd, self.num_levels, t_rand, u)
+                              white_bkgd, self.num_levels, t_rand, u, opts=self._opts, noise=noise)
         return [tuple(o) for o in outs]
 
 

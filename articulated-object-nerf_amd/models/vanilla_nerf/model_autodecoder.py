@@ -103,9 +103,12 @@ class NeRF_AE_Art(nn.Module):
                  noise_std: float = 0.0, lindisp: bool = False, rgb_padding: float = 0.001, density_bias: float = -1.0,
                  enc_after=True, embed_deg=False):
         super().__init__()
-        if (num_coarse_samples, num_fine_samples, use_viewdirs, lindisp, rgb_padding, density_bias, enc_after, embed_deg) != \
-                (64, 128, True, False, 0.001, -1.0, True, False) or num_levels not in (1, 2) or noise_std != 0.0:
-            raise NotImplementedError("only the reference's default NeRF_AE_Art configuration has HIP kernels")
+        if (enc_after, embed_deg) != (True, False) or num_levels not in (1, 2):
+            raise NotImplementedError("enc_after=False / embed_deg=True change the network (model_autodecoder.py:95-103,181-184): only the "
+                                      "reference's default articulated NeRFMLP has HIP kernels; num_levels must be 1 or 2")
+        # sample counts, lindisp, noise_std, rgb_padding and density_bias are runtime arguments of the C calls (aon_render_opts)
+        self._opts = ops.RenderOpts(num_coarse_samples, num_fine_samples, lindisp, noise_std, rgb_padding, density_bias)
+        self.use_viewdirs, self.noise_std, self.lindisp = use_viewdirs, noise_std, lindisp
         self.num_levels, self.min_deg_point, self.max_deg_point, self.deg_view = num_levels, min_deg_point, max_deg_point, deg_view
         self.num_coarse_samples, self.num_fine_samples = num_coarse_samples, num_fine_samples
         self.rgb_padding, self.density_bias, self.enc_after, self.embed_deg = rgb_padding, density_bias, enc_after, embed_deg
@@ -114,7 +117,7 @@ class NeRF_AE_Art(nn.Module):
         self.coarse_mlp = NeRFMLP(min_deg_point, max_deg_point, deg_view)
         self.fine_mlp = NeRFMLP(min_deg_point, max_deg_point, deg_view)
 
-    def forward(self, rays, randomized, white_bkgd, near, far, latents, train=True, t_rand=None, u=None):
+    def forward(self, rays, randomized, white_bkgd, near, far, latents, train=True, t_rand=None, u=None, noise=None):
         rays_o = rays["rays_o"]
         n = rays_o.shape[0]
         if randomized:
@@ -124,6 +127,13 @@ class NeRF_AE_Art(nn.Module):
                 u = torch.rand((n, self.num_fine_samples), device=rays_o.device)
         else:
             t_rand, u = None, None
+        if self.noise_std > 0 and randomized:   # model_autodecoder.py:318-319
+            noise = list(noise) if noise is not None else []
+            noise += [None] * (self.num_levels - len(noise))
+            noise = [noise[lvl] if noise[lvl] is not None else torch.rand((n, self._opts.S(lvl)), device=rays_o.device)
+                     for lvl in range(self.num_levels)]
+        else:
+            noise = None
         if torch.is_grad_enabled() and (any(p.requires_grad for p in self.parameters())
                                         or any(getattr(v, "requires_grad", False) for v in latents.values())):
             # training: HIP forward that keeps the activation planes + HIP backward (autograd.RenderArticulated);
@@ -135,14 +145,15 @@ class NeRF_AE_Art(nn.Module):
                 packs.append((mlp.packed(True), small, mlp.packed_bwd(True)))
             params = [p for mlp in mlps for p in mlp.ordered_params()]
             flat = RenderArticulated.apply(rays_o, rays["rays_d"], rays["viewdirs"], float(near), float(far), bool(white_bkgd),
-                                           self.num_levels, t_rand, u, packs, latents["density"], latents["color"],
+                                           self.num_levels, t_rand, u, packs, self._opts, noise, latents["density"], latents["color"],
                                            latents["articulation"], *params)
             return [tuple(flat[3 * i: 3 * i + 3]) for i in range(self.num_levels)]
         two = self.num_levels == 2
         pc = self.coarse_mlp.packed()
         pf = self.fine_mlp.packed() if two else None
         outs = ops.art_render_fwd(pc, self.coarse_mlp.prepared(latents), pf, self.fine_mlp.prepared(latents) if two else None,
-                                  rays_o, rays["rays_d"], rays["viewdirs"], near, far, white_bkgd, self.num_levels, t_rand, u)
+                                  rays_o, rays["rays_d"], rays["viewdirs"], near, far, white_bkgd, self.num_levels, t_rand, u,
+                                  opts=self._opts, noise=noise)
         return [tuple(o) for o in outs]
 
 

@@ -95,7 +95,7 @@ def cast_rays(t_vals, origins, directions):
     return coords
 
 
-def sample_along_rays(rays_o, rays_d, num_samples: int, near: float, far: float, t_rand=None, want_coords=True):
+def sample_along_rays(rays_o, rays_d, num_samples: int, near: float, far: float, t_rand=None, want_coords=True, lindisp=False):
     o, d = _f32(rays_o, "rays_o"), _f32(rays_d, "rays_d")
     n, S = o.shape[0], num_samples + 1
     tr = None if t_rand is None else _f32(t_rand, "t_rand")
@@ -104,8 +104,12 @@ def sample_along_rays(rays_o, rays_d, num_samples: int, near: float, far: float,
     t_vals = torch.empty((n, S), dtype=torch.float32, device=o.device)
     coords = torch.empty((n, S, 3), dtype=torch.float32, device=o.device) if want_coords else None
     with torch.cuda.device(o.device):
-        check(lib.aon_sample_along_rays(_ptr(o), _ptr(d), n, S, float(near), float(far), _ptr(tr), _ptr(t_vals), _ptr(coords),
-                                        _stream()), "aon_sample_along_rays")
+        if lindisp:   # helper.py:117 evaluates 1.0 / near in Python double precision; ctypes rounds it to fp32 once, as torch does
+            check(lib.aon_sample_along_rays_ex(_ptr(o), _ptr(d), n, S, float(near), float(far), 1, 1.0 / near, 1.0 / far, _ptr(tr),
+                                               _ptr(t_vals), _ptr(coords), _stream()), "aon_sample_along_rays_ex")
+        else:
+            check(lib.aon_sample_along_rays(_ptr(o), _ptr(d), n, S, float(near), float(far), _ptr(tr), _ptr(t_vals), _ptr(coords),
+                                            _stream()), "aon_sample_along_rays")
     return t_vals, coords
 
 
@@ -182,6 +186,55 @@ def mlp_fwd_enc(packed, samples_enc, viewdirs_enc):
     return raw
 
 
+# ------------------------------------------------------------------ constructor arguments beyond the defaults
+class RenderOpts:
+    """Sampler / activation arguments of ``NeRF.__init__`` (model.py:124-135) and ``NeRF_AE_Art.__init__``
+    (model_autodecoder.py:241-257) -> ``aon_render_opts``.  Python numbers become fp32 exactly where torch would round them."""
+
+    def __init__(self, num_coarse_samples=64, num_fine_samples=128, lindisp=False, noise_std=0.0, rgb_padding=0.001, density_bias=-1.0):
+        self.num_coarse_samples, self.num_fine_samples = int(num_coarse_samples), int(num_fine_samples)
+        self.lindisp, self.noise_std = bool(lindisp), float(noise_std)
+        self.rgb_padding, self.density_bias = float(rgb_padding), float(density_bias)
+        if not 2 <= self.num_coarse_samples <= 1023 or self.num_fine_samples < 1:
+            raise ValueError("num_coarse_samples must be in [2, 1023] and num_fine_samples >= 1")
+
+    @property
+    def Sc(self) -> int:
+        return self.num_coarse_samples + 1
+
+    @property
+    def Sf(self) -> int:
+        return self.num_coarse_samples + 1 + self.num_fine_samples
+
+    def S(self, level: int) -> int:
+        return self.Sc if level == 0 else self.Sf
+
+    def c_struct(self, near: float, far: float, noise=None):
+        """-> (aon_render_opts, tensors to keep alive).  ``noise``: per-level (n,S) uniform draws or None (model.py:184)."""
+        st = _lib.RenderOptsC()
+        lib.aon_render_opts_init(C.byref(st))
+        st.num_coarse_samples, st.num_fine_samples, st.lindisp = self.num_coarse_samples, self.num_fine_samples, int(self.lindisp)
+        if self.lindisp:
+            st.inv_near, st.inv_far = 1.0 / near, 1.0 / far      # double -> fp32 once (helper.py:117)
+        st.rgb_scale, st.rgb_shift, st.sigma_bias = 1 + 2 * self.rgb_padding, self.rgb_padding, self.density_bias
+        keep = []
+        if noise is not None and self.noise_std > 0:
+            st.noise_std = self.noise_std
+            for lvl, field in enumerate(("noise_c", "noise_f")):
+                if lvl < len(noise) and noise[lvl] is not None:
+                    t = _f32(noise[lvl], "noise")
+                    keep.append(t)
+                    setattr(st, field, t.data_ptr())
+        return st, keep
+
+
+DEFAULT_OPTS = RenderOpts()
+
+
+def _opts(opts):
+    return DEFAULT_OPTS if opts is None else opts
+
+
 # ------------------------------------------------------------------ R8 compositing
 def _composite(rgb_t, rgb_stride, sig_t, sig_off, sig_stride, t_vals, dirs, white_bkgd, act, want_weights):
     t, d = _f32(t_vals, "t_vals"), _f32(dirs, "dirs")
@@ -204,46 +257,87 @@ def volumetric_rendering(rgb, density, t_vals, dirs, white_bkgd):
     return _composite(r, 3, s, 0, 1, t_vals, dirs, white_bkgd, ACT_NONE, True)
 
 
-def composite_raw(raw, t_vals, dirs, white_bkgd, act=ACT_VANILLA, want_weights=True):
-    """Activation + compositing of the fused kernel's packed raw (n,S,4)."""
+def composite_raw(raw, t_vals, dirs, white_bkgd, act=ACT_VANILLA, want_weights=True, opts=None, noise=None):
+    """Activation + compositing of the fused kernel's packed raw (n,S,4).  ``opts`` / ``noise`` (n,S): the activation scalars
+    and the density noise of a non-default constructor (aon_composite_ex)."""
     r = _f32(raw, "raw")
-    return _composite(r, 4, r, 3, 4, t_vals, dirs, white_bkgd, act, want_weights)
+    if opts is None and noise is None:
+        return _composite(r, 4, r, 3, 4, t_vals, dirs, white_bkgd, act, want_weights)
+    t, d = _f32(t_vals, "t_vals"), _f32(dirs, "dirs")
+    n, S = t.shape
+    dev = t.device
+    st, keep = _opts(opts).c_struct(1.0, 1.0, [noise])
+    comp = torch.empty((n, 3), dtype=torch.float32, device=dev)
+    acc = torch.empty((n,), dtype=torch.float32, device=dev)
+    depth = torch.empty((n,), dtype=torch.float32, device=dev)
+    weights = torch.empty((n, S), dtype=torch.float32, device=dev) if want_weights else None
+    with torch.cuda.device(dev):
+        check(lib.aon_composite_ex(_ptr(r), 4, C.c_void_p(r.data_ptr() + 12), 4, _ptr(t), _ptr(d), n, S, int(bool(white_bkgd)), act,
+                                   C.byref(st), _ptr(comp), _ptr(acc), _ptr(depth), _ptr(weights), _stream()), "aon_composite_ex")
+    return comp, acc, weights, depth
 
 
 # ------------------------------------------------------------------ R6/R7 inverse CDF
 _U_CACHE: dict = {}
 
 
-def deterministic_u(device) -> torch.Tensor:
-    """helper.py:229: torch.linspace(0, 1 - 2**-32, 128) (fp32; the last element rounds to exactly 1.0).
+def deterministic_u(device, num_samples: int = 128) -> torch.Tensor:
+    """helper.py:229: torch.linspace(0, 1 - 2**-32, num_samples) (fp32; the last element rounds to exactly 1.0).
     Computed once on the host and copied, so it is the same vector the reference builds."""
-    key = str(device)
+    key = (str(device), num_samples)
     if key not in _U_CACHE:
-        _U_CACHE[key] = torch.linspace(0.0, 1.0 - 2.0 ** -32, 128).to(device)
+        _U_CACHE[key] = torch.linspace(0.0, 1.0 - 2.0 ** -32, num_samples).to(device)
     return _U_CACHE[key]
 
 
-def _u_args(u, n, device):
+def _u_args(u, n, device, nf: int = 128):
     if u is None:
-        return deterministic_u(device), 0
+        return deterministic_u(device, nf), 0
     uu = _f32(u, "u")
-    if tuple(uu.shape) == (128,):
+    if tuple(uu.shape) == (nf,):
         return uu, 0
-    if tuple(uu.shape) != (n, 128):
-        raise ValueError(f"u must be (128,) or ({n},128), got {tuple(uu.shape)}")
-    return uu, 128
+    if tuple(uu.shape) != (n, nf):
+        raise ValueError(f"u must be ({nf},) or ({n},{nf}), got {tuple(uu.shape)}")
+    return uu, nf
 
 
-def sorted_piecewise_constant_pdf(bins, weights, u=None):
+def sorted_piecewise_constant_pdf(bins, weights, u=None, num_samples: int = 128):
+    """helper.sorted_piecewise_constant_pdf: bins (n,nb), weights (n,nb-1) -> num_samples draws per ray.  The reference
+    geometry (64 bins, 128 draws) runs the specialised kernel, anything else aon_sample_pdf_n (same bits where they overlap)."""
     b, w = _f32(bins, "bins"), _f32(weights, "weights")
-    n = b.shape[0]
-    if tuple(b.shape) != (n, 64) or tuple(w.shape) != (n, 63):
-        raise ValueError("HIP inverse-CDF is fixed to the reference geometry: bins (n,64), weights (n,63)")
-    uu, us = _u_args(u, n, b.device)
-    samples = torch.empty((n, 128), dtype=torch.float32, device=b.device)
+    n, nb = b.shape
+    if tuple(w.shape) != (n, nb - 1) or nb < 2:
+        raise ValueError(f"weights must be ({n},{nb - 1}) for bins ({n},{nb})")
+    uu, us = _u_args(u, n, b.device, num_samples)
+    samples = torch.empty((n, num_samples), dtype=torch.float32, device=b.device)
     with torch.cuda.device(b.device):
-        check(lib.aon_sample_pdf(_ptr(b), _ptr(w), 63, None, _ptr(uu), us, n, _ptr(samples), None, _stream()), "aon_sample_pdf")
+        if (nb, num_samples) == (64, 128):
+            check(lib.aon_sample_pdf(_ptr(b), _ptr(w), 63, None, _ptr(uu), us, n, _ptr(samples), None, _stream()), "aon_sample_pdf")
+        else:
+            check(lib.aon_sample_pdf_n(_ptr(b), _ptr(w), nb - 1, None, _ptr(uu), us, n, nb, num_samples, 0, _ptr(samples), None, _stream()),
+                  "aon_sample_pdf_n")
     return samples
+
+
+def sample_pdf_t_n(t_coarse, coarse_weights, num_samples: int, u=None, bins=None, force_generic=False):
+    """sample_pdf_t for any sizes: t_coarse (n,nt), the full coarse weights (n,nt) (the pdf uses weights[...,1:-1]) or explicit
+    (bins (n,nb), weights (n,nb-1)) -> t_fine (n, nt + num_samples), through aon_sample_pdf_n."""
+    t, w = _f32(t_coarse, "t_coarse"), _f32(coarse_weights, "weights")
+    n, nt = t.shape
+    b = None if bins is None else _f32(bins, "bins")
+    nb = nt - 1 if b is None else b.shape[1]
+    if tuple(w.shape) == (n, nb + 1):
+        w_ptr, w_stride = C.c_void_p(w.data_ptr() + 4), nb + 1
+    elif tuple(w.shape) == (n, nb - 1):
+        w_ptr, w_stride = _ptr(w), nb - 1
+    else:
+        raise ValueError(f"weights must be ({n},{nb + 1}) or ({n},{nb - 1})")
+    uu, us = _u_args(u, n, t.device, num_samples)
+    t_fine = torch.empty((n, nt + num_samples), dtype=torch.float32, device=t.device)
+    with torch.cuda.device(t.device):
+        check(lib.aon_sample_pdf_n(_ptr(b), w_ptr, w_stride, _ptr(t), _ptr(uu), us, n, nb, num_samples, nt, None, _ptr(t_fine), _stream()),
+              "aon_sample_pdf_n")
+    return t_fine
 
 
 def sample_pdf_t(t_coarse, coarse_weights, u=None, bins=None):
@@ -301,8 +395,10 @@ _WS_CACHE: dict = {}
 MAX_CHUNK_RAYS = 327680
 
 
-def _workspace(device, n_rays: int) -> torch.Tensor:
-    need = int(lib.aon_render_workspace_bytes(min(n_rays, MAX_CHUNK_RAYS)))
+def _workspace(device, n_rays: int, st=None) -> torch.Tensor:
+    need = int(lib.aon_render_workspace_bytes_ex(min(n_rays, MAX_CHUNK_RAYS), None if st is None else C.byref(st)))
+    if need < 0:
+        check(need, "aon_render_workspace_bytes_ex")
     key = str(device)
     ws = _WS_CACHE.get(key)
     if ws is None or ws.numel() < need:
@@ -311,25 +407,41 @@ def _workspace(device, n_rays: int) -> torch.Tensor:
     return ws
 
 
-def render_fwd(packed_coarse, packed_fine, rays_o, rays_d, viewdirs, near, far, white_bkgd, num_levels=2, t_rand=None, u=None):
-    """NeRF.forward: returns [(rgb, acc, depth)_coarse, (rgb, acc, depth)_fine] (fine omitted if num_levels == 1)."""
+def _check_noise(noise, n, op, num_levels):
+    if noise is None:
+        return None
+    out = []
+    for lvl in range(num_levels):
+        t = noise[lvl] if lvl < len(noise) else None
+        if t is not None and t.numel() != n * op.S(lvl):
+            raise ValueError(f"noise[{lvl}] must hold ({n},{op.S(lvl)}) values, got {tuple(t.shape)}")
+        out.append(t)
+    return out
+
+
+def render_fwd(packed_coarse, packed_fine, rays_o, rays_d, viewdirs, near, far, white_bkgd, num_levels=2, t_rand=None, u=None,
+               opts=None, noise=None):
+    """NeRF.forward: returns [(rgb, acc, depth)_coarse, (rgb, acc, depth)_fine] (fine omitted if num_levels == 1).
+    ``opts`` (RenderOpts): non-default sample counts / lindisp / noise_std; ``noise``: per-level (n,S) uniform draws."""
     o, d, v = _f32(rays_o, "rays_o"), _f32(rays_d, "rays_d"), _f32(viewdirs, "viewdirs")
     n, dev = o.shape[0], o.device
+    op = _opts(opts)
     tr = None if t_rand is None else _f32(t_rand, "t_rand")
-    if tr is not None and tuple(tr.shape) != (n, 65):
-        raise ValueError(f"t_rand must be ({n},65)")
-    uu, us = _u_args(u, n, dev) if num_levels == 2 else (None, 0)
+    if tr is not None and tuple(tr.shape) != (n, op.Sc):
+        raise ValueError(f"t_rand must be ({n},{op.Sc})")
+    uu, us = _u_args(u, n, dev, op.num_fine_samples) if num_levels == 2 else (None, 0)
     outs = []
     for _ in range(num_levels):
         outs.append((torch.empty((n, 3), dtype=torch.float32, device=dev), torch.empty((n,), dtype=torch.float32, device=dev),
                      torch.empty((n,), dtype=torch.float32, device=dev)))
     fine = outs[1] if num_levels == 2 else (None, None, None)
-    ws = _workspace(dev, n)
+    st, keep = op.c_struct(near, far, _check_noise(noise, n, op, num_levels))
+    ws = _workspace(dev, n, st)
     with torch.cuda.device(dev):
-        check(lib.aon_render_fwd(_ptr(packed_coarse), _ptr(packed_fine), _ptr(o), _ptr(d), _ptr(v), n, float(near), float(far),
-                                 int(bool(white_bkgd)), num_levels, _ptr(tr), _ptr(uu), us,
-                                 _ptr(outs[0][0]), _ptr(outs[0][1]), _ptr(outs[0][2]), _ptr(fine[0]), _ptr(fine[1]), _ptr(fine[2]),
-                                 _ptr(ws), ws.numel(), _stream()), "aon_render_fwd")
+        check(lib.aon_render_fwd_ex(_ptr(packed_coarse), _ptr(packed_fine), _ptr(o), _ptr(d), _ptr(v), n, float(near), float(far),
+                                    int(bool(white_bkgd)), num_levels, _ptr(tr), _ptr(uu), us,
+                                    _ptr(outs[0][0]), _ptr(outs[0][1]), _ptr(outs[0][2]), _ptr(fine[0]), _ptr(fine[1]), _ptr(fine[2]),
+                                    _ptr(ws), ws.numel(), _stream(), C.byref(st)), "aon_render_fwd")
     return outs
 
 
@@ -424,25 +536,27 @@ def art_mlp_fwd_pos(packed, small, pos, viewdirs_enc):
 
 
 def art_render_fwd(packed_c, small_c, packed_f, small_f, rays_o, rays_d, viewdirs, near, far, white_bkgd, num_levels=2,
-                   t_rand=None, u=None):
+                   t_rand=None, u=None, opts=None, noise=None):
     """NeRF_AE_Art.forward: [(rgb, acc, depth)_coarse, (rgb, acc, depth)_fine]."""
     o, d, v = _f32(rays_o, "rays_o"), _f32(rays_d, "rays_d"), _f32(viewdirs, "viewdirs")
     n, dev = o.shape[0], o.device
+    op = _opts(opts)
     tr = None if t_rand is None else _f32(t_rand, "t_rand")
-    if tr is not None and tuple(tr.shape) != (n, 65):
-        raise ValueError(f"t_rand must be ({n},65)")
-    uu, us = _u_args(u, n, dev) if num_levels == 2 else (None, 0)
+    if tr is not None and tuple(tr.shape) != (n, op.Sc):
+        raise ValueError(f"t_rand must be ({n},{op.Sc})")
+    uu, us = _u_args(u, n, dev, op.num_fine_samples) if num_levels == 2 else (None, 0)
     outs = []
     for _ in range(num_levels):
         outs.append((torch.empty((n, 3), dtype=torch.float32, device=dev), torch.empty((n,), dtype=torch.float32, device=dev),
                      torch.empty((n,), dtype=torch.float32, device=dev)))
     fine = outs[1] if num_levels == 2 else (None, None, None)
-    ws = _workspace(dev, n)
+    st, keep = op.c_struct(near, far, _check_noise(noise, n, op, num_levels))
+    ws = _workspace(dev, n, st)
     with torch.cuda.device(dev):
-        check(lib.aon_art_render_fwd(_ptr(packed_c), _ptr(small_c), _ptr(packed_f), _ptr(small_f), _ptr(o), _ptr(d), _ptr(v), n,
+        check(lib.aon_art_render_fwd_ex(_ptr(packed_c), _ptr(small_c), _ptr(packed_f), _ptr(small_f), _ptr(o), _ptr(d), _ptr(v), n,
                  float(near), float(far), int(bool(white_bkgd)), num_levels, _ptr(tr), _ptr(uu), us,
                  _ptr(outs[0][0]), _ptr(outs[0][1]), _ptr(outs[0][2]), _ptr(fine[0]), _ptr(fine[1]), _ptr(fine[2]),
-                 _ptr(ws), ws.numel(), _stream()), "aon_art_render_fwd")
+                 _ptr(ws), ws.numel(), _stream(), C.byref(st)), "aon_art_render_fwd")
     return outs
 
 
@@ -598,16 +712,24 @@ def set_bwd_overlap(on: bool) -> None:
     check(lib.aon_set_bwd_overlap(int(bool(on))), "aon_set_bwd_overlap")
 
 
-def train_workspace(device, n_rays: int, articulated: bool, num_levels: int = 2) -> torch.Tensor:
+def _sized(nbytes: int, what: str, device) -> torch.Tensor:
+    if nbytes < 0:
+        check(nbytes, what)
+    return torch.empty(nbytes, dtype=torch.uint8, device=device)
+
+
+def train_workspace(device, n_rays: int, articulated: bool, num_levels: int = 2, st=None) -> torch.Tensor:
     """Fresh workspace of one training forward/backward pair (it carries the forward's planes to the backward, so it is
     owned by the autograd graph, not cached); sized by the levels in use."""
-    return torch.empty(int(lib.aon_train_workspace_bytes(n_rays, int(articulated), num_levels)), dtype=torch.uint8, device=device)
+    return _sized(int(lib.aon_train_workspace_bytes_ex(n_rays, int(articulated), num_levels, None if st is None else C.byref(st))),
+                  "aon_train_workspace_bytes_ex", device)
 
 
-def train_scratch(device, n_rays: int, articulated: bool, num_levels: int = 2) -> torch.Tensor:
+def train_scratch(device, n_rays: int, articulated: bool, num_levels: int = 2, st=None) -> torch.Tensor:
     """The backward's own temporaries (gradient planes, d_raw, weight-gradient partials): allocated when the backward runs and
     handed back to torch's caching allocator right after, so a live graph pins the forward's workspace only."""
-    return torch.empty(int(lib.aon_train_scratch_bytes(n_rays, int(articulated), num_levels)), dtype=torch.uint8, device=device)
+    return _sized(int(lib.aon_train_scratch_bytes_ex(n_rays, int(articulated), num_levels, None if st is None else C.byref(st))),
+                  "aon_train_scratch_bytes_ex", device)
 
 
 def _level_outs(n, dev, num_levels):
@@ -616,32 +738,37 @@ def _level_outs(n, dev, num_levels):
     return outs, (outs[1] if num_levels == 2 else (None, None, None))
 
 
-def render_fwd_train(packed_c, packed_f, rays_o, rays_d, viewdirs, near, far, white_bkgd, num_levels, t_rand, u, small_c=None, small_f=None):
-    """NeRF.forward / NeRF_AE_Art.forward (small blocks given) under grad mode in ONE C call -> (outs, workspace)."""
+def render_fwd_train(packed_c, packed_f, rays_o, rays_d, viewdirs, near, far, white_bkgd, num_levels, t_rand, u, small_c=None, small_f=None,
+                     opts=None, noise=None):
+    """NeRF.forward / NeRF_AE_Art.forward (small blocks given) under grad mode in ONE C call -> (outs, workspace, geometry).
+    ``geometry`` = (aon_render_opts struct, tensors it points at): the backward of this forward must be given the same one."""
     o, d, v = _f32(rays_o, "rays_o"), _f32(rays_d, "rays_d"), _f32(viewdirs, "viewdirs")
     n, dev = o.shape[0], o.device
     art = small_c is not None
+    op = _opts(opts)
     tr = None if t_rand is None else _f32(t_rand, "t_rand")
-    if tr is not None and tuple(tr.shape) != (n, 65):
-        raise ValueError(f"t_rand must be ({n},65)")
-    uu, us = _u_args(u, n, dev) if num_levels == 2 else (None, 0)
+    if tr is not None and tuple(tr.shape) != (n, op.Sc):
+        raise ValueError(f"t_rand must be ({n},{op.Sc})")
+    uu, us = _u_args(u, n, dev, op.num_fine_samples) if num_levels == 2 else (None, 0)
     outs, fine = _level_outs(n, dev, num_levels)
-    ws = train_workspace(dev, n, art, num_levels)
+    st, keep = op.c_struct(near, far, _check_noise(noise, n, op, num_levels))
+    ws = train_workspace(dev, n, art, num_levels, st)
     common = (_ptr(o), _ptr(d), _ptr(v), n, float(near), float(far), int(bool(white_bkgd)), num_levels, _ptr(tr), _ptr(uu), us,
-              _ptr(outs[0][0]), _ptr(outs[0][1]), _ptr(outs[0][2]), _ptr(fine[0]), _ptr(fine[1]), _ptr(fine[2]), _ptr(ws), ws.numel(), _stream())
+              _ptr(outs[0][0]), _ptr(outs[0][1]), _ptr(outs[0][2]), _ptr(fine[0]), _ptr(fine[1]), _ptr(fine[2]), _ptr(ws), ws.numel(), _stream(),
+              C.byref(st))
     with torch.cuda.device(dev):
         if art:
-            check(lib.aon_art_render_fwd_train(_ptr(packed_c), _ptr(small_c), _ptr(packed_f), _ptr(small_f), *common), "aon_art_render_fwd_train")
+            check(lib.aon_art_render_fwd_train_ex(_ptr(packed_c), _ptr(small_c), _ptr(packed_f), _ptr(small_f), *common), "aon_art_render_fwd_train")
         else:
-            check(lib.aon_render_fwd_train(_ptr(packed_c), _ptr(packed_f), *common), "aon_render_fwd_train")
-    return outs, ws
+            check(lib.aon_render_fwd_train_ex(_ptr(packed_c), _ptr(packed_f), *common), "aon_render_fwd_train")
+    return outs, ws, (st, keep)
 
 
 def _ptr_array(tensors):
     return (C.c_void_p * len(tensors))(*[0 if t is None else t.data_ptr() for t in tensors])
 
 
-def render_bwd(ws, packs_bwd, packs_fwd, rays_d, white_bkgd, num_levels, g_rgb, g_acc, g_depth):
+def render_bwd(ws, packs_bwd, packs_fwd, rays_d, white_bkgd, num_levels, g_rgb, g_acc, g_depth, geometry=None):
     """loss.backward() through render_fwd_train (vanilla): g_* = per-level lists (entries may be None except g_rgb)
     -> per-level dicts of the 24 parameter gradients."""
     d = _f32(rays_d, "rays_d")
@@ -651,15 +778,16 @@ def render_bwd(ws, packs_bwd, packs_fwd, rays_d, white_bkgd, num_levels, g_rgb, 
     pb, pf = list(packs_bwd) + [None] * (2 - num_levels), list(packs_fwd) + [None] * (2 - num_levels)
     keep = [None if t is None else _f32(t, "grad") for t in list(g_rgb) + list(g_acc) + list(g_depth)]
     k = num_levels
-    scratch = train_scratch(dev, n, False, num_levels)
+    st = None if geometry is None else geometry[0]
+    scratch = train_scratch(dev, n, False, num_levels, st)
     with torch.cuda.device(dev):
-        check(lib.aon_render_bwd(_ptr(pb[0]), _ptr(pf[0]), _ptr(pb[1]), _ptr(pf[1]), _ptr(d), n, int(bool(white_bkgd)), num_levels,
-                                 _ptr_array(keep[:k]), _ptr_array(keep[k:2 * k]), _ptr_array(keep[2 * k:3 * k]), garr[0], garr[1], _ptr(ws), ws.numel(),
-                                 _ptr(scratch), scratch.numel(), _stream()), "aon_render_bwd")
+        check(lib.aon_render_bwd_ex(_ptr(pb[0]), _ptr(pf[0]), _ptr(pb[1]), _ptr(pf[1]), _ptr(d), n, int(bool(white_bkgd)), num_levels,
+                                    _ptr_array(keep[:k]), _ptr_array(keep[k:2 * k]), _ptr_array(keep[2 * k:3 * k]), garr[0], garr[1], _ptr(ws), ws.numel(),
+                                    _ptr(scratch), scratch.numel(), _stream(), None if st is None else C.byref(st)), "aon_render_bwd")
     return grads
 
 
-def art_render_bwd(ws, packs_bwd, smalls, rays_d, white_bkgd, num_levels, g_rgb, g_acc, g_depth, params_per_level, latents: dict):
+def art_render_bwd(ws, packs_bwd, smalls, rays_d, white_bkgd, num_levels, g_rgb, g_acc, g_depth, params_per_level, latents: dict, geometry=None):
     """Articulated twin -> (per-level dicts of the 40 parameter gradients, dict of latent gradients summed over the levels)."""
     d = _f32(rays_d, "rays_d")
     n, dev = d.shape[0], d.device
@@ -676,12 +804,14 @@ def art_render_bwd(ws, packs_bwd, smalls, rays_d, white_bkgd, num_levels, g_rgb,
     g_lat = {"density": torch.empty(128, device=dev), "color": torch.empty(128, device=dev), "articulation": torch.empty(32, device=dev)}
     keep = [None if t is None else _f32(t, "grad") for t in list(g_rgb) + list(g_acc) + list(g_depth)]
     k = num_levels
-    scratch = train_scratch(dev, n, True, num_levels)
+    st = None if geometry is None else geometry[0]
+    scratch = train_scratch(dev, n, True, num_levels, st)
     with torch.cuda.device(dev):
-        check(lib.aon_art_render_bwd(_ptr(pb[0]), _ptr(sm[0]), _ptr(pb[1]), _ptr(sm[1]), _ptr(d), n, int(bool(white_bkgd)), num_levels,
-                                     _ptr_array(keep[:k]), _ptr_array(keep[k:2 * k]), _ptr_array(keep[2 * k:3 * k]), parr[0], parr[1],
-                                     _ptr(shape), _ptr(app), _ptr(art), garr[0], garr[1], _ptr(g_lat["density"]), _ptr(g_lat["color"]),
-                                     _ptr(g_lat["articulation"]), _ptr(ws), ws.numel(), _ptr(scratch), scratch.numel(), _stream()), "aon_art_render_bwd")
+        check(lib.aon_art_render_bwd_ex(_ptr(pb[0]), _ptr(sm[0]), _ptr(pb[1]), _ptr(sm[1]), _ptr(d), n, int(bool(white_bkgd)), num_levels,
+                                        _ptr_array(keep[:k]), _ptr_array(keep[k:2 * k]), _ptr_array(keep[2 * k:3 * k]), parr[0], parr[1],
+                                        _ptr(shape), _ptr(app), _ptr(art), garr[0], garr[1], _ptr(g_lat["density"]), _ptr(g_lat["color"]),
+                                        _ptr(g_lat["articulation"]), _ptr(ws), ws.numel(), _ptr(scratch), scratch.numel(), _stream(),
+                                        None if st is None else C.byref(st)), "aon_art_render_bwd")
     return grads, g_lat
 
 

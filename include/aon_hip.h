@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define AON_ABI_VERSION 1
+#define AON_ABI_VERSION 2
 
 #define AON_OK 0
 #define AON_E_INVALID (-1)    /* null pointer, negative size, unsupported geometry */
@@ -260,6 +260,92 @@ int aon_art_render_bwd(const void* packed_bwd_coarse, const void* small_coarse, 
                        const float* appearance, const float* articulation, float* const* grads_coarse_host,
                        float* const* grads_fine_host, float* g_shape, float* g_appearance, float* g_articulation,
                        void* workspace, int64_t workspace_bytes, void* scratch, int64_t scratch_bytes, void* stream);
+
+/* ---- Constructor arguments of NeRF / NeRF_AE_Art beyond their defaults (round 3) ----
+ * NeRF.__init__(num_coarse_samples, num_fine_samples, noise_std, lindisp)          models/vanilla_nerf/model.py:124-135
+ * NeRF_AE_Art.__init__(..., rgb_padding, density_bias)                             models/vanilla_nerf/model_autodecoder.py:241-257
+ * The entry points above are these with the reference's defaults; the *_ex forms take the struct (NULL = defaults).  Scalars are
+ * passed as the reference's fp32 tensor arithmetic sees its Python numbers (the host side computes them in double precision and
+ * rounds once, as torch does when a Python scalar meets an fp32 tensor):
+ *   num_coarse_samples  level 0 evaluates num_coarse_samples + 1 t values (helper.py:115); >= 2, <= 1023
+ *   num_fine_samples    draws of the inverse CDF (helper.py:224-230); level 1 evaluates num_coarse_samples + 1 + num_fine_samples
+ *                       (<= 1024 in the training entry points)
+ *   lindisp             helper.py:116-117: t = 1 / (inv_near (1 - s) + inv_far s) with inv_near = fp32(1.0 / near), inv_far =
+ *                       fp32(1.0 / far) -- the reference evaluates 1.0 / near in Python double precision
+ *   noise_c, noise_f    model.py:183-184 (`noise_std > 0 and randomized`): the caller's torch.rand_like(raw_sigma) draws of level
+ *                       0 (n, num_coarse_samples + 1) and level 1 (n, num_coarse_samples + 1 + num_fine_samples); raw_sigma +=
+ *                       noise * noise_std before the activation.  NULL = no noise at that level.
+ *   rgb_scale, rgb_shift, sigma_bias   articulated activations (model_autodecoder.py:321-323): rgb = sigmoid(raw) * rgb_scale -
+ *                       rgb_shift, sigma = softplus(raw_sigma + sigma_bias); fp32(1 + 2 rgb_padding), fp32(rgb_padding),
+ *                       fp32(density_bias).  Ignored by the vanilla entry points.
+ * Geometries other than 64 / 128 run the coarse level as two kernels (compositing, then aon_sample_pdf_n). */
+typedef struct aon_render_opts {
+  int32_t num_coarse_samples;   /* 64 */
+  int32_t num_fine_samples;     /* 128 */
+  int32_t lindisp;              /* 0 */
+  float inv_near, inv_far;      /* read when lindisp != 0 */
+  float noise_std;              /* 0 */
+  const float* noise_c;         /* NULL */
+  const float* noise_f;         /* NULL */
+  float rgb_scale, rgb_shift, sigma_bias;   /* 1.002f, 0.001f, -1.0f */
+} aon_render_opts;
+void aon_render_opts_init(aon_render_opts* opts);   /* the reference's defaults */
+
+/* helper.sample_along_rays with lindisp (helper.py:116-117); as aon_sample_along_rays otherwise */
+int aon_sample_along_rays_ex(const float* rays_o, const float* rays_d, int64_t n_rays, int S, float near_, float far_, int lindisp,
+                             float inv_near, float inv_far, const float* t_rand, float* t_vals, float* coords, void* stream);
+/* aon_composite with the activation scalars and the density noise of `opts` (noise_c is the (n,S) noise of THIS call; the sample
+ * counts and lindisp fields are ignored) */
+int aon_composite_ex(const float* rgb, int rgb_stride, const float* sigma, int sigma_stride, const float* t_vals, const float* dirs,
+                     int64_t n_rays, int S, int white_bkgd, int act, const aon_render_opts* opts, float* comp_rgb, float* acc,
+                     float* depth, float* weights, void* stream);
+/* helper.sorted_piecewise_constant_pdf / helper.sample_pdf (helper.py:203-252) for ANY sizes: num_bins bins (n,num_bins) -- or
+ * NULL = mid-points of t_coarse, then num_t == num_bins + 1 -- num_bins - 1 weights per ray (w_stride floats apart), num_samples
+ * draws u ((num_samples,) shared when u_stride == 0, else (n, >= num_samples)), num_t coarse t's; outputs samples (n,num_samples)
+ * and / or t_fine (n, num_t + num_samples).  Bit-exact against torch's CPU kernels like aon_sample_pdf (ATen's summation order
+ * for any length, double running sum).  2 <= num_bins, 3 * num_bins + pow2ceil(num_t + num_samples) <= 16384. */
+int aon_sample_pdf_n(const float* bins, const float* weights, int64_t w_stride, const float* t_coarse, const float* u,
+                     int64_t u_stride, int64_t n_rays, int num_bins, int num_samples, int num_t, float* samples, float* t_fine,
+                     void* stream);
+int64_t aon_render_workspace_bytes_ex(int64_t n_rays, const aon_render_opts* opts);
+int aon_render_fwd_ex(const void* packed_coarse, const void* packed_fine, const float* rays_o, const float* rays_d,
+                      const float* viewdirs, int64_t n_rays, float near_, float far_, int white_bkgd, int num_levels,
+                      const float* t_rand, const float* u, int64_t u_stride, float* rgb_c, float* acc_c, float* depth_c,
+                      float* rgb_f, float* acc_f, float* depth_f, void* workspace, int64_t workspace_bytes, void* stream,
+                      const aon_render_opts* opts);
+int aon_art_render_fwd_ex(const void* packed_coarse, const void* small_coarse, const void* packed_fine, const void* small_fine,
+                          const float* rays_o, const float* rays_d, const float* viewdirs, int64_t n_rays, float near_, float far_,
+                          int white_bkgd, int num_levels, const float* t_rand, const float* u, int64_t u_stride, float* rgb_c,
+                          float* acc_c, float* depth_c, float* rgb_f, float* acc_f, float* depth_f, void* workspace,
+                          int64_t workspace_bytes, void* stream, const aon_render_opts* opts);
+/* training twins: the SAME opts (sizes, noise pointers, activation scalars) must be handed to the forward, the backward and the
+ * two size queries of one step */
+int64_t aon_train_workspace_bytes_ex(int64_t n_rays, int articulated, int num_levels, const aon_render_opts* opts);
+int64_t aon_train_scratch_bytes_ex(int64_t n_rays, int articulated, int num_levels, const aon_render_opts* opts);
+int aon_render_fwd_train_ex(const void* packed_coarse, const void* packed_fine, const float* rays_o, const float* rays_d,
+                            const float* viewdirs, int64_t n_rays, float near_, float far_, int white_bkgd, int num_levels,
+                            const float* t_rand, const float* u, int64_t u_stride, float* rgb_c, float* acc_c, float* depth_c,
+                            float* rgb_f, float* acc_f, float* depth_f, void* workspace, int64_t workspace_bytes, void* stream,
+                            const aon_render_opts* opts);
+int aon_render_bwd_ex(const void* packed_bwd_coarse, const void* packed_fwd_coarse, const void* packed_bwd_fine,
+                      const void* packed_fwd_fine, const float* rays_d, int64_t n_rays, int white_bkgd, int num_levels,
+                      const float* const* g_rgb_host, const float* const* g_acc_host, const float* const* g_depth_host,
+                      float* const* grads_coarse_host, float* const* grads_fine_host, void* workspace,
+                      int64_t workspace_bytes, void* scratch, int64_t scratch_bytes, void* stream, const aon_render_opts* opts);
+int aon_art_render_fwd_train_ex(const void* packed_coarse, const void* small_coarse, const void* packed_fine,
+                                const void* small_fine, const float* rays_o, const float* rays_d, const float* viewdirs,
+                                int64_t n_rays, float near_, float far_, int white_bkgd, int num_levels, const float* t_rand,
+                                const float* u, int64_t u_stride, float* rgb_c, float* acc_c, float* depth_c, float* rgb_f,
+                                float* acc_f, float* depth_f, void* workspace, int64_t workspace_bytes, void* stream,
+                                const aon_render_opts* opts);
+int aon_art_render_bwd_ex(const void* packed_bwd_coarse, const void* small_coarse, const void* packed_bwd_fine,
+                          const void* small_fine, const float* rays_d, int64_t n_rays, int white_bkgd, int num_levels,
+                          const float* const* g_rgb_host, const float* const* g_acc_host, const float* const* g_depth_host,
+                          const float* const* params_coarse_host, const float* const* params_fine_host, const float* shape,
+                          const float* appearance, const float* articulation, float* const* grads_coarse_host,
+                          float* const* grads_fine_host, float* g_shape, float* g_appearance, float* g_articulation,
+                          void* workspace, int64_t workspace_bytes, void* scratch, int64_t scratch_bytes, void* stream,
+                          const aon_render_opts* opts);
 
 /* ---- measurement aid (no reference counterpart) ----
  * Between aon_profile_begin() and aon_profile_end() every launch of the path's kernels made through this library is

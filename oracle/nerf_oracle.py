@@ -67,12 +67,16 @@ def cast_rays(t_vals, origins, directions):
     return origins[..., None, :] + t_vals[..., None] * directions[..., None, :]
 
 
-def sample_along_rays(rays_o, rays_d, num_samples, near, far, randomized, t_rand=None):
-    """helper.py:106-133 (lindisp=False branch).  ``t_rand`` (N, num_samples+1) replaces the
-    reference's ``torch.rand`` draw (:126) so randomized runs are reproducible."""
+def sample_along_rays(rays_o, rays_d, num_samples, near, far, randomized, t_rand=None, lindisp=False):
+    """helper.py:106-133.  ``t_rand`` (N, num_samples+1) replaces the reference's ``torch.rand`` draw (:126) so
+    randomized runs are reproducible.  lindisp (:116-117): ``1.0 / near`` is a Python (double) division before it meets
+    the fp32 tensor."""
     n = rays_o.shape[0]
     s = torch.linspace(0.0, 1.0, num_samples + 1)
-    t_vals = near * (1.0 - s) + far * s
+    if lindisp:
+        t_vals = 1.0 / (1.0 / near * (1.0 - s) + 1.0 / far * s)
+    else:
+        t_vals = near * (1.0 - s) + far * s
     if randomized:
         mids = 0.5 * (t_vals[1:] + t_vals[:-1])
         upper = torch.cat([mids, t_vals[-1:]])
@@ -96,9 +100,14 @@ def pos_enc(x, min_deg, max_deg):
 # --------------------------------------------------------------------------------------------------
 # R5  vanilla NeRFMLP                                       models/vanilla_nerf/model.py:95-120
 # --------------------------------------------------------------------------------------------------
-def nerf_mlp(sd: dict, prefix: str, x_enc, view_enc, netdepth: int = 8, skip_layer: int = 4):
+def nerf_mlp(sd: dict, prefix: str, x_enc, view_enc, netdepth: int | None = None, skip_layer: int = 4, netdepth_condition: int | None = None):
     """model.py:95-120.  ``sd`` maps '<prefix>pts_linears.0.weight' ... to tensors in nn.Linear (out,in)
-    layout.  x_enc (N,S,63), view_enc (N,27) -> raw_rgb (N,S,3), raw_density (N,S,1)."""
+    layout.  x_enc (N,S,pos_size), view_enc (N,view_pos_size) -> raw_rgb (N,S,C_rgb), raw_density (N,S,C_density).  Depths
+    default to the number of layers the state dict holds; widths and encoding sizes are the tensors' shapes."""
+    if netdepth is None:
+        netdepth = sum(1 for k in sd if k.startswith(f"{prefix}pts_linears.") and k.endswith(".weight"))
+    if netdepth_condition is None:
+        netdepth_condition = sum(1 for k in sd if k.startswith(f"{prefix}views_linear.") and k.endswith(".weight"))
     n, s, feat = x_enc.shape
     x = x_enc.reshape(-1, feat)
     inputs = x
@@ -106,12 +115,13 @@ def nerf_mlp(sd: dict, prefix: str, x_enc, view_enc, netdepth: int = 8, skip_lay
         x = F.relu(F.linear(x, sd[f"{prefix}pts_linears.{idx}.weight"], sd[f"{prefix}pts_linears.{idx}.bias"]))
         if idx % skip_layer == 0 and idx > 0:
             x = torch.cat([x, inputs], dim=-1)
-    raw_density = F.linear(x, sd[f"{prefix}density_layer.weight"], sd[f"{prefix}density_layer.bias"]).reshape(n, s, 1)
+    raw_density = F.linear(x, sd[f"{prefix}density_layer.weight"], sd[f"{prefix}density_layer.bias"]).reshape(n, s, -1)
     bott = F.linear(x, sd[f"{prefix}bottleneck_layer.weight"], sd[f"{prefix}bottleneck_layer.bias"])
     cond = view_enc[:, None, :].expand(n, s, view_enc.shape[-1]).reshape(-1, view_enc.shape[-1])
     x = torch.cat([bott, cond], dim=-1)
-    x = F.relu(F.linear(x, sd[f"{prefix}views_linear.0.weight"], sd[f"{prefix}views_linear.0.bias"]))
-    raw_rgb = F.linear(x, sd[f"{prefix}rgb_layer.weight"], sd[f"{prefix}rgb_layer.bias"]).reshape(n, s, 3)
+    for idx in range(netdepth_condition):   # model.py:112-114
+        x = F.relu(F.linear(x, sd[f"{prefix}views_linear.{idx}.weight"], sd[f"{prefix}views_linear.{idx}.bias"]))
+    raw_rgb = F.linear(x, sd[f"{prefix}rgb_layer.weight"], sd[f"{prefix}rgb_layer.bias"]).reshape(n, s, -1)
     return raw_rgb, raw_density
 
 
@@ -178,21 +188,85 @@ def sample_pdf(bins, weights, origins, directions, t_vals, num_samples, randomiz
     return t_vals, cast_rays(t_vals, origins, directions)
 
 
+def aten_sum_model(x) -> "np.float32":
+    """What ``torch.sum`` over a contiguous fp32 row of K elements computes on the CPU (helper.py:205 ``weights.sum(dim=-1)``;
+    ATen cpu/SumKernel.cpp, AVX2 build: 8-float vectors, ILP factor 4, four-level cascade of ``multi_row_sum``) restated in
+    numpy, element by element.  The general-size inverse-CDF kernel (csrc/aon_render.hip ``aten_row_sum``) follows the same
+    steps; tests/test_oracle_golden.py holds this model to torch.sum for K = 1 .. 1000."""
+    import numpy as np
+
+    f32 = np.float32
+    x = np.asarray(x, f32)
+    K = x.shape[0]
+
+    def multi_row_sum(load, size, width):
+        cl = 0
+        while (1 << cl) < size:
+            cl += 1
+        level_power = max(4, cl // 4)
+        level_step = 1 << level_power
+        level_mask = level_step - 1
+        acc = [[np.zeros(width, f32) for _ in range(4)] for _ in range(4)]
+        i = 0
+        while i + level_step <= size:
+            for _ in range(level_step):
+                for k in range(4):
+                    acc[0][k] = acc[0][k] + load(i, k)
+                i += 1
+            for j in range(1, 4):
+                for k in range(4):
+                    acc[j][k] = acc[j][k] + acc[j - 1][k]
+                    acc[j - 1][k] = np.zeros(width, f32)
+                if (i & (level_mask << (j * level_power))) != 0:
+                    break
+        while i < size:
+            for k in range(4):
+                acc[0][k] = acc[0][k] + load(i, k)
+            i += 1
+        for j in range(1, 4):
+            for k in range(4):
+                acc[0][k] = acc[0][k] + acc[j][k]
+        return acc[0]
+
+    if K < 8:   # scalar_inner_sum -> row_sum on scalars
+        size_ilp = K // 4
+        part = multi_row_sum(lambda i, k: x[4 * i + k: 4 * i + k + 1], size_ilp, 1)
+        for i in range(size_ilp * 4, K):
+            part[0] = part[0] + x[i: i + 1]
+        for k in range(1, 4):
+            part[0] = part[0] + part[k]
+        return part[0][0]
+    vec = K // 8
+    size_ilp = vec // 4
+    part = multi_row_sum(lambda i, k: x[(4 * i + k) * 8: (4 * i + k) * 8 + 8], size_ilp, 8)
+    for i in range(size_ilp * 4, vec):
+        part[0] = part[0] + x[i * 8: i * 8 + 8]
+    for k in range(1, 4):
+        part[0] = part[0] + part[k]
+    fin = f32(0)
+    for k in range(vec * 8, K):
+        fin = f32(fin + x[k])
+    for k in range(8):
+        fin = f32(fin + part[0][k])
+    return fin
+
+
 # --------------------------------------------------------------------------------------------------
 # R9  NeRF.forward                                          models/vanilla_nerf/model.py:147-199
 # --------------------------------------------------------------------------------------------------
 def nerf_forward(sd, rays, randomized, white_bkgd, near, far, num_levels=2, min_deg_point=0,
                  max_deg_point=10, deg_view=4, num_coarse_samples=64, num_fine_samples=128,
-                 t_rand=None, u=None, return_aux=False):
+                 t_rand=None, u=None, return_aux=False, lindisp=False, noise_std=0.0, noise=None, skip_layer=4):
     """model.py:147-199.  ``sd`` uses the reference's key names ('coarse_mlp.pts_linears.0.weight', ...).
     Returns [(comp_rgb, acc, depth)_coarse, (comp_rgb, acc, depth)_fine]; with ``return_aux`` also a
-    dict of intermediates per level (t_vals, raw_rgb, raw_sigma, weights)."""
+    dict of intermediates per level (t_vals, raw_rgb, raw_sigma, weights).  ``noise``: per-level (N,S,1) tensors replacing
+    ``torch.rand_like(raw_sigma)`` (:184)."""
     ret, aux = [], []
     t_vals = weights = None
     for i_level in range(num_levels):
         if i_level == 0:
             t_vals, samples = sample_along_rays(rays["rays_o"], rays["rays_d"], num_coarse_samples, near, far,
-                                                randomized, t_rand)
+                                                randomized, t_rand, lindisp)
             prefix = "coarse_mlp."
         else:
             t_mids = 0.5 * (t_vals[..., 1:] + t_vals[..., :-1])
@@ -201,7 +275,9 @@ def nerf_forward(sd, rays, randomized, white_bkgd, near, far, num_levels=2, min_
             prefix = "fine_mlp."
         samples_enc = pos_enc(samples, min_deg_point, max_deg_point)
         viewdirs_enc = pos_enc(rays["viewdirs"], 0, deg_view)
-        raw_rgb, raw_sigma = nerf_mlp(sd, prefix, samples_enc, viewdirs_enc)
+        raw_rgb, raw_sigma = nerf_mlp(sd, prefix, samples_enc, viewdirs_enc, skip_layer=skip_layer)
+        if noise_std > 0 and randomized:                                           # model.py:183-184
+            raw_sigma = raw_sigma + noise[i_level].reshape(raw_sigma.shape) * noise_std
         rgb = torch.sigmoid(raw_rgb)
         sigma = F.relu(raw_sigma)
         comp_rgb, acc, weights, depth = volumetric_rendering(rgb, sigma, t_vals, rays["rays_d"], white_bkgd)
@@ -249,21 +325,24 @@ def art_mlp(sd: dict, prefix: str, pos, view_enc, latents: dict):
 # R11  NeRF_AE_Art.forward              models/vanilla_nerf/model_autodecoder.py:278-337
 # --------------------------------------------------------------------------------------------------
 def nerf_ae_art_forward(sd, rays, randomized, white_bkgd, near, far, latents, num_levels=2, t_rand=None, u=None,
-                        return_aux=False):
+                        return_aux=False, num_coarse_samples=64, num_fine_samples=128, lindisp=False, noise_std=0.0, noise=None,
+                        rgb_padding=0.001, density_bias=-1.0):
     ret, aux = [], []
     t_vals = weights = None
     for i_level in range(num_levels):
         if i_level == 0:
-            t_vals, samples = sample_along_rays(rays["rays_o"], rays["rays_d"], 64, near, far, randomized, t_rand)
+            t_vals, samples = sample_along_rays(rays["rays_o"], rays["rays_d"], num_coarse_samples, near, far, randomized, t_rand, lindisp)
             prefix = "coarse_mlp."
         else:
             t_mids = 0.5 * (t_vals[..., 1:] + t_vals[..., :-1])
-            t_vals, samples = sample_pdf(t_mids, weights[..., 1:-1], rays["rays_o"], rays["rays_d"], t_vals, 128, randomized, u)
+            t_vals, samples = sample_pdf(t_mids, weights[..., 1:-1], rays["rays_o"], rays["rays_d"], t_vals, num_fine_samples, randomized, u)
             prefix = "fine_mlp."
         viewdirs_enc = pos_enc(rays["viewdirs"], 0, 4)
         raw_rgb, raw_sigma = art_mlp(sd, prefix, samples, viewdirs_enc, latents)  # samples un-encoded (:306-307)
-        rgb = torch.sigmoid(raw_rgb) * (1 + 2 * 0.001) - 0.001                    # :321-322
-        sigma = F.softplus(raw_sigma + (-1.0))                                     # :323 (density_bias = -1)
+        if noise_std > 0 and randomized:                                           # :318-319
+            raw_sigma = raw_sigma + noise[i_level].reshape(raw_sigma.shape) * noise_std
+        rgb = torch.sigmoid(raw_rgb) * (1 + 2 * rgb_padding) - rgb_padding        # :321-322
+        sigma = F.softplus(raw_sigma + density_bias)                               # :323
         comp_rgb, acc, weights, depth = volumetric_rendering(rgb, sigma, t_vals, rays["rays_d"], white_bkgd)
         ret.append((comp_rgb, acc, depth))
         aux.append({"t_vals": t_vals, "raw_rgb": raw_rgb, "raw_sigma": raw_sigma, "weights": weights})

@@ -126,6 +126,25 @@ def patched_rand(values):
         torch.rand = orig
 
 
+@contextlib.contextmanager
+def patched_rand_like(values):
+    """Make ``torch.rand_like`` return the supplied tensors in order (the density noise of model.py:184 /
+    model_autodecoder.py:319)."""
+    queue = list(values)
+    orig = torch.rand_like
+
+    def fake(t, **kw):
+        v = queue.pop(0)
+        assert v.numel() == t.numel(), (v.shape, t.shape)
+        return v.reshape(t.shape).clone()
+
+    torch.rand_like = fake
+    try:
+        yield
+    finally:
+        torch.rand_like = orig
+
+
 ONLY = set()   # --only g9_backward,g14_sapien_multi : write just these files (the others keep their committed bytes)
 
 
@@ -437,6 +456,85 @@ def main():
         for lvl, name in ((0, "coarse"), (1, "fine")):
             arrs[f"{tag}_{name}_rgb"], arrs[f"{tag}_{name}_acc"], arrs[f"{tag}_{name}_depth"] = out[lvl]
     save("g15_smooth", **arrs)
+
+    # ---------------- G16 constructor arguments beyond the defaults (round 3) ----------------
+    # helper.sample_along_rays(lindisp=True), the inverse CDF / merge at other sizes, and both networks built with other sample
+    # counts, lindisp, noise_std (> 0, randomized) and -- articulated -- rgb_padding / density_bias.  Random draws by seed.
+    arrs = {}
+    rays16 = syn.random_rays(48, seed=16)
+    for tag, (ns, near16, far16) in {"a": (32, 0.2, 6.0), "b": (7, 2.0, 6.0), "c": (200, 0.3, 10.0)}.items():
+        t_d, c_d = helper.sample_along_rays(rays16["rays_o"], rays16["rays_d"], ns, near16, far16, False, True)
+        tr16 = syn.seeded_uniform(1600 + ns, 48, ns + 1)
+        with patched_rand([tr16]):
+            t_r, c_r = helper.sample_along_rays(rays16["rays_o"], rays16["rays_d"], ns, near16, far16, True, True)
+        arrs.update({f"lindisp_{tag}_ns": ns, f"lindisp_{tag}_near": near16, f"lindisp_{tag}_far": far16, f"lindisp_{tag}_t_det": t_d.contiguous(),
+                     f"lindisp_{tag}_t_rnd": t_r, f"lindisp_{tag}_coords_rnd_sum": c_r.double().sum((0, 1))})
+    arrs["lindisp_rays_o"], arrs["lindisp_rays_d"] = rays16["rays_o"], rays16["rays_d"]
+    PDF_SIZES = [(6, 5), (9, 16), (24, 40), (33, 64), (64, 100), (100, 77), (129, 128), (200, 300), (600, 257)]   # (bins, draws)
+    arrs["pdf_sizes"] = np.asarray(PDF_SIZES)
+    g16 = torch.Generator().manual_seed(1616)
+    n16 = 24
+    for nb, nf in PDF_SIZES:
+        t16 = torch.sort(torch.rand((n16, nb + 1), generator=g16) * 4.0 + 2.0, dim=-1).values
+        mids16 = 0.5 * (t16[..., 1:] + t16[..., :-1])
+        w16 = torch.rand((n16, nb - 1), generator=g16) ** 8
+        w16[0] = 0.0
+        w16[1] = 0.0; w16[1, (nb - 1) // 2] = 1.0
+        w16[2] = 1e-9
+        u16 = syn.seeded_uniform(1700 + nb, n16, nf)
+        s_det = helper.sorted_piecewise_constant_pdf(mids16, w16, nf, False)
+        tf_det, _ = helper.sample_pdf(mids16, w16, rays16["rays_o"][:n16], rays16["rays_d"][:n16], t16, nf, False)
+        with patched_rand([u16]):
+            s_rnd = helper.sorted_piecewise_constant_pdf(mids16, w16, nf, True)
+        with patched_rand([u16]):
+            tf_rnd, _ = helper.sample_pdf(mids16, w16, rays16["rays_o"][:n16], rays16["rays_d"][:n16], t16, nf, True)
+        k = f"pdf_{nb}_{nf}"
+        arrs.update({f"{k}_t": t16, f"{k}_w": w16, f"{k}_samples_det": s_det, f"{k}_samples_rnd": s_rnd, f"{k}_t_fine_det": tf_det,
+                     f"{k}_t_fine_rnd": tf_rnd})
+    # whole path, smooth fields (every ray must hold), 256 rays
+    N16 = 256
+    rays_v = {k: v[keep][:N16].contiguous() for k, v in frame_s.items()}
+    CFG_V = dict(num_coarse_samples=32, num_fine_samples=48, lindisp=True, noise_std=1.0)
+    model_o = NeRF(**CFG_V)
+    model_o.load_state_dict(sd_s, strict=True)
+    model_o.eval()
+    Sc, Sf = 33, 33 + 48
+    tr_v, u_v = syn.seeded_uniform(1801, N16, Sc), syn.seeded_uniform(1802, N16, 48)
+    nz_v = [syn.seeded_uniform(1803, N16, Sc), syn.seeded_uniform(1804, N16, Sf)]
+    with torch.no_grad():
+        out_d = model_o(rays_v, False, True, 2.0, 6.0)
+        with patched_rand([tr_v, u_v]), patched_rand_like(nz_v):
+            out_r = model_o(rays_v, True, False, 2.0, 6.0)
+    arrs.update({"van_" + k: v for k, v in rays_v.items()})
+    arrs.update(van_cfg=np.asarray([32, 48, 1]), van_noise_std=1.0, van_seeds=np.asarray([1801, 1802, 1803, 1804]))
+    for tag, out in (("van_det", out_d), ("van_rnd", out_r)):
+        for lvl, name in ((0, "coarse"), (1, "fine")):
+            arrs[f"{tag}_{name}_rgb"], arrs[f"{tag}_{name}_acc"], arrs[f"{tag}_{name}_depth"] = out[lvl]
+    # the far-sample sign margin of these passes (vanilla relu, helper.py:163), by the oracle in the same modes
+    _, aux_d = orc.nerf_forward(sd_s, rays_v, False, True, 2.0, 6.0, return_aux=True, num_coarse_samples=32, num_fine_samples=48, lindisp=True)
+    _, aux_r = orc.nerf_forward(sd_s, rays_v, True, False, 2.0, 6.0, t_rand=tr_v, u=u_v, return_aux=True, num_coarse_samples=32,
+                                num_fine_samples=48, lindisp=True, noise_std=1.0, noise=nz_v)
+    arrs["van_margin_det"] = torch.stack([a["raw_sigma"][:, -1, 0].abs() for a in aux_d]).min(0).values
+    arrs["van_margin_rnd"] = torch.stack([(a["raw_sigma"][:, -1, 0] + 1.0 * nz_v[i][:, -1]).abs() for i, a in enumerate(aux_r)]).min(0).values
+    CFG_A = dict(num_coarse_samples=48, num_fine_samples=64, lindisp=False, noise_std=0.5, rgb_padding=0.01, density_bias=-0.5)
+    amodel_o = NeRF_AE_Art(**CFG_A)
+    amodel_o.load_state_dict(art_sd_s, strict=True)
+    amodel_o.eval()
+    rays_w = {k: v[:N16].contiguous() for k, v in rays_a.items()}
+    tr_a, u_a2 = syn.seeded_uniform(1811, N16, 49), syn.seeded_uniform(1812, N16, 64)
+    nz_a = [syn.seeded_uniform(1813, N16, 49), syn.seeded_uniform(1814, N16, 49 + 64)]
+    with torch.no_grad():
+        out_d = amodel_o(rays_w, False, True, 2.0, 6.0, lat_train)
+        with patched_rand([tr_a, u_a2]), patched_rand_like(nz_a):
+            out_r = amodel_o(rays_w, True, False, 2.0, 6.0, lat_train)
+    arrs.update({"art_" + k: v for k, v in rays_w.items()})
+    arrs.update({"art_lat_" + k: v for k, v in lat_train.items()})
+    arrs.update(art_cfg=np.asarray([48, 64, 0]), art_noise_std=0.5, art_rgb_padding=0.01, art_density_bias=-0.5,
+                art_seeds=np.asarray([1811, 1812, 1813, 1814]))
+    for tag, out in (("art_det", out_d), ("art_rnd", out_r)):
+        for lvl, name in ((0, "coarse"), (1, "fine")):
+            arrs[f"{tag}_{name}_rgb"], arrs[f"{tag}_{name}_acc"], arrs[f"{tag}_{name}_depth"] = out[lvl]
+    save("g16_ctor_options", **arrs)
 
     # ---------------- G13 metrics ----------------
     a = torch.rand((5, 16, 16, 3), generator=g) * 1.2 - 0.1

@@ -1,0 +1,214 @@
+"""GPU: constructor arguments beyond the reference's defaults (VERDICT r2 missing #3) against G16 -- outputs of the REAL reference
+built with other sample counts, ``lindisp=True``, ``noise_std > 0`` and (articulated) other ``rgb_padding`` / ``density_bias`` --
+and against the oracle.  Bars as for the default geometry: stratified t and the inverse CDF / merge bit-exact (``torch.equal``);
+the whole path on the smooth fields 2e-6 (rgb, acc) / 2e-5 (depth) on every ray; gradients against the oracle's autograd."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import nerf_oracle as orc  # noqa: E402  (checker only)
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return torch.device("cuda:0")
+
+
+def rel_l2(a, b):
+    return ((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30)).item()
+
+
+def test_lindisp_sampling_bit_exact(dev, golden):
+    import aon_amd.synthetic as syn
+    from aon_amd.models.vanilla_nerf import helper
+
+    g = golden("g16_ctor_options")
+    o, d = g["lindisp_rays_o"].to(dev), g["lindisp_rays_d"].to(dev)
+    for tag in "abc":
+        ns, near, far = g[f"lindisp_{tag}_ns"], g[f"lindisp_{tag}_near"], g[f"lindisp_{tag}_far"]
+        t, _ = helper.sample_along_rays(o, d, ns, near, far, False, True)
+        assert torch.equal(t.cpu(), g[f"lindisp_{tag}_t_det"])
+        tr = syn.seeded_uniform(1600 + ns, 48, ns + 1).to(dev)
+        t, c = helper.sample_along_rays(o, d, ns, near, far, True, True, t_rand=tr)
+        assert torch.equal(t.cpu(), g[f"lindisp_{tag}_t_rnd"])
+        torch.testing.assert_close(c.double().sum((0, 1)).cpu(), g[f"lindisp_{tag}_coords_rnd_sum"], rtol=1e-6, atol=0)
+        # the t-only kernel of the whole-path calls (four values per thread) gives the same bits
+        from aon_amd import ops
+        t4, _ = ops.sample_along_rays(o, d, ns, near, far, tr, want_coords=False, lindisp=True)
+        assert torch.equal(t4.cpu(), g[f"lindisp_{tag}_t_rnd"])
+
+
+def test_inverse_cdf_any_size_bit_exact(dev, golden):
+    """aon_sample_pdf_n against the reference's draws and sorted unions at nine (bins, draws) geometries: scalar and vector
+    paths of ATen's sum, the cascade (K = 599), non-power-of-two unions."""
+    import aon_amd.synthetic as syn
+    from aon_amd.models.vanilla_nerf import helper
+
+    g = golden("g16_ctor_options")
+    for nb, nf in g["pdf_sizes"].tolist():
+        k = f"pdf_{nb}_{nf}"
+        t, w = g[f"{k}_t"].to(dev), g[f"{k}_w"].to(dev)
+        n = t.shape[0]
+        mids = 0.5 * (t[..., 1:] + t[..., :-1])
+        u = syn.seeded_uniform(1700 + nb, n, nf).to(dev)
+        z = torch.zeros(n, 3, device=dev)
+        assert torch.equal(helper.sorted_piecewise_constant_pdf(mids, w, nf, False).cpu(), g[f"{k}_samples_det"]), k
+        assert torch.equal(helper.sorted_piecewise_constant_pdf(mids, w, nf, True, u=u).cpu(), g[f"{k}_samples_rnd"]), k
+        assert torch.equal(helper.sample_pdf(mids, w, z, z, t, nf, False)[0].cpu(), g[f"{k}_t_fine_det"]), k
+        assert torch.equal(helper.sample_pdf(mids, w, z, z, t, nf, True, u=u)[0].cpu(), g[f"{k}_t_fine_rnd"]), k
+
+
+def test_general_size_kernel_equals_the_specialised_one(dev, golden):
+    """At 64 bins / 128 draws both kernels exist: same bits (G6 / G7 inputs, deterministic and random u)."""
+    from aon_amd import ops
+
+    g6, g7 = golden("g6_pdf"), golden("g7_sample_pdf")
+    t, w, u = g7["t_vals"].to(dev), g7["weights"].to(dev), g7["u"].to(dev)
+    for uu in (None, u):
+        assert torch.equal(ops.sample_pdf_t_n(t, w, 128, uu), ops.sample_pdf_t(t, w, uu))
+    assert torch.equal(ops.sample_pdf_t_n(t, w, 128, None).cpu(), g7["t_fine_det"])
+    # adversarial rows: wide dynamic range, many zero weights
+    gen = torch.Generator().manual_seed(5)
+    n = 4000
+    tt = torch.sort(torch.rand((n, 65), generator=gen) * 4 + 2, dim=-1).values.to(dev)
+    ww = (torch.rand((n, 63), generator=gen) ** 12 * (torch.rand((n, 63), generator=gen) > 0.3)).to(dev)
+    uu = torch.rand((n, 128), generator=gen).to(dev)
+    assert torch.equal(ops.sample_pdf_t_n(tt, ww, 128, uu), ops.sample_pdf_t(tt, ww, uu))
+    assert torch.equal(ops.sample_pdf_t_n(tt, ww, 128, None), ops.sample_pdf_t(tt, ww, None))
+
+
+def _check(out, g, tag, drgb=2e-6, ddepth=2e-5):
+    for lvl, name in ((0, "coarse"), (1, "fine")):
+        rgb, acc, depth = (x.cpu() for x in out[lvl])
+        torch.testing.assert_close(rgb, g[f"{tag}_{name}_rgb"], rtol=0, atol=drgb)
+        torch.testing.assert_close(acc, g[f"{tag}_{name}_acc"], rtol=0, atol=drgb)
+        torch.testing.assert_close(depth, g[f"{tag}_{name}_depth"], rtol=0, atol=ddepth)
+
+
+def test_vanilla_with_options_end_to_end(dev, golden):
+    import aon_amd.synthetic as syn
+    from aon_amd.models.vanilla_nerf.model import NeRF
+
+    g = golden("g16_ctor_options")
+    assert g["van_margin_det"].min() > 0.05 and g["van_margin_rnd"].min() > 0.05   # nothing is masked
+    nc, nf, lind = g["van_cfg"].tolist()
+    model = NeRF(num_coarse_samples=nc, num_fine_samples=nf, lindisp=bool(lind), noise_std=g["van_noise_std"]).to(dev)
+    model.load_state_dict(syn.make_smooth_nerf_state_dict())
+    rays = {k: g["van_" + k].to(dev) for k in ("rays_o", "rays_d", "viewdirs")}
+    n = rays["rays_o"].shape[0]
+    s = g["van_seeds"].tolist()
+    tr, u = syn.seeded_uniform(s[0], n, nc + 1).to(dev), syn.seeded_uniform(s[1], n, nf).to(dev)
+    nz = [syn.seeded_uniform(s[2], n, nc + 1).to(dev), syn.seeded_uniform(s[3], n, nc + 1 + nf).to(dev)]
+    with torch.no_grad():
+        _check(model(rays, False, True, 2.0, 6.0), g, "van_det")
+        _check(model(rays, True, False, 2.0, 6.0, t_rand=tr, u=u, noise=nz), g, "van_rnd")
+        # chunk invariance at this geometry: a sub-range renders to the same bits alone
+        full = model(rays, True, False, 2.0, 6.0, t_rand=tr, u=u, noise=nz)
+        sub = {k: v[64:160].contiguous() for k, v in rays.items()}
+        part = model(sub, True, False, 2.0, 6.0, t_rand=tr[64:160].contiguous(), u=u[64:160].contiguous(), noise=[z[64:160].contiguous() for z in nz])
+        for lvl in (0, 1):
+            for a, b in zip(full[lvl], part[lvl]):
+                assert torch.equal(a[64:160], b)
+        # num_levels = 1 at this geometry against the oracle
+        m1 = NeRF(num_levels=1, num_coarse_samples=nc, lindisp=True).to(dev)
+        m1.load_state_dict(syn.make_smooth_nerf_state_dict())
+        o1 = m1(rays, False, True, 2.0, 6.0)
+        ref = orc.nerf_forward(syn.make_smooth_nerf_state_dict(), {k: v.cpu() for k, v in rays.items()}, False, True, 2.0, 6.0, num_levels=1,
+                               num_coarse_samples=nc, lindisp=True)
+        torch.testing.assert_close(o1[0][0].cpu(), ref[0][0], rtol=0, atol=2e-6)
+
+
+def test_articulated_with_options_end_to_end(dev, golden):
+    import aon_amd.synthetic as syn
+    from aon_amd.models.vanilla_nerf.model_autodecoder import NeRF_AE_Art
+
+    g = golden("g16_ctor_options")
+    nc, nf, lind = g["art_cfg"].tolist()
+    model = NeRF_AE_Art(num_coarse_samples=nc, num_fine_samples=nf, lindisp=bool(lind), noise_std=g["art_noise_std"],
+                        rgb_padding=g["art_rgb_padding"], density_bias=g["art_density_bias"]).to(dev)
+    model.load_state_dict(syn.make_art_state_dict(seed=5, density_scale=2.0))
+    rays = {k: g["art_" + k].to(dev) for k in ("rays_o", "rays_d", "viewdirs")}
+    lat = {k: g["art_lat_" + k].to(dev) for k in ("density", "color", "articulation")}
+    n = rays["rays_o"].shape[0]
+    s = g["art_seeds"].tolist()
+    tr, u = syn.seeded_uniform(s[0], n, nc + 1).to(dev), syn.seeded_uniform(s[1], n, nf).to(dev)
+    nz = [syn.seeded_uniform(s[2], n, nc + 1).to(dev), syn.seeded_uniform(s[3], n, nc + 1 + nf).to(dev)]
+    with torch.no_grad():
+        _check(model(rays, False, True, 2.0, 6.0, lat), g, "art_det")
+        _check(model(rays, True, False, 2.0, 6.0, lat, t_rand=tr, u=u, noise=nz), g, "art_rnd")
+
+
+@pytest.mark.parametrize("net", ["vanilla", "articulated"])
+def test_training_step_with_options(dev, net):
+    """loss.backward() through the drop-in modules at a non-default geometry (40 + 56 samples, lindisp, noise on the densities)
+    against the oracle's autograd on the smooth fields; tolerances of tests/test_hip_smooth.py."""
+    import aon_amd.synthetic as syn
+    from aon_amd.models.vanilla_nerf.model import NeRF
+    from aon_amd.models.vanilla_nerf.model_autodecoder import NeRF_AE_Art
+
+    n, nc, nf = 192, 40, 56
+    frame = syn.make_rays(24, 32, syn.look_at_pose(4.0, 60, 20), syn.focal_from_fovy(24))
+    rays_cpu = {k: v[::4][:n].contiguous() for k, v in frame.items()}
+    rays = {k: v.to(dev) for k, v in rays_cpu.items()}
+    target = syn.seeded_uniform(77, n, 3)
+    tr, u = syn.seeded_uniform(78, n, nc + 1), syn.seeded_uniform(79, n, nf)
+    nz = [syn.seeded_uniform(80, n, nc + 1), syn.seeded_uniform(81, n, nc + 1 + nf)]
+    if net == "vanilla":
+        sd = syn.make_smooth_nerf_state_dict()
+        model = NeRF(num_coarse_samples=nc, num_fine_samples=nf, lindisp=True, noise_std=0.3).to(dev)
+        model.load_state_dict(sd)
+        out = model(rays, True, True, 2.0, 6.0, t_rand=tr.to(dev), u=u.to(dev), noise=[z.to(dev) for z in nz])
+        sd_r = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        ref = orc.nerf_forward(sd_r, rays_cpu, True, True, 2.0, 6.0, t_rand=tr, u=u, num_coarse_samples=nc, num_fine_samples=nf, lindisp=True,
+                               noise_std=0.3, noise=nz)
+        lat_r = {}
+    else:
+        sd = syn.make_art_state_dict(seed=5, density_scale=2.0)
+        lib = syn.make_code_library_state(seed=0, n_max_objs=2)
+        lat_cpu = {"density": lib["embedding_instance_shape.weight"][1:2], "color": lib["embedding_instance_appearance.weight"][1:2],
+                   "articulation": lib["embedding_instance_articulation.weight"][3:4]}
+        model = NeRF_AE_Art(num_coarse_samples=nc, num_fine_samples=nf, lindisp=True, noise_std=0.3, rgb_padding=0.01, density_bias=-0.5).to(dev)
+        model.load_state_dict(sd)
+        lat = {k: v.to(dev).clone().requires_grad_(True) for k, v in lat_cpu.items()}
+        out = model(rays, True, True, 2.0, 6.0, lat, t_rand=tr.to(dev), u=u.to(dev), noise=[z.to(dev) for z in nz])
+        sd_r = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        lat_r = {k: v.clone().requires_grad_(True) for k, v in lat_cpu.items()}
+        ref = orc.nerf_ae_art_forward(sd_r, rays_cpu, True, True, 2.0, 6.0, lat_r, t_rand=tr, u=u, num_coarse_samples=nc, num_fine_samples=nf,
+                                      lindisp=True, noise_std=0.3, noise=nz, rgb_padding=0.01, density_bias=-0.5)
+    loss = ((out[0][0] - target.to(dev)) ** 2).mean() + ((out[1][0] - target.to(dev)) ** 2).mean()
+    loss.backward()
+    loss_r = ((ref[0][0] - target) ** 2).mean() + ((ref[1][0] - target) ** 2).mean()
+    loss_r.backward()
+    assert abs(loss.item() - loss_r.item()) < 2e-6
+    worst = {}
+    for name, p in model.named_parameters():
+        r = sd_r[name].grad
+        lvl = "coarse" if name.startswith("coarse") else "fine"
+        e = ((p.grad.cpu().double() - r.double()).norm() / r.double().norm().clamp_min(1e-12)).item()
+        worst[lvl] = max(worst.get(lvl, 0.0), e)
+    assert worst["coarse"] < 2e-4 and worst["fine"] < 5e-3, worst
+    if lat_r:
+        for k in lat_r:
+            assert rel_l2(lat[k].grad.cpu(), lat_r[k].grad) < 5e-3, k
+
+
+def test_bad_options_are_rejected(dev):
+    from aon_amd import ops
+    from aon_amd.models.vanilla_nerf.model import NeRF
+
+    with pytest.raises(ValueError):
+        NeRF(num_coarse_samples=1)
+    with pytest.raises(NotImplementedError):
+        NeRF(num_levels=3)
+    m = NeRF(num_coarse_samples=900, num_fine_samples=8000)      # exceeds the per-ray LDS image: the C call says so
+    import aon_amd.synthetic as syn
+    m = m.to(dev)
+    frame = syn.make_rays(4, 4, syn.look_at_pose(), syn.focal_from_fovy(4))
+    rays = {k: v.to(dev) for k, v in frame.items()}
+    with pytest.raises(Exception, match="too large"):
+        with torch.no_grad():
+            m(rays, False, True, 2.0, 6.0)
+    assert ops.RenderOpts().Sf == 193

@@ -200,3 +200,81 @@ def test_g15_smooth_fields(golden):
         for lvl, name in ((0, "coarse"), (1, "fine")):
             torch.testing.assert_close(out[lvl][0], g[f"{tag}_{name}_rgb"], rtol=0, atol=2e-6)
             torch.testing.assert_close(out[lvl][2], g[f"{tag}_{name}_depth"], rtol=0, atol=2e-5)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# G16: constructor arguments beyond the defaults (lindisp, other sample counts, noise_std, rgb_padding / density_bias)
+# ---------------------------------------------------------------------------------------------------------------------
+def test_aten_sum_model_is_torch_sum():
+    """The numpy restatement of ATen's CPU row sum (what the general-size inverse-CDF kernel follows) against torch.sum on
+    the non-contiguous `weights[..., 1:-1]` view the reference sums (helper.py:205), K = 1 .. 1000."""
+    import numpy as np
+
+    rng = np.random.default_rng(0)
+    for K in list(range(1, 70)) + [95, 127, 128, 129, 191, 199, 255, 256, 257, 511, 513, 599, 1000]:
+        for _ in range(20):
+            x = (rng.random(K) ** 8 * rng.choice([1.0, 1e-3, 1e3], K)).astype(np.float32)
+            big = np.zeros((3, K + 2), np.float32)
+            big[:, 1:-1] = x
+            want = torch.from_numpy(big)[..., 1:-1].sum(dim=-1, keepdim=True)[0, 0].item()
+            assert np.float32(want) == orc.aten_sum_model(x), K
+
+
+def test_g16_lindisp_and_pdf_sizes(golden):
+    g = golden("g16_ctor_options")
+    o, d = g["lindisp_rays_o"], g["lindisp_rays_d"]
+    import aon_amd.synthetic as syn
+    for tag in "abc":
+        ns, near, far = g[f"lindisp_{tag}_ns"], g[f"lindisp_{tag}_near"], g[f"lindisp_{tag}_far"]
+        t, _ = orc.sample_along_rays(o, d, ns, near, far, False, lindisp=True)
+        assert torch.equal(t, g[f"lindisp_{tag}_t_det"])
+        t, c = orc.sample_along_rays(o, d, ns, near, far, True, syn.seeded_uniform(1600 + ns, 48, ns + 1), lindisp=True)
+        assert torch.equal(t, g[f"lindisp_{tag}_t_rnd"])
+        torch.testing.assert_close(c.double().sum((0, 1)), g[f"lindisp_{tag}_coords_rnd_sum"], rtol=1e-12, atol=0)
+    for nb, nf in g["pdf_sizes"].tolist():
+        k = f"pdf_{nb}_{nf}"
+        t, w = g[f"{k}_t"], g[f"{k}_w"]
+        n = t.shape[0]
+        mids = 0.5 * (t[..., 1:] + t[..., :-1])
+        u = syn.seeded_uniform(1700 + nb, n, nf)
+        assert torch.equal(orc.sorted_piecewise_constant_pdf(mids, w, nf, False), g[f"{k}_samples_det"])
+        assert torch.equal(orc.sorted_piecewise_constant_pdf(mids, w, nf, True, u), g[f"{k}_samples_rnd"])
+        z = torch.zeros(n, 3)
+        assert torch.equal(orc.sample_pdf(mids, w, z, z, t, nf, False)[0], g[f"{k}_t_fine_det"])
+        assert torch.equal(orc.sample_pdf(mids, w, z, z, t, nf, True, u)[0], g[f"{k}_t_fine_rnd"])
+
+
+def test_g16_whole_path_with_options(golden):
+    import aon_amd.synthetic as syn
+
+    g = golden("g16_ctor_options")
+    nc, nf, lind = g["van_cfg"].tolist()
+    rays = {k: g["van_" + k] for k in ("rays_o", "rays_d", "viewdirs")}
+    n = rays["rays_o"].shape[0]
+    s = g["van_seeds"].tolist()
+    tr, u = syn.seeded_uniform(s[0], n, nc + 1), syn.seeded_uniform(s[1], n, nf)
+    nz = [syn.seeded_uniform(s[2], n, nc + 1), syn.seeded_uniform(s[3], n, nc + 1 + nf)]
+    sd = syn.make_smooth_nerf_state_dict()
+    kw = dict(num_coarse_samples=nc, num_fine_samples=nf, lindisp=bool(lind))
+    outs = {"van_det": orc.nerf_forward(sd, rays, False, True, 2.0, 6.0, **kw),
+            "van_rnd": orc.nerf_forward(sd, rays, True, False, 2.0, 6.0, t_rand=tr, u=u, noise_std=g["van_noise_std"], noise=nz, **kw)}
+    for tag, out in outs.items():
+        for lvl, name in ((0, "coarse"), (1, "fine")):
+            torch.testing.assert_close(out[lvl][0], g[f"{tag}_{name}_rgb"], rtol=0, atol=2e-6)
+            torch.testing.assert_close(out[lvl][1], g[f"{tag}_{name}_acc"], rtol=0, atol=2e-6)
+            torch.testing.assert_close(out[lvl][2], g[f"{tag}_{name}_depth"], rtol=0, atol=2e-5)
+    nc, nf, lind = g["art_cfg"].tolist()
+    rays = {k: g["art_" + k] for k in ("rays_o", "rays_d", "viewdirs")}
+    lat = {k: g["art_lat_" + k] for k in ("density", "color", "articulation")}
+    s = g["art_seeds"].tolist()
+    tr, u = syn.seeded_uniform(s[0], n, nc + 1), syn.seeded_uniform(s[1], n, nf)
+    nz = [syn.seeded_uniform(s[2], n, nc + 1), syn.seeded_uniform(s[3], n, nc + 1 + nf)]
+    sd = syn.make_art_state_dict(seed=5, density_scale=2.0)
+    kw = dict(num_coarse_samples=nc, num_fine_samples=nf, lindisp=bool(lind), rgb_padding=g["art_rgb_padding"], density_bias=g["art_density_bias"])
+    outs = {"art_det": orc.nerf_ae_art_forward(sd, rays, False, True, 2.0, 6.0, lat, **kw),
+            "art_rnd": orc.nerf_ae_art_forward(sd, rays, True, False, 2.0, 6.0, lat, t_rand=tr, u=u, noise_std=g["art_noise_std"], noise=nz, **kw)}
+    for tag, out in outs.items():
+        for lvl, name in ((0, "coarse"), (1, "fine")):
+            torch.testing.assert_close(out[lvl][0], g[f"{tag}_{name}_rgb"], rtol=0, atol=2e-6)
+            torch.testing.assert_close(out[lvl][1], g[f"{tag}_{name}_acc"], rtol=0, atol=2e-6)
+            torch.testing.assert_close(out[lvl][2], g[f"{tag}_{name}_depth"], rtol=0, atol=2e-5)
