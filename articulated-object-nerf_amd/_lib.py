@@ -96,7 +96,25 @@ _SIGS = {
     "aon_render_bwd_ex": (_i, [_p, _p, _p, _p, _p, _l, _i, _i, _p, _p, _p, _p, _p, _p, _l, _p, _l, _p, _p]),
     "aon_art_render_fwd_train_ex": (_i, [_p, _p, _p, _p, _p, _p, _p, _l, _f, _f, _i, _i, _p, _p, _l, _p, _p, _p, _p, _p, _p, _p, _l, _p, _p]),
     "aon_art_render_bwd_ex": (_i, [_p, _p, _p, _p, _p, _l, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _l, _p, _l, _p, _p]),
+    # NeRFMLP of any constructor geometry (aon_mlp_geometry first)
+    "aon_mlp_geometry_init": (None, [_p]),
+    "aon_gmlp_param_count": (_i, [_p]),
+    "aon_gmlp_workspace_bytes": (_l, [_p, _l]),
+    "aon_gmlp_fwd": (_i, [_p, _p, _p, _p, _l, _i, _p, _p, _p, _l, _p]),
+    "aon_grender_workspace_bytes": (_l, [_p, _l, _p]),
+    "aon_grender_fwd": (_i, [_p, _p, _p, _p, _p, _p, _l, _f, _f, _i, _i, _p, _p, _l, _p, _p, _p, _p, _p, _p, _p, _l, _p, _p]),
+    "aon_grender_train_workspace_bytes": (_l, [_p, _l, _i, _p]),
+    "aon_grender_train_scratch_bytes": (_l, [_p, _l, _i, _p]),
+    "aon_grender_fwd_train": (_i, [_p, _p, _p, _p, _p, _p, _l, _f, _f, _i, _i, _p, _p, _l, _p, _p, _p, _p, _p, _p, _p, _l, _p, _p]),
+    "aon_grender_bwd": (_i, [_p, _p, _p, _p, _l, _i, _i, _p, _p, _p, _p, _p, _p, _l, _p, _l, _p, _p]),
 }
+
+
+class MlpGeometryC(C.Structure):
+    """aon_mlp_geometry (include/aon_hip.h): the arguments of NeRFMLP.__init__ (model.py:40-54)."""
+    _fields_ = [(n, C.c_int32) for n in ("min_deg_point", "max_deg_point", "deg_view", "netdepth", "netwidth", "netdepth_condition",
+                                         "netwidth_condition", "skip_layer", "input_ch", "input_ch_view", "num_rgb_channels",
+                                         "num_density_channels")]
 
 
 class RenderOptsC(C.Structure):

@@ -46,6 +46,31 @@ class RenderVanilla(torch.autograd.Function):
         return (None,) * 12 + tuple(g[name] for g in per_level for name in ops.VANILLA_PARAM_ORDER)
 
 
+class RenderGeneral(torch.autograd.Function):
+    """NeRF.forward with a NeRFMLP of non-default geometry: layer-wise GEMM engine (aon_grender_fwd_train / aon_grender_bwd)."""
+
+    @staticmethod
+    def forward(ctx, rays_o, rays_d, viewdirs, near, far, white_bkgd, num_levels, t_rand, u, geom, opts, noise, *params):
+        n_per = len(geom.param_order)
+        ctx.geom, ctx.rays_d, ctx.white_bkgd, ctx.num_levels = geom, rays_d, white_bkgd, num_levels
+        ctx.params = [dict(zip(geom.param_order, [p.detach() for p in params[l * n_per: (l + 1) * n_per]])) for l in range(num_levels)]
+        levels, ctx.ws, ctx.geometry = ops.grender_fwd_train(geom, ctx.params[0], ctx.params[1] if num_levels == 2 else None, rays_o, rays_d,
+                                                             viewdirs, near, far, white_bkgd, num_levels, t_rand, u, opts=opts, noise=noise)
+        return tuple(x for lvl in levels for x in lvl)
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        _check_not_released(ctx)
+        n = ctx.rays_d.shape[0]
+        g_rgb = [gouts[3 * l] if gouts[3 * l] is not None else torch.zeros((n, 3), dtype=torch.float32, device=ctx.rays_d.device)
+                 for l in range(ctx.num_levels)]
+        per_level = ops.grender_bwd(ctx.geom, ctx.ws, ctx.params, ctx.rays_d, ctx.white_bkgd, ctx.num_levels, g_rgb,
+                                    [gouts[3 * l + 1] for l in range(ctx.num_levels)], [gouts[3 * l + 2] for l in range(ctx.num_levels)],
+                                    ctx.geometry)
+        ctx.ws, ctx.released, ctx.geometry = None, True, None
+        return (None,) * 12 + tuple(g[name] for g in per_level for name in ctx.geom.param_order)
+
+
 class RenderArticulated(torch.autograd.Function):
     """NeRF_AE_Art.forward with gradients to the 2 x 40 MLP parameters and the three latents."""
 

@@ -8,6 +8,8 @@
 #include <mutex>
 #include <vector>
 
+#include "aon_gmlp.h"
+
 namespace aon {
 hipError_t launch_pack_vanilla(const float* const* params, float* packed, hipStream_t stream);
 hipError_t launch_mlp_fwd(const char* packed, const float* rays_o, const float* rays_d, const float* viewdirs,
@@ -1120,6 +1122,476 @@ int aon_art_render_fwd(const void* packed_coarse, const void* small_coarse, cons
   return aon_art_render_fwd_ex(packed_coarse, small_coarse, packed_fine, small_fine, rays_o, rays_d, viewdirs, n_rays, near_, far_, white_bkgd,
                                num_levels, t_rand, u, u_stride, rgb_c, acc_c, depth_c, rgb_f, acc_f, depth_f, workspace, workspace_bytes, stream,
                                nullptr);
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// NeRFMLP of any constructor geometry: layer-wise GEMM engine (csrc/aon_gmlp.hip)
+// ---------------------------------------------------------------------------------------------------------------------
+}  // extern "C"
+
+namespace {
+
+struct GG {   // aon_mlp_geometry, validated
+  int P, V, D, W, Dc, Wc, skip, Crgb, Cd, min_deg, max_deg, deg_view, in_ch, in_ch_view;
+  int nparams() const { return 2 * (D + Dc + 3); }
+  int pts(int l) const { return 2 * l; }
+  int view(int i) const { return 2 * (D + i); }
+  int bott() const { return 2 * (D + Dc); }
+  int dens() const { return 2 * (D + Dc) + 2; }
+  int rgb() const { return 2 * (D + Dc) + 4; }
+  bool cat_before(int l) const { return l >= 2 && (l - 1) % skip == 0; }   // layer l reads cat([H_{l-1}, inputs]) (model.py:75-76, :103-104)
+  int in_width(int l) const { return l == 0 ? P : (cat_before(l) ? W + P : W); }
+};
+
+const char* make_gg(const aon_mlp_geometry* g, GG& o) {
+  if (!g) return "null geometry";
+  if (g->netdepth < 1 || g->netwidth < 1 || g->netdepth_condition < 1 || g->netwidth_condition < 1 || g->skip_layer < 1 || g->input_ch < 1 ||
+      g->input_ch_view < 1 || g->num_rgb_channels < 1 || g->num_density_channels < 1 || g->max_deg_point < g->min_deg_point || g->deg_view < 0)
+    return "bad NeRFMLP geometry";
+  if (g->netdepth > 64 || g->netdepth_condition > 64 || g->netwidth > 4096 || g->netwidth_condition > 4096) return "NeRFMLP geometry too large";
+  o.min_deg = g->min_deg_point; o.max_deg = g->max_deg_point; o.deg_view = g->deg_view; o.in_ch = g->input_ch; o.in_ch_view = g->input_ch_view;
+  o.P = ((g->max_deg_point - g->min_deg_point) * 2 + 1) * g->input_ch;
+  o.V = (g->deg_view * 2 + 1) * g->input_ch_view;
+  o.D = g->netdepth; o.W = g->netwidth; o.Dc = g->netdepth_condition; o.Wc = g->netwidth_condition; o.skip = g->skip_layer;
+  o.Crgb = g->num_rgb_channels; o.Cd = g->num_density_channels;
+  if (o.D - 1 > 0 && (o.D - 1) % o.skip == 0)
+    return "the last trunk layer would concatenate the encoding: the reference's forward fails on this geometry (model.py:90 vs :103-104)";
+  return nullptr;
+}
+
+// per-sample activation buffers of one MLP evaluation over M samples of n rays
+struct GActs {
+  float* E;        // M x P   (caller-owned when the encoding is given)
+  float* cond;     // n x V
+  float* H[64];    // trunk outputs, M x W each (inference: two buffers alternate)
+  float* bott;     // M x W
+  float* Vh[64];   // view-branch outputs, M x Wc
+};
+
+int gmlp_forward(const GG& g, const float* const* p, const GActs& a, int64_t n_rays, int S, float* raw_rgb, int64_t ld_rgb, float* raw_density,
+                 int64_t ld_density, hipStream_t stream, const char* who) {
+  const int64_t M = n_rays * S;
+  MlpTimer timer(stream, M);
+  for (int l = 0; l < g.D; ++l) {
+    aon::GemmArgs ga{};
+    const int ldw = g.in_width(l);
+    if (l == 0) ga.seg[0] = {a.E, g.P, 1, p[g.pts(0)], ldw, g.P};
+    else ga.seg[0] = {a.H[l - 1], g.W, 1, p[g.pts(l)], ldw, g.W};
+    ga.nseg = 1;
+    if (g.cat_before(l)) { ga.seg[1] = {a.E, g.P, 1, p[g.pts(l)] + g.W, ldw, g.P}; ga.nseg = 2; }
+    ga.bias = p[g.pts(l) + 1]; ga.Y = a.H[l]; ga.ldy = g.W; ga.M = M; ga.N = g.W; ga.epi = 1;
+    if (int rc = check(aon::launch_gemm_tn(ga, stream), who)) return rc;
+  }
+  const float* x = a.H[g.D - 1];
+  {
+    aon::GemmArgs ga{};
+    ga.seg[0] = {x, g.W, 1, p[g.dens()], g.W, g.W}; ga.nseg = 1;
+    ga.bias = p[g.dens() + 1]; ga.Y = raw_density; ga.ldy = ld_density; ga.M = M; ga.N = g.Cd; ga.epi = 0;
+    if (int rc = check(aon::launch_gemm_tn(ga, stream), who)) return rc;
+    ga.seg[0].W = p[g.bott()]; ga.bias = p[g.bott() + 1]; ga.Y = a.bott; ga.ldy = g.W; ga.N = g.W;
+    if (int rc = check(aon::launch_gemm_tn(ga, stream), who)) return rc;
+  }
+  for (int i = 0; i < g.Dc; ++i) {
+    aon::GemmArgs ga{};
+    if (i == 0) {
+      ga.seg[0] = {a.bott, g.W, 1, p[g.view(0)], g.W + g.V, g.W};
+      ga.seg[1] = {a.cond, g.V, S, p[g.view(0)] + g.W, g.W + g.V, g.V};   // condition_tile (model.py:107-110): the ray's row
+      ga.nseg = 2;
+    } else {
+      ga.seg[0] = {a.Vh[i - 1], g.Wc, 1, p[g.view(i)], g.Wc, g.Wc}; ga.nseg = 1;
+    }
+    ga.bias = p[g.view(i) + 1]; ga.Y = a.Vh[i]; ga.ldy = g.Wc; ga.M = M; ga.N = g.Wc; ga.epi = 1;
+    if (int rc = check(aon::launch_gemm_tn(ga, stream), who)) return rc;
+  }
+  {
+    aon::GemmArgs ga{};
+    ga.seg[0] = {a.Vh[g.Dc - 1], g.Wc, 1, p[g.rgb()], g.Wc, g.Wc}; ga.nseg = 1;
+    ga.bias = p[g.rgb() + 1]; ga.Y = raw_rgb; ga.ldy = ld_rgb; ga.M = M; ga.N = g.Crgb; ga.epi = 0;
+    if (int rc = check(aon::launch_gemm_tn(ga, stream), who)) return rc;
+  }
+  return AON_OK;
+}
+
+struct Carver {
+  char* base; int64_t off = 0;
+  explicit Carver(void* b) : base(static_cast<char*>(b)) {}
+  float* f(int64_t floats) { char* p = base + off; off += align_up(floats * 4, 256); return reinterpret_cast<float*>(p); }
+};
+
+// activation buffers: train = every layer keeps its own output, else two alternate
+GActs carve_acts(Carver& c, const GG& g, int64_t M, int64_t n_rays, bool train, bool own_enc) {
+  GActs a{};
+  if (own_enc) { a.E = c.f(M * g.P); a.cond = c.f(n_rays * g.V); }
+  if (train) {
+    for (int l = 0; l < g.D; ++l) a.H[l] = c.f(M * g.W);
+    for (int i = 0; i < g.Dc; ++i) a.Vh[i] = c.f(M * g.Wc);
+  } else {
+    float* h0 = c.f(M * g.W); float* h1 = c.f(M * g.W);
+    for (int l = 0; l < g.D; ++l) a.H[l] = (l & 1) ? h1 : h0;
+    float* v0 = c.f(M * g.Wc); float* v1 = c.f(M * g.Wc);
+    for (int i = 0; i < g.Dc; ++i) a.Vh[i] = (i & 1) ? v1 : v0;
+  }
+  a.bott = c.f(M * g.W);
+  return a;
+}
+
+// whole-path workspace of a chunk of n rays (inference)
+struct GWs { float* t_c; float* w_c; float* t_f; float* raw; float* coords; GActs acts; int64_t bytes; };
+GWs carve_grender(void* base, const GG& g, const Geo& geo, int64_t n) {
+  Carver c(base);
+  GWs w{};
+  w.t_c = c.f(n * geo.Sc); w.w_c = c.f(n * geo.Sc); w.t_f = c.f(n * geo.Sf); w.raw = c.f(n * geo.Sf * 4); w.coords = c.f(n * geo.Sf * 3);
+  w.acts = carve_acts(c, g, n * geo.Sf, n, false, true);
+  w.bytes = c.off;
+  return w;
+}
+
+// encodings of one level: cast_rays + pos_enc of the samples, pos_enc of the view directions (model.py:175-180)
+int g_encode(const GG& g, const float* o, const float* d, const float* v, const float* t, int64_t n, int S, float* coords, const GActs& a,
+             hipStream_t stream, const char* who) {
+  if (int rc = check(aon::launch_cast_rays(t, o, d, n, S, coords, stream), who)) return rc;
+  if (int rc = check(aon::launch_pos_enc(coords, n * S, g.min_deg, g.max_deg, a.E, stream), who)) return rc;
+  return check(aon::launch_pos_enc(v, n, 0, g.deg_view, a.cond, stream), who);
+}
+
+const char* whole_path_ok(const GG& g) {
+  if (g.in_ch != 3 || g.in_ch_view != 3 || g.Crgb != 3 || g.Cd != 1)
+    return "NeRF.forward needs input_ch = input_ch_view = 3, num_rgb_channels = 3, num_density_channels = 1";
+  return nullptr;
+}
+
+// training: what one level's forward leaves for the backward
+struct GTrainLevel { float* t; float* raw; float* coords; GActs acts; int S; int64_t M; };
+struct GTrainWs { GTrainLevel lvl[2]; float* w_c; int64_t bytes; };
+GTrainWs carve_gtrain(void* base, const GG& g, const Geo& geo, int64_t n, int num_levels) {
+  Carver c(base);
+  GTrainWs w{};
+  for (int l = 0; l < num_levels; ++l) {
+    GTrainLevel& L = w.lvl[l];
+    L.S = geo.S(l); L.M = n * L.S;
+    L.t = c.f(L.M); L.raw = c.f(L.M * 4); L.coords = c.f(L.M * 3);
+    L.acts = carve_acts(c, g, L.M, n, true, true);
+  }
+  w.w_c = c.f(n * geo.Sc);
+  w.bytes = c.off;
+  return w;
+}
+struct GScratch { float* d_raw; float* dz[2]; float* dbott; float* dv[2]; float* wt; float* part; int64_t bytes; };
+GScratch carve_gscratch(void* base, const GG& g, const Geo& geo, int64_t n, int num_levels) {
+  Carver c(base);
+  GScratch s{};
+  const int64_t M = n * geo.S(num_levels - 1);   // the larger level; the levels run one after the other
+  s.d_raw = c.f(M * 4);
+  s.dz[0] = c.f(M * g.W); s.dz[1] = c.f(M * g.W); s.dbott = c.f(M * g.W);
+  s.dv[0] = c.f(M * g.Wc); s.dv[1] = c.f(M * g.Wc);
+  const int64_t wmax = (int64_t)(g.W > g.Wc ? g.W : g.Wc);
+  int64_t wt = (int64_t)g.W * g.W + (int64_t)g.Cd * g.W;   // bottleneck + density head together; everything else one at a time
+  for (int64_t cand : {(int64_t)g.Crgb * g.Wc, (int64_t)g.Wc * g.Wc, (int64_t)g.Wc * g.W}) wt = cand > wt ? cand : wt;
+  s.wt = c.f(wt);
+  int64_t part = 0;
+  auto need = [&](int N, int K) { const int64_t f = aon::wgrad_part_floats(M, N, K); if (f > part) part = f; };
+  need(g.W, g.P); need(g.W, g.W); need(g.Wc, g.W); need(g.Wc, g.V); need(g.Wc, g.Wc); need(g.Crgb, g.Wc); need(g.Cd, g.W);
+  const int64_t cs = 512 * wmax;
+  s.part = c.f(part > cs ? part : cs);
+  s.bytes = c.off;
+  return s;
+}
+
+// backward of one level: parameter gradients (order / shapes of the params array) from d_raw (M x 4)
+int gmlp_backward(const GG& g, const float* const* p, float* const* grads, const GActs& a, const GScratch& sc, int64_t n_rays, int S,
+                  hipStream_t stream, const char* who) {
+  const int64_t M = n_rays * S;
+  const float* d_rgb = sc.d_raw;        // (M, 3) with row stride 4
+  const float* d_sig = sc.d_raw + 3;    // (M, 1) with row stride 4
+  int rc;
+  auto wgrad = [&](const float* dZ, int64_t ldz, int N, const float* X, int64_t ldx, int rowdiv, int K, float* dW, int64_t ldd) {
+    KTimer timer(kWgrad, stream, M);
+    return check(aon::launch_wgrad_nk(dZ, ldz, X, ldx, rowdiv, M, N, K, dW, ldd, sc.part, stream), who);
+  };
+  auto bgrad = [&](const float* dZ, int64_t ldz, int N, float* db) { return check(aon::launch_colsum(dZ, ldz, M, N, db, sc.part, stream), who); };
+  // dX[M x K] = dZ[M x N] . W[N x K0:K0+K]  (+ a second product), masked by `mask` > 0 when given
+  auto bdata = [&](const float* dZ, int64_t ldz, int N, const float* Wt, int K, const float* dZ2, int64_t ldz2, int N2, const float* Wt2,
+                   const float* mask, float* dX) {
+    KTimer timer(kBwdChain, stream, M);
+    aon::GemmArgs ga{};
+    ga.seg[0] = {dZ, ldz, 1, Wt, N, N}; ga.nseg = 1;
+    if (dZ2) { ga.seg[1] = {dZ2, ldz2, 1, Wt2, N2, N2}; ga.nseg = 2; }
+    ga.bias = nullptr; ga.Y = dX; ga.ldy = K; ga.M = M; ga.N = K; ga.epi = mask ? 2 : 0; ga.aux = mask; ga.ldaux = K;
+    return check(aon::launch_gemm_tn(ga, stream), who);
+  };
+  // rgb head
+  if ((rc = wgrad(d_rgb, 4, g.Crgb, a.Vh[g.Dc - 1], g.Wc, 1, g.Wc, grads[g.rgb()], g.Wc))) return rc;
+  if ((rc = bgrad(d_rgb, 4, g.Crgb, grads[g.rgb() + 1]))) return rc;
+  if ((rc = check(aon::launch_transpose(p[g.rgb()], g.Wc, g.Crgb, g.Wc, sc.wt, stream), who))) return rc;
+  float* dv = sc.dv[(g.Dc - 1) & 1];
+  if ((rc = bdata(d_rgb, 4, g.Crgb, sc.wt, g.Wc, nullptr, 0, 0, nullptr, a.Vh[g.Dc - 1], dv))) return rc;   // dZ of the last view layer
+  // view branch
+  for (int i = g.Dc - 1; i >= 1; --i) {
+    if ((rc = wgrad(dv, g.Wc, g.Wc, a.Vh[i - 1], g.Wc, 1, g.Wc, grads[g.view(i)], g.Wc))) return rc;
+    if ((rc = bgrad(dv, g.Wc, g.Wc, grads[g.view(i) + 1]))) return rc;
+    if ((rc = check(aon::launch_transpose(p[g.view(i)], g.Wc, g.Wc, g.Wc, sc.wt, stream), who))) return rc;
+    float* nx = sc.dv[(i - 1) & 1];
+    if ((rc = bdata(dv, g.Wc, g.Wc, sc.wt, g.Wc, nullptr, 0, 0, nullptr, a.Vh[i - 1], nx))) return rc;
+    dv = nx;
+  }
+  {
+    const int ldw = g.W + g.V;
+    if ((rc = wgrad(dv, g.Wc, g.Wc, a.bott, g.W, 1, g.W, grads[g.view(0)], ldw))) return rc;
+    if ((rc = wgrad(dv, g.Wc, g.Wc, a.cond, g.V, S, g.V, grads[g.view(0)] + g.W, ldw))) return rc;
+    if ((rc = bgrad(dv, g.Wc, g.Wc, grads[g.view(0) + 1]))) return rc;
+    if ((rc = check(aon::launch_transpose(p[g.view(0)], ldw, g.Wc, g.W, sc.wt, stream), who))) return rc;   // the bottleneck columns only
+    if ((rc = bdata(dv, g.Wc, g.Wc, sc.wt, g.W, nullptr, 0, 0, nullptr, nullptr, sc.dbott))) return rc;      // no activation on the bottleneck
+  }
+  // bottleneck + density heads -> the last trunk output
+  const float* x = a.H[g.D - 1];
+  if ((rc = wgrad(sc.dbott, g.W, g.W, x, g.W, 1, g.W, grads[g.bott()], g.W))) return rc;
+  if ((rc = bgrad(sc.dbott, g.W, g.W, grads[g.bott() + 1]))) return rc;
+  if ((rc = wgrad(d_sig, 4, g.Cd, x, g.W, 1, g.W, grads[g.dens()], g.W))) return rc;
+  if ((rc = bgrad(d_sig, 4, g.Cd, grads[g.dens() + 1]))) return rc;
+  {
+    float* wt2 = sc.wt + (int64_t)g.W * g.W;
+    if ((rc = check(aon::launch_transpose(p[g.bott()], g.W, g.W, g.W, sc.wt, stream), who))) return rc;
+    if ((rc = check(aon::launch_transpose(p[g.dens()], g.W, g.Cd, g.W, wt2, stream), who))) return rc;
+    if ((rc = bdata(sc.dbott, g.W, g.W, sc.wt, g.W, d_sig, 4, g.Cd, wt2, x, sc.dz[(g.D - 1) & 1]))) return rc;
+  }
+  // trunk
+  for (int l = g.D - 1; l >= 0; --l) {
+    const float* dz = sc.dz[l & 1];
+    const int ldw = g.in_width(l);
+    if (l == 0) {
+      if ((rc = wgrad(dz, g.W, g.W, a.E, g.P, 1, g.P, grads[g.pts(0)], ldw))) return rc;
+    } else {
+      if ((rc = wgrad(dz, g.W, g.W, a.H[l - 1], g.W, 1, g.W, grads[g.pts(l)], ldw))) return rc;
+      if (g.cat_before(l) && (rc = wgrad(dz, g.W, g.W, a.E, g.P, 1, g.P, grads[g.pts(l)] + g.W, ldw))) return rc;
+    }
+    if ((rc = bgrad(dz, g.W, g.W, grads[g.pts(l) + 1]))) return rc;
+    if (l > 0) {
+      if ((rc = check(aon::launch_transpose(p[g.pts(l)], ldw, g.W, g.W, sc.wt, stream), who))) return rc;   // the hidden columns only
+      if ((rc = bdata(dz, g.W, g.W, sc.wt, g.W, nullptr, 0, 0, nullptr, a.H[l - 1], sc.dz[(l - 1) & 1]))) return rc;
+    }
+  }
+  return AON_OK;
+}
+
+int check_params(const GG& g, const float* const* p, const char* what) {
+  if (!p) return fail(AON_E_INVALID, what);
+  for (int i = 0; i < g.nparams(); ++i)
+    if (!p[i]) return fail(AON_E_INVALID, what);
+  return AON_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+void aon_mlp_geometry_init(aon_mlp_geometry* g) {
+  if (!g) return;
+  *g = aon_mlp_geometry{0, 10, 4, 8, 256, 1, 128, 4, 3, 3, 3, 1};
+}
+
+int aon_gmlp_param_count(const aon_mlp_geometry* geom) {
+  GG g;
+  if (const char* bad = make_gg(geom, g)) return fail(AON_E_INVALID, bad);
+  return g.nparams();
+}
+
+int64_t aon_gmlp_workspace_bytes(const aon_mlp_geometry* geom, int64_t n_samples) {
+  GG g;
+  if (const char* bad = make_gg(geom, g)) return fail(AON_E_INVALID, bad);
+  Carver c(nullptr);
+  carve_acts(c, g, n_samples < 1 ? 1 : n_samples, 1, false, false);
+  return c.off;
+}
+
+int aon_gmlp_fwd(const aon_mlp_geometry* geom, const float* const* params_host, const float* samples_enc, const float* viewdirs_enc,
+                 int64_t n_rays, int S, float* raw_rgb, float* raw_density, void* workspace, int64_t workspace_bytes, void* stream) {
+  GG g;
+  if (const char* bad = make_gg(geom, g)) return fail(AON_E_INVALID, bad);
+  if (n_rays < 0 || S < 1) return fail(AON_E_INVALID, "aon_gmlp_fwd: bad size");
+  if (n_rays == 0) return AON_OK;
+  if (int rc = check_params(g, params_host, "aon_gmlp_fwd: null parameter pointer")) return rc;
+  if (!samples_enc || !viewdirs_enc || !raw_rgb || !raw_density || !workspace) return fail(AON_E_INVALID, "aon_gmlp_fwd: null pointer");
+  if (reinterpret_cast<uintptr_t>(workspace) & 255) return fail(AON_E_INVALID, "aon_gmlp_fwd: workspace must be 256-byte aligned");
+  Carver c(workspace);
+  GActs a = carve_acts(c, g, n_rays * S, n_rays, false, false);
+  if (c.off > workspace_bytes) return fail(AON_E_WORKSPACE, "aon_gmlp_fwd: workspace smaller than aon_gmlp_workspace_bytes()");
+  a.E = const_cast<float*>(samples_enc); a.cond = const_cast<float*>(viewdirs_enc);
+  return gmlp_forward(g, params_host, a, n_rays, S, raw_rgb, g.Crgb, raw_density, g.Cd, (hipStream_t)stream, "aon_gmlp_fwd");
+}
+
+int64_t aon_grender_workspace_bytes(const aon_mlp_geometry* geom, int64_t n_rays, const aon_render_opts* opts) {
+  GG g; Geo geo;
+  if (const char* bad = make_gg(geom, g)) return fail(AON_E_INVALID, bad);
+  if (const char* bad = make_geo(opts, geo)) return fail(AON_E_INVALID, bad);
+  return carve_grender(nullptr, g, geo, n_rays < 1 ? 1 : n_rays).bytes;
+}
+
+int aon_grender_fwd(const aon_mlp_geometry* geom, const float* const* params_coarse_host, const float* const* params_fine_host,
+                    const float* rays_o, const float* rays_d, const float* viewdirs, int64_t n_rays, float near_, float far_,
+                    int white_bkgd, int num_levels, const float* t_rand, const float* u, int64_t u_stride, float* rgb_c, float* acc_c,
+                    float* depth_c, float* rgb_f, float* acc_f, float* depth_f, void* workspace, int64_t workspace_bytes, void* stream_,
+                    const aon_render_opts* opts) {
+  const char* who = "aon_grender_fwd";
+  hipStream_t stream = (hipStream_t)stream_;
+  GG g; Geo geo;
+  if (const char* bad = make_gg(geom, g)) return fail(AON_E_INVALID, bad);
+  if (const char* bad = whole_path_ok(g)) return fail(AON_E_INVALID, bad);
+  if (const char* bad = make_geo(opts, geo)) return fail(AON_E_INVALID, bad);
+  if (n_rays < 0 || (num_levels != 1 && num_levels != 2)) return fail(AON_E_INVALID, "aon_grender_fwd: bad size / num_levels");
+  if (n_rays == 0) return AON_OK;
+  if (int rc = check_params(g, params_coarse_host, "aon_grender_fwd: null parameter pointer")) return rc;
+  if (num_levels == 2)
+    if (int rc = check_params(g, params_fine_host, "aon_grender_fwd: null parameter pointer")) return rc;
+  if (!rays_o || !rays_d || !viewdirs || !rgb_c || !acc_c || !depth_c || !workspace) return fail(AON_E_INVALID, "aon_grender_fwd: null pointer");
+  if (num_levels == 2 && (!rgb_f || !acc_f || !depth_f || !u || (u_stride != 0 && u_stride < geo.nf)))
+    return fail(AON_E_INVALID, "aon_grender_fwd: null fine-level pointer / bad u_stride");
+  if (reinterpret_cast<uintptr_t>(workspace) & 255) return fail(AON_E_INVALID, "aon_grender_fwd: workspace must be 256-byte aligned");
+  int64_t chunk = n_rays;
+  if (carve_grender(nullptr, g, geo, chunk).bytes > workspace_bytes) {
+    const int64_t one = carve_grender(nullptr, g, geo, 1).bytes, two = carve_grender(nullptr, g, geo, 1025).bytes;
+    const int64_t per_ray = (two - one) / 1024 + 1;
+    chunk = (workspace_bytes - one) / per_ray;
+    while (chunk > 0 && carve_grender(nullptr, g, geo, chunk).bytes > workspace_bytes) --chunk;
+    if (chunk < 1) return fail(AON_E_WORKSPACE, "aon_grender_fwd: workspace smaller than aon_grender_workspace_bytes(geom, 1, opts)");
+  }
+  const GWs w = carve_grender(workspace, g, geo, chunk);
+  const float* const* params[2] = {params_coarse_host, params_fine_host};
+  for (int64_t r0 = 0; r0 < n_rays; r0 += chunk) {
+    const int64_t n = n_rays - r0 < chunk ? n_rays - r0 : chunk;
+    const float* o = rays_o + r0 * 3; const float* d = rays_d + r0 * 3; const float* v = viewdirs + r0 * 3;
+    const float* uu = u_stride ? u + r0 * u_stride : u;
+    float* rgb[2] = {rgb_c + r0 * 3, rgb_f ? rgb_f + r0 * 3 : nullptr};
+    float* acc[2] = {acc_c + r0, acc_f ? acc_f + r0 : nullptr};
+    float* dep[2] = {depth_c + r0, depth_f ? depth_f + r0 : nullptr};
+    for (int l = 0; l < num_levels; ++l) {
+      const int S = geo.S(l);
+      float* t = l == 0 ? w.t_c : w.t_f;
+      int rc;
+      if (l == 0) {
+        KTimer timer(kSampleT, stream, n);
+        rc = check(aon::launch_sample_along_rays(o, d, n, geo.Sc, near_, far_, t_rand ? t_rand + r0 * geo.Sc : nullptr, t, nullptr, stream, geo.lindisp,
+                                                 geo.inv_near, geo.inv_far), who);
+      } else {
+        KTimer timer(kSamplePdf, stream, n);
+        rc = check(geo.default_sizes ? aon::launch_sample_pdf(nullptr, w.w_c + 1, kSc, w.t_c, uu, u_stride, n, nullptr, t, stream)
+                                     : aon::launch_sample_pdf_n(nullptr, w.w_c + 1, geo.Sc, w.t_c, uu, u_stride, n, geo.Sc - 1, geo.nf, geo.Sc, nullptr, t,
+                                                                stream), who);
+      }
+      if (rc) return rc;
+      if ((rc = g_encode(g, o, d, v, t, n, S, w.coords, w.acts, stream, who))) return rc;
+      if ((rc = gmlp_forward(g, params[l], w.acts, n, S, w.raw, 4, w.raw + 3, 4, stream, who))) return rc;
+      {
+        KTimer timer(kComposite, stream, n);
+        rc = check(aon::launch_composite(w.raw, 4, w.raw + 3, 4, t, d, n, S, white_bkgd, geo.act(false, l, r0), rgb[l], acc[l], dep[l],
+                                         (l == 0 && num_levels == 2) ? w.w_c : nullptr, stream), who);
+      }
+      if (rc) return rc;
+    }
+  }
+  return AON_OK;
+}
+
+int64_t aon_grender_train_workspace_bytes(const aon_mlp_geometry* geom, int64_t n_rays, int num_levels, const aon_render_opts* opts) {
+  GG g; Geo geo;
+  if (const char* bad = make_gg(geom, g)) return fail(AON_E_INVALID, bad);
+  if (const char* bad = make_geo(opts, geo)) return fail(AON_E_INVALID, bad);
+  return carve_gtrain(nullptr, g, geo, n_rays < 1 ? 1 : n_rays, num_levels == 1 ? 1 : 2).bytes;
+}
+int64_t aon_grender_train_scratch_bytes(const aon_mlp_geometry* geom, int64_t n_rays, int num_levels, const aon_render_opts* opts) {
+  GG g; Geo geo;
+  if (const char* bad = make_gg(geom, g)) return fail(AON_E_INVALID, bad);
+  if (const char* bad = make_geo(opts, geo)) return fail(AON_E_INVALID, bad);
+  return carve_gscratch(nullptr, g, geo, n_rays < 1 ? 1 : n_rays, num_levels == 1 ? 1 : 2).bytes;
+}
+
+int aon_grender_fwd_train(const aon_mlp_geometry* geom, const float* const* params_coarse_host, const float* const* params_fine_host,
+                          const float* rays_o, const float* rays_d, const float* viewdirs, int64_t n, float near_, float far_,
+                          int white_bkgd, int num_levels, const float* t_rand, const float* u, int64_t u_stride, float* rgb_c,
+                          float* acc_c, float* depth_c, float* rgb_f, float* acc_f, float* depth_f, void* workspace,
+                          int64_t workspace_bytes, void* stream_, const aon_render_opts* opts) {
+  const char* who = "aon_grender_fwd_train";
+  hipStream_t stream = (hipStream_t)stream_;
+  GG g; Geo geo;
+  if (const char* bad = make_gg(geom, g)) return fail(AON_E_INVALID, bad);
+  if (const char* bad = whole_path_ok(g)) return fail(AON_E_INVALID, bad);
+  if (const char* bad = make_geo(opts, geo)) return fail(AON_E_INVALID, bad);
+  if (geo.Sf > 1024) return fail(AON_E_INVALID, "aon_grender_fwd_train: more than 1024 samples per ray at the fine level");
+  if (n <= 0 || (num_levels != 1 && num_levels != 2)) return fail(AON_E_INVALID, "aon_grender_fwd_train: bad size / num_levels");
+  if (int rc = check_params(g, params_coarse_host, "aon_grender_fwd_train: null parameter pointer")) return rc;
+  if (num_levels == 2)
+    if (int rc = check_params(g, params_fine_host, "aon_grender_fwd_train: null parameter pointer")) return rc;
+  if (!rays_o || !rays_d || !viewdirs || !rgb_c || !acc_c || !depth_c || !workspace) return fail(AON_E_INVALID, "aon_grender_fwd_train: null pointer");
+  if (num_levels == 2 && (!rgb_f || !acc_f || !depth_f || !u || (u_stride != 0 && u_stride < geo.nf)))
+    return fail(AON_E_INVALID, "aon_grender_fwd_train: null fine-level pointer / bad u_stride");
+  if (reinterpret_cast<uintptr_t>(workspace) & 255) return fail(AON_E_INVALID, "aon_grender_fwd_train: workspace must be 256-byte aligned");
+  const GTrainWs w = carve_gtrain(workspace, g, geo, n, num_levels);
+  if (w.bytes > workspace_bytes) return fail(AON_E_WORKSPACE, "aon_grender_fwd_train: workspace smaller than aon_grender_train_workspace_bytes()");
+  const float* const* params[2] = {params_coarse_host, params_fine_host};
+  float* rgb[2] = {rgb_c, rgb_f}; float* acc[2] = {acc_c, acc_f}; float* dep[2] = {depth_c, depth_f};
+  for (int l = 0; l < num_levels; ++l) {
+    const GTrainLevel& L = w.lvl[l];
+    int rc;
+    if (l == 0) {
+      KTimer timer(kSampleT, stream, n);
+      rc = check(aon::launch_sample_along_rays(rays_o, rays_d, n, geo.Sc, near_, far_, t_rand, L.t, nullptr, stream, geo.lindisp, geo.inv_near,
+                                               geo.inv_far), who);
+    } else {
+      KTimer timer(kSamplePdf, stream, n);
+      rc = check(geo.default_sizes ? aon::launch_sample_pdf(nullptr, w.w_c + 1, kSc, w.lvl[0].t, u, u_stride, n, nullptr, L.t, stream)
+                                   : aon::launch_sample_pdf_n(nullptr, w.w_c + 1, geo.Sc, w.lvl[0].t, u, u_stride, n, geo.Sc - 1, geo.nf, geo.Sc, nullptr,
+                                                              L.t, stream), who);
+    }
+    if (rc) return rc;
+    if ((rc = g_encode(g, rays_o, rays_d, viewdirs, L.t, n, L.S, L.coords, L.acts, stream, who))) return rc;
+    if ((rc = gmlp_forward(g, params[l], L.acts, n, L.S, L.raw, 4, L.raw + 3, 4, stream, who))) return rc;
+    {
+      KTimer timer(kComposite, stream, n);
+      rc = check(aon::launch_composite(L.raw, 4, L.raw + 3, 4, L.t, rays_d, n, L.S, white_bkgd, geo.act(false, l, 0), rgb[l], acc[l], dep[l],
+                                       (l == 0 && num_levels == 2) ? w.w_c : nullptr, stream), who);
+    }
+    if (rc) return rc;
+  }
+  return AON_OK;
+}
+
+int aon_grender_bwd(const aon_mlp_geometry* geom, const float* const* params_coarse_host, const float* const* params_fine_host,
+                    const float* rays_d, int64_t n, int white_bkgd, int num_levels, const float* const* g_rgb_host,
+                    const float* const* g_acc_host, const float* const* g_depth_host, float* const* grads_coarse_host,
+                    float* const* grads_fine_host, void* workspace, int64_t workspace_bytes, void* scratch, int64_t scratch_bytes,
+                    void* stream_, const aon_render_opts* opts) {
+  const char* who = "aon_grender_bwd";
+  hipStream_t stream = (hipStream_t)stream_;
+  GG g; Geo geo;
+  if (const char* bad = make_gg(geom, g)) return fail(AON_E_INVALID, bad);
+  if (const char* bad = whole_path_ok(g)) return fail(AON_E_INVALID, bad);
+  if (const char* bad = make_geo(opts, geo)) return fail(AON_E_INVALID, bad);
+  if (n <= 0 || (num_levels != 1 && num_levels != 2)) return fail(AON_E_INVALID, "aon_grender_bwd: bad size / num_levels");
+  if (!rays_d || !g_rgb_host || !workspace || !scratch) return fail(AON_E_INVALID, "aon_grender_bwd: null pointer");
+  if ((reinterpret_cast<uintptr_t>(workspace) & 255) || (reinterpret_cast<uintptr_t>(scratch) & 255))
+    return fail(AON_E_INVALID, "aon_grender_bwd: workspace / scratch must be 256-byte aligned");
+  const GTrainWs w = carve_gtrain(workspace, g, geo, n, num_levels);
+  if (w.bytes > workspace_bytes) return fail(AON_E_WORKSPACE, "aon_grender_bwd: workspace smaller than aon_grender_train_workspace_bytes()");
+  const GScratch sc = carve_gscratch(scratch, g, geo, n, num_levels);
+  if (sc.bytes > scratch_bytes) return fail(AON_E_WORKSPACE, "aon_grender_bwd: scratch smaller than aon_grender_train_scratch_bytes()");
+  const float* const* params[2] = {params_coarse_host, params_fine_host};
+  float* const* grads[2] = {grads_coarse_host, grads_fine_host};
+  for (int l = 0; l < num_levels; ++l) {
+    const GTrainLevel& L = w.lvl[l];
+    if (int rc = check_params(g, params[l], "aon_grender_bwd: null parameter pointer")) return rc;
+    if (!grads[l] || !g_rgb_host[l]) return fail(AON_E_INVALID, "aon_grender_bwd: null level pointer");
+    for (int i = 0; i < g.nparams(); ++i)
+      if (!grads[l][i]) return fail(AON_E_INVALID, "aon_grender_bwd: null gradient pointer");
+    int rc;
+    {
+      KTimer timer(kCompositeBwd, stream, n);
+      rc = check(aon::launch_composite_bwd(L.raw, L.t, rays_d, g_rgb_host[l], g_acc_host ? g_acc_host[l] : nullptr, g_depth_host ? g_depth_host[l] : nullptr,
+                                           n, L.S, white_bkgd, geo.act(false, l, 0), sc.d_raw, stream), who);
+    }
+    if (rc) return rc;
+    if ((rc = gmlp_backward(g, params[l], grads[l], L.acts, sc, n, L.S, stream, who))) return rc;
+  }
+  return AON_OK;
 }
 
 }  // extern "C"

@@ -1,0 +1,299 @@
+// General-geometry NeRFMLP engine for gfx950: every NeRFMLP(min_deg_point, max_deg_point, deg_view, netdepth, netwidth,
+// netdepth_condition, netwidth_condition, skip_layer, ...) the reference's constructor accepts (models/vanilla_nerf/model.py:40-93),
+// forward (model.py:95-120) and backward, as LAYER-WISE fp32 MFMA GEMMs on the unmodified nn.Linear storages.
+//
+// The reference's default geometry has the fused register-resident kernels (aon_mlp.hip, aon_train.hip); they are compiled for that
+// geometry and nothing else.  This file is the path for everything else: activations live in HBM between layers (an fp32 layer is
+// still matrix-pipe-bound on this chip: 2 x K x N flops against (K + N) x 4 bytes per sample = 128 flop/B at 256 x 256, the
+// machine balance of the fp32 matrix pipe over HBM is ~20), one launch per layer:
+//   gemm_tn_kernel   Y[M x N] = epi(sum_seg X_seg[M x K_seg] . W_seg[N x K_seg]^T + bias)        forward layers, backward data
+//                    up to two (X, W) segments: torch.cat([x, inputs]) (model.py:103-104) and cat([bottleneck, condition_tile])
+//                    (:111) are never materialised -- the second segment reads the encoding / the per-RAY condition row (row / S);
+//                    epilogue: none | ReLU | mask by aux > 0 (dZ = dH . [H > 0]: the saved post-ReLU output IS the mask)
+//   wgrad_nk_kernel  dW[N x K] += dZ[m0:m1, N]^T . X[m0:m1, K]    split over samples, one partial per split, no atomics
+//   colsum_kernel    db[N] partials;   reduce_kernel: partials -> gradient in a fixed order;   transpose_kernel: W -> W^T
+// 128 x 128 output tiles, 4 waves x (2 x 2) 32x32 MFMA tiles (v_mfma_f32_32x32x2_f32: exact fp32 like the fused kernels),
+// operands staged through LDS with the next tile's global loads in flight in registers.
+#include "aon_gmlp.h"
+
+namespace aon {
+
+constexpr int kGBM = 128, kGBN = 128, kGBK = 32, kGLD = 36;   // LDS rows of 32 k-values padded to 36 floats
+
+// one 128-row x 32-k tile of a k-contiguous operand into registers: thread t takes row t >> 1, k-range (t & 1) * 16 .. + 16
+__device__ __forceinline__ void load_tile_rows(const float* base, int64_t ld, int rowdiv, int64_t row0, int64_t nrows, int k0, int K, int tid,
+                                               f32x4 (&v)[4]) {
+  const int64_t r = row0 + (tid >> 1);
+  const int kb = k0 + (tid & 1) * 16;
+  const bool row_ok = r < nrows;
+  const float* p = base + (row_ok ? (r / rowdiv) * ld : 0);
+  const bool vec_ok = row_ok && ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(base) & 15) == 0);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int k = kb + 4 * q;
+    if (vec_ok && k + 4 <= K) {
+      v[q] = *reinterpret_cast<const f32x4*>(p + k);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[q][e] = (row_ok && k + e < K) ? p[k + e] : 0.f;
+    }
+  }
+}
+
+__device__ __forceinline__ void store_tile_rows(float* lds, int tid, const f32x4 (&v)[4]) {
+  float* p = lds + (tid >> 1) * kGLD + (tid & 1) * 16;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(p + 4 * q) = v[q];
+}
+
+__global__ void __launch_bounds__(256) gemm_tn_kernel(GemmArgs a) {
+  __shared__ __attribute__((aligned(16))) float As[kGBM * kGLD];
+  __shared__ __attribute__((aligned(16))) float Bs[kGBN * kGLD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int64_t m0 = (int64_t)blockIdx.x * kGBM;
+  const int n0 = blockIdx.y * kGBN;
+  const int wr = (wave & 1) * 64, wc = (wave >> 1) * 64;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  // flat list of k-chunks over the segments
+  const int nch0 = (a.seg[0].K + kGBK - 1) / kGBK;
+  const int nch1 = a.nseg > 1 ? (a.seg[1].K + kGBK - 1) / kGBK : 0;
+  const int nch = nch0 + nch1;
+  f32x4 va[4], vb[4];
+  auto fetch = [&](int c) {
+    const int s = c < nch0 ? 0 : 1;
+    const int k0 = (s == 0 ? c : c - nch0) * kGBK;
+    const GemmSeg& g = a.seg[s];
+    load_tile_rows(g.X, g.ldx, g.rowdiv, m0, a.M, k0, g.K, tid, va);
+    load_tile_rows(g.W, g.ldw, 1, n0, a.N, k0, g.K, tid, vb);
+  };
+  fetch(0);
+  for (int c = 0; c < nch; ++c) {
+    __syncthreads();                 // the previous chunk's fragment reads are done
+    store_tile_rows(As, tid, va);
+    store_tile_rows(Bs, tid, vb);
+    __syncthreads();
+    if (c + 1 < nch) fetch(c + 1);   // in flight under the MFMAs below
+#pragma unroll
+    for (int kg = 0; kg < 4; ++kg) {
+      f32x4 fa[2], fb[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const f32x4*>(As + (wr + 32 * i + r) * kGLD + kg * 8 + 4 * h);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) fb[j] = *reinterpret_cast<const f32x4*>(Bs + (wc + 32 * j + r) * kGLD + kg * 8 + 4 * h);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
+    }
+  }
+  // epilogue: lane holds column n = .. + r, rows 8 (e >> 2) + (e & 3) + 4 h of each 32 x 32 tile
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int n = n0 + wc + 32 * j + r;
+    if (n >= a.N) continue;
+    const float b = a.bias ? a.bias[n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int64_t m = m0 + wr + 32 * i + 8 * (e >> 2) + (e & 3) + 4 * h;
+        if (m >= a.M) continue;
+        float y = __fadd_rn(acc[i][j][e], b);
+        if (a.epi == 1) y = __builtin_fmaxf(y, 0.f);
+        else if (a.epi == 2) y = a.aux[m * a.ldaux + n] > 0.f ? y : 0.f;
+        a.Y[m * a.ldy + n] = y;
+      }
+    }
+  }
+}
+
+hipError_t launch_gemm_tn(const GemmArgs& a, hipStream_t stream) {
+  if (a.M <= 0 || a.N <= 0) return hipSuccess;
+  const dim3 grid((unsigned)((a.M + kGBM - 1) / kGBM), (unsigned)((a.N + kGBN - 1) / kGBN));
+  gemm_tn_kernel<<<grid, dim3(256), 0, stream>>>(a);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight gradients: part[split][N x K] = A[m0:m1, 0:N]^T . B[m0:m1, 0:K]   (A = dZ, B = the layer's input segment)
+// ---------------------------------------------------------------------------------------------
+constexpr int kWLD = 132;   // LDS rows of 128 features padded to 132 floats
+constexpr int kWBM = 32;    // samples per staged step
+
+struct WgradArgs {
+  const float* A; int64_t lda;               // (M, N)
+  const float* B; int64_t ldb; int rowdiv;   // row m reads B[(m / rowdiv) * ldb + k]
+  int64_t M; int N, K;
+  int64_t rows_per_split;                    // multiple of kWBM
+  float* part;                               // [splits][N * K]
+};
+
+__device__ __forceinline__ void load_tile_cols(const float* base, int64_t ld, int rowdiv, int64_t m0, int64_t m_end, int c0, int C, int tid,
+                                               f32x4 (&v)[4]) {
+  // 32 rows x 128 columns: thread t takes row t >> 3, columns (t & 7) * 16 .. + 16
+  const int64_t m = m0 + (tid >> 3);
+  const int cb = c0 + (tid & 7) * 16;
+  const bool row_ok = m < m_end;
+  const float* p = base + (row_ok ? (m / rowdiv) * ld : 0);
+  const bool vec_ok = row_ok && ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(base) & 15) == 0);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int c = cb + 4 * q;
+    if (vec_ok && c + 4 <= C) {
+      v[q] = *reinterpret_cast<const f32x4*>(p + c);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[q][e] = (row_ok && c + e < C) ? p[c + e] : 0.f;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) wgrad_nk_kernel(WgradArgs a) {
+  __shared__ __attribute__((aligned(16))) float As[kWBM * kWLD];
+  __shared__ __attribute__((aligned(16))) float Bs[kWBM * kWLD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int n0 = blockIdx.x * 128, k0 = blockIdx.y * 128;
+  const int64_t mb = (int64_t)blockIdx.z * a.rows_per_split;
+  const int64_t me = mb + a.rows_per_split < a.M ? mb + a.rows_per_split : a.M;
+  const int wr = (wave & 1) * 64, wc = (wave >> 1) * 64;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  f32x4 va[4], vb[4];
+  if (mb < me) {
+    load_tile_cols(a.A, a.lda, 1, mb, me, n0, a.N, tid, va);
+    load_tile_cols(a.B, a.ldb, a.rowdiv, mb, me, k0, a.K, tid, vb);
+  }
+  for (int64_t m = mb; m < me; m += kWBM) {
+    __syncthreads();
+    {
+      float* pa = As + (tid >> 3) * kWLD + (tid & 7) * 16;
+      float* pb = Bs + (tid >> 3) * kWLD + (tid & 7) * 16;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { *reinterpret_cast<f32x4*>(pa + 4 * q) = va[q]; *reinterpret_cast<f32x4*>(pb + 4 * q) = vb[q]; }
+    }
+    __syncthreads();
+    if (m + kWBM < me) {
+      load_tile_cols(a.A, a.lda, 1, m + kWBM, me, n0, a.N, tid, va);
+      load_tile_cols(a.B, a.ldb, a.rowdiv, m + kWBM, me, k0, a.K, tid, vb);
+    }
+#pragma unroll
+    for (int ks = 0; ks < kWBM / 2; ++ks) {
+      float fa[2], fb[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) fa[i] = As[(2 * ks + h) * kWLD + wr + 32 * i + r];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) fb[j] = Bs[(2 * ks + h) * kWLD + wc + 32 * j + r];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+  }
+  float* out = a.part + (int64_t)blockIdx.z * a.N * a.K;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int k = k0 + wc + 32 * j + r;
+    if (k >= a.K) continue;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int n = n0 + wr + 32 * i + 8 * (e >> 2) + (e & 3) + 4 * h;
+        if (n < a.N) out[(int64_t)n * a.K + k] = acc[i][j][e];
+      }
+  }
+}
+
+// column sums of A[m0:m1, 0:N] -> part[split][N]
+__global__ void __launch_bounds__(256) colsum_kernel(const float* __restrict__ A, int64_t lda, int64_t M, int N, int64_t rows_per_split,
+                                                     float* __restrict__ part) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  const int64_t mb = (int64_t)blockIdx.y * rows_per_split;
+  const int64_t me = mb + rows_per_split < M ? mb + rows_per_split : M;
+  if (n >= N) return;
+  float s = 0.f;
+  for (int64_t m = mb; m < me; ++m) s += A[m * lda + n];
+  part[(int64_t)blockIdx.y * N + n] = s;
+}
+
+// dst[(i / cols) * ldd + i % cols] = sum_s part[s * count + i]   in split order (deterministic)
+__global__ void __launch_bounds__(256) reduce_kernel(const float* __restrict__ part, int splits, int64_t count, int cols, int64_t ldd,
+                                                     float* __restrict__ dst) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= count) return;
+  float s = 0.f;
+  for (int k = 0; k < splits; ++k) s += part[(int64_t)k * count + i];
+  dst[(i / cols) * ldd + i % cols] = s;
+}
+
+// WT[k * N + n] = W[n * ldw + k]
+__global__ void __launch_bounds__(256) transpose_kernel(const float* __restrict__ W, int64_t ldw, int N, int K, float* __restrict__ WT) {
+  __shared__ float tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+  const int k0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+  for (int i = ty; i < 32; i += 8)
+    tile[i][tx] = (n0 + i < N && k0 + tx < K) ? W[(int64_t)(n0 + i) * ldw + k0 + tx] : 0.f;
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8)
+    if (k0 + i < K && n0 + tx < N) WT[(int64_t)(k0 + i) * N + n0 + tx] = tile[tx][i];
+}
+
+hipError_t launch_transpose(const float* W, int64_t ldw, int N, int K, float* WT, hipStream_t stream) {
+  transpose_kernel<<<dim3((unsigned)((K + 31) / 32), (unsigned)((N + 31) / 32)), dim3(256), 0, stream>>>(W, ldw, N, K, WT);
+  return hipGetLastError();
+}
+
+// number of sample splits of a weight-gradient product: enough workgroups to fill the chip, at least 4,096 samples each
+int wgrad_splits(int64_t M, int N, int K) {
+  const int tiles = ((N + 127) / 128) * ((K + 127) / 128);
+  int64_t s = (512 + tiles - 1) / tiles;
+  const int64_t cap = (M + 4095) / 4096;
+  if (s > cap) s = cap;
+  if (s < 1) s = 1;
+  if (s > 256) s = 256;
+  return (int)s;
+}
+int64_t wgrad_part_floats(int64_t M, int N, int K) { return (int64_t)wgrad_splits(M, N, K) * N * K; }
+
+// dW[0:N, 0:K] (row stride ldd: a column block of an nn.Linear weight) = A^T B, bias gradient optional
+hipError_t launch_wgrad_nk(const float* A, int64_t lda, const float* B, int64_t ldb, int rowdiv, int64_t M, int N, int K, float* dW, int64_t ldd,
+                           float* part, hipStream_t stream) {
+  if (N <= 0 || K <= 0) return hipSuccess;
+  const int splits = wgrad_splits(M, N, K);
+  int64_t rows = (M + splits - 1) / splits;
+  rows = (rows + kWBM - 1) / kWBM * kWBM;
+  WgradArgs a{A, lda, B, ldb, rowdiv, M, N, K, rows, part};
+  wgrad_nk_kernel<<<dim3((unsigned)((N + 127) / 128), (unsigned)((K + 127) / 128), (unsigned)splits), dim3(256), 0, stream>>>(a);
+  const int64_t count = (int64_t)N * K;
+  reduce_kernel<<<dim3((unsigned)((count + 255) / 256)), dim3(256), 0, stream>>>(part, splits, count, K, ldd, dW);
+  return hipGetLastError();
+}
+
+hipError_t launch_colsum(const float* A, int64_t lda, int64_t M, int N, float* db, float* part, hipStream_t stream) {
+  if (N <= 0) return hipSuccess;
+  int64_t splits = (M + 8191) / 8192;
+  if (splits > 512) splits = 512;
+  if (splits < 1) splits = 1;
+  const int64_t rows = (M + splits - 1) / splits;
+  colsum_kernel<<<dim3((unsigned)((N + 255) / 256), (unsigned)splits), dim3(256), 0, stream>>>(A, lda, M, N, rows, part);
+  reduce_kernel<<<dim3((unsigned)((N + 255) / 256)), dim3(256), 0, stream>>>(part, (int)splits, N, N, N, db);
+  return hipGetLastError();
+}
+
+}  // namespace aon

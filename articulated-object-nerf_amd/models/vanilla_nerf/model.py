@@ -2,9 +2,11 @@
 reference's Lightning checkpoints load unchanged) and the same ``forward`` signatures and return structure as
 ``models/vanilla_nerf/model.py:39-199`` -- with ``forward`` running on the fused HIP kernels.
 
-Only the reference's default geometry has kernels (8x256 trunk with a skip at layer 4, 1x128 view branch,
-10/4 encoding degrees, 64+128 samples): that is the only geometry the reference can instantiate from its CLI
-(``LitNeRF`` builds ``NeRF()`` with all defaults, model.py:218).  Anything else raises at construction.
+Two engines, chosen by the constructor arguments.  The reference's default NeRFMLP (8x256 trunk with a skip at layer 4,
+1x128 view branch, 10/4 encoding degrees) -- the only one its CLI can build (``LitNeRF`` builds ``NeRF()``, model.py:218) --
+runs on the fused register-resident kernels.  Every other ``NeRFMLP(...)`` geometry and every ``NeRF(min_deg_point,
+max_deg_point, deg_view)`` runs on the layer-wise MFMA GEMM engine (``csrc/aon_gmlp.hip``): same C boundary, same module
+interface, forward and backward.  Sample counts, ``lindisp`` and ``noise_std`` are runtime arguments of both.
 """
 from __future__ import annotations
 
@@ -13,7 +15,7 @@ import torch.nn as nn
 import torch.nn.init as init
 
 from ... import ops
-from ...autograd import RenderVanilla
+from ...autograd import RenderGeneral, RenderVanilla
 
 
 class NeRFMLP(nn.Module):
@@ -24,10 +26,10 @@ class NeRFMLP(nn.Module):
                  netdepth_condition: int = 1, netwidth_condition: int = 128, skip_layer: int = 4, input_ch: int = 3,
                  input_ch_view: int = 3, num_rgb_channels: int = 3, num_density_channels: int = 1):
         super().__init__()
-        geometry = (min_deg_point, max_deg_point, deg_view, netdepth, netwidth, netdepth_condition, netwidth_condition,
-                    skip_layer, input_ch, input_ch_view, num_rgb_channels, num_density_channels)
-        if geometry != (0, 10, 4, 8, 256, 1, 128, 4, 3, 3, 3, 1):
-            raise NotImplementedError(f"NeRFMLP geometry {geometry} has no HIP kernel (only the reference defaults do)")
+        # validated by the C side (aon_gmlp_param_count): e.g. a skip concatenation after the LAST trunk layer is rejected, the
+        # reference's own forward fails on it (density_layer is built for netwidth inputs)
+        self.geometry = ops.MlpGeometry(min_deg_point, max_deg_point, deg_view, netdepth, netwidth, netdepth_condition, netwidth_condition,
+                                        skip_layer, input_ch, input_ch_view, num_rgb_channels, num_density_channels)
         self.min_deg_point, self.max_deg_point, self.deg_view = min_deg_point, max_deg_point, deg_view
         self.netdepth, self.netwidth, self.skip_layer = netdepth, netwidth, skip_layer
         self.netdepth_condition, self.netwidth_condition = netdepth_condition, netwidth_condition
@@ -41,7 +43,12 @@ class NeRFMLP(nn.Module):
         for layer in layers:
             init.xavier_uniform_(layer.weight)
         self.pts_linears = nn.ModuleList(layers)
-        self.views_linear = nn.ModuleList([nn.Linear(netwidth + view_pos_size, netwidth_condition)])
+        views = [nn.Linear(netwidth + view_pos_size, netwidth_condition)]
+        for _ in range(netdepth_condition - 1):
+            layer = nn.Linear(netwidth_condition, netwidth_condition)
+            init.xavier_uniform_(layer.weight)
+            views.append(layer)
+        self.views_linear = nn.ModuleList(views)
         self.bottleneck_layer = nn.Linear(netwidth, netwidth)
         self.density_layer = nn.Linear(netwidth, num_density_channels)
         self.rgb_layer = nn.Linear(netwidth_condition, num_rgb_channels)
@@ -78,9 +85,11 @@ class NeRFMLP(nn.Module):
 
     def ordered_params(self):
         params = dict(self.named_parameters())
-        return [params[name] for name in ops.VANILLA_PARAM_ORDER]
+        return [params[name] for name in self.geometry.param_order]   # == ops.VANILLA_PARAM_ORDER for the default geometry
 
     def forward(self, x, condition):
+        if not self.geometry.is_default:   # layer-wise engine, any geometry (inference; training goes through NeRF.forward)
+            return ops.gmlp_fwd(self.geometry, dict(self.named_parameters()), x, condition)
         raw = ops.mlp_fwd_enc(self.packed(), x, condition)
         return raw[..., :3], raw[..., 3:4]
 
@@ -109,6 +118,7 @@ class NeRF(nn.Module):
         self.sigma_activation = nn.ReLU()
         self.coarse_mlp = NeRFMLP(min_deg_point, max_deg_point, deg_view)
         self.fine_mlp = NeRFMLP(min_deg_point, max_deg_point, deg_view)
+        self._general = not self.coarse_mlp.geometry.is_default   # other encoding degrees: the layer-wise engine
 
     def _draw_noise(self, noise, randomized, n, device):
         if not (self.noise_std > 0 and randomized):
@@ -129,6 +139,20 @@ class NeRF(nn.Module):
         else:
             t_rand, u = None, None
         noise = self._draw_noise(noise, randomized, n, rays_o.device)
+        if self._general:
+            geom = self.coarse_mlp.geometry
+            mlps = [self.coarse_mlp, self.fine_mlp][: self.num_levels]
+            if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+                if n == 0:
+                    raise ValueError("empty ray batch in training mode")
+                params = [p for m in mlps for p in m.ordered_params()]
+                flat = RenderGeneral.apply(rays_o, rays["rays_d"], rays["viewdirs"], float(near), float(far), bool(white_bkgd),
+                                           self.num_levels, t_rand, u, geom, self._opts, noise, *params)
+                return [tuple(flat[3 * i: 3 * i + 3]) for i in range(self.num_levels)]
+            pd = [dict(m.named_parameters()) for m in mlps]
+            outs = ops.grender_fwd(geom, pd[0], pd[1] if self.num_levels == 2 else None, rays_o, rays["rays_d"], rays["viewdirs"], near, far,
+                                   white_bkgd, self.num_levels, t_rand, u, opts=self._opts, noise=noise)
+            return [tuple(o) for o in outs]
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             # training: fused forward that keeps the activation planes + HIP backward (autograd.RenderVanilla)
             if n == 0:

@@ -815,6 +815,177 @@ def art_render_bwd(ws, packs_bwd, smalls, rays_d, white_bkgd, num_levels, g_rgb,
     return grads, g_lat
 
 
+# ------------------------------------------------------------------ NeRFMLP of any constructor geometry (csrc/aon_gmlp.hip)
+class MlpGeometry:
+    """The arguments of ``NeRFMLP.__init__`` (model.py:40-54) -> ``aon_mlp_geometry``; parameter names / shapes / order of the
+    module that constructor builds."""
+
+    FIELDS = ("min_deg_point", "max_deg_point", "deg_view", "netdepth", "netwidth", "netdepth_condition", "netwidth_condition",
+              "skip_layer", "input_ch", "input_ch_view", "num_rgb_channels", "num_density_channels")
+    DEFAULT = (0, 10, 4, 8, 256, 1, 128, 4, 3, 3, 3, 1)
+
+    def __init__(self, min_deg_point=0, max_deg_point=10, deg_view=4, netdepth=8, netwidth=256, netdepth_condition=1,
+                 netwidth_condition=128, skip_layer=4, input_ch=3, input_ch_view=3, num_rgb_channels=3, num_density_channels=1):
+        vals = (min_deg_point, max_deg_point, deg_view, netdepth, netwidth, netdepth_condition, netwidth_condition, skip_layer, input_ch,
+                input_ch_view, num_rgb_channels, num_density_channels)
+        for name, v in zip(self.FIELDS, vals):
+            setattr(self, name, int(v))
+        self.pos_size = ((self.max_deg_point - self.min_deg_point) * 2 + 1) * self.input_ch
+        self.view_pos_size = (self.deg_view * 2 + 1) * self.input_ch_view
+        st = self.c_struct()
+        if lib.aon_gmlp_param_count(C.byref(st)) < 0:     # the C side owns the validity rules
+            check(-1, "NeRFMLP geometry")
+
+    def as_tuple(self):
+        return tuple(getattr(self, n) for n in self.FIELDS)
+
+    @property
+    def is_default(self) -> bool:
+        return self.as_tuple() == self.DEFAULT
+
+    def c_struct(self):
+        st = _lib.MlpGeometryC()
+        for n in self.FIELDS:
+            setattr(st, n, getattr(self, n))
+        return st
+
+    def cat_before(self, l: int) -> bool:
+        """layer l reads cat([x, inputs]) (model.py:75-76)"""
+        return l >= 2 and (l - 1) % self.skip_layer == 0
+
+    @property
+    def param_order(self):
+        names = [f"pts_linears.{i}" for i in range(self.netdepth)] + [f"views_linear.{i}" for i in range(self.netdepth_condition)]
+        names += ["bottleneck_layer", "density_layer", "rgb_layer"]
+        return [f"{m}.{k}" for m in names for k in ("weight", "bias")]
+
+    @property
+    def param_shapes(self) -> dict:
+        W, Wc, P, V = self.netwidth, self.netwidth_condition, self.pos_size, self.view_pos_size
+        out = {}
+        for l in range(self.netdepth):
+            out[f"pts_linears.{l}.weight"] = (W, P if l == 0 else (W + P if self.cat_before(l) else W))
+            out[f"pts_linears.{l}.bias"] = (W,)
+        for i in range(self.netdepth_condition):
+            out[f"views_linear.{i}.weight"] = (Wc, W + V if i == 0 else Wc)
+            out[f"views_linear.{i}.bias"] = (Wc,)
+        out.update({"bottleneck_layer.weight": (W, W), "bottleneck_layer.bias": (W,),
+                    "density_layer.weight": (self.num_density_channels, W), "density_layer.bias": (self.num_density_channels,),
+                    "rgb_layer.weight": (self.num_rgb_channels, Wc), "rgb_layer.bias": (self.num_rgb_channels,)})
+        return out
+
+
+def _gmlp_param_array(geom: MlpGeometry, params: dict):
+    shapes = geom.param_shapes
+    tensors = []
+    for name in geom.param_order:
+        t = _f32(params[name].detach(), name)
+        if tuple(t.shape) != shapes[name]:
+            raise ValueError(f"{name}: shape {tuple(t.shape)} != {shapes[name]} for NeRFMLP geometry {geom.as_tuple()}")
+        tensors.append(t)
+    return tensors, (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+
+def gmlp_fwd(geom: MlpGeometry, params: dict, samples_enc, viewdirs_enc):
+    """NeRFMLP.forward(x, condition) for any geometry -> (raw_rgb (n,S,C_rgb), raw_density (n,S,C_density))."""
+    x, c = _f32(samples_enc, "samples_enc"), _f32(viewdirs_enc, "viewdirs_enc")
+    n, S, F = x.shape
+    if F != geom.pos_size or tuple(c.shape) != (n, geom.view_pos_size):
+        raise ValueError(f"expected samples_enc (n,S,{geom.pos_size}) and viewdirs_enc (n,{geom.view_pos_size})")
+    tensors, arr = _gmlp_param_array(geom, params)
+    st = geom.c_struct()
+    dev = x.device
+    rgb = torch.empty((n, S, geom.num_rgb_channels), dtype=torch.float32, device=dev)
+    dens = torch.empty((n, S, geom.num_density_channels), dtype=torch.float32, device=dev)
+    ws = _sized(int(lib.aon_gmlp_workspace_bytes(C.byref(st), n * S)), "aon_gmlp_workspace_bytes", dev)
+    with torch.cuda.device(dev):
+        check(lib.aon_gmlp_fwd(C.byref(st), arr, _ptr(x), _ptr(c), n, S, _ptr(rgb), _ptr(dens), _ptr(ws), ws.numel(), _stream()), "aon_gmlp_fwd")
+    return rgb, dens
+
+
+# rays per internal chunk of the layer-wise engine: its activations live in HBM (~ (P + 3 W + 2 Wc) * 4 B per sample)
+G_CHUNK_RAYS = 16384
+_GWS_CACHE: dict = {}
+
+
+def grender_fwd(geom: MlpGeometry, params_c: dict, params_f, rays_o, rays_d, viewdirs, near, far, white_bkgd, num_levels=2, t_rand=None, u=None,
+                opts=None, noise=None):
+    """NeRF.forward with a NeRFMLP of any geometry (aon_grender_fwd)."""
+    o, d, v = _f32(rays_o, "rays_o"), _f32(rays_d, "rays_d"), _f32(viewdirs, "viewdirs")
+    n, dev = o.shape[0], o.device
+    op = _opts(opts)
+    tr = None if t_rand is None else _f32(t_rand, "t_rand")
+    if tr is not None and tuple(tr.shape) != (n, op.Sc):
+        raise ValueError(f"t_rand must be ({n},{op.Sc})")
+    uu, us = _u_args(u, n, dev, op.num_fine_samples) if num_levels == 2 else (None, 0)
+    outs, fine = _level_outs(n, dev, num_levels)
+    st, keep = op.c_struct(near, far, _check_noise(noise, n, op, num_levels))
+    gst = geom.c_struct()
+    tc, arr_c = _gmlp_param_array(geom, params_c)
+    tf, arr_f = _gmlp_param_array(geom, params_f) if num_levels == 2 else (None, None)
+    need = int(lib.aon_grender_workspace_bytes(C.byref(gst), max(1, min(n, G_CHUNK_RAYS)), C.byref(st)))
+    if need < 0:
+        check(need, "aon_grender_workspace_bytes")
+    key = str(dev)
+    ws = _GWS_CACHE.get(key)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        _GWS_CACHE[key] = ws
+    with torch.cuda.device(dev):
+        check(lib.aon_grender_fwd(C.byref(gst), arr_c, arr_f, _ptr(o), _ptr(d), _ptr(v), n, float(near), float(far), int(bool(white_bkgd)), num_levels,
+                                  _ptr(tr), _ptr(uu), us, _ptr(outs[0][0]), _ptr(outs[0][1]), _ptr(outs[0][2]), _ptr(fine[0]), _ptr(fine[1]),
+                                  _ptr(fine[2]), _ptr(ws), ws.numel(), _stream(), C.byref(st)), "aon_grender_fwd")
+    return outs
+
+
+def grender_fwd_train(geom: MlpGeometry, params_c: dict, params_f, rays_o, rays_d, viewdirs, near, far, white_bkgd, num_levels, t_rand, u,
+                      opts=None, noise=None):
+    """-> (outs, workspace, geometry): the forward of a training step; the workspace carries every layer's output to the backward."""
+    o, d, v = _f32(rays_o, "rays_o"), _f32(rays_d, "rays_d"), _f32(viewdirs, "viewdirs")
+    n, dev = o.shape[0], o.device
+    op = _opts(opts)
+    tr = None if t_rand is None else _f32(t_rand, "t_rand")
+    if tr is not None and tuple(tr.shape) != (n, op.Sc):
+        raise ValueError(f"t_rand must be ({n},{op.Sc})")
+    uu, us = _u_args(u, n, dev, op.num_fine_samples) if num_levels == 2 else (None, 0)
+    outs, fine = _level_outs(n, dev, num_levels)
+    st, keep = op.c_struct(near, far, _check_noise(noise, n, op, num_levels))
+    gst = geom.c_struct()
+    tc, arr_c = _gmlp_param_array(geom, params_c)
+    tf, arr_f = _gmlp_param_array(geom, params_f) if num_levels == 2 else (None, None)
+    ws = _sized(int(lib.aon_grender_train_workspace_bytes(C.byref(gst), n, num_levels, C.byref(st))), "aon_grender_train_workspace_bytes", dev)
+    with torch.cuda.device(dev):
+        check(lib.aon_grender_fwd_train(C.byref(gst), arr_c, arr_f, _ptr(o), _ptr(d), _ptr(v), n, float(near), float(far), int(bool(white_bkgd)),
+                                        num_levels, _ptr(tr), _ptr(uu), us, _ptr(outs[0][0]), _ptr(outs[0][1]), _ptr(outs[0][2]), _ptr(fine[0]),
+                                        _ptr(fine[1]), _ptr(fine[2]), _ptr(ws), ws.numel(), _stream(), C.byref(st)), "aon_grender_fwd_train")
+    return outs, ws, (st, keep, uu)
+
+
+def grender_bwd(geom: MlpGeometry, ws, params_per_level, rays_d, white_bkgd, num_levels, g_rgb, g_acc, g_depth, geometry):
+    """loss.backward() through grender_fwd_train -> per-level dicts of parameter gradients."""
+    d = _f32(rays_d, "rays_d")
+    n, dev = d.shape[0], d.device
+    gst = geom.c_struct()
+    shapes, order = geom.param_shapes, geom.param_order
+    grads = [{name: torch.empty(shapes[name], dtype=torch.float32, device=dev) for name in order} for _ in range(num_levels)]
+    garr = [_ptr_array([g[nm] for nm in order]) for g in grads] + [None] * (2 - num_levels)
+    tens, parr = [], []
+    for params in params_per_level:
+        t, arr = _gmlp_param_array(geom, params)
+        tens.append(t)
+        parr.append(arr)
+    parr += [None] * (2 - num_levels)
+    keep = [None if t is None else _f32(t, "grad") for t in list(g_rgb) + list(g_acc) + list(g_depth)]
+    k = num_levels
+    st = geometry[0]
+    scratch = _sized(int(lib.aon_grender_train_scratch_bytes(C.byref(gst), n, num_levels, C.byref(st))), "aon_grender_train_scratch_bytes", dev)
+    with torch.cuda.device(dev):
+        check(lib.aon_grender_bwd(C.byref(gst), parr[0], parr[1], _ptr(d), n, int(bool(white_bkgd)), num_levels, _ptr_array(keep[:k]),
+                                  _ptr_array(keep[k:2 * k]), _ptr_array(keep[2 * k:3 * k]), garr[0], garr[1], _ptr(ws), ws.numel(), _ptr(scratch),
+                                  scratch.numel(), _stream(), C.byref(st)), "aon_grender_bwd")
+    return grads
+
+
 # ------------------------------------------------------------------ measurement aid
 def profile_begin() -> None:
     check(lib.aon_profile_begin(), "aon_profile_begin")

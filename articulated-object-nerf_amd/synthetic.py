@@ -90,6 +90,37 @@ def make_nerf_state_dict(seed: int = 0, density_scale: float = 30.0, **layout_kw
     return sd
 
 
+def general_mlp_layout(min_deg_point=0, max_deg_point=10, deg_view=4, netdepth=8, netwidth=256, netdepth_condition=1,
+                       netwidth_condition=128, skip_layer=4, input_ch=3, input_ch_view=3, num_rgb_channels=3, num_density_channels=1):
+    """Layer list of NeRFMLP(...) for ANY constructor arguments (model.py:40-93), in the module's parameter order."""
+    pos_size = ((max_deg_point - min_deg_point) * 2 + 1) * input_ch
+    view_pos_size = (deg_view * 2 + 1) * input_ch_view
+    layout = [("pts_linears.0", netwidth, pos_size, "xavier")]
+    for idx in range(netdepth - 1):
+        fan_in = netwidth + pos_size if (idx % skip_layer == 0 and idx > 0) else netwidth
+        layout.append((f"pts_linears.{idx + 1}", netwidth, fan_in, "xavier"))
+    layout.append(("views_linear.0", netwidth_condition, netwidth + view_pos_size, "kaiming"))
+    layout += [(f"views_linear.{i}", netwidth_condition, netwidth_condition, "xavier") for i in range(1, netdepth_condition)]
+    layout.append(("bottleneck_layer", netwidth, netwidth, "xavier"))
+    layout.append(("density_layer", num_density_channels, netwidth, "xavier"))
+    layout.append(("rgb_layer", num_rgb_channels, netwidth_condition, "xavier"))
+    return layout
+
+
+def make_general_nerf_state_dict(seed: int, density_scale: float = 2.0, density_bias: float = 0.75, prefixes=("coarse_mlp", "fine_mlp"), **geometry):
+    """Smooth-field weights (see make_smooth_nerf_state_dict) for a NeRFMLP of any geometry; keys '<prefix>.<name>' (or bare names
+    with prefixes=("",))."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    layout = general_mlp_layout(**geometry)
+    sd = OrderedDict()
+    for prefix in prefixes:
+        for k, v in make_mlp_state(rng, layout, density_scale).items():
+            if k == "density_layer.bias":
+                v = v + density_bias
+            sd[f"{prefix}.{k}" if prefix else k] = v
+    return sd
+
+
 # articulated NeRFMLP (models/vanilla_nerf/model_autodecoder.py:60-170, default geometry)
 def make_smooth_nerf_state_dict(seed: int = 5, density_scale: float = 2.0, density_bias: float = 0.75):
     """A "trained-like" smooth field for tight end-to-end parity (density x1-3 instead of the x30 of the

@@ -347,6 +347,53 @@ int aon_art_render_bwd_ex(const void* packed_bwd_coarse, const void* small_coars
                           void* workspace, int64_t workspace_bytes, void* scratch, int64_t scratch_bytes, void* stream,
                           const aon_render_opts* opts);
 
+/* ---- NeRFMLP of ANY constructor geometry (models/vanilla_nerf/model.py:40-120), round 3 ----
+ * The entry points above run the reference's default NeRFMLP (8 x 256, skip 4, 1 x 128, degrees 10 / 4) on fused kernels compiled
+ * for it.  Every other geometry runs here: layer-wise fp32 MFMA GEMMs on the unmodified nn.Linear storages (csrc/aon_gmlp.hip).
+ * aon_mlp_geometry mirrors NeRFMLP.__init__'s arguments (model.py:40-54); pos_size = ((max_deg_point - min_deg_point) * 2 + 1) *
+ * input_ch, view_pos_size = (deg_view * 2 + 1) * input_ch_view.  params: HOST array of 2 * (netdepth + netdepth_condition + 3)
+ * DEVICE pointers: pts_linears.{0..netdepth-1}.{weight,bias}, views_linear.{0..netdepth_condition-1}.{weight,bias},
+ * bottleneck_layer.{w,b}, density_layer.{w,b}, rgb_layer.{w,b} (the vanilla order for the default depths).
+ * A geometry whose LAST trunk layer would concatenate the encoding (netdepth - 1 > 0 and (netdepth - 1) % skip_layer == 0) is
+ * rejected: the reference's own forward fails on it (density_layer is built for netwidth inputs, model.py:90 vs :103-104).
+ *   aon_gmlp_fwd            NeRFMLP.forward(x, condition): samples_enc (n,S,pos_size), viewdirs_enc (n,view_pos_size) ->
+ *                           raw_rgb (n*S, num_rgb_channels), raw_density (n*S, num_density_channels)
+ *   aon_grender_fwd         NeRF.forward (model.py:147-199) with this NeRFMLP at both levels and the sampler options of
+ *                           aon_render_opts; needs input_ch = input_ch_view = 3, 3 rgb channels, 1 density channel.  Chunked
+ *                           internally to the workspace given (>= aon_grender_workspace_bytes(geom, 1, opts)).
+ *   aon_grender_fwd_train / aon_grender_bwd   the training step in two calls, as aon_render_fwd_train / aon_render_bwd: the
+ *                           forward keeps every layer's output in `workspace` (aon_grender_train_workspace_bytes), the backward
+ *                           writes all parameter gradients per level (order and shapes of `params`, overwritten); its
+ *                           temporaries live in `scratch` (aon_grender_train_scratch_bytes).  Deterministic (no atomics). */
+typedef struct aon_mlp_geometry {
+  int32_t min_deg_point, max_deg_point, deg_view;
+  int32_t netdepth, netwidth, netdepth_condition, netwidth_condition, skip_layer;
+  int32_t input_ch, input_ch_view, num_rgb_channels, num_density_channels;
+} aon_mlp_geometry;
+void aon_mlp_geometry_init(aon_mlp_geometry* geom);   /* (0, 10, 4, 8, 256, 1, 128, 4, 3, 3, 3, 1) */
+int aon_gmlp_param_count(const aon_mlp_geometry* geom);   /* number of pointers in `params`, or a negative status */
+int64_t aon_gmlp_workspace_bytes(const aon_mlp_geometry* geom, int64_t n_samples);
+int aon_gmlp_fwd(const aon_mlp_geometry* geom, const float* const* params_host, const float* samples_enc, const float* viewdirs_enc,
+                 int64_t n_rays, int S, float* raw_rgb, float* raw_density, void* workspace, int64_t workspace_bytes, void* stream);
+int64_t aon_grender_workspace_bytes(const aon_mlp_geometry* geom, int64_t n_rays, const aon_render_opts* opts);
+int aon_grender_fwd(const aon_mlp_geometry* geom, const float* const* params_coarse_host, const float* const* params_fine_host,
+                    const float* rays_o, const float* rays_d, const float* viewdirs, int64_t n_rays, float near_, float far_,
+                    int white_bkgd, int num_levels, const float* t_rand, const float* u, int64_t u_stride, float* rgb_c, float* acc_c,
+                    float* depth_c, float* rgb_f, float* acc_f, float* depth_f, void* workspace, int64_t workspace_bytes, void* stream,
+                    const aon_render_opts* opts);
+int64_t aon_grender_train_workspace_bytes(const aon_mlp_geometry* geom, int64_t n_rays, int num_levels, const aon_render_opts* opts);
+int64_t aon_grender_train_scratch_bytes(const aon_mlp_geometry* geom, int64_t n_rays, int num_levels, const aon_render_opts* opts);
+int aon_grender_fwd_train(const aon_mlp_geometry* geom, const float* const* params_coarse_host, const float* const* params_fine_host,
+                          const float* rays_o, const float* rays_d, const float* viewdirs, int64_t n_rays, float near_, float far_,
+                          int white_bkgd, int num_levels, const float* t_rand, const float* u, int64_t u_stride, float* rgb_c,
+                          float* acc_c, float* depth_c, float* rgb_f, float* acc_f, float* depth_f, void* workspace,
+                          int64_t workspace_bytes, void* stream, const aon_render_opts* opts);
+int aon_grender_bwd(const aon_mlp_geometry* geom, const float* const* params_coarse_host, const float* const* params_fine_host,
+                    const float* rays_d, int64_t n_rays, int white_bkgd, int num_levels, const float* const* g_rgb_host,
+                    const float* const* g_acc_host, const float* const* g_depth_host, float* const* grads_coarse_host,
+                    float* const* grads_fine_host, void* workspace, int64_t workspace_bytes, void* scratch, int64_t scratch_bytes,
+                    void* stream, const aon_render_opts* opts);
+
 /* ---- measurement aid (no reference counterpart) ----
  * Between aon_profile_begin() and aon_profile_end() every launch of the path's kernels made through this library is
  * bracketed by HIP events recorded on the LAUNCH stream, by kernel class.  aon_profile_end() waits for those events

@@ -536,6 +536,61 @@ def main():
             arrs[f"{tag}_{name}_rgb"], arrs[f"{tag}_{name}_acc"], arrs[f"{tag}_{name}_depth"] = out[lvl]
     save("g16_ctor_options", **arrs)
 
+    # ---------------- G17 NeRFMLP / NeRF of non-default geometry (round 3: the layer-wise engine) ----------------
+    from models.vanilla_nerf.model import NeRFMLP
+    arrs = {}
+    MLP_GEOMS = {   # NeRFMLP.__init__ keyword arguments
+        "a": dict(min_deg_point=0, max_deg_point=4, deg_view=2, netdepth=4, netwidth=128, netdepth_condition=2, netwidth_condition=64, skip_layer=2),
+        "b": dict(min_deg_point=1, max_deg_point=7, deg_view=3, netdepth=6, netwidth=192, netdepth_condition=3, netwidth_condition=96, skip_layer=3),
+        "c": dict(min_deg_point=0, max_deg_point=3, deg_view=1, netdepth=3, netwidth=100, netdepth_condition=1, netwidth_condition=40, skip_layer=4,
+                  input_ch=2, input_ch_view=4, num_rgb_channels=5, num_density_channels=2),
+        "d": dict(min_deg_point=-2, max_deg_point=12, deg_view=6, netdepth=2, netwidth=320, netdepth_condition=1, netwidth_condition=128, skip_layer=4),
+    }
+    g17 = torch.Generator().manual_seed(1717)
+    for tag, kw in MLP_GEOMS.items():
+        sdm = syn.make_general_nerf_state_dict(1700 + ord(tag), prefixes=("",), **kw)
+        mlp = NeRFMLP(**kw)
+        mlp.load_state_dict(sdm, strict=True)
+        P = ((kw["max_deg_point"] - kw["min_deg_point"]) * 2 + 1) * kw.get("input_ch", 3)
+        V = (kw["deg_view"] * 2 + 1) * kw.get("input_ch_view", 3)
+        xe = torch.rand((7, 19, P), generator=g17) * 2 - 1
+        ve = torch.rand((7, V), generator=g17) * 2 - 1
+        with torch.no_grad():
+            rr, dd = mlp(xe, ve)
+        arrs.update({f"mlp_{tag}_geom": np.asarray([kw.get(k, d) for k, d in zip(
+            ("min_deg_point", "max_deg_point", "deg_view", "netdepth", "netwidth", "netdepth_condition", "netwidth_condition", "skip_layer",
+             "input_ch", "input_ch_view", "num_rgb_channels", "num_density_channels"), (0, 10, 4, 8, 256, 1, 128, 4, 3, 3, 3, 1))]),
+            f"mlp_{tag}_x": xe, f"mlp_{tag}_v": ve, f"mlp_{tag}_rgb": rr, f"mlp_{tag}_density": dd})
+    arrs["mlp_tags"] = np.asarray([ord(t) for t in MLP_GEOMS])
+    # whole path: NeRF(min_deg_point, max_deg_point, deg_view) -- the only NeRFMLP arguments NeRF.__init__ forwards (model.py:144-145)
+    NERF_CFGS = {"p": dict(min_deg_point=0, max_deg_point=6, deg_view=2),
+                 "q": dict(min_deg_point=1, max_deg_point=12, deg_view=5, num_coarse_samples=24, num_fine_samples=40, lindisp=True)}
+    N17 = 192
+    rays_g = {k: v[::5][:N17].contiguous() for k, v in frame_s.items()}
+    arrs.update({"nerf_" + k: v for k, v in rays_g.items()})
+    for tag, kw in NERF_CFGS.items():
+        gk = {k: kw[k] for k in ("min_deg_point", "max_deg_point", "deg_view")}
+        sdn = syn.make_general_nerf_state_dict(1750 + ord(tag), **gk)
+        mdl = NeRF(**kw)
+        mdl.load_state_dict(sdn, strict=True)
+        mdl.eval()
+        nc, nf = kw.get("num_coarse_samples", 64), kw.get("num_fine_samples", 128)
+        tr17, u17 = syn.seeded_uniform(1760 + ord(tag), N17, nc + 1), syn.seeded_uniform(1770 + ord(tag), N17, nf)
+        with torch.no_grad():
+            od = mdl(rays_g, False, True, 2.0, 6.0)
+            with patched_rand([tr17, u17]):
+                orn = mdl(rays_g, True, False, 2.0, 6.0)
+        _, axd = orc.nerf_forward(sdn, rays_g, False, True, 2.0, 6.0, return_aux=True, num_coarse_samples=nc, num_fine_samples=nf,
+                                  lindisp=kw.get("lindisp", False), **gk)
+        _, axr = orc.nerf_forward(sdn, rays_g, True, False, 2.0, 6.0, t_rand=tr17, u=u17, return_aux=True, num_coarse_samples=nc,
+                                  num_fine_samples=nf, lindisp=kw.get("lindisp", False), **gk)
+        arrs[f"nerf_{tag}_cfg"] = np.asarray([gk["min_deg_point"], gk["max_deg_point"], gk["deg_view"], nc, nf, int(kw.get("lindisp", False))])
+        arrs[f"nerf_{tag}_margin"] = torch.stack([a["raw_sigma"][:, -1, 0].abs() for a in axd + axr]).min(0).values
+        for t2, out in (("det", od), ("rnd", orn)):
+            for lvl, name in ((0, "coarse"), (1, "fine")):
+                arrs[f"nerf_{tag}_{t2}_{name}_rgb"], arrs[f"nerf_{tag}_{t2}_{name}_acc"], arrs[f"nerf_{tag}_{t2}_{name}_depth"] = out[lvl]
+    save("g17_general_mlp", **arrs)
+
     # ---------------- G13 metrics ----------------
     a = torch.rand((5, 16, 16, 3), generator=g) * 1.2 - 0.1
     b = torch.rand((5, 16, 16, 3), generator=g)

@@ -1,0 +1,214 @@
+"""GPU: NeRFMLP / NeRF of non-default constructor geometry on the layer-wise MFMA GEMM engine (csrc/aon_gmlp.hip) against G17 --
+outputs of the REAL reference's NeRFMLP(...) / NeRF(min_deg_point, max_deg_point, deg_view, ...) -- against the fused kernels
+where both exist (the default geometry), and against the oracle's autograd for the training step."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import nerf_oracle as orc  # noqa: E402  (checker only)
+
+GEOM_KEYS = ("min_deg_point", "max_deg_point", "deg_view", "netdepth", "netwidth", "netdepth_condition", "netwidth_condition", "skip_layer",
+             "input_ch", "input_ch_view", "num_rgb_channels", "num_density_channels")
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return torch.device("cuda:0")
+
+
+def test_gemm_layers_against_fp64(dev):
+    """The GEMM kernel alone through aon_gmlp_fwd on a one-layer-deep network with ragged sizes: every output against an fp64
+    evaluation (tile edges in M, N and K; unaligned rows; the two-segment view layer with the per-ray condition row)."""
+    import aon_amd.synthetic as syn
+    from aon_amd import ops
+
+    for kw, n, S in ((dict(max_deg_point=1, deg_view=0, netdepth=1, netwidth=5, netwidth_condition=3), 3, 7),
+                     (dict(max_deg_point=5, deg_view=1, netdepth=2, netwidth=131, netwidth_condition=257, netdepth_condition=2), 5, 53),
+                     (dict(max_deg_point=10, deg_view=4, netdepth=3, netwidth=256, netwidth_condition=128, skip_layer=2, netdepth_condition=1), 9, 129)):
+        geom = ops.MlpGeometry(**kw)
+        sd = syn.make_general_nerf_state_dict(11, prefixes=("",), **kw)
+        gen = torch.Generator().manual_seed(3)
+        x = torch.rand((n, S, geom.pos_size), generator=gen) * 2 - 1
+        v = torch.rand((n, geom.view_pos_size), generator=gen) * 2 - 1
+        rgb, dens = ops.gmlp_fwd(geom, {k: t.to(dev) for k, t in sd.items()}, x.to(dev), v.to(dev))
+        sd64 = {k: t.double() for k, t in sd.items()}
+        r64, d64 = orc.nerf_mlp(sd64, "", x.double(), v.double(), skip_layer=geom.skip_layer)
+        torch.testing.assert_close(rgb.cpu().double(), r64, rtol=0, atol=5e-6)
+        torch.testing.assert_close(dens.cpu().double(), d64, rtol=0, atol=2e-5)
+
+
+def test_general_mlp_against_the_reference(dev, golden):
+    import aon_amd.synthetic as syn
+    from aon_amd.models.vanilla_nerf.model import NeRFMLP
+
+    g = golden("g17_general_mlp")
+    for code in g["mlp_tags"].tolist():
+        tag = chr(code)
+        kw = dict(zip(GEOM_KEYS, g[f"mlp_{tag}_geom"].tolist()))
+        mlp = NeRFMLP(**kw).to(dev)
+        mlp.load_state_dict(syn.make_general_nerf_state_dict(1700 + code, prefixes=("",), **kw))
+        with torch.no_grad():
+            rgb, dens = mlp(g[f"mlp_{tag}_x"].to(dev), g[f"mlp_{tag}_v"].to(dev))
+        torch.testing.assert_close(rgb.cpu(), g[f"mlp_{tag}_rgb"], rtol=1e-5, atol=1e-5)
+        torch.testing.assert_close(dens.cpu(), g[f"mlp_{tag}_density"], rtol=1e-5, atol=2e-5)
+
+
+def test_general_engine_equals_the_fused_kernels_on_the_default_geometry(dev, golden):
+    """Both engines exist for NeRFMLP(0, 10, 4): the layer-wise one must agree with the fused kernel to summation-order level
+    (G4: the reference's raw outputs) -- and, whole path, with the fused path's render of a smooth field."""
+    import aon_amd.synthetic as syn
+    from aon_amd import ops
+
+    g = golden("g4_mlp")
+    sd = syn.make_nerf_state_dict(seed=0, density_scale=30.0)
+    geom = ops.MlpGeometry()
+    for lvl in ("coarse", "fine"):
+        params = {k[len(lvl) + 5:]: v.to(dev) for k, v in sd.items() if k.startswith(lvl)}
+        rgb, dens = ops.gmlp_fwd(geom, params, g["samples_enc"].to(dev), g["viewdirs_enc"].to(dev))
+        torch.testing.assert_close(rgb.cpu(), g[f"raw_rgb_{lvl}"], rtol=0, atol=2e-5)
+        torch.testing.assert_close(dens.cpu(), g[f"raw_sigma_{lvl}"], rtol=0, atol=2e-4)
+    g15 = golden("g15_smooth")
+    sds = syn.make_smooth_nerf_state_dict()
+    rays = {k: g15[k][:256].to(dev) for k in ("rays_o", "rays_d", "viewdirs")}
+    pc = {k[11:]: v.to(dev) for k, v in sds.items() if k.startswith("coarse_mlp.")}
+    pf = {k[9:]: v.to(dev) for k, v in sds.items() if k.startswith("fine_mlp.")}
+    outs = ops.grender_fwd(geom, pc, pf, rays["rays_o"], rays["rays_d"], rays["viewdirs"], 2.0, 6.0, True)
+    for lvl, name in ((0, "coarse"), (1, "fine")):
+        torch.testing.assert_close(outs[lvl][0].cpu(), g15[f"van_det_{name}_rgb"][:256], rtol=0, atol=2e-6)
+        torch.testing.assert_close(outs[lvl][2].cpu(), g15[f"van_det_{name}_depth"][:256], rtol=0, atol=1e-5)
+
+
+def test_nerf_with_other_degrees_end_to_end(dev, golden):
+    import aon_amd.synthetic as syn
+    from aon_amd.models.vanilla_nerf.model import NeRF
+
+    g = golden("g17_general_mlp")
+    rays = {k: g["nerf_" + k].to(dev) for k in ("rays_o", "rays_d", "viewdirs")}
+    n = rays["rays_o"].shape[0]
+    for tag, (drgb, ddepth) in {"p": (2e-6, 2e-5), "q": (2e-5, 5e-4)}.items():   # q: 2^11 frequencies, a far less smooth field
+        mn, mx, dv, nc, nf, lind = g[f"nerf_{tag}_cfg"].tolist()
+        model = NeRF(min_deg_point=mn, max_deg_point=mx, deg_view=dv, num_coarse_samples=nc, num_fine_samples=nf, lindisp=bool(lind)).to(dev)
+        model.load_state_dict(syn.make_general_nerf_state_dict(1750 + ord(tag), min_deg_point=mn, max_deg_point=mx, deg_view=dv))
+        ok = g[f"nerf_{tag}_margin"] > 0.05     # far-plane raw sigma robustly signed (helper.py:163), as on the sharp fixtures
+        assert ok.float().mean() > 0.7
+        tr, u = syn.seeded_uniform(1760 + ord(tag), n, nc + 1).to(dev), syn.seeded_uniform(1770 + ord(tag), n, nf).to(dev)
+        with torch.no_grad():
+            outs = {"det": model(rays, False, True, 2.0, 6.0), "rnd": model(rays, True, False, 2.0, 6.0, t_rand=tr, u=u)}
+        for t2, out in outs.items():
+            for lvl, name in ((0, "coarse"), (1, "fine")):
+                rgb, acc, depth = (x.cpu() for x in out[lvl])
+                torch.testing.assert_close(rgb[ok], g[f"nerf_{tag}_{t2}_{name}_rgb"][ok], rtol=0, atol=drgb)
+                torch.testing.assert_close(acc[ok], g[f"nerf_{tag}_{t2}_{name}_acc"][ok], rtol=0, atol=drgb)
+                torch.testing.assert_close(depth[ok], g[f"nerf_{tag}_{t2}_{name}_depth"][ok], rtol=0, atol=ddepth)
+
+
+def test_general_engine_chunking_is_invisible(dev):
+    """A workspace smaller than the batch makes aon_grender_fwd walk ray chunks: same bits as one pass."""
+    import aon_amd.synthetic as syn
+    from aon_amd import ops
+    from aon_amd.models.vanilla_nerf.model import NeRF
+
+    kw = dict(min_deg_point=0, max_deg_point=5, deg_view=2)
+    model = NeRF(**kw).to(dev)
+    model.load_state_dict(syn.make_general_nerf_state_dict(21, **kw))
+    frame = syn.make_rays(20, 24, syn.look_at_pose(4.0, 60, 20), syn.focal_from_fovy(20))
+    rays = {k: v.to(dev) for k, v in frame.items()}
+    with torch.no_grad():
+        one = model(rays, False, True, 2.0, 6.0)
+        old = ops.G_CHUNK_RAYS
+        try:
+            ops.G_CHUNK_RAYS = 100
+            ops._GWS_CACHE.clear()
+            many = model(rays, False, True, 2.0, 6.0)
+        finally:
+            ops.G_CHUNK_RAYS = old
+            ops._GWS_CACHE.clear()
+    for lvl in (0, 1):
+        for a, b in zip(one[lvl], many[lvl]):
+            assert torch.equal(a, b)
+
+
+def test_training_step_on_the_general_engine(dev):
+    """loss.backward() through NeRF(min_deg_point, max_deg_point, deg_view, ...) against the oracle's autograd, every parameter;
+    a second identical step gives identical gradients (no atomics)."""
+    import aon_amd.synthetic as syn
+    from aon_amd.models.vanilla_nerf.model import NeRF
+
+    kw = dict(min_deg_point=0, max_deg_point=6, deg_view=2)
+    n, nc, nf = 200, 40, 56
+    sd = syn.make_general_nerf_state_dict(31, **kw)
+    model = NeRF(num_coarse_samples=nc, num_fine_samples=nf, noise_std=0.2, **kw).to(dev)
+    model.load_state_dict(sd)
+    frame = syn.make_rays(24, 32, syn.look_at_pose(4.0, 60, 20), syn.focal_from_fovy(24))
+    rays_cpu = {k: v[::3][:n].contiguous() for k, v in frame.items()}
+    rays = {k: v.to(dev) for k, v in rays_cpu.items()}
+    target = syn.seeded_uniform(32, n, 3)
+    tr, u = syn.seeded_uniform(33, n, nc + 1), syn.seeded_uniform(34, n, nf)
+    nz = [syn.seeded_uniform(35, n, nc + 1), syn.seeded_uniform(36, n, nc + 1 + nf)]
+
+    def step():
+        model.zero_grad()
+        out = model(rays, True, True, 2.0, 6.0, t_rand=tr.to(dev), u=u.to(dev), noise=[z.to(dev) for z in nz])
+        loss = ((out[0][0] - target.to(dev)) ** 2).mean() + ((out[1][0] - target.to(dev)) ** 2).mean()
+        loss.backward()
+        return loss.item(), {k: p.grad.clone() for k, p in model.named_parameters()}
+
+    loss, grads = step()
+    loss2, grads2 = step()
+    assert loss == loss2 and all(torch.equal(grads[k], grads2[k]) for k in grads)
+    sd_r = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ref = orc.nerf_forward(sd_r, rays_cpu, True, True, 2.0, 6.0, t_rand=tr, u=u, num_coarse_samples=nc, num_fine_samples=nf, noise_std=0.2,
+                           noise=nz, **kw)
+    loss_r = ((ref[0][0] - target) ** 2).mean() + ((ref[1][0] - target) ** 2).mean()
+    loss_r.backward()
+    assert abs(loss - loss_r.item()) < 2e-6
+    worst = {}
+    for name in grads:
+        r = sd_r[name].grad
+        lvl = "coarse" if name.startswith("coarse") else "fine"
+        e = ((grads[name].cpu().double() - r.double()).norm() / r.double().norm().clamp_min(1e-12)).item()
+        worst[lvl] = max(worst.get(lvl, 0.0), e)
+    assert worst["coarse"] < 2e-4 and worst["fine"] < 5e-3, worst
+
+
+def test_general_mlp_gradients_deep_geometry(dev):
+    """The backward of a geometry with a skip concatenation, a three-layer view branch and widths off the tile grid, through the
+    whole path with one level: every parameter gradient against the oracle's autograd."""
+    import aon_amd.synthetic as syn
+    from aon_amd import ops
+    from aon_amd.autograd import RenderGeneral
+
+    kw = dict(min_deg_point=0, max_deg_point=4, deg_view=2, netdepth=6, netwidth=136, netdepth_condition=3, netwidth_condition=72, skip_layer=3)
+    geom = ops.MlpGeometry(**kw)
+    sd = syn.make_general_nerf_state_dict(41, prefixes=("coarse_mlp",), **kw)
+    n, nc = 150, 30
+    frame = syn.make_rays(24, 32, syn.look_at_pose(4.0, 60, 20), syn.focal_from_fovy(24))
+    rays_cpu = {k: v[::5][:n].contiguous() for k, v in frame.items()}
+    target = syn.seeded_uniform(42, n, 3)
+    params = [sd[f"coarse_mlp.{nm}"].to(dev).requires_grad_(True) for nm in geom.param_order]
+    flat = RenderGeneral.apply(rays_cpu["rays_o"].to(dev), rays_cpu["rays_d"].to(dev), rays_cpu["viewdirs"].to(dev), 2.0, 6.0, True, 1, None, None,
+                               geom, ops.RenderOpts(num_coarse_samples=nc), None, *params)
+    loss = ((flat[0] - target.to(dev)) ** 2).mean()
+    loss.backward()
+    sd_r = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ref = orc.nerf_forward(sd_r, rays_cpu, False, True, 2.0, 6.0, num_levels=1, num_coarse_samples=nc, skip_layer=3,
+                           min_deg_point=0, max_deg_point=4, deg_view=2)
+    loss_r = ((ref[0][0] - target) ** 2).mean()
+    loss_r.backward()
+    assert abs(loss.item() - loss_r.item()) < 2e-6
+    for nm, p in zip(geom.param_order, params):
+        r = sd_r[f"coarse_mlp.{nm}"].grad
+        e = ((p.grad.cpu().double() - r.double()).norm() / r.double().norm().clamp_min(1e-12)).item()
+        assert e < 2e-4, (nm, e)
+
+
+def test_invalid_geometry_is_rejected():
+    from aon_amd._lib import AonError
+    from aon_amd.models.vanilla_nerf.model import NeRFMLP
+
+    with pytest.raises(AonError, match="last trunk layer"):
+        NeRFMLP(0, 10, 4, netdepth=5, skip_layer=4)     # the reference's forward raises on this one too (257 != 256 + 63 inputs)
+    NeRFMLP(0, 10, 4, netdepth=6, skip_layer=4)

@@ -278,3 +278,36 @@ def test_g16_whole_path_with_options(golden):
             torch.testing.assert_close(out[lvl][0], g[f"{tag}_{name}_rgb"], rtol=0, atol=2e-6)
             torch.testing.assert_close(out[lvl][1], g[f"{tag}_{name}_acc"], rtol=0, atol=2e-6)
             torch.testing.assert_close(out[lvl][2], g[f"{tag}_{name}_depth"], rtol=0, atol=2e-5)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# G17: NeRFMLP / NeRF of non-default geometry (the reference's constructors with other arguments)
+# ---------------------------------------------------------------------------------------------------------------------
+GEOM_KEYS = ("min_deg_point", "max_deg_point", "deg_view", "netdepth", "netwidth", "netdepth_condition", "netwidth_condition", "skip_layer",
+             "input_ch", "input_ch_view", "num_rgb_channels", "num_density_channels")
+
+
+def test_g17_general_mlp(golden):
+    import aon_amd.synthetic as syn
+
+    g = golden("g17_general_mlp")
+    for code in g["mlp_tags"].tolist():
+        tag = chr(code)
+        kw = dict(zip(GEOM_KEYS, g[f"mlp_{tag}_geom"].tolist()))
+        sd = syn.make_general_nerf_state_dict(1700 + code, prefixes=("",), **kw)
+        rgb, dens = orc.nerf_mlp(sd, "", g[f"mlp_{tag}_x"], g[f"mlp_{tag}_v"], skip_layer=kw["skip_layer"])
+        torch.testing.assert_close(rgb, g[f"mlp_{tag}_rgb"], rtol=1e-5, atol=1e-5)
+        torch.testing.assert_close(dens, g[f"mlp_{tag}_density"], rtol=1e-5, atol=1e-5)
+    rays = {k: g["nerf_" + k] for k in ("rays_o", "rays_d", "viewdirs")}
+    n = rays["rays_o"].shape[0]
+    for tag in "pq":
+        mn, mx, dv, nc, nf, lind = g[f"nerf_{tag}_cfg"].tolist()
+        sd = syn.make_general_nerf_state_dict(1750 + ord(tag), min_deg_point=mn, max_deg_point=mx, deg_view=dv)
+        kw = dict(min_deg_point=mn, max_deg_point=mx, deg_view=dv, num_coarse_samples=nc, num_fine_samples=nf, lindisp=bool(lind))
+        tr, u = syn.seeded_uniform(1760 + ord(tag), n, nc + 1), syn.seeded_uniform(1770 + ord(tag), n, nf)
+        ok = g[f"nerf_{tag}_margin"] > 0.02
+        outs = {"det": orc.nerf_forward(sd, rays, False, True, 2.0, 6.0, **kw), "rnd": orc.nerf_forward(sd, rays, True, False, 2.0, 6.0, t_rand=tr, u=u, **kw)}
+        for t2, out in outs.items():
+            for lvl, name in ((0, "coarse"), (1, "fine")):
+                torch.testing.assert_close(out[lvl][0][ok], g[f"nerf_{tag}_{t2}_{name}_rgb"][ok], rtol=0, atol=2e-5)
+                torch.testing.assert_close(out[lvl][1][ok], g[f"nerf_{tag}_{t2}_{name}_acc"][ok], rtol=0, atol=2e-5)
