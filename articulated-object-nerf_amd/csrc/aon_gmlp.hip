@@ -51,8 +51,15 @@ __global__ void __launch_bounds__(256) gemm_tn_kernel(GemmArgs a) {
   __shared__ __attribute__((aligned(16))) float Bs[kGBN * kGLD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
-  const int64_t m0 = (int64_t)blockIdx.x * kGBM;
-  const int n0 = blockIdx.y * kGBN;
+  // XCD-aware tile order: workgroup L lands on XCD L % 8 (round-robin dispatch), each XCD has its own L2.  The column tiles of
+  // one row tile read the same 128 rows of X: they get consecutive slots of the SAME XCD, so the second read hits that L2.
+  const int tiles_n = (a.N + kGBN - 1) / kGBN;
+  const int64_t total = ((a.M + kGBM - 1) / kGBM) * tiles_n;
+  const int64_t per_xcd = (total + 7) / 8;
+  const int64_t q = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  if (q >= total) return;
+  const int64_t m0 = (q / tiles_n) * kGBM;
+  const int n0 = (int)(q % tiles_n) * kGBN;
   const int wr = (wave & 1) * 64, wc = (wave >> 1) * 64;
   f32x16 acc[2][2];
 #pragma unroll
@@ -104,14 +111,17 @@ __global__ void __launch_bounds__(256) gemm_tn_kernel(GemmArgs a) {
     const float b = a.bias ? a.bias[n] : 0.f;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
+      const int64_t mbase = m0 + wr + 32 * i + 4 * h;
+      float* yrow = a.Y + mbase * a.ldy + n;
+      const float* arow = a.epi == 2 ? a.aux + mbase * a.ldaux + n : nullptr;
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const int64_t m = m0 + wr + 32 * i + 8 * (e >> 2) + (e & 3) + 4 * h;
-        if (m >= a.M) continue;
+        const int dm = 8 * (e >> 2) + (e & 3);
+        if (mbase + dm >= a.M) continue;
         float y = __fadd_rn(acc[i][j][e], b);
         if (a.epi == 1) y = __builtin_fmaxf(y, 0.f);
-        else if (a.epi == 2) y = a.aux[m * a.ldaux + n] > 0.f ? y : 0.f;
-        a.Y[m * a.ldy + n] = y;
+        else if (a.epi == 2) y = arow[dm * a.ldaux] > 0.f ? y : 0.f;
+        yrow[dm * a.ldy] = y;
       }
     }
   }
@@ -119,8 +129,8 @@ __global__ void __launch_bounds__(256) gemm_tn_kernel(GemmArgs a) {
 
 hipError_t launch_gemm_tn(const GemmArgs& a, hipStream_t stream) {
   if (a.M <= 0 || a.N <= 0) return hipSuccess;
-  const dim3 grid((unsigned)((a.M + kGBM - 1) / kGBM), (unsigned)((a.N + kGBN - 1) / kGBN));
-  gemm_tn_kernel<<<grid, dim3(256), 0, stream>>>(a);
+  const int64_t total = ((a.M + kGBM - 1) / kGBM) * ((a.N + kGBN - 1) / kGBN);
+  gemm_tn_kernel<<<dim3((unsigned)((total + 7) / 8 * 8)), dim3(256), 0, stream>>>(a);
   return hipGetLastError();
 }
 

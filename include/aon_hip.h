@@ -98,7 +98,7 @@ int aon_composite(const float* rgb, int rgb_stride, const float* sigma, int sigm
                   float* depth, float* weights, void* stream);
 
 /* ---- R6+R7  helper.sorted_piecewise_constant_pdf (helper.py:203-243) and helper.sample_pdf (:246-252) ----
- * Fixed to the reference geometry: 64 bins, 63 weights, 128 new samples, 65 coarse t's -> 193 sorted t's.
+ * The reference geometry: 64 bins, 63 weights, 128 new samples, 65 coarse t's -> 193 sorted t's (any other: aon_sample_pdf_n).
  *   bins     (n,64) or NULL (then bins = mid-points of t_coarse, model.py:163)
  *   weights  pointer to the first of ray 0's 63 weights; w_stride floats between rays (63 dense, or 65 with
  *            weights = coarse_weights + 1 for the reference's weights[..., 1:-1], model.py:166)
