@@ -159,3 +159,54 @@ def test_wgrad_plan_invariants_without_gpu():
     assert lib.aon_wgrad_plan(1, 100, 256, out, 20, None) < 0 and b"multiple of 32" in lib.aon_last_error()
     assert lib.aon_wgrad_plan(1, 1024, 5, out, 20, None) < 0      # fewer compute units than layers: refused, not mis-planned
     assert lib.aon_wgrad_plan(1, 1024, 256, out, 3, None) < 0
+
+
+def test_constructor_option_entry_points_validate_without_gpu():
+    """aon_render_opts / aon_mlp_geometry (round 3): defaults, size queries and argument checks that need no GPU."""
+    import ctypes as C
+
+    from aon_amd import _lib
+
+    lib = _lib.lib
+    st = _lib.RenderOptsC()
+    lib.aon_render_opts_init(C.byref(st))
+    assert (st.num_coarse_samples, st.num_fine_samples, st.lindisp, st.noise_std) == (64, 128, 0, 0.0)
+    assert abs(st.rgb_scale - 1.002) < 1e-6 and abs(st.rgb_shift - 0.001) < 1e-7 and st.sigma_bias == -1.0
+    assert lib.aon_render_workspace_bytes_ex(1000, C.byref(st)) == lib.aon_render_workspace_bytes(1000)
+    assert lib.aon_train_workspace_bytes_ex(512, 1, 2, C.byref(st)) == lib.aon_train_workspace_bytes(512, 1, 2)
+    st.num_coarse_samples, st.num_fine_samples = 32, 48
+    per_ray = (33 + 33 + 81 + 4 * 81) * 4
+    assert 1000 * per_ray <= lib.aon_render_workspace_bytes_ex(1000, C.byref(st)) <= 1000 * per_ray + 4 * 256
+    assert lib.aon_train_workspace_bytes_ex(512, 0, 2, C.byref(st)) < lib.aon_train_workspace_bytes(512, 0, 2)
+    st.num_coarse_samples = 1
+    assert lib.aon_render_workspace_bytes_ex(1000, C.byref(st)) == -1 and b"num_coarse_samples" in lib.aon_last_error()
+    st.num_coarse_samples, st.num_fine_samples = 900, 20000
+    assert lib.aon_render_workspace_bytes_ex(1000, C.byref(st)) == -1 and b"too large" in lib.aon_last_error()
+    # general-size inverse CDF: size rules
+    assert lib.aon_sample_pdf_n(None, None, 5, None, None, 0, 4, 1, 8, 2, None, None, None) == -1          # < 2 bins
+    assert lib.aon_sample_pdf_n(None, None, 5, None, None, 0, 4, 10, 8, 9, None, None, None) == -1         # bins NULL needs num_t = num_bins + 1
+    assert lib.aon_sample_pdf_n(None, None, 9, None, None, 0, 0, 10, 8, 11, None, None, None) == 0         # empty problem
+    # NeRFMLP geometry
+    g = _lib.MlpGeometryC()
+    lib.aon_mlp_geometry_init(C.byref(g))
+    assert tuple(getattr(g, n) for n, _ in g._fields_) == (0, 10, 4, 8, 256, 1, 128, 4, 3, 3, 3, 1)
+    assert lib.aon_gmlp_param_count(C.byref(g)) == 24
+    g.netdepth, g.netdepth_condition = 6, 3
+    assert lib.aon_gmlp_param_count(C.byref(g)) == 2 * (6 + 3 + 3)
+    g.netdepth = 5                                       # the skip would land on the last trunk layer: the reference fails there too
+    assert lib.aon_gmlp_param_count(C.byref(g)) == -1 and b"last trunk layer" in lib.aon_last_error()
+    g.netdepth, g.netwidth = 6, 0
+    assert lib.aon_gmlp_param_count(C.byref(g)) == -1
+    lib.aon_mlp_geometry_init(C.byref(g))
+    lib.aon_render_opts_init(C.byref(st))
+    n = 256
+    acts = 258                                           # what the training forward keeps: E, H x 8, bott, V (floats per sample) ...
+    per_sample = (63 + 8 * 256 + 256 + 128 + 1 + 4 + 3) * 4
+    ws = lib.aon_grender_train_workspace_bytes(C.byref(g), n, 2, C.byref(st))
+    assert n * acts * per_sample <= ws <= n * acts * per_sample + n * (27 * 2 + 65) * 4 + 64 * 256
+    assert lib.aon_grender_train_scratch_bytes(C.byref(g), n, 2, C.byref(st)) > 0
+    assert lib.aon_grender_workspace_bytes(C.byref(g), n, C.byref(st)) > 0
+    g.input_ch = 2                                       # NeRF.forward encodes 3-vectors
+    assert lib.aon_grender_fwd(C.byref(g), None, None, None, None, None, 8, 2.0, 6.0, 1, 2, None, None, 0, None, None, None, None, None, None,
+                               None, 0, None, None) == -1
+    assert b"input_ch" in lib.aon_last_error()
