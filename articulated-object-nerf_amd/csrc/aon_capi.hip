@@ -816,7 +816,7 @@ int train_fwd_impl(const char* who, bool art, const TrainNet* nets, const float*
                    const aon_render_opts* opts) {
   Geo g;
   if (const char* bad = make_geo(opts, g)) return fail(AON_E_INVALID, bad);
-  if (g.Sf > 1024) return fail(AON_E_INVALID, "train forward: more than 1024 samples per ray at the fine level");
+  if (g.Sf > 512) return fail(AON_E_INVALID, "train forward: more than 512 samples per ray at the fine level");
   if (n <= 0 || (num_levels != 1 && num_levels != 2)) return fail(AON_E_INVALID, "train forward: bad size / num_levels");
   if (!rays_o || !rays_d || !viewdirs || !workspace) return fail(AON_E_INVALID, "train forward: null pointer");
   if (reinterpret_cast<uintptr_t>(workspace) & 255) return fail(AON_E_INVALID, "train forward: workspace must be 256-byte aligned");
@@ -1516,7 +1516,7 @@ int aon_grender_fwd_train(const aon_mlp_geometry* geom, const float* const* para
   if (const char* bad = make_gg(geom, g)) return fail(AON_E_INVALID, bad);
   if (const char* bad = whole_path_ok(g)) return fail(AON_E_INVALID, bad);
   if (const char* bad = make_geo(opts, geo)) return fail(AON_E_INVALID, bad);
-  if (geo.Sf > 1024) return fail(AON_E_INVALID, "aon_grender_fwd_train: more than 1024 samples per ray at the fine level");
+  if (geo.Sf > 512) return fail(AON_E_INVALID, "aon_grender_fwd_train: more than 512 samples per ray at the fine level");
   if (n <= 0 || (num_levels != 1 && num_levels != 2)) return fail(AON_E_INVALID, "aon_grender_fwd_train: bad size / num_levels");
   if (int rc = check_params(g, params_coarse_host, "aon_grender_fwd_train: null parameter pointer")) return rc;
   if (num_levels == 2)

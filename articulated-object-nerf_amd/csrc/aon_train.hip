@@ -35,7 +35,8 @@ struct CompositeBwdArgs {
 
 __device__ __forceinline__ float sigmoidf_(float x) { return __fdiv_rn(1.0f, __fadd_rn(1.0f, expf(-x))); }
 
-// NB: blocks of 64 samples held in registers -- 4 for the reference geometry (S <= 256), 16 for anything up to S = 1024
+// NB: blocks of 64 samples held in registers -- 4 for the reference geometry (S <= 256), 8 for anything up to S = 512
+// (16 blocks spill 1.8 KB per lane: the training entry points stop at 512 samples per ray)
 template <int NB>
 __global__ void __launch_bounds__(256) composite_bwd_kernel(CompositeBwdArgs a) {
   const int lane = threadIdx.x & 63;
@@ -138,10 +139,10 @@ hipError_t launch_composite_bwd(const float* raw, const float* t_vals, const flo
                                 const float* g_depth, int64_t n_rays, int S, int white_bkgd, const ActParams& ap, float* d_raw,
                                 hipStream_t stream) {
   if (n_rays <= 0) return hipSuccess;
-  if (S > 1024) return hipErrorInvalidValue;
+  if (S > 512) return hipErrorInvalidValue;
   CompositeBwdArgs a{raw, t_vals, dirs, g_rgb, g_acc, g_depth, n_rays, S, white_bkgd, ap, d_raw};
   if (S <= 256) composite_bwd_kernel<4><<<dim3((unsigned)((n_rays + 3) / 4)), dim3(256), 0, stream>>>(a);
-  else composite_bwd_kernel<16><<<dim3((unsigned)((n_rays + 3) / 4)), dim3(256), 0, stream>>>(a);
+  else composite_bwd_kernel<8><<<dim3((unsigned)((n_rays + 3) / 4)), dim3(256), 0, stream>>>(a);
   return hipGetLastError();
 }
 

@@ -269,7 +269,7 @@ int aon_art_render_bwd(const void* packed_bwd_coarse, const void* small_coarse, 
  * rounds once, as torch does when a Python scalar meets an fp32 tensor):
  *   num_coarse_samples  level 0 evaluates num_coarse_samples + 1 t values (helper.py:115); >= 2, <= 1023
  *   num_fine_samples    draws of the inverse CDF (helper.py:224-230); level 1 evaluates num_coarse_samples + 1 + num_fine_samples
- *                       (<= 1024 in the training entry points)
+ *                       (<= 512 in the training entry points)
  *   lindisp             helper.py:116-117: t = 1 / (inv_near (1 - s) + inv_far s) with inv_near = fp32(1.0 / near), inv_far =
  *                       fp32(1.0 / far) -- the reference evaluates 1.0 / near in Python double precision
  *   noise_c, noise_f    model.py:183-184 (`noise_std > 0 and randomized`): the caller's torch.rand_like(raw_sigma) draws of level

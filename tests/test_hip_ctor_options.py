@@ -205,6 +205,41 @@ def test_training_step_with_options(dev, net):
     assert_as_close_as_fp32(hip, truth, ref32, net)
 
 
+def test_training_above_256_samples_per_ray(dev):
+    """More than 256 samples per ray take the eight-block form of the compositing backward (S <= 512): loss and gradients
+    against the oracle's autograd at 101 + 250 samples; above 512 the training call refuses."""
+    import aon_amd.synthetic as syn
+    from _gradcheck import assert_as_close_as_fp32
+    from aon_amd.models.vanilla_nerf.model import NeRF
+
+    n, nc, nf = 64, 100, 250
+    sd = syn.make_smooth_nerf_state_dict()
+    model = NeRF(num_coarse_samples=nc, num_fine_samples=nf).to(dev)
+    model.load_state_dict(sd)
+    frame = syn.make_rays(16, 16, syn.look_at_pose(4.0, 60, 20), syn.focal_from_fovy(16))
+    rays_cpu = {k: v[::4][:n].contiguous() for k, v in frame.items()}
+    target = syn.seeded_uniform(91, n, 3)
+    out = model({k: v.to(dev) for k, v in rays_cpu.items()}, False, True, 2.0, 6.0)
+    loss = ((out[0][0] - target.to(dev)) ** 2).mean() + ((out[1][0] - target.to(dev)) ** 2).mean()
+    loss.backward()
+
+    def oracle_grads(dtype):
+        sd_o = {k: v.detach().clone().to(dtype).requires_grad_(True) for k, v in sd.items()}
+        o = orc.nerf_forward(sd_o, {k: v.to(dtype) for k, v in rays_cpu.items()}, False, True, 2.0, 6.0, num_coarse_samples=nc, num_fine_samples=nf)
+        l = orc.img2mse(o[0][0], target.to(dtype)) + orc.img2mse(o[1][0], target.to(dtype))
+        l.backward()
+        return l.item(), {k: v.grad for k, v in sd_o.items()}
+
+    (_, truth), (loss32, ref32) = oracle_grads(torch.float64), oracle_grads(torch.float32)
+    assert abs(loss.item() - loss32) < 2e-6
+    assert_as_close_as_fp32({k: p.grad.cpu() for k, p in model.named_parameters()}, truth, ref32, "351 samples per ray")
+    big = NeRF(num_coarse_samples=200, num_fine_samples=400).to(dev)
+    with pytest.raises(Exception, match="512 samples"):
+        big({k: v.to(dev) for k, v in rays_cpu.items()}, False, True, 2.0, 6.0)
+    with torch.no_grad():                       # inference has no such limit
+        big({k: v.to(dev) for k, v in rays_cpu.items()}, False, True, 2.0, 6.0)
+
+
 def test_bad_options_are_rejected(dev):
     from aon_amd import ops
     from aon_amd.models.vanilla_nerf.model import NeRF
