@@ -20,22 +20,31 @@ namespace aon {
 
 constexpr int kGBM = 128, kGBN = 128, kGBK = 32, kGLD = 36;   // LDS rows of 32 k-values padded to 36 floats
 
-// one 128-row x 32-k tile of a k-contiguous operand into registers: thread t takes row t >> 1, k-range (t & 1) * 16 .. + 16
-__device__ __forceinline__ void load_tile_rows(const float* base, int64_t ld, int rowdiv, int64_t row0, int64_t nrows, int k0, int K, int tid,
-                                               f32x4 (&v)[4]) {
-  const int64_t r = row0 + (tid >> 1);
+// one 128-row x 32-k tile of a k-contiguous operand into registers: thread t takes row t >> 1, k-range (t & 1) * 16 .. + 16.
+// The row pointer (a 64-bit multiply, and a 64-bit DIVISION for the per-ray condition rows) is formed once per workgroup, not per
+// k-chunk: the first version re-derived it in every chunk and executed three other VALU instructions per MFMA (SQ_INSTS_VALU).
+struct RowSrc {
+  const float* p;   // row start (or the segment base for a row outside the matrix: never dereferenced)
+  bool ok, vec;
+};
+__device__ __forceinline__ RowSrc make_row_src(const float* base, int64_t ld, int rowdiv, int64_t row, int64_t nrows) {
+  RowSrc r;
+  r.ok = row < nrows;
+  const int64_t src = rowdiv == 1 ? row : row / rowdiv;
+  r.p = base + (r.ok ? src * ld : 0);
+  r.vec = r.ok && ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(base) & 15) == 0);
+  return r;
+}
+__device__ __forceinline__ void load_tile_rows(const RowSrc& r, int k0, int K, int tid, f32x4 (&v)[4]) {
   const int kb = k0 + (tid & 1) * 16;
-  const bool row_ok = r < nrows;
-  const float* p = base + (row_ok ? (r / rowdiv) * ld : 0);
-  const bool vec_ok = row_ok && ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(base) & 15) == 0);
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int k = kb + 4 * q;
-    if (vec_ok && k + 4 <= K) {
-      v[q] = *reinterpret_cast<const f32x4*>(p + k);
+    if (r.vec && k + 4 <= K) {
+      v[q] = *reinterpret_cast<const f32x4*>(r.p + k);
     } else {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[q][e] = (row_ok && k + e < K) ? p[k + e] : 0.f;
+      for (int e = 0; e < 4; ++e) v[q][e] = (r.ok && k + e < K) ? r.p[k + e] : 0.f;
     }
   }
 }
@@ -47,8 +56,10 @@ __device__ __forceinline__ void store_tile_rows(float* lds, int tid, const f32x4
 }
 
 __global__ void __launch_bounds__(256) gemm_tn_kernel(GemmArgs a) {
-  __shared__ __attribute__((aligned(16))) float As[kGBM * kGLD];
-  __shared__ __attribute__((aligned(16))) float Bs[kGBN * kGLD];
+  // (A two-stage LDS variant with ONE barrier per k-chunk -- 74 KB, two workgroups per CU instead of three -- was measured slower:
+  // 0.452 against 0.510 of the matrix peak, profiles/r03_general_engine_pmc.txt: this kernel lives on its occupancy.)
+  __shared__ __attribute__((aligned(16))) float As[1][kGBM * kGLD];
+  __shared__ __attribute__((aligned(16))) float Bs[1][kGBN * kGLD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   // XCD-aware tile order: workgroup L lands on XCD L % 8 (round-robin dispatch), each XCD has its own L2.  The column tiles of
@@ -74,27 +85,31 @@ __global__ void __launch_bounds__(256) gemm_tn_kernel(GemmArgs a) {
   const int nch1 = a.nseg > 1 ? (a.seg[1].K + kGBK - 1) / kGBK : 0;
   const int nch = nch0 + nch1;
   f32x4 va[4], vb[4];
+  RowSrc xa[2], wb[2];
+#pragma unroll
+  for (int sg = 0; sg < 2; ++sg) {
+    if (sg < a.nseg) {
+      xa[sg] = make_row_src(a.seg[sg].X, a.seg[sg].ldx, a.seg[sg].rowdiv, m0 + (tid >> 1), a.M);
+      wb[sg] = make_row_src(a.seg[sg].W, a.seg[sg].ldw, 1, n0 + (tid >> 1), a.N);
+    } else {
+      xa[sg] = xa[0]; wb[sg] = wb[0];
+    }
+  }
   auto fetch = [&](int c) {
-    const int s = c < nch0 ? 0 : 1;
-    const int k0 = (s == 0 ? c : c - nch0) * kGBK;
-    const GemmSeg& g = a.seg[s];
-    load_tile_rows(g.X, g.ldx, g.rowdiv, m0, a.M, k0, g.K, tid, va);
-    load_tile_rows(g.W, g.ldw, 1, n0, a.N, k0, g.K, tid, vb);
+    const bool second = c >= nch0;
+    const int k0 = (second ? c - nch0 : c) * kGBK;
+    const int K = second ? a.seg[1].K : a.seg[0].K;
+    load_tile_rows(second ? xa[1] : xa[0], k0, K, tid, va);
+    load_tile_rows(second ? wb[1] : wb[0], k0, K, tid, vb);
   };
-  fetch(0);
-  for (int c = 0; c < nch; ++c) {
-    __syncthreads();                 // the previous chunk's fragment reads are done
-    store_tile_rows(As, tid, va);
-    store_tile_rows(Bs, tid, vb);
-    __syncthreads();
-    if (c + 1 < nch) fetch(c + 1);   // in flight under the MFMAs below
+  auto compute = [&](const float* Ab, const float* Bb) {
 #pragma unroll
     for (int kg = 0; kg < 4; ++kg) {
       f32x4 fa[2], fb[2];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const f32x4*>(As + (wr + 32 * i + r) * kGLD + kg * 8 + 4 * h);
+      for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const f32x4*>(Ab + (wr + 32 * i + r) * kGLD + kg * 8 + 4 * h);
 #pragma unroll
-      for (int j = 0; j < 2; ++j) fb[j] = *reinterpret_cast<const f32x4*>(Bs + (wc + 32 * j + r) * kGLD + kg * 8 + 4 * h);
+      for (int j = 0; j < 2; ++j) fb[j] = *reinterpret_cast<const f32x4*>(Bb + (wc + 32 * j + r) * kGLD + kg * 8 + 4 * h);
 #pragma unroll
       for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -102,6 +117,15 @@ __global__ void __launch_bounds__(256) gemm_tn_kernel(GemmArgs a) {
 #pragma unroll
           for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
     }
+  };
+  fetch(0);
+  for (int c = 0; c < nch; ++c) {
+    __syncthreads();                 // the previous chunk's fragment reads are done
+    store_tile_rows(As[0], tid, va);
+    store_tile_rows(Bs[0], tid, vb);
+    __syncthreads();
+    if (c + 1 < nch) fetch(c + 1);   // in flight under the MFMAs below
+    compute(As[0], Bs[0]);
   }
   // epilogue: lane holds column n = .. + r, rows 8 (e >> 2) + (e & 3) + 4 h of each 32 x 32 tile
 #pragma unroll
@@ -148,17 +172,18 @@ struct WgradArgs {
   float* part;                               // [splits][N * K]
 };
 
+// 32 rows x 128 columns: thread t takes row t >> 3 and the four 16-byte pieces at columns (t & 7) * 4 + 32 q -- eight lanes cover
+// 128 contiguous bytes of a row per instruction, in HBM and in LDS (the first version gave a thread 16 consecutive columns: lanes
+// 64 bytes apart, SQ_LDS_BANK_CONFLICT = half of the LDS cycles)
 __device__ __forceinline__ void load_tile_cols(const float* base, int64_t ld, int rowdiv, int64_t m0, int64_t m_end, int c0, int C, int tid,
                                                f32x4 (&v)[4]) {
-  // 32 rows x 128 columns: thread t takes row t >> 3, columns (t & 7) * 16 .. + 16
   const int64_t m = m0 + (tid >> 3);
-  const int cb = c0 + (tid & 7) * 16;
   const bool row_ok = m < m_end;
-  const float* p = base + (row_ok ? (m / rowdiv) * ld : 0);
+  const float* p = base + (row_ok ? (rowdiv == 1 ? m : m / rowdiv) * ld : 0);
   const bool vec_ok = row_ok && ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(base) & 15) == 0);
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    const int c = cb + 4 * q;
+    const int c = c0 + (tid & 7) * 4 + 32 * q;
     if (vec_ok && c + 4 <= C) {
       v[q] = *reinterpret_cast<const f32x4*>(p + c);
     } else {
@@ -192,10 +217,10 @@ __global__ void __launch_bounds__(256) wgrad_nk_kernel(WgradArgs a) {
   for (int64_t m = mb; m < me; m += kWBM) {
     __syncthreads();
     {
-      float* pa = As + (tid >> 3) * kWLD + (tid & 7) * 16;
-      float* pb = Bs + (tid >> 3) * kWLD + (tid & 7) * 16;
+      float* pa = As + (tid >> 3) * kWLD + (tid & 7) * 4;
+      float* pb = Bs + (tid >> 3) * kWLD + (tid & 7) * 4;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) { *reinterpret_cast<f32x4*>(pa + 4 * q) = va[q]; *reinterpret_cast<f32x4*>(pb + 4 * q) = vb[q]; }
+      for (int q = 0; q < 4; ++q) { *reinterpret_cast<f32x4*>(pa + 32 * q) = va[q]; *reinterpret_cast<f32x4*>(pb + 32 * q) = vb[q]; }
     }
     __syncthreads();
     if (m + kWBM < me) {
