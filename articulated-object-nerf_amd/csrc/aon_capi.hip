@@ -62,7 +62,7 @@ hipError_t launch_cast_rays(const float* t_vals, const float* o, const float* d,
 hipError_t launch_sample_along_rays(const float* rays_o, const float* rays_d, int64_t n_rays, int S, float near, float far,
                                     const float* t_rand, float* t_vals, float* coords, hipStream_t stream, int lindisp = 0,
                                     float inv_near = 0.f, float inv_far = 0.f);
-hipError_t launch_pos_enc(const float* x, int64_t n, int min_deg, int max_deg, float* out, hipStream_t stream);
+hipError_t launch_pos_enc(const float* x, int64_t n, int min_deg, int max_deg, float* out, hipStream_t stream, int ld = 0);
 hipError_t launch_composite(const float* rgb, int rgb_stride, const float* sigma, int sigma_stride, const float* t_vals,
                             const float* dirs, int64_t n_rays, int S, int white_bkgd, const ActParams& ap, float* comp_rgb,
                             float* acc, float* depth, float* weights, hipStream_t stream);
@@ -1134,6 +1134,9 @@ namespace {
 
 struct GG {   // aon_mlp_geometry, validated
   int P, V, D, W, Dc, Wc, skip, Crgb, Cd, min_deg, max_deg, deg_view, in_ch, in_ch_view;
+  // row strides of the engine's OWN encoding buffers: padded to whole 8-float groups (zeros) so the GEMM reads 16-byte pieces only
+  int ldP() const { return (P + 7) & ~7; }
+  int ldV() const { return (V + 7) & ~7; }
   int nparams() const { return 2 * (D + Dc + 3); }
   int pts(int l) const { return 2 * l; }
   int view(int i) const { return 2 * (D + i); }
@@ -1162,8 +1165,9 @@ const char* make_gg(const aon_mlp_geometry* g, GG& o) {
 
 // per-sample activation buffers of one MLP evaluation over M samples of n rays
 struct GActs {
-  float* E;        // M x P   (caller-owned when the encoding is given)
-  float* cond;     // n x V
+  float* E;        // M x P, row stride ldE (caller-owned when the encoding is given: then ldE = P)
+  float* cond;     // n x V, row stride ldC
+  int ldE, ldC;
   float* H[64];    // trunk outputs, M x W each (inference: two buffers alternate)
   float* bott;     // M x W
   float* Vh[64];   // view-branch outputs, M x Wc
@@ -1176,10 +1180,10 @@ int gmlp_forward(const GG& g, const float* const* p, const GActs& a, int64_t n_r
   for (int l = 0; l < g.D; ++l) {
     aon::GemmArgs ga{};
     const int ldw = g.in_width(l);
-    if (l == 0) ga.seg[0] = {a.E, g.P, 1, p[g.pts(0)], ldw, g.P};
+    if (l == 0) ga.seg[0] = {a.E, a.ldE, 1, p[g.pts(0)], ldw, g.P};
     else ga.seg[0] = {a.H[l - 1], g.W, 1, p[g.pts(l)], ldw, g.W};
     ga.nseg = 1;
-    if (g.cat_before(l)) { ga.seg[1] = {a.E, g.P, 1, p[g.pts(l)] + g.W, ldw, g.P}; ga.nseg = 2; }
+    if (g.cat_before(l)) { ga.seg[1] = {a.E, a.ldE, 1, p[g.pts(l)] + g.W, ldw, g.P}; ga.nseg = 2; }
     ga.bias = p[g.pts(l) + 1]; ga.Y = a.H[l]; ga.ldy = g.W; ga.M = M; ga.N = g.W; ga.epi = 1;
     if (int rc = check(aon::launch_gemm_tn(ga, stream), who)) return rc;
   }
@@ -1196,7 +1200,7 @@ int gmlp_forward(const GG& g, const float* const* p, const GActs& a, int64_t n_r
     aon::GemmArgs ga{};
     if (i == 0) {
       ga.seg[0] = {a.bott, g.W, 1, p[g.view(0)], g.W + g.V, g.W};
-      ga.seg[1] = {a.cond, g.V, S, p[g.view(0)] + g.W, g.W + g.V, g.V};   // condition_tile (model.py:107-110): the ray's row
+      ga.seg[1] = {a.cond, a.ldC, S, p[g.view(0)] + g.W, g.W + g.V, g.V};   // condition_tile (model.py:107-110): the ray's row
       ga.nseg = 2;
     } else {
       ga.seg[0] = {a.Vh[i - 1], g.Wc, 1, p[g.view(i)], g.Wc, g.Wc}; ga.nseg = 1;
@@ -1222,7 +1226,8 @@ struct Carver {
 // activation buffers: train = every layer keeps its own output, else two alternate
 GActs carve_acts(Carver& c, const GG& g, int64_t M, int64_t n_rays, bool train, bool own_enc) {
   GActs a{};
-  if (own_enc) { a.E = c.f(M * g.P); a.cond = c.f(n_rays * g.V); }
+  a.ldE = g.P; a.ldC = g.V;
+  if (own_enc) { a.ldE = g.ldP(); a.ldC = g.ldV(); a.E = c.f(M * a.ldE); a.cond = c.f(n_rays * a.ldC); }
   if (train) {
     for (int l = 0; l < g.D; ++l) a.H[l] = c.f(M * g.W);
     for (int i = 0; i < g.Dc; ++i) a.Vh[i] = c.f(M * g.Wc);
@@ -1251,8 +1256,8 @@ GWs carve_grender(void* base, const GG& g, const Geo& geo, int64_t n) {
 int g_encode(const GG& g, const float* o, const float* d, const float* v, const float* t, int64_t n, int S, float* coords, const GActs& a,
              hipStream_t stream, const char* who) {
   if (int rc = check(aon::launch_cast_rays(t, o, d, n, S, coords, stream), who)) return rc;
-  if (int rc = check(aon::launch_pos_enc(coords, n * S, g.min_deg, g.max_deg, a.E, stream), who)) return rc;
-  return check(aon::launch_pos_enc(v, n, 0, g.deg_view, a.cond, stream), who);
+  if (int rc = check(aon::launch_pos_enc(coords, n * S, g.min_deg, g.max_deg, a.E, stream, a.ldE), who)) return rc;
+  return check(aon::launch_pos_enc(v, n, 0, g.deg_view, a.cond, stream, a.ldC), who);
 }
 
 const char* whole_path_ok(const GG& g) {
@@ -1338,7 +1343,7 @@ int gmlp_backward(const GG& g, const float* const* p, float* const* grads, const
   {
     const int ldw = g.W + g.V;
     if ((rc = wgrad(dv, g.Wc, g.Wc, a.bott, g.W, 1, g.W, grads[g.view(0)], ldw))) return rc;
-    if ((rc = wgrad(dv, g.Wc, g.Wc, a.cond, g.V, S, g.V, grads[g.view(0)] + g.W, ldw))) return rc;
+    if ((rc = wgrad(dv, g.Wc, g.Wc, a.cond, a.ldC, S, g.V, grads[g.view(0)] + g.W, ldw))) return rc;
     if ((rc = bgrad(dv, g.Wc, g.Wc, grads[g.view(0) + 1]))) return rc;
     if ((rc = check(aon::launch_transpose(p[g.view(0)], ldw, g.Wc, g.W, sc.wt, stream), who))) return rc;   // the bottleneck columns only
     if ((rc = bdata(dv, g.Wc, g.Wc, sc.wt, g.W, nullptr, 0, 0, nullptr, nullptr, sc.dbott))) return rc;      // no activation on the bottleneck
@@ -1360,10 +1365,10 @@ int gmlp_backward(const GG& g, const float* const* p, float* const* grads, const
     const float* dz = sc.dz[l & 1];
     const int ldw = g.in_width(l);
     if (l == 0) {
-      if ((rc = wgrad(dz, g.W, g.W, a.E, g.P, 1, g.P, grads[g.pts(0)], ldw))) return rc;
+      if ((rc = wgrad(dz, g.W, g.W, a.E, a.ldE, 1, g.P, grads[g.pts(0)], ldw))) return rc;
     } else {
       if ((rc = wgrad(dz, g.W, g.W, a.H[l - 1], g.W, 1, g.W, grads[g.pts(l)], ldw))) return rc;
-      if (g.cat_before(l) && (rc = wgrad(dz, g.W, g.W, a.E, g.P, 1, g.P, grads[g.pts(l)] + g.W, ldw))) return rc;
+      if (g.cat_before(l) && (rc = wgrad(dz, g.W, g.W, a.E, a.ldE, 1, g.P, grads[g.pts(l)] + g.W, ldw))) return rc;
     }
     if ((rc = bgrad(dz, g.W, g.W, grads[g.pts(l) + 1]))) return rc;
     if (l > 0) {

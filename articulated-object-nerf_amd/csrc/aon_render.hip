@@ -240,17 +240,19 @@ hipError_t launch_sample_along_rays(const float* rays_o, const float* rays_d, in
 // R4  positional encoding, stage-level entry point   (helper.py:136-140)
 // (the render path never materialises this tensor: the fused MLP kernel encodes in registers)
 // ---------------------------------------------------------------------------------------------
-__global__ void pos_enc_kernel(const float* __restrict__ x, int64_t n, int min_deg, int max_deg, float* __restrict__ out) {
+// `ld` >= F floats between output rows; the pad columns F .. ld-1 are written as zeros (the layer-wise engine reads its operands in
+// whole 16-byte pieces: csrc/aon_gmlp.hip)
+__global__ void pos_enc_kernel(const float* __restrict__ x, int64_t n, int min_deg, int max_deg, int ld, float* __restrict__ out) {
   const int L = max_deg - min_deg;
   const int F = 3 + 6 * L;
   const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= n * F) return;
-  const int64_t row = g / F;
-  const int f = (int)(g - row * F);
-  float v;
+  if (g >= n * ld) return;
+  const int64_t row = g / ld;
+  const int f = (int)(g - row * ld);
+  float v = 0.f;
   if (f < 3) {
     v = x[row * 3 + f];
-  } else {
+  } else if (f < F) {
     const int e = (f - 3) % (3 * L);
     const bool shifted = (f - 3) >= 3 * L;
     const float xb = __fmul_rn(x[row * 3 + e % 3], __builtin_ldexpf(1.0f, min_deg + e / 3));
@@ -259,10 +261,12 @@ __global__ void pos_enc_kernel(const float* __restrict__ x, int64_t n, int min_d
   out[g] = v;
 }
 
-hipError_t launch_pos_enc(const float* x, int64_t n, int min_deg, int max_deg, float* out, hipStream_t stream) {
-  const int64_t tot = n * (3 + 6 * (max_deg - min_deg));
+hipError_t launch_pos_enc(const float* x, int64_t n, int min_deg, int max_deg, float* out, hipStream_t stream, int ld) {
+  const int F = 3 + 6 * (max_deg - min_deg);
+  if (ld < F) ld = F;
+  const int64_t tot = n * ld;
   if (tot <= 0) return hipSuccess;
-  pos_enc_kernel<<<dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream>>>(x, n, min_deg, max_deg, out);
+  pos_enc_kernel<<<dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream>>>(x, n, min_deg, max_deg, ld, out);
   return hipGetLastError();
 }
 

@@ -904,7 +904,7 @@ def gmlp_fwd(geom: MlpGeometry, params: dict, samples_enc, viewdirs_enc):
 
 
 # rays per internal chunk of the layer-wise engine: its activations live in HBM (~ (P + 3 W + 2 Wc) * 4 B per sample)
-G_CHUNK_RAYS = 16384
+G_CHUNK_RAYS = 8192
 _GWS_CACHE: dict = {}
 
 
