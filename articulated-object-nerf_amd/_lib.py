@@ -84,6 +84,7 @@ _SIGS = {
     "aon_render_fwd": (_i, [_p, _p, _p, _p, _p, _l, _f, _f, _i, _i, _p, _p, _l, _p, _p, _p, _p, _p, _p, _p, _l, _p]),
     # constructor arguments beyond the defaults (aon_render_opts; the *_ex forms take the struct pointer last)
     "aon_render_opts_init": (None, [_p]),
+    "aon_pack_vanilla_mlp_deg": (_i, [_p, _i, _i, _i, _p, _p]),
     "aon_sample_along_rays_ex": (_i, [_p, _p, _l, _i, _f, _f, _i, _f, _f, _p, _p, _p, _p]),
     "aon_composite_ex": (_i, [_p, _i, _p, _i, _p, _p, _l, _i, _i, _i, _p, _p, _p, _p, _p, _p]),
     "aon_sample_pdf_n": (_i, [_p, _p, _l, _p, _p, _l, _l, _i, _i, _i, _p, _p, _p]),
@@ -122,7 +123,8 @@ class RenderOptsC(C.Structure):
     _fields_ = [("num_coarse_samples", C.c_int32), ("num_fine_samples", C.c_int32), ("lindisp", C.c_int32),
                 ("inv_near", C.c_float), ("inv_far", C.c_float), ("noise_std", C.c_float),
                 ("noise_c", C.c_void_p), ("noise_f", C.c_void_p),
-                ("rgb_scale", C.c_float), ("rgb_shift", C.c_float), ("sigma_bias", C.c_float)]
+                ("rgb_scale", C.c_float), ("rgb_shift", C.c_float), ("sigma_bias", C.c_float),
+                ("min_deg_point", C.c_int32), ("max_deg_point", C.c_int32), ("deg_view", C.c_int32)]
 
 
 for _name, (_res, _args) in _SIGS.items():

@@ -11,7 +11,7 @@
 #include "aon_gmlp.h"
 
 namespace aon {
-hipError_t launch_pack_vanilla(const float* const* params, float* packed, hipStream_t stream);
+hipError_t launch_pack_vanilla(const float* const* params, float* packed, hipStream_t stream, int pos_levels = 10, int view_levels = 4);
 hipError_t launch_mlp_fwd(const char* packed, const float* rays_o, const float* rays_d, const float* viewdirs,
                           const float* t_vals, int64_t n_rays, int S, float* raw, hipStream_t stream);
 hipError_t launch_mlp_fwd_enc(const char* packed, const float* samples_enc, const float* viewdirs_enc, int64_t n_rays,
@@ -62,7 +62,7 @@ hipError_t launch_cast_rays(const float* t_vals, const float* o, const float* d,
 hipError_t launch_sample_along_rays(const float* rays_o, const float* rays_d, int64_t n_rays, int S, float near, float far,
                                     const float* t_rand, float* t_vals, float* coords, hipStream_t stream, int lindisp = 0,
                                     float inv_near = 0.f, float inv_far = 0.f);
-hipError_t launch_pos_enc(const float* x, int64_t n, int min_deg, int max_deg, float* out, hipStream_t stream, int ld = 0);
+hipError_t launch_pos_enc(const float* x, int64_t n, int min_deg, int max_deg, float* out, hipStream_t stream, int ld = 0, int levels_out = 0);
 hipError_t launch_composite(const float* rgb, int rgb_stride, const float* sigma, int sigma_stride, const float* t_vals,
                             const float* dirs, int64_t n_rays, int S, int white_bkgd, const ActParams& ap, float* comp_rgb,
                             float* acc, float* depth, float* weights, hipStream_t stream);
@@ -148,6 +148,8 @@ struct Geo {
   int lindisp; float inv_near, inv_far;
   const float* noise[2]; float noise_std;
   float rgb_scale, rgb_shift, sigma_bias;
+  int min_deg, max_deg, deg_view;   // encoding degrees of a vanilla network on the fused kernels
+  bool other_degrees;               // != (0, 10, 4): encodings computed outside the MLP kernel, in its padded 63 / 27 layout
   int S(int l) const { return l == 0 ? Sc : Sf; }
   aon::ActParams act(bool art, int level, int64_t ray0) const {
     aon::ActParams ap{art ? AON_ACT_ARTICULATED : AON_ACT_VANILLA, rgb_scale, rgb_shift, sigma_bias, nullptr, noise_std};
@@ -169,6 +171,10 @@ const char* make_geo(const aon_render_opts* o, Geo& g) {
   g.lindisp = d.lindisp != 0; g.inv_near = d.inv_near; g.inv_far = d.inv_far;
   g.noise[0] = d.noise_c; g.noise[1] = d.noise_f; g.noise_std = d.noise_std;
   g.rgb_scale = d.rgb_scale; g.rgb_shift = d.rgb_shift; g.sigma_bias = d.sigma_bias;
+  g.min_deg = d.min_deg_point; g.max_deg = d.max_deg_point; g.deg_view = d.deg_view;
+  if (g.max_deg < g.min_deg || g.max_deg - g.min_deg > 10 || g.deg_view < 0 || g.deg_view > 4)
+    return "the fused kernels hold up to 10 position and 4 view frequency levels (other degrees: aon_grender_*)";
+  g.other_degrees = !(g.min_deg == 0 && g.max_deg == 10 && g.deg_view == 4);
   return nullptr;
 }
 
@@ -178,16 +184,22 @@ struct Ws {
   float* w_c;   // n*Sc
   float* t_f;   // n*Sf
   float* raw;   // n*Sf*4 (coarse raw uses the first n*Sc*4)
+  float* coords; float* enc; float* venc;   // other_degrees only: n*Sf*3, n*Sf*63, n*27
   int64_t bytes;
 };
 
 Ws carve(char* base, int64_t n, const Geo& g) {
-  Ws w;
+  Ws w{};
   int64_t off = 0;
   w.t_c = reinterpret_cast<float*>(base + off); off += align_up(n * g.Sc * 4, 256);
   w.w_c = reinterpret_cast<float*>(base + off); off += align_up(n * g.Sc * 4, 256);
   w.t_f = reinterpret_cast<float*>(base + off); off += align_up(n * g.Sf * 4, 256);
   w.raw = reinterpret_cast<float*>(base + off); off += align_up(n * g.Sf * 16, 256);
+  if (g.other_degrees) {
+    w.coords = reinterpret_cast<float*>(base + off); off += align_up(n * g.Sf * 12, 256);
+    w.enc = reinterpret_cast<float*>(base + off); off += align_up(n * g.Sf * (int64_t)aon::kPosEnc * 4, 256);
+    w.venc = reinterpret_cast<float*>(base + off); off += align_up(n * (int64_t)aon::kViewEnc * 4, 256);
+  }
   w.bytes = off;
   return w;
 }
@@ -264,6 +276,17 @@ int aon_pack_vanilla_mlp(const float* const* params_host, void* packed, void* st
   return check(aon::launch_pack_vanilla(params_host, static_cast<float*>(packed), (hipStream_t)stream), "aon_pack_vanilla_mlp");
 }
 
+int aon_pack_vanilla_mlp_deg(const float* const* params_host, int min_deg_point, int max_deg_point, int deg_view, void* packed, void* stream) {
+  if (!params_host || !packed) return fail(AON_E_INVALID, "aon_pack_vanilla_mlp_deg: null pointer");
+  for (int i = 0; i < aon::kNumVanillaParams; ++i)
+    if (!params_host[i]) return fail(AON_E_INVALID, "aon_pack_vanilla_mlp_deg: null parameter pointer");
+  if (reinterpret_cast<uintptr_t>(packed) & 15) return fail(AON_E_INVALID, "aon_pack_vanilla_mlp_deg: packed must be 16-byte aligned");
+  const int L = max_deg_point - min_deg_point;
+  if (L < 0 || L > 10 || deg_view < 0 || deg_view > 4)
+    return fail(AON_E_INVALID, "aon_pack_vanilla_mlp_deg: the stream holds up to 10 position and 4 view frequency levels");
+  return check(aon::launch_pack_vanilla(params_host, static_cast<float*>(packed), (hipStream_t)stream, L, deg_view), "aon_pack_vanilla_mlp_deg");
+}
+
 int aon_mlp_fwd(const void* packed, const float* rays_o, const float* rays_d, const float* viewdirs, const float* t_vals,
                 int64_t n_rays, int S, float* raw, void* stream) {
   if (n_rays < 0 || S < 1) return fail(AON_E_INVALID, "aon_mlp_fwd: bad size");
@@ -301,6 +324,7 @@ void aon_render_opts_init(aon_render_opts* o) {
   o->num_coarse_samples = 64; o->num_fine_samples = 128; o->lindisp = 0; o->inv_near = 0.f; o->inv_far = 0.f;
   o->noise_std = 0.f; o->noise_c = nullptr; o->noise_f = nullptr;
   o->rgb_scale = 1.002f; o->rgb_shift = 0.001f; o->sigma_bias = -1.0f;
+  o->min_deg_point = 0; o->max_deg_point = 10; o->deg_view = 4;
 }
 
 int aon_sample_along_rays_ex(const float* rays_o, const float* rays_d, int64_t n_rays, int S, float near_, float far_, int lindisp,
@@ -556,7 +580,18 @@ struct NetRef {
 };
 
 static hipError_t launch_net(const NetRef& net, const float* o, const float* d, const float* v, const float* t, int64_t n, int S,
-                             float* raw, hipStream_t stream) {
+                             float* raw, hipStream_t stream, const Geo* g = nullptr, const Ws* w = nullptr) {
+  if (g && g->other_degrees) {
+    // NeRF(min_deg_point, max_deg_point, deg_view) with at most 10 / 4 levels: the encodings are computed by the stage kernels in
+    // the fused kernel's 63 / 27-slot layout (zeros in the missing levels' slots, matched by zero weights in the packed stream,
+    // aon_pack_vanilla_mlp_deg) and the MLP runs as NeRFMLP.forward(x, condition) on them: 252 B/sample of extra HBM traffic
+    // against 1.19 MFLOP/sample
+    if (hipError_t e = aon::launch_cast_rays(t, o, d, n, S, w->coords, stream); e != hipSuccess) return e;
+    if (hipError_t e = aon::launch_pos_enc(w->coords, n * S, g->min_deg, g->max_deg, w->enc, stream, aon::kPosEnc, 10); e != hipSuccess) return e;
+    if (hipError_t e = aon::launch_pos_enc(v, n, 0, g->deg_view, w->venc, stream, aon::kViewEnc, 4); e != hipSuccess) return e;
+    MlpTimer timer(stream, n * S);
+    return aon::launch_mlp_fwd_enc(static_cast<const char*>(net.packed), w->enc, w->venc, n, S, raw, stream);
+  }
   MlpTimer timer(stream, n * S);
   if (net.articulated)
     return aon::launch_art_mlp_fwd(static_cast<const char*>(net.packed), net.small, o, d, v, t, n, S, raw, stream);
@@ -580,13 +615,15 @@ static int render_impl(const char* who, const NetRef& coarse, const NetRef& fine
   if (num_levels == 2 && u_stride != 0 && u_stride < g.nf) return fail(AON_E_INVALID, "render: bad u_stride");
   if (reinterpret_cast<uintptr_t>(workspace) & 255) return fail(AON_E_INVALID, "render: workspace must be 256-byte aligned");
   const bool art = coarse.articulated;
+  if (art && g.other_degrees) return fail(AON_E_INVALID, "render: the articulated network has kernels for degrees (0, 10, 4) only");
   const bool fuse_coarse = num_levels == 2 && g.default_sizes && g_fuse_coarse.load(std::memory_order_relaxed) != 0;
 
   // largest chunk the workspace admits
   int64_t chunk = n_rays;
   if (carve(nullptr, chunk, g).bytes > workspace_bytes) {
-    const int64_t per_ray = (int64_t)(g.Sc + g.Sc + g.Sf + 4 * g.Sf) * 4;
-    chunk = (workspace_bytes - 4 * 256) / per_ray;
+    const int64_t per_ray = (int64_t)(g.Sc + g.Sc + g.Sf + 4 * g.Sf + (g.other_degrees ? (3 + aon::kPosEnc) * g.Sf + aon::kViewEnc : 0)) * 4;
+    const int64_t slack = g.other_degrees ? 7 * 256 : 4 * 256;
+    chunk = (workspace_bytes - slack) / per_ray;
     while (chunk > 0 && carve(nullptr, chunk, g).bytes > workspace_bytes) --chunk;
     if (chunk < 1) return fail(AON_E_WORKSPACE, "render: workspace smaller than aon_render_workspace_bytes(1)");
   }
@@ -606,7 +643,7 @@ static int render_impl(const char* who, const NetRef& coarse, const NetRef& fine
                                                g.lindisp, g.inv_near, g.inv_far), who);
     }
     if (rc) return rc;
-    rc = check(launch_net(coarse, o, d, v, w.t_c, n, g.Sc, w.raw, stream), who);
+    rc = check(launch_net(coarse, o, d, v, w.t_c, n, g.Sc, w.raw, stream, &g, &w), who);
     if (rc) return rc;
     if (fuse_coarse) {
       // compositing + the fine level's sampling (model.py:162-173) in one kernel: the coarse weights stay in registers
@@ -628,7 +665,7 @@ static int render_impl(const char* who, const NetRef& coarse, const NetRef& fine
                                                             w.t_f, stream), who);
       if (rc) return rc;
     }
-    rc = check(launch_net(fine, o, d, v, w.t_f, n, g.Sf, w.raw, stream), who);
+    rc = check(launch_net(fine, o, d, v, w.t_f, n, g.Sf, w.raw, stream, &g, &w), who);
     if (rc) return rc;
     {
       KTimer timer(kComposite, stream, n);
@@ -817,6 +854,7 @@ int train_fwd_impl(const char* who, bool art, const TrainNet* nets, const float*
   Geo g;
   if (const char* bad = make_geo(opts, g)) return fail(AON_E_INVALID, bad);
   if (g.Sf > 512) return fail(AON_E_INVALID, "train forward: more than 512 samples per ray at the fine level");
+  if (g.other_degrees) return fail(AON_E_INVALID, "train forward: the fused training kernels are compiled for degrees (0, 10, 4); other degrees train through aon_grender_fwd_train");
   if (n <= 0 || (num_levels != 1 && num_levels != 2)) return fail(AON_E_INVALID, "train forward: bad size / num_levels");
   if (!rays_o || !rays_d || !viewdirs || !workspace) return fail(AON_E_INVALID, "train forward: null pointer");
   if (reinterpret_cast<uintptr_t>(workspace) & 255) return fail(AON_E_INVALID, "train forward: workspace must be 256-byte aligned");

@@ -37,7 +37,24 @@ struct PackArgs {
   const float* p[kNumVanillaParams];
 };
 
-__global__ void pack_vanilla_kernel(PackArgs a, float* __restrict__ packed) {
+// L / Lv: frequency levels of the network's encodings (max_deg_point - min_deg_point <= 10, deg_view <= 4).  The stream always has
+// the 63 / 27-wide slots of the default geometry; a network with fewer levels leaves the slots of the missing levels at zero
+// weight, and the caller feeds encodings in that padded layout (launch_pos_enc with `levels_out`).
+__device__ __forceinline__ int pos_col_in(int c63, int L) {   // column of the 63-slot layout -> column of the (3 + 6 L)-wide weight
+  if (c63 < 3) return c63;
+  const bool second = c63 >= 33;
+  const int e = second ? c63 - 33 : c63 - 3;
+  return e / 3 < L ? 3 + e + (second ? 3 * L : 0) : -1;
+}
+__device__ __forceinline__ int view_col_in(int c27, int Lv) {
+  if (c27 < 3) return c27;
+  const bool second = c27 >= 15;
+  const int e = second ? c27 - 15 : c27 - 3;
+  return e / 3 < Lv ? 3 + e + (second ? 3 * Lv : 0) : -1;
+}
+
+__global__ void pack_vanilla_kernel(PackArgs a, float* __restrict__ packed, int L, int Lv) {
+  const int P = 3 + 6 * L, V = 3 + 6 * Lv;
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   constexpr int64_t stream_floats = kStreamBytes / 4;
   if (idx >= stream_floats + kSmallFloats) return;
@@ -66,15 +83,17 @@ __global__ void pack_vanilla_kernel(PackArgs a, float* __restrict__ packed) {
   const int h = lane >> 5, row = 32 * tp + (lane & 31);
   const float* W; int ld, n_out = 256, col;
   const int hid_col = 8 * q + 4 * h + cc;  // + 32*T
-  if (c < kChL1) { W = a.p[0]; ld = kPosEnc; col = posenc_col(c, q, cc, h); }
+  auto pcol = [&](int c63) { return c63 < 0 ? -1 : pos_col_in(c63, L); };
+  auto vcol = [&](int c27) { return c27 < 0 ? -1 : view_col_in(c27, Lv); };
+  if (c < kChL1) { W = a.p[0]; ld = P; col = pcol(posenc_col(c, q, cc, h)); }
   else if (c < kChL5) { const int l = 1 + (c - kChL1) / 8; W = a.p[2 * l]; ld = 256; col = 32 * ((c - kChL1) % 8) + hid_col; }
-  else if (c < kChL5 + 8) { W = a.p[10]; ld = 256 + kPosEnc; col = 32 * (c - kChL5) + hid_col; }
-  else if (c < kChL6) { W = a.p[10]; ld = 256 + kPosEnc; col = posenc_col(c - kChL5 - 8, q, cc, h); if (col >= 0) col += 256; }
+  else if (c < kChL5 + 8) { W = a.p[10]; ld = 256 + P; col = 32 * (c - kChL5) + hid_col; }
+  else if (c < kChL6) { W = a.p[10]; ld = 256 + P; col = pcol(posenc_col(c - kChL5 - 8, q, cc, h)); if (col >= 0) col += 256; }
   else if (c < kChL7) { W = a.p[12]; ld = 256; col = 32 * (c - kChL6) + hid_col; }
   else if (c < kChBott) { W = a.p[14]; ld = 256; col = 32 * (c - kChL7) + hid_col; }
   else if (c < kChView) { W = a.p[18]; ld = 256; col = 32 * (c - kChBott) + hid_col; }
-  else if (c < kChView + 8) { W = a.p[16]; ld = 256 + kViewEnc; n_out = kCondWidth; col = 32 * (c - kChView) + hid_col; }
-  else { W = a.p[16]; ld = 256 + kViewEnc; n_out = kCondWidth; col = viewenc_col(q, cc, h); if (col >= 0) col += 256; }
+  else if (c < kChView + 8) { W = a.p[16]; ld = 256 + V; n_out = kCondWidth; col = 32 * (c - kChView) + hid_col; }
+  else { W = a.p[16]; ld = 256 + V; n_out = kCondWidth; col = vcol(viewenc_col(q, cc, h)); if (col >= 0) col += 256; }
   packed[idx] = (col >= 0 && row < n_out) ? W[(int64_t)row * ld + col] : 0.f;
 }
 
@@ -238,11 +257,11 @@ __global__ void __launch_bounds__(256) mlp_fwd_kernel(MlpArgs args) {
 // ---------------------------------------------------------------------------------------------
 // host launchers (called from the C ABI)
 // ---------------------------------------------------------------------------------------------
-hipError_t launch_pack_vanilla(const float* const* params, float* packed, hipStream_t stream) {
+hipError_t launch_pack_vanilla(const float* const* params, float* packed, hipStream_t stream, int pos_levels, int view_levels) {
   PackArgs a;
   for (int i = 0; i < kNumVanillaParams; ++i) a.p[i] = params[i];
   const int64_t n = kStreamBytes / 4 + kSmallFloats;
-  pack_vanilla_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream>>>(a, packed);
+  pack_vanilla_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream>>>(a, packed, pos_levels, view_levels);
   return hipGetLastError();
 }
 

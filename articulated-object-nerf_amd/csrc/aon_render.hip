@@ -241,10 +241,12 @@ hipError_t launch_sample_along_rays(const float* rays_o, const float* rays_d, in
 // (the render path never materialises this tensor: the fused MLP kernel encodes in registers)
 // ---------------------------------------------------------------------------------------------
 // `ld` >= F floats between output rows; the pad columns F .. ld-1 are written as zeros (the layer-wise engine reads its operands in
-// whole 16-byte pieces: csrc/aon_gmlp.hip)
-__global__ void pos_enc_kernel(const float* __restrict__ x, int64_t n, int min_deg, int max_deg, int ld, float* __restrict__ out) {
+// whole 16-byte pieces: csrc/aon_gmlp.hip).  `levels_out` > L: the output has the column layout of an encoding with that many
+// levels -- [x ; sin block of 3 levels_out ; shifted block] -- with zeros in the slots of the levels this encoding lacks (the
+// fused kernels' 63 / 27-wide input slots fed by a network with fewer levels, aon_pack_vanilla_mlp_deg).
+__global__ void pos_enc_kernel(const float* __restrict__ x, int64_t n, int min_deg, int max_deg, int ld, int levels_out, float* __restrict__ out) {
   const int L = max_deg - min_deg;
-  const int F = 3 + 6 * L;
+  const int F = 3 + 6 * levels_out;
   const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= n * ld) return;
   const int64_t row = g / ld;
@@ -253,20 +255,23 @@ __global__ void pos_enc_kernel(const float* __restrict__ x, int64_t n, int min_d
   if (f < 3) {
     v = x[row * 3 + f];
   } else if (f < F) {
-    const int e = (f - 3) % (3 * L);
-    const bool shifted = (f - 3) >= 3 * L;
-    const float xb = __fmul_rn(x[row * 3 + e % 3], __builtin_ldexpf(1.0f, min_deg + e / 3));
-    v = sin_f32(shifted ? __fadd_rn(xb, AON_HALF_PI_F32) : xb);
+    const int e = (f - 3) % (3 * levels_out);
+    const bool shifted = (f - 3) >= 3 * levels_out;
+    if (e / 3 < L) {
+      const float xb = __fmul_rn(x[row * 3 + e % 3], __builtin_ldexpf(1.0f, min_deg + e / 3));
+      v = sin_f32(shifted ? __fadd_rn(xb, AON_HALF_PI_F32) : xb);
+    }
   }
   out[g] = v;
 }
 
-hipError_t launch_pos_enc(const float* x, int64_t n, int min_deg, int max_deg, float* out, hipStream_t stream, int ld) {
-  const int F = 3 + 6 * (max_deg - min_deg);
+hipError_t launch_pos_enc(const float* x, int64_t n, int min_deg, int max_deg, float* out, hipStream_t stream, int ld, int levels_out) {
+  if (levels_out < max_deg - min_deg) levels_out = max_deg - min_deg;
+  const int F = 3 + 6 * levels_out;
   if (ld < F) ld = F;
   const int64_t tot = n * ld;
   if (tot <= 0) return hipSuccess;
-  pos_enc_kernel<<<dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream>>>(x, n, min_deg, max_deg, ld, out);
+  pos_enc_kernel<<<dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream>>>(x, n, min_deg, max_deg, ld, levels_out, out);
   return hipGetLastError();
 }
 

@@ -70,7 +70,10 @@ class NeRFMLP(nn.Module):
         out = None if fresh else self._streams.get(kind)
         if out is not None and out.device != dev:
             out = None
-        out = getattr(ops, self._PACKERS[kind])(params, out=out)
+        if kind == "fwd" and not self.geometry.is_default:   # other degrees on the fused inference kernels (fits_fused_inference)
+            out = ops.pack_vanilla_mlp(params, out=out, degrees=(self.min_deg_point, self.max_deg_point, self.deg_view))
+        else:
+            out = getattr(ops, self._PACKERS[kind])(params, out=out)
         if not fresh:
             self._streams[kind] = out
         return out
@@ -118,7 +121,11 @@ class NeRF(nn.Module):
         self.sigma_activation = nn.ReLU()
         self.coarse_mlp = NeRFMLP(min_deg_point, max_deg_point, deg_view)
         self.fine_mlp = NeRFMLP(min_deg_point, max_deg_point, deg_view)
-        self._general = not self.coarse_mlp.geometry.is_default   # other encoding degrees: the layer-wise engine
+        geom = self.coarse_mlp.geometry
+        self._general = not geom.is_default            # other encoding degrees: training on the layer-wise engine ...
+        self._fused_inference = geom.fits_fused_inference   # ... inference on the fused kernels when the levels fit their 63 / 27 slots
+        if self._general and self._fused_inference:
+            self._opts.degrees = (min_deg_point, max_deg_point, deg_view)
 
     def _draw_noise(self, noise, randomized, n, device):
         if not (self.noise_std > 0 and randomized):
@@ -149,6 +156,10 @@ class NeRF(nn.Module):
                 flat = RenderGeneral.apply(rays_o, rays["rays_d"], rays["viewdirs"], float(near), float(far), bool(white_bkgd),
                                            self.num_levels, t_rand, u, geom, self._opts, noise, *params)
                 return [tuple(flat[3 * i: 3 * i + 3]) for i in range(self.num_levels)]
+            if self._fused_inference:
+                outs = ops.render_fwd(mlps[0].packed(), mlps[1].packed() if self.num_levels == 2 else None, rays_o, rays["rays_d"],
+                                      rays["viewdirs"], near, far, white_bkgd, self.num_levels, t_rand, u, opts=self._opts, noise=noise)
+                return [tuple(o) for o in outs]
             pd = [dict(m.named_parameters()) for m in mlps]
             outs = ops.grender_fwd(geom, pd[0], pd[1] if self.num_levels == 2 else None, rays_o, rays["rays_d"], rays["viewdirs"], near, far,
                                    white_bkgd, self.num_levels, t_rand, u, opts=self._opts, noise=noise)

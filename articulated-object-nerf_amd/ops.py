@@ -146,22 +146,31 @@ def packed_bytes() -> int:
     return int(lib.aon_mlp_packed_bytes())
 
 
-def pack_vanilla_mlp(params: dict, out: torch.Tensor | None = None) -> torch.Tensor:
+def pack_vanilla_mlp(params: dict, out: torch.Tensor | None = None, degrees=(0, 10, 4)) -> torch.Tensor:
     """params: name -> tensor with the reference's NeRFMLP parameter names (no prefix).  Returns the packed
-    uint8 weight stream consumed by mlp_fwd / render_fwd (re-pack whenever the parameters change)."""
+    uint8 weight stream consumed by mlp_fwd / render_fwd (re-pack whenever the parameters change).  ``degrees`` =
+    (min_deg_point, max_deg_point, deg_view) of a default-size network with at most 10 / 4 frequency levels: the slots of the
+    missing levels get zero weight (aon_pack_vanilla_mlp_deg)."""
+    mn, mx, dv = degrees
+    shapes = dict(VANILLA_PARAM_SHAPES)
+    P, V = 3 + 6 * (mx - mn), 3 + 6 * dv
+    shapes.update({"pts_linears.0.weight": (256, P), "pts_linears.5.weight": (256, 256 + P), "views_linear.0.weight": (128, 256 + V)})
     tensors = []
     for name in VANILLA_PARAM_ORDER:
         t = _f32(params[name].detach(), name)
-        if tuple(t.shape) != VANILLA_PARAM_SHAPES[name]:
-            raise ValueError(f"{name}: shape {tuple(t.shape)} != {VANILLA_PARAM_SHAPES[name]} (only the reference's default "
-                             "NeRFMLP geometry has a HIP kernel)")
+        if tuple(t.shape) != shapes[name]:
+            raise ValueError(f"{name}: shape {tuple(t.shape)} != {shapes[name]} (the fused kernels take the reference's default "
+                             f"NeRFMLP sizes with encoding degrees {tuple(degrees)})")
         tensors.append(t)
     dev = tensors[0].device
     if out is None:
         out = torch.empty(packed_bytes(), dtype=torch.uint8, device=dev)
     arr = (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
     with torch.cuda.device(dev):
-        check(lib.aon_pack_vanilla_mlp(arr, _ptr(out), _stream()), "aon_pack_vanilla_mlp")
+        if tuple(degrees) == (0, 10, 4):
+            check(lib.aon_pack_vanilla_mlp(arr, _ptr(out), _stream()), "aon_pack_vanilla_mlp")
+        else:
+            check(lib.aon_pack_vanilla_mlp_deg(arr, mn, mx, dv, _ptr(out), _stream()), "aon_pack_vanilla_mlp_deg")
     return out
 
 
@@ -191,7 +200,9 @@ class RenderOpts:
     """Sampler / activation arguments of ``NeRF.__init__`` (model.py:124-135) and ``NeRF_AE_Art.__init__``
     (model_autodecoder.py:241-257) -> ``aon_render_opts``.  Python numbers become fp32 exactly where torch would round them."""
 
-    def __init__(self, num_coarse_samples=64, num_fine_samples=128, lindisp=False, noise_std=0.0, rgb_padding=0.001, density_bias=-1.0):
+    def __init__(self, num_coarse_samples=64, num_fine_samples=128, lindisp=False, noise_std=0.0, rgb_padding=0.001, density_bias=-1.0,
+                 degrees=(0, 10, 4)):
+        self.degrees = tuple(int(x) for x in degrees)   # (min_deg_point, max_deg_point, deg_view) of a default-size network on the fused kernels
         self.num_coarse_samples, self.num_fine_samples = int(num_coarse_samples), int(num_fine_samples)
         self.lindisp, self.noise_std = bool(lindisp), float(noise_std)
         self.rgb_padding, self.density_bias = float(rgb_padding), float(density_bias)
@@ -217,6 +228,7 @@ class RenderOpts:
         if self.lindisp:
             st.inv_near, st.inv_far = 1.0 / near, 1.0 / far      # double -> fp32 once (helper.py:117)
         st.rgb_scale, st.rgb_shift, st.sigma_bias = 1 + 2 * self.rgb_padding, self.rgb_padding, self.density_bias
+        st.min_deg_point, st.max_deg_point, st.deg_view = self.degrees
         keep = []
         if noise is not None and self.noise_std > 0:
             st.noise_std = self.noise_std
@@ -396,7 +408,10 @@ MAX_CHUNK_RAYS = 327680
 
 
 def _workspace(device, n_rays: int, st=None) -> torch.Tensor:
-    need = int(lib.aon_render_workspace_bytes_ex(min(n_rays, MAX_CHUNK_RAYS), None if st is None else C.byref(st)))
+    chunk = MAX_CHUNK_RAYS
+    if st is not None and (st.min_deg_point, st.max_deg_point, st.deg_view) != (0, 10, 4):
+        chunk = 65536      # the encodings of a chunk are materialised (51 KB per ray) for other degrees
+    need = int(lib.aon_render_workspace_bytes_ex(min(n_rays, chunk), None if st is None else C.byref(st)))
     if need < 0:
         check(need, "aon_render_workspace_bytes_ex")
     key = str(device)
@@ -842,6 +857,13 @@ class MlpGeometry:
     @property
     def is_default(self) -> bool:
         return self.as_tuple() == self.DEFAULT
+
+    @property
+    def fits_fused_inference(self) -> bool:
+        """Default widths / depths with at most 10 position and 4 view frequency levels: the fused inference kernels take it
+        (zero-weight slots for the missing levels, aon_pack_vanilla_mlp_deg)."""
+        return (self.as_tuple()[3:] == self.DEFAULT[3:] and 0 <= self.max_deg_point - self.min_deg_point <= 10
+                and 0 <= self.deg_view <= 4)
 
     def c_struct(self):
         st = _lib.MlpGeometryC()

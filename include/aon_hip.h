@@ -78,6 +78,12 @@ int aon_pos_enc(const float* x, int64_t n, int min_deg, int max_deg, float* out,
 int64_t aon_mlp_packed_bytes(void);
 int aon_pack_vanilla_mlp(const float* const* params_host, void* packed, void* stream);
 
+/* As aon_pack_vanilla_mlp for a NeRFMLP(min_deg_point, max_deg_point, deg_view) of default widths and depths whose encodings have
+ * at most 10 / 4 frequency levels (pts_linears.0: (256, 3 + 6 L), pts_linears.5: (256, 256 + 3 + 6 L), views_linear.0: (128, 256 +
+ * 3 + 6 deg_view)): same stream size, zero weight in the slots of the missing levels.  Consumed by aon_render_fwd_ex with the same
+ * degrees in aon_render_opts, or by aon_mlp_fwd_enc on encodings in the padded 63 / 27-column layout. */
+int aon_pack_vanilla_mlp_deg(const float* const* params_host, int min_deg_point, int max_deg_point, int deg_view, void* packed, void* stream);
+
 /* ---- R3(cast)+R4+R5  cast_rays + pos_enc + NeRFMLP.forward fused (model.py:175-181 -> :95-120) ----
  * raw (n*S,4) = (raw_rgb[3], raw_density) per sample, before the sigmoid/relu of model.py:186-187. */
 int aon_mlp_fwd(const void* packed, const float* rays_o, const float* rays_d, const float* viewdirs,
@@ -278,6 +284,12 @@ int aon_art_render_bwd(const void* packed_bwd_coarse, const void* small_coarse, 
  *   rgb_scale, rgb_shift, sigma_bias   articulated activations (model_autodecoder.py:321-323): rgb = sigmoid(raw) * rgb_scale -
  *                       rgb_shift, sigma = softplus(raw_sigma + sigma_bias); fp32(1 + 2 rgb_padding), fp32(rgb_padding),
  *                       fp32(density_bias).  Ignored by the vanilla entry points.
+   min_deg_point, max_deg_point, deg_view   NeRF.__init__'s encoding degrees (model.py:126-128) on the FUSED inference kernels, for a
+ *                       default-size NeRFMLP with max_deg_point - min_deg_point <= 10 and deg_view <= 4: the stream of
+ *                       aon_pack_vanilla_mlp_deg leaves the 63 / 27-wide input slots of the missing levels at zero weight, and
+ *                       aon_render_fwd_ex computes the encodings outside the MLP kernel in that padded layout (pos_enc stage
+ *                       kernel, +252 B/sample of HBM traffic) and runs the MLP on them.  Inference only: the training entry points
+ *                       refuse other degrees (they train through aon_grender_fwd_train); ignored by the articulated calls.
  * Geometries other than 64 / 128 run the coarse level as two kernels (compositing, then aon_sample_pdf_n). */
 typedef struct aon_render_opts {
   int32_t num_coarse_samples;   /* 64 */
@@ -288,6 +300,7 @@ typedef struct aon_render_opts {
   const float* noise_c;         /* NULL */
   const float* noise_f;         /* NULL */
   float rgb_scale, rgb_shift, sigma_bias;   /* 1.002f, 0.001f, -1.0f */
+  int32_t min_deg_point, max_deg_point, deg_view;   /* 0, 10, 4 */
 } aon_render_opts;
 void aon_render_opts_init(aon_render_opts* opts);   /* the reference's defaults */
 

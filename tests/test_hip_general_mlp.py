@@ -105,6 +105,45 @@ def test_nerf_with_other_degrees_end_to_end(dev, golden):
                 torch.testing.assert_close(depth[ok], g[f"nerf_{tag}_{t2}_{name}_depth"][ok], rtol=0, atol=ddepth)
 
 
+def test_other_degrees_on_the_fused_inference_kernels(dev, golden):
+    """NeRF(min_deg_point, max_deg_point, deg_view) with at most 10 / 4 levels renders on the FUSED kernels (zero-weight slots for
+    the missing levels, encodings in the padded layout): against the reference (G17 'p' = (0, 6, 2)), against the oracle at
+    (1, 8, 3), (-1, 9, 4) and the degenerate (2, 2, 0), and against the layer-wise engine on the same weights."""
+    import aon_amd.synthetic as syn
+    from aon_amd.models.vanilla_nerf.model import NeRF
+
+    g = golden("g17_general_mlp")
+    rays_cpu = {k: g["nerf_" + k] for k in ("rays_o", "rays_d", "viewdirs")}
+    rays = {k: v.to(dev) for k, v in rays_cpu.items()}
+    n = rays["rays_o"].shape[0]
+    for (mn, mx, dv), seed in (((0, 6, 2), 1750 + ord("p")), ((1, 8, 3), 61), ((-1, 9, 4), 62), ((2, 2, 0), 63)):
+        kw = dict(min_deg_point=mn, max_deg_point=mx, deg_view=dv)
+        sd = syn.make_general_nerf_state_dict(seed, **kw)
+        model = NeRF(**kw).to(dev)
+        model.load_state_dict(sd)
+        assert model._fused_inference and model._general
+        tr, u = syn.seeded_uniform(64, n, 65).to(dev), syn.seeded_uniform(65, n, 128).to(dev)
+        with torch.no_grad():
+            fused = [model(rays, False, True, 2.0, 6.0), model(rays, True, False, 2.0, 6.0, t_rand=tr, u=u)]
+            model._fused_inference = False
+            layered = [model(rays, False, True, 2.0, 6.0), model(rays, True, False, 2.0, 6.0, t_rand=tr, u=u)]
+        ref, aux = orc.nerf_forward(sd, rays_cpu, False, True, 2.0, 6.0, return_aux=True, **kw)
+        ok = torch.stack([a["raw_sigma"][:, -1, 0].abs() for a in aux]).min(0).values > 0.05
+        assert ok.float().mean() > 0.6
+        for lvl in (0, 1):
+            torch.testing.assert_close(fused[0][lvl][0].cpu()[ok], ref[lvl][0][ok], rtol=0, atol=2e-6)
+            torch.testing.assert_close(fused[0][lvl][2].cpu()[ok], ref[lvl][2][ok], rtol=0, atol=2e-5)
+            for a, b in zip(fused, layered):      # two engines, same weights
+                torch.testing.assert_close(a[lvl][0][ok.to(dev)], b[lvl][0][ok.to(dev)], rtol=0, atol=2e-6)
+        if (mn, mx, dv) == (0, 6, 2):
+            okg = g["nerf_p_margin"] > 0.05
+            for lvl, name in ((0, "coarse"), (1, "fine")):
+                torch.testing.assert_close(fused[0][lvl][0].cpu()[okg], g[f"nerf_p_det_{name}_rgb"][okg], rtol=0, atol=2e-6)
+    # more than 10 levels do not fit the slots: layer-wise engine
+    big = NeRF(min_deg_point=0, max_deg_point=11, deg_view=4)
+    assert big._general and not big._fused_inference
+
+
 def test_general_engine_chunking_is_invisible(dev):
     """A workspace smaller than the batch makes aon_grender_fwd walk ray chunks: same bits as one pass."""
     import aon_amd.synthetic as syn
@@ -113,6 +152,7 @@ def test_general_engine_chunking_is_invisible(dev):
 
     kw = dict(min_deg_point=0, max_deg_point=5, deg_view=2)
     model = NeRF(**kw).to(dev)
+    model._fused_inference = False        # this test is about the layer-wise engine's chunk walk
     model.load_state_dict(syn.make_general_nerf_state_dict(21, **kw))
     frame = syn.make_rays(20, 24, syn.look_at_pose(4.0, 60, 20), syn.focal_from_fovy(20))
     rays = {k: v.to(dev) for k, v in frame.items()}
