@@ -197,6 +197,44 @@ def render_leg(dev, kind, H, W, steps=3):
         return {"error": f"{type(e).__name__}: {e}"}
 
 
+def other_constructor_leg(dev, H=240, W=320, steps=3):
+    """Informational (never `value`): the drop-in classes built with NON-default constructor arguments on a 320x240
+    frame -- NeRF(max_deg_point=6, deg_view=2) on the fused kernels (zero-weight slots) and on the layer-wise GEMM engine, and a
+    default network with 32 + 64 samples and lindisp (runtime sampler options on the fused kernels)."""
+    try:
+        import aon_amd.synthetic as syn
+        from aon_amd.datasets.ray_utils import get_frame_rays
+        from aon_amd.models.vanilla_nerf.model import NeRF
+
+        ro, vd = get_frame_rays(H, W, syn.focal_from_fovy(H), syn.look_at_pose(), device=dev)
+        rays = {"rays_o": ro, "rays_d": vd, "viewdirs": vd}
+
+        def timed(model):
+            with torch.no_grad():
+                model(rays, False, True, syn.NEAR, syn.FAR)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    model(rays, False, True, syn.NEAR, syn.FAR)
+                torch.cuda.synchronize()
+            return H * W / ((time.perf_counter() - t0) / steps)
+
+        gk = dict(min_deg_point=0, max_deg_point=6, deg_view=2)
+        m = NeRF(**gk).to(dev)
+        m.load_state_dict(syn.make_general_nerf_state_dict(7, **gk))
+        out = {"workload": f"vanilla NeRF {W}x{H}, {H * W} rays, non-default constructor arguments", "unit": "rays/s",
+               "degrees_0_6_2_fused_padded_slots": timed(m)}
+        m._fused_inference = False
+        out["degrees_0_6_2_layerwise_engine"] = timed(m)
+        m2 = NeRF(num_coarse_samples=32, num_fine_samples=64, lindisp=True).to(dev)
+        m2.load_state_dict(syn.make_nerf_state_dict(seed=0, density_scale=30.0))
+        out["default_net_32c_64f_lindisp"] = timed(m2)
+        out["evals_per_ray_32c_64f"] = 33 + 97
+        return out
+    except Exception as e:  # informational leg: never take the headline down with it
+        return {"error": f"{type(e).__name__}: {e}"}
+
+
 def _pmc_file():
     """The newest committed rocprofv3 PMC summary of this same command (profiles/rNN_pmc.json -- NOT rNN_train_pmc.json, the
     counters of the training kernels), or (None, None)."""
@@ -473,6 +511,7 @@ def main():
     # BASELINE configs 1 and 4 on this rank's GPU (informational, never `value`)
     config1 = None if args.no_extra_legs else render_leg(dev, "config1", 240, 320)
     art_render = None if args.no_extra_legs else render_leg(dev, "art", 240, 320)
+    other_ctor = None if args.no_extra_legs else other_constructor_leg(dev)
 
     if rank == 0:
         rays_per_s = world * n_rays * args.steps / dt
@@ -499,6 +538,8 @@ def main():
             res["config1"] = config1
         if art_render is not None:
             res["art_render"] = art_render
+        if other_ctor is not None:
+            res["other_constructor_arguments"] = other_ctor
         if sharded is not None:
             res["sharded_frame"] = sharded
         if train is not None:

@@ -154,3 +154,63 @@ def test_training_gradient_sweep(dev, seed, n):
         if not robust:   # a ray whose far-plane sigma is within rounding of zero flips a whole alpha_last = {0,1} term
             tol = 5e-2
         assert rel_l2(p.grad.cpu(), ref) <= tol, (name, rel_l2(p.grad.cpu(), ref))
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_forward_sweep_constructor_arguments(dev, seed):
+    """Random constructor arguments (sample counts 2..100 / 1..200, lindisp, density noise, encoding degrees on all three routes
+    -- fused, fused with zero-weight slots, layer-wise engine -- articulated rgb_padding / density_bias), ragged ray counts,
+    against the oracle built with the same arguments.  Smooth fields; each ray is held to 5e-5 plus three times the oracle's own
+    fp32-vs-fp64 spread on it."""
+    import aon_amd.synthetic as syn
+    from aon_amd.models.vanilla_nerf.model import NeRF
+    from aon_amd.models.vanilla_nerf.model_autodecoder import NeRF_AE_Art
+
+    rng = np.random.Generator(np.random.PCG64(3000 + seed))
+    n = int(rng.integers(1, 400))
+    nc, nf = int(rng.integers(2, 101)), int(rng.integers(1, 201))
+    lindisp, randomized, white = bool(rng.integers(0, 2)), bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+    noise_std = float(rng.choice([0.0, 0.5, 1.0]))
+    near, far = ((2.0, 6.0), (0.7, 7.0), (2.5, 5.5))[seed % 3]
+    art = seed % 4 == 3
+    rays_cpu = _rays(n, rng, True)
+    rays = {k: v.to(dev) for k, v in rays_cpu.items()}
+    g = torch.Generator().manual_seed(seed)
+    draws = dict(t_rand=torch.rand(n, nc + 1, generator=g), u=torch.rand(n, nf, generator=g)) if randomized else {}
+    noise = [torch.rand(n, nc + 1, generator=g), torch.rand(n, nc + 1 + nf, generator=g)]
+    kw = dict(num_coarse_samples=nc, num_fine_samples=nf, lindisp=lindisp, noise_std=noise_std)
+    dd = lambda d: {k: (v.double() if torch.is_tensor(v) else v) for k, v in d.items()}   # noqa: E731
+    if art:
+        kw.update(rgb_padding=float(rng.choice([0.001, 0.02])), density_bias=float(rng.choice([-1.0, 0.3])))
+        sd = syn.make_art_state_dict(seed=seed, density_scale=2.0)
+        lat = orc.code_library(syn.make_code_library_state(seed=seed, n_max_objs=2), torch.tensor([seed % 2]), torch.tensor([seed % 10]))
+        model = NeRF_AE_Art(**kw).to(dev)
+        model.load_state_dict(sd)
+        with torch.no_grad():
+            out = model(rays, randomized, white, near, far, {k: v.to(dev) for k, v in lat.items()}, noise=[z.to(dev) for z in noise],
+                        **{k: v.to(dev) for k, v in draws.items()})
+        ref = orc.nerf_ae_art_forward(sd, rays_cpu, randomized, white, near, far, lat, noise=noise, **draws, **kw)
+        ref64 = orc.nerf_ae_art_forward(dd(sd), dd(rays_cpu), randomized, white, near, far, dd(lat), noise=[z.double() for z in noise], **dd(draws), **kw)
+        robust = torch.ones(n, dtype=torch.bool)
+    else:
+        gk = [dict(), dict(min_deg_point=0, max_deg_point=7, deg_view=3), dict(min_deg_point=1, max_deg_point=12, deg_view=5),
+              dict(min_deg_point=-1, max_deg_point=5, deg_view=0)][(seed // 4) % 4]
+        sd = syn.make_general_nerf_state_dict(4000 + seed, **gk)
+        model = NeRF(**kw, **gk).to(dev)
+        model.load_state_dict(sd)
+        with torch.no_grad():
+            out = model(rays, randomized, white, near, far, noise=[z.to(dev) for z in noise], **{k: v.to(dev) for k, v in draws.items()})
+        ref, aux = orc.nerf_forward(sd, rays_cpu, randomized, white, near, far, return_aux=True, noise=noise, **draws, **kw, **gk)
+        ref64 = orc.nerf_forward(dd(sd), dd(rays_cpu), randomized, white, near, far, noise=[z.double() for z in noise], **dd(draws), **kw, **gk)
+        robust = torch.ones(n, dtype=torch.bool)
+        for lvl, a in enumerate(aux):   # far-plane sign margin of the vanilla relu, with the noise this pass adds
+            last = a["raw_sigma"][:, -1, 0] + (noise[lvl][:, -1] * noise_std if (noise_std > 0 and randomized) else 0.0)
+            robust &= last.abs() > 2e-2
+    for lvl in (0, 1):
+        rgb, acc, depth = (x.cpu() for x in out[lvl])
+        assert rgb.shape == (n, 3) and torch.isfinite(rgb).all() and torch.isfinite(acc).all()
+        if robust.any():
+            err = (rgb - ref[lvl][0]).abs().max(dim=-1).values
+            spread = (ref[lvl][0].double() - ref64[lvl][0]).abs().max(dim=-1).values.float()
+            bad = robust & (err > 5e-5 + 3 * spread)
+            assert not bad.any(), (lvl, err[bad].max().item(), spread[bad].max().item(), kw)
