@@ -289,7 +289,7 @@ int aon_art_render_bwd(const void* packed_bwd_coarse, const void* small_coarse, 
  *                       aon_pack_vanilla_mlp_deg leaves the 63 / 27-wide input slots of the missing levels at zero weight, and
  *                       aon_render_fwd_ex computes the encodings outside the MLP kernel in that padded layout (pos_enc stage
  *                       kernel, +252 B/sample of HBM traffic) and runs the MLP on them.  Inference only: the training entry points
- *                       refuse other degrees (they train through aon_grender_fwd_train); ignored by the articulated calls.
+ *                       refuse other degrees (they train through aon_grender_fwd_train), and so do the articulated calls.
  * Geometries other than 64 / 128 run the coarse level as two kernels (compositing, then aon_sample_pdf_n). */
 typedef struct aon_render_opts {
   int32_t num_coarse_samples;   /* 64 */
