@@ -20,39 +20,45 @@ namespace aon {
 
 constexpr int kGBM = 128, kGBN = 128, kGBK = 32, kGLD = 36;   // LDS rows of 32 k-values padded to 36 floats
 
-// one 128-row x 32-k tile of a k-contiguous operand into registers: thread t takes row t >> 1, k-range (t & 1) * 16 .. + 16.
-// The row pointer (a 64-bit multiply, and a 64-bit DIVISION for the per-ray condition rows) is formed once per workgroup, not per
-// k-chunk: the first version re-derived it in every chunk and executed three other VALU instructions per MFMA (SQ_INSTS_VALU).
+// one 128-row x 32-k tile of a k-contiguous operand into registers.  Thread t takes the 16-byte piece (t & 7) of rows (t >> 3) + 32 q,
+// q = 0..3: eight lanes cover the 128 contiguous bytes of one row, a wave-instruction touches 8 cache lines (the first version
+// gave a thread 64 contiguous bytes of ONE row -- 32 lines per instruction, each a quarter used -- and the kernel sat at 0.51 of the
+// matrix peak waiting on its own operand fetch).  The row address of q = 0 is formed once per workgroup.
 struct RowSrc {
-  const float* p;   // row start (or the segment base for a row outside the matrix: never dereferenced)
-  bool ok, vec;
+  const float* p;      // row (t >> 3) of the tile (or the base for a row outside the matrix: never dereferenced)
+  int64_t row, nrows, ld;
+  const float* base;
+  int rowdiv;
+  bool vec;
 };
-__device__ __forceinline__ RowSrc make_row_src(const float* base, int64_t ld, int rowdiv, int64_t row, int64_t nrows) {
+__device__ __forceinline__ RowSrc make_row_src(const float* base, int64_t ld, int rowdiv, int64_t row0, int64_t nrows, int tid) {
   RowSrc r;
-  r.ok = row < nrows;
-  const int64_t src = rowdiv == 1 ? row : row / rowdiv;
-  r.p = base + (r.ok ? src * ld : 0);
-  r.vec = r.ok && ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(base) & 15) == 0);
+  r.base = base; r.ld = ld; r.rowdiv = rowdiv; r.nrows = nrows;
+  r.row = row0 + (tid >> 3);
+  r.p = base + (r.row < nrows ? (rowdiv == 1 ? r.row : r.row / rowdiv) * ld : 0);
+  r.vec = ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(base) & 15) == 0);
   return r;
 }
 __device__ __forceinline__ void load_tile_rows(const RowSrc& r, int k0, int K, int tid, f32x4 (&v)[4]) {
-  const int kb = k0 + (tid & 1) * 16;
+  const int k = k0 + (tid & 7) * 4;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    const int k = kb + 4 * q;
-    if (r.vec && k + 4 <= K) {
-      v[q] = *reinterpret_cast<const f32x4*>(r.p + k);
+    const int64_t row = r.row + 32 * q;
+    const bool ok = row < r.nrows;
+    const float* p = r.rowdiv == 1 ? r.p + (int64_t)(32 * q) * r.ld : r.base + (ok ? (row / r.rowdiv) * r.ld : 0);
+    if (ok && r.vec && k + 4 <= K) {
+      v[q] = *reinterpret_cast<const f32x4*>(p + k);
     } else {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[q][e] = (r.ok && k + e < K) ? r.p[k + e] : 0.f;
+      for (int e = 0; e < 4; ++e) v[q][e] = (ok && k + e < K) ? p[k + e] : 0.f;
     }
   }
 }
 
 __device__ __forceinline__ void store_tile_rows(float* lds, int tid, const f32x4 (&v)[4]) {
-  float* p = lds + (tid >> 1) * kGLD + (tid & 1) * 16;
+  float* p = lds + (tid >> 3) * kGLD + (tid & 7) * 4;
 #pragma unroll
-  for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(p + 4 * q) = v[q];
+  for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(p + 32 * q * kGLD) = v[q];
 }
 
 __global__ void __launch_bounds__(256) gemm_tn_kernel(GemmArgs a) {
@@ -89,8 +95,8 @@ __global__ void __launch_bounds__(256) gemm_tn_kernel(GemmArgs a) {
 #pragma unroll
   for (int sg = 0; sg < 2; ++sg) {
     if (sg < a.nseg) {
-      xa[sg] = make_row_src(a.seg[sg].X, a.seg[sg].ldx, a.seg[sg].rowdiv, m0 + (tid >> 1), a.M);
-      wb[sg] = make_row_src(a.seg[sg].W, a.seg[sg].ldw, 1, n0 + (tid >> 1), a.N);
+      xa[sg] = make_row_src(a.seg[sg].X, a.seg[sg].ldx, a.seg[sg].rowdiv, m0, a.M, tid);
+      wb[sg] = make_row_src(a.seg[sg].W, a.seg[sg].ldw, 1, n0, a.N, tid);
     } else {
       xa[sg] = xa[0]; wb[sg] = wb[0];
     }
