@@ -168,7 +168,7 @@ hipError_t launch_gemm_tn(const GemmArgs& a, hipStream_t stream) {
 // weight gradients: part[split][N x K] = A[m0:m1, 0:N]^T . B[m0:m1, 0:K]   (A = dZ, B = the layer's input segment)
 // ---------------------------------------------------------------------------------------------
 constexpr int kWLD = 132;   // LDS rows of 128 features padded to 132 floats
-constexpr int kWBM = 32;    // samples per staged step
+constexpr int kWBM = 32;    // samples per staged step (64: 54.9 ms per training step against 54.1)
 
 struct WgradArgs {
   const float* A; int64_t lda;               // (M, N)
@@ -182,23 +182,33 @@ struct WgradArgs {
 // 128 contiguous bytes of a row per instruction, in HBM and in LDS (the first version gave a thread 16 consecutive columns: lanes
 // 64 bytes apart, SQ_LDS_BANK_CONFLICT = half of the LDS cycles)
 __device__ __forceinline__ void load_tile_cols(const float* base, int64_t ld, int rowdiv, int64_t m0, int64_t m_end, int c0, int C, int tid,
-                                               f32x4 (&v)[4]) {
-  const int64_t m = m0 + (tid >> 3);
-  const bool row_ok = m < m_end;
-  const float* p = base + (row_ok ? (rowdiv == 1 ? m : m / rowdiv) * ld : 0);
-  const bool vec_ok = row_ok && ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(base) & 15) == 0);
+                                               f32x4 (&v)[kWBM / 8]) {
+  const bool vec_base = ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(base) & 15) == 0);
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int c = c0 + (tid & 7) * 4 + 32 * q;
-    if (vec_ok && c + 4 <= C) {
-      v[q] = *reinterpret_cast<const f32x4*>(p + c);
-    } else {
+  for (int rd = 0; rd < kWBM / 32; ++rd) {
+    const int64_t m = m0 + 32 * rd + (tid >> 3);
+    const bool row_ok = m < m_end;
+    const float* p = base + (row_ok ? (rowdiv == 1 ? m : m / rowdiv) * ld : 0);
+    const bool vec_ok = row_ok && vec_base;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[q][e] = (row_ok && c + e < C) ? p[c + e] : 0.f;
+    for (int q = 0; q < 4; ++q) {
+      const int c = c0 + (tid & 7) * 4 + 32 * q;
+      if (vec_ok && c + 4 <= C) {
+        v[4 * rd + q] = *reinterpret_cast<const f32x4*>(p + c);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[4 * rd + q][e] = (row_ok && c + e < C) ? p[c + e] : 0.f;
+      }
     }
   }
 }
 
+// One workgroup = one 128 x 128 tile of dW over a range of samples; each of its four waves accumulates the WHOLE tile (16 MFMA
+// tiles = 256 accumulator registers, one wave per SIMD) over a quarter of every staged 32-sample step and writes its own partial.
+// Lane (r, h) reads ONE 16-byte piece per operand and sample pair -- features n0 + 4 r .. + 3 of sample 2 p + h -- and uses its four
+// values as the A (or B) operand of FOUR tiles: tile e holds the features n0 + 4 i + e, so one A read and one B read feed 16 MFMAs
+// (the fused weight-gradient kernel's fragment scheme, csrc/aon_wgrad.h).  The first version read one float per operand and MFMA
+// (64 x 64 per wave): 64 LDS reads per 64 MFMAs, 0.44 of the matrix pipe.
 __global__ void __launch_bounds__(256) wgrad_nk_kernel(WgradArgs a) {
   __shared__ __attribute__((aligned(16))) float As[kWBM * kWLD];
   __shared__ __attribute__((aligned(16))) float Bs[kWBM * kWLD];
@@ -207,26 +217,26 @@ __global__ void __launch_bounds__(256) wgrad_nk_kernel(WgradArgs a) {
   const int n0 = blockIdx.x * 128, k0 = blockIdx.y * 128;
   const int64_t mb = (int64_t)blockIdx.z * a.rows_per_split;
   const int64_t me = mb + a.rows_per_split < a.M ? mb + a.rows_per_split : a.M;
-  const int wr = (wave & 1) * 64, wc = (wave >> 1) * 64;
-  f32x16 acc[2][2];
+  f32x16 acc[4][4];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-  f32x4 va[4], vb[4];
+  f32x4 va[kWBM / 8], vb[kWBM / 8];
   if (mb < me) {
     load_tile_cols(a.A, a.lda, 1, mb, me, n0, a.N, tid, va);
     load_tile_cols(a.B, a.ldb, a.rowdiv, mb, me, k0, a.K, tid, vb);
   }
   for (int64_t m = mb; m < me; m += kWBM) {
     __syncthreads();
-    {
-      float* pa = As + (tid >> 3) * kWLD + (tid & 7) * 4;
-      float* pb = Bs + (tid >> 3) * kWLD + (tid & 7) * 4;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) { *reinterpret_cast<f32x4*>(pa + 32 * q) = va[q]; *reinterpret_cast<f32x4*>(pb + 32 * q) = vb[q]; }
+    for (int rd = 0; rd < kWBM / 32; ++rd) {
+      float* pa = As + (32 * rd + (tid >> 3)) * kWLD + (tid & 7) * 4;
+      float* pb = Bs + (32 * rd + (tid >> 3)) * kWLD + (tid & 7) * 4;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { *reinterpret_cast<f32x4*>(pa + 32 * q) = va[4 * rd + q]; *reinterpret_cast<f32x4*>(pb + 32 * q) = vb[4 * rd + q]; }
     }
     __syncthreads();
     if (m + kWBM < me) {
@@ -234,30 +244,36 @@ __global__ void __launch_bounds__(256) wgrad_nk_kernel(WgradArgs a) {
       load_tile_cols(a.B, a.ldb, a.rowdiv, m + kWBM, me, k0, a.K, tid, vb);
     }
 #pragma unroll
-    for (int ks = 0; ks < kWBM / 2; ++ks) {
-      float fa[2], fb[2];
+    for (int p = 0; p < kWBM / 8; ++p) {           // this wave's samples (kWBM / 4) w + 2 p + h of the step
+      const int ml = (kWBM / 4) * wave + 2 * p + h;
+      const f32x4 fa = *reinterpret_cast<const f32x4*>(As + ml * kWLD + 4 * r);
+      const f32x4 fb = *reinterpret_cast<const f32x4*>(Bs + ml * kWLD + 4 * r);
 #pragma unroll
-      for (int i = 0; i < 2; ++i) fa[i] = As[(2 * ks + h) * kWLD + wr + 32 * i + r];
+      for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) fb[j] = Bs[(2 * ks + h) * kWLD + wc + 32 * j + r];
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
     }
   }
-  float* out = a.part + (int64_t)blockIdx.z * a.N * a.K;
+  // this wave's partial: tile (i, j), register x, lane (r, h) holds dW[n0 + 4 (8 (x >> 2) + (x & 3) + 4 h) + i][k0 + 4 r + j]
+  float* out = a.part + ((int64_t)blockIdx.z * 4 + wave) * a.N * a.K;
+  const int kc = k0 + 4 * r;
+  const bool vec = (a.K & 3) == 0 && kc + 4 <= a.K;
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int k = k0 + wc + 32 * j + r;
-    if (k >= a.K) continue;
+  for (int i = 0; i < 4; ++i) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int x = 0; x < 16; ++x) {
+      const int n = n0 + 4 * (8 * (x >> 2) + (x & 3) + 4 * h) + i;
+      if (n >= a.N) continue;
+      float* o = out + (int64_t)n * a.K + kc;
+      if (vec) {
+        f32x4 v; v[0] = acc[i][0][x]; v[1] = acc[i][1][x]; v[2] = acc[i][2][x]; v[3] = acc[i][3][x];
+        *reinterpret_cast<f32x4*>(o) = v;
+      } else {
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int n = n0 + wr + 32 * i + 8 * (e >> 2) + (e & 3) + 4 * h;
-        if (n < a.N) out[(int64_t)n * a.K + k] = acc[i][j][e];
+        for (int j = 0; j < 4; ++j)
+          if (kc + j < a.K) o[j] = acc[i][j][x];
       }
+    }
   }
 }
 
@@ -309,17 +325,19 @@ hipError_t launch_transpose(const float* W, int64_t ldw, int N, int K, float* WT
   return hipGetLastError();
 }
 
-// number of sample splits of a weight-gradient product: enough workgroups to fill the chip, at least 4,096 samples each
+// number of sample splits (workgroups per output tile) of a weight-gradient product: about one workgroup per CU in total (a
+// workgroup holds 256 accumulator registers per lane: one wave per SIMD), at least 2,048 samples each; every workgroup leaves
+// FOUR partials (one per wave)
 int wgrad_splits(int64_t M, int N, int K) {
   const int tiles = ((N + 127) / 128) * ((K + 127) / 128);
-  int64_t s = (512 + tiles - 1) / tiles;
-  const int64_t cap = (M + 4095) / 4096;
+  int64_t s = (256 + tiles - 1) / tiles;
+  const int64_t cap = (M + 2047) / 2048;
   if (s > cap) s = cap;
   if (s < 1) s = 1;
   if (s > 256) s = 256;
   return (int)s;
 }
-int64_t wgrad_part_floats(int64_t M, int N, int K) { return (int64_t)wgrad_splits(M, N, K) * N * K; }
+int64_t wgrad_part_floats(int64_t M, int N, int K) { return (int64_t)wgrad_splits(M, N, K) * 4 * N * K; }
 
 // dW[0:N, 0:K] (row stride ldd: a column block of an nn.Linear weight) = A^T B, bias gradient optional
 hipError_t launch_wgrad_nk(const float* A, int64_t lda, const float* B, int64_t ldb, int rowdiv, int64_t M, int N, int K, float* dW, int64_t ldd,
@@ -331,7 +349,7 @@ hipError_t launch_wgrad_nk(const float* A, int64_t lda, const float* B, int64_t 
   WgradArgs a{A, lda, B, ldb, rowdiv, M, N, K, rows, part};
   wgrad_nk_kernel<<<dim3((unsigned)((N + 127) / 128), (unsigned)((K + 127) / 128), (unsigned)splits), dim3(256), 0, stream>>>(a);
   const int64_t count = (int64_t)N * K;
-  reduce_kernel<<<dim3((unsigned)((count + 255) / 256)), dim3(256), 0, stream>>>(part, splits, count, K, ldd, dW);
+  reduce_kernel<<<dim3((unsigned)((count + 255) / 256)), dim3(256), 0, stream>>>(part, splits * 4, count, K, ldd, dW);
   return hipGetLastError();
 }
 
