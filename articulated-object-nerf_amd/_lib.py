@@ -85,6 +85,7 @@ _SIGS = {
     # constructor arguments beyond the defaults (aon_render_opts; the *_ex forms take the struct pointer last)
     "aon_render_opts_init": (None, [_p]),
     "aon_pack_vanilla_mlp_deg": (_i, [_p, _i, _i, _i, _p, _p]),
+    "aon_pack_vanilla_mlp_bwd_deg": (_i, [_p, _i, _i, _i, _p, _p]),
     "aon_sample_along_rays_ex": (_i, [_p, _p, _l, _i, _f, _f, _i, _f, _f, _p, _p, _p, _p]),
     "aon_composite_ex": (_i, [_p, _i, _p, _i, _p, _p, _l, _i, _i, _i, _p, _p, _p, _p, _p, _p]),
     "aon_sample_pdf_n": (_i, [_p, _p, _l, _p, _p, _l, _l, _i, _i, _i, _p, _p, _p]),

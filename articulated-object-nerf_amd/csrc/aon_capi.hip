@@ -32,7 +32,9 @@ hipError_t launch_mlp_fwd_train(const char* packed, const float* rays_o, const f
 hipError_t launch_composite_bwd(const float* raw, const float* t_vals, const float* dirs, const float* g_rgb, const float* g_acc,
                                 const float* g_depth, int64_t n_rays, int S, int white_bkgd, const ActParams& ap, float* d_raw,
                                 hipStream_t stream);
-hipError_t launch_pack_vanilla_bwd(const float* const* params, float* packed, hipStream_t stream);
+hipError_t launch_pack_vanilla_bwd(const float* const* params, float* packed, hipStream_t stream, int pos_size = 63, int view_size = 27);
+hipError_t launch_mlp_fwd_train_enc(const char* packed, const float* samples_enc, const float* viewdirs_enc, int64_t n_rays, int S, float* raw,
+                                    float* planes, void* masks, hipStream_t stream);
 int64_t bwd_stream_bytes();
 hipError_t launch_mlp_bwd_chain(const char* packed_bwd, const char* packed_fwd, const float* d_raw, const void* masks,
                                 float* dplanes, int64_t Np, hipStream_t stream);
@@ -430,6 +432,17 @@ int aon_pack_vanilla_mlp_bwd(const float* const* params_host, void* packed_bwd, 
   return check(aon::launch_pack_vanilla_bwd(params_host, static_cast<float*>(packed_bwd), (hipStream_t)stream), "aon_pack_vanilla_mlp_bwd");
 }
 
+int aon_pack_vanilla_mlp_bwd_deg(const float* const* params_host, int min_deg_point, int max_deg_point, int deg_view, void* packed_bwd, void* stream) {
+  if (!params_host || !packed_bwd) return fail(AON_E_INVALID, "aon_pack_vanilla_mlp_bwd_deg: null pointer");
+  for (int i = 0; i < aon::kNumVanillaParams; ++i)
+    if (!params_host[i]) return fail(AON_E_INVALID, "aon_pack_vanilla_mlp_bwd_deg: null parameter pointer");
+  const int L = max_deg_point - min_deg_point;
+  if (L < 0 || L > 10 || deg_view < 0 || deg_view > 4)
+    return fail(AON_E_INVALID, "aon_pack_vanilla_mlp_bwd_deg: up to 10 position and 4 view frequency levels");
+  return check(aon::launch_pack_vanilla_bwd(params_host, static_cast<float*>(packed_bwd), (hipStream_t)stream, 3 + 6 * L, 3 + 6 * deg_view),
+               "aon_pack_vanilla_mlp_bwd_deg");
+}
+
 int64_t aon_train_mask_bytes(int64_t Np) { return (int64_t)aon::kMaskLayers * Np * 2 * 16; }
 
 int aon_mlp_fwd_train(const void* packed, const float* rays_o, const float* rays_d, const float* viewdirs, const float* t_vals,
@@ -706,6 +719,7 @@ struct TrainLevel {
   float* raw;      // Np*4 (first n*S records valid)
   float* planes;   // rows*Np
   char* masks;     // mask_layers*Np*32
+  float* coords; float* enc; float* venc;   // other encoding degrees only: n*S*3, n*S*63, n*27 (forward-only temporaries)
   int S; int64_t Np;
 };
 // What the forward leaves for the backward (caller-owned, pinned by the autograd graph): per level t, raw, planes, ReLU bits.
@@ -723,8 +737,10 @@ struct TrainScratch {
   float* dxp[2];      // Np*4 (articulated)
   float* wgrad_ws[2];
   float* lat_tmp;     // 288 floats: second level's latent gradients before they are added (articulated)
+  float* grad_tmp[2]; // other encoding degrees: the three encoding-fed weight gradients in the kernels' 63 / 27-column layout
   int64_t bytes;
 };
+constexpr int64_t kGradTmpFloats = 256 * 63 + 256 * (256 + 63) + 128 * (256 + 27);
 
 int64_t level_np(int64_t n, int l, const Geo& g) { return align_up(n * g.S(l), 128); }
 
@@ -743,6 +759,11 @@ TrainWs carve_train(char* base, int64_t n, bool art, int num_levels, const Geo& 
     w.lvl[l].raw = reinterpret_cast<float*>(take(Np * 16));
     w.lvl[l].planes = reinterpret_cast<float*>(take(rows * Np * 4));
     w.lvl[l].masks = take(mlayers * Np * 32);
+    if (g.other_degrees && !art) {
+      w.lvl[l].coords = reinterpret_cast<float*>(take(n * S * 12));
+      w.lvl[l].enc = reinterpret_cast<float*>(take(n * S * (int64_t)aon::kPosEnc * 4));
+      w.lvl[l].venc = reinterpret_cast<float*>(take(n * (int64_t)aon::kViewEnc * 4));
+    }
   }
   w.w_c = reinterpret_cast<float*>(take(n * g.Sc * 4));
   w.bytes = off;
@@ -760,10 +781,23 @@ TrainScratch carve_scratch(char* base, int64_t n, bool art, int num_levels, cons
     sc.dplanes[l] = reinterpret_cast<float*>(take(rows * Np * 4));
     sc.dxp[l] = reinterpret_cast<float*>(take(Np * 16));
     sc.wgrad_ws[l] = reinterpret_cast<float*>(take(aon::wgrad_workspace_bytes()));
+    if (g.other_degrees && !art) sc.grad_tmp[l] = reinterpret_cast<float*>(take(kGradTmpFloats * 4));
   }
   sc.lat_tmp = reinterpret_cast<float*>(take(288 * 4));
   sc.bytes = off;
   return sc;
+}
+
+// dst (rows, hidden + 3 + 6 L) <- src (rows, hidden + 3 + 6 Lfull): the columns of an encoding with L levels picked out of the
+// kernels' Lfull-level slot layout [x ; first block of 3 Lfull ; shifted block of 3 Lfull]
+__global__ void remap_enc_cols_kernel(const float* __restrict__ src, float* __restrict__ dst, int rows, int hidden, int L, int Lfull) {
+  const int cols = hidden + 3 + 6 * L, lds = hidden + 3 + 6 * Lfull;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)rows * cols) return;
+  const int r = (int)(i / cols), c = (int)(i % cols);
+  int sc = c;
+  if (c >= hidden + 3 + 3 * L) sc = c + 3 * (Lfull - L);
+  dst[i] = src[(int64_t)r * lds + sc];
 }
 
 __global__ void add_into_kernel(float* __restrict__ dst, const float* __restrict__ src, int n) {
@@ -854,7 +888,7 @@ int train_fwd_impl(const char* who, bool art, const TrainNet* nets, const float*
   Geo g;
   if (const char* bad = make_geo(opts, g)) return fail(AON_E_INVALID, bad);
   if (g.Sf > 512) return fail(AON_E_INVALID, "train forward: more than 512 samples per ray at the fine level");
-  if (g.other_degrees) return fail(AON_E_INVALID, "train forward: the fused training kernels are compiled for degrees (0, 10, 4); other degrees train through aon_grender_fwd_train");
+  if (g.other_degrees && art) return fail(AON_E_INVALID, "train forward: the articulated network has kernels for degrees (0, 10, 4) only");
   if (n <= 0 || (num_levels != 1 && num_levels != 2)) return fail(AON_E_INVALID, "train forward: bad size / num_levels");
   if (!rays_o || !rays_d || !viewdirs || !workspace) return fail(AON_E_INVALID, "train forward: null pointer");
   if (reinterpret_cast<uintptr_t>(workspace) & 255) return fail(AON_E_INVALID, "train forward: workspace must be 256-byte aligned");
@@ -877,7 +911,15 @@ int train_fwd_impl(const char* who, bool art, const TrainNet* nets, const float*
                                                             L.t, stream), who);
     }
     if (rc) return rc;
-    {
+    if (g.other_degrees) {
+      // other encoding degrees: encodings by the stage kernels in the padded 63 / 27-slot layout, then the training forward on
+      // caller-encoded inputs (same planes, same decision bits)
+      if ((rc = check(aon::launch_cast_rays(L.t, rays_o, rays_d, n, L.S, L.coords, stream), who))) return rc;
+      if ((rc = check(aon::launch_pos_enc(L.coords, n * L.S, g.min_deg, g.max_deg, L.enc, stream, aon::kPosEnc, 10), who))) return rc;
+      if ((rc = check(aon::launch_pos_enc(viewdirs, n, 0, g.deg_view, L.venc, stream, aon::kViewEnc, 4), who))) return rc;
+      MlpTimer timer(stream, n * L.S);
+      rc = check(aon::launch_mlp_fwd_train_enc(static_cast<const char*>(nets[l].packed_fwd), L.enc, L.venc, n, L.S, L.raw, L.planes, L.masks, stream), who);
+    } else {
       MlpTimer timer(stream, n * L.S);
       rc = check(art ? aon::launch_art_mlp_fwd_train(static_cast<const char*>(nets[l].packed_fwd), nets[l].small, rays_o, rays_d, viewdirs, L.t, n, L.S,
                                                      L.raw, L.planes, L.masks, stream)
@@ -1017,7 +1059,23 @@ int aon_render_bwd_ex(const void* packed_bwd_coarse, const void* packed_fwd_coar
     if (rc) return rc;
     {
       KTimer timer(kWgrad, stream, L.Np);
-      rc = check(aon::launch_vanilla_wgrad(L.planes, sc.dplanes[l], sc.d_raw[l], L.Np, grads[l], sc.wgrad_ws[l], stream, fork.aux(l)), "aon_render_bwd");
+      float* gl[aon::kNumVanillaParams];
+      for (int i = 0; i < aon::kNumVanillaParams; ++i) gl[i] = grads[l][i];
+      if (g.other_degrees) {   // the three encoding-fed weights come out in the kernels' 63 / 27-column layout, then lose the empty slots
+        gl[0] = sc.grad_tmp[l]; gl[10] = gl[0] + 256 * 63; gl[16] = gl[10] + 256 * (256 + 63);
+      }
+      rc = check(aon::launch_vanilla_wgrad(L.planes, sc.dplanes[l], sc.d_raw[l], L.Np, gl, sc.wgrad_ws[l], stream, fork.aux(l)), "aon_render_bwd");
+      if (!rc && g.other_degrees) {
+        const int Lp = g.max_deg - g.min_deg, P = 3 + 6 * Lp, V = 3 + 6 * g.deg_view;
+        auto remap = [&](const float* src, float* dst, int rows, int hidden, int Lx, int Lfull, int cols) {
+          const int64_t tot = (int64_t)rows * cols;
+          remap_enc_cols_kernel<<<dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream>>>(src, dst, rows, hidden, Lx, Lfull);
+        };
+        remap(gl[0], grads[l][0], 256, 0, Lp, 10, P);
+        remap(gl[10], grads[l][10], 256, 256, Lp, 10, 256 + P);
+        remap(gl[16], grads[l][16], 128, 256, g.deg_view, 4, 256 + V);
+        rc = check(hipGetLastError(), "aon_render_bwd");
+      }
     }
     if (rc) return rc;
   }

@@ -122,7 +122,8 @@ constexpr int kLdsBytes = kRingBytes + (int)kSmallBytes;
 // TRAIN additionally stores every layer's input/output activations as step-major planes (aon_mlp_core.h) for the backward pass.
 template <bool ENC_IN_KERNEL, bool TRAIN>
 __global__ void __launch_bounds__(256) mlp_fwd_kernel(MlpArgs args) {
-  static_assert(!TRAIN || ENC_IN_KERNEL, "the training path re-encodes from x[] / vd[], which only the in-kernel encoding fills");
+  // <false, true>: training on caller-encoded inputs (other encoding degrees in the padded 63 / 27-slot layout): where the
+  // in-kernel form re-encodes from x[] / vd[], this one re-reads the encodings.
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* sm = reinterpret_cast<float*>(smem + kRingBytes);
 
@@ -160,11 +161,7 @@ __global__ void __launch_bounds__(256) mlp_fwd_kernel(MlpArgs args) {
       encode_pos(x, h, E);
       encode_view(vd, h, V);
     } else {
-      const float* se = args.samples_enc + gc * kPosEnc;
-#pragma unroll
-      for (int rho = 0; rho < 30; ++rho) E[rho >> 4][rho & 15] = se[3 + rho + 30 * h];
-      E[1][14] = h ? se[2] : se[0];
-      E[1][15] = h ? 0.f : se[1];
+      load_pos_enc(args.samples_enc + gc * kPosEnc, h, E);
       load_view_enc(args.viewdirs_enc + ray * kViewEnc, h, V);
     }
 
@@ -210,10 +207,15 @@ __global__ void __launch_bounds__(256) mlp_fwd_kernel(MlpArgs args) {
     // L5: cat[h(256), enc(63)] -> 256     (model.py:102-103: concat after layer 4's ReLU)
     mw = u32x4{0u, 0u, 0u, 0u}; init_bias(Y, sm + kSmBias + 5 * 256, h);
     dense_layer<VanillaNet, kChL5, 8, 8>(p, X, Y, consume(X, plane_h(4), mw, true)); put_mask(mw, 4);
-    if constexpr (TRAIN) {  // (x made opaque: otherwise the two identical encodings are merged and the first stays live)
+    if constexpr (TRAIN && ENC_IN_KERNEL) {  // (x made opaque: otherwise the two identical encodings are merged and the first stays live)
       asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]));
       encode_pos(x, h, E);
     }  // re-encoded (same function, same bits) instead of 32 registers held live across layers 1-4
+    if constexpr (TRAIN && !ENC_IN_KERNEL) {
+      int64_t gq = gc;
+      asm volatile("" : "+v"(gq));   // opaque: a second read, not the first one kept live
+      load_pos_enc(args.samples_enc + gq * kPosEnc, h, E);
+    }
     chunk_mma<VanillaNet, kChL5 + 8, 8, 16>(p, E[0], Y);
     chunk_mma<VanillaNet, kChL5 + 9, 8, 16>(p, E[1], Y);
     relu_tiles(Y);
@@ -229,10 +231,15 @@ __global__ void __launch_bounds__(256) mlp_fwd_kernel(MlpArgs args) {
     f32x16 Z[4];
     init_bias(Z, sm + kSmBiasView, h);
     dense_layer<VanillaNet, kChView, 8, 4>(p, X, Z, consume(X, kPlBot, mw, false));
-    if constexpr (TRAIN) {
+    if constexpr (TRAIN && ENC_IN_KERNEL) {
       asm volatile("" : "+v"(vd[0]), "+v"(vd[1]), "+v"(vd[2]));
       encode_view(vd, h, V);
     }  // likewise: 16 registers not held across the trunk
+    if constexpr (TRAIN && !ENC_IN_KERNEL) {
+      int64_t rq = ray;
+      asm volatile("" : "+v"(rq));
+      load_view_enc(args.viewdirs_enc + rq * kViewEnc, h, V);
+    }
     chunk_mma<VanillaNet, kChView + 8, 4, 14>(p, V, Z);
     relu_tiles(Z);
     if constexpr (TRAIN) {  // the view layer's output feeds the rgb head on the VALU: no consuming chunk, 64 values stored here
@@ -309,6 +316,16 @@ hipError_t launch_mlp_fwd_train(const char* packed, const float* rays_o, const f
   a.raw = raw; a.total = n_rays * S; a.S = S; a.npass = (int)((a.total + 127) / 128);
   a.planes = planes; a.masks = static_cast<u32x4*>(masks); a.Np = (int64_t)a.npass * 128;
   return launch_mlp_t<true, true>(a, stream);
+}
+
+// training forward on caller-encoded inputs (padded 63 / 27-column layout): planes and decision bits as launch_mlp_fwd_train
+hipError_t launch_mlp_fwd_train_enc(const char* packed, const float* samples_enc, const float* viewdirs_enc, int64_t n_rays, int S, float* raw,
+                                    float* planes, void* masks, hipStream_t stream) {
+  MlpArgs a{};
+  a.packed = packed; a.samples_enc = samples_enc; a.viewdirs_enc = viewdirs_enc;
+  a.raw = raw; a.total = n_rays * S; a.S = S; a.npass = (int)((a.total + 127) / 128);
+  a.planes = planes; a.masks = static_cast<u32x4*>(masks); a.Np = (int64_t)a.npass * 128;
+  return launch_mlp_t<false, true>(a, stream);
 }
 
 hipError_t launch_mlp_fwd_enc(const char* packed, const float* samples_enc, const float* viewdirs_enc,

@@ -515,6 +515,13 @@ __device__ __forceinline__ void encode_view(const float (&vd)[3], int h, f32x16&
   V[14] = 0.f; V[15] = 0.f;
 }
 
+__device__ __forceinline__ void load_pos_enc(const float* se, int h, f32x16 (&E)[2]) {  // caller-encoded (n*S,63)
+#pragma unroll
+  for (int rho = 0; rho < 30; ++rho) E[rho >> 4][rho & 15] = se[3 + rho + 30 * h];
+  E[1][14] = h ? se[2] : se[0];
+  E[1][15] = h ? 0.f : se[1];
+}
+
 __device__ __forceinline__ void load_view_enc(const float* ve, int h, f32x16& V) {  // caller-encoded (n,27)
 #pragma unroll
   for (int rho = 0; rho < 12; ++rho) V[rho] = ve[3 + rho + 12 * h];

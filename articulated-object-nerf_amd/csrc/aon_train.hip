@@ -168,7 +168,9 @@ struct PackArgs24 {
   const float* p[kNumVanillaParams];
 };
 
-__global__ void pack_vanilla_bwd_kernel(PackArgs24 a, float* __restrict__ packed) {
+// P / V: widths of the network's encodings (63 / 27 by default; other degrees: only the row strides of the two concatenating layers
+// change -- the chain never needs the encoding columns, gradients do not reach the inputs)
+__global__ void pack_vanilla_bwd_kernel(PackArgs24 a, float* __restrict__ packed, int P, int V) {
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= kBwStreamBytes / 4) return;
   const int c = (int)(idx / (kBigChunkBytes / 4)), r = (int)(idx % (kBigChunkBytes / 4));
@@ -177,11 +179,11 @@ __global__ void pack_vanilla_bwd_kernel(PackArgs24 a, float* __restrict__ packed
   const int h = lane >> 5, f = 32 * tp + (lane & 31);
   const int jo = 8 * q + 4 * h + cc;
   const float* W; int ld, j;
-  if (c < kBwBott) { W = a.p[16]; ld = 256 + kViewEnc; j = 32 * c + jo; }
+  if (c < kBwBott) { W = a.p[16]; ld = 256 + V; j = 32 * c + jo; }
   else if (c < kBwL7) { W = a.p[18]; ld = 256; j = 32 * (c - kBwBott) + jo; }
   else {
     const int l = 7 - (c - kBwL7) / 8;  // 7,6,5,4,3,2,1
-    W = a.p[2 * l]; ld = l == 5 ? 256 + kPosEnc : 256; j = 32 * ((c - kBwL7) % 8) + jo;
+    W = a.p[2 * l]; ld = l == 5 ? 256 + P : 256; j = 32 * ((c - kBwL7) % 8) + jo;
   }
   packed[idx] = W[(int64_t)j * ld + f];
 }
@@ -289,11 +291,11 @@ __global__ void __launch_bounds__(256) mlp_bwd_chain_kernel(BwdArgs args) {
 // ---------------------------------------------------------------------------------------------
 int num_cus();  // aon_mlp.hip
 
-hipError_t launch_pack_vanilla_bwd(const float* const* params, float* packed, hipStream_t stream) {
+hipError_t launch_pack_vanilla_bwd(const float* const* params, float* packed, hipStream_t stream, int pos_size, int view_size) {
   PackArgs24 a;
   for (int i = 0; i < kNumVanillaParams; ++i) a.p[i] = params[i];
   const int64_t n = kBwStreamBytes / 4;
-  pack_vanilla_bwd_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream>>>(a, packed);
+  pack_vanilla_bwd_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream>>>(a, packed, pos_size, view_size);
   return hipGetLastError();
 }
 

@@ -70,8 +70,8 @@ class NeRFMLP(nn.Module):
         out = None if fresh else self._streams.get(kind)
         if out is not None and out.device != dev:
             out = None
-        if kind == "fwd" and not self.geometry.is_default:   # other degrees on the fused inference kernels (fits_fused_inference)
-            out = ops.pack_vanilla_mlp(params, out=out, degrees=(self.min_deg_point, self.max_deg_point, self.deg_view))
+        if not self.geometry.is_default:   # other degrees on the fused kernels (fits_fused_inference): zero-weight slots
+            out = getattr(ops, self._PACKERS[kind])(params, out=out, degrees=(self.min_deg_point, self.max_deg_point, self.deg_view))
         else:
             out = getattr(ops, self._PACKERS[kind])(params, out=out)
         if not fresh:
@@ -122,9 +122,12 @@ class NeRF(nn.Module):
         self.coarse_mlp = NeRFMLP(min_deg_point, max_deg_point, deg_view)
         self.fine_mlp = NeRFMLP(min_deg_point, max_deg_point, deg_view)
         geom = self.coarse_mlp.geometry
-        self._general = not geom.is_default            # other encoding degrees: training on the layer-wise engine ...
-        self._fused_inference = geom.fits_fused_inference   # ... inference on the fused kernels when the levels fit their 63 / 27 slots
-        if self._general and self._fused_inference:
+        # other encoding degrees: on the fused kernels (inference AND training) when the levels fit their 63 / 27 input slots -- zero-weight
+        # slots in the packed streams, encodings in the padded layout -- else on the layer-wise engine
+        self._fused_inference = geom.fits_fused_inference
+        self._general = not geom.is_default and not self._fused_inference
+        self._fused_training = True      # (tests / measurements: False sends the training step of a padded-slot network to the layer-wise engine)
+        if not geom.is_default and self._fused_inference:
             self._opts.degrees = (min_deg_point, max_deg_point, deg_view)
 
     def _draw_noise(self, noise, randomized, n, device):
@@ -146,20 +149,18 @@ class NeRF(nn.Module):
         else:
             t_rand, u = None, None
         noise = self._draw_noise(noise, randomized, n, rays_o.device)
-        if self._general:
+        training = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        layerwise = self._general or not self._fused_inference or (training and not self._fused_training and not self.coarse_mlp.geometry.is_default)
+        if layerwise:
             geom = self.coarse_mlp.geometry
             mlps = [self.coarse_mlp, self.fine_mlp][: self.num_levels]
-            if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            if training:
                 if n == 0:
                     raise ValueError("empty ray batch in training mode")
                 params = [p for m in mlps for p in m.ordered_params()]
                 flat = RenderGeneral.apply(rays_o, rays["rays_d"], rays["viewdirs"], float(near), float(far), bool(white_bkgd),
                                            self.num_levels, t_rand, u, geom, self._opts, noise, *params)
                 return [tuple(flat[3 * i: 3 * i + 3]) for i in range(self.num_levels)]
-            if self._fused_inference:
-                outs = ops.render_fwd(mlps[0].packed(), mlps[1].packed() if self.num_levels == 2 else None, rays_o, rays["rays_d"],
-                                      rays["viewdirs"], near, far, white_bkgd, self.num_levels, t_rand, u, opts=self._opts, noise=noise)
-                return [tuple(o) for o in outs]
             pd = [dict(m.named_parameters()) for m in mlps]
             outs = ops.grender_fwd(geom, pd[0], pd[1] if self.num_levels == 2 else None, rays_o, rays["rays_d"], rays["viewdirs"], near, far,
                                    white_bkgd, self.num_levels, t_rand, u, opts=self._opts, noise=noise)

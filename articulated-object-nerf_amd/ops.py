@@ -576,15 +576,31 @@ def art_render_fwd(packed_c, small_c, packed_f, small_f, rays_o, rays_d, viewdir
 
 
 # ------------------------------------------------------------------ R14 training (vanilla)
-def pack_vanilla_mlp_bwd(params: dict, out: torch.Tensor | None = None) -> torch.Tensor:
+def vanilla_param_shapes(degrees=(0, 10, 4)) -> dict:
+    """Shapes of a default-size NeRFMLP with the given encoding degrees (the fused kernels' networks)."""
+    mn, mx, dv = degrees
+    P, V = 3 + 6 * (mx - mn), 3 + 6 * dv
+    shapes = dict(VANILLA_PARAM_SHAPES)
+    shapes.update({"pts_linears.0.weight": (256, P), "pts_linears.5.weight": (256, 256 + P), "views_linear.0.weight": (128, 256 + V)})
+    return shapes
+
+
+def pack_vanilla_mlp_bwd(params: dict, out: torch.Tensor | None = None, degrees=(0, 10, 4)) -> torch.Tensor:
     """Transposed weight stream for the backward data chain (re-pack whenever the parameters change)."""
+    shapes = vanilla_param_shapes(degrees)
     tensors = [_f32(params[name].detach(), name) for name in VANILLA_PARAM_ORDER]
+    for name, t in zip(VANILLA_PARAM_ORDER, tensors):
+        if tuple(t.shape) != shapes[name]:
+            raise ValueError(f"{name}: shape {tuple(t.shape)} != {shapes[name]} for encoding degrees {tuple(degrees)}")
     dev = tensors[0].device
     if out is None:
         out = torch.empty(int(lib.aon_bwd_packed_bytes()), dtype=torch.uint8, device=dev)
     arr = (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
     with torch.cuda.device(dev):
-        check(lib.aon_pack_vanilla_mlp_bwd(arr, _ptr(out), _stream()), "aon_pack_vanilla_mlp_bwd")
+        if tuple(degrees) == (0, 10, 4):
+            check(lib.aon_pack_vanilla_mlp_bwd(arr, _ptr(out), _stream()), "aon_pack_vanilla_mlp_bwd")
+        else:
+            check(lib.aon_pack_vanilla_mlp_bwd_deg(arr, degrees[0], degrees[1], degrees[2], _ptr(out), _stream()), "aon_pack_vanilla_mlp_bwd_deg")
     return out
 
 
@@ -785,10 +801,12 @@ def _ptr_array(tensors):
 
 def render_bwd(ws, packs_bwd, packs_fwd, rays_d, white_bkgd, num_levels, g_rgb, g_acc, g_depth, geometry=None):
     """loss.backward() through render_fwd_train (vanilla): g_* = per-level lists (entries may be None except g_rgb)
-    -> per-level dicts of the 24 parameter gradients."""
+    -> per-level dicts of the 24 parameter gradients (shapes of the network's own encoding degrees, read from `geometry`)."""
     d = _f32(rays_d, "rays_d")
     n, dev = d.shape[0], d.device
-    grads = [{name: torch.empty(VANILLA_PARAM_SHAPES[name], dtype=torch.float32, device=dev) for name in VANILLA_PARAM_ORDER} for _ in range(num_levels)]
+    st0 = None if geometry is None else geometry[0]
+    shapes = vanilla_param_shapes((0, 10, 4) if st0 is None else (st0.min_deg_point, st0.max_deg_point, st0.deg_view))
+    grads = [{name: torch.empty(shapes[name], dtype=torch.float32, device=dev) for name in VANILLA_PARAM_ORDER} for _ in range(num_levels)]
     garr = [_ptr_array([g[nm] for nm in VANILLA_PARAM_ORDER]) for g in grads] + [None] * (2 - num_levels)
     pb, pf = list(packs_bwd) + [None] * (2 - num_levels), list(packs_fwd) + [None] * (2 - num_levels)
     keep = [None if t is None else _f32(t, "grad") for t in list(g_rgb) + list(g_acc) + list(g_depth)]

@@ -83,6 +83,11 @@ int aon_pack_vanilla_mlp(const float* const* params_host, void* packed, void* st
  * 3 + 6 deg_view)): same stream size, zero weight in the slots of the missing levels.  Consumed by aon_render_fwd_ex with the same
  * degrees in aon_render_opts, or by aon_mlp_fwd_enc on encodings in the padded 63 / 27-column layout. */
 int aon_pack_vanilla_mlp_deg(const float* const* params_host, int min_deg_point, int max_deg_point, int deg_view, void* packed, void* stream);
+/* ... and its transposed twin for the backward data chain (aon_pack_vanilla_mlp_bwd): with these two streams and the degrees in
+ * aon_render_opts, aon_render_fwd_train_ex / aon_render_bwd_ex train such a network on the fused kernels too -- the forward on
+ * encodings in the padded layout, the three encoding-fed weight gradients (pts_linears.0, pts_linears.5, views_linear.0) written in
+ * the network's own (3 + 6 L)-wide column order. */
+int aon_pack_vanilla_mlp_bwd_deg(const float* const* params_host, int min_deg_point, int max_deg_point, int deg_view, void* packed_bwd, void* stream);
 
 /* ---- R3(cast)+R4+R5  cast_rays + pos_enc + NeRFMLP.forward fused (model.py:175-181 -> :95-120) ----
  * raw (n*S,4) = (raw_rgb[3], raw_density) per sample, before the sigmoid/relu of model.py:186-187. */
@@ -288,8 +293,8 @@ int aon_art_render_bwd(const void* packed_bwd_coarse, const void* small_coarse, 
  *                       default-size NeRFMLP with max_deg_point - min_deg_point <= 10 and deg_view <= 4: the stream of
  *                       aon_pack_vanilla_mlp_deg leaves the 63 / 27-wide input slots of the missing levels at zero weight, and
  *                       aon_render_fwd_ex computes the encodings outside the MLP kernel in that padded layout (pos_enc stage
- *                       kernel, +252 B/sample of HBM traffic) and runs the MLP on them.  Inference only: the training entry points
- *                       refuse other degrees (they train through aon_grender_fwd_train), and so do the articulated calls.
+ *                       kernel, +252 B/sample of HBM traffic) and runs the MLP on them; aon_render_fwd_train_ex / aon_render_bwd_ex
+ *                       likewise (streams of aon_pack_vanilla_mlp_deg / _bwd_deg).  The articulated calls refuse other degrees.
  * Geometries other than 64 / 128 run the coarse level as two kernels (compositing, then aon_sample_pdf_n). */
 typedef struct aon_render_opts {
   int32_t num_coarse_samples;   /* 64 */

@@ -121,7 +121,7 @@ def test_other_degrees_on_the_fused_inference_kernels(dev, golden):
         sd = syn.make_general_nerf_state_dict(seed, **kw)
         model = NeRF(**kw).to(dev)
         model.load_state_dict(sd)
-        assert model._fused_inference and model._general
+        assert model._fused_inference and not model._general and not model.coarse_mlp.geometry.is_default
         tr, u = syn.seeded_uniform(64, n, 65).to(dev), syn.seeded_uniform(65, n, 128).to(dev)
         with torch.no_grad():
             fused = [model(rays, False, True, 2.0, 6.0), model(rays, True, False, 2.0, 6.0, t_rand=tr, u=u)]
@@ -142,6 +142,54 @@ def test_other_degrees_on_the_fused_inference_kernels(dev, golden):
     # more than 10 levels do not fit the slots: layer-wise engine
     big = NeRF(min_deg_point=0, max_deg_point=11, deg_view=4)
     assert big._general and not big._fused_inference
+
+
+@pytest.mark.parametrize("degrees", [(0, 6, 2), (1, 8, 3), (-2, 8, 0)])
+def test_training_at_other_degrees_on_the_fused_kernels(dev, degrees):
+    """loss.backward() of NeRF(min_deg_point, max_deg_point, deg_view) with at most 10 / 4 levels on the FUSED training kernels
+    (caller-encoded forward, weight gradients re-cut to the network's own column order): every parameter gradient as close to the
+    oracle's fp64 autograd as the oracle's fp32 is, and equal (to summation-order level) to the layer-wise engine's."""
+    import aon_amd.synthetic as syn
+    from _gradcheck import assert_as_close_as_fp32, rel_l2
+    from aon_amd.models.vanilla_nerf.model import NeRF
+
+    mn, mx, dv = degrees
+    gk = dict(min_deg_point=mn, max_deg_point=mx, deg_view=dv)
+    n = 200
+    sd = syn.make_general_nerf_state_dict(71, **gk)
+    model = NeRF(**gk).to(dev)
+    model.load_state_dict(sd)
+    frame = syn.make_rays(24, 32, syn.look_at_pose(4.0, 60, 20), syn.focal_from_fovy(24))
+    rays_cpu = {k: v[::3][:n].contiguous() for k, v in frame.items()}
+    rays = {k: v.to(dev) for k, v in rays_cpu.items()}
+    target = syn.seeded_uniform(72, n, 3)
+    tr, u = syn.seeded_uniform(73, n, 65), syn.seeded_uniform(74, n, 128)
+
+    def step():
+        model.zero_grad()
+        out = model(rays, True, True, 2.0, 6.0, t_rand=tr.to(dev), u=u.to(dev))
+        loss = ((out[0][0] - target.to(dev)) ** 2).mean() + ((out[1][0] - target.to(dev)) ** 2).mean()
+        loss.backward()
+        return loss.item(), {k: p.grad.clone().cpu() for k, p in model.named_parameters()}
+
+    loss, grads = step()
+    for name, p in model.named_parameters():
+        assert grads[name].shape == p.shape
+    model._fused_training = False
+    loss_l, grads_l = step()
+    assert abs(loss - loss_l) < 2e-6
+
+    def oracle_grads(dtype):
+        sd_o = {k: v.detach().clone().to(dtype).requires_grad_(True) for k, v in sd.items()}
+        out = orc.nerf_forward(sd_o, {k: v.to(dtype) for k, v in rays_cpu.items()}, True, True, 2.0, 6.0, t_rand=tr.to(dtype), u=u.to(dtype), **gk)
+        l = orc.img2mse(out[0][0], target.to(dtype)) + orc.img2mse(out[1][0], target.to(dtype))
+        l.backward()
+        return l.item(), {k: v.grad for k, v in sd_o.items()}
+
+    (_, truth), (loss32, ref32) = oracle_grads(torch.float64), oracle_grads(torch.float32)
+    assert abs(loss - loss32) < 2e-6
+    assert_as_close_as_fp32(grads, truth, ref32, f"fused training at degrees {degrees}")
+    assert_as_close_as_fp32(grads_l, truth, ref32, f"layer-wise training at degrees {degrees}")
 
 
 def test_general_engine_chunking_is_invisible(dev):
@@ -184,6 +232,7 @@ def test_training_step_on_the_general_engine(dev):
     kw = dict(num_coarse_samples=nc, num_fine_samples=nf, noise_std=0.2, **gk)
     sd = syn.make_general_nerf_state_dict(31, **gk)
     model = NeRF(**kw).to(dev)
+    model._fused_inference = False        # (0, 6, 2) fits the fused kernels' slots: this test is about the layer-wise engine
     model.load_state_dict(sd)
     frame = syn.make_rays(24, 32, syn.look_at_pose(4.0, 60, 20), syn.focal_from_fovy(24))
     rays_cpu = {k: v[::3][:n].contiguous() for k, v in frame.items()}

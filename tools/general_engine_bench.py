@@ -93,6 +93,16 @@ def main():
             print(json.dumps({"what": "NeRF.forward (65 + 193), fused kernels on padded encodings", "geometry": name, "rays": n, "ms": round(ms, 3),
                               "rays_per_s": round(n / ms * 1e3), "frac_fp32_matrix_peak": round(fl / ms / 1e9 / PEAK, 4)}), flush=True)
         opt = torch.optim.Adam(model.parameters(), lr=5e-4)
+        if fused_inf:
+            def fstep():
+                opt.zero_grad(set_to_none=True)
+                out = model(rays, True, True, 2.0, 6.0)
+                (((out[0][0] - target) ** 2).mean() + ((out[1][0] - target) ** 2).mean()).backward()
+                opt.step()
+            ms = timeit(fstep, args.reps)
+            print(json.dumps({"what": "training step (fwd + bwd + Adam), fused kernels on padded encodings", "geometry": name, "rays": n, "ms": round(ms, 3),
+                              "rays_per_s": round(n / ms * 1e3), "frac_fp32_matrix_peak": round(3 * fl / ms / 1e9 / PEAK, 4)}), flush=True)
+            model._fused_inference = False
 
         def step():
             opt.zero_grad(set_to_none=True)
