@@ -167,7 +167,8 @@ def sorted_piecewise_constant_pdf(bins, weights, num_samples, randomized, u=None
     weight_sum = weight_sum + padding
     pdf = weights / weight_sum
     cdf = torch.fmin(torch.ones_like(pdf[..., :-1]), torch.cumsum(pdf[..., :-1], dim=-1))
-    cdf = torch.cat([torch.zeros_like(cdf[..., :1]), cdf, torch.ones_like(cdf[..., :1])], dim=-1)
+    one = list(cdf.shape[:-1]) + [1]   # (helper.py:216-221 builds these from the shape: with ONE weight cdf[..., :1] would be empty)
+    cdf = torch.cat([torch.zeros(one, dtype=cdf.dtype), cdf, torch.ones(one, dtype=cdf.dtype)], dim=-1)
     if not randomized:
         u = deterministic_u(num_samples).expand(*cdf.shape[:-1], num_samples)
     u = u.contiguous()
