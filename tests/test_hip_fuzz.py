@@ -214,3 +214,74 @@ def test_forward_sweep_constructor_arguments(dev, seed):
             spread = (ref[lvl][0].double() - ref64[lvl][0]).abs().max(dim=-1).values.float()
             bad = robust & (err > 5e-5 + 3 * spread)
             assert not bad.any(), (lvl, err[bad].max().item(), spread[bad].max().item(), kw)
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("AON_FUZZ_TRAIN_SEEDS", "8"))))
+def test_training_sweep_constructor_arguments(dev, seed):
+    """loss.backward() at random constructor arguments (sample counts up to 120 + 300, lindisp, density noise, the three encoding
+    routes, articulated activation scalars): every gradient as close to the oracle's fp64 autograd as the oracle's own fp32 is
+    (tests/_gradcheck.py), smooth fields."""
+    import aon_amd.synthetic as syn
+    from _gradcheck import assert_as_close_as_fp32
+    from aon_amd.models.vanilla_nerf.model import NeRF
+    from aon_amd.models.vanilla_nerf.model_autodecoder import NeRF_AE_Art
+
+    rng = np.random.Generator(np.random.PCG64(5000 + seed))
+    n = int(rng.integers(8, 160))
+    nc, nf = int(rng.integers(2, 121)), int(rng.integers(1, 301))
+    lindisp, white = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+    noise_std = float(rng.choice([0.0, 0.4]))
+    art = seed % 4 == 3
+    rays_cpu = _rays(n, rng, True)
+    g = torch.Generator().manual_seed(seed)
+    target = torch.rand(n, 3, generator=g)
+    draws = dict(t_rand=torch.rand(n, nc + 1, generator=g), u=torch.rand(n, nf, generator=g))
+    noise = [torch.rand(n, nc + 1, generator=g), torch.rand(n, nc + 1 + nf, generator=g)]
+    kw = dict(num_coarse_samples=nc, num_fine_samples=nf, lindisp=lindisp, noise_std=noise_std)
+    lat0 = None
+    if art:
+        kw.update(rgb_padding=float(rng.choice([0.001, 0.02])), density_bias=float(rng.choice([-1.0, 0.3])))
+        sd = syn.make_art_state_dict(seed=seed, density_scale=2.0)
+        lat0 = orc.code_library(syn.make_code_library_state(seed=seed, n_max_objs=2), torch.tensor([seed % 2]), torch.tensor([seed % 10]))
+        model = NeRF_AE_Art(**kw).to(dev)
+        gk = {}
+    else:
+        gk = [dict(), dict(min_deg_point=0, max_deg_point=7, deg_view=3), dict(min_deg_point=1, max_deg_point=12, deg_view=5)][seed % 3]
+        sd = syn.make_general_nerf_state_dict(6000 + seed, **gk)
+        model = NeRF(**kw, **gk).to(dev)
+    model.load_state_dict(sd)
+
+    def oracle_grads(dtype):
+        sd_o = {k: v.detach().clone().to(dtype).requires_grad_(True) for k, v in sd.items()}
+        r = {k: v.to(dtype) for k, v in rays_cpu.items()}
+        common = dict(noise=[z.to(dtype) for z in noise], **{k: v.to(dtype) for k, v in draws.items()}, **kw)
+        if art:
+            lat = {k: v.detach().clone().to(dtype).requires_grad_(True) for k, v in lat0.items()}
+            out = orc.nerf_ae_art_forward(sd_o, r, True, white, 2.0, 6.0, lat, **common)
+        else:
+            lat = {}
+            out = orc.nerf_forward(sd_o, r, True, white, 2.0, 6.0, **common, **gk)
+        loss = orc.img2mse(out[0][0], target.to(dtype)) + orc.img2mse(out[1][0], target.to(dtype))
+        loss.backward()
+        gr = {k: v.grad for k, v in sd_o.items()}
+        gr.update({f"latent[{k}]": v.grad for k, v in lat.items()})
+        return loss.item(), gr
+
+    (_, truth), (loss32, ref32) = oracle_grads(torch.float64), oracle_grads(torch.float32)
+    rays = {k: v.to(dev) for k, v in rays_cpu.items()}
+    args = dict(noise=[z.to(dev) for z in noise], **{k: v.to(dev) for k, v in draws.items()})
+    if art:
+        lat = {k: v.to(dev).clone().requires_grad_(True) for k, v in lat0.items()}
+        out = model(rays, True, white, 2.0, 6.0, lat, **args)
+    else:
+        out = model(rays, True, white, 2.0, 6.0, **args)
+    loss = ((out[0][0] - target.to(dev)) ** 2).mean() + ((out[1][0] - target.to(dev)) ** 2).mean()
+    loss.backward()
+    assert abs(loss.item() - loss32) < 5e-6, (loss.item(), loss32, kw, gk)
+    hip = {name: p.grad.cpu() for name, p in model.named_parameters()}
+    if art:
+        hip.update({f"latent[{k}]": lat[k].grad.cpu() for k in lat})
+    # a sweep, not a pin: the ratio to the reference-fp32's own error has a distribution over random geometries (measured over 24
+    # seeds: three above 5x -- 5.7x on fine-level weights behind an 11-bin inverse CDF, 7x on the articulated deformation head,
+    # 14x at the 4e-4 level on a coarse view layer); a wrong kernel is off by O(1).  The dedicated tests hold 5x.
+    assert_as_close_as_fp32(hip, truth, ref32, f"seed {seed}: {kw} {gk}", factor=25.0, floor=1e-3)
