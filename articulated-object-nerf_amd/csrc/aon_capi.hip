@@ -28,13 +28,13 @@ int64_t art_stream_bytes();
 int64_t art_small_bytes();
 hipError_t launch_mlp_fwd_train(const char* packed, const float* rays_o, const float* rays_d, const float* viewdirs,
                                 const float* t_vals, int64_t n_rays, int S, float* raw, float* planes, void* masks,
-                                hipStream_t stream);
+                                hipStream_t stream, int64_t np_total = 0);
 hipError_t launch_composite_bwd(const float* raw, const float* t_vals, const float* dirs, const float* g_rgb, const float* g_acc,
                                 const float* g_depth, int64_t n_rays, int S, int white_bkgd, const ActParams& ap, float* d_raw,
                                 hipStream_t stream);
 hipError_t launch_pack_vanilla_bwd(const float* const* params, float* packed, hipStream_t stream, int pos_size = 63, int view_size = 27);
 hipError_t launch_mlp_fwd_train_enc(const char* packed, const float* samples_enc, const float* viewdirs_enc, int64_t n_rays, int S, float* raw,
-                                    float* planes, void* masks, hipStream_t stream);
+                                    float* planes, void* masks, hipStream_t stream, int64_t np_total = 0);
 int64_t bwd_stream_bytes();
 hipError_t launch_mlp_bwd_chain(const char* packed_bwd, const char* packed_fwd, const float* d_raw, const void* masks,
                                 float* dplanes, int64_t Np, hipStream_t stream);
@@ -47,7 +47,7 @@ hipError_t launch_vanilla_wgrad(const float* planes, const float* dplanes, const
                                 float* ws, hipStream_t stream, const WgAux* aux);
 hipError_t launch_art_mlp_fwd_train(const char* packed, const float* small, const float* rays_o, const float* rays_d,
                                     const float* viewdirs, const float* t_vals, int64_t n_rays, int S, float* raw, float* planes,
-                                    void* masks, hipStream_t stream);
+                                    void* masks, hipStream_t stream, int64_t np_total = 0);
 hipError_t launch_pack_art_bwd(const float* const* params, float* packed, hipStream_t stream);
 int64_t art_bwd_stream_bytes();
 hipError_t launch_art_bwd_chain(const char* packed_bwd, const float* small, const float* d_raw, const void* masks, const float* planes,
@@ -876,6 +876,7 @@ class LevelFork {
   bool forked_ = false;
 };
 std::atomic<int> g_bwd_overlap{1};
+std::atomic<int> g_fwd_overlap{2};
 
 struct TrainNet {   // one level's network handles
   const void* packed_fwd; const float* small; const void* packed_bwd;
@@ -896,55 +897,90 @@ int train_fwd_impl(const char* who, bool art, const TrainNet* nets, const float*
   if (w.bytes > workspace_bytes) return fail(AON_E_WORKSPACE, "train forward: workspace smaller than aon_train_workspace_bytes()");
   if (num_levels == 2 && (!u || (u_stride != 0 && u_stride < g.nf))) return fail(AON_E_INVALID, "train forward: bad u / u_stride");
   const bool fuse = num_levels == 2 && g.default_sizes && g_fuse_coarse.load(std::memory_order_relaxed) != 0;
-  for (int l = 0; l < num_levels; ++l) {
-    const TrainLevel& L = w.lvl[l];
+  for (int l = 0; l < num_levels; ++l)
     if (!nets[l].packed_fwd || (art && !nets[l].small) || !rgb[l] || !acc[l] || !depth[l]) return fail(AON_E_INVALID, "train forward: null level pointer");
-    int rc = AON_OK;
-    if (l == 0) {
-      KTimer timer(kSampleT, stream, n);
-      rc = check(aon::launch_sample_along_rays(rays_o, rays_d, n, g.Sc, near_, far_, t_rand, L.t, nullptr, stream, g.lindisp, g.inv_near,
-                                               g.inv_far), who);
-    } else if (!fuse) {
-      KTimer timer(kSamplePdf, stream, n);
-      rc = check(g.default_sizes ? aon::launch_sample_pdf(nullptr, w.w_c + 1, kSc, w.lvl[0].t, u, u_stride, n, nullptr, L.t, stream)
-                                 : aon::launch_sample_pdf_n(nullptr, w.w_c + 1, g.Sc, w.lvl[0].t, u, u_stride, n, g.Sc - 1, g.nf, g.Sc, nullptr,
-                                                            L.t, stream), who);
+  const int64_t rows = art ? aon::kAPlRows : aon::kPlRows;
+
+  // Both levels of the ray range [r0, r0 + nk) on stream `st`.  r0 is a multiple of 128, so the range's samples start on a pass
+  // boundary at both levels: its planes / decision bits / raw records are the whole batch's buffers at an offset, the slot stride of
+  // the decision bits stays the whole batch's Np.
+  auto run_range = [&](int64_t r0, int64_t nk, hipStream_t st) -> int {
+    const float* o = rays_o + r0 * 3; const float* d = rays_d + r0 * 3; const float* v = viewdirs + r0 * 3;
+    const float* uu = (u && u_stride) ? u + r0 * u_stride : u;
+    for (int l = 0; l < num_levels; ++l) {
+      const TrainLevel& L = w.lvl[l];
+      const int64_t s0 = r0 * L.S;
+      float* t = L.t + s0; float* raw = L.raw + s0 * 4;
+      float* planes = L.planes + s0 * rows; char* masks = L.masks + s0 * 32;
+      float* t_next = num_levels == 2 ? w.lvl[1].t + r0 * w.lvl[1].S : nullptr;
+      int rc = AON_OK;
+      if (l == 0) {
+        KTimer timer(kSampleT, st, nk);
+        rc = check(aon::launch_sample_along_rays(o, d, nk, g.Sc, near_, far_, t_rand ? t_rand + r0 * g.Sc : nullptr, t, nullptr, st, g.lindisp, g.inv_near,
+                                                 g.inv_far), who);
+      } else if (!fuse) {
+        KTimer timer(kSamplePdf, st, nk);
+        const float* wc = w.w_c + r0 * g.Sc; const float* tc = w.lvl[0].t + r0 * g.Sc;
+        rc = check(g.default_sizes ? aon::launch_sample_pdf(nullptr, wc + 1, kSc, tc, uu, u_stride, nk, nullptr, t, st)
+                                   : aon::launch_sample_pdf_n(nullptr, wc + 1, g.Sc, tc, uu, u_stride, nk, g.Sc - 1, g.nf, g.Sc, nullptr, t, st), who);
+      }
+      if (rc) return rc;
+      if (g.other_degrees) {
+        // other encoding degrees: encodings by the stage kernels in the padded 63 / 27-slot layout, then the training forward on
+        // caller-encoded inputs (same planes, same decision bits)
+        float* coords = L.coords + s0 * 3; float* enc = L.enc + s0 * aon::kPosEnc; float* venc = L.venc + r0 * aon::kViewEnc;
+        if ((rc = check(aon::launch_cast_rays(t, o, d, nk, L.S, coords, st), who))) return rc;
+        if ((rc = check(aon::launch_pos_enc(coords, nk * L.S, g.min_deg, g.max_deg, enc, st, aon::kPosEnc, 10), who))) return rc;
+        if ((rc = check(aon::launch_pos_enc(v, nk, 0, g.deg_view, venc, st, aon::kViewEnc, 4), who))) return rc;
+        MlpTimer timer(st, nk * L.S);
+        rc = check(aon::launch_mlp_fwd_train_enc(static_cast<const char*>(nets[l].packed_fwd), enc, venc, nk, L.S, raw, planes, masks, st, L.Np), who);
+      } else {
+        MlpTimer timer(st, nk * L.S);
+        rc = check(art ? aon::launch_art_mlp_fwd_train(static_cast<const char*>(nets[l].packed_fwd), nets[l].small, o, d, v, t, nk, L.S, raw, planes, masks,
+                                                       st, L.Np)
+                       : aon::launch_mlp_fwd_train(static_cast<const char*>(nets[l].packed_fwd), o, d, v, t, nk, L.S, raw, planes, masks, st, L.Np), who);
+      }
+      if (rc) return rc;
+      if (l == 0 && fuse) {
+        KTimer timer(kCompositePdf, st, nk);
+        rc = check(aon::launch_composite_pdf(raw, t, d, nk, white_bkgd, g.act(art, 0, r0), uu, u_stride, rgb[0] + r0 * 3, acc[0] + r0, depth[0] + r0, nullptr,
+                                             t_next, st), who);
+      } else {
+        KTimer timer(kComposite, st, nk);
+        rc = check(aon::launch_composite(raw, 4, raw + 3, 4, t, d, nk, L.S, white_bkgd, g.act(art, l, r0), rgb[l] + r0 * 3, acc[l] + r0, depth[l] + r0,
+                                         (l == 0 && num_levels == 2) ? w.w_c + r0 * g.Sc : nullptr, st), who);
+      }
+      if (rc) return rc;
     }
-    if (rc) return rc;
-    if (g.other_degrees) {
-      // other encoding degrees: encodings by the stage kernels in the padded 63 / 27-slot layout, then the training forward on
-      // caller-encoded inputs (same planes, same decision bits)
-      if ((rc = check(aon::launch_cast_rays(L.t, rays_o, rays_d, n, L.S, L.coords, stream), who))) return rc;
-      if ((rc = check(aon::launch_pos_enc(L.coords, n * L.S, g.min_deg, g.max_deg, L.enc, stream, aon::kPosEnc, 10), who))) return rc;
-      if ((rc = check(aon::launch_pos_enc(viewdirs, n, 0, g.deg_view, L.venc, stream, aon::kViewEnc, 4), who))) return rc;
-      MlpTimer timer(stream, n * L.S);
-      rc = check(aon::launch_mlp_fwd_train_enc(static_cast<const char*>(nets[l].packed_fwd), L.enc, L.venc, n, L.S, L.raw, L.planes, L.masks, stream), who);
-    } else {
-      MlpTimer timer(stream, n * L.S);
-      rc = check(art ? aon::launch_art_mlp_fwd_train(static_cast<const char*>(nets[l].packed_fwd), nets[l].small, rays_o, rays_d, viewdirs, L.t, n, L.S,
-                                                     L.raw, L.planes, L.masks, stream)
-                     : aon::launch_mlp_fwd_train(static_cast<const char*>(nets[l].packed_fwd), rays_o, rays_d, viewdirs, L.t, n, L.S, L.raw, L.planes,
-                                                 L.masks, stream), who);
+    return AON_OK;
+  };
+
+  // Two ray halves on the two library streams (round 3): the levels of a half depend on each other through its own inverse CDF
+  // only, so one half's fine level fills the CUs the other half's coarse level leaves idle in its last, partial round of
+  // workgroups (8.125 rounds of 256 cost 9 at 4096 x 65 samples), as the backward does with its two levels.
+  const int parts = g_fwd_overlap.load(std::memory_order_relaxed);   // 0 / 1: one stream; k >= 2: k ray ranges alternating on the two streams
+  const int64_t piece = parts >= 2 ? (n / parts) / 128 * 128 : 0;
+  if (num_levels == 2 && piece > 0) {
+    LevelFork fork(true, stream, who);
+    if (fork.rc()) return fork.rc();
+    for (int k = 0; k < parts; ++k) {
+      const int64_t r0 = k * piece, nk = k == parts - 1 ? n - r0 : piece;
+      if (int rc = run_range(r0, nk, fork.stream(k & 1))) return rc;
     }
-    if (rc) return rc;
-    if (l == 0 && fuse) {
-      KTimer timer(kCompositePdf, stream, n);
-      rc = check(aon::launch_composite_pdf(L.raw, L.t, rays_d, n, white_bkgd, g.act(art, 0, 0), u, u_stride, rgb[0], acc[0], depth[0], nullptr,
-                                           w.lvl[1].t, stream), who);
-    } else {
-      KTimer timer(kComposite, stream, n);
-      rc = check(aon::launch_composite(L.raw, 4, L.raw + 3, 4, L.t, rays_d, n, L.S, white_bkgd, g.act(art, l, 0), rgb[l], acc[l], depth[l],
-                                       (l == 0 && num_levels == 2) ? w.w_c : nullptr, stream), who);
-    }
-    if (rc) return rc;
+    return fork.join();
   }
-  return AON_OK;
+  return run_range(0, n, stream);
 }
 
 }  // namespace
 
 int aon_set_bwd_overlap(int on) {
   g_bwd_overlap.store(on ? 1 : 0, std::memory_order_relaxed);
+  return AON_OK;
+}
+
+int aon_set_fwd_overlap(int on) {
+  g_fwd_overlap.store(on < 0 ? 0 : (on == 1 ? 2 : (on > 16 ? 16 : on)), std::memory_order_relaxed);   // 1 = the default two halves; k >= 2: k ranges (measurements)
   return AON_OK;
 }
 

@@ -308,23 +308,25 @@ hipError_t launch_mlp_fwd(const char* packed, const float* rays_o, const float* 
 }
 
 // Training forward: as launch_mlp_fwd, plus the activation planes (kPlRows x Np floats, Np = 128*ceil(n*S/128)).
+// np_total: the padded sample count of the WHOLE batch when this launch covers a ray range of it starting on a pass boundary
+// (planes / masks / raw / t_vals already point at the range): the decision bits' slot stride is the whole batch's.
 hipError_t launch_mlp_fwd_train(const char* packed, const float* rays_o, const float* rays_d, const float* viewdirs,
                                 const float* t_vals, int64_t n_rays, int S, float* raw, float* planes, void* masks,
-                                hipStream_t stream) {
+                                hipStream_t stream, int64_t np_total) {
   MlpArgs a{};
   a.packed = packed; a.rays_o = rays_o; a.rays_d = rays_d; a.viewdirs = viewdirs; a.t_vals = t_vals;
   a.raw = raw; a.total = n_rays * S; a.S = S; a.npass = (int)((a.total + 127) / 128);
-  a.planes = planes; a.masks = static_cast<u32x4*>(masks); a.Np = (int64_t)a.npass * 128;
+  a.planes = planes; a.masks = static_cast<u32x4*>(masks); a.Np = np_total > 0 ? np_total : (int64_t)a.npass * 128;
   return launch_mlp_t<true, true>(a, stream);
 }
 
 // training forward on caller-encoded inputs (padded 63 / 27-column layout): planes and decision bits as launch_mlp_fwd_train
 hipError_t launch_mlp_fwd_train_enc(const char* packed, const float* samples_enc, const float* viewdirs_enc, int64_t n_rays, int S, float* raw,
-                                    float* planes, void* masks, hipStream_t stream) {
+                                    float* planes, void* masks, hipStream_t stream, int64_t np_total) {
   MlpArgs a{};
   a.packed = packed; a.samples_enc = samples_enc; a.viewdirs_enc = viewdirs_enc;
   a.raw = raw; a.total = n_rays * S; a.S = S; a.npass = (int)((a.total + 127) / 128);
-  a.planes = planes; a.masks = static_cast<u32x4*>(masks); a.Np = (int64_t)a.npass * 128;
+  a.planes = planes; a.masks = static_cast<u32x4*>(masks); a.Np = np_total > 0 ? np_total : (int64_t)a.npass * 128;
   return launch_mlp_t<false, true>(a, stream);
 }
 

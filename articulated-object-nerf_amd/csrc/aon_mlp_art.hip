@@ -342,11 +342,11 @@ hipError_t launch_art_mlp_fwd(const char* packed, const float* small, const floa
 
 hipError_t launch_art_mlp_fwd_train(const char* packed, const float* small, const float* rays_o, const float* rays_d,
                                     const float* viewdirs, const float* t_vals, int64_t n_rays, int S, float* raw, float* planes,
-                                    void* masks, hipStream_t stream) {
+                                    void* masks, hipStream_t stream, int64_t np_total) {
   ArtMlpArgs a{};
   a.packed = packed; a.small = small; a.rays_o = rays_o; a.rays_d = rays_d; a.viewdirs = viewdirs; a.t_vals = t_vals;
   a.raw = raw; a.total = n_rays * S; a.S = S; a.npass = (int)((a.total + 127) / 128);
-  a.planes = planes; a.masks = static_cast<u32x4*>(masks); a.Np = (int64_t)a.npass * 128;
+  a.planes = planes; a.masks = static_cast<u32x4*>(masks); a.Np = np_total > 0 ? np_total : (int64_t)a.npass * 128;   // (launch_mlp_fwd_train)
   return launch_art_t<true, true>(a, stream);
 }
 

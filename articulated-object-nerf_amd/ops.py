@@ -749,6 +749,11 @@ def _sized(nbytes: int, what: str, device) -> torch.Tensor:
     return torch.empty(nbytes, dtype=torch.uint8, device=device)
 
 
+def set_fwd_overlap(on: bool) -> None:
+    """Training forward of two levels as two ray halves on two library streams (default on) or everything on the caller's stream."""
+    check(lib.aon_set_fwd_overlap(int(bool(on))), "aon_set_fwd_overlap")
+
+
 def train_workspace(device, n_rays: int, articulated: bool, num_levels: int = 2, st=None) -> torch.Tensor:
     """Fresh workspace of one training forward/backward pair (it carries the forward's planes to the backward, so it is
     owned by the autograd graph, not cached); sized by the levels in use."""

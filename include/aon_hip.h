@@ -248,6 +248,11 @@ int aon_art_wgrad(const float* planes, const float* dplanes, const float* d_raw,
  * `stream` and `stream` continues only after both (events) -- from the caller's view the call is enqueued on `stream`.
  * aon_set_bwd_overlap(0) keeps everything on `stream` (default 1). */
 int aon_set_bwd_overlap(int on);
+/* Likewise the training FORWARD of two levels runs two ray halves (split on a multiple of 128 rays) on the two library streams: a
+ * half's levels depend on each other only through its own inverse CDF, so one half's fine level fills the CUs the other half's
+ * coarse level leaves idle in its last partial round of workgroups.  Same bits as the one-stream form.  aon_set_fwd_overlap(0)
+ * keeps everything on `stream` (default 1 = two halves; k >= 2 = k ranges alternating on the two streams, for measurements). */
+int aon_set_fwd_overlap(int on);
 int64_t aon_train_workspace_bytes(int64_t n_rays, int articulated, int num_levels);
 int64_t aon_train_scratch_bytes(int64_t n_rays, int articulated, int num_levels);
 int aon_render_fwd_train(const void* packed_coarse, const void* packed_fine, const float* rays_o, const float* rays_d,

@@ -456,3 +456,46 @@ def test_grouped_wgrad_against_fp64_matmul(dev, net, n_samples):
           W["pts_linears.5.weight"][:, 319:447].T @ db_t5)
     close("latent color", gl["color"], W["views_linear.0.weight"][:, 283:411].T @ db_v0)
     close("latent articulation", gl["articulation"], W["deformations_linear.0.weight"][:, 131:163].T @ db0)
+
+
+@pytest.mark.parametrize("net", ["vanilla", "articulated", "other_degrees"])
+def test_forward_overlap_is_bit_identical(dev, net):
+    """The training forward as two ray halves on two library streams (aon_set_fwd_overlap, default) gives the same outputs and --
+    through the planes, decision bits and raw records it leaves -- the same gradients as the one-stream form, bit for bit; ragged
+    ray counts (the split is on a multiple of 128 rays; below 256 rays there is none)."""
+    import aon_amd.synthetic as syn
+    from aon_amd import ops
+    from aon_amd.models.vanilla_nerf.model import NeRF
+    from aon_amd.models.vanilla_nerf.model_autodecoder import NeRF_AE_Art
+
+    for n in (257, 600, 1000):
+        frame = syn.make_rays(32, 40, syn.look_at_pose(4.0, 60, 20), syn.focal_from_fovy(32))
+        rays = {k: v[:n].contiguous().to(dev) for k, v in frame.items()}
+        target = syn.seeded_uniform(5, n, 3).to(dev)
+        tr, u = syn.seeded_uniform(6, n, 65).to(dev), syn.seeded_uniform(7, n, 128).to(dev)
+        lat = None
+        if net == "articulated":
+            model = NeRF_AE_Art().to(dev)
+            model.load_state_dict(syn.make_art_state_dict(seed=5, density_scale=2.0))
+            lib = syn.make_code_library_state(seed=0, n_max_objs=2)
+            lat = {"density": lib["embedding_instance_shape.weight"][1:2].to(dev), "color": lib["embedding_instance_appearance.weight"][1:2].to(dev),
+                   "articulation": lib["embedding_instance_articulation.weight"][3:4].to(dev)}
+        elif net == "other_degrees":
+            gk = dict(min_deg_point=0, max_deg_point=6, deg_view=2)
+            model = NeRF(**gk).to(dev)
+            model.load_state_dict(syn.make_general_nerf_state_dict(9, **gk))
+        else:
+            model = NeRF().to(dev)
+            model.load_state_dict(syn.make_smooth_nerf_state_dict())
+        res = []
+        try:
+            for on in (True, False):
+                ops.set_fwd_overlap(on)
+                model.zero_grad()
+                out = model(rays, True, True, 2.0, 6.0, lat, t_rand=tr, u=u) if lat is not None else model(rays, True, True, 2.0, 6.0, t_rand=tr, u=u)
+                (((out[0][0] - target) ** 2).mean() + ((out[1][0] - target) ** 2).mean() + out[1][2].mean() * 1e-3).backward()
+                res.append([x.detach().clone() for lvl in out for x in lvl] + [p.grad.clone() for p in model.parameters()])
+        finally:
+            ops.set_fwd_overlap(True)
+        for a, b in zip(*res):
+            assert torch.equal(a, b)
