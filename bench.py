@@ -345,10 +345,12 @@ def train_leg(dev, rank, world, distributed, steps=6, n_rays=4096):
         # per-kernel-class durations from a second pass with the two levels SERIALISED on one stream (on two streams the
         # classes of the two levels overlap in time and their HIP-event intervals neither add up nor price one kernel)
         ops.set_bwd_overlap(False)
+        ops.set_fwd_overlap(False)      # likewise the forward's two ray halves
         try:
             dt_serial, _, classes = timed(profile=True)
         finally:
             ops.set_bwd_overlap(True)
+            ops.set_fwd_overlap(True)
         samples = n_rays * EVALS_PER_RAY
         mac_lit, mac_ex = 3 * ART_MAC_LITERAL, ART_MAC_FWD + ART_MAC_BWD_CHAIN + ART_MAC_WGRAD
         kernels = {}
