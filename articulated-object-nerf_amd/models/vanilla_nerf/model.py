@@ -202,12 +202,14 @@ class LitNeRF(Harness):
     reference copies from its dataset in ``setup`` (:245-254), are constructor arguments here (dataset IO is out of scope)."""
 
     def __init__(self, hparams=None, lr_init: float = 5.0e-4, lr_final: float = 5.0e-6, lr_delay_steps: int = 2500,
-                 lr_delay_mult: float = 0.01, randomized: bool = True, near: float = 2.0, far: float = 6.0, white_bkgd: bool = True):
+                 lr_delay_mult: float = 0.01, randomized: bool = True, near: float = 2.0, far: float = 6.0, white_bkgd: bool = True,
+                 model_kwargs: dict | None = None):
         super().__init__()
         self._init_harness(hparams, dict(chunk=3840, run_max_steps=100000, img_wh=(640, 480)))  # opt.py:103,112,17
         self.lr_init, self.lr_final, self.lr_delay_steps, self.lr_delay_mult = lr_init, lr_final, lr_delay_steps, lr_delay_mult
         self.randomized, self.near, self.far, self.white_bkgd = randomized, near, far, white_bkgd
-        self.model = NeRF()
+        # the reference builds NeRF() (model.py:218); `model_kwargs` hands its constructor arguments through (sample counts, degrees, ...)
+        self.model = NeRF(**(model_kwargs or {}))
 
     def training_step(self, batch, batch_idx):
         batch = {k: (v if k == "obj_idx" else v.squeeze(0)) for k, v in batch.items()}

@@ -177,12 +177,13 @@ class LitNeRF_AutoDecoder(Harness):
     (:359-391); ``setup(dataset)`` copies them the same way."""
 
     def __init__(self, hparams=None, lr_init: float = 5.0e-4, lr_final: float = 5.0e-6, lr_delay_steps: int = 2500,
-                 lr_delay_mult: float = 0.01, randomized: bool = True, near: float = 2.0, far: float = 6.0, white_bkgd: bool = True):
+                 lr_delay_mult: float = 0.01, randomized: bool = True, near: float = 2.0, far: float = 6.0, white_bkgd: bool = True,
+                 model_kwargs: dict | None = None):
         super().__init__()
         self._init_harness(hparams, dict(chunk=3840, run_max_steps=100000, img_wh=(320, 240), N_max_objs=1, N_obj_code_length=128))
         self.lr_init, self.lr_final, self.lr_delay_steps, self.lr_delay_mult = lr_init, lr_final, lr_delay_steps, lr_delay_mult
         self.randomized, self.near, self.far, self.white_bkgd = randomized, near, far, white_bkgd
-        self.model = NeRF_AE_Art()
+        self.model = NeRF_AE_Art(**(model_kwargs or {}))   # the reference builds NeRF_AE_Art() (model_autodecoder.py:352)
         self.code_library = CodeLibraryArticulated(self.hparams)
 
     def setup(self, dataset):

@@ -55,3 +55,17 @@ def test_render_rays_contract_and_training_step(nerf_sd):
     assert {"train/psnr0", "train/psnr1", "train/loss"} <= set(lit.logged)
     loss2 = lit.training_step(train_batch, 1)
     assert torch.isfinite(loss2)
+
+
+def test_harness_hands_constructor_arguments_through():
+    """LitNeRF(model_kwargs=...) / LitNeRF_AutoDecoder(model_kwargs=...): the reference builds NeRF() / NeRF_AE_Art() (model.py:218,
+    model_autodecoder.py:356); here the constructor arguments of the drop-in classes can be chosen at the harness level too."""
+    from aon_amd.models.vanilla_nerf.model import LitNeRF
+    from aon_amd.models.vanilla_nerf.model_autodecoder import LitNeRF_AutoDecoder
+
+    lit = LitNeRF(model_kwargs=dict(num_coarse_samples=32, num_fine_samples=64, max_deg_point=6, deg_view=2, lindisp=True))
+    assert lit.model.num_coarse_samples == 32 and lit.model._opts.Sf == 97 and lit.model._opts.lindisp
+    assert lit.model.coarse_mlp.pts_linears[0].weight.shape == (256, 39) and lit.model._fused_inference and not lit.model._general
+    assert LitNeRF().model.coarse_mlp.geometry.is_default
+    art = LitNeRF_AutoDecoder(model_kwargs=dict(num_fine_samples=64, rgb_padding=0.01))
+    assert art.model._opts.num_fine_samples == 64 and art.model._opts.rgb_padding == 0.01
