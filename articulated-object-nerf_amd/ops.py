@@ -1031,6 +1031,15 @@ def grender_bwd(geom: MlpGeometry, ws, params_per_level, rays_d, white_bkgd, num
     return grads
 
 
+def release_workspaces() -> None:
+    """Drop the per-device workspace caches of the inference calls (fused path: up to 1.35 GB, or 3.3 GB with materialised
+    encodings; layer-wise engine: up to ~7 GB at G_CHUNK_RAYS rays) back to torch's caching allocator.  They are re-made on the
+    next call; training workspaces are never cached (they belong to the autograd graph)."""
+    _WS_CACHE.clear()
+    _GWS_CACHE.clear()
+    _WG_WS.clear()
+
+
 # ------------------------------------------------------------------ measurement aid
 def profile_begin() -> None:
     check(lib.aon_profile_begin(), "aon_profile_begin")
