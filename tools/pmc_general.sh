@@ -13,6 +13,7 @@ rays = {k: v[:n].to(dev) for k, v in frame.items()}
 target = torch.rand(n, 3, device=dev)
 gk = dict(min_deg_point=0, max_deg_point=6, deg_view=2)
 model = NeRF(**gk).to(dev)
+model._fused_inference = False   # (0, 6, 2) fits the fused kernels' slots: this script is about the layer-wise engine
 model.load_state_dict(syn.make_general_nerf_state_dict(7, **gk))
 out = model(rays, True, True, 2.0, 6.0)
 (((out[0][0] - target) ** 2).mean() + ((out[1][0] - target) ** 2).mean()).backward()
