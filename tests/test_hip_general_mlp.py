@@ -306,3 +306,33 @@ def test_invalid_geometry_is_rejected():
     with pytest.raises(AonError, match="last trunk layer"):
         NeRFMLP(0, 10, 4, netdepth=5, skip_layer=4)     # the reference's forward raises on this one too (257 != 256 + 63 inputs)
     NeRFMLP(0, 10, 4, netdepth=6, skip_layer=4)
+
+
+def test_edge_batches_on_every_route(dev):
+    """num_levels = 1, one ray and an empty batch through the three routes (fused, fused with zero-weight slots, layer-wise engine),
+    inference and (n >= 1) a training step: shapes, finiteness, the oracle's values."""
+    import aon_amd.synthetic as syn
+    from aon_amd.models.vanilla_nerf.model import NeRF
+
+    frame = syn.make_rays(8, 8, syn.look_at_pose(4.0, 60, 20), syn.focal_from_fovy(8))
+    for gk in (dict(), dict(min_deg_point=0, max_deg_point=6, deg_view=2), dict(min_deg_point=0, max_deg_point=12, deg_view=5)):
+        sd = syn.make_general_nerf_state_dict(81, **gk)
+        for levels in (1, 2):
+            model = NeRF(num_levels=levels, num_coarse_samples=20, num_fine_samples=30, **gk).to(dev)
+            model.load_state_dict(sd)
+            for n in (0, 1, 5):
+                rays_cpu = {k: v[:n].contiguous() for k, v in frame.items()}
+                rays = {k: v.to(dev) for k, v in rays_cpu.items()}
+                with torch.no_grad():
+                    out = model(rays, False, True, 2.0, 6.0)
+                assert len(out) == levels and all(o[0].shape == (n, 3) and o[1].shape == (n,) and o[2].shape == (n,) for o in out)
+                if n == 0:
+                    continue
+                ref = orc.nerf_forward(sd, rays_cpu, False, True, 2.0, 6.0, num_levels=levels, num_coarse_samples=20, num_fine_samples=30, **gk)
+                for lvl in range(levels):
+                    torch.testing.assert_close(out[lvl][0].cpu(), ref[lvl][0], rtol=0, atol=5e-5)
+                model.zero_grad()
+                o2 = model(rays, False, True, 2.0, 6.0)
+                sum(o[0].sum() for o in o2).backward()
+                used = [p for name, p in model.named_parameters() if levels == 2 or name.startswith("coarse")]
+                assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in used)
