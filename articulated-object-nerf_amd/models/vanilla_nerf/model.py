@@ -109,8 +109,10 @@ class NeRF(nn.Module):
                  num_coarse_samples: int = 64, num_fine_samples: int = 128, use_viewdirs: bool = True,
                  noise_std: float = 0.0, lindisp: bool = False):
         super().__init__()
-        if num_levels not in (1, 2):
-            raise NotImplementedError("num_levels must be 1 or 2 (a third level would resample from the fine level's 193 weights)")
+        if num_levels < 1:
+            raise ValueError("num_levels must be >= 1")
+        if num_levels > 2 and (min_deg_point, max_deg_point, deg_view) != (0, 10, 4):
+            raise NotImplementedError("more than two levels are served for the default network only (stage-level calls, inference)")
         # sample counts, lindisp and noise_std are runtime arguments of the C calls (aon_render_opts); use_viewdirs is stored and
         # never read by the reference's forward (model.py:147-199 always encodes rays["viewdirs"])
         self._opts = ops.RenderOpts(num_coarse_samples, num_fine_samples, lindisp, noise_std)
@@ -138,6 +140,31 @@ class NeRF(nn.Module):
         return [noise[lvl] if noise[lvl] is not None else torch.rand((n, self._opts.S(lvl)), device=device)
                 for lvl in range(self.num_levels)]
 
+    def _forward_many_levels(self, rays, randomized, white_bkgd, near, far, t_rand, u, noise):
+        """model.py:147-199 for num_levels > 2 (every level after the first resamples from the previous level's t and weights
+        with fine_mlp, :162-173), driven level by level through the stage-level C calls: fused cast + encode + MLP, compositing with
+        the weights written, general-size inverse CDF.  ``u``: the first resampling's draws, or a list with one entry per
+        resampling level."""
+        o, d, v = rays["rays_o"], rays["rays_d"], rays["viewdirs"]
+        n = o.shape[0]
+        us = list(u) if isinstance(u, (list, tuple)) else [u]
+        t, _ = ops.sample_along_rays(o, d, self.num_coarse_samples, near, far, t_rand, want_coords=False, lindisp=self.lindisp)
+        packed = [self.coarse_mlp.packed(), self.fine_mlp.packed()]
+        ret, weights = [], None
+        for lvl in range(self.num_levels):
+            if lvl > 0:
+                ul = us[lvl - 1] if lvl - 1 < len(us) else None
+                if randomized and ul is None:
+                    ul = torch.rand((n, self.num_fine_samples), device=o.device)
+                t = ops.sample_pdf_t_n(t, weights, self.num_fine_samples, ul if randomized else None)
+            raw = ops.mlp_fwd(packed[min(lvl, 1)], o, d, v, t)
+            nz = None
+            if self.noise_std > 0 and randomized:
+                nz = noise[lvl] if (noise is not None and lvl < len(noise) and noise[lvl] is not None) else torch.rand(t.shape, device=o.device)
+            comp, acc, weights, depth = ops.composite_raw(raw, t, d, white_bkgd, ops.ACT_VANILLA, True, opts=self._opts if nz is not None else None, noise=nz)
+            ret.append((comp, acc, depth))
+        return ret
+
     def forward(self, rays, randomized, white_bkgd, near, far, t_rand=None, u=None, noise=None):
         rays_o = rays["rays_o"]
         n = rays_o.shape[0]
@@ -148,8 +175,12 @@ class NeRF(nn.Module):
                 u = torch.rand((n, self.num_fine_samples), device=rays_o.device)
         else:
             t_rand, u = None, None
-        noise = self._draw_noise(noise, randomized, n, rays_o.device)
+        noise = self._draw_noise(noise, randomized, n, rays_o.device) if self.num_levels <= 2 else noise
         training = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        if self.num_levels > 2:
+            if training:
+                raise NotImplementedError("num_levels > 2 is served for inference only (the training step is two C calls for two levels)")
+            return self._forward_many_levels(rays, randomized, white_bkgd, near, far, t_rand, u, noise)
         layerwise = self._general or not self._fused_inference or (training and not self._fused_training and not self.coarse_mlp.geometry.is_default)
         if layerwise:
             geom = self.coarse_mlp.geometry

@@ -240,6 +240,39 @@ def test_training_above_256_samples_per_ray(dev):
         big({k: v.to(dev) for k, v in rays_cpu.items()}, False, True, 2.0, 6.0)
 
 
+def test_more_than_two_levels(dev):
+    """NeRF(num_levels=3 / 4): every further level resamples from the previous level's t and weights with fine_mlp
+    (model.py:162-173); inference through the stage-level calls against the oracle's loop, smooth field, every robust ray."""
+    import aon_amd.synthetic as syn
+    from aon_amd.models.vanilla_nerf.model import NeRF
+
+    sd = syn.make_smooth_nerf_state_dict()
+    frame = syn.make_rays(16, 24, syn.look_at_pose(4.0, 60, 20), syn.focal_from_fovy(16))
+    rays_cpu = {k: v[::2].contiguous() for k, v in frame.items()}
+    rays = {k: v.to(dev) for k, v in rays_cpu.items()}
+    n = rays["rays_o"].shape[0]
+    for levels, nc, nf in ((3, 64, 128), (4, 24, 40)):
+        model = NeRF(num_levels=levels, num_coarse_samples=nc, num_fine_samples=nf).to(dev)
+        model.load_state_dict(sd)
+        tr, u = syn.seeded_uniform(101, n, nc + 1), syn.seeded_uniform(102, n, nf)
+        with torch.no_grad():
+            det = model(rays, False, True, 2.0, 6.0)
+            rnd = model(rays, True, False, 2.0, 6.0, t_rand=tr.to(dev), u=[u.to(dev)] * (levels - 1))
+        ref_d, aux = orc.nerf_forward(sd, rays_cpu, False, True, 2.0, 6.0, num_levels=levels, num_coarse_samples=nc, num_fine_samples=nf, return_aux=True)
+        ref_r, aux_r = orc.nerf_forward(sd, rays_cpu, True, False, 2.0, 6.0, num_levels=levels, num_coarse_samples=nc, num_fine_samples=nf, t_rand=tr, u=u,
+                                        return_aux=True)
+        ok = torch.stack([a["raw_sigma"][:, -1, 0].abs() for a in aux + aux_r]).min(0).values > 0.05
+        assert len(det) == levels and ok.float().mean() > 0.8
+        for lvl in range(levels):
+            assert det[lvl][0].shape == (n, 3)
+            for out, ref in ((det, ref_d), (rnd, ref_r)):
+                # (every resampling level re-amplifies the last bits of the previous level's weights: measured 5.2e-6 at level 3)
+                torch.testing.assert_close(out[lvl][0].cpu()[ok], ref[lvl][0][ok], rtol=0, atol=2e-5)
+                torch.testing.assert_close(out[lvl][2].cpu()[ok], ref[lvl][2][ok], rtol=0, atol=2e-4)
+    with pytest.raises(NotImplementedError):       # training: two levels
+        model(rays, False, True, 2.0, 6.0)[0][0].sum().backward()
+
+
 def test_bad_options_are_rejected(dev):
     from aon_amd import ops
     from aon_amd.models.vanilla_nerf.model import NeRF
@@ -247,7 +280,9 @@ def test_bad_options_are_rejected(dev):
     with pytest.raises(ValueError):
         NeRF(num_coarse_samples=1)
     with pytest.raises(NotImplementedError):
-        NeRF(num_levels=3)
+        NeRF(num_levels=3, max_deg_point=6)          # more than two levels: default network only
+    with pytest.raises(ValueError):
+        NeRF(num_levels=0)
     m = NeRF(num_coarse_samples=900, num_fine_samples=8000)      # exceeds the per-ray LDS image: the C call says so
     import aon_amd.synthetic as syn
     m = m.to(dev)
