@@ -45,10 +45,14 @@ def pos_enc(x, min_deg, max_deg):
 
 
 def volumetric_rendering(rgb, density, t_vals, dirs, white_bkgd, nocs=None):
-    """helper.py:157-195 -> (comp_rgb, acc, weights, depth)"""
+    """helper.py:157-195 -> (comp_rgb, acc, weights, depth), or with ``nocs`` (n,S,3) -> (comp_rgb, acc, weights, comp_nocs)
+    (:191-193): comp_nocs = sum_s weights * nocs is the same compositing kernel run on `nocs` in place of `rgb` without the white
+    background (the weights depend on density and t only)."""
+    comp_rgb, acc, weights, depth = ops.volumetric_rendering(rgb, density, t_vals, dirs, white_bkgd)
     if nocs is not None:
-        raise NotImplementedError("the nocs branch (helper.py:191-193) is not on the rendered path")
-    return ops.volumetric_rendering(rgb, density, t_vals, dirs, white_bkgd)
+        comp_nocs = ops.volumetric_rendering(nocs, density, t_vals, dirs, False)[0]
+        return comp_rgb, acc, weights, comp_nocs
+    return comp_rgb, acc, weights, depth
 
 
 def sorted_piecewise_constant_pdf(bins, weights, num_samples, randomized, float_min_eps=2 ** -32, u=None):

@@ -654,3 +654,19 @@ def test_full_frame_properties(ops, dev, nerf_sd):
     ref, aux = orc.nerf_forward(nerf_sd, rays_cpu, False, True, 2.0, 6.0, return_aux=True)
     ok = _robust_rays(aux)
     torch.testing.assert_close(full[1][0][pick.to(dev)].cpu()[ok], ref[1][0][ok], rtol=0, atol=2e-4)
+
+
+def test_volumetric_rendering_nocs_branch(dev, golden):
+    """helper.volumetric_rendering(..., nocs=...) (helper.py:191-193): (comp_rgb, acc, weights, comp_nocs) against the reference's
+    formula on G5's inputs (the reference function itself is run in tests/golden only for the nocs=None form)."""
+    from aon_amd.models.vanilla_nerf import helper
+
+    g = golden("g5_volumetric_rendering")
+    gen = torch.Generator().manual_seed(3)
+    nocs = torch.rand(g["rgb"].shape, generator=gen)
+    out = helper.volumetric_rendering(g["rgb"].to(dev), g["density"].to(dev), g["t_vals"].to(dev), g["dirs"].to(dev), True, nocs=nocs.to(dev))
+    assert len(out) == 4
+    torch.testing.assert_close(out[0].cpu(), g["comp_rgb_wb1"], rtol=0, atol=2e-6)
+    torch.testing.assert_close(out[2].cpu(), g["weights_wb1"], rtol=0, atol=2e-6)
+    want = (g["weights_wb1"][..., None] * nocs).sum(dim=-2)
+    torch.testing.assert_close(out[3].cpu(), want, rtol=0, atol=2e-6)
