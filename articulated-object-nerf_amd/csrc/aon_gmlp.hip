@@ -126,13 +126,22 @@ __global__ void __launch_bounds__(256) gemm_tn_kernel(GemmArgs a) {
   };
   fetch(0);
   for (int c = 0; c < nch; ++c) {
+#ifndef AON_EXP_GEMM_NOBARRIER     // timing experiment only (WRONG results)
     __syncthreads();                 // the previous chunk's fragment reads are done
+#endif
     store_tile_rows(As[0], tid, va);
     store_tile_rows(Bs[0], tid, vb);
+#ifndef AON_EXP_GEMM_NOBARRIER
     __syncthreads();
+#else
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
     if (c + 1 < nch) fetch(c + 1);   // in flight under the MFMAs below
     compute(As[0], Bs[0]);
   }
+#ifdef AON_EXP_GEMM_NOSTORE
+  float exp_sum = 0.f;
+#endif
   // epilogue: lane holds column n = .. + r, rows 8 (e >> 2) + (e & 3) + 4 h of each 32 x 32 tile
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
@@ -151,7 +160,12 @@ __global__ void __launch_bounds__(256) gemm_tn_kernel(GemmArgs a) {
         float y = __fadd_rn(acc[i][j][e], b);
         if (a.epi == 1) y = __builtin_fmaxf(y, 0.f);
         else if (a.epi == 2) y = arow[dm * a.ldaux] > 0.f ? y : 0.f;
+#ifdef AON_EXP_GEMM_NOSTORE        // timing experiment only (WRONG results): the 64 values summed into ONE store per lane
+        exp_sum += y;
+        if (e == 15 && i == 1 && j == 1) yrow[dm * a.ldy] = exp_sum;
+#else
         yrow[dm * a.ldy] = y;
+#endif
       }
     }
   }
