@@ -1429,9 +1429,9 @@ GScratch carve_gscratch(void* base, const GG& g, const Geo& geo, int64_t n, int 
   int64_t part = 0;
   auto need = [&](int N, int K) { const int64_t f = aon::wgrad_part_floats(M, N, K); if (f > part) part = f; };
   need(g.W, g.P); need(g.W, g.W); need(g.Wc, g.W); need(g.Wc, g.V); need(g.Wc, g.Wc); need(g.Crgb, g.Wc); need(g.Cd, g.W);
-  int64_t nmax = wmax;                                  // widest bias vector: the column-sum partials are 512 x N
+  int64_t nmax = wmax;                                  // widest bias vector: the column-sum partials are 512 x N DOUBLES
   for (int64_t cand : {(int64_t)g.Crgb, (int64_t)g.Cd}) nmax = cand > nmax ? cand : nmax;
-  const int64_t cs = 512 * nmax;
+  const int64_t cs = 2 * 512 * nmax;
   s.part = c.f(part > cs ? part : cs);
   s.bytes = c.off;
   return s;

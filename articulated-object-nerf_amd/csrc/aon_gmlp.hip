@@ -291,25 +291,35 @@ __global__ void __launch_bounds__(256) wgrad_nk_kernel(WgradArgs a) {
   }
 }
 
-// column sums of A[m0:m1, 0:N] -> part[split][N].  Block = 64 columns x 4 row lanes: a wave reads 256 contiguous bytes of one row,
-// the four waves take rows m, m+1, m+2, m+3 (fixed association: lane sums in row order, then the four lanes in order).
+// column sums of A[m0:m1, 0:N] -> part[split][N] (doubles).  Block = 64 columns x 4 row lanes: a wave reads 256 contiguous bytes of one
+// row, the four waves take rows m, m+1, m+2, m+3 (fixed association: lane sums in row order, then the four lanes in order).
+// Bias gradients are signed sums over every sample (the head biases: pure cancellation), so the running sums, the partials and the
+// second stage are fp64 and the result is rounded to float once (the kernel is HBM-bound; rounds 1-3 summed in fp32).
 // (The first version gave a thread a column and the whole row range: 2.6 ms per call, half of the layer-wise training step.)
 __global__ void __launch_bounds__(256) colsum_kernel(const float* __restrict__ A, int64_t lda, int64_t M, int N, int64_t rows_per_split,
-                                                     float* __restrict__ part) {
-  __shared__ float red[4][64];
+                                                     double* __restrict__ part) {
+  __shared__ double red[4][64];
   const int c = threadIdx.x & 63, y = threadIdx.x >> 6;
   const int n = blockIdx.x * 64 + c;
   const int64_t mb = (int64_t)blockIdx.y * rows_per_split;
   const int64_t me = mb + rows_per_split < M ? mb + rows_per_split : M;
-  float s0 = 0.f, s1 = 0.f;
+  double s0 = 0.0, s1 = 0.0;
   if (n < N) {
     int64_t m = mb + y;
-    for (; m + 4 < me; m += 8) { s0 += A[m * lda + n]; s1 += A[(m + 4) * lda + n]; }
-    if (m < me) s0 += A[m * lda + n];
+    for (; m + 4 < me; m += 8) { s0 += (double)A[m * lda + n]; s1 += (double)A[(m + 4) * lda + n]; }
+    if (m < me) s0 += (double)A[m * lda + n];
   }
   red[y][c] = s0 + s1;
   __syncthreads();
   if (y == 0 && n < N) part[(int64_t)blockIdx.y * N + n] = ((red[0][c] + red[1][c]) + red[2][c]) + red[3][c];
+}
+
+__global__ void __launch_bounds__(256) colsum_reduce_kernel(const double* __restrict__ part, int splits, int N, float* __restrict__ dst) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= N) return;
+  double s = 0.0;
+  for (int k = 0; k < splits; ++k) s += part[(int64_t)k * N + i];
+  dst[i] = (float)s;
 }
 
 // dst[(i / cols) * ldd + i % cols] = sum_s part[s * count + i]   in split order (deterministic)
@@ -373,8 +383,9 @@ hipError_t launch_colsum(const float* A, int64_t lda, int64_t M, int N, float* d
   if (splits > 512) splits = 512;
   if (splits < 1) splits = 1;
   const int64_t rows = (M + splits - 1) / splits;
-  colsum_kernel<<<dim3((unsigned)((N + 63) / 64), (unsigned)splits), dim3(256), 0, stream>>>(A, lda, M, N, rows, part);
-  reduce_kernel<<<dim3((unsigned)((N + 255) / 256)), dim3(256), 0, stream>>>(part, (int)splits, N, N, N, db);
+  double* dpart = reinterpret_cast<double*>(part);   // 512 x N doubles at most (carve_gscratch)
+  colsum_kernel<<<dim3((unsigned)((N + 63) / 64), (unsigned)splits), dim3(256), 0, stream>>>(A, lda, M, N, rows, dpart);
+  colsum_reduce_kernel<<<dim3((unsigned)((N + 255) / 256)), dim3(256), 0, stream>>>(dpart, (int)splits, N, db);
   return hipGetLastError();
 }
 

@@ -299,7 +299,7 @@ struct HeadJob {
   const float* vec;        // record of sample n at vec + (n >> 5) * vec_step + (n & 31) * 4
   int64_t vec_step;        // floats per 32 samples: 128 (sample-major) or rows_total * 32 (a plane unit row)
   int blk_begin;           // first blockIdx.x of this job (ceil(rows / 8) blocks)
-  int part_off;            // float offset of partial[nseg][rows][8]
+  int part_off;            // float offset (even: the records are doubles) of partial[nseg][rows][8 doubles]
 };
 constexpr int kHeadMaxJobs = 8;
 struct HeadArgs {
@@ -311,6 +311,17 @@ struct HeadArgs {
 };
 
 #ifdef AON_WGRAD_KERNELS
+// The sums are SIGNED sums over every sample of a level (the one- and three-element head biases are pure cancellation on a
+// trained field), so every stage accumulates in fp64: the product of two floats is exact in a double, the partials are
+// doubles, and the result is rounded to float ONCE, in the second stage.  The kernel is HBM-bound: the fp64 pipe is idle
+// otherwise.  (Rounds 1-3 summed in fp32: one constructor-fuzz seed in 150 had the coarse density bias 3e-3 from the fp64
+// truth where the reference's own fp32 sits at 9e-5.)
+__device__ __forceinline__ double wsum64d(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+
 __global__ void __launch_bounds__(256) head_wgrad_kernel(HeadArgs a) {
   int j = 0;
 #pragma unroll 1
@@ -321,11 +332,11 @@ __global__ void __launch_bounds__(256) head_wgrad_kernel(HeadArgs a) {
   const int nr = J.rows - row0 < 8 ? J.rows - row0 : 8;
   const int64_t n0 = (int64_t)seg * a.seg_len;
   const int64_t n1 = n0 + a.seg_len < a.Np ? n0 + a.seg_len : a.Np;
-  float s[8][5];
+  double s[8][5];
 #pragma unroll
   for (int r = 0; r < 8; ++r)
 #pragma unroll
-    for (int c = 0; c < 5; ++c) s[r][c] = 0.f;
+    for (int c = 0; c < 5; ++c) s[r][c] = 0.0;
   const float* u0 = J.plane ? J.plane + (int64_t)(J.unit + row0 / 4) * 128 : nullptr;
   for (int64_t n = n0 + threadIdx.x; n < n1; n += 256) {
     const int64_t st = n >> 5;
@@ -336,27 +347,29 @@ __global__ void __launch_bounds__(256) head_wgrad_kernel(HeadArgs a) {
       x0 = *reinterpret_cast<const f32x4*>(u0 + st * a.step_floats + sl * 4);
       if (nr > 4) x1 = *reinterpret_cast<const f32x4*>(u0 + 128 + st * a.step_floats + sl * 4);
     }
+    const double dd[4] = {(double)d[0], (double)d[1], (double)d[2], (double)d[3]};
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
-      const float x = r < 4 ? x0[r] : x1[r - 4];
+      const double x = (double)(r < 4 ? x0[r] : x1[r - 4]);
 #pragma unroll
-      for (int c = 0; c < 4; ++c) s[r][c] = __builtin_fmaf(x, d[c], s[r][c]);
+      for (int c = 0; c < 4; ++c) s[r][c] = __builtin_fma(x, dd[c], s[r][c]);
       s[r][4] += x;
     }
   }
-  __shared__ float red[4][8][5];
+  __shared__ double red[4][8][5];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
   for (int r = 0; r < 8; ++r)
 #pragma unroll
     for (int c = 0; c < 5; ++c) {
-      const float v = wsum64(s[r][c]);
+      const double v = wsum64d(s[r][c]);
       if (lane == 0) red[wv][r][c] = v;
     }
   __syncthreads();
   if (threadIdx.x < 40) {
     const int r = threadIdx.x / 5, c = threadIdx.x % 5;
-    if (r < nr) a.ws[J.part_off + ((int64_t)seg * J.rows + row0 + r) * 8 + c] = (red[0][r][c] + red[1][r][c]) + (red[2][r][c] + red[3][r][c]);
+    double* P = reinterpret_cast<double*>(a.ws + J.part_off);
+    if (r < nr) P[((int64_t)seg * J.rows + row0 + r) * 8 + c] = (red[0][r][c] + red[1][r][c]) + (red[2][r][c] + red[3][r][c]);
   }
 }
 
@@ -390,9 +403,10 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(ReduceArgs a) {
     const HeadOut& H = a.head[(int)blockIdx.x - a.head_blk_begin];
     for (int idx = threadIdx.x; idx < H.rows * H.nchan; idx += 256) {
       const int row = idx / H.nchan, c = idx % H.nchan;
-      float s = 0.f;
-      for (int p = 0; p < a.nseg; ++p) s += a.ws[H.part_off + ((int64_t)p * H.rows + row) * 8 + H.chan0 + c];
-      H.out[(int64_t)c * H.stride_c + (int64_t)row * H.stride_r] = s;
+      const double* P = reinterpret_cast<const double*>(a.ws + H.part_off);
+      double s = 0.0;
+      for (int p = 0; p < a.nseg; ++p) s += P[((int64_t)p * H.rows + row) * 8 + H.chan0 + c];
+      H.out[(int64_t)c * H.stride_c + (int64_t)row * H.stride_r] = (float)s;
     }
     return;
   }
@@ -429,19 +443,20 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(ReduceArgs a) {
     }
   } else if (R.bias_off >= 0) {
     // 16 rows per block; thread (r, g) sums partials g, g+16, ...; the 16 group sums are added in group order
-    float* redf = reinterpret_cast<float*>(&red[0][0]);
+    // (the partials are the fp32 row sums a weight-gradient workgroup took over its steps; from here on in fp64)
+    double* redd = reinterpret_cast<double*>(&red[0][0]);   // 256 doubles of the 4 KiB
     const int r = threadIdx.x & 15, g = threadIdx.x >> 4;
     const int row = (blk - R.nblk_w) * 16 + r;
-    float s = 0.f;
+    double s = 0.0;
     if (row < R.M)
-      for (int pp = g; pp < R.nparts; pp += 16) s += a.ws[R.bias_off + (int64_t)pp * R.M + row];
-    redf[g * 16 + r] = s;
+      for (int pp = g; pp < R.nparts; pp += 16) s += (double)a.ws[R.bias_off + (int64_t)pp * R.M + row];
+    redd[g * 16 + r] = s;
     __syncthreads();
     if (g == 0 && row < R.M) {
-      float t = 0.f;
+      double t = 0.0;
 #pragma unroll
-      for (int q = 0; q < 16; ++q) t += redf[q * 16 + r];
-      R.bias_out[row] = t;
+      for (int q = 0; q < 16; ++q) t += redd[q * 16 + r];
+      R.bias_out[row] = (float)t;
     }
   }
 }
@@ -578,8 +593,9 @@ inline int head_make_plan(const HeadDesc* heads, int nheads, int rows_total, int
     HeadJob& J = H.job[j];
     J.plane = heads[j].plane; J.unit = heads[j].row / 4; J.rows = heads[j].rows; J.vec = heads[j].vec; J.vec_step = heads[j].vec_step;
     J.blk_begin = blk; blk += (heads[j].rows + 7) / 8;
+    ws_off += ws_off & 1;   // records of 8 doubles
     J.part_off = (int)ws_off; part_offs[j] = J.part_off;
-    ws_off += (int64_t)nseg * heads[j].rows * 8;
+    ws_off += (int64_t)nseg * heads[j].rows * 16;
   }
   return blk;
 }

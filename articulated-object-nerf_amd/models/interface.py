@@ -110,6 +110,19 @@ class Harness(LitModel):
         optimizer.step(closure=closure)
         self.global_step += 1
 
+    def fit_step(self, batch, batch_idx, optimizer):
+        """One batch of Lightning's automatic optimisation under its DDP plugin (run.py:144-153): zero_grad, training_step,
+        backward, the data-parallel gradient mean (ONE flat RCCL bucket, `parallel.allreduce_gradients`; a no-op without a process
+        group or at world size 1; DDP's find_unused_parameters=False contract as in run.py:151), then the LR rule + optimizer step."""
+        from ..parallel import allreduce_gradients
+
+        optimizer.zero_grad(set_to_none=True)
+        loss = self.training_step(batch, batch_idx)
+        loss.backward()
+        allreduce_gradients(self)
+        self.optimizer_step(optimizer)
+        return loss.detach()
+
     @torch.no_grad()
     def test_epoch_end(self, outputs, image_sizes, out_dir=None, name="image"):
         """Gather the per-image test outputs over ranks, PSNR over whole images and over object pixels, and (rank 0,

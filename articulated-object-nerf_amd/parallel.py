@@ -96,21 +96,52 @@ def broadcast_parameters(module, src: int = 0, group=None, force: bool = False) 
         torch._foreach_copy_([p.data for p in params], [c.view_as(p) for c, p in zip(flat.split([p.numel() for p in params]), params)])
 
 
-def allreduce_gradients(module, group=None, force: bool = False, shard_align: int = 64) -> None:
+class UnevenGradientsError(RuntimeError):
+    """Ranks disagreed on which parameters produced a gradient while `find_unused_parameters=False` (see allreduce_gradients)."""
+
+
+_pending_checks: list = []   # [(event or None, host flag tensor, message)] of earlier calls, looked at without waiting
+
+
+def _raise_if_earlier_call_was_uneven(wait: bool = False) -> None:
+    keep = []
+    for ev, flag, msg in _pending_checks:
+        if ev is not None and not ev.query():
+            if not wait:
+                keep.append((ev, flag, msg))
+                continue
+            ev.synchronize()
+        if bool(flag.item()):
+            _pending_checks.clear()
+            raise UnevenGradientsError(msg)
+    _pending_checks[:] = keep
+
+
+def allreduce_gradients(module, group=None, force: bool = False, shard_align: int = 64, find_unused_parameters: bool = False) -> None:
     """Mean of the per-rank gradients in ONE flat bucket (vanilla: 1,191,688 fp32 = 4.77 MB; articulated 6.4 MB), call
     between loss.backward() and optimizer.step().
 
     The bucket spans EVERY parameter that requires grad, in module order, with zeros where this rank produced no gradient
-    (a rank may skip a code-library row) -- ranks therefore always agree on the message size -- followed by one "had a
-    gradient" flag per parameter, summed in the same exchange.  The mean is written back as `.grad` for every parameter
-    that SOME rank produced a gradient for; a parameter no rank touched (num_levels=1 leaves fine_mlp alone) keeps
-    `.grad = None` exactly as under torch DDP (run.py:151), so the optimizer skips it and its Adam state does not
-    advance.  On RCCL the exchange is the direct
-    reduce-scatter + all-gather pair (each of the 8 fully connected xGMI peers reduces one eighth of the bucket, scales
-    it, and the eighths are gathered: 2 x 7/8 of the bucket per link instead of a ring's 2 x 7 hops).  Every rank's shard is
-    a multiple of `shard_align` elements (256 B): the bucket is zero-padded to world x that."""
+    -- ranks therefore always agree on the message size -- followed by one "had a gradient" flag per parameter, summed in the
+    same exchange.  A parameter no rank touched (num_levels=1 leaves fine_mlp alone) keeps `.grad = None` exactly as under
+    torch DDP, so the optimizer skips it and its Adam state does not advance.
+
+    `find_unused_parameters=False` (the default, and what the reference wraps its module with: run.py:151) is DDP's contract:
+    every rank produces gradients for the SAME set of parameters.  Then "`.grad is None` here" already means "None
+    everywhere": the exchange needs NO host read and the call never synchronises with the device (round 3 read the flags
+    back with `.tolist()` on every rank that lacked a gradient -- every step of a `num_levels=1` run).  The contract is still
+    checked, the way DDP checks it -- late: a device-side comparison of the summed flags with {0, world} is copied to pinned
+    memory behind the exchange, and the NEXT call (or `check_gradient_exchange()`) raises UnevenGradientsError if it failed.
+    `find_unused_parameters=True` is the permissive mode (a rank may skip a code-library row another rank trained): ranks
+    that lack a gradient read the summed flags (one host synchronisation, as torch DDP has in that mode) and adopt the mean
+    of the ranks that had one.
+
+    On RCCL the exchange is the direct reduce-scatter + all-gather pair (each of the 8 fully connected xGMI peers reduces one
+    eighth of the bucket, scales it, and the eighths are gathered: 2 x 7/8 of the bucket per link instead of a ring's 2 x 7
+    hops).  Every rank's shard is a multiple of `shard_align` elements (256 B): the bucket is zero-padded to world x that."""
     if not (_active(group) or (force and dist.is_available() and dist.is_initialized())):
         return
+    _raise_if_earlier_call_was_uneven()
     params = [p for p in module.parameters() if p.requires_grad]
     if not params:
         return
@@ -129,22 +160,47 @@ def allreduce_gradients(module, group=None, force: bool = False, shard_align: in
         flat[total: total + len(params)] = torch.tensor([float(h) for h in had], dtype=ref.dtype).to(ref.device, non_blocking=True)
         # one code path for both backends: reduce-scatter -> scale the shard -> all-gather.  gloo has no
         # reduce_scatter_tensor, so there the scatter is an all_reduce of which every rank keeps its own shard -- the shard
-        # arithmetic (padding, offsets, rank order) is then exactly what RCCL runs and the world-2 CPU tests cover it.
+        # arithmetic (padding, offsets, rank order) is then exactly what RCCL runs and the CPU tests cover it.
         per = padded // world
+        r = dist.get_rank(group)
         if dist.get_backend(group) == "nccl":
             shard = flat.new_empty(per)
             dist.reduce_scatter_tensor(shard, flat, op=dist.ReduceOp.SUM, group=group)
         else:
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
-            r = dist.get_rank(group)
             shard = flat[r * per: (r + 1) * per].clone()
             flat.fill_(float("nan"))   # nothing below may depend on what the all_reduce left outside this rank's shard
-        shard /= world
+        # the flags are COUNTS and stay unscaled: only the gradient part of this rank's shard is divided by the world size
+        lo, hi = r * per, (r + 1) * per
+        ngrad = min(max(total - lo, 0), per)
+        if ngrad:
+            shard[:ngrad] /= world
         dist.all_gather_into_tensor(flat, shard, group=group)
         if any(had):
             torch._foreach_copy_([p.grad for p, h in zip(params, had) if h], [c.view_as(p) for c, p, h in zip(chunks, params, had) if h])
-        if not all(had):   # the one host read of the exchange, and only on ranks that lack a gradient some other rank may have
-            any_rank = (flat[total: total + len(params)] > 0).tolist()
-            for c, p, h, a in zip(chunks, params, had, any_rank):
-                if not h and a:
-                    p.grad = c.view_as(p).clone()
+        counts = flat[total: total + len(params)]
+        if find_unused_parameters:
+            if not all(had):   # the one host read of the exchange, and only on ranks that lack a gradient some other rank may have
+                any_rank = (counts > 0).tolist()
+                for c, p, h, a in zip(chunks, params, had, any_rank):
+                    if not h and a:
+                        p.grad = c.view_as(p).clone()
+        elif world > 1:
+            # DDP's contract, checked without waiting: every count must be 0 or `world`
+            uneven = ((counts > 0.5) & (counts < world - 0.5)).any()
+            msg = ("allreduce_gradients(find_unused_parameters=False): in an earlier step the ranks produced gradients for different sets "
+                   "of parameters (torch DDP raises the same way, one iteration late: run.py:151); pass find_unused_parameters=True")
+            if uneven.is_cuda:
+                host = torch.empty((), dtype=torch.bool, pin_memory=True)
+                host.copy_(uneven, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record()
+                _pending_checks.append((ev, host, msg))
+            else:
+                _pending_checks.append((None, uneven, msg))
+
+
+def check_gradient_exchange() -> None:
+    """Wait for the deferred checks of earlier allreduce_gradients(find_unused_parameters=False) calls and raise
+    UnevenGradientsError if one failed (end of an epoch, before a checkpoint)."""
+    _raise_if_earlier_call_was_uneven(wait=True)

@@ -307,6 +307,8 @@ def train_leg(dev, rank, world, distributed, steps=6, n_rays=4096):
         rays = {"rays_o": ro[idx].contiguous(), "rays_d": vd[idx].contiguous(), "viewdirs": vd[idx].contiguous()}
         target = torch.rand(n_rays, 3, device=dev, generator=g)
 
+        ar_marks = []
+
         def step():
             opt.zero_grad(set_to_none=True)
             latents = lib(batch)
@@ -314,7 +316,11 @@ def train_leg(dev, rank, world, distributed, steps=6, n_rays=4096):
             reg = sum(torch.mean(torch.norm(latents[k], dim=0)) for k in ("density", "color", "articulation"))
             loss = torch.mean((out[0][0] - target) ** 2) + torch.mean((out[1][0] - target) ** 2) + 1e-4 * reg
             loss.backward()
-            allreduce_gradients(both)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            allreduce_gradients(both)     # a no-op at world size 1
+            e1.record()
+            ar_marks.append((e0, e1))
             opt.step()
             return loss
 
@@ -342,6 +348,12 @@ def train_leg(dev, rank, world, distributed, steps=6, n_rays=4096):
 
         # the step as the product runs it: backward of the two levels on two library streams, no kernel-class timers
         dt, loss, _ = timed()
+        # gradient exchange as this rank saw it (HIP events; includes waiting for the slowest rank's backward), min / max over ranks
+        ar = torch.tensor([sum(a.elapsed_time(b) for a, b in ar_marks[-steps:]) / steps], dtype=torch.float64, device=dev)
+        ar_all = [ar.clone() for _ in range(world)]
+        if distributed:
+            dist.all_gather(ar_all, ar)
+        ar_all = torch.cat(ar_all).cpu()
         # per-kernel-class durations from a second pass with the two levels SERIALISED on one stream (on two streams the
         # classes of the two levels overlap in time and their HIP-event intervals neither add up nor price one kernel)
         ops.set_bwd_overlap(False)
@@ -365,6 +377,9 @@ def train_leg(dev, rank, world, distributed, steps=6, n_rays=4096):
         other_ms = sum(classes[k][0] for k in ("composite", "sample_pdf", "composite_pdf", "composite_bwd", "sample_t") if k in classes) / steps
         res = {"workload": f"articulated NeRF_AE_Art training step, {n_rays} rays/GPU, fwd+bwd" + (" + RCCL gradient all-reduce (6.4 MB, one bucket)" if world > 1 else "") + " + Adam",
                "ms_per_step": dt * 1e3, "rays_per_s": world * n_rays / dt, "steps": steps, "loss": loss,
+               "allreduce_ms": {"min": ar_all.min().item(), "max": ar_all.max().item(), "per_rank": ar_all.tolist(),
+                                "note": "parallel.allreduce_gradients per step, HIP events on the launch stream; 0 at world size 1 (no-op); "
+                                        "includes the wait for the slowest rank's backward"},
                "roofline": {"bound": "mfma", "unit": "TFLOP/s", "peak": PEAK_FP32_MATRIX_TFLOPS,
                             "achieved": samples * mac_ex * 2 / dt / 1e12, "frac": samples * mac_ex * 2 / dt / 1e12 / PEAK_FP32_MATRIX_TFLOPS,
                             "achieved_reference_literal": samples * mac_lit * 2 / dt / 1e12,
@@ -426,11 +441,17 @@ def main():
 
     distributed = dist.is_available() and dist.is_initialized()
 
+    marks = []   # per timed step: (begin, rendered, gathered) events on torch's current stream (recording is asynchronous)
+
     def step():
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        ev[0].record()
         out = model(rays, False, True, syn.NEAR, syn.FAR)
-        if distributed:
-            return all_gather_pixels(out[1], counts=[n_rays] * world)  # one RCCL all-gather of 20 B/ray; (world*n, .) rank-major
-        return out[1]
+        ev[1].record()
+        res = all_gather_pixels(out[1], counts=[n_rays] * world) if distributed else out[1]   # one RCCL all-gather of 20 B/ray; (world*n, .) rank-major
+        ev[2].record()
+        marks.append(ev)
+        return res
 
     def fence():
         torch.cuda.synchronize()
@@ -442,6 +463,7 @@ def main():
         for _ in range(args.warmup):
             step()
         fence()
+        marks.clear()
         ops.profile_begin()
         t0 = time.perf_counter()
         for _ in range(args.steps):
@@ -451,10 +473,27 @@ def main():
         mlp_ms, mlp_launches, mlp_samples = ops.profile_end()
         headline_classes = ops.profile_classes()
 
+    dt_local = dt
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if distributed:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = t.item()
+    # Self-diagnosis of a multi-GPU run (outside the timed region): who took part, and where each rank's time went.  `render_ms`
+    # = NeRF.forward of this rank's frame, `gather_ms` = the all-gather INCLUDING the wait for the slowest rank to arrive.
+    render_ms = sum(e[0].elapsed_time(e[1]) for e in marks) / max(len(marks), 1)
+    gather_ms = sum(e[1].elapsed_time(e[2]) for e in marks) / max(len(marks), 1)
+    mine = torch.tensor([1.0, rank, render_ms, gather_ms, dt_local / args.steps * 1e3], dtype=torch.float64, device=dev)
+    per_rank = [mine.clone() for _ in range(world)]
+    if distributed:
+        dist.all_gather(per_rank, mine)
+    per_rank = torch.stack(per_rank).cpu()
+    diag = {"ranks_seen": int(per_rank[:, 0].sum().item()), "world": world, "device": torch.cuda.get_device_name(dev),
+            "render_ms": {"min": per_rank[:, 2].min().item(), "max": per_rank[:, 2].max().item(), "per_rank": per_rank[:, 2].tolist()},
+            "gather_ms": {"min": per_rank[:, 3].min().item(), "max": per_rank[:, 3].max().item(), "per_rank": per_rank[:, 3].tolist()},
+            "step_ms_host_clock": {"min": per_rank[:, 4].min().item(), "max": per_rank[:, 4].max().item()},
+            "note": "HIP events on the launch stream per timed step; gather_ms includes waiting for the slowest rank, so "
+                    "max(render_ms) + min(gather_ms) ~ ms_per_step; the efficiency of the weak-scaled value is ~ N=1's ms_per_step / ms_per_step"}
+    n1_frame_ms = per_rank[:, 2].mean().item()   # one rank rendering one whole frame alone: the N = 1 reference of the sharded leg
 
     # BASELINE config 3 literally (informational, never `value`): ONE 640x480 frame, contiguous ray ranges sharded over the
     # ranks, fine-level pixels all-gathered (RCCL) -- strong scaling of a single frame, where `value` above is weak scaling.
@@ -488,13 +527,33 @@ def main():
                     frame = render_frame_sharded(model, H, W, focal0, c2w0, syn.NEAR, syn.FAR, True, raygen, force=True)
                 fence()
                 tsd = torch.tensor([time.perf_counter() - ts], dtype=torch.float64, device=dev)
+                # where a rank's time goes: its shard alone (raygen + render, no collective), timed after the frames above
+                from aon_amd.parallel import shard_range
+                b0, e0 = shard_range(n_rays, rank, world)
+                sh0, sh1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                sh0.record()
+                for _ in range(args.steps):
+                    ro_s, vd_s = raygen(H, W, focal0, c2w0, b0, e0)
+                    model({"rays_o": ro_s, "rays_d": vd_s, "viewdirs": vd_s}, False, True, syn.NEAR, syn.FAR)
+                sh1.record()
+                fence()
+                shard_ms = torch.tensor([sh0.elapsed_time(sh1) / args.steps], dtype=torch.float64, device=dev)
+            shard_all = [shard_ms.clone() for _ in range(world)]
             if distributed:
                 dist.all_reduce(tsd, op=dist.ReduceOp.MAX)
+                dist.all_gather(shard_all, shard_ms)
+            shard_all = torch.cat(shard_all).cpu()
             dts = tsd.item() / args.steps
             sharded = {"workload": f"BASELINE config 3: one {W}x{H} frame, contiguous ray ranges sharded over {world} rank(s), raygen on the GPU, "
                                    "fine-level pixels all-gathered over RCCL (the collective runs at world size 1 too)",
                        "ms_per_frame": dts * 1e3, "rays_per_s": n_rays / dts, "frame_rows": int(frame[0].shape[0]), "world": world,
-                       "collective": "all_gather_into_tensor (nccl = RCCL), 20 B/ray"}
+                       "collective": "all_gather_into_tensor (nccl = RCCL), 20 B/ray",
+                       "n1_frame_ms": n1_frame_ms,
+                       "efficiency_vs_n1": n1_frame_ms / world / (dts * 1e3),
+                       "shard_render_ms": {"min": shard_all.min().item(), "max": shard_all.max().item(), "per_rank": shard_all.tolist()},
+                       "exchange_and_skew_ms": dts * 1e3 - shard_all.max().item(),
+                       "note": "efficiency_vs_n1 = (a whole frame rendered by ONE rank in this same run: the mean render_ms of the weak-scaled "
+                               "leg) / world / ms_per_frame; exchange_and_skew_ms = ms_per_frame - the slowest rank's shard rendered alone"}
         except Exception as e:  # informational leg
             sharded = {"error": f"{type(e).__name__}: {e}"}
         finally:
@@ -527,6 +586,7 @@ def main():
                                    f"{n_rays} rays per GPU per step, randomized=False, white_bkgd=True",
                        "rays_per_gpu": n_rays, "evals_per_ray": EVALS_PER_RAY,
                        "exchange": "RCCL all_gather of (rgb,acc,depth)=20 B/ray" if world > 1 else "none"},
+            "multi_gpu": diag,
             "roofline": {"bound": "mfma", "kernel": "aon::mlp_fwd_kernel<true> (fused encode+MLP, fp32 MFMA)",
                          "achieved": mlp_tflops, "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
                          "frac": mlp_tflops / PEAK_FP32_MATRIX_TFLOPS, "traffic": None,

@@ -64,10 +64,7 @@ def main():
     opt = lit.configure_optimizers()
     log, t0 = [], time.perf_counter()
     for step in range(args.steps):
-        opt.zero_grad(set_to_none=True)
-        loss = lit.training_step(collate(train[step], dev), step)
-        loss.backward()
-        lit.optimizer_step(opt)
+        lit.fit_step(collate(train[step], dev), step, opt)   # zero_grad, training_step, backward, (DDP mean), LR rule + Adam
         if (step + 1) % args.val_every == 0 or step + 1 == args.steps:
             lit.validation_step(collate(val[0], dev), 0)
             rec = {"step": step + 1, "train_psnr_fine": lit.logged["train/psnr1"][-1], "val_psnr": lit.logged["val/psnr"][-1],

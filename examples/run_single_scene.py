@@ -59,10 +59,7 @@ def main():
     log = []
     while step < args.steps:
         for batch in train.train_batches(args.batch, generator=gen):
-            opt.zero_grad(set_to_none=True)
-            loss = lit.training_step({k: v.unsqueeze(0) for k, v in batch.items()}, step)
-            loss.backward()
-            lit.optimizer_step(opt)
+            lit.fit_step({k: v.unsqueeze(0) for k, v in batch.items()}, step, opt)
             step = lit.global_step
             if step % args.val_every == 0 or step == args.steps:
                 lit.validation_step({k: v.unsqueeze(0) for k, v in val[0].items()}, 0)

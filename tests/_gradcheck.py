@@ -1,18 +1,26 @@
 """Gradient parity yardstick shared by the GPU training tests (see tests/test_hip_smooth.py): truth = the oracle's autograd in
 fp64; yardstick = the oracle's own fp32 autograd (the reference's arithmetic) against that truth.  The HIP gradients must be as
-close to the truth as the reference's fp32 is, up to a factor 5 (floor 1e-4 relative L2)."""
+close to the truth as the reference's fp32 is, up to a factor 5 (floor 1e-4 relative L2).
+
+Parameters of at most four elements (the density / rgb / deformation head biases: signed sums over EVERY sample of a level) get the
+lower floor `small_floor` = 2e-5: since round 4 their sums are accumulated in fp64 on the device (csrc/aon_wgrad.h head_wgrad_kernel,
+csrc/aon_gmlp.hip colsum_kernel), so they carry no summation error of their own and need no allowance beyond the yardstick."""
 
 
 def rel_l2(a, b):
     return ((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30)).item()
 
 
-def assert_as_close_as_fp32(hip: dict, truth: dict, ref32: dict, what: str, factor: float = 5.0, floor: float = 1e-4):
-    bad, worst = {}, (0.0, 0.0, "")
+def assert_as_close_as_fp32(hip: dict, truth: dict, ref32: dict, what: str, factor: float = 5.0, floor: float = 1e-4, small_floor: float = 2e-5):
+    bad, worst, worst_ratio = {}, (0.0, 0.0, ""), (0.0, 0.0, 0.0, "")
     for name, gh in hip.items():
         e_hip, e_ref = rel_l2(gh, truth[name]), rel_l2(ref32[name], truth[name])
+        fl = small_floor if gh.numel() <= 4 else floor
         worst = max(worst, (e_hip, e_ref, name))
-        if e_hip > max(floor, factor * e_ref):
+        if e_hip > fl:   # the ratio only means something above the floor
+            worst_ratio = max(worst_ratio, (e_hip / max(e_ref, 1e-30), e_hip, e_ref, name))
+        if e_hip > max(fl, factor * e_ref):
             bad[name] = f"hip {e_hip:.1e} vs reference-fp32 {e_ref:.1e}"
-    print(f"{what}: worst gradient distance to the fp64 truth: hip {worst[0]:.2e} on {worst[2]} (reference fp32 there: {worst[1]:.2e})")
+    print(f"{what}: worst gradient distance to the fp64 truth: hip {worst[0]:.2e} on {worst[2]} (reference fp32 there: {worst[1]:.2e}); "
+          f"worst ratio above the floor: {worst_ratio[0]:.1f}x on {worst_ratio[3]} ({worst_ratio[1]:.1e} vs {worst_ratio[2]:.1e})")
     assert not bad, bad

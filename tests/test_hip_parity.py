@@ -648,12 +648,22 @@ def test_full_frame_properties(ops, dev, nerf_sd):
         assert d_ok.min().item() >= 0.0 and d_ok.max().item() <= 6.0 + 1e-3
         # white_bkgd only adds (1 - acc) (helper.py:187-188)
         torch.testing.assert_close(part[lvl][0], nowb[lvl][0] + (1.0 - nowb[lvl][1])[:, None], rtol=0, atol=1e-6)
-    # parity on a strided sample of the frame against the oracle
-    pick = torch.arange(0, H * W, 1201)
+    # parity against the oracle at the bar of config 1 and of the G8 fixture: >= 4,096 strided rays of THIS frame, both levels, every
+    # output (round 3 held 256 rays, fine rgb only, at 2e-4: VERDICT r3), on the far-plane-robust rays (helper.py:163)
+    pick = torch.arange(0, H * W, 73)
+    assert pick.numel() >= 4096
     rays_cpu = {k: v[pick.to(dev)].cpu() for k, v in rays.items()}
     ref, aux = orc.nerf_forward(nerf_sd, rays_cpu, False, True, 2.0, 6.0, return_aux=True)
     ok = _robust_rays(aux)
-    torch.testing.assert_close(full[1][0][pick.to(dev)].cpu()[ok], ref[1][0][ok], rtol=0, atol=2e-4)
+    assert ok.double().mean() > 0.8
+    for lvl in (0, 1):
+        got = [x[pick.to(dev)].cpu() for x in full[lvl]]
+        print(f"config 2 level {lvl}: {int(ok.sum())}/{ok.numel()} robust rays, max |rgb - oracle| {(got[0][ok] - ref[lvl][0][ok]).abs().max():.2e}, "
+              f"acc {(got[1][ok] - ref[lvl][1][ok]).abs().max():.2e}, depth {(got[2][ok] - ref[lvl][2][ok]).abs().max():.2e}")
+        torch.testing.assert_close(got[0][ok], ref[lvl][0][ok], rtol=0, atol=1e-5)
+        torch.testing.assert_close(got[1][ok], ref[lvl][1][ok], rtol=0, atol=1e-5)
+        torch.testing.assert_close(got[2][ok], ref[lvl][2][ok], rtol=0, atol=2e-4)
+        assert _psnr(got[0], ref[lvl][0]) >= 70.0
 
 
 def test_volumetric_rendering_nocs_branch(dev, golden):

@@ -77,7 +77,7 @@ def test_smooth_training_gradients(dev, golden, net):
     must be as close to the truth as the reference's fp32 is, up to a factor 5 (floor 1e-4 relative L2): an fp32 gradient that
     passes through the 2^9-octave encoding of the deformed point is itself only good to ~1e-2 on some deformation parameters.
     Measured round 2: every parameter within 3x except the density head (a signed sum over all samples: 4.8e-5 against the
-    reference's 6.7e-6 coarse, 2.7e-4 against 6.6e-5 fine)."""
+    reference's 6.7e-6 coarse, 2.7e-4 against 6.6e-5 fine); round 4 accumulates the head / bias sums in fp64."""
     import aon_amd.synthetic as syn
 
     g = golden("g15_smooth")
@@ -122,11 +122,7 @@ def test_smooth_training_gradients(dev, golden, net):
     hip = {name: p.grad.cpu() for name, p in model.named_parameters()}
     if art:
         hip.update({f"latent[{k}]": lat[k].grad.cpu() for k in lat})
-    bad, worst = {}, (0.0, 0.0)
-    for name, gh in hip.items():
-        e_hip, e_ref = rel_l2(gh, truth[name]), rel_l2(ref32[name], truth[name])
-        worst = max(worst, (e_hip, e_ref))
-        if e_hip > max(1e-4, 5.0 * e_ref):
-            bad[name] = f"hip {e_hip:.1e} vs reference-fp32 {e_ref:.1e}"
-    print(f"{net}: worst gradient distance to the fp64 truth: hip {worst[0]:.2e} (reference fp32 on the same parameter: {worst[1]:.2e})")
-    assert not bad, bad
+    from _gradcheck import assert_as_close_as_fp32
+
+    # round 4: the shared yardstick, whose floor for the <= 4-element head biases is 2e-5 (their sums are fp64 on the device now)
+    assert_as_close_as_fp32(hip, truth, ref32, net, factor=5.0, floor=1e-4)

@@ -258,6 +258,56 @@ def test_gradients_vs_reference_golden(dev, golden, nerf_sd):
         assert (v.grad.cpu() - ref).abs().max().item() <= 3e-2 * ref.abs().max().item(), k
 
 
+@pytest.mark.parametrize("net", ["vanilla", "articulated"])
+def test_g9_inputs_by_the_fp64_yardstick(dev, golden, nerf_sd, net):
+    """The 2e-2 / 3e-2 bars of the G9 comparison above (sharp x30 field, articulated fine level and latents) are distances between
+    TWO fp32 evaluations.  This test prices them: same rays, weights, latents and target, truth = the oracle's autograd in fp64,
+    yardstick = the oracle's own fp32 autograd (the reference's arithmetic, pinned to G9 by tests/test_oracle_golden.py); every HIP
+    gradient must be as close to the truth as the reference's fp32 is x 5 (tests/_gradcheck.py, floor 1e-4, head biases 2e-5).
+    The ratios are printed (state them)."""
+    import aon_amd.synthetic as syn
+    from _gradcheck import assert_as_close_as_fp32
+    from aon_amd.models.vanilla_nerf.model import NeRF
+    from aon_amd.models.vanilla_nerf.model_autodecoder import NeRF_AE_Art
+
+    g = golden("g9_backward")
+    rays_cpu = {k: g[k] for k in ("rays_o", "rays_d", "viewdirs")}
+    target = g["target"]
+    art = net == "articulated"
+    if art:
+        ga = golden("g11_nerf_ae_art")
+        sd = syn.make_art_state_dict(seed=0, density_scale=30.0)
+        lat0 = {k: ga[f"lat_train_{k}"] for k in ("density", "color", "articulation")}
+        model = NeRF_AE_Art().to(dev)
+    else:
+        sd, lat0, model = nerf_sd, None, NeRF().to(dev)
+    model.load_state_dict(sd)
+
+    def oracle_grads(dtype):
+        sd_o = {k: v.detach().clone().to(dtype).requires_grad_(True) for k, v in sd.items()}
+        r = {k: v.to(dtype) for k, v in rays_cpu.items()}
+        lat = None if lat0 is None else {k: v.detach().clone().to(dtype).requires_grad_(True) for k, v in lat0.items()}
+        out = orc.nerf_ae_art_forward(sd_o, r, False, True, g["near"], g["far"], lat) if art else orc.nerf_forward(sd_o, r, False, True, g["near"], g["far"])
+        (orc.img2mse(out[0][0], target.to(dtype)) + orc.img2mse(out[1][0], target.to(dtype))).backward()
+        gr = {k: v.grad for k, v in sd_o.items()}
+        if lat is not None:
+            gr.update({f"latent[{k}]": v.grad for k, v in lat.items()})
+        return gr
+
+    truth, ref32 = oracle_grads(torch.float64), oracle_grads(torch.float32)
+    rays = {k: v.to(dev) for k, v in rays_cpu.items()}
+    if art:
+        lat = {k: v.detach().clone().to(dev).requires_grad_(True) for k, v in lat0.items()}
+        out = model(rays, False, True, g["near"], g["far"], lat)
+    else:
+        out = model(rays, False, True, g["near"], g["far"])
+    (torch.mean((out[0][0] - target.to(dev)) ** 2) + torch.mean((out[1][0] - target.to(dev)) ** 2)).backward()
+    hip = {name: p.grad.cpu() for name, p in model.named_parameters()}
+    if art:
+        hip.update({f"latent[{k}]": lat[k].grad.cpu() for k in lat})
+    assert_as_close_as_fp32(hip, truth, ref32, f"G9 inputs, {net}", factor=5.0, floor=1e-4)
+
+
 def test_training_trajectory_vs_oracle(dev):
     """Three Adam steps with identical batches and draws: the HIP path (module forward/backward + torch.optim.Adam on the
     device) against the oracle (CPU autograd + the same optimiser).  Losses agree per step; after the steps the parameters

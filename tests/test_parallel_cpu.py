@@ -1,8 +1,9 @@
-"""CPU, world_size 2 over gloo: the multi-GPU form of the path (contiguous ray-range shards + one all-gather of
+"""CPU, world sizes 2, 3 and 8 over gloo: the multi-GPU form of the path (contiguous ray-range shards + one all-gather of
 the rendered pixels) assembles a frame identical to the single-process result, including uneven shard sizes."""
 import os
 import socket
 
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -53,7 +54,7 @@ def _worker(rank, world, port, H, W, q):
         dist.destroy_process_group()
 
 
-def _grad_worker(rank, world, port, q):
+def _grad_worker(rank, world, port, q, shard_align, mode):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -61,46 +62,80 @@ def _grad_worker(rank, world, port, q):
 
         torch.manual_seed(100 + rank)  # ranks start from different parameters and see different data
         net = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.ReLU(), torch.nn.Linear(7, 3))
-        # a parameter NO rank produces a gradient for (num_levels=1 leaves fine_mlp alone): 68 values + 5 flags = 73, so the
-        # bucket is padded to 74 and the two shards of 37 cut through a parameter
+        # a parameter NO rank produces a gradient for (num_levels=1 leaves fine_mlp alone): 68 values + 5 flags = 73 -- with
+        # shard_align=1 the bucket is padded to the next multiple of the world size only (74 at world 2, 75 at 3, 80 at 8) and the
+        # shards cut through parameters and through the flags
         net.register_parameter("unused", torch.nn.Parameter(torch.ones(2)))
         par.broadcast_parameters(net)
         x = torch.randn(11, 5)
         net(x).square().mean().backward()
-        if rank == 1:
+        if mode == "permissive" and rank == 1:
             net[2].bias.grad = None   # a rank that produced no gradient for a parameter still takes part with zeros
         local = [torch.zeros_like(p) if p.grad is None else p.grad.clone() for p in net.parameters()]
-        par.allreduce_gradients(net)
+        late_error = None
+        if mode == "permissive":
+            par.allreduce_gradients(net, shard_align=shard_align, find_unused_parameters=True)
+        elif mode == "contract":
+            # DDP's contract (run.py:151, find_unused_parameters=False): same parameter set on every rank -> no host read at all
+            par.allreduce_gradients(net, shard_align=shard_align)
+            par.check_gradient_exchange()
+        else:   # "violation": rank 1 breaks the contract; like DDP, the NEXT call reports it -- on every rank
+            if rank == 1:
+                net[2].bias.grad = None
+            par.allreduce_gradients(net, shard_align=shard_align)
+            try:
+                par.allreduce_gradients(net, shard_align=shard_align)
+            except par.UnevenGradientsError as e:
+                late_error = str(e)
+            net[2].bias.grad = torch.zeros(3)
         assert net.unused.grad is None   # as under torch DDP: globally unused parameters keep grad None (Adam skips them)
         used = [p for n_, p in net.named_parameters() if n_ != "unused"]
         local = [g for g, (n_, _) in zip(local, net.named_parameters()) if n_ != "unused"]
         # plain numpy payloads: torch tensors travel through shared-memory handles that die with the worker
         q.put((rank, [p.detach().numpy().copy() for p in used], [g.numpy().copy() for g in local],
-               [p.grad.numpy().copy() for p in used]))
+               [p.grad.numpy().copy() for p in used], late_error))
         dist.barrier()
     finally:
         dist.destroy_process_group()
 
 
-def test_data_parallel_gradient_exchange():
-    """broadcast_parameters + allreduce_gradients (the DDP duties of run.py:151) over gloo, world size 2."""
-    world, port = 2, _free_port()
+def _run_grad_workers(world, shard_align, mode):
+    port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_grad_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_grad_worker, args=(r, world, port, q, shard_align, mode)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda r: r[0])
+    res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda r: r[0])
     for p in procs:
-        p.join(timeout=60)
+        p.join(timeout=120)
         assert p.exitcode == 0
-    (_, params0, local0, avg0), (_, params1, local1, avg1) = [
-        (r[0], *[[torch.from_numpy(a) for a in part] for part in r[1:]]) for r in res]
-    for a, b in zip(params0, params1):
-        assert torch.equal(a, b)                      # same parameters everywhere after the broadcast
-    for l0, l1, a0, a1 in zip(local0, local1, avg0, avg1):
-        assert torch.equal(a0, a1)                    # same averaged gradient everywhere
-        torch.testing.assert_close(a0, (l0 + l1) / 2, rtol=1e-6, atol=1e-7)
+    return [(r[0], *[[torch.from_numpy(a) for a in part] for part in r[1:4]], r[4]) for r in res]
+
+
+@pytest.mark.parametrize("world,shard_align,mode", [(2, 64, "permissive"), (2, 1, "contract"), (3, 1, "permissive"), (3, 64, "contract"),
+                                                     (8, 1, "permissive"), (8, 64, "contract")])
+def test_data_parallel_gradient_exchange(world, shard_align, mode):
+    """broadcast_parameters + allreduce_gradients (the DDP duties of run.py:151) over gloo at world sizes 2, 3 and 8,
+    buckets whose shards cut through parameters and flags (shard_align=1: 73 elements over 2 / 3 / 8 ranks), in both modes:
+    DDP's contract (no host read) and the permissive one (a rank without a gradient adopts the others' mean)."""
+    res = _run_grad_workers(world, shard_align, mode)
+    for _, params, _, _, _ in res[1:]:
+        for a, b in zip(res[0][1], params):
+            assert torch.equal(a, b)                      # same parameters everywhere after the broadcast
+    nparam = len(res[0][1])
+    for i in range(nparam):
+        mean = sum(r[2][i].double() for r in res) / world
+        for r in res:
+            assert torch.equal(r[3][i], res[0][3][i])     # same averaged gradient everywhere, bit for bit
+        torch.testing.assert_close(res[0][3][i].double(), mean, rtol=1e-6, atol=1e-7)
+
+
+def test_gradient_contract_violation_is_reported_late_on_every_rank():
+    """find_unused_parameters=False and ranks that disagree on the parameter set: the exchange itself never reads the device, so the
+    violation surfaces at the NEXT call (torch DDP: 'Expected to have finished reduction in the prior iteration'), on every rank."""
+    res = _run_grad_workers(3, 1, "violation")
+    assert all(r[4] is not None and "find_unused_parameters=True" in r[4] for r in res)
 
 
 def test_shard_range_is_a_partition():
@@ -115,28 +150,34 @@ def test_shard_range_is_a_partition():
             assert max(sizes) - min(sizes) <= 1
 
 
-def test_sharded_frame_equals_single_process():
+@pytest.mark.parametrize("H,W,world", [(9, 7, 2), (9, 7, 3), (5, 13, 8), (1, 5, 8), (1, 2, 3)])
+def test_sharded_frame_equals_single_process(H, W, world):
+    """63 rays over 2 (32 / 31) and 3 ranks, 65 over 8 (one rank with 9, seven with 8), and frames with FEWER rays than ranks
+    (5 over 8, 2 over 3: `shard_range` gives the trailing ranks empty ranges; they render nothing and still take part in the
+    all-gather with an empty message padded to the longest)."""
     import aon_amd.synthetic as syn
 
-    H, W, world = 9, 7, 2  # 63 rays: uneven split 32 / 31
     port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_worker, args=(r, world, port, H, W, q)) for r in range(world)]
     for p in procs:
         p.start()
-    results = [q.get(timeout=120) for _ in range(world)]
+    results = [q.get(timeout=300) for _ in range(world)]
     for p in procs:
-        p.join(timeout=60)
+        p.join(timeout=120)
         assert p.exitcode == 0
     ro, vd = _cpu_raygen(H, W, syn.focal_from_fovy(H), syn.look_at_pose(), 0, H * W)
     full = FakeRenderer()({"rays_o": ro, "rays_d": vd, "viewdirs": vd}, False, True, 2.0, 6.0)[1]
+    want_acc = torch.cat([torch.arange(r + 3, dtype=torch.float32) + 100 * r for r in range(world)])
+    want_depth = torch.cat([torch.full((r + 3,), -1.0 * r) for r in range(world)])
+    assert len(results) == world
     for rank, *arrs in results:
         rgb, acc, depth, g_rgb, g_acc, g_depth = (torch.from_numpy(a) for a in arrs)
+        assert rgb.shape == (H * W, 3)
         assert torch.equal(rgb, full[0]) and torch.equal(acc, full[1]) and torch.equal(depth, full[2])
-        assert g_rgb.shape == (3 + 4, 3)
-        assert torch.equal(g_acc, torch.tensor([0., 1., 2., 100., 101., 102., 103.]))
-        assert torch.equal(g_depth, torch.tensor([0., 0., 0., -1., -1., -1., -1.]))
+        assert g_rgb.shape == (want_acc.numel(), 3)
+        assert torch.equal(g_acc, want_acc) and torch.equal(g_depth, want_depth)
 
 
 def test_interface_gather_is_rank_major():
