@@ -70,6 +70,8 @@ _SIGS = {
     "aon_art_wgrad": (_i, [_p, _p, _p, _p, _l, _p, _p, _p, _p, _p, _p, _p, _p, _p, _l, _p]),
     "aon_set_bwd_overlap": (_i, [_i]),
     "aon_set_fwd_overlap": (_i, [_i]),
+    "aon_set_fwd_merge": (_i, [_i]),
+    "aon_set_wgrad_probe": (_i, [_p]),
     "aon_train_workspace_bytes": (_l, [_l, _i, _i]),
     "aon_train_scratch_bytes": (_l, [_l, _i, _i]),
     "aon_render_fwd_train": (_i, [_p, _p, _p, _p, _p, _l, _f, _f, _i, _i, _p, _p, _l, _p, _p, _p, _p, _p, _p, _p, _l, _p]),

@@ -46,6 +46,35 @@ class RenderVanilla(torch.autograd.Function):
         return (None,) * 12 + tuple(g[name] for g in per_level for name in ops.VANILLA_PARAM_ORDER)
 
 
+class RenderLevelVanilla(torch.autograd.Function):
+    """ONE level of NeRF.forward on given sample positions t (model.py:175-193: cast + encode + NeRFMLP + activations +
+    volumetric_rendering), from the stage-level training entry points: aon_mlp_fwd_train -> aon_composite | aon_composite_bwd ->
+    aon_mlp_bwd_chain -> aon_vanilla_wgrad.  The drop-in NeRF loops it for `num_levels > 2` in training (the two-call fused step
+    covers one or two levels); the weights it returns feed the next level's inverse CDF and carry no gradient (helper.py:249)."""
+
+    @staticmethod
+    def forward(ctx, rays_o, rays_d, viewdirs, t_vals, white_bkgd, packed_fwd, packed_bwd, *params):
+        raw, planes, masks = ops.mlp_fwd_train(packed_fwd, rays_o, rays_d, viewdirs, t_vals)
+        comp, acc, weights, depth = ops.composite_raw(raw, t_vals, rays_d, white_bkgd, ops.ACT_VANILLA, True)
+        ctx.keep = (raw, planes, masks, t_vals, rays_d, packed_fwd, packed_bwd)
+        ctx.white_bkgd = white_bkgd
+        ctx.mark_non_differentiable(weights)
+        return comp, acc, depth, weights
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_acc, g_depth, _g_weights):
+        _check_not_released(ctx)
+        raw, planes, masks, t_vals, rays_d, packed_fwd, packed_bwd = ctx.keep
+        n = t_vals.shape[0]
+        if g_rgb is None:
+            g_rgb = torch.zeros((n, 3), dtype=torch.float32, device=t_vals.device)
+        d_raw = ops.composite_bwd(raw, t_vals, rays_d, g_rgb, g_acc, g_depth, ctx.white_bkgd, ops.ACT_VANILLA, ops.plane_samples(planes))
+        dplanes = ops.mlp_bwd_chain(packed_bwd, packed_fwd, d_raw, masks, planes.shape)
+        grads = ops.vanilla_wgrad(planes, dplanes, d_raw)
+        ctx.keep, ctx.released = None, True
+        return (None,) * 7 + tuple(grads[name] for name in ops.VANILLA_PARAM_ORDER)
+
+
 class RenderGeneral(torch.autograd.Function):
     """NeRF.forward with a NeRFMLP of non-default geometry: layer-wise GEMM engine (aon_grender_fwd_train / aon_grender_bwd)."""
 
@@ -53,8 +82,13 @@ class RenderGeneral(torch.autograd.Function):
     def forward(ctx, rays_o, rays_d, viewdirs, near, far, white_bkgd, num_levels, t_rand, u, geom, opts, noise, *params):
         n_per = len(geom.param_order)
         ctx.geom, ctx.rays_d, ctx.white_bkgd, ctx.num_levels = geom, rays_d, white_bkgd, num_levels
-        ctx.params = [dict(zip(geom.param_order, [p.detach() for p in params[l * n_per: (l + 1) * n_per]])) for l in range(num_levels)]
-        levels, ctx.ws, ctx.geometry = ops.grender_fwd_train(geom, ctx.params[0], ctx.params[1] if num_levels == 2 else None, rays_o, rays_d,
+        # The backward reads the parameter storages again (W^T of the data chain) while the activations in the workspace come from the
+        # forward-time weights: save_for_backward, so that an in-place update between this forward and its backward (two live graphs
+        # with an optimizer.step() between their backward calls) raises autograd's version error instead of silently mixing two
+        # sets of weights (round 3 kept p.detach() aliases, which bypass the check).
+        ctx.save_for_backward(*params)
+        pd = [dict(zip(geom.param_order, [p.detach() for p in params[l * n_per: (l + 1) * n_per]])) for l in range(num_levels)]
+        levels, ctx.ws, ctx.geometry = ops.grender_fwd_train(geom, pd[0], pd[1] if num_levels == 2 else None, rays_o, rays_d,
                                                              viewdirs, near, far, white_bkgd, num_levels, t_rand, u, opts=opts, noise=noise)
         return tuple(x for lvl in levels for x in lvl)
 
@@ -64,7 +98,10 @@ class RenderGeneral(torch.autograd.Function):
         n = ctx.rays_d.shape[0]
         g_rgb = [gouts[3 * l] if gouts[3 * l] is not None else torch.zeros((n, 3), dtype=torch.float32, device=ctx.rays_d.device)
                  for l in range(ctx.num_levels)]
-        per_level = ops.grender_bwd(ctx.geom, ctx.ws, ctx.params, ctx.rays_d, ctx.white_bkgd, ctx.num_levels, g_rgb,
+        n_per = len(ctx.geom.param_order)
+        saved = ctx.saved_tensors   # (raises if a parameter was modified in place since the forward)
+        params = [dict(zip(ctx.geom.param_order, saved[l * n_per: (l + 1) * n_per])) for l in range(ctx.num_levels)]
+        per_level = ops.grender_bwd(ctx.geom, ctx.ws, params, ctx.rays_d, ctx.white_bkgd, ctx.num_levels, g_rgb,
                                     [gouts[3 * l + 1] for l in range(ctx.num_levels)], [gouts[3 * l + 2] for l in range(ctx.num_levels)],
                                     ctx.geometry)
         ctx.ws, ctx.released, ctx.geometry = None, True, None
@@ -79,9 +116,10 @@ class RenderArticulated(torch.autograd.Function):
                 lat_articulation, *params):
         # packs: per level (packed_fwd, small, packed_bwd); params: 40 tensors per level in ops.ART_PARAM_ORDER
         ctx.rays_d, ctx.white_bkgd, ctx.num_levels = rays_d, white_bkgd, num_levels
-        ctx.latents = {"density": lat_density.detach(), "color": lat_color.detach(), "articulation": lat_articulation.detach()}
         ctx.lat_shapes = (lat_density.shape, lat_color.shape, lat_articulation.shape)
-        ctx.params = [p.detach() for p in params]
+        # parameters and latents are read again by the backward (latent columns: dW = db (x) latent, d latent = W^T db): saved the
+        # autograd way, so an in-place update in between raises instead of mixing two sets of weights (as RenderGeneral)
+        ctx.save_for_backward(lat_density, lat_color, lat_articulation, *params)
         levels, ws, ctx.geometry = ops.render_fwd_train(packs[0][0], packs[1][0] if num_levels == 2 else None, rays_o, rays_d, viewdirs, near, far,
                                                         white_bkgd, num_levels, t_rand, u, small_c=packs[0][1],
                                                         small_f=packs[1][1] if num_levels == 2 else None, opts=opts, noise=noise)
@@ -96,10 +134,12 @@ class RenderArticulated(torch.autograd.Function):
         n = ctx.rays_d.shape[0]
         g_rgb = [gouts[3 * l] if gouts[3 * l] is not None else torch.zeros((n, 3), dtype=torch.float32, device=ctx.rays_d.device)
                  for l in range(ctx.num_levels)]
-        params = [dict(zip(ops.ART_PARAM_ORDER, ctx.params[l * n_per: (l + 1) * n_per])) for l in range(ctx.num_levels)]
+        saved = ctx.saved_tensors   # (raises if a parameter or latent was modified in place since the forward)
+        latents = {"density": saved[0], "color": saved[1], "articulation": saved[2]}
+        params = [dict(zip(ops.ART_PARAM_ORDER, saved[3 + l * n_per: 3 + (l + 1) * n_per])) for l in range(ctx.num_levels)]
         per_level, g_lat = ops.art_render_bwd(ws, packs_bwd, smalls, ctx.rays_d, ctx.white_bkgd, ctx.num_levels, g_rgb,
                                               [gouts[3 * l + 1] for l in range(ctx.num_levels)], [gouts[3 * l + 2] for l in range(ctx.num_levels)],
-                                              params, ctx.latents, geometry=ctx.geometry)
+                                              params, latents, geometry=ctx.geometry)
         ctx.fused, ctx.released, ctx.geometry = None, True, None
         lat = tuple(g_lat[k].reshape(shp) for k, shp in zip(("density", "color", "articulation"), ctx.lat_shapes))
         return (None,) * 12 + lat + tuple(g[name] for g in per_level for name in ops.ART_PARAM_ORDER)

@@ -40,6 +40,7 @@ hipError_t launch_mlp_bwd_chain(const char* packed_bwd, const char* packed_fwd, 
                                 float* dplanes, int64_t Np, hipStream_t stream);
 int64_t wgrad_workspace_bytes();
 int wgrad_plan_describe(bool art, int64_t Np, int cus, int32_t* out6, int max_jobs, int64_t* ws_bytes);
+void set_wgrad_probe(long long* buf);
 hipError_t launch_wgrad_kind_bench(int kind, int nlayers, const float* planes, const float* dplanes, int rows_total, int64_t Np, float* ws,
                                    float* out_scratch, hipStream_t stream);
 struct WgAux { hipStream_t stream; hipEvent_t fork, join; };   // aon_wgrad.h: optional side stream of a level's head reductions
@@ -48,6 +49,9 @@ hipError_t launch_vanilla_wgrad(const float* planes, const float* dplanes, const
 hipError_t launch_art_mlp_fwd_train(const char* packed, const float* small, const float* rays_o, const float* rays_d,
                                     const float* viewdirs, const float* t_vals, int64_t n_rays, int S, float* raw, float* planes,
                                     void* masks, hipStream_t stream, int64_t np_total = 0);
+hipError_t launch_art_mlp_fwd_train2(const TrainSeg* segs, int nsegs, hipStream_t stream);
+hipError_t launch_mlp_fwd_train2(const TrainSeg* segs, int nsegs, hipStream_t stream);
+int num_cus();
 hipError_t launch_pack_art_bwd(const float* const* params, float* packed, hipStream_t stream);
 int64_t art_bwd_stream_bytes();
 hipError_t launch_art_bwd_chain(const char* packed_bwd, const float* small, const float* d_raw, const void* masks, const float* planes,
@@ -161,7 +165,10 @@ struct Geo {
 };
 
 // returns nullptr when fine, else what is wrong
-const char* make_geo(const aon_render_opts* o, Geo& g) {
+// `general_engine`: the aon_grender_* entry points take the network's degrees from aon_mlp_geometry and ignore the degree fields of
+// aon_render_opts, so those fields are neither validated against the fused kernels' limits nor turned into `other_degrees` there (a C
+// caller who fills them to match a (1, 12, 5) geometry used to get AON_E_INVALID from the general engine: ADVICE r3).
+const char* make_geo(const aon_render_opts* o, Geo& g, bool general_engine = false) {
   aon_render_opts d;
   aon_render_opts_init(&d);
   if (o) d = *o;
@@ -174,6 +181,7 @@ const char* make_geo(const aon_render_opts* o, Geo& g) {
   g.noise[0] = d.noise_c; g.noise[1] = d.noise_f; g.noise_std = d.noise_std;
   g.rgb_scale = d.rgb_scale; g.rgb_shift = d.rgb_shift; g.sigma_bias = d.sigma_bias;
   g.min_deg = d.min_deg_point; g.max_deg = d.max_deg_point; g.deg_view = d.deg_view;
+  if (general_engine) { g.min_deg = 0; g.max_deg = 10; g.deg_view = 4; g.other_degrees = false; return nullptr; }
   if (g.max_deg < g.min_deg || g.max_deg - g.min_deg > 10 || g.deg_view < 0 || g.deg_view > 4)
     return "the fused kernels hold up to 10 position and 4 view frequency levels (other degrees: aon_grender_*)";
   g.other_degrees = !(g.min_deg == 0 && g.max_deg == 10 && g.deg_view == 4);
@@ -412,6 +420,11 @@ int aon_wgrad_plan(int articulated, int64_t Np, int cus, int32_t* jobs6, int max
   if (n < 0) return fail(AON_E_INVALID, n == -1 ? "aon_wgrad_plan: Np must be a positive multiple of 32, cus >= 1"
                                        : n == -2 ? "aon_wgrad_plan: no plan (fewer compute units than layers?)" : "aon_wgrad_plan: max_jobs too small");
   return n;
+}
+
+int aon_set_wgrad_probe(void* device_buffer) {
+  aon::set_wgrad_probe(static_cast<long long*>(device_buffer));
+  return AON_OK;
 }
 
 int aon_wgrad_kind_bench(int kind, int nlayers, const float* planes, const float* dplanes, int rows, int64_t Np, void* workspace,
@@ -877,6 +890,26 @@ class LevelFork {
 };
 std::atomic<int> g_bwd_overlap{1};
 std::atomic<int> g_fwd_overlap{2};
+std::atomic<int> g_fwd_merge{1};
+
+// The merged training forward (round 4) runs the two levels of two ray ranges A = [0, kA), B = [kA, n) as THREE persistent launches
+//   coarse(A)  |  fine(A) + coarse(B)  |  fine(B)
+// (the levels of a range depend on each other through its own inverse CDF only).  kA, a multiple of 128 rays, is chosen so that the
+// three launches together take the fewest rounds of `cus` workgroups: 4096 rays x (65 + 193) samples on 256 CUs are 32.25 rounds of
+// work; one launch per level costs 9 + 25 = 34 rounds, the split at 1,920 rays 4 + 16 + 13 = 33.  Ties: the more balanced split.
+int64_t merged_split(int64_t n, int Sc, int Sf, int cus, bool always) {
+  auto rounds = [&](int64_t passes) { return (passes + cus - 1) / cus; };
+  auto passes = [&](int64_t rays, int S) { return (rays * S + 127) / 128; };
+  int64_t best = 0, best_cost = -1, best_bal = 0;
+  for (int64_t k = 128; k < n; k += 128) {
+    const int64_t cost = rounds(passes(k, Sc)) + rounds(passes(k, Sf) + passes(n - k, Sc)) + rounds(passes(n - k, Sf));
+    const int64_t bal = k < n - k ? n - 2 * k : 2 * k - n;
+    if (best_cost < 0 || cost < best_cost || (cost == best_cost && bal < best_bal)) { best = k; best_cost = cost; best_bal = bal; }
+  }
+  // not worth it when one launch per level is as good (small batches: everything fits one round)
+  if (best_cost < 0 || (!always && best_cost >= rounds(passes(n, Sc)) + rounds(passes(n, Sf)))) return 0;
+  return best;
+}
 
 struct TrainNet {   // one level's network handles
   const void* packed_fwd; const float* small; const void* packed_bwd;
@@ -955,6 +988,69 @@ int train_fwd_impl(const char* who, bool art, const TrainNet* nets, const float*
     return AON_OK;
   };
 
+  // Merged form (round 4, default): coarse(A) | fine(A) + coarse(B) | fine(B) as three persistent launches on the caller's stream.
+  if (const int merge = g_fwd_merge.load(std::memory_order_relaxed); num_levels == 2 && !g.other_degrees && merge) {
+    const int cus = aon::num_cus();
+    const int64_t kA = cus > 0 ? merged_split(n, g.Sc, g.Sf, cus, merge == 2) : 0;
+    if (kA > 0) {
+      struct Rng { int64_t r0, nk; };
+      const Rng R[2] = {{0, kA}, {kA, n - kA}};
+      auto seg_of = [&](const Rng& r, int l) {
+        const TrainLevel& L = w.lvl[l];
+        const int64_t s0 = r.r0 * L.S;
+        return aon::TrainSeg{static_cast<const char*>(nets[l].packed_fwd), nets[l].small, rays_o + r.r0 * 3, rays_d + r.r0 * 3, viewdirs + r.r0 * 3,
+                             L.t + s0, r.nk, L.S, L.raw + s0 * 4, L.planes + s0 * rows, L.masks + s0 * 32, L.Np};
+      };
+      auto mlp = [&](const aon::TrainSeg* segs, int ns) {
+        int64_t samples = 0;
+        for (int i = 0; i < ns; ++i) samples += segs[i].n_rays * segs[i].S;
+        MlpTimer timer(stream, samples);
+        return check(art ? aon::launch_art_mlp_fwd_train2(segs, ns, stream) : aon::launch_mlp_fwd_train2(segs, ns, stream), who);
+      };
+      auto coarse_tail = [&](const Rng& r) {   // compositing + inverse CDF + merge of the range's coarse level -> its fine t
+        const float* d = rays_d + r.r0 * 3;
+        const float* uu = (u && u_stride) ? u + r.r0 * u_stride : u;
+        const TrainLevel& L = w.lvl[0];
+        float* t = L.t + r.r0 * L.S; float* raw = L.raw + r.r0 * L.S * 4;
+        float* t_next = w.lvl[1].t + r.r0 * w.lvl[1].S;
+        if (fuse) {
+          KTimer timer(kCompositePdf, stream, r.nk);
+          return check(aon::launch_composite_pdf(raw, t, d, r.nk, white_bkgd, g.act(art, 0, r.r0), uu, u_stride, rgb[0] + r.r0 * 3, acc[0] + r.r0, depth[0] + r.r0,
+                                                 nullptr, t_next, stream), who);
+        }
+        {
+          KTimer timer(kComposite, stream, r.nk);
+          if (int rc = check(aon::launch_composite(raw, 4, raw + 3, 4, t, d, r.nk, L.S, white_bkgd, g.act(art, 0, r.r0), rgb[0] + r.r0 * 3, acc[0] + r.r0,
+                                                   depth[0] + r.r0, w.w_c + r.r0 * g.Sc, stream), who)) return rc;
+        }
+        KTimer timer(kSamplePdf, stream, r.nk);
+        const float* wc = w.w_c + r.r0 * g.Sc;
+        return check(g.default_sizes ? aon::launch_sample_pdf(nullptr, wc + 1, kSc, t, uu, u_stride, r.nk, nullptr, t_next, stream)
+                                     : aon::launch_sample_pdf_n(nullptr, wc + 1, g.Sc, t, uu, u_stride, r.nk, g.Sc - 1, g.nf, g.Sc, nullptr, t_next, stream), who);
+      };
+      auto fine_tail = [&](const Rng& r) {
+        const TrainLevel& L = w.lvl[1];
+        KTimer timer(kComposite, stream, r.nk);
+        return check(aon::launch_composite(L.raw + r.r0 * L.S * 4, 4, L.raw + r.r0 * L.S * 4 + 3, 4, L.t + r.r0 * L.S, rays_d + r.r0 * 3, r.nk, L.S, white_bkgd,
+                                           g.act(art, 1, r.r0), rgb[1] + r.r0 * 3, acc[1] + r.r0, depth[1] + r.r0, nullptr, stream), who);
+      };
+      {   // stratified t of the whole batch
+        KTimer timer(kSampleT, stream, n);
+        if (int rc = check(aon::launch_sample_along_rays(rays_o, rays_d, n, g.Sc, near_, far_, t_rand, w.lvl[0].t, nullptr, stream, g.lindisp, g.inv_near,
+                                                         g.inv_far), who)) return rc;
+      }
+      const aon::TrainSeg cA = seg_of(R[0], 0), fA = seg_of(R[0], 1), cB = seg_of(R[1], 0), fB = seg_of(R[1], 1);
+      if (int rc = mlp(&cA, 1)) return rc;
+      if (int rc = coarse_tail(R[0])) return rc;
+      const aon::TrainSeg mid[2] = {fA, cB};
+      if (int rc = mlp(mid, 2)) return rc;
+      if (int rc = coarse_tail(R[1])) return rc;
+      if (int rc = fine_tail(R[0])) return rc;
+      if (int rc = mlp(&fB, 1)) return rc;
+      return fine_tail(R[1]);
+    }
+  }
+
   // Two ray halves on the two library streams (round 3): the levels of a half depend on each other through its own inverse CDF
   // only, so one half's fine level fills the CUs the other half's coarse level leaves idle in its last, partial round of
   // workgroups (8.125 rounds of 256 cost 9 at 4096 x 65 samples), as the backward does with its two levels.
@@ -976,6 +1072,11 @@ int train_fwd_impl(const char* who, bool art, const TrainNet* nets, const float*
 
 int aon_set_bwd_overlap(int on) {
   g_bwd_overlap.store(on ? 1 : 0, std::memory_order_relaxed);
+  return AON_OK;
+}
+
+int aon_set_fwd_merge(int on) {
+  g_fwd_merge.store(on == 2 ? 2 : (on ? 1 : 0), std::memory_order_relaxed);   // 2 (tests): merge whenever there are two ranges, gain or not
   return AON_OK;
 }
 
@@ -1562,7 +1663,7 @@ int aon_gmlp_fwd(const aon_mlp_geometry* geom, const float* const* params_host, 
 int64_t aon_grender_workspace_bytes(const aon_mlp_geometry* geom, int64_t n_rays, const aon_render_opts* opts) {
   GG g; Geo geo;
   if (const char* bad = make_gg(geom, g)) return fail(AON_E_INVALID, bad);
-  if (const char* bad = make_geo(opts, geo)) return fail(AON_E_INVALID, bad);
+  if (const char* bad = make_geo(opts, geo, true)) return fail(AON_E_INVALID, bad);
   return carve_grender(nullptr, g, geo, n_rays < 1 ? 1 : n_rays).bytes;
 }
 
@@ -1576,7 +1677,7 @@ int aon_grender_fwd(const aon_mlp_geometry* geom, const float* const* params_coa
   GG g; Geo geo;
   if (const char* bad = make_gg(geom, g)) return fail(AON_E_INVALID, bad);
   if (const char* bad = whole_path_ok(g)) return fail(AON_E_INVALID, bad);
-  if (const char* bad = make_geo(opts, geo)) return fail(AON_E_INVALID, bad);
+  if (const char* bad = make_geo(opts, geo, true)) return fail(AON_E_INVALID, bad);
   if (n_rays < 0 || (num_levels != 1 && num_levels != 2)) return fail(AON_E_INVALID, "aon_grender_fwd: bad size / num_levels");
   if (n_rays == 0) return AON_OK;
   if (int rc = check_params(g, params_coarse_host, "aon_grender_fwd: null parameter pointer")) return rc;
@@ -1634,13 +1735,13 @@ int aon_grender_fwd(const aon_mlp_geometry* geom, const float* const* params_coa
 int64_t aon_grender_train_workspace_bytes(const aon_mlp_geometry* geom, int64_t n_rays, int num_levels, const aon_render_opts* opts) {
   GG g; Geo geo;
   if (const char* bad = make_gg(geom, g)) return fail(AON_E_INVALID, bad);
-  if (const char* bad = make_geo(opts, geo)) return fail(AON_E_INVALID, bad);
+  if (const char* bad = make_geo(opts, geo, true)) return fail(AON_E_INVALID, bad);
   return carve_gtrain(nullptr, g, geo, n_rays < 1 ? 1 : n_rays, num_levels == 1 ? 1 : 2).bytes;
 }
 int64_t aon_grender_train_scratch_bytes(const aon_mlp_geometry* geom, int64_t n_rays, int num_levels, const aon_render_opts* opts) {
   GG g; Geo geo;
   if (const char* bad = make_gg(geom, g)) return fail(AON_E_INVALID, bad);
-  if (const char* bad = make_geo(opts, geo)) return fail(AON_E_INVALID, bad);
+  if (const char* bad = make_geo(opts, geo, true)) return fail(AON_E_INVALID, bad);
   return carve_gscratch(nullptr, g, geo, n_rays < 1 ? 1 : n_rays, num_levels == 1 ? 1 : 2).bytes;
 }
 
@@ -1654,7 +1755,7 @@ int aon_grender_fwd_train(const aon_mlp_geometry* geom, const float* const* para
   GG g; Geo geo;
   if (const char* bad = make_gg(geom, g)) return fail(AON_E_INVALID, bad);
   if (const char* bad = whole_path_ok(g)) return fail(AON_E_INVALID, bad);
-  if (const char* bad = make_geo(opts, geo)) return fail(AON_E_INVALID, bad);
+  if (const char* bad = make_geo(opts, geo, true)) return fail(AON_E_INVALID, bad);
   if (geo.Sf > 512) return fail(AON_E_INVALID, "aon_grender_fwd_train: more than 512 samples per ray at the fine level");
   if (n <= 0 || (num_levels != 1 && num_levels != 2)) return fail(AON_E_INVALID, "aon_grender_fwd_train: bad size / num_levels");
   if (int rc = check_params(g, params_coarse_host, "aon_grender_fwd_train: null parameter pointer")) return rc;
@@ -1704,7 +1805,7 @@ int aon_grender_bwd(const aon_mlp_geometry* geom, const float* const* params_coa
   GG g; Geo geo;
   if (const char* bad = make_gg(geom, g)) return fail(AON_E_INVALID, bad);
   if (const char* bad = whole_path_ok(g)) return fail(AON_E_INVALID, bad);
-  if (const char* bad = make_geo(opts, geo)) return fail(AON_E_INVALID, bad);
+  if (const char* bad = make_geo(opts, geo, true)) return fail(AON_E_INVALID, bad);
   if (n <= 0 || (num_levels != 1 && num_levels != 2)) return fail(AON_E_INVALID, "aon_grender_bwd: bad size / num_levels");
   if (!rays_d || !g_rgb_host || !workspace || !scratch) return fail(AON_E_INVALID, "aon_grender_bwd: null pointer");
   if ((reinterpret_cast<uintptr_t>(workspace) & 255) || (reinterpret_cast<uintptr_t>(scratch) & 255))

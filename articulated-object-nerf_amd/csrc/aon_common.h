@@ -150,6 +150,20 @@ struct ActParams {
 };
 inline ActParams default_act(int act) { return ActParams{act, 1.002f, 0.001f, -1.0f, nullptr, 0.f}; }
 
+// One segment of a training-forward launch (host side): a network's streams and one ray range's buffers at one level.  The fused
+// training forwards take one or two of these per launch (launch_*_fwd_train2): e.g. the fine level of ray range A together with
+// the coarse level of ray range B, so the partial last round of workgroups of one is filled with passes of the other.
+struct TrainSeg {
+  const char* packed;      // the level's packed forward stream
+  const float* small;      // articulated: the level's per-call small block; vanilla: null (it follows the stream)
+  const float* rays_o; const float* rays_d; const float* viewdirs;   // of the ray range
+  const float* t_vals;     // (n_rays, S)
+  int64_t n_rays; int S;
+  float* raw;              // (n_rays * S, 4)
+  float* planes; void* masks;   // the range's offsets into the level's planes / decision bits
+  int64_t np_total;        // padded samples of the WHOLE level (slot stride of the decision bits); 0: this range alone
+};
+
 // ------------------------------------------------------------------------------------------------
 // Host side.  A kernel's dynamic-LDS limit (hipFuncAttributeMaxDynamicSharedMemorySize) is a per-DEVICE function
 // attribute and the CU count is a per-device property: both are remembered per device ordinal, lock-free (a racing

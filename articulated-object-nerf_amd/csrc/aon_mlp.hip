@@ -100,7 +100,9 @@ __global__ void pack_vanilla_kernel(PackArgs a, float* __restrict__ packed, int 
 // ---------------------------------------------------------------------------------------------
 // fused forward
 // ---------------------------------------------------------------------------------------------
-struct MlpArgs {
+// One SEGMENT of a launch: a run of 128-sample passes of one network over one ray range (see ArtSeg, aon_mlp_art.hip: the training
+// forward merges the fine level of one ray range with the coarse level of another into ONE persistent launch).
+struct MlpSeg {
   const char* packed;        // kPackedBytes
   const float* rays_o;       // (n_rays,3)      [ENC_IN_KERNEL]
   const float* rays_d;       // (n_rays,3)
@@ -115,6 +117,10 @@ struct MlpArgs {
   float* planes;             // [TRAIN] kPlRows x Np activation planes, step-major (aon_mlp_core.h)
   u32x4* masks;              // [TRAIN] kMaskLayers x (Np*2) ReLU bit masks
   int64_t Np;                // npass * 128
+};
+struct MlpArgs {
+  MlpSeg seg[2];
+  int npass_total;           // seg[0].npass + seg[1].npass (seg[1].npass == 0: a one-segment launch)
 };
 
 constexpr int kLdsBytes = kRingBytes + (int)kSmallBytes;
@@ -132,42 +138,59 @@ __global__ void __launch_bounds__(256) mlp_fwd_kernel(MlpArgs args) {
   const int m = lane & 31, h = lane >> 5;
   const int wave_s = __builtin_amdgcn_readfirstlane(wave);   // the step base of the training planes is wave-uniform: keep it scalar
 
-  {  // resident small vectors -> LDS (visible after the first acquire's barrier)
-    const f32x4* src = reinterpret_cast<const f32x4*>(args.packed + kStreamBytes);
+  const int npass0 = args.seg[0].npass;
+  int cur = (int)blockIdx.x >= npass0 ? 1 : 0;               // segment of this workgroup's first pass
+  auto load_small = [&](const char* packed) {  // resident small vectors -> LDS (visible after the next workgroup barrier)
+    const f32x4* src = reinterpret_cast<const f32x4*>(packed + kStreamBytes);
     f32x4* dst = reinterpret_cast<f32x4*>(sm);
     for (int i = tid; i < kSmallFloats / 4; i += 256) dst[i] = src[i];
-  }
+  };
+  load_small(args.seg[cur].packed);
 
   Pipe p;
-  pipe_init<VanillaNet>(p, args.packed, smem, wave, lane);  // also publishes the small block just written to LDS
+  pipe_init<VanillaNet>(p, args.seg[cur].packed, smem, wave, lane);  // also publishes the small block just written to LDS
 
-  for (int pass = blockIdx.x; pass < args.npass; pass += gridDim.x) {
+  for (int gpass = blockIdx.x; gpass < args.npass_total; gpass += gridDim.x) {
+    const int si = gpass >= npass0 ? 1 : 0;
+    if (si != cur) {   // (workgroup-uniform, at most once per launch) the other network's biases / head weights replace the resident block
+      __syncthreads();
+      load_small(args.seg[si].packed);
+      __syncthreads();
+      cur = si;
+    }
+    const MlpSeg& sg = args.seg[si];
+    const int pass = gpass - (si ? npass0 : 0);
+    {   // weight stream of this pass, and of this workgroup's next one (its first chunk pair is fetched during this pass's last chunk)
+      const int nxt = gpass + (int)gridDim.x;
+      p.stream = sg.packed;
+      p.next_stream = args.seg[(nxt >= npass0 && nxt < args.npass_total) ? 1 : si].packed;
+    }
     const int64_t g = (int64_t)pass * 128 + wave * 32 + m;
-    const bool valid = g < args.total;
-    const int64_t gc = valid ? g : args.total - 1;
-    const int64_t ray = gc / args.S;
+    const bool valid = g < sg.total;
+    const int64_t gc = valid ? g : sg.total - 1;
+    const int64_t ray = gc / sg.S;
 
     // ---- encode: E[0..1] = 63-wide positional encoding, V = 27-wide view encoding, accumulator layout ----
     f32x16 E[2], V;
     float x[3] = {0.f, 0.f, 0.f}, vd[3] = {0.f, 0.f, 0.f};
     if constexpr (ENC_IN_KERNEL) {
-      const float t = args.t_vals[gc];
+      const float t = sg.t_vals[gc];
 #pragma unroll
       for (int a = 0; a < 3; ++a) {
         // helper.cast_rays (helper.py:25-26): origins + t * directions, multiply then add
-        x[a] = __fadd_rn(args.rays_o[ray * 3 + a], __fmul_rn(t, args.rays_d[ray * 3 + a]));
-        vd[a] = args.viewdirs[ray * 3 + a];
+        x[a] = __fadd_rn(sg.rays_o[ray * 3 + a], __fmul_rn(t, sg.rays_d[ray * 3 + a]));
+        vd[a] = sg.viewdirs[ray * 3 + a];
       }
       encode_pos(x, h, E);
       encode_view(vd, h, V);
     } else {
-      load_pos_enc(args.samples_enc + gc * kPosEnc, h, E);
-      load_view_enc(args.viewdirs_enc + ray * kViewEnc, h, V);
+      load_pos_enc(sg.samples_enc + gc * kPosEnc, h, E);
+      load_view_enc(sg.viewdirs_enc + ray * kViewEnc, h, V);
     }
 
     PlaneIO io{};
     unsigned moff = 0;
-    if constexpr (TRAIN) { io = make_plane_io(args.planes, kPlRows, (int64_t)pass * 4 + wave_s, m, h); moff = mask_lane_off(pass, tid); }
+    if constexpr (TRAIN) { io = make_plane_io(sg.planes, kPlRows, (int64_t)pass * 4 + wave_s, m, h); moff = mask_lane_off(pass, tid); }
     if constexpr (TRAIN) {
       store_pos_enc_plane(E, io, kPlE, h);
       store_view_enc_plane(V, io, kPlVE, h);
@@ -190,7 +213,7 @@ __global__ void __launch_bounds__(256) mlp_fwd_kernel(MlpArgs args) {
     };
     auto put_mask = [&](const u32x4& mw, int mask_layer) {   // all 8 tiles (32 pushes per word) of the layer have been consumed
       if constexpr (TRAIN)
-        *mask_ptr(args.masks, args.Np, mask_layer, moff) = u32x4{mask_word_finish(mw[0]), mask_word_finish(mw[1]), mask_word_finish(mw[2]), mask_word_finish(mw[3])};
+        *mask_ptr(sg.masks, sg.Np, mask_layer, moff) = u32x4{mask_word_finish(mw[0]), mask_word_finish(mw[1]), mask_word_finish(mw[2]), mask_word_finish(mw[3])};
     };
     f32x16 X[8], Y[8];
     u32x4 mw;
@@ -214,7 +237,7 @@ __global__ void __launch_bounds__(256) mlp_fwd_kernel(MlpArgs args) {
     if constexpr (TRAIN && !ENC_IN_KERNEL) {
       int64_t gq = gc;
       asm volatile("" : "+v"(gq));   // opaque: a second read, not the first one kept live
-      load_pos_enc(args.samples_enc + gq * kPosEnc, h, E);
+      load_pos_enc(sg.samples_enc + gq * kPosEnc, h, E);
     }
     chunk_mma<VanillaNet, kChL5 + 8, 8, 16>(p, E[0], Y);
     chunk_mma<VanillaNet, kChL5 + 9, 8, 16>(p, E[1], Y);
@@ -238,12 +261,12 @@ __global__ void __launch_bounds__(256) mlp_fwd_kernel(MlpArgs args) {
     if constexpr (TRAIN && !ENC_IN_KERNEL) {
       int64_t rq = ray;
       asm volatile("" : "+v"(rq));
-      load_view_enc(args.viewdirs_enc + rq * kViewEnc, h, V);
+      load_view_enc(sg.viewdirs_enc + rq * kViewEnc, h, V);
     }
     chunk_mma<VanillaNet, kChView + 8, 4, 14>(p, V, Z);
     relu_tiles(Z);
     if constexpr (TRAIN) {  // the view layer's output feeds the rgb head on the VALU: no consuming chunk, 64 values stored here
-      *mask_ptr(args.masks, args.Np, 8, moff) = relu_mask_bits(Z);   // burst form: already in the stored bit layout
+      *mask_ptr(sg.masks, sg.Np, 8, moff) = relu_mask_bits(Z);   // burst form: already in the stored bit layout
       store_plane(Z, io, kPlHV);
     }
     // rgb head (model.py:118)
@@ -255,7 +278,7 @@ __global__ void __launch_bounds__(256) mlp_fwd_kernel(MlpArgs args) {
     }
     if (valid && h == 0) {
       f32x4 o; o[0] = rgb[0]; o[1] = rgb[1]; o[2] = rgb[2]; o[3] = sigma;
-      reinterpret_cast<f32x4*>(args.raw)[g] = o;
+      reinterpret_cast<f32x4*>(sg.raw)[g] = o;
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the last prefetched chunk must land before the LDS is released
@@ -293,7 +316,7 @@ static hipError_t launch_mlp_t(const MlpArgs& args, hipStream_t stream) {
   if (hipError_t e = set_max_lds(&mlp_fwd_kernel<ENC, TRAIN>, kLdsBytes, lds_once); e != hipSuccess) return e;
   const int g_num_cus = num_cus();
   if (g_num_cus <= 0) return hipErrorInvalidDevice;
-  const int grid = args.npass < g_num_cus ? args.npass : g_num_cus;
+  const int grid = args.npass_total < g_num_cus ? args.npass_total : g_num_cus;
   if (grid <= 0) return hipSuccess;
   mlp_fwd_kernel<ENC, TRAIN><<<dim3(grid), dim3(256), kLdsBytes, stream>>>(args);
   return hipGetLastError();
@@ -301,11 +324,15 @@ static hipError_t launch_mlp_t(const MlpArgs& args, hipStream_t stream) {
 
 hipError_t launch_mlp_fwd(const char* packed, const float* rays_o, const float* rays_d, const float* viewdirs,
                           const float* t_vals, int64_t n_rays, int S, float* raw, hipStream_t stream) {
-  MlpArgs a{};
+  MlpArgs args{};
+  MlpSeg& a = args.seg[0];
   a.packed = packed; a.rays_o = rays_o; a.rays_d = rays_d; a.viewdirs = viewdirs; a.t_vals = t_vals;
   a.raw = raw; a.total = n_rays * S; a.S = S; a.npass = (int)((a.total + 127) / 128);
-  return launch_mlp_t<true, false>(a, stream);
+  args.seg[1] = a; args.seg[1].npass = 0; args.npass_total = a.npass;
+  return launch_mlp_t<true, false>(args, stream);
 }
+
+hipError_t launch_mlp_fwd_train2(const TrainSeg* segs, int nsegs, hipStream_t stream);
 
 // Training forward: as launch_mlp_fwd, plus the activation planes (kPlRows x Np floats, Np = 128*ceil(n*S/128)).
 // np_total: the padded sample count of the WHOLE batch when this launch covers a ray range of it starting on a pass boundary
@@ -313,29 +340,47 @@ hipError_t launch_mlp_fwd(const char* packed, const float* rays_o, const float* 
 hipError_t launch_mlp_fwd_train(const char* packed, const float* rays_o, const float* rays_d, const float* viewdirs,
                                 const float* t_vals, int64_t n_rays, int S, float* raw, float* planes, void* masks,
                                 hipStream_t stream, int64_t np_total) {
-  MlpArgs a{};
-  a.packed = packed; a.rays_o = rays_o; a.rays_d = rays_d; a.viewdirs = viewdirs; a.t_vals = t_vals;
-  a.raw = raw; a.total = n_rays * S; a.S = S; a.npass = (int)((a.total + 127) / 128);
-  a.planes = planes; a.masks = static_cast<u32x4*>(masks); a.Np = np_total > 0 ? np_total : (int64_t)a.npass * 128;
-  return launch_mlp_t<true, true>(a, stream);
+  const TrainSeg one{packed, nullptr, rays_o, rays_d, viewdirs, t_vals, n_rays, S, raw, planes, masks, np_total};
+  return launch_mlp_fwd_train2(&one, 1, stream);
+}
+
+// one or two segments in ONE persistent launch (see MlpSeg)
+hipError_t launch_mlp_fwd_train2(const TrainSeg* segs, int nsegs, hipStream_t stream) {
+  if (nsegs < 1 || nsegs > 2) return hipErrorInvalidValue;
+  MlpArgs args{};
+  for (int i = 0; i < nsegs; ++i) {
+    const TrainSeg& t = segs[i];
+    MlpSeg& a = args.seg[i];
+    a.packed = t.packed; a.rays_o = t.rays_o; a.rays_d = t.rays_d; a.viewdirs = t.viewdirs; a.t_vals = t.t_vals;
+    a.raw = t.raw; a.total = t.n_rays * t.S; a.S = t.S; a.npass = (int)((a.total + 127) / 128);
+    a.planes = t.planes; a.masks = static_cast<u32x4*>(t.masks); a.Np = t.np_total > 0 ? t.np_total : (int64_t)a.npass * 128;
+    args.npass_total += a.npass;
+  }
+  if (nsegs == 1) { args.seg[1] = args.seg[0]; args.seg[1].npass = 0; }
+  else if (args.seg[0].npass == 0) { args.seg[0] = args.seg[1]; args.seg[1].npass = 0; }   // (an empty first segment: the second one alone)
+  return launch_mlp_t<true, true>(args, stream);
 }
 
 // training forward on caller-encoded inputs (padded 63 / 27-column layout): planes and decision bits as launch_mlp_fwd_train
 hipError_t launch_mlp_fwd_train_enc(const char* packed, const float* samples_enc, const float* viewdirs_enc, int64_t n_rays, int S, float* raw,
                                     float* planes, void* masks, hipStream_t stream, int64_t np_total) {
-  MlpArgs a{};
+  MlpArgs args{};
+  MlpSeg& a = args.seg[0];
   a.packed = packed; a.samples_enc = samples_enc; a.viewdirs_enc = viewdirs_enc;
   a.raw = raw; a.total = n_rays * S; a.S = S; a.npass = (int)((a.total + 127) / 128);
   a.planes = planes; a.masks = static_cast<u32x4*>(masks); a.Np = np_total > 0 ? np_total : (int64_t)a.npass * 128;
-  return launch_mlp_t<false, true>(a, stream);
+  args.seg[1] = a; args.seg[1].npass = 0; args.npass_total = a.npass;
+  return launch_mlp_t<false, true>(args, stream);
 }
 
 hipError_t launch_mlp_fwd_enc(const char* packed, const float* samples_enc, const float* viewdirs_enc,
                               int64_t n_rays, int S, float* raw, hipStream_t stream) {
-  MlpArgs a{};
+  MlpArgs args{};
+  MlpSeg& a = args.seg[0];
   a.packed = packed; a.samples_enc = samples_enc; a.viewdirs_enc = viewdirs_enc;
   a.raw = raw; a.total = n_rays * S; a.S = S; a.npass = (int)((a.total + 127) / 128);
-  return launch_mlp_t<false, false>(a, stream);
+  args.seg[1] = a; args.seg[1].npass = 0; args.npass_total = a.npass;
+  return launch_mlp_t<false, false>(args, stream);
 }
 
 }  // namespace aon

@@ -111,7 +111,11 @@ __global__ void prepare_art_kernel(ArtPrepArgs a, float* __restrict__ small) {
   small[s] = v;
 }
 
-struct ArtMlpArgs {
+// One SEGMENT of a launch: a run of 128-sample passes of one network over one ray range.  A launch carries one or two of them
+// (round 4): the training forward merges the fine level of ray range A with the coarse level of ray range B -- different weight
+// streams, small blocks, rays, planes -- into ONE persistent launch, so that the partial last round of the 65-sample level
+// (8.125 rounds of 256 workgroups cost 9) is filled with passes of the other segment instead of idling 7/8 of the chip.
+struct ArtSeg {
   const char* packed;     // kAStreamBytes
   const float* small;     // kASmallFloats (from prepare_art_kernel)
   const float* rays_o;    // [POS_IN_KERNEL]
@@ -128,6 +132,10 @@ struct ArtMlpArgs {
   u32x4* masks;           // [TRAIN] kAMaskLayers x (Np*2)
   int64_t Np;
 };
+struct ArtMlpArgs {
+  ArtSeg seg[2];
+  int npass_total;        // seg[0].npass + seg[1].npass (seg[1].npass == 0: a one-segment launch)
+};
 
 template <bool POS_IN_KERNEL, bool TRAIN>
 __global__ void __launch_bounds__(256) art_mlp_fwd_kernel(ArtMlpArgs args) {
@@ -138,38 +146,55 @@ __global__ void __launch_bounds__(256) art_mlp_fwd_kernel(ArtMlpArgs args) {
   const int lane = tid & 63, wave = tid >> 6;
   const int m = lane & 31, h = lane >> 5;
   const int wave_s = __builtin_amdgcn_readfirstlane(wave);   // the step base of the training planes is wave-uniform: keep it scalar
-  {
-    const f32x4* src = reinterpret_cast<const f32x4*>(args.small);
+  const int npass0 = args.seg[0].npass;
+  int cur = (int)blockIdx.x >= npass0 ? 1 : 0;               // segment of this workgroup's first pass
+  auto load_small = [&](const float* small) {
+    const f32x4* src = reinterpret_cast<const f32x4*>(small);
     f32x4* dst = reinterpret_cast<f32x4*>(sm);
     for (int i = tid; i < kASmallFloats / 4; i += 256) dst[i] = src[i];
-  }
+  };
+  load_small(args.seg[cur].small);
   Pipe p;
-  pipe_init<ArtNet>(p, args.packed, smem, wave, lane);  // also publishes the small block just written to LDS
+  pipe_init<ArtNet>(p, args.seg[cur].packed, smem, wave, lane);  // also publishes the small block just written to LDS
 
-  for (int pass = blockIdx.x; pass < args.npass; pass += gridDim.x) {
+  for (int gpass = blockIdx.x; gpass < args.npass_total; gpass += gridDim.x) {
+    const int si = gpass >= npass0 ? 1 : 0;
+    if (si != cur) {   // (workgroup-uniform, at most once per launch) the other network's biases / head weights replace the resident block
+      __syncthreads();
+      load_small(args.seg[si].small);
+      __syncthreads();
+      cur = si;
+    }
+    const ArtSeg& sg = args.seg[si];
+    const int pass = gpass - (si ? npass0 : 0);
+    {   // weight stream of this pass, and of this workgroup's next one (its first chunk pair is fetched during this pass's last chunk)
+      const int nxt = gpass + (int)gridDim.x;
+      p.stream = sg.packed;
+      p.next_stream = args.seg[(nxt >= npass0 && nxt < args.npass_total) ? 1 : si].packed;
+    }
     const int64_t g = (int64_t)pass * 128 + wave * 32 + m;
-    const bool valid = g < args.total;
-    const int64_t gc = valid ? g : args.total - 1;
-    const int64_t ray = gc / args.S;
+    const bool valid = g < sg.total;
+    const int64_t gc = valid ? g : sg.total - 1;
+    const int64_t ray = gc / sg.S;
     float x[3], vd[3] = {0.f, 0.f, 0.f};
     f32x16 V;
     if constexpr (POS_IN_KERNEL) {
-      const float t = args.t_vals[gc];
+      const float t = sg.t_vals[gc];
 #pragma unroll
       for (int a = 0; a < 3; ++a) {
-        x[a] = __fadd_rn(args.rays_o[ray * 3 + a], __fmul_rn(t, args.rays_d[ray * 3 + a]));
-        vd[a] = args.viewdirs[ray * 3 + a];
+        x[a] = __fadd_rn(sg.rays_o[ray * 3 + a], __fmul_rn(t, sg.rays_d[ray * 3 + a]));
+        vd[a] = sg.viewdirs[ray * 3 + a];
       }
       if constexpr (!TRAIN) encode_view(vd, h, V);  // [TRAIN] encoded where the view branch needs it: 16 registers not held across the trunk
     } else {
 #pragma unroll
-      for (int a = 0; a < 3; ++a) x[a] = args.pos[gc * 3 + a];
-      load_view_enc(args.viewdirs_enc + ray * kViewEnc, h, V);
+      for (int a = 0; a < 3; ++a) x[a] = sg.pos[gc * 3 + a];
+      load_view_enc(sg.viewdirs_enc + ray * kViewEnc, h, V);
     }
 
     PlaneIO io{};
     unsigned moff = 0;
-    if constexpr (TRAIN) { io = make_plane_io(args.planes, kAPlRows, (int64_t)pass * 4 + wave_s, m, h); moff = mask_lane_off(pass, tid); }
+    if constexpr (TRAIN) { io = make_plane_io(sg.planes, kAPlRows, (int64_t)pass * 4 + wave_s, m, h); moff = mask_lane_off(pass, tid); }
     // [TRAIN] activation tiles are stored, and their ReLU decision bits collected, by the chunk that CONSUMES them (side job
     // of chunk_mma, one value per MFMA group, one 16-byte store per four); only the tiles consumed on the VALU (deformation head,
     // rgb head) and the VALU-computed first deformation layer's output go out in a burst of 64 values.
@@ -192,13 +217,13 @@ __global__ void __launch_bounds__(256) art_mlp_fwd_kernel(ArtMlpArgs args) {
     };
     auto put_mask = [&](int slot) {
       if constexpr (TRAIN)   // every word took 0 or 32 pushes (4- and 8-tile layers)
-        *mask_ptr(args.masks, args.Np, slot, moff) = u32x4{mask_word_finish(mw[0]), mask_word_finish(mw[1]), mask_word_finish(mw[2]), mask_word_finish(mw[3])};
+        *mask_ptr(sg.masks, sg.Np, slot, moff) = u32x4{mask_word_finish(mw[0]), mask_word_finish(mw[1]), mask_word_finish(mw[2]), mask_word_finish(mw[3])};
       mw[0] = mw[1] = mw[2] = mw[3] = 0u;
     };
     auto burst = [&](auto& tiles, int row, int mask_slot) {   // VALU-consumed tiles
       if constexpr (TRAIN) {
         store_plane(tiles, io, row);
-        *mask_ptr(args.masks, args.Np, mask_slot, moff) = relu_mask_bits(tiles);
+        *mask_ptr(sg.masks, sg.Np, mask_slot, moff) = relu_mask_bits(tiles);
       }
     };
     auto save_row = [&](int row, float v) {  // one scalar per sample (lanes 0..31)
@@ -291,7 +316,7 @@ __global__ void __launch_bounds__(256) art_mlp_fwd_kernel(ArtMlpArgs args) {
     }
     if (valid && h == 0) {
       f32x4 o; o[0] = rgb[0]; o[1] = rgb[1]; o[2] = rgb[2]; o[3] = sigma;
-      reinterpret_cast<f32x4*>(args.raw)[g] = o;
+      reinterpret_cast<f32x4*>(sg.raw)[g] = o;
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -325,7 +350,7 @@ static hipError_t launch_art_t(const ArtMlpArgs& args, hipStream_t stream) {
   if (hipError_t e = set_max_lds(&art_mlp_fwd_kernel<POS, TRAIN>, kALdsBytes, lds_once); e != hipSuccess) return e;
   const int cus = num_cus();
   if (cus <= 0) return hipErrorInvalidDevice;
-  const int grid = args.npass < cus ? args.npass : cus;
+  const int grid = args.npass_total < cus ? args.npass_total : cus;
   if (grid <= 0) return hipSuccess;
   art_mlp_fwd_kernel<POS, TRAIN><<<dim3(grid), dim3(256), kALdsBytes, stream>>>(args);
   return hipGetLastError();
@@ -334,28 +359,48 @@ static hipError_t launch_art_t(const ArtMlpArgs& args, hipStream_t stream) {
 hipError_t launch_art_mlp_fwd(const char* packed, const float* small, const float* rays_o, const float* rays_d,
                               const float* viewdirs, const float* t_vals, int64_t n_rays, int S, float* raw,
                               hipStream_t stream) {
-  ArtMlpArgs a{};
+  ArtMlpArgs args{};
+  ArtSeg& a = args.seg[0];
   a.packed = packed; a.small = small; a.rays_o = rays_o; a.rays_d = rays_d; a.viewdirs = viewdirs; a.t_vals = t_vals;
   a.raw = raw; a.total = n_rays * S; a.S = S; a.npass = (int)((a.total + 127) / 128);
-  return launch_art_t<true, false>(a, stream);
+  args.seg[1] = a; args.seg[1].npass = 0; args.npass_total = a.npass;
+  return launch_art_t<true, false>(args, stream);
 }
+
+hipError_t launch_art_mlp_fwd_train2(const TrainSeg* segs, int nsegs, hipStream_t stream);
 
 hipError_t launch_art_mlp_fwd_train(const char* packed, const float* small, const float* rays_o, const float* rays_d,
                                     const float* viewdirs, const float* t_vals, int64_t n_rays, int S, float* raw, float* planes,
                                     void* masks, hipStream_t stream, int64_t np_total) {
-  ArtMlpArgs a{};
-  a.packed = packed; a.small = small; a.rays_o = rays_o; a.rays_d = rays_d; a.viewdirs = viewdirs; a.t_vals = t_vals;
-  a.raw = raw; a.total = n_rays * S; a.S = S; a.npass = (int)((a.total + 127) / 128);
-  a.planes = planes; a.masks = static_cast<u32x4*>(masks); a.Np = np_total > 0 ? np_total : (int64_t)a.npass * 128;   // (launch_mlp_fwd_train)
-  return launch_art_t<true, true>(a, stream);
+  const TrainSeg one{packed, small, rays_o, rays_d, viewdirs, t_vals, n_rays, S, raw, planes, masks, np_total};
+  return launch_art_mlp_fwd_train2(&one, 1, stream);
+}
+
+// one or two segments in ONE persistent launch (see ArtSeg)
+hipError_t launch_art_mlp_fwd_train2(const TrainSeg* segs, int nsegs, hipStream_t stream) {
+  if (nsegs < 1 || nsegs > 2) return hipErrorInvalidValue;
+  ArtMlpArgs args{};
+  for (int i = 0; i < nsegs; ++i) {
+    const TrainSeg& t = segs[i];
+    ArtSeg& a = args.seg[i];
+    a.packed = t.packed; a.small = t.small; a.rays_o = t.rays_o; a.rays_d = t.rays_d; a.viewdirs = t.viewdirs; a.t_vals = t.t_vals;
+    a.raw = t.raw; a.total = t.n_rays * t.S; a.S = t.S; a.npass = (int)((a.total + 127) / 128);
+    a.planes = t.planes; a.masks = static_cast<u32x4*>(t.masks); a.Np = t.np_total > 0 ? t.np_total : (int64_t)a.npass * 128;   // (launch_mlp_fwd_train)
+    args.npass_total += a.npass;
+  }
+  if (nsegs == 1) { args.seg[1] = args.seg[0]; args.seg[1].npass = 0; }
+  else if (args.seg[0].npass == 0) { args.seg[0] = args.seg[1]; args.seg[1].npass = 0; }   // (an empty first segment: the second one alone)
+  return launch_art_t<true, true>(args, stream);
 }
 
 hipError_t launch_art_mlp_fwd_pos(const char* packed, const float* small, const float* pos, const float* viewdirs_enc,
                                   int64_t n_rays, int S, float* raw, hipStream_t stream) {
-  ArtMlpArgs a{};
+  ArtMlpArgs args{};
+  ArtSeg& a = args.seg[0];
   a.packed = packed; a.small = small; a.pos = pos; a.viewdirs_enc = viewdirs_enc;
   a.raw = raw; a.total = n_rays * S; a.S = S; a.npass = (int)((a.total + 127) / 128);
-  return launch_art_t<false, false>(a, stream);
+  args.seg[1] = a; args.seg[1].npass = 0; args.npass_total = a.npass;
+  return launch_art_t<false, false>(args, stream);
 }
 
 int64_t art_stream_bytes() { return kAStreamBytes; }

@@ -28,6 +28,9 @@ template <class Net> constexpr int dma_target(int C, int k) {
 
 struct Pipe {
   const char* stream;  // packed stream base (wave-uniform -> SGPR pair)
+  const char* next_stream;  // stream of this workgroup's NEXT pass (round 4: a launch may carry two segments with different networks,
+                            // e.g. the fine level of one ray range and the coarse level of another; the chunks that wrap around the end
+                            // of the stream -- the first pair of the next pass -- are fetched from here).  == stream in one-segment launches.
   char* ring;          // LDS ring base
   unsigned voff;       // this lane's byte offset inside a 4 KiB round: wave*1024 + lane*16
   int wave_off;        // wave*1024
@@ -61,7 +64,7 @@ __device__ __forceinline__ void issue_chunk(Pipe& p, int slot) {
 // The caller's LDS writes (resident small vectors) are published by the barrier inside.
 template <class Net>
 __device__ __forceinline__ void pipe_init(Pipe& p, const char* stream, char* ring, int wave, int lane) {
-  p.stream = stream; p.ring = ring;
+  p.stream = stream; p.next_stream = stream; p.ring = ring;
   p.voff = (unsigned)(wave * 1024 + lane * 16);
   p.wave_off = wave * 1024; p.lane_off = lane * 16;
   p.slot = 1; p.issue_off = 0;  // the first acquire flips to slot 0
@@ -112,7 +115,8 @@ template <class Net, int C>
 __device__ __forceinline__ void dma_round(const Pipe& p, unsigned off, int r) {
   constexpr int T0 = dma_target<Net>(C, 0);
   constexpr int R0 = Net::chunk_bytes(T0) / 4096;
-  gbl_char* src = (gbl_char*)(p.stream + off);
+  constexpr bool WRAPS = T0 <= C;   // the targets belong to the next pass (all targets of a chunk wrap together: 0 and 1 of an odd stream)
+  gbl_char* src = (gbl_char*)((WRAPS ? p.next_stream : p.stream) + off);
   char* slot = p.ring + (p.slot ^ 1) * kPairSlotBytes + p.wave_off;
   char* dst = r < R0 ? slot + pair_offset<Net>(T0) + r * 4096
                      : slot + pair_offset<Net>(dma_target<Net>(C, 1)) + (r - R0) * 4096;

@@ -13,6 +13,7 @@
 //                          sample range of each layer split over workgroups in proportion to its cost, each holding its
 //                          output block in accumulator registers; a deterministic second stage sums the partials (no atomics).
 //   head_wgrad_kernel      the 1- and 3-row head weights and all bias sums (plane rows x one 16-byte record per sample).
+#include <atomic>
 #define AON_WGRAD_KERNELS
 #include "aon_wgrad.h"
 
@@ -33,10 +34,20 @@ struct CompositeBwdArgs {
   float* d_raw;         // (n*S,4) dL/d raw
 };
 
-__device__ __forceinline__ float sigmoidf_(float x) { return __fdiv_rn(1.0f, __fadd_rn(1.0f, expf(-x))); }
+// Round 4: the whole backward of the compositing is evaluated in fp64 on the fp32 inputs and rounded to fp32 ONCE per output.
+// dL/dalpha_i = T_i gw_i - Sfx_i / f_i is a difference of nearly equal terms, and the density-head bias gradient is the plain sum of
+// dL/d raw_sigma over every sample of a level -- on a field where that sum cancels to 1e-4 of its terms (constructor-fuzz seed 112:
+// x6,368) the fp32 form's correlated rounding along each ray (both scans feed every sample in front of them) left the bias 3e-3 from
+// the fp64 truth where torch's fp32 autograd happened to land at 9e-5 (tests/diag/diag_density_bias.py: per-sample errors 1.2x
+// torch's, their per-ray sums 3-5x).  The kernel handles 20 B per sample and runs ~15 us per 4096-ray step: fp64 costs nothing
+// visible, and every d_raw value is now the correctly rounded derivative of the reference's formula at the forward's fp32 inputs.
+__device__ __forceinline__ double sigmoidd_(double x) { return 1.0 / (1.0 + exp(-x)); }
 
-// NB: blocks of 64 samples held in registers -- 4 for the reference geometry (S <= 256), 8 for anything up to S = 512
-// (16 blocks spill 1.8 KB per lane: the training entry points stop at 512 samples per ray)
+__device__ __forceinline__ double shfl_up_d(double v, int off) { return __shfl_up(v, off); }
+__device__ __forceinline__ double shfl_down_d(double v, int off) { return __shfl_down(v, off); }
+
+// NB: blocks of 64 samples held in registers -- 4 for the reference geometry (S <= 256), 8 for anything up to S = 512 (the training
+// entry points stop at 512 samples per ray).  Per block and lane four doubles and three floats survive between the two scans.
 template <int NB>
 __global__ void __launch_bounds__(256) composite_bwd_kernel(CompositeBwdArgs a) {
   const int lane = threadIdx.x & 63;
@@ -46,89 +57,91 @@ __global__ void __launch_bounds__(256) composite_bwd_kernel(CompositeBwdArgs a) 
   const ActParams ap = a.ap;
   const int nblk = (S + 63) >> 6;  // <= NB
   const float* tv = a.t_vals + ray * S;
+  // ||d|| as the forward takes it (fp32, helper.py:167): the interval lengths are INPUTS of the function being differentiated
   const float dn = __fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(a.dirs[ray * 3], a.dirs[ray * 3]),
                                                   __fmul_rn(a.dirs[ray * 3 + 1], a.dirs[ray * 3 + 1])),
                                         __fmul_rn(a.dirs[ray * 3 + 2], a.dirs[ray * 3 + 2])));
-  const float gC0 = a.g_rgb[ray * 3], gC1 = a.g_rgb[ray * 3 + 1], gC2 = a.g_rgb[ray * 3 + 2];
-  const float gA = a.g_acc ? a.g_acc[ray] : 0.f, gD = a.g_depth ? a.g_depth[ray] : 0.f;
+  const double gC0 = a.g_rgb[ray * 3], gC1 = a.g_rgb[ray * 3 + 1], gC2 = a.g_rgb[ray * 3 + 2];
+  const double gA = a.g_acc ? (double)a.g_acc[ray] : 0.0, gD = a.g_depth ? (double)a.g_depth[ray] : 0.0;
   // dL/dw_i = gC.c_i - [white] sum(gC) + g_acc + t_i g_depth     (comp_rgb += 1 - acc, helper.py:187-188)
-  const float gw_const = gA - (a.white_bkgd ? (gC0 + gC1 + gC2) : 0.f);
+  const double gw_const = gA - (a.white_bkgd ? (gC0 + gC1 + gC2) : 0.0);
 
-  float alpha[NB], ex[NB], T[NB], f[NB], dist[NB], wgw[NB], gw[NB], dsig_draw[NB], w_[NB];
-  float dc0[NB], dc1[NB], dc2[NB];  // d c / d raw  (activation derivative), later reused as gC.c' products
-  float carry = 1.0f;
+  double tgw[NB], f[NB], kf[NB], wgw[NB];   // T_i gw_i;  1 - alpha_i + 1e-10;  d alpha_i / d raw_sigma_i;  w_i gw_i
+  float o0[NB], o1[NB], o2[NB];             // dL/d raw rgb, finished in the first sweep
+  double carry = 1.0;
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
-    alpha[b] = 0.f; ex[b] = 1.f; T[b] = 0.f; f[b] = 1.f; dist[b] = 0.f; wgw[b] = 0.f; gw[b] = 0.f; dsig_draw[b] = 0.f; w_[b] = 0.f;
-    dc0[b] = dc1[b] = dc2[b] = 0.f;
+    tgw[b] = 0.0; f[b] = 1.0; kf[b] = 0.0; wgw[b] = 0.0; o0[b] = o1[b] = o2[b] = 0.f;
     if (b < nblk) {
       const int s = b * 64 + lane;
       const bool in = s < S;
-      float c0 = 0.f, c1 = 0.f, c2 = 0.f, t = 0.f;
+      double alpha = 0.0, gw = 0.0, d0 = 0.0, d1 = 0.0, d2 = 0.0;
       if (in) {
         const int64_t g = ray * S + s;
-        t = tv[s];
-        dist[b] = __fmul_rn(s == S - 1 ? 1e10f : __fsub_rn(tv[s + 1], t), dn);
+        const float t = tv[s];
+        const double dist = (double)__fmul_rn(s == S - 1 ? 1e10f : __fsub_rn(tv[s + 1], t), dn);
         float4 r = reinterpret_cast<const float4*>(a.raw)[g];
         if (ap.noise) r.w = __fadd_rn(r.w, __fmul_rn(ap.noise[g], ap.noise_std));   // model.py:183-184 (d/d raw_sigma = 1)
-        float sg;
+        double sg, dsg, c0, c1, c2;
         if (ap.act == 1) {
-          sg = __builtin_fmaxf(r.w, 0.f); dsig_draw[b] = r.w > 0.f ? 1.f : 0.f;
-          c0 = sigmoidf_(r.x); c1 = sigmoidf_(r.y); c2 = sigmoidf_(r.z);
-          dc0[b] = c0 * (1.f - c0); dc1[b] = c1 * (1.f - c1); dc2[b] = c2 * (1.f - c2);
+          sg = r.w > 0.f ? (double)r.w : 0.0; dsg = r.w > 0.f ? 1.0 : 0.0;
+          c0 = sigmoidd_(r.x); c1 = sigmoidd_(r.y); c2 = sigmoidd_(r.z);
+          d0 = c0 * (1.0 - c0); d1 = c1 * (1.0 - c1); d2 = c2 * (1.0 - c2);
         } else if (ap.act == 2) {
-          const float xs = __fadd_rn(r.w, ap.sigma_bias);
-          sg = xs > 20.0f ? xs : log1pf(expf(xs)); dsig_draw[b] = xs > 20.0f ? 1.f : sigmoidf_(xs);
-          const float s0 = sigmoidf_(r.x), s1 = sigmoidf_(r.y), s2 = sigmoidf_(r.z);
-          c0 = s0 * ap.rgb_scale - ap.rgb_shift; c1 = s1 * ap.rgb_scale - ap.rgb_shift; c2 = s2 * ap.rgb_scale - ap.rgb_shift;
-          dc0[b] = ap.rgb_scale * s0 * (1.f - s0); dc1[b] = ap.rgb_scale * s1 * (1.f - s1); dc2[b] = ap.rgb_scale * s2 * (1.f - s2);
+          const float xs = __fadd_rn(r.w, ap.sigma_bias);   // (an fp32 add in the forward: part of the function)
+          sg = xs > 20.0f ? (double)xs : log1p(exp((double)xs)); dsg = xs > 20.0f ? 1.0 : sigmoidd_(xs);   // torch Softplus, threshold 20
+          const double s0 = sigmoidd_(r.x), s1 = sigmoidd_(r.y), s2 = sigmoidd_(r.z);
+          const double sc = ap.rgb_scale, sh = ap.rgb_shift;
+          c0 = s0 * sc - sh; c1 = s1 * sc - sh; c2 = s2 * sc - sh;
+          d0 = sc * s0 * (1.0 - s0); d1 = sc * s1 * (1.0 - s1); d2 = sc * s2 * (1.0 - s2);
         } else {
-          sg = r.w; dsig_draw[b] = 1.f; c0 = r.x; c1 = r.y; c2 = r.z; dc0[b] = dc1[b] = dc2[b] = 1.f;
+          sg = r.w; dsg = 1.0; c0 = r.x; c1 = r.y; c2 = r.z; d0 = d1 = d2 = 1.0;
         }
-        ex[b] = expf(-__fmul_rn(sg, dist[b]));
-        alpha[b] = __fsub_rn(1.0f, ex[b]);
-        f[b] = __fadd_rn(__fsub_rn(1.0f, alpha[b]), 1e-10f);
+        const double ex = exp(-sg * dist);
+        alpha = 1.0 - ex;
+        f[b] = (1.0 - alpha) + 1e-10;
+        kf[b] = dist * ex * dsg;   // d alpha / d sigma = dist exp(-sigma dist), times the density activation's derivative
+        gw = gC0 * c0 + gC1 * c1 + gC2 * c2 + gw_const + (double)t * gD;
       }
-      // forward transmittance, as composite_kernel
-      float incl = f[b];
+      // forward transmittance T_i = prod_{j<i} f_j
+      double incl = f[b];
 #pragma unroll
       for (int off = 1; off < 64; off <<= 1) {
-        const float o = __shfl_up(incl, off);
+        const double o = shfl_up_d(incl, off);
         if (lane >= off) incl = incl * o;
       }
-      float excl = __shfl_up(incl, 1);
-      if (lane == 0) excl = 1.0f;
-      T[b] = carry * excl;
+      double excl = shfl_up_d(incl, 1);
+      if (lane == 0) excl = 1.0;
+      const double T = carry * excl;
       carry = carry * __shfl(incl, 63);
-      w_[b] = alpha[b] * T[b];
-      gw[b] = in ? (gC0 * c0 + gC1 * c1 + gC2 * c2 + gw_const + t * gD) : 0.f;
-      wgw[b] = in ? w_[b] * gw[b] : 0.f;
+      const double w = alpha * T;
+      tgw[b] = T * gw;
+      wgw[b] = in ? w * gw : 0.0;
+      o0[b] = (float)(w * gC0 * d0); o1[b] = (float)(w * gC1 * d1); o2[b] = (float)(w * gC2 * d2);
     }
   }
-  // suffix sums  Sfx_i = sum_{k>i} w_k gw_k, scanned from the far end (no subtractive cancellation)
-  float sfx_carry = 0.f;
+  // suffix sums  Sfx_i = sum_{k>i} w_k gw_k, scanned from the far end
+  double sfx_carry = 0.0;
 #pragma unroll
   for (int b = NB - 1; b >= 0; --b) {
     if (b < nblk) {
-      float incl = wgw[b];
+      double incl = wgw[b];
 #pragma unroll
       for (int off = 1; off < 64; off <<= 1) {
-        const float o = __shfl_down(incl, off);
+        const double o = shfl_down_d(incl, off);
         if (lane + off < 64) incl = incl + o;
       }
-      float excl = __shfl_down(incl, 1);
-      if (lane == 63) excl = 0.f;
-      const float sfx = excl + sfx_carry;
+      double excl = shfl_down_d(incl, 1);
+      if (lane == 63) excl = 0.0;
+      const double sfx = excl + sfx_carry;
       sfx_carry = sfx_carry + __shfl(incl, 0);
       const int s = b * 64 + lane;
       if (s < S) {
-        // dL/dalpha_i = T_i gw_i - Sfx_i / (1 - alpha_i + 1e-10);  dalpha/dsigma = dist * exp(-sigma dist): the exponential
-        // itself, as autograd saves it -- re-deriving it as 1 - alpha loses its low bits once alpha is close to 1
-        const float dalpha = T[b] * gw[b] - sfx / f[b];
-        const float dsigma = dalpha * dist[b] * ex[b];
+        // dL/dalpha_i = T_i gw_i - Sfx_i / (1 - alpha_i + 1e-10)
+        const double dalpha = tgw[b] - sfx / f[b];
         float4 o;
-        o.x = w_[b] * gC0 * dc0[b]; o.y = w_[b] * gC1 * dc1[b]; o.z = w_[b] * gC2 * dc2[b];
-        o.w = dsigma * dsig_draw[b];
+        o.x = o0[b]; o.y = o1[b]; o.z = o2[b];
+        o.w = (float)(dalpha * kf[b]);
         reinterpret_cast<float4*>(a.d_raw)[ray * S + s] = o;
       }
     }
@@ -318,6 +331,10 @@ hipError_t launch_mlp_bwd_chain(const char* packed_bwd, const char* packed_fwd, 
 
 int64_t wgrad_workspace_bytes() { return wgrad_workspace_bytes_impl(); }
 
+// measurement aid: when set, every grouped weight-gradient launch writes its workgroups' entry / exit clocks (100 MHz) there
+static std::atomic<long long*> g_wgrad_probe{nullptr};
+void set_wgrad_probe(long long* buf) { g_wgrad_probe.store(buf, std::memory_order_relaxed); }
+
 // Launch sequence shared by both networks: grouped weight gradients, heads, ONE second stage for both.
 hipError_t run_wgrad_plan(const WgLayerDesc* layers, int nlayers, const HeadDesc* heads, int nheads, const HeadOut* outs, const int* out_head, int nouts,
                           const float* planes, const float* dplanes, int rows_total, int64_t Np, float* ws, hipStream_t stream, const WgAux* aux) {
@@ -353,6 +370,7 @@ hipError_t run_wgrad_plan(const WgLayerDesc* layers, int nlayers, const HeadDesc
     if (err == hipSuccess) err = e;
   }
   if (err == hipSuccess) {
+    plan.args.probe = g_wgrad_probe.load(std::memory_order_relaxed);
     wgrad_grouped_kernel<<<dim3(plan.total_wgs), dim3(256), kWgLdsBytes, stream>>>(plan.args);
     err = hipGetLastError();
   }

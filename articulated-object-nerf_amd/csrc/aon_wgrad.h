@@ -71,6 +71,7 @@ struct WgArgs {
   int nsteps;           // Np / 32
   int njobs;
   float* ws;
+  long long* probe;     // measurement aid (aon_set_wgrad_probe): [2 * workgroup] = wall_clock64() at entry / exit, or null
   WgJob job[kWgMaxJobs];
 };
 
@@ -274,6 +275,7 @@ __global__ void __launch_bounds__(256) wgrad_grouped_kernel(WgArgs a) {
     if ((int)blockIdx.x >= a.job[t].wg_begin) j = t;
   j = __builtin_amdgcn_readfirstlane(j);
   const WgJob& J = a.job[j];
+  if (a.probe && threadIdx.x == 0) a.probe[2 * blockIdx.x] = wall_clock64();
   switch (J.kind) {
     case kWg256x256: wgrad_job<kWg256x256>(a, J, wg_smem); break;
     case kWg128x128: wgrad_job<kWg128x128>(a, J, wg_smem); break;
@@ -281,6 +283,7 @@ __global__ void __launch_bounds__(256) wgrad_grouped_kernel(WgArgs a) {
     case kWg128x256: wgrad_job<kWg128x256>(a, J, wg_smem); break;
     default: wgrad_job<kWg128x32>(a, J, wg_smem); break;
   }
+  if (a.probe && threadIdx.x == 0) a.probe[2 * blockIdx.x + 1] = wall_clock64();
 }
 
 #endif  // AON_WGRAD_KERNELS
@@ -524,6 +527,7 @@ inline bool wg_make_plan(const WgLayerDesc* layers, int nlayers, const float* pl
   if (plan.total_wgs > cus) return false;
   WgArgs& A = plan.args;
   A.dplanes = dplanes; A.planes = planes; A.step_bytes = (int64_t)rows_total * 128; A.nsteps = nsteps; A.njobs = nlayers; A.ws = ws;
+  A.probe = nullptr;
   ReduceArgs& R = plan.red;
   R.nred = 0; R.ws = ws;
   int64_t off = ws_off;

@@ -15,7 +15,7 @@ import torch.nn as nn
 import torch.nn.init as init
 
 from ... import ops
-from ...autograd import RenderGeneral, RenderVanilla
+from ...autograd import RenderGeneral, RenderLevelVanilla, RenderVanilla
 
 
 class NeRFMLP(nn.Module):
@@ -140,16 +140,25 @@ class NeRF(nn.Module):
         return [noise[lvl] if noise[lvl] is not None else torch.rand((n, self._opts.S(lvl)), device=device)
                 for lvl in range(self.num_levels)]
 
-    def _forward_many_levels(self, rays, randomized, white_bkgd, near, far, t_rand, u, noise):
+    def _forward_many_levels(self, rays, randomized, white_bkgd, near, far, t_rand, u, noise, training=False):
         """model.py:147-199 for num_levels > 2 (every level after the first resamples from the previous level's t and weights
         with fine_mlp, :162-173), driven level by level through the stage-level C calls: fused cast + encode + MLP, compositing with
         the weights written, general-size inverse CDF.  ``u``: the first resampling's draws, or a list with one entry per
-        resampling level."""
+        resampling level.  ``training`` (round 4): every level is an autograd node built from the stage-level training calls
+        (autograd.RenderLevelVanilla); fine_mlp's gradients add up over the levels that use it, as under the reference's autograd."""
         o, d, v = rays["rays_o"], rays["rays_d"], rays["viewdirs"]
         n = o.shape[0]
         us = list(u) if isinstance(u, (list, tuple)) else [u]
         t, _ = ops.sample_along_rays(o, d, self.num_coarse_samples, near, far, t_rand, want_coords=False, lindisp=self.lindisp)
-        packed = [self.coarse_mlp.packed(), self.fine_mlp.packed()]
+        mlps = [self.coarse_mlp, self.fine_mlp]
+        if training:
+            if self.noise_std > 0 and randomized:
+                raise NotImplementedError("training with num_levels > 2 AND density noise: the stage-level compositing backward takes no noise")
+            if n == 0:
+                raise ValueError("empty ray batch in training mode")
+            packs = [(m.packed(True), m.packed_bwd(True)) for m in mlps]
+        else:
+            packed = [m.packed() for m in mlps]
         ret, weights = [], None
         for lvl in range(self.num_levels):
             if lvl > 0:
@@ -157,17 +166,27 @@ class NeRF(nn.Module):
                 if randomized and ul is None:
                     ul = torch.rand((n, self.num_fine_samples), device=o.device)
                 t = ops.sample_pdf_t_n(t, weights, self.num_fine_samples, ul if randomized else None)
-            raw = ops.mlp_fwd(packed[min(lvl, 1)], o, d, v, t)
-            nz = None
-            if self.noise_std > 0 and randomized:
-                nz = noise[lvl] if (noise is not None and lvl < len(noise) and noise[lvl] is not None) else torch.rand(t.shape, device=o.device)
-            comp, acc, weights, depth = ops.composite_raw(raw, t, d, white_bkgd, ops.ACT_VANILLA, True, opts=self._opts if nz is not None else None, noise=nz)
+            k = min(lvl, 1)
+            if training:
+                comp, acc, depth, weights = RenderLevelVanilla.apply(o, d, v, t, bool(white_bkgd), packs[k][0], packs[k][1], *mlps[k].ordered_params())
+            else:
+                raw = ops.mlp_fwd(packed[k], o, d, v, t)
+                nz = None
+                if self.noise_std > 0 and randomized:
+                    nz = noise[lvl] if (noise is not None and lvl < len(noise) and noise[lvl] is not None) else torch.rand(t.shape, device=o.device)
+                comp, acc, weights, depth = ops.composite_raw(raw, t, d, white_bkgd, ops.ACT_VANILLA, True, opts=self._opts if nz is not None else None, noise=nz)
             ret.append((comp, acc, depth))
         return ret
 
     def forward(self, rays, randomized, white_bkgd, near, far, t_rand=None, u=None, noise=None):
         rays_o = rays["rays_o"]
         n = rays_o.shape[0]
+        # the stratified / inverse-CDF draws may ride in the batch dict (keys "t_rand", "u": an extension -- the reference's forward
+        # ignores extra keys, model.py:299-306 -- that makes a harness run reproducible: tests/test_hip_long_training.py)
+        if t_rand is None:
+            t_rand = rays.get("t_rand")
+        if u is None:
+            u = rays.get("u")
         if randomized:
             if t_rand is None:
                 t_rand = torch.rand((n, self.num_coarse_samples + 1), device=rays_o.device)
@@ -178,9 +197,9 @@ class NeRF(nn.Module):
         noise = self._draw_noise(noise, randomized, n, rays_o.device) if self.num_levels <= 2 else noise
         training = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
         if self.num_levels > 2:
-            if training:
-                raise NotImplementedError("num_levels > 2 is served for inference only (the training step is two C calls for two levels)")
-            return self._forward_many_levels(rays, randomized, white_bkgd, near, far, t_rand, u, noise)
+            if self._general or not self.coarse_mlp.geometry.is_default:
+                raise NotImplementedError("num_levels > 2 is served for the default network geometry / encoding degrees only")
+            return self._forward_many_levels(rays, randomized, white_bkgd, near, far, t_rand, u, noise, training=training)
         layerwise = self._general or not self._fused_inference or (training and not self._fused_training and not self.coarse_mlp.geometry.is_default)
         if layerwise:
             geom = self.coarse_mlp.geometry

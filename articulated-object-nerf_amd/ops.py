@@ -754,6 +754,12 @@ def set_fwd_overlap(on: bool) -> None:
     check(lib.aon_set_fwd_overlap(int(bool(on))), "aon_set_fwd_overlap")
 
 
+def set_fwd_merge(on: bool) -> None:
+    """Training forward of two levels as three persistent launches, coarse(A) | fine(A) + coarse(B) | fine(B) (default on; off: the
+    forms of set_fwd_overlap)."""
+    check(lib.aon_set_fwd_merge(2 if on == 2 else int(bool(on))), "aon_set_fwd_merge")   # 2 (tests): merge even when no round is saved
+
+
 def train_workspace(device, n_rays: int, articulated: bool, num_levels: int = 2, st=None) -> torch.Tensor:
     """Fresh workspace of one training forward/backward pair (it carries the forward's planes to the backward, so it is
     owned by the autograd graph, not cached); sized by the levels in use."""
@@ -948,9 +954,25 @@ def gmlp_fwd(geom: MlpGeometry, params: dict, samples_enc, viewdirs_enc):
     return rgb, dens
 
 
-# rays per internal chunk of the layer-wise engine: its activations live in HBM (~ (P + 3 W + 2 Wc) * 4 B per sample)
-G_CHUNK_RAYS = 8192
+# Workspace of the layer-wise engine's inference call: its activations live in HBM (~ (P + 3 W + 2 Wc) * 4 B per sample) and the C side
+# chunks over rays to whatever workspace it is given, so the chunk is sized from a BYTE budget (round 3: a fixed 8,192 rays = ~7 GB
+# at 256-wide networks, far more at the widths make_gg accepts, cached per device until release_workspaces(): ADVICE r3).  At 1 GB
+# the default-width network gets ~1,200-ray chunks of 193 samples = 230 k-row GEMMs: still hundreds of 128-row tiles per launch.
+G_WS_BUDGET_BYTES = 1 << 30
+G_CHUNK_RAYS = 8192            # upper bound on rays per chunk
 _GWS_CACHE: dict = {}
+
+
+def _grender_chunk_rays(gst, st, n: int) -> tuple[int, int]:
+    """(rays per chunk, workspace bytes) under G_WS_BUDGET_BYTES; never below 128 rays (then the budget is exceeded, as it must be)."""
+    rays = max(1, min(n, G_CHUNK_RAYS))
+    while True:
+        need = int(lib.aon_grender_workspace_bytes(C.byref(gst), rays, C.byref(st)))
+        if need < 0:
+            check(need, "aon_grender_workspace_bytes")
+        if need <= G_WS_BUDGET_BYTES or rays <= 128:
+            return rays, need
+        rays = max(128, min(rays // 2, int(rays * G_WS_BUDGET_BYTES / need)))
 
 
 def grender_fwd(geom: MlpGeometry, params_c: dict, params_f, rays_o, rays_d, viewdirs, near, far, white_bkgd, num_levels=2, t_rand=None, u=None,
@@ -968,9 +990,7 @@ def grender_fwd(geom: MlpGeometry, params_c: dict, params_f, rays_o, rays_d, vie
     gst = geom.c_struct()
     tc, arr_c = _gmlp_param_array(geom, params_c)
     tf, arr_f = _gmlp_param_array(geom, params_f) if num_levels == 2 else (None, None)
-    need = int(lib.aon_grender_workspace_bytes(C.byref(gst), max(1, min(n, G_CHUNK_RAYS)), C.byref(st)))
-    if need < 0:
-        check(need, "aon_grender_workspace_bytes")
+    _, need = _grender_chunk_rays(gst, st, n)
     key = str(dev)
     ws = _GWS_CACHE.get(key)
     if ws is None or ws.numel() < need:
@@ -1033,7 +1053,7 @@ def grender_bwd(geom: MlpGeometry, ws, params_per_level, rays_d, white_bkgd, num
 
 def release_workspaces() -> None:
     """Drop the per-device workspace caches of the inference calls (fused path: up to 1.35 GB, or 3.3 GB with materialised
-    encodings; layer-wise engine: up to ~7 GB at G_CHUNK_RAYS rays) back to torch's caching allocator.  They are re-made on the
+    encodings; layer-wise engine: G_WS_BUDGET_BYTES = 1 GB) back to torch's caching allocator.  They are re-made on the
     next call; training workspaces are never cached (they belong to the autograd graph)."""
     _WS_CACHE.clear()
     _GWS_CACHE.clear()

@@ -207,6 +207,9 @@ int aon_vanilla_wgrad(const float* planes, const float* dplanes, const float* d_
 int aon_wgrad_plan(int articulated, int64_t Np, int cus, int32_t* jobs6, int max_jobs, int64_t* ws_bytes);
 /* Measurement aid: `nlayers` (<= 20) identical weight-gradient jobs of one kind (0: 256x256, 1: 128x128, 2: 256x64, 3: 128x256, 4: 128x32;
  * csrc/aon_wgrad.h) on arbitrary rows of two plane buffers, the grouped kernel only, partials left in the workspace. */
+/* Measurement aid: while a device buffer of >= 2 x 304 int64 is set, every grouped weight-gradient launch on any stream writes
+ * [2 w] / [2 w + 1] = the 100 MHz wall clock at entry / exit of workgroup w (tools/kernel_bench.py --wgrad-probe); NULL = off. */
+int aon_set_wgrad_probe(void* device_buffer);
 int aon_wgrad_kind_bench(int kind, int nlayers, const float* planes, const float* dplanes, int rows, int64_t Np, void* workspace,
                          int64_t workspace_bytes, void* stream);
 
@@ -253,6 +256,13 @@ int aon_set_bwd_overlap(int on);
  * coarse level leaves idle in its last partial round of workgroups.  Same bits as the one-stream form.  aon_set_fwd_overlap(0)
  * keeps everything on `stream` (default 1 = two halves; k >= 2 = k ranges alternating on the two streams, for measurements). */
 int aon_set_fwd_overlap(int on);
+/* Round 4, default 1 and in front of the above: the training forward of two levels as THREE persistent launches on `stream` --
+ * coarse(A) | fine(A) + coarse(B) | fine(B) for two ray ranges A, B split on a multiple of 128 rays chosen to minimise the rounds of
+ * workgroups (4096 x (65 + 193) samples on 256 CUs: 33 rounds instead of 9 + 25) -- the middle launch carrying two networks'
+ * passes (model.py:149-197 / model_autodecoder.py:297-335: a range's fine level needs only its own coarse weights).  Same bits as
+ * the one-launch-per-level form.  aon_set_fwd_merge(0) falls back to aon_set_fwd_overlap's forms; 2 (tests) merges whenever the batch has
+ * two 128-ray ranges, whether or not rounds are saved. */
+int aon_set_fwd_merge(int on);
 int64_t aon_train_workspace_bytes(int64_t n_rays, int articulated, int num_levels);
 int64_t aon_train_scratch_bytes(int64_t n_rays, int articulated, int num_levels);
 int aon_render_fwd_train(const void* packed_coarse, const void* packed_fine, const float* rays_o, const float* rays_d,
@@ -387,7 +397,9 @@ int aon_art_render_bwd_ex(const void* packed_bwd_coarse, const void* small_coars
  *   aon_grender_fwd_train / aon_grender_bwd   the training step in two calls, as aon_render_fwd_train / aon_render_bwd: the
  *                           forward keeps every layer's output in `workspace` (aon_grender_train_workspace_bytes), the backward
  *                           writes all parameter gradients per level (order and shapes of `params`, overwritten); its
- *                           temporaries live in `scratch` (aon_grender_train_scratch_bytes).  Deterministic (no atomics). */
+ *                           temporaries live in `scratch` (aon_grender_train_scratch_bytes).  Deterministic (no atomics).
+ * The aon_grender_* calls take the encoding degrees from aon_mlp_geometry; the degree fields of aon_render_opts are ignored there
+ * (any value is accepted: they are validated against the fused kernels' 10 / 4-level limits by the fused entry points only). */
 typedef struct aon_mlp_geometry {
   int32_t min_deg_point, max_deg_point, deg_view;
   int32_t netdepth, netwidth, netdepth_condition, netwidth_condition, skip_layer;

@@ -206,6 +206,15 @@ def test_constructor_option_entry_points_validate_without_gpu():
     assert n * acts * per_sample <= ws <= n * acts * per_sample + n * (32 * 2 + 65) * 4 + 64 * 256
     assert lib.aon_grender_train_scratch_bytes(C.byref(g), n, 2, C.byref(st)) > 0
     assert lib.aon_grender_workspace_bytes(C.byref(g), n, C.byref(st)) > 0
+    # the general engine takes its degrees from the geometry: opts' degree fields filled to match a (1, 12, 5) network are accepted
+    # there and still refused by the fused entry points
+    g.min_deg_point, g.max_deg_point, g.deg_view = 1, 12, 5
+    st.min_deg_point, st.max_deg_point, st.deg_view = 1, 12, 5
+    assert lib.aon_grender_workspace_bytes(C.byref(g), n, C.byref(st)) > 0
+    assert lib.aon_grender_train_workspace_bytes(C.byref(g), n, 2, C.byref(st)) > 0
+    assert lib.aon_render_workspace_bytes_ex(n, C.byref(st)) == -1 and b"frequency levels" in lib.aon_last_error()
+    lib.aon_mlp_geometry_init(C.byref(g))
+    lib.aon_render_opts_init(C.byref(st))
     g.input_ch = 2                                       # NeRF.forward encodes 3-vectors
     assert lib.aon_grender_fwd(C.byref(g), None, None, None, None, None, 8, 2.0, 6.0, 1, 2, None, None, 0, None, None, None, None, None, None,
                                None, 0, None, None) == -1

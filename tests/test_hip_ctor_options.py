@@ -269,8 +269,47 @@ def test_more_than_two_levels(dev):
                 # (every resampling level re-amplifies the last bits of the previous level's weights: measured 5.2e-6 at level 3)
                 torch.testing.assert_close(out[lvl][0].cpu()[ok], ref[lvl][0][ok], rtol=0, atol=2e-5)
                 torch.testing.assert_close(out[lvl][2].cpu()[ok], ref[lvl][2][ok], rtol=0, atol=2e-4)
-    with pytest.raises(NotImplementedError):       # training: two levels
-        model(rays, False, True, 2.0, 6.0)[0][0].sum().backward()
+
+
+def test_training_with_more_than_two_levels(dev):
+    """Training at num_levels = 3 and 4 (round 4; round 3 raised): every level an autograd node built from the stage-level training
+    calls (autograd.RenderLevelVanilla), fine_mlp's gradients accumulated over the levels that use it (model.py:149-197 under the
+    reference's autograd).  Loss = sum of the levels' mse; gradients by the fp64-truth yardstick of tests/_gradcheck.py."""
+    import aon_amd.synthetic as syn
+    from _gradcheck import assert_as_close_as_fp32
+    from aon_amd.models.vanilla_nerf.model import NeRF
+
+    sd = syn.make_smooth_nerf_state_dict()
+    frame = syn.make_rays(16, 24, syn.look_at_pose(4.0, 60, 20), syn.focal_from_fovy(16))
+    rays_cpu = {k: v[::3].contiguous() for k, v in frame.items()}
+    rays = {k: v.to(dev) for k, v in rays_cpu.items()}
+    n = rays["rays_o"].shape[0]
+    target = syn.seeded_uniform(77, n, 3)
+    for levels, nc, nf in ((3, 64, 128), (4, 24, 40)):
+        tr, u = syn.seeded_uniform(101, n, nc + 1), syn.seeded_uniform(102, n, nf)
+        kw = dict(num_levels=levels, num_coarse_samples=nc, num_fine_samples=nf)
+
+        def oracle_grads(dtype):
+            sd_o = {k: v.detach().clone().to(dtype).requires_grad_(True) for k, v in sd.items()}
+            out = orc.nerf_forward(sd_o, {k: v.to(dtype) for k, v in rays_cpu.items()}, True, True, 2.0, 6.0, t_rand=tr.to(dtype), u=u.to(dtype), **kw)
+            loss = sum(orc.img2mse(o[0], target.to(dtype)) for o in out)
+            loss.backward()
+            return loss.item(), {k: v.grad for k, v in sd_o.items()}
+
+        (_, truth), (loss32, ref32) = oracle_grads(torch.float64), oracle_grads(torch.float32)
+        model = NeRF(**kw).to(dev)
+        model.load_state_dict(sd)
+        out = model(rays, True, True, 2.0, 6.0, t_rand=tr.to(dev), u=[u.to(dev)] * (levels - 1))
+        assert len(out) == levels and all(o[0].requires_grad for o in out)
+        loss = sum(((o[0] - target.to(dev)) ** 2).mean() for o in out)
+        loss.backward()
+        assert abs(loss.item() - loss32) < 5e-6, (loss.item(), loss32)
+        hip = {name: p.grad.cpu() for name, p in model.named_parameters()}
+        assert_as_close_as_fp32(hip, truth, ref32, f"num_levels = {levels}", factor=5.0, floor=1e-4)
+        # an evaluation call in grad mode on frozen parameters takes the inference route (ADVICE r3)
+        for p in model.parameters():
+            p.requires_grad_(False)
+        assert not model(rays, False, True, 2.0, 6.0)[levels - 1][0].requires_grad
 
 
 def test_bad_options_are_rejected(dev):

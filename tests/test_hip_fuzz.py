@@ -281,9 +281,15 @@ def test_training_sweep_constructor_arguments(dev, seed):
     hip = {name: p.grad.cpu() for name, p in model.named_parameters()}
     if art:
         hip.update({f"latent[{k}]": lat[k].grad.cpu() for k in lat})
-    # a sweep, not a pin: the ratio to the reference-fp32's own error has a distribution over random geometries (measured over 24
-    # seeds: three above 5x -- 5.7x on fine-level weights behind an 11-bin inverse CDF, 7x on the articulated deformation head,
-    # 14x at the 4e-4 level on a coarse view layer); a wrong kernel is off by O(1).  The dedicated tests hold 5x.
-    # The one- and three-element head biases (signed sums over every sample: cancellation) are under the SAME factor since round 4 --
-    # their sums are fp64 on the device -- with _gradcheck's lower floor for parameters of at most four elements.
-    assert_as_close_as_fp32(hip, truth, ref32, f"seed {seed}: {kw} {gk}", factor=25.0, floor=1e-3)
+    # a sweep, not a pin: the ratio to the reference-fp32's own error has a distribution over random geometries -- measured over
+    # 150 seeds on MI355X (round 4, profiles/r04_fuzz150_training.txt): median of the per-seed worst ratio 1.1x, 90th percentile 4.6x,
+    # 14 seeds above 5x, 8 above 10x (12x on trunk layers at the 4e-3 level behind coarse inverse CDFs, 11x on the articulated
+    # deformation head), 2 above 20x (38x / 43x, both a density bias at 2-3e-5 ABSOLUTE relative error, see below); a wrong kernel is
+    # off by O(1).  The dedicated tests (test_hip_smooth.py, test_hip_training.py G9 inputs, test_hip_ctor_options.py) hold 5x.
+    # The one- and three-element head biases (signed sums over every sample: cancellation) are under the SAME factor since round 4 (round
+    # 3: their own call with a 1e-2 floor).  Their sums and the whole compositing backward are fp64 on the device now (aon_wgrad.h,
+    # aon_train.hip), so what is left is the fp32 noise of the forward's raw sigma values times the cancellation of the sum (x20 - x6,000
+    # over these geometries) -- the same for any fp32 forward; where the reference's own fp32 lands is luck (4.8e-7 ... 8.8e-5 on the seeds
+    # below).  Measured over 150 seeds (round 4): worst density bias 3.2e-5 (seeds 75, 95), everything else under 2e-5 or inside 5 x the
+    # reference -- hence the sweep's floor of 5e-5 for <= 4-element parameters (the dedicated tests keep _gradcheck's 2e-5).
+    assert_as_close_as_fp32(hip, truth, ref32, f"seed {seed}: {kw} {gk}", factor=25.0, floor=1e-3, small_floor=5e-5)

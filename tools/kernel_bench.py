@@ -56,6 +56,60 @@ def wgrad_kinds(args):
                               "frac": round(flops / ms / 1e9 / 157.3, 4), "operand_GBs": round((M + K) * 4 * Np * nl / ms / 1e6, 1)}), flush=True)
 
 
+def wgrad_probe(args):
+    """Where the grouped weight-gradient launch spends its time: per job (layer) the workgroups' entry / exit clocks, from the probe
+    of aon_set_wgrad_probe, for the articulated network at both levels.  One JSON line per job: kind, workgroups, steps per
+    workgroup, mean / max duration, idle tail behind its last workgroup until the launch ends."""
+    import ctypes as C
+
+    import aon_amd.synthetic as syn
+    from aon_amd import _lib, ops
+
+    lib = _lib.lib
+    dev = torch.device("cuda:0")
+    n = args.rays
+    asd = {k: v.to(dev) for k, v in syn.make_art_state_dict(seed=0, density_scale=30.0).items()}
+    art = {k[len("fine_mlp."):]: v for k, v in asd.items() if k.startswith("fine_mlp.")}
+    lat = {"density": torch.randn(1, 128, device=dev) * 0.1, "color": torch.randn(1, 128, device=dev) * 0.1,
+           "articulation": torch.randn(1, 32, device=dev) * 0.1}
+    pa, pab, small = ops.pack_art_mlp(art), ops.pack_art_mlp_bwd(art), ops.art_prepare(art, lat)
+    H, W = 480, 640
+    ro, vd = ops.raygen(syn.look_at_pose(), H, W, syn.focal_from_fovy(H), device=dev)
+    idx = torch.randint(0, H * W, (n,), device=dev)
+    o, d = ro[idx].contiguous(), vd[idx].contiguous()
+    cus = torch.cuda.get_device_properties(dev).multi_processor_count
+    names = {0: "256x256", 1: "128x128", 2: "256x64", 3: "128x256", 4: "128x32"}
+    for S in (65, 193):
+        t, _ = ops.sample_along_rays(o, d, S - 1, 2.0, 6.0, want_coords=False)
+        raw, planes, masks = ops.art_mlp_fwd_train(pa, small, o, d, d, t.contiguous())
+        d_raw = torch.randn(ops.plane_samples(planes), 4, device=dev) * 1e-3
+        dpl, dxp = ops.art_bwd_chain(pab, small, d_raw, masks, planes)
+        probe = torch.zeros(2 * 320, dtype=torch.int64, device=dev)
+        ops.art_wgrad(planes, dpl, d_raw, dxp, art, lat)
+        torch.cuda.synchronize()
+        lib.aon_set_wgrad_probe(probe.data_ptr())
+        try:
+            ops.art_wgrad(planes, dpl, d_raw, dxp, art, lat)
+            torch.cuda.synchronize()
+        finally:
+            lib.aon_set_wgrad_probe(None)
+        jobs = (C.c_int32 * (6 * 24))()
+        nj = lib.aon_wgrad_plan(1, ops.plane_samples(planes), cus, jobs, 24, None)
+        assert nj > 0, lib.aon_last_error()
+        pr = probe.cpu().reshape(-1, 2).double() / 100.0     # microseconds
+        total = int(sum(jobs[6 * j + 2] for j in range(nj)))
+        t0, t1 = pr[:total, 0].min().item(), pr[:total, 1].max().item()
+        print(json.dumps({"tag": args.tag, "S": S, "launch_us": round(t1 - t0, 1), "workgroups": total, "jobs": nj}), flush=True)
+        for j in range(nj):
+            kind, b, c, per = jobs[6 * j], jobs[6 * j + 1], jobs[6 * j + 2], jobs[6 * j + 3]
+            dur = pr[b: b + c, 1] - pr[b: b + c, 0]
+            print(json.dumps({"S": S, "job": j, "kind": names[kind], "wgs": c, "steps_per_wg": per, "start_us_max": round((pr[b: b + c, 0].max().item() - t0), 1),
+                              "dur_us_mean": round(dur.mean().item(), 1), "dur_us_max": round(dur.max().item(), 1),
+                              "us_per_step": round(dur.mean().item() / per, 3), "idle_tail_us": round(t1 - pr[b: b + c, 1].max().item(), 1)}), flush=True)
+        del raw, planes, masks, dpl, dxp
+        torch.cuda.empty_cache()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rays", type=int, default=4096)
@@ -63,9 +117,12 @@ def main():
     ap.add_argument("--only", default="")
     ap.add_argument("--tag", default=os.environ.get("AON_HIP_LIB", "product"))
     ap.add_argument("--wgrad-kinds", action="store_true", help="isolated rate of each weight-gradient job kind (aon_wgrad_kind_bench)")
+    ap.add_argument("--wgrad-probe", action="store_true", help="per-job workgroup durations inside the grouped weight-gradient launch (aon_set_wgrad_probe)")
     args = ap.parse_args()
     if args.wgrad_kinds:
         return wgrad_kinds(args)
+    if args.wgrad_probe:
+        return wgrad_probe(args)
     only = set(filter(None, args.only.split(",")))
     import aon_amd.synthetic as syn
     from aon_amd import ops
