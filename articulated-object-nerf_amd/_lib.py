@@ -60,6 +60,7 @@ _SIGS = {
     "aon_mlp_bwd_chain": (_i, [_p, _p, _p, _p, _p, _l, _p]),
     "aon_vanilla_wgrad": (_i, [_p, _p, _p, _l, _p, _p, _l, _p]),
     "aon_wgrad_plan": (_i, [_i, _l, _i, _p, _i, _p]),
+    "aon_wgrad_plan_segment": (_i, [_i, _l, _i, _i, _i, _p]),
     "aon_wgrad_kind_bench": (_i, [_i, _i, _p, _p, _i, _l, _p, _l, _p]),
     "aon_art_train_plane_rows": (_l, []),
     "aon_art_train_mask_bytes": (_l, [_l]),
@@ -71,6 +72,7 @@ _SIGS = {
     "aon_set_bwd_overlap": (_i, [_i]),
     "aon_set_fwd_overlap": (_i, [_i]),
     "aon_set_fwd_merge": (_i, [_i]),
+    "aon_set_bwd_merge": (_i, [_i]),
     "aon_set_wgrad_probe": (_i, [_p]),
     "aon_train_workspace_bytes": (_l, [_l, _i, _i]),
     "aon_train_scratch_bytes": (_l, [_l, _i, _i]),

@@ -26,7 +26,9 @@ HEADERS = [os.path.join(CSRC, "aon_common.h"), os.path.join(CSRC, "aon_mlp_core.
 # backward chain (5.62 -> 4.95 ms per level pair) but costs the forward kernels 2.7 % (144.0 -> 140.2 TFLOP/s) and does
 # nothing for the articulated chains, so it is applied to aon_train.hip only.  (-mllvm -amdgpu-mfma-vgpr-form on the same
 # file: backward chain 5.26 ms but the weight-gradient kernel 0.525 -> 0.643 ms -- a net loss.)
-PER_FILE_FLAGS = {"aon_train.hip": ["-DAON_PIN_PREFETCH"]}
+# Round 4: with two segments per chain launch the pinned form of the vanilla chain spills 3.5 KB per lane (the sched_barrier per step
+# leaves the allocator no room for the segment bookkeeping); unpinned it is at 0 scratch, so the flag is off for every file.
+PER_FILE_FLAGS = {}
 if "AON_PER_FILE_FLAGS" in os.environ:   # experiments: JSON {"file.hip": ["flag", ...]} replaces the table
     import json as _json
     PER_FILE_FLAGS = _json.loads(os.environ["AON_PER_FILE_FLAGS"])

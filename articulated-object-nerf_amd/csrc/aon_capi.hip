@@ -38,9 +38,12 @@ hipError_t launch_mlp_fwd_train_enc(const char* packed, const float* samples_enc
 int64_t bwd_stream_bytes();
 hipError_t launch_mlp_bwd_chain(const char* packed_bwd, const char* packed_fwd, const float* d_raw, const void* masks,
                                 float* dplanes, int64_t Np, hipStream_t stream);
+hipError_t launch_mlp_bwd_chain2(const ChainSeg* segs, int nsegs, hipStream_t stream);
+hipError_t launch_art_bwd_chain2(const ChainSeg* segs, int nsegs, hipStream_t stream);
 int64_t wgrad_workspace_bytes();
 int wgrad_plan_describe(bool art, int64_t Np, int cus, int32_t* out6, int max_jobs, int64_t* ws_bytes);
 void set_wgrad_probe(long long* buf);
+int wgrad_plan_segment(bool art, int64_t Np, int cus, int j, int wg, int32_t* begin_end);
 hipError_t launch_wgrad_kind_bench(int kind, int nlayers, const float* planes, const float* dplanes, int rows_total, int64_t Np, float* ws,
                                    float* out_scratch, hipStream_t stream);
 struct WgAux { hipStream_t stream; hipEvent_t fork, join; };   // aon_wgrad.h: optional side stream of a level's head reductions
@@ -418,8 +421,15 @@ int aon_wgrad_plan(int articulated, int64_t Np, int cus, int32_t* jobs6, int max
   if (!jobs6 || max_jobs < 1) return fail(AON_E_INVALID, "aon_wgrad_plan: null / empty output");
   const int n = aon::wgrad_plan_describe(articulated != 0, Np, cus, jobs6, max_jobs, ws_bytes);
   if (n < 0) return fail(AON_E_INVALID, n == -1 ? "aon_wgrad_plan: Np must be a positive multiple of 32, cus >= 1"
-                                       : n == -2 ? "aon_wgrad_plan: no plan (fewer compute units than layers?)" : "aon_wgrad_plan: max_jobs too small");
+                                       : n == -2 ? "aon_wgrad_plan: no plan" : "aon_wgrad_plan: max_jobs too small");
   return n;
+}
+
+int aon_wgrad_plan_segment(int articulated, int64_t Np, int cus, int job, int workgroup, int32_t* begin_end) {
+  if (!begin_end) return fail(AON_E_INVALID, "aon_wgrad_plan_segment: null output");
+  const int r = aon::wgrad_plan_segment(articulated != 0, Np, cus, job, workgroup, begin_end);
+  if (r < 0) return fail(AON_E_INVALID, "aon_wgrad_plan_segment: bad argument");
+  return r;
 }
 
 int aon_set_wgrad_probe(void* device_buffer) {
@@ -472,7 +482,7 @@ int aon_mlp_fwd_train(const void* packed, const float* rays_o, const float* rays
 
 int aon_composite_bwd(const float* raw, const float* t_vals, const float* dirs, const float* g_rgb, const float* g_acc,
                       const float* g_depth, int64_t n_rays, int S, int white_bkgd, int act, float* d_raw, void* stream) {
-  if (n_rays < 0 || S < 1 || S > 256 || act < 0 || act > 2) return fail(AON_E_INVALID, "aon_composite_bwd: bad size / act (S <= 256)");
+  if (n_rays < 0 || S < 1 || S > 512 || act < 0 || act > 2) return fail(AON_E_INVALID, "aon_composite_bwd: bad size / act (S <= 512)");
   if (n_rays == 0) return AON_OK;
   if (!raw || !t_vals || !dirs || !g_rgb || !d_raw) return fail(AON_E_INVALID, "aon_composite_bwd: null pointer");
   KTimer timer(kCompositeBwd, (hipStream_t)stream, n_rays);
@@ -891,6 +901,7 @@ class LevelFork {
 std::atomic<int> g_bwd_overlap{1};
 std::atomic<int> g_fwd_overlap{2};
 std::atomic<int> g_fwd_merge{1};
+std::atomic<int> g_bwd_merge{1};   // the backward chains of the two levels as ONE persistent launch of two segments (round 4)
 
 // The merged training forward (round 4) runs the two levels of two ray ranges A = [0, kA), B = [kA, n) as THREE persistent launches
 //   coarse(A)  |  fine(A) + coarse(B)  |  fine(B)
@@ -1075,6 +1086,11 @@ int aon_set_bwd_overlap(int on) {
   return AON_OK;
 }
 
+int aon_set_bwd_merge(int on) {
+  g_bwd_merge.store(on ? 1 : 0, std::memory_order_relaxed);
+  return AON_OK;
+}
+
 int aon_set_fwd_merge(int on) {
   g_fwd_merge.store(on == 2 ? 2 : (on ? 1 : 0), std::memory_order_relaxed);   // 2 (tests): merge whenever there are two ranges, gain or not
   return AON_OK;
@@ -1169,29 +1185,47 @@ int aon_render_bwd_ex(const void* packed_bwd_coarse, const void* packed_fwd_coar
   const void* pb[2] = {packed_bwd_coarse, packed_bwd_fine};
   const void* pf[2] = {packed_fwd_coarse, packed_fwd_fine};
   float* const* grads[2] = {grads_coarse_host, grads_fine_host};
-  // fork: with two levels each runs on its own library stream, ordered after everything already enqueued on the caller's
+  for (int l = 0; l < num_levels; ++l) {
+    if (!pb[l] || !pf[l] || !grads[l] || !g_rgb_host[l]) return fail(AON_E_INVALID, "aon_render_bwd: null level pointer");
+    for (int i = 0; i < aon::kNumVanillaParams; ++i)
+      if (!grads[l][i]) return fail(AON_E_INVALID, "aon_render_bwd: null gradient pointer");
+  }
   hipStream_t caller = stream;
+  auto composite_bwd = [&](int l, hipStream_t st) -> int {
+    const TrainLevel& L = w.lvl[l];
+    const int64_t valid = n_rays * L.S;
+    if (int rc = check(hipMemsetAsync(sc.d_raw[l] + valid * 4, 0, (size_t)(L.Np - valid) * 16, st), "aon_render_bwd")) return rc;
+    KTimer timer(kCompositeBwd, st, n_rays);
+    return check(aon::launch_composite_bwd(L.raw, L.t, rays_d, g_rgb_host[l], g_acc_host ? g_acc_host[l] : nullptr, g_depth_host ? g_depth_host[l] : nullptr,
+                                           n_rays, L.S, white_bkgd, g.act(false, l, 0), sc.d_raw[l], st), "aon_render_bwd");
+  };
+  auto chain_seg = [&](int l) {
+    const TrainLevel& L = w.lvl[l];
+    return aon::ChainSeg{static_cast<const char*>(pb[l]), reinterpret_cast<const float*>(static_cast<const char*>(pf[l]) + aon::kStreamBytes), sc.d_raw[l],
+                         L.masks, nullptr, sc.dplanes[l], nullptr, L.Np};
+  };
+  // Round 4: the two levels' chains are independent -> ONE persistent launch of two segments on the caller's stream (33 rounds of
+  // workgroups instead of 9 + 25 at 4096 x (65 + 193) samples), then the weight gradients of the two levels on the two streams.
+  const bool merged = num_levels == 2 && g_bwd_merge.load(std::memory_order_relaxed) != 0;
+  if (merged) {
+    for (int l = 0; l < 2; ++l)
+      if (int rc = composite_bwd(l, caller)) return rc;
+    const aon::ChainSeg segs[2] = {chain_seg(1), chain_seg(0)};
+    KTimer timer(kBwdChain, caller, w.lvl[0].Np + w.lvl[1].Np);
+    if (int rc = check(aon::launch_mlp_bwd_chain2(segs, 2, caller), "aon_render_bwd")) return rc;
+  }
+  // fork: with two levels each runs on its own library stream, ordered after everything already enqueued on the caller's
   LevelFork fork(num_levels == 2 && g_bwd_overlap.load(std::memory_order_relaxed), caller, "aon_render_bwd");
   if (fork.rc()) return fork.rc();
   for (int l = 0; l < num_levels; ++l) {
     const TrainLevel& L = w.lvl[l];
     stream = fork.stream(l);
-    if (!pb[l] || !pf[l] || !grads[l] || !g_rgb_host[l]) return fail(AON_E_INVALID, "aon_render_bwd: null level pointer");
-    for (int i = 0; i < aon::kNumVanillaParams; ++i)
-      if (!grads[l][i]) return fail(AON_E_INVALID, "aon_render_bwd: null gradient pointer");
-    const int64_t valid = n_rays * L.S;
-    int rc = check(hipMemsetAsync(sc.d_raw[l] + valid * 4, 0, (size_t)(L.Np - valid) * 16, stream), "aon_render_bwd");
-    if (rc) return rc;
-    {
-      KTimer timer(kCompositeBwd, stream, n_rays);
-      rc = check(aon::launch_composite_bwd(L.raw, L.t, rays_d, g_rgb_host[l], g_acc_host ? g_acc_host[l] : nullptr, g_depth_host ? g_depth_host[l] : nullptr,
-                                           n_rays, L.S, white_bkgd, g.act(false, l, 0), sc.d_raw[l], stream), "aon_render_bwd");
-    }
-    if (rc) return rc;
-    {
+    int rc = AON_OK;
+    if (!merged) {
+      if ((rc = composite_bwd(l, stream))) return rc;
+      const aon::ChainSeg seg = chain_seg(l);
       KTimer timer(kBwdChain, stream, L.Np);
-      rc = check(aon::launch_mlp_bwd_chain(static_cast<const char*>(pb[l]), static_cast<const char*>(pf[l]), sc.d_raw[l], L.masks, sc.dplanes[l], L.Np, stream),
-                 "aon_render_bwd");
+      rc = check(aon::launch_mlp_bwd_chain2(&seg, 1, stream), "aon_render_bwd");
     }
     if (rc) return rc;
     {
@@ -1253,29 +1287,45 @@ int aon_art_render_bwd_ex(const void* packed_bwd_coarse, const void* small_coars
   const float* sm[2] = {static_cast<const float*>(small_coarse), static_cast<const float*>(small_fine)};
   const float* const* params[2] = {params_coarse_host, params_fine_host};
   float* const* grads[2] = {grads_coarse_host, grads_fine_host};
-  // fork: with two levels each runs on its own library stream, ordered after everything already enqueued on the caller's
+  for (int l = 0; l < num_levels; ++l) {
+    if (!pb[l] || !sm[l] || !grads[l] || !params[l] || !g_rgb_host[l]) return fail(AON_E_INVALID, "aon_art_render_bwd: null level pointer");
+    for (int i = 0; i < 40; ++i)
+      if (!grads[l][i] || !params[l][i]) return fail(AON_E_INVALID, "aon_art_render_bwd: null parameter / gradient pointer");
+  }
   hipStream_t caller = stream;
+  auto composite_bwd = [&](int l, hipStream_t st) -> int {
+    const TrainLevel& L = w.lvl[l];
+    const int64_t valid = n_rays * L.S;
+    if (int rc = check(hipMemsetAsync(sc.d_raw[l] + valid * 4, 0, (size_t)(L.Np - valid) * 16, st), "aon_art_render_bwd")) return rc;
+    KTimer timer(kCompositeBwd, st, n_rays);
+    return check(aon::launch_composite_bwd(L.raw, L.t, rays_d, g_rgb_host[l], g_acc_host ? g_acc_host[l] : nullptr, g_depth_host ? g_depth_host[l] : nullptr,
+                                           n_rays, L.S, white_bkgd, g.act(true, l, 0), sc.d_raw[l], st), "aon_art_render_bwd");
+  };
+  auto chain_seg = [&](int l) {
+    const TrainLevel& L = w.lvl[l];
+    return aon::ChainSeg{static_cast<const char*>(pb[l]), sm[l], sc.d_raw[l], L.masks, L.planes, sc.dplanes[l], sc.dxp[l], L.Np};
+  };
+  // Round 4: the two levels' chains as ONE persistent launch of two segments on the caller's stream (see aon_render_bwd_ex)
+  const bool merged = num_levels == 2 && g_bwd_merge.load(std::memory_order_relaxed) != 0;
+  if (merged) {
+    for (int l = 0; l < 2; ++l)
+      if (int rc = composite_bwd(l, caller)) return rc;
+    const aon::ChainSeg segs[2] = {chain_seg(1), chain_seg(0)};
+    KTimer timer(kBwdChain, caller, w.lvl[0].Np + w.lvl[1].Np);
+    if (int rc = check(aon::launch_art_bwd_chain2(segs, 2, caller), "aon_art_render_bwd")) return rc;
+  }
+  // fork: with two levels each runs on its own library stream, ordered after everything already enqueued on the caller's
   LevelFork fork(num_levels == 2 && g_bwd_overlap.load(std::memory_order_relaxed), caller, "aon_art_render_bwd");
   if (fork.rc()) return fork.rc();
   for (int l = 0; l < num_levels; ++l) {
     const TrainLevel& L = w.lvl[l];
     stream = fork.stream(l);
-    if (!pb[l] || !sm[l] || !grads[l] || !params[l] || !g_rgb_host[l]) return fail(AON_E_INVALID, "aon_art_render_bwd: null level pointer");
-    for (int i = 0; i < 40; ++i)
-      if (!grads[l][i] || !params[l][i]) return fail(AON_E_INVALID, "aon_art_render_bwd: null parameter / gradient pointer");
-    const int64_t valid = n_rays * L.S;
-    int rc = check(hipMemsetAsync(sc.d_raw[l] + valid * 4, 0, (size_t)(L.Np - valid) * 16, stream), "aon_art_render_bwd");
-    if (rc) return rc;
-    {
-      KTimer timer(kCompositeBwd, stream, n_rays);
-      rc = check(aon::launch_composite_bwd(L.raw, L.t, rays_d, g_rgb_host[l], g_acc_host ? g_acc_host[l] : nullptr, g_depth_host ? g_depth_host[l] : nullptr,
-                                           n_rays, L.S, white_bkgd, g.act(true, l, 0), sc.d_raw[l], stream), "aon_art_render_bwd");
-    }
-    if (rc) return rc;
-    {
+    int rc = AON_OK;
+    if (!merged) {
+      if ((rc = composite_bwd(l, stream))) return rc;
+      const aon::ChainSeg seg = chain_seg(l);
       KTimer timer(kBwdChain, stream, L.Np);
-      rc = check(aon::launch_art_bwd_chain(static_cast<const char*>(pb[l]), sm[l], sc.d_raw[l], L.masks, L.planes, sc.dplanes[l], sc.dxp[l], L.Np, stream),
-                 "aon_art_render_bwd");
+      rc = check(aon::launch_art_bwd_chain2(&seg, 1, stream), "aon_art_render_bwd");
     }
     if (rc) return rc;
     {

@@ -150,6 +150,19 @@ struct ActParams {
 };
 inline ActParams default_act(int act) { return ActParams{act, 1.002f, 0.001f, -1.0f, nullptr, 0.f}; }
 
+// One segment of a backward-chain launch (host side): a level's transposed stream, head weights and buffers.  The chains of the two
+// levels of a training step are independent: launch_*_bwd_chain2 runs them as one persistent launch of two segments.
+struct ChainSeg {
+  const char* packed_bwd;
+  const float* small;      // the level's small block (vanilla: packed_fwd + kStreamBytes)
+  const float* d_raw;      // (Np,4)
+  const void* masks;
+  const float* planes;     // articulated: the level's forward planes (deformed position rows); vanilla: null
+  float* dplanes;
+  float* dxp;              // articulated: (Np,4); vanilla: null
+  int64_t Np;
+};
+
 // One segment of a training-forward launch (host side): a network's streams and one ray range's buffers at one level.  The fused
 // training forwards take one or two of these per launch (launch_*_fwd_train2): e.g. the fine level of ray range A together with
 // the coarse level of ray range B, so the partial last round of workgroups of one is filled with passes of the other.

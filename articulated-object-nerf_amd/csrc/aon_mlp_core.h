@@ -86,8 +86,14 @@ __device__ __forceinline__ void pipe_init(Pipe& p, const char* stream, char* rin
 // wave issues in order, so the address-setup + DMA instructions issued as one block at the boundary would hold back the
 // MFMAs behind them while the memory pipeline accepts them; spread out they cost nothing, and being early in the chunk
 // they have landed long before the next barrier's vmcnt(0).
+// first chunk whose DMA targets belong to the NEXT pass (chunk C fetches C + 2; the last chunk of an odd stream fetches 0 and 1)
+template <class Net> constexpr int first_wrapping_chunk() { return (Net::kNumChunks & 1) ? Net::kNumChunks - 1 : Net::kNumChunks - 2; }
+
 template <class Net, int C>
 __device__ __forceinline__ unsigned acquire(Pipe& p) {
+  // every DMA issued from here to the end of the pass fetches the next pass's first pair: ONE stream base is live at any time (a
+  // second base selected per chunk kept two 64-bit per-lane addresses alive and tipped the vanilla chain into 3.5 KB of scratch)
+  if constexpr (C == first_wrapping_chunk<Net>()) p.stream = p.next_stream;
   if constexpr ((C & 1) == 0) {
 #if defined(AON_EXP_NOVMWAIT)    // timing experiment only (WRONG results): the barrier without waiting for this wave's DMA
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -115,8 +121,7 @@ template <class Net, int C>
 __device__ __forceinline__ void dma_round(const Pipe& p, unsigned off, int r) {
   constexpr int T0 = dma_target<Net>(C, 0);
   constexpr int R0 = Net::chunk_bytes(T0) / 4096;
-  constexpr bool WRAPS = T0 <= C;   // the targets belong to the next pass (all targets of a chunk wrap together: 0 and 1 of an odd stream)
-  gbl_char* src = (gbl_char*)((WRAPS ? p.next_stream : p.stream) + off);
+  gbl_char* src = (gbl_char*)(p.stream + off);   // (from the first wrapping chunk on, p.stream IS the next pass's stream: acquire)
   char* slot = p.ring + (p.slot ^ 1) * kPairSlotBytes + p.wave_off;
   char* dst = r < R0 ? slot + pair_offset<Net>(T0) + r * 4096
                      : slot + pair_offset<Net>(dma_target<Net>(C, 1)) + (r - R0) * 4096;

@@ -201,7 +201,8 @@ __global__ void pack_vanilla_bwd_kernel(PackArgs24 a, float* __restrict__ packed
   packed[idx] = W[(int64_t)j * ld + f];
 }
 
-struct BwdArgs {
+// One SEGMENT of a chain launch = the passes of one level (see ArtBwdSeg, aon_train_art.hip: the two levels' chains are one launch).
+struct BwdSeg {
   const char* packed_bwd;   // kBwStreamBytes
   const float* small;       // forward small block (head weights): packed_fwd + kStreamBytes
   const float* d_raw;       // (Np,4)   zero for padded samples
@@ -209,6 +210,10 @@ struct BwdArgs {
   float* dplanes;           // pre-activation gradient planes, same row map
   int64_t Np;
   int npass;
+};
+struct BwdArgs {
+  BwdSeg seg[2];
+  int npass_total;          // seg[1].npass == 0: a one-segment launch
 };
 
 template <int NT>
@@ -222,26 +227,48 @@ __device__ __forceinline__ void zero_tiles(f32x16 (&x)[NT]) {
 __global__ void __launch_bounds__(256) mlp_bwd_chain_kernel(BwdArgs args) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* sm = reinterpret_cast<float*>(smem + kRingBytes);
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
-  const int m = lane & 31, h = lane >> 5;
+  const int tid0 = threadIdx.x;
+  const int lane = tid0 & 63, wave = tid0 >> 6;
   const int wave_s = __builtin_amdgcn_readfirstlane(wave);
-  {
-    const f32x4* src = reinterpret_cast<const f32x4*>(args.small);
+  const int npass0 = args.seg[0].npass;
+  int cur = (int)blockIdx.x >= npass0 ? 1 : 0;
+  auto load_small = [&](const float* small) {
+    const f32x4* src = reinterpret_cast<const f32x4*>(small);
     f32x4* dst = reinterpret_cast<f32x4*>(sm);
-    for (int i = tid; i < kSmallFloats / 4; i += 256) dst[i] = src[i];
-  }
+    for (int i = threadIdx.x; i < kSmallFloats / 4; i += 256) dst[i] = src[i];
+  };
+  load_small(args.seg[cur].small);
   Pipe p;
-  pipe_init<BwdNet>(p, args.packed_bwd, smem, wave, lane);  // also publishes the small block just written to LDS
+  pipe_init<BwdNet>(p, args.seg[cur].packed_bwd, smem, wave, lane);  // also publishes the small block just written to LDS
 
-  for (int pass = blockIdx.x; pass < args.npass; pass += gridDim.x) {
-    const int64_t col = (int64_t)pass * 128 + wave * 32 + m;
-    const PlaneIO io = make_plane_io(args.dplanes, kPlRows, (int64_t)pass * 4 + wave_s, m, h);
+  for (int gpass = blockIdx.x; gpass < args.npass_total; gpass += gridDim.x) {
+    const int si = gpass >= npass0 ? 1 : 0;
+    if (si != cur) {   // (workgroup-uniform, at most once per launch) the other level's head weights replace the resident block
+      __syncthreads();
+      load_small(args.seg[si].small);
+      __syncthreads();
+      cur = si;
+    }
+    const BwdSeg& sg = args.seg[si];
+    const int pass = gpass - (si ? npass0 : 0);
+    {
+      const int nxt = gpass + (int)gridDim.x;
+      p.stream = sg.packed_bwd;
+      p.next_stream = args.seg[(nxt >= npass0 && nxt < args.npass_total) ? 1 : si].packed_bwd;
+    }
+    // lane coordinates re-derived once per pass (v_mbcnt + the wave index in an SGPR) instead of kept across the pass loop, as in
+    // art_bwd_chain_kernel: with the segment bookkeeping added in round 4 the loop-invariant per-lane values were otherwise spilled
+    int lane_p;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_p));
+    const int tid = (wave_s << 6) | lane_p;
+    const int m = lane_p & 31, h = lane_p >> 5;
+    const int64_t col = (int64_t)pass * 128 + wave_s * 32 + m;
+    const PlaneIO io = make_plane_io(sg.dplanes, kPlRows, (int64_t)pass * 4 + wave_s, m, h);
     // The 16-byte decision-bit word of a layer is fetched ONE layer ahead of its use (round 1 fetched all nine up front:
     // 36 registers held through the whole pass).  The offset is made opaque at the point of use so the load stays there.
     const unsigned moff = mask_lane_off(pass, tid);
-    auto load_mask = [&](int layer) { return *mask_ptr(args.masks, args.Np, layer, moff); };
-    const float4 dr = reinterpret_cast<const float4*>(args.d_raw)[col];
+    auto load_mask = [&](int layer) { return *mask_ptr(sg.masks, sg.Np, layer, moff); };
+    const float4 dr = reinterpret_cast<const float4*>(sg.d_raw)[col];
     // half-wave index as the LDS reads below see it: opaque per pass, otherwise every head-weight address (the small block
     // sits beyond the 64 KiB immediate-offset range of the ring) is hoisted out of the pass loop into its own register
     int hl = h;
@@ -314,19 +341,31 @@ hipError_t launch_pack_vanilla_bwd(const float* const* params, float* packed, hi
 
 int64_t bwd_stream_bytes() { return kBwStreamBytes; }
 
-hipError_t launch_mlp_bwd_chain(const char* packed_bwd, const char* packed_fwd, const float* d_raw, const void* masks,
-                                float* dplanes, int64_t Np, hipStream_t stream) {
+hipError_t launch_mlp_bwd_chain2(const ChainSeg* segs, int nsegs, hipStream_t stream) {
   static DeviceOnce lds_once;
   constexpr int lds = kRingBytes + (int)kSmallBytes;
+  if (nsegs < 1 || nsegs > 2) return hipErrorInvalidValue;
   if (hipError_t e = set_max_lds(&mlp_bwd_chain_kernel, lds, lds_once); e != hipSuccess) return e;
-  BwdArgs a{packed_bwd, reinterpret_cast<const float*>(packed_fwd + kStreamBytes), d_raw, static_cast<const u32x4*>(masks), dplanes, Np,
-            (int)(Np / 128)};
+  BwdArgs a{};
+  for (int i = 0; i < nsegs; ++i) {
+    const ChainSeg& c = segs[i];
+    a.seg[i] = BwdSeg{c.packed_bwd, c.small, c.d_raw, static_cast<const u32x4*>(c.masks), c.dplanes, c.Np, (int)(c.Np / 128)};
+    a.npass_total += a.seg[i].npass;
+  }
+  if (nsegs == 1) { a.seg[1] = a.seg[0]; a.seg[1].npass = 0; }
+  else if (a.seg[0].npass == 0) { a.seg[0] = a.seg[1]; a.seg[1].npass = 0; }
   const int cus = num_cus();
   if (cus <= 0) return hipErrorInvalidDevice;
-  const int grid = a.npass < cus ? a.npass : cus;
+  const int grid = a.npass_total < cus ? a.npass_total : cus;
   if (grid <= 0) return hipSuccess;
   mlp_bwd_chain_kernel<<<dim3(grid), dim3(256), lds, stream>>>(a);
   return hipGetLastError();
+}
+
+hipError_t launch_mlp_bwd_chain(const char* packed_bwd, const char* packed_fwd, const float* d_raw, const void* masks,
+                                float* dplanes, int64_t Np, hipStream_t stream) {
+  const ChainSeg one{packed_bwd, reinterpret_cast<const float*>(packed_fwd + kStreamBytes), d_raw, masks, nullptr, dplanes, nullptr, Np};
+  return launch_mlp_bwd_chain2(&one, 1, stream);
 }
 
 int64_t wgrad_workspace_bytes() { return wgrad_workspace_bytes_impl(); }
@@ -437,7 +476,8 @@ hipError_t launch_vanilla_wgrad(const float* planes, const float* dplanes, const
 int art_wgrad_layers(float* const* grads, WgLayerDesc* L);   // aon_train_art.hip
 
 // Host-only view of the plan a level would run on `cus` compute units (tests/test_abi_cpu.py checks its invariants without a
-// GPU): per job (kind, wg_begin, wg_count, steps per workgroup, partial offset in floats, partial count).
+// GPU): per job (kind, first workgroup, workgroups that own a step of it, steps of the job, partial offset in floats, partial count);
+// `line`: {W, G} of the work line.
 int wgrad_plan_describe(bool art, int64_t Np, int cus, int32_t* out6, int max_jobs, int64_t* ws_bytes) {
   if (Np <= 0 || (Np & 31) || cus < 1) return -1;
   float* grads[40];   // >= both parameter counts (24 vanilla, 40 articulated)
@@ -449,12 +489,34 @@ int wgrad_plan_describe(bool art, int64_t Np, int cus, int32_t* out6, int max_jo
   if (n > max_jobs) return -3;
   for (int j = 0; j < n; ++j) {
     const WgJob& J = plan.args.job[j];
-    const int per = (plan.args.nsteps + J.wg_count - 1) / J.wg_count;
     int32_t* o = out6 + 6 * j;
-    o[0] = J.kind; o[1] = J.wg_begin; o[2] = J.wg_count; o[3] = per; o[4] = J.part_off; o[5] = J.wg_count * wg_nsplit(J.kind);
+    o[0] = J.kind; o[1] = J.first_wg; o[2] = J.last_wg - J.first_wg + 1; o[3] = plan.args.nsteps; o[4] = J.part_off;
+    o[5] = (J.last_wg - J.first_wg + 1) * wg_nsplit(J.kind);
   }
   if (ws_bytes) *ws_bytes = plan.ws_floats * 4;
   return n;
+}
+
+// the steps [begin, end) of job j that workgroup wg owns under the plan above (host restatement of the kernel's arithmetic: tests)
+int wgrad_plan_segment(bool art, int64_t Np, int cus, int j, int wg, int32_t* begin_end) {
+  if (Np <= 0 || (Np & 31) || cus < 1) return -1;
+  float* grads[40];
+  for (int i = 0; i < 40; ++i) grads[i] = reinterpret_cast<float*>((uintptr_t)0x1000 + 64 * i);
+  WgLayerDesc L[kWgMaxJobs];
+  const int n = art ? art_wgrad_layers(grads, L) : vanilla_wgrad_layers(grads, L);
+  WgPlan plan;
+  if (!wg_make_plan(L, n, nullptr, nullptr, art ? kAPlRows : kPlRows, Np, cus < 304 ? cus : 304, nullptr, 0, plan)) return -2;
+  if (j < 0 || j >= n || wg < 0 || wg >= plan.total_wgs) return -3;
+  const WgArgs& A = plan.args;
+  const WgJob& J = A.job[j];
+  auto first_step = [&](int64_t x) {
+    const int64_t d = x - J.p_begin;
+    if (d <= 0) return 0;
+    const int64_t q = (d + J.cost - 1) / J.cost;
+    return q < A.nsteps ? (int)q : A.nsteps;
+  };
+  begin_end[0] = first_step(A.w_total * wg / A.nwgs); begin_end[1] = first_step(A.w_total * (wg + 1) / A.nwgs);
+  return (wg >= J.first_wg && wg <= J.last_wg) ? 1 : 0;
 }
 
 }  // namespace aon

@@ -69,7 +69,10 @@ __global__ void pack_art_bwd_kernel(ArtParams a, float* __restrict__ packed) {
   packed[idx] = col >= 0 ? W[(int64_t)j * ld + col] : 0.f;
 }
 
-struct ArtBwdArgs {
+// One SEGMENT of a chain launch: the passes of one level (its transposed stream, small block, decision bits, planes).  Round 4: the
+// backward chains of the two levels of a training step are independent, so they run as ONE persistent launch of two segments --
+// 8,256 passes = 33 rounds of 256 workgroups at 4096 x (65 + 193) samples where two launches cost 9 + 25.
+struct ArtBwdSeg {
   const char* packed_bwd;
   const float* small;     // forward per-call small block (head weights)
   const float* d_raw;     // (Np,4)
@@ -79,6 +82,10 @@ struct ArtBwdArgs {
   float* dxp;             // (Np,4): d x' per sample (for deformation_layer's weight gradient)
   int64_t Np;
   int npass;
+};
+struct ArtBwdArgs {
+  ArtBwdSeg seg[2];
+  int npass_total;        // seg[1].npass == 0: a one-segment launch
 };
 
 template <int NT>
@@ -94,17 +101,34 @@ __global__ void __launch_bounds__(256) art_bwd_chain_kernel(ArtBwdArgs args) {
   float* sm = reinterpret_cast<float*>(smem + kRingBytes);
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
-  {
-    const f32x4* src = reinterpret_cast<const f32x4*>(args.small);
+  const int npass0 = args.seg[0].npass;
+  int cur = (int)blockIdx.x >= npass0 ? 1 : 0;
+  auto load_small = [&](const float* small) {
+    const f32x4* src = reinterpret_cast<const f32x4*>(small);
     f32x4* dst = reinterpret_cast<f32x4*>(sm);
     for (int i = tid; i < kASmallFloats / 4; i += 256) dst[i] = src[i];
-  }
+  };
+  load_small(args.seg[cur].small);
   Pipe p;
-  pipe_init<ArtBwdNet>(p, args.packed_bwd, smem, wave, lane);  // also publishes the small block just written to LDS
+  pipe_init<ArtBwdNet>(p, args.seg[cur].packed_bwd, smem, wave, lane);  // also publishes the small block just written to LDS
   using N = ArtBwdNet;
   const int wave_s = __builtin_amdgcn_readfirstlane(wave);
 
-  for (int pass = blockIdx.x; pass < args.npass; pass += gridDim.x) {
+  for (int gpass = blockIdx.x; gpass < args.npass_total; gpass += gridDim.x) {
+    const int si = gpass >= npass0 ? 1 : 0;
+    if (si != cur) {   // (workgroup-uniform, at most once per launch) the other level's head weights replace the resident block
+      __syncthreads();
+      load_small(args.seg[si].small);
+      __syncthreads();
+      cur = si;
+    }
+    const ArtBwdSeg& sg = args.seg[si];
+    const int pass = gpass - (si ? npass0 : 0);
+    {   // transposed stream of this pass, and of this workgroup's next one (its first chunk pair is fetched by this pass's last two chunks)
+      const int nxt = gpass + (int)gridDim.x;
+      p.stream = sg.packed_bwd;
+      p.next_stream = args.seg[(nxt >= npass0 && nxt < args.npass_total) ? 1 : si].packed_bwd;
+    }
     // Lane coordinates are RE-DERIVED once per pass (v_mbcnt + the wave index in an SGPR) instead of kept: with all 256 + 256
     // registers taken by the two activation sets, every loop-invariant per-lane value -- the thread id itself, lane ^ 32, the
     // 64-bit row offset built from it -- was hoisted out of the pass loop and spilled (24 B/lane of scratch).
@@ -114,14 +138,14 @@ __global__ void __launch_bounds__(256) art_bwd_chain_kernel(ArtBwdArgs args) {
     const int m = lane_p & 31, h = lane_p >> 5;
     const int64_t col = (int64_t)pass * 128 + (tid_p >> 6) * 32 + m;
     const int64_t step = (int64_t)pass * 4 + wave_s;
-    const PlaneIO io = make_plane_io(args.dplanes, kAPlRows, step, m, h);
+    const PlaneIO io = make_plane_io(sg.dplanes, kAPlRows, step, m, h);
     // decision bits of a layer: fetched one layer ahead of their use, offset opaque so the load stays where it is written
     // (round 1 fetched all sixteen words up front: 64 registers held through the pass)
     const unsigned moff = mask_lane_off(pass, tid_p);
-    auto load_mask = [&](int slot) { return *mask_ptr(args.masks, args.Np, slot, moff); };
+    auto load_mask = [&](int slot) { return *mask_ptr(sg.masks, sg.Np, slot, moff); };
     int hl = h;  // half-wave index for the LDS reads of head weights: opaque per pass (see mlp_bwd_chain_kernel)
     asm volatile("" : "+v"(hl));
-    const float4 dr = reinterpret_cast<const float4*>(args.d_raw)[col];
+    const float4 dr = reinterpret_cast<const float4*>(sg.d_raw)[col];
     u32x4 mk = load_mask(15), mk_next;
 
     // ---- view branch, backwards (model_autodecoder.py:231-236) ----
@@ -159,7 +183,7 @@ __global__ void __launch_bounds__(256) art_bwd_chain_kernel(ArtBwdArgs args) {
       asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
       return (int64_t)pass * 128 + wave_s * 32 + (l & 31);
     };
-    const float dsig = args.d_raw[sample_now() * 4 + 3];   // re-read here (L2-hot) instead of carried through the view branch
+    const float dsig = sg.d_raw[sample_now() * 4 + 3];   // re-read here (L2-hot) instead of carried through the view branch
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
 #pragma unroll
@@ -197,7 +221,7 @@ __global__ void __launch_bounds__(256) art_bwd_chain_kernel(ArtBwdArgs args) {
 
     // ---- positional encoding, backwards (helper.py:136-140 on the deformed point) ----
     float xd[3];  // deformed position x' (forward stored it in rows 3..5 of the position block)
-    const PlaneIO fio = make_plane_io(args.planes, kAPlRows, step, m, h);
+    const PlaneIO fio = make_plane_io(sg.planes, kAPlRows, step, m, h);
 #pragma unroll
     for (int a = 0; a < 3; ++a)
       xd[a] = *row_ptr(fio, kAPlPos + 3 + a);
@@ -216,7 +240,7 @@ __global__ void __launch_bounds__(256) art_bwd_chain_kernel(ArtBwdArgs args) {
       dx[a] = dx[a] + __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((lane_p ^ 32) << 2, __builtin_bit_cast(int, dx[a])));
     if (h == 0) {
       float4 o; o.x = dx[0]; o.y = dx[1]; o.z = dx[2]; o.w = 0.f;
-      reinterpret_cast<float4*>(args.dxp)[sample_now()] = o;
+      reinterpret_cast<float4*>(sg.dxp)[sample_now()] = o;
     }
 
     // ---- deformation MLP, backwards (x' = deformation_layer(h3) + pos, :200-205) ----
@@ -317,17 +341,30 @@ hipError_t launch_pack_art_bwd(const float* const* params, float* packed, hipStr
 
 int64_t art_bwd_stream_bytes() { return kABwStreamBytes; }
 
-hipError_t launch_art_bwd_chain(const char* packed_bwd, const float* small, const float* d_raw, const void* masks, const float* planes,
-                                float* dplanes, float* dxp, int64_t Np, hipStream_t stream) {
+hipError_t launch_art_bwd_chain2(const ChainSeg* segs, int nsegs, hipStream_t stream) {
   static DeviceOnce lds_once;
+  if (nsegs < 1 || nsegs > 2) return hipErrorInvalidValue;
   if (hipError_t e = set_max_lds(&art_bwd_chain_kernel, kALdsBytes, lds_once); e != hipSuccess) return e;
-  ArtBwdArgs a{packed_bwd, small, d_raw, static_cast<const u32x4*>(masks), planes, dplanes, dxp, Np, (int)(Np / 128)};
+  ArtBwdArgs a{};
+  for (int i = 0; i < nsegs; ++i) {
+    const ChainSeg& c = segs[i];
+    a.seg[i] = ArtBwdSeg{c.packed_bwd, c.small, c.d_raw, static_cast<const u32x4*>(c.masks), c.planes, c.dplanes, c.dxp, c.Np, (int)(c.Np / 128)};
+    a.npass_total += a.seg[i].npass;
+  }
+  if (nsegs == 1) { a.seg[1] = a.seg[0]; a.seg[1].npass = 0; }
+  else if (a.seg[0].npass == 0) { a.seg[0] = a.seg[1]; a.seg[1].npass = 0; }
   const int cus = num_cus();
   if (cus <= 0) return hipErrorInvalidDevice;
-  const int grid = a.npass < cus ? a.npass : cus;
+  const int grid = a.npass_total < cus ? a.npass_total : cus;
   if (grid <= 0) return hipSuccess;
   art_bwd_chain_kernel<<<dim3(grid), dim3(256), kALdsBytes, stream>>>(a);
   return hipGetLastError();
+}
+
+hipError_t launch_art_bwd_chain(const char* packed_bwd, const float* small, const float* d_raw, const void* masks, const float* planes,
+                                float* dplanes, float* dxp, int64_t Np, hipStream_t stream) {
+  const ChainSeg one{packed_bwd, small, d_raw, masks, planes, dplanes, dxp, Np};
+  return launch_art_bwd_chain2(&one, 1, stream);
 }
 
 hipError_t run_wgrad_plan(const WgLayerDesc* layers, int nlayers, const HeadDesc* heads, int nheads, const HeadOut* outs, const int* out_head, int nouts,

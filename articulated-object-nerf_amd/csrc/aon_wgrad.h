@@ -42,13 +42,20 @@ __device__ __forceinline__ float wsum64(float v) {
 // hipcc shuttle tiles between AGPRs and VGPRs around every MFMA group (160 v_accvgpr moves per 20 MFMAs, 0.60 of peak).
 enum : int { kWg256x256 = 0, kWg128x128 = 1, kWg256x64 = 2, kWg128x256 = 3, kWg128x32 = 4, kWgNumKinds = 5 };
 
+// Round 4: the steps of ALL jobs of a launch form one work line, priced in cost units (steps x wg_cost(kind)); workgroup i of G owns
+// the steps whose START falls into [W i / G, W (i + 1) / G).  A workgroup therefore runs the tail of one layer's range and the head
+// of the next (two or three segments, one partial each) and every workgroup carries the same cost -- round 3 gave each layer a
+// whole number of workgroups (a 256 x 256 layer 23 or 24 of 256, a 128 x 128 one 6 or 7), and the launch lasted as long as the
+// layer whose rounding came out worst (tools/kernel_bench.py --wgrad-probe: profiles/r04_wgrad_probe.txt).
 struct WgJob {
   int a_unit;      // first unit row (plane row / 4) of dZ in the gradient planes
   int b_unit;      // first unit row of the layer input in the forward planes
   int kind;
-  int wg_begin, wg_count;   // workgroups [wg_begin, wg_begin + wg_count) split the steps of this layer
-  int part_off;    // float offset in the workspace of partial[wg_count * nsplit][M][K]
-  int bias_off;    // float offset of bias_partial[wg_count * nsplit][M], or -1
+  int cost;        // wg_cost(kind), integer cost units per step
+  int first_wg, last_wg;    // workgroups that own a step of this job (each writes nsplit partials, indexed from first_wg)
+  int part_off;    // float offset in the workspace of partial[(last_wg - first_wg + 1) * nsplit][M][K]
+  int bias_off;    // float offset of bias_partial[... * nsplit][M], or -1
+  int64_t p_begin; // position of step 0 on the work line
 };
 
 // second stage: out[row * ld + col_off + col] = sum_p partial[p][row][col]  (col < k_valid);  bias_out[row] = sum_p bias_partial[p][row]
@@ -70,6 +77,8 @@ struct WgArgs {
   int64_t step_bytes;   // rows * 128
   int nsteps;           // Np / 32
   int njobs;
+  int nwgs;             // G
+  int64_t w_total;      // W: sum over jobs of nsteps * cost
   float* ws;
   long long* probe;     // measurement aid (aon_set_wgrad_probe): [2 * workgroup] = wall_clock64() at entry / exit, or null
   WgJob job[kWgMaxJobs];
@@ -102,7 +111,7 @@ __device__ __forceinline__ void stage_barrier() {
 }
 
 template <int KIND>
-__device__ __forceinline__ void wgrad_job(const WgArgs& a, const WgJob& J, char* smem) {
+__device__ __forceinline__ void wgrad_job(const WgArgs& a, const WgJob& J, const int c_begin, const int c_end, const int part_wg, char* smem) {
   using T = WgTraits<KIND>;
   constexpr int NB = T::NB, NSTAGE = T::NSTAGE, NSPLIT = T::NSPLIT;
   constexpr int STAGE = wg_stage_bytes<KIND>();
@@ -120,12 +129,8 @@ __device__ __forceinline__ void wgrad_job(const WgArgs& a, const WgJob& J, char*
   const int i = lane & 31, kh = lane >> 5;
   const int wb = wave % T::NBB, wa = (wave / T::NBB) % T::NAB, split = wave / (T::NBB * T::NAB);
 
-  // steps of this workgroup
-  const int part_wg = (int)blockIdx.x - J.wg_begin;
-  const int per = (a.nsteps + J.wg_count - 1) / J.wg_count;
-  const int c_begin = part_wg * per;
-  const int c_end = c_begin + per < a.nsteps ? c_begin + per : a.nsteps;
-  const int c_last = c_end - 1;   // (c_end > c_begin is guaranteed by the host: wg_count <= nsteps)
+  // steps [c_begin, c_end) of this job belong to this workgroup (empty only in tiny problems: then the partial is zeros)
+  const int c_last = c_end - 1;
 
   f32x16 acc[4][NB];
 #pragma unroll
@@ -185,6 +190,7 @@ __device__ __forceinline__ void wgrad_job(const WgArgs& a, const WgJob& J, char*
     return f;
   };
 
+  if (c_end > c_begin) {
   // prologue: NSTAGE - 1 steps in flight, the first one landed
 #pragma unroll
   for (int s = 0; s < NSTAGE - 1; ++s)
@@ -238,6 +244,7 @@ __device__ __forceinline__ void wgrad_job(const WgArgs& a, const WgJob& J, char*
     stage = stage_next;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clamped look-ahead DMAs must land before the LDS is released
+  }
 
   // ---- partials ----
   // accumulator (ca, cb), register r, lane (n, hh): row 4 (32 wa + (r&3) + 8 (r>>2) + 4 hh) + ca, column 128 wb + 4 n + cb
@@ -267,23 +274,37 @@ __device__ __forceinline__ void wgrad_job(const WgArgs& a, const WgJob& J, char*
   }
 }
 
+__device__ __forceinline__ int wg_first_step(int64_t x, int64_t p_begin, int cost, int nsteps) {
+  // number of steps of the job whose start lies below x on the work line: ceil((x - p_begin) / cost), clamped to [0, nsteps]
+  const int64_t d = x - p_begin;
+  if (d <= 0) return 0;
+  const int64_t q = (d + cost - 1) / cost;
+  return q < nsteps ? (int)q : nsteps;
+}
+
 __global__ void __launch_bounds__(256) wgrad_grouped_kernel(WgArgs a) {
   extern __shared__ __attribute__((aligned(1024))) char wg_smem[];
-  int j = 0;
+  const int wg = (int)blockIdx.x;
+  if (a.probe && threadIdx.x == 0) a.probe[2 * wg] = wall_clock64();
+  const int64_t lo = a.w_total * wg / a.nwgs, hi = a.w_total * (wg + 1) / a.nwgs;
+  bool ran = false;
 #pragma unroll 1
-  for (int t = 1; t < a.njobs; ++t)
-    if ((int)blockIdx.x >= a.job[t].wg_begin) j = t;
-  j = __builtin_amdgcn_readfirstlane(j);
-  const WgJob& J = a.job[j];
-  if (a.probe && threadIdx.x == 0) a.probe[2 * blockIdx.x] = wall_clock64();
-  switch (J.kind) {
-    case kWg256x256: wgrad_job<kWg256x256>(a, J, wg_smem); break;
-    case kWg128x128: wgrad_job<kWg128x128>(a, J, wg_smem); break;
-    case kWg256x64: wgrad_job<kWg256x64>(a, J, wg_smem); break;
-    case kWg128x256: wgrad_job<kWg128x256>(a, J, wg_smem); break;
-    default: wgrad_job<kWg128x32>(a, J, wg_smem); break;
+  for (int j = 0; j < a.njobs; ++j) {
+    const WgJob& J = a.job[j];
+    if (wg < J.first_wg || wg > J.last_wg) continue;   // (workgroup-uniform)
+    const int c_begin = wg_first_step(lo, J.p_begin, J.cost, a.nsteps), c_end = wg_first_step(hi, J.p_begin, J.cost, a.nsteps);
+    if (ran) __syncthreads();   // the previous segment's last fragment reads are done in every wave before its stages are refilled
+    ran = true;
+    const int part_wg = wg - J.first_wg;
+    switch (J.kind) {
+      case kWg256x256: wgrad_job<kWg256x256>(a, J, c_begin, c_end, part_wg, wg_smem); break;
+      case kWg128x128: wgrad_job<kWg128x128>(a, J, c_begin, c_end, part_wg, wg_smem); break;
+      case kWg256x64: wgrad_job<kWg256x64>(a, J, c_begin, c_end, part_wg, wg_smem); break;
+      case kWg128x256: wgrad_job<kWg128x256>(a, J, c_begin, c_end, part_wg, wg_smem); break;
+      default: wgrad_job<kWg128x32>(a, J, c_begin, c_end, part_wg, wg_smem); break;
+    }
   }
-  if (a.probe && threadIdx.x == 0) a.probe[2 * blockIdx.x + 1] = wall_clock64();
+  if (a.probe && threadIdx.x == 0) a.probe[2 * wg + 1] = wall_clock64();
 }
 
 #endif  // AON_WGRAD_KERNELS
@@ -476,17 +497,20 @@ struct WgLayerDesc {   // one nn.Linear weight (or a column block of one)
   float* bias_out;     // or null
 };
 
-// relative cost of one step of a job: 16,384 matrix-pipe cycles for a 256 x 256 job, the others scaled by their MEASURED time per
+// cost of one step of a job (integer units): 16,384 matrix-pipe cycles for a 256 x 256 job, the others scaled by their time per step
+// MEASURED INSIDE THE MIXED LAUNCH with the workgroup clock probe (tools/kernel_bench.py --wgrad-probe, round 4, articulated level of
+// 4096 x 193 / x 65 samples: 7.70 / 8.76 us per 256x256 step, the other kinds 0.261 / 0.260, 0.282 / 0.281, 0.507 / 0.508, 0.093 /
+// 0.092 of it).  Round 3 priced them from whole-chip runs of one kind (0.275, 0.299, 0.52, 0.11):
 // step and workgroup with the whole chip running one kind (tools/kernel_bench.py --wgrad-kinds, 4096 x 193 samples, two boxes:
 // 128x128 0.274-0.276, 256x64 0.298-0.301, 128x256 0.51-0.53, 128x32 0.107-0.108 of a 256x256 job).  The narrow kinds are bound
 // by operand traffic per flop (3.9-6.3 TB/s when they run alone), not by the pipe.
-inline double wg_cost(int kind) {
+inline int wg_cost(int kind) {
   switch (kind) {
-    case kWg256x256: return 16384.0;
-    case kWg128x128: return 4500.0;
-    case kWg256x64: return 4900.0;
-    case kWg128x256: return 8500.0;
-    default: return 1800.0;   // kWg128x32: 1,024 matrix-pipe cycles per step, but 20 KB of operands -- DMA-bound
+    case kWg256x256: return 16384;
+    case kWg128x128: return 4280;
+    case kWg256x64: return 4620;
+    case kWg128x256: return 8300;
+    default: return 1510;   // kWg128x32: 1,024 matrix-pipe cycles per step, but 20 KB of operands -- DMA-bound
   }
 }
 
@@ -497,53 +521,43 @@ struct WgPlan {
   int64_t ws_floats;   // workspace floats used by the partials (heads are appended behind by the caller)
 };
 
-// Split the workgroups of one launch (<= cus, all co-resident: ONE round) over the layers in proportion to their cost:
-// the smallest makespan T with sum ceil(cost_l / T) <= cus.
+// workgroup that owns position x of the work line: the i with floor(W i / G) <= x < floor(W (i + 1) / G)
+inline int wg_owner(int64_t x, int64_t W, int G) {
+  int i = (int)((x * G) / W);
+  if (i >= G) i = G - 1;
+  while (i + 1 < G && W * (i + 1) / G <= x) ++i;
+  while (i > 0 && W * i / G > x) --i;
+  return i;
+}
+
+// One launch of G <= cus workgroups (all co-resident: ONE round), every workgroup the same share of the work line.
 inline bool wg_make_plan(const WgLayerDesc* layers, int nlayers, const float* planes, const float* dplanes, int rows_total, int64_t Np,
                          int cus, float* ws, int64_t ws_off, WgPlan& plan) {
-  if (nlayers > kWgMaxJobs || cus < nlayers) return false;
+  if (nlayers > kWgMaxJobs || nlayers < 1 || cus < 1) return false;
   const int nsteps = (int)(Np / 32);
-  double lo = 0.0, hi = 0.0;
-  for (int l = 0; l < nlayers; ++l) hi += wg_cost(layers[l].kind);
-  auto count = [&](double T, int* out) {
-    int tot = 0;
-    for (int l = 0; l < nlayers; ++l) {
-      int w = (int)(wg_cost(layers[l].kind) / T);
-      if (w * T < wg_cost(layers[l].kind)) ++w;
-      if (w < 1) w = 1;
-      if (w > nsteps) w = nsteps;
-      if (out) out[l] = w;
-      tot += w;
-    }
-    return tot;
-  };
-  lo = hi / cus * 0.5;   // below the ideal makespan: infeasible
-  for (int it = 0; it < 60; ++it) {
-    const double mid = 0.5 * (lo + hi);
-    if (count(mid, nullptr) <= cus) hi = mid; else lo = mid;
-  }
-  int wgs[kWgMaxJobs];
-  plan.total_wgs = count(hi, wgs);
-  if (plan.total_wgs > cus) return false;
+  if (nsteps < 1) return false;
   WgArgs& A = plan.args;
   A.dplanes = dplanes; A.planes = planes; A.step_bytes = (int64_t)rows_total * 128; A.nsteps = nsteps; A.njobs = nlayers; A.ws = ws;
   A.probe = nullptr;
+  int64_t W = 0;
+  for (int l = 0; l < nlayers; ++l) { A.job[l].p_begin = W; W += (int64_t)nsteps * wg_cost(layers[l].kind); }
+  // never more workgroups than steps on the line (tiny problems), never more than the compute units
+  const int64_t total_steps = (int64_t)nsteps * nlayers;
+  int G = cus;
+  if (G > total_steps) G = (int)total_steps;
+  A.nwgs = G; A.w_total = W;
   ReduceArgs& R = plan.red;
   R.nred = 0; R.ws = ws;
   int64_t off = ws_off;
-  int wg = 0, blk = 0;
+  int blk = 0;
   for (int l = 0; l < nlayers; ++l) {
     const WgLayerDesc& L = layers[l];
     WgJob& J = A.job[l];
     const int M = wg_M(L.kind), K = wg_K(L.kind), nsplit = wg_nsplit(L.kind);
-    J.a_unit = L.a_row / 4; J.b_unit = L.b_row / 4; J.kind = L.kind; J.wg_begin = wg; J.wg_count = wgs[l];
-    // steps per workgroup are ceil(nsteps / count): trailing workgroups of a short range would start past the end -- shrink
-    {
-      const int per = (nsteps + J.wg_count - 1) / J.wg_count;
-      J.wg_count = (nsteps + per - 1) / per;
-    }
-    wg += J.wg_count;
-    const int nparts = J.wg_count * nsplit;
+    J.a_unit = L.a_row / 4; J.b_unit = L.b_row / 4; J.kind = L.kind; J.cost = wg_cost(L.kind);
+    J.first_wg = wg_owner(J.p_begin, W, G);
+    J.last_wg = wg_owner(J.p_begin + (int64_t)(nsteps - 1) * J.cost, W, G);
+    const int nparts = (J.last_wg - J.first_wg + 1) * nsplit;
     J.part_off = (int)off; off += (int64_t)nparts * M * K;
     J.bias_off = -1;
     if (L.bias_out) { J.bias_off = (int)off; off += (int64_t)nparts * M; }
@@ -553,7 +567,7 @@ inline bool wg_make_plan(const WgLayerDesc* layers, int nlayers, const float* pl
     E.bias_off = J.bias_off; E.out = L.out; E.bias_out = L.bias_out;
     E.blk_begin = blk; E.nblk_w = (M * K / 4 + 63) / 64; blk += E.nblk_w + (L.bias_out ? (M + 15) / 16 : 0);
   }
-  plan.total_wgs = wg;
+  plan.total_wgs = G;
   plan.reduce_blocks = blk;
   plan.ws_floats = off;
   return off < (int64_t)1 << 31;

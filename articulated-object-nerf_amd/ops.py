@@ -754,6 +754,11 @@ def set_fwd_overlap(on: bool) -> None:
     check(lib.aon_set_fwd_overlap(int(bool(on))), "aon_set_fwd_overlap")
 
 
+def set_bwd_merge(on: bool) -> None:
+    """Backward chains of the two levels as ONE persistent launch of two segments (default on; off: one launch per level, round 3)."""
+    check(lib.aon_set_bwd_merge(int(bool(on))), "aon_set_bwd_merge")
+
+
 def set_fwd_merge(on: bool) -> None:
     """Training forward of two levels as three persistent launches, coarse(A) | fine(A) + coarse(B) | fine(B) (default on; off: the
     forms of set_fwd_overlap)."""
@@ -956,9 +961,9 @@ def gmlp_fwd(geom: MlpGeometry, params: dict, samples_enc, viewdirs_enc):
 
 # Workspace of the layer-wise engine's inference call: its activations live in HBM (~ (P + 3 W + 2 Wc) * 4 B per sample) and the C side
 # chunks over rays to whatever workspace it is given, so the chunk is sized from a BYTE budget (round 3: a fixed 8,192 rays = ~7 GB
-# at 256-wide networks, far more at the widths make_gg accepts, cached per device until release_workspaces(): ADVICE r3).  At 1 GB
-# the default-width network gets ~1,200-ray chunks of 193 samples = 230 k-row GEMMs: still hundreds of 128-row tiles per launch.
-G_WS_BUDGET_BYTES = 1 << 30
+# at 256-wide networks, far more at the widths make_gg accepts, cached per device until release_workspaces(): ADVICE r3).  At 2 GB
+# the default-width network gets ~2,400-ray chunks of 193 samples = 460 k-row GEMMs: still hundreds of 128-row tiles per launch.
+G_WS_BUDGET_BYTES = 2 << 30
 G_CHUNK_RAYS = 8192            # upper bound on rays per chunk
 _GWS_CACHE: dict = {}
 
@@ -1053,7 +1058,7 @@ def grender_bwd(geom: MlpGeometry, ws, params_per_level, rays_d, white_bkgd, num
 
 def release_workspaces() -> None:
     """Drop the per-device workspace caches of the inference calls (fused path: up to 1.35 GB, or 3.3 GB with materialised
-    encodings; layer-wise engine: G_WS_BUDGET_BYTES = 1 GB) back to torch's caching allocator.  They are re-made on the
+    encodings; layer-wise engine: G_WS_BUDGET_BYTES = 2 GB) back to torch's caching allocator.  They are re-made on the
     next call; training workspaces are never cached (they belong to the autograd graph)."""
     _WS_CACHE.clear()
     _GWS_CACHE.clear()

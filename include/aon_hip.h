@@ -181,7 +181,8 @@ int aon_art_render_fwd(const void* packed_coarse, const void* small_coarse, cons
  *                       feature rows of one sample, the kernels store / fetch whole units (csrc/aon_mlp_core.h); and the
  *                       ReLU decisions of the nine activated layers as bit masks (aon_train_mask_bytes(Np) bytes).
  *   aon_composite_bwd   (g_rgb (n,3), optional g_acc (n,), g_depth (n,)) -> d_raw (n*S,4) = dL/d(raw rgb, raw sigma);
- *                       the caller zero-fills d_raw up to Np rows (padded samples must carry zero gradient).
+ *                       the caller zero-fills d_raw up to Np rows (padded samples must carry zero gradient); S <= 512; evaluated
+ *                       in fp64 on the fp32 inputs, every output rounded once.
  *   aon_mlp_bwd_chain   data-gradient chain through the MLP (ReLU derivatives from `masks`); writes the pre-activation
  *                       gradient planes `dplanes` (same layout / row map as `planes`, every sample written); needs the
  *                       transposed stream of aon_pack_vanilla_mlp_bwd.
@@ -201,15 +202,21 @@ int aon_mlp_bwd_chain(const void* packed_bwd, const void* packed_fwd, const floa
                       float* dplanes, int64_t Np, void* stream);
 int aon_vanilla_wgrad(const float* planes, const float* dplanes, const float* d_raw, int64_t Np,
                       float* const* grads_host, void* workspace, int64_t workspace_bytes, void* stream);
-/* Host-only: the plan aon_vanilla_wgrad / aon_art_wgrad would run for a level of Np samples on `cus` compute units -- per job six
- * ints (kind, first workgroup, workgroups, 32-sample steps per workgroup, partial offset in floats, partials) -- and the workspace
- * bytes it uses.  Returns the number of jobs (<= max_jobs) or a negative status.  No GPU needed (tests). */
+/* Host-only: the plan aon_vanilla_wgrad / aon_art_wgrad would run for a level of Np samples on `cus` compute units.  Round 4: the
+ * steps of all jobs form one work line priced in cost units, and each of the G = min(cus, 304, steps) workgroups owns the steps that
+ * start in its 1/G of the line (csrc/aon_wgrad.h), so a workgroup runs up to a few segments of consecutive jobs.  Per job six ints:
+ * kind, first workgroup owning a step of it, number of such workgroups, steps of the job (Np / 32), partial offset in floats,
+ * partials.  Returns the number of jobs (<= max_jobs) or a negative status; `ws_bytes` = workspace bytes used.  No GPU needed (tests). */
 int aon_wgrad_plan(int articulated, int64_t Np, int cus, int32_t* jobs6, int max_jobs, int64_t* ws_bytes);
-/* Measurement aid: `nlayers` (<= 20) identical weight-gradient jobs of one kind (0: 256x256, 1: 128x128, 2: 256x64, 3: 128x256, 4: 128x32;
- * csrc/aon_wgrad.h) on arbitrary rows of two plane buffers, the grouped kernel only, partials left in the workspace. */
+/* Host-only: begin_end[0..1] = the steps [begin, end) of job `job` that workgroup `workgroup` owns under that plan (the kernel's own
+ * arithmetic restated on the host).  Returns 1 when the workgroup writes partials for the job (end may equal begin in tiny problems:
+ * a zero partial), 0 when it does not, negative on bad arguments. */
+int aon_wgrad_plan_segment(int articulated, int64_t Np, int cus, int job, int workgroup, int32_t* begin_end);
 /* Measurement aid: while a device buffer of >= 2 x 304 int64 is set, every grouped weight-gradient launch on any stream writes
  * [2 w] / [2 w + 1] = the 100 MHz wall clock at entry / exit of workgroup w (tools/kernel_bench.py --wgrad-probe); NULL = off. */
 int aon_set_wgrad_probe(void* device_buffer);
+/* Measurement aid: `nlayers` (<= 20) identical weight-gradient jobs of one kind (0: 256x256, 1: 128x128, 2: 256x64, 3: 128x256, 4: 128x32;
+ * csrc/aon_wgrad.h) on arbitrary rows of two plane buffers, the grouped kernel only, partials left in the workspace. */
 int aon_wgrad_kind_bench(int kind, int nlayers, const float* planes, const float* dplanes, int rows, int64_t Np, void* workspace,
                          int64_t workspace_bytes, void* stream);
 
@@ -263,6 +270,11 @@ int aon_set_fwd_overlap(int on);
  * the one-launch-per-level form.  aon_set_fwd_merge(0) falls back to aon_set_fwd_overlap's forms; 2 (tests) merges whenever the batch has
  * two 128-ray ranges, whether or not rounds are saved. */
 int aon_set_fwd_merge(int on);
+/* Round 4, default 1: the data-gradient chains of the two levels (independent of each other) run as ONE persistent launch of two
+ * segments on `stream` -- 8,256 passes = 33 rounds of 256 workgroups at 4096 x (65 + 193) samples where two launches cost 9 + 25 --
+ * followed by the two levels' weight gradients on the two library streams (aon_set_bwd_overlap).  Same bits.  0: one chain launch
+ * per level, each on its level's stream (round 3). */
+int aon_set_bwd_merge(int on);
 int64_t aon_train_workspace_bytes(int64_t n_rays, int articulated, int num_levels);
 int64_t aon_train_scratch_bytes(int64_t n_rays, int articulated, int num_levels);
 int aon_render_fwd_train(const void* packed_coarse, const void* packed_fine, const float* rays_o, const float* rays_d,

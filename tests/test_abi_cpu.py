@@ -118,46 +118,61 @@ def test_two_call_training_entries_validate_without_gpu():
 
 
 def test_wgrad_plan_invariants_without_gpu():
-    """The grouped weight-gradient launch's plan (csrc/aon_wgrad.h:wg_make_plan, host-only): for both networks, sample counts from
-    one pass to a 4096-ray fine level, and compute-unit counts from barely enough to 304 -- every job gets >= 1 workgroup, the
-    workgroups tile [0, total) without gaps, the launch never exceeds the compute units (ONE co-resident round), every workgroup has
-    a non-empty step range, partial regions do not overlap and fit aon_wgrad_workspace_bytes(), and the split follows the cost
-    model (a 256x256 job gets ~3.6x the workgroups of a 128x128 one)."""
+    """The grouped weight-gradient launch's plan (csrc/aon_wgrad.h:wg_make_plan, host-only).  Round 4: the steps of all jobs form one
+    work line priced in cost units and workgroup i of G owns the steps that START in its 1/G of the line.  For both networks, sample
+    counts from one pass to a 4096-ray fine level, and compute-unit counts from 1 to 304: the launch never exceeds the compute units
+    (ONE co-resident round) nor the steps on the line; the workgroups that write partials for a job are exactly a contiguous range;
+    their step ranges tile [0, steps) of the job without gap or overlap (the kernel's own arithmetic, restated on the host by
+    aon_wgrad_plan_segment); partial regions do not overlap and fit aon_wgrad_workspace_bytes(); every workgroup's share of the
+    cost is the same to within one step of the widest job."""
     import ctypes as C
 
     from aon_amd import _lib
 
     lib = _lib.lib
     blk = {0: 256 * 256, 1: 128 * 128, 2: 256 * 64, 3: 128 * 256, 4: 128 * 32}
+    cost = {0: 16384, 1: 4280, 2: 4620, 3: 8300, 4: 1510}
     for art, njobs in ((0, 12), (1, 18)):
         for Np in (128, 640, 4096 * 65 + 0, 128 * ((4096 * 193 + 127) // 128)):
             if Np % 128:
                 Np += 128 - Np % 128
-            for cus in (njobs, 64, 255, 256, 304, 1000):
+            for cus in (1, 5, 64, 255, 256, 304, 1000):
                 out = (C.c_int32 * (6 * 20))()
                 ws = C.c_int64(0)
                 n = lib.aon_wgrad_plan(art, Np, cus, out, 20, C.byref(ws))
                 assert n == njobs, (art, Np, cus, n, lib.aon_last_error())
                 jobs = [tuple(out[6 * j: 6 * j + 6]) for j in range(n)]
-                nsteps, nxt, regions = Np // 32, 0, []
-                for kind, wg_begin, wg_count, per, part_off, nparts in jobs:
-                    assert wg_begin == nxt and wg_count >= 1 and per >= 1
-                    assert (wg_count - 1) * per < nsteps <= wg_count * per          # every workgroup's range is non-empty, the last may be short
-                    nxt += wg_count
+                nsteps, regions = Np // 32, []
+                G = max(j[1] + j[2] for j in jobs)
+                assert G <= min(cus, 304, nsteps * njobs)
+                load = [0] * G
+                be = (C.c_int32 * 2)()
+                full = Np <= 640 or cus in (5, 256)     # every (job, workgroup) pair where that is cheap
+                for j, (kind, first, count, steps, part_off, nparts) in enumerate(jobs):
+                    assert steps == nsteps and count >= 1 and first >= 0 and first + count <= G
                     regions.append((part_off, part_off + nparts * blk[kind]))
-                assert nxt <= min(cus, 304)
+                    if not full:
+                        continue
+                    nxt = 0
+                    for wg in range(G):
+                        r = lib.aon_wgrad_plan_segment(art, Np, cus, j, wg, be)
+                        assert r == (1 if first <= wg < first + count else 0), (j, wg, r)
+                        if r:
+                            assert be[0] == nxt and be[1] >= be[0]            # contiguous tiling, in workgroup order
+                            nxt = be[1]
+                            load[wg] += (be[1] - be[0]) * cost[kind]
+                        else:
+                            assert be[0] == be[1]                             # owns nothing of a job it writes no partial for
+                    assert nxt == nsteps
                 regions.sort()
                 assert all(a[1] <= b[0] for a, b in zip(regions, regions[1:])) and regions[0][0] >= 0
                 assert ws.value <= lib.aon_wgrad_workspace_bytes() and ws.value >= regions[-1][1] * 4
-                if cus == 256 and Np > 100_000:
-                    big = [j[2] for j in jobs if j[0] == 0]
-                    small = [j[2] for j in jobs if j[0] == 1]
-                    assert max(big) - min(big) <= 1 and nxt >= 250
-                    if small:
-                        assert 3.0 <= big[0] / small[0] <= 4.5
+                if full:
+                    assert max(load) - min(load) <= 2 * 16384, (art, Np, cus, max(load), min(load))
+                    if cus == 256 and Np > 100_000:
+                        assert G == 256 and max(load) / min(load) < 1.01
     out = (C.c_int32 * 120)()
     assert lib.aon_wgrad_plan(1, 100, 256, out, 20, None) < 0 and b"multiple of 32" in lib.aon_last_error()
-    assert lib.aon_wgrad_plan(1, 1024, 5, out, 20, None) < 0      # fewer compute units than layers: refused, not mis-planned
     assert lib.aon_wgrad_plan(1, 1024, 256, out, 3, None) < 0
 
 

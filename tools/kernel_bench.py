@@ -97,15 +97,14 @@ def wgrad_probe(args):
         nj = lib.aon_wgrad_plan(1, ops.plane_samples(planes), cus, jobs, 24, None)
         assert nj > 0, lib.aon_last_error()
         pr = probe.cpu().reshape(-1, 2).double() / 100.0     # microseconds
-        total = int(sum(jobs[6 * j + 2] for j in range(nj)))
+        total = int(max(jobs[6 * j + 1] + jobs[6 * j + 2] for j in range(nj)))   # workgroups of the launch (a workgroup may serve several jobs)
         t0, t1 = pr[:total, 0].min().item(), pr[:total, 1].max().item()
         print(json.dumps({"tag": args.tag, "S": S, "launch_us": round(t1 - t0, 1), "workgroups": total, "jobs": nj}), flush=True)
         for j in range(nj):
-            kind, b, c, per = jobs[6 * j], jobs[6 * j + 1], jobs[6 * j + 2], jobs[6 * j + 3]
-            dur = pr[b: b + c, 1] - pr[b: b + c, 0]
-            print(json.dumps({"S": S, "job": j, "kind": names[kind], "wgs": c, "steps_per_wg": per, "start_us_max": round((pr[b: b + c, 0].max().item() - t0), 1),
-                              "dur_us_mean": round(dur.mean().item(), 1), "dur_us_max": round(dur.max().item(), 1),
-                              "us_per_step": round(dur.mean().item() / per, 3), "idle_tail_us": round(t1 - pr[b: b + c, 1].max().item(), 1)}), flush=True)
+            kind, b, c, steps = jobs[6 * j], jobs[6 * j + 1], jobs[6 * j + 2], jobs[6 * j + 3]
+            dur = pr[b: b + c, 1] - pr[b: b + c, 0]     # whole duration of the workgroups that serve this job (they may serve its neighbours too)
+            print(json.dumps({"S": S, "job": j, "kind": names[kind], "wgs": c, "steps": steps, "wg_dur_us_mean": round(dur.mean().item(), 1),
+                              "wg_dur_us_max": round(dur.max().item(), 1), "idle_tail_us": round(t1 - pr[b: b + c, 1].max().item(), 1)}), flush=True)
         del raw, planes, masks, dpl, dxp
         torch.cuda.empty_cache()
 

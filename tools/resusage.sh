@@ -5,7 +5,6 @@ set -u
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 f=$1; shift
 extra=""
-[ "$f" = aon_train.hip ] && extra="-DAON_PIN_PREFETCH"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC $extra "$@" -c $ROOT/articulated-object-nerf_amd/csrc/$f -o /tmp/resusage_$$.o \
   -Rpass-analysis=kernel-resource-usage 2>&1 | grep -E "error|Function Name|VGPRs:|AGPRs|ScratchSize|Occupancy|LDS Size" \
   | sed 's/.*remark: [^ ]* //; s/\[-Rpass.*//; s/Function Name: //' | paste - - - - - - | sed 's/  */ /g' | sort -u

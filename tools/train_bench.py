@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--no-overlap", action="store_true", help="backward of both levels on the caller's stream (A/B of the two-stream backward)")
     ap.add_argument("--no-fwd-overlap", action="store_true", help="training forward on the caller's stream only (A/B of the two ray halves on two streams)")
     ap.add_argument("--no-fwd-merge", action="store_true", help="training forward without the merged coarse(A) | fine(A)+coarse(B) | fine(B) launches (round 4 default)")
+    ap.add_argument("--no-bwd-merge", action="store_true", help="one backward-chain launch per level (round 3) instead of the merged two-segment launch")
     ap.add_argument("--articulated", action="store_true", help="NeRF_AE_Art + CodeLibraryArticulated (BASELINE config 5 per GPU)")
     args = ap.parse_args()
     import aon_amd.synthetic as syn
@@ -31,6 +32,7 @@ def main():
     dev = torch.device("cuda:0")
     ops.set_bwd_overlap(not args.no_overlap)
     ops.set_fwd_merge(not args.no_fwd_merge)
+    ops.set_bwd_merge(not args.no_bwd_merge)
     ops.set_fwd_overlap(not args.no_fwd_overlap and not args.no_overlap)
     if os.environ.get("AON_FWD_PARTS"):
         from aon_amd import _lib
