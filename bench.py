@@ -262,9 +262,10 @@ def pmc_traffic():
     cannot run the profiler on itself, so this is the last committed measurement, not a live one; null when no profile is present."""
     pmc, src = _pmc_file()
     try:
-        return {"traffic": _pmc_bytes(pmc, "mlp_fwd_kernel"), "traffic_unit": "B/launch", "traffic_source": src}
+        return {"traffic": _pmc_bytes(pmc, "mlp_fwd_kernel"), "traffic_unit": "B/launch", "traffic_source": src,
+                "traffic_provenance": "committed (rocprofv3 PMC passes of this same command, tools/profile_round.sh; not measured in this run)"}
     except Exception:
-        return {"traffic": None}
+        return {"traffic": None, "traffic_provenance": "none (no committed PMC summary found)"}
 
 
 def pmc_traffic_ray_kernels(hbm):
@@ -274,9 +275,10 @@ def pmc_traffic_ray_kernels(hbm):
                         ("sample_t", "sample_t4_kernel"), ("sample_pdf", "sample_pdf_kernel")):
         if key in hbm and hbm[key] is not None:
             try:
-                hbm[key].update({"traffic": _pmc_bytes(pmc, needle), "traffic_unit": "B/launch", "traffic_source": src})
+                hbm[key].update({"traffic": _pmc_bytes(pmc, needle), "traffic_unit": "B/launch", "traffic_source": src,
+                                 "traffic_provenance": "committed (rocprofv3 PMC passes of this same command; not measured in this run)"})
             except Exception:
-                pass
+                hbm[key]["traffic_provenance"] = "none (kernel not in the committed PMC summary)"
     return hbm
 
 
