@@ -1215,11 +1215,14 @@ int aon_render_bwd_ex(const void* packed_bwd_coarse, const void* packed_fwd_coar
     if (int rc = check(aon::launch_mlp_bwd_chain2(segs, 2, caller), "aon_render_bwd")) return rc;
   }
   // fork: with two levels each runs on its own library stream, ordered after everything already enqueued on the caller's
-  LevelFork fork(num_levels == 2 && g_bwd_overlap.load(std::memory_order_relaxed), caller, "aon_render_bwd");
+  // (merged: no side streams at all -- chain, weight gradients and head reductions follow each other on the caller's stream; with equal-cost
+  // workgroups filling the chip in every launch the fork / join events and the dispatcher's sharing of compute units between streams cost
+  // more than the tails they used to fill: profiles/r04_backward_schedules.txt)
+  LevelFork fork(!merged && num_levels == 2 && g_bwd_overlap.load(std::memory_order_relaxed), caller, "aon_render_bwd");
   if (fork.rc()) return fork.rc();
   for (int l = 0; l < num_levels; ++l) {
     const TrainLevel& L = w.lvl[l];
-    stream = fork.stream(l);
+    stream = merged ? caller : fork.stream(l);
     int rc = AON_OK;
     if (!merged) {
       if ((rc = composite_bwd(l, stream))) return rc;
@@ -1315,11 +1318,14 @@ int aon_art_render_bwd_ex(const void* packed_bwd_coarse, const void* small_coars
     if (int rc = check(aon::launch_art_bwd_chain2(segs, 2, caller), "aon_art_render_bwd")) return rc;
   }
   // fork: with two levels each runs on its own library stream, ordered after everything already enqueued on the caller's
-  LevelFork fork(num_levels == 2 && g_bwd_overlap.load(std::memory_order_relaxed), caller, "aon_art_render_bwd");
+  // (merged: no side streams at all -- chain, weight gradients and head reductions follow each other on the caller's stream; with equal-cost
+  // workgroups filling the chip in every launch the fork / join events and the dispatcher's sharing of compute units between streams cost
+  // more than the tails they used to fill: profiles/r04_backward_schedules.txt)
+  LevelFork fork(!merged && num_levels == 2 && g_bwd_overlap.load(std::memory_order_relaxed), caller, "aon_art_render_bwd");
   if (fork.rc()) return fork.rc();
   for (int l = 0; l < num_levels; ++l) {
     const TrainLevel& L = w.lvl[l];
-    stream = fork.stream(l);
+    stream = merged ? caller : fork.stream(l);
     int rc = AON_OK;
     if (!merged) {
       if ((rc = composite_bwd(l, stream))) return rc;

@@ -42,6 +42,20 @@ struct Pipe {
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) char gbl_char;
 
+// Round 4: the weight stream is fetched with BUFFER loads to LDS (`buffer_load_dwordx4 v_off, s[rsrc], s_soff offen lds`): the stream is a
+// raw buffer whose descriptor sits in four SGPRs, the lane's slice is ONE 32-bit VGPR offset that never changes, and everything that
+// does change -- chunk, round -- is a scalar offset.  The `global_load_lds` form of rounds 1-3 took a 64-bit per-lane address: hipcc
+// hoisted (stream + lane offset) into a VGPR pair and paid a 64-bit VALU add per DMA, plus a v_readfirstlane + s_mov to bring the
+// LDS destination (derived from threadIdx, so "divergent") into M0 -- ~1,200 of the ~5,100 vector instructions of a pass of the
+// headline kernel that were not MFMAs (tools/isa_mix.py).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t stream_rsrc(const char* stream) {
+  // raw buffer, stride 0, no range limit below 2 GiB, gfx9 data format word (the 0x00020000 every CDNA kernel library uses)
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(stream), 0, 0x7ffffffe, 0x00020000);
+}
+__device__ __forceinline__ void dma_1k(const char* stream, unsigned soff, unsigned voff, char* lds_dst) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(stream_rsrc(stream), (lds_void*)lds_dst, 16, (int)voff, (int)soff, 0, 0);
+}
+
 // LDS-DMA one chunk: global (SGPR base + per-lane VGPR offset) -> LDS (M0 base + lane*16), 1 KiB per wave per
 // instruction.  The stream offset is kept as an opaque loop-carried scalar so that the several hundred
 // distinct chunk addresses are recomputed with one s_add instead of being hoisted out of the pass loop.
@@ -50,13 +64,9 @@ __device__ __forceinline__ void issue_chunk(Pipe& p, int slot) {
   constexpr int rounds = Net::chunk_bytes(C) / 4096;
   unsigned off = p.issue_off;
   asm volatile("" : "+s"(off));
-  gbl_char* src = (gbl_char*)(p.stream + off);
   char* dst = p.ring + slot * Net::kSlotBytes + p.wave_off;  // wave-uniform; hardware adds lane*16
 #pragma unroll
-  for (int r = 0; r < rounds; ++r) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + r * 4096 + p.voff),
-                                     (lds_void*)(dst + r * 4096), 16, 0, 0);
-  }
+  for (int r = 0; r < rounds; ++r) dma_1k(p.stream, off + (unsigned)(r * 4096), p.voff, dst + r * 4096);
   p.issue_off = (C == Net::kNumChunks - 1) ? 0u : off + (unsigned)Net::chunk_bytes(C);
 }
 
@@ -65,17 +75,19 @@ __device__ __forceinline__ void issue_chunk(Pipe& p, int slot) {
 template <class Net>
 __device__ __forceinline__ void pipe_init(Pipe& p, const char* stream, char* ring, int wave, int lane) {
   p.stream = stream; p.next_stream = stream; p.ring = ring;
+  // the wave's 1 KiB slice of a DMA round is WAVE-UNIFORM: kept on the scalar unit (round 4).  Derived from threadIdx it lived in a
+  // VGPR, and every one of the ~600 DMA instructions of a pass paid a v_readfirstlane + s_mov to get its LDS destination into M0,
+  // with a dozen pre-computed destinations parked in VGPRs (tools/isa_mix.py).
+  const int wave_s = __builtin_amdgcn_readfirstlane(wave);
   p.voff = (unsigned)(wave * 1024 + lane * 16);
-  p.wave_off = wave * 1024; p.lane_off = lane * 16;
+  p.wave_off = wave_s * 1024; p.lane_off = lane * 16;
   p.slot = 1; p.issue_off = 0;  // the first acquire flips to slot 0
   issue_chunk<Net, 0>(p, 0);
   if constexpr (Net::kPair) {
-    gbl_char* src = (gbl_char*)(p.stream + Net::chunk_bytes(0));
     char* dst = p.ring + Net::chunk_bytes(0) + p.wave_off;
 #pragma unroll
     for (int r = 0; r < Net::chunk_bytes(1) / 4096; ++r)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + r * 4096 + p.voff),
-                                       (lds_void*)(dst + r * 4096), 16, 0, 0);
+      dma_1k(p.stream, (unsigned)(Net::chunk_bytes(0) + r * 4096), p.voff, dst + r * 4096);
     p.issue_off = (unsigned)(Net::chunk_bytes(0) + Net::chunk_bytes(1));
   }
   __syncthreads();
@@ -121,11 +133,11 @@ template <class Net, int C>
 __device__ __forceinline__ void dma_round(const Pipe& p, unsigned off, int r) {
   constexpr int T0 = dma_target<Net>(C, 0);
   constexpr int R0 = Net::chunk_bytes(T0) / 4096;
-  gbl_char* src = (gbl_char*)(p.stream + off);   // (from the first wrapping chunk on, p.stream IS the next pass's stream: acquire)
+  // (from the first wrapping chunk on, p.stream IS the next pass's stream: acquire)
   char* slot = p.ring + (p.slot ^ 1) * kPairSlotBytes + p.wave_off;
   char* dst = r < R0 ? slot + pair_offset<Net>(T0) + r * 4096
                      : slot + pair_offset<Net>(dma_target<Net>(C, 1)) + (r - R0) * 4096;
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + r * 4096 + p.voff), (lds_void*)dst, 16, 0, 0);
+  dma_1k(p.stream, off + (unsigned)(r * 4096), p.voff, dst);
 }
 
 // out[Tp] += W_chunk[Tp] * in   for one 32-feature input tile held in accumulator layout.
