@@ -204,7 +204,7 @@ __global__ void __launch_bounds__(256) mlp_fwd_kernel(MlpArgs args) {
         return [&, in_row, with_mask, j](int i) {
           if constexpr (TRAIN) {
             if (i < 16) {
-              if ((i & 3) == 0) store_quad(io, in_row + 32 * j, i >> 2, in[j]);
+              if ((i & 3) == 0) store_quad<false>(io, in_row + 32 * j, i >> 2, in[j]);
               if (with_mask) mw[j >> 1] = mask_push_post(mw[j >> 1], in[j][i]);
             }
           }

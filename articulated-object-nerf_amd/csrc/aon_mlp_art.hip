@@ -202,7 +202,7 @@ __global__ void __launch_bounds__(256) art_mlp_fwd_kernel(ArtMlpArgs args) {
       return [&, row, with_mask](int i) {
         if constexpr (TRAIN) {
           if (i < 16) {
-            if ((i & 3) == 0) store_quad(io, row, i >> 2, tile);
+            if ((i & 3) == 0) store_quad<false>(io, row, i >> 2, tile);
             if (with_mask) word = mask_push_post(word, tile[i]);
           }
         }

@@ -332,9 +332,13 @@ __device__ __forceinline__ f32x4* quad_ptr(const PlaneIO& io, int row, int g) {
 __device__ __forceinline__ float* row_ptr(const PlaneIO& io, int row) {
   return reinterpret_cast<float*>(io.base + (int64_t)((row >> 2) * 512 + (row & 3) * 4) + io.soff);
 }
+template <bool STAGE = true>
 __device__ __forceinline__ void store_quad(const PlaneIO& io, int row, int g, const f32x16& t) {
 #ifndef AON_EXP_NOSTORE   // experiment builds only (tools/exp_train.sh): what the plane stores cost
   f32x4 v; v[0] = t[4 * g]; v[1] = t[4 * g + 1]; v[2] = t[4 * g + 2]; v[3] = t[4 * g + 3];
+  // (STAGE = false, round 4: the forward's tiles are post-ReLU values that already live in architectural VGPRs; the staging asm, which
+  // "modifies" its operand, forced a copy of every quad there -- 770 v_mov_b64 per pass of the articulated training forward)
+  if constexpr (STAGE)
   // The store's data is staged in architectural VGPRs (four v_accvgpr_read where the tile sits in AGPRs, as the gradient
   // tiles of the backward chains do): a global_store whose data operand is an AGPR range reads it while MFMAs are streaming
   // their accumulators through the same register banks and holds the wave's issue port meanwhile.  Measured round 3
@@ -440,7 +444,16 @@ struct BwdSideOf {
     const u32x4& m = mk;
     return [&t, trow, &pio, &m, j](int i) {
       if (i < 16) {
-        if ((i & 3) == 0) store_quad(pio, trow, i >> 2, t[j]);   // one 16-byte store per four slots
+        // one 16-byte store per four slots.  A MASKED tile was turned into dZ by the previous chunk's side job (or by the caller, tile 0):
+        // its values already sit in architectural VGPRs, staging them again is a copy (round 4: 694 v_mov_b64 per pass of the
+        // articulated chain); an unmasked tile (d bottleneck) comes straight from the accumulators and is staged
+        // (per translation unit: in the vanilla chain hipcc keeps masked tiles in AGPRs -- 192 of its stores would read them directly --
+        // so aon_train.hip defines AON_CHAIN_STAGE_MASKED and stages every quad as before)
+#ifdef AON_CHAIN_STAGE_MASKED
+        if ((i & 3) == 0) store_quad<true>(pio, trow, i >> 2, t[j]);
+#else
+        if ((i & 3) == 0) store_quad<!MASKED>(pio, trow, i >> 2, t[j]);
+#endif
         if constexpr (MASKED) {
           if (j + 1 < NT) {
             float z = mask_apply(m[(j + 1) >> 1], t[j + 1][i], ((j + 1) & 1) * 16 + i);

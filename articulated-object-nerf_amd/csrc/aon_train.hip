@@ -15,6 +15,7 @@
 //   head_wgrad_kernel      the 1- and 3-row head weights and all bias sums (plane rows x one 16-byte record per sample).
 #include <atomic>
 #define AON_WGRAD_KERNELS
+#define AON_CHAIN_STAGE_MASKED   // see BwdSideOf (aon_mlp_core.h)
 #include "aon_wgrad.h"
 
 namespace aon {
