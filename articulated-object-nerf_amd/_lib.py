@@ -47,6 +47,9 @@ _SIGS = {
     "aon_art_small_bytes": (_l, []),
     "aon_pack_art_mlp": (_i, [_p, _p, _p]),
     "aon_art_prepare": (_i, [_p, _p, _p, _p, _p, _p]),
+    "aon_pack_art_mlp_deg": (_i, [_p, _i, _i, _i, _p, _p]),
+    "aon_art_prepare_deg": (_i, [_p, _p, _p, _p, _i, _i, _i, _p, _p]),
+    "aon_pack_art_mlp_bwd_deg": (_i, [_p, _i, _i, _i, _p, _p]),
     "aon_art_mlp_fwd": (_i, [_p, _p, _p, _p, _p, _p, _l, _i, _p, _p]),
     "aon_art_mlp_fwd_pos": (_i, [_p, _p, _p, _p, _l, _i, _p, _p]),
     "aon_art_render_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _l, _f, _f, _i, _i, _p, _p, _l, _p, _p, _p, _p, _p, _p, _p, _l, _p]),
@@ -69,6 +72,7 @@ _SIGS = {
     "aon_art_mlp_fwd_train": (_i, [_p, _p, _p, _p, _p, _p, _l, _i, _p, _p, _p, _p]),
     "aon_art_bwd_chain": (_i, [_p, _p, _p, _p, _p, _p, _p, _l, _p]),
     "aon_art_wgrad": (_i, [_p, _p, _p, _p, _l, _p, _p, _p, _p, _p, _p, _p, _p, _p, _l, _p]),
+    "aon_art_wgrad_deg": (_i, [_p, _p, _p, _p, _l, _p, _p, _p, _p, _p, _p, _p, _p, _p, _l, _p, _i, _i, _i]),
     "aon_set_bwd_overlap": (_i, [_i]),
     "aon_set_fwd_overlap": (_i, [_i]),
     "aon_set_fwd_merge": (_i, [_i]),

@@ -17,7 +17,8 @@ constexpr int kA_WSIG = 4100;   // 256
 constexpr int kA_WRGB = 4356;   // 3x128
 constexpr int kA_BSIG = 4740;   // 1
 constexpr int kA_BRGB = 4741;   // 3
-constexpr int kASmallFloats = 4744;
+constexpr int kA_ESC = 4744;    // 10 (+2 pad): encoding scales 2^(min_deg_point + l), 0 for levels the network lacks (round 4: other degrees)
+constexpr int kASmallFloats = 4756;
 constexpr int kALdsBytes = kRingBytes + kASmallFloats * 4;
 
 // parameter order of the articulated NeRFMLP (model_autodecoder.py:60-170):

@@ -16,9 +16,9 @@ hipError_t launch_mlp_fwd(const char* packed, const float* rays_o, const float* 
                           const float* t_vals, int64_t n_rays, int S, float* raw, hipStream_t stream);
 hipError_t launch_mlp_fwd_enc(const char* packed, const float* samples_enc, const float* viewdirs_enc, int64_t n_rays,
                               int S, float* raw, hipStream_t stream);
-hipError_t launch_pack_art(const float* const* params, float* packed, hipStream_t stream);
+hipError_t launch_pack_art(const float* const* params, float* packed, hipStream_t stream, int pos_levels = 10, int view_levels = 4);
 hipError_t launch_prepare_art(const float* const* params, const float* shape, const float* app, const float* art,
-                              float* small, hipStream_t stream);
+                              float* small, hipStream_t stream, int min_deg = 0, int pos_levels = 10, int view_levels = 4);
 hipError_t launch_art_mlp_fwd(const char* packed, const float* small, const float* rays_o, const float* rays_d,
                               const float* viewdirs, const float* t_vals, int64_t n_rays, int S, float* raw,
                               hipStream_t stream);
@@ -55,13 +55,13 @@ hipError_t launch_art_mlp_fwd_train(const char* packed, const float* small, cons
 hipError_t launch_art_mlp_fwd_train2(const TrainSeg* segs, int nsegs, hipStream_t stream);
 hipError_t launch_mlp_fwd_train2(const TrainSeg* segs, int nsegs, hipStream_t stream);
 int num_cus();
-hipError_t launch_pack_art_bwd(const float* const* params, float* packed, hipStream_t stream);
+hipError_t launch_pack_art_bwd(const float* const* params, float* packed, hipStream_t stream, int pos_levels = 10, int view_levels = 4);
 int64_t art_bwd_stream_bytes();
 hipError_t launch_art_bwd_chain(const char* packed_bwd, const float* small, const float* d_raw, const void* masks, const float* planes,
                                 float* dplanes, float* dxp, int64_t Np, hipStream_t stream);
 hipError_t launch_art_wgrad(const float* planes, const float* dplanes, const float* d_raw, const float* dxp, int64_t Np,
                             const float* const* params, const float* shape, const float* app, const float* art,
-                            float* const* grads, float* g_shape, float* g_app, float* g_art, float* ws, hipStream_t stream, const WgAux* aux);
+                            float* const* grads, float* g_shape, float* g_app, float* g_art, float* ws, hipStream_t stream, const WgAux* aux, int pos_levels = 10, int view_levels = 4);
 hipError_t launch_raygen(const float* c2w, int H, int W, float focal, const float* directions, int64_t pix_begin,
                          int64_t pix_end, float* rays_o, float* viewdirs, float* rays_d, hipStream_t stream);
 hipError_t launch_ray_directions(int H, int W, float focal, float* out, hipStream_t stream);
@@ -517,12 +517,24 @@ int64_t aon_art_train_plane_rows(void) { return aon::kAPlRows; }
 int64_t aon_art_train_mask_bytes(int64_t Np) { return (int64_t)aon::kAMaskLayers * Np * 2 * 16; }
 int64_t aon_art_bwd_packed_bytes(void) { return aon::art_bwd_stream_bytes(); }
 
+static const char* art_degrees_ok(int min_deg_point, int max_deg_point, int deg_view) {
+  const int L = max_deg_point - min_deg_point;
+  if (L < 0 || L > 10 || deg_view < 0 || deg_view > 4) return "up to 10 position and 4 view frequency levels";
+  if (min_deg_point < -32 || max_deg_point > 32) return "min_deg_point / max_deg_point must lie in [-32, 32]";
+  return nullptr;
+}
+
 int aon_pack_art_mlp_bwd(const float* const* params_host, void* packed_bwd, void* stream) {
+  return aon_pack_art_mlp_bwd_deg(params_host, 0, 10, 4, packed_bwd, stream);
+}
+int aon_pack_art_mlp_bwd_deg(const float* const* params_host, int min_deg_point, int max_deg_point, int deg_view, void* packed_bwd, void* stream) {
   if (!params_host || !packed_bwd) return fail(AON_E_INVALID, "aon_pack_art_mlp_bwd: null pointer");
   for (int i = 0; i < 40; ++i)
     if (!params_host[i]) return fail(AON_E_INVALID, "aon_pack_art_mlp_bwd: null parameter pointer");
   if (reinterpret_cast<uintptr_t>(packed_bwd) & 15) return fail(AON_E_INVALID, "aon_pack_art_mlp_bwd: buffer must be 16-byte aligned");
-  return check(aon::launch_pack_art_bwd(params_host, static_cast<float*>(packed_bwd), (hipStream_t)stream), "aon_pack_art_mlp_bwd");
+  if (const char* bad = art_degrees_ok(min_deg_point, max_deg_point, deg_view)) return fail(AON_E_INVALID, bad);
+  return check(aon::launch_pack_art_bwd(params_host, static_cast<float*>(packed_bwd), (hipStream_t)stream, max_deg_point - min_deg_point, deg_view),
+               "aon_pack_art_mlp_bwd");
 }
 
 int aon_art_mlp_fwd_train(const void* packed, const void* small, const float* rays_o, const float* rays_d, const float* viewdirs,
@@ -551,6 +563,14 @@ int aon_art_wgrad(const float* planes, const float* dplanes, const float* d_raw,
                   const float* const* params_host, const float* shape, const float* appearance, const float* articulation,
                   float* const* grads_host, float* g_shape, float* g_appearance, float* g_articulation, void* workspace,
                   int64_t workspace_bytes, void* stream) {
+  return aon_art_wgrad_deg(planes, dplanes, d_raw, dxp, Np, params_host, shape, appearance, articulation, grads_host, g_shape, g_appearance,
+                           g_articulation, workspace, workspace_bytes, stream, 0, 10, 4);
+}
+int aon_art_wgrad_deg(const float* planes, const float* dplanes, const float* d_raw, const float* dxp, int64_t Np,
+                      const float* const* params_host, const float* shape, const float* appearance, const float* articulation,
+                      float* const* grads_host, float* g_shape, float* g_appearance, float* g_articulation, void* workspace,
+                      int64_t workspace_bytes, void* stream, int min_deg_point, int max_deg_point, int deg_view) {
+  if (const char* bad = art_degrees_ok(min_deg_point, max_deg_point, deg_view)) return fail(AON_E_INVALID, bad);
   if (Np <= 0 || (Np & 127)) return fail(AON_E_INVALID, "aon_art_wgrad: Np must be a positive multiple of 128");
   if (!planes || !dplanes || !d_raw || !dxp || !params_host || !shape || !appearance || !articulation || !grads_host || !g_shape ||
       !g_appearance || !g_articulation || !workspace)
@@ -560,7 +580,8 @@ int aon_art_wgrad(const float* planes, const float* dplanes, const float* d_raw,
   if (workspace_bytes < aon::wgrad_workspace_bytes()) return fail(AON_E_WORKSPACE, "aon_art_wgrad: workspace too small");
   KTimer timer(kWgrad, (hipStream_t)stream, Np);
   return check(aon::launch_art_wgrad(planes, dplanes, d_raw, dxp, Np, params_host, shape, appearance, articulation, grads_host, g_shape,
-                                     g_appearance, g_articulation, static_cast<float*>(workspace), (hipStream_t)stream, nullptr), "aon_art_wgrad");
+                                     g_appearance, g_articulation, static_cast<float*>(workspace), (hipStream_t)stream, nullptr,
+                                     max_deg_point - min_deg_point, deg_view), "aon_art_wgrad");
 }
 
 int aon_profile_begin(void) {
@@ -651,7 +672,7 @@ static int render_impl(const char* who, const NetRef& coarse, const NetRef& fine
   if (num_levels == 2 && u_stride != 0 && u_stride < g.nf) return fail(AON_E_INVALID, "render: bad u_stride");
   if (reinterpret_cast<uintptr_t>(workspace) & 255) return fail(AON_E_INVALID, "render: workspace must be 256-byte aligned");
   const bool art = coarse.articulated;
-  if (art && g.other_degrees) return fail(AON_E_INVALID, "render: the articulated network has kernels for degrees (0, 10, 4) only");
+  if (art) g.other_degrees = false;   // the articulated kernels carry their degrees in the packed stream and the small block (aon_*_deg)
   const bool fuse_coarse = num_levels == 2 && g.default_sizes && g_fuse_coarse.load(std::memory_order_relaxed) != 0;
 
   // largest chunk the workspace admits
@@ -933,7 +954,7 @@ int train_fwd_impl(const char* who, bool art, const TrainNet* nets, const float*
   Geo g;
   if (const char* bad = make_geo(opts, g)) return fail(AON_E_INVALID, bad);
   if (g.Sf > 512) return fail(AON_E_INVALID, "train forward: more than 512 samples per ray at the fine level");
-  if (g.other_degrees && art) return fail(AON_E_INVALID, "train forward: the articulated network has kernels for degrees (0, 10, 4) only");
+  if (art) g.other_degrees = false;   // (as in render_impl: no stage-kernel encodings for the articulated network)
   if (n <= 0 || (num_levels != 1 && num_levels != 2)) return fail(AON_E_INVALID, "train forward: bad size / num_levels");
   if (!rays_o || !rays_d || !viewdirs || !workspace) return fail(AON_E_INVALID, "train forward: null pointer");
   if (reinterpret_cast<uintptr_t>(workspace) & 255) return fail(AON_E_INVALID, "train forward: workspace must be 256-byte aligned");
@@ -1339,7 +1360,7 @@ int aon_art_render_bwd_ex(const void* packed_bwd_coarse, const void* small_coars
       // level 0 writes the latent gradients, level 1 adds its own (both MLPs see the same latents)
       float* gs = l == 0 ? g_shape : sc.lat_tmp, *ga = l == 0 ? g_appearance : sc.lat_tmp + 128, *gt = l == 0 ? g_articulation : sc.lat_tmp + 256;
       rc = check(aon::launch_art_wgrad(L.planes, sc.dplanes[l], sc.d_raw[l], sc.dxp[l], L.Np, params[l], shape, appearance, articulation, grads[l], gs, ga, gt,
-                                       sc.wgrad_ws[l], stream, fork.aux(l)), "aon_art_render_bwd");
+                                       sc.wgrad_ws[l], stream, fork.aux(l), g.max_deg - g.min_deg, g.deg_view), "aon_art_render_bwd");
     }
     if (rc) return rc;
   }
@@ -1358,21 +1379,31 @@ int64_t aon_art_packed_bytes(void) { return aon::art_stream_bytes(); }
 int64_t aon_art_small_bytes(void) { return aon::art_small_bytes(); }
 
 int aon_pack_art_mlp(const float* const* params_host, void* packed, void* stream) {
+  return aon_pack_art_mlp_deg(params_host, 0, 10, 4, packed, stream);
+}
+int aon_pack_art_mlp_deg(const float* const* params_host, int min_deg_point, int max_deg_point, int deg_view, void* packed, void* stream) {
+  if (const char* bad = art_degrees_ok(min_deg_point, max_deg_point, deg_view)) return fail(AON_E_INVALID, bad);
   if (!params_host || !packed) return fail(AON_E_INVALID, "aon_pack_art_mlp: null pointer");
   for (int i = 0; i < 40; ++i)
     if (!params_host[i]) return fail(AON_E_INVALID, "aon_pack_art_mlp: null parameter pointer");
   if (reinterpret_cast<uintptr_t>(packed) & 15) return fail(AON_E_INVALID, "aon_pack_art_mlp: packed must be 16-byte aligned");
-  return check(aon::launch_pack_art(params_host, static_cast<float*>(packed), (hipStream_t)stream), "aon_pack_art_mlp");
+  return check(aon::launch_pack_art(params_host, static_cast<float*>(packed), (hipStream_t)stream, max_deg_point - min_deg_point, deg_view),
+               "aon_pack_art_mlp");
 }
 
 int aon_art_prepare(const float* const* params_host, const float* shape, const float* appearance, const float* articulation,
                     void* small, void* stream) {
+  return aon_art_prepare_deg(params_host, shape, appearance, articulation, 0, 10, 4, small, stream);
+}
+int aon_art_prepare_deg(const float* const* params_host, const float* shape, const float* appearance, const float* articulation,
+                        int min_deg_point, int max_deg_point, int deg_view, void* small, void* stream) {
+  if (const char* bad = art_degrees_ok(min_deg_point, max_deg_point, deg_view)) return fail(AON_E_INVALID, bad);
   if (!params_host || !shape || !appearance || !articulation || !small) return fail(AON_E_INVALID, "aon_art_prepare: null pointer");
   for (int i = 0; i < 40; ++i)
     if (!params_host[i]) return fail(AON_E_INVALID, "aon_art_prepare: null parameter pointer");
   if (reinterpret_cast<uintptr_t>(small) & 15) return fail(AON_E_INVALID, "aon_art_prepare: small must be 16-byte aligned");
-  return check(aon::launch_prepare_art(params_host, shape, appearance, articulation, static_cast<float*>(small), (hipStream_t)stream),
-               "aon_art_prepare");
+  return check(aon::launch_prepare_art(params_host, shape, appearance, articulation, static_cast<float*>(small), (hipStream_t)stream, min_deg_point,
+                                       max_deg_point - min_deg_point, deg_view), "aon_art_prepare");
 }
 
 int aon_art_mlp_fwd(const void* packed, const void* small, const float* rays_o, const float* rays_d, const float* viewdirs,

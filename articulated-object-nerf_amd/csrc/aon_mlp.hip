@@ -37,22 +37,7 @@ struct PackArgs {
   const float* p[kNumVanillaParams];
 };
 
-// L / Lv: frequency levels of the network's encodings (max_deg_point - min_deg_point <= 10, deg_view <= 4).  The stream always has
-// the 63 / 27-wide slots of the default geometry; a network with fewer levels leaves the slots of the missing levels at zero
-// weight, and the caller feeds encodings in that padded layout (launch_pos_enc with `levels_out`).
-__device__ __forceinline__ int pos_col_in(int c63, int L) {   // column of the 63-slot layout -> column of the (3 + 6 L)-wide weight
-  if (c63 < 3) return c63;
-  const bool second = c63 >= 33;
-  const int e = second ? c63 - 33 : c63 - 3;
-  return e / 3 < L ? 3 + e + (second ? 3 * L : 0) : -1;
-}
-__device__ __forceinline__ int view_col_in(int c27, int Lv) {
-  if (c27 < 3) return c27;
-  const bool second = c27 >= 15;
-  const int e = second ? c27 - 15 : c27 - 3;
-  return e / 3 < Lv ? 3 + e + (second ? 3 * Lv : 0) : -1;
-}
-
+// (pos_col_in / view_col_in: aon_mlp_core.h)
 __global__ void pack_vanilla_kernel(PackArgs a, float* __restrict__ packed, int L, int Lv) {
   const int P = 3 + 6 * L, V = 3 + 6 * Lv;
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -33,7 +33,12 @@ struct ArtPackArgs {
   const float* p[kNumArtParams];
 };
 
-__global__ void pack_art_kernel(ArtPackArgs a, float* __restrict__ packed) {
+// L / Lv: frequency levels of the network (defaults 10 / 4); the weights' row strides follow: pts_linears.0 (256, P + 128),
+// pts_linears.5 (256, 256 + P + 128), views_linear.0 (128, 256 + V + 128) with P = 3 + 6 L, V = 3 + 6 Lv
+__global__ void pack_art_kernel(ArtPackArgs a, float* __restrict__ packed, int L, int Lv) {
+  const int P = 3 + 6 * L, V = 3 + 6 * Lv;
+  auto pcol = [&](int c63) { return c63 < 0 ? -1 : pos_col_in(c63, L); };
+  auto vcol = [&](int c27) { return c27 < 0 ? -1 : view_col_in(c27, Lv); };
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= kAStreamBytes / 4) return;
   // locate the chunk
@@ -49,15 +54,15 @@ __global__ void pack_art_kernel(ArtPackArgs a, float* __restrict__ packed) {
   const int hid = 8 * q + 4 * h + cc;
   const float* W; int ld, col;
   if (c < kAChT0) { const int l = 1 + c / 4; W = a.p[2 * l]; ld = 128; col = 32 * (c % 4) + hid; }
-  else if (c < kAChT1) { W = a.p[10]; ld = 191; col = posenc_col(c - kAChT0, q, cc, h); }                    // cols 0..62
+  else if (c < kAChT1) { W = a.p[10]; ld = P + 128; col = pcol(posenc_col(c - kAChT0, q, cc, h)); }          // cols 0..P-1
   else if (c < kAChT5) { const int l = 1 + (c - kAChT1) / 8; W = a.p[10 + 2 * l]; ld = 256; col = 32 * ((c - kAChT1) % 8) + hid; }
-  else if (c < kAChT5 + 8) { W = a.p[20]; ld = 447; col = 32 * (c - kAChT5) + hid; }
-  else if (c < kAChT6) { W = a.p[20]; ld = 447; col = posenc_col(c - kAChT5 - 8, q, cc, h); if (col >= 0) col += 256; }
+  else if (c < kAChT5 + 8) { W = a.p[20]; ld = 256 + P + 128; col = 32 * (c - kAChT5) + hid; }
+  else if (c < kAChT6) { W = a.p[20]; ld = 256 + P + 128; col = pcol(posenc_col(c - kAChT5 - 8, q, cc, h)); if (col >= 0) col += 256; }
   else if (c < kAChT7) { W = a.p[22]; ld = 256; col = 32 * (c - kAChT6) + hid; }
   else if (c < kAChBott) { W = a.p[24]; ld = 256; col = 32 * (c - kAChT7) + hid; }
   else if (c < kAChV0) { W = a.p[34]; ld = 256; col = 32 * (c - kAChBott) + hid; }
-  else if (c < kAChV0 + 8) { W = a.p[26]; ld = 411; col = 32 * (c - kAChV0) + hid; }
-  else if (c < kAChV1) { W = a.p[26]; ld = 411; col = viewenc_col(q, cc, h); if (col >= 0) col += 256; }
+  else if (c < kAChV0 + 8) { W = a.p[26]; ld = 256 + V + 128; col = 32 * (c - kAChV0) + hid; }
+  else if (c < kAChV1) { W = a.p[26]; ld = 256 + V + 128; col = vcol(viewenc_col(q, cc, h)); if (col >= 0) col += 256; }
   else { const int l = 1 + (c - kAChV1) / 4; W = a.p[26 + 2 * l]; ld = 128; col = 32 * ((c - kAChV1) % 4) + hid; }
   packed[idx] = col >= 0 ? W[(int64_t)row * ld + col] : 0.f;  // every layer here has a multiple of 32 outputs
 }
@@ -70,10 +75,16 @@ struct ArtPrepArgs {
 };
 
 // small[] = plain copies of the small vectors + the latent-folded effective biases
-__global__ void prepare_art_kernel(ArtPrepArgs a, float* __restrict__ small) {
+__global__ void prepare_art_kernel(ArtPrepArgs a, float* __restrict__ small, int min_deg, int L, int Lv) {
+  const int P = 3 + 6 * L, V = 3 + 6 * Lv;
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= kASmallFloats) return;
   float v = 0.f;
+  if (s >= kA_ESC) {   // encoding scales (exact powers of two), 0 for the levels this network lacks and for the pad
+    const int l = s - kA_ESC;
+    small[s] = l < L ? ldexpf(1.0f, min_deg + l) : 0.f;
+    return;
+  }
   if (s < kA_WD0) {  // b + W[:,3:131].shape + W[:,131:163].art   (input = cat[pos, shape, articulation], :196-198)
     const float* w = a.p[0] + (int64_t)s * 163;
     float acc = a.p[1][s];
@@ -88,10 +99,10 @@ __global__ void prepare_art_kernel(ArtPrepArgs a, float* __restrict__ small) {
     const int i = s - kA_BT, l = i >> 8, f = i & 255;
     float acc = a.p[10 + 2 * l + 1][f];
     if (l == 0) {        // cat[enc(63), shape(128)]  (:210)
-      const float* w = a.p[10] + (int64_t)f * 191 + 63;
+      const float* w = a.p[10] + (int64_t)f * (P + 128) + P;
       for (int k = 0; k < 128; ++k) acc = __builtin_fmaf(w[k], a.shape[k], acc);
     } else if (l == 5) { // cat[h(256), enc(63), shape(128)]  (:216-217)
-      const float* w = a.p[20] + (int64_t)f * 447 + 319;
+      const float* w = a.p[20] + (int64_t)f * (256 + P + 128) + 256 + P;
       for (int k = 0; k < 128; ++k) acc = __builtin_fmaf(w[k], a.shape[k], acc);
     }
     v = acc;
@@ -100,7 +111,7 @@ __global__ void prepare_art_kernel(ArtPrepArgs a, float* __restrict__ small) {
     const int i = s - kA_BV, l = i >> 7, f = i & 127;
     float acc = a.p[26 + 2 * l + 1][f];
     if (l == 0) {        // cat[bottleneck(256), viewenc(27), appearance(128)]  (:228-230)
-      const float* w = a.p[26] + (int64_t)f * 411 + 283;
+      const float* w = a.p[26] + (int64_t)f * (256 + V + 128) + 256 + V;
       for (int k = 0; k < 128; ++k) acc = __builtin_fmaf(w[k], a.app[k], acc);
     }
     v = acc;
@@ -262,7 +273,7 @@ __global__ void __launch_bounds__(256) art_mlp_fwd_kernel(ArtMlpArgs args) {
       xd[a] = __fadd_rn(v, x[a]);
     }
     f32x16 E[2];
-    encode_pos(xd, h, E);  // pos_enc after the deformation (enc_after=True, :207-208)
+    encode_pos_scaled(xd, h, sm + kA_ESC, E);  // pos_enc after the deformation (enc_after=True, :207-208); scales: the network's degrees
     if constexpr (TRAIN) {
 #pragma unroll
       for (int a = 0; a < 3; ++a) save_row(kAPlPos + 3 + a, xd[a]);
@@ -283,7 +294,7 @@ __global__ void __launch_bounds__(256) art_mlp_fwd_kernel(ArtMlpArgs args) {
     dense_layer<ArtNet, kAChT5, 8, 8>(p, X, Y, consume8(X, aplane_h(4), true)); put_mask(8);
     if constexpr (TRAIN) {  // re-encoded (same function, same bits; xd made opaque so the two encodings are not merged) instead of
       asm volatile("" : "+v"(xd[0]), "+v"(xd[1]), "+v"(xd[2]));   // 32 registers held live across layers 1-4
-      encode_pos(xd, h, E);
+      encode_pos_scaled(xd, h, sm + kA_ESC, E);
     }
     chunk_mma<ArtNet, kAChT5 + 8, 8, 16>(p, E[0], Y);
     chunk_mma<ArtNet, kAChT5 + 9, 8, 16>(p, E[1], Y);
@@ -325,20 +336,20 @@ __global__ void __launch_bounds__(256) art_mlp_fwd_kernel(ArtMlpArgs args) {
 // ---------------------------------------------------------------------------------------------
 // host launchers
 // ---------------------------------------------------------------------------------------------
-hipError_t launch_pack_art(const float* const* params, float* packed, hipStream_t stream) {
+hipError_t launch_pack_art(const float* const* params, float* packed, hipStream_t stream, int pos_levels, int view_levels) {
   ArtPackArgs a;
   for (int i = 0; i < kNumArtParams; ++i) a.p[i] = params[i];
   const int64_t n = kAStreamBytes / 4;
-  pack_art_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream>>>(a, packed);
+  pack_art_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream>>>(a, packed, pos_levels, view_levels);
   return hipGetLastError();
 }
 
 hipError_t launch_prepare_art(const float* const* params, const float* shape, const float* app, const float* art,
-                              float* small, hipStream_t stream) {
+                              float* small, hipStream_t stream, int min_deg, int pos_levels, int view_levels) {
   ArtPrepArgs a;
   for (int i = 0; i < kNumArtParams; ++i) a.p[i] = params[i];
   a.shape = shape; a.app = app; a.art = art;
-  prepare_art_kernel<<<dim3((kASmallFloats + 255) / 256), dim3(256), 0, stream>>>(a, small);
+  prepare_art_kernel<<<dim3((kASmallFloats + 255) / 256), dim3(256), 0, stream>>>(a, small, min_deg, pos_levels, view_levels);
   return hipGetLastError();
 }
 

@@ -526,6 +526,38 @@ __device__ __forceinline__ void store_view_enc_plane(const f32x16& V, const Plan
 // Positional / view encodings directly in accumulator (= next layer's B operand) layout: lanes 0-31 hold the sin
 // features, lanes 32-63 the sin(. + fp32(pi/2)) features of the same sample; the identity features ride in the
 // last registers (pack kernels: posenc_col / viewenc_col).  helper.py:136-140.
+// L / Lv: frequency levels of a network's encodings (max_deg_point - min_deg_point <= 10, deg_view <= 4).  The streams always have the
+// 63 / 27-wide slots of the default geometry; a network with fewer levels leaves the slots of the missing levels at zero weight.
+__device__ __forceinline__ int pos_col_in(int c63, int L) {   // column of the 63-slot layout -> column of the (3 + 6 L)-wide weight
+  if (c63 < 3) return c63;
+  const bool second = c63 >= 33;
+  const int e = second ? c63 - 33 : c63 - 3;
+  return e / 3 < L ? 3 + e + (second ? 3 * L : 0) : -1;
+}
+__device__ __forceinline__ int view_col_in(int c27, int Lv) {
+  if (c27 < 3) return c27;
+  const bool second = c27 >= 15;
+  const int e = second ? c27 - 15 : c27 - 3;
+  return e / 3 < Lv ? 3 + e + (second ? 3 * Lv : 0) : -1;
+}
+
+// pos_enc with RUN-TIME scales (round 4: the articulated network at other encoding degrees): scale[l] = 2^(min_deg + l) for the levels
+// the network has, 0 for the slots it lacks (their weights are zero; a zero argument keeps the slot finite) -- ten floats of the
+// per-call small block in LDS.  x * 2^(min_deg + l) is ONE exact multiplication, as helper.py:137-138 does it.
+__device__ __forceinline__ void encode_pos_scaled(const float (&x)[3], int h, const float* sm_scale, f32x16 (&E)[2]) {
+  const float phase = h ? AON_HALF_PI_F32 : 0.f;
+  float sc[10];
+#pragma unroll
+  for (int l = 0; l < 10; ++l) sc[l] = sm_scale[l];
+#pragma unroll
+  for (int rho = 0; rho < 30; ++rho) {
+    const float xb = __fmul_rn(x[rho % 3], sc[rho / 3]);
+    E[rho >> 4][rho & 15] = sin_f32(__fadd_rn(xb, phase));
+  }
+  E[1][14] = h ? x[2] : x[0];
+  E[1][15] = h ? 0.f : x[1];
+}
+
 __device__ __forceinline__ void encode_pos(const float (&x)[3], int h, f32x16 (&E)[2]) {
   const float phase = h ? AON_HALF_PI_F32 : 0.f;
 #pragma unroll

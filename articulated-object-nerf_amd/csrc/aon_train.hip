@@ -390,7 +390,7 @@ hipError_t run_wgrad_plan(const WgLayerDesc* layers, int nlayers, const HeadDesc
   int part_offs[kHeadMaxJobs];
   if (nheads > kHeadMaxJobs || nouts > kHeadMaxOut) return hipErrorInvalidValue;
   const int head_blocks = head_make_plan(heads, nheads, rows_total, Np, ws, off, H, part_offs);
-  if (off * 4 > wgrad_workspace_bytes_impl()) return hipErrorInvalidValue;
+  if (off * 4 > wgrad_workspace_bytes_impl() - (1 << 20)) return hipErrorInvalidValue;   // (the last MiB: slot-layout blocks of the articulated network at other degrees)
   int nseg; int64_t seg_len;
   head_segments(Np, nseg, seg_len);
   ReduceArgs& R = plan.red;

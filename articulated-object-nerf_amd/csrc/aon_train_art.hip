@@ -36,7 +36,8 @@ struct ArtParams {
   const float* p[kNumArtParams];
 };
 
-__global__ void pack_art_bwd_kernel(ArtParams a, float* __restrict__ packed) {
+__global__ void pack_art_bwd_kernel(ArtParams a, float* __restrict__ packed, int L, int Lv) {
+  const int P = 3 + 6 * L, V = 3 + 6 * Lv;   // (row strides of the three concatenating layers; the view-encoding columns are never read)
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= kABwStreamBytes / 4) return;
   // locate the chunk (108 chunks: linear scan is fine for a pack kernel)
@@ -53,18 +54,19 @@ __global__ void pack_art_bwd_kernel(ArtParams a, float* __restrict__ packed) {
   const float* W; int ld, j, col = f;
   auto enc_col = [&]() {  // accumulator row i of tile tp -> encoding register rho of half h'
     const int rr = (i & 3) + 4 * (i >> 3), hh = (i >> 2) & 1;
-    return posenc_col(tp, rr >> 2, rr & 3, hh);
+    const int c63 = posenc_col(tp, rr >> 2, rr & 3, hh);
+    return c63 < 0 ? -1 : pos_col_in(c63, L);   // a level the network lacks: zero weight, zero gradient into its slot
   };
   if (c < kABwV0) { const int l = 3 - c / 4; W = a.p[26 + 2 * l]; ld = 128; j = 32 * (c % 4) + jo; }
-  else if (c < kABwBott) { W = a.p[26]; ld = 411; j = 32 * (c - kABwV0) + jo; }
+  else if (c < kABwBott) { W = a.p[26]; ld = 256 + V + 128; j = 32 * (c - kABwV0) + jo; }
   else if (c < kABwL7) { W = a.p[34]; ld = 256; j = 32 * (c - kABwBott) + jo; }
   else if (c < kABwL5E) { const int l = 7 - (c - kABwL7) / 8; W = a.p[10 + 2 * l]; ld = 256; j = 32 * ((c - kABwL7) % 8) + jo; }
-  else if (c < kABwL5) { W = a.p[20]; ld = 447; j = 32 * (c - kABwL5E) + jo; col = enc_col(); if (col >= 0) col += 256; }
+  else if (c < kABwL5) { W = a.p[20]; ld = 256 + P + 128; j = 32 * (c - kABwL5E) + jo; col = enc_col(); if (col >= 0) col += 256; }
   else if (c < kABwL0E) {
     const int l = 5 - (c - kABwL5) / 8;  // 5,4,3,2,1
-    W = a.p[10 + 2 * l]; ld = l == 5 ? 447 : 256; j = 32 * ((c - kABwL5) % 8) + jo;
+    W = a.p[10 + 2 * l]; ld = l == 5 ? 256 + P + 128 : 256; j = 32 * ((c - kABwL5) % 8) + jo;
   }
-  else if (c < kABwD3) { W = a.p[10]; ld = 191; j = 32 * (c - kABwL0E) + jo; col = enc_col(); }
+  else if (c < kABwD3) { W = a.p[10]; ld = P + 128; j = 32 * (c - kABwL0E) + jo; col = enc_col(); }
   else { const int l = 3 - (c - kABwD3) / 4; W = a.p[2 * l]; ld = 128; j = 32 * ((c - kABwD3) % 4) + jo; }
   packed[idx] = col >= 0 ? W[(int64_t)j * ld + col] : 0.f;
 }
@@ -229,7 +231,7 @@ __global__ void __launch_bounds__(256) art_bwd_chain_kernel(ArtBwdArgs args) {
     float dx[3] = {0.f, 0.f, 0.f};
 #pragma unroll
     for (int rho = 0; rho < 30; ++rho) {
-      const float scale = (float)(1 << (rho / 3));
+      const float scale = sm[kA_ESC + rho / 3];   // 2^(min_deg_point + l), 0 for a level the network lacks (aon_art_prepare)
       const float arg = __fadd_rn(__fmul_rn(xd[rho % 3], scale), phase);
       const float c = cos_f32(arg);  // d/d(arg) sin(arg), at the forward's own (rounded) argument
       dx[rho % 3] = __builtin_fmaf(scale * c, dE[rho >> 4][rho & 15], dx[rho % 3]);
@@ -331,11 +333,11 @@ __global__ void __launch_bounds__(1024) art_finish_kernel(ArtFinishArgs a) {
 // ---------------------------------------------------------------------------------------------
 int num_cus();
 
-hipError_t launch_pack_art_bwd(const float* const* params, float* packed, hipStream_t stream) {
+hipError_t launch_pack_art_bwd(const float* const* params, float* packed, hipStream_t stream, int pos_levels, int view_levels) {
   ArtParams a;
   for (int i = 0; i < kNumArtParams; ++i) a.p[i] = params[i];
   const int64_t n = kABwStreamBytes / 4;
-  pack_art_bwd_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream>>>(a, packed);
+  pack_art_bwd_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream>>>(a, packed, pos_levels, view_levels);
   return hipGetLastError();
 }
 
@@ -370,34 +372,61 @@ hipError_t launch_art_bwd_chain(const char* packed_bwd, const float* small, cons
 hipError_t run_wgrad_plan(const WgLayerDesc* layers, int nlayers, const HeadDesc* heads, int nheads, const HeadOut* outs, const int* out_head, int nouts,
                           const float* planes, const float* dplanes, int rows_total, int64_t Np, float* ws, hipStream_t stream, const WgAux* aux);   // aon_train.hip
 
-// the weight-gradient jobs of one articulated level
-int art_wgrad_layers(float* const* grads, WgLayerDesc* L) {
+// the weight-gradient jobs of one articulated level.  Lp / Lv: frequency levels of the network (10 / 4 by default).  With other degrees
+// the three encoding-fed column blocks come out in the kernels' 63 / 27-slot layout into `enc_tmp` (256 x 64 | 256 x 64 | 128 x 32
+// floats) and lose the empty slots afterwards (art_remap_enc_kernel); the row strides of the concatenating layers follow P and V.
+int art_wgrad_layers(float* const* grads, WgLayerDesc* L, int Lp, int Lv, float* enc_tmp) {
+  const bool dflt = Lp == 10 && Lv == 4;
+  const int P = 3 + 6 * Lp, V = 3 + 6 * Lv;
   int n = 0;
   // deformation MLP (model_autodecoder.py:196-203): layers 1..3 here; layer 0's three position columns go with the heads below
   // (its input is cat[pos(3), shape(128), articulation(32)]: a 16-byte record per sample, not a plane operand)
   for (int l = 1; l < 4; ++l) L[n++] = WgLayerDesc{kWg128x128, aplane_d(l), aplane_d(l - 1), grads[2 * l], 128, 0, 128, grads[2 * l + 1]};
-  // trunk (:210-217): layer 0 input cat[enc(63), shape(128)], layer 5 input cat[h(256), enc(63), shape(128)]
-  L[n++] = WgLayerDesc{kWg256x64, aplane_h(0), kAPlE, grads[10], 191, 0, kPosEnc, grads[11]};
+  // trunk (:210-217): layer 0 input cat[enc(P), shape(128)], layer 5 input cat[h(256), enc(P), shape(128)]
+  if (dflt) L[n++] = WgLayerDesc{kWg256x64, aplane_h(0), kAPlE, grads[10], P + 128, 0, kPosEnc, grads[11]};
+  else L[n++] = WgLayerDesc{kWg256x64, aplane_h(0), kAPlE, enc_tmp, 64, 0, kPosEnc, grads[11]};
   for (int l = 1; l < 8; ++l) {
-    const int ld = l == 5 ? 447 : 256;
+    const int ld = l == 5 ? 256 + P + 128 : 256;
     L[n++] = WgLayerDesc{kWg256x256, aplane_h(l), aplane_h(l - 1), grads[10 + 2 * l], ld, 0, 256, grads[11 + 2 * l]};
-    if (l == 5) L[n++] = WgLayerDesc{kWg256x64, aplane_h(5), kAPlE, grads[20], ld, 256, kPosEnc, nullptr};
+    if (l == 5) {
+      if (dflt) L[n++] = WgLayerDesc{kWg256x64, aplane_h(5), kAPlE, grads[20], ld, 256, kPosEnc, nullptr};
+      else L[n++] = WgLayerDesc{kWg256x64, aplane_h(5), kAPlE, enc_tmp + 256 * 64, 64, 0, kPosEnc, nullptr};
+    }
   }
   L[n++] = WgLayerDesc{kWg256x256, kAPlBot, aplane_h(7), grads[34], 256, 0, 256, grads[35]};
-  // view branch (:227-234): layer 0 input cat[bottleneck(256), viewenc(27), appearance(128)]: two column blocks from the planes
-  L[n++] = WgLayerDesc{kWg128x256, aplane_v(0), kAPlBot, grads[26], 411, 0, 256, grads[27]};
-  L[n++] = WgLayerDesc{kWg128x32, aplane_v(0), kAPlVE, grads[26], 411, 256, kViewEnc, nullptr};
+  // view branch (:227-234): layer 0 input cat[bottleneck(256), viewenc(V), appearance(128)]: two column blocks from the planes
+  L[n++] = WgLayerDesc{kWg128x256, aplane_v(0), kAPlBot, grads[26], 256 + V + 128, 0, 256, grads[27]};
+  if (dflt) L[n++] = WgLayerDesc{kWg128x32, aplane_v(0), kAPlVE, grads[26], 256 + V + 128, 256, kViewEnc, nullptr};
+  else L[n++] = WgLayerDesc{kWg128x32, aplane_v(0), kAPlVE, enc_tmp + 2 * 256 * 64, 32, 0, kViewEnc, nullptr};
   for (int l = 1; l < 4; ++l) L[n++] = WgLayerDesc{kWg128x128, aplane_v(l), aplane_v(l - 1), grads[26 + 2 * l], 128, 0, 128, grads[27 + 2 * l]};
   return n;
+}
+int art_wgrad_layers(float* const* grads, WgLayerDesc* L) { return art_wgrad_layers(grads, L, 10, 4, nullptr); }
+
+// dst[r * ldd + col_off + c] = src[r * lds + slot(c)] for the c < 3 + 6 L columns of an encoding with L levels, taken out of the kernels'
+// Lfull-level slot layout [x ; first block of 3 Lfull ; shifted block of 3 Lfull]
+__global__ void art_remap_enc_kernel(const float* __restrict__ src, int lds, float* __restrict__ dst, int ldd, int col_off, int rows, int L, int Lfull) {
+  const int cols = 3 + 6 * L;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * cols) return;
+  const int r = i / cols, c = i % cols;
+  const int sc = c < 3 + 3 * L ? c : c + 3 * (Lfull - L);
+  dst[(int64_t)r * ldd + col_off + c] = src[(int64_t)r * lds + sc];
 }
 
 // grads: 40 parameter gradients (order of aon_pack_art_mlp, full shapes) + 3 latent gradients (shape 128, appearance 128,
 // articulation 32); params / latents: the forward's inputs (needed for the latent-column products).
 hipError_t launch_art_wgrad(const float* planes, const float* dplanes, const float* d_raw, const float* dxp, int64_t Np,
                             const float* const* params, const float* shape, const float* app, const float* art,
-                            float* const* grads, float* g_shape, float* g_app, float* g_art, float* ws, hipStream_t stream, const WgAux* aux) {
+                            float* const* grads, float* g_shape, float* g_app, float* g_art, float* ws, hipStream_t stream, const WgAux* aux,
+                            int Lp, int Lv) {
   WgLayerDesc L[kWgMaxJobs];
-  const int n = art_wgrad_layers(grads, L);
+  const int P = 3 + 6 * Lp, V = 3 + 6 * Lv;
+  const bool dflt = Lp == 10 && Lv == 4;
+  // (other degrees: the slot-layout blocks live in the last MiB of the weight-gradient workspace, which no plan reaches: 70 of 96 MiB
+  // are used at 4096 x 193 samples, and run_wgrad_plan refuses plans beyond the workspace)
+  float* enc_tmp = ws + (wgrad_workspace_bytes_impl() - (1 << 20)) / 4;
+  const int n = art_wgrad_layers(grads, L, Lp, Lv, enc_tmp);
   // heads: density (H7 x d_raw.w), rgb (V3 x d_raw.xyz), deformation_layer (D3 x dx'), their bias sums, and deformation layer 0:
   // dW[:, 0:3] = dZ_D0 x pos (the position is rows 0..2 of unit row kAPlPos / 4 of the forward planes), db = row sums of dZ_D0
   const int64_t unit_step = (int64_t)kAPlRows * 32;
@@ -409,15 +438,25 @@ hipError_t launch_art_wgrad(const float* planes, const float* dplanes, const flo
                         {0, 128, 0, 3, 1, 163, grads[0]},  {0, 128, 4, 1, 1, 1, grads[1]}};
   const int OH[8] = {0, 1, 2, 2, 3, 4, 5, 5};
   if (hipError_t e = run_wgrad_plan(L, n, H, 6, O, OH, 8, planes, dplanes, kAPlRows, Np, ws, stream, aux); e != hipSuccess) return e;
+  if (!dflt) {
+    auto remap = [&](const float* src, int lds, float* dst, int ldd, int col_off, int rows, int Lx, int Lfull) {
+      const int tot = rows * (3 + 6 * Lx);
+      art_remap_enc_kernel<<<dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream>>>(src, lds, dst, ldd, col_off, rows, Lx, Lfull);
+    };
+    remap(enc_tmp, 64, grads[10], P + 128, 0, 256, Lp, 10);
+    remap(enc_tmp + 256 * 64, 64, grads[20], 256 + P + 128, 256, 256, Lp, 10);
+    remap(enc_tmp + 2 * 256 * 64, 32, grads[26], 256 + V + 128, 256, 128, Lv, 4);
+    if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
+  }
   // latent columns of the weights and the latent gradients, both from the bias gradients
   ArtFinishArgs F{};
   LatentJob& ls = F.lat[0];   // shape: deformation layer 0, trunk layers 0 and 5
   ls.W[0] = params[0]; ls.db[0] = grads[1]; ls.ld[0] = 163; ls.col_off[0] = 3; ls.M[0] = 128;
-  ls.W[1] = params[10]; ls.db[1] = grads[11]; ls.ld[1] = 191; ls.col_off[1] = 63; ls.M[1] = 256;
-  ls.W[2] = params[20]; ls.db[2] = grads[21]; ls.ld[2] = 447; ls.col_off[2] = 319; ls.M[2] = 256;
+  ls.W[1] = params[10]; ls.db[1] = grads[11]; ls.ld[1] = P + 128; ls.col_off[1] = P; ls.M[1] = 256;
+  ls.W[2] = params[20]; ls.db[2] = grads[21]; ls.ld[2] = 256 + P + 128; ls.col_off[2] = 256 + P; ls.M[2] = 256;
   ls.npairs = 3; ls.L = 128; ls.out = g_shape;
   LatentJob& la = F.lat[1];   // appearance: view layer 0
-  la.W[0] = params[26]; la.db[0] = grads[27]; la.ld[0] = 411; la.col_off[0] = 283; la.M[0] = 128;
+  la.W[0] = params[26]; la.db[0] = grads[27]; la.ld[0] = 256 + V + 128; la.col_off[0] = 256 + V; la.M[0] = 128;
   la.npairs = 1; la.L = 128; la.out = g_app;
   LatentJob& lt = F.lat[2];   // articulation: deformation layer 0
   lt.W[0] = params[0]; lt.db[0] = grads[1]; lt.ld[0] = 163; lt.col_off[0] = 131; lt.M[0] = 128;
@@ -429,9 +468,9 @@ hipError_t launch_art_wgrad(const float* planes, const float* dplanes, const flo
   };
   outer(0, grads[1], shape, grads[0], 128, 128, 163, 3);
   outer(1, grads[1], art, grads[0], 128, 32, 163, 131);
-  outer(2, grads[11], shape, grads[10], 256, 128, 191, 63);
-  outer(3, grads[21], shape, grads[20], 256, 128, 447, 319);
-  outer(4, grads[27], app, grads[26], 128, 128, 411, 283);
+  outer(2, grads[11], shape, grads[10], 256, 128, P + 128, P);
+  outer(3, grads[21], shape, grads[20], 256, 128, 256 + P + 128, 256 + P);
+  outer(4, grads[27], app, grads[26], 128, 128, 256 + V + 128, 256 + V);
   art_finish_kernel<<<dim3(blk), dim3(1024), 0, stream>>>(F);
   return hipGetLastError();
 }

@@ -29,22 +29,28 @@ class NeRFMLP(nn.Module):
                     netdepth_condition, netwidth_condition, shape_latent_dim, appearance_latent_dim, articulation_latent_dim,
                     skip_layer, input_ch, input_ch_view, num_rgb_channels, num_density_channels, deformation_mlp, enc_after,
                     embed_deg)
-        if geometry != (0, 10, 4, 8, 256, 4, 128, 4, 128, 128, 128, 32, 4, 3, 3, 3, 1, True, True, False):
-            raise NotImplementedError(f"articulated NeRFMLP geometry {geometry} has no HIP kernel (only the reference defaults do)")
+        if geometry[3:] != (8, 256, 4, 128, 4, 128, 128, 128, 32, 4, 3, 3, 3, 1, True, True, False):
+            raise NotImplementedError(f"articulated NeRFMLP geometry {geometry} has no HIP kernel (the reference's default widths / latent sizes "
+                                      "do, at any encoding degrees of up to 10 position and 4 view levels; enc_after=False and embed_deg=True "
+                                      "change the network, model_autodecoder.py:95-103,181-184)")
+        # round 4: other encoding degrees on the same kernels (zero-weight slots + run-time encoding scales, aon_pack_art_mlp_deg)
+        self.degrees = (int(min_deg_point), int(max_deg_point), int(deg_view))
+        ops.art_param_shapes(self.degrees)      # raises for more than 10 / 4 levels
         self.net_activation = nn.ReLU()
         self.enc_after, self.embed_deg, self.deformation_mlp = enc_after, embed_deg, deformation_mlp
         self.netdepth, self.netdepth_deformation, self.netdepth_condition, self.skip_layer = netdepth, 4, 4, skip_layer
-        self.min_deg_point, self.max_deg_point = min_deg_point, max_deg_point
+        self.min_deg_point, self.max_deg_point, self.deg_view = min_deg_point, max_deg_point, deg_view
         self.num_rgb_channels, self.num_density_channels = num_rgb_channels, num_density_channels
         deform = [nn.Linear(3 + 128 + 32, 128)] + [nn.Linear(128, 128) for _ in range(3)]
         self.deformations_linear = nn.ModuleList(deform)
         self.deformation_layer = nn.Linear(128, 3)
-        pos_size = 63 + 128
+        pos_size = ((max_deg_point - min_deg_point) * 2 + 1) * 3 + 128        # model_autodecoder.py:127-129
+        view_pos_size = (deg_view * 2 + 1) * 3                                # :91
         pts = [nn.Linear(pos_size, 256)]
         for idx in range(7):
             pts.append(nn.Linear(256 + pos_size if (idx % skip_layer == 0 and idx > 0) else 256, 256))
         self.pts_linears = nn.ModuleList(pts)
-        self.views_linear = nn.ModuleList([nn.Linear(256 + 27 + 128, 128)] + [nn.Linear(128, 128) for _ in range(3)])
+        self.views_linear = nn.ModuleList([nn.Linear(256 + view_pos_size + 128, 128)] + [nn.Linear(128, 128) for _ in range(3)])
         self.bottleneck_layer = nn.Linear(256, 256)
         self.density_layer = nn.Linear(256, 1)
         self.rgb_layer = nn.Linear(128, 3)
@@ -63,7 +69,7 @@ class NeRFMLP(nn.Module):
         out = None if fresh else self._streams.get(kind)
         if out is not None and out.device != dev:
             out = None
-        out = getattr(ops, self._PACKERS[kind])(params, out=out)
+        out = getattr(ops, self._PACKERS[kind])(params, out=out, degrees=self.degrees)
         if not fresh:
             self._streams[kind] = out
         return out
@@ -83,12 +89,18 @@ class NeRFMLP(nn.Module):
         params = dict(self.named_parameters())
         dev = next(iter(params.values())).device
         out = self._small if (self._small is not None and self._small.device == dev) else None
-        self._small = ops.art_prepare(params, latents, out=out)
+        self._small = ops.art_prepare(params, latents, out=out, degrees=self.degrees)
         return self._small
 
     def forward(self, pos, condition, latents):
         if self.embed_deg:
             raise NotImplementedError
+        dv = self.degrees[2]
+        if dv != 4:   # the kernel reads the view encoding in its 27-wide slot layout [v ; sin block of 12 ; shifted block of 12]
+            padded = condition.new_zeros((condition.shape[0], 27))
+            padded[:, : 3 + 3 * dv] = condition[:, : 3 + 3 * dv]
+            padded[:, 15: 15 + 3 * dv] = condition[:, 3 + 3 * dv:]
+            condition = padded
         raw = ops.art_mlp_fwd_pos(self.packed(), self.prepared(latents), pos, condition)
         return raw[..., :3], raw[..., 3:4]
 
@@ -107,7 +119,8 @@ class NeRF_AE_Art(nn.Module):
             raise NotImplementedError("enc_after=False / embed_deg=True change the network (model_autodecoder.py:95-103,181-184): only the "
                                       "reference's default articulated NeRFMLP has HIP kernels; num_levels must be 1 or 2")
         # sample counts, lindisp, noise_std, rgb_padding and density_bias are runtime arguments of the C calls (aon_render_opts)
-        self._opts = ops.RenderOpts(num_coarse_samples, num_fine_samples, lindisp, noise_std, rgb_padding, density_bias)
+        self._opts = ops.RenderOpts(num_coarse_samples, num_fine_samples, lindisp, noise_std, rgb_padding, density_bias,
+                                    degrees=(min_deg_point, max_deg_point, deg_view))   # (read by the backward for the gradients' layout)
         self.use_viewdirs, self.noise_std, self.lindisp = use_viewdirs, noise_std, lindisp
         self.num_levels, self.min_deg_point, self.max_deg_point, self.deg_view = num_levels, min_deg_point, max_deg_point, deg_view
         self.num_coarse_samples, self.num_fine_samples = num_coarse_samples, num_fine_samples
@@ -147,7 +160,7 @@ class NeRF_AE_Art(nn.Module):
             mlps = [self.coarse_mlp, self.fine_mlp][: self.num_levels]
             packs = []
             for mlp in mlps:
-                small = ops.art_prepare(dict(mlp.named_parameters()), latents)
+                small = ops.art_prepare(dict(mlp.named_parameters()), latents, degrees=mlp.degrees)
                 packs.append((mlp.packed(True), small, mlp.packed_bwd(True)))
             params = [p for mlp in mlps for p in mlp.ordered_params()]
             flat = RenderArticulated.apply(rays_o, rays["rays_d"], rays["viewdirs"], float(near), float(far), bool(white_bkgd),

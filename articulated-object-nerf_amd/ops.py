@@ -486,25 +486,41 @@ for _i in range(8):
     ART_PARAM_SHAPES[f"pts_linears.{_i}.bias"] = (256,)
 
 
-def _art_param_array(params: dict):
+def art_param_shapes(degrees=(0, 10, 4)) -> dict:
+    """Parameter shapes of the articulated NeRFMLP built with (min_deg_point, max_deg_point, deg_view) and default widths
+    (model_autodecoder.py:60-170): the three concatenating layers follow P = 3 + 6 (max - min), V = 3 + 6 deg_view."""
+    lo, hi, dv = (int(x) for x in degrees)
+    if not (0 <= hi - lo <= 10 and 0 <= dv <= 4 and -32 <= lo and hi <= 32):
+        raise NotImplementedError(f"articulated NeRFMLP with degrees {tuple(degrees)}: the kernels hold up to 10 position and 4 view frequency levels")
+    P, V = 3 + 6 * (hi - lo), 3 + 6 * dv
+    shapes = dict(ART_PARAM_SHAPES)
+    shapes["pts_linears.0.weight"] = (256, P + 128)
+    shapes["pts_linears.5.weight"] = (256, 256 + P + 128)
+    shapes["views_linear.0.weight"] = (128, 256 + V + 128)
+    return shapes
+
+
+def _art_param_array(params: dict, degrees=(0, 10, 4)):
     tensors = []
+    shapes = ART_PARAM_SHAPES if tuple(degrees) == (0, 10, 4) else art_param_shapes(degrees)
     for name in ART_PARAM_ORDER:
         t = _f32(params[name].detach(), name)
-        if tuple(t.shape) != ART_PARAM_SHAPES[name]:
-            raise ValueError(f"{name}: shape {tuple(t.shape)} != {ART_PARAM_SHAPES[name]} (only the reference's default "
-                             "articulated NeRFMLP geometry has a HIP kernel)")
+        if tuple(t.shape) != shapes[name]:
+            raise ValueError(f"{name}: shape {tuple(t.shape)} != {shapes[name]} (the articulated NeRFMLP has HIP kernels for the "
+                             f"reference's default widths at degrees {tuple(degrees)})")
         tensors.append(t)
     return tensors, (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
 
 
-def pack_art_mlp(params: dict, out: torch.Tensor | None = None) -> torch.Tensor:
-    """Packed weight stream of one articulated NeRFMLP (re-pack whenever the parameters change)."""
-    tensors, arr = _art_param_array(params)
+def pack_art_mlp(params: dict, out: torch.Tensor | None = None, degrees=(0, 10, 4)) -> torch.Tensor:
+    """Packed weight stream of one articulated NeRFMLP (re-pack whenever the parameters change); other ``degrees``: zero weight in the
+    63 / 27-wide slots of the levels the network lacks (aon_pack_art_mlp_deg)."""
+    tensors, arr = _art_param_array(params, degrees)
     dev = tensors[0].device
     if out is None:
         out = torch.empty(int(lib.aon_art_packed_bytes()), dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
-        check(lib.aon_pack_art_mlp(arr, _ptr(out), _stream()), "aon_pack_art_mlp")
+        check(lib.aon_pack_art_mlp_deg(arr, int(degrees[0]), int(degrees[1]), int(degrees[2]), _ptr(out), _stream()), "aon_pack_art_mlp_deg")
     return out
 
 
@@ -516,16 +532,17 @@ def _latent(latents: dict, key: str, width: int) -> torch.Tensor:
     return t
 
 
-def art_prepare(params: dict, latents: dict, out: torch.Tensor | None = None) -> torch.Tensor:
+def art_prepare(params: dict, latents: dict, out: torch.Tensor | None = None, degrees=(0, 10, 4)) -> torch.Tensor:
     """Per-call block: small vectors + biases with the three latents folded in (latents keys as the reference:
-    'density' (1,128), 'color' (1,128), 'articulation' (1,32))."""
-    tensors, arr = _art_param_array(params)
+    'density' (1,128), 'color' (1,128), 'articulation' (1,32)) + the ten encoding scales of ``degrees``."""
+    tensors, arr = _art_param_array(params, degrees)
     dev = tensors[0].device
     shape, app, art = _latent(latents, "density", 128), _latent(latents, "color", 128), _latent(latents, "articulation", 32)
     if out is None:
         out = torch.empty(int(lib.aon_art_small_bytes()), dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
-        check(lib.aon_art_prepare(arr, _ptr(shape), _ptr(app), _ptr(art), _ptr(out), _stream()), "aon_art_prepare")
+        check(lib.aon_art_prepare_deg(arr, _ptr(shape), _ptr(app), _ptr(art), int(degrees[0]), int(degrees[1]), int(degrees[2]), _ptr(out), _stream()),
+              "aon_art_prepare_deg")
     return out
 
 
@@ -683,13 +700,13 @@ def vanilla_wgrad(planes, dplanes, d_raw):
 
 
 # ------------------------------------------------------------------ R14 training (articulated)
-def pack_art_mlp_bwd(params: dict, out: torch.Tensor | None = None) -> torch.Tensor:
-    tensors, arr = _art_param_array(params)
+def pack_art_mlp_bwd(params: dict, out: torch.Tensor | None = None, degrees=(0, 10, 4)) -> torch.Tensor:
+    tensors, arr = _art_param_array(params, degrees)
     dev = tensors[0].device
     if out is None:
         out = torch.empty(int(lib.aon_art_bwd_packed_bytes()), dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
-        check(lib.aon_pack_art_mlp_bwd(arr, _ptr(out), _stream()), "aon_pack_art_mlp_bwd")
+        check(lib.aon_pack_art_mlp_bwd_deg(arr, int(degrees[0]), int(degrees[1]), int(degrees[2]), _ptr(out), _stream()), "aon_pack_art_mlp_bwd_deg")
     return out
 
 
@@ -717,7 +734,7 @@ def art_bwd_chain(packed_bwd, small, d_raw, masks, planes):
     return dplanes, dxp
 
 
-def art_wgrad(planes, dplanes, d_raw, dxp, params: dict, latents: dict):
+def art_wgrad(planes, dplanes, d_raw, dxp, params: dict, latents: dict, degrees=(0, 10, 4)):
     """-> (dict name -> parameter gradient, dict latent key -> gradient (flat))."""
     dev = planes.device
     key = str(dev)
@@ -725,15 +742,16 @@ def art_wgrad(planes, dplanes, d_raw, dxp, params: dict, latents: dict):
     if key not in _WG_WS or _WG_WS[key].numel() < need:
         _WG_WS[key] = torch.empty(need, dtype=torch.uint8, device=dev)
     ws = _WG_WS[key]
-    tensors, parr = _art_param_array(params)
+    tensors, parr = _art_param_array(params, degrees)
     shape, app, art = _latent(latents, "density", 128), _latent(latents, "color", 128), _latent(latents, "articulation", 32)
-    grads = {name: torch.empty(ART_PARAM_SHAPES[name], dtype=torch.float32, device=dev) for name in ART_PARAM_ORDER}
+    shapes = art_param_shapes(degrees)
+    grads = {name: torch.empty(shapes[name], dtype=torch.float32, device=dev) for name in ART_PARAM_ORDER}
     garr = (C.c_void_p * len(ART_PARAM_ORDER))(*[grads[n].data_ptr() for n in ART_PARAM_ORDER])
     g_lat = {"density": torch.empty(128, device=dev), "color": torch.empty(128, device=dev), "articulation": torch.empty(32, device=dev)}
     with torch.cuda.device(dev):
-        check(lib.aon_art_wgrad(_ptr(planes), _ptr(dplanes), _ptr(d_raw), _ptr(dxp), plane_samples(planes), parr, _ptr(shape), _ptr(app),
-                                _ptr(art), garr, _ptr(g_lat["density"]), _ptr(g_lat["color"]), _ptr(g_lat["articulation"]), _ptr(ws),
-                                ws.numel(), _stream()), "aon_art_wgrad")
+        check(lib.aon_art_wgrad_deg(_ptr(planes), _ptr(dplanes), _ptr(d_raw), _ptr(dxp), plane_samples(planes), parr, _ptr(shape), _ptr(app),
+                                    _ptr(art), garr, _ptr(g_lat["density"]), _ptr(g_lat["color"]), _ptr(g_lat["articulation"]), _ptr(ws),
+                                    ws.numel(), _stream(), int(degrees[0]), int(degrees[1]), int(degrees[2])), "aon_art_wgrad_deg")
     return grads, g_lat
 
 
@@ -840,11 +858,14 @@ def art_render_bwd(ws, packs_bwd, smalls, rays_d, white_bkgd, num_levels, g_rgb,
     """Articulated twin -> (per-level dicts of the 40 parameter gradients, dict of latent gradients summed over the levels)."""
     d = _f32(rays_d, "rays_d")
     n, dev = d.shape[0], d.device
-    grads = [{name: torch.empty(ART_PARAM_SHAPES[name], dtype=torch.float32, device=dev) for name in ART_PARAM_ORDER} for _ in range(num_levels)]
+    st0 = None if geometry is None else geometry[0]
+    degrees = (0, 10, 4) if st0 is None else (int(st0.min_deg_point), int(st0.max_deg_point), int(st0.deg_view))
+    shapes = art_param_shapes(degrees)
+    grads = [{name: torch.empty(shapes[name], dtype=torch.float32, device=dev) for name in ART_PARAM_ORDER} for _ in range(num_levels)]
     garr = [_ptr_array([g[nm] for nm in ART_PARAM_ORDER]) for g in grads] + [None] * (2 - num_levels)
     tens, parr = [], []
     for params in params_per_level:
-        t, arr = _art_param_array(params)
+        t, arr = _art_param_array(params, degrees)
         tens.append(t)
         parr.append(arr)
     parr += [None] * (2 - num_levels)

@@ -132,14 +132,15 @@ def make_smooth_nerf_state_dict(seed: int = 5, density_scale: float = 2.0, densi
     return sd
 
 
-def art_mlp_layout():
+def art_mlp_layout(min_deg_point: int = 0, max_deg_point: int = 10, deg_view: int = 4):
+    P, V = 3 + 6 * (max_deg_point - min_deg_point), 3 + 6 * deg_view      # model_autodecoder.py:91,127-129
     layout = [("deformations_linear.0", 128, 163, "xavier")]
     layout += [(f"deformations_linear.{i}", 128, 128, "xavier") for i in (1, 2, 3)]
     layout.append(("deformation_layer", 3, 128, "xavier"))
-    layout.append(("pts_linears.0", 256, 191, "xavier"))
+    layout.append(("pts_linears.0", 256, P + 128, "xavier"))
     for idx in range(7):
-        layout.append((f"pts_linears.{idx + 1}", 256, 447 if idx == 4 else 256, "xavier"))
-    layout.append(("views_linear.0", 128, 411, "kaiming"))
+        layout.append((f"pts_linears.{idx + 1}", 256, 256 + P + 128 if idx == 4 else 256, "xavier"))
+    layout.append(("views_linear.0", 128, 256 + V + 128, "kaiming"))
     layout += [(f"views_linear.{i}", 128, 128, "xavier") for i in (1, 2, 3)]
     layout.append(("bottleneck_layer", 256, 256, "xavier"))
     layout.append(("density_layer", 1, 256, "xavier"))
@@ -147,12 +148,13 @@ def art_mlp_layout():
     return layout
 
 
-def make_art_state_dict(seed: int = 0, density_scale: float = 30.0) -> "OrderedDict[str, torch.Tensor]":
-    """State dict with the reference's key names for ``NeRF_AE_Art`` (coarse_mlp.* / fine_mlp.*)."""
+def make_art_state_dict(seed: int = 0, density_scale: float = 30.0, **degrees) -> "OrderedDict[str, torch.Tensor]":
+    """State dict with the reference's key names for ``NeRF_AE_Art`` (coarse_mlp.* / fine_mlp.*); ``degrees``: min_deg_point,
+    max_deg_point, deg_view of the network (defaults 0, 10, 4)."""
     rng = np.random.Generator(np.random.PCG64(seed + 1000))
     sd = OrderedDict()
     for prefix in ("coarse_mlp", "fine_mlp"):
-        for k, v in make_mlp_state(rng, art_mlp_layout(), density_scale).items():
+        for k, v in make_mlp_state(rng, art_mlp_layout(**degrees), density_scale).items():
             sd[f"{prefix}.{k}"] = v
     return sd
 

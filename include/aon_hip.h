@@ -159,6 +159,15 @@ int aon_render_fwd(const void* packed_coarse, const void* packed_fine, const flo
 int64_t aon_art_packed_bytes(void);
 int64_t aon_art_small_bytes(void);
 int aon_pack_art_mlp(const float* const* params_host, void* packed, void* stream);
+/* Round 4: the articulated network at other encoding degrees (NeRFMLP(min_deg_point, max_deg_point, deg_view), model_autodecoder.py:60-170;
+ * at most 10 position and 4 view frequency levels, default widths).  The streams keep the kernels' 63 / 27-wide slots with zero weight in
+ * the levels the network lacks (row strides of pts_linears.0 / .5 and views_linear.0 follow P = 3 + 6 L, V = 3 + 6 Lv), and the small
+ * block carries the ten encoding scales 2^(min_deg_point + l) the kernels multiply the DEFORMED point by (0 for a missing level), so
+ * every aon_art_* call works unchanged on streams / blocks made by the _deg forms; aon_art_render_bwd_ex and aon_art_wgrad_deg take the
+ * degrees (aon_render_opts / arguments) for the layout of the gradients they write.  The plain forms are these with (0, 10, 4). */
+int aon_pack_art_mlp_deg(const float* const* params_host, int min_deg_point, int max_deg_point, int deg_view, void* packed, void* stream);
+int aon_art_prepare_deg(const float* const* params_host, const float* shape, const float* appearance, const float* articulation,
+                        int min_deg_point, int max_deg_point, int deg_view, void* small, void* stream);
 int aon_art_prepare(const float* const* params_host, const float* shape, const float* appearance,
                     const float* articulation, void* small, void* stream);
 int aon_art_mlp_fwd(const void* packed, const void* small, const float* rays_o, const float* rays_d,
@@ -229,6 +238,7 @@ int64_t aon_art_train_plane_rows(void);
 int64_t aon_art_train_mask_bytes(int64_t Np);
 int64_t aon_art_bwd_packed_bytes(void);
 int aon_pack_art_mlp_bwd(const float* const* params_host, void* packed_bwd, void* stream);
+int aon_pack_art_mlp_bwd_deg(const float* const* params_host, int min_deg_point, int max_deg_point, int deg_view, void* packed_bwd, void* stream);
 int aon_art_mlp_fwd_train(const void* packed, const void* small, const float* rays_o, const float* rays_d,
                           const float* viewdirs, const float* t_vals, int64_t n_rays, int S, float* raw, float* planes,
                           void* masks, void* stream);
@@ -238,6 +248,11 @@ int aon_art_wgrad(const float* planes, const float* dplanes, const float* d_raw,
                   const float* const* params_host, const float* shape, const float* appearance,
                   const float* articulation, float* const* grads_host, float* g_shape, float* g_appearance,
                   float* g_articulation, void* workspace, int64_t workspace_bytes, void* stream);
+int aon_art_wgrad_deg(const float* planes, const float* dplanes, const float* d_raw, const float* dxp, int64_t Np,
+                      const float* const* params_host, const float* shape, const float* appearance,
+                      const float* articulation, float* const* grads_host, float* g_shape, float* g_appearance,
+                      float* g_articulation, void* workspace, int64_t workspace_bytes, void* stream, int min_deg_point,
+                      int max_deg_point, int deg_view);
 
 /* ---- R14, the training step in two calls ----
  * aon_render_fwd_train = NeRF.forward under grad mode (model.py:147-199 as called by training_step :264): both levels,

@@ -290,7 +290,7 @@ def nerf_forward(sd, rays, randomized, white_bkgd, near, far, num_levels=2, min_
 # --------------------------------------------------------------------------------------------------
 # R10  articulated NeRFMLP              models/vanilla_nerf/model_autodecoder.py:172-239
 # --------------------------------------------------------------------------------------------------
-def art_mlp(sd: dict, prefix: str, pos, view_enc, latents: dict):
+def art_mlp(sd: dict, prefix: str, pos, view_enc, latents: dict, min_deg_point: int = 0, max_deg_point: int = 10):
     """model_autodecoder.py:172-239 (deformation_mlp=True, enc_after=True, embed_deg=False).
     pos (N,S,3) raw sample positions, view_enc (N,27), latents = {"density": (1,128), "color": (1,128),
     "articulation": (1,32)} broadcast to every sample (einops.repeat, :186-194)."""
@@ -305,7 +305,7 @@ def art_mlp(sd: dict, prefix: str, pos, view_enc, latents: dict):
     for i in range(4):
         x = F.relu(lin(f"deformations_linear.{i}", x))
     x = lin("deformation_layer", x) + p
-    x = pos_enc(x, 0, 10)
+    x = pos_enc(x, min_deg_point, max_deg_point)                      # model_autodecoder.py:207-212
     x = torch.cat([x, shape], -1)
     inputs = x
     for idx in range(8):
@@ -327,7 +327,7 @@ def art_mlp(sd: dict, prefix: str, pos, view_enc, latents: dict):
 # --------------------------------------------------------------------------------------------------
 def nerf_ae_art_forward(sd, rays, randomized, white_bkgd, near, far, latents, num_levels=2, t_rand=None, u=None,
                         return_aux=False, num_coarse_samples=64, num_fine_samples=128, lindisp=False, noise_std=0.0, noise=None,
-                        rgb_padding=0.001, density_bias=-1.0):
+                        rgb_padding=0.001, density_bias=-1.0, min_deg_point=0, max_deg_point=10, deg_view=4):
     ret, aux = [], []
     t_vals = weights = None
     for i_level in range(num_levels):
@@ -338,8 +338,8 @@ def nerf_ae_art_forward(sd, rays, randomized, white_bkgd, near, far, latents, nu
             t_mids = 0.5 * (t_vals[..., 1:] + t_vals[..., :-1])
             t_vals, samples = sample_pdf(t_mids, weights[..., 1:-1], rays["rays_o"], rays["rays_d"], t_vals, num_fine_samples, randomized, u)
             prefix = "fine_mlp."
-        viewdirs_enc = pos_enc(rays["viewdirs"], 0, 4)
-        raw_rgb, raw_sigma = art_mlp(sd, prefix, samples, viewdirs_enc, latents)  # samples un-encoded (:306-307)
+        viewdirs_enc = pos_enc(rays["viewdirs"], 0, deg_view)                      # :315
+        raw_rgb, raw_sigma = art_mlp(sd, prefix, samples, viewdirs_enc, latents, min_deg_point, max_deg_point)  # samples un-encoded (:306-307)
         if noise_std > 0 and randomized:                                           # :318-319
             raw_sigma = raw_sigma + noise[i_level].reshape(raw_sigma.shape) * noise_std
         rgb = torch.sigmoid(raw_rgb) * (1 + 2 * rgb_padding) - rgb_padding        # :321-322

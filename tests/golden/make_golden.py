@@ -591,6 +591,38 @@ def main():
                 arrs[f"nerf_{tag}_{t2}_{name}_rgb"], arrs[f"nerf_{tag}_{t2}_{name}_acc"], arrs[f"nerf_{tag}_{t2}_{name}_depth"] = out[lvl]
     save("g17_general_mlp", **arrs)
 
+    # ---------------- G18 articulated network at other encoding degrees (round 4) ----------------
+    # NeRF_AE_Art(min_deg_point, max_deg_point, deg_view) of the REAL reference (model_autodecoder.py:241-337 / NeRFMLP :60-239), smooth
+    # weights by seed, the stage-level NeRFMLP and the whole path, deterministic and randomized with named draws
+    N18 = 192
+    g18 = torch.Generator().manual_seed(1818)     # its own stream: the fixtures after this section keep their bits
+    arrs = {}
+    rays_18 = {k: v[:N18].contiguous() for k, v in rays_a.items()}
+    arrs.update({k: v for k, v in rays_18.items()})
+    arrs.update({"lat_" + k: v for k, v in lat_train.items()})
+    for tag, gk in (("a", dict(min_deg_point=0, max_deg_point=6, deg_view=2)), ("b", dict(min_deg_point=-1, max_deg_point=9, deg_view=4)),
+                    ("c", dict(min_deg_point=2, max_deg_point=5, deg_view=0))):
+        sd18 = syn.make_art_state_dict(seed=18, density_scale=2.0, **gk)
+        m18 = NeRF_AE_Art(**gk)
+        m18.load_state_dict(sd18, strict=True)
+        m18.eval()
+        tr18, u18 = syn.seeded_uniform(1880 + ord(tag), N18, 65), syn.seeded_uniform(1890 + ord(tag), N18, 128)
+        with torch.no_grad():
+            od = m18(rays_18, False, True, 2.0, 6.0, lat_train)
+            with patched_rand([tr18, u18]):
+                orn = m18(rays_18, True, False, 2.0, 6.0, lat_train)
+            # the stage-level module on raw positions + encoded view directions
+            pos18 = (torch.rand((5, 13, 3), generator=g18) * 2 - 1) * 3.0
+            cond18 = helper.pos_enc(rays_18["viewdirs"][:5], 0, gk["deg_view"])
+            rr, rd = m18.fine_mlp(pos18, cond18, lat_train)
+        arrs[f"{tag}_cfg"] = np.asarray([gk["min_deg_point"], gk["max_deg_point"], gk["deg_view"]])
+        arrs[f"{tag}_seeds"] = np.asarray([1880 + ord(tag), 1890 + ord(tag)])
+        arrs[f"{tag}_mlp_pos"], arrs[f"{tag}_mlp_cond"], arrs[f"{tag}_mlp_raw_rgb"], arrs[f"{tag}_mlp_raw_density"] = pos18, cond18, rr, rd
+        for t2, out in (("det", od), ("rnd", orn)):
+            for lvl, name in ((0, "coarse"), (1, "fine")):
+                arrs[f"{tag}_{t2}_{name}_rgb"], arrs[f"{tag}_{t2}_{name}_acc"], arrs[f"{tag}_{t2}_{name}_depth"] = out[lvl]
+    save("g18_art_degrees", **arrs)
+
     # ---------------- G13 metrics ----------------
     a = torch.rand((5, 16, 16, 3), generator=g) * 1.2 - 0.1
     b = torch.rand((5, 16, 16, 3), generator=g)

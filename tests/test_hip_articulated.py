@@ -162,3 +162,74 @@ def test_articulated_frame_320x240_properties(dev, art_sd):
     rays_cpu = {k: v[pick.to(dev)].cpu() for k, v in rays.items()}
     ref = orc.nerf_ae_art_forward(art_sd, rays_cpu, False, True, 2.0, 6.0, {k: v.cpu() for k, v in lat.items()})
     assert_render_close(full[1][0][pick.to(dev)].cpu(), ref[1][0], "320x240 strided sample vs oracle")
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_articulated_network_at_other_degrees(dev, golden, tag):
+    """NeRF_AE_Art(min_deg_point, max_deg_point, deg_view) with up to 10 / 4 frequency levels on the fused articulated kernels (round 4:
+    zero-weight slots in the packed streams, the encoding scales 2^(min_deg_point + l) as run-time values of the per-call block) against
+    the REAL reference built with those arguments (G18): (0, 6, 2), (-1, 9, 4), (2, 5, 0); the stage-level NeRFMLP on raw positions,
+    the whole path deterministic and randomized on every ray (smooth field: the bars of test_hip_smooth.py), and the gradients of
+    the training loss -- every parameter and latent -- by the fp64-truth yardstick."""
+    import sys
+
+    import aon_amd.synthetic as syn
+    from aon_amd.models.vanilla_nerf.model_autodecoder import NeRF_AE_Art
+
+    sys.path.insert(0, __import__("os").path.dirname(__file__))
+    from _gradcheck import assert_as_close_as_fp32
+
+    g = golden("g18_art_degrees")
+    mn, mx, dv = g[f"{tag}_cfg"].tolist()
+    gk = dict(min_deg_point=mn, max_deg_point=mx, deg_view=dv)
+    sd = syn.make_art_state_dict(seed=18, density_scale=2.0, **gk)
+    model = NeRF_AE_Art(**gk).to(dev)
+    model.load_state_dict(sd)
+    rays_cpu = {k: g[k] for k in ("rays_o", "rays_d", "viewdirs")}
+    rays = {k: v.to(dev) for k, v in rays_cpu.items()}
+    lat_cpu = {k: g["lat_" + k] for k in ("density", "color", "articulation")}
+    lat = {k: v.to(dev) for k, v in lat_cpu.items()}
+    n = rays["rays_o"].shape[0]
+    with torch.no_grad():
+        rgb, dens = model.fine_mlp(g[f"{tag}_mlp_pos"].to(dev), g[f"{tag}_mlp_cond"].to(dev), lat)
+    torch.testing.assert_close(rgb.cpu(), g[f"{tag}_mlp_raw_rgb"], rtol=5e-5, atol=5e-5)
+    torch.testing.assert_close(dens.cpu(), g[f"{tag}_mlp_raw_density"], rtol=5e-5, atol=2e-4)
+    s = g[f"{tag}_seeds"].tolist()
+    tr, u = syn.seeded_uniform(s[0], n, 65), syn.seeded_uniform(s[1], n, 128)
+    with torch.no_grad():
+        outs = {"det": model(rays, False, True, 2.0, 6.0, lat), "rnd": model(rays, True, False, 2.0, 6.0, lat, t_rand=tr.to(dev), u=u.to(dev))}
+    for t2, out in outs.items():
+        for lvl, name in ((0, "coarse"), (1, "fine")):
+            r, a, d = (x.cpu() for x in out[lvl])
+            print(f"degrees {(mn, mx, dv)} {t2} {name}: max |rgb - ref| {(r - g[f'{tag}_{t2}_{name}_rgb']).abs().max():.2e}, "
+                  f"depth {(d - g[f'{tag}_{t2}_{name}_depth']).abs().max():.2e}")
+            torch.testing.assert_close(r, g[f"{tag}_{t2}_{name}_rgb"], rtol=0, atol=2e-6)
+            torch.testing.assert_close(a, g[f"{tag}_{t2}_{name}_acc"], rtol=0, atol=2e-6)
+            torch.testing.assert_close(d, g[f"{tag}_{t2}_{name}_depth"], rtol=0, atol=2e-5)
+    # gradients (96 rays, randomized with the named draws)
+    m = 96
+    rc = {k: v[:m] for k, v in rays_cpu.items()}
+    target = syn.seeded_uniform(1899, m, 3)
+
+    def oracle_grads(dtype):
+        sd_o = {k: v.detach().clone().to(dtype).requires_grad_(True) for k, v in sd.items()}
+        lo = {k: v.detach().clone().to(dtype).requires_grad_(True) for k, v in lat_cpu.items()}
+        out = orc.nerf_ae_art_forward(sd_o, {k: v.to(dtype) for k, v in rc.items()}, True, True, 2.0, 6.0, lo, t_rand=tr[:m].to(dtype), u=u[:m].to(dtype), **gk)
+        (orc.img2mse(out[0][0], target.to(dtype)) + orc.img2mse(out[1][0], target.to(dtype))).backward()
+        gr = {k: v.grad for k, v in sd_o.items()}
+        gr.update({f"latent[{k}]": v.grad for k, v in lo.items()})
+        return gr
+
+    truth, ref32 = oracle_grads(torch.float64), oracle_grads(torch.float32)
+    lg = {k: v.clone().requires_grad_(True) for k, v in lat.items()}
+    out = model({k: v[:m] for k, v in rays.items()}, True, True, 2.0, 6.0, lg, t_rand=tr[:m].to(dev), u=u[:m].to(dev))
+    (((out[0][0] - target.to(dev)) ** 2).mean() + ((out[1][0] - target.to(dev)) ** 2).mean()).backward()
+    hip = {name: p.grad.cpu() for name, p in model.named_parameters()}
+    hip.update({f"latent[{k}]": v.grad.cpu() for k, v in lg.items()})
+    for name, gh in hip.items():
+        assert gh.shape == truth[name].shape, name
+    # Measured (round 4): (-1, 9, 4) 1.1x, (2, 5, 0) 1.0x, the same weights at the default degrees 1.1x; (0, 6, 2): 8.1x on the coarse trunk --
+    # HIP 9.5e-4 where the fp32 oracle happens to sit at 1.2e-4 on this low-frequency field (HIP's absolute level is the same 5e-4..1e-3
+    # as at the other degrees; its compositing backward alone is 2e-7 from the truth there, tests/diag/diag_art_draw.py, and the
+    # deterministic pass of the same network is at 2.0x: tests/diag/diag_art_degrees_grads.py).  A wrong scale or column map is O(1).
+    assert_as_close_as_fp32(hip, truth, ref32, f"articulated, degrees {(mn, mx, dv)}", factor=10.0, floor=1e-4)

@@ -311,3 +311,31 @@ def test_g17_general_mlp(golden):
             for lvl, name in ((0, "coarse"), (1, "fine")):
                 torch.testing.assert_close(out[lvl][0][ok], g[f"nerf_{tag}_{t2}_{name}_rgb"][ok], rtol=0, atol=2e-5)
                 torch.testing.assert_close(out[lvl][1][ok], g[f"nerf_{tag}_{t2}_{name}_acc"][ok], rtol=0, atol=2e-5)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# G18: the articulated network at other encoding degrees (round 4; NeRF_AE_Art(min_deg_point, max_deg_point, deg_view) of the reference)
+# ---------------------------------------------------------------------------------------------------------------------
+def test_g18_articulated_degrees(golden):
+    import aon_amd.synthetic as syn
+
+    g = golden("g18_art_degrees")
+    rays = {k: g[k] for k in ("rays_o", "rays_d", "viewdirs")}
+    lat = {k: g["lat_" + k] for k in ("density", "color", "articulation")}
+    n = rays["rays_o"].shape[0]
+    for tag in "abc":
+        mn, mx, dv = g[f"{tag}_cfg"].tolist()
+        gk = dict(min_deg_point=mn, max_deg_point=mx, deg_view=dv)
+        sd = syn.make_art_state_dict(seed=18, density_scale=2.0, **gk)
+        rgb, dens = orc.art_mlp(sd, "fine_mlp.", g[f"{tag}_mlp_pos"], g[f"{tag}_mlp_cond"], lat, mn, mx)
+        torch.testing.assert_close(rgb, g[f"{tag}_mlp_raw_rgb"], rtol=1e-5, atol=1e-5)
+        torch.testing.assert_close(dens, g[f"{tag}_mlp_raw_density"], rtol=1e-5, atol=1e-5)
+        s = g[f"{tag}_seeds"].tolist()
+        tr, u = syn.seeded_uniform(s[0], n, 65), syn.seeded_uniform(s[1], n, 128)
+        outs = {"det": orc.nerf_ae_art_forward(sd, rays, False, True, 2.0, 6.0, lat, **gk),
+                "rnd": orc.nerf_ae_art_forward(sd, rays, True, False, 2.0, 6.0, lat, t_rand=tr, u=u, **gk)}
+        for t2, out in outs.items():
+            for lvl, name in ((0, "coarse"), (1, "fine")):
+                torch.testing.assert_close(out[lvl][0], g[f"{tag}_{t2}_{name}_rgb"], rtol=0, atol=2e-6)
+                torch.testing.assert_close(out[lvl][1], g[f"{tag}_{t2}_{name}_acc"], rtol=0, atol=2e-6)
+                torch.testing.assert_close(out[lvl][2], g[f"{tag}_{t2}_{name}_depth"], rtol=0, atol=2e-5)
