@@ -885,25 +885,29 @@ LevelStreams* level_streams() {
 // event records, and no side-stream work is ever left un-joined while the caller frees the workspace on its stream.
 class LevelFork {
  public:
-  LevelFork(bool overlap, hipStream_t caller, const char* who) : caller_(caller), who_(who) {
+  // aux_only: no level streams -- the caller's stream carries both levels -- but the side streams of the head reductions (aux()) are
+  // handed out (each use forks from / joins to the stream it is given inside run_wgrad_plan); the device's enqueue lock is held alike
+  LevelFork(bool overlap, hipStream_t caller, const char* who, bool aux_only = false) : caller_(caller), who_(who), aux_only_(aux_only) {
     if (!overlap) return;
     ls_ = level_streams();
     if (!ls_) return;   // no streams: run serially on the caller's stream
     lk_ = std::unique_lock<std::mutex>(ls_->enqueue);
-    rc_ = check(hipEventRecord(ls_->fork, caller_), who_);
-    for (int l = 0; l < 2 && !rc_; ++l) rc_ = check(hipStreamWaitEvent(ls_->s[l], ls_->fork, 0), who_);
+    if (!aux_only_) {
+      rc_ = check(hipEventRecord(ls_->fork, caller_), who_);
+      for (int l = 0; l < 2 && !rc_; ++l) rc_ = check(hipStreamWaitEvent(ls_->s[l], ls_->fork, 0), who_);
+    }
     forked_ = true;     // even on a partial failure: join() is harmless and keeps the caller ordered behind the side streams
   }
   ~LevelFork() { (void)join(); }
   int rc() const { return rc_; }
-  hipStream_t stream(int level) const { return forked_ ? ls_->s[level] : caller_; }
+  hipStream_t stream(int level) const { return forked_ && !aux_only_ ? ls_->s[level] : caller_; }
   // side stream of a level's head reductions (only while this object holds the device's enqueue lock: the events are shared)
   const aon::WgAux* aux(int level) const { return forked_ ? &ls_->aux[level] : nullptr; }
   int join() {
     if (!forked_) return AON_OK;
     forked_ = false;
     int rc = AON_OK;
-    for (int l = 0; l < 2; ++l) {
+    for (int l = 0; l < 2 && !aux_only_; ++l) {
       hipError_t e = hipEventRecord(ls_->join[l], ls_->s[l]);
       if (e == hipSuccess) e = hipStreamWaitEvent(caller_, ls_->join[l], 0);
       if (e != hipSuccess && !rc) rc = check(e, who_);
@@ -918,6 +922,7 @@ class LevelFork {
   std::unique_lock<std::mutex> lk_;
   int rc_ = AON_OK;
   bool forked_ = false;
+  bool aux_only_ = false;
 };
 std::atomic<int> g_bwd_overlap{1};
 std::atomic<int> g_fwd_overlap{2};
@@ -1103,7 +1108,7 @@ int train_fwd_impl(const char* who, bool art, const TrainNet* nets, const float*
 }  // namespace
 
 int aon_set_bwd_overlap(int on) {
-  g_bwd_overlap.store(on ? 1 : 0, std::memory_order_relaxed);
+  g_bwd_overlap.store(on == 2 ? 2 : (on ? 1 : 0), std::memory_order_relaxed);
   return AON_OK;
 }
 
@@ -1239,7 +1244,8 @@ int aon_render_bwd_ex(const void* packed_bwd_coarse, const void* packed_fwd_coar
   // (merged: no side streams at all -- chain, weight gradients and head reductions follow each other on the caller's stream; with equal-cost
   // workgroups filling the chip in every launch the fork / join events and the dispatcher's sharing of compute units between streams cost
   // more than the tails they used to fill: profiles/r04_backward_schedules.txt)
-  LevelFork fork(!merged && num_levels == 2 && g_bwd_overlap.load(std::memory_order_relaxed), caller, "aon_render_bwd");
+  const int overlap_mode = g_bwd_overlap.load(std::memory_order_relaxed);   // 0: none; 1: round-3 level streams when not merged; 2: + head reductions on side streams when merged
+  LevelFork fork(num_levels == 2 && (merged ? overlap_mode == 2 : overlap_mode != 0), caller, "aon_render_bwd", merged);
   if (fork.rc()) return fork.rc();
   for (int l = 0; l < num_levels; ++l) {
     const TrainLevel& L = w.lvl[l];
@@ -1342,7 +1348,8 @@ int aon_art_render_bwd_ex(const void* packed_bwd_coarse, const void* small_coars
   // (merged: no side streams at all -- chain, weight gradients and head reductions follow each other on the caller's stream; with equal-cost
   // workgroups filling the chip in every launch the fork / join events and the dispatcher's sharing of compute units between streams cost
   // more than the tails they used to fill: profiles/r04_backward_schedules.txt)
-  LevelFork fork(!merged && num_levels == 2 && g_bwd_overlap.load(std::memory_order_relaxed), caller, "aon_art_render_bwd");
+  const int overlap_mode = g_bwd_overlap.load(std::memory_order_relaxed);   // 0: none; 1: round-3 level streams when not merged; 2: + head reductions on side streams when merged
+  LevelFork fork(num_levels == 2 && (merged ? overlap_mode == 2 : overlap_mode != 0), caller, "aon_art_render_bwd", merged);
   if (fork.rc()) return fork.rc();
   for (int l = 0; l < num_levels; ++l) {
     const TrainLevel& L = w.lvl[l];

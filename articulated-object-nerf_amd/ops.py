@@ -758,7 +758,7 @@ def art_wgrad(planes, dplanes, d_raw, dxp, params: dict, latents: dict, degrees=
 # ------------------------------------------------------------------ R14 training step in two C calls
 def set_bwd_overlap(on: bool) -> None:
     """Two-level backward on two library streams (default on) or everything on the caller's stream."""
-    check(lib.aon_set_bwd_overlap(int(bool(on))), "aon_set_bwd_overlap")
+    check(lib.aon_set_bwd_overlap(2 if on == 2 else int(bool(on))), "aon_set_bwd_overlap")   # 2 (measurements): head reductions on side streams in the merged form
 
 
 def _sized(nbytes: int, what: str, device) -> torch.Tensor:

@@ -210,3 +210,29 @@ def test_art_training_step_full_size_properties(dev):
     _, gs = grads(reduce="sum")
     for k in g1:
         assert rel_l2((ga[k] + gb[k]).cpu(), gs[k].cpu()) <= 2e-5 or ((ga[k] + gb[k]) - gs[k]).abs().max().item() <= 1e-6, k
+
+
+def test_inplace_update_between_forward_and_backward_raises(dev):
+    """the articulated and the layer-wise autograd functions read the parameter storages again in their backward (latent
+    columns / W^T of the data chain) while the activations in the workspace come from the forward-time weights.  They save the
+    parameters with save_for_backward, so an in-place update between a forward and ITS backward (two live graphs with an
+    optimizer.step() between their backward calls) raises autograd's version error instead of silently mixing two sets of weights."""
+    import aon_amd.synthetic as syn
+    from aon_amd.models.vanilla_nerf.model import NeRF
+    from aon_amd.models.vanilla_nerf.model_autodecoder import NeRF_AE_Art
+
+    rays = {k: v.to(dev) for k, v in syn.random_rays(64, seed=3).items()}
+    art = NeRF_AE_Art().to(dev)
+    art.load_state_dict(syn.make_art_state_dict(seed=5, density_scale=2.0))
+    lat = _latents()
+    lat = {k: v.to(dev) for k, v in lat.items()}
+    gen = NeRF(max_deg_point=12, deg_view=5).to(dev)     # more than 10 / 4 frequency levels: layer-wise engine (autograd.RenderGeneral)
+    for model, call in ((art, lambda m: m(rays, False, True, 2.0, 6.0, lat)), (gen, lambda m: m(rays, False, True, 2.0, 6.0))):
+        out = call(model)
+        with torch.no_grad():
+            next(iter(model.fine_mlp.parameters())).add_(1e-3)    # an optimizer step of ANOTHER graph
+        with pytest.raises(RuntimeError, match="modified by an inplace operation"):
+            out[1][0].sum().backward()
+        out = call(model)                                         # an untouched pair still works
+        out[1][0].sum().backward()
+        assert all(p.grad is not None for p in model.parameters())

@@ -30,7 +30,7 @@ def main():
     from aon_amd.models.vanilla_nerf.model import NeRF
 
     dev = torch.device("cuda:0")
-    ops.set_bwd_overlap(not args.no_overlap)
+    ops.set_bwd_overlap(2 if os.environ.get("AON_BWD_AUX") else (not args.no_overlap))
     ops.set_fwd_merge(not args.no_fwd_merge)
     ops.set_bwd_merge(not args.no_bwd_merge)
     ops.set_fwd_overlap(not args.no_fwd_overlap and not args.no_overlap)
