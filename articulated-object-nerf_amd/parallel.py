@@ -185,8 +185,9 @@ def allreduce_gradients(module, group=None, force: bool = False, shard_align: in
                 for c, p, h, a in zip(chunks, params, had, any_rank):
                     if not h and a:
                         p.grad = c.view_as(p).clone()
-        elif world > 1:
-            # DDP's contract, checked without waiting: every count must be 0 or `world`
+        elif world > 1 or force:
+            # DDP's contract, checked without waiting: every count must be 0 or `world` (`force`: the world-1 GPU tests drive this path --
+            # pinned flag, event, late look -- through the real backend)
             uneven = ((counts > 0.5) & (counts < world - 0.5)).any()
             msg = ("allreduce_gradients(find_unused_parameters=False): in an earlier step the ranks produced gradients for different sets "
                    "of parameters (torch DDP raises the same way, one iteration late: run.py:151); pass find_unused_parameters=True")
