@@ -431,29 +431,43 @@ __device__ __forceinline__ void apply_mask_tile(f32x16& x, const u32x4 w, int t)
 //   * stores it -- it IS the pre-activation gradient dZ the weight-gradient kernels read -- to its plane rows, and
 //   * [MASKED] turns tile j+1 from dH into dZ = relu'(Z) . dH with the forward's decision bits,
 // one value per MFMA group; tile 0 is masked by the caller before the layer starts (16 values).
-template <int NT, bool MASKED>
+// STORE = false: the chunks that consume the tiles only turn the next one into dZ; their stores ride on another layer's chunks
+// (StoreSideOf).  Used where the consuming chunks are TINY (the articulated chain's encoding chunks: 2 output tiles = 8 MFMA groups =
+// 0.9 us each, a workgroup barrier every 1.8 us): vmcnt retires in order, so the barrier's wait for the next pair's weight DMA also
+// waits for every plane store issued before that DMA, and a streaming store's acknowledgement takes longer than such a chunk lasts.
+template <int NT, bool MASKED, bool STORE = true>
 struct BwdSideOf {
   f32x16 (&tiles)[NT];
   int row;             // plane row of tile 0 in the gradient planes
   const PlaneIO& io;
   const u32x4& mk;
+  // `touch`: the NEXT layer's decision bits, fetched at the start of this layer.  vmcnt retires in order, so the wait for a load is
+  // also a wait for every plane store issued before it -- and left to its first use (the next layer's start) that wait sits right
+  // behind this layer's last stores, whose acknowledgements take microseconds.  The second chunk's last slot "uses" the word
+  // (an empty asm): the wait lands there, two chunks behind the load, when everything older has long been acknowledged and the
+  // stores issued since do not matter (round 4: the articulated chain lost ~40 us per pass = 12 % to sixteen such waits).
+  const u32x4* touch = nullptr;
   __device__ __forceinline__ auto operator()(int j) const {
     f32x16 (&t)[NT] = tiles;
     const int trow = row + 32 * j;
     const PlaneIO& pio = io;
     const u32x4& m = mk;
-    return [&t, trow, &pio, &m, j](int i) {
+    const u32x4* tch = touch;
+    return [&t, trow, &pio, &m, j, tch](int i) {
+      if (j == 1 && i == 15 && tch) asm volatile("" ::"v"(*tch));
       if (i < 16) {
         // one 16-byte store per four slots.  A MASKED tile was turned into dZ by the previous chunk's side job (or by the caller, tile 0):
         // its values already sit in architectural VGPRs, staging them again is a copy (round 4: 694 v_mov_b64 per pass of the
         // articulated chain); an unmasked tile (d bottleneck) comes straight from the accumulators and is staged
         // (per translation unit: in the vanilla chain hipcc keeps masked tiles in AGPRs -- 192 of its stores would read them directly --
         // so aon_train.hip defines AON_CHAIN_STAGE_MASKED and stages every quad as before)
+        if constexpr (STORE) {
 #ifdef AON_CHAIN_STAGE_MASKED
-        if ((i & 3) == 0) store_quad<true>(pio, trow, i >> 2, t[j]);
+          if ((i & 3) == 0) store_quad<true>(pio, trow, i >> 2, t[j]);
 #else
-        if ((i & 3) == 0) store_quad<!MASKED>(pio, trow, i >> 2, t[j]);
+          if ((i & 3) == 0) store_quad<!MASKED>(pio, trow, i >> 2, t[j]);
 #endif
+        }
         if constexpr (MASKED) {
           if (j + 1 < NT) {
             float z = mask_apply(m[(j + 1) >> 1], t[j + 1][i], ((j + 1) & 1) * 16 + i);
@@ -464,6 +478,22 @@ struct BwdSideOf {
           }
         }
       }
+    };
+  }
+};
+
+// side job that only stores already-masked tiles (their masking rode on the chunks of BwdSideOf<.., true, false>)
+template <int NT>
+struct StoreSideOf {
+  f32x16 (&tiles)[NT];
+  int row;
+  const PlaneIO& io;
+  __device__ __forceinline__ auto operator()(int j) const {
+    f32x16 (&t)[NT] = tiles;
+    const int trow = row + 32 * j;
+    const PlaneIO& pio = io;
+    return [&t, trow, &pio, j](int i) {
+      if (i < 16 && (i & 3) == 0) store_quad<false>(pio, trow, i >> 2, t[j]);
     };
   }
 };

@@ -294,7 +294,7 @@ __global__ void __launch_bounds__(256) mlp_bwd_chain_kernel(BwdArgs args) {
     // d bottleneck = W_view[:, :256]^T . dZ_view, dZ_view = view-layer ReLU mask . dHV   (model.py:109-116)
     mk_next = load_mask(7);
     apply_mask_tile(Z[0], mk, 0);
-    dense_layer<BwdNet, kBwView, 4, 8, BwdSideOf<4, true>, true>(p, Z, X, BwdSideOf<4, true>{Z, kPlHV, io, mk});   // X starts from zero
+    dense_layer<BwdNet, kBwView, 4, 8, BwdSideOf<4, true>, true>(p, Z, X, BwdSideOf<4, true>{Z, kPlHV, io, mk, &mk_next});   // X starts from zero
     // dH7 = W_bott^T . dBot + W_sigma^T * d_sigma   (the bottleneck has no activation; the density head reads the
     // post-ReLU layer-7 output, model.py:105)
 #pragma unroll
@@ -311,7 +311,7 @@ __global__ void __launch_bounds__(256) mlp_bwd_chain_kernel(BwdArgs args) {
 #define AON_BWD_LAYER(IN, OUT, CB, L)                                                                                  \
     mk = mk_next; if (L > 0) mk_next = load_mask(L - 1);                                                               \
     apply_mask_tile(IN[0], mk, 0);                                                                                     \
-    dense_layer<BwdNet, CB, 8, 8, BwdSideOf<8, true>, true>(p, IN, OUT, BwdSideOf<8, true>{IN, plane_h(L), io, mk});   /* OUT starts from zero */
+    dense_layer<BwdNet, CB, 8, 8, BwdSideOf<8, true>, true>(p, IN, OUT, BwdSideOf<8, true>{IN, plane_h(L), io, mk, L > 0 ? &mk_next : nullptr});   /* OUT starts from zero; the next layer's bits are waited for two chunks in (BwdSideOf::touch) */
     AON_BWD_LAYER(Y, X, kBwL7 + 0, 7)
     AON_BWD_LAYER(X, Y, kBwL7 + 8, 6)
     AON_BWD_LAYER(Y, X, kBwL7 + 16, 5)

@@ -170,7 +170,7 @@ __global__ void __launch_bounds__(256) art_bwd_chain_kernel(ArtBwdArgs args) {
 #define AON_ABWD_LAYER(NT_IN, NT_OUT, IN, OUT, CB, ROW, NEXT_SLOT)                                                   \
     if (NEXT_SLOT >= 0) mk_next = load_mask(NEXT_SLOT);                                                               \
     apply_mask_tile(IN[0], mk, 0);                                                                                   \
-    dense_layer<N, CB, NT_IN, NT_OUT, BwdSideOf<NT_IN, true>, true>(p, IN, OUT, BwdSideOf<NT_IN, true>{IN, ROW, io, mk});   /* OUT starts from zero */ \
+    dense_layer<N, CB, NT_IN, NT_OUT, BwdSideOf<NT_IN, true>, true>(p, IN, OUT, BwdSideOf<NT_IN, true>{IN, ROW, io, mk, NEXT_SLOT >= 0 ? &mk_next : nullptr});   /* OUT starts from zero */ \
     mk = mk_next;
     AON_ABWD_LAYER(4, 4, Z1, Z0, kABwV3 + 0, aplane_v(3), 14)
     AON_ABWD_LAYER(4, 4, Z0, Z1, kABwV3 + 4, aplane_v(2), 13)
@@ -185,7 +185,7 @@ __global__ void __launch_bounds__(256) art_bwd_chain_kernel(ArtBwdArgs args) {
       asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
       return (int64_t)pass * 128 + wave_s * 32 + (l & 31);
     };
-    const float dsig = sg.d_raw[sample_now() * 4 + 3];   // re-read here (L2-hot) instead of carried through the view branch
+    const float dsig = dr.w;   // (round 3 re-read it here to save a register across the view branch: a load whose wait also waits for the view branch's stores)
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
 #pragma unroll
@@ -203,13 +203,14 @@ __global__ void __launch_bounds__(256) art_bwd_chain_kernel(ArtBwdArgs args) {
     f32x16 dE[2];
     mk_next = load_mask(8);
     apply_mask_tile(Y[0], mk, 0);
-    dense_layer<N, kABwL5E, 8, 2, BwdSideOf<8, true>, true>(p, Y, dE, BwdSideOf<8, true>{Y, aplane_h(5), io, mk});   // dE starts from zero
+    // (the eight encoding chunks are tiny -- 8 MFMA groups each: they only mask; dZ5's stores ride on layer 5's own chunks below)
+    dense_layer<N, kABwL5E, 8, 2, BwdSideOf<8, true, false>, true>(p, Y, dE, BwdSideOf<8, true, false>{Y, aplane_h(5), io, mk, &mk_next});   // dE starts from zero
     mk = mk_next;
     // The partial d enc (32 accumulator registers) would have to stay live across layers 5..1 on top of the two 128-register
     // activation sets; it is parked in the (otherwise unused) pos-enc rows of the gradient planes instead -- 128 B per lane out
     // and back per pass, against 13.8 KB of plane traffic -- rather than left to the register allocator's scratch spills.
     store_plane(dE, io, kAPlE);
-    dense_layer<N, kABwL5 + 0, 8, 8, NoSideOf, true>(p, Y, X);   // X = dH4 (from zero)
+    dense_layer<N, kABwL5 + 0, 8, 8, StoreSideOf<8>, true>(p, Y, X, StoreSideOf<8>{Y, aplane_h(5), io});   // X = dH4 (from zero); stores dZ5
     AON_ABWD_LAYER(8, 8, X, Y, kABwL5 + 8, aplane_h(4), 7)
     AON_ABWD_LAYER(8, 8, Y, X, kABwL5 + 16, aplane_h(3), 6)
     AON_ABWD_LAYER(8, 8, X, Y, kABwL5 + 24, aplane_h(2), 5)
@@ -218,15 +219,29 @@ __global__ void __launch_bounds__(256) art_bwd_chain_kernel(ArtBwdArgs args) {
     mk_next = load_mask(3);
     apply_mask_tile(X[0], mk, 0);
     load_plane(dE, io, kAPlE);
-    dense_layer<N, kABwL0E, 8, 2>(p, X, dE, BwdSideOf<8, true>{X, aplane_h(0), io, mk});
-    mk = mk_next;
-
-    // ---- positional encoding, backwards (helper.py:136-140 on the deformed point) ----
+    // the deformed position x' for the encoding's backward is fetched HERE, in front of the encoding chunks, not behind them: its wait
+    // then covers only what is older than this point, not the burst of dZ0 stores below
     float xd[3];  // deformed position x' (forward stored it in rows 3..5 of the position block)
     const PlaneIO fio = make_plane_io(sg.planes, kAPlRows, step, m, h);
 #pragma unroll
     for (int a = 0; a < 3; ++a)
       xd[a] = *row_ptr(fio, kAPlPos + 3 + a);
+#if defined(AON_EXP_NOSTORE_L0E)   // timing experiment only (dZ0 never stored: WRONG layer-0 weight gradients)
+    dense_layer<N, kABwL0E, 8, 2>(p, X, dE, BwdSideOf<8, true, false>{X, aplane_h(0), io, mk});
+#elif defined(AON_EXP_L0E_SIDE)    // round-3 form: dZ0 stored by the tiny encoding chunks themselves
+    dense_layer<N, kABwL0E, 8, 2>(p, X, dE, BwdSideOf<8, true>{X, aplane_h(0), io, mk});
+#else
+    // the encoding chunks (tiny, see BwdSideOf) only mask; dZ0 goes out in one burst behind them, in front of the ~600 VALU
+    // instructions of the encoding's backward, which give its acknowledgements time before the next weight DMA is waited for
+    dense_layer<N, kABwL0E, 8, 2>(p, X, dE, BwdSideOf<8, true, false>{X, aplane_h(0), io, mk, &mk_next});
+#pragma unroll
+    for (int t8 = 0; t8 < 8; ++t8)
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) store_quad<false>(io, aplane_h(0) + 32 * t8, gq, X[t8]);
+#endif
+    mk = mk_next;
+
+    // ---- positional encoding, backwards (helper.py:136-140 on the deformed point) ----
     const float phase = h ? AON_HALF_PI_F32 : 0.f;
     float dx[3] = {0.f, 0.f, 0.f};
 #pragma unroll
