@@ -61,7 +61,7 @@ _SIGS = {
     "aon_mlp_fwd_train": (_i, [_p, _p, _p, _p, _p, _l, _i, _p, _p, _p, _p]),
     "aon_composite_bwd": (_i, [_p, _p, _p, _p, _p, _p, _l, _i, _i, _i, _p, _p]),
     "aon_mlp_bwd_chain": (_i, [_p, _p, _p, _p, _p, _l, _p]),
-    "aon_vanilla_wgrad": (_i, [_p, _p, _p, _l, _p, _p, _l, _p]),
+    "aon_vanilla_wgrad": (_i, [_p, _p, _p, _l, _p, _p, _l, _p, _p]),
     "aon_wgrad_plan": (_i, [_i, _l, _i, _p, _i, _p]),
     "aon_wgrad_plan_segment": (_i, [_i, _l, _i, _i, _i, _p]),
     "aon_wgrad_kind_bench": (_i, [_i, _i, _p, _p, _i, _l, _p, _l, _p]),
@@ -71,8 +71,11 @@ _SIGS = {
     "aon_pack_art_mlp_bwd": (_i, [_p, _p, _p]),
     "aon_art_mlp_fwd_train": (_i, [_p, _p, _p, _p, _p, _p, _l, _i, _p, _p, _p, _p]),
     "aon_art_bwd_chain": (_i, [_p, _p, _p, _p, _p, _p, _p, _l, _p]),
-    "aon_art_wgrad": (_i, [_p, _p, _p, _p, _l, _p, _p, _p, _p, _p, _p, _p, _p, _p, _l, _p]),
-    "aon_art_wgrad_deg": (_i, [_p, _p, _p, _p, _l, _p, _p, _p, _p, _p, _p, _p, _p, _p, _l, _p, _i, _i, _i]),
+    "aon_art_wgrad": (_i, [_p, _p, _p, _p, _l, _p, _p, _p, _p, _p, _p, _p, _p, _p, _l, _p, _p]),
+    "aon_art_wgrad_deg": (_i, [_p, _p, _p, _p, _l, _p, _p, _p, _p, _p, _p, _p, _p, _p, _l, _p, _i, _i, _i, _p]),
+    "aon_set_bottleneck_fold": (_i, [_i]),
+    "aon_get_bottleneck_fold": (_i, []),
+    "aon_stream_is_folded": (_i, [_p]),
     "aon_set_bwd_overlap": (_i, [_i]),
     "aon_set_fwd_overlap": (_i, [_i]),
     "aon_set_fwd_merge": (_i, [_i]),
@@ -142,7 +145,7 @@ for _name, (_res, _args) in _SIGS.items():
     _fn.restype = _res
     _fn.argtypes = _args
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 if lib.aon_abi_version() != ABI_VERSION:
     raise ImportError(f"libaon_hip.so ABI {lib.aon_abi_version()} != binding ABI {ABI_VERSION}; rebuild")
 

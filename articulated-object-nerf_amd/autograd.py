@@ -70,7 +70,7 @@ class RenderLevelVanilla(torch.autograd.Function):
             g_rgb = torch.zeros((n, 3), dtype=torch.float32, device=t_vals.device)
         d_raw = ops.composite_bwd(raw, t_vals, rays_d, g_rgb, g_acc, g_depth, ctx.white_bkgd, ops.ACT_VANILLA, ops.plane_samples(planes))
         dplanes = ops.mlp_bwd_chain(packed_bwd, packed_fwd, d_raw, masks, planes.shape)
-        grads = ops.vanilla_wgrad(planes, dplanes, d_raw)
+        grads = ops.vanilla_wgrad(planes, dplanes, d_raw, packed_bwd)
         ctx.keep, ctx.released = None, True
         return (None,) * 7 + tuple(grads[name] for name in ops.VANILLA_PARAM_ORDER)
 

@@ -17,8 +17,8 @@ CSRC = os.path.join(PKG, "csrc")
 _TAG = os.environ.get("AON_BUILD_TAG", "")
 OBJ = os.path.join(PKG, "build" + ("_" + _TAG if _TAG else ""))
 LIB = os.path.join(PKG, "libaon_hip" + ("_" + _TAG if _TAG else "") + ".so")
-SOURCES = ["aon_mlp.hip", "aon_mlp_art.hip", "aon_train.hip", "aon_train_art.hip", "aon_render.hip", "aon_gmlp.hip", "aon_capi.hip"]
-HEADERS = [os.path.join(CSRC, "aon_common.h"), os.path.join(CSRC, "aon_mlp_core.h"), os.path.join(CSRC, "aon_wgrad.h"), os.path.join(CSRC, "aon_art_common.h"), os.path.join(CSRC, "aon_ray_core.h"), os.path.join(CSRC, "aon_gmlp.h"),
+SOURCES = ["aon_mlp.hip", "aon_mlp_art.hip", "aon_train.hip", "aon_train_art.hip", "aon_render.hip", "aon_gmlp.hip", "aon_fold.hip", "aon_capi.hip"]
+HEADERS = [os.path.join(CSRC, "aon_common.h"), os.path.join(CSRC, "aon_mlp_core.h"), os.path.join(CSRC, "aon_wgrad.h"), os.path.join(CSRC, "aon_art_common.h"), os.path.join(CSRC, "aon_ray_core.h"), os.path.join(CSRC, "aon_gmlp.h"), os.path.join(CSRC, "aon_fold.h"),
            os.path.join(os.path.dirname(PKG), "include", "aon_hip.h")]
 # -ffp-contract=off: the stage kernels reproduce the reference's un-fused mul/add sequences; FMAs are explicit.
 # Per-file code-generation choices, A/B-measured on MI355X (round 1, tools/ab_train.sh, 4096-ray vanilla training step):
@@ -70,7 +70,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         with open(cmd[-1] + ".cmd", "w") as f:
             f.write(" ".join(cmd))
 
-    with ThreadPoolExecutor(max_workers=7) as ex:
+    with ThreadPoolExecutor(max_workers=8) as ex:
         list(ex.map(run, jobs))
     objs = [os.path.join(OBJ, s.replace(".hip", ".o")) for s in SOURCES]
     if force or jobs or _stale(LIB, objs):

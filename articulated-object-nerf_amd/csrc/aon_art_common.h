@@ -50,5 +50,20 @@ constexpr int kABwL0E = 88;    // pts_linears.0[:, :63]^T : 8 chunks, 2 output t
 constexpr int kABwD3 = 96;     // deformations_linear.3^T, .2^T, .1^T : 4 chunks each, 4 output tiles
 constexpr int kABwNumChunks = 108;
 
+// ---- FOLDED forms (round 5; aon_common.h kChFView for the algebra): bottleneck_layer (no activation, model_autodecoder.py:223) folded into
+// views_linear.0's 256 bottleneck columns, W' = W_v0[:, :256] W_b -- 65,536 of the 692,480 MACs per sample the un-folded kernels execute.
+// Forward stream: the eight bottleneck chunks are gone, every later chunk moves up by 8; views_linear.0's hidden chunks hold W' and
+// read the post-ReLU layer-7 output.  The per-call block's effective bias of views_linear.0 additionally carries W_v0[:, :256] b_b.
+constexpr int kAChFV0 = 72;    // W' : 8 hidden + 1 view-enc
+constexpr int kAChFV1 = 81;
+constexpr int kANumChunksF = 93;
+// Transposed stream: views_linear.0's four chunks hold W'^T (d H7 directly), the eight bottleneck chunks are gone.
+constexpr int kABwFL7 = 16;
+constexpr int kABwFL5E = 32;
+constexpr int kABwFL5 = 40;
+constexpr int kABwFL0E = 80;
+constexpr int kABwFD3 = 88;
+constexpr int kABwFNumChunks = 100;
+
 
 }  // namespace aon

@@ -8,6 +8,7 @@
 #include <mutex>
 #include <vector>
 
+#include "aon_fold.h"
 #include "aon_gmlp.h"
 
 namespace aon {
@@ -48,7 +49,7 @@ hipError_t launch_wgrad_kind_bench(int kind, int nlayers, const float* planes, c
                                    float* out_scratch, hipStream_t stream);
 struct WgAux { hipStream_t stream; hipEvent_t fork, join; };   // aon_wgrad.h: optional side stream of a level's head reductions
 hipError_t launch_vanilla_wgrad(const float* planes, const float* dplanes, const float* d_raw, int64_t Np, float* const* grads,
-                                float* ws, hipStream_t stream, const WgAux* aux);
+                                float* ws, hipStream_t stream, const WgAux* aux, const void* packed_bwd);
 hipError_t launch_art_mlp_fwd_train(const char* packed, const float* small, const float* rays_o, const float* rays_d,
                                     const float* viewdirs, const float* t_vals, int64_t n_rays, int S, float* raw, float* planes,
                                     void* masks, hipStream_t stream, int64_t np_total = 0);
@@ -61,7 +62,8 @@ hipError_t launch_art_bwd_chain(const char* packed_bwd, const float* small, cons
                                 float* dplanes, float* dxp, int64_t Np, hipStream_t stream);
 hipError_t launch_art_wgrad(const float* planes, const float* dplanes, const float* d_raw, const float* dxp, int64_t Np,
                             const float* const* params, const float* shape, const float* app, const float* art,
-                            float* const* grads, float* g_shape, float* g_app, float* g_art, float* ws, hipStream_t stream, const WgAux* aux, int pos_levels = 10, int view_levels = 4);
+                            float* const* grads, float* g_shape, float* g_app, float* g_art, float* ws, hipStream_t stream, const WgAux* aux, int pos_levels, int view_levels,
+                            const void* packed_bwd);
 hipError_t launch_raygen(const float* c2w, int H, int W, float focal, const float* directions, int64_t pix_begin,
                          int64_t pix_end, float* rays_o, float* viewdirs, float* rays_d, hipStream_t stream);
 hipError_t launch_ray_directions(int H, int W, float focal, float* out, hipStream_t stream);
@@ -501,14 +503,14 @@ int aon_mlp_bwd_chain(const void* packed_bwd, const void* packed_fwd, const floa
 }
 
 int aon_vanilla_wgrad(const float* planes, const float* dplanes, const float* d_raw, int64_t Np, float* const* grads_host,
-                      void* workspace, int64_t workspace_bytes, void* stream) {
+                      void* workspace, int64_t workspace_bytes, void* stream, const void* packed_bwd) {
   if (Np <= 0 || (Np & 127)) return fail(AON_E_INVALID, "aon_vanilla_wgrad: Np must be a positive multiple of 128");
   if (!planes || !dplanes || !d_raw || !grads_host || !workspace) return fail(AON_E_INVALID, "aon_vanilla_wgrad: null pointer");
   for (int i = 0; i < aon::kNumVanillaParams; ++i)
     if (!grads_host[i]) return fail(AON_E_INVALID, "aon_vanilla_wgrad: null gradient pointer");
   if (workspace_bytes < aon::wgrad_workspace_bytes()) return fail(AON_E_WORKSPACE, "aon_vanilla_wgrad: workspace too small");
   KTimer timer(kWgrad, (hipStream_t)stream, Np);
-  return check(aon::launch_vanilla_wgrad(planes, dplanes, d_raw, Np, grads_host, static_cast<float*>(workspace), (hipStream_t)stream, nullptr),
+  return check(aon::launch_vanilla_wgrad(planes, dplanes, d_raw, Np, grads_host, static_cast<float*>(workspace), (hipStream_t)stream, nullptr, packed_bwd),
                "aon_vanilla_wgrad");
 }
 
@@ -562,14 +564,14 @@ int aon_art_bwd_chain(const void* packed_bwd, const void* small, const float* d_
 int aon_art_wgrad(const float* planes, const float* dplanes, const float* d_raw, const float* dxp, int64_t Np,
                   const float* const* params_host, const float* shape, const float* appearance, const float* articulation,
                   float* const* grads_host, float* g_shape, float* g_appearance, float* g_articulation, void* workspace,
-                  int64_t workspace_bytes, void* stream) {
+                  int64_t workspace_bytes, void* stream, const void* packed_bwd) {
   return aon_art_wgrad_deg(planes, dplanes, d_raw, dxp, Np, params_host, shape, appearance, articulation, grads_host, g_shape, g_appearance,
-                           g_articulation, workspace, workspace_bytes, stream, 0, 10, 4);
+                           g_articulation, workspace, workspace_bytes, stream, 0, 10, 4, packed_bwd);
 }
 int aon_art_wgrad_deg(const float* planes, const float* dplanes, const float* d_raw, const float* dxp, int64_t Np,
                       const float* const* params_host, const float* shape, const float* appearance, const float* articulation,
                       float* const* grads_host, float* g_shape, float* g_appearance, float* g_articulation, void* workspace,
-                      int64_t workspace_bytes, void* stream, int min_deg_point, int max_deg_point, int deg_view) {
+                      int64_t workspace_bytes, void* stream, int min_deg_point, int max_deg_point, int deg_view, const void* packed_bwd) {
   if (const char* bad = art_degrees_ok(min_deg_point, max_deg_point, deg_view)) return fail(AON_E_INVALID, bad);
   if (Np <= 0 || (Np & 127)) return fail(AON_E_INVALID, "aon_art_wgrad: Np must be a positive multiple of 128");
   if (!planes || !dplanes || !d_raw || !dxp || !params_host || !shape || !appearance || !articulation || !grads_host || !g_shape ||
@@ -581,7 +583,7 @@ int aon_art_wgrad_deg(const float* planes, const float* dplanes, const float* d_
   KTimer timer(kWgrad, (hipStream_t)stream, Np);
   return check(aon::launch_art_wgrad(planes, dplanes, d_raw, dxp, Np, params_host, shape, appearance, articulation, grads_host, g_shape,
                                      g_appearance, g_articulation, static_cast<float*>(workspace), (hipStream_t)stream, nullptr,
-                                     max_deg_point - min_deg_point, deg_view), "aon_art_wgrad");
+                                     max_deg_point - min_deg_point, deg_view, packed_bwd), "aon_art_wgrad");
 }
 
 int aon_profile_begin(void) {
@@ -1107,6 +1109,13 @@ int train_fwd_impl(const char* who, bool art, const TrainNet* nets, const float*
 
 }  // namespace
 
+int aon_set_bottleneck_fold(int on) {
+  aon::set_fold_default(on);
+  return AON_OK;
+}
+int aon_get_bottleneck_fold(void) { return aon::fold_default(); }
+int aon_stream_is_folded(const void* packed) { return aon::stream_form(packed) == aon::kFormFolded ? 1 : 0; }
+
 int aon_set_bwd_overlap(int on) {
   g_bwd_overlap.store(on == 2 ? 2 : (on ? 1 : 0), std::memory_order_relaxed);
   return AON_OK;
@@ -1213,6 +1222,8 @@ int aon_render_bwd_ex(const void* packed_bwd_coarse, const void* packed_fwd_coar
   float* const* grads[2] = {grads_coarse_host, grads_fine_host};
   for (int l = 0; l < num_levels; ++l) {
     if (!pb[l] || !pf[l] || !grads[l] || !g_rgb_host[l]) return fail(AON_E_INVALID, "aon_render_bwd: null level pointer");
+    if (aon::stream_form(pb[l]) != aon::stream_form(pf[l]) || aon::stream_form(pb[l]) != aon::stream_form(pb[0]))
+      return fail(AON_E_INVALID, "aon_render_bwd: forward and transposed streams were packed in different forms (aon_set_bottleneck_fold changed in between)");
     for (int i = 0; i < aon::kNumVanillaParams; ++i)
       if (!grads[l][i]) return fail(AON_E_INVALID, "aon_render_bwd: null gradient pointer");
   }
@@ -1265,7 +1276,7 @@ int aon_render_bwd_ex(const void* packed_bwd_coarse, const void* packed_fwd_coar
       if (g.other_degrees) {   // the three encoding-fed weights come out in the kernels' 63 / 27-column layout, then lose the empty slots
         gl[0] = sc.grad_tmp[l]; gl[10] = gl[0] + 256 * 63; gl[16] = gl[10] + 256 * (256 + 63);
       }
-      rc = check(aon::launch_vanilla_wgrad(L.planes, sc.dplanes[l], sc.d_raw[l], L.Np, gl, sc.wgrad_ws[l], stream, fork.aux(l)), "aon_render_bwd");
+      rc = check(aon::launch_vanilla_wgrad(L.planes, sc.dplanes[l], sc.d_raw[l], L.Np, gl, sc.wgrad_ws[l], stream, fork.aux(l), pb[l]), "aon_render_bwd");
       if (!rc && g.other_degrees) {
         const int Lp = g.max_deg - g.min_deg, P = 3 + 6 * Lp, V = 3 + 6 * g.deg_view;
         auto remap = [&](const float* src, float* dst, int rows, int hidden, int Lx, int Lfull, int cols) {
@@ -1319,6 +1330,8 @@ int aon_art_render_bwd_ex(const void* packed_bwd_coarse, const void* small_coars
   float* const* grads[2] = {grads_coarse_host, grads_fine_host};
   for (int l = 0; l < num_levels; ++l) {
     if (!pb[l] || !sm[l] || !grads[l] || !params[l] || !g_rgb_host[l]) return fail(AON_E_INVALID, "aon_art_render_bwd: null level pointer");
+    if (aon::stream_form(pb[l]) != aon::stream_form(sm[l]) || aon::stream_form(pb[l]) != aon::stream_form(pb[0]))
+      return fail(AON_E_INVALID, "aon_art_render_bwd: transposed stream and per-call block were made in different forms (aon_set_bottleneck_fold changed in between)");
     for (int i = 0; i < 40; ++i)
       if (!grads[l][i] || !params[l][i]) return fail(AON_E_INVALID, "aon_art_render_bwd: null parameter / gradient pointer");
   }
@@ -1367,7 +1380,7 @@ int aon_art_render_bwd_ex(const void* packed_bwd_coarse, const void* small_coars
       // level 0 writes the latent gradients, level 1 adds its own (both MLPs see the same latents)
       float* gs = l == 0 ? g_shape : sc.lat_tmp, *ga = l == 0 ? g_appearance : sc.lat_tmp + 128, *gt = l == 0 ? g_articulation : sc.lat_tmp + 256;
       rc = check(aon::launch_art_wgrad(L.planes, sc.dplanes[l], sc.d_raw[l], sc.dxp[l], L.Np, params[l], shape, appearance, articulation, grads[l], gs, ga, gt,
-                                       sc.wgrad_ws[l], stream, fork.aux(l), g.max_deg - g.min_deg, g.deg_view), "aon_art_render_bwd");
+                                       sc.wgrad_ws[l], stream, fork.aux(l), g.max_deg - g.min_deg, g.deg_view, pb[l]), "aon_art_render_bwd");
     }
     if (rc) return rc;
   }

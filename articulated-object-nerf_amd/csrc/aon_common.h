@@ -91,6 +91,23 @@ __host__ __device__ constexpr int64_t chunk_offset(int c) {
 }
 constexpr int64_t kStreamBytes = chunk_offset(kNumChunks);  // 2,375,680 B
 
+// FOLDED form of the stream (round 5).  bottleneck_layer has NO activation and feeds views_linear[0] directly (model.py:109-114), so
+//   W_v0[:, :256] (W_b h + b_b) + W_v0[:, 256:] ve + b_v0  =  (W_v0[:, :256] W_b) h + W_v0[:, 256:] ve + (W_v0[:, :256] b_b + b_v0):
+// ONE 256 -> 128 layer W' = W_v0[:, :256] W_b where the literal form runs 256 -> 256 then 256 -> 128 -- 65,536 of the network's 593,408
+// MACs per sample (11.0 %).  W' and b' are evaluated in fp64 from the fp32 parameters at pack time and rounded once
+// (aon_fold.hip).  Chunks 0 .. 59 are the literal stream's; then 8 small chunks of W' and the view-encoding chunk.  The buffer keeps the
+// literal size: the small block stays at kStreamBytes, and the 256 KiB between the end of the folded stream and the small block hold
+// W' (128 x 256) and b' (128) for the pack kernel.  Which form a buffer holds is remembered per pointer (stream_form, aon_fold.hip).
+constexpr int kChFView = 60;        // 8 hidden (W') + 1 view-enc, 4 output tiles each
+constexpr int kNumChunksF = 69;
+__host__ __device__ constexpr int chunk_bytes_f(int c) { return c < kChFView ? kBigChunkBytes : kSmallChunkBytes; }
+__host__ __device__ constexpr int64_t chunk_offset_f(int c) {
+  return c < kChFView ? (int64_t)c * kBigChunkBytes : (int64_t)kChFView * kBigChunkBytes + (int64_t)(c - kChFView) * kSmallChunkBytes;
+}
+constexpr int64_t kStreamBytesF = chunk_offset_f(kNumChunksF);   // 2,113,536 B
+constexpr int64_t kFoldTmpOff = kStreamBytesF;                   // W' (128 x 256 floats) then b' (128 floats), inside the literal-size buffer
+static_assert(kStreamBytesF + (128 * 256 + 128) * 4 <= kStreamBytes, "fold temporaries fit between the folded stream and the small block");
+
 // Small per-layer vectors, kept resident in LDS for the whole kernel (floats):
 constexpr int kSmBias = 0;                    // 8 x 256  trunk biases
 constexpr int kSmBiasBott = 8 * 256;          // 256

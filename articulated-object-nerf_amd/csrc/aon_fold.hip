@@ -1,0 +1,122 @@
+// bottleneck_layer folded into views_linear[0] (models/vanilla_nerf/model.py:105-118, model_autodecoder.py:222-237): the products on the
+// PARAMETERS (pack time: W' = W_v0[:, :256] W_b, b' = W_v0[:, :256] b_b + b_v0) and on their GRADIENTS (backward: the reference's
+// dW_b, db_b, dW_v0[:, :256] from the folded layer's dW', db').  128 x 256 x 256 multiply-adds each -- 0.03 % of a training step's
+// arithmetic -- accumulated in fp64 and rounded once, so the folded layer is the correctly rounded product of the fp32 parameters
+// and the un-folded gradients carry no summation error of their own.
+#include "aon_fold.h"
+
+#include <mutex>
+#include <unordered_map>
+
+namespace aon {
+
+// ---------------------------------------------------------------------------------------------
+// which form a packed buffer holds
+// ---------------------------------------------------------------------------------------------
+static std::atomic<int> g_fold_default{1};
+int fold_default() { return g_fold_default.load(std::memory_order_relaxed); }
+void set_fold_default(int on) { g_fold_default.store(on ? kFormFolded : kFormLiteral, std::memory_order_relaxed); }
+
+namespace {
+std::mutex g_form_mu;
+std::unordered_map<uintptr_t, int>& form_table() {
+  static std::unordered_map<uintptr_t, int> t;
+  return t;
+}
+}  // namespace
+
+void set_stream_form(const void* p, int form) {
+  std::lock_guard<std::mutex> lk(g_form_mu);
+  auto& t = form_table();
+  if (t.size() > (1u << 16)) t.clear();   // (addresses a caching allocator hands out repeat; a process that packs into >65k distinct ones starts over)
+  t[reinterpret_cast<uintptr_t>(p)] = form;
+}
+
+int stream_form(const void* p) {
+  std::lock_guard<std::mutex> lk(g_form_mu);
+  auto& t = form_table();
+  auto it = t.find(reinterpret_cast<uintptr_t>(p));
+  return it == t.end() ? fold_default() : it->second;
+}
+
+// ---------------------------------------------------------------------------------------------
+// small products in fp64
+// ---------------------------------------------------------------------------------------------
+struct FoldArgs {
+  FoldGemm job[kFoldMaxJobs];
+  int blk_begin[kFoldMaxJobs + 1];
+  int njobs;
+};
+
+// 16 x 16 outputs per block, K in tiles of 16 through LDS (as doubles: the conversion is paid once per element, not once per use).
+// Tile loads pick the thread order that makes the faster-varying thread index walk the operand's unit stride.
+__global__ void __launch_bounds__(256) fold_gemm_kernel(FoldArgs a) {
+  __shared__ double As[16][17], Bs[16][17];
+  int j = 0;
+#pragma unroll 1
+  for (int t = 1; t < a.njobs; ++t)
+    if ((int)blockIdx.x >= a.blk_begin[t]) j = t;
+  const FoldGemm& G = a.job[j];
+  const int blk = (int)blockIdx.x - a.blk_begin[j];
+  const int nbn = (G.N + 15) / 16;
+  const int m0 = (blk / nbn) * 16, n0 = (blk % nbn) * 16;
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const bool a_k_fast = G.sak <= G.sam, b_n_fast = G.sbn <= G.sbk;
+  double acc = 0.0;
+  for (int k0 = 0; k0 < G.K; k0 += 16) {
+    {
+      const int mm = a_k_fast ? ty : tx, kk = a_k_fast ? tx : ty;
+      const int m = m0 + mm, k = k0 + kk;
+      As[mm][kk] = (m < G.M && k < G.K) ? (double)G.A[(int64_t)m * G.sam + (int64_t)k * G.sak] : 0.0;
+    }
+    {
+      const int kk = b_n_fast ? ty : tx, nn = b_n_fast ? tx : ty;
+      const int k = k0 + kk, n = n0 + nn;
+      Bs[kk][nn] = (k < G.K && n < G.N) ? (double)G.B[(int64_t)k * G.sbk + (int64_t)n * G.sbn] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) acc = __builtin_fma(As[ty][kk], Bs[kk][tx], acc);
+    __syncthreads();
+  }
+  const int m = m0 + ty, n = n0 + tx;
+  if (m < G.M && n < G.N) {
+    if (G.u) acc += (double)G.u[m] * (G.v ? (double)G.v[n] : 1.0);
+    G.C[(int64_t)m * G.ldc + n] = (float)acc;
+  }
+}
+
+hipError_t launch_fold_gemms(const FoldGemm* jobs, int njobs, hipStream_t stream) {
+  if (njobs < 1 || njobs > kFoldMaxJobs) return hipErrorInvalidValue;
+  FoldArgs a{};
+  a.njobs = njobs;
+  int blk = 0;
+  for (int j = 0; j < njobs; ++j) {
+    a.job[j] = jobs[j];
+    a.blk_begin[j] = blk;
+    blk += ((jobs[j].M + 15) / 16) * ((jobs[j].N + 15) / 16);
+  }
+  a.blk_begin[njobs] = blk;
+  fold_gemm_kernel<<<dim3(blk), dim3(256), 0, stream>>>(a);
+  return hipGetLastError();
+}
+
+hipError_t launch_fold_view(const float* Wv, int ldv, const float* bv, const float* Wb, const float* bb, float* Wf, float* bf, hipStream_t stream) {
+  const FoldGemm jobs[2] = {
+      {Wv, ldv, 1, Wb, 256, 1, Wf, 256, 128, 256, 256, nullptr, nullptr},      // W'[o][i] = sum_k Wv[o][k] Wb[k][i]
+      {Wv, ldv, 1, bb, 1, 0, bf, 1, 128, 1, 256, bv, nullptr},                  // b'[o] = sum_k Wv[o][k] bb[k] + bv[o]
+  };
+  return launch_fold_gemms(jobs, 2, stream);
+}
+
+hipError_t launch_unfold_view(const float* dWf, const float* dbf, const float* Wv, int ldv, const float* Wb, const float* bb, float* dWv, int ld_dwv,
+                              float* dWb, float* dbb, hipStream_t stream) {
+  const FoldGemm jobs[3] = {
+      {Wv, 1, ldv, dWf, 256, 1, dWb, 256, 256, 256, 128, nullptr, nullptr},     // dWb[k][i] = sum_o Wv[o][k] dW'[o][i]
+      {dWf, 256, 1, Wb, 1, 256, dWv, ld_dwv, 128, 256, 256, dbf, bb},           // dWv[o][k] = sum_i dW'[o][i] Wb[k][i] + db'[o] bb[k]
+      {Wv, 1, ldv, dbf, 1, 0, dbb, 1, 256, 1, 128, nullptr, nullptr},           // dbb[k] = sum_o Wv[o][k] db'[o]
+  };
+  return launch_fold_gemms(jobs, 3, stream);
+}
+
+}  // namespace aon

@@ -19,6 +19,7 @@
 //     read their A operands with conflict-free ds_read_b128 (4 MFMA steps per read).
 //   * per 128-sample pass a wave issues ~9.3k MFMAs (64 cycles each) against ~2.4k ds_read_b128 and a few
 //     hundred VALU ops (bias init, ReLU, heads), so the kernel is bound by the fp32 matrix pipe.
+#include "aon_fold.h"
 #include "aon_mlp_core.h"
 
 namespace aon {
@@ -29,6 +30,13 @@ struct VanillaNet {
   static constexpr int kNumChunks = aon::kNumChunks;
   static constexpr int chunk_bytes(int c) { return aon::chunk_bytes(c); }
 };
+// bottleneck_layer folded into views_linear[0] (aon_common.h): chunks 0 .. 59 of the literal stream, 8 small chunks of W', the view-encoding chunk
+struct VanillaFoldNet {
+  static constexpr int kSlotBytes = kPairSlotBytes;
+  static constexpr bool kPair = true;
+  static constexpr int kNumChunks = aon::kNumChunksF;
+  static constexpr int chunk_bytes(int c) { return aon::chunk_bytes_f(c); }
+};
 
 // ---------------------------------------------------------------------------------------------
 // weight packing
@@ -38,17 +46,23 @@ struct PackArgs {
 };
 
 // (pos_col_in / view_col_in: aon_mlp_core.h)
+// FOLD: the folded form (aon_common.h).  W' / b' were written to packed + kFoldTmpOff by launch_fold_view on the same stream; the pack
+// kernel's own writes stay below kStreamBytesF or at / above kStreamBytes, so it never overwrites what it reads.
+template <bool FOLD>
 __global__ void pack_vanilla_kernel(PackArgs a, float* __restrict__ packed, int L, int Lv) {
   const int P = 3 + 6 * L, V = 3 + 6 * Lv;
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   constexpr int64_t stream_floats = kStreamBytes / 4;
+  constexpr int64_t used_floats = FOLD ? kStreamBytesF / 4 : stream_floats;
+  const float* Wf = packed + kFoldTmpOff / 4;      // [FOLD] (128, 256), then b' (128)
   if (idx >= stream_floats + kSmallFloats) return;
+  if (idx >= used_floats && idx < stream_floats) return;   // [FOLD] the fold temporaries / unused tail of the literal-size buffer
   if (idx >= stream_floats) {  // resident small vectors
     const int s = (int)(idx - stream_floats);
     float v = 0.f;
     if (s < kSmBiasBott) v = a.p[2 * (s >> 8) + 1][s & 255];
     else if (s < kSmBiasView) v = a.p[19][s - kSmBiasBott];
-    else if (s < kSmWSigma) v = a.p[17][s - kSmBiasView];
+    else if (s < kSmWSigma) v = FOLD ? Wf[128 * 256 + s - kSmBiasView] : a.p[17][s - kSmBiasView];
     else if (s < kSmWRgb) v = a.p[20][s - kSmWSigma];
     else if (s < kSmBSigma) v = a.p[22][s - kSmWRgb];
     else if (s < kSmBRgb) v = a.p[21][0];
@@ -57,11 +71,13 @@ __global__ void pack_vanilla_kernel(PackArgs a, float* __restrict__ packed, int 
     return;
   }
   int c, r, nt;
-  if (idx < (int64_t)kNumBigChunks * (kBigChunkBytes / 4)) {
+  constexpr int nbig = FOLD ? kChFView : kNumBigChunks;
+  if (idx < (int64_t)nbig * (kBigChunkBytes / 4)) {
     c = (int)(idx / (kBigChunkBytes / 4)); r = (int)(idx % (kBigChunkBytes / 4)); nt = 8;
   } else {
-    const int64_t i2 = idx - (int64_t)kNumBigChunks * (kBigChunkBytes / 4);
-    c = kNumBigChunks + (int)(i2 / (kSmallChunkBytes / 4)); r = (int)(i2 % (kSmallChunkBytes / 4)); nt = 4;
+    const int64_t i2 = idx - (int64_t)nbig * (kBigChunkBytes / 4);
+    c = nbig + (int)(i2 / (kSmallChunkBytes / 4)); r = (int)(i2 % (kSmallChunkBytes / 4)); nt = 4;
+    if constexpr (FOLD) c += kChView - kChFView;   // the folded view chunks take the literal view layer's branches below, with W' for the hidden columns
   }
   const int cc = r & 3, lane = (r >> 2) & 63, rest = r >> 8;
   const int tp = rest % nt, q = rest / nt;
@@ -77,7 +93,10 @@ __global__ void pack_vanilla_kernel(PackArgs a, float* __restrict__ packed, int 
   else if (c < kChL7) { W = a.p[12]; ld = 256; col = 32 * (c - kChL6) + hid_col; }
   else if (c < kChBott) { W = a.p[14]; ld = 256; col = 32 * (c - kChL7) + hid_col; }
   else if (c < kChView) { W = a.p[18]; ld = 256; col = 32 * (c - kChBott) + hid_col; }
-  else if (c < kChView + 8) { W = a.p[16]; ld = 256 + V; n_out = kCondWidth; col = 32 * (c - kChView) + hid_col; }
+  else if (c < kChView + 8) {
+    W = a.p[16]; ld = 256 + V; n_out = kCondWidth; col = 32 * (c - kChView) + hid_col;
+    if constexpr (FOLD) { W = Wf; ld = 256; }
+  }
   else { W = a.p[16]; ld = 256 + V; n_out = kCondWidth; col = vcol(viewenc_col(q, cc, h)); if (col >= 0) col += 256; }
   packed[idx] = (col >= 0 && row < n_out) ? W[(int64_t)row * ld + col] : 0.f;
 }
@@ -111,8 +130,11 @@ struct MlpArgs {
 constexpr int kLdsBytes = kRingBytes + (int)kSmallBytes;
 
 // TRAIN additionally stores every layer's input/output activations as step-major planes (aon_mlp_core.h) for the backward pass.
-template <bool ENC_IN_KERNEL, bool TRAIN>
+// FOLD: the stream is the folded form -- the view layer reads the post-ReLU layer-7 output through W' (aon_common.h), there is no
+// bottleneck layer (and, [TRAIN], no bottleneck rows in the planes: rows kPlBot .. kPlBot + 255 stay unwritten).
+template <bool ENC_IN_KERNEL, bool TRAIN, bool FOLD>
 __global__ void __launch_bounds__(256) mlp_fwd_kernel(MlpArgs args) {
+  using Net = std::conditional_t<FOLD, VanillaFoldNet, VanillaNet>;
   // <false, true>: training on caller-encoded inputs (other encoding degrees in the padded 63 / 27-slot layout): where the
   // in-kernel form re-encodes from x[] / vd[], this one re-reads the encodings.
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -133,7 +155,7 @@ __global__ void __launch_bounds__(256) mlp_fwd_kernel(MlpArgs args) {
   load_small(args.seg[cur].packed);
 
   Pipe p;
-  pipe_init<VanillaNet>(p, args.seg[cur].packed, smem, wave, lane);  // also publishes the small block just written to LDS
+  pipe_init<Net>(p, args.seg[cur].packed, smem, wave, lane);  // also publishes the small block just written to LDS
 
   for (int gpass = blockIdx.x; gpass < args.npass_total; gpass += gridDim.x) {
     const int si = gpass >= npass0 ? 1 : 0;
@@ -204,17 +226,17 @@ __global__ void __launch_bounds__(256) mlp_fwd_kernel(MlpArgs args) {
     u32x4 mw;
     // L0: enc(63) -> 256
     init_bias(X, sm + kSmBias + 0 * 256, h);
-    chunk_mma<VanillaNet, kChL0 + 0, 8, 16>(p, E[0], X);
-    chunk_mma<VanillaNet, kChL0 + 1, 8, 16>(p, E[1], X);
+    chunk_mma<Net, kChL0 + 0, 8, 16>(p, E[0], X);
+    chunk_mma<Net, kChL0 + 1, 8, 16>(p, E[1], X);
     relu_tiles(X);
     // L1..L4
-    mw = u32x4{0u, 0u, 0u, 0u}; init_bias(Y, sm + kSmBias + 1 * 256, h); dense_layer<VanillaNet, kChL1 + 0, 8, 8>(p, X, Y, consume(X, plane_h(0), mw, true)); put_mask(mw, 0); relu_tiles(Y);
-    mw = u32x4{0u, 0u, 0u, 0u}; init_bias(X, sm + kSmBias + 2 * 256, h); dense_layer<VanillaNet, kChL1 + 8, 8, 8>(p, Y, X, consume(Y, plane_h(1), mw, true)); put_mask(mw, 1); relu_tiles(X);
-    mw = u32x4{0u, 0u, 0u, 0u}; init_bias(Y, sm + kSmBias + 3 * 256, h); dense_layer<VanillaNet, kChL1 + 16, 8, 8>(p, X, Y, consume(X, plane_h(2), mw, true)); put_mask(mw, 2); relu_tiles(Y);
-    mw = u32x4{0u, 0u, 0u, 0u}; init_bias(X, sm + kSmBias + 4 * 256, h); dense_layer<VanillaNet, kChL1 + 24, 8, 8>(p, Y, X, consume(Y, plane_h(3), mw, true)); put_mask(mw, 3); relu_tiles(X);
+    mw = u32x4{0u, 0u, 0u, 0u}; init_bias(Y, sm + kSmBias + 1 * 256, h); dense_layer<Net, kChL1 + 0, 8, 8>(p, X, Y, consume(X, plane_h(0), mw, true)); put_mask(mw, 0); relu_tiles(Y);
+    mw = u32x4{0u, 0u, 0u, 0u}; init_bias(X, sm + kSmBias + 2 * 256, h); dense_layer<Net, kChL1 + 8, 8, 8>(p, Y, X, consume(Y, plane_h(1), mw, true)); put_mask(mw, 1); relu_tiles(X);
+    mw = u32x4{0u, 0u, 0u, 0u}; init_bias(Y, sm + kSmBias + 3 * 256, h); dense_layer<Net, kChL1 + 16, 8, 8>(p, X, Y, consume(X, plane_h(2), mw, true)); put_mask(mw, 2); relu_tiles(Y);
+    mw = u32x4{0u, 0u, 0u, 0u}; init_bias(X, sm + kSmBias + 4 * 256, h); dense_layer<Net, kChL1 + 24, 8, 8>(p, Y, X, consume(Y, plane_h(3), mw, true)); put_mask(mw, 3); relu_tiles(X);
     // L5: cat[h(256), enc(63)] -> 256     (model.py:102-103: concat after layer 4's ReLU)
     mw = u32x4{0u, 0u, 0u, 0u}; init_bias(Y, sm + kSmBias + 5 * 256, h);
-    dense_layer<VanillaNet, kChL5, 8, 8>(p, X, Y, consume(X, plane_h(4), mw, true)); put_mask(mw, 4);
+    dense_layer<Net, kChL5, 8, 8>(p, X, Y, consume(X, plane_h(4), mw, true)); put_mask(mw, 4);
     if constexpr (TRAIN && ENC_IN_KERNEL) {  // (x made opaque: otherwise the two identical encodings are merged and the first stays live)
       asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]));
       encode_pos(x, h, E);
@@ -224,21 +246,29 @@ __global__ void __launch_bounds__(256) mlp_fwd_kernel(MlpArgs args) {
       asm volatile("" : "+v"(gq));   // opaque: a second read, not the first one kept live
       load_pos_enc(sg.samples_enc + gq * kPosEnc, h, E);
     }
-    chunk_mma<VanillaNet, kChL5 + 8, 8, 16>(p, E[0], Y);
-    chunk_mma<VanillaNet, kChL5 + 9, 8, 16>(p, E[1], Y);
+    chunk_mma<Net, kChL5 + 8, 8, 16>(p, E[0], Y);
+    chunk_mma<Net, kChL5 + 9, 8, 16>(p, E[1], Y);
     relu_tiles(Y);
     // L6, L7
-    mw = u32x4{0u, 0u, 0u, 0u}; init_bias(X, sm + kSmBias + 6 * 256, h); dense_layer<VanillaNet, kChL6, 8, 8>(p, Y, X, consume(Y, plane_h(5), mw, true)); put_mask(mw, 5); relu_tiles(X);
-    mw = u32x4{0u, 0u, 0u, 0u}; init_bias(Y, sm + kSmBias + 7 * 256, h); dense_layer<VanillaNet, kChL7, 8, 8>(p, X, Y, consume(X, plane_h(6), mw, true)); put_mask(mw, 6); relu_tiles(Y);
+    mw = u32x4{0u, 0u, 0u, 0u}; init_bias(X, sm + kSmBias + 6 * 256, h); dense_layer<Net, kChL6, 8, 8>(p, Y, X, consume(Y, plane_h(5), mw, true)); put_mask(mw, 5); relu_tiles(X);
+    mw = u32x4{0u, 0u, 0u, 0u}; init_bias(Y, sm + kSmBias + 7 * 256, h); dense_layer<Net, kChL7, 8, 8>(p, X, Y, consume(X, plane_h(6), mw, true)); put_mask(mw, 6); relu_tiles(Y);
     // density head (model.py:105) on the post-ReLU layer-7 output
     float sigma = head_partial<8>(Y, sm + kSmWSigma, h);
     sigma = sigma + __shfl_xor(sigma, 32) + sm[kSmBSigma];
-    // bottleneck, no activation (model.py:109)
-    mw = u32x4{0u, 0u, 0u, 0u}; init_bias(X, sm + kSmBiasBott, h); dense_layer<VanillaNet, kChBott, 8, 8>(p, Y, X, consume(Y, plane_h(7), mw, true)); put_mask(mw, 7);
-    // view branch: cat[bottleneck(256), viewenc(27)] -> 128, ReLU (model.py:110-116)
     f32x16 Z[4];
-    init_bias(Z, sm + kSmBiasView, h);
-    dense_layer<VanillaNet, kChView, 8, 4>(p, X, Z, consume(X, kPlBot, mw, false));
+    constexpr int kChV = FOLD ? kChFView : kChView;
+    if constexpr (FOLD) {
+      // bottleneck (no activation, model.py:109) and the view layer's hidden columns (model.py:110-116) as ONE layer W' = W_v0[:, :256] W_b,
+      // b' = W_v0[:, :256] b_b + b_v0 on the post-ReLU layer-7 output
+      mw = u32x4{0u, 0u, 0u, 0u}; init_bias(Z, sm + kSmBiasView, h);
+      dense_layer<Net, kChV, 8, 4>(p, Y, Z, consume(Y, plane_h(7), mw, true)); put_mask(mw, 7);
+    } else {
+      // bottleneck, no activation (model.py:109)
+      mw = u32x4{0u, 0u, 0u, 0u}; init_bias(X, sm + kSmBiasBott, h); dense_layer<Net, kChBott, 8, 8>(p, Y, X, consume(Y, plane_h(7), mw, true)); put_mask(mw, 7);
+      // view branch: cat[bottleneck(256), viewenc(27)] -> 128, ReLU (model.py:110-116)
+      init_bias(Z, sm + kSmBiasView, h);
+      dense_layer<Net, kChV, 8, 4>(p, X, Z, consume(X, kPlBot, mw, false));
+    }
     if constexpr (TRAIN && ENC_IN_KERNEL) {
       asm volatile("" : "+v"(vd[0]), "+v"(vd[1]), "+v"(vd[2]));
       encode_view(vd, h, V);
@@ -248,7 +278,7 @@ __global__ void __launch_bounds__(256) mlp_fwd_kernel(MlpArgs args) {
       asm volatile("" : "+v"(rq));
       load_view_enc(sg.viewdirs_enc + rq * kViewEnc, h, V);
     }
-    chunk_mma<VanillaNet, kChView + 8, 4, 14>(p, V, Z);
+    chunk_mma<Net, kChV + 8, 4, 14>(p, V, Z);
     relu_tiles(Z);
     if constexpr (TRAIN) {  // the view layer's output feeds the rgb head on the VALU: no consuming chunk, 64 values stored here
       *mask_ptr(sg.masks, sg.Np, 8, moff) = relu_mask_bits(Z);   // burst form: already in the stored bit layout
@@ -272,11 +302,20 @@ __global__ void __launch_bounds__(256) mlp_fwd_kernel(MlpArgs args) {
 // ---------------------------------------------------------------------------------------------
 // host launchers (called from the C ABI)
 // ---------------------------------------------------------------------------------------------
+// The form packed is the process default at the time of the call (aon_set_bottleneck_fold), remembered for `packed` (stream_form).
 hipError_t launch_pack_vanilla(const float* const* params, float* packed, hipStream_t stream, int pos_levels, int view_levels) {
   PackArgs a;
   for (int i = 0; i < kNumVanillaParams; ++i) a.p[i] = params[i];
   const int64_t n = kStreamBytes / 4 + kSmallFloats;
-  pack_vanilla_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream>>>(a, packed, pos_levels, view_levels);
+  const int form = fold_default();
+  set_stream_form(packed, form);
+  if (form == kFormFolded) {
+    float* Wf = packed + kFoldTmpOff / 4;
+    if (hipError_t e = launch_fold_view(params[16], 256 + 3 + 6 * view_levels, params[17], params[18], params[19], Wf, Wf + 128 * 256, stream); e != hipSuccess) return e;
+    pack_vanilla_kernel<true><<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream>>>(a, packed, pos_levels, view_levels);
+  } else {
+    pack_vanilla_kernel<false><<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream>>>(a, packed, pos_levels, view_levels);
+  }
   return hipGetLastError();
 }
 
@@ -295,16 +334,24 @@ int num_cus() {  // CUs of the CURRENT device, cached per device ordinal (ops.py
   return cus;
 }
 
-template <bool ENC, bool TRAIN>
-static hipError_t launch_mlp_t(const MlpArgs& args, hipStream_t stream) {
+template <bool ENC, bool TRAIN, bool FOLD>
+static hipError_t launch_mlp_tf(const MlpArgs& args, hipStream_t stream) {
   static DeviceOnce lds_once;  // one per template instance
-  if (hipError_t e = set_max_lds(&mlp_fwd_kernel<ENC, TRAIN>, kLdsBytes, lds_once); e != hipSuccess) return e;
+  if (hipError_t e = set_max_lds(&mlp_fwd_kernel<ENC, TRAIN, FOLD>, kLdsBytes, lds_once); e != hipSuccess) return e;
   const int g_num_cus = num_cus();
   if (g_num_cus <= 0) return hipErrorInvalidDevice;
   const int grid = args.npass_total < g_num_cus ? args.npass_total : g_num_cus;
   if (grid <= 0) return hipSuccess;
-  mlp_fwd_kernel<ENC, TRAIN><<<dim3(grid), dim3(256), kLdsBytes, stream>>>(args);
+  mlp_fwd_kernel<ENC, TRAIN, FOLD><<<dim3(grid), dim3(256), kLdsBytes, stream>>>(args);
   return hipGetLastError();
+}
+
+// the kernel of the form the launch's streams were packed in; the segments of one launch must agree
+template <bool ENC, bool TRAIN>
+static hipError_t launch_mlp_t(const MlpArgs& args, hipStream_t stream) {
+  const int form = stream_form(args.seg[0].packed);
+  if (args.seg[1].npass > 0 && stream_form(args.seg[1].packed) != form) return hipErrorInvalidValue;
+  return form == kFormFolded ? launch_mlp_tf<ENC, TRAIN, true>(args, stream) : launch_mlp_tf<ENC, TRAIN, false>(args, stream);
 }
 
 hipError_t launch_mlp_fwd(const char* packed, const float* rays_o, const float* rays_d, const float* viewdirs,

@@ -12,6 +12,7 @@
 //   * the 3->128 first deformation layer and the 128->3 deformation head are VALU work on register tiles;
 //     the deformed point is encoded in registers exactly like the vanilla path.
 #include "aon_art_common.h"
+#include "aon_fold.h"
 
 namespace aon {
 
@@ -29,25 +30,41 @@ struct ArtNet {
 };
 constexpr int64_t kAStreamBytes = ArtNet::chunk_offset(kANumChunks);  // 2,768,896 B
 
+struct ArtFoldNet {   // folded form (aon_art_common.h)
+  static constexpr int kSlotBytes = kPairSlotBytes;
+  static constexpr bool kPair = true;
+  static constexpr int kNumChunks = kANumChunksF;
+  static constexpr int chunk_bytes(int c) { return (c < kAChT0 || c >= kAChFV0) ? kSmallChunkBytes : kBigChunkBytes; }
+};
+constexpr int64_t kAStreamBytesF = (int64_t)kAChT0 * kSmallChunkBytes + (int64_t)(kAChFV0 - kAChT0) * kBigChunkBytes + (int64_t)(kANumChunksF - kAChFV0) * kSmallChunkBytes;
+constexpr int64_t kAFoldTmpOff = kAStreamBytesF;   // W' (128 x 256 floats) for the pack kernel, inside the literal-size buffer
+static_assert(kAStreamBytesF + 128 * 256 * 4 <= kAStreamBytes, "fold temporary fits behind the folded stream");
+
 struct ArtPackArgs {
   const float* p[kNumArtParams];
 };
 
 // L / Lv: frequency levels of the network (defaults 10 / 4); the weights' row strides follow: pts_linears.0 (256, P + 128),
 // pts_linears.5 (256, 256 + P + 128), views_linear.0 (128, 256 + V + 128) with P = 3 + 6 L, V = 3 + 6 Lv
+// FOLD: the folded form; W' was written to packed + kAFoldTmpOff by launch_fold_view on the same stream (b' belongs to the per-call block)
+template <bool FOLD>
 __global__ void pack_art_kernel(ArtPackArgs a, float* __restrict__ packed, int L, int Lv) {
   const int P = 3 + 6 * L, V = 3 + 6 * Lv;
   auto pcol = [&](int c63) { return c63 < 0 ? -1 : pos_col_in(c63, L); };
   auto vcol = [&](int c27) { return c27 < 0 ? -1 : view_col_in(c27, Lv); };
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= kAStreamBytes / 4) return;
+  if (idx >= (FOLD ? kAStreamBytesF : kAStreamBytes) / 4) return;
   // locate the chunk
   int c, r, nt;
+  constexpr int first_small_tail = FOLD ? kAChFV0 : kAChV0;
   const int64_t s0 = (int64_t)kAChT0 * (kSmallChunkBytes / 4);
-  const int64_t s1 = s0 + (int64_t)(kAChV0 - kAChT0) * (kBigChunkBytes / 4);
+  const int64_t s1 = s0 + (int64_t)(first_small_tail - kAChT0) * (kBigChunkBytes / 4);
   if (idx < s0) { c = (int)(idx / (kSmallChunkBytes / 4)); r = (int)(idx % (kSmallChunkBytes / 4)); nt = 4; }
   else if (idx < s1) { c = kAChT0 + (int)((idx - s0) / (kBigChunkBytes / 4)); r = (int)((idx - s0) % (kBigChunkBytes / 4)); nt = 8; }
-  else { c = kAChV0 + (int)((idx - s1) / (kSmallChunkBytes / 4)); r = (int)((idx - s1) % (kSmallChunkBytes / 4)); nt = 4; }
+  else {
+    c = first_small_tail + (int)((idx - s1) / (kSmallChunkBytes / 4)); r = (int)((idx - s1) % (kSmallChunkBytes / 4)); nt = 4;
+    if constexpr (FOLD) c += kAChV0 - kAChFV0;   // the view branch's chunks take the literal branches below, W' for views_linear.0's hidden columns
+  }
   const int cc = r & 3, lane = (r >> 2) & 63, rest = r >> 8;
   const int tp = rest % nt, q = rest / nt;
   const int h = lane >> 5, row = 32 * tp + (lane & 31);
@@ -61,7 +78,10 @@ __global__ void pack_art_kernel(ArtPackArgs a, float* __restrict__ packed, int L
   else if (c < kAChT7) { W = a.p[22]; ld = 256; col = 32 * (c - kAChT6) + hid; }
   else if (c < kAChBott) { W = a.p[24]; ld = 256; col = 32 * (c - kAChT7) + hid; }
   else if (c < kAChV0) { W = a.p[34]; ld = 256; col = 32 * (c - kAChBott) + hid; }
-  else if (c < kAChV0 + 8) { W = a.p[26]; ld = 256 + V + 128; col = 32 * (c - kAChV0) + hid; }
+  else if (c < kAChV0 + 8) {
+    W = a.p[26]; ld = 256 + V + 128; col = 32 * (c - kAChV0) + hid;
+    if constexpr (FOLD) { W = packed + kAFoldTmpOff / 4; ld = 256; }
+  }
   else if (c < kAChV1) { W = a.p[26]; ld = 256 + V + 128; col = vcol(viewenc_col(q, cc, h)); if (col >= 0) col += 256; }
   else { const int l = 1 + (c - kAChV1) / 4; W = a.p[26 + 2 * l]; ld = 128; col = 32 * ((c - kAChV1) % 4) + hid; }
   packed[idx] = col >= 0 ? W[(int64_t)row * ld + col] : 0.f;  // every layer here has a multiple of 32 outputs
@@ -75,7 +95,8 @@ struct ArtPrepArgs {
 };
 
 // small[] = plain copies of the small vectors + the latent-folded effective biases
-__global__ void prepare_art_kernel(ArtPrepArgs a, float* __restrict__ small, int min_deg, int L, int Lv) {
+// fold: the block of a FOLDED stream -- views_linear.0's effective bias additionally carries W_v0[:, :256] b_b (in fp64, rounded once with the rest)
+__global__ void prepare_art_kernel(ArtPrepArgs a, float* __restrict__ small, int min_deg, int L, int Lv, int fold) {
   const int P = 3 + 6 * L, V = 3 + 6 * Lv;
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= kASmallFloats) return;
@@ -113,6 +134,12 @@ __global__ void prepare_art_kernel(ArtPrepArgs a, float* __restrict__ small, int
     if (l == 0) {        // cat[bottleneck(256), viewenc(27), appearance(128)]  (:228-230)
       const float* w = a.p[26] + (int64_t)f * (256 + V + 128) + 256 + V;
       for (int k = 0; k < 128; ++k) acc = __builtin_fmaf(w[k], a.app[k], acc);
+      if (fold) {
+        const float* wb = a.p[26] + (int64_t)f * (256 + V + 128);
+        double t = 0.0;
+        for (int k = 0; k < 256; ++k) t = __builtin_fma((double)wb[k], (double)a.p[35][k], t);
+        acc = (float)((double)acc + t);
+      }
     }
     v = acc;
   } else if (s < kA_WRGB) { v = a.p[36][s - kA_WSIG]; }
@@ -148,8 +175,12 @@ struct ArtMlpArgs {
   int npass_total;        // seg[0].npass + seg[1].npass (seg[1].npass == 0: a one-segment launch)
 };
 
-template <bool POS_IN_KERNEL, bool TRAIN>
+// FOLD: stream and per-call block are the folded form's (aon_art_common.h): views_linear.0 reads the post-ReLU layer-7 output through W';
+// no bottleneck layer and, [TRAIN], no bottleneck rows in the planes (rows kAPlBot .. kAPlBot + 255 stay unwritten).
+template <bool POS_IN_KERNEL, bool TRAIN, bool FOLD>
 __global__ void __launch_bounds__(256) art_mlp_fwd_kernel(ArtMlpArgs args) {
+  using Net = std::conditional_t<FOLD, ArtFoldNet, ArtNet>;
+  constexpr int kV0 = FOLD ? kAChFV0 : kAChV0, kV1 = FOLD ? kAChFV1 : kAChV1;
   static_assert(!TRAIN || POS_IN_KERNEL, "the training path encodes the view direction from vd[], which only the in-kernel ray cast fills");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* sm = reinterpret_cast<float*>(smem + kRingBytes);
@@ -166,7 +197,7 @@ __global__ void __launch_bounds__(256) art_mlp_fwd_kernel(ArtMlpArgs args) {
   };
   load_small(args.seg[cur].small);
   Pipe p;
-  pipe_init<ArtNet>(p, args.seg[cur].packed, smem, wave, lane);  // also publishes the small block just written to LDS
+  pipe_init<Net>(p, args.seg[cur].packed, smem, wave, lane);  // also publishes the small block just written to LDS
 
   for (int gpass = blockIdx.x; gpass < args.npass_total; gpass += gridDim.x) {
     const int si = gpass >= npass0 ? 1 : 0;
@@ -261,9 +292,9 @@ __global__ void __launch_bounds__(256) art_mlp_fwd_kernel(ArtMlpArgs args) {
       }
     }
     relu_tiles(H0);
-    init_bias(H1, sm + kA_BD + 0 * 128, h); dense_layer<ArtNet, kAChD1 + 0, 4, 4>(p, H0, H1, consume4(H0, aplane_d(0), true)); put_mask(0); relu_tiles(H1);
-    init_bias(H0, sm + kA_BD + 1 * 128, h); dense_layer<ArtNet, kAChD1 + 4, 4, 4>(p, H1, H0, consume4(H1, aplane_d(1), true)); put_mask(1); relu_tiles(H0);
-    init_bias(H1, sm + kA_BD + 2 * 128, h); dense_layer<ArtNet, kAChD1 + 8, 4, 4>(p, H0, H1, consume4(H0, aplane_d(2), true)); put_mask(2); relu_tiles(H1);
+    init_bias(H1, sm + kA_BD + 0 * 128, h); dense_layer<Net, kAChD1 + 0, 4, 4>(p, H0, H1, consume4(H0, aplane_d(0), true)); put_mask(0); relu_tiles(H1);
+    init_bias(H0, sm + kA_BD + 1 * 128, h); dense_layer<Net, kAChD1 + 4, 4, 4>(p, H1, H0, consume4(H1, aplane_d(1), true)); put_mask(1); relu_tiles(H0);
+    init_bias(H1, sm + kA_BD + 2 * 128, h); dense_layer<Net, kAChD1 + 8, 4, 4>(p, H0, H1, consume4(H0, aplane_d(2), true)); put_mask(2); relu_tiles(H1);
     burst(H1, aplane_d(3), 3);
     float xd[3];
 #pragma unroll
@@ -283,41 +314,46 @@ __global__ void __launch_bounds__(256) art_mlp_fwd_kernel(ArtMlpArgs args) {
     // ---- trunk (:212-217), shape latent folded into the biases of layers 0 and 5 ----
     f32x16 X[8], Y[8];
     init_bias(X, sm + kA_BT + 0 * 256, h);
-    chunk_mma<ArtNet, kAChT0 + 0, 8, 16>(p, E[0], X);
-    chunk_mma<ArtNet, kAChT0 + 1, 8, 16>(p, E[1], X);
+    chunk_mma<Net, kAChT0 + 0, 8, 16>(p, E[0], X);
+    chunk_mma<Net, kAChT0 + 1, 8, 16>(p, E[1], X);
     relu_tiles(X);
-    init_bias(Y, sm + kA_BT + 1 * 256, h); dense_layer<ArtNet, kAChT1 + 0, 8, 8>(p, X, Y, consume8(X, aplane_h(0), true)); put_mask(4); relu_tiles(Y);
-    init_bias(X, sm + kA_BT + 2 * 256, h); dense_layer<ArtNet, kAChT1 + 8, 8, 8>(p, Y, X, consume8(Y, aplane_h(1), true)); put_mask(5); relu_tiles(X);
-    init_bias(Y, sm + kA_BT + 3 * 256, h); dense_layer<ArtNet, kAChT1 + 16, 8, 8>(p, X, Y, consume8(X, aplane_h(2), true)); put_mask(6); relu_tiles(Y);
-    init_bias(X, sm + kA_BT + 4 * 256, h); dense_layer<ArtNet, kAChT1 + 24, 8, 8>(p, Y, X, consume8(Y, aplane_h(3), true)); put_mask(7); relu_tiles(X);
+    init_bias(Y, sm + kA_BT + 1 * 256, h); dense_layer<Net, kAChT1 + 0, 8, 8>(p, X, Y, consume8(X, aplane_h(0), true)); put_mask(4); relu_tiles(Y);
+    init_bias(X, sm + kA_BT + 2 * 256, h); dense_layer<Net, kAChT1 + 8, 8, 8>(p, Y, X, consume8(Y, aplane_h(1), true)); put_mask(5); relu_tiles(X);
+    init_bias(Y, sm + kA_BT + 3 * 256, h); dense_layer<Net, kAChT1 + 16, 8, 8>(p, X, Y, consume8(X, aplane_h(2), true)); put_mask(6); relu_tiles(Y);
+    init_bias(X, sm + kA_BT + 4 * 256, h); dense_layer<Net, kAChT1 + 24, 8, 8>(p, Y, X, consume8(Y, aplane_h(3), true)); put_mask(7); relu_tiles(X);
     init_bias(Y, sm + kA_BT + 5 * 256, h);
-    dense_layer<ArtNet, kAChT5, 8, 8>(p, X, Y, consume8(X, aplane_h(4), true)); put_mask(8);
+    dense_layer<Net, kAChT5, 8, 8>(p, X, Y, consume8(X, aplane_h(4), true)); put_mask(8);
     if constexpr (TRAIN) {  // re-encoded (same function, same bits; xd made opaque so the two encodings are not merged) instead of
       asm volatile("" : "+v"(xd[0]), "+v"(xd[1]), "+v"(xd[2]));   // 32 registers held live across layers 1-4
       encode_pos_scaled(xd, h, sm + kA_ESC, E);
     }
-    chunk_mma<ArtNet, kAChT5 + 8, 8, 16>(p, E[0], Y);
-    chunk_mma<ArtNet, kAChT5 + 9, 8, 16>(p, E[1], Y);
+    chunk_mma<Net, kAChT5 + 8, 8, 16>(p, E[0], Y);
+    chunk_mma<Net, kAChT5 + 9, 8, 16>(p, E[1], Y);
     relu_tiles(Y);
-    init_bias(X, sm + kA_BT + 6 * 256, h); dense_layer<ArtNet, kAChT6, 8, 8>(p, Y, X, consume8(Y, aplane_h(5), true)); put_mask(9); relu_tiles(X);
-    init_bias(Y, sm + kA_BT + 7 * 256, h); dense_layer<ArtNet, kAChT7, 8, 8>(p, X, Y, consume8(X, aplane_h(6), true)); put_mask(10); relu_tiles(Y);
+    init_bias(X, sm + kA_BT + 6 * 256, h); dense_layer<Net, kAChT6, 8, 8>(p, Y, X, consume8(Y, aplane_h(5), true)); put_mask(9); relu_tiles(X);
+    init_bias(Y, sm + kA_BT + 7 * 256, h); dense_layer<Net, kAChT7, 8, 8>(p, X, Y, consume8(X, aplane_h(6), true)); put_mask(10); relu_tiles(Y);
     float sigma = head_partial<8>(Y, sm + kA_WSIG, h);  // density_layer (:219)
     sigma = sigma + __shfl_xor(sigma, 32) + sm[kA_BSIG];
-    init_bias(X, sm + kA_BBOT, h); dense_layer<ArtNet, kAChBott, 8, 8>(p, Y, X, consume8(Y, aplane_h(7), true)); put_mask(11);  // bottleneck (:223)
-
     // ---- view branch (:227-234): cat[bottleneck, viewenc, appearance] -> 4 x (128, ReLU) ----
     f32x16 Z0[4], Z1[4];
-    init_bias(Z0, sm + kA_BV + 0 * 128, h);
-    dense_layer<ArtNet, kAChV0, 8, 4>(p, X, Z0, consume8(X, kAPlBot, false));
+    if constexpr (FOLD) {
+      // bottleneck (:223, no activation) and views_linear.0's bottleneck columns as ONE layer W' on the layer-7 output (effective bias incl. W_v0[:, :256] b_b)
+      init_bias(Z0, sm + kA_BV + 0 * 128, h);
+      dense_layer<Net, kV0, 8, 4>(p, Y, Z0, consume8(Y, aplane_h(7), true)); put_mask(11);
+    } else {
+      init_bias(X, sm + kA_BBOT, h); dense_layer<Net, kAChBott, 8, 8>(p, Y, X, consume8(Y, aplane_h(7), true)); put_mask(11);  // bottleneck (:223)
+      init_bias(Z0, sm + kA_BV + 0 * 128, h);
+      dense_layer<Net, kV0, 8, 4>(p, X, Z0, consume8(X, kAPlBot, false));
+    }
     if constexpr (TRAIN) {
       encode_view(vd, h, V);
       store_view_enc_plane(V, io, kAPlVE, h);
     }
-    chunk_mma<ArtNet, kAChV0 + 8, 4, 14>(p, V, Z0);
+    chunk_mma<Net, kV0 + 8, 4, 14>(p, V, Z0);
     relu_tiles(Z0);
-    init_bias(Z1, sm + kA_BV + 1 * 128, h); dense_layer<ArtNet, kAChV1 + 0, 4, 4>(p, Z0, Z1, consume4(Z0, aplane_v(0), true)); put_mask(12); relu_tiles(Z1);
-    init_bias(Z0, sm + kA_BV + 2 * 128, h); dense_layer<ArtNet, kAChV1 + 4, 4, 4>(p, Z1, Z0, consume4(Z1, aplane_v(1), true)); put_mask(13); relu_tiles(Z0);
-    init_bias(Z1, sm + kA_BV + 3 * 128, h); dense_layer<ArtNet, kAChV1 + 8, 4, 4>(p, Z0, Z1, consume4(Z0, aplane_v(2), true)); put_mask(14); relu_tiles(Z1);
+    init_bias(Z1, sm + kA_BV + 1 * 128, h); dense_layer<Net, kV1 + 0, 4, 4>(p, Z0, Z1, consume4(Z0, aplane_v(0), true)); put_mask(12); relu_tiles(Z1);
+    init_bias(Z0, sm + kA_BV + 2 * 128, h); dense_layer<Net, kV1 + 4, 4, 4>(p, Z1, Z0, consume4(Z1, aplane_v(1), true)); put_mask(13); relu_tiles(Z0);
+    init_bias(Z1, sm + kA_BV + 3 * 128, h); dense_layer<Net, kV1 + 8, 4, 4>(p, Z0, Z1, consume4(Z0, aplane_v(2), true)); put_mask(14); relu_tiles(Z1);
     burst(Z1, aplane_v(3), 15);
     float rgb[3];
 #pragma unroll
@@ -336,11 +372,23 @@ __global__ void __launch_bounds__(256) art_mlp_fwd_kernel(ArtMlpArgs args) {
 // ---------------------------------------------------------------------------------------------
 // host launchers
 // ---------------------------------------------------------------------------------------------
+// The form packed is the process default at the time of the call (aon_set_bottleneck_fold), remembered for `packed` (stream_form).
 hipError_t launch_pack_art(const float* const* params, float* packed, hipStream_t stream, int pos_levels, int view_levels) {
   ArtPackArgs a;
   for (int i = 0; i < kNumArtParams; ++i) a.p[i] = params[i];
-  const int64_t n = kAStreamBytes / 4;
-  pack_art_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream>>>(a, packed, pos_levels, view_levels);
+  const int form = fold_default();
+  set_stream_form(packed, form);
+  if (form == kFormFolded) {
+    float* Wf = packed + kAFoldTmpOff / 4;
+    // (b' is the per-call block's business: prepare_art_kernel; the 128 floats it would take here are not written)
+    const FoldGemm job{params[26], 256 + 3 + 6 * view_levels + 128, 1, params[34], 256, 1, Wf, 256, 128, 256, 256, nullptr, nullptr};
+    if (hipError_t e = launch_fold_gemms(&job, 1, stream); e != hipSuccess) return e;
+    const int64_t n = kAStreamBytesF / 4;
+    pack_art_kernel<true><<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream>>>(a, packed, pos_levels, view_levels);
+  } else {
+    const int64_t n = kAStreamBytes / 4;
+    pack_art_kernel<false><<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream>>>(a, packed, pos_levels, view_levels);
+  }
   return hipGetLastError();
 }
 
@@ -349,22 +397,34 @@ hipError_t launch_prepare_art(const float* const* params, const float* shape, co
   ArtPrepArgs a;
   for (int i = 0; i < kNumArtParams; ++i) a.p[i] = params[i];
   a.shape = shape; a.app = app; a.art = art;
-  prepare_art_kernel<<<dim3((kASmallFloats + 255) / 256), dim3(256), 0, stream>>>(a, small, min_deg, pos_levels, view_levels);
+  // the block's form is the process default at the time of the call, remembered for `small`: a launch refuses a block and a stream of two forms
+  const int form = fold_default();
+  set_stream_form(small, form);
+  prepare_art_kernel<<<dim3((kASmallFloats + 255) / 256), dim3(256), 0, stream>>>(a, small, min_deg, pos_levels, view_levels, form == kFormFolded ? 1 : 0);
   return hipGetLastError();
 }
 
 int num_cus();  // aon_mlp.hip
 
-template <bool POS, bool TRAIN>
-static hipError_t launch_art_t(const ArtMlpArgs& args, hipStream_t stream) {
+template <bool POS, bool TRAIN, bool FOLD>
+static hipError_t launch_art_tf(const ArtMlpArgs& args, hipStream_t stream) {
   static DeviceOnce lds_once;
-  if (hipError_t e = set_max_lds(&art_mlp_fwd_kernel<POS, TRAIN>, kALdsBytes, lds_once); e != hipSuccess) return e;
+  if (hipError_t e = set_max_lds(&art_mlp_fwd_kernel<POS, TRAIN, FOLD>, kALdsBytes, lds_once); e != hipSuccess) return e;
   const int cus = num_cus();
   if (cus <= 0) return hipErrorInvalidDevice;
   const int grid = args.npass_total < cus ? args.npass_total : cus;
   if (grid <= 0) return hipSuccess;
-  art_mlp_fwd_kernel<POS, TRAIN><<<dim3(grid), dim3(256), kALdsBytes, stream>>>(args);
+  art_mlp_fwd_kernel<POS, TRAIN, FOLD><<<dim3(grid), dim3(256), kALdsBytes, stream>>>(args);
   return hipGetLastError();
+}
+
+// the kernel of the form the launch's streams AND per-call blocks were made in; everything in one launch must agree
+template <bool POS, bool TRAIN>
+static hipError_t launch_art_t(const ArtMlpArgs& args, hipStream_t stream) {
+  const int form = stream_form(args.seg[0].packed);
+  if (stream_form(args.seg[0].small) != form) return hipErrorInvalidValue;
+  if (args.seg[1].npass > 0 && (stream_form(args.seg[1].packed) != form || stream_form(args.seg[1].small) != form)) return hipErrorInvalidValue;
+  return form == kFormFolded ? launch_art_tf<POS, TRAIN, true>(args, stream) : launch_art_tf<POS, TRAIN, false>(args, stream);
 }
 
 hipError_t launch_art_mlp_fwd(const char* packed, const float* small, const float* rays_o, const float* rays_d,

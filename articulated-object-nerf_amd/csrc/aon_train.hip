@@ -16,6 +16,7 @@
 #include <atomic>
 #define AON_WGRAD_KERNELS
 #define AON_CHAIN_STAGE_MASKED   // see BwdSideOf (aon_mlp_core.h)
+#include "aon_fold.h"
 #include "aon_wgrad.h"
 
 namespace aon {
@@ -178,22 +179,56 @@ struct BwdNet {
 };
 constexpr int64_t kBwStreamBytes = (int64_t)kBwNumChunks * kBigChunkBytes;
 
+// FOLDED form (aon_common.h: W' = W_v0[:, :256] W_b): chunks 0..3 are W'^T -- d H7 = W'^T dZ_view (+ the density head's term) -- and the
+// bottleneck's eight chunks are gone: 60 chunks.  Behind the stream the buffer keeps what the un-folding of the gradients needs
+// (launch_unfold_view): W_v0[:, :256] compact (128 x 256), W_b (256 x 256), b_b (256); then W' / b' for the pack kernel.
+constexpr int kBwFL7 = 4;
+constexpr int kBwFNumChunks = 60;
+struct BwdFoldNet {
+  static constexpr int kSlotBytes = kPairSlotBytes;
+  static constexpr bool kPair = true;
+  static constexpr int kNumChunks = kBwFNumChunks;
+  static constexpr int chunk_bytes(int) { return kBigChunkBytes; }
+};
+constexpr int64_t kBwFStreamBytes = (int64_t)kBwFNumChunks * kBigChunkBytes;
+constexpr int64_t kBwFOffWv = kBwFStreamBytes;                       // 128 x 256 floats
+constexpr int64_t kBwFOffWb = kBwFOffWv + 128 * 256 * 4;             // 256 x 256
+constexpr int64_t kBwFOffBb = kBwFOffWb + 256 * 256 * 4;             // 256
+constexpr int64_t kBwFOffWf = kBwFOffBb + 256 * 4;                   // 128 x 256, then b' (128)
+constexpr int64_t kBwFBytes = kBwFOffWf + (128 * 256 + 128) * 4;
+constexpr int64_t kBwBufferBytes = kBwFBytes > kBwStreamBytes ? kBwFBytes : kBwStreamBytes;   // aon_bwd_packed_bytes(): either form fits
+
 struct PackArgs24 {
   const float* p[kNumVanillaParams];
 };
 
 // P / V: widths of the network's encodings (63 / 27 by default; other degrees: only the row strides of the two concatenating layers
 // change -- the chain never needs the encoding columns, gradients do not reach the inputs)
+template <bool FOLD>
 __global__ void pack_vanilla_bwd_kernel(PackArgs24 a, float* __restrict__ packed, int P, int V) {
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= kBwStreamBytes / 4) return;
-  const int c = (int)(idx / (kBigChunkBytes / 4)), r = (int)(idx % (kBigChunkBytes / 4));
+  if constexpr (FOLD) {   // raw copies for launch_unfold_view, behind the stream
+    const int64_t i = idx - kBwFOffWv / 4;
+    if (i >= 0) {
+      if (i < 128 * 256) packed[idx] = a.p[16][(i >> 8) * (256 + V) + (i & 255)];
+      else if (i < 128 * 256 + 256 * 256) packed[idx] = a.p[18][i - 128 * 256];
+      else if (i < 128 * 256 + 256 * 256 + 256) packed[idx] = a.p[19][i - 128 * 256 - 256 * 256];
+      return;
+    }
+  }
+  if (idx >= (FOLD ? kBwFStreamBytes : kBwStreamBytes) / 4) return;
+  int c = (int)(idx / (kBigChunkBytes / 4));
+  const int r = (int)(idx % (kBigChunkBytes / 4));
   const int cc = r & 3, lane = (r >> 2) & 63, rest = r >> 8;
   const int tp = rest & 7, q = rest >> 3;
   const int h = lane >> 5, f = 32 * tp + (lane & 31);
   const int jo = 8 * q + 4 * h + cc;
   const float* W; int ld, j;
-  if (c < kBwBott) { W = a.p[16]; ld = 256 + V; j = 32 * c + jo; }
+  if constexpr (FOLD) { if (c >= kBwFL7) c += kBwL7 - kBwFL7; }   // the trunk's chunks take the literal branches below
+  if (c < kBwBott) {
+    W = a.p[16]; ld = 256 + V; j = 32 * c + jo;
+    if constexpr (FOLD) { W = packed + kBwFOffWf / 4; ld = 256; }   // W' (launch_fold_view, same stream, in front of this kernel)
+  }
   else if (c < kBwL7) { W = a.p[18]; ld = 256; j = 32 * (c - kBwBott) + jo; }
   else {
     const int l = 7 - (c - kBwL7) / 8;  // 7,6,5,4,3,2,1
@@ -225,7 +260,11 @@ __device__ __forceinline__ void zero_tiles(f32x16 (&x)[NT]) {
     for (int r = 0; r < 16; ++r) x[t][r] = 0.f;
 }
 
+// FOLD: the transposed stream is the folded form (BwdFoldNet): d H7 = W'^T dZ_view + W_sigma^T d_sigma in one layer, no bottleneck gradient.
+template <bool FOLD>
 __global__ void __launch_bounds__(256) mlp_bwd_chain_kernel(BwdArgs args) {
+  using Net = std::conditional_t<FOLD, BwdFoldNet, BwdNet>;
+  constexpr int kL7 = FOLD ? kBwFL7 : kBwL7;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* sm = reinterpret_cast<float*>(smem + kRingBytes);
   const int tid0 = threadIdx.x;
@@ -240,7 +279,7 @@ __global__ void __launch_bounds__(256) mlp_bwd_chain_kernel(BwdArgs args) {
   };
   load_small(args.seg[cur].small);
   Pipe p;
-  pipe_init<BwdNet>(p, args.seg[cur].packed_bwd, smem, wave, lane);  // also publishes the small block just written to LDS
+  pipe_init<Net>(p, args.seg[cur].packed_bwd, smem, wave, lane);  // also publishes the small block just written to LDS
 
   for (int gpass = blockIdx.x; gpass < args.npass_total; gpass += gridDim.x) {
     const int si = gpass >= npass0 ? 1 : 0;
@@ -291,34 +330,51 @@ __global__ void __launch_bounds__(256) mlp_bwd_chain_kernel(BwdArgs args) {
       }
     }
     f32x16 X[8], Y[8];
-    // d bottleneck = W_view[:, :256]^T . dZ_view, dZ_view = view-layer ReLU mask . dHV   (model.py:109-116)
     mk_next = load_mask(7);
     apply_mask_tile(Z[0], mk, 0);
-    dense_layer<BwdNet, kBwView, 4, 8, BwdSideOf<4, true>, true>(p, Z, X, BwdSideOf<4, true>{Z, kPlHV, io, mk, &mk_next});   // X starts from zero
-    // dH7 = W_bott^T . dBot + W_sigma^T * d_sigma   (the bottleneck has no activation; the density head reads the
-    // post-ReLU layer-7 output, model.py:105)
+    auto sigma_head_into = [&](f32x16 (&T)[8]) {   // W_sigma^T * d_sigma: the density head reads the post-ReLU layer-7 output (model.py:105)
 #pragma unroll
-    for (int t = 0; t < 8; ++t) {
+      for (int t = 0; t < 8; ++t) {
 #pragma unroll
-      for (int gq = 0; gq < 4; ++gq) {
-        const f32x4 w = *reinterpret_cast<const f32x4*>(sm + kSmWSigma + 32 * t + 8 * gq + 4 * hl);
+        for (int gq = 0; gq < 4; ++gq) {
+          const f32x4 w = *reinterpret_cast<const f32x4*>(sm + kSmWSigma + 32 * t + 8 * gq + 4 * hl);
 #pragma unroll
-        for (int cc = 0; cc < 4; ++cc) Y[t][4 * gq + cc] = w[cc] * dr.w;
+          for (int cc = 0; cc < 4; ++cc) T[t][4 * gq + cc] = w[cc] * dr.w;
+        }
       }
+    };
+    if constexpr (FOLD) {
+      // dH7 = W'^T . dZ_view + W_sigma^T * d_sigma, dZ_view = view-layer ReLU mask . dHV   (W' = W_v0[:, :256] W_b: model.py:109-116 as one layer)
+      // (the view layer first, from zero, the density head's term added behind it: initialising Y in front of the layer cost 24 B/lane of scratch)
+      dense_layer<Net, kBwView, 4, 8, BwdSideOf<4, true>, true>(p, Z, Y, BwdSideOf<4, true>{Z, kPlHV, io, mk, &mk_next});
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+          const f32x4 w = *reinterpret_cast<const f32x4*>(sm + kSmWSigma + 32 * t + 8 * gq + 4 * hl);
+#pragma unroll
+          for (int cc = 0; cc < 4; ++cc) Y[t][4 * gq + cc] = __builtin_fmaf(w[cc], dr.w, Y[t][4 * gq + cc]);
+        }
+      }
+    } else {
+      // d bottleneck = W_view[:, :256]^T . dZ_view, dZ_view = view-layer ReLU mask . dHV   (model.py:109-116)
+      dense_layer<Net, kBwView, 4, 8, BwdSideOf<4, true>, true>(p, Z, X, BwdSideOf<4, true>{Z, kPlHV, io, mk, &mk_next});   // X starts from zero
+      // dH7 = W_bott^T . dBot + W_sigma^T * d_sigma   (the bottleneck has no activation)
+      sigma_head_into(Y);
+      dense_layer<Net, kBwBott, 8, 8>(p, X, Y, BwdSideOf<8, false>{X, kPlBot, io, mk});
     }
-    dense_layer<BwdNet, kBwBott, 8, 8>(p, X, Y, BwdSideOf<8, false>{X, kPlBot, io, mk});
     // trunk: dZ_l = mask_l . dH_l (stored by the chunks that consume it), dH_{l-1} = W_l^T . dZ_l
 #define AON_BWD_LAYER(IN, OUT, CB, L)                                                                                  \
     mk = mk_next; if (L > 0) mk_next = load_mask(L - 1);                                                               \
     apply_mask_tile(IN[0], mk, 0);                                                                                     \
-    dense_layer<BwdNet, CB, 8, 8, BwdSideOf<8, true>, true>(p, IN, OUT, BwdSideOf<8, true>{IN, plane_h(L), io, mk, L > 0 ? &mk_next : nullptr});   /* OUT starts from zero; the next layer's bits are waited for two chunks in (BwdSideOf::touch) */
-    AON_BWD_LAYER(Y, X, kBwL7 + 0, 7)
-    AON_BWD_LAYER(X, Y, kBwL7 + 8, 6)
-    AON_BWD_LAYER(Y, X, kBwL7 + 16, 5)
-    AON_BWD_LAYER(X, Y, kBwL7 + 24, 4)
-    AON_BWD_LAYER(Y, X, kBwL7 + 32, 3)
-    AON_BWD_LAYER(X, Y, kBwL7 + 40, 2)
-    AON_BWD_LAYER(Y, X, kBwL7 + 48, 1)
+    dense_layer<Net, CB, 8, 8, BwdSideOf<8, true>, true>(p, IN, OUT, BwdSideOf<8, true>{IN, plane_h(L), io, mk, L > 0 ? &mk_next : nullptr});   /* OUT starts from zero; the next layer's bits are waited for two chunks in (BwdSideOf::touch) */
+    AON_BWD_LAYER(Y, X, kL7 + 0, 7)
+    AON_BWD_LAYER(X, Y, kL7 + 8, 6)
+    AON_BWD_LAYER(Y, X, kL7 + 16, 5)
+    AON_BWD_LAYER(X, Y, kL7 + 24, 4)
+    AON_BWD_LAYER(Y, X, kL7 + 32, 3)
+    AON_BWD_LAYER(X, Y, kL7 + 40, 2)
+    AON_BWD_LAYER(Y, X, kL7 + 48, 1)
 #undef AON_BWD_LAYER
     // dZ0: no data gradient flows into the encoding, so no chunk consumes it -- masked and stored here (128 values)
     apply_mask_bits(X, mk_next);
@@ -332,21 +388,39 @@ __global__ void __launch_bounds__(256) mlp_bwd_chain_kernel(BwdArgs args) {
 // ---------------------------------------------------------------------------------------------
 int num_cus();  // aon_mlp.hip
 
+// The form packed is the process default at the time of the call (aon_set_bottleneck_fold), remembered for `packed` (stream_form).
 hipError_t launch_pack_vanilla_bwd(const float* const* params, float* packed, hipStream_t stream, int pos_size, int view_size) {
   PackArgs24 a;
   for (int i = 0; i < kNumVanillaParams; ++i) a.p[i] = params[i];
-  const int64_t n = kBwStreamBytes / 4;
-  pack_vanilla_bwd_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream>>>(a, packed, pos_size, view_size);
+  const int form = fold_default();
+  set_stream_form(packed, form);
+  if (form == kFormFolded) {
+    float* Wf = packed + kBwFOffWf / 4;
+    if (hipError_t e = launch_fold_view(params[16], 256 + view_size, params[17], params[18], params[19], Wf, Wf + 128 * 256, stream); e != hipSuccess) return e;
+    const int64_t n = kBwFOffWf / 4;   // the stream and the raw copies behind it
+    pack_vanilla_bwd_kernel<true><<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream>>>(a, packed, pos_size, view_size);
+  } else {
+    const int64_t n = kBwStreamBytes / 4;
+    pack_vanilla_bwd_kernel<false><<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream>>>(a, packed, pos_size, view_size);
+  }
   return hipGetLastError();
 }
 
-int64_t bwd_stream_bytes() { return kBwStreamBytes; }
+int64_t bwd_stream_bytes() { return kBwBufferBytes; }
 
-hipError_t launch_mlp_bwd_chain2(const ChainSeg* segs, int nsegs, hipStream_t stream) {
+template <bool FOLD>
+static hipError_t launch_chain_f(const BwdArgs& a, int grid, hipStream_t stream) {
   static DeviceOnce lds_once;
   constexpr int lds = kRingBytes + (int)kSmallBytes;
+  if (hipError_t e = set_max_lds(&mlp_bwd_chain_kernel<FOLD>, lds, lds_once); e != hipSuccess) return e;
+  mlp_bwd_chain_kernel<FOLD><<<dim3(grid), dim3(256), lds, stream>>>(a);
+  return hipGetLastError();
+}
+
+hipError_t launch_mlp_bwd_chain2(const ChainSeg* segs, int nsegs, hipStream_t stream) {
   if (nsegs < 1 || nsegs > 2) return hipErrorInvalidValue;
-  if (hipError_t e = set_max_lds(&mlp_bwd_chain_kernel, lds, lds_once); e != hipSuccess) return e;
+  const int form = stream_form(segs[0].packed_bwd);
+  if (nsegs == 2 && stream_form(segs[1].packed_bwd) != form) return hipErrorInvalidValue;
   BwdArgs a{};
   for (int i = 0; i < nsegs; ++i) {
     const ChainSeg& c = segs[i];
@@ -359,8 +433,7 @@ hipError_t launch_mlp_bwd_chain2(const ChainSeg* segs, int nsegs, hipStream_t st
   if (cus <= 0) return hipErrorInvalidDevice;
   const int grid = a.npass_total < cus ? a.npass_total : cus;
   if (grid <= 0) return hipSuccess;
-  mlp_bwd_chain_kernel<<<dim3(grid), dim3(256), lds, stream>>>(a);
-  return hipGetLastError();
+  return form == kFormFolded ? launch_chain_f<true>(a, grid, stream) : launch_chain_f<false>(a, grid, stream);
 }
 
 hipError_t launch_mlp_bwd_chain(const char* packed_bwd, const char* packed_fwd, const float* d_raw, const void* masks,
@@ -446,7 +519,10 @@ hipError_t launch_wgrad_kind_bench(int kind, int nlayers, const float* planes, c
 
 // grads: 24 device pointers in the parameter order of aon_pack_vanilla_mlp (each the full (out,in) / (out,) tensor), overwritten.
 // the weight-gradient jobs of one vanilla level
-int vanilla_wgrad_layers(float* const* grads, WgLayerDesc* L) {
+// fold_tmp != null: the planes are the folded form's (no bottleneck rows).  The bottleneck and the view layer's hidden columns are ONE job
+// dW' = dZ_view . H7^T (128 x 256) into fold_tmp, db' = db_v0 straight into views_linear.0.bias; launch_unfold_view turns (dW', db') into
+// the gradients of bottleneck_layer and views_linear.0[:, :256].
+int vanilla_wgrad_layers(float* const* grads, WgLayerDesc* L, float* fold_tmp) {
   int n = 0;
   // trunk: dW_l = dZ_l . H_{l-1}^T  (+ the pos-enc columns for layers 0 and 5)
   L[n++] = WgLayerDesc{kWg256x64, plane_h(0), kPlE, grads[0], kPosEnc, 0, kPosEnc, grads[1]};
@@ -455,36 +531,60 @@ int vanilla_wgrad_layers(float* const* grads, WgLayerDesc* L) {
     L[n++] = WgLayerDesc{kWg256x256, plane_h(l), plane_h(l - 1), grads[2 * l], ld, 0, 256, grads[2 * l + 1]};
     if (l == 5) L[n++] = WgLayerDesc{kWg256x64, plane_h(5), kPlE, grads[10], ld, 256, kPosEnc, nullptr};
   }
-  // bottleneck (input: post-ReLU layer-7 output)
-  L[n++] = WgLayerDesc{kWg256x256, kPlBot, plane_h(7), grads[18], 256, 0, 256, grads[19]};
-  // view layer: cat[bottleneck(256), viewenc(27)]: two column blocks of one weight
-  L[n++] = WgLayerDesc{kWg128x256, kPlHV, kPlBot, grads[16], 256 + kViewEnc, 0, 256, grads[17]};
+  if (fold_tmp) {
+    L[n++] = WgLayerDesc{kWg128x256, kPlHV, plane_h(7), fold_tmp, 256, 0, 256, grads[17]};
+  } else {
+    // bottleneck (input: post-ReLU layer-7 output)
+    L[n++] = WgLayerDesc{kWg256x256, kPlBot, plane_h(7), grads[18], 256, 0, 256, grads[19]};
+    // view layer: cat[bottleneck(256), viewenc(27)]: two column blocks of one weight
+    L[n++] = WgLayerDesc{kWg128x256, kPlHV, kPlBot, grads[16], 256 + kViewEnc, 0, 256, grads[17]};
+  }
   L[n++] = WgLayerDesc{kWg128x32, kPlHV, kPlVE, grads[16], 256 + kViewEnc, 256, kViewEnc, nullptr};
   return n;
 }
+int vanilla_wgrad_layers(float* const* grads, WgLayerDesc* L) { return vanilla_wgrad_layers(grads, L, nullptr); }
 
+// dW' (128 x 256) of a folded level: the last MiB of the weight-gradient workspace, which no plan reaches (run_wgrad_plan refuses plans beyond it;
+// the articulated network's slot-layout blocks at other degrees take its first 144 KiB: art_wgrad_layers)
+float* wgrad_fold_tmp(float* ws) { return ws + (wgrad_workspace_bytes_impl() - (1 << 20)) / 4 + 48 * 1024; }   // 192 KiB into that MiB
+
+// packed_bwd: the transposed stream the chain of these planes ran with -- its FORM says whether the planes carry bottleneck rows, and the
+// folded form's buffer holds the raw W_v0[:, :256], W_b, b_b the un-folding needs.  Null: literal planes.
 hipError_t launch_vanilla_wgrad(const float* planes, const float* dplanes, const float* d_raw, int64_t Np, float* const* grads,
-                                float* ws, hipStream_t stream, const WgAux* aux) {
+                                float* ws, hipStream_t stream, const WgAux* aux, const void* packed_bwd) {
   WgLayerDesc L[kWgMaxJobs];
-  const int n = vanilla_wgrad_layers(grads, L);
+  const bool fold = packed_bwd && stream_form(packed_bwd) == kFormFolded;
+  float* fold_tmp = fold ? wgrad_fold_tmp(ws) : nullptr;
+  const int n = vanilla_wgrad_layers(grads, L, fold_tmp);
   // heads and their biases: density_layer (1,256) <- H7 x d_raw.w, rgb_layer (3,128) <- HV x d_raw.xyz, bias sums of d_raw
   const HeadDesc H[3] = {{planes, plane_h(7), 256, d_raw, 128}, {planes, kPlHV, 128, d_raw, 128}, {nullptr, 0, 1, d_raw, 128}};
   const HeadOut O[4] = {{0, 256, 3, 1, 256, 1, grads[20]}, {0, 128, 0, 3, 128, 1, grads[22]}, {0, 1, 3, 1, 1, 1, grads[21]}, {0, 1, 0, 3, 1, 1, grads[23]}};
   const int OH[4] = {0, 1, 2, 2};
-  return run_wgrad_plan(L, n, H, 3, O, OH, 4, planes, dplanes, kPlRows, Np, ws, stream, aux);
+  if (hipError_t e = run_wgrad_plan(L, n, H, 3, O, OH, 4, planes, dplanes, kPlRows, Np, ws, stream, aux); e != hipSuccess) return e;
+  if (!fold) return hipSuccess;
+  const float* raw = reinterpret_cast<const float*>(static_cast<const char*>(packed_bwd) + kBwFOffWv);
+  // (grads[16]'s row stride is the 27-slot layout's here: other view degrees write a slot-layout temporary first, aon_render_bwd_ex)
+  return launch_unfold_view(fold_tmp, grads[17], raw, 256, raw + 128 * 256, raw + 128 * 256 + 256 * 256, grads[16], 256 + kViewEnc, grads[18], grads[19], stream);
 }
 
-int art_wgrad_layers(float* const* grads, WgLayerDesc* L);   // aon_train_art.hip
 
 // Host-only view of the plan a level would run on `cus` compute units (tests/test_abi_cpu.py checks its invariants without a
 // GPU): per job (kind, first workgroup, workgroups that own a step of it, steps of the job, partial offset in floats, partial count);
 // `line`: {W, G} of the work line.
+int art_wgrad_layers(float* const* grads, WgLayerDesc* L, int Lp, int Lv, float* enc_tmp, float* fold_tmp);   // aon_train_art.hip
+
+// (the host-only plan views describe the plan of the process's current default form)
+static int plan_layers(bool art, float* const* grads, WgLayerDesc* L) {
+  float* fold_tmp = fold_default() == kFormFolded ? reinterpret_cast<float*>((uintptr_t)0x100000) : nullptr;   // never dereferenced
+  return art ? art_wgrad_layers(grads, L, 10, 4, nullptr, fold_tmp) : vanilla_wgrad_layers(grads, L, fold_tmp);
+}
+
 int wgrad_plan_describe(bool art, int64_t Np, int cus, int32_t* out6, int max_jobs, int64_t* ws_bytes) {
   if (Np <= 0 || (Np & 31) || cus < 1) return -1;
   float* grads[40];   // >= both parameter counts (24 vanilla, 40 articulated)
   for (int i = 0; i < 40; ++i) grads[i] = reinterpret_cast<float*>((uintptr_t)0x1000 + 64 * i);   // never dereferenced
   WgLayerDesc L[kWgMaxJobs];
-  const int n = art ? art_wgrad_layers(grads, L) : vanilla_wgrad_layers(grads, L);
+  const int n = plan_layers(art, grads, L);
   WgPlan plan;
   if (!wg_make_plan(L, n, nullptr, nullptr, art ? kAPlRows : kPlRows, Np, cus < 304 ? cus : 304, nullptr, 0, plan)) return -2;
   if (n > max_jobs) return -3;
@@ -504,7 +604,7 @@ int wgrad_plan_segment(bool art, int64_t Np, int cus, int j, int wg, int32_t* be
   float* grads[40];
   for (int i = 0; i < 40; ++i) grads[i] = reinterpret_cast<float*>((uintptr_t)0x1000 + 64 * i);
   WgLayerDesc L[kWgMaxJobs];
-  const int n = art ? art_wgrad_layers(grads, L) : vanilla_wgrad_layers(grads, L);
+  const int n = plan_layers(art, grads, L);
   WgPlan plan;
   if (!wg_make_plan(L, n, nullptr, nullptr, art ? kAPlRows : kPlRows, Np, cus < 304 ? cus : 304, nullptr, 0, plan)) return -2;
   if (j < 0 || j >= n || wg < 0 || wg >= plan.total_wgs) return -3;

@@ -10,6 +10,7 @@
 //   * every latent is broadcast to all samples, so  dW[:, latent cols] = db (x) latent  and  d latent = W[:, cols]^T db:
 //     both come from the bias gradients, no per-sample work.
 #include "aon_art_common.h"
+#include "aon_fold.h"
 #include "aon_wgrad.h"
 
 namespace aon {
@@ -32,20 +33,33 @@ __host__ __device__ constexpr int64_t abw_offset(int c) {
 }
 constexpr int64_t kABwStreamBytes = abw_offset(kABwNumChunks);
 
+struct ArtBwdFoldNet {   // folded form (aon_art_common.h): the literal stream without its eight bottleneck chunks
+  static constexpr int kSlotBytes = kPairSlotBytes;
+  static constexpr bool kPair = true;
+  static constexpr int kNumChunks = kABwFNumChunks;
+  static constexpr int chunk_bytes(int c) { return ArtBwdNet::chunk_bytes(c < kABwBott ? c : c + (kABwL7 - kABwBott)); }
+};
+constexpr int64_t kABwFStreamBytes = kABwStreamBytes - (int64_t)(kABwL7 - kABwBott) * kBigChunkBytes;
+constexpr int64_t kABwFOffWf = kABwFStreamBytes;   // W' (128 x 256 floats) for the pack kernel, inside the literal-size buffer
+static_assert(kABwFStreamBytes + 128 * 256 * 4 <= kABwStreamBytes, "fold temporary fits behind the folded stream");
+
 struct ArtParams {
   const float* p[kNumArtParams];
 };
 
+template <bool FOLD>
 __global__ void pack_art_bwd_kernel(ArtParams a, float* __restrict__ packed, int L, int Lv) {
+  using N = std::conditional_t<FOLD, ArtBwdFoldNet, ArtBwdNet>;
   const int P = 3 + 6 * L, V = 3 + 6 * Lv;   // (row strides of the three concatenating layers; the view-encoding columns are never read)
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= kABwStreamBytes / 4) return;
-  // locate the chunk (108 chunks: linear scan is fine for a pack kernel)
+  if (idx >= (FOLD ? kABwFStreamBytes : kABwStreamBytes) / 4) return;
+  // locate the chunk (~100 chunks: linear scan is fine for a pack kernel)
   int c = 0;
   int64_t base = 0;
-  while (c < kABwNumChunks - 1 && idx >= base + ArtBwdNet::chunk_bytes(c) / 4) { base += ArtBwdNet::chunk_bytes(c) / 4; ++c; }
+  while (c < N::kNumChunks - 1 && idx >= base + N::chunk_bytes(c) / 4) { base += N::chunk_bytes(c) / 4; ++c; }
   const int r = (int)(idx - base);
-  const int nt = ArtBwdNet::chunk_bytes(c) / 4096;
+  const int nt = N::chunk_bytes(c) / 4096;
+  if constexpr (FOLD) { if (c >= kABwBott) c += kABwL7 - kABwBott; }   // the chunks behind views_linear.0 take the literal branches below
   const int cc = r & 3, lane = (r >> 2) & 63, rest = r >> 8;
   const int tp = rest % nt, q = rest / nt;
   const int h = lane >> 5, i = lane & 31;
@@ -58,7 +72,10 @@ __global__ void pack_art_bwd_kernel(ArtParams a, float* __restrict__ packed, int
     return c63 < 0 ? -1 : pos_col_in(c63, L);   // a level the network lacks: zero weight, zero gradient into its slot
   };
   if (c < kABwV0) { const int l = 3 - c / 4; W = a.p[26 + 2 * l]; ld = 128; j = 32 * (c % 4) + jo; }
-  else if (c < kABwBott) { W = a.p[26]; ld = 256 + V + 128; j = 32 * (c - kABwV0) + jo; }
+  else if (c < kABwBott) {
+    W = a.p[26]; ld = 256 + V + 128; j = 32 * (c - kABwV0) + jo;
+    if constexpr (FOLD) { W = packed + kABwFOffWf / 4; ld = 256; }   // W' (launch_fold_gemms on the same stream, in front of this kernel)
+  }
   else if (c < kABwL7) { W = a.p[34]; ld = 256; j = 32 * (c - kABwBott) + jo; }
   else if (c < kABwL5E) { const int l = 7 - (c - kABwL7) / 8; W = a.p[10 + 2 * l]; ld = 256; j = 32 * ((c - kABwL7) % 8) + jo; }
   else if (c < kABwL5) { W = a.p[20]; ld = 256 + P + 128; j = 32 * (c - kABwL5E) + jo; col = enc_col(); if (col >= 0) col += 256; }
@@ -98,7 +115,11 @@ __device__ __forceinline__ void zero_tiles_a(f32x16 (&x)[NT]) {
     for (int r = 0; r < 16; ++r) x[t][r] = 0.f;
 }
 
+// FOLD: transposed stream of the folded form: d H7 = W'^T dZ_V0 + W_sigma^T d_sigma in one layer, no bottleneck gradient.
+template <bool FOLD>
 __global__ void __launch_bounds__(256) art_bwd_chain_kernel(ArtBwdArgs args) {
+  constexpr int kL7 = FOLD ? kABwFL7 : kABwL7, kL5E = FOLD ? kABwFL5E : kABwL5E, kL5 = FOLD ? kABwFL5 : kABwL5, kL0E = FOLD ? kABwFL0E : kABwL0E,
+                kD3 = FOLD ? kABwFD3 : kABwD3;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* sm = reinterpret_cast<float*>(smem + kRingBytes);
   const int tid = threadIdx.x;
@@ -112,8 +133,8 @@ __global__ void __launch_bounds__(256) art_bwd_chain_kernel(ArtBwdArgs args) {
   };
   load_small(args.seg[cur].small);
   Pipe p;
-  pipe_init<ArtBwdNet>(p, args.seg[cur].packed_bwd, smem, wave, lane);  // also publishes the small block just written to LDS
-  using N = ArtBwdNet;
+  pipe_init<std::conditional_t<FOLD, ArtBwdFoldNet, ArtBwdNet>>(p, args.seg[cur].packed_bwd, smem, wave, lane);  // also publishes the small block just written to LDS
+  using N = std::conditional_t<FOLD, ArtBwdFoldNet, ArtBwdNet>;
   const int wave_s = __builtin_amdgcn_readfirstlane(wave);
 
   for (int gpass = blockIdx.x; gpass < args.npass_total; gpass += gridDim.x) {
@@ -176,7 +197,9 @@ __global__ void __launch_bounds__(256) art_bwd_chain_kernel(ArtBwdArgs args) {
     AON_ABWD_LAYER(4, 4, Z0, Z1, kABwV3 + 4, aplane_v(2), 13)
     AON_ABWD_LAYER(4, 4, Z1, Z0, kABwV3 + 8, aplane_v(1), 12)
     f32x16 X[8], Y[8];
-    AON_ABWD_LAYER(4, 8, Z0, X, kABwV0, aplane_v(0), 11)   // X = d bottleneck (no activation)
+    if constexpr (!FOLD) {
+      AON_ABWD_LAYER(4, 8, Z0, X, kABwV0, aplane_v(0), 11)   // X = d bottleneck (no activation)
+    }
     // ---- trunk ----
     // the sample index is re-derived where it is needed (one v_mbcnt pair) instead of held in a register pair across the view
     // branch / the trunk: that pair was the kernel's last scratch spill
@@ -195,26 +218,34 @@ __global__ void __launch_bounds__(256) art_bwd_chain_kernel(ArtBwdArgs args) {
         for (int cc = 0; cc < 4; ++cc) Y[t][4 * gq + cc] = w[cc] * dsig;
       }
     }
-    dense_layer<N, kABwBott, 8, 8>(p, X, Y, BwdSideOf<8, false>{X, kAPlBot, io, mk});   // Y = dH7
-    AON_ABWD_LAYER(8, 8, Y, X, kABwL7 + 0, aplane_h(7), 10)
-    AON_ABWD_LAYER(8, 8, X, Y, kABwL7 + 8, aplane_h(6), 9)
+    if constexpr (FOLD) {
+      // Y = dH7 = W'^T dZ_V0 on top of the density head's term (W' = W_v0[:, :256] W_b: model_autodecoder.py:223-230 as one layer)
+      mk_next = load_mask(11);
+      apply_mask_tile(Z0[0], mk, 0);
+      dense_layer<N, kABwV0, 4, 8, BwdSideOf<4, true>, false>(p, Z0, Y, BwdSideOf<4, true>{Z0, aplane_v(0), io, mk, &mk_next});
+      mk = mk_next;
+    } else {
+      dense_layer<N, kABwBott, 8, 8>(p, X, Y, BwdSideOf<8, false>{X, kAPlBot, io, mk});   // Y = dH7
+    }
+    AON_ABWD_LAYER(8, 8, Y, X, kL7 + 0, aplane_h(7), 10)
+    AON_ABWD_LAYER(8, 8, X, Y, kL7 + 8, aplane_h(6), 9)
     // Y = dH5 -> dZ5, consumed twice: by the skip-connection chunks (d enc += W5[:, 256:319]^T dZ5), which mask and store it,
     // then by layer 5's own transposed chunks
     f32x16 dE[2];
     mk_next = load_mask(8);
     apply_mask_tile(Y[0], mk, 0);
     // (the eight encoding chunks are tiny -- 8 MFMA groups each: they only mask; dZ5's stores ride on layer 5's own chunks below)
-    dense_layer<N, kABwL5E, 8, 2, BwdSideOf<8, true, false>, true>(p, Y, dE, BwdSideOf<8, true, false>{Y, aplane_h(5), io, mk, &mk_next});   // dE starts from zero
+    dense_layer<N, kL5E, 8, 2, BwdSideOf<8, true, false>, true>(p, Y, dE, BwdSideOf<8, true, false>{Y, aplane_h(5), io, mk, &mk_next});   // dE starts from zero
     mk = mk_next;
     // The partial d enc (32 accumulator registers) would have to stay live across layers 5..1 on top of the two 128-register
     // activation sets; it is parked in the (otherwise unused) pos-enc rows of the gradient planes instead -- 128 B per lane out
     // and back per pass, against 13.8 KB of plane traffic -- rather than left to the register allocator's scratch spills.
     store_plane(dE, io, kAPlE);
-    dense_layer<N, kABwL5 + 0, 8, 8, StoreSideOf<8>, true>(p, Y, X, StoreSideOf<8>{Y, aplane_h(5), io});   // X = dH4 (from zero); stores dZ5
-    AON_ABWD_LAYER(8, 8, X, Y, kABwL5 + 8, aplane_h(4), 7)
-    AON_ABWD_LAYER(8, 8, Y, X, kABwL5 + 16, aplane_h(3), 6)
-    AON_ABWD_LAYER(8, 8, X, Y, kABwL5 + 24, aplane_h(2), 5)
-    AON_ABWD_LAYER(8, 8, Y, X, kABwL5 + 32, aplane_h(1), 4)
+    dense_layer<N, kL5 + 0, 8, 8, StoreSideOf<8>, true>(p, Y, X, StoreSideOf<8>{Y, aplane_h(5), io});   // X = dH4 (from zero); stores dZ5
+    AON_ABWD_LAYER(8, 8, X, Y, kL5 + 8, aplane_h(4), 7)
+    AON_ABWD_LAYER(8, 8, Y, X, kL5 + 16, aplane_h(3), 6)
+    AON_ABWD_LAYER(8, 8, X, Y, kL5 + 24, aplane_h(2), 5)
+    AON_ABWD_LAYER(8, 8, Y, X, kL5 + 32, aplane_h(1), 4)
     // X = dH0 -> dZ0, consumed by the encoding chunks: d enc += W0[:, :63]^T dZ0
     mk_next = load_mask(3);
     apply_mask_tile(X[0], mk, 0);
@@ -227,13 +258,13 @@ __global__ void __launch_bounds__(256) art_bwd_chain_kernel(ArtBwdArgs args) {
     for (int a = 0; a < 3; ++a)
       xd[a] = *row_ptr(fio, kAPlPos + 3 + a);
 #if defined(AON_EXP_NOSTORE_L0E)   // timing experiment only (dZ0 never stored: WRONG layer-0 weight gradients)
-    dense_layer<N, kABwL0E, 8, 2>(p, X, dE, BwdSideOf<8, true, false>{X, aplane_h(0), io, mk});
+    dense_layer<N, kL0E, 8, 2>(p, X, dE, BwdSideOf<8, true, false>{X, aplane_h(0), io, mk});
 #elif defined(AON_EXP_L0E_SIDE)    // round-3 form: dZ0 stored by the tiny encoding chunks themselves
-    dense_layer<N, kABwL0E, 8, 2>(p, X, dE, BwdSideOf<8, true>{X, aplane_h(0), io, mk});
+    dense_layer<N, kL0E, 8, 2>(p, X, dE, BwdSideOf<8, true>{X, aplane_h(0), io, mk});
 #else
     // the encoding chunks (tiny, see BwdSideOf) only mask; dZ0 goes out in one burst behind them, in front of the ~600 VALU
     // instructions of the encoding's backward, which give its acknowledgements time before the next weight DMA is waited for
-    dense_layer<N, kABwL0E, 8, 2>(p, X, dE, BwdSideOf<8, true, false>{X, aplane_h(0), io, mk, &mk_next});
+    dense_layer<N, kL0E, 8, 2>(p, X, dE, BwdSideOf<8, true, false>{X, aplane_h(0), io, mk, &mk_next});
 #pragma unroll
     for (int t8 = 0; t8 < 8; ++t8)
 #pragma unroll
@@ -276,9 +307,9 @@ __global__ void __launch_bounds__(256) art_bwd_chain_kernel(ArtBwdArgs args) {
           H1[t][4 * gq + cc] = __builtin_fmaf(w2[cc], dx[2], __builtin_fmaf(w1[cc], dx[1], w0[cc] * dx[0]));
       }
     }
-    AON_ABWD_LAYER(4, 4, H1, H0, kABwD3 + 0, aplane_d(3), 2)
-    AON_ABWD_LAYER(4, 4, H0, H1, kABwD3 + 4, aplane_d(2), 1)
-    AON_ABWD_LAYER(4, 4, H1, H0, kABwD3 + 8, aplane_d(1), 0)
+    AON_ABWD_LAYER(4, 4, H1, H0, kD3 + 0, aplane_d(3), 2)
+    AON_ABWD_LAYER(4, 4, H0, H1, kD3 + 4, aplane_d(2), 1)
+    AON_ABWD_LAYER(4, 4, H1, H0, kD3 + 8, aplane_d(1), 0)
 #undef AON_ABWD_LAYER
     // dZ of deformation layer 0: its input is (pos, latents) -- no data gradient continues, no consuming chunk: 64 values here
     apply_mask_bits(H0, mk);
@@ -348,20 +379,39 @@ __global__ void __launch_bounds__(1024) art_finish_kernel(ArtFinishArgs a) {
 // ---------------------------------------------------------------------------------------------
 int num_cus();
 
+// The form packed is the process default at the time of the call (aon_set_bottleneck_fold), remembered for `packed` (stream_form).
 hipError_t launch_pack_art_bwd(const float* const* params, float* packed, hipStream_t stream, int pos_levels, int view_levels) {
   ArtParams a;
   for (int i = 0; i < kNumArtParams; ++i) a.p[i] = params[i];
-  const int64_t n = kABwStreamBytes / 4;
-  pack_art_bwd_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream>>>(a, packed, pos_levels, view_levels);
+  const int form = fold_default();
+  set_stream_form(packed, form);
+  if (form == kFormFolded) {
+    const FoldGemm job{params[26], 256 + 3 + 6 * view_levels + 128, 1, params[34], 256, 1, packed + kABwFOffWf / 4, 256, 128, 256, 256, nullptr, nullptr};
+    if (hipError_t e = launch_fold_gemms(&job, 1, stream); e != hipSuccess) return e;
+    const int64_t n = kABwFStreamBytes / 4;
+    pack_art_bwd_kernel<true><<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream>>>(a, packed, pos_levels, view_levels);
+  } else {
+    const int64_t n = kABwStreamBytes / 4;
+    pack_art_bwd_kernel<false><<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream>>>(a, packed, pos_levels, view_levels);
+  }
   return hipGetLastError();
 }
 
 int64_t art_bwd_stream_bytes() { return kABwStreamBytes; }
 
-hipError_t launch_art_bwd_chain2(const ChainSeg* segs, int nsegs, hipStream_t stream) {
+template <bool FOLD>
+static hipError_t launch_art_chain_f(const ArtBwdArgs& a, int grid, hipStream_t stream) {
   static DeviceOnce lds_once;
+  if (hipError_t e = set_max_lds(&art_bwd_chain_kernel<FOLD>, kALdsBytes, lds_once); e != hipSuccess) return e;
+  art_bwd_chain_kernel<FOLD><<<dim3(grid), dim3(256), kALdsBytes, stream>>>(a);
+  return hipGetLastError();
+}
+
+hipError_t launch_art_bwd_chain2(const ChainSeg* segs, int nsegs, hipStream_t stream) {
   if (nsegs < 1 || nsegs > 2) return hipErrorInvalidValue;
-  if (hipError_t e = set_max_lds(&art_bwd_chain_kernel, kALdsBytes, lds_once); e != hipSuccess) return e;
+  const int form = stream_form(segs[0].packed_bwd);
+  for (int i = 0; i < nsegs; ++i)   // streams and per-call blocks of one launch: one form
+    if (stream_form(segs[i].packed_bwd) != form || stream_form(segs[i].small) != form) return hipErrorInvalidValue;
   ArtBwdArgs a{};
   for (int i = 0; i < nsegs; ++i) {
     const ChainSeg& c = segs[i];
@@ -374,8 +424,7 @@ hipError_t launch_art_bwd_chain2(const ChainSeg* segs, int nsegs, hipStream_t st
   if (cus <= 0) return hipErrorInvalidDevice;
   const int grid = a.npass_total < cus ? a.npass_total : cus;
   if (grid <= 0) return hipSuccess;
-  art_bwd_chain_kernel<<<dim3(grid), dim3(256), kALdsBytes, stream>>>(a);
-  return hipGetLastError();
+  return form == kFormFolded ? launch_art_chain_f<true>(a, grid, stream) : launch_art_chain_f<false>(a, grid, stream);
 }
 
 hipError_t launch_art_bwd_chain(const char* packed_bwd, const float* small, const float* d_raw, const void* masks, const float* planes,
@@ -390,7 +439,9 @@ hipError_t run_wgrad_plan(const WgLayerDesc* layers, int nlayers, const HeadDesc
 // the weight-gradient jobs of one articulated level.  Lp / Lv: frequency levels of the network (10 / 4 by default).  With other degrees
 // the three encoding-fed column blocks come out in the kernels' 63 / 27-slot layout into `enc_tmp` (256 x 64 | 256 x 64 | 128 x 32
 // floats) and lose the empty slots afterwards (art_remap_enc_kernel); the row strides of the concatenating layers follow P and V.
-int art_wgrad_layers(float* const* grads, WgLayerDesc* L, int Lp, int Lv, float* enc_tmp) {
+// fold_tmp != null: the planes are the folded form's (no bottleneck rows): the bottleneck and views_linear.0's bottleneck columns are ONE job
+// dW' = dZ_V0 . H7^T (128 x 256) into fold_tmp, db' = db_v0 straight into views_linear.0.bias; launch_unfold_view makes the reference's gradients.
+int art_wgrad_layers(float* const* grads, WgLayerDesc* L, int Lp, int Lv, float* enc_tmp, float* fold_tmp) {
   const bool dflt = Lp == 10 && Lv == 4;
   const int P = 3 + 6 * Lp, V = 3 + 6 * Lv;
   int n = 0;
@@ -408,15 +459,20 @@ int art_wgrad_layers(float* const* grads, WgLayerDesc* L, int Lp, int Lv, float*
       else L[n++] = WgLayerDesc{kWg256x64, aplane_h(5), kAPlE, enc_tmp + 256 * 64, 64, 0, kPosEnc, nullptr};
     }
   }
-  L[n++] = WgLayerDesc{kWg256x256, kAPlBot, aplane_h(7), grads[34], 256, 0, 256, grads[35]};
-  // view branch (:227-234): layer 0 input cat[bottleneck(256), viewenc(V), appearance(128)]: two column blocks from the planes
-  L[n++] = WgLayerDesc{kWg128x256, aplane_v(0), kAPlBot, grads[26], 256 + V + 128, 0, 256, grads[27]};
+  if (fold_tmp) {
+    L[n++] = WgLayerDesc{kWg128x256, aplane_v(0), aplane_h(7), fold_tmp, 256, 0, 256, grads[27]};
+  } else {
+    L[n++] = WgLayerDesc{kWg256x256, kAPlBot, aplane_h(7), grads[34], 256, 0, 256, grads[35]};
+    // view branch (:227-234): layer 0 input cat[bottleneck(256), viewenc(V), appearance(128)]: two column blocks from the planes
+    L[n++] = WgLayerDesc{kWg128x256, aplane_v(0), kAPlBot, grads[26], 256 + V + 128, 0, 256, grads[27]};
+  }
   if (dflt) L[n++] = WgLayerDesc{kWg128x32, aplane_v(0), kAPlVE, grads[26], 256 + V + 128, 256, kViewEnc, nullptr};
   else L[n++] = WgLayerDesc{kWg128x32, aplane_v(0), kAPlVE, enc_tmp + 2 * 256 * 64, 32, 0, kViewEnc, nullptr};
   for (int l = 1; l < 4; ++l) L[n++] = WgLayerDesc{kWg128x128, aplane_v(l), aplane_v(l - 1), grads[26 + 2 * l], 128, 0, 128, grads[27 + 2 * l]};
   return n;
 }
-int art_wgrad_layers(float* const* grads, WgLayerDesc* L) { return art_wgrad_layers(grads, L, 10, 4, nullptr); }
+int art_wgrad_layers(float* const* grads, WgLayerDesc* L) { return art_wgrad_layers(grads, L, 10, 4, nullptr, nullptr); }
+float* wgrad_fold_tmp(float* ws);   // aon_train.hip
 
 // dst[r * ldd + col_off + c] = src[r * lds + slot(c)] for the c < 3 + 6 L columns of an encoding with L levels, taken out of the kernels'
 // Lfull-level slot layout [x ; first block of 3 Lfull ; shifted block of 3 Lfull]
@@ -434,14 +490,17 @@ __global__ void art_remap_enc_kernel(const float* __restrict__ src, int lds, flo
 hipError_t launch_art_wgrad(const float* planes, const float* dplanes, const float* d_raw, const float* dxp, int64_t Np,
                             const float* const* params, const float* shape, const float* app, const float* art,
                             float* const* grads, float* g_shape, float* g_app, float* g_art, float* ws, hipStream_t stream, const WgAux* aux,
-                            int Lp, int Lv) {
+                            int Lp, int Lv, const void* packed_bwd) {
+  // packed_bwd: the transposed stream the chain of these planes ran with -- its FORM says whether the planes carry bottleneck rows (null: literal)
+  const bool fold = packed_bwd && stream_form(packed_bwd) == kFormFolded;
+  float* fold_tmp = fold ? wgrad_fold_tmp(ws) : nullptr;
   WgLayerDesc L[kWgMaxJobs];
   const int P = 3 + 6 * Lp, V = 3 + 6 * Lv;
   const bool dflt = Lp == 10 && Lv == 4;
   // (other degrees: the slot-layout blocks live in the last MiB of the weight-gradient workspace, which no plan reaches: 70 of 96 MiB
   // are used at 4096 x 193 samples, and run_wgrad_plan refuses plans beyond the workspace)
   float* enc_tmp = ws + (wgrad_workspace_bytes_impl() - (1 << 20)) / 4;
-  const int n = art_wgrad_layers(grads, L, Lp, Lv, enc_tmp);
+  const int n = art_wgrad_layers(grads, L, Lp, Lv, enc_tmp, fold_tmp);
   // heads: density (H7 x d_raw.w), rgb (V3 x d_raw.xyz), deformation_layer (D3 x dx'), their bias sums, and deformation layer 0:
   // dW[:, 0:3] = dZ_D0 x pos (the position is rows 0..2 of unit row kAPlPos / 4 of the forward planes), db = row sums of dZ_D0
   const int64_t unit_step = (int64_t)kAPlRows * 32;
@@ -463,6 +522,9 @@ hipError_t launch_art_wgrad(const float* planes, const float* dplanes, const flo
     remap(enc_tmp + 2 * 256 * 64, 32, grads[26], 256 + V + 128, 256, 128, Lv, 4);
     if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
   }
+  if (fold)   // bottleneck_layer's and views_linear.0[:, :256]'s gradients from (dW', db' = views_linear.0.bias's gradient)
+    if (hipError_t e = launch_unfold_view(fold_tmp, grads[27], params[26], 256 + V + 128, params[34], params[35], grads[26], 256 + V + 128, grads[34], grads[35], stream);
+        e != hipSuccess) return e;
   // latent columns of the weights and the latent gradients, both from the bias gradients
   ArtFinishArgs F{};
   LatentJob& ls = F.lat[0];   // shape: deformation layer 0, trunk layers 0 and 5

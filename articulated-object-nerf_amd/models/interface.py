@@ -110,18 +110,28 @@ class Harness(LitModel):
         optimizer.step(closure=closure)
         self.global_step += 1
 
-    def fit_step(self, batch, batch_idx, optimizer):
+    def fit_step(self, batch, batch_idx, optimizer, find_unused_parameters: bool = False):
         """One batch of Lightning's automatic optimisation under its DDP plugin (run.py:144-153): zero_grad, training_step,
         backward, the data-parallel gradient mean (ONE flat RCCL bucket, `parallel.allreduce_gradients`; a no-op without a process
-        group or at world size 1; DDP's find_unused_parameters=False contract as in run.py:151), then the LR rule + optimizer step."""
+        group or at world size 1), then the LR rule + optimizer step.  `find_unused_parameters` is DDPPlugin's argument (run.py:109,
+        :129, :151): False -- the reference's value -- is DDP's strict contract (every rank produces gradients for the same parameters;
+        a violation raises UnevenGradientsError on EVERY rank at the next exchange, or at `finish_fit()` / a checkpoint / test_epoch_end
+        when there is no next one); True lets a rank whose batch did not touch a parameter adopt the others' mean."""
         from ..parallel import allreduce_gradients
 
         optimizer.zero_grad(set_to_none=True)
         loss = self.training_step(batch, batch_idx)
         loss.backward()
-        allreduce_gradients(self)
+        allreduce_gradients(self, find_unused_parameters=find_unused_parameters)
         self.optimizer_step(optimizer)
         return loss.detach()
+
+    def finish_fit(self) -> None:
+        """End of a training loop (Lightning's on_train_end): the deferred check of the LAST gradient exchange, which no later
+        fit_step will look at.  Also run by utils.save_checkpoint and test_epoch_end."""
+        from ..parallel import check_gradient_exchange
+
+        check_gradient_exchange()
 
     @torch.no_grad()
     def test_epoch_end(self, outputs, image_sizes, out_dir=None, name="image"):
@@ -129,6 +139,7 @@ class Harness(LitModel):
         when ``out_dir`` is given) the JPEG dump + results.json of the reference."""
         from ..utils import store_image, write_stats
 
+        self.finish_fit()
         rgbs = self.alter_gather_cat(outputs, "rgb", image_sizes)
         masks = self.alter_gather_cat(outputs, "instance_mask", image_sizes)
         targets = self.alter_gather_cat(outputs, "target", image_sizes)

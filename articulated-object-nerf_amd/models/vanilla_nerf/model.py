@@ -152,8 +152,15 @@ class NeRF(nn.Module):
         t, _ = ops.sample_along_rays(o, d, self.num_coarse_samples, near, far, t_rand, want_coords=False, lindisp=self.lindisp)
         mlps = [self.coarse_mlp, self.fine_mlp]
         if training:
+            # (limits of this unmerged path -- one launch set per level, no merged three-launch forward, no one-launch chain -- named up
+            # front, not as AON_E_INVALID from inside loss.backward() after a full forward: ADVICE r4)
+            s_last = self.num_coarse_samples + 1 + (self.num_levels - 1) * self.num_fine_samples
+            if s_last > 512:
+                raise NotImplementedError(f"training with num_levels={self.num_levels}: level {self.num_levels - 1} evaluates {s_last} samples per ray, "
+                                          "the compositing backward (aon_composite_bwd) holds at most 512; inference has no such limit")
             if self.noise_std > 0 and randomized:
-                raise NotImplementedError("training with num_levels > 2 AND density noise: the stage-level compositing backward takes no noise")
+                raise NotImplementedError("training with num_levels > 2 AND density noise (noise_std > 0, randomized=True): the stage-level "
+                                          "compositing backward takes no noise; inference with noise, and training with noise at num_levels <= 2, work")
             if n == 0:
                 raise ValueError("empty ray batch in training mode")
             packs = [(m.packed(True), m.packed_bwd(True)) for m in mlps]
@@ -181,12 +188,12 @@ class NeRF(nn.Module):
     def forward(self, rays, randomized, white_bkgd, near, far, t_rand=None, u=None, noise=None):
         rays_o = rays["rays_o"]
         n = rays_o.shape[0]
-        # the stratified / inverse-CDF draws may ride in the batch dict (keys "t_rand", "u": an extension -- the reference's forward
+        # the stratified / inverse-CDF draws may ride in the batch dict (keys "aon_t_rand", "aon_u": an extension, namespaced so that a user batch carrying its own "u" / "t_rand" is never misread -- the reference's forward
         # ignores extra keys, model.py:299-306 -- that makes a harness run reproducible: tests/test_hip_long_training.py)
         if t_rand is None:
-            t_rand = rays.get("t_rand")
+            t_rand = rays.get("aon_t_rand")
         if u is None:
-            u = rays.get("u")
+            u = rays.get("aon_u")
         if randomized:
             if t_rand is None:
                 t_rand = torch.rand((n, self.num_coarse_samples + 1), device=rays_o.device)

@@ -133,12 +133,12 @@ class NeRF_AE_Art(nn.Module):
     def forward(self, rays, randomized, white_bkgd, near, far, latents, train=True, t_rand=None, u=None, noise=None):
         rays_o = rays["rays_o"]
         n = rays_o.shape[0]
-        # the stratified / inverse-CDF draws may ride in the batch dict (keys "t_rand", "u": an extension -- the reference's forward
+        # the stratified / inverse-CDF draws may ride in the batch dict (keys "aon_t_rand", "aon_u": an extension, namespaced so that a user batch carrying its own "u" / "t_rand" is never misread -- the reference's forward
         # ignores extra keys, model.py:299-306 -- that makes a harness run reproducible: tests/test_hip_long_training.py)
         if t_rand is None:
-            t_rand = rays.get("t_rand")
+            t_rand = rays.get("aon_t_rand")
         if u is None:
-            u = rays.get("u")
+            u = rays.get("aon_u")
         if randomized:
             if t_rand is None:
                 t_rand = torch.rand((n, self.num_coarse_samples + 1), device=rays_o.device)

@@ -683,8 +683,9 @@ def mlp_bwd_chain(packed_bwd, packed_fwd, d_raw, masks, plane_shape):
 _WG_WS: dict = {}
 
 
-def vanilla_wgrad(planes, dplanes, d_raw):
-    """-> dict name -> gradient (the reference's NeRFMLP parameter names / shapes)."""
+def vanilla_wgrad(planes, dplanes, d_raw, packed_bwd=None):
+    """-> dict name -> gradient (the reference's NeRFMLP parameter names / shapes).  ``packed_bwd``: the transposed stream the chain
+    of these planes ran with (its form -- bottleneck folded or literal -- is the planes'; None = literal)."""
     dev = planes.device
     key = str(dev)
     need = int(lib.aon_wgrad_workspace_bytes())
@@ -694,8 +695,8 @@ def vanilla_wgrad(planes, dplanes, d_raw):
     grads = {name: torch.empty(VANILLA_PARAM_SHAPES[name], dtype=torch.float32, device=dev) for name in VANILLA_PARAM_ORDER}
     arr = (C.c_void_p * len(VANILLA_PARAM_ORDER))(*[grads[n].data_ptr() for n in VANILLA_PARAM_ORDER])
     with torch.cuda.device(dev):
-        check(lib.aon_vanilla_wgrad(_ptr(planes), _ptr(dplanes), _ptr(d_raw), plane_samples(planes), arr, _ptr(ws), ws.numel(), _stream()),
-              "aon_vanilla_wgrad")
+        check(lib.aon_vanilla_wgrad(_ptr(planes), _ptr(dplanes), _ptr(d_raw), plane_samples(planes), arr, _ptr(ws), ws.numel(), _stream(),
+                                    _ptr(packed_bwd)), "aon_vanilla_wgrad")
     return grads
 
 
@@ -734,8 +735,8 @@ def art_bwd_chain(packed_bwd, small, d_raw, masks, planes):
     return dplanes, dxp
 
 
-def art_wgrad(planes, dplanes, d_raw, dxp, params: dict, latents: dict, degrees=(0, 10, 4)):
-    """-> (dict name -> parameter gradient, dict latent key -> gradient (flat))."""
+def art_wgrad(planes, dplanes, d_raw, dxp, params: dict, latents: dict, degrees=(0, 10, 4), packed_bwd=None):
+    """-> (dict name -> parameter gradient, dict latent key -> gradient (flat)).  ``packed_bwd``: as vanilla_wgrad."""
     dev = planes.device
     key = str(dev)
     need = int(lib.aon_wgrad_workspace_bytes())
@@ -751,8 +752,20 @@ def art_wgrad(planes, dplanes, d_raw, dxp, params: dict, latents: dict, degrees=
     with torch.cuda.device(dev):
         check(lib.aon_art_wgrad_deg(_ptr(planes), _ptr(dplanes), _ptr(d_raw), _ptr(dxp), plane_samples(planes), parr, _ptr(shape), _ptr(app),
                                     _ptr(art), garr, _ptr(g_lat["density"]), _ptr(g_lat["color"]), _ptr(g_lat["articulation"]), _ptr(ws),
-                                    ws.numel(), _stream(), int(degrees[0]), int(degrees[1]), int(degrees[2])), "aon_art_wgrad_deg")
+                                    ws.numel(), _stream(), int(degrees[0]), int(degrees[1]), int(degrees[2]), _ptr(packed_bwd)), "aon_art_wgrad_deg")
     return grads, g_lat
+
+
+# ------------------------------------------------------------------ bottleneck_layer folded into views_linear[0] (round 5)
+def set_bottleneck_fold(on: bool) -> None:
+    """Form of the streams / per-call blocks the pack calls build from now on: folded (default: W' = W_v0[:, :256] W_b, one 256 -> 128
+    layer where the reference's graph runs 256 -> 256 then 256 -> 128, model.py:109-114) or the literal two layers.  Buffers already
+    packed keep their form (include/aon_hip.h)."""
+    check(lib.aon_set_bottleneck_fold(int(bool(on))), "aon_set_bottleneck_fold")
+
+
+def bottleneck_fold() -> bool:
+    return bool(lib.aon_get_bottleneck_fold())
 
 
 # ------------------------------------------------------------------ R14 training step in two C calls

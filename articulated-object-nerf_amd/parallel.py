@@ -100,21 +100,22 @@ class UnevenGradientsError(RuntimeError):
     """Ranks disagreed on which parameters produced a gradient while `find_unused_parameters=False` (see allreduce_gradients)."""
 
 
-_pending_checks: list = []   # [(event or None, host flag tensor, message)] of earlier calls, looked at without waiting
+_pending_checks: list = []   # [(event or None, host flag tensor, message)] of earlier calls
 
 
-def _raise_if_earlier_call_was_uneven(wait: bool = False) -> None:
-    keep = []
-    for ev, flag, msg in _pending_checks:
-        if ev is not None and not ev.query():
-            if not wait:
-                keep.append((ev, flag, msg))
-                continue
+def _raise_if_earlier_call_was_uneven() -> None:
+    """Every rank must reach the SAME verdict about an earlier exchange before it enters the next one: a rank that raised while the
+    others went into reduce_scatter would leave them hanging until the RCCL watchdog fires (ADVICE r4 -- rounds 3-4 looked at the
+    pinned flag with a non-blocking event query, which can have completed on one rank and not on another).  So the event of the
+    earlier call is WAITED for.  The flag itself is computed from the all-gathered counts, i.e. identical on every rank; with the wait
+    the decision is too.  The wait costs nothing in steady state: the earlier exchange finished a whole forward + backward ago, and
+    the host still runs up to one step ahead of the device."""
+    pending, _pending_checks[:] = list(_pending_checks), []
+    for ev, flag, msg in pending:
+        if ev is not None:
             ev.synchronize()
         if bool(flag.item()):
-            _pending_checks.clear()
             raise UnevenGradientsError(msg)
-    _pending_checks[:] = keep
 
 
 def allreduce_gradients(module, group=None, force: bool = False, shard_align: int = 64, find_unused_parameters: bool = False) -> None:
@@ -131,7 +132,8 @@ def allreduce_gradients(module, group=None, force: bool = False, shard_align: in
     everywhere": the exchange needs NO host read and the call never synchronises with the device (round 3 read the flags
     back with `.tolist()` on every rank that lacked a gradient -- every step of a `num_levels=1` run).  The contract is still
     checked, the way DDP checks it -- late: a device-side comparison of the summed flags with {0, world} is copied to pinned
-    memory behind the exchange, and the NEXT call (or `check_gradient_exchange()`) raises UnevenGradientsError if it failed.
+    memory behind the exchange, and the NEXT call (or `check_gradient_exchange()`) waits for that copy -- long finished by then --
+    and raises UnevenGradientsError if it failed: on EVERY rank, before any of them enters the next collective.
     `find_unused_parameters=True` is the permissive mode (a rank may skip a code-library row another rank trained): ranks
     that lack a gradient read the summed flags (one host synchronisation, as torch DDP has in that mode) and adopt the mean
     of the ranks that had one.
@@ -204,4 +206,4 @@ def allreduce_gradients(module, group=None, force: bool = False, shard_align: in
 def check_gradient_exchange() -> None:
     """Wait for the deferred checks of earlier allreduce_gradients(find_unused_parameters=False) calls and raise
     UnevenGradientsError if one failed (end of an epoch, before a checkpoint)."""
-    _raise_if_earlier_call_was_uneven(wait=True)
+    _raise_if_earlier_call_was_uneven()

@@ -13,7 +13,11 @@ from PIL import Image
 
 def save_checkpoint(path, lit_module, optimizer=None, epoch: int = 0):
     """Write ``{epoch, global_step, state_dict[, optimizer_states]}`` -- the subset of a Lightning 1.5 checkpoint that
-    ``Trainer(resume_from_checkpoint=...)`` / ``load_from_checkpoint`` read for the weights."""
+    ``Trainer(resume_from_checkpoint=...)`` / ``load_from_checkpoint`` read for the weights.  A data-parallel run first settles the
+    deferred check of its last gradient exchange (parallel.check_gradient_exchange): replicas that diverged are not checkpointed."""
+    from ..parallel import check_gradient_exchange
+
+    check_gradient_exchange()
     ckpt = {"epoch": epoch, "global_step": int(getattr(lit_module, "global_step", 0)),
             "pytorch-lightning_version": "1.5.2",
             "state_dict": {k: v.detach().cpu() for k, v in lit_module.state_dict().items()}}

@@ -35,6 +35,15 @@ ART_MAC_BWD_CHAIN = ART_MAC_FWD - 128 * 3 - 128 * 27      # no data gradient int
 ART_MAC_WGRAD = ART_MAC_FWD                                # latent-column weight gradients are outer products of bias gradients
 VAN_MAC = 593_408
 VAN_MAC_BWD_CHAIN = VAN_MAC - 2 * 256 * 63 - 128 * 27     # no data gradient into the encodings
+# Round 5: bottleneck_layer (256 -> 256, no activation) folded into views_linear[0] (include/aon_hip.h, aon_set_bottleneck_fold): the
+# kernels execute 65,536 fewer MACs per sample in the forward, in the backward chain and in the weight gradients alike.  `executed`
+# figures below subtract them when the fold is on (default); `reference_literal` figures never do.
+FOLD_MAC = 256 * 256
+
+
+def executed(mac: int, fold: bool) -> int:
+    return mac - FOLD_MAC if fold else mac
+
 # algorithmic HBM bytes per ray of the per-ray kernels: compositing reads float4(rgb, sigma) + t per sample and
 # the direction, writes rgb/acc/depth (+ the 65 weights at the coarse level); the inverse CDF reads t (65) and 63 weights and
 # writes 193 sorted t values
@@ -161,8 +170,8 @@ def render_leg(dev, kind, H, W, steps=3):
             model = NeRF(num_levels=1).to(dev)
             model.load_state_dict(syn.make_nerf_state_dict(seed=0, density_scale=30.0))
             call = lambda: model(rays, False, True, syn.NEAR, syn.FAR)
-            evals, mac_ex, mac_lit = 65, VAN_MAC, VAN_MAC
-            name = "aon::mlp_fwd_kernel<true,false> (fused encode+MLP, fp32 MFMA)"
+            evals, mac_ex, mac_lit = 65, executed(VAN_MAC, ops.bottleneck_fold()), VAN_MAC
+            name = "aon::mlp_fwd_kernel<true,false,fold> (fused encode+MLP, fp32 MFMA)"
             work = f"vanilla NeRF {W}x{H}, 65 coarse evals/ray only (num_levels=1), {H * W} rays"
         else:
             from aon_amd.models.code_library import CodeLibraryArticulated
@@ -175,8 +184,8 @@ def render_leg(dev, kind, H, W, steps=3):
             with torch.no_grad():
                 lat = lib({"instance_id": torch.tensor([0], device=dev), "articulation_id": torch.tensor([3], device=dev)})
             call = lambda: model(rays, False, True, syn.NEAR, syn.FAR, lat)
-            evals, mac_ex, mac_lit = EVALS_PER_RAY, ART_MAC_FWD, ART_MAC_LITERAL
-            name = "aon::art_mlp_fwd_kernel<true,false> (deformation + trunk + view branch, latents folded into biases, fp32 MFMA)"
+            evals, mac_ex, mac_lit = EVALS_PER_RAY, executed(ART_MAC_FWD, ops.bottleneck_fold()), ART_MAC_LITERAL
+            name = "aon::art_mlp_fwd_kernel<true,false,fold> (deformation + trunk + view branch, latents folded into biases, fp32 MFMA)"
             work = f"articulated NeRF_AE_Art {W}x{H}, 65 coarse + 193 fine evals/ray, {H * W} rays"
         with torch.no_grad():
             call()
@@ -189,7 +198,7 @@ def render_leg(dev, kind, H, W, steps=3):
             dt = (time.perf_counter() - t0) / steps
             ms, launches, samples = ops.profile_end()
         res = {"workload": work, "value": H * W / dt, "unit": "rays/s", "ms_per_frame": dt * 1e3, "steps": steps, "evals_per_ray": evals,
-               "roofline": mfma_roofline(name, ms, launches, samples, mac_ex, mac_lit)}
+               "bottleneck_fold": bool(ops.bottleneck_fold()), "roofline": mfma_roofline(name, ms, launches, samples, mac_ex, mac_lit)}
         if kind != "config1":
             res["hbm_kernels"] = per_ray_rooflines(ops.profile_classes())
         return res
@@ -368,11 +377,13 @@ def train_leg(dev, rank, world, distributed, steps=6, n_rays=4096):
             ops.set_bwd_overlap(True)
             ops.set_fwd_overlap(True)
         samples = n_rays * EVALS_PER_RAY
-        mac_lit, mac_ex = 3 * ART_MAC_LITERAL, ART_MAC_FWD + ART_MAC_BWD_CHAIN + ART_MAC_WGRAD
+        fold = bool(ops.bottleneck_fold())
+        mac_f, mac_c, mac_w = executed(ART_MAC_FWD, fold), executed(ART_MAC_BWD_CHAIN, fold), executed(ART_MAC_WGRAD, fold)
+        mac_lit, mac_ex = 3 * ART_MAC_LITERAL, mac_f + mac_c + mac_w
         kernels = {}
-        for key, name, mac in (("mlp_fwd", "aon::art_mlp_fwd_kernel<true,true> (training forward: + activation planes, ReLU bits)", ART_MAC_FWD),
-                               ("bwd_chain", "aon::art_bwd_chain_kernel (data-gradient chain + gradient planes)", ART_MAC_BWD_CHAIN),
-                               ("wgrad", "aon::wgrad_grouped_kernel (all layers of a level in one launch) + heads + second stage + latent outer products", ART_MAC_WGRAD)):
+        for key, name, mac in (("mlp_fwd", "aon::art_mlp_fwd_kernel<true,true,fold> (training forward: + activation planes, ReLU bits)", mac_f),
+                               ("bwd_chain", "aon::art_bwd_chain_kernel<fold> (data-gradient chain + gradient planes)", mac_c),
+                               ("wgrad", "aon::wgrad_grouped_kernel (all layers of a level in one launch) + heads + second stage + un-fold + latent outer products", mac_w)):
             ms, launches, units = classes[key]
             r = mfma_roofline(name, ms, launches, samples * steps, mac, ART_MAC_LITERAL)   # units are padded samples: price the real ones
             if r is not None:
@@ -380,7 +391,7 @@ def train_leg(dev, rank, world, distributed, steps=6, n_rays=4096):
                 kernels[key] = r
         other_ms = sum(classes[k][0] for k in ("composite", "sample_pdf", "composite_pdf", "composite_bwd", "sample_t") if k in classes) / steps
         res = {"workload": f"articulated NeRF_AE_Art training step, {n_rays} rays/GPU, fwd+bwd" + (" + RCCL gradient all-reduce (6.4 MB, one bucket)" if world > 1 else "") + " + Adam",
-               "ms_per_step": dt * 1e3, "rays_per_s": world * n_rays / dt, "steps": steps, "loss": loss,
+               "ms_per_step": dt * 1e3, "rays_per_s": world * n_rays / dt, "steps": steps, "loss": loss, "bottleneck_fold": fold,
                "allreduce_ms": {"min": ar_all.min().item(), "max": ar_all.max().item(), "per_rank": ar_all.tolist(),
                                 "note": "parallel.allreduce_gradients per step, HIP events on the launch stream; 0 at world size 1 (no-op); "
                                         "includes the wait for the slowest rank's backward"},
@@ -390,7 +401,8 @@ def train_leg(dev, rank, world, distributed, steps=6, n_rays=4096):
                             "frac_reference_literal": samples * mac_lit * 2 / dt / 1e12 / PEAK_FP32_MATRIX_TFLOPS,
                             "flop_per_ray_executed": 2 * mac_ex * EVALS_PER_RAY, "flop_per_ray_reference_literal": 2 * mac_lit * EVALS_PER_RAY,
                             "note": "whole step (kernels + Adam + harness) priced against the fp32-matrix peak; executed = MACs the kernels issue "
-                                    "(latent columns folded into biases), reference-literal = 3 x the forward MACs of SURVEY R10",
+                                    "(latent columns folded into biases; bottleneck_layer folded into views_linear[0] when bottleneck_fold), "
+                                    "reference-literal = 3 x the forward MACs of SURVEY R10",
                             "kernels": kernels, "per_ray_kernels_ms_per_step": other_ms,
                             "kernel_ms_per_step": sum(k["ms_per_step"] for k in kernels.values()) + other_ms,
                             "kernels_measured_on": "a second pass of the same schedule with the library's per-kernel-class HIP-event timers on "
@@ -415,6 +427,7 @@ def main():
     ap.add_argument("--no-sharded-leg", action="store_true", help="skip the informational BASELINE config 3 leg (one frame sharded over the ranks + RCCL all-gather)")
     ap.add_argument("--no-train-leg", action="store_true", help="skip the extra (informational) articulated training-step timing")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the informational BASELINE config 1 / config 4 render legs")
+    ap.add_argument("--literal", action="store_true", help="A/B: aon_set_bottleneck_fold(0) -- the reference-literal two-layer bottleneck + view layer of rounds 1-4")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -434,6 +447,9 @@ def main():
     from aon_amd.models.vanilla_nerf.model import NeRF
     from aon_amd.parallel import all_gather_pixels
 
+    if args.literal:
+        ops.set_bottleneck_fold(False)
+    fold = bool(ops.bottleneck_fold())
     H, W = args.height, args.width
     n_rays = H * W
     sd = syn.make_nerf_state_dict(seed=0, density_scale=30.0)
@@ -581,7 +597,9 @@ def main():
 
     if rank == 0:
         rays_per_s = world * n_rays * args.steps / dt
-        mlp_tflops = mlp_samples * FLOP_PER_SAMPLE / (mlp_ms * 1e-3) / 1e12 if mlp_ms > 0 else 0.0
+        flop_ex = 2 * executed(VAN_MAC, fold)       # what the kernel executes per network evaluation
+        mlp_tflops = mlp_samples * flop_ex / (mlp_ms * 1e-3) / 1e12 if mlp_ms > 0 else 0.0
+        mlp_tflops_lit = mlp_samples * FLOP_PER_SAMPLE / (mlp_ms * 1e-3) / 1e12 if mlp_ms > 0 else 0.0
         res = {
             "metric": "rays/sec (64c+128f samples)", "value": rays_per_s, "unit": "rays/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
@@ -592,12 +610,18 @@ def main():
                        "rays_per_gpu": n_rays, "evals_per_ray": EVALS_PER_RAY,
                        "exchange": "RCCL all_gather of (rgb,acc,depth)=20 B/ray" if world > 1 else "none"},
             "multi_gpu": diag,
-            "roofline": {"bound": "mfma", "kernel": "aon::mlp_fwd_kernel<true> (fused encode+MLP, fp32 MFMA)",
+            "bottleneck_fold": fold,
+            "roofline": {"bound": "mfma", "kernel": "aon::mlp_fwd_kernel<true,false,fold> (fused encode+MLP, fp32 MFMA)",
                          "achieved": mlp_tflops, "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
                          "frac": mlp_tflops / PEAK_FP32_MATRIX_TFLOPS, "traffic": None,
+                         "achieved_reference_literal": mlp_tflops_lit, "frac_reference_literal": mlp_tflops_lit / PEAK_FP32_MATRIX_TFLOPS,
                          "launches": mlp_launches, "avg_launch_ms": mlp_ms / max(mlp_launches, 1),
-                         "flop_per_sample": FLOP_PER_SAMPLE,
-                         "whole_path_frac": rays_per_s / world * EVALS_PER_RAY * FLOP_PER_SAMPLE / (PEAK_FP32_MATRIX_TFLOPS * 1e12)},
+                         "flop_per_sample": flop_ex, "flop_per_sample_reference_literal": FLOP_PER_SAMPLE,
+                         "note": "achieved / frac price the FLOPs the kernel EXECUTES (bottleneck_layer folded into views_linear[0] when bottleneck_fold: "
+                                 "65,536 MACs per sample fewer than the reference's graph); *_reference_literal price the reference's 1,186,816 FLOP per "
+                                 "sample against the same time and can exceed the executed fraction",
+                         "whole_path_frac": rays_per_s / world * EVALS_PER_RAY * flop_ex / (PEAK_FP32_MATRIX_TFLOPS * 1e12),
+                         "whole_path_frac_reference_literal": rays_per_s / world * EVALS_PER_RAY * FLOP_PER_SAMPLE / (PEAK_FP32_MATRIX_TFLOPS * 1e12)},
         }
         res["roofline"].update(pmc_traffic())
         res["hbm_kernels"] = pmc_traffic_ray_kernels(per_ray_rooflines(headline_classes))   # the non-GEMM kernels of the same timed region (>= 50 % of HBM peak each)

@@ -72,6 +72,7 @@ def main():
             log.append(rec)
             print(json.dumps(rec), flush=True)
     os.makedirs(args.exp_dir, exist_ok=True)
+    lit.finish_fit()   # the deferred check of the last data-parallel gradient exchange
     save_checkpoint(os.path.join(args.exp_dir, "last.ckpt"), lit, opt, epoch=0)
     # test split: 19 poses on the spheric path, articulation code i of the 19-row interpolated table (code_library.py:41-71)
     outs = [lit.test_step(collate(test[i], dev), i) for i in range(len(test))]

@@ -70,6 +70,7 @@ def main():
             if step >= args.steps:
                 break
     os.makedirs(args.exp_dir, exist_ok=True)
+    lit.finish_fit()   # the deferred check of the last data-parallel gradient exchange
     save_checkpoint(os.path.join(args.exp_dir, "last.ckpt"), lit, opt, epoch=0)
     outs = [lit.test_step({k: v.unsqueeze(0) for k, v in test[i].items()}, i) for i in range(len(test))]
     psnr, psnr_obj = lit.test_epoch_end(outs, test.image_sizes, out_dir=os.path.join(args.exp_dir, "render"))

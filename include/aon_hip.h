@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define AON_ABI_VERSION 2
+#define AON_ABI_VERSION 3
 
 #define AON_OK 0
 #define AON_E_INVALID (-1)    /* null pointer, negative size, unsupported geometry */
@@ -77,6 +77,25 @@ int aon_pos_enc(const float* x, int64_t n, int min_deg, int max_deg, float* out,
  * Re-run whenever the parameters change; `packed` needs aon_mlp_packed_bytes() bytes, 16-byte aligned. */
 int64_t aon_mlp_packed_bytes(void);
 int aon_pack_vanilla_mlp(const float* const* params_host, void* packed, void* stream);
+
+/* ---- Round 5: bottleneck_layer folded into views_linear[0] ----
+ * The reference's bottleneck_layer has NO activation and feeds views_linear[0] directly (models/vanilla_nerf/model.py:109-114,
+ * model_autodecoder.py:223-230), so
+ *     W_v0[:, :256] (W_b h + b_b) + W_v0[:, 256:] c + b_v0  ==  (W_v0[:, :256] W_b) h + W_v0[:, 256:] c + (W_v0[:, :256] b_b + b_v0)
+ * and a from-scratch kernel can run ONE 256 -> 128 layer where the literal graph runs 256 -> 256 then 256 -> 128: 65,536 of the
+ * vanilla network's 593,408 multiply-adds per sample (11.0 %; 9.5 % of the articulated network's executed 692,480), in the forward,
+ * the backward data chain and the weight gradients alike.  With the switch on (default) every aon_pack_* / aon_art_prepare* call
+ * builds the FOLDED form: W' = W_v0[:, :256] W_b and b' are evaluated in fp64 from the fp32 parameters and rounded once; the training
+ * forward writes no bottleneck rows; the backward computes dW' = dZ_v0 H7^T, db' and un-folds them exactly as autograd's chain rule
+ * does -- dW_b = W_v0[:, :256]^T dW', db_b = W_v0[:, :256]^T db', dW_v0[:, :256] = dW' W_b^T + db' (x) b_b (fp64 accumulation) -- so
+ * the 24 / 40 parameter gradients keep the reference's shapes and meaning.  Buffer sizes do not depend on the switch.
+ * The form is a property of each packed buffer / per-call block, fixed when it was made and remembered per pointer: flipping the
+ * switch later does not change how an existing buffer is run, and a call that is handed buffers of two forms returns AON_E_INVALID
+ * (HIP "invalid value").  A buffer this process did not pack (a device-side copy of one) is taken to have the current default form.
+ * aon_set_bottleneck_fold(0): the literal two-layer form (rounds 1-4), for A/B measurements and bit-level comparisons. */
+int aon_set_bottleneck_fold(int on);
+int aon_get_bottleneck_fold(void);
+int aon_stream_is_folded(const void* packed);   /* 1 / 0: the form `packed` (stream or per-call block) would be run in */
 
 /* As aon_pack_vanilla_mlp for a NeRFMLP(min_deg_point, max_deg_point, deg_view) of default widths and depths whose encodings have
  * at most 10 / 4 frequency levels (pts_linears.0: (256, 3 + 6 L), pts_linears.5: (256, 256 + 3 + 6 L), views_linear.0: (128, 256 +
@@ -164,7 +183,12 @@ int aon_pack_art_mlp(const float* const* params_host, void* packed, void* stream
  * the levels the network lacks (row strides of pts_linears.0 / .5 and views_linear.0 follow P = 3 + 6 L, V = 3 + 6 Lv), and the small
  * block carries the ten encoding scales 2^(min_deg_point + l) the kernels multiply the DEFORMED point by (0 for a missing level), so
  * every aon_art_* call works unchanged on streams / blocks made by the _deg forms; aon_art_render_bwd_ex and aon_art_wgrad_deg take the
- * degrees (aon_render_opts / arguments) for the layout of the gradients they write.  The plain forms are these with (0, 10, 4). */
+ * degrees (aon_render_opts / arguments) for the layout of the gradients they write.  The plain forms are these with (0, 10, 4).
+ * WARNING: nothing cross-checks the degrees a stream / block was packed with against the degrees handed to aon_art_render_bwd_ex
+ * (aon_render_opts, NULL = (0, 10, 4)) or aon_art_wgrad_deg: they fix the ROW STRIDES of the three concatenating layers' gradients
+ * (P + 128, 256 + P + 128, 256 + V + 128 columns), so passing larger degrees than the gradient buffers were allocated for writes out
+ * of bounds, and smaller ones leave columns unwritten.  Pass the same three numbers to pack, prepare, backward and size your buffers
+ * by them.  aon_art_small_bytes() grew from 18,976 to 19,024 bytes in round 4 (the ten encoding scales): query it, do not hard-code it. */
 int aon_pack_art_mlp_deg(const float* const* params_host, int min_deg_point, int max_deg_point, int deg_view, void* packed, void* stream);
 int aon_art_prepare_deg(const float* const* params_host, const float* shape, const float* appearance, const float* articulation,
                         int min_deg_point, int max_deg_point, int deg_view, void* small, void* stream);
@@ -197,7 +221,10 @@ int aon_art_render_fwd(const void* packed_coarse, const void* small_coarse, cons
  *                       transposed stream of aon_pack_vanilla_mlp_bwd.
  *   aon_vanilla_wgrad   all 24 parameter gradients (order of aon_pack_vanilla_mlp, full nn.Linear shapes, overwritten)
  *                       from planes x dplanes: one grouped launch over all layers + one over the heads + one second stage
- *                       (csrc/aon_wgrad.h); workspace >= aon_wgrad_workspace_bytes(); deterministic (no atomics). */
+ *                       (csrc/aon_wgrad.h); workspace >= aon_wgrad_workspace_bytes(); deterministic (no atomics).
+ *                       packed_bwd (round 5): the transposed stream aon_mlp_bwd_chain ran with -- its form says whether the planes
+ *                       carry bottleneck rows, and a folded stream's buffer holds the raw W_v0[:, :256], W_b, b_b the un-folding
+ *                       of (dW', db') reads.  NULL = planes of the literal form.  aon_art_wgrad* likewise (form only). */
 int64_t aon_train_plane_rows(void);
 int64_t aon_train_mask_bytes(int64_t Np);
 int64_t aon_bwd_packed_bytes(void);
@@ -210,7 +237,7 @@ int aon_composite_bwd(const float* raw, const float* t_vals, const float* dirs, 
 int aon_mlp_bwd_chain(const void* packed_bwd, const void* packed_fwd, const float* d_raw, const void* masks,
                       float* dplanes, int64_t Np, void* stream);
 int aon_vanilla_wgrad(const float* planes, const float* dplanes, const float* d_raw, int64_t Np,
-                      float* const* grads_host, void* workspace, int64_t workspace_bytes, void* stream);
+                      float* const* grads_host, void* workspace, int64_t workspace_bytes, void* stream, const void* packed_bwd);
 /* Host-only: the plan aon_vanilla_wgrad / aon_art_wgrad would run for a level of Np samples on `cus` compute units.  Round 4: the
  * steps of all jobs form one work line priced in cost units, and each of the G = min(cus, 304, steps) workgroups owns the steps that
  * start in its 1/G of the line (csrc/aon_wgrad.h), so a workgroup runs up to a few segments of consecutive jobs.  Per job six ints:
@@ -247,12 +274,12 @@ int aon_art_bwd_chain(const void* packed_bwd, const void* small, const float* d_
 int aon_art_wgrad(const float* planes, const float* dplanes, const float* d_raw, const float* dxp, int64_t Np,
                   const float* const* params_host, const float* shape, const float* appearance,
                   const float* articulation, float* const* grads_host, float* g_shape, float* g_appearance,
-                  float* g_articulation, void* workspace, int64_t workspace_bytes, void* stream);
+                  float* g_articulation, void* workspace, int64_t workspace_bytes, void* stream, const void* packed_bwd);
 int aon_art_wgrad_deg(const float* planes, const float* dplanes, const float* d_raw, const float* dxp, int64_t Np,
                       const float* const* params_host, const float* shape, const float* appearance,
                       const float* articulation, float* const* grads_host, float* g_shape, float* g_appearance,
                       float* g_articulation, void* workspace, int64_t workspace_bytes, void* stream, int min_deg_point,
-                      int max_deg_point, int deg_view);
+                      int max_deg_point, int deg_view, const void* packed_bwd);
 
 /* ---- R14, the training step in two calls ----
  * aon_render_fwd_train = NeRF.forward under grad mode (model.py:147-199 as called by training_step :264): both levels,

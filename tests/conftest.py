@@ -35,3 +35,15 @@ def nerf_sd():
     import aon_amd.synthetic as syn
 
     return syn.make_nerf_state_dict(seed=0, density_scale=30.0)
+
+
+@pytest.fixture(params=["folded", "literal"])
+def fold_form(request):
+    """Round 5: both forms of the fused kernels' streams -- bottleneck_layer folded into views_linear[0] (the default) and the literal
+    two layers (aon_set_bottleneck_fold(0)).  Tests that take this fixture run once per form; the switch is restored afterwards."""
+    from aon_amd import ops
+
+    before = ops.bottleneck_fold()
+    ops.set_bottleneck_fold(request.param == "folded")
+    yield request.param
+    ops.set_bottleneck_fold(before)

@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(_lib.lib, n), f"{n} declared in aon_hip.h but not exported"
     assert sorted(_lib.exported_symbols()) == names, "ctypes binding and header disagree"
-    assert _lib.lib.aon_abi_version() == 2
+    assert _lib.lib.aon_abi_version() == 3
 
 
 def test_argument_validation_without_gpu():
@@ -132,7 +132,13 @@ def test_wgrad_plan_invariants_without_gpu():
     lib = _lib.lib
     blk = {0: 256 * 256, 1: 128 * 128, 2: 256 * 64, 3: 128 * 256, 4: 128 * 32}
     cost = {0: 16384, 1: 4280, 2: 4620, 3: 8300, 4: 1510}
-    for art, njobs in ((0, 12), (1, 18)):
+    # both forms of the networks (round 5): with bottleneck_layer folded into views_linear[0] a level has one job fewer (the
+    # 256x256 bottleneck job and the 128x256 view job on the bottleneck output become ONE 128x256 job on the layer-7 output)
+    cases = []
+    for fold in (1, 0):
+        cases += [(fold, 0, 12 - fold), (fold, 1, 18 - fold)]
+    for fold, art, njobs in cases:
+        lib.aon_set_bottleneck_fold(fold)
         for Np in (128, 640, 4096 * 65 + 0, 128 * ((4096 * 193 + 127) // 128)):
             if Np % 128:
                 Np += 128 - Np % 128
@@ -171,6 +177,7 @@ def test_wgrad_plan_invariants_without_gpu():
                     assert max(load) - min(load) <= 2 * 16384, (art, Np, cus, max(load), min(load))
                     if cus == 256 and Np > 100_000:
                         assert G == 256 and max(load) / min(load) < 1.01
+    lib.aon_set_bottleneck_fold(1)
     out = (C.c_int32 * 120)()
     assert lib.aon_wgrad_plan(1, 100, 256, out, 20, None) < 0 and b"multiple of 32" in lib.aon_last_error()
     assert lib.aon_wgrad_plan(1, 1024, 256, out, 3, None) < 0

@@ -158,10 +158,47 @@ def test_articulated_frame_320x240_properties(dev, art_sd):
         assert torch.isfinite(rgb).all() and torch.isfinite(depth).all()
         assert acc.min().item() >= 1.0 - 1e-5 and acc.max().item() <= 1.0 + 1e-5   # softplus sigma > 0 -> alpha_last = 1
         assert rgb.min().item() >= -0.001 - 1e-5 and rgb.max().item() <= 1.001 + 1e-4
-    pick = torch.arange(0, H * W, 601)
+    # parity against the oracle at the bar of BASELINE config 2 (tests/test_hip_parity.py::test_full_frame_properties): >= 4,096 strided
+    # rays of THIS frame, both levels, every output (rounds 1-4 held 128 rays, fine rgb only, PSNR >= 70 dB / 1e-3: VERDICT r4).
+    # Bars: 1e-5 rgb / acc, 2e-4 depth per ray.  Where the REFERENCE ARITHMETIC ITSELF is less certain than that on this sharp x30 field
+    # (a 1e-7 difference of the deformed point is multiplied by 2^9 inside the encoding that follows the deformation MLP, and a 1e-7
+    # difference of a coarse weight moves fine samples across thin shells) the yardstick is the distance between the oracle's fp32 and
+    # fp64 evaluations of the same rays (see the fine-level criterion below).  Softplus keeps sigma > 0: every ray is far-plane robust.
+    pick = torch.arange(0, H * W, 18)
+    assert pick.numel() >= 4096
     rays_cpu = {k: v[pick.to(dev)].cpu() for k, v in rays.items()}
-    ref = orc.nerf_ae_art_forward(art_sd, rays_cpu, False, True, 2.0, 6.0, {k: v.cpu() for k, v in lat.items()})
-    assert_render_close(full[1][0][pick.to(dev)].cpu(), ref[1][0], "320x240 strided sample vs oracle")
+    lat_cpu = {k: v.cpu() for k, v in lat.items()}
+    ref = orc.nerf_ae_art_forward(art_sd, rays_cpu, False, True, 2.0, 6.0, lat_cpu)
+    ref64 = orc.nerf_ae_art_forward({k: v.double() for k, v in art_sd.items()}, {k: v.double() for k, v in rays_cpu.items()}, False, True, 2.0, 6.0,
+                                    {k: v.double() for k, v in lat_cpu.items()})
+    nrays = pick.numel()
+    for lvl in (0, 1):
+        got = [x[pick.to(dev)].cpu() for x in full[lvl]]
+        for i, (name, bar) in enumerate((("rgb", 1e-5), ("acc", 1e-5), ("depth", 2e-4))):
+            err = (got[i] - ref[lvl][i]).abs()
+            spread = (ref[lvl][i].double() - ref64[lvl][i]).abs().float()
+            if err.dim() > 1:
+                err, spread = err.max(dim=-1).values, spread.max(dim=-1).values
+            above, above_ref = int((err > bar).sum()), int((spread > bar).sum())
+            beyond = int((err > torch.clamp(3.0 * spread, min=bar)).sum())
+            q = lambda x, p: torch.quantile(x.double(), p).item()   # noqa: E731
+            print(f"config 4 level {lvl} {name}: {nrays} rays, |hip - oracle| max {err.max():.2e} p99 {q(err, 0.99):.2e} p50 {q(err, 0.5):.2e}; oracle fp32 vs "
+                  f"fp64 on the same rays max {spread.max():.2e} p99 {q(spread, 0.99):.2e} p50 {q(spread, 0.5):.2e}; rays above {bar:g}: hip {above}, "
+                  f"oracle's own {above_ref}; hip beyond 3 x that ray's spread: {beyond}")
+            if lvl == 0:
+                # coarse level: the same t on both sides -- per ray, the plain bar
+                assert above == 0, (name, err.max().item())
+            else:
+                # Fine level.  Measured before the bottleneck fold (round 5, 4,267 rays): rgb 185 rays above 1e-5 where the oracle's own
+                # fp32-vs-fp64 distance exceeds it on MORE rays and by more (max 4.6e-4 vs 7.0e-4) -- which evaluation lands on which side
+                # of a thin shell is a coin toss per ray, so a per-ray "3 x this ray's spread" rule does not hold (47 rays) while the
+                # DISTRIBUTIONS agree.  Criterion: HIP is to the fp32 oracle what the fp32 oracle is to the fp64 truth -- no more rays
+                # above the bar than 1.5 x the oracle's own count (+ 0.5 % of the rays), the worst ray within 2 x the oracle's worst,
+                # the 99th percentile within 2 x the oracle's (or the bar).
+                assert above <= 1.5 * above_ref + 0.005 * nrays, (name, above, above_ref)
+                assert err.max().item() <= max(bar, 2.0 * spread.max().item()), (name, err.max().item(), spread.max().item())
+                assert q(err, 0.99) <= max(bar, 2.0 * q(spread, 0.99)), (name, q(err, 0.99), q(spread, 0.99))
+        assert_render_close(got[0], ref[lvl][0], f"320x240 strided sample vs oracle, level {lvl}")
 
 
 @pytest.mark.parametrize("tag", ["a", "b", "c"])

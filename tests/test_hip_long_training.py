@@ -127,7 +127,7 @@ def test_vanilla_32_steps_vs_oracle(dev, golden):
     opt = lit.configure_optimizers()
     losses_h = []
     for i, (t_rand, u) in enumerate(draws):
-        batch = {**rays_cpu, "target": target, "t_rand": t_rand, "u": u}
+        batch = {**rays_cpu, "target": target, "aon_t_rand": t_rand, "aon_u": u}
         loss = lit.fit_step({k: v.unsqueeze(0).to(dev) for k, v in batch.items()}, i, opt)
         assert abs(opt.param_groups[0]["lr"] - reference_lr(i)) <= 1e-12 * reference_lr(i)
         losses_h.append(loss.item())
@@ -178,7 +178,7 @@ def test_articulated_32_steps_vs_oracle(dev, golden):
     opt = lit.configure_optimizers()
     losses_h = []
     for i, (t_rand, u) in enumerate(draws):
-        batch = {k: v.unsqueeze(0).to(dev) for k, v in {**rays_cpu, "target": target, "t_rand": t_rand, "u": u}.items()}
+        batch = {k: v.unsqueeze(0).to(dev) for k, v in {**rays_cpu, "target": target, "aon_t_rand": t_rand, "aon_u": u}.items()}
         batch["instance_id"] = torch.tensor([ids[i][0]], device=dev)
         batch["articulation_id"] = torch.tensor([ids[i][1]], device=dev)
         loss = lit.fit_step(batch, i, opt)

@@ -80,7 +80,7 @@ def _layer_activations(sd, prefix, enc, venc):
     return acts, bott, hv
 
 
-def test_forward_train_planes(dev, nerf_sd):
+def test_forward_train_planes(dev, nerf_sd, fold_form):
     import aon_amd.synthetic as syn
     from aon_amd import ops
 
@@ -100,7 +100,8 @@ def test_forward_train_planes(dev, nerf_sd):
     torch.testing.assert_close(pl[0:63].T, enc.reshape(-1, 63), rtol=0, atol=2.5e-7)
     for l in range(8):
         torch.testing.assert_close(pl[64 + 256 * l: 64 + 256 * (l + 1)].T, acts[l], rtol=2e-5, atol=2e-5)
-    torch.testing.assert_close(pl[2112:2368].T, bott, rtol=2e-5, atol=2e-5)
+    if fold_form == "literal":   # (the folded form has no bottleneck output: views_linear[0] reads H7 through W' = W_v0[:, :256] W_b)
+        torch.testing.assert_close(pl[2112:2368].T, bott, rtol=2e-5, atol=2e-5)
     torch.testing.assert_close(pl[2368:2395].T, venc[:, None, :].expand(n, S, 27).reshape(-1, 27), rtol=0, atol=2.5e-7)
     torch.testing.assert_close(pl[2400:2528].T, hv, rtol=2e-5, atol=2e-5)
 
@@ -145,7 +146,7 @@ def test_training_step_gradients_vs_oracle_autograd(dev, randomized, white, dens
 
 
 @pytest.mark.parametrize("n,S", [(40, 193), (3, 65)])
-def test_level_backward_with_shared_samples(dev, nerf_sd, n, S):
+def test_level_backward_with_shared_samples(dev, nerf_sd, n, S, fold_form):
     """One level in isolation with the SAME sample positions on both sides: forward-train -> composite -> loss ->
     composite_bwd -> bwd chain -> wgrad against autograd on the oracle.  Pins the fine-level (S = 193) kernels tightly."""
     import aon_amd.synthetic as syn
@@ -169,7 +170,8 @@ def test_level_backward_with_shared_samples(dev, nerf_sd, n, S):
     g_rgb = 2.0 * (rgb - target.to(dev)) / (n * 3)
     d_raw = ops.composite_bwd(raw, tt, d, g_rgb, None, None, True, ops.ACT_VANILLA, ops.plane_samples(planes))
     dplanes = ops.mlp_bwd_chain(packed_bwd, packed, d_raw, masks, planes.shape)
-    grads = ops.vanilla_wgrad(planes, dplanes, d_raw)
+    assert ops.lib.aon_stream_is_folded(ops._ptr(packed_bwd)) == (fold_form == "folded")
+    grads = ops.vanilla_wgrad(planes, dplanes, d_raw, packed_bwd)
     for name, g in grads.items():
         err = rel_l2(g.cpu(), sd_o[prefix + name].grad)
         assert err <= 2e-5, f"{name}: relative L2 gradient error {err:.3e}"
@@ -251,11 +253,12 @@ def test_gradients_vs_reference_golden(dev, golden, nerf_sd):
     loss = torch.mean((out[0][0] - target) ** 2) + torch.mean((out[1][0] - target) ** 2)
     loss.backward()
     assert abs(loss.item() - g["art_loss"]) <= 1e-4
-    # measured: coarse 1.2e-4 (norm) / 3.1e-4 (entries); fine 4.6e-3 / 4.7e-2 (sharp x30 field: fine samples move); latents 1.6e-2
-    check("art", amodel.named_parameters(), lambda n: 2e-2 if n.startswith("fine_mlp") else 1e-3)
-    for k, v in lat.items():
-        ref = g[f"art_latgrad_{k}"]
-        assert (v.grad.cpu() - ref).abs().max().item() <= 3e-2 * ref.abs().max().item(), k
+    # measured: coarse 1.2e-4 (norm) / 3.1e-4 (entries).  The articulated FINE level and the latents are not held to G9 here: on this
+    # sharp x30 field two fp32 evaluations of them sit 4.6e-3 .. 4.7e-2 apart (fine samples move across thin shells), and a fixed
+    # 2e-2 / 3e-2 bar (rounds 1-4) could hide a tenfold regression inside itself.  Their check is the fp64 yardstick on
+    # these very inputs, test_g9_inputs_by_the_fp64_yardstick below (G9 == the oracle's fp32 autograd: tests/test_oracle_golden.py).
+    check("art", [(n, p) for n, p in amodel.named_parameters() if n.startswith("coarse_mlp")], lambda n: 1e-3)
+    assert all(v.grad is not None and torch.isfinite(v.grad).all() for v in lat.values())
 
 
 @pytest.mark.parametrize("net", ["vanilla", "articulated"])
@@ -400,7 +403,7 @@ def test_two_call_step_equals_the_staged_entry_points(dev, nerf_sd):
         g_rgb = 2.0 * (rgb - target) / (3 * n)
         d_raw = ops.composite_bwd(raw, t_vals, rays["rays_d"], g_rgb.contiguous(), None, None, False, ops.ACT_VANILLA, ops.plane_samples(planes))
         dpl = ops.mlp_bwd_chain(pb, pf, d_raw, masks, planes.shape)
-        for k, v in ops.vanilla_wgrad(planes, dpl, d_raw).items():
+        for k, v in ops.vanilla_wgrad(planes, dpl, d_raw, pb).items():
             grads_s[f"{name}.{k}"] = v
     assert all(torch.equal(a, b) for a, b in zip(outs_a, outs_s))
     for k in grads_a:
@@ -414,7 +417,7 @@ def _to_step_major(rows_view):
 
 
 @pytest.mark.parametrize("net,n_samples", [("vanilla", 640), ("vanilla", 4096 * 3 + 128), ("articulated", 1152), ("articulated", 9984)])
-def test_grouped_wgrad_against_fp64_matmul(dev, net, n_samples):
+def test_grouped_wgrad_against_fp64_matmul(dev, net, n_samples, fold_form):
     """The grouped weight-gradient launch on RANDOM step-major planes against dW = dZ . H^T in fp64, every parameter of the network
     -- all five job kinds (256x256, 128x128, 256x64, 128x256, 128x32), the head / bias / first-deformation-layer reductions, the
     second stage, the latent outer products and latent gradients -- independent of the forward and the chain (round 3; until now
@@ -439,9 +442,19 @@ def test_grouped_wgrad_against_fp64_matmul(dev, net, n_samples):
         err = (got.double().cpu() - want).abs().max().item() / max(want.abs().max().item(), 1e-30)
         assert err <= tol, (name, err)
 
+    # Folded form (round 5): the bottleneck rows of the planes are not read; dW' = dZ_v0 . H7^T and db' are un-folded with the raw
+    # W_v0[:, :256], W_b, b_b (fp64 products): dW_b = W_v0h^T dW', db_b = W_v0h^T db', dW_v0h = dW' W_b^T + db' (x) b_b.
+    folded = fold_form == "folded"
+
+    def unfolded(dhv, h7, Wv_h, Wb, bb):
+        dWf, dbf = dhv @ h7.T, dhv.sum(1)
+        return Wv_h.T @ dWf, Wv_h.T @ dbf, dWf @ Wb.T + torch.outer(dbf, bb)
+
     if not art:
-        g = ops.vanilla_wgrad(planes, dplanes, d_raw.to(dev))
-        g2 = ops.vanilla_wgrad(planes, dplanes, d_raw.to(dev))
+        vsd = {k[len("fine_mlp."):]: v.to(dev) for k, v in syn.make_nerf_state_dict(seed=7, density_scale=1.0).items() if k.startswith("fine_mlp.")}
+        pb = ops.pack_vanilla_mlp_bwd(vsd)
+        g = ops.vanilla_wgrad(planes, dplanes, d_raw.to(dev), pb)
+        g2 = ops.vanilla_wgrad(planes, dplanes, d_raw.to(dev), pb)
         assert all(torch.equal(g[k], g2[k]) for k in g)
         E, VE = P64[0:63], P64[2368:2395]
         H = lambda l: P64[64 + 256 * l: 64 + 256 * (l + 1)]
@@ -455,9 +468,16 @@ def test_grouped_wgrad_against_fp64_matmul(dev, net, n_samples):
             close(f"pts_linears.{l}.weight", g[f"pts_linears.{l}.weight"], want)
             close(f"pts_linears.{l}.bias", g[f"pts_linears.{l}.bias"], dZ(l).sum(1))
         dbot, dhv, bott, hv = D64[2112:2368], D64[2400:2528], P64[2112:2368], P64[2400:2528]
-        close("bottleneck_layer.weight", g["bottleneck_layer.weight"], dbot @ H(7).T)
-        close("bottleneck_layer.bias", g["bottleneck_layer.bias"], dbot.sum(1))
-        close("views_linear.0.weight", g["views_linear.0.weight"], torch.cat([dhv @ bott.T, dhv @ VE.T], 1))
+        if folded:
+            Wd = {k: v.double().cpu() for k, v in vsd.items()}
+            dWb, dbb, dWvh = unfolded(dhv, H(7), Wd["views_linear.0.weight"][:, :256], Wd["bottleneck_layer.weight"], Wd["bottleneck_layer.bias"])
+            close("bottleneck_layer.weight", g["bottleneck_layer.weight"], dWb)
+            close("bottleneck_layer.bias", g["bottleneck_layer.bias"], dbb)
+            close("views_linear.0.weight", g["views_linear.0.weight"], torch.cat([dWvh, dhv @ VE.T], 1))
+        else:
+            close("bottleneck_layer.weight", g["bottleneck_layer.weight"], dbot @ H(7).T)
+            close("bottleneck_layer.bias", g["bottleneck_layer.bias"], dbot.sum(1))
+            close("views_linear.0.weight", g["views_linear.0.weight"], torch.cat([dhv @ bott.T, dhv @ VE.T], 1))
         close("views_linear.0.bias", g["views_linear.0.bias"], dhv.sum(1))
         close("density_layer.weight", g["density_layer.weight"], (H(7) @ R64[:, 3:4]).T)
         close("density_layer.bias", g["density_layer.bias"], R64[:, 3].sum(0, keepdim=True))
@@ -468,8 +488,9 @@ def test_grouped_wgrad_against_fp64_matmul(dev, net, n_samples):
     lat = {"density": torch.randn(1, 128, generator=gen).to(dev), "color": torch.randn(1, 128, generator=gen).to(dev),
            "articulation": torch.randn(1, 32, generator=gen).to(dev)}
     dxp = torch.randn(Np, 4, generator=gen) * 0.1
-    g, gl = ops.art_wgrad(planes, dplanes, d_raw.to(dev), dxp.to(dev), sd, lat)
-    g2, gl2 = ops.art_wgrad(planes, dplanes, d_raw.to(dev), dxp.to(dev), sd, lat)
+    pb = ops.pack_art_mlp_bwd(sd)
+    g, gl = ops.art_wgrad(planes, dplanes, d_raw.to(dev), dxp.to(dev), sd, lat, packed_bwd=pb)
+    g2, gl2 = ops.art_wgrad(planes, dplanes, d_raw.to(dev), dxp.to(dev), sd, lat, packed_bwd=pb)
     assert all(torch.equal(g[k], g2[k]) for k in g) and all(torch.equal(gl[k], gl2[k]) for k in gl)
     X64 = dxp.double()
     d_ = lambda l: slice(32 + 128 * l, 32 + 128 * (l + 1))
@@ -496,12 +517,20 @@ def test_grouped_wgrad_against_fp64_matmul(dev, net, n_samples):
             want = torch.cat([want, D64[h_(5)] @ E.T, torch.outer(db_t5, shape)], 1)
         close(f"pts_linears.{l}.weight", g[f"pts_linears.{l}.weight"], want)
         close(f"pts_linears.{l}.bias", g[f"pts_linears.{l}.bias"], D64[h_(l)].sum(1))
-    close("bottleneck_layer.weight", g["bottleneck_layer.weight"], D64[bot] @ P64[h_(7)].T)
-    close("views_linear.0.weight", g["views_linear.0.weight"], torch.cat([D64[v_(0)] @ P64[bot].T, D64[v_(0)] @ VE.T, torch.outer(db_v0, app)], 1))
+    W = {k: v.double().cpu() for k, v in sd.items()}
+    if folded:
+        dWb, dbb, dWvh = unfolded(D64[v_(0)], P64[h_(7)], W["views_linear.0.weight"][:, :256], W["bottleneck_layer.weight"], W["bottleneck_layer.bias"])
+        close("bottleneck_layer.weight", g["bottleneck_layer.weight"], dWb)
+        close("bottleneck_layer.bias", g["bottleneck_layer.bias"], dbb)
+        close("views_linear.0.weight", g["views_linear.0.weight"], torch.cat([dWvh, D64[v_(0)] @ VE.T, torch.outer(db_v0, app)], 1))
+    else:
+        close("bottleneck_layer.weight", g["bottleneck_layer.weight"], D64[bot] @ P64[h_(7)].T)
+        close("bottleneck_layer.bias", g["bottleneck_layer.bias"], D64[bot].sum(1))
+        close("views_linear.0.weight", g["views_linear.0.weight"], torch.cat([D64[v_(0)] @ P64[bot].T, D64[v_(0)] @ VE.T, torch.outer(db_v0, app)], 1))
+    close("views_linear.0.bias", g["views_linear.0.bias"], db_v0)
     close("density_layer.weight", g["density_layer.weight"], (P64[h_(7)] @ R64[:, 3:4]).T)
     close("rgb_layer.weight", g["rgb_layer.weight"], (P64[v_(3)] @ R64[:, :3]).T)
     close("rgb_layer.bias", g["rgb_layer.bias"], R64[:, :3].sum(0))
-    W = {k: v.double().cpu() for k, v in sd.items()}
     close("latent density", gl["density"], W["deformations_linear.0.weight"][:, 3:131].T @ db0 + W["pts_linears.0.weight"][:, 63:191].T @ db_t0 +
           W["pts_linears.5.weight"][:, 319:447].T @ db_t5)
     close("latent color", gl["color"], W["views_linear.0.weight"][:, 283:411].T @ db_v0)

@@ -85,11 +85,11 @@ def wgrad_probe(args):
         d_raw = torch.randn(ops.plane_samples(planes), 4, device=dev) * 1e-3
         dpl, dxp = ops.art_bwd_chain(pab, small, d_raw, masks, planes)
         probe = torch.zeros(2 * 320, dtype=torch.int64, device=dev)
-        ops.art_wgrad(planes, dpl, d_raw, dxp, art, lat)
+        ops.art_wgrad(planes, dpl, d_raw, dxp, art, lat, packed_bwd=pab)
         torch.cuda.synchronize()
         lib.aon_set_wgrad_probe(probe.data_ptr())
         try:
-            ops.art_wgrad(planes, dpl, d_raw, dxp, art, lat)
+            ops.art_wgrad(planes, dpl, d_raw, dxp, art, lat, packed_bwd=pab)
             torch.cuda.synchronize()
         finally:
             lib.aon_set_wgrad_probe(None)
@@ -173,7 +173,7 @@ def main():
                 emit("mlp_bwd_chain", S, timeit(lambda: ops.mlp_bwd_chain(pvb, pv, d_raw, masks, planes.shape), args.reps), bw_mac, VAN_MAC)
             if want("wgrad"):
                 dpl = ops.mlp_bwd_chain(pvb, pv, d_raw, masks, planes.shape)
-                emit("vanilla_wgrad(all layers)", S, timeit(lambda: ops.vanilla_wgrad(planes, dpl, d_raw), args.reps), VAN_MAC, VAN_MAC)
+                emit("vanilla_wgrad(all layers)", S, timeit(lambda: ops.vanilla_wgrad(planes, dpl, d_raw, pvb), args.reps), VAN_MAC, VAN_MAC)
                 del dpl
             del raw, planes, masks
         if want("art_fwd_train") or want("art_bwd_chain") or want("art_wgrad"):
@@ -187,7 +187,7 @@ def main():
                 emit("art_bwd_chain", S, timeit(lambda: ops.art_bwd_chain(pab, small, d_raw, masks, planes), args.reps), bw_mac, ART_MAC)
             if want("art_wgrad"):
                 dpl, dxp = ops.art_bwd_chain(pab, small, d_raw, masks, planes)
-                emit("art_wgrad(all layers)", S, timeit(lambda: ops.art_wgrad(planes, dpl, d_raw, dxp, art, lat), args.reps), ART_MAC_EXEC, ART_MAC)
+                emit("art_wgrad(all layers)", S, timeit(lambda: ops.art_wgrad(planes, dpl, d_raw, dxp, art, lat, packed_bwd=pab), args.reps), ART_MAC_EXEC, ART_MAC)
                 del dpl, dxp
             del raw, planes, masks
         torch.cuda.empty_cache()

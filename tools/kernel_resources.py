@@ -9,7 +9,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-FILES = ["aon_mlp.hip", "aon_mlp_art.hip", "aon_train.hip", "aon_train_art.hip", "aon_render.hip", "aon_gmlp.hip"]
+FILES = ["aon_mlp.hip", "aon_mlp_art.hip", "aon_train.hip", "aon_train_art.hip", "aon_render.hip", "aon_gmlp.hip", "aon_fold.hip"]
 PAT = re.compile(r"Name: (\S+).*?VGPRs: (\d+).*?AGPRs: (\d+).*?ScratchSize \[bytes/lane\]: (\d+).*?Occupancy \[waves/SIMD\]: (\d+)")
 
 
