@@ -154,6 +154,12 @@ class AonError(RuntimeError):
     pass
 
 
+# measurements: AON_BOTTLENECK_FOLD=0 in the environment starts the process in the literal two-layer form (aon_set_bottleneck_fold(0)),
+# so every tool / test can be A/B'd without a flag of its own
+if os.environ.get("AON_BOTTLENECK_FOLD", "") == "0":
+    lib.aon_set_bottleneck_fold(0)
+
+
 def check(rc: int, what: str = "") -> None:
     if rc != 0:
         msg = lib.aon_last_error().decode("utf-8", "replace")

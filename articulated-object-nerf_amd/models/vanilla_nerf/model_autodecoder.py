@@ -264,4 +264,4 @@ class LitNeRF_AutoDecoder(Harness):
 
     def configure_optimizers(self):
         params = list(self.model.parameters()) + list(self.code_library.parameters())
-        return torch.optim.Adam(params=params, lr=self.lr_init, betas=(0.9, 0.999))
+        return torch.optim.Adam(params=params, lr=self.lr_init, betas=(0.9, 0.999), fused=all(p.is_cuda for p in params))   # (fused on a GPU: LitNeRF)

@@ -200,7 +200,7 @@ def render_leg(dev, kind, H, W, steps=3):
         res = {"workload": work, "value": H * W / dt, "unit": "rays/s", "ms_per_frame": dt * 1e3, "steps": steps, "evals_per_ray": evals,
                "bottleneck_fold": bool(ops.bottleneck_fold()), "roofline": mfma_roofline(name, ms, launches, samples, mac_ex, mac_lit)}
         if kind != "config1":
-            res["hbm_kernels"] = per_ray_rooflines(ops.profile_classes())
+            res["hbm_kernels"] = pmc_traffic_ray_kernels(per_ray_rooflines(ops.profile_classes()), rays_per_launch=H * W)
         return res
     except Exception as e:  # informational leg: never take the headline down with it
         return {"error": f"{type(e).__name__}: {e}"}
@@ -244,13 +244,14 @@ def other_constructor_leg(dev, H=240, W=320, steps=3):
         return {"error": f"{type(e).__name__}: {e}"}
 
 
-def _pmc_file():
-    """The newest committed rocprofv3 PMC summary of this same command (profiles/rNN_pmc.json -- NOT rNN_train_pmc.json, the
-    counters of the training kernels), or (None, None)."""
+def _pmc_file(kind="render"):
+    """The newest committed rocprofv3 PMC summary: kind "render" = profiles/rNN_pmc.json (counters of THIS command's headline region),
+    "train" = profiles/rNN_train_pmc.json (counters of the config-5 training step, tools/pmc_wgrad.sh); or (None, None)."""
     import glob
     import re
 
-    paths = [p for p in glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")) if re.fullmatch(r"r\d+_pmc\.json", os.path.basename(p))]
+    pat = r"r\d+_pmc\.json" if kind == "render" else r"r\d+_train_pmc\.json"
+    paths = [p for p in glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")) if re.fullmatch(pat, os.path.basename(p))]
     for path in sorted(paths, reverse=True):
         try:
             return json.load(open(path)), os.path.relpath(path, ROOT)
@@ -266,29 +267,68 @@ def _pmc_bytes(pmc, needle):
     return (2.0 * k["FETCH_SIZE"]["avg_per_dispatch"] + k["WRITE_SIZE"]["avg_per_dispatch"]) * 1024.0
 
 
+COMMITTED = "committed (rocprofv3 PMC passes, separate --pmc runs; not measured in this run)"
+
+
 def pmc_traffic():
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command.  bench.py
     cannot run the profiler on itself, so this is the last committed measurement, not a live one; null when no profile is present."""
     pmc, src = _pmc_file()
     try:
         return {"traffic": _pmc_bytes(pmc, "mlp_fwd_kernel"), "traffic_unit": "B/launch", "traffic_source": src,
-                "traffic_provenance": "committed (rocprofv3 PMC passes of this same command, tools/profile_round.sh; not measured in this run)"}
+                "traffic_provenance": COMMITTED + ": " + "tools/profile_round.sh, this same command"}
     except Exception:
         return {"traffic": None, "traffic_provenance": "none (no committed PMC summary found)"}
 
 
-def pmc_traffic_ray_kernels(hbm):
-    """Same for the per-ray kernels of the headline region (`hbm_kernels`), each a frame-sized launch in the profiled command."""
+RAY_KERNEL_NEEDLES = (("coarse_fused", "composite_kernel<true, true, 65>"), ("composite", "composite_kernel<true, false, 193>"),
+                      ("sample_t", "sample_t4_kernel"), ("sample_pdf", "sample_pdf_kernel"))
+PROFILED_FRAME_RAYS = 640 * 480    # the frame of the profiled command (tools/profile_round.sh runs bench.py's default workload)
+
+
+def pmc_traffic_ray_kernels(hbm, rays_per_launch=PROFILED_FRAME_RAYS):
+    """Same for the per-ray kernels (`hbm_kernels`).  The committed counters are of frame-sized launches (307,200 rays); a leg whose
+    launches cover another number of rays (the 320x240 legs) gets the profiled bytes PER RAY times its own rays -- these kernels move
+    a fixed number of bytes per ray -- and says so."""
     pmc, src = _pmc_file()
-    for key, needle in (("coarse_fused", "composite_kernel<true, true, 65>"), ("composite", "composite_kernel<true, false, 193>"),
-                        ("sample_t", "sample_t4_kernel"), ("sample_pdf", "sample_pdf_kernel")):
+    for key, needle in RAY_KERNEL_NEEDLES:
         if key in hbm and hbm[key] is not None:
             try:
-                hbm[key].update({"traffic": _pmc_bytes(pmc, needle), "traffic_unit": "B/launch", "traffic_source": src,
-                                 "traffic_provenance": "committed (rocprofv3 PMC passes of this same command; not measured in this run)"})
+                b = _pmc_bytes(pmc, needle) * rays_per_launch / PROFILED_FRAME_RAYS
+                how = "" if rays_per_launch == PROFILED_FRAME_RAYS else f"; scaled per ray from the profiled {PROFILED_FRAME_RAYS}-ray launch to {rays_per_launch} rays"
+                hbm[key].update({"traffic": b, "traffic_unit": "B/launch", "traffic_source": src, "traffic_provenance": COMMITTED + how})
             except Exception:
                 hbm[key]["traffic_provenance"] = "none (kernel not in the committed PMC summary)"
     return hbm
+
+
+TRAIN_KERNEL_NEEDLES = {"mlp_fwd": "art_mlp_fwd_kernel<true, true", "bwd_chain": "art_bwd_chain_kernel", "wgrad": "wgrad_grouped_kernel"}
+
+
+def pmc_traffic_train(kernels, launches_per_step):
+    """HBM bytes of the training step's kernel classes from profiles/rNN_train_pmc.json (the same 4096-ray articulated step,
+    tools/pmc_wgrad.sh): per launch (average over the class's launches of a step) and per step; -> (bytes per step of the three
+    classes + the head reductions, source) or (None, None)."""
+    pmc, src = _pmc_file("train")
+    total = 0.0
+    try:
+        for key, needle in TRAIN_KERNEL_NEEDLES.items():
+            if key in kernels:
+                b = _pmc_bytes(pmc, needle)
+                kernels[key].update({"traffic": b, "traffic_unit": "B/launch (average over the class's launches)", "traffic_per_step": b * launches_per_step[key],
+                                     "traffic_source": src, "traffic_provenance": COMMITTED + ": tools/pmc_wgrad.sh, the same 4096-ray step"})
+                total += b * launches_per_step[key]
+        head = _pmc_bytes(pmc, "head_wgrad_kernel")
+        total += head * launches_per_step["wgrad"]
+        hk = next(v for name, v in pmc.items() if "head_wgrad_kernel" in name)
+        dur_s = hk["FETCH_SIZE"]["avg_duration_ns"] * 1e-9
+        head_roof = {"bound": "hbm", "kernel": "aon::head_wgrad_kernel (head / bias / first-deformation-layer reductions: plane rows x one 16-byte record per sample, fp64 sums)",
+                     "traffic": head, "traffic_unit": "B/launch", "avg_launch_us": dur_s * 1e6, "achieved": head / dur_s / 1e9, "peak": PEAK_HBM_TBS * 1e3, "unit": "GB/s",
+                     "frac": head / dur_s / 1e12 / PEAK_HBM_TBS, "traffic_source": src,
+                     "traffic_provenance": COMMITTED + ": duration and bytes both from that profile (the kernel has no timer class of its own)"}
+        return total, src, head_roof
+    except Exception:
+        return None, None, None
 
 
 def train_leg(dev, rank, world, distributed, steps=6, n_rays=4096):
@@ -309,7 +349,7 @@ def train_leg(dev, rank, world, distributed, steps=6, n_rays=4096):
         lib = CodeLibraryArticulated(types.SimpleNamespace(N_max_objs=1, N_obj_code_length=128)).to(dev)
         lib.load_state_dict(syn.make_code_library_state(seed=0, n_max_objs=1))
         both = torch.nn.ModuleList([model, lib])
-        opt = torch.optim.Adam(both.parameters(), lr=5e-4, betas=(0.9, 0.999))
+        opt = torch.optim.Adam(both.parameters(), lr=5e-4, betas=(0.9, 0.999), fused=True)   # the harness's optimizer (LitNeRF_AutoDecoder.configure_optimizers): Adam, fused form
         batch = {"instance_id": torch.tensor([0], device=dev), "articulation_id": torch.tensor([3], device=dev)}
         H, W = 480, 640
         ro, vd = ops.raygen(syn.look_at_pose(4.0, 30.0 + 45.0 * rank, 30.0), H, W, syn.focal_from_fovy(H), device=dev)
@@ -390,7 +430,8 @@ def train_leg(dev, rank, world, distributed, steps=6, n_rays=4096):
                 r["ms_per_step"] = ms / steps
                 kernels[key] = r
         other_ms = sum(classes[k][0] for k in ("composite", "sample_pdf", "composite_pdf", "composite_bwd", "sample_t") if k in classes) / steps
-        res = {"workload": f"articulated NeRF_AE_Art training step, {n_rays} rays/GPU, fwd+bwd" + (" + RCCL gradient all-reduce (6.4 MB, one bucket)" if world > 1 else "") + " + Adam",
+        step_traffic, traffic_src, head_bytes = pmc_traffic_train(kernels, {k: v["launches"] / steps for k, v in kernels.items()})
+        res = {"workload": f"articulated NeRF_AE_Art training step, {n_rays} rays/GPU, fwd+bwd" + (" + RCCL gradient all-reduce (6.4 MB, one bucket)" if world > 1 else "") + " + Adam (torch.optim.Adam, fused=True)",
                "ms_per_step": dt * 1e3, "rays_per_s": world * n_rays / dt, "steps": steps, "loss": loss, "bottleneck_fold": fold,
                "allreduce_ms": {"min": ar_all.min().item(), "max": ar_all.max().item(), "per_rank": ar_all.tolist(),
                                 "note": "parallel.allreduce_gradients per step, HIP events on the launch stream; 0 at world size 1 (no-op); "
@@ -408,7 +449,9 @@ def train_leg(dev, rank, world, distributed, steps=6, n_rays=4096):
                             "kernels_measured_on": "a second pass of the same schedule with the library's per-kernel-class HIP-event timers on "
                                                    f"({dt_serial * 1e3:.2f} ms per step); forward = 3 merged launches per step, chain = 1 launch "
                                                    "for both levels, wgrad = 1 grouped launch per level",
-                            "traffic": None}}
+                            "traffic": step_traffic, "traffic_unit": "B/step (forward + chain + weight gradients + head reductions)", "traffic_source": traffic_src,
+                            "traffic_provenance": (COMMITTED + ": tools/pmc_wgrad.sh, the same 4096-ray step") if step_traffic else "none (no committed training PMC summary found)",
+                            "hbm_kernels": {"head_reductions": head_bytes}}}
         return res
     except Exception as e:  # informational leg: never take the headline down with it
         return {"error": f"{type(e).__name__}: {e}"}

@@ -11,8 +11,12 @@ inverse CDF (composite_kernel<true, true>), composite_kernel<true, false> is the
 import sqlite3
 import sys
 
+import os
+
 PEAK_HBM, PEAK_MFMA = 8.0e12, 157.3e12
-FLOP_PER_EVAL = 1_186_816
+FLOP_LITERAL = 1_186_816
+# round 5: bottleneck_layer folded into views_linear[0] (default) -- the kernel EXECUTES 65,536 MACs per evaluation fewer; both fractions are printed
+FLOP_PER_EVAL = FLOP_LITERAL - (0 if os.environ.get("AON_BOTTLENECK_FOLD", "") == "0" else 2 * 65_536)
 B_COMP = {65: 65 * 20 + 12 + 20 + 65 * 4, 193: 193 * 20 + 12 + 20}
 B_PDF = 65 * 4 + 63 * 4 + 193 * 4
 B_SAR = 65 * 4          # sample_along_rays: writes 65 t per ray (reads nothing per ray when deterministic)
@@ -61,7 +65,8 @@ def main():
             bound = items[0][2]
             if bound == "mfma":
                 rate = work / (avg * 1e-9)
-                print(f"{short + ' ' + tag:<58} {n:>8} {avg / 1e3:>10.2f} {work / 1e12:>12.3f} TFLOP {rate / 1e12:>9.1f} TF/s {bound:>6} {rate / PEAK_MFMA:>7.3f}")
+                print(f"{short + ' ' + tag:<58} {n:>8} {avg / 1e3:>10.2f} {work / 1e12:>12.3f} TFLOP {rate / 1e12:>9.1f} TF/s {bound:>6} {rate / PEAK_MFMA:>7.3f}"
+                      f"   (executed; reference-literal {rate / PEAK_MFMA * FLOP_LITERAL / FLOP_PER_EVAL:.3f})")
             elif bound == "hbm":
                 rate = work / (avg * 1e-9)
                 print(f"{short + ' ' + tag:<58} {n:>8} {avg / 1e3:>10.2f} {work / 1e6:>13.1f} MB {rate / 1e12:>9.2f} TB/s {bound:>6} {rate / PEAK_HBM:>7.3f}")

@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--no-fwd-merge", action="store_true", help="training forward without the merged coarse(A) | fine(A)+coarse(B) | fine(B) launches (round 4 default)")
     ap.add_argument("--no-bwd-merge", action="store_true", help="one backward-chain launch per level (round 3) instead of the merged two-segment launch")
     ap.add_argument("--articulated", action="store_true", help="NeRF_AE_Art + CodeLibraryArticulated (BASELINE config 5 per GPU)")
+    ap.add_argument("--foreach-adam", action="store_true", help="torch.optim.Adam's default foreach form instead of fused=True (the harness's choice on a GPU since round 5)")
     args = ap.parse_args()
     import aon_amd.synthetic as syn
     from aon_amd import ops
@@ -49,11 +50,11 @@ def main():
         lib = CodeLibraryArticulated(types.SimpleNamespace(N_max_objs=1, N_obj_code_length=128)).to(dev)
         lib.load_state_dict(syn.make_code_library_state(seed=0, n_max_objs=1))
         batch = {"instance_id": torch.tensor([0], device=dev), "articulation_id": torch.tensor([3], device=dev)}
-        opt = torch.optim.Adam(list(model.parameters()) + list(lib.parameters()), lr=5e-4, betas=(0.9, 0.999))
+        opt = torch.optim.Adam(list(model.parameters()) + list(lib.parameters()), lr=5e-4, betas=(0.9, 0.999), fused=not args.foreach_adam)
     else:
         model = NeRF().to(dev)
         model.load_state_dict(syn.make_nerf_state_dict(seed=0, density_scale=30.0))
-        opt = torch.optim.Adam(model.parameters(), lr=5e-4, betas=(0.9, 0.999))
+        opt = torch.optim.Adam(model.parameters(), lr=5e-4, betas=(0.9, 0.999), fused=not args.foreach_adam)
     H, W = 480, 640
     ro, vd = ops.raygen(syn.look_at_pose(), H, W, syn.focal_from_fovy(H), device=dev)
     g = torch.Generator(device=dev).manual_seed(0)
@@ -81,10 +82,11 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
+    enqueue_ms = (time.perf_counter() - t0) / args.steps * 1e3   # host time to ENQUEUE a step (the device runs behind): must stay well below ms_per_step
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.steps
     flop = args.rays * 258 * (1_589_760 if args.articulated else 1_186_816) * 3  # fwd + 2x bwd, reference-literal
-    print(json.dumps({"model": "articulated" if args.articulated else "vanilla", "rays_per_step": args.rays, "ms_per_step": dt * 1e3, "rays_per_s": args.rays / dt,
+    print(json.dumps({"model": "articulated" if args.articulated else "vanilla", "rays_per_step": args.rays, "ms_per_step": dt * 1e3, "host_enqueue_ms_per_step": enqueue_ms, "fused_adam": not args.foreach_adam, "rays_per_s": args.rays / dt,
                       "train_tflops_3x_fwd": flop / dt / 1e12, "loss": loss.item()}))
 
 
