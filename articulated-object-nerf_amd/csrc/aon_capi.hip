@@ -105,6 +105,10 @@ int check(hipError_t e, const char* where) {
 
 constexpr int kSc = 65, kSf = 193;
 
+// round 5: the articulated calls take a packed stream AND a per-call block; both carry a form (bottleneck folded / literal, aon_fold.h)
+const char* kFormsMsg = "packed stream and per-call block were made in different forms (aon_set_bottleneck_fold changed between aon_pack_art_mlp* and aon_art_prepare*)";
+bool forms_differ(const void* a, const void* b) { return a && b && aon::stream_form(a) != aon::stream_form(b); }
+
 // Optional live timing of the path's kernels with HIP events on the LAUNCH stream (torch.cuda.Event would only see torch's
 // current stream), by kernel class; bench.py turns the totals into roofline figures.  Off unless aon_profile_begin() was
 // called: one mutex-guarded branch per launch otherwise.
@@ -545,6 +549,7 @@ int aon_art_mlp_fwd_train(const void* packed, const void* small, const float* ra
   if (n_rays == 0) return AON_OK;
   if (!packed || !small || !rays_o || !rays_d || !viewdirs || !t_vals || !raw || !planes || !masks)
     return fail(AON_E_INVALID, "aon_art_mlp_fwd_train: null pointer");
+  if (forms_differ(packed, small)) return fail(AON_E_INVALID, kFormsMsg);
   if (reinterpret_cast<uintptr_t>(masks) & 15) return fail(AON_E_INVALID, "aon_art_mlp_fwd_train: masks must be 16-byte aligned");
   MlpTimer timer((hipStream_t)stream, n_rays * S);
   return check(aon::launch_art_mlp_fwd_train(static_cast<const char*>(packed), static_cast<const float*>(small), rays_o, rays_d, viewdirs,
@@ -556,6 +561,7 @@ int aon_art_bwd_chain(const void* packed_bwd, const void* small, const float* d_
   if (Np < 0 || (Np & 127)) return fail(AON_E_INVALID, "aon_art_bwd_chain: Np must be a multiple of 128");
   if (Np == 0) return AON_OK;
   if (!packed_bwd || !small || !d_raw || !masks || !planes || !dplanes || !dxp) return fail(AON_E_INVALID, "aon_art_bwd_chain: null pointer");
+  if (forms_differ(packed_bwd, small)) return fail(AON_E_INVALID, kFormsMsg);
   KTimer timer(kBwdChain, (hipStream_t)stream, Np);
   return check(aon::launch_art_bwd_chain(static_cast<const char*>(packed_bwd), static_cast<const float*>(small), d_raw, masks, planes,
                                          dplanes, dxp, Np, (hipStream_t)stream), "aon_art_bwd_chain");
@@ -671,6 +677,7 @@ static int render_impl(const char* who, const NetRef& coarse, const NetRef& fine
   if (num_levels == 2 && (!fine.packed || !rgb_f || !acc_f || !depth_f || !u))
     return fail(AON_E_INVALID, "render: null fine-level pointer");
   if (coarse.articulated && (!coarse.small || (num_levels == 2 && !fine.small))) return fail(AON_E_INVALID, "render: null latent block");
+  if (coarse.articulated && (forms_differ(coarse.packed, coarse.small) || (num_levels == 2 && forms_differ(fine.packed, fine.small)))) return fail(AON_E_INVALID, kFormsMsg);
   if (num_levels == 2 && u_stride != 0 && u_stride < g.nf) return fail(AON_E_INVALID, "render: bad u_stride");
   if (reinterpret_cast<uintptr_t>(workspace) & 255) return fail(AON_E_INVALID, "render: workspace must be 256-byte aligned");
   const bool art = coarse.articulated;
@@ -971,6 +978,9 @@ int train_fwd_impl(const char* who, bool art, const TrainNet* nets, const float*
   const bool fuse = num_levels == 2 && g.default_sizes && g_fuse_coarse.load(std::memory_order_relaxed) != 0;
   for (int l = 0; l < num_levels; ++l)
     if (!nets[l].packed_fwd || (art && !nets[l].small) || !rgb[l] || !acc[l] || !depth[l]) return fail(AON_E_INVALID, "train forward: null level pointer");
+  for (int l = 0; l < num_levels; ++l)
+    if ((art && forms_differ(nets[l].packed_fwd, nets[l].small)) || forms_differ(nets[l].packed_fwd, nets[0].packed_fwd))
+      return fail(AON_E_INVALID, "train forward: the levels' streams / per-call blocks were made in different forms (aon_set_bottleneck_fold changed in between)");
   const int64_t rows = art ? aon::kAPlRows : aon::kPlRows;
 
   // Both levels of the ray range [r0, r0 + nk) on stream `st`.  r0 is a multiple of 128, so the range's samples start on a pass
@@ -1431,6 +1441,7 @@ int aon_art_mlp_fwd(const void* packed, const void* small, const float* rays_o, 
   if (n_rays < 0 || S < 1) return fail(AON_E_INVALID, "aon_art_mlp_fwd: bad size");
   if (n_rays == 0) return AON_OK;
   if (!packed || !small || !rays_o || !rays_d || !viewdirs || !t_vals || !raw) return fail(AON_E_INVALID, "aon_art_mlp_fwd: null pointer");
+  if (forms_differ(packed, small)) return fail(AON_E_INVALID, kFormsMsg);
   MlpTimer timer((hipStream_t)stream, n_rays * S);
   return check(aon::launch_art_mlp_fwd(static_cast<const char*>(packed), static_cast<const float*>(small), rays_o, rays_d, viewdirs,
                                        t_vals, n_rays, S, raw, (hipStream_t)stream), "aon_art_mlp_fwd");
@@ -1441,6 +1452,7 @@ int aon_art_mlp_fwd_pos(const void* packed, const void* small, const float* pos,
   if (n_rays < 0 || S < 1) return fail(AON_E_INVALID, "aon_art_mlp_fwd_pos: bad size");
   if (n_rays == 0) return AON_OK;
   if (!packed || !small || !pos || !viewdirs_enc || !raw) return fail(AON_E_INVALID, "aon_art_mlp_fwd_pos: null pointer");
+  if (forms_differ(packed, small)) return fail(AON_E_INVALID, kFormsMsg);
   return check(aon::launch_art_mlp_fwd_pos(static_cast<const char*>(packed), static_cast<const float*>(small), pos, viewdirs_enc,
                                            n_rays, S, raw, (hipStream_t)stream), "aon_art_mlp_fwd_pos");
 }

@@ -220,6 +220,13 @@ __device__ __forceinline__ void chunk_mma(Pipe& p, const f32x16& in, f32x16 (&ou
 
 template <int NT_OUT>
 __device__ __forceinline__ void init_bias(f32x16 (&acc)[NT_OUT], const float* sm_bias, int h) {
+#ifdef AON_EXP_NOBIAS    // timing experiment only (WRONG results): what the per-layer bias reads cost
+#pragma unroll
+  for (int tp = 0; tp < NT_OUT; ++tp)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[tp][r] = 0.f;
+  return;
+#endif
 #pragma unroll
   for (int tp = 0; tp < NT_OUT; ++tp) {
 #pragma unroll
@@ -250,6 +257,9 @@ __device__ __forceinline__ float relu1(float x) {
 // "a" constraints, which frees ~75 arch VGPRs -- was measured in round 1: 0.875 of peak against 0.908 for this form.)
 template <int NT>
 __device__ __forceinline__ void relu_tiles(f32x16 (&x)[NT]) {
+#ifdef AON_EXP_NORELU    // timing experiment only (WRONG results): what the per-layer ReLU bursts cost
+  return;
+#endif
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
 #pragma unroll

@@ -250,6 +250,13 @@ from . import helper
 from ..interface import Harness
 
 
+def _fused_adam(params) -> bool:
+    """torch.optim.Adam's fused form when every parameter lives on a GPU (AON_FUSED_ADAM=0 in the environment: the foreach form, A/B)."""
+    import os
+
+    return os.environ.get("AON_FUSED_ADAM", "1") != "0" and all(p.is_cuda for p in params)
+
+
 class LitNeRF(Harness):
     """``models/vanilla_nerf/model.py:202-419`` minus Lightning: same method names, batch contracts and return
     structures for ``training_step`` (:256-282), ``render_rays`` (:295-321, fine level only, chunked by ``hparams.chunk``,
@@ -315,4 +322,4 @@ class LitNeRF(Harness):
         # model.py:386-389.  On a GPU the optimizer runs in its fused form -- one kernel for all 48 parameter tensors instead of the
         # foreach form's dozen multi-tensor launches: the same update rule, 1 ms of a 32 ms training step (round 5, tools/train_bench.py)
         params = list(self.parameters())
-        return torch.optim.Adam(params=params, lr=self.lr_init, betas=(0.9, 0.999), fused=all(p.is_cuda for p in params))
+        return torch.optim.Adam(params=params, lr=self.lr_init, betas=(0.9, 0.999), fused=_fused_adam(params))

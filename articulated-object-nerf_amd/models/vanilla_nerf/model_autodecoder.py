@@ -182,6 +182,7 @@ from collections import defaultdict  # noqa: E402
 from . import helper  # noqa: E402
 from ..code_library import CodeLibraryArticulated  # noqa: E402
 from ..interface import Harness  # noqa: E402
+from .model import _fused_adam  # noqa: E402
 
 _SCALAR_KEYS = ("deg", "instance_id", "articulation_id")
 
@@ -264,4 +265,4 @@ class LitNeRF_AutoDecoder(Harness):
 
     def configure_optimizers(self):
         params = list(self.model.parameters()) + list(self.code_library.parameters())
-        return torch.optim.Adam(params=params, lr=self.lr_init, betas=(0.9, 0.999), fused=all(p.is_cuda for p in params))   # (fused on a GPU: LitNeRF)
+        return torch.optim.Adam(params=params, lr=self.lr_init, betas=(0.9, 0.999), fused=_fused_adam(params))   # (fused on a GPU: LitNeRF)

@@ -91,7 +91,9 @@ int aon_pack_vanilla_mlp(const float* const* params_host, void* packed, void* st
  * the 24 / 40 parameter gradients keep the reference's shapes and meaning.  Buffer sizes do not depend on the switch.
  * The form is a property of each packed buffer / per-call block, fixed when it was made and remembered per pointer: flipping the
  * switch later does not change how an existing buffer is run, and a call that is handed buffers of two forms returns AON_E_INVALID
- * (HIP "invalid value").  A buffer this process did not pack (a device-side copy of one) is taken to have the current default form.
+ * (HIP "invalid value").  A buffer this process did not pack (a device-side copy of one) is taken to have the current default form;
+ * copying a packed buffer onto an address that was itself packed earlier in the OTHER form is not supported (the address keeps the
+ * form of its last pack call): pack into the destination instead.
  * aon_set_bottleneck_fold(0): the literal two-layer form (rounds 1-4), for A/B measurements and bit-level comparisons. */
 int aon_set_bottleneck_fold(int on);
 int aon_get_bottleneck_fold(void);
