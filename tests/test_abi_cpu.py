@@ -241,3 +241,26 @@ def test_constructor_option_entry_points_validate_without_gpu():
     assert lib.aon_grender_fwd(C.byref(g), None, None, None, None, None, 8, 2.0, 6.0, 1, 2, None, None, 0, None, None, None, None, None, None,
                                None, 0, None, None) == -1
     assert b"input_ch" in lib.aon_last_error()
+
+
+def test_bottleneck_fold_switch_without_gpu():
+    """Round 5: the form switch of the pack calls (include/aon_hip.h, aon_set_bottleneck_fold) is host state: default folded, and a
+    pointer this process never packed reports the current default form."""
+    import ctypes as C
+
+    from aon_amd import _lib
+
+    lib = _lib.lib
+    before = lib.aon_get_bottleneck_fold()
+    try:
+        lib.aon_set_bottleneck_fold(1)
+        assert lib.aon_get_bottleneck_fold() == 1 and lib.aon_stream_is_folded(C.c_void_p(0x1000)) == 1
+        lib.aon_set_bottleneck_fold(0)
+        assert lib.aon_get_bottleneck_fold() == 0 and lib.aon_stream_is_folded(C.c_void_p(0x1000)) == 0
+        # either form fits the buffers whose sizes the library reports (the sizes do not depend on the switch)
+        sizes = (lib.aon_mlp_packed_bytes(), lib.aon_bwd_packed_bytes(), lib.aon_art_packed_bytes(), lib.aon_art_bwd_packed_bytes())
+        lib.aon_set_bottleneck_fold(1)
+        assert sizes == (lib.aon_mlp_packed_bytes(), lib.aon_bwd_packed_bytes(), lib.aon_art_packed_bytes(), lib.aon_art_bwd_packed_bytes())
+        assert lib.aon_bwd_packed_bytes() >= 60 * 32768 + (128 * 256 + 256 * 256 + 256 + 128 * 256 + 128) * 4   # folded stream + raw copies + W', b'
+    finally:
+        lib.aon_set_bottleneck_fold(before)
