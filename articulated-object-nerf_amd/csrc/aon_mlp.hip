@@ -180,7 +180,7 @@ __global__ void __launch_bounds__(256) mlp_fwd_kernel(MlpArgs args) {
     // ---- encode: E[0..1] = 63-wide positional encoding, V = 27-wide view encoding, accumulator layout ----
     f32x16 E[2], V;
     float x[3] = {0.f, 0.f, 0.f}, vd[3] = {0.f, 0.f, 0.f};
-#ifdef AON_EXP_NOENC     // timing experiment only (WRONG results): no sample fetch, no encoding (tools/exp_mlp.sh, profiles/r05_infer_attribution.txt)
+#ifdef AON_EXP_NOENC     // timing experiment only (WRONG results): no sample fetch, no encoding (tools/exp_tu.sh, profiles/r05_infer_attribution.txt)
     if constexpr (ENC_IN_KERNEL && !TRAIN) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) { E[0][r] = 0.25f; E[1][r] = 0.5f; V[r] = 0.125f; }

@@ -107,6 +107,16 @@ struct ArtBwdArgs {
   int npass_total;        // seg[1].npass == 0: a one-segment launch
 };
 
+// timing experiments only (WRONG results): the chain without the plane stores of its 128-wide layers (view branch, deformation MLP:
+// tiny chunks, a barrier every 128 MFMAs) or of its 256-wide layers -- which stores cost what (profiles/r05_chain_store_attribution.txt)
+#if defined(AON_EXP_NOSTORE4)
+#define AON_EXP_STORE_OF(NT) ((NT) != 4)
+#elif defined(AON_EXP_NOSTORE8)
+#define AON_EXP_STORE_OF(NT) ((NT) != 8)
+#else
+#define AON_EXP_STORE_OF(NT) true
+#endif
+
 template <int NT>
 __device__ __forceinline__ void zero_tiles_a(f32x16 (&x)[NT]) {
 #pragma unroll
@@ -191,7 +201,7 @@ __global__ void __launch_bounds__(256) art_bwd_chain_kernel(ArtBwdArgs args) {
 #define AON_ABWD_LAYER(NT_IN, NT_OUT, IN, OUT, CB, ROW, NEXT_SLOT)                                                   \
     if (NEXT_SLOT >= 0) mk_next = load_mask(NEXT_SLOT);                                                               \
     apply_mask_tile(IN[0], mk, 0);                                                                                   \
-    dense_layer<N, CB, NT_IN, NT_OUT, BwdSideOf<NT_IN, true>, true>(p, IN, OUT, BwdSideOf<NT_IN, true>{IN, ROW, io, mk, NEXT_SLOT >= 0 ? &mk_next : nullptr});   /* OUT starts from zero */ \
+    dense_layer<N, CB, NT_IN, NT_OUT, BwdSideOf<NT_IN, true, AON_EXP_STORE_OF(NT_IN)>, true>(p, IN, OUT, BwdSideOf<NT_IN, true, AON_EXP_STORE_OF(NT_IN)>{IN, ROW, io, mk, NEXT_SLOT >= 0 ? &mk_next : nullptr});   /* OUT starts from zero */ \
     mk = mk_next;
     AON_ABWD_LAYER(4, 4, Z1, Z0, kABwV3 + 0, aplane_v(3), 14)
     AON_ABWD_LAYER(4, 4, Z0, Z1, kABwV3 + 4, aplane_v(2), 13)
@@ -240,8 +250,14 @@ __global__ void __launch_bounds__(256) art_bwd_chain_kernel(ArtBwdArgs args) {
     // The partial d enc (32 accumulator registers) would have to stay live across layers 5..1 on top of the two 128-register
     // activation sets; it is parked in the (otherwise unused) pos-enc rows of the gradient planes instead -- 128 B per lane out
     // and back per pass, against 13.8 KB of plane traffic -- rather than left to the register allocator's scratch spills.
+#ifndef AON_EXP_NOPARK      // timing experiment only (WRONG results): d enc not parked in the planes
     store_plane(dE, io, kAPlE);
+#endif
+#ifdef AON_EXP_NOSTORE_L5   // timing experiment only (WRONG results): dZ5 never stored
+    dense_layer<N, kL5 + 0, 8, 8, NoSideOf, true>(p, Y, X);
+#else
     dense_layer<N, kL5 + 0, 8, 8, StoreSideOf<8>, true>(p, Y, X, StoreSideOf<8>{Y, aplane_h(5), io});   // X = dH4 (from zero); stores dZ5
+#endif
     AON_ABWD_LAYER(8, 8, X, Y, kL5 + 8, aplane_h(4), 7)
     AON_ABWD_LAYER(8, 8, Y, X, kL5 + 16, aplane_h(3), 6)
     AON_ABWD_LAYER(8, 8, X, Y, kL5 + 24, aplane_h(2), 5)
@@ -313,7 +329,9 @@ __global__ void __launch_bounds__(256) art_bwd_chain_kernel(ArtBwdArgs args) {
 #undef AON_ABWD_LAYER
     // dZ of deformation layer 0: its input is (pos, latents) -- no data gradient continues, no consuming chunk: 64 values here
     apply_mask_bits(H0, mk);
+#ifndef AON_EXP_NOFINAL     // timing experiment only (WRONG results): the pass's last burst (dZ of deformation layer 0) not stored
     store_plane(H0, io, aplane_d(0));
+#endif
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }

@@ -1,7 +1,7 @@
 """Quick A/B of the headline region (BASELINE config 2: vanilla 640x480, 65 + 193 evaluations per ray) without bench.py's other legs:
     [AON_HIP_LIB=...] python tools/headline_bench.py [--steps 3] [--literal] [--tag name]
 One JSON line: rays/s, ms per frame, the fused MLP kernel's HIP-event time and its executed / reference-literal fraction of the fp32
-matrix peak.  AON_HIP_LIB selects an experiment build of the library (tools/exp_mlp.sh)."""
+matrix peak.  AON_HIP_LIB selects an experiment build of the library (tools/exp_tu.sh)."""
 import argparse
 import json
 import os

@@ -15,9 +15,13 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-VAN_MAC = 593_408                 # reference-literal MACs / sample, vanilla
+import os as _os
+
+_FOLD = 0 if _os.environ.get("AON_BOTTLENECK_FOLD", "") == "0" else 65_536   # round 5: bottleneck_layer folded into views_linear[0] (default)
+VAN_MAC_LIT = 593_408             # reference-literal MACs / sample, vanilla
+VAN_MAC = VAN_MAC_LIT - _FOLD     # executed
 ART_MAC = 794_880                 # articulated, latent columns included
-ART_MAC_EXEC = 794_880 - 102_400  # latent columns folded into biases: 128*(128+32) + 2*256*128 + 128*128
+ART_MAC_EXEC = 794_880 - 102_400 - _FOLD  # latent columns folded into biases: 128*(128+32) + 2*256*128 + 128*128; bottleneck fold
 
 
 def timeit(fn, reps):
@@ -159,21 +163,21 @@ def main():
         t, _ = ops.sample_along_rays(o, d, S - 1, 2.0, 6.0, want_coords=False)
         t = t.contiguous()
         if want("fwd"):
-            emit("mlp_fwd", S, timeit(lambda: ops.mlp_fwd(pv, o, d, d, t), args.reps), VAN_MAC, VAN_MAC)
+            emit("mlp_fwd", S, timeit(lambda: ops.mlp_fwd(pv, o, d, d, t), args.reps), VAN_MAC, VAN_MAC_LIT)
         if want("art_fwd"):
             emit("art_mlp_fwd", S, timeit(lambda: ops.art_mlp_fwd(pa, small, o, d, d, t), args.reps), ART_MAC_EXEC, ART_MAC)
         if want("fwd_train") or want("bwd_chain") or want("wgrad"):
             raw, planes, masks = ops.mlp_fwd_train(pv, o, d, d, t)
             if want("fwd_train"):
-                emit("mlp_fwd_train", S, timeit(lambda: ops.mlp_fwd_train(pv, o, d, d, t), args.reps), VAN_MAC, VAN_MAC,
+                emit("mlp_fwd_train", S, timeit(lambda: ops.mlp_fwd_train(pv, o, d, d, t), args.reps), VAN_MAC, VAN_MAC_LIT,
                      {"plane_GB": round(planes.numel() * 4 / 1e9, 3)})
             d_raw = torch.randn(ops.plane_samples(planes), 4, device=dev) * 1e-3
             if want("bwd_chain"):
                 bw_mac = VAN_MAC - 256 * 63 * 2 - 128 * 27 - 256 - 3 * 128   # no data gradient into the encodings / heads on the VALU
-                emit("mlp_bwd_chain", S, timeit(lambda: ops.mlp_bwd_chain(pvb, pv, d_raw, masks, planes.shape), args.reps), bw_mac, VAN_MAC)
+                emit("mlp_bwd_chain", S, timeit(lambda: ops.mlp_bwd_chain(pvb, pv, d_raw, masks, planes.shape), args.reps), bw_mac, VAN_MAC_LIT)
             if want("wgrad"):
                 dpl = ops.mlp_bwd_chain(pvb, pv, d_raw, masks, planes.shape)
-                emit("vanilla_wgrad(all layers)", S, timeit(lambda: ops.vanilla_wgrad(planes, dpl, d_raw, pvb), args.reps), VAN_MAC, VAN_MAC)
+                emit("vanilla_wgrad(all layers)", S, timeit(lambda: ops.vanilla_wgrad(planes, dpl, d_raw, pvb), args.reps), VAN_MAC, VAN_MAC_LIT)
                 del dpl
             del raw, planes, masks
         if want("art_fwd_train") or want("art_bwd_chain") or want("art_wgrad"):
