@@ -683,9 +683,12 @@ def mlp_bwd_chain(packed_bwd, packed_fwd, d_raw, masks, plane_shape):
 _WG_WS: dict = {}
 
 
-def vanilla_wgrad(planes, dplanes, d_raw, packed_bwd=None):
-    """-> dict name -> gradient (the reference's NeRFMLP parameter names / shapes).  ``packed_bwd``: the transposed stream the chain
-    of these planes ran with (its form -- bottleneck folded or literal -- is the planes'; None = literal)."""
+def vanilla_wgrad(planes, dplanes, d_raw, packed_bwd):
+    """-> dict name -> gradient (the reference's NeRFMLP parameter names / shapes).  ``packed_bwd`` (required): the transposed stream the
+    chain of these planes ran with -- its form (bottleneck folded or literal) is the planes' form, and the folded form's buffer carries the
+    raw weights the un-folding reads.  (No default: with the fold on by default, "None = literal planes" would silently mis-read folded ones.)"""
+    if packed_bwd is None:
+        raise ValueError("vanilla_wgrad: pass the transposed stream (pack_vanilla_mlp_bwd) the backward chain of these planes ran with")
     dev = planes.device
     key = str(dev)
     need = int(lib.aon_wgrad_workspace_bytes())
@@ -735,8 +738,10 @@ def art_bwd_chain(packed_bwd, small, d_raw, masks, planes):
     return dplanes, dxp
 
 
-def art_wgrad(planes, dplanes, d_raw, dxp, params: dict, latents: dict, degrees=(0, 10, 4), packed_bwd=None):
-    """-> (dict name -> parameter gradient, dict latent key -> gradient (flat)).  ``packed_bwd``: as vanilla_wgrad."""
+def art_wgrad(planes, dplanes, d_raw, dxp, params: dict, latents: dict, degrees=(0, 10, 4), *, packed_bwd):
+    """-> (dict name -> parameter gradient, dict latent key -> gradient (flat)).  ``packed_bwd`` (required keyword): as vanilla_wgrad."""
+    if packed_bwd is None:
+        raise ValueError("art_wgrad: pass packed_bwd= the transposed stream (pack_art_mlp_bwd) the backward chain of these planes ran with")
     dev = planes.device
     key = str(dev)
     need = int(lib.aon_wgrad_workspace_bytes())
