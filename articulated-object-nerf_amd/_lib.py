@@ -76,6 +76,7 @@ _SIGS = {
     "aon_set_bottleneck_fold": (_i, [_i]),
     "aon_get_bottleneck_fold": (_i, []),
     "aon_stream_is_folded": (_i, [_p]),
+    "aon_set_bwd_early_heads": (_i, [_i]),
     "aon_set_bwd_overlap": (_i, [_i]),
     "aon_set_fwd_overlap": (_i, [_i]),
     "aon_set_fwd_merge": (_i, [_i]),

@@ -49,7 +49,7 @@ hipError_t launch_wgrad_kind_bench(int kind, int nlayers, const float* planes, c
                                    float* out_scratch, hipStream_t stream);
 struct WgAux { hipStream_t stream; hipEvent_t fork, join; };   // aon_wgrad.h: optional side stream of a level's head reductions
 hipError_t launch_vanilla_wgrad(const float* planes, const float* dplanes, const float* d_raw, int64_t Np, float* const* grads,
-                                float* ws, hipStream_t stream, const WgAux* aux, const void* packed_bwd);
+                                float* ws, hipStream_t stream, const WgAux* aux, const void* packed_bwd, int phase = 0);
 hipError_t launch_art_mlp_fwd_train(const char* packed, const float* small, const float* rays_o, const float* rays_d,
                                     const float* viewdirs, const float* t_vals, int64_t n_rays, int S, float* raw, float* planes,
                                     void* masks, hipStream_t stream, int64_t np_total = 0);
@@ -63,7 +63,7 @@ hipError_t launch_art_bwd_chain(const char* packed_bwd, const float* small, cons
 hipError_t launch_art_wgrad(const float* planes, const float* dplanes, const float* d_raw, const float* dxp, int64_t Np,
                             const float* const* params, const float* shape, const float* app, const float* art,
                             float* const* grads, float* g_shape, float* g_app, float* g_art, float* ws, hipStream_t stream, const WgAux* aux, int pos_levels, int view_levels,
-                            const void* packed_bwd);
+                            const void* packed_bwd, int phase = 0);
 hipError_t launch_raygen(const float* c2w, int H, int W, float focal, const float* directions, int64_t pix_begin,
                          int64_t pix_end, float* rays_o, float* viewdirs, float* rays_d, hipStream_t stream);
 hipError_t launch_ray_directions(int H, int W, float focal, float* out, hipStream_t stream);
@@ -937,6 +937,11 @@ std::atomic<int> g_bwd_overlap{1};
 std::atomic<int> g_fwd_overlap{2};
 std::atomic<int> g_fwd_merge{1};
 std::atomic<int> g_bwd_merge{1};   // the backward chains of the two levels as ONE persistent launch of two segments (round 4)
+// Round 5: the head / bias reductions that need nothing from the chain (density head on H7, rgb head, sums of d_raw: 60 % of the head
+// kernel's bytes) run on a library side stream BESIDE the merged chain launch, whose last round of workgroups is a quarter full
+// (8,256 passes on 256 CUs): they fill compute units that would idle for one pass.  Phases kWgEarly / kWgRest of the levels' weight-gradient calls.
+std::atomic<int> g_bwd_early_heads{1};
+constexpr int kWgAll = 0, kWgEarly = 1, kWgRest = 2;   // aon_wgrad.h
 
 // The merged training forward (round 4) runs the two levels of two ray ranges A = [0, kA), B = [kA, n) as THREE persistent launches
 //   coarse(A)  |  fine(A) + coarse(B)  |  fine(B)
@@ -1131,6 +1136,11 @@ int aon_set_bwd_overlap(int on) {
   return AON_OK;
 }
 
+int aon_set_bwd_early_heads(int on) {
+  g_bwd_early_heads.store(on ? 1 : 0, std::memory_order_relaxed);
+  return AON_OK;
+}
+
 int aon_set_bwd_merge(int on) {
   g_bwd_merge.store(on ? 1 : 0, std::memory_order_relaxed);
   return AON_OK;
@@ -1254,20 +1264,38 @@ int aon_render_bwd_ex(const void* packed_bwd_coarse, const void* packed_fwd_coar
   // Round 4: the two levels' chains are independent -> ONE persistent launch of two segments on the caller's stream (33 rounds of
   // workgroups instead of 9 + 25 at 4096 x (65 + 193) samples), then the weight gradients of the two levels on the two streams.
   const bool merged = num_levels == 2 && g_bwd_merge.load(std::memory_order_relaxed) != 0;
+  const int overlap_mode = g_bwd_overlap.load(std::memory_order_relaxed);   // 0: none; 1: round-3 level streams when not merged; 2: + head reductions on side streams when merged
+  const bool early_heads = merged && g_bwd_early_heads.load(std::memory_order_relaxed) != 0;
+  // fork: with two levels each runs on its own library stream, ordered after everything already enqueued on the caller's
+  // (merged: no LEVEL streams -- chain and weight gradients follow each other on the caller's stream; with equal-cost workgroups filling the
+  // chip in every launch the dispatcher's sharing of compute units between streams costs more than the tails it used to fill:
+  // profiles/r04_backward_schedules.txt.  The one tail that is left, the chain's last quarter-full round, takes the early head reductions.)
+  LevelFork fork(num_levels == 2 && (merged ? (overlap_mode == 2 || early_heads) : overlap_mode != 0), caller, "aon_render_bwd", merged);
+  if (fork.rc()) return fork.rc();
+  const aon::WgAux* side = early_heads ? fork.aux(0) : nullptr;
   if (merged) {
     for (int l = 0; l < 2; ++l)
       if (int rc = composite_bwd(l, caller)) return rc;
-    const aon::ChainSeg segs[2] = {chain_seg(1), chain_seg(0)};
-    KTimer timer(kBwdChain, caller, w.lvl[0].Np + w.lvl[1].Np);
-    if (int rc = check(aon::launch_mlp_bwd_chain2(segs, 2, caller), "aon_render_bwd")) return rc;
+    if (side)
+      if (int rc = check(hipEventRecord(side->fork, caller), "aon_render_bwd")) return rc;
+    {
+      const aon::ChainSeg segs[2] = {chain_seg(1), chain_seg(0)};
+      KTimer timer(kBwdChain, caller, w.lvl[0].Np + w.lvl[1].Np);
+      if (int rc = check(aon::launch_mlp_bwd_chain2(segs, 2, caller), "aon_render_bwd")) return rc;
+    }
+    if (side) {   // enqueued BEHIND the chain in host order, eligible from the fork event on: the chain's workgroups take the chip first
+      int rc = check(hipStreamWaitEvent(side->stream, side->fork, 0), "aon_render_bwd");
+      for (int l = 0; l < 2 && !rc; ++l) {
+        float* gl[aon::kNumVanillaParams];
+        for (int i = 0; i < aon::kNumVanillaParams; ++i) gl[i] = grads[l][i];
+        rc = check(aon::launch_vanilla_wgrad(w.lvl[l].planes, sc.dplanes[l], sc.d_raw[l], w.lvl[l].Np, gl, sc.wgrad_ws[l], side->stream, nullptr, pb[l], kWgEarly),
+                   "aon_render_bwd");
+      }
+      const int rj = check(hipEventRecord(side->join, side->stream), "aon_render_bwd");
+      const int rw = check(hipStreamWaitEvent(caller, side->join, 0), "aon_render_bwd");
+      if (rc || rj || rw) return rc ? rc : (rj ? rj : rw);
+    }
   }
-  // fork: with two levels each runs on its own library stream, ordered after everything already enqueued on the caller's
-  // (merged: no side streams at all -- chain, weight gradients and head reductions follow each other on the caller's stream; with equal-cost
-  // workgroups filling the chip in every launch the fork / join events and the dispatcher's sharing of compute units between streams cost
-  // more than the tails they used to fill: profiles/r04_backward_schedules.txt)
-  const int overlap_mode = g_bwd_overlap.load(std::memory_order_relaxed);   // 0: none; 1: round-3 level streams when not merged; 2: + head reductions on side streams when merged
-  LevelFork fork(num_levels == 2 && (merged ? overlap_mode == 2 : overlap_mode != 0), caller, "aon_render_bwd", merged);
-  if (fork.rc()) return fork.rc();
   for (int l = 0; l < num_levels; ++l) {
     const TrainLevel& L = w.lvl[l];
     stream = merged ? caller : fork.stream(l);
@@ -1286,7 +1314,8 @@ int aon_render_bwd_ex(const void* packed_bwd_coarse, const void* packed_fwd_coar
       if (g.other_degrees) {   // the three encoding-fed weights come out in the kernels' 63 / 27-column layout, then lose the empty slots
         gl[0] = sc.grad_tmp[l]; gl[10] = gl[0] + 256 * 63; gl[16] = gl[10] + 256 * (256 + 63);
       }
-      rc = check(aon::launch_vanilla_wgrad(L.planes, sc.dplanes[l], sc.d_raw[l], L.Np, gl, sc.wgrad_ws[l], stream, fork.aux(l), pb[l]), "aon_render_bwd");
+      rc = check(aon::launch_vanilla_wgrad(L.planes, sc.dplanes[l], sc.d_raw[l], L.Np, gl, sc.wgrad_ws[l], stream, (merged && overlap_mode != 2) ? nullptr : fork.aux(l), pb[l],
+                                           side ? kWgRest : kWgAll), "aon_render_bwd");
       if (!rc && g.other_degrees) {
         const int Lp = g.max_deg - g.min_deg, P = 3 + 6 * Lp, V = 3 + 6 * g.deg_view;
         auto remap = [&](const float* src, float* dst, int rows, int hidden, int Lx, int Lfull, int cols) {
@@ -1360,20 +1389,36 @@ int aon_art_render_bwd_ex(const void* packed_bwd_coarse, const void* small_coars
   };
   // Round 4: the two levels' chains as ONE persistent launch of two segments on the caller's stream (see aon_render_bwd_ex)
   const bool merged = num_levels == 2 && g_bwd_merge.load(std::memory_order_relaxed) != 0;
+  const int overlap_mode = g_bwd_overlap.load(std::memory_order_relaxed);   // 0: none; 1: round-3 level streams when not merged; 2: + head reductions on side streams when merged
+  const bool early_heads = merged && g_bwd_early_heads.load(std::memory_order_relaxed) != 0;
+  // fork: see aon_render_bwd_ex (merged: no level streams; the chain's last, quarter-full round takes the early head reductions on a side stream)
+  LevelFork fork(num_levels == 2 && (merged ? (overlap_mode == 2 || early_heads) : overlap_mode != 0), caller, "aon_art_render_bwd", merged);
+  if (fork.rc()) return fork.rc();
+  const aon::WgAux* side = early_heads ? fork.aux(0) : nullptr;
+  auto level_wgrad = [&](int l, hipStream_t st, const aon::WgAux* aux, int phase) {
+    // level 0 writes the latent gradients, level 1 adds its own (both MLPs see the same latents)
+    float* gs = l == 0 ? g_shape : sc.lat_tmp, *ga = l == 0 ? g_appearance : sc.lat_tmp + 128, *gt = l == 0 ? g_articulation : sc.lat_tmp + 256;
+    return check(aon::launch_art_wgrad(w.lvl[l].planes, sc.dplanes[l], sc.d_raw[l], sc.dxp[l], w.lvl[l].Np, params[l], shape, appearance, articulation, grads[l], gs, ga, gt,
+                                       sc.wgrad_ws[l], st, aux, g.max_deg - g.min_deg, g.deg_view, pb[l], phase), "aon_art_render_bwd");
+  };
   if (merged) {
     for (int l = 0; l < 2; ++l)
       if (int rc = composite_bwd(l, caller)) return rc;
-    const aon::ChainSeg segs[2] = {chain_seg(1), chain_seg(0)};
-    KTimer timer(kBwdChain, caller, w.lvl[0].Np + w.lvl[1].Np);
-    if (int rc = check(aon::launch_art_bwd_chain2(segs, 2, caller), "aon_art_render_bwd")) return rc;
+    if (side)
+      if (int rc = check(hipEventRecord(side->fork, caller), "aon_art_render_bwd")) return rc;
+    {
+      const aon::ChainSeg segs[2] = {chain_seg(1), chain_seg(0)};
+      KTimer timer(kBwdChain, caller, w.lvl[0].Np + w.lvl[1].Np);
+      if (int rc = check(aon::launch_art_bwd_chain2(segs, 2, caller), "aon_art_render_bwd")) return rc;
+    }
+    if (side) {   // enqueued BEHIND the chain in host order, eligible from the fork event on: the chain's workgroups take the chip first
+      int rc = check(hipStreamWaitEvent(side->stream, side->fork, 0), "aon_art_render_bwd");
+      for (int l = 0; l < 2 && !rc; ++l) rc = level_wgrad(l, side->stream, nullptr, kWgEarly);
+      const int rj = check(hipEventRecord(side->join, side->stream), "aon_art_render_bwd");
+      const int rw = check(hipStreamWaitEvent(caller, side->join, 0), "aon_art_render_bwd");
+      if (rc || rj || rw) return rc ? rc : (rj ? rj : rw);
+    }
   }
-  // fork: with two levels each runs on its own library stream, ordered after everything already enqueued on the caller's
-  // (merged: no side streams at all -- chain, weight gradients and head reductions follow each other on the caller's stream; with equal-cost
-  // workgroups filling the chip in every launch the fork / join events and the dispatcher's sharing of compute units between streams cost
-  // more than the tails they used to fill: profiles/r04_backward_schedules.txt)
-  const int overlap_mode = g_bwd_overlap.load(std::memory_order_relaxed);   // 0: none; 1: round-3 level streams when not merged; 2: + head reductions on side streams when merged
-  LevelFork fork(num_levels == 2 && (merged ? overlap_mode == 2 : overlap_mode != 0), caller, "aon_art_render_bwd", merged);
-  if (fork.rc()) return fork.rc();
   for (int l = 0; l < num_levels; ++l) {
     const TrainLevel& L = w.lvl[l];
     stream = merged ? caller : fork.stream(l);
@@ -1387,10 +1432,7 @@ int aon_art_render_bwd_ex(const void* packed_bwd_coarse, const void* small_coars
     if (rc) return rc;
     {
       KTimer timer(kWgrad, stream, L.Np);
-      // level 0 writes the latent gradients, level 1 adds its own (both MLPs see the same latents)
-      float* gs = l == 0 ? g_shape : sc.lat_tmp, *ga = l == 0 ? g_appearance : sc.lat_tmp + 128, *gt = l == 0 ? g_articulation : sc.lat_tmp + 256;
-      rc = check(aon::launch_art_wgrad(L.planes, sc.dplanes[l], sc.d_raw[l], sc.dxp[l], L.Np, params[l], shape, appearance, articulation, grads[l], gs, ga, gt,
-                                       sc.wgrad_ws[l], stream, fork.aux(l), g.max_deg - g.min_deg, g.deg_view, pb[l]), "aon_art_render_bwd");
+      rc = level_wgrad(l, stream, (merged && overlap_mode != 2) ? nullptr : fork.aux(l), side ? kWgRest : kWgAll);
     }
     if (rc) return rc;
   }

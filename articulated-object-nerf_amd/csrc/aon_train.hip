@@ -449,8 +449,15 @@ static std::atomic<long long*> g_wgrad_probe{nullptr};
 void set_wgrad_probe(long long* buf) { g_wgrad_probe.store(buf, std::memory_order_relaxed); }
 
 // Launch sequence shared by both networks: grouped weight gradients, heads, ONE second stage for both.
+// phase / n_early (round 5): the first n_early head jobs read only what exists BEFORE the backward chain runs (forward planes, d_raw).
+//   kWgAll    everything, as rounds 3-4;
+//   kWgEarly  only those head reductions -- the fused backward launches them on a side stream beside the chain, whose last, quarter-full
+//             round of workgroups (8,256 passes on 256 CUs) leaves three quarters of the chip idle for one pass;
+//   kWgRest   the remaining head jobs, the grouped weight gradients and the second stage (which sums the early partials too).
+// The plan (workspace offsets of every partial) is a pure function of the arguments: the two phases of a level compute the same one.
 hipError_t run_wgrad_plan(const WgLayerDesc* layers, int nlayers, const HeadDesc* heads, int nheads, const HeadOut* outs, const int* out_head, int nouts,
-                          const float* planes, const float* dplanes, int rows_total, int64_t Np, float* ws, hipStream_t stream, const WgAux* aux) {
+                          const float* planes, const float* dplanes, int rows_total, int64_t Np, float* ws, hipStream_t stream, const WgAux* aux,
+                          int phase, int n_early) {
   static DeviceOnce lds_once;
   if (hipError_t e = set_max_lds(&wgrad_grouped_kernel, kWgLdsBytes, lds_once); e != hipSuccess) return e;
   const int cus = num_cus();
@@ -471,12 +478,20 @@ hipError_t run_wgrad_plan(const WgLayerDesc* layers, int nlayers, const HeadDesc
   for (int o = 0; o < nouts; ++o) { R.head[o] = outs[o]; R.head[o].part_off = part_offs[out_head[o]]; }
   // the heads go first, on the side stream when there is one (their workgroups are resident before the weight-gradient launch
   // fills every compute unit) and run beside it; the second stage waits for both
+  if (n_early < 0 || n_early > nheads) return hipErrorInvalidValue;
+  const int early_blocks = n_early == nheads ? head_blocks : H.job[n_early].blk_begin;
+  if (phase == kWgEarly) {
+    if (early_blocks > 0) head_wgrad_kernel<<<dim3(early_blocks, nseg), dim3(256), 0, stream>>>(H);
+    return hipGetLastError();
+  }
+  const int first_block = phase == kWgRest ? early_blocks : 0;
+  H.blk_offset = first_block;
   hipStream_t hs = aux ? aux->stream : stream;
   if (aux) {
     if (hipError_t e = hipEventRecord(aux->fork, stream); e != hipSuccess) return e;
     if (hipError_t e = hipStreamWaitEvent(hs, aux->fork, 0); e != hipSuccess) return e;
   }
-  head_wgrad_kernel<<<dim3(head_blocks, nseg), dim3(256), 0, hs>>>(H);
+  if (head_blocks > first_block) head_wgrad_kernel<<<dim3(head_blocks - first_block, nseg), dim3(256), 0, hs>>>(H);
   hipError_t err = hipGetLastError();
   if (aux) {
     const hipError_t e = hipEventRecord(aux->join, hs);
@@ -551,7 +566,7 @@ float* wgrad_fold_tmp(float* ws) { return ws + (wgrad_workspace_bytes_impl() - (
 // packed_bwd: the transposed stream the chain of these planes ran with -- its FORM says whether the planes carry bottleneck rows, and the
 // folded form's buffer holds the raw W_v0[:, :256], W_b, b_b the un-folding needs.  Null: literal planes.
 hipError_t launch_vanilla_wgrad(const float* planes, const float* dplanes, const float* d_raw, int64_t Np, float* const* grads,
-                                float* ws, hipStream_t stream, const WgAux* aux, const void* packed_bwd) {
+                                float* ws, hipStream_t stream, const WgAux* aux, const void* packed_bwd, int phase) {
   WgLayerDesc L[kWgMaxJobs];
   const bool fold = packed_bwd && stream_form(packed_bwd) == kFormFolded;
   float* fold_tmp = fold ? wgrad_fold_tmp(ws) : nullptr;
@@ -560,8 +575,9 @@ hipError_t launch_vanilla_wgrad(const float* planes, const float* dplanes, const
   const HeadDesc H[3] = {{planes, plane_h(7), 256, d_raw, 128}, {planes, kPlHV, 128, d_raw, 128}, {nullptr, 0, 1, d_raw, 128}};
   const HeadOut O[4] = {{0, 256, 3, 1, 256, 1, grads[20]}, {0, 128, 0, 3, 128, 1, grads[22]}, {0, 1, 3, 1, 1, 1, grads[21]}, {0, 1, 0, 3, 1, 1, grads[23]}};
   const int OH[4] = {0, 1, 2, 2};
-  if (hipError_t e = run_wgrad_plan(L, n, H, 3, O, OH, 4, planes, dplanes, kPlRows, Np, ws, stream, aux); e != hipSuccess) return e;
-  if (!fold) return hipSuccess;
+  // all three head jobs (density head on H7, rgb head on HV, the sums of d_raw) are independent of the chain: n_early = 3
+  if (hipError_t e = run_wgrad_plan(L, n, H, 3, O, OH, 4, planes, dplanes, kPlRows, Np, ws, stream, aux, phase, 3); e != hipSuccess) return e;
+  if (!fold || phase == kWgEarly) return hipSuccess;
   const float* raw = reinterpret_cast<const float*>(static_cast<const char*>(packed_bwd) + kBwFOffWv);
   // (grads[16]'s row stride is the 27-slot layout's here: other view degrees write a slot-layout temporary first, aon_render_bwd_ex)
   return launch_unfold_view(fold_tmp, grads[17], raw, 256, raw + 128 * 256, raw + 128 * 256 + 256 * 256, grads[16], 256 + kViewEnc, grads[18], grads[19], stream);

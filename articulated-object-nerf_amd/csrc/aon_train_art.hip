@@ -452,7 +452,8 @@ hipError_t launch_art_bwd_chain(const char* packed_bwd, const float* small, cons
 }
 
 hipError_t run_wgrad_plan(const WgLayerDesc* layers, int nlayers, const HeadDesc* heads, int nheads, const HeadOut* outs, const int* out_head, int nouts,
-                          const float* planes, const float* dplanes, int rows_total, int64_t Np, float* ws, hipStream_t stream, const WgAux* aux);   // aon_train.hip
+                          const float* planes, const float* dplanes, int rows_total, int64_t Np, float* ws, hipStream_t stream, const WgAux* aux,
+                          int phase, int n_early);   // aon_train.hip
 
 // the weight-gradient jobs of one articulated level.  Lp / Lv: frequency levels of the network (10 / 4 by default).  With other degrees
 // the three encoding-fed column blocks come out in the kernels' 63 / 27-slot layout into `enc_tmp` (256 x 64 | 256 x 64 | 128 x 32
@@ -508,7 +509,7 @@ __global__ void art_remap_enc_kernel(const float* __restrict__ src, int lds, flo
 hipError_t launch_art_wgrad(const float* planes, const float* dplanes, const float* d_raw, const float* dxp, int64_t Np,
                             const float* const* params, const float* shape, const float* app, const float* art,
                             float* const* grads, float* g_shape, float* g_app, float* g_art, float* ws, hipStream_t stream, const WgAux* aux,
-                            int Lp, int Lv, const void* packed_bwd) {
+                            int Lp, int Lv, const void* packed_bwd, int phase) {
   // packed_bwd: the transposed stream the chain of these planes ran with -- its FORM says whether the planes carry bottleneck rows (null: literal)
   const bool fold = packed_bwd && stream_form(packed_bwd) == kFormFolded;
   float* fold_tmp = fold ? wgrad_fold_tmp(ws) : nullptr;
@@ -529,7 +530,9 @@ hipError_t launch_art_wgrad(const float* planes, const float* dplanes, const flo
                         {0, 128, 0, 3, 128, 1, grads[8]},  {0, 1, 0, 3, 1, 1, grads[9]},
                         {0, 128, 0, 3, 1, 163, grads[0]},  {0, 128, 4, 1, 1, 1, grads[1]}};
   const int OH[8] = {0, 1, 2, 2, 3, 4, 5, 5};
-  if (hipError_t e = run_wgrad_plan(L, n, H, 6, O, OH, 8, planes, dplanes, kAPlRows, Np, ws, stream, aux); e != hipSuccess) return e;
+  // head jobs 0..2 (density head on H7, rgb head on V3, the sums of d_raw) read forward planes and d_raw only: independent of the chain
+  if (hipError_t e = run_wgrad_plan(L, n, H, 6, O, OH, 8, planes, dplanes, kAPlRows, Np, ws, stream, aux, phase, 3); e != hipSuccess) return e;
+  if (phase == kWgEarly) return hipSuccess;
   if (!dflt) {
     auto remap = [&](const float* src, int lds, float* dst, int ldd, int col_off, int rows, int Lx, int Lfull) {
       const int tot = rows * (3 + 6 * Lx);

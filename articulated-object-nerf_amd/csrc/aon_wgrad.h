@@ -329,6 +329,7 @@ constexpr int kHeadMaxJobs = 8;
 struct HeadArgs {
   HeadJob job[kHeadMaxJobs];
   int njobs;
+  int blk_offset;          // added to blockIdx.x: a launch may cover a suffix of the jobs' blocks (round 5: early / late head reductions)
   int64_t step_floats;     // rows_total * 32
   int64_t Np, seg_len;
   float* ws;
@@ -347,12 +348,13 @@ __device__ __forceinline__ double wsum64d(double v) {
 }
 
 __global__ void __launch_bounds__(256) head_wgrad_kernel(HeadArgs a) {
+  const int bx = (int)blockIdx.x + a.blk_offset;
   int j = 0;
 #pragma unroll 1
   for (int t = 1; t < a.njobs; ++t)
-    if ((int)blockIdx.x >= a.job[t].blk_begin) j = t;
+    if (bx >= a.job[t].blk_begin) j = t;
   const HeadJob& J = a.job[j];
-  const int row0 = ((int)blockIdx.x - J.blk_begin) * 8, seg = blockIdx.y;
+  const int row0 = (bx - J.blk_begin) * 8, seg = blockIdx.y;
   const int nr = J.rows - row0 < 8 ? J.rows - row0 : 8;
   const int64_t n0 = (int64_t)seg * a.seg_len;
   const int64_t n1 = n0 + a.seg_len < a.Np ? n0 + a.seg_len : a.Np;
@@ -595,6 +597,8 @@ struct WgAux {
   hipStream_t stream;
   hipEvent_t fork, join;
 };
+
+enum : int { kWgAll = 0, kWgEarly = 1, kWgRest = 2 };   // phases of a level's weight-gradient call (run_wgrad_plan)
 
 struct HeadDesc {
   const float* plane; int row; int rows;   // plane == null: record sums only (rows = 1)

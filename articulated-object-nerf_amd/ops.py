@@ -790,6 +790,11 @@ def set_fwd_overlap(on: bool) -> None:
     check(lib.aon_set_fwd_overlap(int(bool(on))), "aon_set_fwd_overlap")
 
 
+def set_bwd_early_heads(on: bool) -> None:
+    """Merged backward: the chain-independent head / bias reductions on a side stream beside the chain launch (default on; same bits)."""
+    check(lib.aon_set_bwd_early_heads(int(bool(on))), "aon_set_bwd_early_heads")
+
+
 def set_bwd_merge(on: bool) -> None:
     """Backward chains of the two levels as ONE persistent launch of two segments (default on; off: one launch per level, round 3)."""
     check(lib.aon_set_bwd_merge(int(bool(on))), "aon_set_bwd_merge")

@@ -321,6 +321,12 @@ int aon_set_fwd_merge(int on);
  * followed by the two levels' weight gradients on the two library streams (aon_set_bwd_overlap).  Same bits.  0: one chain launch
  * per level, each on its level's stream (round 3). */
 int aon_set_bwd_merge(int on);
+/* Round 5, default 1 (merged form only): the head / bias reductions that need nothing from the chain -- density head on the layer-7
+ * output, rgb head, the sums of d_raw: 60 % of the head kernel's bytes -- are launched on a library side stream behind the merged
+ * chain launch, whose last round of workgroups is a quarter full (8,256 passes on 256 compute units at 4096 x (65 + 193) samples):
+ * they run on compute units that would idle for one pass.  Ordered by events on both sides like the level streams; same bits
+ * (the partials are summed by the same second stage).  0: every head reduction behind the chain, on `stream` (round 4). */
+int aon_set_bwd_early_heads(int on);
 int64_t aon_train_workspace_bytes(int64_t n_rays, int articulated, int num_levels);
 int64_t aon_train_scratch_bytes(int64_t n_rays, int articulated, int num_levels);
 int aon_render_fwd_train(const void* packed_coarse, const void* packed_fine, const float* rays_o, const float* rays_d,

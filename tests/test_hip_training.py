@@ -570,10 +570,12 @@ def test_forward_overlap_is_bit_identical(dev, net):
             model.load_state_dict(syn.make_smooth_nerf_state_dict())
         res = []
         try:
-            for merge, on, bwd_merge in ((2, True, True), (0, True, False), (0, False, True)):   # (and the backward chains merged or per level)
+            # (and the backward chains merged or per level; merged: the chain-independent head reductions beside the chain or behind it)
+            for merge, on, bwd_merge, early in ((2, True, True, True), (0, True, False, True), (0, False, True, False)):
                 ops.set_fwd_merge(merge)
                 ops.set_fwd_overlap(on)
                 ops.set_bwd_merge(bwd_merge)
+                ops.set_bwd_early_heads(early)
                 model.zero_grad()
                 out = model(rays, True, True, 2.0, 6.0, lat, t_rand=tr, u=u) if lat is not None else model(rays, True, True, 2.0, 6.0, t_rand=tr, u=u)
                 (((out[0][0] - target) ** 2).mean() + ((out[1][0] - target) ** 2).mean() + out[1][2].mean() * 1e-3).backward()
@@ -582,5 +584,6 @@ def test_forward_overlap_is_bit_identical(dev, net):
             ops.set_fwd_overlap(True)
             ops.set_fwd_merge(True)
             ops.set_bwd_merge(True)
+            ops.set_bwd_early_heads(True)
         for a, b, c in zip(*res):
             assert torch.equal(a, b) and torch.equal(a, c)
