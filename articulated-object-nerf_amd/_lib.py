@@ -31,6 +31,8 @@ _SIGS = {
     "aon_abi_version": (_i, []),
     "aon_last_error": (C.c_char_p, []),
     "aon_raygen": (_i, [_p, _i, _i, _f, _l, _l, _p, _p, _p, _p]),
+    "aon_train_loss_fwd": (_i, [_p, _p, _p, _l, _p, _p, _f, _p, _p, _p]),
+    "aon_train_loss_bwd": (_i, [_p, _p, _p, _l, _p, _p, _f, _p, _p, _p, _p, _p]),
     "aon_ray_directions": (_i, [_i, _i, _f, _p, _p]),
     "aon_get_rays": (_i, [_p, _p, _l, _p, _p, _p, _p]),
     "aon_ray_radii": (_i, [_p, _p, _i, _i, _p, _p]),

@@ -64,6 +64,8 @@ hipError_t launch_art_wgrad(const float* planes, const float* dplanes, const flo
                             const float* const* params, const float* shape, const float* app, const float* art,
                             float* const* grads, float* g_shape, float* g_app, float* g_art, float* ws, hipStream_t stream, const WgAux* aux, int pos_levels, int view_levels,
                             const void* packed_bwd, int phase = 0);
+hipError_t launch_train_loss(bool backward, const float* rgb_c, const float* rgb_f, const float* target, int64_t n, const float* const* lat, const int* lat_len,
+                             float reg_scale, float* stats, float* loss, const float* go, float* d_rgb_c, float* d_rgb_f, float* const* d_lat, hipStream_t stream);
 hipError_t launch_raygen(const float* c2w, int H, int W, float focal, const float* directions, int64_t pix_begin,
                          int64_t pix_end, float* rays_o, float* viewdirs, float* rays_d, hipStream_t stream);
 hipError_t launch_ray_directions(int H, int W, float focal, float* out, hipStream_t stream);
@@ -238,6 +240,27 @@ int aon_raygen(const float* c2w_host, int H, int W, float focal, int64_t pix_beg
     return fail(AON_E_INVALID, "aon_raygen: bad geometry");
   return check(aon::launch_raygen(c2w_host, H, W, focal, nullptr, pix_begin, pix_end, rays_o, viewdirs, rays_d,
                                   (hipStream_t)stream), "aon_raygen");
+}
+
+int aon_train_loss_fwd(const float* rgb_coarse, const float* rgb_fine, const float* target, int64_t n, const float* const* latents_host, const int* latent_len_host,
+                       float reg_scale, float* stats, float* loss, void* stream) {
+  if (!rgb_fine || !target || !stats || !loss) return fail(AON_E_INVALID, "aon_train_loss_fwd: null pointer");
+  if (n <= 0) return fail(AON_E_INVALID, "aon_train_loss_fwd: bad size");
+  for (int k = 0; k < 3 && latents_host; ++k)
+    if (latents_host[k] && (!latent_len_host || latent_len_host[k] <= 0)) return fail(AON_E_INVALID, "aon_train_loss_fwd: bad latent length");
+  return check(aon::launch_train_loss(false, rgb_coarse, rgb_fine, target, n, latents_host, latent_len_host, reg_scale, stats, loss, nullptr, nullptr, nullptr, nullptr,
+                                      (hipStream_t)stream), "aon_train_loss_fwd");
+}
+
+int aon_train_loss_bwd(const float* rgb_coarse, const float* rgb_fine, const float* target, int64_t n, const float* const* latents_host, const int* latent_len_host,
+                       float reg_scale, const float* grad_loss, float* d_rgb_coarse, float* d_rgb_fine, float* const* d_latents_host, void* stream) {
+  if (!rgb_fine || !target || !grad_loss || !d_rgb_fine) return fail(AON_E_INVALID, "aon_train_loss_bwd: null pointer");
+  if (n <= 0) return fail(AON_E_INVALID, "aon_train_loss_bwd: bad size");
+  if ((rgb_coarse == nullptr) != (d_rgb_coarse == nullptr)) return fail(AON_E_INVALID, "aon_train_loss_bwd: coarse level input / gradient mismatch");
+  for (int k = 0; k < 3 && latents_host; ++k)
+    if (latents_host[k] && (!latent_len_host || latent_len_host[k] <= 0)) return fail(AON_E_INVALID, "aon_train_loss_bwd: bad latent length");
+  return check(aon::launch_train_loss(true, rgb_coarse, rgb_fine, target, n, latents_host, latent_len_host, reg_scale, nullptr, nullptr, grad_loss, d_rgb_coarse, d_rgb_fine,
+                                      d_latents_host, (hipStream_t)stream), "aon_train_loss_bwd");
 }
 
 int aon_ray_directions(int H, int W, float focal, float* directions, void* stream) {

@@ -732,4 +732,101 @@ hipError_t launch_sample_pdf_n(const float* bins, const float* weights, int64_t 
   return hipGetLastError();
 }
 
+// ---- Training losses as TWO launches: helper.py:17-22 (img2mse, mse2psnr), model.py:271-273 (loss0 + loss1),
+// model_autodecoder.py:460-466 (+ 1e-4 * sum of mean |code|).  Written in torch the forward and backward of these lines are ~47 launches
+// of 5-7 us around 12,288 numbers -- 0.29 ms of a 31 ms step (profiles/r05_step_timeline.txt).
+// Forward: one workgroup, fp64 sums in a fixed order, every output rounded once.  stats = {loss0, loss1, reg, loss, psnr0, psnr1};
+// loss = fl(fl(loss1 + loss0) + reg) as the reference adds them.
+struct LossArgs {
+  const float* rgb[2];   // coarse, fine (n,3); rgb[0] may be null (num_levels = 1: loss0 = 0 and no gradient)
+  const float* target;   // (n,3)
+  int64_t numel;         // 3 n
+  const float* lat[3];   // latent codes whose mean |.| is regularised (null: none)
+  int lat_len[3];
+  float reg_scale;       // 1e-4
+  float* stats;          // (8,)
+  float* loss;           // (1,) the differentiable output
+  const float* go;       // backward: d loss (device scalar)
+  float* d_rgb[2];       // backward outputs
+  float* d_lat[3];
+};
+
+__global__ __launch_bounds__(1024) void train_loss_fwd_kernel(LossArgs a) {
+  __shared__ double red[2][16];
+  __shared__ double lat_red[3][16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  double s[2] = {0.0, 0.0};
+  for (int64_t i = tid; i < a.numel; i += 1024) {
+    const float t = a.target[i];
+    for (int l = 0; l < 2; ++l)
+      if (a.rgb[l]) { const float d = __fsub_rn(a.rgb[l][i], t); s[l] += (double)d * (double)d; }
+  }
+  double ls[3] = {0.0, 0.0, 0.0};
+  for (int k = 0; k < 3; ++k)
+    if (a.lat[k])
+      for (int i = tid; i < a.lat_len[k]; i += 1024) ls[k] += (double)__builtin_fabsf(a.lat[k][i]);
+  // wave sums by shuffles (fixed order), then the 16 wave partials in order
+  for (int off = 32; off > 0; off >>= 1) {
+    s[0] += __shfl_down(s[0], off); s[1] += __shfl_down(s[1], off);
+    ls[0] += __shfl_down(ls[0], off); ls[1] += __shfl_down(ls[1], off); ls[2] += __shfl_down(ls[2], off);
+  }
+  if (lane == 0) { red[0][wave] = s[0]; red[1][wave] = s[1]; lat_red[0][wave] = ls[0]; lat_red[1][wave] = ls[1]; lat_red[2][wave] = ls[2]; }
+  __syncthreads();
+  if (tid == 0) {
+    double t[2] = {0.0, 0.0}, lt[3] = {0.0, 0.0, 0.0};
+    for (int w = 0; w < 16; ++w) { t[0] += red[0][w]; t[1] += red[1][w]; lt[0] += lat_red[0][w]; lt[1] += lat_red[1][w]; lt[2] += lat_red[2][w]; }
+    const float loss0 = a.rgb[0] ? (float)(t[0] / (double)a.numel) : 0.f;
+    const float loss1 = (float)(t[1] / (double)a.numel);
+    float means = 0.f;   // torch.mean(...) + torch.mean(...) + torch.mean(...), left to right in fp32
+    for (int k = 0; k < 3; ++k)
+      if (a.lat[k]) means = __fadd_rn(means, (float)(lt[k] / (double)a.lat_len[k]));
+    const float reg = __fmul_rn(a.reg_scale, means);
+    const float loss = __fadd_rn(__fadd_rn(loss1, loss0), reg);
+    const double inv_ln10 = 1.0 / 2.302585092994046;
+    a.stats[0] = loss0; a.stats[1] = loss1; a.stats[2] = reg; a.stats[3] = loss;
+    a.stats[4] = a.rgb[0] ? (float)(-10.0 * log((double)loss0) * inv_ln10) : 0.f;
+    a.stats[5] = (float)(-10.0 * log((double)loss1) * inv_ln10);
+    a.stats[6] = 0.f; a.stats[7] = 0.f;
+    a.loss[0] = loss;
+  }
+}
+
+// Backward, the operations autograd would run: mean -> g = fl(go / numel); pow(2) -> fl(g * fl(2 d)); torch.norm(code, dim=0) of a
+// one-row code is |x|: fl(x * fl(gm / |x|)), 0 where x = 0 (norm_backward's masked_fill); gm = fl(fl(go * scale) / len).
+__global__ __launch_bounds__(256) void train_loss_bwd_kernel(LossArgs a) {
+  const float go = a.go[0];
+  const float g = __fdiv_rn(go, (float)a.numel);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.numel; i += (int64_t)gridDim.x * 256) {
+    const float t = a.target[i];
+    for (int l = 0; l < 2; ++l)
+      if (a.rgb[l] && a.d_rgb[l]) a.d_rgb[l][i] = __fmul_rn(g, __fmul_rn(2.f, __fsub_rn(a.rgb[l][i], t)));
+  }
+  if (blockIdx.x == 0) {
+    const float gs = __fmul_rn(go, a.reg_scale);
+    for (int k = 0; k < 3; ++k) {
+      if (!a.lat[k] || !a.d_lat[k]) continue;
+      const float gm = __fdiv_rn(gs, (float)a.lat_len[k]);
+      for (int i = threadIdx.x; i < a.lat_len[k]; i += 256) {
+        const float x = a.lat[k][i], n = __builtin_fabsf(x);
+        a.d_lat[k][i] = n == 0.f ? 0.f : __fmul_rn(x, __fdiv_rn(gm, n));
+      }
+    }
+  }
+}
+
+hipError_t launch_train_loss(bool backward, const float* rgb_c, const float* rgb_f, const float* target, int64_t n, const float* const* lat, const int* lat_len,
+                             float reg_scale, float* stats, float* loss, const float* go, float* d_rgb_c, float* d_rgb_f, float* const* d_lat, hipStream_t stream) {
+  LossArgs a{};
+  a.rgb[0] = rgb_c; a.rgb[1] = rgb_f; a.target = target; a.numel = 3 * n; a.reg_scale = reg_scale;
+  for (int k = 0; k < 3; ++k) { a.lat[k] = lat ? lat[k] : nullptr; a.lat_len[k] = lat_len ? lat_len[k] : 0; a.d_lat[k] = d_lat ? d_lat[k] : nullptr; }
+  a.stats = stats; a.loss = loss; a.go = go; a.d_rgb[0] = d_rgb_c; a.d_rgb[1] = d_rgb_f;
+  if (!backward) {
+    train_loss_fwd_kernel<<<dim3(1), dim3(1024), 0, stream>>>(a);
+  } else {
+    const int64_t blocks = (a.numel + 255) / 256;
+    train_loss_bwd_kernel<<<dim3((unsigned)(blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks))), dim3(256), 0, stream>>>(a);
+  }
+  return hipGetLastError();
+}
+
 }  // namespace aon

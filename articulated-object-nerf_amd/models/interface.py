@@ -74,6 +74,42 @@ def get_obj_rgbs_from_segmap(all_segmap, all_pred_img, all_pred_target):
     return objs, tgts
 
 
+class _LogSeries(list):
+    """The values one name was logged with, as floats -- read lazily.  ``float(tensor)`` at log time is a host synchronisation, four per
+    training step (the host then enqueues the backward only after the forward has finished); device scalars are kept as they are and turned
+    into floats when somebody looks (``series[-1]``, iteration, ``len`` stays cheap), or 512 at a time with ONE device read."""
+
+    _pending = 0
+
+    def append(self, value):
+        if isinstance(value, torch.Tensor):
+            list.append(self, value.detach())
+            self._pending += 1
+            if self._pending >= 512:
+                self._settle()
+        else:
+            list.append(self, float(value))
+
+    def _settle(self):
+        if not self._pending:
+            return
+        idx = [i for i in range(len(self)) if isinstance(list.__getitem__(self, i), torch.Tensor)]
+        if idx:
+            ts = [list.__getitem__(self, i).reshape(()).float() for i in idx]
+            vals = torch.stack(ts).tolist() if len({t.device for t in ts}) == 1 else [float(t) for t in ts]
+            for i, v in zip(idx, vals):
+                list.__setitem__(self, i, v)
+        self._pending = 0
+
+    def __getitem__(self, i):
+        self._settle()
+        return list.__getitem__(self, i)
+
+    def __iter__(self):
+        self._settle()
+        return list.__iter__(self)
+
+
 class Harness(LitModel):
     """What the two LightningModules of the reference share once Lightning is removed: the ``self.log`` sink, the
     learning-rate rule of ``optimizer_step`` (model.py:391-419 == model_autodecoder.py:607-636) and the PSNR half of
@@ -89,11 +125,11 @@ class Harness(LitModel):
         hp = dict(defaults)
         hp.update(vars(hparams) if hparams is not None and not isinstance(hparams, dict) else (hparams or {}))
         self.hparams = SimpleNamespace(**hp)
-        self.logged = defaultdict(list)
+        self.logged = defaultdict(_LogSeries)
         self.global_step = 0
 
     def log(self, name, value, **_):
-        self.logged[name].append(float(value))
+        self.logged[name].append(value)
 
     def lr_at_step(self, step: int) -> float:
         """log-linear decay lr_init -> lr_final over run_max_steps, times a sine warm-up over lr_delay_steps."""

@@ -27,6 +27,47 @@ def mse2psnr(x):
     return -10.0 * torch.log(x) / math.log(10.0)
 
 
+class _TrainLoss(torch.autograd.Function):
+    """loss0 + loss1 (+ reg) with their gradients as two launches (ops.train_loss_fwd / _bwd) instead of ~47 tiny torch kernels."""
+
+    @staticmethod
+    def forward(ctx, rgb_c, rgb_f, target, reg_scale, *latents):
+        loss, stats = ops.train_loss_fwd(rgb_c, rgb_f, target, latents, reg_scale)
+        ctx.save_for_backward(*[t for t in (rgb_c, rgb_f, target) + tuple(latents) if t is not None])
+        ctx.layout = (rgb_c is not None, len(latents), reg_scale)
+        ctx.mark_non_differentiable(stats)
+        return loss.reshape(()), stats
+
+    @staticmethod
+    def backward(ctx, grad_loss, _grad_stats):
+        has_c, n_lat, reg_scale = ctx.layout
+        saved = list(ctx.saved_tensors)
+        rgb_c = saved.pop(0) if has_c else None
+        rgb_f, target = saved.pop(0), saved.pop(0)
+        d_c, d_f, d_l = ops.train_loss_bwd(rgb_c, rgb_f, target, saved, reg_scale, grad_loss.reshape(1))
+        return (d_c, d_f, None, None) + tuple(d_l[:n_lat])
+
+
+def train_loss(rendered, target, latents=(), reg_scale=1e-4):
+    """The training steps' loss lines in one piece: model.py:271-273 (``loss0 + loss1``) and model_autodecoder.py:460-466
+    (``+ 1e-4 * (mean ||shape|| + mean ||appearance|| + mean ||articulation||)``, ``torch.norm(code, dim=0)`` of the one-row codes).
+    ``rendered``: the model's output list (one or two levels of ``(rgb, acc, depth)``).  Returns ``(loss, stats)``; ``loss`` carries the
+    autograd graph to the rendered colours and the codes, ``stats`` = ``[loss0, loss1, reg, loss, psnr0, psnr1, 0, 0]`` (detached, for
+    the logs: ``mse2psnr`` of the two levels included).  Codes with more than one row fall back to the reference's torch formula."""
+    rgb_f = rendered[-1][0]
+    rgb_c = rendered[0][0] if len(rendered) > 1 else None
+    latents = tuple(latents)
+    if any(c.dim() != 2 or c.shape[0] != 1 for c in latents) or len(latents) > 3 or len(rendered) > 2:
+        loss_levels = [img2mse(r[0], target) for r in rendered]
+        reg = reg_scale * sum(torch.mean(torch.norm(c, dim=0)) for c in latents) if latents else torch.zeros((), device=target.device)
+        loss = sum(reversed(loss_levels)) + reg if latents else sum(loss_levels)
+        l0 = loss_levels[0].detach() if len(rendered) > 1 else torch.zeros((), device=target.device)
+        l1 = loss_levels[-1].detach()
+        zero = torch.zeros((), device=target.device)
+        return loss, torch.stack([l0, l1, reg.detach(), loss.detach(), mse2psnr(l0), mse2psnr(l1), zero, zero])
+    return _TrainLoss.apply(rgb_c, rgb_f, target, float(reg_scale), *latents)
+
+
 def cast_rays(t_vals, origins, directions):
     """helper.py:25-26"""
     return ops.cast_rays(t_vals, origins, directions)

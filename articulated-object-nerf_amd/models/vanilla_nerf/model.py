@@ -278,13 +278,11 @@ class LitNeRF(Harness):
     def training_step(self, batch, batch_idx):
         batch = {k: (v if k == "obj_idx" else v.squeeze(0)) for k, v in batch.items()}
         rendered = self.model(batch, self.randomized, self.white_bkgd, self.near, self.far)
-        target = batch["target"]
-        loss0 = helper.img2mse(rendered[0][0], target)
-        loss1 = helper.img2mse(rendered[1][0], target)
-        loss = loss1 + loss0
-        self.log("train/psnr1", helper.mse2psnr(loss1.detach()))
-        self.log("train/psnr0", helper.mse2psnr(loss0.detach()))
-        self.log("train/loss", loss.detach())
+        # model.py:271-279: loss0 + loss1 and the three logged values -- one launch forward, one backward (helper.train_loss)
+        loss, stats = helper.train_loss(rendered, batch["target"])
+        self.log("train/psnr1", stats[5])
+        self.log("train/psnr0", stats[4])
+        self.log("train/loss", stats[3])
         return loss
 
     @torch.no_grad()

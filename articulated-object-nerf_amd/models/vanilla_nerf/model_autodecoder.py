@@ -217,16 +217,13 @@ class LitNeRF_AutoDecoder(Harness):
         batch = self._unbatch(batch)
         latents = self.code_library(batch)
         rendered = self.model(batch, self.randomized, self.white_bkgd, self.near, self.far, latents)
-        target = batch["target"]
-        loss0 = helper.img2mse(rendered[0][0], target)
-        loss1 = helper.img2mse(rendered[1][0], target)
-        reg_loss = 1e-4 * (torch.mean(torch.norm(latents["density"], dim=0)) + torch.mean(torch.norm(latents["color"], dim=0))
-                           + torch.mean(torch.norm(latents["articulation"], dim=0)))
-        loss = loss1 + loss0 + reg_loss
-        self.log("train/psnr1", helper.mse2psnr(loss1.detach()))
-        self.log("train/psnr0", helper.mse2psnr(loss0.detach()))
-        self.log("train/loss", loss.detach())
-        self.log("train/loss/reg", reg_loss.detach())
+        # model_autodecoder.py:455-477: loss1 + loss0 + 1e-4 * (mean ||shape|| + mean ||appearance|| + mean ||articulation||) and the four
+        # logged values -- one launch forward, one backward (helper.train_loss) where torch runs ~47
+        loss, stats = helper.train_loss(rendered, batch["target"], (latents["density"], latents["color"], latents["articulation"]), 1e-4)
+        self.log("train/psnr1", stats[5])
+        self.log("train/psnr0", stats[4])
+        self.log("train/loss", stats[3])
+        self.log("train/loss/reg", stats[2])
         return loss
 
     def _render_chunks(self, batch, latents, skip=()):

@@ -55,6 +55,44 @@ def raygen(c2w, H: int, W: int, focal: float, pix_begin: int = 0, pix_end: int |
     return rays_o, viewdirs
 
 
+# ------------------------------------------------------------------ R13 training losses, two launches
+def _loss_args(rgb_c, rgb_f, target, latents):
+    rgb_f, target = _f32(rgb_f, "rgb_fine"), _f32(target, "target")
+    rgb_c = None if rgb_c is None else _f32(rgb_c, "rgb_coarse")
+    n = rgb_f.numel() // 3
+    if target.numel() != 3 * n or (rgb_c is not None and rgb_c.numel() != 3 * n):
+        raise ValueError("train_loss: rgb / target sizes differ")
+    lats = [None, None, None]
+    for k, t in enumerate(latents or ()):
+        lats[k] = None if t is None else _f32(t, "latent")
+    lens = (C.c_int * 3)(*[0 if t is None else t.numel() for t in lats])
+    return rgb_c, rgb_f, target, n, lats, lens
+
+
+def train_loss_fwd(rgb_c, rgb_f, target, latents=(), reg_scale: float = 1e-4):
+    """-> (loss (1,), stats (8,) = {loss0, loss1, reg, loss, psnr0, psnr1, 0, 0}); `latents`: up to three one-row codes."""
+    rgb_c, rgb_f, target, n, lats, lens = _loss_args(rgb_c, rgb_f, target, latents)
+    stats = torch.empty(8, dtype=torch.float32, device=rgb_f.device)
+    loss = torch.empty(1, dtype=torch.float32, device=rgb_f.device)
+    with torch.cuda.device(rgb_f.device):
+        check(lib.aon_train_loss_fwd(_ptr(rgb_c), _ptr(rgb_f), _ptr(target), n, _ptr_array(lats), lens, float(reg_scale), _ptr(stats), _ptr(loss), _stream()),
+              "aon_train_loss_fwd")
+    return loss, stats
+
+
+def train_loss_bwd(rgb_c, rgb_f, target, latents, reg_scale: float, grad_loss):
+    """-> (d_rgb_c or None, d_rgb_f, [d_latent or None] * 3)"""
+    rgb_c, rgb_f, target, n, lats, lens = _loss_args(rgb_c, rgb_f, target, latents)
+    go = _f32(grad_loss, "grad_loss")
+    d_c = None if rgb_c is None else torch.empty_like(rgb_c)
+    d_f = torch.empty_like(rgb_f)
+    d_l = [None if t is None else torch.empty_like(t) for t in lats]
+    with torch.cuda.device(rgb_f.device):
+        check(lib.aon_train_loss_bwd(_ptr(rgb_c), _ptr(rgb_f), _ptr(target), n, _ptr_array(lats), lens, float(reg_scale), _ptr(go), _ptr(d_c), _ptr(d_f),
+                                     _ptr_array(d_l), _stream()), "aon_train_loss_bwd")
+    return d_c, d_f, d_l
+
+
 def ray_directions(H: int, W: int, focal: float, device=None):
     dev = torch.device("cuda") if device is None else torch.device(device)
     out = torch.empty((H, W, 3), dtype=torch.float32, device=dev)

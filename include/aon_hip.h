@@ -45,6 +45,20 @@ const char* aon_last_error(void);
 int aon_raygen(const float* c2w_host, int H, int W, float focal, int64_t pix_begin, int64_t pix_end,
                float* rays_o, float* viewdirs, float* rays_d, void* stream);
 
+/* ---- R13  the training losses as two launches (round 5) ----
+ * helper.py:17-22 (img2mse, mse2psnr), model.py:271-273 (loss0 + loss1), model_autodecoder.py:460-466 (+ reg_scale * the sum of the
+ * means of |code| over the latent codes, each ONE row: torch.norm(code, dim=0) of a (1,D) code is |code|).
+ * fwd: stats (8 floats, device) = {loss0, loss1, reg, loss, psnr0, psnr1, 0, 0}; loss (1 float, device) = fl(fl(loss1 + loss0) + reg);
+ *      fp64 sums in a fixed order, each output rounded once.  rgb_coarse may be NULL (num_levels = 1): loss0 = 0.
+ *      latents_host / latent_len_host: HOST arrays of 3 device pointers / lengths, NULL entries (or NULL arrays) = no such code.
+ * bwd: d_rgb_* (n,3) = fl(fl(grad_loss / 3n) * fl(2 (rgb - target))), d_latents[k] = fl(x * fl(fl(fl(grad_loss * reg_scale) / len) / |x|)),
+ *      0 where x = 0 -- the operations torch autograd runs for the same lines; grad_loss: device scalar. */
+int aon_train_loss_fwd(const float* rgb_coarse, const float* rgb_fine, const float* target, int64_t n, const float* const* latents_host,
+                       const int* latent_len_host, float reg_scale, float* stats, float* loss, void* stream);
+int aon_train_loss_bwd(const float* rgb_coarse, const float* rgb_fine, const float* target, int64_t n, const float* const* latents_host,
+                       const int* latent_len_host, float reg_scale, const float* grad_loss, float* d_rgb_coarse, float* d_rgb_fine,
+                       float* const* d_latents_host, void* stream);
+
 /* get_ray_directions alone (ray_utils.py:71-90): directions (H*W,3), un-normalised camera-space. */
 int aon_ray_directions(int H, int W, float focal, float* directions, void* stream);
 

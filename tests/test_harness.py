@@ -69,3 +69,17 @@ def test_harness_hands_constructor_arguments_through():
     assert LitNeRF().model.coarse_mlp.geometry.is_default
     art = LitNeRF_AutoDecoder(model_kwargs=dict(num_fine_samples=64, rgb_padding=0.01))
     assert art.model._opts.num_fine_samples == 64 and art.model._opts.rgb_padding == 0.01
+
+
+def test_log_series_reads_device_scalars_lazily():
+    """Harness.log keeps tensors as they are (no float() = host synchronisation per logged value) and hands out floats on access."""
+    from aon_amd.models.interface import _LogSeries
+
+    s = _LogSeries()
+    s.append(torch.tensor(1.5))
+    s.append(2.5)
+    s.append(torch.tensor([3.5])[0])
+    assert len(s) == 3 and s[-1] == 3.5 and list(s) == [1.5, 2.5, 3.5] and all(isinstance(v, float) for v in s)
+    for i in range(600):
+        s.append(torch.tensor(float(i)))
+    assert s._pending < 512 and s[3] == 0.0 and s[-1] == 599.0

@@ -125,6 +125,56 @@ def test_metrics_product_side_vs_golden(dev, golden):
     torch.testing.assert_close((helper.img2mse(a, b) + helper.img2mse(b, a)).cpu(), 2 * torch.as_tensor(g["mse"]), rtol=2e-6, atol=0)
 
 
+def test_train_loss_two_launches_vs_torch_lines(dev, golden):
+    """R13, round 5: helper.train_loss (aon_train_loss_fwd / _bwd: the loss lines of model.py:271-273 and model_autodecoder.py:455-466 as
+    two launches) against the same lines written in torch, the reference's formulation, on the G13 images and on a 4096-ray batch:
+    values to 2e-6 relative (fp64 sums here, fp32 tree sums there), gradients of the rendered colours to 1e-6 relative per element
+    (same operations in the same order: observed equal), codes likewise, incl. a zero entry (norm_backward's masked_fill) and a loss
+    scaled before backward (grad_loss != 1)."""
+    from aon_amd.models.vanilla_nerf import helper
+
+    g = golden("g13_metrics")
+    gen = torch.Generator().manual_seed(3)
+    cases = [(g["a"].reshape(-1, 3).to(dev), g["b"].reshape(-1, 3).to(dev), g["b"].flip(0).reshape(-1, 3).to(dev)),
+             (torch.rand(4096, 3, generator=gen).to(dev), torch.rand(4096, 3, generator=gen).to(dev), torch.rand(4096, 3, generator=gen).to(dev))]
+    for rgb_c0, rgb_f0, target in cases:
+        for with_codes in (False, True):
+            codes0 = [torch.randn(1, 128, generator=gen), torch.randn(1, 128, generator=gen), torch.randn(1, 32, generator=gen)] if with_codes else []
+            if with_codes:
+                codes0[0][0, 5] = 0.0
+            res = {}
+            for form in ("torch", "fused"):
+                rc, rf = rgb_c0.clone().requires_grad_(True), rgb_f0.clone().requires_grad_(True)
+                codes = [c.clone().to(dev).requires_grad_(True) for c in codes0]
+                rendered = [(rc, None, None), (rf, None, None)]
+                if form == "torch":
+                    loss0, loss1 = helper.img2mse(rc, target), helper.img2mse(rf, target)
+                    loss = loss1 + loss0
+                    reg = torch.zeros((), device=dev)
+                    if with_codes:
+                        reg = 1e-4 * (torch.mean(torch.norm(codes[0], dim=0)) + torch.mean(torch.norm(codes[1], dim=0)) + torch.mean(torch.norm(codes[2], dim=0)))
+                        loss = loss + reg
+                    stats = torch.stack([loss0, loss1, reg, loss, helper.mse2psnr(loss0), helper.mse2psnr(loss1)]).detach()
+                else:
+                    loss, stats = helper.train_loss(rendered, target, codes, 1e-4)
+                    assert not stats.requires_grad and loss.shape == ()
+                (loss * 3.0).backward()
+                res[form] = (loss.detach(), stats[:6], rc.grad, rf.grad, [c.grad for c in codes])
+            t, f = res["torch"], res["fused"]
+            torch.testing.assert_close(f[0], t[0], rtol=2e-6, atol=0)
+            torch.testing.assert_close(f[1], t[1], rtol=2e-6, atol=2e-5)
+            for a, b in zip((f[2], f[3]) + tuple(f[4]), (t[2], t[3]) + tuple(t[4])):
+                torch.testing.assert_close(a, b, rtol=1e-6, atol=0)
+            if with_codes:
+                assert f[4][0][0, 5].item() == 0.0
+    # one level (num_levels = 1): loss0 = 0, no coarse gradient
+    rf = cases[1][1].clone().requires_grad_(True)
+    loss, stats = helper.train_loss([(rf, None, None)], cases[1][2])
+    loss.backward()
+    torch.testing.assert_close(loss.detach(), helper.img2mse(rf.detach(), cases[1][2]), rtol=2e-6, atol=0)
+    assert stats[0].item() == 0.0 and torch.isfinite(rf.grad).all()
+
+
 # ------------------------------------------------------------------ R3
 def test_sample_along_rays_bit_exact(ops, dev, golden):
     g = golden("g2_sample_along_rays")

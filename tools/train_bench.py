@@ -23,12 +23,14 @@ def main():
     ap.add_argument("--no-fwd-overlap", action="store_true", help="training forward on the caller's stream only (A/B of the two ray halves on two streams)")
     ap.add_argument("--no-fwd-merge", action="store_true", help="training forward without the merged coarse(A) | fine(A)+coarse(B) | fine(B) launches (round 4 default)")
     ap.add_argument("--no-bwd-merge", action="store_true", help="one backward-chain launch per level (round 3) instead of the merged two-segment launch")
+    ap.add_argument("--torch-loss", action="store_true", help="the loss lines as torch ops (~47 launches) instead of helper.train_loss")
     ap.add_argument("--late-heads", action="store_true", help="every head reduction behind the chain (round 4) instead of the chain-independent ones beside it")
     ap.add_argument("--articulated", action="store_true", help="NeRF_AE_Art + CodeLibraryArticulated (BASELINE config 5 per GPU)")
     ap.add_argument("--foreach-adam", action="store_true", help="torch.optim.Adam's default foreach form instead of fused=True (the harness's choice on a GPU since round 5)")
     args = ap.parse_args()
     import aon_amd.synthetic as syn
     from aon_amd import ops
+    from aon_amd.models.vanilla_nerf.helper import train_loss
     from aon_amd.models.vanilla_nerf.model import NeRF
 
     dev = torch.device("cuda:0")
@@ -69,11 +71,15 @@ def main():
         if lib is not None:
             latents = lib(batch)
             out = model(rays, True, True, syn.NEAR, syn.FAR, latents)
-            reg = sum(torch.mean(torch.norm(latents[k], dim=0)) for k in ("density", "color", "articulation"))
+            codes = (latents["density"], latents["color"], latents["articulation"])
         else:
             out = model(rays, True, True, syn.NEAR, syn.FAR)
-            reg = 0.0
-        loss = torch.mean((out[0][0] - target) ** 2) + torch.mean((out[1][0] - target) ** 2) + 1e-4 * reg
+            codes = ()
+        if args.torch_loss:
+            reg = sum(torch.mean(torch.norm(c, dim=0)) for c in codes) if codes else 0.0
+            loss = torch.mean((out[0][0] - target) ** 2) + torch.mean((out[1][0] - target) ** 2) + 1e-4 * reg
+        else:
+            loss, _ = train_loss(out, target, codes, 1e-4)   # the harness's loss lines in two launches (helper.train_loss)
         loss.backward()
         opt.step()
         return loss
