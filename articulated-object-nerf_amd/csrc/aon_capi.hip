@@ -14,7 +14,8 @@
 namespace aon {
 hipError_t launch_pack_vanilla(const float* const* params, float* packed, hipStream_t stream, int pos_levels = 10, int view_levels = 4);
 hipError_t launch_mlp_fwd(const char* packed, const float* rays_o, const float* rays_d, const float* viewdirs,
-                          const float* t_vals, int64_t n_rays, int S, float* raw, hipStream_t stream);
+                          const float* t_vals, int64_t n_rays, int S, float* raw, hipStream_t stream, const float* view_bias = nullptr);
+hipError_t launch_view_bias(const char* packed, const float* viewdirs, int64_t n_rays, float* out, hipStream_t stream);
 hipError_t launch_mlp_fwd_enc(const char* packed, const float* samples_enc, const float* viewdirs_enc, int64_t n_rays,
                               int S, float* raw, hipStream_t stream);
 hipError_t launch_pack_art(const float* const* params, float* packed, hipStream_t stream, int pos_levels = 10, int view_levels = 4);
@@ -29,7 +30,7 @@ int64_t art_stream_bytes();
 int64_t art_small_bytes();
 hipError_t launch_mlp_fwd_train(const char* packed, const float* rays_o, const float* rays_d, const float* viewdirs,
                                 const float* t_vals, int64_t n_rays, int S, float* raw, float* planes, void* masks,
-                                hipStream_t stream, int64_t np_total = 0);
+                                hipStream_t stream, int64_t np_total = 0, const float* view_bias = nullptr);
 hipError_t launch_composite_bwd(const float* raw, const float* t_vals, const float* dirs, const float* g_rgb, const float* g_acc,
                                 const float* g_depth, int64_t n_rays, int S, int white_bkgd, const ActParams& ap, float* d_raw,
                                 hipStream_t stream);
@@ -206,6 +207,7 @@ struct Ws {
   float* t_f;   // n*Sf
   float* raw;   // n*Sf*4 (coarse raw uses the first n*Sc*4)
   float* coords; float* enc; float* venc;   // other_degrees only: n*Sf*3, n*Sf*63, n*27
+  float* vbias;   // n*128: the level's per-ray view bias (vanilla, folded form; launch_view_bias) -- both levels in turn
   int64_t bytes;
 };
 
@@ -220,6 +222,8 @@ Ws carve(char* base, int64_t n, const Geo& g) {
     w.coords = reinterpret_cast<float*>(base + off); off += align_up(n * g.Sf * 12, 256);
     w.enc = reinterpret_cast<float*>(base + off); off += align_up(n * g.Sf * (int64_t)aon::kPosEnc * 4, 256);
     w.venc = reinterpret_cast<float*>(base + off); off += align_up(n * (int64_t)aon::kViewEnc * 4, 256);
+  } else {
+    w.vbias = reinterpret_cast<float*>(base + off); off += align_up(n * (int64_t)aon::kCondWidth * 4, 256);
   }
   w.bytes = off;
   return w;
@@ -261,6 +265,14 @@ int aon_train_loss_bwd(const float* rgb_coarse, const float* rgb_fine, const flo
     if (latents_host[k] && (!latent_len_host || latent_len_host[k] <= 0)) return fail(AON_E_INVALID, "aon_train_loss_bwd: bad latent length");
   return check(aon::launch_train_loss(true, rgb_coarse, rgb_fine, target, n, latents_host, latent_len_host, reg_scale, nullptr, nullptr, grad_loss, d_rgb_coarse, d_rgb_fine,
                                       d_latents_host, (hipStream_t)stream), "aon_train_loss_bwd");
+}
+
+int aon_view_bias(const void* packed, const float* viewdirs, int64_t n_rays, float* view_bias, void* stream) {
+  if (n_rays < 0) return fail(AON_E_INVALID, "aon_view_bias: bad size");
+  if (n_rays == 0) return AON_OK;
+  if (!packed || !viewdirs || !view_bias) return fail(AON_E_INVALID, "aon_view_bias: null pointer");
+  if (aon::stream_form(packed) != aon::kFormFolded) return fail(AON_E_INVALID, "aon_view_bias: the stream was packed in the literal form (aon_set_bottleneck_fold)");
+  return check(aon::launch_view_bias(static_cast<const char*>(packed), viewdirs, n_rays, view_bias, (hipStream_t)stream), "aon_view_bias");
 }
 
 int aon_ray_directions(int H, int W, float focal, float* directions, void* stream) {
@@ -661,6 +673,10 @@ int64_t aon_render_workspace_bytes(int64_t n_rays) { return aon_render_workspace
 
 // Whole-path orchestration shared by the vanilla and the articulated network (NeRF.forward, model.py:147-199;
 // NeRF_AE_Art.forward, model_autodecoder.py:278-337): only the MLP launch and the output activation differ.
+// Round 5: whole-path calls of the vanilla network in its folded form hand the view layer b' + W_v0[:, 256:] ve as a per-ray bias
+// (launch_view_bias) instead of running the view-encoding chunk per sample -- same bits (aon_common.h).  0: the chunk form.
+std::atomic<int> g_view_bias{1};
+
 struct NetRef {
   bool articulated;
   const void* packed;
@@ -680,10 +696,15 @@ static hipError_t launch_net(const NetRef& net, const float* o, const float* d, 
     MlpTimer timer(stream, n * S);
     return aon::launch_mlp_fwd_enc(static_cast<const char*>(net.packed), w->enc, w->venc, n, S, raw, stream);
   }
+  const float* vbias = nullptr;
+  if (!net.articulated && w && w->vbias && g_view_bias.load(std::memory_order_relaxed) != 0 && aon::stream_form(net.packed) == aon::kFormFolded) {
+    if (hipError_t e = aon::launch_view_bias(static_cast<const char*>(net.packed), v, n, w->vbias, stream); e != hipSuccess) return e;
+    vbias = w->vbias;
+  }
   MlpTimer timer(stream, n * S);
   if (net.articulated)
     return aon::launch_art_mlp_fwd(static_cast<const char*>(net.packed), net.small, o, d, v, t, n, S, raw, stream);
-  return aon::launch_mlp_fwd(static_cast<const char*>(net.packed), o, d, v, t, n, S, raw, stream);
+  return aon::launch_mlp_fwd(static_cast<const char*>(net.packed), o, d, v, t, n, S, raw, stream, vbias);
 }
 
 static int render_impl(const char* who, const NetRef& coarse, const NetRef& fine, const float* rays_o, const float* rays_d,
@@ -710,8 +731,8 @@ static int render_impl(const char* who, const NetRef& coarse, const NetRef& fine
   // largest chunk the workspace admits
   int64_t chunk = n_rays;
   if (carve(nullptr, chunk, g).bytes > workspace_bytes) {
-    const int64_t per_ray = (int64_t)(g.Sc + g.Sc + g.Sf + 4 * g.Sf + (g.other_degrees ? (3 + aon::kPosEnc) * g.Sf + aon::kViewEnc : 0)) * 4;
-    const int64_t slack = g.other_degrees ? 7 * 256 : 4 * 256;
+    const int64_t per_ray = (int64_t)(g.Sc + g.Sc + g.Sf + 4 * g.Sf + (g.other_degrees ? (3 + aon::kPosEnc) * g.Sf + aon::kViewEnc : aon::kCondWidth)) * 4;
+    const int64_t slack = g.other_degrees ? 7 * 256 : 5 * 256;
     chunk = (workspace_bytes - slack) / per_ray;
     while (chunk > 0 && carve(nullptr, chunk, g).bytes > workspace_bytes) --chunk;
     if (chunk < 1) return fail(AON_E_WORKSPACE, "render: workspace smaller than aon_render_workspace_bytes(1)");
@@ -796,6 +817,7 @@ struct TrainLevel {
   float* planes;   // rows*Np
   char* masks;     // mask_layers*Np*32
   float* coords; float* enc; float* venc;   // other encoding degrees only: n*S*3, n*S*63, n*27 (forward-only temporaries)
+  float* vbias;    // vanilla network at the default degrees: n*128, the level's per-ray view bias (forward-only temporary)
   int S; int64_t Np;
 };
 // What the forward leaves for the backward (caller-owned, pinned by the autograd graph): per level t, raw, planes, ReLU bits.
@@ -840,6 +862,7 @@ TrainWs carve_train(char* base, int64_t n, bool art, int num_levels, const Geo& 
       w.lvl[l].enc = reinterpret_cast<float*>(take(n * S * (int64_t)aon::kPosEnc * 4));
       w.lvl[l].venc = reinterpret_cast<float*>(take(n * (int64_t)aon::kViewEnc * 4));
     }
+    if (!g.other_degrees && !art) w.lvl[l].vbias = reinterpret_cast<float*>(take(n * (int64_t)aon::kCondWidth * 4));
   }
   w.w_c = reinterpret_cast<float*>(take(n * g.Sc * 4));
   w.bytes = off;
@@ -1010,6 +1033,11 @@ int train_fwd_impl(const char* who, bool art, const TrainNet* nets, const float*
     if ((art && forms_differ(nets[l].packed_fwd, nets[l].small)) || forms_differ(nets[l].packed_fwd, nets[0].packed_fwd))
       return fail(AON_E_INVALID, "train forward: the levels' streams / per-call blocks were made in different forms (aon_set_bottleneck_fold changed in between)");
   const int64_t rows = art ? aon::kAPlRows : aon::kPlRows;
+  // the vanilla network's view-encoding term as a per-ray bias (aon_set_view_bias): both levels' biases of the whole batch up front
+  const bool use_vb = !art && !g.other_degrees && g_view_bias.load(std::memory_order_relaxed) != 0 && aon::stream_form(nets[0].packed_fwd) == aon::kFormFolded;
+  if (use_vb)
+    for (int l = 0; l < num_levels; ++l)
+      if (int rc = check(aon::launch_view_bias(static_cast<const char*>(nets[l].packed_fwd), viewdirs, n, w.lvl[l].vbias, stream), who)) return rc;
 
   // Both levels of the ray range [r0, r0 + nk) on stream `st`.  r0 is a multiple of 128, so the range's samples start on a pass
   // boundary at both levels: its planes / decision bits / raw records are the whole batch's buffers at an offset, the slot stride of
@@ -1048,7 +1076,8 @@ int train_fwd_impl(const char* who, bool art, const TrainNet* nets, const float*
         MlpTimer timer(st, nk * L.S);
         rc = check(art ? aon::launch_art_mlp_fwd_train(static_cast<const char*>(nets[l].packed_fwd), nets[l].small, o, d, v, t, nk, L.S, raw, planes, masks,
                                                        st, L.Np)
-                       : aon::launch_mlp_fwd_train(static_cast<const char*>(nets[l].packed_fwd), o, d, v, t, nk, L.S, raw, planes, masks, st, L.Np), who);
+                       : aon::launch_mlp_fwd_train(static_cast<const char*>(nets[l].packed_fwd), o, d, v, t, nk, L.S, raw, planes, masks, st, L.Np,
+                                                   use_vb ? L.vbias + r0 * aon::kCondWidth : nullptr), who);
       }
       if (rc) return rc;
       if (l == 0 && fuse) {
@@ -1076,7 +1105,8 @@ int train_fwd_impl(const char* who, bool art, const TrainNet* nets, const float*
         const TrainLevel& L = w.lvl[l];
         const int64_t s0 = r.r0 * L.S;
         return aon::TrainSeg{static_cast<const char*>(nets[l].packed_fwd), nets[l].small, rays_o + r.r0 * 3, rays_d + r.r0 * 3, viewdirs + r.r0 * 3,
-                             L.t + s0, r.nk, L.S, L.raw + s0 * 4, L.planes + s0 * rows, L.masks + s0 * 32, L.Np};
+                             L.t + s0, r.nk, L.S, L.raw + s0 * 4, L.planes + s0 * rows, L.masks + s0 * 32, L.Np,
+                             use_vb ? L.vbias + r.r0 * aon::kCondWidth : nullptr};
       };
       auto mlp = [&](const aon::TrainSeg* segs, int ns) {
         int64_t samples = 0;
@@ -1156,6 +1186,11 @@ int aon_stream_is_folded(const void* packed) { return aon::stream_form(packed) =
 
 int aon_set_bwd_overlap(int on) {
   g_bwd_overlap.store(on == 2 ? 2 : (on ? 1 : 0), std::memory_order_relaxed);
+  return AON_OK;
+}
+
+int aon_set_view_bias(int on) {
+  g_view_bias.store(on ? 1 : 0, std::memory_order_relaxed);
   return AON_OK;
 }
 

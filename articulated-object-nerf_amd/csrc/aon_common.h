@@ -95,10 +95,13 @@ constexpr int64_t kStreamBytes = chunk_offset(kNumChunks);  // 2,375,680 B
 //   W_v0[:, :256] (W_b h + b_b) + W_v0[:, 256:] ve + b_v0  =  (W_v0[:, :256] W_b) h + W_v0[:, 256:] ve + (W_v0[:, :256] b_b + b_v0):
 // ONE 256 -> 128 layer W' = W_v0[:, :256] W_b where the literal form runs 256 -> 256 then 256 -> 128 -- 65,536 of the network's 593,408
 // MACs per sample (11.0 %).  W' and b' are evaluated in fp64 from the fp32 parameters at pack time and rounded once
-// (aon_fold.hip).  Chunks 0 .. 59 are the literal stream's; then 8 small chunks of W' and the view-encoding chunk.  The buffer keeps the
+// (aon_fold.hip).  Chunks 0 .. 59 are the literal stream's; then the view-encoding chunk and 8 small chunks of W'.  The buffer keeps the
 // literal size: the small block stays at kStreamBytes, and the 256 KiB between the end of the folded stream and the small block hold
 // W' (128 x 256) and b' (128) for the pack kernel.  Which form a buffer holds is remembered per pointer (stream_form, aon_fold.hip).
-constexpr int kChFView = 60;        // 8 hidden (W') + 1 view-enc, 4 output tiles each
+// The view-encoding chunk comes FIRST in the view layer: b' + W_v0[:, 256:] ve, the head of every accumulation chain, is a constant of
+// the RAY, and the whole-path calls hand it to the kernel as a per-ray bias (view_bias_kernel: the same fused multiply-adds in the same
+// order, so both forms give the same bits) instead of 56 MFMAs, 12 sines and a 16 KiB chunk per 128-sample pass.
+constexpr int kChFView = 60;        // 1 view-enc + 8 hidden (W'), 4 output tiles each
 constexpr int kNumChunksF = 69;
 __host__ __device__ constexpr int chunk_bytes_f(int c) { return c < kChFView ? kBigChunkBytes : kSmallChunkBytes; }
 __host__ __device__ constexpr int64_t chunk_offset_f(int c) {
@@ -192,6 +195,7 @@ struct TrainSeg {
   float* raw;              // (n_rays * S, 4)
   float* planes; void* masks;   // the range's offsets into the level's planes / decision bits
   int64_t np_total;        // padded samples of the WHOLE level (slot stride of the decision bits); 0: this range alone
+  const float* view_bias = nullptr;   // vanilla, folded form: (n_rays, 128) per-ray bias of the view layer (launch_view_bias), or null
 };
 
 // ------------------------------------------------------------------------------------------------

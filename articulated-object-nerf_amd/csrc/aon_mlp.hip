@@ -30,12 +30,20 @@ struct VanillaNet {
   static constexpr int kNumChunks = aon::kNumChunks;
   static constexpr int chunk_bytes(int c) { return aon::chunk_bytes(c); }
 };
-// bottleneck_layer folded into views_linear[0] (aon_common.h): chunks 0 .. 59 of the literal stream, 8 small chunks of W', the view-encoding chunk
+// bottleneck_layer folded into views_linear[0] (aon_common.h): chunks 0 .. 59 of the literal stream, the view-encoding chunk, 8 small chunks of W'
 struct VanillaFoldNet {
   static constexpr int kSlotBytes = kPairSlotBytes;
   static constexpr bool kPair = true;
   static constexpr int kNumChunks = aon::kNumChunksF;
   static constexpr int chunk_bytes(int c) { return aon::chunk_bytes_f(c); }
+};
+// ... with the view-encoding term as a per-ray bias: the same buffer without its chunk 60 (chunk c >= 60 here is chunk c + 1 there)
+struct VanillaFoldVbNet {
+  static constexpr int kSlotBytes = kPairSlotBytes;
+  static constexpr bool kPair = true;
+  static constexpr int kNumChunks = aon::kNumChunksF - 1;
+  static constexpr int chunk_bytes(int c) { return aon::chunk_bytes_f(c < kChFView ? c : c + 1); }
+  static constexpr int skip_before(int c) { return c == kChFView ? kSmallChunkBytes : 0; }
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -77,7 +85,9 @@ __global__ void pack_vanilla_kernel(PackArgs a, float* __restrict__ packed, int 
   } else {
     const int64_t i2 = idx - (int64_t)nbig * (kBigChunkBytes / 4);
     c = nbig + (int)(i2 / (kSmallChunkBytes / 4)); r = (int)(i2 % (kSmallChunkBytes / 4)); nt = 4;
-    if constexpr (FOLD) c += kChView - kChFView;   // the folded view chunks take the literal view layer's branches below, with W' for the hidden columns
+    // the folded view chunks take the literal view layer's branches below, with W' for the hidden columns; the view-encoding chunk is the
+    // FIRST of the folded view layer (aon_common.h), the last of the literal one
+    if constexpr (FOLD) c = c == kChFView ? kChView + 8 : c - 1 + (kChView - kChFView);
   }
   const int cc = r & 3, lane = (r >> 2) & 63, rest = r >> 8;
   const int tp = rest % nt, q = rest / nt;
@@ -121,6 +131,7 @@ struct MlpSeg {
   float* planes;             // [TRAIN] kPlRows x Np activation planes, step-major (aon_mlp_core.h)
   u32x4* masks;              // [TRAIN] kMaskLayers x (Np*2) ReLU bit masks
   int64_t Np;                // npass * 128
+  const float* view_bias;    // [VB] (n_rays,128): b' + W_v0[:, 256:] ve of the ray (view_bias_kernel)
 };
 struct MlpArgs {
   MlpSeg seg[2];
@@ -132,9 +143,13 @@ constexpr int kLdsBytes = kRingBytes + (int)kSmallBytes;
 // TRAIN additionally stores every layer's input/output activations as step-major planes (aon_mlp_core.h) for the backward pass.
 // FOLD: the stream is the folded form -- the view layer reads the post-ReLU layer-7 output through W' (aon_common.h), there is no
 // bottleneck layer (and, [TRAIN], no bottleneck rows in the planes: rows kPlBot .. kPlBot + 255 stay unwritten).
-template <bool ENC_IN_KERNEL, bool TRAIN, bool FOLD>
+// VB (folded form only): the view layer's accumulators start from the ray's b' + W_v0[:, 256:] ve, fetched from `view_bias` while the last
+// chunk of layer 7 runs, instead of from b' followed by the view-encoding chunk -- same bits (aon_common.h), 56 MFMAs, 12 sines and a
+// 16 KiB chunk fewer per pass; the inference kernel no longer carries the 16 registers of the view encoding through the trunk.
+template <bool ENC_IN_KERNEL, bool TRAIN, bool FOLD, bool VB = false>
 __global__ void __launch_bounds__(256) mlp_fwd_kernel(MlpArgs args) {
-  using Net = std::conditional_t<FOLD, VanillaFoldNet, VanillaNet>;
+  static_assert(FOLD || !VB, "the per-ray view bias belongs to the folded form");
+  using Net = std::conditional_t<VB, VanillaFoldVbNet, std::conditional_t<FOLD, VanillaFoldNet, VanillaNet>>;
   // <false, true>: training on caller-encoded inputs (other encoding degrees in the padded 63 / 27-slot layout): where the
   // in-kernel form re-encodes from x[] / vd[], this one re-reads the encodings.
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -195,11 +210,13 @@ __global__ void __launch_bounds__(256) mlp_fwd_kernel(MlpArgs args) {
         vd[a] = sg.viewdirs[ray * 3 + a];
       }
       encode_pos(x, h, E);
-      encode_view(vd, h, V);
+      if constexpr (!VB || TRAIN) encode_view(vd, h, V);   // [VB] only the training planes still want the view encoding
     } else {
       load_pos_enc(sg.samples_enc + gc * kPosEnc, h, E);
-      load_view_enc(sg.viewdirs_enc + ray * kViewEnc, h, V);
+      if constexpr (!VB || TRAIN) load_view_enc(sg.viewdirs_enc + ray * kViewEnc, h, V);
     }
+    int ray32 = (int)ray;   // [VB] the one value of the prologue that is still needed at the view layer
+    (void)ray32;
 
     PlaneIO io{};
     unsigned moff = 0;
@@ -257,34 +274,62 @@ __global__ void __launch_bounds__(256) mlp_fwd_kernel(MlpArgs args) {
     relu_tiles(Y);
     // L6, L7
     mw = u32x4{0u, 0u, 0u, 0u}; init_bias(X, sm + kSmBias + 6 * 256, h); dense_layer<Net, kChL6, 8, 8>(p, Y, X, consume(Y, plane_h(5), mw, true)); put_mask(mw, 5); relu_tiles(X);
-    mw = u32x4{0u, 0u, 0u, 0u}; init_bias(Y, sm + kSmBias + 7 * 256, h); dense_layer<Net, kChL7, 8, 8>(p, X, Y, consume(X, plane_h(6), mw, true)); put_mask(mw, 6); relu_tiles(Y);
+    f32x16 Z[4];
+    mw = u32x4{0u, 0u, 0u, 0u}; init_bias(Y, sm + kSmBias + 7 * 256, h);
+    if constexpr (VB) {
+      // the ray's view bias straight into the view layer's accumulators, one 16-byte load per side slot of layer 7's LAST chunk (tiles 0 .. 6
+      // of X are dead by then): a chunk of MFMAs (3.4 us) between the loads and their first use
+      asm volatile("" : "+v"(ray32));
+      const float* vb = sg.view_bias + (int64_t)ray32 * kCondWidth + 4 * h;
+      auto l7_side = [&](int j) {
+        auto base = consume(X, plane_h(6), mw, true)(j);
+        return [&, base, j, vb](int i) {
+          base(i);
+          if (j == 7 && i < 16) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(vb + 32 * (i >> 2) + 8 * (i & 3));
+            Z[i >> 2][4 * (i & 3)] = v[0]; Z[i >> 2][4 * (i & 3) + 1] = v[1]; Z[i >> 2][4 * (i & 3) + 2] = v[2]; Z[i >> 2][4 * (i & 3) + 3] = v[3];
+          }
+        };
+      };
+      dense_layer<Net, kChL7, 8, 8>(p, X, Y, l7_side);
+    } else {
+      dense_layer<Net, kChL7, 8, 8>(p, X, Y, consume(X, plane_h(6), mw, true));
+    }
+    put_mask(mw, 6); relu_tiles(Y);
     // density head (model.py:105) on the post-ReLU layer-7 output
     float sigma = head_partial<8>(Y, sm + kSmWSigma, h);
     sigma = sigma + __shfl_xor(sigma, 32) + sm[kSmBSigma];
-    f32x16 Z[4];
     constexpr int kChV = FOLD ? kChFView : kChView;
+    auto reencode_view = [&]() {   // [TRAIN] the view encoding again (same function, same bits): 16 registers not held across the trunk
+      if constexpr (TRAIN && ENC_IN_KERNEL) {
+        asm volatile("" : "+v"(vd[0]), "+v"(vd[1]), "+v"(vd[2]));
+        encode_view(vd, h, V);
+      }
+      if constexpr (TRAIN && !ENC_IN_KERNEL) {
+        int64_t rq = ray;
+        asm volatile("" : "+v"(rq));
+        load_view_enc(sg.viewdirs_enc + rq * kViewEnc, h, V);
+      }
+    };
     if constexpr (FOLD) {
       // bottleneck (no activation, model.py:109) and the view layer's hidden columns (model.py:110-116) as ONE layer W' = W_v0[:, :256] W_b,
-      // b' = W_v0[:, :256] b_b + b_v0 on the post-ReLU layer-7 output
-      mw = u32x4{0u, 0u, 0u, 0u}; init_bias(Z, sm + kSmBiasView, h);
-      dense_layer<Net, kChV, 8, 4>(p, Y, Z, consume(Y, plane_h(7), mw, true)); put_mask(mw, 7);
+      // b' = W_v0[:, :256] b_b + b_v0 on the post-ReLU layer-7 output; the view-encoding columns FIRST (chunk form) or already in Z (VB)
+      mw = u32x4{0u, 0u, 0u, 0u};
+      if constexpr (!VB) {
+        init_bias(Z, sm + kSmBiasView, h);
+        reencode_view();
+        chunk_mma<Net, kChV, 4, 14>(p, V, Z);
+      }
+      dense_layer<Net, kChV + (VB ? 0 : 1), 8, 4>(p, Y, Z, consume(Y, plane_h(7), mw, true)); put_mask(mw, 7);
     } else {
       // bottleneck, no activation (model.py:109)
       mw = u32x4{0u, 0u, 0u, 0u}; init_bias(X, sm + kSmBiasBott, h); dense_layer<Net, kChBott, 8, 8>(p, Y, X, consume(Y, plane_h(7), mw, true)); put_mask(mw, 7);
       // view branch: cat[bottleneck(256), viewenc(27)] -> 128, ReLU (model.py:110-116)
       init_bias(Z, sm + kSmBiasView, h);
       dense_layer<Net, kChV, 8, 4>(p, X, Z, consume(X, kPlBot, mw, false));
+      reencode_view();
+      chunk_mma<Net, kChV + 8, 4, 14>(p, V, Z);
     }
-    if constexpr (TRAIN && ENC_IN_KERNEL) {
-      asm volatile("" : "+v"(vd[0]), "+v"(vd[1]), "+v"(vd[2]));
-      encode_view(vd, h, V);
-    }  // likewise: 16 registers not held across the trunk
-    if constexpr (TRAIN && !ENC_IN_KERNEL) {
-      int64_t rq = ray;
-      asm volatile("" : "+v"(rq));
-      load_view_enc(sg.viewdirs_enc + rq * kViewEnc, h, V);
-    }
-    chunk_mma<Net, kChV + 8, 4, 14>(p, V, Z);
     relu_tiles(Z);
     if constexpr (TRAIN) {  // the view layer's output feeds the rgb head on the VALU: no consuming chunk, 64 values stored here
       *mask_ptr(sg.masks, sg.Np, 8, moff) = relu_mask_bits(Z);   // burst form: already in the stored bit layout
@@ -340,15 +385,15 @@ int num_cus() {  // CUs of the CURRENT device, cached per device ordinal (ops.py
   return cus;
 }
 
-template <bool ENC, bool TRAIN, bool FOLD>
+template <bool ENC, bool TRAIN, bool FOLD, bool VB = false>
 static hipError_t launch_mlp_tf(const MlpArgs& args, hipStream_t stream) {
   static DeviceOnce lds_once;  // one per template instance
-  if (hipError_t e = set_max_lds(&mlp_fwd_kernel<ENC, TRAIN, FOLD>, kLdsBytes, lds_once); e != hipSuccess) return e;
+  if (hipError_t e = set_max_lds(&mlp_fwd_kernel<ENC, TRAIN, FOLD, VB>, kLdsBytes, lds_once); e != hipSuccess) return e;
   const int g_num_cus = num_cus();
   if (g_num_cus <= 0) return hipErrorInvalidDevice;
   const int grid = args.npass_total < g_num_cus ? args.npass_total : g_num_cus;
   if (grid <= 0) return hipSuccess;
-  mlp_fwd_kernel<ENC, TRAIN, FOLD><<<dim3(grid), dim3(256), kLdsBytes, stream>>>(args);
+  mlp_fwd_kernel<ENC, TRAIN, FOLD, VB><<<dim3(grid), dim3(256), kLdsBytes, stream>>>(args);
   return hipGetLastError();
 }
 
@@ -357,14 +402,69 @@ template <bool ENC, bool TRAIN>
 static hipError_t launch_mlp_t(const MlpArgs& args, hipStream_t stream) {
   const int form = stream_form(args.seg[0].packed);
   if (args.seg[1].npass > 0 && stream_form(args.seg[1].packed) != form) return hipErrorInvalidValue;
+  // the per-ray view bias: every segment of the launch or none (whole-path calls on the in-kernel encodings; folded form only)
+  const bool vb = args.seg[0].view_bias != nullptr;
+  if (args.seg[1].npass > 0 && (args.seg[1].view_bias != nullptr) != vb) return hipErrorInvalidValue;
+  if (vb && form != kFormFolded) return hipErrorInvalidValue;
+  if constexpr (ENC) {
+    if (vb) return launch_mlp_tf<ENC, TRAIN, true, true>(args, stream);
+  } else {
+    if (vb) return hipErrorInvalidValue;
+  }
   return form == kFormFolded ? launch_mlp_tf<ENC, TRAIN, true>(args, stream) : launch_mlp_tf<ENC, TRAIN, false>(args, stream);
 }
 
+// b' + W_v0[:, 256:] ve per ray, the head of the view layer's accumulation chains (aon_common.h): the fused multiply-adds the view-encoding
+// chunk performs, in its order -- register r = 0 .. 13 of the encoding tile, half-wave 0 then 1 (one v_mfma_f32_32x32x2_f32 step adds the
+// k = 0 product, then the k = 1 product) -- with the weights read from the packed chunk itself.  One workgroup serves eight rays.
+__global__ __launch_bounds__(256) void view_bias_kernel(const char* packed, const float* viewdirs, int64_t n_rays, float* out) {
+  __shared__ float enc[8][2][16];
+  const int tid = threadIdx.x;
+  const int64_t ray0 = (int64_t)blockIdx.x * 8;
+  if (tid < 16) {
+    const int64_t ray = ray0 + (tid >> 1);
+    if (ray < n_rays) {
+      float vd[3] = {viewdirs[ray * 3], viewdirs[ray * 3 + 1], viewdirs[ray * 3 + 2]};
+      f32x16 V;
+      encode_view(vd, tid & 1, V);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) enc[tid >> 1][tid & 1][r] = V[r];
+    }
+  }
+  const int row = tid & 127, tp = row >> 5;
+  const float* chunk = reinterpret_cast<const float*>(packed + chunk_offset_f(kChFView));
+  const float bias = reinterpret_cast<const float*>(packed + kStreamBytes)[kSmBiasView + row];
+  float w[14][2];
+#pragma unroll
+  for (int r = 0; r < 14; ++r)
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) w[r][hh] = chunk[((((r >> 2) * 4 + tp) * 64 + hh * 32 + (row & 31)) << 2) + (r & 3)];
+  __syncthreads();
+  for (int k = tid >> 7; k < 8; k += 2) {
+    const int64_t ray = ray0 + k;
+    if (ray >= n_rays) break;
+    float acc = bias;
+#pragma unroll
+    for (int r = 0; r < 14; ++r) {
+      acc = __builtin_fmaf(w[r][0], enc[k][0][r], acc);
+      acc = __builtin_fmaf(w[r][1], enc[k][1][r], acc);
+    }
+    out[ray * kCondWidth + row] = acc;
+  }
+}
+
+hipError_t launch_view_bias(const char* packed, const float* viewdirs, int64_t n_rays, float* out, hipStream_t stream) {
+  if (n_rays <= 0) return hipSuccess;
+  if (stream_form(packed) != kFormFolded) return hipErrorInvalidValue;
+  view_bias_kernel<<<dim3((unsigned)((n_rays + 7) / 8)), dim3(256), 0, stream>>>(packed, viewdirs, n_rays, out);
+  return hipGetLastError();
+}
+
 hipError_t launch_mlp_fwd(const char* packed, const float* rays_o, const float* rays_d, const float* viewdirs,
-                          const float* t_vals, int64_t n_rays, int S, float* raw, hipStream_t stream) {
+                          const float* t_vals, int64_t n_rays, int S, float* raw, hipStream_t stream, const float* view_bias) {
   MlpArgs args{};
   MlpSeg& a = args.seg[0];
-  a.packed = packed; a.rays_o = rays_o; a.rays_d = rays_d; a.viewdirs = viewdirs; a.t_vals = t_vals;
+  a.packed = packed; a.rays_o = rays_o; a.rays_d = rays_d; a.viewdirs = viewdirs; a.t_vals = t_vals; a.view_bias = view_bias;
   a.raw = raw; a.total = n_rays * S; a.S = S; a.npass = (int)((a.total + 127) / 128);
   args.seg[1] = a; args.seg[1].npass = 0; args.npass_total = a.npass;
   return launch_mlp_t<true, false>(args, stream);
@@ -377,8 +477,8 @@ hipError_t launch_mlp_fwd_train2(const TrainSeg* segs, int nsegs, hipStream_t st
 // (planes / masks / raw / t_vals already point at the range): the decision bits' slot stride is the whole batch's.
 hipError_t launch_mlp_fwd_train(const char* packed, const float* rays_o, const float* rays_d, const float* viewdirs,
                                 const float* t_vals, int64_t n_rays, int S, float* raw, float* planes, void* masks,
-                                hipStream_t stream, int64_t np_total) {
-  const TrainSeg one{packed, nullptr, rays_o, rays_d, viewdirs, t_vals, n_rays, S, raw, planes, masks, np_total};
+                                hipStream_t stream, int64_t np_total, const float* view_bias) {
+  const TrainSeg one{packed, nullptr, rays_o, rays_d, viewdirs, t_vals, n_rays, S, raw, planes, masks, np_total, view_bias};
   return launch_mlp_fwd_train2(&one, 1, stream);
 }
 
@@ -392,6 +492,7 @@ hipError_t launch_mlp_fwd_train2(const TrainSeg* segs, int nsegs, hipStream_t st
     a.packed = t.packed; a.rays_o = t.rays_o; a.rays_d = t.rays_d; a.viewdirs = t.viewdirs; a.t_vals = t.t_vals;
     a.raw = t.raw; a.total = t.n_rays * t.S; a.S = t.S; a.npass = (int)((a.total + 127) / 128);
     a.planes = t.planes; a.masks = static_cast<u32x4*>(t.masks); a.Np = t.np_total > 0 ? t.np_total : (int64_t)a.npass * 128;
+    a.view_bias = t.view_bias;
     args.npass_total += a.npass;
   }
   if (nsegs == 1) { args.seg[1] = args.seg[0]; args.seg[1].npass = 0; }

@@ -26,6 +26,11 @@ template <class Net> constexpr int dma_target(int C, int k) {
   return ((Net::kNumChunks & 1) && C == Net::kNumChunks - 1) ? k : (C + 2) % Net::kNumChunks;
 }
 
+// A net may leave a gap in its stream in front of a chunk (`static constexpr int skip_before(int c)`, bytes): the per-ray-bias form of the
+// folded vanilla network reads the same buffer as the chunk form and steps over the view-encoding chunk.
+template <class Net, class = void> struct NetSkip { static constexpr int at(int) { return 0; } };
+template <class Net> struct NetSkip<Net, std::void_t<decltype(Net::skip_before(0))>> { static constexpr int at(int c) { return Net::skip_before(c); } };
+
 struct Pipe {
   const char* stream;  // packed stream base (wave-uniform -> SGPR pair)
   const char* next_stream;  // stream of this workgroup's NEXT pass (round 4: a launch may carry two segments with different networks,
@@ -120,6 +125,9 @@ __device__ __forceinline__ unsigned acquire(Pipe& p) {
   asm volatile("" : "+s"(off));
   constexpr int n = dma_count<Net>(C);
   if constexpr (n > 0) {
+    static_assert(n == 1 || NetSkip<Net>::at(dma_target<Net>(C, n - 1)) == 0, "no gap in front of the second target of a two-target chunk");
+    static_assert(NetSkip<Net>::at(0) == 0 && NetSkip<Net>::at(1) == 0, "no gap in front of the first pair (pipe_init)");
+    if constexpr (NetSkip<Net>::at(dma_target<Net>(C, 0)) != 0) off += (unsigned)NetSkip<Net>::at(dma_target<Net>(C, 0));
     constexpr int last = dma_target<Net>(C, n - 1);
     constexpr int bytes = Net::chunk_bytes(dma_target<Net>(C, 0)) + (n > 1 ? Net::chunk_bytes(dma_target<Net>(C, 1)) : 0);
     p.issue_off = (last == Net::kNumChunks - 1) ? 0u : off + (unsigned)bytes;

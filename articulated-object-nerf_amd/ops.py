@@ -828,6 +828,21 @@ def set_fwd_overlap(on: bool) -> None:
     check(lib.aon_set_fwd_overlap(int(bool(on))), "aon_set_fwd_overlap")
 
 
+def set_view_bias(on: bool) -> None:
+    """Whole-path calls of the folded vanilla network: the view-encoding term as a per-ray bias (default on; same bits as the chunk form)."""
+    check(lib.aon_set_view_bias(int(bool(on))), "aon_set_view_bias")
+
+
+def view_bias(packed: torch.Tensor, viewdirs: torch.Tensor) -> torch.Tensor:
+    """(n,128) = b' + W_v0[:, 256:] pos_enc(viewdirs, 0, 4) of a folded vanilla stream: what the whole-path calls start the view layer from."""
+    v = _f32(viewdirs, "viewdirs")
+    n = v.numel() // 3
+    out = torch.empty((n, 128), dtype=torch.float32, device=v.device)
+    with torch.cuda.device(v.device):
+        check(lib.aon_view_bias(_ptr(packed), _ptr(v), n, _ptr(out), _stream()), "aon_view_bias")
+    return out
+
+
 def set_bwd_early_heads(on: bool) -> None:
     """Merged backward: the chain-independent head / bias reductions on a side stream beside the chain launch (default on; same bits)."""
     check(lib.aon_set_bwd_early_heads(int(bool(on))), "aon_set_bwd_early_heads")

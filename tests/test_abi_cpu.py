@@ -42,9 +42,9 @@ def test_argument_validation_without_gpu():
     assert lib.aon_pos_enc(None, 0, 0, 10, None, None) == 0
     assert lib.aon_mlp_fwd(None, None, None, None, None, 0, 65, None, None) == 0
     assert lib.aon_mlp_packed_bytes() == 2_375_680 + 3076 * 4
-    per_ray = (65 + 65 + 193 + 4 * 193) * 4
+    per_ray = (65 + 65 + 193 + 4 * 193 + 128) * 4     # t_c, w_c, t_f, raw, the per-ray view bias
     assert lib.aon_render_workspace_bytes(1000) >= 1000 * per_ray
-    assert lib.aon_render_workspace_bytes(1000) < 1000 * per_ray + 4 * 256 + 1
+    assert lib.aon_render_workspace_bytes(1000) < 1000 * per_ray + 5 * 256 + 1
 
 
 def test_ops_reject_cpu_tensors():
@@ -197,8 +197,8 @@ def test_constructor_option_entry_points_validate_without_gpu():
     assert lib.aon_render_workspace_bytes_ex(1000, C.byref(st)) == lib.aon_render_workspace_bytes(1000)
     assert lib.aon_train_workspace_bytes_ex(512, 1, 2, C.byref(st)) == lib.aon_train_workspace_bytes(512, 1, 2)
     st.num_coarse_samples, st.num_fine_samples = 32, 48
-    per_ray = (33 + 33 + 81 + 4 * 81) * 4
-    assert 1000 * per_ray <= lib.aon_render_workspace_bytes_ex(1000, C.byref(st)) <= 1000 * per_ray + 4 * 256
+    per_ray = (33 + 33 + 81 + 4 * 81 + 128) * 4
+    assert 1000 * per_ray <= lib.aon_render_workspace_bytes_ex(1000, C.byref(st)) <= 1000 * per_ray + 5 * 256
     assert lib.aon_train_workspace_bytes_ex(512, 0, 2, C.byref(st)) < lib.aon_train_workspace_bytes(512, 0, 2)
     st.num_coarse_samples = 1
     assert lib.aon_render_workspace_bytes_ex(1000, C.byref(st)) == -1 and b"num_coarse_samples" in lib.aon_last_error()

@@ -175,3 +175,50 @@ def test_form_is_a_property_of_the_buffer(ops, dev, nerf_sd):
         ws_out, ws, geo = ops.render_fwd_train(pf_fold, pf_fold, rays["rays_o"], rays["rays_d"], rays["viewdirs"], 2.0, 6.0, True, 2, None, None)
         g = [torch.zeros(70, 3, device=dev)] * 2
         ops.render_bwd(ws, [pb_lit, pb_lit], [pf_fold, pf_fold], rays["rays_d"], True, 2, g, [None, None], [None, None], geometry=geo)
+
+
+def test_per_ray_view_bias_gives_the_chunk_forms_bits(ops, dev, nerf_sd):
+    """Round 5: whole-path calls of the folded vanilla network start the view layer's accumulators from b' + W_v0[:, 256:] ve of the RAY
+    (aon_set_view_bias, default on) where the chunk form runs the view-encoding chunk per sample.  The per-ray kernel performs the
+    chunk's fused multiply-adds in the chunk's order, so the two forms -- and the stage-level MLP call, which keeps the chunk -- agree
+    bit for bit: inference and training forward, ragged ray counts, rays whose samples straddle wave tiles."""
+    import aon_amd.synthetic as syn
+    from aon_amd.models.vanilla_nerf.model import NeRF
+
+    ops.set_bottleneck_fold(True)
+    model = NeRF().to(dev)
+    model.load_state_dict(nerf_sd)
+    try:
+        for n in (1, 37, 640, 1500):
+            rays = {k: v.to(dev) for k, v in syn.random_rays(n, seed=60 + n).items()}
+            tr, u = syn.seeded_uniform(61, n, 65).to(dev), syn.seeded_uniform(62, n, 128).to(dev)
+            res = []
+            for on in (True, False):
+                ops.set_view_bias(on)
+                with torch.no_grad():
+                    det = model(rays, False, True, 2.0, 6.0)
+                model.zero_grad()
+                out = model(rays, True, True, 2.0, 6.0, t_rand=tr, u=u)
+                (out[0][0].sum() + out[1][0].sum()).backward()
+                res.append([x.detach().clone() for lvl in det + out for x in lvl] + [p.grad.clone() for p in model.parameters()])
+            for a, b in zip(*res):
+                assert torch.equal(a, b)
+        # the stage-level call (chunk form) against the same samples through the per-ray form of the whole path
+        ops.set_view_bias(True)
+        n = 300
+        rays = {k: v.to(dev) for k, v in syn.random_rays(n, seed=9).items()}
+        packed = model.fine_mlp.packed()
+        t = torch.sort(torch.rand(n, 65, generator=torch.Generator().manual_seed(4)) * 4 + 2, dim=-1).values.to(dev)
+        raw = ops.mlp_fwd(packed, rays["rays_o"], rays["rays_d"], rays["viewdirs"], t)
+        vb = ops.view_bias(packed, rays["viewdirs"])
+        # b' + W_v0[:, 256:] ve against torch in fp64: the kernel's 28-term fp32 chains stay within a few ulp of the exact value
+        p = dict(model.fine_mlp.named_parameters())
+        from oracle import nerf_oracle as orc2
+        venc = orc2.pos_enc(rays["viewdirs"].cpu(), 0, 4).double()
+        Wv, Wb = p["views_linear.0.weight"].detach().double().cpu(), p["bottleneck_layer.weight"].detach().double().cpu()
+        want = venc @ Wv[:, 256:].T + (Wv[:, :256] @ p["bottleneck_layer.bias"].detach().double().cpu() + p["views_linear.0.bias"].detach().double().cpu())
+        assert (vb.cpu().double() - want).abs().max().item() <= 2e-6 * max(1.0, want.abs().max().item())
+        assert raw.shape == (n, 65, 4) and torch.isfinite(raw).all()
+        del Wb
+    finally:
+        ops.set_view_bias(True)

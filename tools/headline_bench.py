@@ -18,6 +18,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--literal", action="store_true")
+    ap.add_argument("--no-view-bias", action="store_true", help="the view-encoding chunk per sample (round 5's first form) instead of the per-ray view bias")
     ap.add_argument("--tag", default=os.environ.get("AON_HIP_LIB", "default"))
     args = ap.parse_args()
     import aon_amd.synthetic as syn
@@ -26,6 +27,7 @@ def main():
 
     dev = torch.device("cuda:0")
     ops.set_bottleneck_fold(not args.literal)
+    ops.set_view_bias(not args.no_view_bias)
     H, W = 480, 640
     model = NeRF().to(dev)
     model.load_state_dict(syn.make_nerf_state_dict(seed=0, density_scale=30.0))
@@ -42,10 +44,11 @@ def main():
         dt = (time.perf_counter() - t0) / args.steps
         ms, launches, samples = ops.profile_end()
         del out
-    mac = 593_408 - (0 if args.literal else 65_536)
+    vb = not args.literal and not args.no_view_bias
+    mac = 593_408 - (0 if args.literal else 65_536) - (128 * 28 if vb else 0)   # (the chunk runs 14 two-deep steps: 28 columns incl. one of padding)
     ex = samples * mac * 2 / (ms * 1e-3) / 1e12
     lit = samples * 593_408 * 2 / (ms * 1e-3) / 1e12
-    print(json.dumps({"tag": args.tag, "fold": not args.literal, "rays_per_s": H * W / dt, "ms_per_frame": dt * 1e3,
+    print(json.dumps({"tag": args.tag, "fold": not args.literal, "view_bias": vb, "rays_per_s": H * W / dt, "ms_per_frame": dt * 1e3,
                       "mlp_ms_per_launch": ms / launches, "frac_executed": ex / 157.3, "frac_reference_literal": lit / 157.3}))
 
 

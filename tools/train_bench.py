@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--no-fwd-overlap", action="store_true", help="training forward on the caller's stream only (A/B of the two ray halves on two streams)")
     ap.add_argument("--no-fwd-merge", action="store_true", help="training forward without the merged coarse(A) | fine(A)+coarse(B) | fine(B) launches (round 4 default)")
     ap.add_argument("--no-bwd-merge", action="store_true", help="one backward-chain launch per level (round 3) instead of the merged two-segment launch")
+    ap.add_argument("--no-view-bias", action="store_true", help="vanilla: the view-encoding chunk per sample instead of the per-ray view bias")
     ap.add_argument("--torch-loss", action="store_true", help="the loss lines as torch ops (~47 launches) instead of helper.train_loss")
     ap.add_argument("--late-heads", action="store_true", help="every head reduction behind the chain (round 4) instead of the chain-independent ones beside it")
     ap.add_argument("--articulated", action="store_true", help="NeRF_AE_Art + CodeLibraryArticulated (BASELINE config 5 per GPU)")
@@ -38,6 +39,7 @@ def main():
     ops.set_fwd_merge(not args.no_fwd_merge)
     ops.set_bwd_merge(not args.no_bwd_merge)
     ops.set_bwd_early_heads(not args.late_heads)
+    ops.set_view_bias(not args.no_view_bias)
     ops.set_fwd_overlap(not args.no_fwd_overlap and not args.no_overlap)
     if os.environ.get("AON_FWD_PARTS"):
         from aon_amd import _lib
