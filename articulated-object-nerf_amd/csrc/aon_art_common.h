@@ -54,7 +54,9 @@ constexpr int kABwNumChunks = 108;
 // views_linear.0's 256 bottleneck columns, W' = W_v0[:, :256] W_b -- 65,536 of the 692,480 MACs per sample the un-folded kernels execute.
 // Forward stream: the eight bottleneck chunks are gone, every later chunk moves up by 8; views_linear.0's hidden chunks hold W' and
 // read the post-ReLU layer-7 output.  The per-call block's effective bias of views_linear.0 additionally carries W_v0[:, :256] b_b.
-constexpr int kAChFV0 = 72;    // W' : 8 hidden + 1 view-enc
+// views_linear.0's view-encoding chunk comes FIRST (as in the vanilla network, aon_common.h): its term and the effective bias are a constant
+// of the ray, handed to the whole-path kernels as a per-ray bias (ArtFoldVbNet: the same buffer without that chunk).
+constexpr int kAChFV0 = 72;    // W' : 1 view-enc + 8 hidden
 constexpr int kAChFV1 = 81;
 constexpr int kANumChunksF = 93;
 // Transposed stream: views_linear.0's four chunks hold W'^T (d H7 directly), the eight bottleneck chunks are gone.

@@ -23,7 +23,8 @@ hipError_t launch_prepare_art(const float* const* params, const float* shape, co
                               float* small, hipStream_t stream, int min_deg = 0, int pos_levels = 10, int view_levels = 4);
 hipError_t launch_art_mlp_fwd(const char* packed, const float* small, const float* rays_o, const float* rays_d,
                               const float* viewdirs, const float* t_vals, int64_t n_rays, int S, float* raw,
-                              hipStream_t stream);
+                              hipStream_t stream, const float* view_bias = nullptr);
+hipError_t launch_art_view_bias(const char* packed, const float* small, const float* viewdirs, int64_t n_rays, float* out, hipStream_t stream);
 hipError_t launch_art_mlp_fwd_pos(const char* packed, const float* small, const float* pos, const float* viewdirs_enc,
                                   int64_t n_rays, int S, float* raw, hipStream_t stream);
 int64_t art_stream_bytes();
@@ -53,7 +54,7 @@ hipError_t launch_vanilla_wgrad(const float* planes, const float* dplanes, const
                                 float* ws, hipStream_t stream, const WgAux* aux, const void* packed_bwd, int phase = 0);
 hipError_t launch_art_mlp_fwd_train(const char* packed, const float* small, const float* rays_o, const float* rays_d,
                                     const float* viewdirs, const float* t_vals, int64_t n_rays, int S, float* raw, float* planes,
-                                    void* masks, hipStream_t stream, int64_t np_total = 0);
+                                    void* masks, hipStream_t stream, int64_t np_total = 0, const float* view_bias = nullptr);
 hipError_t launch_art_mlp_fwd_train2(const TrainSeg* segs, int nsegs, hipStream_t stream);
 hipError_t launch_mlp_fwd_train2(const TrainSeg* segs, int nsegs, hipStream_t stream);
 int num_cus();
@@ -697,13 +698,15 @@ static hipError_t launch_net(const NetRef& net, const float* o, const float* d, 
     return aon::launch_mlp_fwd_enc(static_cast<const char*>(net.packed), w->enc, w->venc, n, S, raw, stream);
   }
   const float* vbias = nullptr;
-  if (!net.articulated && w && w->vbias && g_view_bias.load(std::memory_order_relaxed) != 0 && aon::stream_form(net.packed) == aon::kFormFolded) {
-    if (hipError_t e = aon::launch_view_bias(static_cast<const char*>(net.packed), v, n, w->vbias, stream); e != hipSuccess) return e;
+  if (w && w->vbias && g_view_bias.load(std::memory_order_relaxed) != 0 && aon::stream_form(net.packed) == aon::kFormFolded) {
+    const hipError_t e = net.articulated ? aon::launch_art_view_bias(static_cast<const char*>(net.packed), net.small, v, n, w->vbias, stream)
+                                         : aon::launch_view_bias(static_cast<const char*>(net.packed), v, n, w->vbias, stream);
+    if (e != hipSuccess) return e;
     vbias = w->vbias;
   }
   MlpTimer timer(stream, n * S);
   if (net.articulated)
-    return aon::launch_art_mlp_fwd(static_cast<const char*>(net.packed), net.small, o, d, v, t, n, S, raw, stream);
+    return aon::launch_art_mlp_fwd(static_cast<const char*>(net.packed), net.small, o, d, v, t, n, S, raw, stream, vbias);
   return aon::launch_mlp_fwd(static_cast<const char*>(net.packed), o, d, v, t, n, S, raw, stream, vbias);
 }
 
@@ -817,7 +820,7 @@ struct TrainLevel {
   float* planes;   // rows*Np
   char* masks;     // mask_layers*Np*32
   float* coords; float* enc; float* venc;   // other encoding degrees only: n*S*3, n*S*63, n*27 (forward-only temporaries)
-  float* vbias;    // vanilla network at the default degrees: n*128, the level's per-ray view bias (forward-only temporary)
+  float* vbias;    // n*128, the level's per-ray view bias (forward-only temporary; not for the vanilla network at other degrees)
   int S; int64_t Np;
 };
 // What the forward leaves for the backward (caller-owned, pinned by the autograd graph): per level t, raw, planes, ReLU bits.
@@ -862,7 +865,7 @@ TrainWs carve_train(char* base, int64_t n, bool art, int num_levels, const Geo& 
       w.lvl[l].enc = reinterpret_cast<float*>(take(n * S * (int64_t)aon::kPosEnc * 4));
       w.lvl[l].venc = reinterpret_cast<float*>(take(n * (int64_t)aon::kViewEnc * 4));
     }
-    if (!g.other_degrees && !art) w.lvl[l].vbias = reinterpret_cast<float*>(take(n * (int64_t)aon::kCondWidth * 4));
+    if (!g.other_degrees || art) w.lvl[l].vbias = reinterpret_cast<float*>(take(n * (int64_t)aon::kCondWidth * 4));
   }
   w.w_c = reinterpret_cast<float*>(take(n * g.Sc * 4));
   w.bytes = off;
@@ -1033,11 +1036,12 @@ int train_fwd_impl(const char* who, bool art, const TrainNet* nets, const float*
     if ((art && forms_differ(nets[l].packed_fwd, nets[l].small)) || forms_differ(nets[l].packed_fwd, nets[0].packed_fwd))
       return fail(AON_E_INVALID, "train forward: the levels' streams / per-call blocks were made in different forms (aon_set_bottleneck_fold changed in between)");
   const int64_t rows = art ? aon::kAPlRows : aon::kPlRows;
-  // the vanilla network's view-encoding term as a per-ray bias (aon_set_view_bias): both levels' biases of the whole batch up front
-  const bool use_vb = !art && !g.other_degrees && g_view_bias.load(std::memory_order_relaxed) != 0 && aon::stream_form(nets[0].packed_fwd) == aon::kFormFolded;
+  // the view-encoding term of the first view layer as a per-ray bias (aon_set_view_bias): both levels' biases of the whole batch up front
+  const bool use_vb = !g.other_degrees && g_view_bias.load(std::memory_order_relaxed) != 0 && aon::stream_form(nets[0].packed_fwd) == aon::kFormFolded;
   if (use_vb)
     for (int l = 0; l < num_levels; ++l)
-      if (int rc = check(aon::launch_view_bias(static_cast<const char*>(nets[l].packed_fwd), viewdirs, n, w.lvl[l].vbias, stream), who)) return rc;
+      if (int rc = check(art ? aon::launch_art_view_bias(static_cast<const char*>(nets[l].packed_fwd), nets[l].small, viewdirs, n, w.lvl[l].vbias, stream)
+                             : aon::launch_view_bias(static_cast<const char*>(nets[l].packed_fwd), viewdirs, n, w.lvl[l].vbias, stream), who)) return rc;
 
   // Both levels of the ray range [r0, r0 + nk) on stream `st`.  r0 is a multiple of 128, so the range's samples start on a pass
   // boundary at both levels: its planes / decision bits / raw records are the whole batch's buffers at an offset, the slot stride of
@@ -1074,10 +1078,10 @@ int train_fwd_impl(const char* who, bool art, const TrainNet* nets, const float*
         rc = check(aon::launch_mlp_fwd_train_enc(static_cast<const char*>(nets[l].packed_fwd), enc, venc, nk, L.S, raw, planes, masks, st, L.Np), who);
       } else {
         MlpTimer timer(st, nk * L.S);
+        const float* vb = use_vb ? L.vbias + r0 * aon::kCondWidth : nullptr;
         rc = check(art ? aon::launch_art_mlp_fwd_train(static_cast<const char*>(nets[l].packed_fwd), nets[l].small, o, d, v, t, nk, L.S, raw, planes, masks,
-                                                       st, L.Np)
-                       : aon::launch_mlp_fwd_train(static_cast<const char*>(nets[l].packed_fwd), o, d, v, t, nk, L.S, raw, planes, masks, st, L.Np,
-                                                   use_vb ? L.vbias + r0 * aon::kCondWidth : nullptr), who);
+                                                       st, L.Np, vb)
+                       : aon::launch_mlp_fwd_train(static_cast<const char*>(nets[l].packed_fwd), o, d, v, t, nk, L.S, raw, planes, masks, st, L.Np, vb), who);
       }
       if (rc) return rc;
       if (l == 0 && fuse) {

@@ -417,7 +417,7 @@ static hipError_t launch_mlp_t(const MlpArgs& args, hipStream_t stream) {
 // b' + W_v0[:, 256:] ve per ray, the head of the view layer's accumulation chains (aon_common.h): the fused multiply-adds the view-encoding
 // chunk performs, in its order -- register r = 0 .. 13 of the encoding tile, half-wave 0 then 1 (one v_mfma_f32_32x32x2_f32 step adds the
 // k = 0 product, then the k = 1 product) -- with the weights read from the packed chunk itself.  One workgroup serves eight rays.
-__global__ __launch_bounds__(256) void view_bias_kernel(const char* packed, const float* viewdirs, int64_t n_rays, float* out) {
+__global__ __launch_bounds__(256) void view_bias_kernel(const float* chunk, const float* bias_vec, const float* viewdirs, int64_t n_rays, float* out) {
   __shared__ float enc[8][2][16];
   const int tid = threadIdx.x;
   const int64_t ray0 = (int64_t)blockIdx.x * 8;
@@ -432,8 +432,7 @@ __global__ __launch_bounds__(256) void view_bias_kernel(const char* packed, cons
     }
   }
   const int row = tid & 127, tp = row >> 5;
-  const float* chunk = reinterpret_cast<const float*>(packed + chunk_offset_f(kChFView));
-  const float bias = reinterpret_cast<const float*>(packed + kStreamBytes)[kSmBiasView + row];
+  const float bias = bias_vec[row];
   float w[14][2];
 #pragma unroll
   for (int r = 0; r < 14; ++r)
@@ -453,11 +452,17 @@ __global__ __launch_bounds__(256) void view_bias_kernel(const char* packed, cons
   }
 }
 
-hipError_t launch_view_bias(const char* packed, const float* viewdirs, int64_t n_rays, float* out, hipStream_t stream) {
+// chunk: the view-encoding chunk of a folded stream (4 output tiles); bias_vec: the 128 biases the chunk form starts the view layer from
+hipError_t launch_view_bias_raw(const float* chunk, const float* bias_vec, const float* viewdirs, int64_t n_rays, float* out, hipStream_t stream) {
   if (n_rays <= 0) return hipSuccess;
-  if (stream_form(packed) != kFormFolded) return hipErrorInvalidValue;
-  view_bias_kernel<<<dim3((unsigned)((n_rays + 7) / 8)), dim3(256), 0, stream>>>(packed, viewdirs, n_rays, out);
+  view_bias_kernel<<<dim3((unsigned)((n_rays + 7) / 8)), dim3(256), 0, stream>>>(chunk, bias_vec, viewdirs, n_rays, out);
   return hipGetLastError();
+}
+
+hipError_t launch_view_bias(const char* packed, const float* viewdirs, int64_t n_rays, float* out, hipStream_t stream) {
+  if (stream_form(packed) != kFormFolded) return hipErrorInvalidValue;
+  return launch_view_bias_raw(reinterpret_cast<const float*>(packed + chunk_offset_f(kChFView)), reinterpret_cast<const float*>(packed + kStreamBytes) + kSmBiasView,
+                              viewdirs, n_rays, out, stream);
 }
 
 hipError_t launch_mlp_fwd(const char* packed, const float* rays_o, const float* rays_d, const float* viewdirs,

@@ -36,6 +36,13 @@ struct ArtFoldNet {   // folded form (aon_art_common.h)
   static constexpr int kNumChunks = kANumChunksF;
   static constexpr int chunk_bytes(int c) { return (c < kAChT0 || c >= kAChFV0) ? kSmallChunkBytes : kBigChunkBytes; }
 };
+struct ArtFoldVbNet {   // folded form, view-encoding term as a per-ray bias: chunk c >= kAChFV0 here is chunk c + 1 of ArtFoldNet
+  static constexpr int kSlotBytes = kPairSlotBytes;
+  static constexpr bool kPair = true;
+  static constexpr int kNumChunks = kANumChunksF - 1;
+  static constexpr int chunk_bytes(int c) { return (c < kAChT0 || c >= kAChFV0) ? kSmallChunkBytes : kBigChunkBytes; }
+  static constexpr int skip_before(int c) { return c == kAChFV0 ? kSmallChunkBytes : 0; }
+};
 constexpr int64_t kAStreamBytesF = (int64_t)kAChT0 * kSmallChunkBytes + (int64_t)(kAChFV0 - kAChT0) * kBigChunkBytes + (int64_t)(kANumChunksF - kAChFV0) * kSmallChunkBytes;
 constexpr int64_t kAFoldTmpOff = kAStreamBytesF;   // W' (128 x 256 floats) for the pack kernel, inside the literal-size buffer
 static_assert(kAStreamBytesF + 128 * 256 * 4 <= kAStreamBytes, "fold temporary fits behind the folded stream");
@@ -63,7 +70,9 @@ __global__ void pack_art_kernel(ArtPackArgs a, float* __restrict__ packed, int L
   else if (idx < s1) { c = kAChT0 + (int)((idx - s0) / (kBigChunkBytes / 4)); r = (int)((idx - s0) % (kBigChunkBytes / 4)); nt = 8; }
   else {
     c = first_small_tail + (int)((idx - s1) / (kSmallChunkBytes / 4)); r = (int)((idx - s1) % (kSmallChunkBytes / 4)); nt = 4;
-    if constexpr (FOLD) c += kAChV0 - kAChFV0;   // the view branch's chunks take the literal branches below, W' for views_linear.0's hidden columns
+    // the view branch's chunks take the literal branches below, W' for views_linear.0's hidden columns; views_linear.0's view-encoding chunk
+    // is the FIRST of the folded layer (aon_art_common.h), the last of the literal one
+    if constexpr (FOLD) c = c == kAChFV0 ? kAChV0 + 8 : (c <= kAChFV0 + 8 ? c - 1 : c) + (kAChV0 - kAChFV0);
   }
   const int cc = r & 3, lane = (r >> 2) & 63, rest = r >> 8;
   const int tp = rest % nt, q = rest / nt;
@@ -169,6 +178,7 @@ struct ArtSeg {
   float* planes;          // [TRAIN] kAPlRows x Np
   u32x4* masks;           // [TRAIN] kAMaskLayers x (Np*2)
   int64_t Np;
+  const float* view_bias; // [VB] (n_rays,128): views_linear.0's effective bias + W_v0[:, 256:283] ve of the ray (launch_art_view_bias)
 };
 struct ArtMlpArgs {
   ArtSeg seg[2];
@@ -177,10 +187,12 @@ struct ArtMlpArgs {
 
 // FOLD: stream and per-call block are the folded form's (aon_art_common.h): views_linear.0 reads the post-ReLU layer-7 output through W';
 // no bottleneck layer and, [TRAIN], no bottleneck rows in the planes (rows kAPlBot .. kAPlBot + 255 stay unwritten).
-template <bool POS_IN_KERNEL, bool TRAIN, bool FOLD>
+// VB (folded form, in-kernel ray cast): views_linear.0's accumulators start from the ray's bias + view-encoding term (see mlp_fwd_kernel).
+template <bool POS_IN_KERNEL, bool TRAIN, bool FOLD, bool VB = false>
 __global__ void __launch_bounds__(256) art_mlp_fwd_kernel(ArtMlpArgs args) {
-  using Net = std::conditional_t<FOLD, ArtFoldNet, ArtNet>;
-  constexpr int kV0 = FOLD ? kAChFV0 : kAChV0, kV1 = FOLD ? kAChFV1 : kAChV1;
+  static_assert((FOLD && POS_IN_KERNEL) || !VB, "the per-ray view bias belongs to the folded form of the whole-path kernels");
+  using Net = std::conditional_t<VB, ArtFoldVbNet, std::conditional_t<FOLD, ArtFoldNet, ArtNet>>;
+  constexpr int kV0 = FOLD ? kAChFV0 : kAChV0, kV1 = (FOLD ? kAChFV1 : kAChV1) - (VB ? 1 : 0);
   static_assert(!TRAIN || POS_IN_KERNEL, "the training path encodes the view direction from vd[], which only the in-kernel ray cast fills");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* sm = reinterpret_cast<float*>(smem + kRingBytes);
@@ -227,7 +239,7 @@ __global__ void __launch_bounds__(256) art_mlp_fwd_kernel(ArtMlpArgs args) {
         x[a] = __fadd_rn(sg.rays_o[ray * 3 + a], __fmul_rn(t, sg.rays_d[ray * 3 + a]));
         vd[a] = sg.viewdirs[ray * 3 + a];
       }
-      if constexpr (!TRAIN) encode_view(vd, h, V);  // [TRAIN] encoded where the view branch needs it: 16 registers not held across the trunk
+      if constexpr (!TRAIN && !VB) encode_view(vd, h, V);  // [TRAIN] encoded where the view branch needs it: 16 registers not held across the trunk
     } else {
 #pragma unroll
       for (int a = 0; a < 3; ++a) x[a] = sg.pos[gc * 3 + a];
@@ -331,25 +343,53 @@ __global__ void __launch_bounds__(256) art_mlp_fwd_kernel(ArtMlpArgs args) {
     chunk_mma<Net, kAChT5 + 9, 8, 16>(p, E[1], Y);
     relu_tiles(Y);
     init_bias(X, sm + kA_BT + 6 * 256, h); dense_layer<Net, kAChT6, 8, 8>(p, Y, X, consume8(Y, aplane_h(5), true)); put_mask(9); relu_tiles(X);
-    init_bias(Y, sm + kA_BT + 7 * 256, h); dense_layer<Net, kAChT7, 8, 8>(p, X, Y, consume8(X, aplane_h(6), true)); put_mask(10); relu_tiles(Y);
+    f32x16 Z0[4], Z1[4];
+    init_bias(Y, sm + kA_BT + 7 * 256, h);
+    if constexpr (VB) {
+      // the ray's view bias straight into views_linear.0's accumulators, one 16-byte load per side slot of layer 7's LAST chunk
+      int ray32 = (int)ray;
+      asm volatile("" : "+v"(ray32));
+      const float* vb = sg.view_bias + (int64_t)ray32 * kCondWidth + 4 * h;
+      auto l7_side = [&](int j) {
+        auto base = consume8(X, aplane_h(6), true)(j);
+        return [&, base, j, vb](int i) {
+          base(i);
+          if (j == 7 && i < 16) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(vb + 32 * (i >> 2) + 8 * (i & 3));
+            Z0[i >> 2][4 * (i & 3)] = v[0]; Z0[i >> 2][4 * (i & 3) + 1] = v[1]; Z0[i >> 2][4 * (i & 3) + 2] = v[2]; Z0[i >> 2][4 * (i & 3) + 3] = v[3];
+          }
+        };
+      };
+      dense_layer<Net, kAChT7, 8, 8>(p, X, Y, l7_side);
+    } else {
+      dense_layer<Net, kAChT7, 8, 8>(p, X, Y, consume8(X, aplane_h(6), true));
+    }
+    put_mask(10); relu_tiles(Y);
     float sigma = head_partial<8>(Y, sm + kA_WSIG, h);  // density_layer (:219)
     sigma = sigma + __shfl_xor(sigma, 32) + sm[kA_BSIG];
     // ---- view branch (:227-234): cat[bottleneck, viewenc, appearance] -> 4 x (128, ReLU) ----
-    f32x16 Z0[4], Z1[4];
+    auto view_enc_here = [&]() {   // [TRAIN] the view encoding where the branch needs it (and its plane rows)
+      if constexpr (TRAIN) {
+        encode_view(vd, h, V);
+        store_view_enc_plane(V, io, kAPlVE, h);
+      }
+    };
     if constexpr (FOLD) {
-      // bottleneck (:223, no activation) and views_linear.0's bottleneck columns as ONE layer W' on the layer-7 output (effective bias incl. W_v0[:, :256] b_b)
-      init_bias(Z0, sm + kA_BV + 0 * 128, h);
-      dense_layer<Net, kV0, 8, 4>(p, Y, Z0, consume8(Y, aplane_h(7), true)); put_mask(11);
+      // bottleneck (:223, no activation) and views_linear.0's bottleneck columns as ONE layer W' on the layer-7 output (effective bias incl.
+      // W_v0[:, :256] b_b); the view-encoding columns FIRST (chunk form) or already in Z0 with the bias (VB)
+      view_enc_here();
+      if constexpr (!VB) {
+        init_bias(Z0, sm + kA_BV + 0 * 128, h);
+        chunk_mma<Net, kV0, 4, 14>(p, V, Z0);
+      }
+      dense_layer<Net, kV0 + (VB ? 0 : 1), 8, 4>(p, Y, Z0, consume8(Y, aplane_h(7), true)); put_mask(11);
     } else {
       init_bias(X, sm + kA_BBOT, h); dense_layer<Net, kAChBott, 8, 8>(p, Y, X, consume8(Y, aplane_h(7), true)); put_mask(11);  // bottleneck (:223)
       init_bias(Z0, sm + kA_BV + 0 * 128, h);
       dense_layer<Net, kV0, 8, 4>(p, X, Z0, consume8(X, kAPlBot, false));
+      view_enc_here();
+      chunk_mma<Net, kV0 + 8, 4, 14>(p, V, Z0);
     }
-    if constexpr (TRAIN) {
-      encode_view(vd, h, V);
-      store_view_enc_plane(V, io, kAPlVE, h);
-    }
-    chunk_mma<Net, kV0 + 8, 4, 14>(p, V, Z0);
     relu_tiles(Z0);
     init_bias(Z1, sm + kA_BV + 1 * 128, h); dense_layer<Net, kV1 + 0, 4, 4>(p, Z0, Z1, consume4(Z0, aplane_v(0), true)); put_mask(12); relu_tiles(Z1);
     init_bias(Z0, sm + kA_BV + 2 * 128, h); dense_layer<Net, kV1 + 4, 4, 4>(p, Z1, Z0, consume4(Z1, aplane_v(1), true)); put_mask(13); relu_tiles(Z0);
@@ -406,15 +446,15 @@ hipError_t launch_prepare_art(const float* const* params, const float* shape, co
 
 int num_cus();  // aon_mlp.hip
 
-template <bool POS, bool TRAIN, bool FOLD>
+template <bool POS, bool TRAIN, bool FOLD, bool VB = false>
 static hipError_t launch_art_tf(const ArtMlpArgs& args, hipStream_t stream) {
   static DeviceOnce lds_once;
-  if (hipError_t e = set_max_lds(&art_mlp_fwd_kernel<POS, TRAIN, FOLD>, kALdsBytes, lds_once); e != hipSuccess) return e;
+  if (hipError_t e = set_max_lds(&art_mlp_fwd_kernel<POS, TRAIN, FOLD, VB>, kALdsBytes, lds_once); e != hipSuccess) return e;
   const int cus = num_cus();
   if (cus <= 0) return hipErrorInvalidDevice;
   const int grid = args.npass_total < cus ? args.npass_total : cus;
   if (grid <= 0) return hipSuccess;
-  art_mlp_fwd_kernel<POS, TRAIN, FOLD><<<dim3(grid), dim3(256), kALdsBytes, stream>>>(args);
+  art_mlp_fwd_kernel<POS, TRAIN, FOLD, VB><<<dim3(grid), dim3(256), kALdsBytes, stream>>>(args);
   return hipGetLastError();
 }
 
@@ -424,15 +464,32 @@ static hipError_t launch_art_t(const ArtMlpArgs& args, hipStream_t stream) {
   const int form = stream_form(args.seg[0].packed);
   if (stream_form(args.seg[0].small) != form) return hipErrorInvalidValue;
   if (args.seg[1].npass > 0 && (stream_form(args.seg[1].packed) != form || stream_form(args.seg[1].small) != form)) return hipErrorInvalidValue;
+  const bool vb = args.seg[0].view_bias != nullptr;   // every segment of the launch or none; folded form, in-kernel ray cast only
+  if (args.seg[1].npass > 0 && (args.seg[1].view_bias != nullptr) != vb) return hipErrorInvalidValue;
+  if (vb && form != kFormFolded) return hipErrorInvalidValue;
+  if constexpr (POS) {
+    if (vb) return launch_art_tf<POS, TRAIN, true, true>(args, stream);
+  } else {
+    if (vb) return hipErrorInvalidValue;
+  }
   return form == kFormFolded ? launch_art_tf<POS, TRAIN, true>(args, stream) : launch_art_tf<POS, TRAIN, false>(args, stream);
+}
+
+hipError_t launch_view_bias_raw(const float* chunk, const float* bias_vec, const float* viewdirs, int64_t n_rays, float* out, hipStream_t stream);   // aon_mlp.hip
+
+// views_linear.0's effective bias (per-call block: appearance latent and W_v0[:, :256] b_b folded in) + its view-encoding term, per ray
+hipError_t launch_art_view_bias(const char* packed, const float* small, const float* viewdirs, int64_t n_rays, float* out, hipStream_t stream) {
+  if (stream_form(packed) != kFormFolded || stream_form(small) != kFormFolded) return hipErrorInvalidValue;
+  constexpr int64_t off = (int64_t)kAChT0 * kSmallChunkBytes + (int64_t)(kAChFV0 - kAChT0) * kBigChunkBytes;
+  return launch_view_bias_raw(reinterpret_cast<const float*>(packed + off), small + kA_BV, viewdirs, n_rays, out, stream);
 }
 
 hipError_t launch_art_mlp_fwd(const char* packed, const float* small, const float* rays_o, const float* rays_d,
                               const float* viewdirs, const float* t_vals, int64_t n_rays, int S, float* raw,
-                              hipStream_t stream) {
+                              hipStream_t stream, const float* view_bias) {
   ArtMlpArgs args{};
   ArtSeg& a = args.seg[0];
-  a.packed = packed; a.small = small; a.rays_o = rays_o; a.rays_d = rays_d; a.viewdirs = viewdirs; a.t_vals = t_vals;
+  a.packed = packed; a.small = small; a.rays_o = rays_o; a.rays_d = rays_d; a.viewdirs = viewdirs; a.t_vals = t_vals; a.view_bias = view_bias;
   a.raw = raw; a.total = n_rays * S; a.S = S; a.npass = (int)((a.total + 127) / 128);
   args.seg[1] = a; args.seg[1].npass = 0; args.npass_total = a.npass;
   return launch_art_t<true, false>(args, stream);
@@ -442,8 +499,8 @@ hipError_t launch_art_mlp_fwd_train2(const TrainSeg* segs, int nsegs, hipStream_
 
 hipError_t launch_art_mlp_fwd_train(const char* packed, const float* small, const float* rays_o, const float* rays_d,
                                     const float* viewdirs, const float* t_vals, int64_t n_rays, int S, float* raw, float* planes,
-                                    void* masks, hipStream_t stream, int64_t np_total) {
-  const TrainSeg one{packed, small, rays_o, rays_d, viewdirs, t_vals, n_rays, S, raw, planes, masks, np_total};
+                                    void* masks, hipStream_t stream, int64_t np_total, const float* view_bias) {
+  const TrainSeg one{packed, small, rays_o, rays_d, viewdirs, t_vals, n_rays, S, raw, planes, masks, np_total, view_bias};
   return launch_art_mlp_fwd_train2(&one, 1, stream);
 }
 
@@ -457,6 +514,7 @@ hipError_t launch_art_mlp_fwd_train2(const TrainSeg* segs, int nsegs, hipStream_
     a.packed = t.packed; a.small = t.small; a.rays_o = t.rays_o; a.rays_d = t.rays_d; a.viewdirs = t.viewdirs; a.t_vals = t.t_vals;
     a.raw = t.raw; a.total = t.n_rays * t.S; a.S = t.S; a.npass = (int)((a.total + 127) / 128);
     a.planes = t.planes; a.masks = static_cast<u32x4*>(t.masks); a.Np = t.np_total > 0 ? t.np_total : (int64_t)a.npass * 128;   // (launch_mlp_fwd_train)
+    a.view_bias = t.view_bias;
     args.npass_total += a.npass;
   }
   if (nsegs == 1) { args.seg[1] = args.seg[0]; args.seg[1].npass = 0; }

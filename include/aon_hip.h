@@ -341,9 +341,10 @@ int aon_set_bwd_merge(int on);
  * they run on compute units that would idle for one pass.  Ordered by events on both sides like the level streams; same bits
  * (the partials are summed by the same second stage).  0: every head reduction behind the chain, on `stream` (round 4). */
 int aon_set_bwd_early_heads(int on);
-/* Round 5, default 1: whole-path calls (aon_render_fwd*, aon_render_fwd_train*) of the vanilla network in its folded form compute
- * b' + W_v0[:, 256:] viewenc(ray) -- a constant of the RAY, the head of the view layer's accumulation chains -- once per ray in a small
- * kernel and start the view layer's accumulators from it, instead of running the 27 -> 128 view-encoding chunk for every sample:
+/* Round 5, default 1: whole-path calls (aon_render_fwd*, aon_art_render_fwd*, the training forwards) of a network in its folded form compute
+ * b' + W_v0[:, 256:283] viewenc(ray) -- a constant of the RAY, the head of the first view layer's accumulation chains (articulated: b' is
+ * the per-call effective bias) -- once per ray in a small kernel and start that layer's accumulators from it, instead of running the
+ * 27 -> 128 view-encoding chunk for every sample:
  * 56 MFMAs, 12 sines and a 16 KiB weight chunk fewer per 128-sample pass, the same fused multiply-adds in the same order (bit-equal to
  * the chunk form, which the stage-level calls keep).  0: the chunk form everywhere (the A/B partner). */
 int aon_set_view_bias(int on);

@@ -222,3 +222,35 @@ def test_per_ray_view_bias_gives_the_chunk_forms_bits(ops, dev, nerf_sd):
         del Wb
     finally:
         ops.set_view_bias(True)
+
+
+def test_per_ray_view_bias_articulated(ops, dev):
+    """... and the articulated network: views_linear.0's effective bias (appearance latent and W_v0[:, :256] b_b folded in per call) plus its
+    view-encoding term per ray; inference, training forward and every gradient bit-equal to the chunk form."""
+    import aon_amd.synthetic as syn
+    from aon_amd.models.vanilla_nerf.model_autodecoder import NeRF_AE_Art
+
+    ops.set_bottleneck_fold(True)
+    model = NeRF_AE_Art().to(dev)
+    model.load_state_dict(syn.make_art_state_dict(seed=18, density_scale=2.0))
+    lib = syn.make_code_library_state(seed=0, n_max_objs=2)
+    lat0 = {"density": lib["embedding_instance_shape.weight"][1:2], "color": lib["embedding_instance_appearance.weight"][1:2],
+            "articulation": lib["embedding_instance_articulation.weight"][3:4]}
+    try:
+        for n in (5, 700):
+            rays = {k: v.to(dev) for k, v in syn.random_rays(n, seed=80 + n).items()}
+            tr, u = syn.seeded_uniform(81, n, 65).to(dev), syn.seeded_uniform(82, n, 128).to(dev)
+            res = []
+            for on in (True, False):
+                ops.set_view_bias(on)
+                lat = {k: v.clone().to(dev).requires_grad_(True) for k, v in lat0.items()}
+                with torch.no_grad():
+                    det = model(rays, False, True, 2.0, 6.0, lat)
+                model.zero_grad()
+                out = model(rays, True, True, 2.0, 6.0, lat, t_rand=tr, u=u)
+                (out[0][0].sum() + out[1][0].sum()).backward()
+                res.append([x.detach().clone() for lvl in det + out for x in lvl] + [p.grad.clone() for p in model.parameters()] + [v.grad.clone() for v in lat.values()])
+            for a, b in zip(*res):
+                assert torch.equal(a, b)
+    finally:
+        ops.set_view_bias(True)
