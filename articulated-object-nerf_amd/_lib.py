@@ -80,6 +80,7 @@ _SIGS = {
     "aon_stream_is_folded": (_i, [_p]),
     "aon_set_bwd_early_heads": (_i, [_i]),
     "aon_set_view_bias": (_i, [_i]),
+    "aon_get_view_bias": (_i, []),
     "aon_view_bias": (_i, [_p, _p, _l, _p, _p]),
     "aon_set_bwd_overlap": (_i, [_i]),
     "aon_set_fwd_overlap": (_i, [_i]),

@@ -1198,6 +1198,8 @@ int aon_set_view_bias(int on) {
   return AON_OK;
 }
 
+int aon_get_view_bias(void) { return g_view_bias.load(std::memory_order_relaxed); }
+
 int aon_set_bwd_early_heads(int on) {
   g_bwd_early_heads.store(on ? 1 : 0, std::memory_order_relaxed);
   return AON_OK;

@@ -833,6 +833,11 @@ def set_view_bias(on: bool) -> None:
     check(lib.aon_set_view_bias(int(bool(on))), "aon_set_view_bias")
 
 
+def view_bias_enabled() -> bool:
+    """True when the whole-path calls of folded networks use the per-ray view bias (needs the fold: bottleneck_fold())."""
+    return bool(lib.aon_get_view_bias()) and bottleneck_fold()
+
+
 def view_bias(packed: torch.Tensor, viewdirs: torch.Tensor) -> torch.Tensor:
     """(n,128) = b' + W_v0[:, 256:] pos_enc(viewdirs, 0, 4) of a folded vanilla stream: what the whole-path calls start the view layer from."""
     v = _f32(viewdirs, "viewdirs")

@@ -39,10 +39,13 @@ VAN_MAC_BWD_CHAIN = VAN_MAC - 2 * 256 * 63 - 128 * 27     # no data gradient int
 # kernels execute 65,536 fewer MACs per sample in the forward, in the backward chain and in the weight gradients alike.  `executed`
 # figures below subtract them when the fold is on (default); `reference_literal` figures never do.
 FOLD_MAC = 256 * 256
+# ... and the first view layer's view-encoding columns (27 -> 128, a constant of the ray) enter as a per-ray bias in the whole-path FORWARD
+# kernels (aon_set_view_bias): the 14 two-deep MFMA steps of that chunk -- 28 columns, one of them padding -- are no longer executed.
+VIEW_BIAS_MAC = 128 * 28
 
 
-def executed(mac: int, fold: bool) -> int:
-    return mac - FOLD_MAC if fold else mac
+def executed(mac: int, fold: bool, view_bias: bool = False) -> int:
+    return mac - (FOLD_MAC if fold else 0) - (VIEW_BIAS_MAC if fold and view_bias else 0)
 
 # algorithmic HBM bytes per ray of the per-ray kernels: compositing reads float4(rgb, sigma) + t per sample and
 # the direction, writes rgb/acc/depth (+ the 65 weights at the coarse level); the inverse CDF reads t (65) and 63 weights and
@@ -170,7 +173,7 @@ def render_leg(dev, kind, H, W, steps=3):
             model = NeRF(num_levels=1).to(dev)
             model.load_state_dict(syn.make_nerf_state_dict(seed=0, density_scale=30.0))
             call = lambda: model(rays, False, True, syn.NEAR, syn.FAR)
-            evals, mac_ex, mac_lit = 65, executed(VAN_MAC, ops.bottleneck_fold()), VAN_MAC
+            evals, mac_ex, mac_lit = 65, executed(VAN_MAC, ops.bottleneck_fold(), ops.view_bias_enabled()), VAN_MAC
             name = "aon::mlp_fwd_kernel<true,false,fold> (fused encode+MLP, fp32 MFMA)"
             work = f"vanilla NeRF {W}x{H}, 65 coarse evals/ray only (num_levels=1), {H * W} rays"
         else:
@@ -184,7 +187,7 @@ def render_leg(dev, kind, H, W, steps=3):
             with torch.no_grad():
                 lat = lib({"instance_id": torch.tensor([0], device=dev), "articulation_id": torch.tensor([3], device=dev)})
             call = lambda: model(rays, False, True, syn.NEAR, syn.FAR, lat)
-            evals, mac_ex, mac_lit = EVALS_PER_RAY, executed(ART_MAC_FWD, ops.bottleneck_fold()), ART_MAC_LITERAL
+            evals, mac_ex, mac_lit = EVALS_PER_RAY, executed(ART_MAC_FWD, ops.bottleneck_fold(), ops.view_bias_enabled()), ART_MAC_LITERAL
             name = "aon::art_mlp_fwd_kernel<true,false,fold> (deformation + trunk + view branch, latents folded into biases, fp32 MFMA)"
             work = f"articulated NeRF_AE_Art {W}x{H}, 65 coarse + 193 fine evals/ray, {H * W} rays"
         with torch.no_grad():
@@ -419,7 +422,7 @@ def train_leg(dev, rank, world, distributed, steps=6, n_rays=4096):
             ops.set_fwd_overlap(True)
         samples = n_rays * EVALS_PER_RAY
         fold = bool(ops.bottleneck_fold())
-        mac_f, mac_c, mac_w = executed(ART_MAC_FWD, fold), executed(ART_MAC_BWD_CHAIN, fold), executed(ART_MAC_WGRAD, fold)
+        mac_f, mac_c, mac_w = executed(ART_MAC_FWD, fold, ops.view_bias_enabled()), executed(ART_MAC_BWD_CHAIN, fold), executed(ART_MAC_WGRAD, fold)
         mac_lit, mac_ex = 3 * ART_MAC_LITERAL, mac_f + mac_c + mac_w
         kernels = {}
         for key, name, mac in (("mlp_fwd", "aon::art_mlp_fwd_kernel<true,true,fold> (training forward: + activation planes, ReLU bits)", mac_f),
@@ -433,7 +436,7 @@ def train_leg(dev, rank, world, distributed, steps=6, n_rays=4096):
         other_ms = sum(classes[k][0] for k in ("composite", "sample_pdf", "composite_pdf", "composite_bwd", "sample_t") if k in classes) / steps
         step_traffic, traffic_src, head_bytes = pmc_traffic_train(kernels, {k: v["launches"] / steps for k, v in kernels.items()})
         res = {"workload": f"articulated NeRF_AE_Art training step, {n_rays} rays/GPU, fwd+bwd" + (" + RCCL gradient all-reduce (6.4 MB, one bucket)" if world > 1 else "") + " + Adam (torch.optim.Adam, fused=True)",
-               "ms_per_step": dt * 1e3, "rays_per_s": world * n_rays / dt, "steps": steps, "loss": loss, "bottleneck_fold": fold,
+               "ms_per_step": dt * 1e3, "rays_per_s": world * n_rays / dt, "steps": steps, "loss": loss, "bottleneck_fold": fold, "view_bias": bool(ops.view_bias_enabled()),
                "allreduce_ms": {"min": ar_all.min().item(), "max": ar_all.max().item(), "per_rank": ar_all.tolist(),
                                 "note": "parallel.allreduce_gradients per step, HIP events on the launch stream; 0 at world size 1 (no-op); "
                                         "includes the wait for the slowest rank's backward"},
@@ -443,7 +446,8 @@ def train_leg(dev, rank, world, distributed, steps=6, n_rays=4096):
                             "frac_reference_literal": samples * mac_lit * 2 / dt / 1e12 / PEAK_FP32_MATRIX_TFLOPS,
                             "flop_per_ray_executed": 2 * mac_ex * EVALS_PER_RAY, "flop_per_ray_reference_literal": 2 * mac_lit * EVALS_PER_RAY,
                             "note": "whole step (kernels + Adam + harness) priced against the fp32-matrix peak; executed = MACs the kernels issue "
-                                    "(latent columns folded into biases; bottleneck_layer folded into views_linear[0] when bottleneck_fold), "
+                                    "(latent columns folded into biases; bottleneck_layer folded into views_linear[0] when bottleneck_fold; the forward's "
+                                    "view-encoding chunk replaced by a per-ray bias when view_bias), "
                                     "reference-literal = 3 x the forward MACs of SURVEY R10",
                             "kernels": kernels, "per_ray_kernels_ms_per_step": other_ms,
                             "kernel_ms_per_step": sum(k["ms_per_step"] for k in kernels.values()) + other_ms,
@@ -641,7 +645,7 @@ def main():
 
     if rank == 0:
         rays_per_s = world * n_rays * args.steps / dt
-        flop_ex = 2 * executed(VAN_MAC, fold)       # what the kernel executes per network evaluation
+        flop_ex = 2 * executed(VAN_MAC, fold, ops.view_bias_enabled())       # what the kernel executes per network evaluation
         mlp_tflops = mlp_samples * flop_ex / (mlp_ms * 1e-3) / 1e12 if mlp_ms > 0 else 0.0
         mlp_tflops_lit = mlp_samples * FLOP_PER_SAMPLE / (mlp_ms * 1e-3) / 1e12 if mlp_ms > 0 else 0.0
         res = {
@@ -655,14 +659,16 @@ def main():
                        "exchange": "RCCL all_gather of (rgb,acc,depth)=20 B/ray" if world > 1 else "none"},
             "multi_gpu": diag,
             "bottleneck_fold": fold,
-            "roofline": {"bound": "mfma", "kernel": "aon::mlp_fwd_kernel<true,false,fold> (fused encode+MLP, fp32 MFMA)",
+            "view_bias": bool(ops.view_bias_enabled()),
+            "roofline": {"bound": "mfma", "kernel": "aon::mlp_fwd_kernel<true,false,fold,view-bias> (fused encode+MLP, fp32 MFMA)",
                          "achieved": mlp_tflops, "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
                          "frac": mlp_tflops / PEAK_FP32_MATRIX_TFLOPS, "traffic": None,
                          "achieved_reference_literal": mlp_tflops_lit, "frac_reference_literal": mlp_tflops_lit / PEAK_FP32_MATRIX_TFLOPS,
                          "launches": mlp_launches, "avg_launch_ms": mlp_ms / max(mlp_launches, 1),
                          "flop_per_sample": flop_ex, "flop_per_sample_reference_literal": FLOP_PER_SAMPLE,
                          "note": "achieved / frac price the FLOPs the kernel EXECUTES (bottleneck_layer folded into views_linear[0] when bottleneck_fold: "
-                                 "65,536 MACs per sample fewer than the reference's graph); *_reference_literal price the reference's 1,186,816 FLOP per "
+                                 "65,536 MACs per sample fewer than the reference's graph; the view-encoding columns of that layer as a per-ray bias when "
+                                 "view_bias: 3,584 fewer); *_reference_literal price the reference's 1,186,816 FLOP per "
                                  "sample against the same time and can exceed the executed fraction",
                          "whole_path_frac": rays_per_s / world * EVALS_PER_RAY * flop_ex / (PEAK_FP32_MATRIX_TFLOPS * 1e12),
                          "whole_path_frac_reference_literal": rays_per_s / world * EVALS_PER_RAY * FLOP_PER_SAMPLE / (PEAK_FP32_MATRIX_TFLOPS * 1e12)},

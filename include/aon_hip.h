@@ -348,6 +348,7 @@ int aon_set_bwd_early_heads(int on);
  * 56 MFMAs, 12 sines and a 16 KiB weight chunk fewer per 128-sample pass, the same fused multiply-adds in the same order (bit-equal to
  * the chunk form, which the stage-level calls keep).  0: the chunk form everywhere (the A/B partner). */
 int aon_set_view_bias(int on);
+int aon_get_view_bias(void);
 /* The per-ray kernel on its own: view_bias (n_rays,128) = b' + W_v0[:, 256:] pos_enc(viewdirs, 0, 4) of a FOLDED vanilla stream
  * (model.py:110-116; W_v0 = views_linear.0.weight, b' = W_v0[:, :256] b_bottleneck + b_v0). */
 int aon_view_bias(const void* packed, const float* viewdirs, int64_t n_rays, float* view_bias, void* stream);
