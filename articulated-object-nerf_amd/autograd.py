@@ -27,6 +27,7 @@ class RenderVanilla(torch.autograd.Function):
         ctx.rays_d = rays_d
         ctx.white_bkgd = white_bkgd
         ctx.num_levels = num_levels
+        ctx.set_materialize_grads(False)   # acc / depth carry no gradient in training: None, not four zero-filled tensors per step
         levels, ws, ctx.geometry = ops.render_fwd_train(packs[0][0], packs[1][0] if num_levels == 2 else None, rays_o, rays_d, viewdirs, near, far,
                                                         white_bkgd, num_levels, t_rand, u, opts=opts, noise=noise)
         ctx.fused = (ws, [pk[1] for pk in packs], [pk[0] for pk in packs])
@@ -116,6 +117,7 @@ class RenderArticulated(torch.autograd.Function):
                 lat_articulation, *params):
         # packs: per level (packed_fwd, small, packed_bwd); params: 40 tensors per level in ops.ART_PARAM_ORDER
         ctx.rays_d, ctx.white_bkgd, ctx.num_levels = rays_d, white_bkgd, num_levels
+        ctx.set_materialize_grads(False)   # acc / depth carry no gradient in training: None, not four zero-filled tensors per step
         ctx.lat_shapes = (lat_density.shape, lat_color.shape, lat_articulation.shape)
         # parameters and latents are read again by the backward (latent columns: dW = db (x) latent, d latent = W^T db): saved the
         # autograd way, so an in-place update in between raises instead of mixing two sets of weights (as RenderGeneral)
