@@ -64,10 +64,11 @@ class NeRFMLP(nn.Module):
     # overwrite what an earlier graph still needs; inference reuses one buffer per stream kind (stream-ordered).
     _PACKERS = {"fwd": "pack_vanilla_mlp", "bwd": "pack_vanilla_mlp_bwd"}
 
-    def _pack(self, kind: str, fresh: bool) -> torch.Tensor:
+    def _pack(self, kind: str, fresh: bool, out: torch.Tensor | None = None) -> torch.Tensor:
         params = dict(self.named_parameters())
         dev = next(iter(params.values())).device
-        out = None if fresh else self._streams.get(kind)
+        if out is None:
+            out = None if fresh else self._streams.get(kind)
         if out is not None and out.device != dev:
             out = None
         if not self.geometry.is_default:   # other degrees on the fused kernels (fits_fused_inference): zero-weight slots
@@ -82,9 +83,14 @@ class NeRFMLP(nn.Module):
         """Forward weight stream of the fp32 kernels."""
         return self._pack("fwd", fresh)
 
-    def packed_bwd(self, fresh: bool = False) -> torch.Tensor:
+    def packed_bwd(self, fresh: bool = False, out: torch.Tensor | None = None) -> torch.Tensor:
         """Transposed weight stream for the backward data chain (training only)."""
-        return self._pack("bwd", fresh)
+        return self._pack("bwd", fresh, out)
+
+    _BWD_BYTES = "aon_bwd_packed_bytes"
+
+    def new_bwd_buffer(self) -> torch.Tensor:
+        return torch.empty(int(getattr(ops.lib, self._BWD_BYTES)()), dtype=torch.uint8, device=next(self.parameters()).device)
 
     def ordered_params(self):
         params = dict(self.named_parameters())
@@ -95,6 +101,31 @@ class NeRFMLP(nn.Module):
             return ops.gmlp_fwd(self.geometry, dict(self.named_parameters()), x, condition)
         raw = ops.mlp_fwd_enc(self.packed(), x, condition)
         return raw[..., :3], raw[..., 3:4]
+
+
+_SIDE_STREAMS: dict = {}
+
+
+def packed_bwd_aside(mlps):
+    """The levels' transposed weight streams (read by the BACKWARD only), packed on a side stream so that the two small launches per level
+    (38 us each in a 31 ms step, profiles/r05_step_timeline.txt) run beside the forward's own pack kernels and launches instead of in front
+    of them.  Returns (buffers, event): the buffers are allocated on the current stream; the caller makes the current stream wait for
+    `event` once the forward is enqueued -- long before the backward reads them.  AON_PACK_ASIDE=0: packed in line, event None."""
+    import os
+
+    dev = next(mlps[0].parameters()).device
+    if os.environ.get("AON_PACK_ASIDE", "1") == "0" or dev.type != "cuda":
+        return [m.packed_bwd(True) for m in mlps], None
+    cur = torch.cuda.current_stream(dev)
+    side = _SIDE_STREAMS.get(dev)
+    if side is None:
+        side = _SIDE_STREAMS[dev] = torch.cuda.Stream(device=dev)
+    outs = [m.new_bwd_buffer() for m in mlps]
+    side.wait_stream(cur)        # the parameters as the optimiser step left them
+    with torch.cuda.stream(side):
+        for m, o in zip(mlps, outs):
+            m.packed_bwd(True, out=o)
+    return outs, side.record_event()
 
 
 class NeRF(nn.Module):
@@ -227,10 +258,13 @@ class NeRF(nn.Module):
             if n == 0:
                 raise ValueError("empty ray batch in training mode")
             mlps = [self.coarse_mlp, self.fine_mlp][: self.num_levels]
-            packs = [(m.packed(True), m.packed_bwd(True)) for m in mlps]
+            bwd, bwd_ready = packed_bwd_aside(mlps)
+            packs = [(m.packed(True), b) for m, b in zip(mlps, bwd)]
             params = [p for m in mlps for p in m.ordered_params()]
             flat = RenderVanilla.apply(rays_o, rays["rays_d"], rays["viewdirs"], float(near), float(far), bool(white_bkgd),
                                        self.num_levels, t_rand, u, packs, self._opts, noise, *params)
+            if bwd_ready is not None:
+                torch.cuda.current_stream(rays_o.device).wait_event(bwd_ready)   # (behind the forward's launches: free by then)
             return [tuple(flat[3 * i: 3 * i + 3]) for i in range(self.num_levels)]
         coarse = self.coarse_mlp.packed()
         fine = self.fine_mlp.packed() if self.num_levels == 2 else None

@@ -63,10 +63,11 @@ class NeRFMLP(nn.Module):
     # weight streams are rebuilt from the live parameters on every call (see vanilla NeRFMLP._pack: nothing can go stale)
     _PACKERS = {"fwd": "pack_art_mlp", "bwd": "pack_art_mlp_bwd"}
 
-    def _pack(self, kind: str, fresh: bool) -> torch.Tensor:
+    def _pack(self, kind: str, fresh: bool, out: torch.Tensor | None = None) -> torch.Tensor:
         params = dict(self.named_parameters())
         dev = next(iter(params.values())).device
-        out = None if fresh else self._streams.get(kind)
+        if out is None:
+            out = None if fresh else self._streams.get(kind)
         if out is not None and out.device != dev:
             out = None
         out = getattr(ops, self._PACKERS[kind])(params, out=out, degrees=self.degrees)
@@ -77,8 +78,11 @@ class NeRFMLP(nn.Module):
     def packed(self, fresh: bool = False) -> torch.Tensor:
         return self._pack("fwd", fresh)
 
-    def packed_bwd(self, fresh: bool = False) -> torch.Tensor:
-        return self._pack("bwd", fresh)
+    def packed_bwd(self, fresh: bool = False, out: torch.Tensor | None = None) -> torch.Tensor:
+        return self._pack("bwd", fresh, out)
+
+    def new_bwd_buffer(self) -> torch.Tensor:
+        return torch.empty(int(ops.lib.aon_art_bwd_packed_bytes()), dtype=torch.uint8, device=next(self.parameters()).device)
 
     def ordered_params(self):
         params = dict(self.named_parameters())
@@ -158,14 +162,17 @@ class NeRF_AE_Art(nn.Module):
             # training: HIP forward that keeps the activation planes + HIP backward (autograd.RenderArticulated);
             # the per-call block must not alias the cached inference buffer (it is saved for backward)
             mlps = [self.coarse_mlp, self.fine_mlp][: self.num_levels]
+            bwd, bwd_ready = packed_bwd_aside(mlps)
             packs = []
-            for mlp in mlps:
+            for mlp, b in zip(mlps, bwd):
                 small = ops.art_prepare(dict(mlp.named_parameters()), latents, degrees=mlp.degrees)
-                packs.append((mlp.packed(True), small, mlp.packed_bwd(True)))
+                packs.append((mlp.packed(True), small, b))
             params = [p for mlp in mlps for p in mlp.ordered_params()]
             flat = RenderArticulated.apply(rays_o, rays["rays_d"], rays["viewdirs"], float(near), float(far), bool(white_bkgd),
                                            self.num_levels, t_rand, u, packs, self._opts, noise, latents["density"], latents["color"],
                                            latents["articulation"], *params)
+            if bwd_ready is not None:
+                torch.cuda.current_stream(rays_o.device).wait_event(bwd_ready)   # (behind the forward's launches: free by then)
             return [tuple(flat[3 * i: 3 * i + 3]) for i in range(self.num_levels)]
         two = self.num_levels == 2
         pc = self.coarse_mlp.packed()
@@ -182,7 +189,7 @@ from collections import defaultdict  # noqa: E402
 from . import helper  # noqa: E402
 from ..code_library import CodeLibraryArticulated  # noqa: E402
 from ..interface import Harness  # noqa: E402
-from .model import _fused_adam  # noqa: E402
+from .model import _fused_adam, packed_bwd_aside  # noqa: E402
 
 _SCALAR_KEYS = ("deg", "instance_id", "articulation_id")
 
