@@ -151,7 +151,7 @@ for _name, (_res, _args) in _SIGS.items():
     _fn.restype = _res
     _fn.argtypes = _args
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 if lib.aon_abi_version() != ABI_VERSION:
     raise ImportError(f"libaon_hip.so ABI {lib.aon_abi_version()} != binding ABI {ABI_VERSION}; rebuild")
 

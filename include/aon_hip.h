@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define AON_ABI_VERSION 3
+#define AON_ABI_VERSION 4   /* 4: + aon_train_loss_*, aon_view_bias, aon_set_view_bias, aon_set_bwd_early_heads; render / train workspaces hold a per-ray view bias */
 
 #define AON_OK 0
 #define AON_E_INVALID (-1)    /* null pointer, negative size, unsupported geometry */

@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(_lib.lib, n), f"{n} declared in aon_hip.h but not exported"
     assert sorted(_lib.exported_symbols()) == names, "ctypes binding and header disagree"
-    assert _lib.lib.aon_abi_version() == 3
+    assert _lib.lib.aon_abi_version() == 4
 
 
 def test_argument_validation_without_gpu():
