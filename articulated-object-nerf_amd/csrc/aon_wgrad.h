@@ -107,7 +107,13 @@ __host__ __device__ constexpr int wg_K(int kind) {
 // (lgkmcnt), and the "memory" clobber keeps the compiler from moving LDS accesses across it.
 template <int N>
 __device__ __forceinline__ void stage_barrier() {
+#if defined(AON_EXP_WG_NOBAR)     // timing experiment only (WRONG results): the waits without the workgroup barrier
+  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
+#elif defined(AON_EXP_WG_NOVM)    // timing experiment only (WRONG results): the barrier without the wait for the stage's DMA
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
+#else
   asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
+#endif
 }
 
 template <int KIND>
