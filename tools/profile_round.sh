@@ -21,9 +21,10 @@ run rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GR
 run rocprofv3 --kernel-trace --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY -d $OUT/pmc_sq2 -o $TAG -- python $REPO/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-train-leg --no-extra-legs --no-alt > $OUT/pmc_sq2.log 2>&1
 # 3. training steps (BASELINE config 5 per GPU, and the reference's vanilla batch).  Kernel statistics with the two levels'
 #    backward SERIALISED on one stream (--no-overlap): on the product's two library streams kernels of the two levels share the
-#    CUs and their individual durations stretch; the product's step time comes from the un-profiled runs below.
-run rocprofv3 --kernel-trace --stats -d $OUT/train_art -o $TAG -- python $REPO/tools/train_bench.py --rays 4096 --steps 10 --articulated --no-overlap > $OUT/train_art_serial.log 2>&1
-run rocprofv3 --kernel-trace --stats -d $OUT/train_van -o $TAG -- python $REPO/tools/train_bench.py --rays 4096 --steps 10 --no-overlap > $OUT/train_van_serial.log 2>&1
+#    CUs and their individual durations stretch (likewise --late-heads: the early head reductions wait for compute units beside the chain and
+#    would show the chain's duration as their own); the product's step time comes from the un-profiled runs below.
+run rocprofv3 --kernel-trace --stats -d $OUT/train_art -o $TAG -- python $REPO/tools/train_bench.py --rays 4096 --steps 10 --articulated --no-overlap --late-heads > $OUT/train_art_serial.log 2>&1
+run rocprofv3 --kernel-trace --stats -d $OUT/train_van -o $TAG -- python $REPO/tools/train_bench.py --rays 4096 --steps 10 --no-overlap --late-heads > $OUT/train_van_serial.log 2>&1
 run python $REPO/tools/train_bench.py --rays 4096 --steps 20 --articulated > $OUT/train_art.log 2>&1
 run python $REPO/tools/train_bench.py --rays 4096 --steps 20 > $OUT/train_van.log 2>&1
 # 4. articulated render (BASELINE config 4)
