@@ -756,10 +756,22 @@ __global__ __launch_bounds__(1024) void train_loss_fwd_kernel(LossArgs a) {
   __shared__ double lat_red[3][16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   double s[2] = {0.0, 0.0};
-  for (int64_t i = tid; i < a.numel; i += 1024) {
-    const float t = a.target[i];
-    for (int l = 0; l < 2; ++l)
-      if (a.rgb[l]) { const float d = __fsub_rn(a.rgb[l][i], t); s[l] += (double)d * (double)d; }
+  // four strides per trip, every load issued before the first use: one workgroup's sum is a chain of load latencies otherwise
+  // (12 trips at 4096 rays); the order of the additions per thread is the element order either way
+  for (int64_t i0 = tid; i0 < a.numel; i0 += 4 * 1024) {
+    float t[4], x[2][4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int64_t i = i0 + (int64_t)e * 1024;
+      const bool in = i < a.numel;
+      t[e] = in ? a.target[i] : 0.f;
+      x[0][e] = (in && a.rgb[0]) ? a.rgb[0][i] : t[e];
+      x[1][e] = in ? a.rgb[1][i] : t[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int l = 0; l < 2; ++l) { const float d = __fsub_rn(x[l][e], t[e]); s[l] += (double)d * (double)d; }
   }
   double ls[3] = {0.0, 0.0, 0.0};
   for (int k = 0; k < 3; ++k)

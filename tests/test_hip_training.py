@@ -587,3 +587,31 @@ def test_forward_overlap_is_bit_identical(dev, net):
             ops.set_bwd_early_heads(True)
         for a, b, c in zip(*res):
             assert torch.equal(a, b) and torch.equal(a, c)
+
+
+def test_transposed_streams_packed_on_a_side_stream_same_gradients(dev, nerf_sd, monkeypatch):
+    """Round 5: the drop-in modules pack the levels' transposed streams on a side torch stream beside the forward
+    (models/vanilla_nerf/model.py packed_bwd_aside; AON_PACK_ASIDE=0 packs in line).  Same buffers, same kernels: every output and
+    gradient bit-equal, over several steps with an optimiser step in between (the side stream must see the updated parameters)."""
+    import aon_amd.synthetic as syn
+    from aon_amd.models.vanilla_nerf.model import NeRF
+
+    n = 300
+    rays = {k: v.to(dev) for k, v in syn.random_rays(n, seed=77).items()}
+    target = syn.seeded_uniform(78, n, 3).to(dev)
+    res = {}
+    for aside in ("1", "0"):
+        monkeypatch.setenv("AON_PACK_ASIDE", aside)
+        model = NeRF().to(dev)
+        model.load_state_dict(nerf_sd)
+        opt = torch.optim.SGD(model.parameters(), lr=1e-3)
+        out_all = []
+        for step in range(3):
+            tr, u = syn.seeded_uniform(80 + step, n, 65).to(dev), syn.seeded_uniform(90 + step, n, 128).to(dev)
+            opt.zero_grad()
+            out = model(rays, True, True, 2.0, 6.0, t_rand=tr, u=u)
+            (((out[0][0] - target) ** 2).mean() + ((out[1][0] - target) ** 2).mean()).backward()
+            out_all += [x.detach().clone() for lvl in out for x in lvl] + [p.grad.clone() for p in model.parameters()]
+            opt.step()
+        res[aside] = out_all
+    assert all(torch.equal(a, b) for a, b in zip(res["1"], res["0"]))
