@@ -260,10 +260,14 @@ __global__ void __launch_bounds__(256) mlp_fwd_kernel(MlpArgs args) {
     // L5: cat[h(256), enc(63)] -> 256     (model.py:102-103: concat after layer 4's ReLU)
     mw = u32x4{0u, 0u, 0u, 0u}; init_bias(Y, sm + kSmBias + 5 * 256, h);
     dense_layer<Net, kChL5, 8, 8>(p, X, Y, consume(X, plane_h(4), mw, true)); put_mask(mw, 4);
+    // (the in-kernel encoding stays live across layers 1-4, 32 registers, as in the inference kernel; rounds 2-4 re-encoded it here:
+    // see art_mlp_fwd_kernel)
+#ifdef AON_TRAIN_REENCODE
     if constexpr (TRAIN && ENC_IN_KERNEL) {  // (x made opaque: otherwise the two identical encodings are merged and the first stays live)
       asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]));
       encode_pos(x, h, E);
-    }  // re-encoded (same function, same bits) instead of 32 registers held live across layers 1-4
+    }
+#endif
     if constexpr (TRAIN && !ENC_IN_KERNEL) {
       int64_t gq = gc;
       asm volatile("" : "+v"(gq));   // opaque: a second read, not the first one kept live

@@ -335,10 +335,15 @@ __global__ void __launch_bounds__(256) art_mlp_fwd_kernel(ArtMlpArgs args) {
     init_bias(X, sm + kA_BT + 4 * 256, h); dense_layer<Net, kAChT1 + 24, 8, 8>(p, Y, X, consume8(Y, aplane_h(3), true)); put_mask(7); relu_tiles(X);
     init_bias(Y, sm + kA_BT + 5 * 256, h);
     dense_layer<Net, kAChT5, 8, 8>(p, X, Y, consume8(X, aplane_h(4), true)); put_mask(8);
-    if constexpr (TRAIN) {  // re-encoded (same function, same bits; xd made opaque so the two encodings are not merged) instead of
-      asm volatile("" : "+v"(xd[0]), "+v"(xd[1]), "+v"(xd[2]));   // 32 registers held live across layers 1-4
+    // (the encoding stays live across layers 1-4, 32 registers, as in the inference kernel.  Rounds 2-4 re-encoded it here -- 30 sines --
+    // to stay clear of spills; with the view encoding gone from the trunk (per-ray view bias) both forms build with 0 scratch and this one
+    // is 0.04 ms per step faster: profiles/r05_view_bias_ab.txt)
+#ifdef AON_TRAIN_REENCODE
+    if constexpr (TRAIN) {
+      asm volatile("" : "+v"(xd[0]), "+v"(xd[1]), "+v"(xd[2]));
       encode_pos_scaled(xd, h, sm + kA_ESC, E);
     }
+#endif
     chunk_mma<Net, kAChT5 + 8, 8, 16>(p, E[0], Y);
     chunk_mma<Net, kAChT5 + 9, 8, 16>(p, E[1], Y);
     relu_tiles(Y);
