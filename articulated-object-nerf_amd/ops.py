@@ -439,8 +439,8 @@ def set_coarse_fusion(on: bool) -> None:
 
 # ------------------------------------------------------------------ R9 whole path
 _WS_CACHE: dict = {}
-# rays rendered per internal chunk: a whole 640x480 frame (307,200 rays) in one pass -- 4,380 B/ray of per-ray sample buffers =
-# 1.35 GB of the 288 GB, so that every per-ray kernel is ONE launch per frame (round 2: 65,536-ray chunks, five 30-60 us launches
+# rays rendered per internal chunk: a whole 640x480 frame (307,200 rays) in one pass -- 4,892 B/ray of per-ray buffers (sample
+# records, t, weights, the per-ray view bias) = 1.5 GB of the 288 GB, so that every per-ray kernel is ONE launch per frame (round 2: 65,536-ray chunks, five 30-60 us launches
 # each of which spent a fifth of its time ramping up and draining)
 MAX_CHUNK_RAYS = 327680
 
