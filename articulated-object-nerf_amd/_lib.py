@@ -78,6 +78,11 @@ _SIGS = {
     "aon_set_bottleneck_fold": (_i, [_i]),
     "aon_get_bottleneck_fold": (_i, []),
     "aon_stream_is_folded": (_i, [_p]),
+    "aon_stream_form": (_i, [_p]),
+    "aon_declare_stream_form": (_i, [_p, _i]),
+    "aon_adam_step": (_i, [_p, _p, _p, _p, _l, C.c_double, C.c_double, C.c_double, C.c_double, _l, _p]),
+    "aon_code_library_fwd": (_i, [_p, _p, _p, _p, _p, _p]),
+    "aon_code_library_bwd": (_i, [_p, _p, _p, _p, _p, _p]),
     "aon_set_bwd_early_heads": (_i, [_i]),
     "aon_set_view_bias": (_i, [_i]),
     "aon_get_view_bias": (_i, []),
@@ -151,7 +156,7 @@ for _name, (_res, _args) in _SIGS.items():
     _fn.restype = _res
     _fn.argtypes = _args
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 if lib.aon_abi_version() != ABI_VERSION:
     raise ImportError(f"libaon_hip.so ABI {lib.aon_abi_version()} != binding ABI {ABI_VERSION}; rebuild")
 

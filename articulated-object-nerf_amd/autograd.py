@@ -9,6 +9,57 @@ from __future__ import annotations
 import torch
 
 from . import ops
+from .arena import arena_of, grad_views
+
+
+def _arena_plan(ctx, params):
+    """Round 6: when every parameter of this forward lives in one ParamArena (aon_amd/arena.py), its backward writes the parameter
+    gradients straight into the arena's gradient slots and returns views of them -- autograd adopts a returned tensor as `.grad` without
+    copying -- so that the optimiser and the data-parallel mean run on one flat buffer.  Decided here (forward): the arena and a claim on
+    the slots (see ParamArena.claim); re-checked in the backward (`_arena_grads`)."""
+    ctx.arena_plan = None
+    ao = arena_of(params)
+    if ao is None:
+        return
+    tok = ao[0].claim(ao[1])
+    if tok is not None:
+        ctx.arena_plan = (ao, tok, list(params))
+
+
+def _arena_grads(ctx, per_level_shapes):
+    """-> per level list of gradient-slot views, or None: only if the plan was granted AND no parameter holds a gradient yet (a second
+    backward before zero_grad must ADD to the first one's gradients, which live in those very slots)."""
+    plan = getattr(ctx, "arena_plan", None)
+    if plan is None:
+        return None
+    (arena, offs), tok, params = plan
+    if tok.done or not arena.intact() or any(p.grad is not None for p in params):
+        return None
+    flat_shapes = [shp for lvl in per_level_shapes for shp in lvl]
+    views = grad_views((arena, offs), flat_shapes)
+    out, k = [], 0
+    for lvl in per_level_shapes:
+        out.append(views[k: k + len(lvl)])
+        k += len(lvl)
+    return out
+
+
+def _arena_done(ctx):
+    plan = getattr(ctx, "arena_plan", None)
+    if plan is not None:
+        plan[1].done = True
+        ctx.arena_plan = None
+
+
+def _wait_packed(packs_bwd, device):
+    """The transposed streams may have been packed on a side stream (models.vanilla_nerf.model.packed_bwd_aside): the stream this backward
+    runs on -- not necessarily the forward's -- waits for that pack."""
+    seen = set()
+    for b in packs_bwd:
+        ev = getattr(b, "_aon_ready", None)
+        if ev is not None and id(ev) not in seen:
+            seen.add(id(ev))
+            torch.cuda.current_stream(device).wait_event(ev)
 
 
 def _check_not_released(ctx):
@@ -31,19 +82,25 @@ class RenderVanilla(torch.autograd.Function):
         levels, ws, ctx.geometry = ops.render_fwd_train(packs[0][0], packs[1][0] if num_levels == 2 else None, rays_o, rays_d, viewdirs, near, far,
                                                         white_bkgd, num_levels, t_rand, u, opts=opts, noise=noise)
         ctx.fused = (ws, [pk[1] for pk in packs], [pk[0] for pk in packs])
+        _arena_plan(ctx, params)
+        ctx.param_shapes = [tuple(p.shape) for p in params]
         return tuple(x for lvl in levels for x in lvl)
 
     @staticmethod
     def backward(ctx, *gouts):
         _check_not_released(ctx)
         ws, packs_bwd, packs_fwd = ctx.fused    # the whole backward is ONE C call too (aon_render_bwd)
+        _wait_packed(packs_bwd, ctx.rays_d.device)
+        n_per = len(ops.VANILLA_PARAM_ORDER)
+        slots = _arena_grads(ctx, [ctx.param_shapes[l * n_per: (l + 1) * n_per] for l in range(ctx.num_levels)])
         n = ctx.rays_d.shape[0]
         g_rgb = [gouts[3 * l] if gouts[3 * l] is not None else torch.zeros((n, 3), dtype=torch.float32, device=ctx.rays_d.device)
                  for l in range(ctx.num_levels)]
         per_level = ops.render_bwd(ws, packs_bwd, packs_fwd, ctx.rays_d, ctx.white_bkgd, ctx.num_levels, g_rgb,
                                    [gouts[3 * l + 1] for l in range(ctx.num_levels)], [gouts[3 * l + 2] for l in range(ctx.num_levels)],
-                                   geometry=ctx.geometry)
+                                   geometry=ctx.geometry, grads_out=slots)
         ctx.fused, ctx.released, ctx.geometry = None, True, None
+        _arena_done(ctx)
         return (None,) * 12 + tuple(g[name] for g in per_level for name in ops.VANILLA_PARAM_ORDER)
 
 
@@ -126,6 +183,7 @@ class RenderArticulated(torch.autograd.Function):
                                                         white_bkgd, num_levels, t_rand, u, small_c=packs[0][1],
                                                         small_f=packs[1][1] if num_levels == 2 else None, opts=opts, noise=noise)
         ctx.fused = (ws, [pk[2] for pk in packs], [pk[1] for pk in packs])   # ONE C call (aon_art_render_fwd_train)
+        _arena_plan(ctx, params)
         return tuple(x for lvl in levels for x in lvl)
 
     @staticmethod
@@ -133,15 +191,18 @@ class RenderArticulated(torch.autograd.Function):
         n_per = len(ops.ART_PARAM_ORDER)
         _check_not_released(ctx)
         ws, packs_bwd, smalls = ctx.fused       # the whole backward in ONE C call (aon_art_render_bwd)
+        _wait_packed(packs_bwd, ctx.rays_d.device)
         n = ctx.rays_d.shape[0]
         g_rgb = [gouts[3 * l] if gouts[3 * l] is not None else torch.zeros((n, 3), dtype=torch.float32, device=ctx.rays_d.device)
                  for l in range(ctx.num_levels)]
         saved = ctx.saved_tensors   # (raises if a parameter or latent was modified in place since the forward)
         latents = {"density": saved[0], "color": saved[1], "articulation": saved[2]}
         params = [dict(zip(ops.ART_PARAM_ORDER, saved[3 + l * n_per: 3 + (l + 1) * n_per])) for l in range(ctx.num_levels)]
+        slots = _arena_grads(ctx, [[tuple(t.shape) for t in saved[3 + l * n_per: 3 + (l + 1) * n_per]] for l in range(ctx.num_levels)])
         per_level, g_lat = ops.art_render_bwd(ws, packs_bwd, smalls, ctx.rays_d, ctx.white_bkgd, ctx.num_levels, g_rgb,
                                               [gouts[3 * l + 1] for l in range(ctx.num_levels)], [gouts[3 * l + 2] for l in range(ctx.num_levels)],
-                                              params, latents, geometry=ctx.geometry)
+                                              params, latents, geometry=ctx.geometry, grads_out=slots)
         ctx.fused, ctx.released, ctx.geometry = None, True, None
+        _arena_done(ctx)
         lat = tuple(g_lat[k].reshape(shp) for k, shp in zip(("density", "color", "articulation"), ctx.lat_shapes))
         return (None,) * 12 + lat + tuple(g[name] for g in per_level for name in ops.ART_PARAM_ORDER)

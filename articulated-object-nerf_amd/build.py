@@ -17,7 +17,7 @@ CSRC = os.path.join(PKG, "csrc")
 _TAG = os.environ.get("AON_BUILD_TAG", "")
 OBJ = os.path.join(PKG, "build" + ("_" + _TAG if _TAG else ""))
 LIB = os.path.join(PKG, "libaon_hip" + ("_" + _TAG if _TAG else "") + ".so")
-SOURCES = ["aon_mlp.hip", "aon_mlp_art.hip", "aon_train.hip", "aon_train_art.hip", "aon_render.hip", "aon_gmlp.hip", "aon_fold.hip", "aon_capi.hip"]
+SOURCES = ["aon_mlp.hip", "aon_mlp_art.hip", "aon_train.hip", "aon_train_art.hip", "aon_render.hip", "aon_gmlp.hip", "aon_fold.hip", "aon_optim.hip", "aon_capi.hip"]
 HEADERS = [os.path.join(CSRC, "aon_common.h"), os.path.join(CSRC, "aon_mlp_core.h"), os.path.join(CSRC, "aon_wgrad.h"), os.path.join(CSRC, "aon_art_common.h"), os.path.join(CSRC, "aon_ray_core.h"), os.path.join(CSRC, "aon_gmlp.h"), os.path.join(CSRC, "aon_fold.h"),
            os.path.join(os.path.dirname(PKG), "include", "aon_hip.h")]
 # -ffp-contract=off: the stage kernels reproduce the reference's un-fused mul/add sequences; FMAs are explicit.

@@ -65,9 +65,11 @@ hipError_t launch_art_bwd_chain(const char* packed_bwd, const float* small, cons
 hipError_t launch_art_wgrad(const float* planes, const float* dplanes, const float* d_raw, const float* dxp, int64_t Np,
                             const float* const* params, const float* shape, const float* app, const float* art,
                             float* const* grads, float* g_shape, float* g_app, float* g_art, float* ws, hipStream_t stream, const WgAux* aux, int pos_levels, int view_levels,
-                            const void* packed_bwd, int phase = 0);
+                            const void* packed_bwd, int phase = 0, bool accumulate_latents = false);
 hipError_t launch_train_loss(bool backward, const float* rgb_c, const float* rgb_f, const float* target, int64_t n, const float* const* lat, const int* lat_len,
                              float reg_scale, float* stats, float* loss, const float* go, float* d_rgb_c, float* d_rgb_f, float* const* d_lat, hipStream_t stream);
+hipError_t launch_adam(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2, double eps, int64_t step, hipStream_t stream);
+hipError_t launch_code_library(bool backward, const float* const* src, const int64_t* const* idx, const int* rows, const int* dim, float* const* dst, hipStream_t stream);
 hipError_t launch_raygen(const float* c2w, int H, int W, float focal, const float* directions, int64_t pix_begin,
                          int64_t pix_end, float* rays_o, float* viewdirs, float* rays_d, hipStream_t stream);
 hipError_t launch_ray_directions(int H, int W, float focal, float* out, hipStream_t stream);
@@ -110,8 +112,13 @@ int check(hipError_t e, const char* where) {
 constexpr int kSc = 65, kSf = 193;
 
 // round 5: the articulated calls take a packed stream AND a per-call block; both carry a form (bottleneck folded / literal, aon_fold.h)
-const char* kFormsMsg = "packed stream and per-call block were made in different forms (aon_set_bottleneck_fold changed between aon_pack_art_mlp* and aon_art_prepare*)";
-bool forms_differ(const void* a, const void* b) { return a && b && aon::stream_form(a) != aon::stream_form(b); }
+const char* kFormsMsg = "two of the packed buffers of this call were made in different forms (aon_set_bottleneck_fold changed between the pack / prepare calls), "
+                        "or one of them was never packed or declared by this process (a copy: aon_declare_stream_form)";
+const char* kNullBwdMsg = "packed_bwd is NULL (= literal planes) while the process default is the folded form: pass the transposed stream the chain ran with";
+// (an unknown pointer -- a copy nobody declared -- differs from everything, itself included)
+bool forms_differ(const void* a, const void* b) {
+  return a && b && (aon::stream_form(a) != aon::stream_form(b) || aon::stream_form(a) == aon::kFormUnknown);
+}
 
 // Optional live timing of the path's kernels with HIP events on the LAUNCH stream (torch.cuda.Event would only see torch's
 // current stream), by kernel class; bench.py turns the totals into roofline figures.  Off unless aon_profile_begin() was
@@ -537,6 +544,7 @@ int aon_mlp_bwd_chain(const void* packed_bwd, const void* packed_fwd, const floa
   if (Np < 0 || (Np & 127)) return fail(AON_E_INVALID, "aon_mlp_bwd_chain: Np must be a multiple of 128");
   if (Np == 0) return AON_OK;
   if (!packed_bwd || !packed_fwd || !d_raw || !masks || !dplanes) return fail(AON_E_INVALID, "aon_mlp_bwd_chain: null pointer");
+  if (forms_differ(packed_bwd, packed_fwd)) return fail(AON_E_INVALID, kFormsMsg);   // (the masks / planes came from packed_fwd's kernel: ADVICE r5)
   KTimer timer(kBwdChain, (hipStream_t)stream, Np);
   return check(aon::launch_mlp_bwd_chain(static_cast<const char*>(packed_bwd), static_cast<const char*>(packed_fwd), d_raw, masks,
                                          dplanes, Np, (hipStream_t)stream), "aon_mlp_bwd_chain");
@@ -549,6 +557,7 @@ int aon_vanilla_wgrad(const float* planes, const float* dplanes, const float* d_
   for (int i = 0; i < aon::kNumVanillaParams; ++i)
     if (!grads_host[i]) return fail(AON_E_INVALID, "aon_vanilla_wgrad: null gradient pointer");
   if (workspace_bytes < aon::wgrad_workspace_bytes()) return fail(AON_E_WORKSPACE, "aon_vanilla_wgrad: workspace too small");
+  if (!packed_bwd && aon::fold_default() == aon::kFormFolded) return fail(AON_E_INVALID, kNullBwdMsg);
   KTimer timer(kWgrad, (hipStream_t)stream, Np);
   return check(aon::launch_vanilla_wgrad(planes, dplanes, d_raw, Np, grads_host, static_cast<float*>(workspace), (hipStream_t)stream, nullptr, packed_bwd),
                "aon_vanilla_wgrad");
@@ -622,10 +631,37 @@ int aon_art_wgrad_deg(const float* planes, const float* dplanes, const float* d_
   for (int i = 0; i < 40; ++i)
     if (!params_host[i] || !grads_host[i]) return fail(AON_E_INVALID, "aon_art_wgrad: null parameter / gradient pointer");
   if (workspace_bytes < aon::wgrad_workspace_bytes()) return fail(AON_E_WORKSPACE, "aon_art_wgrad: workspace too small");
+  if (!packed_bwd && aon::fold_default() == aon::kFormFolded) return fail(AON_E_INVALID, kNullBwdMsg);
   KTimer timer(kWgrad, (hipStream_t)stream, Np);
   return check(aon::launch_art_wgrad(planes, dplanes, d_raw, dxp, Np, params_host, shape, appearance, articulation, grads_host, g_shape,
                                      g_appearance, g_articulation, static_cast<float*>(workspace), (hipStream_t)stream, nullptr,
                                      max_deg_point - min_deg_point, deg_view, packed_bwd), "aon_art_wgrad");
+}
+
+// ---- round 6: the end of a training step on one parameter arena (csrc/aon_optim.hip) ----
+int aon_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, double lr, double beta1, double beta2, double eps,
+                  int64_t step, void* stream) {
+  if (n < 0 || step < 1) return fail(AON_E_INVALID, "aon_adam_step: n must be >= 0 and step >= 1 (the count AFTER this update, as torch.optim.Adam's state['step'])");
+  if (n == 0) return AON_OK;
+  if (!params || !grads || !exp_avg || !exp_avg_sq) return fail(AON_E_INVALID, "aon_adam_step: null pointer");
+  if (!(lr >= 0.0) || !(beta1 >= 0.0 && beta1 < 1.0) || !(beta2 >= 0.0 && beta2 < 1.0) || !(eps >= 0.0)) return fail(AON_E_INVALID, "aon_adam_step: bad hyper-parameter");
+  return check(aon::launch_adam(params, grads, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, step, (hipStream_t)stream), "aon_adam_step");
+}
+
+static int code_library_call(bool backward, const float* const* src, const int64_t* const* ids, const int* rows, const int* dims, float* const* dst, void* stream,
+                             const char* who) {
+  if (!src || !ids || !rows || !dims || !dst) return fail(AON_E_INVALID, "aon_code_library: null array");
+  for (int t = 0; t < 3; ++t)
+    if (!src[t] || !ids[t] || !dst[t] || rows[t] < 1 || dims[t] < 1 || (int64_t)rows[t] * dims[t] > (1 << 28)) return fail(AON_E_INVALID, "aon_code_library: null pointer or bad table size");
+  return check(aon::launch_code_library(backward, src, ids, rows, dims, dst, (hipStream_t)stream), who);
+}
+int aon_code_library_fwd(const float* const* tables_host, const int64_t* const* ids_host, const int* rows_host, const int* dims_host, float* const* out_host,
+                         void* stream) {
+  return code_library_call(false, tables_host, ids_host, rows_host, dims_host, out_host, stream, "aon_code_library_fwd");
+}
+int aon_code_library_bwd(const float* const* g_rows_host, const int64_t* const* ids_host, const int* rows_host, const int* dims_host, float* const* g_tables_host,
+                         void* stream) {
+  return code_library_call(true, g_rows_host, ids_host, rows_host, dims_host, g_tables_host, stream, "aon_code_library_bwd");
 }
 
 int aon_profile_begin(void) {
@@ -1187,6 +1223,12 @@ int aon_set_bottleneck_fold(int on) {
 }
 int aon_get_bottleneck_fold(void) { return aon::fold_default(); }
 int aon_stream_is_folded(const void* packed) { return aon::stream_form(packed) == aon::kFormFolded ? 1 : 0; }
+int aon_stream_form(const void* packed) { return aon::stream_form(packed); }
+int aon_declare_stream_form(const void* packed, int form) {
+  if (!packed || (form != aon::kFormLiteral && form != aon::kFormFolded)) return fail(AON_E_INVALID, "aon_declare_stream_form: null pointer or form not 0 / 1");
+  aon::set_stream_form(packed, form);
+  return AON_OK;
+}
 
 int aon_set_bwd_overlap(int on) {
   g_bwd_overlap.store(on == 2 ? 2 : (on ? 1 : 0), std::memory_order_relaxed);
@@ -1460,10 +1502,13 @@ int aon_art_render_bwd_ex(const void* packed_bwd_coarse, const void* small_coars
   if (fork.rc()) return fork.rc();
   const aon::WgAux* side = early_heads ? fork.aux(0) : nullptr;
   auto level_wgrad = [&](int l, hipStream_t st, const aon::WgAux* aux, int phase) {
-    // level 0 writes the latent gradients, level 1 adds its own (both MLPs see the same latents)
-    float* gs = l == 0 ? g_shape : sc.lat_tmp, *ga = l == 0 ? g_appearance : sc.lat_tmp + 128, *gt = l == 0 ? g_articulation : sc.lat_tmp + 256;
+    // level 0 writes the latent gradients, level 1 adds its own (both MLPs see the same latents).  Merged schedule (round 6): both levels'
+    // finishing kernels run on the caller's stream in level order, so level 1's adds onto level 0's result in place (g = coarse + fine, the
+    // bits of the three add launches this replaces); level streams: into a temporary, added after the join
+    const bool acc = merged && l == 1;
+    float* gs = (l == 0 || acc) ? g_shape : sc.lat_tmp, *ga = (l == 0 || acc) ? g_appearance : sc.lat_tmp + 128, *gt = (l == 0 || acc) ? g_articulation : sc.lat_tmp + 256;
     return check(aon::launch_art_wgrad(w.lvl[l].planes, sc.dplanes[l], sc.d_raw[l], sc.dxp[l], w.lvl[l].Np, params[l], shape, appearance, articulation, grads[l], gs, ga, gt,
-                                       sc.wgrad_ws[l], st, aux, g.max_deg - g.min_deg, g.deg_view, pb[l], phase), "aon_art_render_bwd");
+                                       sc.wgrad_ws[l], st, aux, g.max_deg - g.min_deg, g.deg_view, pb[l], phase, acc), "aon_art_render_bwd");
   };
   if (merged) {
     for (int l = 0; l < 2; ++l)
@@ -1501,7 +1546,7 @@ int aon_art_render_bwd_ex(const void* packed_bwd_coarse, const void* small_coars
     if (rc) return rc;
   }
   if (int rc = fork.join()) return rc;   // the caller's stream continues after both levels
-  if (num_levels == 2) {
+  if (num_levels == 2 && !merged) {
     add_into_kernel<<<dim3(1), dim3(128), 0, caller>>>(g_shape, sc.lat_tmp, 128);
     add_into_kernel<<<dim3(1), dim3(128), 0, caller>>>(g_appearance, sc.lat_tmp + 128, 128);
     add_into_kernel<<<dim3(1), dim3(32), 0, caller>>>(g_articulation, sc.lat_tmp + 256, 32);

@@ -1,6 +1,12 @@
 // Shared constants and small device helpers for the gfx950 (MI355X / CDNA4) NeRF render kernels.
 // Wave size is 64 on CDNA; every wave-width constant below is hard-coded to 64.
 #pragma once
+// Timing-experiment switches (AON_EXP_*: kernels with a piece removed, WRONG results -- tools/exp_*.sh build them as side libraries) must never
+// reach a product build: they are honoured only together with AON_EXPERIMENT_BUILD.
+#if (defined(AON_EXP_GEMM_NOBARRIER) || defined(AON_EXP_GEMM_NOSTORE) || defined(AON_EXP_L0E_SIDE) || defined(AON_EXP_MASK_VGPR) || defined(AON_EXP_NOBARRIER) || defined(AON_EXP_NOBIAS) || defined(AON_EXP_NOENC) || defined(AON_EXP_NOFINAL) || defined(AON_EXP_NOMASK) || defined(AON_EXP_NOPARK) || defined(AON_EXP_NORELU) || defined(AON_EXP_NOSTORE) || defined(AON_EXP_NOSTORE4) || defined(AON_EXP_NOSTORE8) || defined(AON_EXP_NOSTORE_L0E) || defined(AON_EXP_NOSTORE_L5) || defined(AON_EXP_NOVMWAIT) || defined(AON_EXP_NO_NT) || defined(AON_EXP_STORE_OF) || defined(AON_EXP_WG_NOBAR) || defined(AON_EXP_WG_NOVM)) && !defined(AON_EXPERIMENT_BUILD)
+#error "an AON_EXP_* timing-experiment switch is defined without AON_EXPERIMENT_BUILD: these kernels compute wrong results"
+#endif
+
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 

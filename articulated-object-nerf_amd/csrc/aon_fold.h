@@ -5,14 +5,16 @@
 
 namespace aon {
 
-enum : int { kFormLiteral = 0, kFormFolded = 1 };
+enum : int { kFormUnknown = -1, kFormLiteral = 0, kFormFolded = 1 };
 
 // process-wide default of the pack entry points (aon_set_bottleneck_fold); every pack call reads it ONCE
 int fold_default();
 void set_fold_default(int on);
 // The form of a packed buffer is a property of the BUFFER, decided when it was packed: the launchers look it up by pointer, so flipping
 // the switch between packing a stream and using it cannot pair a stream with the other form's kernel.  A pointer this process never
-// packed (a copy of a packed buffer) has the current default.
+// packed or declared (a copy of a packed buffer) is kFormUnknown and every launcher refuses it (round 6, ADVICE r5: rounds 5 assumed the
+// current default, which pairs a cloned literal stream with the folded kernels after the switch moved).  The owner of a copy states its
+// form with aon_declare_stream_form; the Python binding carries the form next to the tensor and re-declares it on every call.
 void set_stream_form(const void* p, int form);
 int stream_form(const void* p);
 

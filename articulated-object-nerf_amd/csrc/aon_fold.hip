@@ -27,16 +27,16 @@ std::unordered_map<uintptr_t, int>& form_table() {
 
 void set_stream_form(const void* p, int form) {
   std::lock_guard<std::mutex> lk(g_form_mu);
-  auto& t = form_table();
-  if (t.size() > (1u << 16)) t.clear();   // (addresses a caching allocator hands out repeat; a process that packs into >65k distinct ones starts over)
-  t[reinterpret_cast<uintptr_t>(p)] = form;
+  // (never cleared: an entry is 50 bytes and a caching allocator hands the same addresses out again; clearing while buffers are live
+  // would make them "never packed" -- ADVICE r5)
+  form_table()[reinterpret_cast<uintptr_t>(p)] = form;
 }
 
 int stream_form(const void* p) {
   std::lock_guard<std::mutex> lk(g_form_mu);
   auto& t = form_table();
   auto it = t.find(reinterpret_cast<uintptr_t>(p));
-  return it == t.end() ? fold_default() : it->second;
+  return it == t.end() ? kFormUnknown : it->second;
 }
 
 // ---------------------------------------------------------------------------------------------

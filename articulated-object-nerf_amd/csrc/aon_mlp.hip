@@ -405,6 +405,7 @@ static hipError_t launch_mlp_tf(const MlpArgs& args, hipStream_t stream) {
 template <bool ENC, bool TRAIN>
 static hipError_t launch_mlp_t(const MlpArgs& args, hipStream_t stream) {
   const int form = stream_form(args.seg[0].packed);
+  if (form == kFormUnknown) return hipErrorInvalidValue;   // never packed / declared (a copy): refuse instead of guessing
   if (args.seg[1].npass > 0 && stream_form(args.seg[1].packed) != form) return hipErrorInvalidValue;
   // the per-ray view bias: every segment of the launch or none (whole-path calls on the in-kernel encodings; folded form only)
   const bool vb = args.seg[0].view_bias != nullptr;

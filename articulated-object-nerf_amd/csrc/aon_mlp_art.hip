@@ -104,7 +104,10 @@ struct ArtPrepArgs {
 };
 
 // small[] = plain copies of the small vectors + the latent-folded effective biases
-// fold: the block of a FOLDED stream -- views_linear.0's effective bias additionally carries W_v0[:, :256] b_b (in fp64, rounded once with the rest)
+// fold: the block of a FOLDED stream -- views_linear.0's effective bias additionally carries W_v0[:, :256] b_b: that sum is accumulated in fp64 and
+// added to the fp32 value of b_v0 + (appearance term) -- which the literal form rounds as well -- so the effective bias is rounded TWICE (the
+// fp32 chain of the latent term, then once more with the fp64 sum on top), not once like the vanilla b' (the earlier wording
+// claimed one rounding; the un-folded gradients treat the bias as exact either way, and the second rounding is half an ulp of the bias)
 __global__ void prepare_art_kernel(ArtPrepArgs a, float* __restrict__ small, int min_deg, int L, int Lv, int fold) {
   const int P = 3 + 6 * L, V = 3 + 6 * Lv;
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
@@ -467,6 +470,7 @@ static hipError_t launch_art_tf(const ArtMlpArgs& args, hipStream_t stream) {
 template <bool POS, bool TRAIN>
 static hipError_t launch_art_t(const ArtMlpArgs& args, hipStream_t stream) {
   const int form = stream_form(args.seg[0].packed);
+  if (form == kFormUnknown) return hipErrorInvalidValue;   // never packed / declared (a copy): refuse instead of guessing
   if (stream_form(args.seg[0].small) != form) return hipErrorInvalidValue;
   if (args.seg[1].npass > 0 && (stream_form(args.seg[1].packed) != form || stream_form(args.seg[1].small) != form)) return hipErrorInvalidValue;
   const bool vb = args.seg[0].view_bias != nullptr;   // every segment of the launch or none; folded form, in-kernel ray cast only

@@ -420,6 +420,7 @@ static hipError_t launch_chain_f(const BwdArgs& a, int grid, hipStream_t stream)
 hipError_t launch_mlp_bwd_chain2(const ChainSeg* segs, int nsegs, hipStream_t stream) {
   if (nsegs < 1 || nsegs > 2) return hipErrorInvalidValue;
   const int form = stream_form(segs[0].packed_bwd);
+  if (form == kFormUnknown) return hipErrorInvalidValue;   // never packed / declared (a copy): refuse instead of guessing
   if (nsegs == 2 && stream_form(segs[1].packed_bwd) != form) return hipErrorInvalidValue;
   BwdArgs a{};
   for (int i = 0; i < nsegs; ++i) {
@@ -568,6 +569,7 @@ float* wgrad_fold_tmp(float* ws) { return ws + (wgrad_workspace_bytes_impl() - (
 hipError_t launch_vanilla_wgrad(const float* planes, const float* dplanes, const float* d_raw, int64_t Np, float* const* grads,
                                 float* ws, hipStream_t stream, const WgAux* aux, const void* packed_bwd, int phase) {
   WgLayerDesc L[kWgMaxJobs];
+  if (packed_bwd && stream_form(packed_bwd) == kFormUnknown) return hipErrorInvalidValue;   // (a copy nobody declared)
   const bool fold = packed_bwd && stream_form(packed_bwd) == kFormFolded;
   float* fold_tmp = fold ? wgrad_fold_tmp(ws) : nullptr;
   const int n = vanilla_wgrad_layers(grads, L, fold_tmp);

@@ -346,6 +346,7 @@ struct LatentJob {
   const float* W[3]; const float* db[3]; int ld[3]; int col_off[3]; int M[3];
   int npairs; int L;
   float* out;
+  const float* add;   // null, or the other level's result: out = add + this level's (both MLPs see the same latents; may alias out)
 };
 struct OuterJob {
   const float* db; const float* latent; float* out;
@@ -388,7 +389,7 @@ __global__ void __launch_bounds__(1024) art_finish_kernel(ArtFinishArgs a) {
     float t = red[0][k];
 #pragma unroll
     for (int q = 1; q < 8; ++q) t += red[q][k];
-    j.out[k] = t;
+    j.out[k] = j.add ? j.add[k] + t : t;
   }
 }
 
@@ -428,6 +429,7 @@ static hipError_t launch_art_chain_f(const ArtBwdArgs& a, int grid, hipStream_t 
 hipError_t launch_art_bwd_chain2(const ChainSeg* segs, int nsegs, hipStream_t stream) {
   if (nsegs < 1 || nsegs > 2) return hipErrorInvalidValue;
   const int form = stream_form(segs[0].packed_bwd);
+  if (form == kFormUnknown) return hipErrorInvalidValue;   // never packed / declared (a copy): refuse instead of guessing
   for (int i = 0; i < nsegs; ++i)   // streams and per-call blocks of one launch: one form
     if (stream_form(segs[i].packed_bwd) != form || stream_form(segs[i].small) != form) return hipErrorInvalidValue;
   ArtBwdArgs a{};
@@ -509,8 +511,9 @@ __global__ void art_remap_enc_kernel(const float* __restrict__ src, int lds, flo
 hipError_t launch_art_wgrad(const float* planes, const float* dplanes, const float* d_raw, const float* dxp, int64_t Np,
                             const float* const* params, const float* shape, const float* app, const float* art,
                             float* const* grads, float* g_shape, float* g_app, float* g_art, float* ws, hipStream_t stream, const WgAux* aux,
-                            int Lp, int Lv, const void* packed_bwd, int phase) {
+                            int Lp, int Lv, const void* packed_bwd, int phase, bool accumulate_latents) {
   // packed_bwd: the transposed stream the chain of these planes ran with -- its FORM says whether the planes carry bottleneck rows (null: literal)
+  if (packed_bwd && stream_form(packed_bwd) == kFormUnknown) return hipErrorInvalidValue;   // (a copy nobody declared)
   const bool fold = packed_bwd && stream_form(packed_bwd) == kFormFolded;
   float* fold_tmp = fold ? wgrad_fold_tmp(ws) : nullptr;
   WgLayerDesc L[kWgMaxJobs];
@@ -552,13 +555,13 @@ hipError_t launch_art_wgrad(const float* planes, const float* dplanes, const flo
   ls.W[0] = params[0]; ls.db[0] = grads[1]; ls.ld[0] = 163; ls.col_off[0] = 3; ls.M[0] = 128;
   ls.W[1] = params[10]; ls.db[1] = grads[11]; ls.ld[1] = P + 128; ls.col_off[1] = P; ls.M[1] = 256;
   ls.W[2] = params[20]; ls.db[2] = grads[21]; ls.ld[2] = 256 + P + 128; ls.col_off[2] = 256 + P; ls.M[2] = 256;
-  ls.npairs = 3; ls.L = 128; ls.out = g_shape;
+  ls.npairs = 3; ls.L = 128; ls.out = g_shape; ls.add = accumulate_latents ? g_shape : nullptr;
   LatentJob& la = F.lat[1];   // appearance: view layer 0
   la.W[0] = params[26]; la.db[0] = grads[27]; la.ld[0] = 256 + V + 128; la.col_off[0] = 256 + V; la.M[0] = 128;
-  la.npairs = 1; la.L = 128; la.out = g_app;
+  la.npairs = 1; la.L = 128; la.out = g_app; la.add = accumulate_latents ? g_app : nullptr;
   LatentJob& lt = F.lat[2];   // articulation: deformation layer 0
   lt.W[0] = params[0]; lt.db[0] = grads[1]; lt.ld[0] = 163; lt.col_off[0] = 131; lt.M[0] = 128;
-  lt.npairs = 1; lt.L = 32; lt.out = g_art;
+  lt.npairs = 1; lt.L = 32; lt.out = g_art; lt.add = accumulate_latents ? g_art : nullptr;
   int blk = 3;
   auto outer = [&](int i, const float* db, const float* latent, float* out, int M, int Ll, int ld, int col_off) {
     F.outer[i] = OuterJob{db, latent, out, M, Ll, ld, col_off, blk};

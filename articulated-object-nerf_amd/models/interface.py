@@ -75,39 +75,52 @@ def get_obj_rgbs_from_segmap(all_segmap, all_pred_img, all_pred_target):
 
 
 class _LogSeries(list):
-    """The values one name was logged with, as floats -- read lazily.  ``float(tensor)`` at log time is a host synchronisation, four per
-    training step (the host then enqueues the backward only after the forward has finished); device scalars are kept as they are and turned
-    into floats when somebody looks (``series[-1]``, iteration, ``len`` stays cheap), or 512 at a time with ONE device read."""
+    """The values one name was logged with, as floats.  ``float(tensor)`` at log time is a host synchronisation, four per training step
+    (the host then enqueues the backward only after the forward has finished), so device scalars wait in a SIDE buffer and are turned into
+    floats when anybody looks at the list -- any read entry point, pickling and copying included (round 5 kept the pending
+    tensors inside the list itself, and ``copy()``, ``+``, ``==``, ``repr``, ``np.asarray`` handed raw device tensors out) -- or 512 at a
+    time with ONE device read.  The list proper only ever holds floats."""
 
-    _pending = 0
+    def __init__(self, *a):
+        super().__init__(*a)
+        self._wait = []          # device scalars logged since the last read, in order (they follow everything already in the list)
 
     def append(self, value):
         if isinstance(value, torch.Tensor):
-            list.append(self, value.detach())
-            self._pending += 1
-            if self._pending >= 512:
+            self._wait.append(value.detach())
+            if len(self._wait) >= 512:
                 self._settle()
         else:
+            self._settle()
             list.append(self, float(value))
 
     def _settle(self):
-        if not self._pending:
-            return
-        idx = [i for i in range(len(self)) if isinstance(list.__getitem__(self, i), torch.Tensor)]
-        if idx:
-            ts = [list.__getitem__(self, i).reshape(()).float() for i in idx]
+        wait, self._wait = getattr(self, "_wait", []), []
+        if wait:
+            ts = [t.reshape(()).float() for t in wait]
             vals = torch.stack(ts).tolist() if len({t.device for t in ts}) == 1 else [float(t) for t in ts]
-            for i, v in zip(idx, vals):
-                list.__setitem__(self, i, v)
-        self._pending = 0
+            list.extend(self, vals)
 
-    def __getitem__(self, i):
+    def __reduce_ex__(self, protocol):          # pickle / copy.copy / copy.deepcopy: a plain list of floats
         self._settle()
-        return list.__getitem__(self, i)
+        return (list, (list(self),))
 
-    def __iter__(self):
+
+def _settled(name):
+    base = getattr(list, name)
+
+    def method(self, *a, **k):
         self._settle()
-        return list.__iter__(self)
+        return base(self, *a, **k)
+
+    method.__name__ = name
+    return method
+
+
+for _name in ("__getitem__", "__iter__", "__len__", "__repr__", "__eq__", "__ne__", "__lt__", "__le__", "__gt__", "__ge__", "__contains__", "__add__", "__mul__",
+              "__rmul__", "__reversed__", "__setitem__", "__delitem__", "__iadd__", "__imul__", "copy", "count", "index", "extend", "insert", "pop", "remove",
+              "reverse", "sort", "clear"):
+    setattr(_LogSeries, _name, _settled(_name))
 
 
 class Harness(LitModel):

@@ -125,7 +125,14 @@ def packed_bwd_aside(mlps):
     with torch.cuda.stream(side):
         for m, o in zip(mlps, outs):
             m.packed_bwd(True, out=o)
-    return outs, side.record_event()
+    ev = side.record_event()
+    for o in outs:
+        # (1) the buffers were allocated on the current stream but are written on the side stream: the caching allocator must not
+        # hand their memory to current-stream work before the pack kernels are done, even if the caller drops them early (an exception
+        # inside the forward); (2) the event travels WITH the buffer, so that a backward run on another stream than the forward waits too
+        o.record_stream(side)
+        o._aon_ready = ev
+    return outs, ev
 
 
 class NeRF(nn.Module):
@@ -261,10 +268,12 @@ class NeRF(nn.Module):
             bwd, bwd_ready = packed_bwd_aside(mlps)
             packs = [(m.packed(True), b) for m, b in zip(mlps, bwd)]
             params = [p for m in mlps for p in m.ordered_params()]
-            flat = RenderVanilla.apply(rays_o, rays["rays_d"], rays["viewdirs"], float(near), float(far), bool(white_bkgd),
-                                       self.num_levels, t_rand, u, packs, self._opts, noise, *params)
-            if bwd_ready is not None:
-                torch.cuda.current_stream(rays_o.device).wait_event(bwd_ready)   # (behind the forward's launches: free by then)
+            try:
+                flat = RenderVanilla.apply(rays_o, rays["rays_d"], rays["viewdirs"], float(near), float(far), bool(white_bkgd),
+                                           self.num_levels, t_rand, u, packs, self._opts, noise, *params)
+            finally:
+                if bwd_ready is not None:   # (behind the forward's launches: free by then; also when the forward raised)
+                    torch.cuda.current_stream(rays_o.device).wait_event(bwd_ready)
             return [tuple(flat[3 * i: 3 * i + 3]) for i in range(self.num_levels)]
         coarse = self.coarse_mlp.packed()
         fine = self.fine_mlp.packed() if self.num_levels == 2 else None
@@ -289,6 +298,22 @@ def _fused_adam(params) -> bool:
     import os
 
     return os.environ.get("AON_FUSED_ADAM", "1") != "0" and all(p.is_cuda for p in params)
+
+
+def build_adam(modules, lr: float):
+    """``torch.optim.Adam(params, lr, betas=(0.9, 0.999))`` of the reference's ``configure_optimizers`` (model.py:386-389,
+    model_autodecoder.py:604-606).  On a GPU (round 6): the parameters move into ONE flat arena and the optimizer is ``ArenaAdam`` -- the
+    same update as ONE HIP launch, the HIP backward writes the gradients into the arena, the data-parallel mean reduces it in place
+    (``aon_amd/arena.py``).  ``state_dict`` keeps torch.optim.Adam's layout.  AON_ARENA=0 in the environment (A/B) or CPU parameters:
+    torch's own Adam (fused form on a GPU)."""
+    import os
+
+    params = [p for m in modules for p in m.parameters()]
+    if os.environ.get("AON_ARENA", "1") != "0" and params and all(p.is_cuda and p.dtype == torch.float32 for p in params):
+        from ...arena import ArenaAdam, ParamArena
+
+        return ArenaAdam(ParamArena(list(modules)), lr=lr, betas=(0.9, 0.999))
+    return torch.optim.Adam(params=params, lr=lr, betas=(0.9, 0.999), fused=_fused_adam(params))
 
 
 class LitNeRF(Harness):
@@ -353,5 +378,4 @@ class LitNeRF(Harness):
     def configure_optimizers(self):
         # model.py:386-389.  On a GPU the optimizer runs in its fused form -- one kernel for all 48 parameter tensors instead of the
         # foreach form's dozen multi-tensor launches: the same update rule, 1 ms of a 32 ms training step (round 5, tools/train_bench.py)
-        params = list(self.parameters())
-        return torch.optim.Adam(params=params, lr=self.lr_init, betas=(0.9, 0.999), fused=_fused_adam(params))
+        return build_adam([self], self.lr_init)     # (round 6: ONE launch on a parameter arena; torch.optim.Adam's state layout)

@@ -168,11 +168,13 @@ class NeRF_AE_Art(nn.Module):
                 small = ops.art_prepare(dict(mlp.named_parameters()), latents, degrees=mlp.degrees)
                 packs.append((mlp.packed(True), small, b))
             params = [p for mlp in mlps for p in mlp.ordered_params()]
-            flat = RenderArticulated.apply(rays_o, rays["rays_d"], rays["viewdirs"], float(near), float(far), bool(white_bkgd),
-                                           self.num_levels, t_rand, u, packs, self._opts, noise, latents["density"], latents["color"],
-                                           latents["articulation"], *params)
-            if bwd_ready is not None:
-                torch.cuda.current_stream(rays_o.device).wait_event(bwd_ready)   # (behind the forward's launches: free by then)
+            try:
+                flat = RenderArticulated.apply(rays_o, rays["rays_d"], rays["viewdirs"], float(near), float(far), bool(white_bkgd),
+                                               self.num_levels, t_rand, u, packs, self._opts, noise, latents["density"], latents["color"],
+                                               latents["articulation"], *params)
+            finally:
+                if bwd_ready is not None:   # (behind the forward's launches: free by then; also when the forward raised)
+                    torch.cuda.current_stream(rays_o.device).wait_event(bwd_ready)
             return [tuple(flat[3 * i: 3 * i + 3]) for i in range(self.num_levels)]
         two = self.num_levels == 2
         pc = self.coarse_mlp.packed()
@@ -189,7 +191,7 @@ from collections import defaultdict  # noqa: E402
 from . import helper  # noqa: E402
 from ..code_library import CodeLibraryArticulated  # noqa: E402
 from ..interface import Harness  # noqa: E402
-from .model import _fused_adam, packed_bwd_aside  # noqa: E402
+from .model import build_adam, packed_bwd_aside  # noqa: E402
 
 _SCALAR_KEYS = ("deg", "instance_id", "articulation_id")
 
@@ -268,5 +270,4 @@ class LitNeRF_AutoDecoder(Harness):
         return self.render_rays_test(batch, self.code_library(batch, is_test=True))
 
     def configure_optimizers(self):
-        params = list(self.model.parameters()) + list(self.code_library.parameters())
-        return torch.optim.Adam(params=params, lr=self.lr_init, betas=(0.9, 0.999), fused=_fused_adam(params))   # (fused on a GPU: LitNeRF)
+        return build_adam([self.model, self.code_library], self.lr_init)   # (model_autodecoder.py:604-606; one arena, one launch: LitNeRF)

@@ -29,6 +29,35 @@ def _f32(t: torch.Tensor, name: str) -> torch.Tensor:
     return t.contiguous()
 
 
+def _tag(out: torch.Tensor) -> torch.Tensor:
+    """A freshly packed stream / per-call block remembers the form it was packed in (bottleneck folded or literal) ON THE TENSOR: the
+    launchers look the form up by address (csrc/aon_fold.hip), and `_pk` re-declares it from here on every call, so an address the caching
+    allocator hands out again can never carry an earlier tenant's form."""
+    out._aon_form = int(lib.aon_stream_form(out.data_ptr()))
+    return out
+
+
+def _pk(t: torch.Tensor | None) -> C.c_void_p:
+    """Pointer of a packed weight stream / per-call block for a C call, with its form re-declared.  A tensor without a form is not one
+    this binding packed (a clone or a moved copy of a packed buffer has none): refused here instead of being run under a guessed form."""
+    if t is None:
+        return None
+    form = getattr(t, "_aon_form", None)
+    if form is None:
+        raise ValueError("not a packed stream of this binding (tensors returned by ops.pack_* / ops.art_prepare carry their form; a clone or "
+                         "copy does not: use ops.clone_packed)")
+    check(lib.aon_declare_stream_form(t.data_ptr(), form), "aon_declare_stream_form")
+    return C.c_void_p(t.data_ptr())
+
+
+def clone_packed(t: torch.Tensor) -> torch.Tensor:
+    """A copy of a packed stream / per-call block that keeps its form (plain `.clone()` yields a buffer every call refuses)."""
+    out = t.clone()
+    out._aon_form = t._aon_form
+    check(lib.aon_declare_stream_form(out.data_ptr(), out._aon_form), "aon_declare_stream_form")
+    return out
+
+
 def _ptr(t: torch.Tensor | None) -> C.c_void_p:
     return C.c_void_p(0 if t is None else t.data_ptr())
 
@@ -209,7 +238,7 @@ def pack_vanilla_mlp(params: dict, out: torch.Tensor | None = None, degrees=(0, 
             check(lib.aon_pack_vanilla_mlp(arr, _ptr(out), _stream()), "aon_pack_vanilla_mlp")
         else:
             check(lib.aon_pack_vanilla_mlp_deg(arr, mn, mx, dv, _ptr(out), _stream()), "aon_pack_vanilla_mlp_deg")
-    return out
+    return _tag(out)
 
 
 def mlp_fwd(packed, rays_o, rays_d, viewdirs, t_vals):
@@ -218,7 +247,7 @@ def mlp_fwd(packed, rays_o, rays_d, viewdirs, t_vals):
     n, S = t.shape
     raw = torch.empty((n, S, 4), dtype=torch.float32, device=t.device)
     with torch.cuda.device(t.device):
-        check(lib.aon_mlp_fwd(_ptr(packed), _ptr(o), _ptr(d), _ptr(v), _ptr(t), n, S, _ptr(raw), _stream()), "aon_mlp_fwd")
+        check(lib.aon_mlp_fwd(_pk(packed), _ptr(o), _ptr(d), _ptr(v), _ptr(t), n, S, _ptr(raw), _stream()), "aon_mlp_fwd")
     return raw
 
 
@@ -229,7 +258,7 @@ def mlp_fwd_enc(packed, samples_enc, viewdirs_enc):
         raise ValueError("mlp_fwd_enc expects samples_enc (n,S,63) and viewdirs_enc (n,27)")
     raw = torch.empty((n, S, 4), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
-        check(lib.aon_mlp_fwd_enc(_ptr(packed), _ptr(x), _ptr(c), n, S, _ptr(raw), _stream()), "aon_mlp_fwd_enc")
+        check(lib.aon_mlp_fwd_enc(_pk(packed), _ptr(x), _ptr(c), n, S, _ptr(raw), _stream()), "aon_mlp_fwd_enc")
     return raw
 
 
@@ -491,7 +520,7 @@ def render_fwd(packed_coarse, packed_fine, rays_o, rays_d, viewdirs, near, far, 
     st, keep = op.c_struct(near, far, _check_noise(noise, n, op, num_levels))
     ws = _workspace(dev, n, st)
     with torch.cuda.device(dev):
-        check(lib.aon_render_fwd_ex(_ptr(packed_coarse), _ptr(packed_fine), _ptr(o), _ptr(d), _ptr(v), n, float(near), float(far),
+        check(lib.aon_render_fwd_ex(_pk(packed_coarse), _pk(packed_fine), _ptr(o), _ptr(d), _ptr(v), n, float(near), float(far),
                                     int(bool(white_bkgd)), num_levels, _ptr(tr), _ptr(uu), us,
                                     _ptr(outs[0][0]), _ptr(outs[0][1]), _ptr(outs[0][2]), _ptr(fine[0]), _ptr(fine[1]), _ptr(fine[2]),
                                     _ptr(ws), ws.numel(), _stream(), C.byref(st)), "aon_render_fwd")
@@ -559,7 +588,7 @@ def pack_art_mlp(params: dict, out: torch.Tensor | None = None, degrees=(0, 10, 
         out = torch.empty(int(lib.aon_art_packed_bytes()), dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
         check(lib.aon_pack_art_mlp_deg(arr, int(degrees[0]), int(degrees[1]), int(degrees[2]), _ptr(out), _stream()), "aon_pack_art_mlp_deg")
-    return out
+    return _tag(out)
 
 
 def _latent(latents: dict, key: str, width: int) -> torch.Tensor:
@@ -581,7 +610,7 @@ def art_prepare(params: dict, latents: dict, out: torch.Tensor | None = None, de
     with torch.cuda.device(dev):
         check(lib.aon_art_prepare_deg(arr, _ptr(shape), _ptr(app), _ptr(art), int(degrees[0]), int(degrees[1]), int(degrees[2]), _ptr(out), _stream()),
               "aon_art_prepare_deg")
-    return out
+    return _tag(out)
 
 
 def art_mlp_fwd(packed, small, rays_o, rays_d, viewdirs, t_vals):
@@ -589,7 +618,7 @@ def art_mlp_fwd(packed, small, rays_o, rays_d, viewdirs, t_vals):
     n, S = t.shape
     raw = torch.empty((n, S, 4), dtype=torch.float32, device=t.device)
     with torch.cuda.device(t.device):
-        check(lib.aon_art_mlp_fwd(_ptr(packed), _ptr(small), _ptr(o), _ptr(d), _ptr(v), _ptr(t), n, S, _ptr(raw), _stream()),
+        check(lib.aon_art_mlp_fwd(_pk(packed), _pk(small), _ptr(o), _ptr(d), _ptr(v), _ptr(t), n, S, _ptr(raw), _stream()),
               "aon_art_mlp_fwd")
     return raw
 
@@ -601,7 +630,7 @@ def art_mlp_fwd_pos(packed, small, pos, viewdirs_enc):
         raise ValueError("art_mlp_fwd_pos expects pos (n,S,3) and viewdirs_enc (n,27)")
     raw = torch.empty((n, S, 4), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
-        check(lib.aon_art_mlp_fwd_pos(_ptr(packed), _ptr(small), _ptr(x), _ptr(c), n, S, _ptr(raw), _stream()), "aon_art_mlp_fwd_pos")
+        check(lib.aon_art_mlp_fwd_pos(_pk(packed), _pk(small), _ptr(x), _ptr(c), n, S, _ptr(raw), _stream()), "aon_art_mlp_fwd_pos")
     return raw
 
 
@@ -623,7 +652,7 @@ def art_render_fwd(packed_c, small_c, packed_f, small_f, rays_o, rays_d, viewdir
     st, keep = op.c_struct(near, far, _check_noise(noise, n, op, num_levels))
     ws = _workspace(dev, n, st)
     with torch.cuda.device(dev):
-        check(lib.aon_art_render_fwd_ex(_ptr(packed_c), _ptr(small_c), _ptr(packed_f), _ptr(small_f), _ptr(o), _ptr(d), _ptr(v), n,
+        check(lib.aon_art_render_fwd_ex(_pk(packed_c), _pk(small_c), _pk(packed_f), _pk(small_f), _ptr(o), _ptr(d), _ptr(v), n,
                  float(near), float(far), int(bool(white_bkgd)), num_levels, _ptr(tr), _ptr(uu), us,
                  _ptr(outs[0][0]), _ptr(outs[0][1]), _ptr(outs[0][2]), _ptr(fine[0]), _ptr(fine[1]), _ptr(fine[2]),
                  _ptr(ws), ws.numel(), _stream(), C.byref(st)), "aon_art_render_fwd")
@@ -656,7 +685,7 @@ def pack_vanilla_mlp_bwd(params: dict, out: torch.Tensor | None = None, degrees=
             check(lib.aon_pack_vanilla_mlp_bwd(arr, _ptr(out), _stream()), "aon_pack_vanilla_mlp_bwd")
         else:
             check(lib.aon_pack_vanilla_mlp_bwd_deg(arr, degrees[0], degrees[1], degrees[2], _ptr(out), _stream()), "aon_pack_vanilla_mlp_bwd_deg")
-    return out
+    return _tag(out)
 
 
 def padded_samples(n_samples: int) -> int:
@@ -692,7 +721,7 @@ def mlp_fwd_train(packed, rays_o, rays_d, viewdirs, t_vals):
     planes = _new_planes(int(lib.aon_train_plane_rows()), Np, t.device)
     masks = torch.empty(int(lib.aon_train_mask_bytes(Np)), dtype=torch.uint8, device=t.device)
     with torch.cuda.device(t.device):
-        check(lib.aon_mlp_fwd_train(_ptr(packed), _ptr(o), _ptr(d), _ptr(v), _ptr(t), n, S, _ptr(raw), _ptr(planes), _ptr(masks), _stream()), "aon_mlp_fwd_train")
+        check(lib.aon_mlp_fwd_train(_pk(packed), _ptr(o), _ptr(d), _ptr(v), _ptr(t), n, S, _ptr(raw), _ptr(planes), _ptr(masks), _stream()), "aon_mlp_fwd_train")
     return raw, planes, masks
 
 
@@ -714,7 +743,7 @@ def mlp_bwd_chain(packed_bwd, packed_fwd, d_raw, masks, plane_shape):
     dplanes = torch.empty(tuple(plane_shape), dtype=torch.float32, device=d_raw.device)
     Np = plane_shape[0] * 32
     with torch.cuda.device(d_raw.device):
-        check(lib.aon_mlp_bwd_chain(_ptr(packed_bwd), _ptr(packed_fwd), _ptr(d_raw), _ptr(masks), _ptr(dplanes), Np, _stream()), "aon_mlp_bwd_chain")
+        check(lib.aon_mlp_bwd_chain(_pk(packed_bwd), _pk(packed_fwd), _ptr(d_raw), _ptr(masks), _ptr(dplanes), Np, _stream()), "aon_mlp_bwd_chain")
     return dplanes
 
 
@@ -737,7 +766,7 @@ def vanilla_wgrad(planes, dplanes, d_raw, packed_bwd):
     arr = (C.c_void_p * len(VANILLA_PARAM_ORDER))(*[grads[n].data_ptr() for n in VANILLA_PARAM_ORDER])
     with torch.cuda.device(dev):
         check(lib.aon_vanilla_wgrad(_ptr(planes), _ptr(dplanes), _ptr(d_raw), plane_samples(planes), arr, _ptr(ws), ws.numel(), _stream(),
-                                    _ptr(packed_bwd)), "aon_vanilla_wgrad")
+                                    _pk(packed_bwd)), "aon_vanilla_wgrad")
     return grads
 
 
@@ -749,7 +778,7 @@ def pack_art_mlp_bwd(params: dict, out: torch.Tensor | None = None, degrees=(0, 
         out = torch.empty(int(lib.aon_art_bwd_packed_bytes()), dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
         check(lib.aon_pack_art_mlp_bwd_deg(arr, int(degrees[0]), int(degrees[1]), int(degrees[2]), _ptr(out), _stream()), "aon_pack_art_mlp_bwd_deg")
-    return out
+    return _tag(out)
 
 
 def art_mlp_fwd_train(packed, small, rays_o, rays_d, viewdirs, t_vals):
@@ -760,7 +789,7 @@ def art_mlp_fwd_train(packed, small, rays_o, rays_d, viewdirs, t_vals):
     planes = _new_planes(int(lib.aon_art_train_plane_rows()), Np, t.device)
     masks = torch.empty(int(lib.aon_art_train_mask_bytes(Np)), dtype=torch.uint8, device=t.device)
     with torch.cuda.device(t.device):
-        check(lib.aon_art_mlp_fwd_train(_ptr(packed), _ptr(small), _ptr(o), _ptr(d), _ptr(v), _ptr(t), n, S, _ptr(raw), _ptr(planes), _ptr(masks), _stream()),
+        check(lib.aon_art_mlp_fwd_train(_pk(packed), _pk(small), _ptr(o), _ptr(d), _ptr(v), _ptr(t), n, S, _ptr(raw), _ptr(planes), _ptr(masks), _stream()),
               "aon_art_mlp_fwd_train")
     return raw, planes, masks
 
@@ -771,7 +800,7 @@ def art_bwd_chain(packed_bwd, small, d_raw, masks, planes):
     Np = plane_samples(planes)
     dxp = torch.empty((Np, 4), dtype=torch.float32, device=planes.device)
     with torch.cuda.device(planes.device):
-        check(lib.aon_art_bwd_chain(_ptr(packed_bwd), _ptr(small), _ptr(d_raw), _ptr(masks), _ptr(planes), _ptr(dplanes), _ptr(dxp), Np, _stream()),
+        check(lib.aon_art_bwd_chain(_pk(packed_bwd), _pk(small), _ptr(d_raw), _ptr(masks), _ptr(planes), _ptr(dplanes), _ptr(dxp), Np, _stream()),
               "aon_art_bwd_chain")
     return dplanes, dxp
 
@@ -795,7 +824,7 @@ def art_wgrad(planes, dplanes, d_raw, dxp, params: dict, latents: dict, degrees=
     with torch.cuda.device(dev):
         check(lib.aon_art_wgrad_deg(_ptr(planes), _ptr(dplanes), _ptr(d_raw), _ptr(dxp), plane_samples(planes), parr, _ptr(shape), _ptr(app),
                                     _ptr(art), garr, _ptr(g_lat["density"]), _ptr(g_lat["color"]), _ptr(g_lat["articulation"]), _ptr(ws),
-                                    ws.numel(), _stream(), int(degrees[0]), int(degrees[1]), int(degrees[2]), _ptr(packed_bwd)), "aon_art_wgrad_deg")
+                                    ws.numel(), _stream(), int(degrees[0]), int(degrees[1]), int(degrees[2]), _pk(packed_bwd)), "aon_art_wgrad_deg")
     return grads, g_lat
 
 
@@ -844,7 +873,7 @@ def view_bias(packed: torch.Tensor, viewdirs: torch.Tensor) -> torch.Tensor:
     n = v.numel() // 3
     out = torch.empty((n, 128), dtype=torch.float32, device=v.device)
     with torch.cuda.device(v.device):
-        check(lib.aon_view_bias(_ptr(packed), _ptr(v), n, _ptr(out), _stream()), "aon_view_bias")
+        check(lib.aon_view_bias(_pk(packed), _ptr(v), n, _ptr(out), _stream()), "aon_view_bias")
     return out
 
 
@@ -904,24 +933,41 @@ def render_fwd_train(packed_c, packed_f, rays_o, rays_d, viewdirs, near, far, wh
               C.byref(st))
     with torch.cuda.device(dev):
         if art:
-            check(lib.aon_art_render_fwd_train_ex(_ptr(packed_c), _ptr(small_c), _ptr(packed_f), _ptr(small_f), *common), "aon_art_render_fwd_train")
+            check(lib.aon_art_render_fwd_train_ex(_pk(packed_c), _pk(small_c), _pk(packed_f), _pk(small_f), *common), "aon_art_render_fwd_train")
         else:
-            check(lib.aon_render_fwd_train_ex(_ptr(packed_c), _ptr(packed_f), *common), "aon_render_fwd_train")
+            check(lib.aon_render_fwd_train_ex(_pk(packed_c), _pk(packed_f), *common), "aon_render_fwd_train")
     return outs, ws, (st, keep)
+
+
+def _grad_dicts(order, shapes, num_levels, dev, grads_out):
+    """Per level {parameter name: tensor the C call writes the gradient into}: fresh tensors, or the caller's (checked: fp32, contiguous,
+    right shape and device -- the kernels write every element, 16-byte vector stores included)."""
+    if grads_out is None:
+        return [{name: torch.empty(shapes[name], dtype=torch.float32, device=dev) for name in order} for _ in range(num_levels)]
+    out = []
+    for lvl in range(num_levels):
+        d = {}
+        for name, t in zip(order, grads_out[lvl]):
+            if tuple(t.shape) != tuple(shapes[name]) or t.dtype != torch.float32 or t.device != dev or not t.is_contiguous() or (t.data_ptr() & 15):
+                raise ValueError(f"gradient buffer for {name}: expected a contiguous 16-byte aligned float32 {tuple(shapes[name])} tensor on {dev}")
+            d[name] = t
+        out.append(d)
+    return out
 
 
 def _ptr_array(tensors):
     return (C.c_void_p * len(tensors))(*[0 if t is None else t.data_ptr() for t in tensors])
 
 
-def render_bwd(ws, packs_bwd, packs_fwd, rays_d, white_bkgd, num_levels, g_rgb, g_acc, g_depth, geometry=None):
+def render_bwd(ws, packs_bwd, packs_fwd, rays_d, white_bkgd, num_levels, g_rgb, g_acc, g_depth, geometry=None, grads_out=None):
     """loss.backward() through render_fwd_train (vanilla): g_* = per-level lists (entries may be None except g_rgb)
-    -> per-level dicts of the 24 parameter gradients (shapes of the network's own encoding degrees, read from `geometry`)."""
+    -> per-level dicts of the 24 parameter gradients (shapes of the network's own encoding degrees, read from `geometry`).
+    `grads_out`: per level, the 24 tensors to write them into (views of a gradient arena, aon_amd/arena.py) instead of fresh ones."""
     d = _f32(rays_d, "rays_d")
     n, dev = d.shape[0], d.device
     st0 = None if geometry is None else geometry[0]
     shapes = vanilla_param_shapes((0, 10, 4) if st0 is None else (st0.min_deg_point, st0.max_deg_point, st0.deg_view))
-    grads = [{name: torch.empty(shapes[name], dtype=torch.float32, device=dev) for name in VANILLA_PARAM_ORDER} for _ in range(num_levels)]
+    grads = _grad_dicts(VANILLA_PARAM_ORDER, shapes, num_levels, dev, grads_out)
     garr = [_ptr_array([g[nm] for nm in VANILLA_PARAM_ORDER]) for g in grads] + [None] * (2 - num_levels)
     pb, pf = list(packs_bwd) + [None] * (2 - num_levels), list(packs_fwd) + [None] * (2 - num_levels)
     keep = [None if t is None else _f32(t, "grad") for t in list(g_rgb) + list(g_acc) + list(g_depth)]
@@ -929,20 +975,22 @@ def render_bwd(ws, packs_bwd, packs_fwd, rays_d, white_bkgd, num_levels, g_rgb, 
     st = None if geometry is None else geometry[0]
     scratch = train_scratch(dev, n, False, num_levels, st)
     with torch.cuda.device(dev):
-        check(lib.aon_render_bwd_ex(_ptr(pb[0]), _ptr(pf[0]), _ptr(pb[1]), _ptr(pf[1]), _ptr(d), n, int(bool(white_bkgd)), num_levels,
+        check(lib.aon_render_bwd_ex(_pk(pb[0]), _pk(pf[0]), _pk(pb[1]), _pk(pf[1]), _ptr(d), n, int(bool(white_bkgd)), num_levels,
                                     _ptr_array(keep[:k]), _ptr_array(keep[k:2 * k]), _ptr_array(keep[2 * k:3 * k]), garr[0], garr[1], _ptr(ws), ws.numel(),
                                     _ptr(scratch), scratch.numel(), _stream(), None if st is None else C.byref(st)), "aon_render_bwd")
     return grads
 
 
-def art_render_bwd(ws, packs_bwd, smalls, rays_d, white_bkgd, num_levels, g_rgb, g_acc, g_depth, params_per_level, latents: dict, geometry=None):
-    """Articulated twin -> (per-level dicts of the 40 parameter gradients, dict of latent gradients summed over the levels)."""
+def art_render_bwd(ws, packs_bwd, smalls, rays_d, white_bkgd, num_levels, g_rgb, g_acc, g_depth, params_per_level, latents: dict, geometry=None,
+                   grads_out=None):
+    """Articulated twin -> (per-level dicts of the 40 parameter gradients, dict of latent gradients summed over the levels).
+    `grads_out`: as render_bwd."""
     d = _f32(rays_d, "rays_d")
     n, dev = d.shape[0], d.device
     st0 = None if geometry is None else geometry[0]
     degrees = (0, 10, 4) if st0 is None else (int(st0.min_deg_point), int(st0.max_deg_point), int(st0.deg_view))
     shapes = art_param_shapes(degrees)
-    grads = [{name: torch.empty(shapes[name], dtype=torch.float32, device=dev) for name in ART_PARAM_ORDER} for _ in range(num_levels)]
+    grads = _grad_dicts(ART_PARAM_ORDER, shapes, num_levels, dev, grads_out)
     garr = [_ptr_array([g[nm] for nm in ART_PARAM_ORDER]) for g in grads] + [None] * (2 - num_levels)
     tens, parr = [], []
     for params in params_per_level:
@@ -958,7 +1006,7 @@ def art_render_bwd(ws, packs_bwd, smalls, rays_d, white_bkgd, num_levels, g_rgb,
     st = None if geometry is None else geometry[0]
     scratch = train_scratch(dev, n, True, num_levels, st)
     with torch.cuda.device(dev):
-        check(lib.aon_art_render_bwd_ex(_ptr(pb[0]), _ptr(sm[0]), _ptr(pb[1]), _ptr(sm[1]), _ptr(d), n, int(bool(white_bkgd)), num_levels,
+        check(lib.aon_art_render_bwd_ex(_pk(pb[0]), _pk(sm[0]), _pk(pb[1]), _pk(sm[1]), _ptr(d), n, int(bool(white_bkgd)), num_levels,
                                         _ptr_array(keep[:k]), _ptr_array(keep[k:2 * k]), _ptr_array(keep[2 * k:3 * k]), parr[0], parr[1],
                                         _ptr(shape), _ptr(app), _ptr(art), garr[0], garr[1], _ptr(g_lat["density"]), _ptr(g_lat["color"]),
                                         _ptr(g_lat["articulation"]), _ptr(ws), ws.numel(), _ptr(scratch), scratch.numel(), _stream(),
@@ -1191,3 +1239,55 @@ def profile_classes() -> dict:
         check(lib.aon_profile_class(cls, C.byref(ms), C.byref(launches), C.byref(units)), "aon_profile_class")
         out[name] = (ms.value, launches.value, units.value)
     return out
+
+
+# ------------------------------------------------------------------ the end of a training step on one parameter arena (csrc/aon_optim.hip)
+def adam_step(params_flat, grads_flat, exp_avg, exp_avg_sq, begin: int, count: int, lr: float, beta1: float, beta2: float, eps: float, step: int) -> None:
+    """torch.optim.Adam's update (the reference's optimizer: model.py:386-389) on elements [begin, begin + count) of four flat fp32 buffers of
+    one layout, ONE launch.  `step` = the count after this update."""
+    for name, t in (("params", params_flat), ("grads", grads_flat), ("exp_avg", exp_avg), ("exp_avg_sq", exp_avg_sq)):
+        if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.dim() == 1):
+            raise RuntimeError(f"adam_step: {name} must be a flat contiguous float32 cuda tensor (no CPU fallback)")
+        if begin < 0 or count < 0 or begin + count > t.numel():
+            raise ValueError(f"adam_step: range [{begin}, {begin + count}) outside {name} ({t.numel()} elements)")
+    off = 4 * int(begin)
+    with torch.cuda.device(params_flat.device):
+        check(lib.aon_adam_step(C.c_void_p(params_flat.data_ptr() + off), C.c_void_p(grads_flat.data_ptr() + off), C.c_void_p(exp_avg.data_ptr() + off),
+                                C.c_void_p(exp_avg_sq.data_ptr() + off), int(count), float(lr), float(beta1), float(beta2), float(eps), int(step), _stream()),
+              "aon_adam_step")
+
+
+def _code_library_args(tables, ids):
+    rows = (C.c_int * 3)(*[int(t.shape[0]) for t in tables])
+    dims = (C.c_int * 3)(*[int(t.shape[1]) for t in tables])
+    idp = (C.c_void_p * 3)(*[i.data_ptr() for i in ids])
+    return rows, dims, idp
+
+
+def code_library_fwd(tables, ids):
+    """CodeLibraryArticulated.forward (code_library.py:36-53) for ids of ONE element each: tables = (shape, appearance, articulation) weight
+    matrices, ids = (instance_id, instance_id, articulation_id) int64 device tensors -> three (1, dim) rows, one launch."""
+    tabs = [_f32(t, "table") for t in tables]
+    idl = [i if (i.dtype == torch.int64 and i.is_cuda) else i.to(device=tabs[0].device, dtype=torch.int64) for i in ids]
+    if any(i.numel() != 1 for i in idl):
+        raise ValueError("code_library_fwd: one id per table (the reference's batch of one object in one state)")
+    outs = [torch.empty((1, t.shape[1]), dtype=torch.float32, device=t.device) for t in tabs]
+    rows, dims, idp = _code_library_args(tabs, idl)
+    with torch.cuda.device(tabs[0].device):
+        check(lib.aon_code_library_fwd(_ptr_array(tabs), idp, rows, dims, _ptr_array(outs), _stream()), "aon_code_library_fwd")
+    return outs, idl
+
+
+def code_library_bwd(g_rows, ids, shapes, outs=None):
+    """The dense table gradients of the three lookups (what nn.Embedding's autograd produces), one launch; `outs`: tensors to write into
+    (the gradient arena's views) or None."""
+    dev = ids[0].device
+    gr = [_f32(g, "g_row") if g is not None else torch.zeros((1, shp[1]), dtype=torch.float32, device=dev) for g, shp in zip(g_rows, shapes)]
+    if outs is None:
+        outs = [torch.empty(tuple(shp), dtype=torch.float32, device=dev) for shp in shapes]
+    rows = (C.c_int * 3)(*[int(s[0]) for s in shapes])
+    dims = (C.c_int * 3)(*[int(s[1]) for s in shapes])
+    idp = (C.c_void_p * 3)(*[i.data_ptr() for i in ids])
+    with torch.cuda.device(dev):
+        check(lib.aon_code_library_bwd(_ptr_array(gr), idp, rows, dims, _ptr_array(outs), _stream()), "aon_code_library_bwd")
+    return outs

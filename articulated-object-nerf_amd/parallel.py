@@ -91,6 +91,10 @@ def broadcast_parameters(module, src: int = 0, group=None, force: bool = False) 
         return
     with torch.no_grad():
         params = list(module.parameters())
+        arena = _arena_bucket([p for p in params if p.requires_grad]) if all(p.requires_grad for p in params) else None
+        if arena is not None:       # the parameters already ARE one flat buffer (aon_amd/arena.py): broadcast it in place
+            dist.broadcast(arena.flat[: arena.total], src=src, group=group)
+            return
         flat = torch.cat([p.detach().reshape(-1) for p in params])
         dist.broadcast(flat, src=src, group=group)
         torch._foreach_copy_([p.data for p in params], [c.view_as(p) for c, p in zip(flat.split([p.numel() for p in params]), params)])
@@ -148,18 +152,41 @@ def allreduce_gradients(module, group=None, force: bool = False, shard_align: in
     if not params:
         return
     world = dist.get_world_size(group)
-    sizes = [p.numel() for p in params]
-    total = sum(sizes)
-    quantum = world * max(1, int(shard_align))
-    padded = (total + len(params) + quantum - 1) // quantum * quantum
     ref = params[0]
-    flat = torch.zeros(padded, dtype=ref.dtype, device=ref.device)
+    quantum = world * max(1, int(shard_align))
+    had = [p.grad is not None for p in params]
+    # Round 6: parameters that live in ONE arena (aon_amd/arena.py -- the harness's optimizer puts them there) are reduced IN PLACE: the
+    # gradient arena already is the flat bucket (the HIP backward wrote every gradient into its slot), the per-parameter flags go into its
+    # spare tail, and nothing is allocated or copied per step (rounds 3-5: a fresh torch.zeros bucket + 2 x 83-tensor copies).
+    arena = _arena_bucket(params)
+    if arena is not None:
+        total = arena.total
+        padded = (total + len(params) + quantum - 1) // quantum * quantum
+        if padded > arena.capacity:
+            arena = None
     with torch.no_grad():
-        chunks = flat[:total].split(sizes)
-        had = [p.grad is not None for p in params]
-        if any(had):
-            torch._foreach_copy_([c for c, h in zip(chunks, had) if h], [p.grad.reshape(-1) for p, h in zip(params, had) if h])
+        if arena is not None:
+            flat = arena.grad[:padded]
+            chunks = [arena.grad_view(i) for i in range(len(params))]
+            for i, (p, h) in enumerate(zip(params, had)):
+                if not h:
+                    chunks[i].zero_()                      # this rank contributes nothing to that parameter
+                elif not arena.grad_in_place(i):           # a gradient that arrived outside the arena (another autograd path): adopt it
+                    chunks[i].copy_(p.grad)
+                    p.grad = chunks[i]
+            in_place = True
+        else:
+            sizes = [p.numel() for p in params]
+            total = sum(sizes)
+            padded = (total + len(params) + quantum - 1) // quantum * quantum
+            flat = torch.zeros(padded, dtype=ref.dtype, device=ref.device)
+            chunks = flat[:total].split(sizes)
+            if any(had):
+                torch._foreach_copy_([c for c, h in zip(chunks, had) if h], [p.grad.reshape(-1) for p, h in zip(params, had) if h])
+            in_place = False
         flat[total: total + len(params)] = torch.tensor([float(h) for h in had], dtype=ref.dtype).to(ref.device, non_blocking=True)
+        if in_place and padded > total + len(params):
+            flat[total + len(params): padded].zero_()
         # one code path for both backends: reduce-scatter -> scale the shard -> all-gather.  gloo has no
         # reduce_scatter_tensor, so there the scatter is an all_reduce of which every rank keeps its own shard -- the shard
         # arithmetic (padding, offsets, rank order) is then exactly what RCCL runs and the CPU tests cover it.
@@ -178,7 +205,7 @@ def allreduce_gradients(module, group=None, force: bool = False, shard_align: in
         if ngrad:
             shard[:ngrad] /= world
         dist.all_gather_into_tensor(flat, shard, group=group)
-        if any(had):
+        if not in_place and any(had):
             torch._foreach_copy_([p.grad for p, h in zip(params, had) if h], [c.view_as(p) for c, p, h in zip(chunks, params, had) if h])
         counts = flat[total: total + len(params)]
         if find_unused_parameters:
@@ -186,7 +213,7 @@ def allreduce_gradients(module, group=None, force: bool = False, shard_align: in
                 any_rank = (counts > 0).tolist()
                 for c, p, h, a in zip(chunks, params, had, any_rank):
                     if not h and a:
-                        p.grad = c.view_as(p).clone()
+                        p.grad = c.view_as(p) if in_place else c.view_as(p).clone()   # (in place: the slot itself becomes the gradient)
         elif world > 1 or force:
             # DDP's contract, checked without waiting: every count must be 0 or `world` (`force`: the world-1 GPU tests drive this path --
             # pinned flag, event, late look -- through the real backend)
@@ -201,6 +228,19 @@ def allreduce_gradients(module, group=None, force: bool = False, shard_align: in
                 _pending_checks.append((ev, host, msg))
             else:
                 _pending_checks.append((None, uneven, msg))
+
+
+def _arena_bucket(params):
+    """The ParamArena whose layout IS this parameter list (same tensors, same order), or None."""
+    from .arena import arena_of
+
+    ao = arena_of(params)
+    if ao is None:
+        return None
+    arena = ao[0]
+    if len(arena.params) != len(params) or any(a is not b for a, b in zip(arena.params, params)):
+        return None
+    return arena
 
 
 def check_gradient_exchange() -> None:

@@ -23,7 +23,8 @@
 extern "C" {
 #endif
 
-#define AON_ABI_VERSION 4   /* 4: + aon_train_loss_*, aon_view_bias, aon_set_view_bias, aon_set_bwd_early_heads; render / train workspaces hold a per-ray view bias */
+#define AON_ABI_VERSION 5   /* 5: + aon_adam_step, aon_code_library_fwd / _bwd, aon_stream_form, aon_declare_stream_form; a packed pointer this process never
+                               packed or declared is refused (AON_E_INVALID / HIP "invalid value") instead of being taken to have the default form */
 
 #define AON_OK 0
 #define AON_E_INVALID (-1)    /* null pointer, negative size, unsupported geometry */
@@ -58,6 +59,26 @@ int aon_train_loss_fwd(const float* rgb_coarse, const float* rgb_fine, const flo
 int aon_train_loss_bwd(const float* rgb_coarse, const float* rgb_fine, const float* target, int64_t n, const float* const* latents_host,
                        const int* latent_len_host, float reg_scale, const float* grad_loss, float* d_rgb_coarse, float* d_rgb_fine,
                        float* const* d_latents_host, void* stream);
+
+/* ---- the end of a training step on one flat parameter arena (round 6) ----
+ * aon_adam_step: torch.optim.Adam(lr, betas=(beta1, beta2), eps) as configured by the reference (model.py:386-389, model_autodecoder.py:604-606;
+ * weight_decay = 0, amsgrad = False) over `n` contiguous fp32 elements in ONE launch: params, grads and both moments are flat buffers of the
+ * same layout (the Python side makes every nn.Parameter, its .grad and its Adam state views into them: aon_amd/arena.py).  `step` is the
+ * count AFTER this update (torch's state["step"]), lr the value the harness's rule set for this step (model.py:391-419).  The element-wise
+ * operations and their order are those of torch's single-tensor implementation (exp_avg.lerp_, exp_avg_sq.mul_().addcmul_(), sqrt / bias
+ * correction + eps, addcdiv_), fp32 with one rounding each; the bias corrections are evaluated in double on the host. */
+int aon_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, double lr, double beta1, double beta2, double eps,
+                  int64_t step, void* stream);
+
+/* CodeLibraryArticulated.forward for the reference's batch of ONE object in ONE state (models/code_library.py:36-53; sapien_multi.py:362-479
+ * delivers instance_id / articulation_id of shape (1,)): out[t] (dims[t],) = tables[t][ids[t][0]] for the three tables (shape, appearance,
+ * articulation) in one launch; an out-of-range id gives a NaN row (nn.Embedding raises; a kernel cannot).  All *_host arguments are HOST
+ * arrays of 3 entries; ids[t]: device pointer to ONE int64.
+ * _bwd: the dense table gradients nn.Embedding's autograd produces, g_tables[t] (rows[t], dims[t]) = 0 except row ids[t][0] = g_rows[t]. */
+int aon_code_library_fwd(const float* const* tables_host, const int64_t* const* ids_host, const int* rows_host, const int* dims_host, float* const* out_host,
+                         void* stream);
+int aon_code_library_bwd(const float* const* g_rows_host, const int64_t* const* ids_host, const int* rows_host, const int* dims_host, float* const* g_tables_host,
+                         void* stream);
 
 /* get_ray_directions alone (ray_utils.py:71-90): directions (H*W,3), un-normalised camera-space. */
 int aon_ray_directions(int H, int W, float focal, float* directions, void* stream);
@@ -105,13 +126,16 @@ int aon_pack_vanilla_mlp(const float* const* params_host, void* packed, void* st
  * the 24 / 40 parameter gradients keep the reference's shapes and meaning.  Buffer sizes do not depend on the switch.
  * The form is a property of each packed buffer / per-call block, fixed when it was made and remembered per pointer: flipping the
  * switch later does not change how an existing buffer is run, and a call that is handed buffers of two forms returns AON_E_INVALID
- * (HIP "invalid value").  A buffer this process did not pack (a device-side copy of one) is taken to have the current default form;
- * copying a packed buffer onto an address that was itself packed earlier in the OTHER form is not supported (the address keeps the
- * form of its last pack call): pack into the destination instead.
+ * (HIP "invalid value").  A buffer this process neither packed nor declared (a device-side copy of a packed buffer) has NO form and every
+ * call refuses it the same way (round 6; rounds 5 assumed the current default): its owner states the form of the copy with
+ * aon_declare_stream_form(copy, aon_stream_form(original)).  The Python binding keeps the form next to the tensor and re-declares it on every
+ * call, so an address the caching allocator hands out again cannot carry the form of an earlier tenant.
  * aon_set_bottleneck_fold(0): the literal two-layer form (rounds 1-4), for A/B measurements and bit-level comparisons. */
 int aon_set_bottleneck_fold(int on);
 int aon_get_bottleneck_fold(void);
 int aon_stream_is_folded(const void* packed);   /* 1 / 0: the form `packed` (stream or per-call block) would be run in */
+int aon_stream_form(const void* packed);        /* 1 folded, 0 literal, -1 never packed / declared by this process */
+int aon_declare_stream_form(const void* packed, int form);   /* form 0 / 1: states the form of a COPY of a packed buffer (or re-states a known one) */
 
 /* As aon_pack_vanilla_mlp for a NeRFMLP(min_deg_point, max_deg_point, deg_view) of default widths and depths whose encodings have
  * at most 10 / 4 frequency levels (pts_linears.0: (256, 3 + 6 L), pts_linears.5: (256, 256 + 3 + 6 L), views_linear.0: (128, 256 +

@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(_lib.lib, n), f"{n} declared in aon_hip.h but not exported"
     assert sorted(_lib.exported_symbols()) == names, "ctypes binding and header disagree"
-    assert _lib.lib.aon_abi_version() == 4
+    assert _lib.lib.aon_abi_version() == 5
 
 
 def test_argument_validation_without_gpu():
@@ -244,8 +244,9 @@ def test_constructor_option_entry_points_validate_without_gpu():
 
 
 def test_bottleneck_fold_switch_without_gpu():
-    """Round 5: the form switch of the pack calls (include/aon_hip.h, aon_set_bottleneck_fold) is host state: default folded, and a
-    pointer this process never packed reports the current default form."""
+    """Round 5: the form switch of the pack calls (include/aon_hip.h, aon_set_bottleneck_fold) is host state: default folded.  Round 6
+    (ADVICE r5): a pointer this process never packed or declared has NO form (-1) whatever the switch says -- the launchers refuse it --
+    until its owner declares one (the form of a copy of a packed buffer); the switch never changes a form that was declared."""
     import ctypes as C
 
     from aon_amd import _lib
@@ -254,9 +255,16 @@ def test_bottleneck_fold_switch_without_gpu():
     before = lib.aon_get_bottleneck_fold()
     try:
         lib.aon_set_bottleneck_fold(1)
-        assert lib.aon_get_bottleneck_fold() == 1 and lib.aon_stream_is_folded(C.c_void_p(0x1000)) == 1
+        assert lib.aon_get_bottleneck_fold() == 1 and lib.aon_stream_form(C.c_void_p(0x1000)) == -1 and lib.aon_stream_is_folded(C.c_void_p(0x1000)) == 0
         lib.aon_set_bottleneck_fold(0)
-        assert lib.aon_get_bottleneck_fold() == 0 and lib.aon_stream_is_folded(C.c_void_p(0x1000)) == 0
+        assert lib.aon_get_bottleneck_fold() == 0 and lib.aon_stream_form(C.c_void_p(0x1000)) == -1
+        assert lib.aon_declare_stream_form(C.c_void_p(0x1000), 1) == 0 and lib.aon_stream_form(C.c_void_p(0x1000)) == 1
+        lib.aon_set_bottleneck_fold(1)
+        lib.aon_set_bottleneck_fold(0)
+        assert lib.aon_stream_form(C.c_void_p(0x1000)) == 1 and lib.aon_stream_is_folded(C.c_void_p(0x1000)) == 1     # declared: the switch does not touch it
+        assert lib.aon_declare_stream_form(C.c_void_p(0x1000), 0) == 0 and lib.aon_stream_form(C.c_void_p(0x1000)) == 0
+        assert lib.aon_declare_stream_form(C.c_void_p(0x1000), 7) == -1 and lib.aon_declare_stream_form(None, 1) == -1
+        assert lib.aon_stream_form(C.c_void_p(0x2000)) == -1
         # either form fits the buffers whose sizes the library reports (the sizes do not depend on the switch)
         sizes = (lib.aon_mlp_packed_bytes(), lib.aon_bwd_packed_bytes(), lib.aon_art_packed_bytes(), lib.aon_art_bwd_packed_bytes())
         lib.aon_set_bottleneck_fold(1)

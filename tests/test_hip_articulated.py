@@ -133,7 +133,7 @@ def test_nerf_ae_art_forward(dev, golden, art_sd):
     assert out[1][0].requires_grad
 
 
-def test_articulated_frame_320x240_properties(dev, art_sd):
+def test_articulated_frame_320x240_properties(dev, art_sd, golden):
     """BASELINE config 4 size (320x240 articulated, 1 GPU): chunk invariance, determinism, ranges."""
     import aon_amd.synthetic as syn
     from aon_amd import ops
@@ -158,47 +158,71 @@ def test_articulated_frame_320x240_properties(dev, art_sd):
         assert torch.isfinite(rgb).all() and torch.isfinite(depth).all()
         assert acc.min().item() >= 1.0 - 1e-5 and acc.max().item() <= 1.0 + 1e-5   # softplus sigma > 0 -> alpha_last = 1
         assert rgb.min().item() >= -0.001 - 1e-5 and rgb.max().item() <= 1.001 + 1e-4
-    # parity against the oracle at the bar of BASELINE config 2 (tests/test_hip_parity.py::test_full_frame_properties): >= 4,096 strided
-    # rays of THIS frame, both levels, every output (rounds 1-4 held 128 rays, fine rgb only, PSNR >= 70 dB / 1e-3: VERDICT r4).
-    # Bars: 1e-5 rgb / acc, 2e-4 depth per ray.  Where the REFERENCE ARITHMETIC ITSELF is less certain than that on this sharp x30 field
-    # (a 1e-7 difference of the deformed point is multiplied by 2^9 inside the encoding that follows the deformation MLP, and a 1e-7
-    # difference of a coarse weight moves fine samples across thin shells) the yardstick is the distance between the oracle's fp32 and
-    # fp64 evaluations of the same rays (see the fine-level criterion below).  Softplus keeps sigma > 0: every ray is far-plane robust.
-    pick = torch.arange(0, H * W, 18)
-    assert pick.numel() >= 4096
-    rays_cpu = {k: v[pick.to(dev)].cpu() for k, v in rays.items()}
-    lat_cpu = {k: v.cpu() for k, v in lat.items()}
-    ref = orc.nerf_ae_art_forward(art_sd, rays_cpu, False, True, 2.0, 6.0, lat_cpu)
-    ref64 = orc.nerf_ae_art_forward({k: v.double() for k, v in art_sd.items()}, {k: v.double() for k, v in rays_cpu.items()}, False, True, 2.0, 6.0,
-                                    {k: v.double() for k, v in lat_cpu.items()})
-    nrays = pick.numel()
-    for lvl in (0, 1):
-        got = [x[pick.to(dev)].cpu() for x in full[lvl]]
+    # Parity AT THIS SIZE against the REFERENCE's own outputs (round 6, G20): the 4,267 strided rays of this frame (every 18th pixel) that
+    # tests/golden/make_golden_full.py put through the real `NeRF_AE_Art.forward` in fp32 and fp64 -- both levels, every output (rounds
+    # 3-5 evaluated the oracle live here, fp32 + fp64; rounds 1-4 held 128 rays, fine rgb only).  The fixture's rays are rendered as their
+    # own batch (chunk invariance is asserted above).  Bars: 1e-5 rgb / acc, 2e-4 depth per ray.  Where the REFERENCE ARITHMETIC ITSELF is
+    # less certain than that on this sharp x30 field (a 1e-7 difference of the deformed point is multiplied by 2^9 inside the encoding that
+    # follows the deformation MLP, and a 1e-7 difference of a coarse weight moves fine samples across thin shells) the yardstick is the
+    # distance between the reference's fp32 and fp64 evaluations of the same rays.  Softplus keeps sigma > 0: every ray is far-plane robust.
+    g = golden("g20_config4_frame")
+    assert (g["H"], g["W"]) == (H, W) and g["pick"].numel() >= 4096
+    for k in ("density", "color", "articulation"):
+        assert torch.equal(lat[k].cpu(), g["lat_" + k])                      # the product's code library gave the reference's latents
+    grays = {k: g[k].to(dev) for k in ("rays_o", "rays_d", "viewdirs")}
+    assert torch.equal(grays["rays_o"], ro[g["pick"].to(dev)])
+    torch.testing.assert_close(grays["rays_d"], vd[g["pick"].to(dev)], rtol=0, atol=2e-7)
+    with torch.no_grad():
+        sub = model(grays, False, True, 2.0, 6.0, lat)
+    nrays = g["pick"].numel()
+    for lvl, lname in ((0, "coarse"), (1, "fine")):
+        got = [x.cpu() for x in sub[lvl]]
         for i, (name, bar) in enumerate((("rgb", 1e-5), ("acc", 1e-5), ("depth", 2e-4))):
-            err = (got[i] - ref[lvl][i]).abs()
-            spread = (ref[lvl][i].double() - ref64[lvl][i]).abs().float()
+            # CALM rays of this output: the reference's own fp32 and fp64 evaluations agree to a tenth of the bar (1e-6 rgb / acc, 2e-5 depth)
+            calm = g[f"spread_{lname}_{name}"] <= 0.1 * bar
+            ref = g[f"ref_{lname}_{name}"]
+            err = (got[i] - ref).abs()
+            spread = g[f"spread_{lname}_{name}"]
             if err.dim() > 1:
-                err, spread = err.max(dim=-1).values, spread.max(dim=-1).values
+                err = err.max(dim=-1).values
             above, above_ref = int((err > bar).sum()), int((spread > bar).sum())
             beyond = int((err > torch.clamp(3.0 * spread, min=bar)).sum())
             q = lambda x, p: torch.quantile(x.double(), p).item()   # noqa: E731
-            print(f"config 4 level {lvl} {name}: {nrays} rays, |hip - oracle| max {err.max():.2e} p99 {q(err, 0.99):.2e} p50 {q(err, 0.5):.2e}; oracle fp32 vs "
+            print(f"config 4 level {lvl} {name}: {nrays} rays, |hip - reference| max {err.max():.2e} p99 {q(err, 0.99):.2e} p50 {q(err, 0.5):.2e}; reference fp32 vs "
                   f"fp64 on the same rays max {spread.max():.2e} p99 {q(spread, 0.99):.2e} p50 {q(spread, 0.5):.2e}; rays above {bar:g}: hip {above}, "
-                  f"oracle's own {above_ref}; hip beyond 3 x that ray's spread: {beyond}")
+                  f"reference's own {above_ref}; hip beyond 3 x that ray's spread: {beyond}; calm rays {int(calm.sum())} "
+                  f"({100.0 * calm.double().mean():.1f} %), worst calm ray {err[calm].max():.2e}")
             if lvl == 0:
                 # coarse level: the same t on both sides -- per ray, the plain bar
                 assert above == 0, (name, err.max().item())
             else:
-                # Fine level.  Measured before the bottleneck fold (round 5, 4,267 rays): rgb 185 rays above 1e-5 where the oracle's own
+                # Fine level.  Measured before the bottleneck fold (round 5, 4,267 rays): rgb 185 rays above 1e-5 where the reference's own
                 # fp32-vs-fp64 distance exceeds it on MORE rays and by more (max 4.6e-4 vs 7.0e-4) -- which evaluation lands on which side
                 # of a thin shell is a coin toss per ray, so a per-ray "3 x this ray's spread" rule does not hold (47 rays) while the
-                # DISTRIBUTIONS agree.  Criterion: HIP is to the fp32 oracle what the fp32 oracle is to the fp64 truth -- no more rays
-                # above the bar than 1.5 x the oracle's own count (+ 0.5 % of the rays), the worst ray within 2 x the oracle's worst,
-                # the 99th percentile within 2 x the oracle's (or the bar).
+                # DISTRIBUTIONS agree.  Criterion: HIP is to the fp32 reference what the fp32 reference is to the fp64 truth -- no more rays
+                # above the bar than 1.5 x the reference's own count (+ 0.5 % of the rays), the worst ray within 2 x the reference's worst,
+                # the 99th percentile within 2 x the reference's (or the bar).
                 assert above <= 1.5 * above_ref + 0.005 * nrays, (name, above, above_ref)
                 assert err.max().item() <= max(bar, 2.0 * spread.max().item()), (name, err.max().item(), spread.max().item())
                 assert q(err, 0.99) <= max(bar, 2.0 * q(spread, 0.99)), (name, q(err, 0.99), q(spread, 0.99))
-        assert_render_close(got[0], ref[lvl][0], f"320x240 strided sample vs oracle, level {lvl}")
+                # ... and a per-ray net under the distributional rule: the CALM rays of this output -- the reference's own
+                # fp32 and fp64 agree to a tenth of the bar there -- must meet the plain bar.  Not every one can: "calm between fp32 and fp64"
+                # is not "calm for every fp32 evaluation".  G20 records a third evaluation on the CPU (every Linear accumulated in fp64 and
+                # rounded once -- more accurate than the reference's fp32): against the reference's fp32 it is above 1e-5 on 5 of the 2,514
+                # calm rgb rays (worst 2.1e-5; 139 rays overall), and on 33 of the 424 calm DEPTH rays (worst 1.6e-3).  HIP measured: rgb 9
+                # (worst 5.1e-5; 183 overall).  So: at most 1 % of the calm rays above the bar -- or 3 x the third evaluation's own count --
+                # (+ 5), the worst within 10 x the bar (or 3 x the third evaluation's worst): a systematic fine-level bias of 1e-4 on 5 % of
+                # the rays fails.  How many rays are calm is a property of the FIELD
+                # (rgb 58.9 %, acc 100 %, depth 9.9 % of the 4,267: the un-normalised depth sum of helper.py:180 moves by 2e-4 at the median
+                # between the reference's own two precisions); the sizes are asserted so that the net cannot silently shrink.
+                ncalm, over = int(calm.sum()), int((calm & (err > bar)).sum())
+                over_alt = int((calm & (g[f"alt_err_{lname}_{name}"] > bar)).sum())
+                print(f"    calm rays above the bar: hip {over}, the CPU's third evaluation {over_alt} (of {ncalm})")
+                assert calm.double().mean().item() > {"rgb": 0.5, "acc": 0.99, "depth": 0.05}[name], (name, calm.double().mean().item())
+                worst_alt = g[f"alt_err_{lname}_{name}"][calm].max().item()
+                assert over <= max(0.01 * ncalm, 3 * over_alt) + 5, (name, over, over_alt, ncalm)
+                assert err[calm].max().item() <= max(10.0 * bar, 3.0 * worst_alt), (name, err[calm].max().item(), worst_alt)
+        assert_render_close(got[0], g[f"ref_{lname}_rgb"], f"320x240 strided sample vs reference, level {lvl}")
 
 
 @pytest.mark.parametrize("tag", ["a", "b", "c"])

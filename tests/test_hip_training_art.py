@@ -212,13 +212,13 @@ def test_art_training_step_full_size_properties(dev):
         assert rel_l2((ga[k] + gb[k]).cpu(), gs[k].cpu()) <= 2e-5 or ((ga[k] + gb[k]) - gs[k]).abs().max().item() <= 1e-6, k
 
 
-def test_art_training_step_full_size_vs_oracle(dev):
-    """BASELINE config 5 per GPU AT ITS REAL SIZE -- 4096 rays drawn from a 640x480 frame, randomized=True with supplied draws, code
-    library, latent-norm regulariser (model_autodecoder.py:395-477) -- against the oracle's autograd in fp32 AND fp64 by the yardstick
-    of tests/_gradcheck.py (factor 5, floors 1e-4 / 2e-5): every one of the 80 parameter gradients and the three embedding tables.
+def test_art_training_step_full_size_vs_reference(dev, golden):
+    """BASELINE config 5 per GPU AT ITS REAL SIZE -- 4096 rays drawn from a 640x480 frame, randomized=True with named draws, code
+    library, latent-norm regulariser (model_autodecoder.py:395-477) -- against the REAL reference's autograd in fp32 AND fp64 (G21,
+    tests/golden/make_golden_full.py; rounds 3-5 ran the oracle's autograd live on the GPU host here) by the yardstick of
+    tests/_gradcheck.py (factor 5, floors 1e-4 / 2e-5): every one of the 80 parameter gradients and the three embedding tables.
     At 1.06 M samples the weight-gradient work line, the two-segment persistent launches and the merged three-launch forward run the
-    plan they run in the benchmark (rounds 1-4 compared gradients with the oracle at 64-256 rays only: VERDICT r4).  The oracle
-    accumulates over 512-ray chunks (the loss is a mean over rays: gradients add), which bounds its fp64 graph to ~5 GB."""
+    plan they run in the benchmark.  The reference accumulated the mean over 512-ray chunks (gradients add)."""
     import sys
     import types
 
@@ -227,58 +227,40 @@ def test_art_training_step_full_size_vs_oracle(dev):
     from aon_amd.models.vanilla_nerf.model_autodecoder import NeRF_AE_Art
 
     sys.path.insert(0, __import__("os").path.dirname(__file__))
-    from _gradcheck import assert_as_close_as_fp32
+    from _gradcheck import assert_as_close_as_fp32_fixture
 
-    n, H, W = 4096, 480, 640
-    sd = syn.make_art_state_dict(seed=0, density_scale=30.0)
+    g = golden("g21_config5_step")
+    n = int(g["n"])
+    sd = syn.make_art_state_dict(seed=int(g["seed"]), density_scale=float(g["density_scale"]))
     lib_sd = syn.make_code_library_state(seed=0, n_max_objs=1)
-    frame = syn.make_rays(H, W, syn.look_at_pose(), syn.focal_from_fovy(H))
-    gen = torch.Generator().manual_seed(5)
-    idx = torch.randint(0, H * W, (n,), generator=gen)                      # sapien_multi.py:235
-    rays_cpu = {k: frame[k][idx].contiguous() for k in ("rays_o", "rays_d", "viewdirs")}
+    rays = {k: g[k].to(dev) for k in ("rays_o", "rays_d", "viewdirs")}
+    # the draws of round 5's live-oracle test of this step (torch's CPU generator): ray indices, target, t_rand, u -- checked against the fixture
+    gen = torch.Generator().manual_seed(int(g["generator_seed"]))
+    assert torch.equal(torch.randint(0, int(g["H"]) * int(g["W"]), (n,), generator=gen), g["idx"])
     target = torch.rand(n, 3, generator=gen)
     t_rand, u = torch.rand(n, 65, generator=gen), torch.rand(n, 128, generator=gen)
-    inst, art_id = torch.tensor([0]), torch.tensor([5])
+    for t, key in ((target, "sum_target"), (t_rand, "sum_t_rand"), (u, "sum_u")):
+        assert t.double().sum().item() == float(g[key]), key
+    target, t_rand, u = target.to(dev), t_rand.to(dev), u.to(dev)
+    inst, art_id = torch.tensor([int(g["instance_id"])], device=dev), torch.tensor([int(g["articulation_id"])], device=dev)
 
     def reg_of(latents):
         return 1e-4 * sum(torch.mean(torch.norm(latents[k], dim=0)) for k in ("density", "color", "articulation"))   # :460-466
 
-    def oracle_grads(dtype, chunk=512):
-        sd_o = {k: v.detach().clone().to(dtype).requires_grad_(True) for k, v in sd.items()}
-        lib_o = {k: v.detach().clone().to(dtype).requires_grad_(True) for k, v in lib_sd.items()}
-        total = 0.0
-        for r0 in range(0, n, chunk):
-            sl = slice(r0, r0 + chunk)
-            lat = orc.code_library(lib_o, inst, art_id)
-            out = orc.nerf_ae_art_forward(sd_o, {k: v[sl].to(dtype) for k, v in rays_cpu.items()}, True, True, 2.0, 6.0, lat,
-                                          t_rand=t_rand[sl].to(dtype), u=u[sl].to(dtype))
-            tg = target[sl].to(dtype)
-            part = (((out[0][0] - tg) ** 2).sum() + ((out[1][0] - tg) ** 2).sum()) / (n * 3)
-            part.backward()
-            total += part.item()
-        reg = reg_of(orc.code_library(lib_o, inst, art_id))
-        reg.backward()
-        gr = {k: v.grad for k, v in sd_o.items()}
-        gr.update({"lib." + k: v.grad for k, v in lib_o.items()})
-        return total + reg.item(), gr
-
-    loss32, ref32 = oracle_grads(torch.float32)
-    loss64, truth = oracle_grads(torch.float64)
     model = NeRF_AE_Art().to(dev)
     model.load_state_dict(sd)
     lib = CodeLibraryArticulated(types.SimpleNamespace(N_max_objs=1, N_obj_code_length=128)).to(dev)
     lib.load_state_dict(lib_sd)
-    latents = lib({"instance_id": inst.to(dev), "articulation_id": art_id.to(dev)})
-    out = model({k: v.to(dev) for k, v in rays_cpu.items()}, True, True, 2.0, 6.0, latents, t_rand=t_rand.to(dev), u=u.to(dev))
-    tg = target.to(dev)
-    loss = torch.mean((out[1][0] - tg) ** 2) + torch.mean((out[0][0] - tg) ** 2) + reg_of(latents)
+    latents = lib({"instance_id": inst, "articulation_id": art_id})
+    out = model(rays, True, True, 2.0, 6.0, latents, t_rand=t_rand, u=u)
+    loss = torch.mean((out[1][0] - target) ** 2) + torch.mean((out[0][0] - target) ** 2) + reg_of(latents)
     loss.backward()
-    print(f"config 5 step, 4096 rays: loss hip {loss.item():.7f}, oracle fp32 {loss32:.7f}, fp64 {loss64:.7f}")
+    loss32, loss64 = float(g["loss32"]), float(g["loss64"])
+    print(f"config 5 step, {n} rays: loss hip {loss.item():.7f}, reference fp32 {loss32:.7f}, fp64 {loss64:.7f}")
     assert abs(loss.item() - loss64) <= max(5.0 * abs(loss32 - loss64), 2e-6 * abs(loss64))
     hip = {name: p.grad.cpu() for name, p in model.named_parameters()}
     hip.update({"lib." + name: p.grad.cpu() for name, p in lib.named_parameters()})
-    assert set(hip) == set(truth)
-    assert_as_close_as_fp32(hip, truth, ref32, "config 5 step at 4096 rays, articulated", factor=5.0, floor=1e-4)
+    assert_as_close_as_fp32_fixture(hip, g, f"config 5 step at {n} rays, articulated", factor=5.0, floor=1e-4)
 
 
 def test_inplace_update_between_forward_and_backward_raises(dev):

@@ -339,3 +339,101 @@ def test_g18_articulated_degrees(golden):
                 torch.testing.assert_close(out[lvl][0], g[f"{tag}_{t2}_{name}_rgb"], rtol=0, atol=2e-6)
                 torch.testing.assert_close(out[lvl][1], g[f"{tag}_{t2}_{name}_acc"], rtol=0, atol=2e-6)
                 torch.testing.assert_close(out[lvl][2], g[f"{tag}_{t2}_{name}_depth"], rtol=0, atol=2e-5)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# Round 6: the full-size fixtures of tests/golden/make_golden_full.py (REAL reference outputs at the sizes of BASELINE configs 2, 4, 5).
+# The GPU tests compare the HIP path with these directly; here the oracle is held to them, so that the oracle-vs-HIP tests elsewhere and
+# the cpu_baseline leg of bench.py stand on reference-pinned ground at these sizes too.
+# ---------------------------------------------------------------------------------------------------------------------------------
+def _frame_fixture_vs_oracle(g, out):
+    for lvl, lname in ((0, "coarse"), (1, "fine")):
+        for i, (name, atol) in enumerate((("rgb", 2e-6), ("acc", 2e-6), ("depth", 2e-5))):
+            ref = g[f"ref_{lname}_{name}"]
+            err = (out[lvl][i] - ref).abs()
+            print(f"{lname} {name}: {ref.shape[0]} rays, max |oracle - reference| {err.max():.2e}")
+            # same operations in the same order: the only freedom is the thread count of the (N*S,256)x(256,256) products
+            assert err.max().item() <= atol, (lname, name, err.max().item())
+
+
+def test_g19_config2_frame(golden, nerf_sd):
+    """4,209 strided rays of the 640x480 frame through the reference's NeRF.forward (fp32): both levels, rgb / acc / depth."""
+    g = golden("g19_config2_frame")
+    rays = {k: g[k] for k in ("rays_o", "rays_d", "viewdirs")}
+    torch.set_num_threads(8)
+    with torch.no_grad():
+        out, aux = orc.nerf_forward(nerf_sd, rays, False, True, g["near"], g["far"], return_aux=True)
+    _frame_fixture_vs_oracle(g, out)
+    margin = torch.stack([a["raw_sigma"][:, -1, 0].abs() for a in aux]).min(0).values
+    torch.testing.assert_close(margin, g["margin"], rtol=0, atol=1e-3)
+    # the recorded spreads are distances of the reference to ITSELF in fp64: sane magnitudes (coarse: 1e-5 class; fine: chaotic tail)
+    assert g["spread_coarse_rgb"].max().item() < 1e-3 and g["spread_fine_rgb"].median().item() < 1e-5
+
+
+def test_g20_config4_frame(golden):
+    """4,267 strided rays of the articulated 320x240 frame through the reference's NeRF_AE_Art.forward (fp32)."""
+    import aon_amd.synthetic as syn
+
+    g = golden("g20_config4_frame")
+    sd = syn.make_art_state_dict(seed=0, density_scale=30.0)
+    lib = syn.make_code_library_state(seed=0, n_max_objs=1)
+    lat = orc.code_library(lib, torch.tensor([g["instance_id"]]), torch.tensor([g["articulation_id"]]))
+    for k in ("density", "color", "articulation"):
+        assert torch.equal(lat[k], g["lat_" + k])
+    rays = {k: g[k] for k in ("rays_o", "rays_d", "viewdirs")}
+    torch.set_num_threads(8)
+    with torch.no_grad():
+        out = orc.nerf_ae_art_forward(sd, rays, False, True, g["near"], g["far"], lat)
+    _frame_fixture_vs_oracle(g, out)
+
+
+def test_g21_config5_step(golden):
+    """One 4096-ray articulated training step: the oracle's fp32 autograd must be to the reference's fp64 truth what the reference's own
+    fp32 autograd is (G21 holds both) -- same operations, so the two fp32 distances agree closely; and the loss."""
+    import aon_amd.synthetic as syn
+
+    g = golden("g21_config5_step")
+    n = g["n"]
+    sd = syn.make_art_state_dict(seed=0, density_scale=30.0)
+    lib_sd = syn.make_code_library_state(seed=0, n_max_objs=1)
+    rays = {k: g[k] for k in ("rays_o", "rays_d", "viewdirs")}
+    gen = torch.Generator().manual_seed(g["generator_seed"])
+    assert torch.equal(torch.randint(0, g["H"] * g["W"], (n,), generator=gen), g["idx"])
+    target = torch.rand(n, 3, generator=gen)
+    t_rand, u = torch.rand(n, 65, generator=gen), torch.rand(n, 128, generator=gen)
+    assert target.double().sum().item() == g["sum_target"] and t_rand.double().sum().item() == g["sum_t_rand"] and u.double().sum().item() == g["sum_u"]
+    inst, art_id = torch.tensor([g["instance_id"]]), torch.tensor([g["articulation_id"]])
+    torch.set_num_threads(8)
+    sd_o = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    lib_o = {k: v.clone().requires_grad_(True) for k, v in lib_sd.items()}
+    total, chunk = 0.0, 512
+    for r0 in range(0, n, chunk):
+        sl = slice(r0, r0 + chunk)
+        lat = orc.code_library(lib_o, inst, art_id)
+        out = orc.nerf_ae_art_forward(sd_o, {k: v[sl] for k, v in rays.items()}, True, True, 2.0, 6.0, lat, t_rand=t_rand[sl], u=u[sl])
+        m = target[sl].shape[0]
+        part = (orc.img2mse(out[1][0], target[sl]) + orc.img2mse(out[0][0], target[sl])) * (m / n)
+        part.backward()
+        total += part.item()
+    lat = orc.code_library(lib_o, inst, art_id)
+    reg = 1e-4 * sum(torch.mean(torch.norm(lat[k], dim=0)) for k in ("density", "color", "articulation"))
+    reg.backward()
+    loss = total + reg.item()
+    assert abs(loss - g["loss32"]) <= 2e-6 * abs(g["loss32"]), (loss, g["loss32"])
+    grads = {k: v.grad for k, v in sd_o.items()}
+    grads.update({"lib." + k: v.grad for k, v in lib_o.items()})
+    names = sorted(k[: -len("|norm")] for k in g if k.endswith("|norm"))
+    assert set(names) == set(grads)
+    worst = (0.0, "")
+    for name in names:
+        gh, nrm = grads[name].double().reshape(-1), max(g[f"{name}|norm"], 1e-30)
+        if f"{name}|truth" in g:
+            e, e_ref = (gh - g[f"{name}|truth"].double().reshape(-1)).norm().item() / nrm, g[f"{name}|ref32_dist"] / nrm
+        else:
+            sel = torch.arange(g[f"{name}|truth_sel"].numel()) * g[f"{name}|sel_step"]
+            nsel = max(g[f"{name}|norm_sel"], 1e-30)
+            e, e_ref = (gh[sel] - g[f"{name}|truth_sel"].double()).norm().item() / nsel, g[f"{name}|ref32_dist_sel"] / nsel
+        worst = max(worst, (e / max(e_ref, 1e-7), name))
+        # the oracle's fp32 is the reference's fp32 up to summation order: within 1.5 x of its distance to the truth (+ the fp32 storage of the truth)
+        assert e <= 1.5 * e_ref + 2e-7, (name, e, e_ref)
+    print(f"g21: worst (oracle fp32 distance to truth) / (reference fp32 distance to truth) = {worst[0]:.2f} on {worst[1]}")

@@ -66,6 +66,12 @@ def _grad_worker(rank, world, port, q, shard_align, mode):
         # shard_align=1 the bucket is padded to the next multiple of the world size only (74 at world 2, 75 at 3, 80 at 8) and the
         # shards cut through parameters and through the flags
         net.register_parameter("unused", torch.nn.Parameter(torch.ones(2)))
+        arena = None
+        if mode.endswith("+arena"):   # round 6: the parameters in ONE flat arena -- the exchange reduces its gradient buffer in place
+            from aon_amd.arena import ParamArena
+
+            mode = mode[: -len("+arena")]
+            arena = ParamArena(net)
         par.broadcast_parameters(net)
         x = torch.randn(11, 5)
         net(x).square().mean().backward()
@@ -89,6 +95,15 @@ def _grad_worker(rank, world, port, q, shard_align, mode):
                 late_error = str(e)
             net[2].bias.grad = torch.zeros(3)
         assert net.unused.grad is None   # as under torch DDP: globally unused parameters keep grad None (Adam skips them)
+        if arena is not None:
+            # torch's autograd delivered these gradients OUTSIDE the arena: the exchange adopted them into their slots and ran on the flat
+            # buffer itself; the slot of the parameter nobody touched holds the zeros this rank contributed, gaps and tail stay zero
+            assert arena.intact() and all(arena.grad_in_place(i) for i, p in enumerate(arena.params) if p.grad is not None)
+            mask = torch.ones(arena.capacity, dtype=torch.bool)
+            for p_, o_ in zip(arena.params, arena.offsets):
+                mask[o_: o_ + p_.numel()] = False
+            mask[arena.total: arena.total + len(arena.params)] = False     # the per-parameter counts of the exchange
+            assert not arena.grad[mask].any() and not arena.grad_view([i for i, p_ in enumerate(arena.params) if p_ is net.unused][0]).any()
         used = [p for n_, p in net.named_parameters() if n_ != "unused"]
         local = [g for g, (n_, _) in zip(local, net.named_parameters()) if n_ != "unused"]
         # plain numpy payloads: torch tensors travel through shared-memory handles that die with the worker
@@ -114,7 +129,8 @@ def _run_grad_workers(world, shard_align, mode):
 
 
 @pytest.mark.parametrize("world,shard_align,mode", [(2, 64, "permissive"), (2, 1, "contract"), (3, 1, "permissive"), (3, 64, "contract"),
-                                                     (8, 1, "permissive"), (8, 64, "contract")])
+                                                     (8, 1, "permissive"), (8, 64, "contract"), (2, 64, "contract+arena"), (3, 1, "permissive+arena"),
+                                                     (8, 64, "contract+arena")])
 def test_data_parallel_gradient_exchange(world, shard_align, mode):
     """broadcast_parameters + allreduce_gradients (the DDP duties of run.py:151) over gloo at world sizes 2, 3 and 8,
     buckets whose shards cut through parameters and flags (shard_align=1: 73 elements over 2 / 3 / 8 ranks), in both modes:

@@ -27,7 +27,8 @@ def main():
     ap.add_argument("--torch-loss", action="store_true", help="the loss lines as torch ops (~47 launches) instead of helper.train_loss")
     ap.add_argument("--late-heads", action="store_true", help="every head reduction behind the chain (round 4) instead of the chain-independent ones beside it")
     ap.add_argument("--articulated", action="store_true", help="NeRF_AE_Art + CodeLibraryArticulated (BASELINE config 5 per GPU)")
-    ap.add_argument("--foreach-adam", action="store_true", help="torch.optim.Adam's default foreach form instead of fused=True (the harness's choice on a GPU since round 5)")
+    ap.add_argument("--foreach-adam", action="store_true", help="torch.optim.Adam's default foreach form instead of fused=True (the harness's choice on a GPU in round 5)")
+    ap.add_argument("--torch-adam", action="store_true", help="torch.optim.Adam (fused unless --foreach-adam) instead of the parameter arena + ArenaAdam the harness builds since round 6")
     args = ap.parse_args()
     import aon_amd.synthetic as syn
     from aon_amd import ops
@@ -56,11 +57,19 @@ def main():
         lib = CodeLibraryArticulated(types.SimpleNamespace(N_max_objs=1, N_obj_code_length=128)).to(dev)
         lib.load_state_dict(syn.make_code_library_state(seed=0, n_max_objs=1))
         batch = {"instance_id": torch.tensor([0], device=dev), "articulation_id": torch.tensor([3], device=dev)}
-        opt = torch.optim.Adam(list(model.parameters()) + list(lib.parameters()), lr=5e-4, betas=(0.9, 0.999), fused=not args.foreach_adam)
+        if args.torch_adam or args.foreach_adam:
+            opt = torch.optim.Adam(list(model.parameters()) + list(lib.parameters()), lr=5e-4, betas=(0.9, 0.999), fused=not args.foreach_adam)
+        else:
+            from aon_amd.models.vanilla_nerf.model import build_adam
+            opt = build_adam([model, lib], 5e-4)
     else:
         model = NeRF().to(dev)
         model.load_state_dict(syn.make_nerf_state_dict(seed=0, density_scale=30.0))
-        opt = torch.optim.Adam(model.parameters(), lr=5e-4, betas=(0.9, 0.999), fused=not args.foreach_adam)
+        if args.torch_adam or args.foreach_adam:
+            opt = torch.optim.Adam(model.parameters(), lr=5e-4, betas=(0.9, 0.999), fused=not args.foreach_adam)
+        else:
+            from aon_amd.models.vanilla_nerf.model import build_adam
+            opt = build_adam([model], 5e-4)
     H, W = 480, 640
     ro, vd = ops.raygen(syn.look_at_pose(), H, W, syn.focal_from_fovy(H), device=dev)
     g = torch.Generator(device=dev).manual_seed(0)
@@ -96,7 +105,7 @@ def main():
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.steps
     flop = args.rays * 258 * (1_589_760 if args.articulated else 1_186_816) * 3  # fwd + 2x bwd, reference-literal
-    print(json.dumps({"model": "articulated" if args.articulated else "vanilla", "rays_per_step": args.rays, "ms_per_step": dt * 1e3, "host_enqueue_ms_per_step": enqueue_ms, "fused_adam": not args.foreach_adam, "rays_per_s": args.rays / dt,
+    print(json.dumps({"model": "articulated" if args.articulated else "vanilla", "rays_per_step": args.rays, "ms_per_step": dt * 1e3, "host_enqueue_ms_per_step": enqueue_ms, "optimizer": type(opt).__name__ + ("" if type(opt).__name__ == "ArenaAdam" else (" foreach" if args.foreach_adam else " fused")), "rays_per_s": args.rays / dt,
                       "train_tflops_3x_fwd": flop / dt / 1e12, "loss": loss.item()}))
 
 
