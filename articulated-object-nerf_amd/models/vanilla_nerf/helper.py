@@ -36,11 +36,14 @@ class _TrainLoss(torch.autograd.Function):
         ctx.save_for_backward(*[t for t in (rgb_c, rgb_f, target) + tuple(latents) if t is not None])
         ctx.layout = (rgb_c is not None, len(latents), reg_scale)
         ctx.mark_non_differentiable(stats)
+        ctx.set_materialize_grads(False)     # the logged stats carry no gradient: None, not a zero-filled tensor per step
         return loss.reshape(()), stats
 
     @staticmethod
     def backward(ctx, grad_loss, _grad_stats):
         has_c, n_lat, reg_scale = ctx.layout
+        if grad_loss is None:
+            return (None,) * (4 + n_lat)
         saved = list(ctx.saved_tensors)
         rgb_c = saved.pop(0) if has_c else None
         rgb_f, target = saved.pop(0), saved.pop(0)

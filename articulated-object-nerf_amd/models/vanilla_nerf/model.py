@@ -135,6 +135,28 @@ def packed_bwd_aside(mlps):
     return outs, ev
 
 
+def run_aside(dev, key: str, fn):
+    """`fn()` -> tuple of tensors, enqueued on a side stream of its own (one per device and `key`) behind everything the current stream
+    holds; -> (tensors, event or None).  Round 6: the FINE level's pack / prepare launches (fold -> pack, ~48 us in a row) run beside the
+    coarse level's instead of behind them; the caller makes the current stream wait for the event before the forward's C call.  The tensors
+    are allocated on the side stream and used on the current one: recorded for it, so the caching allocator keeps them until both are done."""
+    import os
+
+    if os.environ.get("AON_PACK_ASIDE", "1") == "0" or dev.type != "cuda":
+        return fn(), None
+    cur = torch.cuda.current_stream(dev)
+    side = _SIDE_STREAMS.get((dev, key))
+    if side is None:
+        side = _SIDE_STREAMS[(dev, key)] = torch.cuda.Stream(device=dev)
+    side.wait_stream(cur)
+    with torch.cuda.stream(side):
+        outs = fn()
+    ev = side.record_event()
+    for o in outs:
+        o.record_stream(cur)
+    return outs, ev
+
+
 class NeRF(nn.Module):
     """model.py:123-199.  ``forward(rays, randomized, white_bkgd, near, far)`` with ``rays`` a dict holding
     ``rays_o``, ``rays_d``, ``viewdirs`` (extra keys are ignored, as in the reference) returns
@@ -266,7 +288,10 @@ class NeRF(nn.Module):
                 raise ValueError("empty ray batch in training mode")
             mlps = [self.coarse_mlp, self.fine_mlp][: self.num_levels]
             bwd, bwd_ready = packed_bwd_aside(mlps)
-            packs = [(m.packed(True), b) for m, b in zip(mlps, bwd)]
+            fine_pk, fine_ready = run_aside(rays_o.device, "fine", lambda: (mlps[1].packed(True),)) if len(mlps) == 2 else (None, None)
+            packs = [(mlps[0].packed(True), bwd[0])] + ([(fine_pk[0], bwd[1])] if len(mlps) == 2 else [])
+            if fine_ready is not None:
+                torch.cuda.current_stream(rays_o.device).wait_event(fine_ready)
             params = [p for m in mlps for p in m.ordered_params()]
             try:
                 flat = RenderVanilla.apply(rays_o, rays["rays_d"], rays["viewdirs"], float(near), float(far), bool(white_bkgd),

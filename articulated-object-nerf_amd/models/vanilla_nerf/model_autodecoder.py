@@ -163,10 +163,16 @@ class NeRF_AE_Art(nn.Module):
             # the per-call block must not alias the cached inference buffer (it is saved for backward)
             mlps = [self.coarse_mlp, self.fine_mlp][: self.num_levels]
             bwd, bwd_ready = packed_bwd_aside(mlps)
-            packs = []
-            for mlp, b in zip(mlps, bwd):
-                small = ops.art_prepare(dict(mlp.named_parameters()), latents, degrees=mlp.degrees)
-                packs.append((mlp.packed(True), small, b))
+
+            def level_pack(mlp):     # the per-call latent-folded block + the forward weight stream of one level (prepare | fold -> pack)
+                return ops.art_prepare(dict(mlp.named_parameters()), latents, degrees=mlp.degrees), mlp.packed(True)
+
+            # round 6: the fine level's three launches on a side stream of their own, beside the coarse level's (they were 2 x 48 us in a row)
+            fine, fine_ready = run_aside(rays_o.device, "fine", lambda: level_pack(mlps[1])) if len(mlps) == 2 else (None, None)
+            small_c, pk_c = level_pack(mlps[0])
+            packs = [(pk_c, small_c, bwd[0])] + ([(fine[1], fine[0], bwd[1])] if len(mlps) == 2 else [])
+            if fine_ready is not None:
+                torch.cuda.current_stream(rays_o.device).wait_event(fine_ready)
             params = [p for mlp in mlps for p in mlp.ordered_params()]
             try:
                 flat = RenderArticulated.apply(rays_o, rays["rays_d"], rays["viewdirs"], float(near), float(far), bool(white_bkgd),
@@ -191,7 +197,7 @@ from collections import defaultdict  # noqa: E402
 from . import helper  # noqa: E402
 from ..code_library import CodeLibraryArticulated  # noqa: E402
 from ..interface import Harness  # noqa: E402
-from .model import build_adam, packed_bwd_aside  # noqa: E402
+from .model import build_adam, packed_bwd_aside, run_aside  # noqa: E402
 
 _SCALAR_KEYS = ("deg", "instance_id", "articulation_id")
 

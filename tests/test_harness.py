@@ -82,4 +82,14 @@ def test_log_series_reads_device_scalars_lazily():
     assert len(s) == 3 and s[-1] == 3.5 and list(s) == [1.5, 2.5, 3.5] and all(isinstance(v, float) for v in s)
     for i in range(600):
         s.append(torch.tensor(float(i)))
-    assert s._pending < 512 and s[3] == 0.0 and s[-1] == 599.0
+    assert len(s._wait) < 512 and s[3] == 0.0 and s[-1] == 599.0
+    # round 6: the list proper only ever holds floats -- every other way of looking at it settles the pending scalars first
+    import copy
+    import pickle
+
+    s.append(torch.tensor(7.0))
+    assert s.copy()[-1] == 7.0 and all(isinstance(v, float) for v in s.copy())
+    s.append(torch.tensor(8.0))
+    assert (s + [1.0])[-2] == 8.0 and repr(s).endswith("8.0]") and 8.0 in s and s == list(s)
+    s.append(torch.tensor(9.0))
+    assert copy.deepcopy(s)[-1] == 9.0 and pickle.loads(pickle.dumps(s))[-1] == 9.0 and type(pickle.loads(pickle.dumps(s))) is list

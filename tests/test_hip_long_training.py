@@ -14,7 +14,8 @@ compared with fixtures produced by tests/golden/make_golden_full.py from the REA
          elements (whole tensors below that); all three statistics are taken on the same sample.
   G22  convergence ("PSNR vs ref", BASELINE.json's metric): 300 steps x 256 rays from scratch on the synthetic 64x48 scene (8 training
        images, batches named by seed) for the vanilla network, and for the articulated network + code library:
-       * the first 32 steps at the bars above,
+       * the first 32 steps: worst per-step loss distance to the reference's fp32 run within 2 x (articulated 3 x) the reference's own
+         fp32-vs-fp64 distance over those steps (the loss falls fourfold in that window: single steps of two fp32 runs differ by a percent),
        * the held-out PSNR of the val image every 50 steps and at the end within max(0.2 dB, 2 x |reference fp32 - reference fp64|),
        * the final train loss (mean of the last 25 steps) within 3 %.
 
@@ -65,29 +66,50 @@ def _check_losses(tag, losses_h, losses_32, losses_64, loss_floor, spread_factor
         assert abs(a - b) <= loss_floor * abs(b) or abs(a - c) <= spread_factor * spread, (tag, i, a, b, c, spread)
 
 
+def _check_losses_window(tag, losses_h, losses_32, losses_64, factor=2.0, floor=5e-5):
+    """From-scratch runs: the loss falls by a factor of four within 30 steps and two fp32 trajectories separate by a percent on single steps
+    (the reference's own fp32 and fp64 runs: 1.3e-2 at worst over the first 32 steps of the vanilla run), not monotonically -- the
+    running-spread rule of `_check_losses` belongs to the slow G23 runs.  Here: the worst relative distance of the HIP run to the reference's
+    fp32 run over the window is within `factor` x the worst distance of the reference's fp32 run to its own fp64 run over the same window."""
+    rel = lambda xs, ys: max(abs(a - b) / max(abs(b), 1e-12) for a, b in zip(xs, ys))   # noqa: E731
+    worst, worst_ref = rel(losses_h, losses_32), rel(losses_32, losses_64)
+    print(f"{tag}: first {len(losses_h)} steps, loss {losses_32[0]:.6f} -> {losses_32[len(losses_h) - 1]:.6f}; worst per-step relative loss difference hip vs "
+          f"reference fp32 {worst:.2e}; the reference's fp32 against its own fp64 run: {worst_ref:.2e}")
+    assert worst <= max(floor, factor * worst_ref), (tag, worst, worst_ref)
+
+
 def _check_drift(tag, kind, g, named_final, named_init):
     """named_final / named_init: name -> tensor (HIP run's final parameters / the initial ones).  G23 holds, per parameter, a fixed sample
-    of the reference's movement p_final - p_initial in fp64 (`move64`) and fp32 (`move32`)."""
+    of the reference's movement p_final - p_initial in fp64 (`move64`) and fp32 (`move32`), and of a SECOND fp64 evaluation of the same 32
+    steps (`move64_alt`: the oracle's restatement in fp64, whose constants are the fp32 graph's).  The fp64 "truth" of these trajectories is
+    not unique: on the articulated network's deformation branch the two fp64 runs end 60-96 % of a parameter's movement apart -- as far as
+    the reference's fp32 run ends from either -- and one-element head biases move by several percent between them (round 6: with the
+    reference's fp64 run as the only truth the fine density bias read 7.5 % for torch's fused Adam and 10 % for the arena's, against 2.7 %
+    in round 5, where the oracle's fp64 run was the only truth).  Every distance is therefore taken to the CLOSER of the two fp64 runs, for
+    the HIP run and for the reference's fp32 run alike."""
     worst, worst_ref, widened = (0.0, ""), (0.0, ""), []
     names = sorted(k.split("|")[1] for k in g if k.startswith(kind + "|") and k.endswith("|move64"))
     assert set(names) == set(named_final), set(names) ^ set(named_final)
     for name in names:
         m64, m32 = g[f"{kind}|{name}|move64"].double(), g[f"{kind}|{name}|move32"].double()
+        malt = g[f"{kind}|{name}|move64_alt"].double()
         step = int(g[f"{kind}|{name}|sel_step"])
         sel = torch.arange(m64.numel()) * step
         mh = (named_final[name].detach().cpu().double().reshape(-1) - named_init[name].double().reshape(-1))[sel]
         move = m64.abs().mean().item()
         assert move > 1e-7, (name, "did not move")
-        drift, drift_ref = (mh - m64).abs().mean().item() / move, (m32 - m64).abs().mean().item() / move
+        dist = lambda x: min((x - m64).abs().mean().item(), (x - malt).abs().mean().item()) / move   # noqa: E731
+        drift, drift_ref = dist(mh), dist(m32)
+        ambiguity = (m64 - malt).abs().mean().item() / move
         worst, worst_ref = max(worst, (drift, name)), max(worst_ref, (drift_ref, name))
         if drift > 0.02:
-            widened.append((name, round(drift, 4), round(drift_ref, 4)))
+            widened.append((name, round(drift, 4), round(drift_ref, 4), round(ambiguity, 4)))
         # (a one- or three-element head bias has no averaging in this statistic: one Adam trajectory; measured round 4: 2.7 % for HIP against
         # 1.0 % for the fp32 oracle on the articulated coarse density bias)
         small = named_final[name].numel() <= 4
-        assert drift <= max(0.05 if small else 0.02, (3.0 if small else 2.0) * drift_ref), (tag, name, drift, drift_ref)
-    print(f"{tag}: worst mean parameter drift / mean movement against the reference's fp64 run: hip {worst[0]:.2e} on {worst[1]}; the reference's fp32 itself "
-          f"{worst_ref[0]:.2e} on {worst_ref[1]}; parameters above 2 % (each within 2 x the reference-fp32's own drift): {len(widened)}: {widened[:6]}")
+        assert drift <= max(0.05 if small else 0.02, (3.0 if small else 2.0) * max(drift_ref, 0.5 * ambiguity)), (tag, name, drift, drift_ref, ambiguity)
+    print(f"{tag}: worst mean parameter drift / mean movement against the closer fp64 run: hip {worst[0]:.2e} on {worst[1]}; the reference's fp32 itself "
+          f"{worst_ref[0]:.2e} on {worst_ref[1]}; parameters above 2 % (hip, reference fp32, distance between the two fp64 runs): {len(widened)}: {widened[:6]}")
 
 
 # ---------------------------------------------------------------------------------------------------------------------------------------
@@ -233,7 +255,7 @@ def test_vanilla_300_steps_converge_like_the_reference(dev, golden):
     losses = torch.stack(losses).tolist()
     c32, c64 = g["van_curve32"], g["van_curve64"]
     assert abs(opt.param_groups[0]["lr"] - c32[-1, 3].item()) <= 1e-12
-    _check_losses("vanilla, from scratch", losses[:32], c32[:32, 0].tolist(), c64[:32, 0].tolist(), 5e-5, 2.0)
+    _check_losses_window("vanilla, from scratch", losses[:32], c32[:32, 0].tolist(), c64[:32, 0].tolist())
     _check_convergence("vanilla, from scratch", g, "van_", losses, vals, _val_psnr(render, item))
     # the rendered held-out image itself, against the reference's (fp32) after its own 300 steps
     with torch.no_grad():
@@ -271,5 +293,5 @@ def test_articulated_300_steps_converge_like_the_reference(dev, golden):
             vals.append((i + 1, _val_psnr(render, item)))
     losses = torch.stack(losses).tolist()
     c32, c64 = g["art_curve32"], g["art_curve64"]
-    _check_losses("articulated, from scratch", losses[:32], c32[:32, 0].tolist(), c64[:32, 0].tolist(), 1e-4, 3.0)
+    _check_losses_window("articulated, from scratch", losses[:32], c32[:32, 0].tolist(), c64[:32, 0].tolist(), factor=3.0, floor=1e-4)
     _check_convergence("articulated, from scratch", g, "art_", losses, vals, _val_psnr(render, item))

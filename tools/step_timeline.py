@@ -19,7 +19,7 @@ def main():
     rows.sort()
     # a step starts at the first anchor launch after a non-anchor stretch that contains an optimiser kernel
     idx = [i for i, r in enumerate(rows) if anchor in r[2]]
-    starts = [i for k, i in enumerate(idx) if k == 0 or any("multi_tensor" in rows[j][2] for j in range(idx[k - 1], i))]
+    starts = [i for k, i in enumerate(idx) if k == 0 or any(("multi_tensor" in rows[j][2] or "adam_arena" in rows[j][2]) for j in range(idx[k - 1], i))]
     a, b = starts[-2], starts[-1]
     step = rows[a:b]
     t0 = step[0][0]
