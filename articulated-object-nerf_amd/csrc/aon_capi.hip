@@ -4,6 +4,7 @@
 
 #include <atomic>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <vector>
@@ -50,6 +51,7 @@ int wgrad_plan_segment(bool art, int64_t Np, int cus, int j, int wg, int32_t* be
 hipError_t launch_wgrad_kind_bench(int kind, int nlayers, const float* planes, const float* dplanes, int rows_total, int64_t Np, float* ws,
                                    float* out_scratch, hipStream_t stream);
 struct WgAux { hipStream_t stream; hipEvent_t fork, join; };   // aon_wgrad.h: optional side stream of a level's head reductions
+struct WgPost { const WgAux* side; hipEvent_t wait_first; };   // aon_wgrad.h: a level's second stage + finishing kernels on a side stream
 hipError_t launch_vanilla_wgrad(const float* planes, const float* dplanes, const float* d_raw, int64_t Np, float* const* grads,
                                 float* ws, hipStream_t stream, const WgAux* aux, const void* packed_bwd, int phase = 0);
 hipError_t launch_art_mlp_fwd_train(const char* packed, const float* small, const float* rays_o, const float* rays_d,
@@ -65,7 +67,7 @@ hipError_t launch_art_bwd_chain(const char* packed_bwd, const float* small, cons
 hipError_t launch_art_wgrad(const float* planes, const float* dplanes, const float* d_raw, const float* dxp, int64_t Np,
                             const float* const* params, const float* shape, const float* app, const float* art,
                             float* const* grads, float* g_shape, float* g_app, float* g_art, float* ws, hipStream_t stream, const WgAux* aux, int pos_levels, int view_levels,
-                            const void* packed_bwd, int phase = 0, bool accumulate_latents = false);
+                            const void* packed_bwd, int phase = 0, bool accumulate_latents = false, const struct WgPost* post = nullptr);
 hipError_t launch_train_loss(bool backward, const float* rgb_c, const float* rgb_f, const float* target, int64_t n, const float* const* lat, const int* lat_len,
                              float reg_scale, float* stats, float* loss, const float* go, float* d_rgb_c, float* d_rgb_f, float* const* d_lat, hipStream_t stream);
 hipError_t launch_adam(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2, double eps, int64_t step, hipStream_t stream);
@@ -1501,6 +1503,12 @@ int aon_art_render_bwd_ex(const void* packed_bwd_coarse, const void* small_coars
   LevelFork fork(num_levels == 2 && (merged ? (overlap_mode == 2 || early_heads) : overlap_mode != 0), caller, "aon_art_render_bwd", merged);
   if (fork.rc()) return fork.rc();
   const aon::WgAux* side = early_heads ? fork.aux(0) : nullptr;
+  // Round 6: level 0's second stage, un-folding products and latent columns (reduce 30 us -> fold 19 us -> finish 15 us in a row, the
+  // chip all but idle) run on a side stream beside level 1's head reductions and grouped kernel; level 1's own second stage waits for them
+  // (its finishing kernel adds onto level 0's latent gradients).  Tied to the early-heads switch: both are "small work in the shadows".
+  static const bool post_aside = [] { const char* e = std::getenv("AON_POST_ASIDE"); return !(e && e[0] == '0'); }();   // (A/B switch, read once)
+  const aon::WgAux* post_side = (merged && side && overlap_mode != 2 && post_aside) ? fork.aux(1) : nullptr;
+  const aon::WgPost post0{post_side, nullptr}, post1{nullptr, post_side ? post_side->join : nullptr};
   auto level_wgrad = [&](int l, hipStream_t st, const aon::WgAux* aux, int phase) {
     // level 0 writes the latent gradients, level 1 adds its own (both MLPs see the same latents).  Merged schedule (round 6): both levels'
     // finishing kernels run on the caller's stream in level order, so level 1's adds onto level 0's result in place (g = coarse + fine, the
@@ -1508,7 +1516,8 @@ int aon_art_render_bwd_ex(const void* packed_bwd_coarse, const void* small_coars
     const bool acc = merged && l == 1;
     float* gs = (l == 0 || acc) ? g_shape : sc.lat_tmp, *ga = (l == 0 || acc) ? g_appearance : sc.lat_tmp + 128, *gt = (l == 0 || acc) ? g_articulation : sc.lat_tmp + 256;
     return check(aon::launch_art_wgrad(w.lvl[l].planes, sc.dplanes[l], sc.d_raw[l], sc.dxp[l], w.lvl[l].Np, params[l], shape, appearance, articulation, grads[l], gs, ga, gt,
-                                       sc.wgrad_ws[l], st, aux, g.max_deg - g.min_deg, g.deg_view, pb[l], phase, acc), "aon_art_render_bwd");
+                                       sc.wgrad_ws[l], st, aux, g.max_deg - g.min_deg, g.deg_view, pb[l], phase, acc,
+                                       (post_side && phase != kWgEarly) ? (l == 0 ? &post0 : &post1) : nullptr), "aon_art_render_bwd");
   };
   if (merged) {
     for (int l = 0; l < 2; ++l)

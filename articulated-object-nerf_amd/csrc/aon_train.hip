@@ -458,7 +458,8 @@ void set_wgrad_probe(long long* buf) { g_wgrad_probe.store(buf, std::memory_orde
 // The plan (workspace offsets of every partial) is a pure function of the arguments: the two phases of a level compute the same one.
 hipError_t run_wgrad_plan(const WgLayerDesc* layers, int nlayers, const HeadDesc* heads, int nheads, const HeadOut* outs, const int* out_head, int nouts,
                           const float* planes, const float* dplanes, int rows_total, int64_t Np, float* ws, hipStream_t stream, const WgAux* aux,
-                          int phase, int n_early) {
+                          int phase, int n_early, const WgPost* post, hipStream_t* post_stream) {
+  if (post_stream) *post_stream = stream;
   static DeviceOnce lds_once;
   if (hipError_t e = set_max_lds(&wgrad_grouped_kernel, kWgLdsBytes, lds_once); e != hipSuccess) return e;
   const int cus = num_cus();
@@ -508,7 +509,18 @@ hipError_t run_wgrad_plan(const WgLayerDesc* layers, int nlayers, const HeadDesc
     if (err == hipSuccess) err = e;
   }
   if (err != hipSuccess) return err;
-  wgrad_reduce_kernel<<<dim3(plan.reduce_blocks + nouts), dim3(256), 0, stream>>>(R);
+  hipStream_t ps = stream;
+  if (post) {
+    if (post->wait_first)
+      if (hipError_t e = hipStreamWaitEvent(stream, post->wait_first, 0); e != hipSuccess) return e;
+    if (post->side) {   // the second stage and everything behind it on the side stream, ordered behind the grouped kernel
+      if (hipError_t e = hipEventRecord(post->side->fork, stream); e != hipSuccess) return e;
+      if (hipError_t e = hipStreamWaitEvent(post->side->stream, post->side->fork, 0); e != hipSuccess) return e;
+      ps = post->side->stream;
+    }
+  }
+  if (post_stream) *post_stream = ps;
+  wgrad_reduce_kernel<<<dim3(plan.reduce_blocks + nouts), dim3(256), 0, ps>>>(R);
   return hipGetLastError();
 }
 
@@ -578,7 +590,7 @@ hipError_t launch_vanilla_wgrad(const float* planes, const float* dplanes, const
   const HeadOut O[4] = {{0, 256, 3, 1, 256, 1, grads[20]}, {0, 128, 0, 3, 128, 1, grads[22]}, {0, 1, 3, 1, 1, 1, grads[21]}, {0, 1, 0, 3, 1, 1, grads[23]}};
   const int OH[4] = {0, 1, 2, 2};
   // all three head jobs (density head on H7, rgb head on HV, the sums of d_raw) are independent of the chain: n_early = 3
-  if (hipError_t e = run_wgrad_plan(L, n, H, 3, O, OH, 4, planes, dplanes, kPlRows, Np, ws, stream, aux, phase, 3); e != hipSuccess) return e;
+  if (hipError_t e = run_wgrad_plan(L, n, H, 3, O, OH, 4, planes, dplanes, kPlRows, Np, ws, stream, aux, phase, 3, nullptr, nullptr); e != hipSuccess) return e;
   if (!fold || phase == kWgEarly) return hipSuccess;
   const float* raw = reinterpret_cast<const float*>(static_cast<const char*>(packed_bwd) + kBwFOffWv);
   // (grads[16]'s row stride is the 27-slot layout's here: other view degrees write a slot-layout temporary first, aon_render_bwd_ex)

@@ -455,7 +455,7 @@ hipError_t launch_art_bwd_chain(const char* packed_bwd, const float* small, cons
 
 hipError_t run_wgrad_plan(const WgLayerDesc* layers, int nlayers, const HeadDesc* heads, int nheads, const HeadOut* outs, const int* out_head, int nouts,
                           const float* planes, const float* dplanes, int rows_total, int64_t Np, float* ws, hipStream_t stream, const WgAux* aux,
-                          int phase, int n_early);   // aon_train.hip
+                          int phase, int n_early, const WgPost* post, hipStream_t* post_stream);   // aon_train.hip
 
 // the weight-gradient jobs of one articulated level.  Lp / Lv: frequency levels of the network (10 / 4 by default).  With other degrees
 // the three encoding-fed column blocks come out in the kernels' 63 / 27-slot layout into `enc_tmp` (256 x 64 | 256 x 64 | 128 x 32
@@ -511,7 +511,7 @@ __global__ void art_remap_enc_kernel(const float* __restrict__ src, int lds, flo
 hipError_t launch_art_wgrad(const float* planes, const float* dplanes, const float* d_raw, const float* dxp, int64_t Np,
                             const float* const* params, const float* shape, const float* app, const float* art,
                             float* const* grads, float* g_shape, float* g_app, float* g_art, float* ws, hipStream_t stream, const WgAux* aux,
-                            int Lp, int Lv, const void* packed_bwd, int phase, bool accumulate_latents) {
+                            int Lp, int Lv, const void* packed_bwd, int phase, bool accumulate_latents, const WgPost* post) {
   // packed_bwd: the transposed stream the chain of these planes ran with -- its FORM says whether the planes carry bottleneck rows (null: literal)
   if (packed_bwd && stream_form(packed_bwd) == kFormUnknown) return hipErrorInvalidValue;   // (a copy nobody declared)
   const bool fold = packed_bwd && stream_form(packed_bwd) == kFormFolded;
@@ -534,8 +534,12 @@ hipError_t launch_art_wgrad(const float* planes, const float* dplanes, const flo
                         {0, 128, 0, 3, 1, 163, grads[0]},  {0, 128, 4, 1, 1, 1, grads[1]}};
   const int OH[8] = {0, 1, 2, 2, 3, 4, 5, 5};
   // head jobs 0..2 (density head on H7, rgb head on V3, the sums of d_raw) read forward planes and d_raw only: independent of the chain
-  if (hipError_t e = run_wgrad_plan(L, n, H, 6, O, OH, 8, planes, dplanes, kAPlRows, Np, ws, stream, aux, phase, 3); e != hipSuccess) return e;
+  hipStream_t caller_stream = stream;
+  if (hipError_t e = run_wgrad_plan(L, n, H, 6, O, OH, 8, planes, dplanes, kAPlRows, Np, ws, stream, aux, phase, 3, phase == kWgEarly ? nullptr : post, &stream); e != hipSuccess)
+    return e;
   if (phase == kWgEarly) return hipSuccess;
+  // (from here on `stream` is the stream of the second stage: the caller's, or the side stream of `post`)
+  (void)caller_stream;
   if (!dflt) {
     auto remap = [&](const float* src, int lds, float* dst, int ldd, int col_off, int rows, int Lx, int Lfull) {
       const int tot = rows * (3 + 6 * Lx);
@@ -573,7 +577,9 @@ hipError_t launch_art_wgrad(const float* planes, const float* dplanes, const flo
   outer(3, grads[21], shape, grads[20], 256, 128, 256 + P + 128, 256 + P);
   outer(4, grads[27], app, grads[26], 128, 128, 256 + V + 128, 256 + V);
   art_finish_kernel<<<dim3(blk), dim3(1024), 0, stream>>>(F);
-  return hipGetLastError();
+  if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
+  if (post && post->side) return hipEventRecord(post->side->join, stream);   // the caller (or the next level's second stage) waits for this
+  return hipSuccess;
 }
 
 }  // namespace aon

@@ -604,6 +604,15 @@ struct WgAux {
   hipEvent_t fork, join;
 };
 
+// Round 6: what follows a level's grouped kernel -- the second stage, the un-folding products, the latent columns (three launches of 15-60 us
+// in a row) -- may run on a side stream (`side`), beside the NEXT level's head reductions and grouped kernel instead of in front of them;
+// `wait_first`: an event the second stage of THIS level waits for first (the other level's finishing kernels, whose latent gradients this
+// level's are added to).  The caller orders its stream behind `side->join` before it reads any result.
+struct WgPost {
+  const WgAux* side;
+  hipEvent_t wait_first;
+};
+
 enum : int { kWgAll = 0, kWgEarly = 1, kWgRest = 2 };   // phases of a level's weight-gradient call (run_wgrad_plan)
 
 struct HeadDesc {
