@@ -6,7 +6,9 @@
   (b) BASELINE config 5's exchange: after `allreduce_gradients` every rank holds the mean of the per-rank single-GPU gradients
       (gathered independently with dist.all_gather and averaged in fp64), 1e-6 relative;
   (c) DDP's contract (run.py:151, find_unused_parameters=False): a rank that produced no gradient for a parameter makes EVERY rank raise
-      UnevenGradientsError at the next exchange -- none of them enters the collective alone.
+      UnevenGradientsError at the next exchange -- none of them enters the collective alone (ADVICE r4);
+  (d) round 6: the exchange in place on a parameter arena (aon_amd/arena.py) -- same mean, gradients never leave their slots -- and the
+      one-launch Adam behind it leaves every rank with bit-identical parameters.
 
 Writes one JSON line to the path in argv[1] (rank 0)."""
 import json
@@ -80,6 +82,35 @@ def main():
     res["grad_exchange_rel_err"] = err
     ok &= agree(err <= 1e-6 and distinct)
     par.check_gradient_exchange()   # the even exchange above: no complaint
+
+    # ---- (d) round 6: the same exchange IN PLACE on a parameter arena, then the one-launch Adam: every rank ends with the same parameters ----
+    from aon_amd.arena import ArenaAdam, ParamArena
+
+    model.zero_grad(set_to_none=True)
+    arena = ParamArena(model)
+    opt = ArenaAdam(arena, lr=5e-4)
+    out = model(rays, True, True, syn.NEAR, syn.FAR, t_rand=tr, u=u)
+    (((out[0][0] - target) ** 2).mean() + ((out[1][0] - target) ** 2).mean()).backward()
+    in_place = all(arena.grad_in_place(i) for i in range(len(arena.params)))
+    local2 = torch.cat([p.grad.reshape(-1) for p in params])
+    same_as_plain = torch.equal(local2, local_flat)                  # the arena only re-homes storage: the local gradients keep their bits
+    gathered2 = [torch.empty_like(local2) for _ in range(world)]
+    dist.all_gather(gathered2, local2)
+    mean2 = sum(g.double() for g in gathered2) / world
+    ptr = arena.grad.data_ptr()
+    par.allreduce_gradients(model, force=force)
+    got2 = torch.cat([p.grad.reshape(-1) for p in params])
+    err2 = ((got2.double() - mean2).norm() / mean2.norm().clamp_min(1e-30)).item()
+    in_place &= arena.grad.data_ptr() == ptr and all(arena.grad_in_place(i) for i in range(len(arena.params)))
+    opt.step()
+    hi, lo = arena.flat[: arena.total].clone(), arena.flat[: arena.total].clone()
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    res["arena_exchange_rel_err"] = err2
+    res["arena_in_place"] = agree(bool(in_place and same_as_plain))
+    res["arena_same_parameters_after_adam"] = agree(torch.equal(hi, lo) and opt.last_launches == 1)
+    ok &= agree(err2 <= 1e-6) and res["arena_in_place"] and res["arena_same_parameters_after_adam"]
+    par.check_gradient_exchange()
 
     # ---- (c) uneven gradient sets raise late, on every rank ----
     if world > 1:

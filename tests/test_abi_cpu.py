@@ -272,3 +272,62 @@ def test_bottleneck_fold_switch_without_gpu():
         assert lib.aon_bwd_packed_bytes() >= 60 * 32768 + (128 * 256 + 256 * 256 + 256 + 128 * 256 + 128) * 4   # folded stream + raw copies + W', b'
     finally:
         lib.aon_set_bottleneck_fold(before)
+
+
+def test_round6_entry_points_validate_without_gpu():
+    """aon_adam_step / aon_code_library_fwd / _bwd (ABI 5): argument validation happens on the host, before any launch."""
+    import ctypes as C
+
+    from aon_amd import _lib
+
+    lib = _lib.lib
+    p = C.c_void_p(0x1000)
+    assert lib.aon_adam_step(p, p, p, p, 0, 5e-4, 0.9, 0.999, 1e-8, 1, None) == 0                      # nothing to do
+    assert lib.aon_adam_step(p, p, p, p, -1, 5e-4, 0.9, 0.999, 1e-8, 1, None) == -1
+    assert lib.aon_adam_step(p, p, p, p, 16, 5e-4, 0.9, 0.999, 1e-8, 0, None) == -1 and b"step" in lib.aon_last_error()   # torch's state["step"] AFTER the update
+    assert lib.aon_adam_step(None, p, p, p, 16, 5e-4, 0.9, 0.999, 1e-8, 1, None) == -1 and b"null" in lib.aon_last_error()
+    for bad in ((-1.0, 0.9, 0.999, 1e-8), (5e-4, 1.0, 0.999, 1e-8), (5e-4, 0.9, -0.1, 1e-8), (5e-4, 0.9, 0.999, -1.0), (float("nan"), 0.9, 0.999, 1e-8)):
+        assert lib.aon_adam_step(p, p, p, p, 16, *bad, 1, None) == -1 and b"hyper-parameter" in lib.aon_last_error()
+    three = (C.c_void_p * 3)(0x1000, 0x2000, 0x3000)
+    rows, dims = (C.c_int * 3)(2, 2, 10), (C.c_int * 3)(128, 128, 32)
+    for fn in (lib.aon_code_library_fwd, lib.aon_code_library_bwd):
+        assert fn(None, three, rows, dims, three, None) == -1
+        assert fn(three, three, (C.c_int * 3)(2, 0, 10), dims, three, None) == -1 and b"table size" in lib.aon_last_error()
+        assert fn((C.c_void_p * 3)(0x1000, 0, 0x3000), three, rows, dims, three, None) == -1
+
+
+def test_param_arena_mechanics_on_cpu():
+    """aon_amd/arena.py without a GPU: the arena re-homes parameters (values, names, shapes kept), gradient slots, the claim rule for two
+    live graphs, and ArenaAdam's refusal to run on CPU tensors (no fallback)."""
+    import pytest
+    import torch
+
+    from aon_amd.arena import ALIGN, ArenaAdam, ParamArena, arena_of, grad_views
+
+    net = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.ReLU(), torch.nn.Linear(7, 3))
+    before = {k: v.clone() for k, v in net.state_dict().items()}
+    arena = ParamArena(net)
+    assert arena.intact() and all(o % ALIGN == 0 for o in arena.offsets) and arena.total == 4 * ALIGN
+    assert all(torch.equal(v, before[k]) for k, v in net.state_dict().items())
+    net.load_state_dict({k: v + 1 for k, v in before.items()})       # load_state_dict copies INTO the views
+    assert arena.intact() and torch.equal(arena.flat[:35].view(7, 5), before["0.weight"] + 1)
+    params = list(net.parameters())
+    ao = arena_of(params)
+    assert ao is not None and ao[0] is arena and ao[1] == arena.offsets
+    views = grad_views(ao, [tuple(p.shape) for p in params])
+    assert all(v.data_ptr() == arena.grad.data_ptr() + 4 * o for v, o in zip(views, arena.offsets))
+    tok = arena.claim(arena.offsets)
+    assert tok is not None and arena.claim(arena.offsets[:1]) is None          # a second live graph over a held slot gets none
+    tok.done = True
+    tok2 = arena.claim(arena.offsets)
+    assert tok2 is not None
+    del tok2                                                                   # a graph dropped without a backward frees its claim
+    assert arena.claim(arena.offsets) is not None
+    with pytest.raises(ValueError):
+        ParamArena(net)                                                        # already lives in an arena
+    net[0].weight.data = torch.zeros(7, 5)                                     # re-homed behind the arena's back
+    assert not arena.intact() and arena_of(params) is None
+    opt = ArenaAdam(ParamArena(torch.nn.Linear(3, 2)))
+    opt.arena.params[0].grad = torch.ones(2, 3)
+    with pytest.raises(RuntimeError, match="cuda"):
+        opt.step()                                                             # the product path has no CPU form

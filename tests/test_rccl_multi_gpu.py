@@ -42,6 +42,7 @@ def test_rccl_worker_at_world_size_one():
     res = _launch(1)
     print(res)
     assert res["ok"] and res["world"] == 1 and res["ranks_seen"] == 1 and res["sharded_frame_bit_equal"] and res["grad_exchange_rel_err"] <= 1e-6
+    assert res["arena_in_place"] and res["arena_same_parameters_after_adam"] and res["arena_exchange_rel_err"] <= 1e-6
 
 
 @pytest.mark.skipif(not torch.cuda.is_available() or torch.cuda.device_count() < 2, reason="needs >= 2 GPUs on the box (one-GPU lease: skipped)")
@@ -51,3 +52,4 @@ def test_rccl_with_every_gpu_of_the_box():
     print(res)
     assert res["ok"] and res["world"] == n and res["ranks_seen"] == n
     assert res["sharded_frame_bit_equal"] and res["grad_exchange_rel_err"] <= 1e-6 and res["uneven_raised_everywhere"]
+    assert res["arena_in_place"] and res["arena_same_parameters_after_adam"] and res["arena_exchange_rel_err"] <= 1e-6
