@@ -61,6 +61,22 @@ class ParamArena:
                 p._aon_arena = (self, o)
         self.device = dev
 
+    @classmethod
+    def for_modules(cls, modules):
+        """The arena the trainable parameters of `modules` ALREADY live in, if it is exactly theirs (same tensors, same order) and intact
+        -- `configure_optimizers()` called again, a second optimizer over the same model -- else a new one."""
+        mods = [modules] if isinstance(modules, torch.nn.Module) else list(modules)
+        seen, params = set(), []
+        for m in mods:
+            for p in m.parameters():
+                if p.requires_grad and id(p) not in seen:
+                    seen.add(id(p))
+                    params.append(p)
+        ao = arena_of(params) if params else None
+        if ao is not None and len(ao[0].params) == len(params) and all(a is b for a, b in zip(ao[0].params, params)):
+            return ao[0]
+        return cls(mods)
+
     # ------------------------------------------------------------------ queries
     def owns(self, p) -> bool:
         a = getattr(p, "_aon_arena", None)

@@ -337,7 +337,7 @@ def build_adam(modules, lr: float):
     if os.environ.get("AON_ARENA", "1") != "0" and params and all(p.is_cuda and p.dtype == torch.float32 for p in params):
         from ...arena import ArenaAdam, ParamArena
 
-        return ArenaAdam(ParamArena(list(modules)), lr=lr, betas=(0.9, 0.999))
+        return ArenaAdam(ParamArena.for_modules(list(modules)), lr=lr, betas=(0.9, 0.999))   # (a second call reuses the arena the parameters live in)
     return torch.optim.Adam(params=params, lr=lr, betas=(0.9, 0.999), fused=_fused_adam(params))
 
 

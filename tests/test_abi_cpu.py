@@ -325,6 +325,9 @@ def test_param_arena_mechanics_on_cpu():
     assert arena.claim(arena.offsets) is not None
     with pytest.raises(ValueError):
         ParamArena(net)                                                        # already lives in an arena
+    assert ParamArena.for_modules(net) is arena                                # ... which `configure_optimizers()` called again reuses
+    with pytest.raises(ValueError):
+        ParamArena.for_modules([net[0]])                                       # part of another arena: refused, not silently re-homed
     net[0].weight.data = torch.zeros(7, 5)                                     # re-homed behind the arena's back
     assert not arena.intact() and arena_of(params) is None
     opt = ArenaAdam(ParamArena(torch.nn.Linear(3, 2)))

@@ -259,6 +259,11 @@ def test_fit_step_runs_on_the_arena(dev, golden):
         assert torch.isfinite(loss)
         assert all(opt.arena.grad_in_place(j) for j in range(83)) and opt.last_launches == 1
     assert opt._steps == [3] * 83
+    # configure_optimizers() again (a resumed run builds its optimizer anew): the parameters stay where they are, the arena is reused
+    opt2 = lit.configure_optimizers()
+    assert opt2.arena is opt.arena and opt2 is not opt
+    opt2.load_state_dict(opt.state_dict())
+    assert opt2._steps == [3] * 83
 
 
 def test_allreduce_in_place_over_rccl(dev):
