@@ -301,3 +301,71 @@ def test_allreduce_in_place_over_rccl(dev):
     finally:
         if own_group:
             dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_arena_sweep_constructor_arguments(dev, seed):
+    """The arena path at random constructor arguments (sample counts, lindisp, density noise, the three encoding routes of the vanilla
+    network -- the slot-layout temporaries + remap kernels of other degrees write THROUGH the gradient pointers --, num_levels = 1,
+    articulated activation scalars): gradients with the arena are the bits without it and sit in their slots; an optimiser step of
+    ArenaAdam on them stays with torch.optim.Adam's."""
+    import numpy as np
+
+    import aon_amd.synthetic as syn
+    from aon_amd.arena import ArenaAdam, ParamArena
+    from aon_amd.models.vanilla_nerf.model import NeRF
+    from aon_amd.models.vanilla_nerf.model_autodecoder import NeRF_AE_Art
+    from oracle import nerf_oracle as orc   # (code-library rows for the latents only: no oracle arithmetic is compared here)
+
+    rng = np.random.Generator(np.random.PCG64(9100 + seed))
+    n = int(rng.integers(8, 200))
+    nc, nf = int(rng.integers(2, 100)), int(rng.integers(1, 220))
+    kw = dict(num_coarse_samples=nc, num_fine_samples=nf, lindisp=bool(rng.integers(0, 2)), noise_std=float(rng.choice([0.0, 0.4])))
+    white = bool(rng.integers(0, 2))
+    art = seed % 4 == 3
+    levels = 1 if seed == 5 else 2
+    g = torch.Generator().manual_seed(seed)
+    rays = {k: v.to(dev) for k, v in syn.random_rays(n, seed=300 + seed).items()}
+    target = torch.rand(n, 3, generator=g).to(dev)
+    args = dict(t_rand=torch.rand(n, nc + 1, generator=g).to(dev), u=torch.rand(n, nf, generator=g).to(dev),
+                noise=[torch.rand(n, nc + 1, generator=g).to(dev), torch.rand(n, nc + 1 + nf, generator=g).to(dev)][:levels])
+
+    def build():
+        if art:
+            m = NeRF_AE_Art(rgb_padding=0.02, density_bias=0.3, **kw).to(dev)
+            m.load_state_dict(syn.make_art_state_dict(seed=seed, density_scale=2.0))
+            lat = {k: v.to(dev).clone().requires_grad_(True) for k, v in
+                   orc.code_library(syn.make_code_library_state(seed=seed, n_max_objs=2), torch.tensor([seed % 2]), torch.tensor([seed % 10])).items()}
+            return m, lat
+        gk = [dict(), dict(min_deg_point=0, max_deg_point=7, deg_view=3), dict(min_deg_point=1, max_deg_point=9, deg_view=2)][seed % 3]
+        m = NeRF(num_levels=levels, **kw, **gk).to(dev)
+        m.load_state_dict(syn.make_general_nerf_state_dict(6000 + seed, **gk))
+        return m, None
+
+    def backward(m, lat):
+        out = m(rays, True, white, 2.0, 6.0, lat, **args) if art else m(rays, True, white, 2.0, 6.0, **args)
+        sum(((o[0] - target) ** 2).mean() for o in out).backward()
+        return {k: p.grad for k, p in m.named_parameters() if p.grad is not None}
+
+    plain_m, plain_lat = build()
+    plain = backward(plain_m, plain_lat)
+    m, lat = build()
+    arena = ParamArena(m)
+    got = backward(m, lat)
+    assert set(got) == set(plain) and len(got) == (len(arena.params) if levels == 2 else len(arena.params) // 2)
+    for k in plain:
+        assert torch.equal(got[k], plain[k]), (k, kw)
+    with_grad = [i for i, p in enumerate(arena.params) if p.grad is not None]
+    assert all(arena.grad_in_place(i) for i in with_grad)
+    if lat is not None:
+        for k in lat:
+            assert torch.equal(lat[k].grad, plain_lat[k].grad), k
+    # one optimiser step on these (bit-identical) gradients: the arena's one-launch Adam against torch's on the plain twin (several steps on
+    # identical gradients: test_arena_adam_is_torch_adam_in_one_launch; a second step HERE would compare two backward passes of
+    # parameters that already differ in their last bits)
+    opt, ref = ArenaAdam(arena, lr=5e-4), torch.optim.Adam(plain_m.parameters(), lr=5e-4, betas=(0.9, 0.999), foreach=False, fused=False)
+    opt.step()
+    ref.step()
+    assert opt.last_launches == 1
+    for (k, pa), pr in zip(m.named_parameters(), plain_m.parameters()):
+        assert (pa - pr).abs().max().item() <= 4e-7 * (pr.abs().max().item() + 1e-12), k
