@@ -436,8 +436,21 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(ReduceArgs a) {
     for (int idx = threadIdx.x; idx < H.rows * H.nchan; idx += 256) {
       const int row = idx / H.nchan, c = idx % H.nchan;
       const double* P = reinterpret_cast<const double*>(a.ws + H.part_off);
+      // (round 6: the loads of eight segments in flight at once, the additions in the SAME order as the plain loop -- same bits.  As a
+      // plain loop the 49 segment partials of a 4096 x 193 level were 49 dependent-latency loads in a row: these few blocks made the
+      // whole second stage 58 us long, at the very end of the backward)
+      const double* Pr = P + (int64_t)row * 8 + H.chan0 + c;
+      const int64_t seg_stride = (int64_t)H.rows * 8;
       double s = 0.0;
-      for (int p = 0; p < a.nseg; ++p) s += P[((int64_t)p * H.rows + row) * 8 + H.chan0 + c];
+      int p = 0;
+      for (; p + 8 <= a.nseg; p += 8) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = Pr[(int64_t)(p + u) * seg_stride];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+      }
+      for (; p < a.nseg; ++p) s += Pr[(int64_t)p * seg_stride];
       H.out[(int64_t)c * H.stride_c + (int64_t)row * H.stride_r] = (float)s;
     }
     return;
@@ -480,8 +493,18 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(ReduceArgs a) {
     const int r = threadIdx.x & 15, g = threadIdx.x >> 4;
     const int row = (blk - R.nblk_w) * 16 + r;
     double s = 0.0;
-    if (row < R.M)
-      for (int pp = g; pp < R.nparts; pp += 16) s += (double)a.ws[R.bias_off + (int64_t)pp * R.M + row];
+    if (row < R.M) {
+      const float* B = a.ws + R.bias_off + row;
+      int pp = g;
+      for (; pp + 48 < R.nparts; pp += 64) {   // four loads in flight, added in the order of the plain loop (same bits)
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = B[(int64_t)(pp + 16 * u) * R.M];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) s += (double)v[u];
+      }
+      for (; pp < R.nparts; pp += 16) s += (double)B[(int64_t)pp * R.M];
+    }
     redd[g * 16 + r] = s;
     __syncthreads();
     if (g == 0 && row < R.M) {
