@@ -1503,11 +1503,16 @@ int aon_art_render_bwd_ex(const void* packed_bwd_coarse, const void* small_coars
   LevelFork fork(num_levels == 2 && (merged ? (overlap_mode == 2 || early_heads) : overlap_mode != 0), caller, "aon_art_render_bwd", merged);
   if (fork.rc()) return fork.rc();
   const aon::WgAux* side = early_heads ? fork.aux(0) : nullptr;
-  // Round 6: level 0's second stage, un-folding products and latent columns (reduce 30 us -> fold 19 us -> finish 15 us in a row, the
-  // chip all but idle) run on a side stream beside level 1's head reductions and grouped kernel; level 1's own second stage waits for them
-  // (its finishing kernel adds onto level 0's latent gradients).  Tied to the early-heads switch: both are "small work in the shadows".
-  static const bool post_aside = [] { const char* e = std::getenv("AON_POST_ASIDE"); return !(e && e[0] == '0'); }();   // (A/B switch, read once)
-  const aon::WgAux* post_side = (merged && side && overlap_mode != 2 && post_aside) ? fork.aux(1) : nullptr;
+  // Round 6 experiment, OFF by default (AON_POST_ASIDE=1 enables it): level 0's second stage, un-folding products and latent columns
+  // (reduce 30 us -> fold 19 us -> finish 15 us in a row, the chip all but idle) on a side stream beside level 1's head reductions and
+  // grouped kernel; level 1's own second stage waits for them (its finishing kernel adds onto level 0's latent gradients).  Same bits
+  // (tools/grad_hash.py), -0.01 .. -0.05 ms per step on the runs where nothing goes wrong -- and on two boxes of the pool 6 of 16 runs
+  // with it took 34-42 ms per step instead of 30.3 (0 of 16 without): the second stage's thousands of small blocks are in flight when the
+  // persistent grouped kernel of level 1 is dispatched, and a workgroup with a static share that starts late (or shares a compute unit)
+  // stretches the whole launch.  The same lesson as profiles/r04_backward_schedules.txt: nothing beside the start of a persistent launch.
+  static const bool post_aside = [] { const char* e = std::getenv("AON_POST_ASIDE"); return e && e[0] == '1'; }();   // (read once)
+  // (overlap mode 2 runs level l's head reductions on aux(l) beside its grouped kernel: level 0's aux stream is free again by then)
+  const aon::WgAux* post_side = (merged && post_aside && fork.aux(0)) ? (overlap_mode == 2 ? fork.aux(0) : fork.aux(1)) : nullptr;
   const aon::WgPost post0{post_side, nullptr}, post1{nullptr, post_side ? post_side->join : nullptr};
   auto level_wgrad = [&](int l, hipStream_t st, const aon::WgAux* aux, int phase) {
     // level 0 writes the latent gradients, level 1 adds its own (both MLPs see the same latents).  Merged schedule (round 6): both levels'
