@@ -120,7 +120,9 @@ int aon_pack_vanilla_mlp(const float* const* params_host, void* packed, void* st
  * and a from-scratch kernel can run ONE 256 -> 128 layer where the literal graph runs 256 -> 256 then 256 -> 128: 65,536 of the
  * vanilla network's 593,408 multiply-adds per sample (11.0 %; 9.5 % of the articulated network's executed 692,480), in the forward,
  * the backward data chain and the weight gradients alike.  With the switch on (default) every aon_pack_* / aon_art_prepare* call
- * builds the FOLDED form: W' = W_v0[:, :256] W_b and b' are evaluated in fp64 from the fp32 parameters and rounded once; the training
+ * builds the FOLDED form: W' = W_v0[:, :256] W_b and the vanilla b' are evaluated in fp64 from the fp32 parameters and rounded once (the
+ * articulated per-call block: the fp64 sum W_v0[:, :256] b_b is added to the fp32 value of b_v0 + the appearance-latent term and the
+ * result rounded again -- two roundings, the second half an ulp of the bias); the training
  * forward writes no bottleneck rows; the backward computes dW' = dZ_v0 H7^T, db' and un-folds them exactly as autograd's chain rule
  * does -- dW_b = W_v0[:, :256]^T dW', db_b = W_v0[:, :256]^T db', dW_v0[:, :256] = dW' W_b^T + db' (x) b_b (fp64 accumulation) -- so
  * the 24 / 40 parameter gradients keep the reference's shapes and meaning.  Buffer sizes do not depend on the switch.
