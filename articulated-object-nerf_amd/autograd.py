@@ -100,6 +100,7 @@ class RenderVanilla(torch.autograd.Function):
                                    [gouts[3 * l + 1] for l in range(ctx.num_levels)], [gouts[3 * l + 2] for l in range(ctx.num_levels)],
                                    geometry=ctx.geometry, grads_out=slots)
         ctx.fused, ctx.released, ctx.geometry = None, True, None
+        ops.pool_give(ws)      # (the backward's launches are enqueued: whoever takes the workspace next is ordered behind them)
         _arena_done(ctx)
         return (None,) * 12 + tuple(g[name] for g in per_level for name in ops.VANILLA_PARAM_ORDER)
 
@@ -203,6 +204,7 @@ class RenderArticulated(torch.autograd.Function):
                                               [gouts[3 * l + 1] for l in range(ctx.num_levels)], [gouts[3 * l + 2] for l in range(ctx.num_levels)],
                                               params, latents, geometry=ctx.geometry, grads_out=slots)
         ctx.fused, ctx.released, ctx.geometry = None, True, None
+        ops.pool_give(ws)      # (the backward's launches are enqueued: whoever takes the workspace next is ordered behind them)
         _arena_done(ctx)
         lat = tuple(g_lat[k].reshape(shp) for k, shp in zip(("density", "color", "articulation"), ctx.lat_shapes))
         return (None,) * 12 + lat + tuple(g[name] for g in per_level for name in ops.ART_PARAM_ORDER)

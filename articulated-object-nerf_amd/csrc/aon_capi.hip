@@ -962,10 +962,20 @@ LevelStreams* level_streams() {
   std::lock_guard<std::mutex> lk(mu);
   LevelStreams& ls = per_dev[dev];
   if (!ls.fork) {
+    // AON_SIDE_PRIORITY=1 (experiment, round 6): the side streams at the LOWEST priority the device offers, so that when a side-stream kernel and
+    // a persistent launch on the caller's stream become eligible at the same moment the command processor dispatches the persistent launch
+    // first.  Built while hunting whole processes that ran the config-5 step at 33-40 ms instead of 30.4 (tools/slowmode_probe.sh); the cause
+    // turned out to be a hipMalloc of the 11-15 GB workspaces inside the step (ops._TRAIN_POOL), not the dispatch order -- and at low
+    // priority the early head reductions start too late to fill the chain's last round (+0.25 ms per step).  Default: normal priority.
+    int least = 0, greatest = 0;
+    const char* e = std::getenv("AON_SIDE_PRIORITY");
+    const bool low = e && e[0] == '1';
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = 0;
+    auto make = [&](hipStream_t* st) { return low ? hipStreamCreateWithPriority(st, hipStreamNonBlocking, least) : hipStreamCreateWithFlags(st, hipStreamNonBlocking); };
     for (int i = 0; i < 2; ++i) {
-      if (hipStreamCreateWithFlags(&ls.s[i], hipStreamNonBlocking) != hipSuccess) return nullptr;
+      if (make(&ls.s[i]) != hipSuccess) return nullptr;
       if (hipEventCreateWithFlags(&ls.join[i], hipEventDisableTiming) != hipSuccess) return nullptr;
-      if (hipStreamCreateWithFlags(&ls.aux[i].stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
+      if (make(&ls.aux[i].stream) != hipSuccess) return nullptr;
       if (hipEventCreateWithFlags(&ls.aux[i].fork, hipEventDisableTiming) != hipSuccess) return nullptr;
       if (hipEventCreateWithFlags(&ls.aux[i].join, hipEventDisableTiming) != hipSuccess) return nullptr;
     }
@@ -1506,10 +1516,9 @@ int aon_art_render_bwd_ex(const void* packed_bwd_coarse, const void* small_coars
   // Round 6 experiment, OFF by default (AON_POST_ASIDE=1 enables it): level 0's second stage, un-folding products and latent columns
   // (reduce 30 us -> fold 19 us -> finish 15 us in a row, the chip all but idle) on a side stream beside level 1's head reductions and
   // grouped kernel; level 1's own second stage waits for them (its finishing kernel adds onto level 0's latent gradients).  Same bits
-  // (tools/grad_hash.py), -0.01 .. -0.05 ms per step on the runs where nothing goes wrong -- and on two boxes of the pool 6 of 16 runs
-  // with it took 34-42 ms per step instead of 30.3 (0 of 16 without): the second stage's thousands of small blocks are in flight when the
-  // persistent grouped kernel of level 1 is dispatched, and a workgroup with a static share that starts late (or shares a compute unit)
-  // stretches the whole launch.  The same lesson as profiles/r04_backward_schedules.txt: nothing beside the start of a persistent launch.
+  // (tools/grad_hash.py).  Three-run A/Bs read -0.05 ms; six alternating runs each, with the allocator stall of ops._TRAIN_POOL out of
+  // the way, read 30.404 vs 30.403 ms -- nothing.  (The 34-42 ms steps first blamed on it were that stall.)  Left off: no gain, and side
+  // work beside the start of a persistent launch is where this code has been burnt before (profiles/r04_backward_schedules.txt).
   static const bool post_aside = [] { const char* e = std::getenv("AON_POST_ASIDE"); return e && e[0] == '1'; }();   // (read once)
   // (overlap mode 2 runs level l's head reductions on aux(l) beside its grouped kernel: level 0's aux stream is free again by then)
   const aon::WgAux* post_side = (merged && post_aside && fork.aux(0)) ? (overlap_mode == 2 ? fork.aux(0) : fork.aux(1)) : nullptr;

@@ -106,6 +106,20 @@ class NeRFMLP(nn.Module):
 _SIDE_STREAMS: dict = {}
 
 
+def pack_aside_mode() -> int:
+    """AON_PACK_ASIDE: 0 (default since round 6) = every pack launch in line on the current stream; 1 = round 5: the transposed streams (and,
+    round 6, the fine level's forward pack) on side streams, the transposed ones waited for AFTER the forward's launches; 2 = the same side
+    streams, all of them waited for BEFORE the forward is launched.
+    Why 0: measured with the workspace pool in place (ops._TRAIN_POOL), six alternating runs each on one box, the four variants are the same to
+    0.02 ms per 30.4 ms step (30.401 / 30.403 / 30.404 / 30.421 ms: in line / mode 1 / mode 1 + the level-0 second stage aside / mode 2) --
+    the 0.03-0.05 ms that rounds 5 and 6 first read off shorter A/Bs do not survive more repetitions -- and side streams around persistent
+    launches are exactly where this code base has been burnt before (profiles/r04_backward_schedules.txt).  The modes stay for experiments."""
+    import os
+
+    v = os.environ.get("AON_PACK_ASIDE", "0")
+    return int(v) if v in ("0", "1", "2") else 0
+
+
 def packed_bwd_aside(mlps):
     """The levels' transposed weight streams (read by the BACKWARD only), packed on a side stream so that the two small launches per level
     (38 us each in a 31 ms step, profiles/r05_step_timeline.txt) run beside the forward's own pack kernels and launches instead of in front
@@ -114,23 +128,32 @@ def packed_bwd_aside(mlps):
     import os
 
     dev = next(mlps[0].parameters()).device
-    if os.environ.get("AON_PACK_ASIDE", "1") == "0" or dev.type != "cuda":
+    if pack_aside_mode() == 0 or dev.type != "cuda":
         return [m.packed_bwd(True) for m in mlps], None
     cur = torch.cuda.current_stream(dev)
-    side = _SIDE_STREAMS.get(dev)
-    if side is None:
-        side = _SIDE_STREAMS[dev] = torch.cuda.Stream(device=dev)
     outs = [m.new_bwd_buffer() for m in mlps]
-    side.wait_stream(cur)        # the parameters as the optimiser step left them
-    with torch.cuda.stream(side):
-        for m, o in zip(mlps, outs):
+    # one side stream per level (round 6: the two levels' fold -> pack chains beside each other; the last stream waits for the others,
+    # so ONE event covers them all)
+    sides = []
+    for lvl in range(len(mlps)):
+        side = _SIDE_STREAMS.get((dev, "bwd", lvl))
+        if side is None:
+            side = _SIDE_STREAMS[(dev, "bwd", lvl)] = torch.cuda.Stream(device=dev)
+        sides.append(side)
+    for side, m, o in zip(sides, mlps, outs):
+        side.wait_stream(cur)        # the parameters as the optimiser step left them
+        with torch.cuda.stream(side):
             m.packed_bwd(True, out=o)
+    for side in sides[:-1]:
+        sides[-1].wait_stream(side)
+    side = sides[-1]
     ev = side.record_event()
     for o in outs:
         # (1) the buffers were allocated on the current stream but are written on the side stream: the caching allocator must not
         # hand their memory to current-stream work before the pack kernels are done, even if the caller drops them early (an exception
         # inside the forward); (2) the event travels WITH the buffer, so that a backward run on another stream than the forward waits too
-        o.record_stream(side)
+        for sd in sides:
+            o.record_stream(sd)
         o._aon_ready = ev
     return outs, ev
 
@@ -142,7 +165,7 @@ def run_aside(dev, key: str, fn):
     are allocated on the side stream and used on the current one: recorded for it, so the caching allocator keeps them until both are done."""
     import os
 
-    if os.environ.get("AON_PACK_ASIDE", "1") == "0" or dev.type != "cuda":
+    if pack_aside_mode() == 0 or dev.type != "cuda":
         return fn(), None
     cur = torch.cuda.current_stream(dev)
     side = _SIDE_STREAMS.get((dev, key))
@@ -292,6 +315,9 @@ class NeRF(nn.Module):
             packs = [(mlps[0].packed(True), bwd[0])] + ([(fine_pk[0], bwd[1])] if len(mlps) == 2 else [])
             if fine_ready is not None:
                 torch.cuda.current_stream(rays_o.device).wait_event(fine_ready)
+            if bwd_ready is not None and pack_aside_mode() == 2:
+                # no side-stream kernel may be in flight when the forward's persistent launches are dispatched (see pack_aside_mode)
+                torch.cuda.current_stream(rays_o.device).wait_event(bwd_ready)
             params = [p for m in mlps for p in m.ordered_params()]
             try:
                 flat = RenderVanilla.apply(rays_o, rays["rays_d"], rays["viewdirs"], float(near), float(far), bool(white_bkgd),

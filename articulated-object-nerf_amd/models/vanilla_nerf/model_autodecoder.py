@@ -173,6 +173,9 @@ class NeRF_AE_Art(nn.Module):
             packs = [(pk_c, small_c, bwd[0])] + ([(fine[1], fine[0], bwd[1])] if len(mlps) == 2 else [])
             if fine_ready is not None:
                 torch.cuda.current_stream(rays_o.device).wait_event(fine_ready)
+            if bwd_ready is not None and pack_aside_mode() == 2:
+                # no side-stream kernel may be in flight when the forward's persistent launches are dispatched (see pack_aside_mode)
+                torch.cuda.current_stream(rays_o.device).wait_event(bwd_ready)
             params = [p for mlp in mlps for p in mlp.ordered_params()]
             try:
                 flat = RenderArticulated.apply(rays_o, rays["rays_d"], rays["viewdirs"], float(near), float(far), bool(white_bkgd),
@@ -197,7 +200,7 @@ from collections import defaultdict  # noqa: E402
 from . import helper  # noqa: E402
 from ..code_library import CodeLibraryArticulated  # noqa: E402
 from ..interface import Harness  # noqa: E402
-from .model import build_adam, packed_bwd_aside, run_aside  # noqa: E402
+from .model import build_adam, pack_aside_mode, packed_bwd_aside, run_aside  # noqa: E402
 
 _SCALAR_KEYS = ("deg", "instance_id", "articulation_id")
 

@@ -893,18 +893,56 @@ def set_fwd_merge(on: bool) -> None:
     check(lib.aon_set_fwd_merge(2 if on == 2 else int(bool(on))), "aon_set_fwd_merge")   # 2 (tests): merge even when no round is saved
 
 
+# The two big buffers of a training step -- the forward -> backward workspace (15 GB at 4096 articulated rays) and the backward's scratch
+# (11 GB) -- are taken from / given back to a small POOL of this module instead of torch's caching allocator (round 6).  Through the allocator
+# they were freed and re-requested every step, and while such a block sat free the step's own 2-7 MB allocations (weight streams, gradient
+# buffers) could be carved out of it: the next request for the full size then found no block and the allocator went to the driver -- ONE
+# hipMalloc of 11-15 GB, 80-125 ms of host time, once per process at a step that depends on timing (measured: 4 device mallocs and +13.9 GB
+# reserved INSIDE the timed loop of every run of tools/train_bench.py; when the stall fell on an early step the device ran dry and the run
+# averaged 33-40 ms per step instead of 30.4, tools/slowmode_probe.sh).  A pooled buffer is only handed to the stream it was returned on;
+# at most two per (device, size) are kept; release_workspaces() drops them.
+_TRAIN_POOL: dict = {}
+_TRAIN_POOL_KEEP = 2
+
+
+def _pool_take(nbytes: int, what: str, device) -> torch.Tensor:
+    if nbytes < 0:
+        check(nbytes, what)
+    dev = torch.device(device)
+    if dev.type == "cuda":
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        free = _TRAIN_POOL.get((dev.index if dev.index is not None else torch.cuda.current_device(), nbytes))
+        if free:
+            for i, (t, s) in enumerate(free):
+                if s == stream:
+                    del free[i]
+                    return t
+    return torch.empty(nbytes, dtype=torch.uint8, device=device)
+
+
+def pool_give(t) -> None:
+    """Hand a training workspace / scratch back (stream-ordered: everything enqueued on the current stream so far may still use it, whatever
+    takes it next is enqueued behind).  Called by the backward once it has enqueued its last launch."""
+    if t is None or not isinstance(t, torch.Tensor) or not t.is_cuda or t.dtype != torch.uint8 or t.dim() != 1:
+        return
+    key = (t.device.index, t.numel())
+    free = _TRAIN_POOL.setdefault(key, [])
+    if len(free) < _TRAIN_POOL_KEEP:
+        free.append((t, torch.cuda.current_stream(t.device).cuda_stream))
+
+
 def train_workspace(device, n_rays: int, articulated: bool, num_levels: int = 2, st=None) -> torch.Tensor:
-    """Fresh workspace of one training forward/backward pair (it carries the forward's planes to the backward, so it is
-    owned by the autograd graph, not cached); sized by the levels in use."""
-    return _sized(int(lib.aon_train_workspace_bytes_ex(n_rays, int(articulated), num_levels, None if st is None else C.byref(st))),
-                  "aon_train_workspace_bytes_ex", device)
+    """Workspace of one training forward/backward pair (it carries the forward's planes to the backward, so it is owned by the autograd
+    graph until the backward gives it back to the pool: `pool_give`); sized by the levels in use."""
+    return _pool_take(int(lib.aon_train_workspace_bytes_ex(n_rays, int(articulated), num_levels, None if st is None else C.byref(st))),
+                      "aon_train_workspace_bytes_ex", device)
 
 
 def train_scratch(device, n_rays: int, articulated: bool, num_levels: int = 2, st=None) -> torch.Tensor:
-    """The backward's own temporaries (gradient planes, d_raw, weight-gradient partials): allocated when the backward runs and
-    handed back to torch's caching allocator right after, so a live graph pins the forward's workspace only."""
-    return _sized(int(lib.aon_train_scratch_bytes_ex(n_rays, int(articulated), num_levels, None if st is None else C.byref(st))),
-                  "aon_train_scratch_bytes_ex", device)
+    """The backward's own temporaries (gradient planes, d_raw, weight-gradient partials): taken from the pool when the backward runs and
+    given back right after, so a live graph pins the forward's workspace only."""
+    return _pool_take(int(lib.aon_train_scratch_bytes_ex(n_rays, int(articulated), num_levels, None if st is None else C.byref(st))),
+                      "aon_train_scratch_bytes_ex", device)
 
 
 def _level_outs(n, dev, num_levels):
@@ -978,6 +1016,7 @@ def render_bwd(ws, packs_bwd, packs_fwd, rays_d, white_bkgd, num_levels, g_rgb, 
         check(lib.aon_render_bwd_ex(_pk(pb[0]), _pk(pf[0]), _pk(pb[1]), _pk(pf[1]), _ptr(d), n, int(bool(white_bkgd)), num_levels,
                                     _ptr_array(keep[:k]), _ptr_array(keep[k:2 * k]), _ptr_array(keep[2 * k:3 * k]), garr[0], garr[1], _ptr(ws), ws.numel(),
                                     _ptr(scratch), scratch.numel(), _stream(), None if st is None else C.byref(st)), "aon_render_bwd")
+    pool_give(scratch)
     return grads
 
 
@@ -1011,6 +1050,7 @@ def art_render_bwd(ws, packs_bwd, smalls, rays_d, white_bkgd, num_levels, g_rgb,
                                         _ptr(shape), _ptr(app), _ptr(art), garr[0], garr[1], _ptr(g_lat["density"]), _ptr(g_lat["color"]),
                                         _ptr(g_lat["articulation"]), _ptr(ws), ws.numel(), _ptr(scratch), scratch.numel(), _stream(),
                                         None if st is None else C.byref(st)), "aon_art_render_bwd")
+    pool_give(scratch)
     return grads, g_lat
 
 
@@ -1209,7 +1249,9 @@ def grender_bwd(geom: MlpGeometry, ws, params_per_level, rays_d, white_bkgd, num
 def release_workspaces() -> None:
     """Drop the per-device workspace caches of the inference calls (fused path: up to 1.35 GB, or 3.3 GB with materialised
     encodings; layer-wise engine: G_WS_BUDGET_BYTES = 2 GB) back to torch's caching allocator.  They are re-made on the
-    next call; training workspaces are never cached (they belong to the autograd graph)."""
+    next call; and the pool of training workspaces / scratch buffers (`_TRAIN_POOL`: up to two of each size in use, 26 GB per pair at
+    4096 articulated rays)."""
+    _TRAIN_POOL.clear()
     _WS_CACHE.clear()
     _GWS_CACHE.clear()
     _WG_WS.clear()

@@ -112,6 +112,51 @@ def host_cpu():
         return os.cpu_count() or 1, "?"
 
 
+class GpuStateSampler:
+    """Shader clock and package power of this rank's GPU, sampled with rocm-smi about once a second WHILE a timed region runs (a host
+    thread; nothing is enqueued on the GPU).  Informational: the config-5 training loop draws ~1.25 kW at 2.39 GHz, close to the board's
+    limit, and boxes of the pool were seen running whole calls 12-14 % slower with no other difference (34.6 instead of 30.4 ms per step,
+    round 6) -- a line that carries the clock it was measured at explains itself."""
+
+    def __init__(self, index: int):
+        import threading
+
+        self.index, self.samples, self._stop = index, [], threading.Event()
+        self._thread = threading.Thread(target=self._run, daemon=True)
+
+    def _run(self):
+        import re
+        import subprocess
+
+        self._stop.wait(0.15)     # (the first sample a moment into the region, not at its idle edge)
+        while not self._stop.is_set():
+            try:
+                out = subprocess.run(["rocm-smi", "-d", str(self.index), "--showclocks", "--showpower"], capture_output=True, text=True, timeout=5).stdout
+                sclk = re.search(r"sclk clock level: \d+: \((\d+)Mhz\)", out)
+                power = re.search(r"Power \(W\): ([0-9.]+)", out)
+                if sclk:
+                    self.samples.append((int(sclk.group(1)), float(power.group(1)) if power else None))
+            except Exception:
+                return
+            self._stop.wait(0.3)
+
+    def __enter__(self):
+        self._thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop.set()
+        self._thread.join(timeout=6)
+
+    def summary(self):
+        if not self.samples:
+            return None
+        clk = sorted(c for c, _ in self.samples)
+        pw = sorted(p for _, p in self.samples if p is not None)
+        return {"samples": len(clk), "sclk_mhz_median": clk[len(clk) // 2], "sclk_mhz_min": clk[0], "sclk_mhz_max": clk[-1],
+                "power_w_median": pw[len(pw) // 2] if pw else None, "source": "rocm-smi --showclocks --showpower, ~2 samples/s during the timed region"}
+
+
 def mfma_roofline(kernel, ms, launches, samples, mac_executed, mac_literal):
     """Roofline object of an MFMA-bound kernel class from live HIP-event totals: executed and reference-literal FLOP rates."""
     if ms <= 0 or launches <= 0:
@@ -347,7 +392,7 @@ def pmc_traffic_train(kernels, launches_per_step):
         return None, None, None
 
 
-def train_leg(dev, rank, world, distributed, steps=6, n_rays=4096):
+def train_leg(dev, rank, world, distributed, steps=12, n_rays=4096):
     """Informational only (never `value`): BASELINE config 5 per GPU -- articulated NeRF_AE_Art + code library, 4096 rays,
     randomized sampling, loss of model_autodecoder.py:395-477, HIP forward+backward, ONE flat gradient all-reduce over RCCL
     when world > 1 (parallel.allreduce_gradients), Adam.  Returns a dict for the JSON line (or {"error": ...})."""
@@ -418,6 +463,8 @@ def train_leg(dev, rank, world, distributed, steps=6, n_rays=4096):
 
         # the step as the product runs it (round 4: merged launches on ONE stream -- forward coarse(A) | fine(A)+coarse(B) | fine(B), one
         # backward chain launch for both levels, then the levels' weight gradients), no kernel-class timers
+        train_state = GpuStateSampler(dev.index or 0)
+        train_state.__enter__()     # (spans the product pass and the per-class pass below: ~0.8 s of the same load)
         dt, loss, _ = timed()
         # gradient exchange as this rank saw it (HIP events; includes waiting for the slowest rank's backward), min / max over ranks
         ar = torch.tensor([sum(a.elapsed_time(b) for a, b in ar_marks[-steps:]) / steps], dtype=torch.float64, device=dev)
@@ -434,6 +481,7 @@ def train_leg(dev, rank, world, distributed, steps=6, n_rays=4096):
         finally:
             ops.set_bwd_overlap(True)
             ops.set_fwd_overlap(True)
+            train_state.__exit__(None, None, None)
         samples = n_rays * EVALS_PER_RAY
         fold = bool(ops.bottleneck_fold())
         mac_f, mac_c, mac_w = executed(ART_MAC_FWD, fold, ops.view_bias_enabled()), executed(ART_MAC_BWD_CHAIN, fold), executed(ART_MAC_WGRAD, fold)
@@ -450,7 +498,7 @@ def train_leg(dev, rank, world, distributed, steps=6, n_rays=4096):
         other_ms = sum(classes[k][0] for k in ("composite", "sample_pdf", "composite_pdf", "composite_bwd", "sample_t") if k in classes) / steps
         step_traffic, traffic_src, head_bytes = pmc_traffic_train(kernels, {k: v["launches"] / steps for k, v in kernels.items()})
         res = {"workload": f"articulated NeRF_AE_Art training step, {n_rays} rays/GPU, fwd+bwd" + (" + RCCL gradient all-reduce (6.4 MB, one bucket)" if world > 1 else "") + " + Adam (" + type(opt).__name__ + ": one launch on the parameter arena)",
-               "ms_per_step": dt * 1e3, "rays_per_s": world * n_rays / dt, "steps": steps, "loss": loss, "bottleneck_fold": fold, "view_bias": bool(ops.view_bias_enabled()),
+               "ms_per_step": dt * 1e3, "rays_per_s": world * n_rays / dt, "steps": steps, "loss": loss, "gpu_state": train_state.summary(), "bottleneck_fold": fold, "view_bias": bool(ops.view_bias_enabled()),
                "allreduce_ms": {"min": ar_all.min().item(), "max": ar_all.max().item(), "per_rank": ar_all.tolist(),
                                 "note": "parallel.allreduce_gradients per step, HIP events on the launch stream; 0 at world size 1 (no-op); "
                                         "includes the wait for the slowest rank's backward"},
@@ -548,11 +596,12 @@ def main():
         fence()
         marks.clear()
         ops.profile_begin()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            fine = step()
-        fence()
-        dt = time.perf_counter() - t0
+        with GpuStateSampler(local_rank) as gpu_state:
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                fine = step()
+            fence()
+            dt = time.perf_counter() - t0
         mlp_ms, mlp_launches, mlp_samples = ops.profile_end()
         headline_classes = ops.profile_classes()
 
@@ -672,6 +721,7 @@ def main():
                        "rays_per_gpu": n_rays, "evals_per_ray": EVALS_PER_RAY,
                        "exchange": "RCCL all_gather of (rgb,acc,depth)=20 B/ray" if world > 1 else "none"},
             "multi_gpu": diag,
+            "gpu_state": gpu_state.summary(),
             "bottleneck_fold": fold,
             "view_bias": bool(ops.view_bias_enabled()),
             "roofline": {"bound": "mfma", "kernel": "aon::mlp_fwd_kernel<true,false,fold,view-bias> (fused encode+MLP, fp32 MFMA)",

@@ -28,6 +28,9 @@ def main():
     ap.add_argument("--late-heads", action="store_true", help="every head reduction behind the chain (round 4) instead of the chain-independent ones beside it")
     ap.add_argument("--articulated", action="store_true", help="NeRF_AE_Art + CodeLibraryArticulated (BASELINE config 5 per GPU)")
     ap.add_argument("--foreach-adam", action="store_true", help="torch.optim.Adam's default foreach form instead of fused=True (the harness's choice on a GPU in round 5)")
+    ap.add_argument("--classes", action="store_true", help="a second timed loop with the library's per-kernel-class HIP-event timers on: ms per step of forward / chain / weight gradients")
+    ap.add_argument("--exchange", action="store_true", help="run parallel.allreduce_gradients(force=True) every step under a world-size-1 RCCL group: the fixed cost of the "
+                                                             "data-parallel exchange (in place on the arena; with --torch-adam: the round-5 bucket with its 2 x 83-tensor copies)")
     ap.add_argument("--torch-adam", action="store_true", help="torch.optim.Adam (fused unless --foreach-adam) instead of the parameter arena + ArenaAdam the harness builds since round 6")
     args = ap.parse_args()
     import aon_amd.synthetic as syn
@@ -77,6 +80,21 @@ def main():
     rays = {"rays_o": ro[idx].contiguous(), "rays_d": vd[idx].contiguous(), "viewdirs": vd[idx].contiguous()}
     target = torch.rand(args.rays, 3, device=dev, generator=g)
 
+    exchange = None
+    if args.exchange:
+        import socket
+
+        import torch.distributed as dist
+        from aon_amd.parallel import allreduce_gradients
+
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        both = torch.nn.ModuleList([model] + ([lib] if lib is not None else []))
+        exchange = lambda: allreduce_gradients(both, force=True)   # noqa: E731
+
     def step():
         opt.zero_grad(set_to_none=True)
         if lib is not None:
@@ -92,21 +110,49 @@ def main():
         else:
             loss, _ = train_loss(out, target, codes, 1e-4)   # the harness's loss lines in two launches (helper.train_loss)
         loss.backward()
+        if exchange is not None:
+            exchange()
         opt.step()
         return loss
 
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
+    st0 = torch.cuda.memory_stats()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    host_ms = []
+    marks[0].record()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        th = time.perf_counter()
         loss = step()
+        host_ms.append((time.perf_counter() - th) * 1e3)
+        marks[i + 1].record()
     enqueue_ms = (time.perf_counter() - t0) / args.steps * 1e3   # host time to ENQUEUE a step (the device runs behind): must stay well below ms_per_step
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.steps
+    classes = None
+    if args.classes:
+        ops.profile_begin()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        dt2 = (time.perf_counter() - t1) / args.steps
+        ops.profile_end()
+        classes = {k: round(v[0] / args.steps, 3) for k, v in ops.profile_classes().items() if v[1]}
+        classes["step_ms_with_timers"] = round(dt2 * 1e3, 3)
+    st1 = torch.cuda.memory_stats()
+    alloc = {"device_mallocs_in_timed_loop": st1.get("num_device_alloc", 0) - st0.get("num_device_alloc", 0),
+             "device_frees_in_timed_loop": st1.get("num_device_free", 0) - st0.get("num_device_free", 0),
+             "reserved_GB": round(st1.get("reserved_bytes.all.current", 0) / 2 ** 30, 2), "reserved_GB_before": round(st0.get("reserved_bytes.all.current", 0) / 2 ** 30, 2)}
+    per_step = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]   # device time between the ends of consecutive steps
+    worst = max(range(args.steps), key=lambda i: per_step[i])
     flop = args.rays * 258 * (1_589_760 if args.articulated else 1_186_816) * 3  # fwd + 2x bwd, reference-literal
-    print(json.dumps({"model": "articulated" if args.articulated else "vanilla", "rays_per_step": args.rays, "ms_per_step": dt * 1e3, "host_enqueue_ms_per_step": enqueue_ms, "optimizer": type(opt).__name__ + ("" if type(opt).__name__ == "ArenaAdam" else (" foreach" if args.foreach_adam else " fused")), "rays_per_s": args.rays / dt,
-                      "train_tflops_3x_fwd": flop / dt / 1e12, "loss": loss.item()}))
+    print(json.dumps({"model": "articulated" if args.articulated else "vanilla", "rays_per_step": args.rays, "ms_per_step": dt * 1e3, "host_enqueue_ms_per_step": enqueue_ms, "exchange": bool(args.exchange), "optimizer": type(opt).__name__ + ("" if type(opt).__name__ == "ArenaAdam" else (" foreach" if args.foreach_adam else " fused")), "rays_per_s": args.rays / dt,
+                      "train_tflops_3x_fwd": flop / dt / 1e12, "loss": loss.item(), "allocator": alloc,
+                      "step_ms_device": {"median": sorted(per_step)[len(per_step) // 2], "max": per_step[worst], "argmax": worst, "host_ms_of_that_step": host_ms[worst],
+                                         "host_ms_max": max(host_ms), "host_argmax": max(range(args.steps), key=lambda i: host_ms[i])}, **({"classes_ms_per_step": classes} if classes else {})}))
 
 
 if __name__ == "__main__":
