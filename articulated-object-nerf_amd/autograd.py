@@ -163,6 +163,7 @@ class RenderGeneral(torch.autograd.Function):
         per_level = ops.grender_bwd(ctx.geom, ctx.ws, params, ctx.rays_d, ctx.white_bkgd, ctx.num_levels, g_rgb,
                                     [gouts[3 * l + 1] for l in range(ctx.num_levels)], [gouts[3 * l + 2] for l in range(ctx.num_levels)],
                                     ctx.geometry)
+        ops.pool_give(ctx.ws)
         ctx.ws, ctx.released, ctx.geometry = None, True, None
         return (None,) * 12 + tuple(g[name] for g in per_level for name in ctx.geom.param_order)
 

@@ -1213,7 +1213,7 @@ def grender_fwd_train(geom: MlpGeometry, params_c: dict, params_f, rays_o, rays_
     gst = geom.c_struct()
     tc, arr_c = _gmlp_param_array(geom, params_c)
     tf, arr_f = _gmlp_param_array(geom, params_f) if num_levels == 2 else (None, None)
-    ws = _sized(int(lib.aon_grender_train_workspace_bytes(C.byref(gst), n, num_levels, C.byref(st))), "aon_grender_train_workspace_bytes", dev)
+    ws = _pool_take(int(lib.aon_grender_train_workspace_bytes(C.byref(gst), n, num_levels, C.byref(st))), "aon_grender_train_workspace_bytes", dev)   # (pooled: see _TRAIN_POOL)
     with torch.cuda.device(dev):
         check(lib.aon_grender_fwd_train(C.byref(gst), arr_c, arr_f, _ptr(o), _ptr(d), _ptr(v), n, float(near), float(far), int(bool(white_bkgd)),
                                         num_levels, _ptr(tr), _ptr(uu), us, _ptr(outs[0][0]), _ptr(outs[0][1]), _ptr(outs[0][2]), _ptr(fine[0]),
@@ -1238,11 +1238,12 @@ def grender_bwd(geom: MlpGeometry, ws, params_per_level, rays_d, white_bkgd, num
     keep = [None if t is None else _f32(t, "grad") for t in list(g_rgb) + list(g_acc) + list(g_depth)]
     k = num_levels
     st = geometry[0]
-    scratch = _sized(int(lib.aon_grender_train_scratch_bytes(C.byref(gst), n, num_levels, C.byref(st))), "aon_grender_train_scratch_bytes", dev)
+    scratch = _pool_take(int(lib.aon_grender_train_scratch_bytes(C.byref(gst), n, num_levels, C.byref(st))), "aon_grender_train_scratch_bytes", dev)
     with torch.cuda.device(dev):
         check(lib.aon_grender_bwd(C.byref(gst), parr[0], parr[1], _ptr(d), n, int(bool(white_bkgd)), num_levels, _ptr_array(keep[:k]),
                                   _ptr_array(keep[k:2 * k]), _ptr_array(keep[2 * k:3 * k]), garr[0], garr[1], _ptr(ws), ws.numel(), _ptr(scratch),
                                   scratch.numel(), _stream(), C.byref(st)), "aon_grender_bwd")
+    pool_give(scratch)
     return grads
 
 

@@ -369,3 +369,57 @@ def test_arena_sweep_constructor_arguments(dev, seed):
     assert opt.last_launches == 1
     for (k, pa), pr in zip(m.named_parameters(), plain_m.parameters()):
         assert (pa - pr).abs().max().item() <= 4e-7 * (pr.abs().max().item() + 1e-12), k
+
+
+def test_training_buffers_are_pooled(dev):
+    """ops._TRAIN_POOL (round 6): the forward -> backward workspace and the backward's scratch are not handed back to torch's caching allocator
+    between steps -- the reserved memory of a training loop is flat after its first step (through the allocator, a full-size request that found
+    its block carved up went to hipMalloc inside a step: 80-125 ms, `profiles/r06_slowmode.txt`) --, two live graphs never share a workspace,
+    and release_workspaces() drops the pool."""
+    from aon_amd import ops
+
+    model, lib, rays, target, draws, ids = _art_setup(dev, n=512)
+    r2 = {k: v.repeat(1, 1) for k, v in rays.items()}
+    d2 = (draws[0].repeat(3, 1)[:512], draws[1].repeat(3, 1)[:512])
+    tg = target.repeat(3, 1)[:512]
+    ops.release_workspaces()
+    assert not ops._TRAIN_POOL
+
+    def step():
+        for p in list(model.parameters()) + list(lib.parameters()):
+            p.grad = None
+        _art_step(model, lib, r2, tg, d2, ids)
+
+    step()
+    step()
+    torch.cuda.synchronize()
+    keys = {k: len(v) for k, v in ops._TRAIN_POOL.items()}
+    assert len(keys) == 2 and all(n == 1 for n in keys.values()), keys          # one workspace, one scratch, both back in the pool
+    ptrs = sorted(t.data_ptr() for v in ops._TRAIN_POOL.values() for t, _ in v)
+    reserved = torch.cuda.memory_stats()["reserved_bytes.all.current"]
+    mallocs = torch.cuda.memory_stats()["num_device_alloc"]
+    for _ in range(6):
+        step()
+    torch.cuda.synchronize()
+    assert sorted(t.data_ptr() for v in ops._TRAIN_POOL.values() for t, _ in v) == ptrs     # the same two buffers, step after step
+    grown = torch.cuda.memory_stats()["reserved_bytes.all.current"] - reserved
+    assert grown <= 64 << 20, (grown, torch.cuda.memory_stats()["num_device_alloc"] - mallocs)
+    # two live graphs: the second forward must not get the first one's workspace
+    for p in list(model.parameters()) + list(lib.parameters()):
+        p.grad = None
+    lat = lib(ids)
+    out_a = model(r2, True, True, 2.0, 6.0, lat, t_rand=d2[0], u=d2[1])
+    out_b = model(r2, True, True, 2.0, 6.0, lat, t_rand=d2[0], u=d2[1])
+    assert torch.equal(out_a[1][0], out_b[1][0])
+    (out_a[1][0].sum() + out_b[1][0].sum()).backward()
+    torch.cuda.synchronize()
+    assert all(len(v) <= 2 for v in ops._TRAIN_POOL.values())
+    ga = {k: p.grad.clone() for k, p in model.named_parameters()}
+    for p in list(model.parameters()) + list(lib.parameters()):
+        p.grad = None
+    out_c = model(r2, True, True, 2.0, 6.0, lib(ids), t_rand=d2[0], u=d2[1])
+    (2.0 * out_c[1][0].sum()).backward()
+    for k, p in model.named_parameters():
+        assert torch.equal(p.grad, ga[k]), k     # (a + a against 2a: exact in fp32, and the backward is exactly linear in the upstream gradient)
+    ops.release_workspaces()
+    assert not ops._TRAIN_POOL
