@@ -901,8 +901,12 @@ def set_fwd_merge(on: bool) -> None:
 # reserved INSIDE the timed loop of every run of tools/train_bench.py; when the stall fell on an early step the device ran dry and the run
 # averaged 33-40 ms per step instead of 30.4, tools/slowmode_probe.sh).  A pooled buffer is only handed to the stream it was returned on;
 # at most two per (device, size) are kept; release_workspaces() drops them.
-_TRAIN_POOL: dict = {}
-_TRAIN_POOL_KEEP = 2
+import collections as _collections
+
+_TRAIN_POOL: "_collections.OrderedDict" = _collections.OrderedDict()
+_TRAIN_POOL_KEEP = 2          # buffers kept per (device, size)
+_TRAIN_POOL_SIZES = 6         # distinct (device, size) keys kept, least recently returned dropped first (a loop whose ray count changes every
+                              # step must not pile up buffers: workspace + scratch of the full batch and of an epoch's tail batch are four keys)
 
 
 def _pool_take(nbytes: int, what: str, device) -> torch.Tensor:
@@ -911,8 +915,10 @@ def _pool_take(nbytes: int, what: str, device) -> torch.Tensor:
     dev = torch.device(device)
     if dev.type == "cuda":
         stream = torch.cuda.current_stream(dev).cuda_stream
-        free = _TRAIN_POOL.get((dev.index if dev.index is not None else torch.cuda.current_device(), nbytes))
+        key = (dev.index if dev.index is not None else torch.cuda.current_device(), nbytes)
+        free = _TRAIN_POOL.get(key)
         if free:
+            _TRAIN_POOL.move_to_end(key)
             for i, (t, s) in enumerate(free):
                 if s == stream:
                     del free[i]
@@ -927,8 +933,11 @@ def pool_give(t) -> None:
         return
     key = (t.device.index, t.numel())
     free = _TRAIN_POOL.setdefault(key, [])
+    _TRAIN_POOL.move_to_end(key)
     if len(free) < _TRAIN_POOL_KEEP:
         free.append((t, torch.cuda.current_stream(t.device).cuda_stream))
+    while len(_TRAIN_POOL) > _TRAIN_POOL_SIZES:
+        _TRAIN_POOL.popitem(last=False)
 
 
 def train_workspace(device, n_rays: int, articulated: bool, num_levels: int = 2, st=None) -> torch.Tensor:

@@ -423,3 +423,11 @@ def test_training_buffers_are_pooled(dev):
         assert torch.equal(p.grad, ga[k]), k     # (a + a against 2a: exact in fp32, and the backward is exactly linear in the upstream gradient)
     ops.release_workspaces()
     assert not ops._TRAIN_POOL
+    # a loop whose batch size changes every step must not pile buffers up: at most _TRAIN_POOL_SIZES distinct sizes are kept
+    for n in (64, 96, 128, 160, 192, 224, 256, 288):
+        for p in list(model.parameters()) + list(lib.parameters()):
+            p.grad = None
+        o = model({k: v[:n] for k, v in r2.items()}, True, True, 2.0, 6.0, lib(ids), t_rand=d2[0][:n], u=d2[1][:n])
+        o[1][0].sum().backward()
+    assert len(ops._TRAIN_POOL) <= ops._TRAIN_POOL_SIZES
+    ops.release_workspaces()
