@@ -1507,7 +1507,15 @@ int aon_art_render_bwd_ex(const void* packed_bwd_coarse, const void* small_coars
   };
   // Round 4: the two levels' chains as ONE persistent launch of two segments on the caller's stream (see aon_render_bwd_ex)
   const bool merged = num_levels == 2 && g_bwd_merge.load(std::memory_order_relaxed) != 0;
-  const int overlap_mode = g_bwd_overlap.load(std::memory_order_relaxed);   // 0: none; 1: round-3 level streams when not merged; 2: + head reductions on side streams when merged
+  // 0: none; 1: round-3 level streams when not merged; 2: + head reductions on side streams when merged.  ARTICULATED network, round 6: mode 1
+  // means mode 2 here -- each level's remaining head reductions (six jobs, 70 + 185 us, HBM-bound ordinary blocks) go onto the level's aux
+  // stream just BEFORE its grouped kernel and run beside it instead of in front of it: 30.418 -> 30.309 ms per 4096-ray step over eight
+  // alternating runs each (all eight below all eight), same bits (tools/grad_hash.py).  Round 4 had measured this form slower (34.5 vs 34.1 ms,
+  // profiles/r04_backward_schedules.txt; the kernels have changed since); the vanilla network's three head jobs gain nothing (24.446 vs
+  // 24.423 ms) and keep mode 1.  AON_ART_AUX_HEADS=0 in the environment: mode 1 as before (A/B).
+  static const bool art_aux_heads = [] { const char* e = std::getenv("AON_ART_AUX_HEADS"); return !(e && e[0] == '0'); }();
+  const int overlap_raw = g_bwd_overlap.load(std::memory_order_relaxed);
+  const int overlap_mode = (overlap_raw == 1 && art_aux_heads) ? 2 : overlap_raw;
   const bool early_heads = merged && g_bwd_early_heads.load(std::memory_order_relaxed) != 0;
   // fork: see aon_render_bwd_ex (merged: no level streams; the chain's last, quarter-full round takes the early head reductions on a side stream)
   LevelFork fork(num_levels == 2 && (merged ? (overlap_mode == 2 || early_heads) : overlap_mode != 0), caller, "aon_art_render_bwd", merged);

@@ -341,8 +341,10 @@ int aon_art_wgrad_deg(const float* planes, const float* dplanes, const float* d_
  * level's kernels fill the CUs the other's tail rounds leave idle; both are ordered after everything already enqueued on
  * `stream` and `stream` continues only after both (events) -- from the caller's view the call is enqueued on `stream`.
  * aon_set_bwd_overlap(0) keeps everything on `stream` (default 1).  The level streams are only used when the merged chain launch is off
- * (aon_set_bwd_merge(0)); 2 (measurements) additionally puts the head reductions of the merged form on side streams (slower: measured
- * 34.5 against 34.1 ms per step, profiles/r04_backward_schedules.txt). */
+ * (aon_set_bwd_merge(0)); 2 additionally puts the head reductions of the merged form on side streams beside each level's grouped
+ * weight-gradient kernel (round 4 measured it slower, 34.5 against 34.1 ms per step, profiles/r04_backward_schedules.txt; round 6, with
+ * today's kernels: 30.31 against 30.42 ms for the ARTICULATED network -- whose calls therefore treat 1 as 2 -- and no gain for the vanilla
+ * one, which keeps 1). */
 int aon_set_bwd_overlap(int on);
 /* Likewise the training FORWARD of two levels runs two ray halves (split on a multiple of 128 rays) on the two library streams: a
  * half's levels depend on each other only through its own inverse CDF, so one half's fine level fills the CUs the other half's
