@@ -118,10 +118,10 @@ class GpuStateSampler:
     limit, and boxes of the pool were seen running whole calls 12-14 % slower with no other difference (34.6 instead of 30.4 ms per step,
     round 6) -- a line that carries the clock it was measured at explains itself."""
 
-    def __init__(self, index: int):
+    def __init__(self, index: int, enabled: bool = True):
         import threading
 
-        self.index, self.samples, self._stop = index, [], threading.Event()
+        self.index, self.samples, self._stop, self.enabled = index, [], threading.Event(), enabled     # (rank 0 only: one sampler per node)
         self._thread = threading.Thread(target=self._run, daemon=True)
 
     def _run(self):
@@ -141,12 +141,14 @@ class GpuStateSampler:
             self._stop.wait(0.3)
 
     def __enter__(self):
-        self._thread.start()
+        if self.enabled:
+            self._thread.start()
         return self
 
     def __exit__(self, *exc):
         self._stop.set()
-        self._thread.join(timeout=6)
+        if self.enabled:
+            self._thread.join(timeout=6)
 
     def summary(self):
         if not self.samples:
@@ -463,7 +465,7 @@ def train_leg(dev, rank, world, distributed, steps=12, n_rays=4096):
 
         # the step as the product runs it (round 4: merged launches on ONE stream -- forward coarse(A) | fine(A)+coarse(B) | fine(B), one
         # backward chain launch for both levels, then the levels' weight gradients), no kernel-class timers
-        train_state = GpuStateSampler(dev.index or 0)
+        train_state = GpuStateSampler(dev.index or 0, enabled=rank == 0)
         train_state.__enter__()     # (spans the product pass and the per-class pass below: ~0.8 s of the same load)
         dt, loss, _ = timed()
         # gradient exchange as this rank saw it (HIP events; includes waiting for the slowest rank's backward), min / max over ranks
@@ -596,7 +598,7 @@ def main():
         fence()
         marks.clear()
         ops.profile_begin()
-        with GpuStateSampler(local_rank) as gpu_state:
+        with GpuStateSampler(local_rank, enabled=rank == 0) as gpu_state:
             t0 = time.perf_counter()
             for _ in range(args.steps):
                 fine = step()
