@@ -431,3 +431,23 @@ def test_training_buffers_are_pooled(dev):
         o[1][0].sum().backward()
     assert len(ops._TRAIN_POOL) <= ops._TRAIN_POOL_SIZES
     ops.release_workspaces()
+
+
+def test_gradient_bits_are_pinned(dev):
+    """Every gradient tensor of the articulated config-5 step and of the vanilla step on 4096 seeded rays (131 tensors + the two losses),
+    hashed (tools/grad_hash.py) and held to tests/golden/g24_gradient_hashes.json: the kernels are deterministic, so ANY change that moves a
+    bit of a gradient shows here -- schedule changes (side streams, launch merges, load batching) must not, arithmetic changes update the file
+    on purpose (`python tools/grad_hash.py --write`)."""
+    import json
+    import os
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import grad_hash
+
+    want = json.load(open(os.path.join(root, "tests", "golden", "g24_gradient_hashes.json")))
+    got = dict(grad_hash.hashes(int(want["n_rays"])))
+    assert set(got) == set(want["hashes"])
+    moved = [k for k in got if got[k] != want["hashes"][k]]
+    assert not moved, f"{len(moved)} of {len(got)} tensors changed bits: {moved[:6]}"

@@ -16,7 +16,27 @@ def h(t):
     return hashlib.sha256(t.detach().cpu().contiguous().numpy().tobytes()).hexdigest()[:16]
 
 
+def hashes(n=4096):
+    """-> ordered list of (label, 16-hex-digit hash) for the articulated and the vanilla step on n seeded rays."""
+    out = []
+    _run(n, lambda *a: out.append((" ".join(a[:-1]), a[-1])))
+    return out
+
+
 def main():
+    if "--write" in sys.argv:     # tests/golden/g24_gradient_hashes.json (tests/test_hip_arena.py::test_gradient_bits_are_pinned)
+        import json
+
+        path = os.path.join(ROOT, "tests", "golden", "g24_gradient_hashes.json")
+        json.dump({"n_rays": 4096, "note": "sha256[:16] of every gradient of the seeded articulated / vanilla 4096-ray steps on gfx950 (tools/grad_hash.py)",
+                   "hashes": dict(hashes(4096))}, open(path, "w"), indent=0)
+        print("wrote", path)
+        return
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+    _run(n, lambda *a: print(*a))
+
+
+def _run(n, emit):
     import aon_amd.synthetic as syn
     from aon_amd.models.code_library import CodeLibraryArticulated
     from aon_amd.models.vanilla_nerf.helper import train_loss
@@ -24,7 +44,6 @@ def main():
     from aon_amd.models.vanilla_nerf.model_autodecoder import NeRF_AE_Art
 
     dev = torch.device("cuda:0")
-    n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
     rays = {k: v.to(dev) for k, v in syn.random_rays(n, seed=11).items()}
     target = syn.seeded_uniform(12, n, 3).to(dev)
     tr, u = syn.seeded_uniform(13, n, 65).to(dev), syn.seeded_uniform(14, n, 128).to(dev)
@@ -36,17 +55,17 @@ def main():
     out = model(rays, True, True, 2.0, 6.0, lat, t_rand=tr, u=u)
     loss, _ = train_loss(out, target, (lat["density"], lat["color"], lat["articulation"]), 1e-4)
     loss.backward()
-    print("art loss", h(loss))
+    emit("art loss", h(loss))
     for k, p in list(model.named_parameters()) + [("lib." + k, p) for k, p in lib.named_parameters()]:
-        print("art", k, h(p.grad))
+        emit("art", k, h(p.grad))
     van = NeRF().to(dev)
     van.load_state_dict(syn.make_nerf_state_dict(seed=0, density_scale=30.0))
     out = van(rays, True, True, 2.0, 6.0, t_rand=tr, u=u)
     loss, _ = train_loss(out, target)
     loss.backward()
-    print("van loss", h(loss))
+    emit("van loss", h(loss))
     for k, p in van.named_parameters():
-        print("van", k, h(p.grad))
+        emit("van", k, h(p.grad))
 
 
 if __name__ == "__main__":
