@@ -1,6 +1,8 @@
 #!/bin/bash
-# Round 6: some boxes of the pool run the config-5 step in a SLOW MODE (33.6-36.5 ms instead of 30.4) for whole processes at a time.  This probe
-# runs the default step twice; on a box that shows the slow mode it runs a matrix of switches to find what it depends on.
+# Round 6: on some boxes of the pool whole processes ran the config-5 step at 33.6-42 ms instead of 30.4.  This probe runs the step four
+# times; if a run is slow it prints, per process, the longest HOST step and the allocator's activity inside the timed loop -- which is
+# what showed the cause (one hipMalloc of the 11-15 GB training buffers inside a step; fixed by ops._TRAIN_POOL: profiles/r06_slowmode.txt).
+# Kept as the regression probe: with the pool no run should be slow and "device_mallocs_in_timed_loop" should only count 20 MB segments.
 #   gpurun -- 'bash tools/slowmode_probe.sh'
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 run() { env "$@" python $REPO/tools/train_bench.py --articulated --rays 4096 --steps 30 $FL 2>/dev/null | grep "^{" | python -c "import sys,json; print(round(json.loads(sys.stdin.read())['ms_per_step'],3))"; }
