@@ -19,7 +19,9 @@ hipError_t launch_mlp_fwd(const char* packed, const float* rays_o, const float* 
 hipError_t launch_view_bias(const char* packed, const float* viewdirs, int64_t n_rays, float* out, hipStream_t stream);
 hipError_t launch_mlp_fwd_enc(const char* packed, const float* samples_enc, const float* viewdirs_enc, int64_t n_rays,
                               int S, float* raw, hipStream_t stream);
-hipError_t launch_pack_art(const float* const* params, float* packed, hipStream_t stream, int pos_levels = 10, int view_levels = 4);
+hipError_t launch_pack_art(const float* const* params, float* packed, hipStream_t stream, int pos_levels = 10, int view_levels = 4, bool fold_done = false);
+FoldGemm art_fold_job_fwd(const float* const* params, float* packed, int view_levels);
+FoldGemm art_fold_job_bwd(const float* const* params, float* packed, int view_levels);
 hipError_t launch_prepare_art(const float* const* params, const float* shape, const float* app, const float* art,
                               float* small, hipStream_t stream, int min_deg = 0, int pos_levels = 10, int view_levels = 4);
 hipError_t launch_art_mlp_fwd(const char* packed, const float* small, const float* rays_o, const float* rays_d,
@@ -60,7 +62,7 @@ hipError_t launch_art_mlp_fwd_train(const char* packed, const float* small, cons
 hipError_t launch_art_mlp_fwd_train2(const TrainSeg* segs, int nsegs, hipStream_t stream);
 hipError_t launch_mlp_fwd_train2(const TrainSeg* segs, int nsegs, hipStream_t stream);
 int num_cus();
-hipError_t launch_pack_art_bwd(const float* const* params, float* packed, hipStream_t stream, int pos_levels = 10, int view_levels = 4);
+hipError_t launch_pack_art_bwd(const float* const* params, float* packed, hipStream_t stream, int pos_levels = 10, int view_levels = 4, bool fold_done = false);
 int64_t art_bwd_stream_bytes();
 hipError_t launch_art_bwd_chain(const char* packed_bwd, const float* small, const float* d_raw, const void* masks, const float* planes,
                                 float* dplanes, float* dxp, int64_t Np, hipStream_t stream);
@@ -1541,6 +1543,7 @@ int aon_art_render_bwd_ex(const void* packed_bwd_coarse, const void* small_coars
                                        sc.wgrad_ws[l], st, aux, g.max_deg - g.min_deg, g.deg_view, pb[l], phase, acc,
                                        (post_side && phase != kWgEarly) ? (l == 0 ? &post0 : &post1) : nullptr), "aon_art_render_bwd");
   };
+  bool early_unjoined = false;   // (the early reductions are on the side stream and the caller's stream has not been told to wait for them)
   if (merged) {
     for (int l = 0; l < 2; ++l)
       if (int rc = composite_bwd(l, caller)) return rc;
@@ -1555,7 +1558,15 @@ int aon_art_render_bwd_ex(const void* packed_bwd_coarse, const void* small_coars
       int rc = check(hipStreamWaitEvent(side->stream, side->fork, 0), "aon_art_render_bwd");
       for (int l = 0; l < 2 && !rc; ++l) rc = level_wgrad(l, side->stream, nullptr, kWgEarly);
       const int rj = check(hipEventRecord(side->join, side->stream), "aon_art_render_bwd");
-      const int rw = check(hipStreamWaitEvent(caller, side->join, 0), "aon_art_render_bwd");
+      // Who waits for the early reductions: nobody needs their partial sums before level 0's SECOND stage (wgrad_reduce), and in overlap
+      // mode 2 that stage already waits for this very stream -- level 0's remaining reductions are queued on it (aux(0) == side), behind
+      // the early ones, and run_wgrad_plan joins it in front of the second stage.  So the caller's stream does not wait here: level 0's
+      // grouped kernel follows the chain directly instead of sitting out the early reductions' tail (~90 us past the chain's end, plus the
+      // event round trip).  Mode 1 (remaining reductions on the caller's stream, no later join): waits here as before.
+      // AON_EARLY_JOIN=1 in the environment: wait here in mode 2 as well (A/B).
+      static const bool join_here = [] { const char* e = std::getenv("AON_EARLY_JOIN"); return e && e[0] == '1'; }();
+      early_unjoined = overlap_mode == 2 && !join_here && !rc && !rj;
+      const int rw = early_unjoined ? AON_OK : check(hipStreamWaitEvent(caller, side->join, 0), "aon_art_render_bwd");
       if (rc || rj || rw) return rc ? rc : (rj ? rj : rw);
     }
   }
@@ -1574,7 +1585,13 @@ int aon_art_render_bwd_ex(const void* packed_bwd_coarse, const void* small_coars
       KTimer timer(kWgrad, stream, L.Np);
       rc = level_wgrad(l, stream, (merged && overlap_mode != 2) ? nullptr : fork.aux(l), side ? kWgRest : kWgAll);
     }
-    if (rc) return rc;
+    if (rc) {
+      // level 0's call failed before it joined the side stream (a refused plan): the early reductions are still un-joined -- never leave
+      // side-stream work behind the caller's view of this call (the workspace is the caller's to free)
+      if (early_unjoined) (void)hipStreamWaitEvent(caller, side->join, 0);
+      return rc;
+    }
+    early_unjoined = false;   // (run_wgrad_plan joined aux(0) == the early reductions' stream in front of level 0's second stage)
   }
   if (int rc = fork.join()) return rc;   // the caller's stream continues after both levels
   if (num_levels == 2 && !merged) {
@@ -1616,6 +1633,45 @@ int aon_art_prepare_deg(const float* const* params_host, const float* shape, con
   if (reinterpret_cast<uintptr_t>(small) & 15) return fail(AON_E_INVALID, "aon_art_prepare: small must be 16-byte aligned");
   return check(aon::launch_prepare_art(params_host, shape, appearance, articulation, static_cast<float*>(small), (hipStream_t)stream, min_deg_point,
                                        max_deg_point - min_deg_point, deg_view), "aon_art_prepare");
+}
+
+// Round 6: everything a training step of a TWO-level articulated model packs, in one call -- both networks' forward streams, per-call blocks
+// and transposed streams -- with the four 128 x 256 x 256 fp64 products (W' of each network, once for its forward and once for its transposed
+// stream) as ONE launch in front instead of four launches of 17 us each in a row with their pack kernels (the step's prologue: 174 -> ~115 us).
+// The same kernels on the same operands as the six separate calls: same bytes in every buffer.  packed_bwd_* may be NULL (no backward wanted).
+int aon_art_pack_step(const float* const* params_coarse_host, const float* const* params_fine_host, const float* shape, const float* appearance,
+                      const float* articulation, int min_deg_point, int max_deg_point, int deg_view, void* packed_coarse, void* small_coarse,
+                      void* packed_bwd_coarse, void* packed_fine, void* small_fine, void* packed_bwd_fine, void* stream_) {
+  if (const char* bad = art_degrees_ok(min_deg_point, max_deg_point, deg_view)) return fail(AON_E_INVALID, bad);
+  if (!params_coarse_host || !params_fine_host || !shape || !appearance || !articulation || !packed_coarse || !small_coarse || !packed_fine || !small_fine)
+    return fail(AON_E_INVALID, "aon_art_pack_step: null pointer");
+  for (int i = 0; i < 40; ++i)
+    if (!params_coarse_host[i] || !params_fine_host[i]) return fail(AON_E_INVALID, "aon_art_pack_step: null parameter pointer");
+  for (const void* p : {(const void*)packed_coarse, (const void*)small_coarse, (const void*)packed_fine, (const void*)small_fine, (const void*)packed_bwd_coarse, (const void*)packed_bwd_fine})
+    if (reinterpret_cast<uintptr_t>(p) & 15) return fail(AON_E_INVALID, "aon_art_pack_step: buffers must be 16-byte aligned");
+  hipStream_t stream = (hipStream_t)stream_;
+  const int Lp = max_deg_point - min_deg_point, Lv = deg_view;
+  const float* const* P[2] = {params_coarse_host, params_fine_host};
+  float* fwd[2] = {static_cast<float*>(packed_coarse), static_cast<float*>(packed_fine)};
+  float* sm[2] = {static_cast<float*>(small_coarse), static_cast<float*>(small_fine)};
+  float* bwd[2] = {static_cast<float*>(packed_bwd_coarse), static_cast<float*>(packed_bwd_fine)};
+  const bool folded = aon::fold_default() == aon::kFormFolded;
+  if (folded) {
+    aon::FoldGemm jobs[4];
+    int n = 0;
+    for (int l = 0; l < 2; ++l) jobs[n++] = aon::art_fold_job_fwd(P[l], fwd[l], Lv);
+    for (int l = 0; l < 2; ++l)
+      if (bwd[l]) jobs[n++] = aon::art_fold_job_bwd(P[l], bwd[l], Lv);
+    if (int rc = check(aon::launch_fold_gemms(jobs, n, stream), "aon_art_pack_step")) return rc;
+  }
+  for (int l = 0; l < 2; ++l) {
+    if (int rc = check(aon::launch_prepare_art(P[l], shape, appearance, articulation, sm[l], stream, min_deg_point, Lp, Lv), "aon_art_pack_step")) return rc;
+    if (int rc = check(aon::launch_pack_art(P[l], fwd[l], stream, Lp, Lv, folded), "aon_art_pack_step")) return rc;
+  }
+  for (int l = 0; l < 2; ++l)
+    if (bwd[l])
+      if (int rc = check(aon::launch_pack_art_bwd(P[l], bwd[l], stream, Lp, Lv, folded), "aon_art_pack_step")) return rc;
+  return AON_OK;
 }
 
 int aon_art_mlp_fwd(const void* packed, const void* small, const float* rays_o, const float* rays_d, const float* viewdirs,

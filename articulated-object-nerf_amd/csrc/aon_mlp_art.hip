@@ -421,16 +421,22 @@ __global__ void __launch_bounds__(256) art_mlp_fwd_kernel(ArtMlpArgs args) {
 // host launchers
 // ---------------------------------------------------------------------------------------------
 // The form packed is the process default at the time of the call (aon_set_bottleneck_fold), remembered for `packed` (stream_form).
-hipError_t launch_pack_art(const float* const* params, float* packed, hipStream_t stream, int pos_levels, int view_levels) {
+// W' = W_v0[:, :256] W_b of one network into the fold area of its forward stream (the job launch_pack_art runs unless told it has been run)
+FoldGemm art_fold_job_fwd(const float* const* params, float* packed, int view_levels) {
+  // (b' is the per-call block's business: prepare_art_kernel; the 128 floats it would take here are not written)
+  return FoldGemm{params[26], 256 + 3 + 6 * view_levels + 128, 1, params[34], 256, 1, packed + kAFoldTmpOff / 4, 256, 128, 256, 256, nullptr, nullptr};
+}
+
+hipError_t launch_pack_art(const float* const* params, float* packed, hipStream_t stream, int pos_levels, int view_levels, bool fold_done) {
   ArtPackArgs a;
   for (int i = 0; i < kNumArtParams; ++i) a.p[i] = params[i];
   const int form = fold_default();
   set_stream_form(packed, form);
   if (form == kFormFolded) {
-    float* Wf = packed + kAFoldTmpOff / 4;
-    // (b' is the per-call block's business: prepare_art_kernel; the 128 floats it would take here are not written)
-    const FoldGemm job{params[26], 256 + 3 + 6 * view_levels + 128, 1, params[34], 256, 1, Wf, 256, 128, 256, 256, nullptr, nullptr};
-    if (hipError_t e = launch_fold_gemms(&job, 1, stream); e != hipSuccess) return e;
+    if (!fold_done) {   // (aon_art_pack_step runs the products of both networks and both directions as ONE launch in front)
+      const FoldGemm job = art_fold_job_fwd(params, packed, view_levels);
+      if (hipError_t e = launch_fold_gemms(&job, 1, stream); e != hipSuccess) return e;
+    }
     const int64_t n = kAStreamBytesF / 4;
     pack_art_kernel<true><<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream>>>(a, packed, pos_levels, view_levels);
   } else {

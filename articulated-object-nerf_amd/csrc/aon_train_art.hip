@@ -399,14 +399,20 @@ __global__ void __launch_bounds__(1024) art_finish_kernel(ArtFinishArgs a) {
 int num_cus();
 
 // The form packed is the process default at the time of the call (aon_set_bottleneck_fold), remembered for `packed` (stream_form).
-hipError_t launch_pack_art_bwd(const float* const* params, float* packed, hipStream_t stream, int pos_levels, int view_levels) {
+FoldGemm art_fold_job_bwd(const float* const* params, float* packed, int view_levels) {
+  return FoldGemm{params[26], 256 + 3 + 6 * view_levels + 128, 1, params[34], 256, 1, packed + kABwFOffWf / 4, 256, 128, 256, 256, nullptr, nullptr};
+}
+
+hipError_t launch_pack_art_bwd(const float* const* params, float* packed, hipStream_t stream, int pos_levels, int view_levels, bool fold_done) {
   ArtParams a;
   for (int i = 0; i < kNumArtParams; ++i) a.p[i] = params[i];
   const int form = fold_default();
   set_stream_form(packed, form);
   if (form == kFormFolded) {
-    const FoldGemm job{params[26], 256 + 3 + 6 * view_levels + 128, 1, params[34], 256, 1, packed + kABwFOffWf / 4, 256, 128, 256, 256, nullptr, nullptr};
-    if (hipError_t e = launch_fold_gemms(&job, 1, stream); e != hipSuccess) return e;
+    if (!fold_done) {
+      const FoldGemm job = art_fold_job_bwd(params, packed, view_levels);
+      if (hipError_t e = launch_fold_gemms(&job, 1, stream); e != hipSuccess) return e;
+    }
     const int64_t n = kABwFStreamBytes / 4;
     pack_art_bwd_kernel<true><<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream>>>(a, packed, pos_levels, view_levels);
   } else {

@@ -5,6 +5,8 @@ same constructor defaults, parameter names (``deformations_linear.*``, ``deforma
 (deformation_mlp=True, enc_after=True, embed_deg=False, 4x128 deformation and view branches) has kernels."""
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.init as init
@@ -162,15 +164,22 @@ class NeRF_AE_Art(nn.Module):
             # training: HIP forward that keeps the activation planes + HIP backward (autograd.RenderArticulated);
             # the per-call block must not alias the cached inference buffer (it is saved for backward)
             mlps = [self.coarse_mlp, self.fine_mlp][: self.num_levels]
-            bwd, bwd_ready = packed_bwd_aside(mlps)
+            bwd_ready = fine_ready = None
+            if (len(mlps) == 2 and pack_aside_mode() == 0 and mlps[0].degrees == mlps[1].degrees
+                    and os.environ.get("AON_PACK_STEP", "1") != "0"):
+                # round 6: both networks' streams, per-call blocks and transposed streams in ONE C call -- the four fp64 fold products as one
+                # launch in front instead of four in a row with their pack kernels (aon_art_pack_step; the same bytes in every buffer)
+                packs = ops.art_pack_step(dict(mlps[0].named_parameters()), dict(mlps[1].named_parameters()), latents, degrees=mlps[0].degrees)
+            else:
+                bwd, bwd_ready = packed_bwd_aside(mlps)
 
-            def level_pack(mlp):     # the per-call latent-folded block + the forward weight stream of one level (prepare | fold -> pack)
-                return ops.art_prepare(dict(mlp.named_parameters()), latents, degrees=mlp.degrees), mlp.packed(True)
+                def level_pack(mlp):     # the per-call latent-folded block + the forward weight stream of one level (prepare | fold -> pack)
+                    return ops.art_prepare(dict(mlp.named_parameters()), latents, degrees=mlp.degrees), mlp.packed(True)
 
-            # round 6: the fine level's three launches on a side stream of their own, beside the coarse level's (they were 2 x 48 us in a row)
-            fine, fine_ready = run_aside(rays_o.device, "fine", lambda: level_pack(mlps[1])) if len(mlps) == 2 else (None, None)
-            small_c, pk_c = level_pack(mlps[0])
-            packs = [(pk_c, small_c, bwd[0])] + ([(fine[1], fine[0], bwd[1])] if len(mlps) == 2 else [])
+                # (AON_PACK_ASIDE=1/2: the fine level's three launches on a side stream of their own, beside the coarse level's)
+                fine, fine_ready = run_aside(rays_o.device, "fine", lambda: level_pack(mlps[1])) if len(mlps) == 2 else (None, None)
+                small_c, pk_c = level_pack(mlps[0])
+                packs = [(pk_c, small_c, bwd[0])] + ([(fine[1], fine[0], bwd[1])] if len(mlps) == 2 else [])
             if fine_ready is not None:
                 torch.cuda.current_stream(rays_o.device).wait_event(fine_ready)
             if bwd_ready is not None and pack_aside_mode() == 2:

@@ -613,6 +613,33 @@ def art_prepare(params: dict, latents: dict, out: torch.Tensor | None = None, de
     return _tag(out)
 
 
+def art_pack_step(params_c: dict, params_f: dict, latents: dict, degrees=(0, 10, 4), with_bwd: bool = True, out=None):
+    """pack_art_mlp + art_prepare (+ pack_art_mlp_bwd) of the coarse and the fine network in ONE C call (aon_art_pack_step): the four fp64
+    fold products as one launch in front.  -> [(packed, small, packed_bwd or None)] per level, tagged with their form; fresh buffers unless
+    ``out`` = [(packed, small, packed_bwd or None)] x 2 hands in uint8 buffers of the library's sizes."""
+    tens, arrs = [], []
+    for params in (params_c, params_f):
+        t, arr = _art_param_array(params, degrees)
+        tens.append(t)
+        arrs.append(arr)
+    shape, app, art = _latent(latents, "density", 128), _latent(latents, "color", 128), _latent(latents, "articulation", 32)
+    dev = tens[0][0].device
+    new = lambda nbytes: torch.empty(int(nbytes), dtype=torch.uint8, device=dev)   # noqa: E731
+    if out is not None:
+        pk, sm, bw = ([o[i] for o in out] for i in range(3))
+        for got, want in zip(pk + sm + bw, [lib.aon_art_packed_bytes()] * 2 + [lib.aon_art_small_bytes()] * 2 + [lib.aon_art_bwd_packed_bytes()] * 2):
+            if got is not None and (got.dtype != torch.uint8 or got.numel() != int(want) or got.device != dev or not got.is_contiguous()):
+                raise ValueError(f"art_pack_step: out buffers must be contiguous uint8 tensors of the library's sizes on {dev}")
+    else:
+        pk = [new(lib.aon_art_packed_bytes()) for _ in range(2)]
+        sm = [new(lib.aon_art_small_bytes()) for _ in range(2)]
+        bw = [new(lib.aon_art_bwd_packed_bytes()) if with_bwd else None for _ in range(2)]
+    with torch.cuda.device(dev):
+        check(lib.aon_art_pack_step(arrs[0], arrs[1], _ptr(shape), _ptr(app), _ptr(art), int(degrees[0]), int(degrees[1]), int(degrees[2]),
+                                    _ptr(pk[0]), _ptr(sm[0]), _ptr(bw[0]), _ptr(pk[1]), _ptr(sm[1]), _ptr(bw[1]), _stream()), "aon_art_pack_step")
+    return [(_tag(pk[l]), _tag(sm[l]), None if bw[l] is None else _tag(bw[l])) for l in range(2)]
+
+
 def art_mlp_fwd(packed, small, rays_o, rays_d, viewdirs, t_vals):
     o, d, v, t = _f32(rays_o, "rays_o"), _f32(rays_d, "rays_d"), _f32(viewdirs, "viewdirs"), _f32(t_vals, "t_vals")
     n, S = t.shape

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define AON_ABI_VERSION 5   /* 5: + aon_adam_step, aon_code_library_fwd / _bwd, aon_stream_form, aon_declare_stream_form; a packed pointer this process never
+#define AON_ABI_VERSION 5   /* 5: + aon_adam_step, aon_code_library_fwd / _bwd, aon_art_pack_step, aon_stream_form, aon_declare_stream_form; a packed pointer this process never
                                packed or declared is refused (AON_E_INVALID / HIP "invalid value") instead of being taken to have the default form */
 
 #define AON_OK 0
@@ -79,6 +79,15 @@ int aon_code_library_fwd(const float* const* tables_host, const int64_t* const* 
                          void* stream);
 int aon_code_library_bwd(const float* const* g_rows_host, const int64_t* const* ids_host, const int* rows_host, const int* dims_host, float* const* g_tables_host,
                          void* stream);
+
+/* Everything a training step of a TWO-level articulated model packs, in one call (round 6): aon_pack_art_mlp_deg + aon_art_prepare_deg +
+ * aon_pack_art_mlp_bwd_deg for the coarse and the fine network -- the same kernels on the same operands, the same bytes in all six buffers --
+ * with the four fp64 products W' = W_v0[:, :256] W_b (each network's, for its forward and for its transposed stream) as ONE launch in front
+ * instead of one launch in front of each pack kernel.  packed_bwd_* may be NULL.  Buffer sizes: aon_art_packed_bytes / aon_art_small_bytes /
+ * aon_art_bwd_packed_bytes. */
+int aon_art_pack_step(const float* const* params_coarse_host, const float* const* params_fine_host, const float* shape, const float* appearance,
+                      const float* articulation, int min_deg_point, int max_deg_point, int deg_view, void* packed_coarse, void* small_coarse,
+                      void* packed_bwd_coarse, void* packed_fine, void* small_fine, void* packed_bwd_fine, void* stream);
 
 /* get_ray_directions alone (ray_utils.py:71-90): directions (H*W,3), un-normalised camera-space. */
 int aon_ray_directions(int H, int W, float focal, float* directions, void* stream);

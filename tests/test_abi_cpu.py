@@ -294,6 +294,17 @@ def test_round6_entry_points_validate_without_gpu():
         assert fn(None, three, rows, dims, three, None) == -1
         assert fn(three, three, (C.c_int * 3)(2, 0, 10), dims, three, None) == -1 and b"table size" in lib.aon_last_error()
         assert fn((C.c_void_p * 3)(0x1000, 0, 0x3000), three, rows, dims, three, None) == -1
+    # aon_art_pack_step: degrees, null pointers and alignment are judged before anything is launched
+    forty = (C.c_void_p * 40)(*[0x1000 + 64 * i for i in range(40)])
+    a = C.c_void_p(0x4000)
+    ok = (forty, forty, p, p, p, 0, 10, 4, a, a, a, a, a, a, None)
+    swap = lambda i, v: ok[:i] + (v,) + ok[i + 1:]     # noqa: E731
+    assert lib.aon_art_pack_step(*swap(6, 11)) == -1                                          # more than ten position levels
+    assert lib.aon_art_pack_step(*swap(0, None)) == -1 and b"null" in lib.aon_last_error()
+    assert lib.aon_art_pack_step(*swap(11, None)) == -1 and b"null" in lib.aon_last_error()   # the fine forward stream is not optional
+    holed = (C.c_void_p * 40)(*[0 if i == 17 else 0x1000 + 64 * i for i in range(40)])
+    assert lib.aon_art_pack_step(*swap(1, holed)) == -1 and b"null parameter" in lib.aon_last_error()
+    assert lib.aon_art_pack_step(*swap(13, C.c_void_p(0x4004))) == -1 and b"16-byte" in lib.aon_last_error()
 
 
 def test_param_arena_mechanics_on_cpu():
