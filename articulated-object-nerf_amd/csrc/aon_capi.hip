@@ -21,6 +21,9 @@ hipError_t launch_mlp_fwd_enc(const char* packed, const float* samples_enc, cons
                               int S, float* raw, hipStream_t stream);
 hipError_t launch_pack_art(const float* const* params, float* packed, hipStream_t stream, int pos_levels = 10, int view_levels = 4, bool fold_done = false);
 FoldGemm art_fold_job_fwd(const float* const* params, float* packed, int view_levels);
+hipError_t launch_pack_prepare_art2(const float* const* const params[2], const float* shape, const float* app, const float* art, float* const packed[2],
+                                    float* const small[2], hipStream_t stream, int min_deg, int pos_levels, int view_levels);
+hipError_t launch_pack_art_bwd2(const float* const* const params[2], float* const packed[2], hipStream_t stream, int pos_levels, int view_levels);
 FoldGemm art_fold_job_bwd(const float* const* params, float* packed, int view_levels);
 hipError_t launch_prepare_art(const float* const* params, const float* shape, const float* app, const float* art,
                               float* small, hipStream_t stream, int min_deg = 0, int pos_levels = 10, int view_levels = 4);
@@ -69,7 +72,10 @@ hipError_t launch_art_bwd_chain(const char* packed_bwd, const float* small, cons
 hipError_t launch_art_wgrad(const float* planes, const float* dplanes, const float* d_raw, const float* dxp, int64_t Np,
                             const float* const* params, const float* shape, const float* app, const float* art,
                             float* const* grads, float* g_shape, float* g_app, float* g_art, float* ws, hipStream_t stream, const WgAux* aux, int pos_levels, int view_levels,
-                            const void* packed_bwd, int phase = 0, bool accumulate_latents = false, const struct WgPost* post = nullptr);
+                            const void* packed_bwd, int phase = 0, bool accumulate_latents = false, const struct WgPost* post = nullptr,
+                            struct ArtWgDeferred* defer = nullptr);
+constexpr int kArtWgDeferredBytes = 4096;   // aon_train_art.hip (static_assert there): a level's second stage handed back instead of launched
+hipError_t launch_art_wgrad_post2(const struct ArtWgDeferred* d0, const struct ArtWgDeferred* d1, hipStream_t stream);
 hipError_t launch_train_loss(bool backward, const float* rgb_c, const float* rgb_f, const float* target, int64_t n, const float* const* lat, const int* lat_len,
                              float reg_scale, float* stats, float* loss, const float* go, float* d_rgb_c, float* d_rgb_f, float* const* d_lat, hipStream_t stream);
 hipError_t launch_adam(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2, double eps, int64_t step, hipStream_t stream);
@@ -1533,6 +1539,15 @@ int aon_art_render_bwd_ex(const void* packed_bwd_coarse, const void* small_coars
   // (overlap mode 2 runs level l's head reductions on aux(l) beside its grouped kernel: level 0's aux stream is free again by then)
   const aon::WgAux* post_side = (merged && post_aside && fork.aux(0)) ? (overlap_mode == 2 ? fork.aux(0) : fork.aux(1)) : nullptr;
   const aon::WgPost post0{post_side, nullptr}, post1{nullptr, post_side ? post_side->join : nullptr};
+  // Round 6: ONE second stage for both levels.  Level 0's (reduce 20 us -> un-folding products 18 us -> finishing kernel 15 us, plus an
+  // event gap either side) used to sit between the two grouped kernels with the chip all but idle; deferred, the grouped kernels follow
+  // each other and the levels' reduce blocks, un-folding products and finishing kernels go out as 1 + 1 + 2 launches behind level 1's
+  // (launch_art_wgrad_post2; every block does what it did: same bits, tools/grad_hash.py).  Default degrees only (other degrees put
+  // remap launches between the stages).  AON_POST_MERGE=0 in the environment: per level as before (A/B).
+  static const bool post_merge_env = [] { const char* e = std::getenv("AON_POST_MERGE"); return !(e && e[0] == '0'); }();
+  const bool post_merged = merged && post_merge_env && !post_side && g.max_deg - g.min_deg == 10 && g.deg_view == 4;
+  alignas(16) unsigned char defer_store[2][aon::kArtWgDeferredBytes];
+  auto deferred = [&](int l) { return reinterpret_cast<aon::ArtWgDeferred*>(defer_store[l]); };
   auto level_wgrad = [&](int l, hipStream_t st, const aon::WgAux* aux, int phase) {
     // level 0 writes the latent gradients, level 1 adds its own (both MLPs see the same latents).  Merged schedule (round 6): both levels'
     // finishing kernels run on the caller's stream in level order, so level 1's adds onto level 0's result in place (g = coarse + fine, the
@@ -1541,7 +1556,8 @@ int aon_art_render_bwd_ex(const void* packed_bwd_coarse, const void* small_coars
     float* gs = (l == 0 || acc) ? g_shape : sc.lat_tmp, *ga = (l == 0 || acc) ? g_appearance : sc.lat_tmp + 128, *gt = (l == 0 || acc) ? g_articulation : sc.lat_tmp + 256;
     return check(aon::launch_art_wgrad(w.lvl[l].planes, sc.dplanes[l], sc.d_raw[l], sc.dxp[l], w.lvl[l].Np, params[l], shape, appearance, articulation, grads[l], gs, ga, gt,
                                        sc.wgrad_ws[l], st, aux, g.max_deg - g.min_deg, g.deg_view, pb[l], phase, acc,
-                                       (post_side && phase != kWgEarly) ? (l == 0 ? &post0 : &post1) : nullptr), "aon_art_render_bwd");
+                                       (post_side && phase != kWgEarly) ? (l == 0 ? &post0 : &post1) : nullptr,
+                                       (post_merged && phase != kWgEarly) ? deferred(l) : nullptr), "aon_art_render_bwd");
   };
   bool early_unjoined = false;   // (the early reductions are on the side stream and the caller's stream has not been told to wait for them)
   if (merged) {
@@ -1592,6 +1608,10 @@ int aon_art_render_bwd_ex(const void* packed_bwd_coarse, const void* small_coars
       return rc;
     }
     early_unjoined = false;   // (run_wgrad_plan joined aux(0) == the early reductions' stream in front of level 0's second stage)
+  }
+  if (post_merged) {
+    KTimer timer(kWgrad, caller, 0);
+    if (int rc = check(aon::launch_art_wgrad_post2(deferred(0), deferred(1), caller), "aon_art_render_bwd")) return rc;
   }
   if (int rc = fork.join()) return rc;   // the caller's stream continues after both levels
   if (num_levels == 2 && !merged) {
@@ -1664,12 +1684,19 @@ int aon_art_pack_step(const float* const* params_coarse_host, const float* const
       if (bwd[l]) jobs[n++] = aon::art_fold_job_bwd(P[l], bwd[l], Lv);
     if (int rc = check(aon::launch_fold_gemms(jobs, n, stream), "aon_art_pack_step")) return rc;
   }
-  for (int l = 0; l < 2; ++l) {
-    if (int rc = check(aon::launch_prepare_art(P[l], shape, appearance, articulation, sm[l], stream, min_deg_point, Lp, Lv), "aon_art_pack_step")) return rc;
-    if (int rc = check(aon::launch_pack_art(P[l], fwd[l], stream, Lp, Lv, folded), "aon_art_pack_step")) return rc;
+  // (AON_PACK_MERGE=0 in the environment: one launch per network and buffer as before, for A/B)
+  static const bool merge = [] { const char* e = std::getenv("AON_PACK_MERGE"); return !(e && e[0] == '0'); }();
+  if (merge) {
+    if (int rc = check(aon::launch_pack_prepare_art2(P, shape, appearance, articulation, fwd, sm, stream, min_deg_point, Lp, Lv), "aon_art_pack_step")) return rc;
+    if (bwd[0] && bwd[1]) return check(aon::launch_pack_art_bwd2(P, bwd, stream, Lp, Lv), "aon_art_pack_step");
+  } else {
+    for (int l = 0; l < 2; ++l) {
+      if (int rc = check(aon::launch_prepare_art(P[l], shape, appearance, articulation, sm[l], stream, min_deg_point, Lp, Lv), "aon_art_pack_step")) return rc;
+      if (int rc = check(aon::launch_pack_art(P[l], fwd[l], stream, Lp, Lv, folded), "aon_art_pack_step")) return rc;
+    }
   }
   for (int l = 0; l < 2; ++l)
-    if (bwd[l])
+    if (bwd[l] && !(merge && bwd[0] && bwd[1]))
       if (int rc = check(aon::launch_pack_art_bwd(P[l], bwd[l], stream, Lp, Lv, folded), "aon_art_pack_step")) return rc;
   return AON_OK;
 }

@@ -26,7 +26,7 @@ struct FoldGemm {
   int M, N, K;
   const float* u; const float* v;
 };
-constexpr int kFoldMaxJobs = 4;
+constexpr int kFoldMaxJobs = 6;
 hipError_t launch_fold_gemms(const FoldGemm* jobs, int njobs, hipStream_t stream);
 
 // Wf (128, 256) = Wv[:, :256] Wb,  bf (128) = Wv[:, :256] bb + bv      (Wv: (128, ldv), Wb: (256, 256))
@@ -36,5 +36,8 @@ hipError_t launch_fold_view(const float* Wv, int ldv, const float* bv, const flo
 // (dbv = dbf is written by the weight-gradient kernels directly)
 hipError_t launch_unfold_view(const float* dWf, const float* dbf, const float* Wv, int ldv, const float* Wb, const float* bb, float* dWv, int ld_dwv,
                               float* dWb, float* dbb, hipStream_t stream);
+// ... its three products as jobs, for a caller that launches several levels' at once (launch_fold_gemms)
+void unfold_view_jobs(const float* dWf, const float* dbf, const float* Wv, int ldv, const float* Wb, const float* bb, float* dWv, int ld_dwv,
+                      float* dWb, float* dbb, FoldGemm jobs[3]);
 
 }  // namespace aon

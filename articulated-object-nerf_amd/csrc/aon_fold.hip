@@ -109,13 +109,17 @@ hipError_t launch_fold_view(const float* Wv, int ldv, const float* bv, const flo
   return launch_fold_gemms(jobs, 2, stream);
 }
 
+void unfold_view_jobs(const float* dWf, const float* dbf, const float* Wv, int ldv, const float* Wb, const float* bb, float* dWv, int ld_dwv,
+                      float* dWb, float* dbb, FoldGemm jobs[3]) {
+  jobs[0] = FoldGemm{Wv, 1, ldv, dWf, 256, 1, dWb, 256, 256, 256, 128, nullptr, nullptr};     // dWb[k][i] = sum_o Wv[o][k] dW'[o][i]
+  jobs[1] = FoldGemm{dWf, 256, 1, Wb, 1, 256, dWv, ld_dwv, 128, 256, 256, dbf, bb};           // dWv[o][k] = sum_i dW'[o][i] Wb[k][i] + db'[o] bb[k]
+  jobs[2] = FoldGemm{Wv, 1, ldv, dbf, 1, 0, dbb, 1, 256, 1, 128, nullptr, nullptr};           // dbb[k] = sum_o Wv[o][k] db'[o]
+}
+
 hipError_t launch_unfold_view(const float* dWf, const float* dbf, const float* Wv, int ldv, const float* Wb, const float* bb, float* dWv, int ld_dwv,
                               float* dWb, float* dbb, hipStream_t stream) {
-  const FoldGemm jobs[3] = {
-      {Wv, 1, ldv, dWf, 256, 1, dWb, 256, 256, 256, 128, nullptr, nullptr},     // dWb[k][i] = sum_o Wv[o][k] dW'[o][i]
-      {dWf, 256, 1, Wb, 1, 256, dWv, ld_dwv, 128, 256, 256, dbf, bb},           // dWv[o][k] = sum_i dW'[o][i] Wb[k][i] + db'[o] bb[k]
-      {Wv, 1, ldv, dbf, 1, 0, dbb, 1, 256, 1, 128, nullptr, nullptr},           // dbb[k] = sum_o Wv[o][k] db'[o]
-  };
+  FoldGemm jobs[3];
+  unfold_view_jobs(dWf, dbf, Wv, ldv, Wb, bb, dWv, ld_dwv, dWb, dbb, jobs);
   return launch_fold_gemms(jobs, 3, stream);
 }
 

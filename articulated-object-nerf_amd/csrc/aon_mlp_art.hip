@@ -54,12 +54,11 @@ struct ArtPackArgs {
 // L / Lv: frequency levels of the network (defaults 10 / 4); the weights' row strides follow: pts_linears.0 (256, P + 128),
 // pts_linears.5 (256, 256 + P + 128), views_linear.0 (128, 256 + V + 128) with P = 3 + 6 L, V = 3 + 6 Lv
 // FOLD: the folded form; W' was written to packed + kAFoldTmpOff by launch_fold_view on the same stream (b' belongs to the per-call block)
-template <bool FOLD>
-__global__ void pack_art_kernel(ArtPackArgs a, float* __restrict__ packed, int L, int Lv) {
+template <bool FOLD, class Args>   // Args: anything with the 40 parameter pointers as `p` (kernel arguments: read in place, never copied)
+__device__ __forceinline__ void pack_art_element(const Args& a, float* __restrict__ packed, int L, int Lv, const int64_t idx) {
   const int P = 3 + 6 * L, V = 3 + 6 * Lv;
   auto pcol = [&](int c63) { return c63 < 0 ? -1 : pos_col_in(c63, L); };
   auto vcol = [&](int c27) { return c27 < 0 ? -1 : view_col_in(c27, Lv); };
-  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (FOLD ? kAStreamBytesF : kAStreamBytes) / 4) return;
   // locate the chunk
   int c, r, nt;
@@ -95,6 +94,10 @@ __global__ void pack_art_kernel(ArtPackArgs a, float* __restrict__ packed, int L
   else { const int l = 1 + (c - kAChV1) / 4; W = a.p[26 + 2 * l]; ld = 128; col = 32 * ((c - kAChV1) % 4) + hid; }
   packed[idx] = col >= 0 ? W[(int64_t)row * ld + col] : 0.f;  // every layer here has a multiple of 32 outputs
 }
+template <bool FOLD>
+__global__ void pack_art_kernel(ArtPackArgs a, float* __restrict__ packed, int L, int Lv) {
+  pack_art_element<FOLD>(a, packed, L, Lv, (int64_t)blockIdx.x * blockDim.x + threadIdx.x);
+}
 
 struct ArtPrepArgs {
   const float* p[kNumArtParams];
@@ -108,9 +111,8 @@ struct ArtPrepArgs {
 // added to the fp32 value of b_v0 + (appearance term) -- which the literal form rounds as well -- so the effective bias is rounded TWICE (the
 // fp32 chain of the latent term, then once more with the fp64 sum on top), not once like the vanilla b' (the earlier wording
 // claimed one rounding; the un-folded gradients treat the bias as exact either way, and the second rounding is half an ulp of the bias)
-__global__ void prepare_art_kernel(ArtPrepArgs a, float* __restrict__ small, int min_deg, int L, int Lv, int fold) {
+__device__ __forceinline__ void prepare_art_element(const ArtPrepArgs& a, float* __restrict__ small, int min_deg, int L, int Lv, int fold, const int s) {
   const int P = 3 + 6 * L, V = 3 + 6 * Lv;
-  const int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= kASmallFloats) return;
   float v = 0.f;
   if (s >= kA_ESC) {   // encoding scales (exact powers of two), 0 for the levels this network lacks and for the pad
@@ -159,6 +161,28 @@ __global__ void prepare_art_kernel(ArtPrepArgs a, float* __restrict__ small, int
   else if (s < kA_BRGB) { v = a.p[37][0]; }
   else if (s < kA_BRGB + 3) { v = a.p[39][s - kA_BRGB]; }
   small[s] = v;
+}
+__global__ void prepare_art_kernel(ArtPrepArgs a, float* __restrict__ small, int min_deg, int L, int Lv, int fold) {
+  prepare_art_element(a, small, min_deg, L, Lv, fold, blockIdx.x * blockDim.x + threadIdx.x);
+}
+
+// Round 6: the per-call blocks AND the forward streams of TWO networks (a training step's coarse and fine level) in one launch --
+// blockIdx.y: network; blocks [0, kPrepBlocks): the per-call block, the rest: the stream.  Every element is computed by the code of the
+// single-network kernels above (same bits); the folded form expects W' in each stream's fold area (aon_art_pack_step runs the products first).
+constexpr int kPrepBlocks = (kASmallFloats + 255) / 256;
+struct ArtPackPrep2Args {
+  ArtPrepArgs net[2];
+  float* small[2];
+  float* packed[2];
+};
+template <bool FOLD>
+__global__ void __launch_bounds__(256) pack_prepare_art2_kernel(ArtPackPrep2Args a, int min_deg, int L, int Lv) {
+  const ArtPrepArgs& n = a.net[blockIdx.y];
+  if ((int)blockIdx.x < kPrepBlocks) {
+    prepare_art_element(n, a.small[blockIdx.y], min_deg, L, Lv, FOLD ? 1 : 0, (int)blockIdx.x * 256 + (int)threadIdx.x);
+  } else {
+    pack_art_element<FOLD>(n, a.packed[blockIdx.y], L, Lv, (int64_t)((int)blockIdx.x - kPrepBlocks) * 256 + threadIdx.x);
+  }
 }
 
 // One SEGMENT of a launch: a run of 128-sample passes of one network over one ray range.  A launch carries one or two of them
@@ -455,6 +479,25 @@ hipError_t launch_prepare_art(const float* const* params, const float* shape, co
   const int form = fold_default();
   set_stream_form(small, form);
   prepare_art_kernel<<<dim3((kASmallFloats + 255) / 256), dim3(256), 0, stream>>>(a, small, min_deg, pos_levels, view_levels, form == kFormFolded ? 1 : 0);
+  return hipGetLastError();
+}
+
+// both networks of a two-level model: per-call blocks + forward streams, one launch (the folded form's W' must be in place: fold_done)
+hipError_t launch_pack_prepare_art2(const float* const* const params[2], const float* shape, const float* app, const float* art, float* const packed[2],
+                                    float* const small[2], hipStream_t stream, int min_deg, int pos_levels, int view_levels) {
+  ArtPackPrep2Args a;
+  const int form = fold_default();
+  for (int l = 0; l < 2; ++l) {
+    for (int i = 0; i < kNumArtParams; ++i) a.net[l].p[i] = params[l][i];
+    a.net[l].shape = shape; a.net[l].app = app; a.net[l].art = art;
+    a.small[l] = small[l]; a.packed[l] = packed[l];
+    set_stream_form(packed[l], form);
+    set_stream_form(small[l], form);
+  }
+  const int64_t n = (form == kFormFolded ? kAStreamBytesF : kAStreamBytes) / 4;
+  const dim3 grid((unsigned)(kPrepBlocks + (n + 255) / 256), 2);
+  if (form == kFormFolded) pack_prepare_art2_kernel<true><<<grid, dim3(256), 0, stream>>>(a, min_deg, pos_levels, view_levels);
+  else pack_prepare_art2_kernel<false><<<grid, dim3(256), 0, stream>>>(a, min_deg, pos_levels, view_levels);
   return hipGetLastError();
 }
 

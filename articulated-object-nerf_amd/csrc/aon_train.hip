@@ -458,7 +458,7 @@ void set_wgrad_probe(long long* buf) { g_wgrad_probe.store(buf, std::memory_orde
 // The plan (workspace offsets of every partial) is a pure function of the arguments: the two phases of a level compute the same one.
 hipError_t run_wgrad_plan(const WgLayerDesc* layers, int nlayers, const HeadDesc* heads, int nheads, const HeadOut* outs, const int* out_head, int nouts,
                           const float* planes, const float* dplanes, int rows_total, int64_t Np, float* ws, hipStream_t stream, const WgAux* aux,
-                          int phase, int n_early, const WgPost* post, hipStream_t* post_stream) {
+                          int phase, int n_early, const WgPost* post, hipStream_t* post_stream, ReduceArgs* defer_reduce, int* defer_blocks) {
   if (post_stream) *post_stream = stream;
   static DeviceOnce lds_once;
   if (hipError_t e = set_max_lds(&wgrad_grouped_kernel, kWgLdsBytes, lds_once); e != hipSuccess) return e;
@@ -509,6 +509,12 @@ hipError_t run_wgrad_plan(const WgLayerDesc* layers, int nlayers, const HeadDesc
     if (err == hipSuccess) err = e;
   }
   if (err != hipSuccess) return err;
+  if (defer_reduce) {   // the caller launches this level's second stage itself, together with the other level's (launch_wgrad_reduce2)
+    if (post || !defer_blocks) return hipErrorInvalidValue;
+    *defer_reduce = R;
+    *defer_blocks = plan.reduce_blocks + nouts;
+    return hipSuccess;
+  }
   hipStream_t ps = stream;
   if (post) {
     if (post->wait_first)
@@ -521,6 +527,13 @@ hipError_t run_wgrad_plan(const WgLayerDesc* layers, int nlayers, const HeadDesc
   }
   if (post_stream) *post_stream = ps;
   wgrad_reduce_kernel<<<dim3(plan.reduce_blocks + nouts), dim3(256), 0, ps>>>(R);
+  return hipGetLastError();
+}
+
+// The second stages of two levels in one launch: each block does what it does in wgrad_reduce_kernel (same sums, same order).
+hipError_t launch_wgrad_reduce2(const ReduceArgs& a0, int n0, const ReduceArgs& a1, int n1, hipStream_t stream) {
+  if (n0 < 1 || n1 < 1) return hipErrorInvalidValue;
+  wgrad_reduce2_kernel<<<dim3(n0 + n1), dim3(256), 0, stream>>>(a0, a1, n0);
   return hipGetLastError();
 }
 
@@ -590,7 +603,7 @@ hipError_t launch_vanilla_wgrad(const float* planes, const float* dplanes, const
   const HeadOut O[4] = {{0, 256, 3, 1, 256, 1, grads[20]}, {0, 128, 0, 3, 128, 1, grads[22]}, {0, 1, 3, 1, 1, 1, grads[21]}, {0, 1, 0, 3, 1, 1, grads[23]}};
   const int OH[4] = {0, 1, 2, 2};
   // all three head jobs (density head on H7, rgb head on HV, the sums of d_raw) are independent of the chain: n_early = 3
-  if (hipError_t e = run_wgrad_plan(L, n, H, 3, O, OH, 4, planes, dplanes, kPlRows, Np, ws, stream, aux, phase, 3, nullptr, nullptr); e != hipSuccess) return e;
+  if (hipError_t e = run_wgrad_plan(L, n, H, 3, O, OH, 4, planes, dplanes, kPlRows, Np, ws, stream, aux, phase, 3, nullptr, nullptr, nullptr, nullptr); e != hipSuccess) return e;
   if (!fold || phase == kWgEarly) return hipSuccess;
   const float* raw = reinterpret_cast<const float*>(static_cast<const char*>(packed_bwd) + kBwFOffWv);
   // (grads[16]'s row stride is the 27-slot layout's here: other view degrees write a slot-layout temporary first, aon_render_bwd_ex)

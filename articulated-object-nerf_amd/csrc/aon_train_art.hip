@@ -47,16 +47,48 @@ struct ArtParams {
   const float* p[kNumArtParams];
 };
 
+// the chunks of a stream as runs of equal size (compile time): first chunk, offset in floats and log2(floats per chunk) of each run
+template <class N>
+struct ChunkRuns {
+  int n = 0;
+  int first[8] = {};
+  int shift[8] = {};
+  int64_t off[8] = {};
+  constexpr ChunkRuns() {
+    int64_t o = 0;
+    int prev = -1;
+    for (int c = 0; c < N::kNumChunks; ++c) {
+      const int b = N::chunk_bytes(c);
+      if (b != prev) {
+        first[n] = c; off[n] = o;
+        int lg = 0;
+        while ((4 << lg) < b) ++lg;
+        shift[n] = lg;
+        ++n;
+        prev = b;
+      }
+      o += b / 4;
+    }
+  }
+};
+
 template <bool FOLD>
-__global__ void pack_art_bwd_kernel(ArtParams a, float* __restrict__ packed, int L, int Lv) {
+__device__ __forceinline__ void pack_art_bwd_element(const ArtParams& a, float* __restrict__ packed, int L, int Lv, const int64_t idx0, const int64_t idx) {
   using N = std::conditional_t<FOLD, ArtBwdFoldNet, ArtBwdNet>;
   const int P = 3 + 6 * L, V = 3 + 6 * Lv;   // (row strides of the three concatenating layers; the view-encoding columns are never read)
-  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (FOLD ? kABwFStreamBytes : kABwStreamBytes) / 4) return;
-  // locate the chunk (~100 chunks: linear scan is fine for a pack kernel)
-  int c = 0;
-  int64_t base = 0;
-  while (c < N::kNumChunks - 1 && idx >= base + N::chunk_bytes(c) / 4) { base += N::chunk_bytes(c) / 4; ++c; }
+  // locate the chunk.  The stream is a handful of RUNS of equal-sized chunks (16 / 32 / 8 / 32 / 8 / 16 KiB): find the run of the BLOCK's
+  // first index `idx0` (chunks are multiples of 4 KiB, a block is 1 KiB of the stream: one chunk per block, scalar instructions), then the
+  // chunk inside it by a shift.  Rounds 2-5 scanned the ~100 chunks one by one on the thread's own index -- a few thousand vector
+  // instructions per element, which made this the longest kernel of a training step's prologue.
+  constexpr ChunkRuns<N> runs{};
+  int c0 = 0, sh = runs.shift[0];
+  int64_t off0 = 0;
+#pragma unroll
+  for (int t = 1; t < runs.n; ++t)
+    if (idx0 >= runs.off[t]) { c0 = runs.first[t]; off0 = runs.off[t]; sh = runs.shift[t]; }
+  int c = c0 + (int)((idx0 - off0) >> sh);
+  const int64_t base = off0 + ((int64_t)(c - c0) << sh);
   const int r = (int)(idx - base);
   const int nt = N::chunk_bytes(c) / 4096;
   if constexpr (FOLD) { if (c >= kABwBott) c += kABwL7 - kABwBott; }   // the chunks behind views_linear.0 take the literal branches below
@@ -86,6 +118,20 @@ __global__ void pack_art_bwd_kernel(ArtParams a, float* __restrict__ packed, int
   else if (c < kABwD3) { W = a.p[10]; ld = P + 128; j = 32 * (c - kABwL0E) + jo; col = enc_col(); }
   else { const int l = 3 - (c - kABwD3) / 4; W = a.p[2 * l]; ld = 128; j = 32 * ((c - kABwD3) % 4) + jo; }
   packed[idx] = col >= 0 ? W[(int64_t)j * ld + col] : 0.f;
+}
+template <bool FOLD>
+__global__ void __launch_bounds__(256) pack_art_bwd_kernel(ArtParams a, float* __restrict__ packed, int L, int Lv) {
+  static_assert(kSmallChunkBytes % 4096 == 0 && kTinyChunkBytes % 4096 == 0 && kBigChunkBytes % 4096 == 0, "a 256-thread block never straddles two chunks");
+  pack_art_bwd_element<FOLD>(a, packed, L, Lv, (int64_t)blockIdx.x * 256, (int64_t)blockIdx.x * 256 + threadIdx.x);
+}
+// the transposed streams of TWO networks in one launch (round 6; blockIdx.y: network), element by element the kernel above
+struct ArtParams2 {
+  ArtParams net[2];
+  float* packed[2];
+};
+template <bool FOLD>
+__global__ void __launch_bounds__(256) pack_art_bwd2_kernel(ArtParams2 a, int L, int Lv) {
+  pack_art_bwd_element<FOLD>(a.net[blockIdx.y], a.packed[blockIdx.y], L, Lv, (int64_t)blockIdx.x * 256, (int64_t)blockIdx.x * 256 + threadIdx.x);
 }
 
 // One SEGMENT of a chain launch: the passes of one level (its transposed stream, small block, decision bits, planes).  Round 4: the
@@ -356,22 +402,21 @@ struct ArtFinishArgs {
   LatentJob lat[3];
   OuterJob outer[5];
 };
-__global__ void __launch_bounds__(1024) art_finish_kernel(ArtFinishArgs a) {
-  __shared__ float red[8][128];
-  if (blockIdx.x >= 3) {
-    int j = 0;
+// (blocks 3.. of a level's finishing launch; bx: the block's index in that launch)
+__device__ __forceinline__ void art_finish_outer(const ArtFinishArgs& a, const int bx) {
+  int j = 0;
 #pragma unroll 1
-    for (int t = 1; t < 5; ++t)
-      if ((int)blockIdx.x >= a.outer[t].blk_begin) j = t;
-    const OuterJob& O = a.outer[j];
-    const int idx = ((int)blockIdx.x - O.blk_begin) * 1024 + threadIdx.x;
-    if (idx < O.M * O.L) {
-      const int f = idx / O.L, k = idx % O.L;
-      O.out[(int64_t)f * O.ld + O.col_off + k] = O.db[f] * O.latent[k];
-    }
-    return;
+  for (int t = 1; t < 5; ++t)
+    if (bx >= a.outer[t].blk_begin) j = t;
+  const OuterJob& O = a.outer[j];
+  const int idx = (bx - O.blk_begin) * 1024 + threadIdx.x;
+  if (idx < O.M * O.L) {
+    const int f = idx / O.L, k = idx % O.L;
+    O.out[(int64_t)f * O.ld + O.col_off + k] = O.db[f] * O.latent[k];
   }
-  const LatentJob& j = a.lat[blockIdx.x];
+}
+// (blocks 0..2: this level's d latent[k], valid in the threads of row group 0 with k < L)
+__device__ __forceinline__ float art_finish_latent(const LatentJob& j, float (*red)[128]) {
   const int k = threadIdx.x & 127, g = threadIdx.x >> 7;
   float s = 0.f;
   if (k < j.L) {
@@ -385,11 +430,59 @@ __global__ void __launch_bounds__(1024) art_finish_kernel(ArtFinishArgs a) {
   }
   red[g][k] = s;
   __syncthreads();
+  float t = 0.f;
   if (g == 0 && k < j.L) {
-    float t = red[0][k];
+    t = red[0][k];
 #pragma unroll
     for (int q = 1; q < 8; ++q) t += red[q][k];
-    j.out[k] = j.add ? j.add[k] + t : t;
+  }
+  return t;
+}
+__global__ void __launch_bounds__(1024) art_finish_kernel(ArtFinishArgs a) {
+  __shared__ float red[8][128];
+  if (blockIdx.x >= 3) { art_finish_outer(a, (int)blockIdx.x); return; }
+  const LatentJob& j = a.lat[blockIdx.x];
+  const float t = art_finish_latent(j, red);
+  const int k = threadIdx.x & 127, g = threadIdx.x >> 7;
+  if (g == 0 && k < j.L) j.out[k] = j.add ? j.add[k] + t : t;
+}
+// The finishing kernels of TWO levels as one launch (round 6): blocks 0..2 take each latent through level 0 and then level 1 --
+// out = (level 0's sum) + (level 1's sum), the value the two launches in a row leave there (level 0 stores its fp32 sum, level 1 adds
+// its own to it) -- blocks [3, n0) are level 0's latent-column blocks, the rest level 1's.
+// (the two levels' sums run in lockstep -- two independent chains of multiply-adds, each in its own order, their loads in flight together:
+// the kernel is load latency from end to end)
+__global__ void __launch_bounds__(1024) art_finish2_kernel(ArtFinishArgs a0, ArtFinishArgs a1, int n0) {
+  __shared__ float red[2][8][128];
+  const int bx = (int)blockIdx.x;
+  if (bx >= n0) { art_finish_outer(a1, bx - n0 + 3); return; }
+  if (bx >= 3) { art_finish_outer(a0, bx); return; }
+  const LatentJob& j0 = a0.lat[bx];
+  const LatentJob& j1 = a1.lat[bx];
+  const int k = threadIdx.x & 127, g = threadIdx.x >> 7;
+  float s0 = 0.f, s1 = 0.f;
+  if (k < j0.L) {   // (launch_art_wgrad_post2 checked that the two levels' jobs have the same shape: L, pairs, M)
+    for (int pi = 0; pi < j0.npairs; ++pi) {
+      const float* W0 = j0.W[pi] + j0.col_off[pi] + k;
+      const float* W1 = j1.W[pi] + j1.col_off[pi] + k;
+      const float* db0 = j0.db[pi];
+      const float* db1 = j1.db[pi];
+      const int ld0 = j0.ld[pi], ld1 = j1.ld[pi];
+#pragma unroll 4
+      for (int f = g; f < j0.M[pi]; f += 8) {
+        s0 = __builtin_fmaf(W0[(int64_t)f * ld0], db0[f], s0);
+        s1 = __builtin_fmaf(W1[(int64_t)f * ld1], db1[f], s1);
+      }
+    }
+  }
+  red[0][g][k] = s0;
+  red[1][g][k] = s1;
+  __syncthreads();
+  if (g == 0 && k < j0.L) {
+    float t0 = red[0][0][k], t1 = red[1][0][k];
+#pragma unroll
+    for (int q = 1; q < 8; ++q) { t0 += red[0][q][k]; t1 += red[1][q][k]; }
+    const float v0 = j0.add ? j0.add[k] + t0 : t0;
+    j1.out[k] = v0 + t1;
   }
 }
 
@@ -401,6 +494,22 @@ int num_cus();
 // The form packed is the process default at the time of the call (aon_set_bottleneck_fold), remembered for `packed` (stream_form).
 FoldGemm art_fold_job_bwd(const float* const* params, float* packed, int view_levels) {
   return FoldGemm{params[26], 256 + 3 + 6 * view_levels + 128, 1, params[34], 256, 1, packed + kABwFOffWf / 4, 256, 128, 256, 256, nullptr, nullptr};
+}
+
+// both networks of a two-level model, one launch (the folded form's W' must be in place: aon_art_pack_step)
+hipError_t launch_pack_art_bwd2(const float* const* const params[2], float* const packed[2], hipStream_t stream, int pos_levels, int view_levels) {
+  ArtParams2 a;
+  const int form = fold_default();
+  for (int l = 0; l < 2; ++l) {
+    for (int i = 0; i < kNumArtParams; ++i) a.net[l].p[i] = params[l][i];
+    a.packed[l] = packed[l];
+    set_stream_form(packed[l], form);
+  }
+  const int64_t n = (form == kFormFolded ? kABwFStreamBytes : kABwStreamBytes) / 4;
+  const dim3 grid((unsigned)((n + 255) / 256), 2);
+  if (form == kFormFolded) pack_art_bwd2_kernel<true><<<grid, dim3(256), 0, stream>>>(a, pos_levels, view_levels);
+  else pack_art_bwd2_kernel<false><<<grid, dim3(256), 0, stream>>>(a, pos_levels, view_levels);
+  return hipGetLastError();
 }
 
 hipError_t launch_pack_art_bwd(const float* const* params, float* packed, hipStream_t stream, int pos_levels, int view_levels, bool fold_done) {
@@ -461,7 +570,8 @@ hipError_t launch_art_bwd_chain(const char* packed_bwd, const float* small, cons
 
 hipError_t run_wgrad_plan(const WgLayerDesc* layers, int nlayers, const HeadDesc* heads, int nheads, const HeadOut* outs, const int* out_head, int nouts,
                           const float* planes, const float* dplanes, int rows_total, int64_t Np, float* ws, hipStream_t stream, const WgAux* aux,
-                          int phase, int n_early, const WgPost* post, hipStream_t* post_stream);   // aon_train.hip
+                          int phase, int n_early, const WgPost* post, hipStream_t* post_stream, ReduceArgs* defer_reduce, int* defer_blocks);   // aon_train.hip
+hipError_t launch_wgrad_reduce2(const ReduceArgs& a0, int n0, const ReduceArgs& a1, int n1, hipStream_t stream);   // aon_train.hip
 
 // the weight-gradient jobs of one articulated level.  Lp / Lv: frequency levels of the network (10 / 4 by default).  With other degrees
 // the three encoding-fed column blocks come out in the kernels' 63 / 27-slot layout into `enc_tmp` (256 x 64 | 256 x 64 | 128 x 32
@@ -514,10 +624,24 @@ __global__ void art_remap_enc_kernel(const float* __restrict__ src, int lds, flo
 
 // grads: 40 parameter gradients (order of aon_pack_art_mlp, full shapes) + 3 latent gradients (shape 128, appearance 128,
 // articulation 32); params / latents: the forward's inputs (needed for the latent-column products).
+// Round 6: a level's second stage NOT launched by its own call but handed back, so that the two levels' grouped kernels run back to back
+// and ONE second stage serves both (launch_art_wgrad_post2): reduce -> un-folding products -> finishing kernel were three launches in a
+// row per level with the chip all but idle, level 0's in front of level 1's grouped kernel.  Opaque to the C ABI layer (kArtWgDeferredBytes).
+struct ArtWgDeferred {
+  ReduceArgs reduce;
+  int reduce_blocks;
+  int n_unfold;           // 3 (folded form) or 0
+  FoldGemm unfold[3];
+  ArtFinishArgs finish;
+  int finish_blocks;
+};
+constexpr int kArtWgDeferredBytes = 4096;   // (aon_capi.hip keeps two of these on its stack)
+static_assert(sizeof(ArtWgDeferred) <= kArtWgDeferredBytes && alignof(ArtWgDeferred) <= 16, "ArtWgDeferred outgrew its storage in aon_capi.hip");
+
 hipError_t launch_art_wgrad(const float* planes, const float* dplanes, const float* d_raw, const float* dxp, int64_t Np,
                             const float* const* params, const float* shape, const float* app, const float* art,
                             float* const* grads, float* g_shape, float* g_app, float* g_art, float* ws, hipStream_t stream, const WgAux* aux,
-                            int Lp, int Lv, const void* packed_bwd, int phase, bool accumulate_latents, const WgPost* post) {
+                            int Lp, int Lv, const void* packed_bwd, int phase, bool accumulate_latents, const WgPost* post, ArtWgDeferred* defer) {
   // packed_bwd: the transposed stream the chain of these planes ran with -- its FORM says whether the planes carry bottleneck rows (null: literal)
   if (packed_bwd && stream_form(packed_bwd) == kFormUnknown) return hipErrorInvalidValue;   // (a copy nobody declared)
   const bool fold = packed_bwd && stream_form(packed_bwd) == kFormFolded;
@@ -541,7 +665,9 @@ hipError_t launch_art_wgrad(const float* planes, const float* dplanes, const flo
   const int OH[8] = {0, 1, 2, 2, 3, 4, 5, 5};
   // head jobs 0..2 (density head on H7, rgb head on V3, the sums of d_raw) read forward planes and d_raw only: independent of the chain
   hipStream_t caller_stream = stream;
-  if (hipError_t e = run_wgrad_plan(L, n, H, 6, O, OH, 8, planes, dplanes, kAPlRows, Np, ws, stream, aux, phase, 3, phase == kWgEarly ? nullptr : post, &stream); e != hipSuccess)
+  if (defer && (phase == kWgEarly || post || !dflt)) return hipErrorInvalidValue;   // (other degrees: remap launches between the stages; not deferred)
+  if (hipError_t e = run_wgrad_plan(L, n, H, 6, O, OH, 8, planes, dplanes, kAPlRows, Np, ws, stream, aux, phase, 3, phase == kWgEarly ? nullptr : post, &stream,
+                                    defer ? &defer->reduce : nullptr, defer ? &defer->reduce_blocks : nullptr); e != hipSuccess)
     return e;
   if (phase == kWgEarly) return hipSuccess;
   // (from here on `stream` is the stream of the second stage: the caller's, or the side stream of `post`)
@@ -556,7 +682,10 @@ hipError_t launch_art_wgrad(const float* planes, const float* dplanes, const flo
     remap(enc_tmp + 2 * 256 * 64, 32, grads[26], 256 + V + 128, 256, 128, Lv, 4);
     if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
   }
-  if (fold)   // bottleneck_layer's and views_linear.0[:, :256]'s gradients from (dW', db' = views_linear.0.bias's gradient)
+  if (defer) {
+    defer->n_unfold = fold ? 3 : 0;
+    if (fold) unfold_view_jobs(fold_tmp, grads[27], params[26], 256 + V + 128, params[34], params[35], grads[26], 256 + V + 128, grads[34], grads[35], defer->unfold);
+  } else if (fold)   // bottleneck_layer's and views_linear.0[:, :256]'s gradients from (dW', db' = views_linear.0.bias's gradient)
     if (hipError_t e = launch_unfold_view(fold_tmp, grads[27], params[26], 256 + V + 128, params[34], params[35], grads[26], 256 + V + 128, grads[34], grads[35], stream);
         e != hipSuccess) return e;
   // latent columns of the weights and the latent gradients, both from the bias gradients
@@ -582,10 +711,42 @@ hipError_t launch_art_wgrad(const float* planes, const float* dplanes, const flo
   outer(2, grads[11], shape, grads[10], 256, 128, P + 128, P);
   outer(3, grads[21], shape, grads[20], 256, 128, 256 + P + 128, 256 + P);
   outer(4, grads[27], app, grads[26], 128, 128, 256 + V + 128, 256 + V);
+  if (defer) {
+    defer->finish = F;
+    defer->finish_blocks = blk;
+    return hipSuccess;
+  }
   art_finish_kernel<<<dim3(blk), dim3(1024), 0, stream>>>(F);
   if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
   if (post && post->side) return hipEventRecord(post->side->join, stream);   // the caller (or the next level's second stage) waits for this
   return hipSuccess;
+}
+
+// The deferred second stages of two levels: ONE reduce launch, ONE launch of the (up to) six un-folding products, then the finishing
+// kernels of both levels as one launch (art_finish2_kernel; level 1's latent gradients are added onto level 0's).  Every block of every launch does what it does in the per-level
+// launches: same bits.
+hipError_t launch_art_wgrad_post2(const ArtWgDeferred* d0, const ArtWgDeferred* d1, hipStream_t stream) {
+  if (hipError_t e = launch_wgrad_reduce2(d0->reduce, d0->reduce_blocks, d1->reduce, d1->reduce_blocks, stream); e != hipSuccess) return e;
+  FoldGemm jobs[6];
+  int n = 0;
+  for (const ArtWgDeferred* d : {d0, d1})
+    for (int j = 0; j < d->n_unfold; ++j) jobs[n++] = d->unfold[j];
+  if (n > 0)
+    if (hipError_t e = launch_fold_gemms(jobs, n, stream); e != hipSuccess) return e;
+  // one finishing launch when level 1 adds onto level 0's latent gradients in place (the training step's arrangement), else two
+  bool chained = true;
+  for (int k = 0; k < 3; ++k)
+  {
+    const LatentJob &a = d0->finish.lat[k], &b = d1->finish.lat[k];
+    chained = chained && b.add == a.out && b.out == a.out && b.L == a.L && b.npairs == a.npairs;
+    for (int pi = 0; pi < a.npairs && chained; ++pi) chained = b.M[pi] == a.M[pi];
+  }
+  if (chained && d0->finish_blocks >= 3 && d1->finish_blocks >= 3) {
+    art_finish2_kernel<<<dim3(d0->finish_blocks + d1->finish_blocks - 3), dim3(1024), 0, stream>>>(d0->finish, d1->finish, d0->finish_blocks);
+    return hipGetLastError();
+  }
+  for (const ArtWgDeferred* d : {d0, d1}) art_finish_kernel<<<dim3(d->finish_blocks), dim3(1024), 0, stream>>>(d->finish);
+  return hipGetLastError();
 }
 
 }  // namespace aon

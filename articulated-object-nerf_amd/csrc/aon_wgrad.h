@@ -428,11 +428,11 @@ struct ReduceArgs {
 };
 
 #ifdef AON_WGRAD_KERNELS
-__global__ void __launch_bounds__(256) wgrad_reduce_kernel(ReduceArgs a) {
-  __shared__ f32x4 red[4][64];
+// (the body of one block of the second stage; `bx`: the block's index in ITS level's launch)
+__device__ __forceinline__ void wgrad_reduce_block(const ReduceArgs& a, const int bx, f32x4 (*red)[64]) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if ((int)blockIdx.x >= a.head_blk_begin) {
-    const HeadOut& H = a.head[(int)blockIdx.x - a.head_blk_begin];
+  if (bx >= a.head_blk_begin) {
+    const HeadOut& H = a.head[bx - a.head_blk_begin];
     for (int idx = threadIdx.x; idx < H.rows * H.nchan; idx += 256) {
       const int row = idx / H.nchan, c = idx % H.nchan;
       const double* P = reinterpret_cast<const double*>(a.ws + H.part_off);
@@ -458,9 +458,9 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(ReduceArgs a) {
   int e = 0;
 #pragma unroll 1
   for (int t = 1; t < a.nred; ++t)
-    if ((int)blockIdx.x >= a.red[t].blk_begin) e = t;
+    if (bx >= a.red[t].blk_begin) e = t;
   const WgReduce& R = a.red[e];
-  const int blk = (int)blockIdx.x - R.blk_begin;
+  const int blk = bx - R.blk_begin;
   if (blk < R.nblk_w) {
     const int idx = (blk * 64 + lane) * 4;  // first of 4 consecutive columns of one row (K is a multiple of 32)
     if (idx < R.M * R.K) {
@@ -515,6 +515,20 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(ReduceArgs a) {
     }
   }
 }
+
+__global__ void __launch_bounds__(256) wgrad_reduce_kernel(ReduceArgs a) {
+  __shared__ f32x4 red[4][64];
+  wgrad_reduce_block(a, (int)blockIdx.x, red);
+}
+
+// The second stages of TWO levels as one launch (round 6: both levels' grouped kernels run back to back and their partial sums are
+// reduced together): blocks [0, n0) are level 0's, the rest level 1's; each block does exactly what it does in a launch of its own.
+__global__ void __launch_bounds__(256) wgrad_reduce2_kernel(ReduceArgs a0, ReduceArgs a1, int n0) {
+  __shared__ f32x4 red[4][64];
+  if ((int)blockIdx.x < n0) wgrad_reduce_block(a0, (int)blockIdx.x, red);
+  else wgrad_reduce_block(a1, (int)blockIdx.x - n0, red);
+}
+static_assert(2 * sizeof(ReduceArgs) + 16 <= 4096, "two levels' second-stage arguments must fit the kernel argument segment");
 
 #endif  // AON_WGRAD_KERNELS
 

@@ -451,3 +451,27 @@ def test_gradient_bits_are_pinned(dev):
     assert set(got) == set(want["hashes"])
     moved = [k for k in got if got[k] != want["hashes"][k]]
     assert not moved, f"{len(moved)} of {len(got)} tensors changed bits: {moved[:6]}"
+
+
+def test_gradient_bits_do_not_depend_on_the_schedule_switches(dev):
+    """Round 6's launch merges are schedule changes only: with every one switched off in the environment (the prologue as six pack calls,
+    a second stage per level, the early reductions joined behind the chain, one pack launch per network) a fresh process produces the
+    pinned gradient hashes too.  (The switches are read once per process, hence the subprocess.)"""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    want = json.load(open(os.path.join(root, "tests", "golden", "g24_gradient_hashes.json")))["hashes"]
+    env = dict(os.environ, AON_PACK_STEP="0", AON_PACK_MERGE="0", AON_POST_MERGE="0", AON_EARLY_JOIN="1", AON_ART_AUX_HEADS="0")
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "grad_hash.py")], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    got = {}
+    for line in out.stdout.splitlines():
+        parts = line.split()
+        if len(parts) >= 2 and len(parts[-1]) == 16:
+            got[" ".join(parts[:-1])] = parts[-1]
+    assert set(got) == set(want), (sorted(set(want) - set(got))[:4], sorted(set(got) - set(want))[:4])
+    moved = [k for k in got if got[k] != want[k]]
+    assert not moved, f"{len(moved)} of {len(got)} tensors changed bits with the merges switched off: {moved[:6]}"
