@@ -1657,7 +1657,8 @@ int aon_art_prepare_deg(const float* const* params_host, const float* shape, con
 
 // Round 6: everything a training step of a TWO-level articulated model packs, in one call -- both networks' forward streams, per-call blocks
 // and transposed streams -- with the four 128 x 256 x 256 fp64 products (W' of each network, once for its forward and once for its transposed
-// stream) as ONE launch in front instead of four launches of 17 us each in a row with their pack kernels (the step's prologue: 174 -> ~115 us).
+// stream) as ONE launch in front instead of four launches of 17 us each in a row with their pack kernels, then both networks' per-call blocks +
+// forward streams as one launch and both transposed streams as another (the step's prologue: 174 -> 68 us, profiles/r06_step_timeline.txt).
 // The same kernels on the same operands as the six separate calls: same bytes in every buffer.  packed_bwd_* may be NULL (no backward wanted).
 int aon_art_pack_step(const float* const* params_coarse_host, const float* const* params_fine_host, const float* shape, const float* appearance,
                       const float* articulation, int min_deg_point, int max_deg_point, int deg_view, void* packed_coarse, void* small_coarse,

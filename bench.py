@@ -394,7 +394,7 @@ def pmc_traffic_train(kernels, launches_per_step):
         return None, None, None
 
 
-def train_leg(dev, rank, world, distributed, steps=12, n_rays=4096):
+def train_leg(dev, rank, world, distributed, steps=24, n_rays=4096):
     """Informational only (never `value`): BASELINE config 5 per GPU -- articulated NeRF_AE_Art + code library, 4096 rays,
     randomized sampling, loss of model_autodecoder.py:395-477, HIP forward+backward, ONE flat gradient all-reduce over RCCL
     when world > 1 (parallel.allreduce_gradients), Adam.  Returns a dict for the JSON line (or {"error": ...})."""
@@ -447,7 +447,7 @@ def train_leg(dev, rank, world, distributed, steps=12, n_rays=4096):
                 torch.cuda.synchronize()
 
         def timed(profile=False):
-            for _ in range(2):   # two untimed steps: the first allocates the 26 GB of workspaces of a step from the driver
+            for _ in range(4):   # untimed steps: the first allocates the 26 GB of workspaces of a step from the driver; the clock settles over the next ones
                 step()
             fence()
             if profile:

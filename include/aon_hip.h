@@ -81,10 +81,12 @@ int aon_code_library_bwd(const float* const* g_rows_host, const int64_t* const* 
                          void* stream);
 
 /* Everything a training step of a TWO-level articulated model packs, in one call (round 6): aon_pack_art_mlp_deg + aon_art_prepare_deg +
- * aon_pack_art_mlp_bwd_deg for the coarse and the fine network -- the same kernels on the same operands, the same bytes in all six buffers --
- * with the four fp64 products W' = W_v0[:, :256] W_b (each network's, for its forward and for its transposed stream) as ONE launch in front
- * instead of one launch in front of each pack kernel.  packed_bwd_* may be NULL.  Buffer sizes: aon_art_packed_bytes / aon_art_small_bytes /
- * aon_art_bwd_packed_bytes. */
+ * aon_pack_art_mlp_bwd_deg for the coarse and the fine network -- every element computed by the same code on the same operands, the same
+ * bytes in all six buffers -- as THREE launches instead of ten: the four fp64 products W' = W_v0[:, :256] W_b (each network's, for its
+ * forward and for its transposed stream) as one, both networks' per-call blocks + forward streams as one, both transposed streams as one.
+ * packed_bwd_* may be NULL (then one pack launch per network and buffer, as the separate calls).  Buffer sizes: aon_art_packed_bytes /
+ * aon_art_small_bytes / aon_art_bwd_packed_bytes; all 16-byte aligned.  The form (folded / literal) is the process default at the time of
+ * the call, recorded for all six buffers. */
 int aon_art_pack_step(const float* const* params_coarse_host, const float* const* params_fine_host, const float* shape, const float* appearance,
                       const float* articulation, int min_deg_point, int max_deg_point, int deg_view, void* packed_coarse, void* small_coarse,
                       void* packed_bwd_coarse, void* packed_fine, void* small_fine, void* packed_bwd_fine, void* stream);
