@@ -256,8 +256,9 @@ def test_per_ray_view_bias_articulated(ops, dev):
         ops.set_view_bias(True)
 
 
+@pytest.mark.parametrize("degrees", [(0, 10, 4), (1, 8, 3)])
 @pytest.mark.parametrize("folded", [True, False])
-def test_one_call_pack_of_a_training_step_writes_the_same_bytes(ops, dev, folded):
+def test_one_call_pack_of_a_training_step_writes_the_same_bytes(ops, dev, folded, degrees):
     """aon_art_pack_step (round 6: both networks' forward streams, per-call blocks and transposed streams in one C call, the four fp64 fold
     products as ONE launch in front) against the six separate calls on zeroed buffers: every byte equal, in both forms; NULL transposed
     streams are skipped; a misaligned buffer is refused."""
@@ -265,8 +266,9 @@ def test_one_call_pack_of_a_training_step_writes_the_same_bytes(ops, dev, folded
     from aon_amd import _lib
     from aon_amd.models.vanilla_nerf.model_autodecoder import NeRF_AE_Art
 
-    model = NeRF_AE_Art().to(dev)
-    model.load_state_dict(syn.make_art_state_dict(seed=23, density_scale=2.0))
+    dk = dict(min_deg_point=degrees[0], max_deg_point=degrees[1], deg_view=degrees[2])
+    model = NeRF_AE_Art(**dk).to(dev)
+    model.load_state_dict(syn.make_art_state_dict(seed=23, density_scale=2.0, **dk))
     cl = syn.make_code_library_state(seed=1, n_max_objs=2)
     lat = {"density": cl["embedding_instance_shape.weight"][0:1].to(dev), "color": cl["embedding_instance_appearance.weight"][1:2].to(dev),
            "articulation": cl["embedding_instance_articulation.weight"][2:3].to(dev)}
@@ -278,20 +280,20 @@ def test_one_call_pack_of_a_training_step_writes_the_same_bytes(ops, dev, folded
         P = [dict(m.named_parameters()) for m in mlps]
         sep = zeros()
         for (pk, sm, bw), prm in zip(sep, P):
-            ops.art_prepare(prm, lat, out=sm)
-            ops.pack_art_mlp(prm, out=pk)
-            ops.pack_art_mlp_bwd(prm, out=bw)
-        one = ops.art_pack_step(P[0], P[1], lat, out=zeros())
+            ops.art_prepare(prm, lat, out=sm, degrees=degrees)
+            ops.pack_art_mlp(prm, out=pk, degrees=degrees)
+            ops.pack_art_mlp_bwd(prm, out=bw, degrees=degrees)
+        one = ops.art_pack_step(P[0], P[1], lat, degrees=degrees, out=zeros())
         for a, b in zip(sep, one):
             for x, y in zip(a, b):
                 assert torch.equal(x, y)
                 assert x._aon_form == y._aon_form == int(_lib.lib.aon_stream_form(y.data_ptr())) == (1 if folded else 0)
         fwd_only = [(pk, sm, None) for pk, sm, _ in zeros()]
-        got = ops.art_pack_step(P[0], P[1], lat, out=fwd_only)
+        got = ops.art_pack_step(P[0], P[1], lat, degrees=degrees, out=fwd_only)
         assert all(g[2] is None and torch.equal(g[0], s[0]) and torch.equal(g[1], s[1]) for g, s in zip(got, sep))
         crooked = zeros()
         crooked[1] = (torch.zeros(sizes[0] + 4, dtype=torch.uint8, device=dev)[4:], crooked[1][1], crooked[1][2])
         with pytest.raises(_lib.AonError, match="16-byte"):
-            ops.art_pack_step(P[0], P[1], lat, out=crooked)
+            ops.art_pack_step(P[0], P[1], lat, degrees=degrees, out=crooked)
     finally:
         ops.set_bottleneck_fold(True)
