@@ -293,4 +293,5 @@ def test_articulated_network_at_other_degrees(dev, golden, tag):
     # HIP 9.5e-4 where the fp32 oracle happens to sit at 1.2e-4 on this low-frequency field (HIP's absolute level is the same 5e-4..1e-3
     # as at the other degrees; its compositing backward alone is 2e-7 from the truth there, tests/diag/diag_art_draw.py, and the
     # deterministic pass of the same network is at 2.0x: tests/diag/diag_art_degrees_grads.py).  A wrong scale or column map is O(1).
-    assert_as_close_as_fp32(hip, truth, ref32, f"articulated, degrees {(mn, mx, dv)}", factor=10.0, floor=1e-4)
+    # (factor 10 for that one draw only; every other degree set is held to the factor 5 of all other gradient tests -- VERDICT r5)
+    assert_as_close_as_fp32(hip, truth, ref32, f"articulated, degrees {(mn, mx, dv)}", factor=10.0 if (mn, mx, dv) == (0, 6, 2) else 5.0, floor=1e-4)
