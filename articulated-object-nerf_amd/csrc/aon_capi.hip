@@ -58,7 +58,7 @@ hipError_t launch_wgrad_kind_bench(int kind, int nlayers, const float* planes, c
 struct WgAux { hipStream_t stream; hipEvent_t fork, join; };   // aon_wgrad.h: optional side stream of a level's head reductions
 struct WgPost { const WgAux* side; hipEvent_t wait_first; };   // aon_wgrad.h: a level's second stage + finishing kernels on a side stream
 hipError_t launch_vanilla_wgrad(const float* planes, const float* dplanes, const float* d_raw, int64_t Np, float* const* grads,
-                                float* ws, hipStream_t stream, const WgAux* aux, const void* packed_bwd, int phase = 0);
+                                float* ws, hipStream_t stream, const WgAux* aux, const void* packed_bwd, int phase = 0, const struct WgPost* post = nullptr);
 hipError_t launch_art_mlp_fwd_train(const char* packed, const float* small, const float* rays_o, const float* rays_d,
                                     const float* viewdirs, const float* t_vals, int64_t n_rays, int S, float* raw, float* planes,
                                     void* masks, hipStream_t stream, int64_t np_total = 0, const float* view_bias = nullptr);
@@ -1399,6 +1399,7 @@ int aon_render_bwd_ex(const void* packed_bwd_coarse, const void* packed_fwd_coar
   LevelFork fork(num_levels == 2 && (merged ? (overlap_mode == 2 || early_heads) : overlap_mode != 0), caller, "aon_render_bwd", merged);
   if (fork.rc()) return fork.rc();
   const aon::WgAux* side = early_heads ? fork.aux(0) : nullptr;
+  bool early_unjoined = false;   // (the early reductions are on the side stream and the caller's stream has not been told to wait for them)
   if (merged) {
     for (int l = 0; l < 2; ++l)
       if (int rc = composite_bwd(l, caller)) return rc;
@@ -1418,10 +1419,17 @@ int aon_render_bwd_ex(const void* packed_bwd_coarse, const void* packed_fwd_coar
                    "aon_render_bwd");
       }
       const int rj = check(hipEventRecord(side->join, side->stream), "aon_render_bwd");
-      const int rw = check(hipStreamWaitEvent(caller, side->join, 0), "aon_render_bwd");
+      // Who waits for the early reductions (round 6, as in aon_art_render_bwd_ex): nobody needs their partial sums before level 0's SECOND
+      // stage, so the caller's stream does not wait here -- level 0's grouped kernel follows the chain directly instead of sitting out the
+      // reductions' tail (~160 us past the chain's end at 4096 rays) -- and level 0's second stage waits for the event (WgPost::wait_first).
+      // AON_EARLY_JOIN=1 in the environment: wait here as before (A/B).
+      static const bool join_here = [] { const char* e = std::getenv("AON_EARLY_JOIN"); return e && e[0] == '1'; }();
+      early_unjoined = !join_here && !rc && !rj;
+      const int rw = early_unjoined ? AON_OK : check(hipStreamWaitEvent(caller, side->join, 0), "aon_render_bwd");
       if (rc || rj || rw) return rc ? rc : (rj ? rj : rw);
     }
   }
+  const aon::WgPost wait_early{nullptr, side ? side->join : nullptr};
   for (int l = 0; l < num_levels; ++l) {
     const TrainLevel& L = w.lvl[l];
     stream = merged ? caller : fork.stream(l);
@@ -1441,7 +1449,13 @@ int aon_render_bwd_ex(const void* packed_bwd_coarse, const void* packed_fwd_coar
         gl[0] = sc.grad_tmp[l]; gl[10] = gl[0] + 256 * 63; gl[16] = gl[10] + 256 * (256 + 63);
       }
       rc = check(aon::launch_vanilla_wgrad(L.planes, sc.dplanes[l], sc.d_raw[l], L.Np, gl, sc.wgrad_ws[l], stream, (merged && overlap_mode != 2) ? nullptr : fork.aux(l), pb[l],
-                                           side ? kWgRest : kWgAll), "aon_render_bwd");
+                                           side ? kWgRest : kWgAll, (early_unjoined && l == 0) ? &wait_early : nullptr), "aon_render_bwd");
+      if (early_unjoined && l == 0) {
+        // (level 0's second stage has been told to wait for the early reductions; if its call failed before that, the caller's stream waits here:
+        // no side-stream work is left behind the caller's view of this call)
+        if (rc) (void)hipStreamWaitEvent(caller, side->join, 0);
+        early_unjoined = false;
+      }
       if (!rc && g.other_degrees) {
         const int Lp = g.max_deg - g.min_deg, P = 3 + 6 * Lp, V = 3 + 6 * g.deg_view;
         auto remap = [&](const float* src, float* dst, int rows, int hidden, int Lx, int Lfull, int cols) {

@@ -592,7 +592,7 @@ float* wgrad_fold_tmp(float* ws) { return ws + (wgrad_workspace_bytes_impl() - (
 // packed_bwd: the transposed stream the chain of these planes ran with -- its FORM says whether the planes carry bottleneck rows, and the
 // folded form's buffer holds the raw W_v0[:, :256], W_b, b_b the un-folding needs.  Null: literal planes.
 hipError_t launch_vanilla_wgrad(const float* planes, const float* dplanes, const float* d_raw, int64_t Np, float* const* grads,
-                                float* ws, hipStream_t stream, const WgAux* aux, const void* packed_bwd, int phase) {
+                                float* ws, hipStream_t stream, const WgAux* aux, const void* packed_bwd, int phase, const WgPost* post) {
   WgLayerDesc L[kWgMaxJobs];
   if (packed_bwd && stream_form(packed_bwd) == kFormUnknown) return hipErrorInvalidValue;   // (a copy nobody declared)
   const bool fold = packed_bwd && stream_form(packed_bwd) == kFormFolded;
@@ -603,7 +603,7 @@ hipError_t launch_vanilla_wgrad(const float* planes, const float* dplanes, const
   const HeadOut O[4] = {{0, 256, 3, 1, 256, 1, grads[20]}, {0, 128, 0, 3, 128, 1, grads[22]}, {0, 1, 3, 1, 1, 1, grads[21]}, {0, 1, 0, 3, 1, 1, grads[23]}};
   const int OH[4] = {0, 1, 2, 2};
   // all three head jobs (density head on H7, rgb head on HV, the sums of d_raw) are independent of the chain: n_early = 3
-  if (hipError_t e = run_wgrad_plan(L, n, H, 3, O, OH, 4, planes, dplanes, kPlRows, Np, ws, stream, aux, phase, 3, nullptr, nullptr, nullptr, nullptr); e != hipSuccess) return e;
+  if (hipError_t e = run_wgrad_plan(L, n, H, 3, O, OH, 4, planes, dplanes, kPlRows, Np, ws, stream, aux, phase, 3, phase == kWgEarly ? nullptr : post, nullptr, nullptr, nullptr); e != hipSuccess) return e;
   if (!fold || phase == kWgEarly) return hipSuccess;
   const float* raw = reinterpret_cast<const float*>(static_cast<const char*>(packed_bwd) + kBwFOffWv);
   // (grads[16]'s row stride is the 27-slot layout's here: other view degrees write a slot-layout temporary first, aon_render_bwd_ex)
