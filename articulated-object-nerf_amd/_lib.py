@@ -84,6 +84,7 @@ _SIGS = {
     "aon_code_library_fwd": (_i, [_p, _p, _p, _p, _p, _p]),
     "aon_code_library_bwd": (_i, [_p, _p, _p, _p, _p, _p]),
     "aon_art_pack_step": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p]),
+    "aon_vanilla_pack_step": (_i, [_p, _p, _i, _i, _i, _p, _p, _p, _p, _p]),
     "aon_set_bwd_early_heads": (_i, [_i]),
     "aon_set_view_bias": (_i, [_i]),
     "aon_get_view_bias": (_i, []),

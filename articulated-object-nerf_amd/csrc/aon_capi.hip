@@ -13,7 +13,9 @@
 #include "aon_gmlp.h"
 
 namespace aon {
-hipError_t launch_pack_vanilla(const float* const* params, float* packed, hipStream_t stream, int pos_levels = 10, int view_levels = 4);
+hipError_t launch_pack_vanilla(const float* const* params, float* packed, hipStream_t stream, int pos_levels = 10, int view_levels = 4, bool fold_done = false);
+void vanilla_fold_jobs_fwd(const float* const* params, float* packed, int view_levels, FoldGemm jobs[2]);
+void vanilla_fold_jobs_bwd(const float* const* params, float* packed, int view_size, FoldGemm jobs[2]);
 hipError_t launch_mlp_fwd(const char* packed, const float* rays_o, const float* rays_d, const float* viewdirs,
                           const float* t_vals, int64_t n_rays, int S, float* raw, hipStream_t stream, const float* view_bias = nullptr);
 hipError_t launch_view_bias(const char* packed, const float* viewdirs, int64_t n_rays, float* out, hipStream_t stream);
@@ -41,7 +43,7 @@ hipError_t launch_mlp_fwd_train(const char* packed, const float* rays_o, const f
 hipError_t launch_composite_bwd(const float* raw, const float* t_vals, const float* dirs, const float* g_rgb, const float* g_acc,
                                 const float* g_depth, int64_t n_rays, int S, int white_bkgd, const ActParams& ap, float* d_raw,
                                 hipStream_t stream);
-hipError_t launch_pack_vanilla_bwd(const float* const* params, float* packed, hipStream_t stream, int pos_size = 63, int view_size = 27);
+hipError_t launch_pack_vanilla_bwd(const float* const* params, float* packed, hipStream_t stream, int pos_size = 63, int view_size = 27, bool fold_done = false);
 hipError_t launch_mlp_fwd_train_enc(const char* packed, const float* samples_enc, const float* viewdirs_enc, int64_t n_rays, int S, float* raw,
                                     float* planes, void* masks, hipStream_t stream, int64_t np_total = 0);
 int64_t bwd_stream_bytes();
@@ -58,7 +60,10 @@ hipError_t launch_wgrad_kind_bench(int kind, int nlayers, const float* planes, c
 struct WgAux { hipStream_t stream; hipEvent_t fork, join; };   // aon_wgrad.h: optional side stream of a level's head reductions
 struct WgPost { const WgAux* side; hipEvent_t wait_first; };   // aon_wgrad.h: a level's second stage + finishing kernels on a side stream
 hipError_t launch_vanilla_wgrad(const float* planes, const float* dplanes, const float* d_raw, int64_t Np, float* const* grads,
-                                float* ws, hipStream_t stream, const WgAux* aux, const void* packed_bwd, int phase = 0, const struct WgPost* post = nullptr);
+                                float* ws, hipStream_t stream, const WgAux* aux, const void* packed_bwd, int phase = 0, const struct WgPost* post = nullptr,
+                                struct VanillaWgDeferred* defer = nullptr);
+constexpr int kVanillaWgDeferredBytes = 4096;   // aon_train.hip (static_assert there)
+hipError_t launch_vanilla_wgrad_post2(const struct VanillaWgDeferred* d0, const struct VanillaWgDeferred* d1, hipStream_t stream);
 hipError_t launch_art_mlp_fwd_train(const char* packed, const float* small, const float* rays_o, const float* rays_d,
                                     const float* viewdirs, const float* t_vals, int64_t n_rays, int S, float* raw, float* planes,
                                     void* masks, hipStream_t stream, int64_t np_total = 0, const float* view_bias = nullptr);
@@ -523,6 +528,41 @@ int aon_pack_vanilla_mlp_bwd_deg(const float* const* params_host, int min_deg_po
     return fail(AON_E_INVALID, "aon_pack_vanilla_mlp_bwd_deg: up to 10 position and 4 view frequency levels");
   return check(aon::launch_pack_vanilla_bwd(params_host, static_cast<float*>(packed_bwd), (hipStream_t)stream, 3 + 6 * L, 3 + 6 * deg_view),
                "aon_pack_vanilla_mlp_bwd_deg");
+}
+
+// Round 6: everything a training step of a TWO-level vanilla model packs, in one call -- both networks' forward and transposed streams --
+// with the eight fp64 fold products (W' and b' of each network, once for its forward and once for its transposed stream) as ONE launch in
+// front instead of four launches of 13-16 us in a row with their pack kernels.  The same kernels on the same operands as the four separate
+// calls: same bytes in every buffer.  packed_bwd_* may be NULL (no backward wanted).
+int aon_vanilla_pack_step(const float* const* params_coarse_host, const float* const* params_fine_host, int min_deg_point, int max_deg_point, int deg_view,
+                          void* packed_coarse, void* packed_bwd_coarse, void* packed_fine, void* packed_bwd_fine, void* stream_) {
+  if (!params_coarse_host || !params_fine_host || !packed_coarse || !packed_fine) return fail(AON_E_INVALID, "aon_vanilla_pack_step: null pointer");
+  for (int i = 0; i < aon::kNumVanillaParams; ++i)
+    if (!params_coarse_host[i] || !params_fine_host[i]) return fail(AON_E_INVALID, "aon_vanilla_pack_step: null parameter pointer");
+  for (const void* p : {(const void*)packed_coarse, (const void*)packed_fine, (const void*)packed_bwd_coarse, (const void*)packed_bwd_fine})
+    if (reinterpret_cast<uintptr_t>(p) & 15) return fail(AON_E_INVALID, "aon_vanilla_pack_step: buffers must be 16-byte aligned");
+  const int L = max_deg_point - min_deg_point;
+  if (L < 0 || L > 10 || deg_view < 0 || deg_view > 4)
+    return fail(AON_E_INVALID, "aon_vanilla_pack_step: the streams hold up to 10 position and 4 view frequency levels");
+  hipStream_t stream = (hipStream_t)stream_;
+  const float* const* P[2] = {params_coarse_host, params_fine_host};
+  float* fwd[2] = {static_cast<float*>(packed_coarse), static_cast<float*>(packed_fine)};
+  float* bwd[2] = {static_cast<float*>(packed_bwd_coarse), static_cast<float*>(packed_bwd_fine)};
+  const bool folded = aon::fold_default() == aon::kFormFolded;
+  if (folded) {
+    aon::FoldGemm jobs[8];
+    int n = 0;
+    for (int l = 0; l < 2; ++l) { aon::vanilla_fold_jobs_fwd(P[l], fwd[l], deg_view, jobs + n); n += 2; }
+    for (int l = 0; l < 2; ++l)
+      if (bwd[l]) { aon::vanilla_fold_jobs_bwd(P[l], bwd[l], 3 + 6 * deg_view, jobs + n); n += 2; }
+    if (int rc = check(aon::launch_fold_gemms(jobs, n, stream), "aon_vanilla_pack_step")) return rc;
+  }
+  for (int l = 0; l < 2; ++l)
+    if (int rc = check(aon::launch_pack_vanilla(P[l], fwd[l], stream, L, deg_view, folded), "aon_vanilla_pack_step")) return rc;
+  for (int l = 0; l < 2; ++l)
+    if (bwd[l])
+      if (int rc = check(aon::launch_pack_vanilla_bwd(P[l], bwd[l], stream, 3 + 6 * L, 3 + 6 * deg_view, folded), "aon_vanilla_pack_step")) return rc;
+  return AON_OK;
 }
 
 int64_t aon_train_mask_bytes(int64_t Np) { return (int64_t)aon::kMaskLayers * Np * 2 * 16; }
@@ -1430,6 +1470,13 @@ int aon_render_bwd_ex(const void* packed_bwd_coarse, const void* packed_fwd_coar
     }
   }
   const aon::WgPost wait_early{nullptr, side ? side->join : nullptr};
+  // Round 6: ONE second stage for both levels, as in aon_art_render_bwd_ex (the grouped kernels back to back, then one reduce launch and one
+  // launch of the six un-folding products; same bits).  Not with other encoding degrees (remap launches between a level's stages).
+  // AON_POST_MERGE=0 in the environment: per level as before (A/B).
+  static const bool post_merge_env = [] { const char* e = std::getenv("AON_POST_MERGE"); return !(e && e[0] == '0'); }();
+  const bool post_merged = merged && post_merge_env && !g.other_degrees;
+  alignas(16) unsigned char defer_store[2][aon::kVanillaWgDeferredBytes];
+  auto deferred = [&](int l) { return reinterpret_cast<aon::VanillaWgDeferred*>(defer_store[l]); };
   for (int l = 0; l < num_levels; ++l) {
     const TrainLevel& L = w.lvl[l];
     stream = merged ? caller : fork.stream(l);
@@ -1449,8 +1496,11 @@ int aon_render_bwd_ex(const void* packed_bwd_coarse, const void* packed_fwd_coar
         gl[0] = sc.grad_tmp[l]; gl[10] = gl[0] + 256 * 63; gl[16] = gl[10] + 256 * (256 + 63);
       }
       rc = check(aon::launch_vanilla_wgrad(L.planes, sc.dplanes[l], sc.d_raw[l], L.Np, gl, sc.wgrad_ws[l], stream, (merged && overlap_mode != 2) ? nullptr : fork.aux(l), pb[l],
-                                           side ? kWgRest : kWgAll, (early_unjoined && l == 0) ? &wait_early : nullptr), "aon_render_bwd");
-      if (early_unjoined && l == 0) {
+                                           side ? kWgRest : kWgAll, (early_unjoined && l == 0 && !post_merged) ? &wait_early : nullptr,
+                                           post_merged ? deferred(l) : nullptr), "aon_render_bwd");
+      if (early_unjoined && post_merged) {
+        if (rc) { (void)hipStreamWaitEvent(caller, side->join, 0); early_unjoined = false; }   // (else: joined in front of the merged second stage below)
+      } else if (early_unjoined && l == 0) {
         // (level 0's second stage has been told to wait for the early reductions; if its call failed before that, the caller's stream waits here:
         // no side-stream work is left behind the caller's view of this call)
         if (rc) (void)hipStreamWaitEvent(caller, side->join, 0);
@@ -1469,6 +1519,12 @@ int aon_render_bwd_ex(const void* packed_bwd_coarse, const void* packed_fwd_coar
       }
     }
     if (rc) return rc;
+  }
+  if (post_merged) {
+    if (early_unjoined)
+      if (int rc = check(hipStreamWaitEvent(caller, side->join, 0), "aon_render_bwd")) return rc;
+    KTimer timer(kWgrad, caller, 0);
+    if (int rc = check(aon::launch_vanilla_wgrad_post2(deferred(0), deferred(1), caller), "aon_render_bwd")) return rc;
   }
   if (int rc = fork.join()) return rc;   // the caller's stream continues after both levels
   return AON_OK;

@@ -26,11 +26,13 @@ struct FoldGemm {
   int M, N, K;
   const float* u; const float* v;
 };
-constexpr int kFoldMaxJobs = 6;
+constexpr int kFoldMaxJobs = 8;
 hipError_t launch_fold_gemms(const FoldGemm* jobs, int njobs, hipStream_t stream);
 
 // Wf (128, 256) = Wv[:, :256] Wb,  bf (128) = Wv[:, :256] bb + bv      (Wv: (128, ldv), Wb: (256, 256))
 hipError_t launch_fold_view(const float* Wv, int ldv, const float* bv, const float* Wb, const float* bb, float* Wf, float* bf, hipStream_t stream);
+// ... its two products as jobs, for a caller that folds several networks / buffers in one launch (launch_fold_gemms)
+void fold_view_jobs(const float* Wv, int ldv, const float* bv, const float* Wb, const float* bb, float* Wf, float* bf, FoldGemm jobs[2]);
 // the parameter gradients the reference's autograd would produce, from the folded layer's:
 //   dWb (256, 256) = Wv[:, :256]^T dWf        dbb (256) = Wv[:, :256]^T dbf        dWv[:, :256] (ld ld_dwv) = dWf Wb^T + dbf (x) bb
 // (dbv = dbf is written by the weight-gradient kernels directly)

@@ -101,11 +101,14 @@ hipError_t launch_fold_gemms(const FoldGemm* jobs, int njobs, hipStream_t stream
   return hipGetLastError();
 }
 
+void fold_view_jobs(const float* Wv, int ldv, const float* bv, const float* Wb, const float* bb, float* Wf, float* bf, FoldGemm jobs[2]) {
+  jobs[0] = FoldGemm{Wv, ldv, 1, Wb, 256, 1, Wf, 256, 128, 256, 256, nullptr, nullptr};      // W'[o][i] = sum_k Wv[o][k] Wb[k][i]
+  jobs[1] = FoldGemm{Wv, ldv, 1, bb, 1, 0, bf, 1, 128, 1, 256, bv, nullptr};                  // b'[o] = sum_k Wv[o][k] bb[k] + bv[o]
+}
+
 hipError_t launch_fold_view(const float* Wv, int ldv, const float* bv, const float* Wb, const float* bb, float* Wf, float* bf, hipStream_t stream) {
-  const FoldGemm jobs[2] = {
-      {Wv, ldv, 1, Wb, 256, 1, Wf, 256, 128, 256, 256, nullptr, nullptr},      // W'[o][i] = sum_k Wv[o][k] Wb[k][i]
-      {Wv, ldv, 1, bb, 1, 0, bf, 1, 128, 1, 256, bv, nullptr},                  // b'[o] = sum_k Wv[o][k] bb[k] + bv[o]
-  };
+  FoldGemm jobs[2];
+  fold_view_jobs(Wv, ldv, bv, Wb, bb, Wf, bf, jobs);
   return launch_fold_gemms(jobs, 2, stream);
 }
 

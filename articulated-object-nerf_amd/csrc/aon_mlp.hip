@@ -358,15 +358,24 @@ __global__ void __launch_bounds__(256) mlp_fwd_kernel(MlpArgs args) {
 // host launchers (called from the C ABI)
 // ---------------------------------------------------------------------------------------------
 // The form packed is the process default at the time of the call (aon_set_bottleneck_fold), remembered for `packed` (stream_form).
-hipError_t launch_pack_vanilla(const float* const* params, float* packed, hipStream_t stream, int pos_levels, int view_levels) {
+// W' and b' of one network into the fold area of its forward stream (the jobs launch_pack_vanilla runs unless told they have been run)
+void vanilla_fold_jobs_fwd(const float* const* params, float* packed, int view_levels, FoldGemm jobs[2]) {
+  float* Wf = packed + kFoldTmpOff / 4;
+  fold_view_jobs(params[16], 256 + 3 + 6 * view_levels, params[17], params[18], params[19], Wf, Wf + 128 * 256, jobs);
+}
+
+hipError_t launch_pack_vanilla(const float* const* params, float* packed, hipStream_t stream, int pos_levels, int view_levels, bool fold_done) {
   PackArgs a;
   for (int i = 0; i < kNumVanillaParams; ++i) a.p[i] = params[i];
   const int64_t n = kStreamBytes / 4 + kSmallFloats;
   const int form = fold_default();
   set_stream_form(packed, form);
   if (form == kFormFolded) {
-    float* Wf = packed + kFoldTmpOff / 4;
-    if (hipError_t e = launch_fold_view(params[16], 256 + 3 + 6 * view_levels, params[17], params[18], params[19], Wf, Wf + 128 * 256, stream); e != hipSuccess) return e;
+    if (!fold_done) {   // (aon_vanilla_pack_step runs the products of both networks and both directions as ONE launch in front)
+      FoldGemm jobs[2];
+      vanilla_fold_jobs_fwd(params, packed, view_levels, jobs);
+      if (hipError_t e = launch_fold_gemms(jobs, 2, stream); e != hipSuccess) return e;
+    }
     pack_vanilla_kernel<true><<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream>>>(a, packed, pos_levels, view_levels);
   } else {
     pack_vanilla_kernel<false><<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream>>>(a, packed, pos_levels, view_levels);

@@ -389,14 +389,22 @@ __global__ void __launch_bounds__(256) mlp_bwd_chain_kernel(BwdArgs args) {
 int num_cus();  // aon_mlp.hip
 
 // The form packed is the process default at the time of the call (aon_set_bottleneck_fold), remembered for `packed` (stream_form).
-hipError_t launch_pack_vanilla_bwd(const float* const* params, float* packed, hipStream_t stream, int pos_size, int view_size) {
+void vanilla_fold_jobs_bwd(const float* const* params, float* packed, int view_size, FoldGemm jobs[2]) {
+  float* Wf = packed + kBwFOffWf / 4;
+  fold_view_jobs(params[16], 256 + view_size, params[17], params[18], params[19], Wf, Wf + 128 * 256, jobs);
+}
+
+hipError_t launch_pack_vanilla_bwd(const float* const* params, float* packed, hipStream_t stream, int pos_size, int view_size, bool fold_done) {
   PackArgs24 a;
   for (int i = 0; i < kNumVanillaParams; ++i) a.p[i] = params[i];
   const int form = fold_default();
   set_stream_form(packed, form);
   if (form == kFormFolded) {
-    float* Wf = packed + kBwFOffWf / 4;
-    if (hipError_t e = launch_fold_view(params[16], 256 + view_size, params[17], params[18], params[19], Wf, Wf + 128 * 256, stream); e != hipSuccess) return e;
+    if (!fold_done) {
+      FoldGemm jobs[2];
+      vanilla_fold_jobs_bwd(params, packed, view_size, jobs);
+      if (hipError_t e = launch_fold_gemms(jobs, 2, stream); e != hipSuccess) return e;
+    }
     const int64_t n = kBwFOffWf / 4;   // the stream and the raw copies behind it
     pack_vanilla_bwd_kernel<true><<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream>>>(a, packed, pos_size, view_size);
   } else {
@@ -591,9 +599,22 @@ float* wgrad_fold_tmp(float* ws) { return ws + (wgrad_workspace_bytes_impl() - (
 
 // packed_bwd: the transposed stream the chain of these planes ran with -- its FORM says whether the planes carry bottleneck rows, and the
 // folded form's buffer holds the raw W_v0[:, :256], W_b, b_b the un-folding needs.  Null: literal planes.
+// Round 6: a vanilla level's second stage handed back instead of launched (the two levels' grouped kernels then run back to back and ONE
+// reduce launch + ONE launch of the un-folding products serve both: launch_vanilla_wgrad_post2); see ArtWgDeferred in aon_train_art.hip.
+struct VanillaWgDeferred {
+  ReduceArgs reduce;
+  int reduce_blocks;
+  int n_unfold;           // 3 (folded form) or 0
+  FoldGemm unfold[3];
+};
+constexpr int kVanillaWgDeferredBytes = 4096;   // (aon_capi.hip keeps two of these on its stack)
+static_assert(sizeof(VanillaWgDeferred) <= kVanillaWgDeferredBytes && alignof(VanillaWgDeferred) <= 16, "VanillaWgDeferred outgrew its storage in aon_capi.hip");
+
 hipError_t launch_vanilla_wgrad(const float* planes, const float* dplanes, const float* d_raw, int64_t Np, float* const* grads,
-                                float* ws, hipStream_t stream, const WgAux* aux, const void* packed_bwd, int phase, const WgPost* post) {
+                                float* ws, hipStream_t stream, const WgAux* aux, const void* packed_bwd, int phase, const WgPost* post,
+                                VanillaWgDeferred* defer) {
   WgLayerDesc L[kWgMaxJobs];
+  if (defer && (phase == kWgEarly || post)) return hipErrorInvalidValue;
   if (packed_bwd && stream_form(packed_bwd) == kFormUnknown) return hipErrorInvalidValue;   // (a copy nobody declared)
   const bool fold = packed_bwd && stream_form(packed_bwd) == kFormFolded;
   float* fold_tmp = fold ? wgrad_fold_tmp(ws) : nullptr;
@@ -603,11 +624,29 @@ hipError_t launch_vanilla_wgrad(const float* planes, const float* dplanes, const
   const HeadOut O[4] = {{0, 256, 3, 1, 256, 1, grads[20]}, {0, 128, 0, 3, 128, 1, grads[22]}, {0, 1, 3, 1, 1, 1, grads[21]}, {0, 1, 0, 3, 1, 1, grads[23]}};
   const int OH[4] = {0, 1, 2, 2};
   // all three head jobs (density head on H7, rgb head on HV, the sums of d_raw) are independent of the chain: n_early = 3
-  if (hipError_t e = run_wgrad_plan(L, n, H, 3, O, OH, 4, planes, dplanes, kPlRows, Np, ws, stream, aux, phase, 3, phase == kWgEarly ? nullptr : post, nullptr, nullptr, nullptr); e != hipSuccess) return e;
+  if (hipError_t e = run_wgrad_plan(L, n, H, 3, O, OH, 4, planes, dplanes, kPlRows, Np, ws, stream, aux, phase, 3, phase == kWgEarly ? nullptr : post, nullptr,
+                                    defer ? &defer->reduce : nullptr, defer ? &defer->reduce_blocks : nullptr); e != hipSuccess) return e;
+  if (defer) defer->n_unfold = 0;
   if (!fold || phase == kWgEarly) return hipSuccess;
   const float* raw = reinterpret_cast<const float*>(static_cast<const char*>(packed_bwd) + kBwFOffWv);
   // (grads[16]'s row stride is the 27-slot layout's here: other view degrees write a slot-layout temporary first, aon_render_bwd_ex)
+  if (defer) {
+    defer->n_unfold = 3;
+    unfold_view_jobs(fold_tmp, grads[17], raw, 256, raw + 128 * 256, raw + 128 * 256 + 256 * 256, grads[16], 256 + kViewEnc, grads[18], grads[19], defer->unfold);
+    return hipSuccess;
+  }
   return launch_unfold_view(fold_tmp, grads[17], raw, 256, raw + 128 * 256, raw + 128 * 256 + 256 * 256, grads[16], 256 + kViewEnc, grads[18], grads[19], stream);
+}
+
+// the deferred second stages of two vanilla levels: one reduce launch, one launch of the (up to) six un-folding products; every block of
+// either does what it does in the per-level launches (same bits)
+hipError_t launch_vanilla_wgrad_post2(const VanillaWgDeferred* d0, const VanillaWgDeferred* d1, hipStream_t stream) {
+  if (hipError_t e = launch_wgrad_reduce2(d0->reduce, d0->reduce_blocks, d1->reduce, d1->reduce_blocks, stream); e != hipSuccess) return e;
+  FoldGemm jobs[6];
+  int n = 0;
+  for (const VanillaWgDeferred* d : {d0, d1})
+    for (int j = 0; j < d->n_unfold; ++j) jobs[n++] = d->unfold[j];
+  return n > 0 ? launch_fold_gemms(jobs, n, stream) : hipSuccess;
 }
 
 

@@ -10,6 +10,8 @@ interface, forward and backward.  Sample counts, ``lindisp`` and ``noise_std`` a
 """
 from __future__ import annotations
 
+import os as _os
+
 import torch
 import torch.nn as nn
 import torch.nn.init as init
@@ -310,9 +312,16 @@ class NeRF(nn.Module):
             if n == 0:
                 raise ValueError("empty ray batch in training mode")
             mlps = [self.coarse_mlp, self.fine_mlp][: self.num_levels]
-            bwd, bwd_ready = packed_bwd_aside(mlps)
-            fine_pk, fine_ready = run_aside(rays_o.device, "fine", lambda: (mlps[1].packed(True),)) if len(mlps) == 2 else (None, None)
-            packs = [(mlps[0].packed(True), bwd[0])] + ([(fine_pk[0], bwd[1])] if len(mlps) == 2 else [])
+            bwd_ready = fine_ready = None
+            degs = [(m.min_deg_point, m.max_deg_point, m.deg_view) for m in mlps]
+            if len(mlps) == 2 and pack_aside_mode() == 0 and degs[0] == degs[1] and _os.environ.get("AON_PACK_STEP", "1") != "0":
+                # round 6: both networks' forward and transposed streams in ONE C call -- the eight fp64 fold products as one launch in front
+                # instead of four in a row with their pack kernels (aon_vanilla_pack_step; the same bytes in every buffer)
+                packs = ops.vanilla_pack_step(dict(mlps[0].named_parameters()), dict(mlps[1].named_parameters()), degrees=degs[0])
+            else:
+                bwd, bwd_ready = packed_bwd_aside(mlps)
+                fine_pk, fine_ready = run_aside(rays_o.device, "fine", lambda: (mlps[1].packed(True),)) if len(mlps) == 2 else (None, None)
+                packs = [(mlps[0].packed(True), bwd[0])] + ([(fine_pk[0], bwd[1])] if len(mlps) == 2 else [])
             if fine_ready is not None:
                 torch.cuda.current_stream(rays_o.device).wait_event(fine_ready)
             if bwd_ready is not None and pack_aside_mode() == 2:

@@ -640,6 +640,35 @@ def art_pack_step(params_c: dict, params_f: dict, latents: dict, degrees=(0, 10,
     return [(_tag(pk[l]), _tag(sm[l]), None if bw[l] is None else _tag(bw[l])) for l in range(2)]
 
 
+def vanilla_pack_step(params_c: dict, params_f: dict, degrees=(0, 10, 4), with_bwd: bool = True, out=None):
+    """pack_vanilla_mlp (+ pack_vanilla_mlp_bwd) of the coarse and the fine network in ONE C call (aon_vanilla_pack_step): the eight fp64
+    fold products as one launch in front.  -> [(packed, packed_bwd or None)] per level, tagged with their form; fresh buffers unless ``out`` =
+    [(packed, packed_bwd or None)] x 2 hands in uint8 buffers of the library's sizes."""
+    shapes = vanilla_param_shapes(degrees)
+    arrs, keep = [], []
+    for params in (params_c, params_f):
+        tensors = [_f32(params[name].detach(), name) for name in VANILLA_PARAM_ORDER]
+        for name, t in zip(VANILLA_PARAM_ORDER, tensors):
+            if tuple(t.shape) != shapes[name]:
+                raise ValueError(f"{name}: shape {tuple(t.shape)} != {shapes[name]} for encoding degrees {tuple(degrees)}")
+        keep.append(tensors)
+        arrs.append((C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors]))
+    dev = keep[0][0].device
+    sizes = (packed_bytes(), int(lib.aon_bwd_packed_bytes()))
+    if out is not None:
+        pk, bw = ([o[i] for o in out] for i in range(2))
+        for got, want in zip(pk + bw, [sizes[0]] * 2 + [sizes[1]] * 2):
+            if got is not None and (got.dtype != torch.uint8 or got.numel() != want or got.device != dev or not got.is_contiguous()):
+                raise ValueError(f"vanilla_pack_step: out buffers must be contiguous uint8 tensors of the library's sizes on {dev}")
+    else:
+        pk = [torch.empty(sizes[0], dtype=torch.uint8, device=dev) for _ in range(2)]
+        bw = [torch.empty(sizes[1], dtype=torch.uint8, device=dev) if with_bwd else None for _ in range(2)]
+    with torch.cuda.device(dev):
+        check(lib.aon_vanilla_pack_step(arrs[0], arrs[1], int(degrees[0]), int(degrees[1]), int(degrees[2]), _ptr(pk[0]), _ptr(bw[0]), _ptr(pk[1]), _ptr(bw[1]),
+                                        _stream()), "aon_vanilla_pack_step")
+    return [(_tag(pk[l]), None if bw[l] is None else _tag(bw[l])) for l in range(2)]
+
+
 def art_mlp_fwd(packed, small, rays_o, rays_d, viewdirs, t_vals):
     o, d, v, t = _f32(rays_o, "rays_o"), _f32(rays_d, "rays_d"), _f32(viewdirs, "viewdirs"), _f32(t_vals, "t_vals")
     n, S = t.shape

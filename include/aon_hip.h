@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define AON_ABI_VERSION 5   /* 5: + aon_adam_step, aon_code_library_fwd / _bwd, aon_art_pack_step, aon_stream_form, aon_declare_stream_form; a packed pointer this process never
+#define AON_ABI_VERSION 5   /* 5: + aon_adam_step, aon_code_library_fwd / _bwd, aon_art_pack_step, aon_vanilla_pack_step, aon_stream_form, aon_declare_stream_form; a packed pointer this process never
                                packed or declared is refused (AON_E_INVALID / HIP "invalid value") instead of being taken to have the default form */
 
 #define AON_OK 0
@@ -90,6 +90,13 @@ int aon_code_library_bwd(const float* const* g_rows_host, const int64_t* const* 
 int aon_art_pack_step(const float* const* params_coarse_host, const float* const* params_fine_host, const float* shape, const float* appearance,
                       const float* articulation, int min_deg_point, int max_deg_point, int deg_view, void* packed_coarse, void* small_coarse,
                       void* packed_bwd_coarse, void* packed_fine, void* small_fine, void* packed_bwd_fine, void* stream);
+
+/* The vanilla counterpart: aon_pack_vanilla_mlp_deg + aon_pack_vanilla_mlp_bwd_deg for the coarse and the fine network (models/vanilla_nerf/
+ * model.py:147-199 holds two NeRFMLPs), the same bytes in all four buffers, with the eight fp64 fold products (W', b' of each network, for
+ * its forward and for its transposed stream) as ONE launch in front.  packed_bwd_* may be NULL.  Buffer sizes: aon_mlp_packed_bytes /
+ * aon_bwd_packed_bytes; 16-byte aligned. */
+int aon_vanilla_pack_step(const float* const* params_coarse_host, const float* const* params_fine_host, int min_deg_point, int max_deg_point,
+                          int deg_view, void* packed_coarse, void* packed_bwd_coarse, void* packed_fine, void* packed_bwd_fine, void* stream);
 
 /* get_ray_directions alone (ray_utils.py:71-90): directions (H*W,3), un-normalised camera-space. */
 int aon_ray_directions(int H, int W, float focal, float* directions, void* stream);

@@ -305,6 +305,15 @@ def test_round6_entry_points_validate_without_gpu():
     holed = (C.c_void_p * 40)(*[0 if i == 17 else 0x1000 + 64 * i for i in range(40)])
     assert lib.aon_art_pack_step(*swap(1, holed)) == -1 and b"null parameter" in lib.aon_last_error()
     assert lib.aon_art_pack_step(*swap(13, C.c_void_p(0x4004))) == -1 and b"16-byte" in lib.aon_last_error()
+    # aon_vanilla_pack_step likewise
+    t24 = (C.c_void_p * 24)(*[0x1000 + 64 * i for i in range(24)])
+    okv = (t24, t24, 0, 10, 4, a, a, a, a, None)
+    swv = lambda i, v: okv[:i] + (v,) + okv[i + 1:]     # noqa: E731
+    assert lib.aon_vanilla_pack_step(*swv(3, 11)) == -1 and b"frequency levels" in lib.aon_last_error()
+    assert lib.aon_vanilla_pack_step(*swv(1, None)) == -1 and b"null" in lib.aon_last_error()
+    assert lib.aon_vanilla_pack_step(*swv(7, None)) == -1 and b"null" in lib.aon_last_error()      # the fine forward stream is not optional
+    assert lib.aon_vanilla_pack_step(*swv(0, (C.c_void_p * 24)(*[0 if i == 5 else 0x1000 for i in range(24)]))) == -1 and b"null parameter" in lib.aon_last_error()
+    assert lib.aon_vanilla_pack_step(*swv(6, C.c_void_p(0x4008))) == -1 and b"16-byte" in lib.aon_last_error()
 
 
 def test_param_arena_mechanics_on_cpu():

@@ -297,3 +297,37 @@ def test_one_call_pack_of_a_training_step_writes_the_same_bytes(ops, dev, folded
             ops.art_pack_step(P[0], P[1], lat, degrees=degrees, out=crooked)
     finally:
         ops.set_bottleneck_fold(True)
+
+
+@pytest.mark.parametrize("degrees", [(0, 10, 4), (1, 8, 3)])
+@pytest.mark.parametrize("folded", [True, False])
+def test_one_call_pack_of_a_vanilla_training_step_writes_the_same_bytes(ops, dev, folded, degrees):
+    """aon_vanilla_pack_step (round 6: both networks' forward and transposed streams in one C call, the eight fp64 fold products as ONE launch
+    in front) against the four separate calls on zeroed buffers: every byte equal, in both forms, at the default and at other encoding
+    degrees; NULL transposed streams are skipped; a misaligned buffer is refused."""
+    import aon_amd.synthetic as syn
+    from aon_amd import _lib
+
+    sizes = [ops.packed_bytes(), int(_lib.lib.aon_bwd_packed_bytes())]
+    zeros = lambda: [tuple(torch.zeros(n, dtype=torch.uint8, device=dev) for n in sizes) for _ in range(2)]   # noqa: E731
+    sd = syn.make_nerf_state_dict(seed=29, density_scale=2.0, pos_size=3 + 6 * (degrees[1] - degrees[0]), view_pos_size=3 + 6 * degrees[2])
+    P = [{k[len(pre):]: v.to(dev) for k, v in sd.items() if k.startswith(pre)} for pre in ("coarse_mlp.", "fine_mlp.")]
+    ops.set_bottleneck_fold(folded)
+    try:
+        sep = zeros()
+        for (pk, bw), prm in zip(sep, P):
+            ops.pack_vanilla_mlp(prm, out=pk, degrees=degrees)
+            ops.pack_vanilla_mlp_bwd(prm, out=bw, degrees=degrees)
+        one = ops.vanilla_pack_step(P[0], P[1], degrees=degrees, out=zeros())
+        for a, b in zip(sep, one):
+            for x, y in zip(a, b):
+                assert torch.equal(x, y)
+                assert x._aon_form == y._aon_form == int(_lib.lib.aon_stream_form(y.data_ptr())) == (1 if folded else 0)
+        got = ops.vanilla_pack_step(P[0], P[1], degrees=degrees, out=[(pk, None) for pk, _ in zeros()])
+        assert all(g[1] is None and torch.equal(g[0], s[0]) for g, s in zip(got, sep))
+        crooked = zeros()
+        crooked[1] = (torch.zeros(sizes[0] + 8, dtype=torch.uint8, device=dev)[8:], crooked[1][1])
+        with pytest.raises(_lib.AonError, match="16-byte"):
+            ops.vanilla_pack_step(P[0], P[1], degrees=degrees, out=crooked)
+    finally:
+        ops.set_bottleneck_fold(True)
