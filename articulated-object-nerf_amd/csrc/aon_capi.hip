@@ -24,8 +24,8 @@ hipError_t launch_mlp_fwd_enc(const char* packed, const float* samples_enc, cons
 hipError_t launch_pack_art(const float* const* params, float* packed, hipStream_t stream, int pos_levels = 10, int view_levels = 4, bool fold_done = false);
 FoldGemm art_fold_job_fwd(const float* const* params, float* packed, int view_levels);
 hipError_t launch_pack_prepare_art2(const float* const* const params[2], const float* shape, const float* app, const float* art, float* const packed[2],
-                                    float* const small[2], hipStream_t stream, int min_deg, int pos_levels, int view_levels);
-hipError_t launch_pack_art_bwd2(const float* const* const params[2], float* const packed[2], hipStream_t stream, int pos_levels, int view_levels);
+                                    float* const small[2], hipStream_t stream, int min_deg, int pos_levels, int view_levels, int form);
+hipError_t launch_pack_art_bwd2(const float* const* const params[2], float* const packed[2], hipStream_t stream, int pos_levels, int view_levels, int form);
 FoldGemm art_fold_job_bwd(const float* const* params, float* packed, int view_levels);
 hipError_t launch_prepare_art(const float* const* params, const float* shape, const float* app, const float* art,
                               float* small, hipStream_t stream, int min_deg = 0, int pos_levels = 10, int view_levels = 4);
@@ -1746,7 +1746,8 @@ int aon_art_pack_step(const float* const* params_coarse_host, const float* const
   float* fwd[2] = {static_cast<float*>(packed_coarse), static_cast<float*>(packed_fine)};
   float* sm[2] = {static_cast<float*>(small_coarse), static_cast<float*>(small_fine)};
   float* bwd[2] = {static_cast<float*>(packed_bwd_coarse), static_cast<float*>(packed_bwd_fine)};
-  const bool folded = aon::fold_default() == aon::kFormFolded;
+  const int form = aon::fold_default();   // read ONCE: the merged launches below are told, the single-buffer ones cope with either answer
+  const bool folded = form == aon::kFormFolded;
   if (folded) {
     aon::FoldGemm jobs[4];
     int n = 0;
@@ -1758,8 +1759,8 @@ int aon_art_pack_step(const float* const* params_coarse_host, const float* const
   // (AON_PACK_MERGE=0 in the environment: one launch per network and buffer as before, for A/B)
   static const bool merge = [] { const char* e = std::getenv("AON_PACK_MERGE"); return !(e && e[0] == '0'); }();
   if (merge) {
-    if (int rc = check(aon::launch_pack_prepare_art2(P, shape, appearance, articulation, fwd, sm, stream, min_deg_point, Lp, Lv), "aon_art_pack_step")) return rc;
-    if (bwd[0] && bwd[1]) return check(aon::launch_pack_art_bwd2(P, bwd, stream, Lp, Lv), "aon_art_pack_step");
+    if (int rc = check(aon::launch_pack_prepare_art2(P, shape, appearance, articulation, fwd, sm, stream, min_deg_point, Lp, Lv, form), "aon_art_pack_step")) return rc;
+    if (bwd[0] && bwd[1]) return check(aon::launch_pack_art_bwd2(P, bwd, stream, Lp, Lv, form), "aon_art_pack_step");
   } else {
     for (int l = 0; l < 2; ++l) {
       if (int rc = check(aon::launch_prepare_art(P[l], shape, appearance, articulation, sm[l], stream, min_deg_point, Lp, Lv), "aon_art_pack_step")) return rc;

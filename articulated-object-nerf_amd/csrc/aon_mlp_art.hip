@@ -484,9 +484,8 @@ hipError_t launch_prepare_art(const float* const* params, const float* shape, co
 
 // both networks of a two-level model: per-call blocks + forward streams, one launch (the folded form's W' must be in place: fold_done)
 hipError_t launch_pack_prepare_art2(const float* const* const params[2], const float* shape, const float* app, const float* art, float* const packed[2],
-                                    float* const small[2], hipStream_t stream, int min_deg, int pos_levels, int view_levels) {
-  ArtPackPrep2Args a;
-  const int form = fold_default();
+                                    float* const small[2], hipStream_t stream, int min_deg, int pos_levels, int view_levels, int form) {
+  ArtPackPrep2Args a;   // (form: decided ONCE by the caller -- it has, or has not, run the fold products for it)
   for (int l = 0; l < 2; ++l) {
     for (int i = 0; i < kNumArtParams; ++i) a.net[l].p[i] = params[l][i];
     a.net[l].shape = shape; a.net[l].app = app; a.net[l].art = art;

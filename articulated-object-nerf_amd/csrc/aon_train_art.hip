@@ -497,9 +497,8 @@ FoldGemm art_fold_job_bwd(const float* const* params, float* packed, int view_le
 }
 
 // both networks of a two-level model, one launch (the folded form's W' must be in place: aon_art_pack_step)
-hipError_t launch_pack_art_bwd2(const float* const* const params[2], float* const packed[2], hipStream_t stream, int pos_levels, int view_levels) {
-  ArtParams2 a;
-  const int form = fold_default();
+hipError_t launch_pack_art_bwd2(const float* const* const params[2], float* const packed[2], hipStream_t stream, int pos_levels, int view_levels, int form) {
+  ArtParams2 a;   // (form: decided ONCE by the caller)
   for (int l = 0; l < 2; ++l) {
     for (int i = 0; i < kNumArtParams; ++i) a.net[l].p[i] = params[l][i];
     a.packed[l] = packed[l];
