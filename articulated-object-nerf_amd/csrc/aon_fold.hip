@@ -48,10 +48,18 @@ struct FoldArgs {
   int njobs;
 };
 
-// 16 x 16 outputs per block, K in tiles of 16 through LDS (as doubles: the conversion is paid once per element, not once per use).
-// Tile loads pick the thread order that makes the faster-varying thread index walk the operand's unit stride.
+// 16 x 16 outputs per block, K in tiles of 64 through LDS (as doubles: the conversion is paid once per element, not once per use).
+// Tile loads pick the thread order that makes the faster-varying thread index walk the operand's unit stride.  The kernel is pure load
+// latency (128 x 256 x 256 multiply-adds on a whole chip), so the loads are what is shaped (round 6): every load is UNCONDITIONAL, from
+// an index clamped into the operand, and the out-of-range ones are replaced by 0 afterwards -- as `in_range ? load : 0` each load sat
+// in a branch of its own with an `s_waitcnt vmcnt(0)` behind it, so the A and B loads of a tile ran one after the other, 2 x 16
+// memory round trips for K = 256 -- and a tile is 64 deep: eight loads in flight per thread, four rounds.  The multiply-adds of an
+// output run in the same order of k with the same values (zeros where they were): same bits.  The four products of a step's prologue:
+// 18 -> 12 us; the six of its un-folding: 20 -> 17 us (tiles of 128: no further change -- what is left is the chain of 256 dependent
+// fp64 multiply-adds fed from LDS and the launch itself).
+constexpr int kFoldKT = 64;
 __global__ void __launch_bounds__(256) fold_gemm_kernel(FoldArgs a) {
-  __shared__ double As[16][17], Bs[16][17];
+  __shared__ double As[16][kFoldKT + 1], Bs[kFoldKT][17];
   int j = 0;
 #pragma unroll 1
   for (int t = 1; t < a.njobs; ++t)
@@ -62,21 +70,29 @@ __global__ void __launch_bounds__(256) fold_gemm_kernel(FoldArgs a) {
   const int m0 = (blk / nbn) * 16, n0 = (blk % nbn) * 16;
   const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
   const bool a_k_fast = G.sak <= G.sam, b_n_fast = G.sbn <= G.sbk;
+  const int amm = a_k_fast ? ty : tx, akk = a_k_fast ? tx : ty;
+  const int bkk = b_n_fast ? ty : tx, bnn = b_n_fast ? tx : ty;
+  const int am = m0 + amm, bn = n0 + bnn;
+  const int am_c = am < G.M ? am : G.M - 1, bn_c = bn < G.N ? bn : G.N - 1;   // (M, N, K >= 1)
   double acc = 0.0;
-  for (int k0 = 0; k0 < G.K; k0 += 16) {
-    {
-      const int mm = a_k_fast ? ty : tx, kk = a_k_fast ? tx : ty;
-      const int m = m0 + mm, k = k0 + kk;
-      As[mm][kk] = (m < G.M && k < G.K) ? (double)G.A[(int64_t)m * G.sam + (int64_t)k * G.sak] : 0.0;
+  for (int k0 = 0; k0 < G.K; k0 += kFoldKT) {
+    float av[kFoldKT / 16], bv[kFoldKT / 16];
+#pragma unroll
+    for (int q = 0; q < kFoldKT / 16; ++q) {
+      const int ka = k0 + 16 * q + akk, kb = k0 + 16 * q + bkk;
+      const int ka_c = ka < G.K ? ka : G.K - 1, kb_c = kb < G.K ? kb : G.K - 1;
+      av[q] = G.A[(int64_t)am_c * G.sam + (int64_t)ka_c * G.sak];
+      bv[q] = G.B[(int64_t)kb_c * G.sbk + (int64_t)bn_c * G.sbn];
     }
-    {
-      const int kk = b_n_fast ? ty : tx, nn = b_n_fast ? tx : ty;
-      const int k = k0 + kk, n = n0 + nn;
-      Bs[kk][nn] = (k < G.K && n < G.N) ? (double)G.B[(int64_t)k * G.sbk + (int64_t)n * G.sbn] : 0.0;
+#pragma unroll
+    for (int q = 0; q < kFoldKT / 16; ++q) {
+      const int ka = k0 + 16 * q + akk, kb = k0 + 16 * q + bkk;
+      As[amm][16 * q + akk] = (am < G.M && ka < G.K) ? (double)av[q] : 0.0;
+      Bs[16 * q + bkk][bnn] = (kb < G.K && bn < G.N) ? (double)bv[q] : 0.0;
     }
     __syncthreads();
 #pragma unroll
-    for (int kk = 0; kk < 16; ++kk) acc = __builtin_fma(As[ty][kk], Bs[kk][tx], acc);
+    for (int kk = 0; kk < kFoldKT; ++kk) acc = __builtin_fma(As[ty][kk], Bs[kk][tx], acc);
     __syncthreads();
   }
   const int m = m0 + ty, n = n0 + tx;
