@@ -64,6 +64,7 @@ hipError_t launch_vanilla_wgrad(const float* planes, const float* dplanes, const
                                 struct VanillaWgDeferred* defer = nullptr);
 constexpr int kVanillaWgDeferredBytes = 4096;   // aon_train.hip (static_assert there)
 hipError_t launch_vanilla_wgrad_post2(const struct VanillaWgDeferred* d0, const struct VanillaWgDeferred* d1, hipStream_t stream);
+int vanilla_wgrad_deferred_bytes();
 hipError_t launch_art_mlp_fwd_train(const char* packed, const float* small, const float* rays_o, const float* rays_d,
                                     const float* viewdirs, const float* t_vals, int64_t n_rays, int S, float* raw, float* planes,
                                     void* masks, hipStream_t stream, int64_t np_total = 0, const float* view_bias = nullptr);
@@ -81,6 +82,7 @@ hipError_t launch_art_wgrad(const float* planes, const float* dplanes, const flo
                             struct ArtWgDeferred* defer = nullptr);
 constexpr int kArtWgDeferredBytes = 4096;   // aon_train_art.hip (static_assert there): a level's second stage handed back instead of launched
 hipError_t launch_art_wgrad_post2(const struct ArtWgDeferred* d0, const struct ArtWgDeferred* d1, hipStream_t stream);
+int art_wgrad_deferred_bytes();
 hipError_t launch_train_loss(bool backward, const float* rgb_c, const float* rgb_f, const float* target, int64_t n, const float* const* lat, const int* lat_len,
                              float reg_scale, float* stats, float* loss, const float* go, float* d_rgb_c, float* d_rgb_f, float* const* d_lat, hipStream_t stream);
 hipError_t launch_adam(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2, double eps, int64_t step, hipStream_t stream);
@@ -1474,7 +1476,7 @@ int aon_render_bwd_ex(const void* packed_bwd_coarse, const void* packed_fwd_coar
   // launch of the six un-folding products; same bits).  Not with other encoding degrees (remap launches between a level's stages).
   // AON_POST_MERGE=0 in the environment: per level as before (A/B).
   static const bool post_merge_env = [] { const char* e = std::getenv("AON_POST_MERGE"); return !(e && e[0] == '0'); }();
-  const bool post_merged = merged && post_merge_env && !g.other_degrees;
+  const bool post_merged = merged && post_merge_env && !g.other_degrees && aon::vanilla_wgrad_deferred_bytes() <= aon::kVanillaWgDeferredBytes;
   alignas(16) unsigned char defer_store[2][aon::kVanillaWgDeferredBytes];
   auto deferred = [&](int l) { return reinterpret_cast<aon::VanillaWgDeferred*>(defer_store[l]); };
   for (int l = 0; l < num_levels; ++l) {
@@ -1615,7 +1617,8 @@ int aon_art_render_bwd_ex(const void* packed_bwd_coarse, const void* small_coars
   // (launch_art_wgrad_post2; every block does what it did: same bits, tools/grad_hash.py).  Default degrees only (other degrees put
   // remap launches between the stages).  AON_POST_MERGE=0 in the environment: per level as before (A/B).
   static const bool post_merge_env = [] { const char* e = std::getenv("AON_POST_MERGE"); return !(e && e[0] == '0'); }();
-  const bool post_merged = merged && post_merge_env && !post_side && g.max_deg - g.min_deg == 10 && g.deg_view == 4;
+  const bool post_merged = merged && post_merge_env && !post_side && g.max_deg - g.min_deg == 10 && g.deg_view == 4 &&
+                           aon::art_wgrad_deferred_bytes() <= aon::kArtWgDeferredBytes;   // (the storage below is sized by a constant repeated here)
   alignas(16) unsigned char defer_store[2][aon::kArtWgDeferredBytes];
   auto deferred = [&](int l) { return reinterpret_cast<aon::ArtWgDeferred*>(defer_store[l]); };
   auto level_wgrad = [&](int l, hipStream_t st, const aon::WgAux* aux, int phase) {

@@ -609,6 +609,7 @@ struct VanillaWgDeferred {
 };
 constexpr int kVanillaWgDeferredBytes = 4096;   // (aon_capi.hip keeps two of these on its stack)
 static_assert(sizeof(VanillaWgDeferred) <= kVanillaWgDeferredBytes && alignof(VanillaWgDeferred) <= 16, "VanillaWgDeferred outgrew its storage in aon_capi.hip");
+int vanilla_wgrad_deferred_bytes() { return (int)sizeof(VanillaWgDeferred); }   // (aon_capi.hip checks its storage against this)
 
 hipError_t launch_vanilla_wgrad(const float* planes, const float* dplanes, const float* d_raw, int64_t Np, float* const* grads,
                                 float* ws, hipStream_t stream, const WgAux* aux, const void* packed_bwd, int phase, const WgPost* post,

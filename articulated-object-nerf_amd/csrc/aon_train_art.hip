@@ -636,6 +636,7 @@ struct ArtWgDeferred {
 };
 constexpr int kArtWgDeferredBytes = 4096;   // (aon_capi.hip keeps two of these on its stack)
 static_assert(sizeof(ArtWgDeferred) <= kArtWgDeferredBytes && alignof(ArtWgDeferred) <= 16, "ArtWgDeferred outgrew its storage in aon_capi.hip");
+int art_wgrad_deferred_bytes() { return (int)sizeof(ArtWgDeferred); }   // (aon_capi.hip checks its storage against this: the constant is repeated there)
 
 hipError_t launch_art_wgrad(const float* planes, const float* dplanes, const float* d_raw, const float* dxp, int64_t Np,
                             const float* const* params, const float* shape, const float* app, const float* art,
